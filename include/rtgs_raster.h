@@ -1,0 +1,125 @@
+/*
+ * rtgs_raster.h - C ABI of the MI355X (gfx950) differentiable Gaussian-splatting rasterizer.
+ *
+ * Drop-in boundary for the native op behind RTG-SLAM's
+ *   diff_gaussian_rasterization_depth.GaussianRasterizer
+ * (reference call site /root/reference/SLAM/render.py:68-128; the CUDA sources it binds are an
+ * un-vendored submodule, /root/reference/.gitmodules:1-4).  The pybind entry points that
+ * submodule exports (`_C.rasterize_gaussians`, `_C.rasterize_gaussians_backward`) map 1:1 onto
+ * rtgs_raster_forward / rtgs_raster_backward below; the three resize-callbacks mirror the
+ * geometry / binning / image scratch buffers the autograd ctx carries from forward to backward.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless its name ends in `_host`; all tensors
+ * are dense row-major float32 / int32; inputs are borrowed and never written; the call is
+ * enqueued on `stream` (a hipStream_t passed as void*).  Return value 0 = success, negative =
+ * error (see RTGS_E_*); nothing throws across the boundary.
+ */
+#ifndef RTGS_RASTER_H
+#define RTGS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTGS_OK 0
+#define RTGS_E_INVALID (-1)   /* bad argument (null pointer, negative size, sh_degree > 3 ...) */
+#define RTGS_E_HIP (-2)       /* a HIP runtime call or kernel launch failed                     */
+#define RTGS_E_ALLOC (-3)     /* a resize callback returned NULL                                */
+
+#define RTGS_TILE 16          /* tile edge in pixels: SLAM/render.py:104-105, mapper.py:488-505  */
+
+/* The 19 fields of GaussianRasterizationSettings, SLAM/render.py:68-88, in that order.
+ * bg / viewmatrix / projmatrix / campos stay device tensors exactly as the reference passes
+ * them (no host read-back of camera state). */
+typedef struct rtgs_raster_settings {
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;
+  float tanfovy;
+  const float* bg;          /* [3]   device                                               */
+  float scale_modifier;
+  const float* viewmatrix;  /* [4,4] device, = W2C transposed (scene/cameras.py:96-98)     */
+  const float* projmatrix;  /* [4,4] device, accepted for API parity, not read             */
+  int32_t sh_degree;        /* active degree 0..3                                          */
+  const float* campos;      /* [3]   device                                               */
+  float opaque_threshold;
+  float depth_threshold;
+  float normal_threshold;   /* cosine                                                      */
+  float color_sigma;
+  int32_t prefiltered;
+  int32_t debug;            /* non-zero: synchronise + check after every kernel            */
+  float cx;                 /* <= 0 -> (W-1)/2                                             */
+  float cy;
+  float T_threshold;
+} rtgs_raster_settings;
+
+/* Resize callback: return a device allocation of at least `bytes` bytes, 256-byte aligned,
+ * that stays alive until the matching backward has run (mirrors the resize-lambdas over
+ * torch::empty byte tensors of the reference binding). */
+typedef void* (*rtgs_resize_fn)(void* user, size_t bytes);
+
+/* Forward: the 9-argument call of SLAM/render.py:110-120 (colors_precomp / cov3D_precomp are
+ * always None in RTG-SLAM and are not part of this ABI).
+ *   P            number of Gaussians (may be 0)
+ *   sh_coeffs    coefficients per channel held in `shs` (16 for max_sh_degree 3)
+ * Outputs (SLAM/render.py:122-128), all fully written:
+ *   out_color[3,H,W] out_depth[1,H,W] out_color_index[1,H,W](i32,-1) out_depth_index[1,H,W](i32,-1)
+ *   out_color_weight[1,H,W] out_depth_weight[1,H,W] out_T[1,H,W] (exactly 1.0f where untouched)
+ *   out_radii[P] (i32, 0 = culled; may be NULL)
+ *   num_rendered_host  number of (Gaussian, tile) instances, written to HOST memory
+ */
+int rtgs_raster_forward(const rtgs_raster_settings* settings, int32_t P, int32_t sh_coeffs,
+                        const float* means3D, const float* opacities, const float* shs,
+                        const float* scales, const float* rotations, const float* normal_w,
+                        const int32_t* tile_mask,
+                        float* out_color, float* out_depth, int32_t* out_color_index,
+                        int32_t* out_depth_index, float* out_color_weight,
+                        float* out_depth_weight, float* out_T, int32_t* out_radii,
+                        rtgs_resize_fn geom_resize, void* geom_user,
+                        rtgs_resize_fn binning_resize, void* binning_user,
+                        rtgs_resize_fn image_resize, void* image_user,
+                        int64_t* num_rendered_host, void* stream);
+
+/* Backward: consumes the three scratch buffers of the matching forward plus the forward's
+ * out_T and out_depth_index.  Writes (never accumulates into) the gradient tensors:
+ *   dL_dmeans3D[P,3] dL_dopacities[P,1] dL_dshs[P,sh_coeffs,3] dL_dscales[P,3]
+ *   dL_drotations[P,4] dL_dnormal_w[P,3]
+ * Rows of Gaussians that touched no rendered pixel are exactly 0 (mapper.py:455 relies on it).
+ * `grad_scratch` must hold rtgs_raster_backward_scratch_bytes(P) bytes. */
+int rtgs_raster_backward(const rtgs_raster_settings* settings, int32_t P, int32_t sh_coeffs,
+                         int64_t num_rendered,
+                         const float* means3D, const float* opacities, const float* shs,
+                         const float* scales, const float* rotations, const float* normal_w,
+                         const void* geom_buffer, const void* binning_buffer,
+                         const void* image_buffer, const float* out_T,
+                         const int32_t* out_depth_index,
+                         const float* dL_dcolor, const float* dL_ddepth,
+                         float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
+                         float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
+                         void* grad_scratch, void* stream);
+
+size_t rtgs_raster_backward_scratch_bytes(int32_t P);
+
+/* Sizes the forward will request through the callbacks (for pre-allocation / accounting). */
+size_t rtgs_raster_geom_bytes(int32_t P);
+size_t rtgs_raster_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
+size_t rtgs_raster_image_bytes(int32_t image_height, int32_t image_width);
+
+/* Per-call statistics of the LAST forward on this thread (host values, for roofline
+ * accounting): [0] num_rendered, [1] sort bits used, [2] tiles, reserved... */
+int rtgs_raster_last_stats(int64_t* stats8_host);
+
+/* Device-side counters of work actually done by blend_fwd (instances consumed before the
+ * per-tile early exit).  `counters` = device int64[2] zeroed by the caller, or NULL to
+ * disable.  Sticky per thread until reset with NULL. */
+void rtgs_raster_set_counters(void* counters);
+
+const char* rtgs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGS_RASTER_H */

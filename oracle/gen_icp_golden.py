@@ -1,0 +1,144 @@
+"""Generates tests/golden/icp_*.npz by running the REFERENCE's own code
+(/root/reference/SLAM/icp.py + SLAM/utils.py) on seeded synthetic inputs, on CPU.
+
+Runs only in the build container (where /root/reference exists); the vectors it writes are
+committed so the GPU box - which has no /root/reference - can check against them.
+
+    python oracle/gen_icp_golden.py
+
+The reference modules import cv2 / open3d / plyfile / pytorch3d / skimage at module scope and
+utils/general_utils.py allocates CUDA tensors at import; none of that is on the ICP path, so
+those modules are stubbed and devF/devI/devB are replaced by CPU identities before import.
+The reference sources are imported from where they lie - nothing is copied.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def import_reference_icp():
+    if not os.path.isdir(REF):
+        raise RuntimeError("reference tree not present (this script only runs in the build container)")
+    for name in ["cv2", "open3d", "plyfile", "pytorch3d", "pytorch3d.loss", "pytorch3d.ops", "skimage",
+                 "skimage.color", "skimage.filters"]:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["cv2"].COLORMAP_JET = 2
+    sys.modules["plyfile"].PlyData = object
+    sys.modules["plyfile"].PlyElement = object
+    sys.modules["pytorch3d.loss"].chamfer_distance = None
+    sys.modules["pytorch3d.ops"].knn_points = None
+    sys.modules["skimage"].filters = sys.modules["skimage.filters"]
+    sys.modules["skimage.color"].rgb2gray = None
+    gu = types.ModuleType("utils.general_utils")
+    gu.devF = lambda t: t.float()
+    gu.devI = lambda t: t.int()
+    gu.devB = lambda t: t.bool()
+    gu.quaternion_from_axis_angle = None
+    pkg = types.ModuleType("utils")
+    pkg.__path__ = [os.path.join(REF, "utils")]
+    sys.modules.setdefault("utils", pkg)
+    sys.modules["utils.general_utils"] = gu
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import SLAM.icp as ref_icp          # noqa: E402
+    import SLAM.utils as ref_utils      # noqa: E402
+    return ref_icp, ref_utils
+
+
+def make_case(cam, seed, noise=False):
+    sys.path.insert(0, ROOT)
+    from rtg_slam_amd import synth
+    poses = synth.trajectory(3, seed=seed)
+    c2w0 = synth.look_at_pose(seed=seed + 100, max_angle_deg=5, max_trans=0.3)
+    d0 = synth.box_room_depth(cam, c2w0 @ poses[0])
+    d1 = synth.box_room_depth(cam, c2w0 @ poses[1])
+    if noise:
+        d0 = synth.tum_noise(d0, seed=seed + 1)
+        d1 = synth.tum_noise(d1, seed=seed + 2)
+    K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32)
+    rel = torch.linalg.inv(poses[0]) @ poses[1]            # c2w_0^-1 c2w_1 = pose_t1_t0 ground truth
+    return d0, d1, K, rel
+
+
+def main():
+    ref_icp, ref_utils = import_reference_icp()
+    sys.path.insert(0, ROOT)
+    from rtg_slam_amd import synth
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    torch.set_num_threads(8)
+
+    small = synth.CameraSpec(96, 128, 110.0, 110.0, 63.5, 47.5)
+    cases = {
+        "small_clean": (small, 3, False),
+        "small_noisy": (small, 5, True),
+    }
+    for name, (cam, seed, noise) in cases.items():
+        d0, d1, K, rel = make_case(cam, seed, noise)
+        builder = ref_icp.ImagePyramids([2, 1, 0], "max")
+        vp0 = ref_utils.build_vertex_pyramid(d0, builder, K.clone())
+        np0 = ref_utils.build_normal_pyramid(vp0)
+        vp1 = ref_utils.build_vertex_pyramid(d1, builder, K.clone())
+        np1 = ref_utils.build_normal_pyramid(vp1)
+        save = dict(depth0=d0.numpy(), depth1=d1.numpy(), K=K.numpy(), rel_gt=rel.numpy(),
+                    cam=np.array([cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy], dtype=np.float64))
+        for l in range(3):
+            save[f"v0_{l}"] = vp0[l].numpy(); save[f"n0_{l}"] = np0[l].numpy()
+            save[f"v1_{l}"] = vp1[l].numpy(); save[f"n1_{l}"] = np1[l].numpy()
+        # one residual/Jacobian evaluation per level at a non-trivial pose
+        g = torch.Generator().manual_seed(seed)
+        xi = (torch.rand(6, generator=g) - 0.5) * torch.tensor([0.02, 0.02, 0.02, 0.03, 0.03, 0.03])
+        pose_probe = ref_icp.exp_se3(xi)
+        save["pose_probe"] = pose_probe.numpy()
+        cos_thr = float(np.cos(np.deg2rad(20.0)))
+        for l, ds in enumerate([0.25, 0.5, 1.0]):
+            Kl = K * ds
+            Kl[2, 2] = 1.0
+            mask0 = vp1[l][..., -1] > 0
+            res, J, valid = ref_icp.ICP.compute_residuals_jacobian(vp1[l], vp0[l], np1[l], np0[l], mask0, pose_probe,
+                                                                   Kl, 0.1, cos_thr)
+            save[f"JtJ_{l}"] = ref_icp.ICP.compute_jtj(J).numpy()
+            save[f"Jtr_{l}"] = ref_icp.ICP.compute_jtr(J, res).numpy()
+            save[f"nvalid_{l}"] = np.array(int(valid.sum()))
+        # one GN update from the probe equations of the finest level
+        save["gn_pose"] = ref_icp.ICP.GN_solver(torch.from_numpy(save["JtJ_2"]), torch.from_numpy(save["Jtr_2"]),
+                                                pose_probe, damping=1e-4).numpy()
+        # full level loop (the CPU-runnable part of predict_pose, icp.py:428-447)
+        pose = torch.eye(4)
+        ratio = None
+        for l, ds in enumerate([0.25, 0.5, 1.0]):
+            Kl = K * ds
+            Kl[2, 2] = 1.0
+            tracker = ref_icp.ICP(5, damping=1e-4, distance_threshold=0.1, normal_threshold=20)
+            pose, ratio = tracker.icp(pose, vp1[l], vp0[l], np1[l], np0[l], Kl)
+        save["pose_final"] = pose.numpy()
+        save["valid_ratio"] = np.array(float(ratio))
+        save["p2p_loss"] = np.array(float(ref_icp.point2plane_loss(vp0[-1], vp1[-1] @ pose[:3, :3].T + pose[:3, 3], np0[-1])))
+        # hole filling (update_last_status, icp.py:397-415) on the full-resolution maps
+        rd = (d0 * (1 + 0.004 * torch.sin(torch.arange(d0.numel()).reshape(d0.shape) * 0.37))).clone()
+        rd[::7, ::5] = 0
+        rn = np0[-1].clone()
+        rn[::11] = 0
+        tr = types.SimpleNamespace(icp_sample_normal_threshold=0.01, icp_sample_distance_threshold=0.01)
+        frame = types.SimpleNamespace(get_intrinsic=K)
+        save["fill_in"] = rd.numpy().copy()
+        save["fill_rn"] = rn.numpy()
+        ref_icp.IcpTracker.update_last_status(tr, frame, rd, d1, rn, np1[-1])
+        save["fill_out"] = rd.numpy()
+        path = os.path.join(out_dir, f"icp_{name}.npz")
+        np.savez_compressed(path, **save)
+        print(name, "pose err vs gt", float((pose - rel.float()).abs().max()), "valid", float(ratio),
+              "loss", float(save["p2p_loss"]), os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""ctypes binding of the C-ABI library (include/rtgs_raster.h, include/rtgs_icp.h).
+
+The library is the product: there is NO fallback.  If `librtgs_hip.so` is missing or fails to
+load, importing any op raises (build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C rtg_slam_amd/csrc`)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtgs_hip.so")
+
+RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class RasterSettingsC(C.Structure):
+    """Mirror of `rtgs_raster_settings` (include/rtgs_raster.h), i.e. SLAM/render.py:68-88."""
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+        ("bg", C.c_void_p), ("scale_modifier", C.c_float),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+        ("sh_degree", C.c_int32), ("campos", C.c_void_p),
+        ("opaque_threshold", C.c_float), ("depth_threshold", C.c_float),
+        ("normal_threshold", C.c_float), ("color_sigma", C.c_float),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("cx", C.c_float), ("cy", C.c_float), ("T_threshold", C.c_float),
+    ]
+
+
+class IcpLevelC(C.Structure):
+    """Mirror of `rtgs_icp_level` (include/rtgs_icp.h)."""
+    _fields_ = [
+        ("H", C.c_int32), ("W", C.c_int32), ("downscale", C.c_float), ("iters", C.c_int32),
+        ("vertex_src", C.c_void_p), ("normal_src", C.c_void_p),
+        ("vertex_tgt", C.c_void_p), ("normal_tgt", C.c_void_p),
+    ]
+
+
+_lock = threading.Lock()
+_lib = None
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "rtgs_version": (C.c_char_p, []),
+    "rtgs_raster_forward": (C.c_int, [C.POINTER(RasterSettingsC), C.c_int32, C.c_int32] + [_P] * 6 + [_P]
+                            + [_P] * 8 + [RESIZE_FN, _P, RESIZE_FN, _P, RESIZE_FN, _P,
+                                          C.POINTER(C.c_int64), _P]),
+    "rtgs_raster_backward": (C.c_int, [C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6
+                             + [_P] * 3 + [_P, _P] + [_P, _P] + [_P] * 6 + [_P, _P]),
+    "rtgs_raster_backward_scratch_bytes": (C.c_size_t, [C.c_int32]),
+    "rtgs_raster_geom_bytes": (C.c_size_t, [C.c_int32]),
+    "rtgs_raster_binning_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "rtgs_raster_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "rtgs_raster_last_stats": (C.c_int, [C.POINTER(C.c_int64)]),
+    "rtgs_raster_set_counters": (None, [_P]),
+    "rtgs_icp_build_pyramids": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P), _P, _P]),
+    "rtgs_icp_step": (C.c_int, [_P] * 4 + [C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
+    "rtgs_icp_track": (C.c_int, [C.POINTER(IcpLevelC), C.c_int32, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P]),
+    "rtgs_icp_fill_model_depth": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, _P]),
+    "rtgs_icp_scratch_bytes": (C.c_size_t, []),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises RuntimeError when the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"rtg_slam_amd: native library not found at {LIB_PATH}. There is no CPU fallback; build it "
+                "with `make -C rtg_slam_amd/csrc` (hipcc --offload-arch=gfx950).")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise RuntimeError(f"rtg_slam_amd: failed to load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = {-1: "invalid argument", -2: "HIP runtime / kernel launch failure", -3: "scratch allocation failed"}.get(rc, "unknown")
+        raise RuntimeError(f"{what} failed: {msg} (code {rc})")

@@ -1,0 +1,437 @@
+// gfx950 kernels + C ABI of the projective point-to-plane ICP tracker (include/rtgs_icp.h).
+// Restates /root/reference/SLAM/icp.py and the helpers it takes from SLAM/utils.py:65-122,
+// 511-527, fused: one kernel per pyramid stage, one residual/Jacobian/6x6-reduction kernel and
+// one single-workgroup solve+update kernel per Gauss-Newton iteration, pose resident on the
+// device.  Compiled with -ffp-contract=off so the float32 op sequence of the gating
+// arithmetic (projection, nearest-neighbour association, thresholds) follows the reference's.
+#include "../../include/rtgs_icp.h"
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace rtgs_icp {
+
+constexpr int MAX_BLOCKS = 1024;
+constexpr int NACC = 28;            // 21 upper-triangular JtJ + 6 Jtr + 1 valid count
+constexpr int PSTRIDE = 32;         // floats per block partial
+
+struct Scratch {
+  uint32_t minmax[2 * RTGS_ICP_MAX_LEVELS];   // per level: enc(min), ~enc(max)
+  float partials[MAX_BLOCKS * PSTRIDE];
+  float k_level[16];
+};
+
+__device__ __forceinline__ uint32_t enc_f(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f(uint32_t e) {
+  return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
+struct PyrDesc {
+  int levels;
+  int H, W;                                   // full resolution
+  int Hl[RTGS_ICP_MAX_LEVELS], Wl[RTGS_ICP_MAX_LEVELS], shift[RTGS_ICP_MAX_LEVELS];
+  int block_start[RTGS_ICP_MAX_LEVELS + 1];
+  float* vertex[RTGS_ICP_MAX_LEVELS];
+  float* normal[RTGS_ICP_MAX_LEVELS];
+};
+
+// ---- K10: max-pool depth pyramid + back-projection (SLAM/utils.py:511-521, :65-75) ------------
+__global__ void __launch_bounds__(256) icp_vertex_kernel(PyrDesc d, const float* __restrict__ depth,
+                                                         const float* __restrict__ K, Scratch* sc) {
+  int l = 0;
+  while (l + 1 < d.levels && (int)blockIdx.x >= d.block_start[l + 1]) ++l;
+  const int Hl = d.Hl[l], Wl = d.Wl[l], sh = d.shift[l];
+  const int idx = ((int)blockIdx.x - d.block_start[l]) * 256 + (int)threadIdx.x;
+  float dmax = 0.f;
+  const bool live = idx < Hl * Wl;
+  if (live) {
+    const int y = idx / Wl, x = idx % Wl;
+    const int f = 1 << sh;
+    dmax = -INFINITY;
+    for (int a = 0; a < f; ++a)
+      for (int b = 0; b < f; ++b) dmax = fmaxf(dmax, depth[(size_t)(y * f + a) * d.W + (x * f + b)]);
+    const float ds = 1.f / (float)f;                       // K * downscale, K[2][2] = 1
+    const float fx = K[0] * ds, fy = K[4] * ds, cx = K[2] * ds, cy = K[5] * ds;
+    float* v = d.vertex[l] + (size_t)idx * 3;
+    v[0] = (((float)x - cx) / fx) * dmax;
+    v[1] = (((float)y - cy) / fy) * dmax;
+    v[2] = dmax;                                           // 1 * depth
+  }
+  // min / max of the level's depth for the invalid mask of compute_normal_map
+  __shared__ uint32_t s_min, s_maxinv;
+  if (threadIdx.x == 0) { s_min = 0xffffffffu; s_maxinv = 0xffffffffu; }
+  __syncthreads();
+  if (live) {
+    const uint32_t e = enc_f(dmax);
+    atomicMin(&s_min, e);
+    atomicMin(&s_maxinv, ~e);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMin(&sc->minmax[2 * l], s_min);
+    atomicMin(&sc->minmax[2 * l + 1], s_maxinv);
+  }
+}
+
+// ---- K11: Sobel normals (SLAM/utils.py:77-122): replicate pad, cross(dy, dx), / (|n| + 1e-8),
+//      zero where depth <= min or depth >= max --------------------------------------------------
+__global__ void __launch_bounds__(256) icp_normal_kernel(PyrDesc d, const Scratch* sc) {
+  int l = 0;
+  while (l + 1 < d.levels && (int)blockIdx.x >= d.block_start[l + 1]) ++l;
+  const int Hl = d.Hl[l], Wl = d.Wl[l];
+  const int idx = ((int)blockIdx.x - d.block_start[l]) * 256 + (int)threadIdx.x;
+  if (idx >= Hl * Wl) return;
+  const int y = idx / Wl, x = idx % Wl;
+  const float* V = d.vertex[l];
+  const int ym = max(y - 1, 0), yp = min(y + 1, Hl - 1), xm = max(x - 1, 0), xp = min(x + 1, Wl - 1);
+  float gx[3], gy[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a00 = V[((size_t)ym * Wl + xm) * 3 + c], a01 = V[((size_t)ym * Wl + x) * 3 + c], a02 = V[((size_t)ym * Wl + xp) * 3 + c];
+    const float a10 = V[((size_t)y * Wl + xm) * 3 + c], a12 = V[((size_t)y * Wl + xp) * 3 + c];
+    const float a20 = V[((size_t)yp * Wl + xm) * 3 + c], a21 = V[((size_t)yp * Wl + x) * 3 + c], a22 = V[((size_t)yp * Wl + xp) * 3 + c];
+    gx[c] = -a00 + a02 - 2.f * a10 + 2.f * a12 - a20 + a22;
+    gy[c] = -a00 - 2.f * a01 - a02 + a20 + 2.f * a21 + a22;
+  }
+  // cross(dy, dx)
+  float nx = gy[1] * gx[2] - gy[2] * gx[1];
+  float ny = gy[2] * gx[0] - gy[0] * gx[2];
+  float nz = gy[0] * gx[1] - gy[1] * gx[0];
+  const float mag = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-8f;
+  nx /= mag; ny /= mag; nz /= mag;
+  const float dep = V[(size_t)idx * 3 + 2];
+  const float dmin = dec_f(sc->minmax[2 * l]), dmax = dec_f(~sc->minmax[2 * l + 1]);
+  if (dep <= dmin || dep >= dmax) { nx = 0.f; ny = 0.f; nz = 0.f; }
+  float* N = d.normal[l] + (size_t)idx * 3;
+  N[0] = nx; N[1] = ny; N[2] = nz;
+}
+
+// ---- wave64 sum via DPP, result in lane 63 ---------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum63(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  v = dpp_add<0x140>(v);
+  v = dpp_add<0x142, 0xa>(v);
+  v = dpp_add<0x143, 0xc>(v);
+  return v;
+}
+
+__device__ __forceinline__ void block_write_partials(float (&acc)[NACC], float* __restrict__ partials) {
+  __shared__ float s_part[4 * PSTRIDE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    const float r = wave_sum63(acc[k]);
+    if (lane == 63) s_part[wave * PSTRIDE + k] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    const int k = threadIdx.x;
+    partials[(size_t)blockIdx.x * PSTRIDE + k] =
+        (s_part[k] + s_part[PSTRIDE + k]) + (s_part[2 * PSTRIDE + k] + s_part[3 * PSTRIDE + k]);
+  }
+}
+
+// ---- K12: residual + Jacobian + 6x6 reduction (icp.py:52-119) ---------------------------------
+// K points at the FULL-resolution intrinsics; `ds` is the level's downscale (icp.py:431-433).
+__global__ void __launch_bounds__(256) icp_reduce_kernel(
+    const float* __restrict__ vs, const float* __restrict__ ns, const float* __restrict__ vt,
+    const float* __restrict__ nt, int H, int W, const float* __restrict__ K, float ds,
+    const float* __restrict__ pose, float dist_thr, float cos_thr, float* __restrict__ partials) {
+  const float R00 = pose[0], R01 = pose[1], R02 = pose[2], t0 = pose[3];
+  const float R10 = pose[4], R11 = pose[5], R12 = pose[6], t1 = pose[7];
+  const float R20 = pose[8], R21 = pose[9], R22 = pose[10], t2 = pose[11];
+  const float fx = K[0] * ds, fy = K[4] * ds, cx = K[2] * ds, cy = K[5] * ds;
+  const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1);
+  const float hw = Wm1 / 2.f, hh = Hm1 / 2.f;
+  float acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+
+  const int n = H * W;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+    const float v0 = vs[(size_t)idx * 3], v1 = vs[(size_t)idx * 3 + 1], v2 = vs[(size_t)idx * 3 + 2];
+    const float px = (R00 * v0 + R01 * v1 + R02 * v2) + t0;
+    const float py = (R10 * v0 + R11 * v1 + R12 * v2) + t1;
+    const float pz = (R20 * v0 + R21 * v1 + R22 * v2) + t2;
+    const float u = (px / pz) * fx + cx;
+    const float v = (py / pz) * fy + cy;
+    const bool inview = (u > 0.f) && (u < Wm1) && (v > 0.f) && (v < Hm1);
+    if (!inview || !(v2 > 0.f)) continue;
+    // grid_sample(nearest, border, align_corners=True) of warp_features (icp.py:132-148)
+    const float un = u / hw - 1.f, vn = v / hh - 1.f;
+    float ix = ((un + 1.f) / 2.f) * Wm1, iy = ((vn + 1.f) / 2.f) * Hm1;
+    ix = fminf(Wm1, fmaxf(ix, 0.f));
+    iy = fminf(Hm1, fmaxf(iy, 0.f));
+    const int xi = (int)nearbyintf(ix), yi = (int)nearbyintf(iy);
+    const size_t j = ((size_t)yi * W + xi) * 3;
+    const float q0 = vt[j], q1 = vt[j + 1], q2 = vt[j + 2];
+    if (!(q2 > 0.f)) continue;
+    const float m0 = nt[j], m1 = nt[j + 1], m2 = nt[j + 2];
+    const float n0 = ns[(size_t)idx * 3], n1 = ns[(size_t)idx * 3 + 1], n2 = ns[(size_t)idx * 3 + 2];
+    const float rn0 = R00 * n0 + R01 * n1 + R02 * n2;
+    const float rn1 = R10 * n0 + R11 * n1 + R12 * n2;
+    const float rn2 = R20 * n0 + R21 * n1 + R22 * n2;
+    if (!(rn0 * m0 + rn1 * m1 + rn2 * m2 > cos_thr)) continue;
+    const float d0 = px - q0, d1 = py - q1, d2 = pz - q2;
+    if (sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > dist_thr) continue;
+    const float r = m0 * d0 + m1 * d1 + m2 * d2;
+    float J[6];
+    J[0] = py * m2 - pz * m1;        // -(m^T [p]x) = p x m
+    J[1] = pz * m0 - px * m2;
+    J[2] = px * m1 - py * m0;
+    J[3] = m0; J[4] = m1; J[5] = m2;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+    acc[27] += 1.f;
+  }
+  block_write_partials(acc, partials);
+}
+
+// ---- point2plane_loss (icp.py:7-13) at one level: sum(((R v1 + t - v0) . n0)^2) ---------------
+__global__ void __launch_bounds__(256) icp_p2p_kernel(const float* __restrict__ vs, const float* __restrict__ vt,
+                                                      const float* __restrict__ nt, int n,
+                                                      const float* __restrict__ pose, float* __restrict__ partials) {
+  const float R00 = pose[0], R01 = pose[1], R02 = pose[2], t0 = pose[3];
+  const float R10 = pose[4], R11 = pose[5], R12 = pose[6], t1 = pose[7];
+  const float R20 = pose[8], R21 = pose[9], R22 = pose[10], t2 = pose[11];
+  float acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+    const size_t j = (size_t)idx * 3;
+    const float v0 = vs[j], v1 = vs[j + 1], v2 = vs[j + 2];
+    const float px = (v0 * R00 + v1 * R01 + v2 * R02) + t0;
+    const float py = (v0 * R10 + v1 * R11 + v2 * R12) + t1;
+    const float pz = (v0 * R20 + v1 * R21 + v2 * R22) + t2;
+    const float l = (px - vt[j]) * nt[j] + (py - vt[j + 1]) * nt[j + 1] + (pz - vt[j + 2]) * nt[j + 2];
+    acc[0] += l * l;
+  }
+  block_write_partials(acc, partials);
+}
+
+// ---- K13: final reduction + damped 6x6 solve + SE(3) exp update, one workgroup ------------------
+enum { MODE_SOLVE = 0, MODE_EQUATIONS = 1, MODE_P2P = 2 };
+
+__global__ void __launch_bounds__(256) icp_final_kernel(const float* __restrict__ partials, int nblocks, int mode,
+                                                        float damping, float inv_pixels, float* __restrict__ pose,
+                                                        float* __restrict__ stats, float* __restrict__ JtJ_out,
+                                                        float* __restrict__ Jtr_out, float* __restrict__ nvalid_out) {
+  __shared__ double s_sum[8 * PSTRIDE];
+  const int grp = threadIdx.x >> 5, k = threadIdx.x & 31;
+  double a = 0.0;
+  if (k < NACC)
+    for (int b = grp; b < nblocks; b += 8) a += (double)partials[(size_t)b * PSTRIDE + k];
+  s_sum[grp * PSTRIDE + k] = a;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double S[NACC];
+  for (int c = 0; c < NACC; ++c) {
+    double t = 0.0;
+    for (int g = 0; g < 8; ++g) t += s_sum[g * PSTRIDE + c];
+    S[c] = t;
+  }
+  if (mode == MODE_P2P) { stats[1] = (float)(S[0] * (double)inv_pixels); return; }
+  double Hm[6][6], bvec[6];
+  int idx = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) { Hm[r][c] = S[idx]; Hm[c][r] = S[idx]; ++idx; }
+  for (int r = 0; r < 6; ++r) bvec[r] = S[21 + r];
+  if (mode == MODE_EQUATIONS) {
+    for (int r = 0; r < 6; ++r) {
+      for (int c = 0; c < 6; ++c) JtJ_out[r * 6 + c] = (float)Hm[r][c];
+      Jtr_out[r] = (float)bvec[r];
+    }
+    nvalid_out[0] = (float)S[27];
+    return;
+  }
+  stats[0] = (float)(S[27] * (double)inv_pixels);            // valid_ratio (icp.py:46-47)
+  // lev_mar_H (icp.py:248-256): H += trace(H) * damping * I
+  double tr = 0.0;
+  for (int r = 0; r < 6; ++r) tr += Hm[r][r];
+  for (int r = 0; r < 6; ++r) Hm[r][r] += tr * (double)damping;
+  // Cholesky H = L L^T
+  double L[6][6];
+  bool spd = true;
+  for (int r = 0; r < 6 && spd; ++r)
+    for (int c = 0; c <= r; ++c) {
+      double s = Hm[r][c];
+      for (int m = 0; m < c; ++m) s -= L[r][m] * L[c][m];
+      if (r == c) {
+        if (!(s > 0.0)) { spd = false; break; }
+        L[r][r] = sqrt(s);
+      } else {
+        L[r][c] = s / L[c][c];
+      }
+    }
+  if (!spd) { stats[2] += 1.f; return; }
+  double yv[6], xi[6];
+  for (int r = 0; r < 6; ++r) {
+    double s = -bvec[r];                                     // xi = -H^-1 Jtr (icp.py:328-334)
+    for (int m = 0; m < r; ++m) s -= L[r][m] * yv[m];
+    yv[r] = s / L[r][r];
+  }
+  for (int r = 5; r >= 0; --r) {
+    double s = yv[r];
+    for (int m = r + 1; m < 6; ++m) s -= L[m][r] * xi[m];
+    xi[r] = s / L[r][r];
+  }
+  // exp_se3 (icp.py:271-310): Rodrigues + left Jacobian, eps 1e-8
+  const double w0 = xi[0], w1 = xi[1], w2 = xi[2];
+  const double Wh[3][3] = {{0.0, -w2, w1}, {w2, 0.0, -w0}, {-w1, w0, 0.0}};
+  double W2[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) W2[r][c] = Wh[r][0] * Wh[0][c] + Wh[r][1] * Wh[1][c] + Wh[r][2] * Wh[2][c];
+  const double th = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+  double E[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  double Jl[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  if (th > 1e-8) {
+    const double th2 = th * th, th3 = th2 * th, sn = sin(th), cs = cos(th);
+    const double ka = sn / th, kb = (1.0 - cs) / th2, kc = (th - sn) / th3;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        E[r][c] += ka * Wh[r][c] + kb * W2[r][c];
+        Jl[r][c] += kb * Wh[r][c] + kc * W2[r][c];
+      }
+  }
+  for (int r = 0; r < 3; ++r) E[r][3] = Jl[r][0] * xi[3] + Jl[r][1] * xi[4] + Jl[r][2] * xi[5];
+  double Pm[4][4], Out[4][4];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) Pm[r][c] = (double)pose[r * 4 + c];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) Out[r][c] = E[r][0] * Pm[0][c] + E[r][1] * Pm[1][c] + E[r][2] * Pm[2][c] + E[r][3] * Pm[3][c];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) pose[r * 4 + c] = (float)Out[r][c];
+}
+
+// ---- model-depth hole filling (icp.py:397-415) ------------------------------------------------
+__global__ void __launch_bounds__(256) icp_fill_kernel(float* __restrict__ rd, const float* __restrict__ fd,
+                                                       const float* __restrict__ rn, const float* __restrict__ fn,
+                                                       int n, float dist_thr, float normal_thr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float r = rd[i], f = fd[i];
+  const float a0 = rn[3 * i], a1 = rn[3 * i + 1], a2 = rn[3 * i + 2];
+  const float b0 = fn[3 * i], b1 = fn[3 * i + 1], b2 = fn[3 * i + 2];
+  // F.cosine_similarity(dim=-1, eps=1e-8): (a / max(|a|, eps)) . (b / max(|b|, eps))
+  const float na = fmaxf(sqrtf(a0 * a0 + a1 * a1 + a2 * a2), 1e-8f);
+  const float nb = fmaxf(sqrtf(b0 * b0 + b1 * b1 + b2 * b2), 1e-8f);
+  const float cs = (a0 / na) * (b0 / nb) + (a1 / na) * (b1 / nb) + (a2 / na) * (b2 / nb);
+  const bool fill = ((fabsf(r - f) > dist_thr) || (r == 0.f) || ((1.f - cs) > normal_thr)) && (f > 0.f);
+  if (fill) rd[i] = f;
+}
+
+static int grid_for(int n) {
+  int g = (n + 255) / 256;
+  return g > MAX_BLOCKS ? MAX_BLOCKS : (g < 1 ? 1 : g);
+}
+
+}  // namespace rtgs_icp
+
+using namespace rtgs_icp;
+
+#define ICP_TRY(expr)                \
+  do {                               \
+    if ((expr) != hipSuccess) return -2; \
+  } while (0)
+
+extern "C" {
+
+size_t rtgs_icp_scratch_bytes(void) { return sizeof(Scratch); }
+
+int rtgs_icp_build_pyramids(const float* depth, int32_t H, int32_t W, const float* K, int32_t levels,
+                            float* const* vertex_out, float* const* normal_out, void* scratch, void* stream) {
+  if (!depth || !K || !vertex_out || !normal_out || !scratch || H <= 0 || W <= 0 || levels < 1 ||
+      levels > RTGS_ICP_MAX_LEVELS)
+    return -1;
+  hipStream_t st = (hipStream_t)stream;
+  Scratch* sc = (Scratch*)scratch;
+  PyrDesc d{};
+  d.levels = levels; d.H = H; d.W = W;
+  int blocks = 0;
+  for (int l = 0; l < levels; ++l) {
+    const int sh = levels - 1 - l;
+    d.shift[l] = sh; d.Hl[l] = H >> sh; d.Wl[l] = W >> sh;     // MaxPool2d(2^sh, 2^sh), floor mode
+    if (d.Hl[l] < 1 || d.Wl[l] < 1 || !vertex_out[l] || !normal_out[l]) return -1;
+    d.vertex[l] = vertex_out[l]; d.normal[l] = normal_out[l];
+    d.block_start[l] = blocks;
+    blocks += (d.Hl[l] * d.Wl[l] + 255) / 256;
+  }
+  d.block_start[levels] = blocks;
+  ICP_TRY(hipMemsetAsync(sc->minmax, 0xff, sizeof(sc->minmax), st));
+  hipLaunchKernelGGL(icp_vertex_kernel, dim3(blocks), dim3(256), 0, st, d, depth, K, sc);
+  hipLaunchKernelGGL(icp_normal_kernel, dim3(blocks), dim3(256), 0, st, d, (const Scratch*)sc);
+  ICP_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_icp_step(const float* vs, const float* ns, const float* vt, const float* nt, int32_t H, int32_t W,
+                  const float* K, const float* pose, float dist_thr, float cos_thr, float* JtJ_out, float* Jtr_out,
+                  float* nvalid_out, void* scratch, void* stream) {
+  if (!vs || !ns || !vt || !nt || !K || !pose || !JtJ_out || !Jtr_out || !nvalid_out || !scratch || H <= 0 || W <= 0)
+    return -1;
+  hipStream_t st = (hipStream_t)stream;
+  Scratch* sc = (Scratch*)scratch;
+  const int g = grid_for(H * W);
+  hipLaunchKernelGGL(icp_reduce_kernel, dim3(g), dim3(256), 0, st, vs, ns, vt, nt, H, W, K, 1.0f, pose, dist_thr,
+                     cos_thr, sc->partials);
+  hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(256), 0, st, (const float*)sc->partials, g, (int)MODE_EQUATIONS,
+                     0.f, 0.f, (float*)nullptr, (float*)nullptr, JtJ_out, Jtr_out, nvalid_out);
+  ICP_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, float dist_thr, float cos_thr,
+                   float damping, float* pose, float* stats, void* scratch, void* stream) {
+  if (!lv || n_levels < 1 || n_levels > RTGS_ICP_MAX_LEVELS || !K || !pose || !stats || !scratch) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  Scratch* sc = (Scratch*)scratch;
+  ICP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
+  for (int l = 0; l < n_levels; ++l) {
+    const rtgs_icp_level& L = lv[l];
+    if (!L.vertex_src || !L.normal_src || !L.vertex_tgt || !L.normal_tgt || L.H <= 0 || L.W <= 0 || L.iters < 0)
+      return -1;
+    const int g = grid_for(L.H * L.W);
+    const float inv = 1.f / ((float)L.H * (float)L.W);
+    for (int it = 0; it < L.iters; ++it) {
+      hipLaunchKernelGGL(icp_reduce_kernel, dim3(g), dim3(256), 0, st, L.vertex_src, L.normal_src, L.vertex_tgt,
+                         L.normal_tgt, L.H, L.W, K, L.downscale, (const float*)pose, dist_thr, cos_thr, sc->partials);
+      hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(256), 0, st, (const float*)sc->partials, g, (int)MODE_SOLVE,
+                         damping, inv, pose, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    }
+  }
+  const rtgs_icp_level& F = lv[n_levels - 1];
+  const int n = F.H * F.W;
+  const int g = grid_for(n);
+  hipLaunchKernelGGL(icp_p2p_kernel, dim3(g), dim3(256), 0, st, F.vertex_src, F.vertex_tgt, F.normal_tgt, n,
+                     (const float*)pose, sc->partials);
+  hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(256), 0, st, (const float*)sc->partials, g, (int)MODE_P2P, 0.f,
+                     1.f / (float)n, pose, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  ICP_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_icp_fill_model_depth(float* rd, const float* fd, const float* rn, const float* fn, int32_t H, int32_t W,
+                              float dist_thr, float normal_thr, void* stream) {
+  if (!rd || !fd || !rn || !fn || H <= 0 || W <= 0) return -1;
+  const int n = H * W;
+  hipLaunchKernelGGL(icp_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rd, fd, rn, fn, n,
+                     dist_thr, normal_thr);
+  ICP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+// C-ABI entry points of the rasterizer (include/rtgs_raster.h): argument checks, scratch-buffer
+// carving, the rocPRIM scan / radix sort between the hand-written kernels, and launch order.
+#include "../../include/rtgs_raster.h"
+#include "raster_common.h"
+
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+#include <string.h>
+
+namespace rtgs {
+void launch_mask_sat(const int32_t*, int, int, int32_t*, hipStream_t);
+void launch_preprocess_fwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
+                           const float*, const int32_t*, Splat*, uint32_t*, int32_t*, uint8_t*, int32_t*, hipStream_t);
+void launch_emit_keys(const RasterParams&, const Splat*, const int32_t*, const uint32_t*, const int32_t*, uint64_t*,
+                      uint32_t*, hipStream_t);
+void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
+void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
+                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, hipStream_t);
+void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const uint32_t*,
+                      const int32_t*, const float*, const float*, SplatGrad*, hipStream_t);
+void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
+                           const float*, const int32_t*, const uint8_t*, const SplatGrad*, float*, float*, float*,
+                           float*, float*, float*, hipStream_t);
+
+static thread_local int64_t g_stats[8] = {0};
+static thread_local unsigned long long* g_counters = nullptr;
+
+static int bits_for(uint32_t n) {   // bits needed to represent values in [0, n)
+  int b = 0;
+  while ((1ull << b) < (unsigned long long)n) ++b;
+  return b < 1 ? 1 : b;
+}
+
+static GeomLayout geom_layout(int32_t P, int gx, int gy) {
+  GeomLayout L{};
+  size_t off = 0;
+  const size_t Pn = (size_t)(P > 0 ? P : 1);
+  L.splats = off; off = align_up(off + Pn * sizeof(Splat));
+  L.tiles_touched = off; off = align_up(off + Pn * sizeof(uint32_t));
+  L.offsets = off; off = align_up(off + Pn * sizeof(uint32_t));
+  L.radii = off; off = align_up(off + Pn * sizeof(int32_t));
+  L.clamped = off; off = align_up(off + Pn);
+  L.sat = off; off = align_up(off + (size_t)(gx + 1) * (gy + 1) * sizeof(int32_t));
+  size_t tb = 0;
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)Pn);
+  L.scan_temp_bytes = tb;
+  L.scan_temp = off; off = align_up(off + tb);
+  L.total = off;
+  return L;
+}
+
+static BinLayout bin_layout(int64_t R, int ntiles) {
+  BinLayout L{};
+  size_t off = 0;
+  const size_t Rn = (size_t)(R > 0 ? R : 1);
+  L.keys_a = off; off = align_up(off + Rn * sizeof(uint64_t));
+  L.keys_b = off; off = align_up(off + Rn * sizeof(uint64_t));
+  L.vals_a = off; off = align_up(off + Rn * sizeof(uint32_t));
+  L.vals_b = off; off = align_up(off + Rn * sizeof(uint32_t));
+  size_t tb = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                     (uint32_t*)nullptr, (int)Rn, 0, 32 + bits_for((uint32_t)ntiles));
+  L.sort_temp_bytes = tb;
+  L.sort_temp = off; off = align_up(off + tb);
+  L.total = off;
+  return L;
+}
+
+static ImgLayout img_layout(int H, int W, int ntiles) {
+  ImgLayout L{};
+  size_t off = 0;
+  L.ranges = off; off = align_up(off + (size_t)ntiles * sizeof(uint2));
+  L.n_contrib = off; off = align_up(off + (size_t)H * W * sizeof(uint32_t));
+  L.total = off;
+  return L;
+}
+
+static int make_params(const rtgs_raster_settings* s, int32_t P, int32_t M, RasterParams& p) {
+  if (!s || P < 0 || M < 1 || M > 16) return RTGS_E_INVALID;
+  if (s->image_height <= 0 || s->image_width <= 0) return RTGS_E_INVALID;
+  if (s->sh_degree < 0 || s->sh_degree > 3 || (s->sh_degree + 1) * (s->sh_degree + 1) > M) return RTGS_E_INVALID;
+  if (!s->bg || !s->viewmatrix || !s->campos) return RTGS_E_INVALID;
+  p.H = s->image_height; p.W = s->image_width;
+  p.gx = (p.W + TILE - 1) / TILE; p.gy = (p.H + TILE - 1) / TILE;
+  p.P = P; p.M = M; p.deg = s->sh_degree;
+  p.tanfovx = s->tanfovx; p.tanfovy = s->tanfovy;
+  p.fx = (float)(p.W / (2.0 * (double)s->tanfovx));      // utils/graphics_utils.py:89-90
+  p.fy = (float)(p.H / (2.0 * (double)s->tanfovy));
+  p.cx = s->cx > 0.f ? s->cx : 0.5f * (float)(p.W - 1);
+  p.cy = s->cy > 0.f ? s->cy : 0.5f * (float)(p.H - 1);
+  p.scale_modifier = s->scale_modifier;
+  p.opaque_thr = s->opaque_threshold; p.depth_thr = s->depth_threshold; p.normal_thr = s->normal_threshold;
+  p.color_sigma = s->color_sigma; p.T_thr = s->T_threshold;
+  p.view = s->viewmatrix; p.campos = s->campos; p.bg = s->bg;
+  return RTGS_OK;
+}
+
+#define HIP_TRY(expr)                         \
+  do {                                        \
+    hipError_t e_ = (expr);                   \
+    if (e_ != hipSuccess) return RTGS_E_HIP;  \
+  } while (0)
+
+static int dbg_sync(const rtgs_raster_settings* s, hipStream_t st) {
+  if (s->debug) {
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+  }
+  return RTGS_OK;
+}
+#define DBG(s, st)                              \
+  do {                                          \
+    int r_ = dbg_sync(s, st);                   \
+    if (r_ != RTGS_OK) return r_;               \
+  } while (0)
+
+}  // namespace rtgs
+
+using namespace rtgs;
+
+extern "C" {
+
+const char* rtgs_version(void) { return "rtgs-hip 0.1.0 (gfx950)"; }
+
+size_t rtgs_raster_geom_bytes(int32_t P) {
+  // the SAT term depends on the image; callers that pre-allocate should add image tiles * 4 B.
+  return geom_layout(P, 512, 512).total;
+}
+size_t rtgs_raster_binning_bytes(int64_t R, int32_t H, int32_t W) {
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  return bin_layout(R, gx * gy).total;
+}
+size_t rtgs_raster_image_bytes(int32_t H, int32_t W) {
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  return img_layout(H, W, gx * gy).total;
+}
+size_t rtgs_raster_backward_scratch_bytes(int32_t P) { return align_up((size_t)(P > 0 ? P : 1) * sizeof(SplatGrad)); }
+
+int rtgs_raster_last_stats(int64_t* out) {
+  if (!out) return RTGS_E_INVALID;
+  memcpy(out, g_stats, sizeof(g_stats));
+  return RTGS_OK;
+}
+void rtgs_raster_set_counters(void* c) { g_counters = (unsigned long long*)c; }
+
+int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, const float* means3D,
+                        const float* opacities, const float* shs, const float* scales, const float* rotations,
+                        const float* normal_w, const int32_t* tile_mask, float* out_color, float* out_depth,
+                        int32_t* out_cidx, int32_t* out_didx, float* out_cw, float* out_dw, float* out_T,
+                        int32_t* out_radii, rtgs_resize_fn geom_resize, void* geom_user,
+                        rtgs_resize_fn binning_resize, void* binning_user, rtgs_resize_fn image_resize,
+                        void* image_user, int64_t* num_rendered_host, void* stream) {
+  RasterParams p;
+  int rc = make_params(s, P, M, p);
+  if (rc != RTGS_OK) return rc;
+  if (P > 0 && (!means3D || !opacities || !shs || !scales || !rotations || !normal_w)) return RTGS_E_INVALID;
+  if (!tile_mask || !out_color || !out_depth || !out_cidx || !out_didx || !out_cw || !out_dw || !out_T)
+    return RTGS_E_INVALID;
+  if (!geom_resize || !binning_resize || !image_resize || !num_rendered_host) return RTGS_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntiles = p.gx * p.gy;
+
+  const GeomLayout G = geom_layout(P, p.gx, p.gy);
+  char* geom = (char*)geom_resize(geom_user, G.total);
+  const ImgLayout I = img_layout(p.H, p.W, ntiles);
+  char* img = (char*)image_resize(image_user, I.total);
+  if (!geom || !img) return RTGS_E_ALLOC;
+  Splat* splats = (Splat*)(geom + G.splats);
+  uint32_t* tiles_touched = (uint32_t*)(geom + G.tiles_touched);
+  uint32_t* offsets = (uint32_t*)(geom + G.offsets);
+  int32_t* radii = (int32_t*)(geom + G.radii);
+  uint8_t* clamped = (uint8_t*)(geom + G.clamped);
+  int32_t* sat = (int32_t*)(geom + G.sat);
+  uint2* ranges = (uint2*)(img + I.ranges);
+  uint32_t* n_contrib = (uint32_t*)(img + I.n_contrib);
+
+  int64_t R = 0;
+  if (P > 0) {
+    launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
+    DBG(s, st);
+    launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sat, splats, tiles_touched, radii,
+                          clamped, out_radii, st);
+    DBG(s, st);
+    size_t tb = G.scan_temp_bytes;
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(geom + G.scan_temp, tb, tiles_touched, offsets, P, st));
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));   // the one host sync of the forward: sizes the instance arrays
+    R = (int64_t)total;
+  }
+  *num_rendered_host = R;
+
+  const BinLayout B = bin_layout(R, ntiles);
+  char* bin = (char*)binning_resize(binning_user, B.total);
+  if (!bin) return RTGS_E_ALLOC;
+  uint64_t* keys_a = (uint64_t*)(bin + B.keys_a);
+  uint64_t* keys_b = (uint64_t*)(bin + B.keys_b);
+  uint32_t* vals_a = (uint32_t*)(bin + B.vals_a);
+  uint32_t* vals_b = (uint32_t*)(bin + B.vals_b);
+
+  HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), st));
+  const int sort_bits = 32 + bits_for((uint32_t)ntiles);
+  if (R > 0) {
+    launch_emit_keys(p, splats, radii, offsets, tile_mask, keys_a, vals_a, st);
+    DBG(s, st);
+    size_t tb = B.sort_temp_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin + B.sort_temp, tb, keys_a, keys_b, vals_a, vals_b, (int)R, 0,
+                                               sort_bits, st));
+    DBG(s, st);
+    launch_tile_ranges(R, keys_b, ranges, st);
+    DBG(s, st);
+  }
+  launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
+                   n_contrib, g_counters, st);
+  DBG(s, st);
+  HIP_TRY(hipGetLastError());
+  g_stats[0] = R; g_stats[1] = sort_bits; g_stats[2] = ntiles; g_stats[3] = (int64_t)G.total;
+  g_stats[4] = (int64_t)B.total; g_stats[5] = (int64_t)I.total;
+  return RTGS_OK;
+}
+
+int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
+                         const float* opacities, const float* shs, const float* scales, const float* rotations,
+                         const float* normal_w, const void* geom_buffer, const void* binning_buffer,
+                         const void* image_buffer, const float* out_T, const int32_t* out_didx,
+                         const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
+                         float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
+                         void* grad_scratch, void* stream) {
+  RasterParams p;
+  int rc = make_params(s, P, M, p);
+  if (rc != RTGS_OK) return rc;
+  if (P == 0) return RTGS_OK;
+  if (!means3D || !opacities || !shs || !scales || !rotations || !normal_w || !geom_buffer || !binning_buffer ||
+      !image_buffer || !out_T || !out_didx || !dL_dcolor || !dL_ddepth || !dL_dmeans3D || !dL_dopacities || !dL_dshs ||
+      !dL_dscales || !dL_drotations || !dL_dnormal_w || !grad_scratch || R < 0)
+    return RTGS_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntiles = p.gx * p.gy;
+  const GeomLayout G = geom_layout(P, p.gx, p.gy);
+  const BinLayout B = bin_layout(R, ntiles);
+  const ImgLayout I = img_layout(p.H, p.W, ntiles);
+  const char* geom = (const char*)geom_buffer;
+  const char* bin = (const char*)binning_buffer;
+  const char* img = (const char*)image_buffer;
+  SplatGrad* grads = (SplatGrad*)grad_scratch;
+  HIP_TRY(hipMemsetAsync(grads, 0, (size_t)P * sizeof(SplatGrad), st));
+  if (R > 0) {
+    launch_blend_bwd(p, (const uint2*)(img + I.ranges), (const uint32_t*)(bin + B.vals_b),
+                     (const Splat*)(geom + G.splats), out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
+                     dL_dcolor, dL_ddepth, grads, st);
+    DBG(s, st);
+  }
+  launch_preprocess_bwd(p, means3D, opacities, shs, scales, rotations, normal_w, (const int32_t*)(geom + G.radii),
+                        (const uint8_t*)(geom + G.clamped), grads, dL_dmeans3D, dL_dopacities, dL_dshs, dL_dscales,
+                        dL_drotations, dL_dnormal_w, st);
+  DBG(s, st);
+  HIP_TRY(hipGetLastError());
+  return RTGS_OK;
+}
+
+}  // extern "C"

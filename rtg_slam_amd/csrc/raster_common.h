@@ -1,0 +1,87 @@
+// Shared declarations of the gfx950 rasterizer kernels (internal; the public ABI is
+// include/rtgs_raster.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace rtgs {
+
+constexpr int TILE = 16;
+constexpr int BLOCK = TILE * TILE;   // 256 threads = 4 wave64, each wave a 16x4 pixel strip
+constexpr int WAVE = 64;
+
+// One 64-byte record per Gaussian: everything blend_fwd / blend_bwd need, so that a list
+// entry costs exactly one aligned 64-B gather.
+struct __attribute__((aligned(16))) Splat {
+  float u, v;          // pixel centre
+  float ca, cb, cc;    // conic (inverse 2D covariance)
+  float o;             // opacity
+  float r, g, b;       // view-dependent colour, clamped at 0
+  float nx, ny, nz;    // camera-space plane normal
+  float pd;            // plane offset n_c . p_c
+  float z;             // camera-space depth of the centre
+  float pad0, pad1;
+};
+static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
+
+// Per-Gaussian gradient record produced by blend_bwd, consumed by preprocess_bwd.
+struct __attribute__((aligned(16))) SplatGrad {
+  float du, dv;
+  float dca, dcb, dcc;
+  float dop;
+  float dr, dg, db;
+  float dnx, dny, dnz;
+  float dpd;
+  float pad0, pad1, pad2;
+};
+static_assert(sizeof(SplatGrad) == 64, "SplatGrad must be one 64-byte line");
+
+struct RasterParams {
+  int H, W, gx, gy, P, M, deg;
+  float fx, fy, cx, cy, tanfovx, tanfovy, scale_modifier;
+  float opaque_thr, depth_thr, normal_thr, color_sigma, T_thr;
+  const float* view;     // [16] W2C transposed
+  const float* campos;   // [3]
+  const float* bg;       // [3]
+};
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct GeomLayout {
+  size_t splats, tiles_touched, offsets, radii, clamped, sat, scan_temp, total;
+  size_t scan_temp_bytes;
+};
+struct BinLayout {
+  size_t keys_a, keys_b, vals_a, vals_b, sort_temp, total;
+  size_t sort_temp_bytes;
+};
+struct ImgLayout {
+  size_t ranges, n_contrib, total;
+};
+
+// Pinned SH constants (utils/sh_utils.py:26-45 of the reference).
+#define RTGS_SH_C0 0.28209479177387814f
+#define RTGS_SH_C1 0.4886025119029199f
+#define RTGS_SH_C2_0 1.0925484305920792f
+#define RTGS_SH_C2_1 -1.0925484305920792f
+#define RTGS_SH_C2_2 0.31539156525252005f
+#define RTGS_SH_C2_3 -1.0925484305920792f
+#define RTGS_SH_C2_4 0.5462742152960396f
+#define RTGS_SH_C3_0 -0.5900435899266435f
+#define RTGS_SH_C3_1 2.890611442640554f
+#define RTGS_SH_C3_2 -0.4570457994644658f
+#define RTGS_SH_C3_3 0.3731763325901154f
+#define RTGS_SH_C3_4 -0.4570457994644658f
+#define RTGS_SH_C3_5 1.445305721320277f
+#define RTGS_SH_C3_6 -0.5900435899266435f
+
+// The alpha of one (Gaussian, pixel) pair.  Written with explicit _rn intrinsics so the forward
+// and the backward kernel evaluate bit-identical skip / stop decisions regardless of how the
+// compiler contracts the surrounding code.
+__device__ __forceinline__ float splat_power(float ca, float cb, float cc, float dx, float dy) {
+  float q = __fmaf_rn(ca * dx, dx, (cc * dy) * dy);   // ca*dx*dx + cc*dy*dy
+  return __fmaf_rn(-0.5f, q, -(cb * dx) * dy);
+}
+
+}  // namespace rtgs

@@ -1,0 +1,351 @@
+// Forward kernels of the gfx950 rasterizer: per-Gaussian preprocess, (Gaussian, tile) instance
+// emission, tile ranges and the per-tile front-to-back alpha blend with opaque-surface depth.
+// Arithmetic follows SURVEY.md Appendix B (frozen in oracle/raster_oracle.py); the reference's
+// own CUDA sources are an un-vendored submodule (/root/reference/.gitmodules:1-4), its call
+// contract is /root/reference/SLAM/render.py:68-128.
+#include "raster_common.h"
+
+namespace rtgs {
+
+// ---------------------------------------------------------------------------------------------
+// tile-mask summed-area table: sat[(y+1)*(gx+1)+(x+1)] = #{mask != 0 in [0..y]x[0..x]}
+// One workgroup; the grid is at most a few thousand tiles (43x75 for Replica).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mask_sat_kernel(const int32_t* __restrict__ mask, int gx, int gy,
+                                                       int32_t* __restrict__ sat) {
+  const int sw = gx + 1;
+  for (int i = threadIdx.x; i < (gy + 1) * sw; i += blockDim.x) {
+    int y = i / sw, x = i % sw;
+    sat[i] = (y == 0 || x == 0) ? 0 : (mask[(y - 1) * gx + (x - 1)] != 0);
+  }
+  __syncthreads();
+  for (int y = 1 + threadIdx.x; y <= gy; y += blockDim.x) {      // row prefix
+    int acc = 0;
+    for (int x = 1; x <= gx; ++x) { acc += sat[y * sw + x]; sat[y * sw + x] = acc; }
+  }
+  __syncthreads();
+  for (int x = 1 + threadIdx.x; x <= gx; x += blockDim.x) {      // column prefix
+    int acc = 0;
+    for (int y = 1; y <= gy; ++y) { acc += sat[y * sw + x]; sat[y * sw + x] = acc; }
+  }
+}
+
+__device__ __forceinline__ void tile_rect(float u, float v, int radius, int gx, int gy,
+                                          int& x0, int& y0, int& x1, int& y1) {
+  // C (int) truncation then clamp, identical to floor-and-clamp on the clamped range
+  const float r = (float)radius;
+  x0 = min(gx, max(0, (int)((u - r) / (float)TILE)));
+  y0 = min(gy, max(0, (int)((v - r) / (float)TILE)));
+  x1 = min(gx, max(0, (int)((u + r + (float)(TILE - 1)) / (float)TILE)));
+  y1 = min(gy, max(0, (int)((v + r + (float)(TILE - 1)) / (float)TILE)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 preprocess_fwd: one lane per Gaussian.  Reads 62 floats (248 B), writes one 64-B Splat +
+// radius + tiles_touched + clamp flags.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(
+    RasterParams p, const float* __restrict__ means, const float* __restrict__ opac,
+    const float* __restrict__ shs, const float* __restrict__ scales, const float* __restrict__ rots,
+    const float* __restrict__ normal_w, const int32_t* __restrict__ sat,
+    Splat* __restrict__ splats, uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii,
+    uint8_t* __restrict__ clamped, int32_t* __restrict__ out_radii) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.P) return;
+  tiles_touched[i] = 0;
+  radii[i] = 0;
+  if (out_radii) out_radii[i] = 0;
+
+  const float* V = p.view;   // V[j*4+i] = W2C[i][j]
+  const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+  const float pcx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+  const float pcy = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+  const float pcz = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+  if (!(pcz > 0.2f)) return;
+
+  // Sigma3D = (R S)(R S)^T
+  const float qr = rots[4 * i], qx = rots[4 * i + 1], qy = rots[4 * i + 2], qz = rots[4 * i + 3];
+  const float sx = scales[3 * i] * p.scale_modifier, sy = scales[3 * i + 1] * p.scale_modifier,
+              sz = scales[3 * i + 2] * p.scale_modifier;
+  const float R00 = 1.f - 2.f * (qy * qy + qz * qz), R01 = 2.f * (qx * qy - qr * qz), R02 = 2.f * (qx * qz + qr * qy);
+  const float R10 = 2.f * (qx * qy + qr * qz), R11 = 1.f - 2.f * (qx * qx + qz * qz), R12 = 2.f * (qy * qz - qr * qx);
+  const float R20 = 2.f * (qx * qz - qr * qy), R21 = 2.f * (qy * qz + qr * qx), R22 = 1.f - 2.f * (qx * qx + qy * qy);
+  const float M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
+  const float M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
+  const float M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
+  const float S00 = M00 * M00 + M01 * M01 + M02 * M02;
+  const float S01 = M00 * M10 + M01 * M11 + M02 * M12;
+  const float S02 = M00 * M20 + M01 * M21 + M02 * M22;
+  const float S11 = M10 * M10 + M11 * M11 + M12 * M12;
+  const float S12 = M10 * M20 + M11 * M21 + M12 * M22;
+  const float S22 = M20 * M20 + M21 * M21 + M22 * M22;
+
+  // EWA: Sigma2D = T Sigma T^T, T = J Wr
+  const float limx = 1.3f * p.tanfovx, limy = 1.3f * p.tanfovy;
+  const float txtz = pcx / pcz, tytz = pcy / pcz;
+  const float tx = fminf(limx, fmaxf(-limx, txtz)) * pcz;
+  const float ty = fminf(limy, fmaxf(-limy, tytz)) * pcz;
+  const float iz = 1.f / pcz;
+  const float J00 = p.fx * iz, J02 = -p.fx * tx * iz * iz;
+  const float J11 = p.fy * iz, J12 = -p.fy * ty * iz * iz;
+  // Wr[r][c] = V[c*4+r]
+  const float T00 = J00 * V[0] + J02 * V[2], T01 = J00 * V[4] + J02 * V[6], T02 = J00 * V[8] + J02 * V[10];
+  const float T10 = J11 * V[1] + J12 * V[2], T11 = J11 * V[5] + J12 * V[6], T12 = J11 * V[9] + J12 * V[10];
+  const float a0 = S00 * T00 + S01 * T01 + S02 * T02;
+  const float a1 = S01 * T00 + S11 * T01 + S12 * T02;
+  const float a2 = S02 * T00 + S12 * T01 + S22 * T02;
+  const float b0 = S00 * T10 + S01 * T11 + S02 * T12;
+  const float b1 = S01 * T10 + S11 * T11 + S12 * T12;
+  const float b2 = S02 * T10 + S12 * T11 + S22 * T12;
+  const float ca = T00 * a0 + T01 * a1 + T02 * a2 + 0.3f;
+  const float cb = T00 * b0 + T01 * b1 + T02 * b2;
+  const float cc = T10 * b0 + T11 * b1 + T12 * b2 + 0.3f;
+  const float det = ca * cc - cb * cb;
+  if (det == 0.f) return;
+  const float idet = 1.f / det;
+  const float mid = 0.5f * (ca + cc);
+  const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+  const int radius = (int)ceilf(p.color_sigma * sqrtf(lam));
+  const float u = p.fx * pcx / pcz + p.cx;
+  const float v = p.fy * pcy / pcz + p.cy;
+  int x0, y0, x1, y1;
+  tile_rect(u, v, radius, p.gx, p.gy, x0, y0, x1, y1);
+  if ((x1 - x0) * (y1 - y0) == 0) return;
+  const int sw = p.gx + 1;
+  const int touched = sat[y1 * sw + x1] - sat[y0 * sw + x1] - sat[y1 * sw + x0] + sat[y0 * sw + x0];
+
+  // view-dependent colour (utils/sh_utils.py:57-120 basis), clamped at 0
+  float dxw = mx - p.campos[0], dyw = my - p.campos[1], dzw = mz - p.campos[2];
+  const float il = 1.f / sqrtf(dxw * dxw + dyw * dyw + dzw * dzw);
+  dxw *= il; dyw *= il; dzw *= il;
+  const float* sh = shs + (size_t)i * p.M * 3;
+  float col[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float r = RTGS_SH_C0 * sh[c];
+    if (p.deg > 0) {
+      r = r - RTGS_SH_C1 * dyw * sh[3 + c] + RTGS_SH_C1 * dzw * sh[6 + c] - RTGS_SH_C1 * dxw * sh[9 + c];
+      if (p.deg > 1) {
+        const float xx = dxw * dxw, yy = dyw * dyw, zz = dzw * dzw, xy = dxw * dyw, yz = dyw * dzw, xz = dxw * dzw;
+        r = r + RTGS_SH_C2_0 * xy * sh[12 + c] + RTGS_SH_C2_1 * yz * sh[15 + c] +
+            RTGS_SH_C2_2 * (2.f * zz - xx - yy) * sh[18 + c] + RTGS_SH_C2_3 * xz * sh[21 + c] +
+            RTGS_SH_C2_4 * (xx - yy) * sh[24 + c];
+        if (p.deg > 2) {
+          r = r + RTGS_SH_C3_0 * dyw * (3.f * xx - yy) * sh[27 + c] + RTGS_SH_C3_1 * xy * dzw * sh[30 + c] +
+              RTGS_SH_C3_2 * dyw * (4.f * zz - xx - yy) * sh[33 + c] +
+              RTGS_SH_C3_3 * dzw * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + c] +
+              RTGS_SH_C3_4 * dxw * (4.f * zz - xx - yy) * sh[39 + c] + RTGS_SH_C3_5 * dzw * (xx - yy) * sh[42 + c] +
+              RTGS_SH_C3_6 * dxw * (xx - 3.f * yy) * sh[45 + c];
+        }
+      }
+    }
+    col[c] = r + 0.5f;
+  }
+  uint8_t cl = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (col[c] < 0.f) { cl |= (uint8_t)(1u << c); col[c] = 0.f; }
+  }
+
+  const float nwx = normal_w[3 * i], nwy = normal_w[3 * i + 1], nwz = normal_w[3 * i + 2];
+  const float ncx = V[0] * nwx + V[4] * nwy + V[8] * nwz;
+  const float ncy = V[1] * nwx + V[5] * nwy + V[9] * nwz;
+  const float ncz = V[2] * nwx + V[6] * nwy + V[10] * nwz;
+
+  Splat s;
+  s.u = u; s.v = v;
+  s.ca = cc * idet; s.cb = -cb * idet; s.cc = ca * idet;
+  s.o = opac[i];
+  s.r = col[0]; s.g = col[1]; s.b = col[2];
+  s.nx = ncx; s.ny = ncy; s.nz = ncz;
+  s.pd = ncx * pcx + ncy * pcy + ncz * pcz;
+  s.z = pcz;
+  s.pad0 = 0.f; s.pad1 = 0.f;
+  float4* dst = reinterpret_cast<float4*>(splats + i);
+  const float4* src = reinterpret_cast<const float4*>(&s);
+  dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+  clamped[i] = cl;
+  radii[i] = radius;
+  if (out_radii) out_radii[i] = radius;
+  tiles_touched[i] = (uint32_t)touched;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3 emit: key = tile << 32 | f32 depth bits, value = Gaussian id, for unmasked tiles of the rect
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) emit_keys_kernel(
+    RasterParams p, const Splat* __restrict__ splats, const int32_t* __restrict__ radii,
+    const uint32_t* __restrict__ offsets, const int32_t* __restrict__ mask,
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.P) return;
+  const int radius = radii[i];
+  if (radius <= 0) return;
+  uint32_t off = (i == 0) ? 0u : offsets[i - 1];
+  const uint32_t end = offsets[i];
+  if (off == end) return;
+  const float u = splats[i].u, v = splats[i].v;
+  const uint32_t zbits = __float_as_uint(splats[i].z);
+  int x0, y0, x1, y1;
+  tile_rect(u, v, radius, p.gx, p.gy, x0, y0, x1, y1);
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      const int t = y * p.gx + x;
+      if (mask[t] != 0) {
+        keys[off] = ((uint64_t)(uint32_t)t << 32) | zbits;
+        vals[off] = (uint32_t)i;
+        ++off;
+      }
+    }
+}
+
+// K5 tile ranges over the sorted keys
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint64_t* __restrict__ keys,
+                                                          uint2* __restrict__ ranges) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const uint32_t t = (uint32_t)(keys[i] >> 32);
+  if (i == 0) ranges[t].x = 0;
+  else {
+    const uint32_t tp = (uint32_t)(keys[i - 1] >> 32);
+    if (tp != t) { ranges[tp].y = (uint32_t)i; ranges[t].x = (uint32_t)i; }
+  }
+  if (i == R - 1) ranges[t].y = (uint32_t)R;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 blend_fwd: one workgroup (4 wave64) per 16x16 tile; list entries staged through LDS in
+// batches of 256 records (one 64-B gather per thread), then every pixel walks the batch with
+// LDS broadcast reads.  Per-wave ballot ends a wave's walk as soon as its 64 pixels are done;
+// __syncthreads_and ends the tile.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) blend_fwd_kernel(
+    RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
+    int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
+    float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
+    unsigned long long* __restrict__ counters) {
+  __shared__ float4 s_rec[BLOCK * 4];
+  __shared__ int32_t s_id[BLOCK];
+
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.y * p.gx + blockIdx.x;
+  const int px = blockIdx.x * TILE + (tid & 15);
+  const int py = blockIdx.y * TILE + (tid >> 4);
+  const bool inside = px < p.W && py < p.H;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint2 range = ranges[tile];
+  const int n = (int)(range.y - range.x);
+
+  bool done = !inside;
+  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  float best_w = 0.f; int best_id = -1;
+  float D = 0.f, d_w = 0.f; int d_id = -1;
+  uint32_t contributor = 0, last_contributor = 0;
+  const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
+  const float rnorm = sqrtf(rx * rx + ry * ry + 1.f);
+  unsigned long long evals = 0;
+
+  for (int base = 0; base < n; base += BLOCK) {
+    if (__syncthreads_and(done)) break;
+    const int m = min(BLOCK, n - base);
+    if (tid < m) {
+      const uint32_t id = point_list[range.x + base + tid];
+      s_id[tid] = (int32_t)id;
+      const float4* src = reinterpret_cast<const float4*>(splats + id);
+      s_rec[tid * 4 + 0] = src[0];
+      s_rec[tid * 4 + 1] = src[1];
+      s_rec[tid * 4 + 2] = src[2];
+      s_rec[tid * 4 + 3] = src[3];
+    }
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+      if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;   // whole wave finished
+      if (done) continue;
+      ++contributor;
+      ++evals;
+      const float4 r0 = s_rec[j * 4 + 0];   // u v ca cb
+      const float4 r1 = s_rec[j * 4 + 1];   // cc o r g
+      const float dx = r0.x - pxf, dy = r0.y - pyf;
+      const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
+      if (power > 0.f) continue;
+      const float alpha = fminf(0.99f, r1.y * expf(power));
+      if (alpha < 1.f / 255.f) continue;
+      const float test_T = T * (1.f - alpha);
+      if (test_T < p.T_thr) { done = true; continue; }
+      const float4 r2 = s_rec[j * 4 + 2];   // b nx ny nz
+      const float w = alpha * T;
+      C0 += r1.z * w; C1 += r1.w * w; C2 += r2.x * w;
+      if (w > best_w) { best_w = w; best_id = s_id[j]; }
+      if (d_id < 0 && alpha > p.opaque_thr) {
+        const float4 r3 = s_rec[j * 4 + 3];  // pd z - -
+        const float den = r2.y * rx + r2.z * ry + r2.w;
+        if (fabsf(den) / rnorm > p.normal_thr) {
+          const float zhit = r3.x / den;
+          if (zhit > 0.f && fabsf(zhit - r3.y) < p.depth_thr) { D = zhit; d_w = alpha; d_id = s_id[j]; }
+        }
+      }
+      T = test_T;
+      last_contributor = contributor;
+    }
+  }
+
+  if (inside) {
+    const size_t pix = (size_t)py * p.W + px;
+    const size_t HW = (size_t)p.H * p.W;
+    out_color[pix] = C0 + T * p.bg[0];
+    out_color[HW + pix] = C1 + T * p.bg[1];
+    out_color[2 * HW + pix] = C2 + T * p.bg[2];
+    out_depth[pix] = D;
+    out_cidx[pix] = best_id;
+    out_didx[pix] = d_id;
+    out_cw[pix] = best_w;
+    out_dw[pix] = d_w;
+    out_T[pix] = T;
+    n_contrib[pix] = last_contributor;
+  }
+  if (counters) {
+    // work accounting for the roofline: entries any pixel of this tile consumed, and
+    // (entry, pixel) pairs evaluated
+    __shared__ unsigned int s_max;
+    __shared__ unsigned long long s_ev;
+    if (tid == 0) { s_max = 0; s_ev = 0; }
+    __syncthreads();
+    atomicMax(&s_max, contributor);
+    atomicAdd(&s_ev, evals);
+    __syncthreads();
+    if (tid == 0) { atomicAdd(&counters[0], (unsigned long long)s_max); atomicAdd(&counters[1], s_ev); }
+  }
+}
+
+// ------------------------------------------------------------------ host-side launch helpers
+void launch_mask_sat(const int32_t* mask, int gx, int gy, int32_t* sat, hipStream_t st) {
+  hipLaunchKernelGGL(mask_sat_kernel, dim3(1), dim3(256), 0, st, mask, gx, gy, sat);
+}
+void launch_preprocess_fwd(const RasterParams& p, const float* means, const float* opac, const float* shs,
+                           const float* scales, const float* rots, const float* normal_w, const int32_t* sat,
+                           Splat* splats, uint32_t* tiles_touched, int32_t* radii, uint8_t* clamped,
+                           int32_t* out_radii, hipStream_t st) {
+  if (p.P == 0) return;
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, opac, shs, scales,
+                     rots, normal_w, sat, splats, tiles_touched, radii, clamped, out_radii);
+}
+void launch_emit_keys(const RasterParams& p, const Splat* splats, const int32_t* radii, const uint32_t* offsets,
+                      const int32_t* mask, uint64_t* keys, uint32_t* vals, hipStream_t st) {
+  if (p.P == 0) return;
+  hipLaunchKernelGGL(emit_keys_kernel, dim3((p.P + 255) / 256), dim3(256), 0, st, p, splats, radii, offsets, mask,
+                     keys, vals);
+}
+void launch_tile_ranges(int64_t R, const uint64_t* keys, uint2* ranges, hipStream_t st) {
+  if (R == 0) return;
+  hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, R, keys, ranges);
+}
+void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
+                      float* out_color, float* out_depth, int32_t* out_cidx, int32_t* out_didx, float* out_cw,
+                      float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
+                     out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters);
+}
+
+}  // namespace rtgs

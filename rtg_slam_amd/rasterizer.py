@@ -1,0 +1,199 @@
+"""Host side of the rasterizer: the Python surface of `diff_gaussian_rasterization_depth`
+exactly as /root/reference/SLAM/render.py:8-13, 68-128 uses it, over the C ABI of
+include/rtgs_raster.h.  torch supplies device memory, the current HIP stream and autograd
+plumbing only; all arithmetic runs in the HIP kernels of rtg_slam_amd/csrc."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """The 19 keyword fields of SLAM/render.py:68-88 (same names, same order)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    opaque_threshold: float
+    depth_threshold: float
+    normal_threshold: float
+    color_sigma: float
+    prefiltered: bool
+    debug: bool
+    cx: float
+    cy: float
+    T_threshold: float
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class _Keep:
+    """Holds the device tensors the settings struct points at alive for the call."""
+
+    def __init__(self, rs: GaussianRasterizationSettings, device):
+        self.bg = _f32c(rs.bg.to(device))
+        self.view = _f32c(rs.viewmatrix.to(device))
+        self.proj = _f32c(rs.projmatrix.to(device))
+        self.campos = _f32c(rs.campos.to(device))
+        self.c = _lib.RasterSettingsC(
+            int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
+            self.bg.data_ptr(), float(rs.scale_modifier), self.view.data_ptr(), self.proj.data_ptr(),
+            int(rs.sh_degree), self.campos.data_ptr(), float(rs.opaque_threshold), float(rs.depth_threshold),
+            float(rs.normal_threshold), float(rs.color_sigma), int(bool(rs.prefiltered)), int(bool(rs.debug)),
+            float(rs.cx), float(rs.cy), float(rs.T_threshold))
+
+
+class _Arena:
+    """Resize callback target: allocates through torch's caching allocator on the op's device."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor: Optional[torch.Tensor] = None
+        self.cb = _lib.RESIZE_FN(self._resize)
+
+    def _resize(self, _user, nbytes):
+        try:
+            self.tensor = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+            return self.tensor.data_ptr()
+        except Exception:  # surfaces as RTGS_E_ALLOC
+            return 0
+
+
+def _require_device(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "diff_gaussian_rasterization_depth (rtg_slam_amd): tensors must live on a HIP device; "
+            "this build has no CPU path.")
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, opacities, shs, scales, rotations, normal_w, tile_mask, raster_settings):
+        lib = _lib.load()
+        _require_device(means3D)
+        dev = means3D.device
+        rs = raster_settings
+        H, W = int(rs.image_height), int(rs.image_width)
+        P = int(means3D.shape[0])
+        means3D, opacities, shs = _f32c(means3D), _f32c(opacities), _f32c(shs)
+        scales, rotations, normal_w = _f32c(scales), _f32c(rotations), _f32c(normal_w)
+        M = int(shs.shape[1]) if shs.dim() == 3 and P > 0 else 16
+        tile_mask = tile_mask.to(device=dev, dtype=torch.int32).contiguous()
+        gy, gx = (H + 15) // 16, (W + 15) // 16
+        if tuple(tile_mask.shape) != (gy, gx):
+            raise RuntimeError(f"tile_mask must be int32[{gy},{gx}], got {tuple(tile_mask.shape)}")
+
+        f = dict(dtype=torch.float32, device=dev)
+        i = dict(dtype=torch.int32, device=dev)
+        color = torch.empty(3, H, W, **f)
+        depth = torch.empty(1, H, W, **f)
+        cidx = torch.empty(1, H, W, **i)
+        didx = torch.empty(1, H, W, **i)
+        cw = torch.empty(1, H, W, **f)
+        dw = torch.empty(1, H, W, **f)
+        Tm = torch.empty(1, H, W, **f)
+        radii = torch.empty(max(P, 1), **i)
+        keep = _Keep(rs, dev)
+        geom, binning, img = _Arena(dev), _Arena(dev), _Arena(dev)
+        R = C.c_int64(0)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            rc = lib.rtgs_raster_forward(
+                C.byref(keep.c), P, M, _ptr(means3D), _ptr(opacities), _ptr(shs), _ptr(scales), _ptr(rotations),
+                _ptr(normal_w), _ptr(tile_mask), _ptr(color), _ptr(depth), _ptr(cidx), _ptr(didx), _ptr(cw),
+                _ptr(dw), _ptr(Tm), _ptr(radii), geom.cb, None, binning.cb, None, img.cb, None, C.byref(R),
+                C.c_void_p(stream))
+        _lib.check(rc, "rtgs_raster_forward")
+        ctx.raster_settings = rs
+        ctx.num_rendered = int(R.value)
+        ctx.M = M
+        ctx.save_for_backward(means3D, opacities, shs, scales, rotations, normal_w, geom.tensor, binning.tensor,
+                              img.tensor, Tm, didx)
+        ctx.mark_non_differentiable(cidx, didx, cw, dw, Tm)
+        return color, depth, cidx, didx, cw, dw, Tm
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth, *_unused):
+        lib = _lib.load()
+        (means3D, opacities, shs, scales, rotations, normal_w, geom, binning, img, Tm, didx) = ctx.saved_tensors
+        rs = ctx.raster_settings
+        dev = means3D.device
+        P = int(means3D.shape[0])
+        H, W = int(rs.image_height), int(rs.image_width)
+        f = dict(dtype=torch.float32, device=dev)
+        g_color = torch.zeros(3, H, W, **f) if g_color is None else _f32c(g_color)
+        g_depth = torch.zeros(1, H, W, **f) if g_depth is None else _f32c(g_depth)
+        d_means = torch.empty_like(means3D)
+        d_opac = torch.empty_like(opacities)
+        d_shs = torch.empty_like(shs)
+        d_scales = torch.empty_like(scales)
+        d_rots = torch.empty_like(rotations)
+        d_normal = torch.empty_like(normal_w)
+        if P > 0:
+            scratch = torch.empty(lib.rtgs_raster_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
+            keep = _Keep(rs, dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            with torch.cuda.device(dev):
+                rc = lib.rtgs_raster_backward(
+                    C.byref(keep.c), P, ctx.M, ctx.num_rendered, _ptr(means3D), _ptr(opacities), _ptr(shs),
+                    _ptr(scales), _ptr(rotations), _ptr(normal_w), _ptr(geom), _ptr(binning), _ptr(img), _ptr(Tm),
+                    _ptr(didx), _ptr(g_color), _ptr(g_depth), _ptr(d_means), _ptr(d_opac), _ptr(d_shs),
+                    _ptr(d_scales), _ptr(d_rots), _ptr(d_normal), _ptr(scratch), C.c_void_p(stream))
+            _lib.check(rc, "rtgs_raster_backward")
+        return d_means, d_opac, d_shs, d_scales, d_rots, d_normal, None, None
+
+
+class GaussianRasterizer(nn.Module):
+    """`GaussianRasterizer(raster_settings=...)(means3D=..., opacities=..., shs=..., colors_precomp=None,
+    scales=..., rotations=..., cov3D_precomp=None, normal_w=..., tile_mask=...)` ->
+    (color[3,H,W], depth[1,H,W], color_index_map, depth_index_map, color_hit_weight,
+    depth_hit_weight, T_map) - SLAM/render.py:89-128."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, normal_w=None, tile_mask=None):
+        rs = self.raster_settings
+        if colors_precomp is not None or cov3D_precomp is not None:
+            raise NotImplementedError(
+                "colors_precomp / cov3D_precomp are always None in RTG-SLAM (SLAM/render.py:99-100) and are "
+                "not part of this build")
+        if shs is None or scales is None or rotations is None:
+            raise ValueError("shs, scales and rotations are required")
+        P = means3D.shape[0]
+        if P == 0:
+            # mapper.py:1000-1009 hands torch.empty(0) for every field of an empty sub-map
+            dev = means3D.device
+            means3D = means3D.reshape(0, 3)
+            opacities = opacities.reshape(0, 1)
+            shs = shs.reshape(0, 16, 3) if shs.numel() == 0 else shs
+            scales = scales.reshape(0, 3)
+            rotations = rotations.reshape(0, 4)
+            normal_w = torch.zeros(0, 3, device=dev) if normal_w is None else normal_w.reshape(0, 3)
+        if normal_w is None:
+            raise ValueError("normal_w is required")
+        if tile_mask is None:
+            tile_mask = torch.ones((int(rs.image_height) + 15) // 16, (int(rs.image_width) + 15) // 16,
+                                   dtype=torch.int32, device=means3D.device)
+        return _RasterizeGaussians.apply(means3D, opacities, shs, scales, rotations, normal_w, tile_mask, rs)

@@ -1,0 +1,112 @@
+"""Parity of the HIP ICP tracker with the reference's own outputs (tests/golden/icp_*.npz) and,
+on larger seeded frames, with the pinned oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import icp_oracle as io
+from rtg_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, f"icp_{name}.npz"))
+    return {k: (torch.from_numpy(z[k]) if z[k].ndim else z[k]) for k in z.files}
+
+
+@pytest.mark.parametrize("name", ["small_clean", "small_noisy"])
+def test_pyramids_vs_reference(golden_dir, name):
+    from rtg_slam_amd import icp
+    g = load(golden_dir, name)
+    for tag in ("0", "1"):
+        vp, npyr = icp.build_pyramids(g[f"depth{tag}"].to(DEV), g["K"].to(DEV), 3)
+        for l in range(3):
+            assert torch.equal(vp[l].cpu(), g[f"v{tag}_{l}"]), "vertex maps bit-exact"
+            d = (npyr[l].cpu() - g[f"n{tag}_{l}"]).abs().amax(dim=-1)
+            assert float((d > 1e-4).float().mean()) < 1e-3, (l, float(d.max()))
+
+
+@pytest.mark.parametrize("name", ["small_clean", "small_noisy"])
+def test_icp_step_vs_reference(golden_dir, name):
+    from rtg_slam_amd import icp
+    g = load(golden_dir, name)
+    cos_thr = float(np.cos(np.deg2rad(20.0)))
+    for l, ds in enumerate([0.25, 0.5, 1.0]):
+        Kl = g["K"] * ds
+        Kl[2, 2] = 1.0
+        JtJ, Jtr, nv = icp.icp_step(g[f"v1_{l}"].to(DEV), g[f"n1_{l}"].to(DEV), g[f"v0_{l}"].to(DEV),
+                                    g[f"n0_{l}"].to(DEV), Kl, g["pose_probe"], 0.1, cos_thr)
+        assert int(nv.item()) == int(g[f"nvalid_{l}"])                 # identical valid count
+        ref = g[f"JtJ_{l}"]
+        assert float((JtJ.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+        rj = g[f"Jtr_{l}"].reshape(-1)
+        assert float((Jtr.cpu() - rj).abs().max()) <= 1e-4 * float(rj.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("name", ["small_clean", "small_noisy"])
+def test_track_vs_reference(golden_dir, name):
+    from rtg_slam_amd import icp
+    g = load(golden_dir, name)
+    mk = lambda p: [g[f"{p}_{l}"].to(DEV) for l in range(3)]
+    out = icp.icp_track(mk("v1"), mk("n1"), mk("v0"), mk("n0"), g["K"], [0.25, 0.5, 1.0], [5, 5, 5], 0.1,
+                        float(np.cos(np.deg2rad(20.0))), 1e-4).cpu()
+    pose = out[:16].reshape(4, 4)
+    assert float((pose - g["pose_final"]).abs().max()) < 1e-5
+    assert abs(float(out[16]) - float(g["valid_ratio"])) < 1e-4
+    assert abs(float(out[17]) - float(g["p2p_loss"])) <= 1e-4 * max(1.0, float(g["p2p_loss"]))
+    assert float(out[18]) == 0
+
+
+@pytest.mark.parametrize("name", ["small_clean", "small_noisy"])
+def test_fill_vs_reference(golden_dir, name):
+    from rtg_slam_amd import icp
+    g = load(golden_dir, name)
+    rd = g["fill_in"].to(DEV).clone()
+    icp.fill_model_depth(rd, g["depth1"].to(DEV), g["fill_rn"].to(DEV), g["n1_2"].to(DEV), 0.01, 0.01)
+    assert torch.equal(rd.cpu(), g["fill_out"])
+
+
+class Args:
+    icp_downscales = [0.25, 0.5, 1.0]
+    icp_downscale_iters = [5, 5, 5]
+    icp_warmup_frames = 0
+    icp_use_model_depth = True
+    icp_distance_threshold = 0.1
+    icp_normal_threshold = 20
+    icp_damping = 1e-4
+    icp_sample_distance_threshold = 0.01
+    icp_sample_normal_threshold = 0.01
+    icp_fail_threshold = 0.02
+    verbose = False
+
+
+@pytest.mark.parametrize("cam,noise", [(synth.TUM_FR1, True), (synth.REPLICA, False)])
+def test_tracker_class_vs_oracle_full_size(cam, noise):
+    """IcpTracker API (SLAM/icp.py:357-452) on Replica / TUM shaped frames vs the pinned oracle."""
+    from rtg_slam_amd.icp import IcpTracker
+    poses = synth.trajectory(2, seed=9)
+    base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
+    d0 = synth.box_room_depth(cam, base @ poses[0])
+    d1 = synth.box_room_depth(cam, base @ poses[1])
+    if noise:
+        d0, d1 = synth.tum_noise(d0, 1), synth.tum_noise(d1, 2)
+    K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32)
+    tr = IcpTracker(Args())
+    tr.update_curr_status(d0.to(DEV), K.to(DEV))
+    tr.move_last_status()
+    tr.update_curr_status(d1.to(DEV), K.to(DEV))
+    pose, ok = tr.predict_pose({"K": K.to(DEV), "frame_id": 1})
+    vp0 = io.vertex_pyramid(d0, K.clone(), 3); np0 = io.normal_pyramid(vp0)
+    vp1 = io.vertex_pyramid(d1, K.clone(), 3); np1 = io.normal_pyramid(vp1)
+    pose_o, ratio_o, loss_o = io.track(vp1, np1, vp0, np0, K.clone())
+    assert pose.shape == (4, 4) and pose.dtype == np.float32
+    assert float(np.abs(pose - pose_o.numpy()).max()) < 2e-5
+    assert abs(tr.last_valid_ratio - ratio_o) < 1e-3
+    assert ok == (not (loss_o > 0.02))
+    if not noise:
+        rel = (torch.linalg.inv(poses[0]) @ poses[1]).float().numpy()
+        assert float(np.abs(pose - rel).max()) < 5e-3
