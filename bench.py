@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""bench.py - the hot path of RTG-SLAM on MI355X, measured.
+
+A "step" is one synthetic Replica-shaped SLAM frame on the headline configuration of
+BASELINE.json (1.2 M Gaussians, 1200x680):
+    1 ICP frame-to-model track (3 pyramid levels x 5 Gauss-Newton iterations, SLAM/icp.py)
+  + 1 map-optimisation iteration (rasterizer forward, L1 colour + depth loss, rasterizer
+    backward, fused Adam) over the whole Gaussian set (mapper.py:176-205).
+`value` = frames / s over all ranks (weak scaling: every rank tracks and renders its own view of
+the replicated map; per-Gaussian gradients are reduce-scattered over RCCL, Adam runs on the
+rank's row shard, updated rows are all-gathered).
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with `roofline` for the
+dominant kernel and `cpu_baseline` (oracle on the host cores, bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=1_200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=48, help="tiles blended by the CPU oracle sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from rtg_slam_amd import _lib, synth, icp as hicp
+    from rtg_slam_amd import map_optim as mo
+    from rtg_slam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    lib = _lib.load()
+
+    cam = synth.REPLICA
+    N = args.gaussians
+    g = synth.random_gaussians(N, cam, seed=2024)                 # same map on every rank
+    packed = mo.pack_from_activated({k: v.to(dev) for k, v in g.items()})
+    opt = mo.ShardedMapOptimizer(packed)
+
+    # this rank's view: a small pose offset per rank (sliding-window views of one map)
+    c2w = synth.look_at_pose(seed=100 + rank, max_angle_deg=2.0, max_trans=0.05) if world > 1 else torch.eye(4, dtype=torch.float64)
+    view = torch.linalg.inv(c2w).float().t().contiguous().to(dev)
+    campos = c2w[:3, 3].float().to(dev)
+    tanfovx, tanfovy = cam.W / (2 * cam.fx), cam.H / (2 * cam.fy)
+    rs = GaussianRasterizationSettings(
+        image_height=cam.H, image_width=cam.W, tanfovx=tanfovx, tanfovy=tanfovy,
+        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=view, projmatrix=view,
+        sh_degree=3, campos=campos, opaque_threshold=0.6, depth_threshold=1.0,
+        normal_threshold=math.cos(math.radians(60.0)), color_sigma=3.0, prefiltered=False, debug=False,
+        cx=cam.cx, cy=cam.cy, T_threshold=1e-4)
+    rast = GaussianRasterizer(raster_settings=rs)
+    tile_mask = torch.ones((cam.H + 15) // 16, (cam.W + 15) // 16, dtype=torch.int32, device=dev)
+
+    gen = torch.Generator().manual_seed(7 + rank)
+    gt_color = torch.rand(3, cam.H, cam.W, generator=gen).to(dev)
+    poses = synth.trajectory(2, seed=9 + rank)
+    base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
+    d0 = synth.box_room_depth(cam, base @ poses[0]).to(dev)
+    d1 = synth.box_room_depth(cam, base @ poses[1]).to(dev)
+    gt_depth = d1.reshape(1, cam.H, cam.W)
+    K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32, device=dev)
+    vp0, np0 = hicp.build_pyramids(d0, K, 3)
+    cos_thr = math.cos(math.radians(20.0))
+
+    def render(gd):
+        return rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None,
+                    scales=gd["scales"], rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"],
+                    tile_mask=tile_mask)
+
+    def loss_fn(gd):
+        return mo.slam_losses(render(gd), gt_color, gt_depth)
+
+    def frame():
+        vp1, np1 = hicp.build_pyramids(d1, K, 3)
+        out = hicp.icp_track(vp1, np1, vp0, np0, K, [0.25, 0.5, 1.0], [5, 5, 5], 0.1, cos_thr, 1e-4)
+        opt.step(loss_fn)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        frame()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        # ---- per-kernel stage timing (HIP events on the launch stream) + work counters ---------
+        counters = torch.zeros(2, dtype=torch.int64, device=dev)
+        lib.rtgs_raster_set_profiling(1)
+        acc = [0.0] * 8
+        nprof = max(3, min(10, args.steps))
+        icp_ms = 0.0
+        consumed = pairs = 0
+        R = 0
+        for i in range(nprof):
+            counters.zero_()
+            lib.rtgs_raster_set_counters(C.c_void_p(counters.data_ptr()))
+            leaf = opt.params.detach().clone().requires_grad_(True)
+            loss = loss_fn(mo.activate(leaf))
+            lib.rtgs_raster_set_counters(None)
+            loss.backward()
+            torch.cuda.synchronize(dev)
+            ms = (C.c_float * 10)()
+            lib.rtgs_raster_last_timings(ms)
+            for k in range(8):
+                acc[k] += max(0.0, ms[k])
+            st = (C.c_int64 * 8)()
+            lib.rtgs_raster_last_stats(st)
+            R = int(st[0])
+            cc = counters.cpu()
+            consumed, pairs = int(cc[0]), int(cc[1])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            vp1, np1 = hicp.build_pyramids(d1, K, 3)
+            hicp.icp_track(vp1, np1, vp0, np0, K, [0.25, 0.5, 1.0], [5, 5, 5], 0.1, cos_thr, 1e-4)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            icp_ms += e0.elapsed_time(e1)
+        lib.rtgs_raster_set_profiling(0)
+        stage = [a / nprof for a in acc]
+        names = ["preprocess_fwd", "scan", "emit_keys", "radix_sort", "tile_ranges", "blend_fwd", "blend_bwd",
+                 "preprocess_bwd"]
+        Px = cam.H * cam.W
+        Nv = N   # upper bound; culled rows write nothing
+        # algorithmic bytes per launch (I := instances the tile walk consumes)
+        alg = {
+            "preprocess_fwd": 248 * N + 64 * Nv,
+            "emit_keys": 12 * R + 16 * N,
+            "radix_sort": 24 * R,
+            "tile_ranges": 8 * R,
+            "blend_fwd": 68 * consumed + 40 * Px,
+            "blend_bwd": 68 * consumed + 28 * Px + 36 * consumed,
+            "preprocess_bwd": 248 * N + 64 * N + 236 * N,
+        }
+        kernels = {}
+        for nm, ms_ in zip(names, stage):
+            if nm in alg and ms_ > 0:
+                kernels[nm] = {"ms": round(ms_, 4), "alg_MB": round(alg[nm] / 1e6, 2),
+                               "GBps": round(alg[nm] / (ms_ * 1e-3) / 1e9, 1)}
+            else:
+                kernels[nm] = {"ms": round(ms_, 4)}
+        dom = max((n for n in names if n in alg), key=lambda n: stage[names.index(n)])
+        dom_ms = stage[names.index(dom)]
+        achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(dom_ms, 4), "alg_bytes_per_launch": int(alg[dom])}
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(g, cam, args.cpu_tiles, d0, d1)
+
+        fps = world * args.steps / dt
+        result = {
+            "metric": "slam_frames_per_sec", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic Replica-shaped SLAM frame: ICP track (3 levels x 5 GN iters, 1200x680) + "
+                                   "1 map-optimisation iteration (raster fwd + L1 colour/depth loss + raster bwd + fused "
+                                   f"Adam) over {N} random Gaussians (SURVEY.md 8d generator, seed 2024), all tiles",
+                       "gaussians": N, "image": [cam.H, cam.W], "instances": R, "instances_consumed": consumed,
+                       "pixel_pairs_evaluated": pairs,
+                       "parallelism": f"dp{world}: replicated map, per-rank view, RCCL reduce-scatter grads + sharded Adam + all-gather"},
+            "raster_fwd_ms": round(sum(stage[:6]), 4), "raster_bwd_ms": round(sum(stage[6:]), 4),
+            "raster_fwd_bwd_ms": round(sum(stage), 4), "icp_track_ms": round(icp_ms / nprof, 4),
+            "kernels": kernels, "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(g, cam, n_tiles, d0, d1):
+    """Oracle (PyTorch-CPU restatement) on the host cores, bounded sample of the same workload:
+    full preprocess + binning of all Gaussians, blend fwd+bwd of `n_tiles` tiles (time scaled to
+    the full tile grid), plus one full ICP track with the pinned ICP oracle."""
+    from oracle import raster_oracle as ro
+    from oracle import icp_oracle as io
+    torch.set_num_threads(os.cpu_count() or 1)
+    s = ro.make_settings(cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy)
+    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+    mask = torch.zeros(gy, gx, dtype=torch.int32)
+    sel = torch.linspace(0, gy * gx - 1, n_tiles).long()
+    mask.view(-1)[sel] = 1
+    leaves = {k: v.clone().requires_grad_(True) for k, v in g.items()}
+    t0 = time.perf_counter()
+    outs = ro.rasterize(s, leaves["xyz"], leaves["opacity"], leaves["shs"], leaves["scales"], leaves["rotations"],
+                        leaves["normal"], mask)
+    t1 = time.perf_counter()
+    (outs[0].sum() + outs[1].sum()).backward()
+    t2 = time.perf_counter()
+    # split: preprocess+binning do not scale with the tile count, the blend does
+    with torch.no_grad():
+        tp0 = time.perf_counter()
+        pre = ro.preprocess(s, g["xyz"], g["opacity"], g["shs"], g["scales"], g["rotations"], g["normal"])
+        ro.bin_tiles(pre, mask)
+        tp1 = time.perf_counter()
+    fixed = tp1 - tp0
+    blend = max(0.0, (t2 - t0) - 2 * fixed)
+    raster_full = 2 * fixed + blend * (gy * gx) / n_tiles
+    K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32)
+    ti0 = time.perf_counter()
+    vp0 = io.vertex_pyramid(d0.cpu(), K.clone(), 3); np0 = io.normal_pyramid(vp0)
+    vp1 = io.vertex_pyramid(d1.cpu(), K.clone(), 3); np1 = io.normal_pyramid(vp1)
+    io.track(vp1, np1, vp0, np0, K.clone())
+    ti1 = time.perf_counter()
+    icp_s = ti1 - ti0
+    return {"value": round(1.0 / (raster_full + icp_s), 5), "unit": "frames/s", "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": f"oracle raster fwd+bwd on all {g['xyz'].shape[0]} Gaussians with {n_tiles} of {gy * gx} tiles "
+                      f"blended ({t2 - t0:.1f} s measured; blend share scaled x{gy * gx / n_tiles:.0f} -> "
+                      f"{raster_full:.1f} s/frame) + 1 full ICP track incl. pyramids ({icp_s:.2f} s)",
+            "measured_s": round((t2 - t0) + icp_s, 2)}
+
+
+if __name__ == "__main__":
+    main()

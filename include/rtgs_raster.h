@@ -117,6 +117,21 @@ int rtgs_raster_last_stats(int64_t* stats8_host);
  * disable.  Sticky per thread until reset with NULL. */
 void rtgs_raster_set_counters(void* counters);
 
+/* Optional per-stage HIP-event timing of the calls made on this thread (off by default).
+ * rtgs_raster_last_timings fills ms10_host[0..7] with the last forward/backward's stage
+ * durations in milliseconds (-1 = stage did not run):
+ *   [0] preprocess_fwd (+ mask SAT)  [1] scan  [2] emit_keys  [3] radix sort  [4] tile_ranges
+ *   [5] blend_fwd  [6] grad memset + blend_bwd  [7] preprocess_bwd */
+void rtgs_raster_set_profiling(int enable);
+int rtgs_raster_last_timings(float* ms10_host);
+
+/* Fused Adam over a packed [rows, cols] float32 parameter shard with one learning rate per
+ * column (the six Adam groups of SLAM/gaussian_pointcloud.py:245-284; torch.optim.Adam
+ * semantics with eps as given, mapper.py:156).  `step` is the 1-based step count. */
+int rtgs_fused_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                    const float* lr_per_column, int64_t rows, int32_t cols, int32_t step,
+                    float beta1, float beta2, float eps, void* stream);
+
 const char* rtgs_version(void);
 
 #ifdef __cplusplus

@@ -25,6 +25,22 @@ void launch_preprocess_bwd(const RasterParams&, const float*, const float*, cons
 static thread_local int64_t g_stats[8] = {0};
 static thread_local unsigned long long* g_counters = nullptr;
 
+// optional per-stage HIP-event timing (bench.py's roofline leg); off by default
+enum { EV_F0 = 0, EV_PRE, EV_SCAN, EV_BIN0, EV_EMIT, EV_SORT, EV_RANGES, EV_BLEND, EV_B0, EV_BBLEND, EV_BPRE, EV_N };
+static thread_local bool g_prof = false;
+static thread_local bool g_ev_init = false;
+static thread_local hipEvent_t g_ev[EV_N];
+static thread_local bool g_ev_set[EV_N] = {false};
+static void prof_mark(int which, hipStream_t st) {
+  if (!g_prof) return;
+  if (!g_ev_init) {
+    for (int i = 0; i < EV_N; ++i) (void)hipEventCreate(&g_ev[i]);
+    g_ev_init = true;
+  }
+  (void)hipEventRecord(g_ev[which], st);
+  g_ev_set[which] = true;
+}
+
 static int bits_for(uint32_t n) {   // bits needed to represent values in [0, n)
   int b = 0;
   while ((1ull << b) < (unsigned long long)n) ++b;
@@ -175,16 +191,20 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   uint32_t* n_contrib = (uint32_t*)(img + I.n_contrib);
 
   int64_t R = 0;
+  for (int i = 0; i < EV_B0; ++i) g_ev_set[i] = false;
+  prof_mark(EV_F0, st);
   if (P > 0) {
     launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
     DBG(s, st);
     launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sat, splats, tiles_touched, radii,
                           clamped, out_radii, st);
     DBG(s, st);
+    prof_mark(EV_PRE, st);
     size_t tb = G.scan_temp_bytes;
     HIP_TRY(hipcub::DeviceScan::InclusiveSum(geom + G.scan_temp, tb, tiles_touched, offsets, P, st));
     uint32_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    prof_mark(EV_SCAN, st);
     HIP_TRY(hipStreamSynchronize(st));   // the one host sync of the forward: sizes the instance arrays
     R = (int64_t)total;
   }
@@ -201,17 +221,22 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), st));
   const int sort_bits = 32 + bits_for((uint32_t)ntiles);
   if (R > 0) {
+    prof_mark(EV_BIN0, st);
     launch_emit_keys(p, splats, radii, offsets, tile_mask, keys_a, vals_a, st);
     DBG(s, st);
+    prof_mark(EV_EMIT, st);
     size_t tb = B.sort_temp_bytes;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin + B.sort_temp, tb, keys_a, keys_b, vals_a, vals_b, (int)R, 0,
                                                sort_bits, st));
     DBG(s, st);
+    prof_mark(EV_SORT, st);
     launch_tile_ranges(R, keys_b, ranges, st);
     DBG(s, st);
+    prof_mark(EV_RANGES, st);
   }
   launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
                    n_contrib, g_counters, st);
+  prof_mark(EV_BLEND, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
   g_stats[0] = R; g_stats[1] = sort_bits; g_stats[2] = ntiles; g_stats[3] = (int64_t)G.total;
@@ -243,6 +268,8 @@ int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, in
   const char* bin = (const char*)binning_buffer;
   const char* img = (const char*)image_buffer;
   SplatGrad* grads = (SplatGrad*)grad_scratch;
+  for (int i = EV_B0; i < EV_N; ++i) g_ev_set[i] = false;
+  prof_mark(EV_B0, st);
   HIP_TRY(hipMemsetAsync(grads, 0, (size_t)P * sizeof(SplatGrad), st));
   if (R > 0) {
     launch_blend_bwd(p, (const uint2*)(img + I.ranges), (const uint32_t*)(bin + B.vals_b),
@@ -250,11 +277,33 @@ int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, in
                      dL_dcolor, dL_ddepth, grads, st);
     DBG(s, st);
   }
+  prof_mark(EV_BBLEND, st);
   launch_preprocess_bwd(p, means3D, opacities, shs, scales, rotations, normal_w, (const int32_t*)(geom + G.radii),
                         (const uint8_t*)(geom + G.clamped), grads, dL_dmeans3D, dL_dopacities, dL_dshs, dL_dscales,
                         dL_drotations, dL_dnormal_w, st);
+  prof_mark(EV_BPRE, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
+  return RTGS_OK;
+}
+
+void rtgs_raster_set_profiling(int enable) { g_prof = enable != 0; }
+
+int rtgs_raster_last_timings(float* ms) {
+  if (!ms) return RTGS_E_INVALID;
+  for (int i = 0; i < 10; ++i) ms[i] = -1.f;
+  if (!g_ev_init) return RTGS_OK;
+  // [0] preprocess_fwd(+sat) [1] scan [2] emit_keys [3] radix sort [4] tile_ranges [5] blend_fwd
+  // [6] memset+blend_bwd [7] preprocess_bwd
+  const int pairs[8][2] = {{EV_F0, EV_PRE}, {EV_PRE, EV_SCAN}, {EV_BIN0, EV_EMIT}, {EV_EMIT, EV_SORT},
+                           {EV_SORT, EV_RANGES}, {EV_RANGES, EV_BLEND}, {EV_B0, EV_BBLEND}, {EV_BBLEND, EV_BPRE}};
+  for (int i = 0; i < 8; ++i) {
+    const int a = pairs[i][0], b = pairs[i][1];
+    if (!g_ev_set[a] || !g_ev_set[b]) continue;
+    if (hipEventSynchronize(g_ev[b]) != hipSuccess) return RTGS_E_HIP;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_ev[a], g_ev[b]) == hipSuccess) ms[i] = t;
+  }
   return RTGS_OK;
 }
 

@@ -382,3 +382,41 @@ void launch_preprocess_bwd(const RasterParams& p, const float* means, const floa
 }
 
 }  // namespace rtgs
+
+// ---------------------------------------------------------------------------------------------
+// Fused Adam over a packed [n, C] float32 parameter shard with a per-column learning rate
+// (xyz / f_dc / f_rest / opacity / scaling / rotation groups of
+// SLAM/gaussian_pointcloud.py:245-284; torch.optim.Adam(eps=1e-15) semantics, mapper.py:156).
+// ---------------------------------------------------------------------------------------------
+namespace rtgs {
+__global__ void __launch_bounds__(256) fused_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         const float* __restrict__ lr_col, long long n_elems, int C,
+                                                         float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float lr = lr_col[(int)(i % C)];
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+}  // namespace rtgs
+
+extern "C" int rtgs_fused_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                               const float* lr_per_column, int64_t rows, int32_t cols, int32_t step, float beta1,
+                               float beta2, float eps, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_per_column || rows < 0 || cols < 1 || step < 1) return -1;
+  const long long n = (long long)rows * cols;
+  if (n == 0) return 0;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  long long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rtgs::fused_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads,
+                     exp_avg, exp_avg_sq, lr_per_column, n, (int)cols, beta1, beta2, eps, bc1, bc2s);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,164 @@
+"""One map-optimisation iteration (the body of RTG-SLAM's hot loop B,
+/root/reference/SLAM/multiprocess/mapper.py:176-205 -> :371-469) with the unstable-Gaussian set
+sharded across the GPUs of one node:
+
+    every rank holds the full packed parameter buffer [N,59] (replicated: 236 B x N, trivial
+    next to 288 GB), renders ITS view forward+backward through the HIP rasterizer, the
+    per-Gaussian gradients of all ranks are summed with ONE reduce-scatter over RCCL/xGMI
+    (each rank receives the rows of its shard), the rank runs fused Adam on its N/world rows
+    (optimizer state is sharded, never replicated), and ONE all-gather returns the updated rows.
+
+Packed column layout (raw, pre-activation values; SLAM/gaussian_pointcloud.py:407-466 order):
+    xyz 0:3 | f_dc 3:6 | f_rest 6:51 | opacity 51:52 | scaling 52:55 | rotation 55:59
+Activations (gaussian_pointcloud.py:16-25, 502-595): exp / sigmoid / normalize, normal = column
+of R(q) for the smallest scale.  Learning rates: configs/replica_base.yaml:19-23,
+gaussian_pointcloud.py:252-283; Adam eps 1e-15 (mapper.py:156).
+
+The render/loss closure and the Adam kernel are injected (HIP rasterizer + rtgs_fused_adam in
+production; the CPU oracle + a torch restatement in the world_size-2 gloo tests) so the
+sharding / collective logic is testable without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+COLS = 59
+SL = dict(xyz=(0, 3), f_dc=(3, 6), f_rest=(6, 51), opacity=(51, 52), scaling=(52, 55), rotation=(55, 59))
+
+
+def default_lr_columns(position_lr=1e-3, feature_lr=5e-4, opacity_lr=0.0, scaling_lr=4e-3, rotation_lr=1e-3):
+    lr = torch.zeros(COLS)
+    lr[0:3] = position_lr
+    lr[3:6] = feature_lr
+    lr[6:51] = feature_lr / 20.0
+    lr[51:52] = opacity_lr
+    lr[52:55] = scaling_lr
+    lr[55:59] = rotation_lr
+    return lr
+
+
+def pack_from_activated(g: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """Inverse activations of a `gaussian_data` dict (SLAM/render.py:93-98 keys) -> packed raw [N,59]."""
+    N = g["xyz"].shape[0]
+    out = torch.empty(N, COLS, dtype=torch.float32, device=g["xyz"].device)
+    out[:, 0:3] = g["xyz"]
+    out[:, 3:51] = g["shs"].reshape(N, 48)
+    o = g["opacity"].clamp(1e-6, 1 - 1e-6)
+    out[:, 51:52] = torch.log(o / (1 - o))
+    out[:, 52:55] = torch.log(g["scales"])
+    out[:, 55:59] = g["rotations"]
+    return out
+
+
+def rotmat_cols(q: torch.Tensor):
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    c0 = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y + r * z), 2 * (x * z - r * y)], -1)
+    c1 = torch.stack([2 * (x * y - r * z), 1 - 2 * (x * x + z * z), 2 * (y * z + r * x)], -1)
+    c2 = torch.stack([2 * (x * z + r * y), 2 * (y * z - r * x), 1 - 2 * (x * x + y * y)], -1)
+    return torch.stack([c0, c1, c2], dim=1)          # [N, 3 (column), 3]
+
+
+def activate(packed: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Packed raw params -> the `gaussian_data` dict Renderer.render consumes (differentiable)."""
+    N = packed.shape[0]
+    scales = torch.exp(packed[:, 52:55])
+    rot = torch.nn.functional.normalize(packed[:, 55:59])
+    cols = rotmat_cols(rot)
+    k = scales.argmin(dim=1)
+    n = cols[torch.arange(N, device=packed.device), k]
+    normal = n / (n.norm(dim=-1, keepdim=True) + 1e-8)
+    return dict(xyz=packed[:, 0:3], opacity=torch.sigmoid(packed[:, 51:52]), scales=scales, rotations=rot,
+                shs=packed[:, 3:51].reshape(N, 16, 3), normal=normal)
+
+
+def shard_rows(N: int, world: int):
+    """Row partition used for reduce-scatter / all-gather: equal shards of ceil(N/world) rows
+    (the packed buffer is padded to world * rows_per_rank)."""
+    per = (N + world - 1) // world
+    return per, per * world
+
+
+def _adam_hip(p, g, m, v, lr_col, step, eps):
+    from . import _lib
+    if not p.is_cuda:
+        raise RuntimeError("rtg_slam_amd.map_optim: fused Adam needs HIP device tensors; this build has no CPU path.")
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(p.device).cuda_stream
+    with torch.cuda.device(p.device):
+        rc = lib.rtgs_fused_adam(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+                                 C.c_void_p(v.data_ptr()), C.c_void_p(lr_col.data_ptr()), p.shape[0], p.shape[1],
+                                 int(step), 0.9, 0.999, float(eps), C.c_void_p(stream))
+    _lib.check(rc, "rtgs_fused_adam")
+
+
+class ShardedMapOptimizer:
+    def __init__(self, packed: torch.Tensor, lr_col: Optional[torch.Tensor] = None, eps: float = 1e-15,
+                 group=None, adam_fn: Optional[Callable] = None):
+        """`adam_fn(p, g, m, v, lr_col, step, eps)` defaults to the HIP fused Adam (device tensors only -
+        there is no CPU path in the product); the gloo tests inject a torch restatement."""
+        self.group = group
+        self.adam_fn = adam_fn if adam_fn is not None else _adam_hip
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.N = int(packed.shape[0])
+        self.per, self.Npad = shard_rows(self.N, self.world)
+        dev = packed.device
+        self.packed = torch.zeros(self.Npad, COLS, dtype=torch.float32, device=dev)
+        self.packed[:self.N] = packed
+        self.lr_col = (default_lr_columns() if lr_col is None else lr_col).to(dev).float().contiguous()
+        self.eps = eps
+        self.m = torch.zeros(self.per, COLS, dtype=torch.float32, device=dev)      # sharded state
+        self.v = torch.zeros(self.per, COLS, dtype=torch.float32, device=dev)
+        self.grad_full = torch.zeros(self.Npad, COLS, dtype=torch.float32, device=dev)
+        self.grad_shard = torch.zeros(self.per, COLS, dtype=torch.float32, device=dev)
+        self.step_count = 0
+
+    @property
+    def params(self) -> torch.Tensor:
+        return self.packed[:self.N]
+
+    def my_rows(self) -> slice:
+        return slice(self.rank * self.per, (self.rank + 1) * self.per)
+
+    def step(self, loss_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor]) -> torch.Tensor:
+        """loss_fn(gaussian_data) -> scalar loss of THIS rank's view.  Gradients are summed over
+        ranks (the sum of per-view losses is what a single GPU looping over the views optimises)."""
+        leaf = self.packed[:self.N].detach().requires_grad_(True)
+        loss = loss_fn(activate(leaf))
+        (g,) = torch.autograd.grad(loss, leaf)
+        self.grad_full[:self.N] = g
+        if self.world > 1 and self.backend == "gloo":
+            # gloo (CPU tests) has no reduce-scatter: all-reduce and take the local rows
+            dist.all_reduce(self.grad_full, op=dist.ReduceOp.SUM, group=self.group)
+            gs = self.grad_full[self.my_rows()].contiguous()
+        elif self.world > 1:
+            dist.reduce_scatter_tensor(self.grad_shard, self.grad_full, op=dist.ReduceOp.SUM, group=self.group)
+            gs = self.grad_shard
+        else:
+            gs = self.grad_full
+        self.step_count += 1
+        shard = self.packed[self.my_rows()]
+        self.adam_fn(shard, gs, self.m, self.v, self.lr_col, self.step_count, self.eps)
+        if self.world > 1 and self.backend == "gloo":
+            parts = [torch.empty_like(shard) for _ in range(self.world)]
+            dist.all_gather(parts, shard.clone(), group=self.group)
+            self.packed.copy_(torch.cat(parts, dim=0))
+        elif self.world > 1:
+            dist.all_gather_into_tensor(self.packed, shard.clone(), group=self.group)
+        return loss.detach()
+
+
+def slam_losses(render: Dict[str, torch.Tensor], gt_color: torch.Tensor, gt_depth: torch.Tensor,
+                color_weight: float = 0.8, depth_weight: float = 1.0) -> torch.Tensor:
+    """Sync-free restatement of the live losses of mapper.py:402-442 (L1 colour over the render
+    mask, masked L1 depth); `render` = (color[3,H,W], depth[1,H,W], ..., depth_index[1,H,W])."""
+    color, depth, didx = render[0], render[1], render[3]
+    color_loss = (color - gt_color).abs().mean()
+    m = ((didx != -1) & (gt_depth > 0)).to(depth.dtype)
+    depth_loss = ((depth - gt_depth).abs() * m).sum() / m.sum().clamp_min(1.0)
+    return color_weight * color_loss + depth_weight * depth_loss

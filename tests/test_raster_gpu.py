@@ -93,9 +93,10 @@ def test_empty_and_all_masked():
 
 
 def test_behind_camera_and_stacked_opaque():
-    """Two stacked alpha=0.99 discs: after the first T = 1-0.99f; the second would give
-    T' ~ 9.99998e-5 < 1e-4 in float32 and is NOT blended."""
-    cam = SMALL
+    """Two stacked alpha=0.99 discs seen exactly through their centres: after the first
+    T = 1-0.99f = 0.00999999; the second would give T' ~ 9.99998e-5 < 1e-4 in float32 and is NOT
+    blended (exact arithmetic says 1e-4, i.e. blended) - SURVEY.md Appendix B (iv)."""
+    cam = synth.CameraSpec(64, 96, 80.0, 80.0, 48.0, 32.0)
     g, s = ru.make_scene(3, cam, seed=6)
     g["xyz"] = torch.tensor([[0.0, 0.0, 1.0], [0.0, 0.0, 2.0], [0.0, 0.0, -1.0]])
     g["scales"] = torch.tensor([[0.2, 0.2, 0.02]] * 3)
@@ -107,8 +108,10 @@ def test_behind_camera_and_stacked_opaque():
     check_forward(out_h, out_o, max_bad=0.0)
     cy, cx = 32, 48
     assert int(out_h[2][0, cy, cx]) == 0 and int(out_h[3][0, cy, cx]) == 0
-    assert abs(float(out_h[1][0, cy, cx]) - 1.0) < 1e-3
-    assert abs(float(out_h[6][0, cy, cx]) - (1.0 - 0.99)) < 1e-3     # second disc not blended
+    assert abs(float(out_h[1][0, cy, cx]) - 1.0) < 1e-6
+    t_expect = float(torch.tensor(1.0) - torch.tensor(0.99))
+    assert float(out_h[6][0, cy, cx]) == t_expect == float(out_o[6][0, cy, cx])   # second disc not blended
+    assert float(out_h[4][0, cy, cx]) == float(torch.tensor(0.99))
     assert not bool((out_h[2] == 2).any())                            # behind the camera: culled
 
 
