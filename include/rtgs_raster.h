@@ -108,16 +108,17 @@ size_t rtgs_raster_geom_bytes(int32_t P);
 size_t rtgs_raster_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
 size_t rtgs_raster_image_bytes(int32_t image_height, int32_t image_width);
 
-/* Per-call statistics of the LAST forward on this thread (host values, for roofline
+/* Per-call statistics of the LAST forward in this process (host values, for roofline
  * accounting): [0] num_rendered, [1] sort bits used, [2] tiles, reserved... */
 int rtgs_raster_last_stats(int64_t* stats8_host);
 
 /* Device-side counters of work actually done by blend_fwd (instances consumed before the
  * per-tile early exit).  `counters` = device int64[2] zeroed by the caller, or NULL to
- * disable.  Sticky per thread until reset with NULL. */
+ * disable.  Process-wide, sticky until reset with NULL (measurement aid, not thread-safe). */
 void rtgs_raster_set_counters(void* counters);
 
-/* Optional per-stage HIP-event timing of the calls made on this thread (off by default).
+/* Optional per-stage HIP-event timing of the calls made by this process (off by default;
+ * measurement aid for single-threaded benches - autograd may run backward on another thread).
  * rtgs_raster_last_timings fills ms10_host[0..7] with the last forward/backward's stage
  * durations in milliseconds (-1 = stage did not run):
  *   [0] preprocess_fwd (+ mask SAT)  [1] scan  [2] emit_keys  [3] radix sort  [4] tile_ranges

@@ -22,15 +22,16 @@ void launch_preprocess_bwd(const RasterParams&, const float*, const float*, cons
                            const float*, const int32_t*, const uint8_t*, const SplatGrad*, float*, float*, float*,
                            float*, float*, float*, hipStream_t);
 
-static thread_local int64_t g_stats[8] = {0};
-static thread_local unsigned long long* g_counters = nullptr;
+// process-wide (autograd runs backward on its own thread): last-call stats, counters, profiling
+static int64_t g_stats[8] = {0};
+static unsigned long long* g_counters = nullptr;
 
 // optional per-stage HIP-event timing (bench.py's roofline leg); off by default
 enum { EV_F0 = 0, EV_PRE, EV_SCAN, EV_BIN0, EV_EMIT, EV_SORT, EV_RANGES, EV_BLEND, EV_B0, EV_BBLEND, EV_BPRE, EV_N };
-static thread_local bool g_prof = false;
-static thread_local bool g_ev_init = false;
-static thread_local hipEvent_t g_ev[EV_N];
-static thread_local bool g_ev_set[EV_N] = {false};
+static bool g_prof = false;
+static bool g_ev_init = false;
+static hipEvent_t g_ev[EV_N];
+static bool g_ev_set[EV_N] = {false};
 static void prof_mark(int which, hipStream_t st) {
   if (!g_prof) return;
   if (!g_ev_init) {
