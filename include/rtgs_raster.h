@@ -84,7 +84,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* settings, int32_t P, int32_t
                         int64_t* num_rendered_host, void* stream);
 
 /* Backward: consumes the three scratch buffers of the matching forward plus the forward's
- * out_T and out_depth_index.  Writes (never accumulates into) the gradient tensors:
+ * out_color, out_T and out_depth_index.  Writes (never accumulates into) the gradient tensors:
  *   dL_dmeans3D[P,3] dL_dopacities[P,1] dL_dshs[P,sh_coeffs,3] dL_dscales[P,3]
  *   dL_drotations[P,4] dL_dnormal_w[P,3]
  * Rows of Gaussians that touched no rendered pixel are exactly 0 (mapper.py:455 relies on it).
@@ -94,7 +94,7 @@ int rtgs_raster_backward(const rtgs_raster_settings* settings, int32_t P, int32_
                          const float* means3D, const float* opacities, const float* shs,
                          const float* scales, const float* rotations, const float* normal_w,
                          const void* geom_buffer, const void* binning_buffer,
-                         const void* image_buffer, const float* out_T,
+                         const void* image_buffer, const float* out_color, const float* out_T,
                          const int32_t* out_depth_index,
                          const float* dL_dcolor, const float* dL_ddepth,
                          float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,

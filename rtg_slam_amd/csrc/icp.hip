@@ -10,7 +10,7 @@
 
 namespace rtgs_icp {
 
-constexpr int MAX_BLOCKS = 1024;
+constexpr int MAX_BLOCKS = 256;     // one residual block per CU; the final kernel reads 8 x 32 partial rows
 constexpr int NACC = 28;            // 21 upper-triangular JtJ + 6 Jtr + 1 valid count
 constexpr int PSTRIDE = 32;         // floats per block partial
 
@@ -60,18 +60,16 @@ __global__ void __launch_bounds__(256) icp_vertex_kernel(PyrDesc d, const float*
     v[2] = dmax;                                           // 1 * depth
   }
   // min / max of the level's depth for the invalid mask of compute_normal_map
-  __shared__ uint32_t s_min, s_maxinv;
-  if (threadIdx.x == 0) { s_min = 0xffffffffu; s_maxinv = 0xffffffffu; }
-  __syncthreads();
-  if (live) {
-    const uint32_t e = enc_f(dmax);
-    atomicMin(&s_min, e);
-    atomicMin(&s_maxinv, ~e);
+  uint32_t emin = 0xffffffffu, emaxinv = 0xffffffffu;
+  if (live) { emin = enc_f(dmax); emaxinv = ~emin; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {          // wave64 min via shuffles (6 steps, once per wave)
+    emin = min(emin, (uint32_t)__shfl_xor((int)emin, off));
+    emaxinv = min(emaxinv, (uint32_t)__shfl_xor((int)emaxinv, off));
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicMin(&sc->minmax[2 * l], s_min);
-    atomicMin(&sc->minmax[2 * l + 1], s_maxinv);
+  if ((threadIdx.x & 63) == 0 && emin != 0xffffffffu) {
+    atomicMin(&sc->minmax[2 * l], emin);
+    atomicMin(&sc->minmax[2 * l + 1], emaxinv);
   }
 }
 
@@ -233,8 +231,15 @@ __global__ void __launch_bounds__(256) icp_final_kernel(const float* __restrict_
   __shared__ double s_sum[8 * PSTRIDE];
   const int grp = threadIdx.x >> 5, k = threadIdx.x & 31;
   double a = 0.0;
-  if (k < NACC)
-    for (int b = grp; b < nblocks; b += 8) a += (double)partials[(size_t)b * PSTRIDE + k];
+  if (k < NACC) {
+    int b = grp;
+    for (; b + 24 < nblocks; b += 32) {              // 4 independent loads in flight
+      const float p0 = partials[(size_t)b * PSTRIDE + k], p1 = partials[(size_t)(b + 8) * PSTRIDE + k];
+      const float p2 = partials[(size_t)(b + 16) * PSTRIDE + k], p3 = partials[(size_t)(b + 24) * PSTRIDE + k];
+      a += ((double)p0 + (double)p1) + ((double)p2 + (double)p3);
+    }
+    for (; b < nblocks; b += 8) a += (double)partials[(size_t)b * PSTRIDE + k];
+  }
   s_sum[grp * PSTRIDE + k] = a;
   __syncthreads();
   if (threadIdx.x != 0) return;

@@ -16,8 +16,8 @@ void launch_emit_keys(const RasterParams&, const Splat*, const int32_t*, const u
 void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
                       int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, hipStream_t);
-void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const uint32_t*,
-                      const int32_t*, const float*, const float*, SplatGrad*, hipStream_t);
+void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
+                      const uint32_t*, const int32_t*, const float*, const float*, SplatGrad*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, const uint8_t*, const SplatGrad*, float*, float*, float*,
                            float*, float*, float*, hipStream_t);
@@ -248,7 +248,8 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
 int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
                          const float* opacities, const float* shs, const float* scales, const float* rotations,
                          const float* normal_w, const void* geom_buffer, const void* binning_buffer,
-                         const void* image_buffer, const float* out_T, const int32_t* out_didx,
+                         const void* image_buffer, const float* out_color, const float* out_T,
+                         const int32_t* out_didx,
                          const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
                          float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
                          void* grad_scratch, void* stream) {
@@ -257,7 +258,7 @@ int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, in
   if (rc != RTGS_OK) return rc;
   if (P == 0) return RTGS_OK;
   if (!means3D || !opacities || !shs || !scales || !rotations || !normal_w || !geom_buffer || !binning_buffer ||
-      !image_buffer || !out_T || !out_didx || !dL_dcolor || !dL_ddepth || !dL_dmeans3D || !dL_dopacities || !dL_dshs ||
+      !image_buffer || !out_color || !out_T || !out_didx || !dL_dcolor || !dL_ddepth || !dL_dmeans3D || !dL_dopacities || !dL_dshs ||
       !dL_dscales || !dL_drotations || !dL_dnormal_w || !grad_scratch || R < 0)
     return RTGS_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -274,7 +275,7 @@ int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, in
   HIP_TRY(hipMemsetAsync(grads, 0, (size_t)P * sizeof(SplatGrad), st));
   if (R > 0) {
     launch_blend_bwd(p, (const uint2*)(img + I.ranges), (const uint32_t*)(bin + B.vals_b),
-                     (const Splat*)(geom + G.splats), out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
+                     (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
                      dL_dcolor, dL_ddepth, grads, st);
     DBG(s, st);
   }

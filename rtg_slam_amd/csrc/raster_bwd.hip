@@ -1,42 +1,70 @@
-// Backward kernels of the gfx950 rasterizer: per-tile back-to-front replay with wave64 DPP
-// reductions (one LDS atomic per wave per quantity, one global atomic per tile per quantity),
+// Backward kernels of the gfx950 rasterizer: per-tile front-to-back replay with wave64 DPP
+// butterfly reductions (one LDS add per wave per entry, one global atomic per tile per quantity),
 // and the per-Gaussian chain rule back to {means3D, opacities, shs, scales, rotations, normal_w}.
 // Math: SURVEY.md Appendix B "Backward"; checked against autograd of oracle/raster_oracle.py.
 #include "raster_common.h"
 
 namespace rtgs {
 
-// ---- wave64 sum via DPP (gfx9 row ops): result valid in lane 63 -------------------------------
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-  return v + __int_as_float(moved);
+// ---------------------------------------------------------------------------------------------
+// K7 blend_bwd: FRONT-TO-BACK replay.  Walking the tile list in the forward's own order makes
+// T bit-identical to the forward (no T/(1-alpha) reconstruction), lets a wave leave as soon as
+// its 64 pixels have passed their last contributor, and needs only the pixel's final colour:
+//   S_k      = C_total - sum_{m<=k} c_m a_m T_m                  (colour behind entry k)
+//   dL/da_k  = T_k (c_k . g) - (S_k . g) / (1 - a_k) - T_final (bg . g) / (1 - a_k)
+// Per entry the 9 per-Gaussian partials are reduced inside the wave with a 3-step multi-value
+// DPP butterfly (lanes end up holding one of 8 quantities, summed over their 8-lane group) and
+// land in an LDS accumulator with one ds_add_f32; the tile flushes one global atomic per
+// touched (Gaussian, quantity).
+// ---------------------------------------------------------------------------------------------
+constexpr int NG = 9;   // du dv dca dcb dcc dr dg db | dop
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v = dpp_add<0xB1>(v);          // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);          // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);         // row_half_mirror
-  v = dpp_add<0x140>(v);         // row_mirror  -> every lane of a row holds the row sum
-  v = dpp_add<0x142, 0xa>(v);    // row_bcast:15 into rows 1,3
-  v = dpp_add<0x143, 0xc>(v);    // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
+__device__ __forceinline__ float xor4(float v) {     // value of lane l^4 (within a row of 16)
+  float t = dpp_mov<0x104, 0xf, 0x5>(v, v);          // row_shl:4 into banks 0,2  (lane l <- l+4)
+  return dpp_mov<0x114, 0xf, 0xa>(t, v);             // row_shr:4 into banks 1,3  (lane l <- l-4)
+}
+
+// in: v[0..7] per lane.  out: lane l holds sum over its aligned 8-lane group of quantity
+// idx(l) = ((l&1)<<2) | (l&2) | ((l>>2)&1).
+__device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  float w[4], x[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float keep = b0 ? v[i + 4] : v[i];
+    const float send = b0 ? v[i] : v[i + 4];
+    w[i] = keep + dpp_mov<0xB1>(0.f, send);          // quad_perm [1,0,3,2]: lane l^1
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float keep = b1 ? w[i + 2] : w[i];
+    const float send = b1 ? w[i] : w[i + 2];
+    x[i] = keep + dpp_mov<0x4E>(0.f, send);          // quad_perm [2,3,0,1]: lane l^2
+  }
+  const float keep = b2 ? x[1] : x[0];
+  const float send = b2 ? x[0] : x[1];
+  return keep + xor4(send);
+}
+__device__ __forceinline__ float group8_sum(float v) {   // every lane: sum over its 8-lane group
+  v += dpp_mov<0xB1>(0.f, v);
+  v += dpp_mov<0x4E>(0.f, v);
+  v += xor4(v);
   return v;
 }
 
-// ---------------------------------------------------------------------------------------------
-// K7 blend_bwd
-// ---------------------------------------------------------------------------------------------
-constexpr int NG = 9;   // du dv dca dcb dcc dop dr dg db
-
 __global__ void __launch_bounds__(256) blend_bwd_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const Splat* __restrict__ splats, const float* __restrict__ final_T,
+    const Splat* __restrict__ splats, const float* __restrict__ out_color, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const int32_t* __restrict__ depth_index,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     SplatGrad* __restrict__ grads) {
   __shared__ float4 s_rec[BLOCK * 4];
   __shared__ int32_t s_id[BLOCK];
   __shared__ float s_grad[BLOCK * NG];
-  __shared__ unsigned int s_max;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -48,32 +76,29 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
   const uint2 range = ranges[tile];
   const size_t pix = (size_t)py * p.W + px;
   const size_t HW = (size_t)p.H * p.W;
+  const int n = (int)(range.y - range.x);
 
   const uint32_t last = inside ? n_contrib[pix] : 0u;
-  if (tid == 0) s_max = 0;
-  __syncthreads();
-  if (last) atomicMax(&s_max, last);
-  __syncthreads();
-  const int n = (int)s_max;           // entries [0, n) of the tile list were used by some pixel
-  if (n == 0 && !(inside && depth_index[pix] >= 0)) {
-    // nothing blended in this tile (depth owners imply n > 0, test kept for clarity)
-  }
-
   const float T_final = inside ? final_T[pix] : 0.f;
-  float T = T_final;
-  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-  if (inside) { g0 = dL_dcolor[pix]; g1 = dL_dcolor[HW + pix]; g2 = dL_dcolor[2 * HW + pix]; }
-  const float bg_dot = p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;     // colour accumulated behind the current entry
-  float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f, S0 = 0.f, S1 = 0.f, S2 = 0.f;
+  if (inside) {
+    g0 = dL_dcolor[pix]; g1 = dL_dcolor[HW + pix]; g2 = dL_dcolor[2 * HW + pix];
+    // colour behind the (not yet started) walk = everything the pixel accumulated, without background
+    S0 = out_color[pix] - T_final * p.bg[0];
+    S1 = out_color[HW + pix] - T_final * p.bg[1];
+    S2 = out_color[2 * HW + pix] - T_final * p.bg[2];
+  }
+  const float bgT = T_final * (p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2);
+  float T = 1.f;
+  uint32_t pos = 0;                       // list position of the next entry
+  bool done = last == 0;
+  const int gidx = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
 
-  // walk entries n-1 .. 0 in batches; batch b covers list positions [hi - m, hi)
-  for (int hi = n; hi > 0; hi -= BLOCK) {
-    const int m = min(BLOCK, hi);
-    const int lo = hi - m;
-    __syncthreads();
+  for (int base = 0; base < n; base += BLOCK) {
+    if (__syncthreads_and(done)) break;
+    const int m = min(BLOCK, n - base);
     if (tid < m) {
-      const uint32_t id = point_list[range.x + lo + tid];
+      const uint32_t id = point_list[range.x + base + tid];
       s_id[tid] = (int32_t)id;
       const float4* src = reinterpret_cast<const float4*>(splats + id);
       s_rec[tid * 4 + 0] = src[0];
@@ -84,55 +109,52 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     for (int k = 0; k < NG; ++k) s_grad[tid * NG + k] = 0.f;
     __syncthreads();
 
-    for (int j = m - 1; j >= 0; --j) {
-      const uint32_t pos = (uint32_t)(lo + j);         // 0-based list position
-      float v[NG];
+    for (int j = 0; j < m; ++j) {
+      if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;     // whole wave past its last contributor
+      float v[8];
 #pragma unroll
-      for (int k = 0; k < NG; ++k) v[k] = 0.f;
-      bool valid = pos < last;
-      if (valid) {
+      for (int k = 0; k < 8; ++k) v[k] = 0.f;
+      float vop = 0.f;
+      bool valid = false;
+      if (!done) {
         const float4 r0 = s_rec[j * 4 + 0];
         const float4 r1 = s_rec[j * 4 + 1];
         const float dx = r0.x - pxf, dy = r0.y - pyf;
         const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
-        valid = !(power > 0.f);
-        if (valid) {
-          const float G = expf(power);
+        if (!(power > 0.f)) {
+          const float G = splat_exp(power);
           const float oG = r1.y * G;
           const float alpha = fminf(0.99f, oG);
-          valid = !(alpha < 1.f / 255.f);
-          if (valid) {
+          if (!(alpha < 1.f / 255.f)) {
+            valid = true;
             const float4 r2 = s_rec[j * 4 + 2];
-            T = T / (1.f - alpha);
-            const float w = alpha * T;
             const float c0 = r1.z, c1 = r1.w, c2 = r2.x;
-            acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-            acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-            acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-            lc0 = c0; lc1 = c1; lc2 = c2; last_alpha = alpha;
-            float dL_dalpha = ((c0 - acc0) * g0 + (c1 - acc1) * g1 + (c2 - acc2) * g2) * T;
-            dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-            v[6] = w * g0; v[7] = w * g1; v[8] = w * g2;
-            if (oG <= 0.99f) {                    // d min(0.99, oG)/d(oG): autograd of clamp
-              const float dL_dG = r1.y * dL_dalpha;
-              v[5] = G * dL_dalpha;
-              const float gdl = G * dL_dG;
+            const float w = alpha * T;
+            S0 -= c0 * w; S1 -= c1 * w; S2 -= c2 * w;            // colour strictly behind this entry
+            const float ia = 1.f / (1.f - alpha);
+            const float dL_dalpha = T * (c0 * g0 + c1 * g1 + c2 * g2) - (S0 * g0 + S1 * g1 + S2 * g2 + bgT) * ia;
+            v[5] = w * g0; v[6] = w * g1; v[7] = w * g2;
+            if (oG <= 0.99f) {                                   // d min(0.99, oG)/d(oG): autograd of clamp
+              vop = G * dL_dalpha;
+              const float gdl = G * r1.y * dL_dalpha;
               v[0] = gdl * (-r0.z * dx - r0.w * dy);
               v[1] = gdl * (-r1.x * dy - r0.w * dx);
               v[2] = gdl * (-0.5f * dx * dx);
               v[3] = gdl * (-dx * dy);
               v[4] = gdl * (-0.5f * dy * dy);
             }
+            T *= (1.f - alpha);
           }
         }
+        ++pos;
+        if (pos >= last) done = true;
       }
-      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;   // wave-uniform
-#pragma unroll
-      for (int k = 0; k < NG; ++k) v[k] = wave_sum_to_lane63(v[k]);
-      if (lane == 63) {
-#pragma unroll
-        for (int k = 0; k < NG; ++k) atomicAdd(&s_grad[j * NG + k], v[k]);
-      }
+      const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+      if (vm == 0ull) continue;                                   // wave-uniform
+      const float r8 = butterfly8(v, lane);
+      const float ro = group8_sum(vop);
+      atomicAdd(&s_grad[j * NG + gidx], r8);                      // 8 groups -> 8-way same-address add
+      if ((lane & 7) == 0) atomicAdd(&s_grad[j * NG + 8], ro);
     }
     __syncthreads();
     if (tid < m) {
@@ -142,9 +164,16 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
       for (int k = 0; k < NG; ++k) { t[k] = s_grad[tid * NG + k]; any |= (t[k] != 0.f); }
       if (any) {
         float* dst = reinterpret_cast<float*>(grads + s_id[tid]);
-#pragma unroll
-        for (int k = 0; k < NG; ++k)
-          if (t[k] != 0.f) unsafeAtomicAdd(dst + k, t[k]);
+        // SplatGrad order: du dv dca dcb dcc dop dr dg db
+        if (t[0] != 0.f) unsafeAtomicAdd(dst + 0, t[0]);
+        if (t[1] != 0.f) unsafeAtomicAdd(dst + 1, t[1]);
+        if (t[2] != 0.f) unsafeAtomicAdd(dst + 2, t[2]);
+        if (t[3] != 0.f) unsafeAtomicAdd(dst + 3, t[3]);
+        if (t[4] != 0.f) unsafeAtomicAdd(dst + 4, t[4]);
+        if (t[8] != 0.f) unsafeAtomicAdd(dst + 5, t[8]);
+        if (t[5] != 0.f) unsafeAtomicAdd(dst + 6, t[5]);
+        if (t[6] != 0.f) unsafeAtomicAdd(dst + 7, t[6]);
+        if (t[7] != 0.f) unsafeAtomicAdd(dst + 8, t[7]);
       }
     }
   }
@@ -367,10 +396,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 }
 
 void launch_blend_bwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
-                      const float* final_T, const uint32_t* n_contrib, const int32_t* depth_index,
-                      const float* dL_dcolor, const float* dL_ddepth, SplatGrad* grads, hipStream_t st) {
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, final_T,
-                     n_contrib, depth_index, dL_dcolor, dL_ddepth, grads);
+                      const float* out_color, const float* final_T, const uint32_t* n_contrib,
+                      const int32_t* depth_index, const float* dL_dcolor, const float* dL_ddepth, SplatGrad* grads,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
+                     final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, grads);
 }
 void launch_preprocess_bwd(const RasterParams& p, const float* means, const float* opac, const float* shs,
                            const float* scales, const float* rots, const float* normal_w, const int32_t* radii,

@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
       if (power > 0.f) continue;
-      const float alpha = fminf(0.99f, r1.y * expf(power));
+      const float alpha = fminf(0.99f, r1.y * splat_exp(power));
       if (alpha < 1.f / 255.f) continue;
       const float test_T = T * (1.f - alpha);
       if (test_T < p.T_thr) { done = true; continue; }

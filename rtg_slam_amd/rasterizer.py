@@ -127,14 +127,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = int(R.value)
         ctx.M = M
         ctx.save_for_backward(means3D, opacities, shs, scales, rotations, normal_w, geom.tensor, binning.tensor,
-                              img.tensor, Tm, didx)
+                              img.tensor, color, Tm, didx)
         ctx.mark_non_differentiable(cidx, didx, cw, dw, Tm)
         return color, depth, cidx, didx, cw, dw, Tm
 
     @staticmethod
     def backward(ctx, g_color, g_depth, *_unused):
         lib = _lib.load()
-        (means3D, opacities, shs, scales, rotations, normal_w, geom, binning, img, Tm, didx) = ctx.saved_tensors
+        (means3D, opacities, shs, scales, rotations, normal_w, geom, binning, img, color, Tm, didx) = ctx.saved_tensors
         rs = ctx.raster_settings
         dev = means3D.device
         P = int(means3D.shape[0])
@@ -155,8 +155,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             with torch.cuda.device(dev):
                 rc = lib.rtgs_raster_backward(
                     C.byref(keep.c), P, ctx.M, ctx.num_rendered, _ptr(means3D), _ptr(opacities), _ptr(shs),
-                    _ptr(scales), _ptr(rotations), _ptr(normal_w), _ptr(geom), _ptr(binning), _ptr(img), _ptr(Tm),
-                    _ptr(didx), _ptr(g_color), _ptr(g_depth), _ptr(d_means), _ptr(d_opac), _ptr(d_shs),
+                    _ptr(scales), _ptr(rotations), _ptr(normal_w), _ptr(geom), _ptr(binning), _ptr(img), _ptr(color),
+                    _ptr(Tm), _ptr(didx), _ptr(g_color), _ptr(g_depth), _ptr(d_means), _ptr(d_opac), _ptr(d_shs),
                     _ptr(d_scales), _ptr(d_rots), _ptr(d_normal), _ptr(scratch), C.c_void_p(stream))
             _lib.check(rc, "rtgs_raster_backward")
         return d_means, d_opac, d_shs, d_scales, d_rots, d_normal, None, None
