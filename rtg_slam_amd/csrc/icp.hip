@@ -244,19 +244,28 @@ __global__ void __launch_bounds__(256) icp_final_kernel(const float* __restrict_
   __syncthreads();
   if (threadIdx.x != 0) return;
   double S[NACC];
+#pragma unroll
   for (int c = 0; c < NACC; ++c) {
     double t = 0.0;
+#pragma unroll
     for (int g = 0; g < 8; ++g) t += s_sum[g * PSTRIDE + c];
     S[c] = t;
   }
   if (mode == MODE_P2P) { stats[1] = (float)(S[0] * (double)inv_pixels); return; }
   double Hm[6][6], bvec[6];
-  int idx = 0;
+#pragma unroll
   for (int r = 0; r < 6; ++r)
-    for (int c = r; c < 6; ++c) { Hm[r][c] = S[idx]; Hm[c][r] = S[idx]; ++idx; }
+#pragma unroll
+    for (int c = r; c < 6; ++c) {
+      const int idx = r * 6 - (r * (r - 1)) / 2 + (c - r);     // position in the packed upper triangle
+      Hm[r][c] = S[idx]; Hm[c][r] = S[idx];
+    }
+#pragma unroll
   for (int r = 0; r < 6; ++r) bvec[r] = S[21 + r];
   if (mode == MODE_EQUATIONS) {
+#pragma unroll
     for (int r = 0; r < 6; ++r) {
+#pragma unroll
       for (int c = 0; c < 6; ++c) JtJ_out[r * 6 + c] = (float)Hm[r][c];
       Jtr_out[r] = (float)bvec[r];
     }
@@ -266,60 +275,94 @@ __global__ void __launch_bounds__(256) icp_final_kernel(const float* __restrict_
   stats[0] = (float)(S[27] * (double)inv_pixels);            // valid_ratio (icp.py:46-47)
   // lev_mar_H (icp.py:248-256): H += trace(H) * damping * I
   double tr = 0.0;
+#pragma unroll
   for (int r = 0; r < 6; ++r) tr += Hm[r][r];
+#pragma unroll
   for (int r = 0; r < 6; ++r) Hm[r][r] += tr * (double)damping;
-  // Cholesky H = L L^T
+  // Cholesky H = L L^T, fully unrolled so every array stays in registers (no scratch)
   double L[6][6];
   bool spd = true;
-  for (int r = 0; r < 6 && spd; ++r)
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
     for (int c = 0; c <= r; ++c) {
       double s = Hm[r][c];
+#pragma unroll
       for (int m = 0; m < c; ++m) s -= L[r][m] * L[c][m];
       if (r == c) {
-        if (!(s > 0.0)) { spd = false; break; }
-        L[r][r] = sqrt(s);
+        spd = spd && (s > 0.0);
+        L[r][r] = sqrt(s > 0.0 ? s : 1.0);
       } else {
         L[r][c] = s / L[c][c];
       }
     }
+  }
   if (!spd) { stats[2] += 1.f; return; }
   double yv[6], xi[6];
+#pragma unroll
   for (int r = 0; r < 6; ++r) {
     double s = -bvec[r];                                     // xi = -H^-1 Jtr (icp.py:328-334)
+#pragma unroll
     for (int m = 0; m < r; ++m) s -= L[r][m] * yv[m];
     yv[r] = s / L[r][r];
   }
+#pragma unroll
   for (int r = 5; r >= 0; --r) {
     double s = yv[r];
+#pragma unroll
     for (int m = r + 1; m < 6; ++m) s -= L[m][r] * xi[m];
     xi[r] = s / L[r][r];
   }
-  // exp_se3 (icp.py:271-310): Rodrigues + left Jacobian, eps 1e-8
+  // exp_se3 (icp.py:271-310): Rodrigues + left Jacobian.  The three coefficients sin(t)/t,
+  // (1-cos t)/t^2, (t-sin t)/t^3 are evaluated by their Maclaurin series in double (|xi_w| of an
+  // ICP step is far below 1; 10 terms are exact to double rounding for t < 1 and the identity
+  // limit of the reference's eps test falls out), libm sin/cos only beyond that.
   const double w0 = xi[0], w1 = xi[1], w2 = xi[2];
-  const double Wh[3][3] = {{0.0, -w2, w1}, {w2, 0.0, -w0}, {-w1, w0, 0.0}};
-  double W2[3][3];
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) W2[r][c] = Wh[r][0] * Wh[0][c] + Wh[r][1] * Wh[1][c] + Wh[r][2] * Wh[2][c];
-  const double th = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
-  double E[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
-  double Jl[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  if (th > 1e-8) {
-    const double th2 = th * th, th3 = th2 * th, sn = sin(th), cs = cos(th);
-    const double ka = sn / th, kb = (1.0 - cs) / th2, kc = (th - sn) / th3;
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) {
-        E[r][c] += ka * Wh[r][c] + kb * W2[r][c];
-        Jl[r][c] += kb * Wh[r][c] + kc * W2[r][c];
-      }
+  const double t2 = w0 * w0 + w1 * w1 + w2 * w2;
+  double ka, kb, kc;
+  if (t2 < 1.0) {
+    ka = 1.0; kb = 0.5; kc = 1.0 / 6.0;
+    double ta = 1.0, tb = 0.5, tc = 1.0 / 6.0;
+#pragma unroll
+    for (int n = 1; n <= 10; ++n) {
+      ta *= -t2 / (double)((2 * n) * (2 * n + 1));
+      tb *= -t2 / (double)((2 * n + 1) * (2 * n + 2));
+      tc *= -t2 / (double)((2 * n + 2) * (2 * n + 3));
+      ka += ta; kb += tb; kc += tc;
+    }
+  } else {
+    const float th = sqrtf((float)t2);
+    ka = (double)(sinf(th) / th);
+    kb = (double)((1.f - cosf(th)) / (th * th));
+    kc = (double)((th - sinf(th)) / (th * th * th));
   }
+  // W = [w]x, W2 = W W
+  const double W2_00 = -(w1 * w1 + w2 * w2), W2_11 = -(w0 * w0 + w2 * w2), W2_22 = -(w0 * w0 + w1 * w1);
+  const double W2_01 = w0 * w1, W2_02 = w0 * w2, W2_12 = w1 * w2;
+  double E[3][4];
+  double Jl[3][3];
+  E[0][0] = 1.0 + kb * W2_00; E[0][1] = -ka * w2 + kb * W2_01; E[0][2] = ka * w1 + kb * W2_02;
+  E[1][0] = ka * w2 + kb * W2_01; E[1][1] = 1.0 + kb * W2_11; E[1][2] = -ka * w0 + kb * W2_12;
+  E[2][0] = -ka * w1 + kb * W2_02; E[2][1] = ka * w0 + kb * W2_12; E[2][2] = 1.0 + kb * W2_22;
+  Jl[0][0] = 1.0 + kc * W2_00; Jl[0][1] = -kb * w2 + kc * W2_01; Jl[0][2] = kb * w1 + kc * W2_02;
+  Jl[1][0] = kb * w2 + kc * W2_01; Jl[1][1] = 1.0 + kc * W2_11; Jl[1][2] = -kb * w0 + kc * W2_12;
+  Jl[2][0] = -kb * w1 + kc * W2_02; Jl[2][1] = kb * w0 + kc * W2_12; Jl[2][2] = 1.0 + kc * W2_22;
+#pragma unroll
   for (int r = 0; r < 3; ++r) E[r][3] = Jl[r][0] * xi[3] + Jl[r][1] * xi[4] + Jl[r][2] * xi[5];
-  double Pm[4][4], Out[4][4];
-  for (int r = 0; r < 4; ++r)
+  double Pm[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
     for (int c = 0; c < 4; ++c) Pm[r][c] = (double)pose[r * 4 + c];
-  for (int r = 0; r < 4; ++r)
-    for (int c = 0; c < 4; ++c) Out[r][c] = E[r][0] * Pm[0][c] + E[r][1] * Pm[1][c] + E[r][2] * Pm[2][c] + E[r][3] * Pm[3][c];
-  for (int r = 0; r < 4; ++r)
-    for (int c = 0; c < 4; ++c) pose[r * 4 + c] = (float)Out[r][c];
+  // pose <- exp(xi) @ pose (bottom row stays 0 0 0 1)
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double o = E[r][0] * Pm[0][c] + E[r][1] * Pm[1][c] + E[r][2] * Pm[2][c];
+      if (c == 3) o += E[r][3];
+      pose[r * 4 + c] = (float)o;
+    }
 }
 
 // ---- model-depth hole filling (icp.py:397-415) ------------------------------------------------

@@ -49,6 +49,15 @@ __device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
   const float send = b2 ? x[0] : x[1];
   return keep + xor4(send);
 }
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_mov<0xB1>(0.f, v);               // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(0.f, v);               // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(0.f, v);              // row_half_mirror
+  v += dpp_mov<0x140>(0.f, v);              // row_mirror: every lane of a row holds the row sum
+  v += dpp_mov<0x142, 0xa>(0.f, v);         // row_bcast:15 into rows 1,3
+  v += dpp_mov<0x143, 0xc>(0.f, v);         // row_bcast:31 into rows 2,3: lane 63 = wave sum
+  return v;
+}
 __device__ __forceinline__ float group8_sum(float v) {   // every lane: sum over its 8-lane group
   v += dpp_mov<0xB1>(0.f, v);
   v += dpp_mov<0x4E>(0.f, v);
@@ -178,25 +187,42 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     }
   }
 
-  // opaque-surface depth: D = pd / (n_c . r) for the owner only
+  // opaque-surface depth: D = pd / (n_c . r), owner only.  Neighbouring pixels share owners (one
+  // opaque disc owns hundreds of pixels), so lanes are grouped by owner and each group issues ONE
+  // set of 4 atomics instead of one per pixel (same-address atomics serialise at ~12 ns each).
+  int owner = -1;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (inside) {
-    const int owner = depth_index[pix];
+    owner = depth_index[pix];
+    const float gD = owner >= 0 ? dL_ddepth[pix] : 0.f;
+    if (gD == 0.f) owner = -1;
     if (owner >= 0) {
-      const float gD = dL_ddepth[pix];
-      if (gD != 0.f) {
-        const Splat* s = splats + owner;
-        const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
-        const float den = s->nx * rx + s->ny * ry + s->nz;
-        const float iden = 1.f / den;
-        const float zhit = s->pd * iden;
-        const float k = -gD * zhit * iden;
-        float* dst = reinterpret_cast<float*>(grads + owner);
-        unsafeAtomicAdd(dst + 9, k * rx);
-        unsafeAtomicAdd(dst + 10, k * ry);
-        unsafeAtomicAdd(dst + 11, k);
-        unsafeAtomicAdd(dst + 12, gD * iden);
-      }
+      const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
+      const float pd = reinterpret_cast<const float*>(splats + owner)[12];
+      const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
+      const float den = r2.y * rx + r2.z * ry + r2.w;
+      const float iden = 1.f / den;
+      const float k = -gD * (pd * iden) * iden;
+      a0 = k * rx; a1 = k * ry; a2 = k; a3 = gD * iden;
     }
+  }
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(owner >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int o = __builtin_amdgcn_readlane(owner, leader);
+    const bool mine = owner == o;
+    const float s0 = wave_sum_to_lane63(mine ? a0 : 0.f);
+    const float s1 = wave_sum_to_lane63(mine ? a1 : 0.f);
+    const float s2 = wave_sum_to_lane63(mine ? a2 : 0.f);
+    const float s3 = wave_sum_to_lane63(mine ? a3 : 0.f);
+    if (lane == 63) {
+      float* dst = reinterpret_cast<float*>(grads + o);
+      unsafeAtomicAdd(dst + 9, s0);
+      unsafeAtomicAdd(dst + 10, s1);
+      unsafeAtomicAdd(dst + 11, s2);
+      unsafeAtomicAdd(dst + 12, s3);
+    }
+    todo &= ~__builtin_amdgcn_ballot_w64(mine);
   }
 }
 
