@@ -160,16 +160,16 @@ def main():
             icp_ms += e0.elapsed_time(e1)
         lib.rtgs_raster_set_profiling(0)
         stage = [a / nprof for a in acc]
-        names = ["preprocess_fwd", "scan", "emit_keys", "radix_sort", "tile_ranges", "blend_fwd", "blend_bwd",
-                 "preprocess_bwd"]
+        names = ["preprocess_fwd", "bin_count", "bin_scatter", "bin_tilesort", "tile_ranges_fallback_only",
+                 "blend_fwd", "blend_bwd", "preprocess_bwd"]
         Px = cam.H * cam.W
         Nv = N   # upper bound; culled rows write nothing
         # algorithmic bytes per launch (I := instances the tile walk consumes)
         alg = {
             "preprocess_fwd": 248 * N + 64 * Nv,
-            "emit_keys": 12 * R + 16 * N,
-            "radix_sort": 24 * R,
-            "tile_ranges": 8 * R,
+            "bin_count": 68 * N,
+            "bin_scatter": 68 * N + 8 * R,
+            "bin_tilesort": 12 * R,
             "blend_fwd": 68 * consumed + 40 * Px,
             "blend_bwd": 68 * consumed + 28 * Px + 36 * consumed,
             "preprocess_bwd": 248 * N + 64 * N + 236 * N,

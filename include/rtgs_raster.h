@@ -109,7 +109,8 @@ size_t rtgs_raster_binning_bytes(int64_t num_rendered, int32_t image_height, int
 size_t rtgs_raster_image_bytes(int32_t image_height, int32_t image_width);
 
 /* Per-call statistics of the LAST forward in this process (host values, for roofline
- * accounting): [0] num_rendered, [1] sort bits used, [2] tiles, reserved... */
+ * accounting): [0] num_rendered, [1] sort bits (fallback path), [2] tiles, [3..5] scratch bytes,
+ * [6] 1 = LDS tile-sort binning / 0 = global radix-sort fallback, [7] longest tile list. */
 int rtgs_raster_last_stats(int64_t* stats8_host);
 
 /* Device-side counters of work actually done by blend_fwd (instances consumed before the
@@ -121,9 +122,13 @@ void rtgs_raster_set_counters(void* counters);
  * measurement aid for single-threaded benches - autograd may run backward on another thread).
  * rtgs_raster_last_timings fills ms10_host[0..7] with the last forward/backward's stage
  * durations in milliseconds (-1 = stage did not run):
- *   [0] preprocess_fwd (+ mask SAT)  [1] scan  [2] emit_keys  [3] radix sort  [4] tile_ranges
+ *   [0] preprocess_fwd (+ mask SAT)  [1] bin_count + tilescan (fallback: scan)  [2] bin_scatter
+ *   (fallback: emit_keys)  [3] bin_tilesort (fallback: radix sort)  [4] tile_ranges (fallback only)
  *   [5] blend_fwd  [6] grad memset + blend_bwd  [7] preprocess_bwd */
 void rtgs_raster_set_profiling(int enable);
+/* Testing aid: force the fallback binning path (global 64-bit radix sort, rocPRIM) that is
+ * otherwise taken only when the tile grid or one tile list exceeds the LDS-resident path. */
+void rtgs_raster_force_sort_path(int enable);
 int rtgs_raster_last_timings(float* ms10_host);
 
 /* Fused Adam over a packed [rows, cols] float32 parameter shard with one learning rate per

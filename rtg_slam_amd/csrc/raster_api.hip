@@ -23,12 +23,21 @@ void launch_preprocess_bwd(const RasterParams&, const float*, const float*, cons
                            float*, float*, float*, hipStream_t);
 
 // process-wide (autograd runs backward on its own thread): last-call stats, counters, profiling
+size_t bin_lds_limit_tiles();
+int bin_sort_capacity();
+int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, hipStream_t);
+void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, hipStream_t);
+void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*,
+                        unsigned long long*, hipStream_t);
+void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*, uint32_t*, hipStream_t);
+
 static int64_t g_stats[8] = {0};
 static unsigned long long* g_counters = nullptr;
 
 // optional per-stage HIP-event timing (bench.py's roofline leg); off by default
 enum { EV_F0 = 0, EV_PRE, EV_SCAN, EV_BIN0, EV_EMIT, EV_SORT, EV_RANGES, EV_BLEND, EV_B0, EV_BBLEND, EV_BPRE, EV_N };
 static bool g_prof = false;
+static bool g_force_sort_path = false;   // testing aid: take the global radix-sort binning path
 static bool g_ev_init = false;
 static hipEvent_t g_ev[EV_N];
 static bool g_ev_set[EV_N] = {false};
@@ -58,6 +67,9 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy) {
   L.radii = off; off = align_up(off + Pn * sizeof(int32_t));
   L.clamped = off; off = align_up(off + Pn);
   L.sat = off; off = align_up(off + (size_t)(gx + 1) * (gy + 1) * sizeof(int32_t));
+  L.tile_count = off; off = align_up(off + (size_t)gx * gy * sizeof(uint32_t));
+  L.cursor = off; off = align_up(off + (size_t)gx * gy * sizeof(uint32_t));
+  L.info = off; off = align_up(off + 4 * sizeof(uint32_t));
   size_t tb = 0;
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)Pn);
   L.scan_temp_bytes = tb;
@@ -66,14 +78,15 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy) {
   return L;
 }
 
-static BinLayout bin_layout(int64_t R, int ntiles) {
+static BinLayout bin_layout(int64_t R, int ntiles, bool sort_path) {
   BinLayout L{};
   size_t off = 0;
   const size_t Rn = (size_t)(R > 0 ? R : 1);
-  L.keys_a = off; off = align_up(off + Rn * sizeof(uint64_t));
+  L.vals_b = off; off = align_up(off + Rn * sizeof(uint32_t));     // point_list: offset 0 in BOTH layouts
+  L.keys_a = off; off = align_up(off + Rn * sizeof(uint64_t));     // tile buckets / unsorted keys
+  if (!sort_path) { L.keys_b = L.vals_a = L.sort_temp = off; L.sort_temp_bytes = 0; L.total = off; return L; }
   L.keys_b = off; off = align_up(off + Rn * sizeof(uint64_t));
   L.vals_a = off; off = align_up(off + Rn * sizeof(uint32_t));
-  L.vals_b = off; off = align_up(off + Rn * sizeof(uint32_t));
   size_t tb = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                                      (uint32_t*)nullptr, (int)Rn, 0, 32 + bits_for((uint32_t)ntiles));
@@ -145,7 +158,7 @@ size_t rtgs_raster_geom_bytes(int32_t P) {
 }
 size_t rtgs_raster_binning_bytes(int64_t R, int32_t H, int32_t W) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  return bin_layout(R, gx * gy).total;
+  return bin_layout(R, gx * gy, true).total;
 }
 size_t rtgs_raster_image_bytes(int32_t H, int32_t W) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
@@ -194,6 +207,11 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   int64_t R = 0;
   for (int i = 0; i < EV_B0; ++i) g_ev_set[i] = false;
   prof_mark(EV_F0, st);
+  uint32_t* tile_count = (uint32_t*)(geom + G.tile_count);
+  uint32_t* cursor = (uint32_t*)(geom + G.cursor);
+  uint32_t* info = (uint32_t*)(geom + G.info);
+  uint32_t longest = 0;
+  bool sort_path = (size_t)ntiles > bin_lds_limit_tiles() || g_force_sort_path;
   if (P > 0) {
     launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
     DBG(s, st);
@@ -201,17 +219,32 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
                           clamped, out_radii, st);
     DBG(s, st);
     prof_mark(EV_PRE, st);
-    size_t tb = G.scan_temp_bytes;
-    HIP_TRY(hipcub::DeviceScan::InclusiveSum(geom + G.scan_temp, tb, tiles_touched, offsets, P, st));
-    uint32_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    prof_mark(EV_SCAN, st);
-    HIP_TRY(hipStreamSynchronize(st));   // the one host sync of the forward: sizes the instance arrays
-    R = (int64_t)total;
+    if (!sort_path) {
+      // exact per-tile counts -> ranges; the one host sync of the forward sizes the instance arrays
+      if (launch_bin_count(p, splats, radii, tile_mask, tile_count, st) != 0) return RTGS_E_HIP;
+      launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, st);
+      DBG(s, st);
+      uint32_t h[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(h, info, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      prof_mark(EV_SCAN, st);
+      HIP_TRY(hipStreamSynchronize(st));
+      R = (int64_t)h[0];
+      longest = h[1];
+      if ((int)longest > bin_sort_capacity()) sort_path = true;   // a tile list too long for the LDS sort
+    }
+    if (sort_path) {
+      size_t tb = G.scan_temp_bytes;
+      HIP_TRY(hipcub::DeviceScan::InclusiveSum(geom + G.scan_temp, tb, tiles_touched, offsets, P, st));
+      uint32_t total = 0;
+      HIP_TRY(hipMemcpyAsync(&total, offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      prof_mark(EV_SCAN, st);
+      HIP_TRY(hipStreamSynchronize(st));
+      R = (int64_t)total;
+    }
   }
   *num_rendered_host = R;
 
-  const BinLayout B = bin_layout(R, ntiles);
+  const BinLayout B = bin_layout(R, ntiles, sort_path);
   char* bin = (char*)binning_resize(binning_user, B.total);
   if (!bin) return RTGS_E_ALLOC;
   uint64_t* keys_a = (uint64_t*)(bin + B.keys_a);
@@ -219,9 +252,17 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   uint32_t* vals_a = (uint32_t*)(bin + B.vals_a);
   uint32_t* vals_b = (uint32_t*)(bin + B.vals_b);
 
-  HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), st));
   const int sort_bits = 32 + bits_for((uint32_t)ntiles);
-  if (R > 0) {
+  if (P == 0 || sort_path) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), st));
+  if (R > 0 && !sort_path) {
+    prof_mark(EV_BIN0, st);
+    launch_bin_scatter(p, splats, radii, tile_mask, cursor, (unsigned long long*)keys_a, st);
+    DBG(s, st);
+    prof_mark(EV_EMIT, st);
+    launch_bin_tilesort(ntiles, longest, ranges, (const unsigned long long*)keys_a, vals_b, st);
+    DBG(s, st);
+    prof_mark(EV_SORT, st);
+  } else if (R > 0) {
     prof_mark(EV_BIN0, st);
     launch_emit_keys(p, splats, radii, offsets, tile_mask, keys_a, vals_a, st);
     DBG(s, st);
@@ -242,6 +283,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   HIP_TRY(hipGetLastError());
   g_stats[0] = R; g_stats[1] = sort_bits; g_stats[2] = ntiles; g_stats[3] = (int64_t)G.total;
   g_stats[4] = (int64_t)B.total; g_stats[5] = (int64_t)I.total;
+  g_stats[6] = sort_path ? 0 : 1; g_stats[7] = (int64_t)longest;
   return RTGS_OK;
 }
 
@@ -264,7 +306,7 @@ int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, in
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = p.gx * p.gy;
   const GeomLayout G = geom_layout(P, p.gx, p.gy);
-  const BinLayout B = bin_layout(R, ntiles);
+  const BinLayout B = bin_layout(R, ntiles, false);   // point_list sits at offset 0 in both layouts
   const ImgLayout I = img_layout(p.H, p.W, ntiles);
   const char* geom = (const char*)geom_buffer;
   const char* bin = (const char*)binning_buffer;
@@ -290,6 +332,7 @@ int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, in
 }
 
 void rtgs_raster_set_profiling(int enable) { g_prof = enable != 0; }
+void rtgs_raster_force_sort_path(int enable) { g_force_sort_path = enable != 0; }
 
 int rtgs_raster_last_timings(float* ms) {
   if (!ms) return RTGS_E_INVALID;

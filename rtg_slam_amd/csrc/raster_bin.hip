@@ -1,0 +1,278 @@
+// Tile binning of the gfx950 rasterizer without a global sort.
+//
+//   bin_count    per-tile instance counts   (LDS-aggregated atomics, one global add per block x tile)
+//   bin_tilescan exclusive scan over tiles  -> ranges, cursors, total R, longest list
+//   bin_scatter  (depth bits << 32 | id) into the tile's bucket (LDS-aggregated slot reservation)
+//   bin_tilesort one workgroup per tile: in-LDS bitonic sort of the bucket by (depth, id)
+//                -> point_list (ids, front to back)
+//
+// Replaces the upstream design's duplicateWithKeys + 64-bit global radix sort + identifyTileRanges
+// (6+ passes over 12 B x instances) with one 8-B write, one 8-B read and one 4-B write per
+// instance.  The resulting per-tile order is (depth, Gaussian id) ascending - exactly the stable
+// order of the sort-based path and of oracle/raster_oracle.py::bin_tiles.
+//
+// Tiles of the 3-sigma rect that provably contain no pixel with
+// alpha >= 1/255 are dropped here: such an entry is skipped by every pixel of the tile in
+// blend_fwd, so removing it changes no output.  The test is the minimum of the conic form over
+// the tile's pixel-centre box against 2 ln(255 o), with a safety margin far above float rounding.
+#include "raster_common.h"
+
+namespace rtgs {
+
+constexpr int GPB = 2048;       // Gaussians per workgroup in bin_count / bin_scatter
+constexpr int BIG_RECT = 32;    // rects above this many tiles are enumerated by the whole wave
+
+struct BinG {
+  float u, v, ca, cb, cc, thr;  // thr = 2 ln(255 o) with margin; < 0 -> never visible
+  int x0, y0, x1, y1;
+  uint32_t zbits;
+};
+
+__device__ __forceinline__ void bin_rect(float u, float v, int radius, int gx, int gy, int& x0, int& y0, int& x1, int& y1) {
+  const float r = (float)radius;      // identical to tile_rect() of raster_fwd.hip
+  x0 = min(gx, max(0, (int)((u - r) / (float)TILE)));
+  y0 = min(gy, max(0, (int)((v - r) / (float)TILE)));
+  x1 = min(gx, max(0, (int)((u + r + (float)(TILE - 1)) / (float)TILE)));
+  y1 = min(gy, max(0, (int)((v + r + (float)(TILE - 1)) / (float)TILE)));
+}
+
+__device__ __forceinline__ bool load_bing(const RasterParams& p, const Splat* __restrict__ splats,
+                                          const int32_t* __restrict__ radii, int i, BinG& g) {
+  g.x0 = g.y0 = g.x1 = g.y1 = 0;
+  g.u = g.v = g.ca = g.cb = g.cc = 0.f; g.thr = -1.f; g.zbits = 0;
+  if (i >= p.P) return false;
+  const int radius = radii[i];
+  if (radius <= 0) return false;
+  const float4 r0 = reinterpret_cast<const float4*>(splats + i)[0];
+  const float4 r1 = reinterpret_cast<const float4*>(splats + i)[1];
+  g.u = r0.x; g.v = r0.y; g.ca = r0.z; g.cb = r0.w; g.cc = r1.x;
+  const float o = r1.y;
+  if (!(o >= 1.f / 255.f)) return false;            // alpha = min(.99, o G) <= o < 1/255 everywhere
+  g.zbits = __float_as_uint(reinterpret_cast<const float*>(splats + i)[13]);
+  const bool pd = (g.ca > 0.f) && (g.cc > 0.f) && (g.ca * g.cc - g.cb * g.cb > 0.f);
+  // q <= 2 ln(255 o) <=> alpha >= 1/255; margin: 1e-3 relative + 1e-2 absolute on q (float rounding
+  // of power in blend is ~1e-6 relative).  Non-PD conics (never seen; det guard) keep every tile.
+  g.thr = pd ? (2.f * __logf(255.f * o)) * 1.001f + 1e-2f : 3.0e38f;
+  bin_rect(g.u, g.v, radius, p.gx, p.gy, g.x0, g.y0, g.x1, g.y1);
+  return (g.x1 - g.x0) * (g.y1 - g.y0) > 0;
+}
+
+// min over the tile's pixel-centre box of q(d) = ca dx^2 + 2 cb dx dy + cc dy^2, d = centre - pixel
+__device__ __forceinline__ bool tile_visible(const BinG& g, int tx, int ty) {
+  const float dx0 = g.u - (float)(tx * TILE + TILE - 1), dx1 = g.u - (float)(tx * TILE);
+  const float dy0 = g.v - (float)(ty * TILE + TILE - 1), dy1 = g.v - (float)(ty * TILE);
+  if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
+  float qmin = 3.4e38f;
+  const float ica = 1.f / g.ca, icc = 1.f / g.cc;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {                      // edges dx = const
+    const float dx = e ? dx1 : dx0;
+    const float dy = fminf(dy1, fmaxf(dy0, -g.cb * dx * icc));
+    qmin = fminf(qmin, g.ca * dx * dx + 2.f * g.cb * dx * dy + g.cc * dy * dy);
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {                      // edges dy = const
+    const float dy = e ? dy1 : dy0;
+    const float dx = fminf(dx1, fmaxf(dx0, -g.cb * dy * ica));
+    qmin = fminf(qmin, g.ca * dx * dx + 2.f * g.cb * dx * dy + g.cc * dy * dy);
+  }
+  return qmin <= g.thr;
+}
+
+__device__ __forceinline__ BinG bcast(const BinG& g, int src) {
+  BinG o;
+  o.u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.u), src));
+  o.v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.v), src));
+  o.ca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.ca), src));
+  o.cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.cb), src));
+  o.cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.cc), src));
+  o.thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.thr), src));
+  o.x0 = __builtin_amdgcn_readlane(g.x0, src); o.y0 = __builtin_amdgcn_readlane(g.y0, src);
+  o.x1 = __builtin_amdgcn_readlane(g.x1, src); o.y1 = __builtin_amdgcn_readlane(g.y1, src);
+  o.zbits = (uint32_t)__builtin_amdgcn_readlane((int)g.zbits, src);
+  return o;
+}
+
+// Calls f(tile, gaussian_id, zbits) for every kept (Gaussian, tile) instance of this workgroup's
+// Gaussians.  Small rects: one lane per Gaussian; big rects: the wave enumerates them together.
+template <class F>
+__device__ __forceinline__ void enumerate_instances(const RasterParams& p, const Splat* __restrict__ splats,
+                                                    const int32_t* __restrict__ radii,
+                                                    const int32_t* __restrict__ mask, F f) {
+  const int lane = threadIdx.x & 63;
+  for (int k = 0; k < GPB / BLOCK; ++k) {
+    const int i = blockIdx.x * GPB + k * BLOCK + (int)threadIdx.x;
+    BinG g;
+    const bool live = load_bing(p, splats, radii, i, g);
+    const int w = g.x1 - g.x0, area = live ? w * (g.y1 - g.y0) : 0;
+    const bool big = area > BIG_RECT;
+    if (live && !big) {
+      for (int ty = g.y0; ty < g.y1; ++ty)
+        for (int tx = g.x0; tx < g.x1; ++tx) {
+          const int t = ty * p.gx + tx;
+          if (mask[t] != 0 && tile_visible(g, tx, ty)) f(t, (uint32_t)i, g.zbits);
+        }
+    }
+    unsigned long long bm = __builtin_amdgcn_ballot_w64(big);
+    while (bm) {
+      const int src = __ffsll((long long)bm) - 1;
+      bm &= bm - 1;
+      const BinG b = bcast(g, src);
+      const uint32_t id = (uint32_t)(i - lane + src);
+      const int bw = b.x1 - b.x0, barea = bw * (b.y1 - b.y0);
+      for (int e = lane; e < barea; e += 64) {
+        const int ry = e / bw, rx = e - ry * bw;
+        const int tx = b.x0 + rx, ty = b.y0 + ry;
+        const int t = ty * p.gx + tx;
+        if (mask[t] != 0 && tile_visible(b, tx, ty)) f(t, id, b.zbits);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) bin_count_kernel(RasterParams p, const Splat* __restrict__ splats,
+                                                        const int32_t* __restrict__ radii,
+                                                        const int32_t* __restrict__ mask,
+                                                        uint32_t* __restrict__ tile_count) {
+  extern __shared__ uint32_t s_cnt[];
+  const int ntiles = p.gx * p.gy;
+  for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
+  __syncthreads();
+  enumerate_instances(p, splats, radii, mask, [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntiles; t += BLOCK) {
+    const uint32_t c = s_cnt[t];
+    if (c) atomicAdd(&tile_count[t], c);
+  }
+}
+
+// one workgroup: ranges[t] = [start, end), cursor[t] = start, info = {R, longest list}
+__global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const uint32_t* __restrict__ tile_count,
+                                                            uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
+                                                            uint32_t* __restrict__ info) {
+  __shared__ uint32_t s_sum[1024];
+  __shared__ uint32_t s_max[1024];
+  const int tid = threadIdx.x;
+  const int per = (ntiles + 1023) / 1024;
+  const int lo = min(ntiles, tid * per), hi = min(ntiles, lo + per);
+  uint32_t sum = 0, mx = 0;
+  for (int t = lo; t < hi; ++t) { const uint32_t c = tile_count[t]; sum += c; mx = max(mx, c); }
+  s_sum[tid] = sum; s_max[tid] = mx;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan (10 steps, once per frame)
+    const uint32_t a = (tid >= off) ? s_sum[tid - off] : 0u;
+    const uint32_t m = (tid >= off) ? s_max[tid - off] : 0u;
+    __syncthreads();
+    s_sum[tid] += a; s_max[tid] = max(s_max[tid], m);
+    __syncthreads();
+  }
+  uint32_t start = s_sum[tid] - sum;
+  for (int t = lo; t < hi; ++t) {
+    const uint32_t c = tile_count[t];
+    ranges[t] = make_uint2(start, start + c);
+    cursor[t] = start;
+    start += c;
+  }
+  if (tid == 1023) { info[0] = s_sum[1023]; info[1] = s_max[1023]; }
+}
+
+__global__ void __launch_bounds__(256) bin_scatter_kernel(RasterParams p, const Splat* __restrict__ splats,
+                                                          const int32_t* __restrict__ radii,
+                                                          const int32_t* __restrict__ mask,
+                                                          uint32_t* __restrict__ cursor,
+                                                          unsigned long long* __restrict__ bucket) {
+  extern __shared__ uint32_t s_mem[];
+  const int ntiles = p.gx * p.gy;
+  uint32_t* s_cnt = s_mem;
+  uint32_t* s_base = s_mem + ntiles;
+  for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
+  __syncthreads();
+  enumerate_instances(p, splats, radii, mask, [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntiles; t += BLOCK) {
+    const uint32_t c = s_cnt[t];
+    if (c) { s_base[t] = atomicAdd(&cursor[t], c); s_cnt[t] = 0; }
+  }
+  __syncthreads();
+  enumerate_instances(p, splats, radii, mask, [&](int t, uint32_t id, uint32_t zbits) {
+    const uint32_t slot = s_base[t] + atomicAdd(&s_cnt[t], 1u);
+    bucket[slot] = ((unsigned long long)zbits << 32) | id;
+  });
+}
+
+// one workgroup per tile; keys (depth bits << 32 | id) are unique, so the order is total
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) bin_tilesort_kernel(const uint2* __restrict__ ranges,
+                                                               const unsigned long long* __restrict__ bucket,
+                                                               uint32_t* __restrict__ point_list) {
+  extern __shared__ unsigned long long s_key[];
+  const uint2 r = ranges[blockIdx.x];
+  const int n = (int)(r.y - r.x);
+  if (n == 0) return;
+  const int tid = threadIdx.x;
+  if (n == 1) { if (tid == 0) point_list[r.x] = (uint32_t)bucket[r.x]; return; }
+  int n2 = 2;
+  while (n2 < n) n2 <<= 1;
+  for (int i = tid; i < n2; i += THREADS) s_key[i] = (i < n) ? bucket[r.x + i] : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < (n2 >> 1); i += THREADS) {
+        const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));     // index with bit j clear
+        const int b = a | j;
+        const unsigned long long ka = s_key[a], kb = s_key[b];
+        const bool up = (a & k) == 0;
+        if ((ka > kb) == up) { s_key[a] = kb; s_key[b] = ka; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n; i += THREADS) point_list[r.x + i] = (uint32_t)s_key[i];
+}
+
+// ------------------------------------------------------------------------------ launchers
+size_t bin_lds_limit_tiles() { return 16000; }       // 2 x 4 B x tiles must fit the 160 KiB LDS
+int bin_sort_capacity() { return 16384; }            // 16384 x 8 B = 128 KiB
+
+int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
+                     uint32_t* tile_count, hipStream_t st) {
+  const int ntiles = p.gx * p.gy;
+  if (hipMemsetAsync(tile_count, 0, (size_t)ntiles * sizeof(uint32_t), st) != hipSuccess) return -1;
+  if (p.P == 0) return 0;
+  const size_t lds = (size_t)ntiles * sizeof(uint32_t);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(bin_count_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii, mask,
+                     tile_count);
+  return 0;
+}
+void launch_bin_tilescan(int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* cursor, uint32_t* info,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(1024), 0, st, ntiles, tile_count, ranges, cursor, info);
+}
+void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
+                        uint32_t* cursor, unsigned long long* bucket, hipStream_t st) {
+  if (p.P == 0) return;
+  const int ntiles = p.gx * p.gy;
+  const size_t lds = 2 * (size_t)ntiles * sizeof(uint32_t);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii, mask,
+                     cursor, bucket);
+}
+void launch_bin_tilesort(int ntiles, uint32_t longest, const uint2* ranges, const unsigned long long* bucket,
+                         uint32_t* point_list, hipStream_t st) {
+  uint32_t cap = 1024;
+  while (cap < longest) cap <<= 1;
+  const size_t lds = (size_t)cap * sizeof(unsigned long long);
+  if (cap <= 2048) {
+    hipLaunchKernelGGL(bin_tilesort_kernel<256>, dim3(ntiles), dim3(256), lds, st, ranges, bucket, point_list);
+  } else if (cap <= 4096) {
+    hipLaunchKernelGGL(bin_tilesort_kernel<512>, dim3(ntiles), dim3(512), lds, st, ranges, bucket, point_list);
+  } else {
+    (void)hipFuncSetAttribute((const void*)bin_tilesort_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bin_tilesort_kernel<1024>, dim3(ntiles), dim3(1024), lds, st, ranges, bucket, point_list);
+  }
+}
+
+}  // namespace rtgs
