@@ -35,7 +35,7 @@ static int64_t g_stats[8] = {0};
 static unsigned long long* g_counters = nullptr;
 
 // optional per-stage HIP-event timing (bench.py's roofline leg); off by default
-enum { EV_F0 = 0, EV_PRE, EV_SCAN, EV_BIN0, EV_EMIT, EV_SORT, EV_RANGES, EV_BLEND, EV_B0, EV_BBLEND, EV_BPRE, EV_N };
+enum { EV_F0 = 0, EV_PRE, EV_SCAN, EV_BIN0, EV_EMIT, EV_SORT, EV_RANGES, EV_BLEND0, EV_BLEND, EV_B0, EV_BBLEND, EV_BPRE, EV_N };
 static bool g_prof = false;
 static bool g_force_sort_path = false;   // testing aid: take the global radix-sort binning path
 static bool g_ev_init = false;
@@ -276,6 +276,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
     DBG(s, st);
     prof_mark(EV_RANGES, st);
   }
+  prof_mark(EV_BLEND0, st);
   launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
                    n_contrib, g_counters, st);
   prof_mark(EV_BLEND, st);
@@ -341,7 +342,7 @@ int rtgs_raster_last_timings(float* ms) {
   // [0] preprocess_fwd(+sat) [1] scan [2] emit_keys [3] radix sort [4] tile_ranges [5] blend_fwd
   // [6] memset+blend_bwd [7] preprocess_bwd
   const int pairs[8][2] = {{EV_F0, EV_PRE}, {EV_PRE, EV_SCAN}, {EV_BIN0, EV_EMIT}, {EV_EMIT, EV_SORT},
-                           {EV_SORT, EV_RANGES}, {EV_RANGES, EV_BLEND}, {EV_B0, EV_BBLEND}, {EV_BBLEND, EV_BPRE}};
+                           {EV_SORT, EV_RANGES}, {EV_BLEND0, EV_BLEND}, {EV_B0, EV_BBLEND}, {EV_BBLEND, EV_BPRE}};
   for (int i = 0; i < 8; ++i) {
     const int a = pairs[i][0], b = pairs[i][1];
     if (!g_ev_set[a] || !g_ev_set[b]) continue;

@@ -19,7 +19,7 @@
 
 namespace rtgs {
 
-constexpr int GPB = 2048;       // Gaussians per workgroup in bin_count / bin_scatter
+constexpr int GPB = 1024;       // Gaussians per workgroup in bin_count / bin_scatter
 constexpr int BIG_RECT = 32;    // rects above this many tiles are enumerated by the whole wave
 
 struct BinG {
@@ -93,13 +93,17 @@ __device__ __forceinline__ BinG bcast(const BinG& g, int src) {
   return o;
 }
 
-// Calls f(tile, gaussian_id, zbits) for every kept (Gaussian, tile) instance of this workgroup's
-// Gaussians.  Small rects: one lane per Gaussian; big rects: the wave enumerates them together.
-template <class F>
+// Calls f(tile, gaussian_id, zbits) for every (Gaussian, tile) instance of this workgroup's
+// Gaussians whose tile can see it (the tile MASK is applied by the callers at flush /
+// reservation time, not per instance).  Small rects: one lane per Gaussian, the visibility bits
+// of its <= 32 tiles are cached in `vis[k]` on the first sweep (REPLAY = false) and replayed on
+// the second (REPLAY = true); big rects: the whole wave enumerates them together.
+template <bool REPLAY, class F>
 __device__ __forceinline__ void enumerate_instances(const RasterParams& p, const Splat* __restrict__ splats,
-                                                    const int32_t* __restrict__ radii,
-                                                    const int32_t* __restrict__ mask, F f) {
+                                                    const int32_t* __restrict__ radii, uint32_t (&vis)[GPB / BLOCK],
+                                                    F f) {
   const int lane = threadIdx.x & 63;
+#pragma unroll
   for (int k = 0; k < GPB / BLOCK; ++k) {
     const int i = blockIdx.x * GPB + k * BLOCK + (int)threadIdx.x;
     BinG g;
@@ -107,11 +111,23 @@ __device__ __forceinline__ void enumerate_instances(const RasterParams& p, const
     const int w = g.x1 - g.x0, area = live ? w * (g.y1 - g.y0) : 0;
     const bool big = area > BIG_RECT;
     if (live && !big) {
-      for (int ty = g.y0; ty < g.y1; ++ty)
-        for (int tx = g.x0; tx < g.x1; ++tx) {
-          const int t = ty * p.gx + tx;
-          if (mask[t] != 0 && tile_visible(g, tx, ty)) f(t, (uint32_t)i, g.zbits);
+      if (!REPLAY) {
+        uint32_t bits = 0;
+        int e = 0;
+        for (int ty = g.y0; ty < g.y1; ++ty)
+          for (int tx = g.x0; tx < g.x1; ++tx, ++e)
+            if (tile_visible(g, tx, ty)) { bits |= 1u << e; f(ty * p.gx + tx, (uint32_t)i, g.zbits); }
+        vis[k] = bits;
+      } else {
+        uint32_t bits = vis[k];
+        const float iw = 1.f / (float)w;
+        while (bits) {
+          const int e = __ffs((int)bits) - 1;
+          bits &= bits - 1;
+          const int ry = (int)(((float)e + 0.5f) * iw), rx = e - ry * w;
+          f((g.y0 + ry) * p.gx + g.x0 + rx, (uint32_t)i, g.zbits);
         }
+      }
     }
     unsigned long long bm = __builtin_amdgcn_ballot_w64(big);
     while (bm) {
@@ -120,11 +136,11 @@ __device__ __forceinline__ void enumerate_instances(const RasterParams& p, const
       const BinG b = bcast(g, src);
       const uint32_t id = (uint32_t)(i - lane + src);
       const int bw = b.x1 - b.x0, barea = bw * (b.y1 - b.y0);
+      const float ibw = 1.f / (float)bw;
       for (int e = lane; e < barea; e += 64) {
-        const int ry = e / bw, rx = e - ry * bw;
+        const int ry = (int)(((float)e + 0.5f) * ibw), rx = e - ry * bw;   // exact for e < 2^22
         const int tx = b.x0 + rx, ty = b.y0 + ry;
-        const int t = ty * p.gx + tx;
-        if (mask[t] != 0 && tile_visible(b, tx, ty)) f(t, id, b.zbits);
+        if (tile_visible(b, tx, ty)) f(ty * p.gx + tx, id, b.zbits);
       }
     }
   }
@@ -138,11 +154,12 @@ __global__ void __launch_bounds__(256) bin_count_kernel(RasterParams p, const Sp
   const int ntiles = p.gx * p.gy;
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
   __syncthreads();
-  enumerate_instances(p, splats, radii, mask, [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
+  uint32_t vis[GPB / BLOCK];
+  enumerate_instances<false>(p, splats, radii, vis, [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
   __syncthreads();
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) {
     const uint32_t c = s_cnt[t];
-    if (c) atomicAdd(&tile_count[t], c);
+    if (c && mask[t] != 0) atomicAdd(&tile_count[t], c);
   }
 }
 
@@ -187,28 +204,34 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(RasterParams p, const 
   uint32_t* s_base = s_mem + ntiles;
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
   __syncthreads();
-  enumerate_instances(p, splats, radii, mask, [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
+  uint32_t vis[GPB / BLOCK];
+  enumerate_instances<false>(p, splats, radii, vis, [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
   __syncthreads();
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) {
     const uint32_t c = s_cnt[t];
-    if (c) { s_base[t] = atomicAdd(&cursor[t], c); s_cnt[t] = 0; }
+    if (c) { s_base[t] = (mask[t] != 0) ? atomicAdd(&cursor[t], c) : 0xffffffffu; s_cnt[t] = 0; }
   }
   __syncthreads();
-  enumerate_instances(p, splats, radii, mask, [&](int t, uint32_t id, uint32_t zbits) {
-    const uint32_t slot = s_base[t] + atomicAdd(&s_cnt[t], 1u);
-    bucket[slot] = ((unsigned long long)zbits << 32) | id;
+  enumerate_instances<true>(p, splats, radii, vis, [&](int t, uint32_t id, uint32_t zbits) {
+    const uint32_t base = s_base[t];
+    if (base != 0xffffffffu) {
+      const uint32_t slot = base + atomicAdd(&s_cnt[t], 1u);
+      bucket[slot] = ((unsigned long long)zbits << 32) | id;
+    }
   });
 }
 
 // one workgroup per tile; keys (depth bits << 32 | id) are unique, so the order is total
+// Launched once per size class [lo, hi): a workgroup whose tile is outside its class exits at
+// once, so every class runs with the LDS footprint (and occupancy) its lists need.
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) bin_tilesort_kernel(const uint2* __restrict__ ranges,
                                                                const unsigned long long* __restrict__ bucket,
-                                                               uint32_t* __restrict__ point_list) {
+                                                               uint32_t* __restrict__ point_list, int lo, int hi) {
   extern __shared__ unsigned long long s_key[];
   const uint2 r = ranges[blockIdx.x];
   const int n = (int)(r.y - r.x);
-  if (n == 0) return;
+  if (n < lo || n >= hi) return;
   const int tid = threadIdx.x;
   if (n == 1) { if (tid == 0) point_list[r.x] = (uint32_t)bucket[r.x]; return; }
   int n2 = 2;
@@ -262,16 +285,19 @@ void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_
 }
 void launch_bin_tilesort(int ntiles, uint32_t longest, const uint2* ranges, const unsigned long long* bucket,
                          uint32_t* point_list, hipStream_t st) {
-  uint32_t cap = 1024;
-  while (cap < longest) cap <<= 1;
-  const size_t lds = (size_t)cap * sizeof(unsigned long long);
-  if (cap <= 2048) {
-    hipLaunchKernelGGL(bin_tilesort_kernel<256>, dim3(ntiles), dim3(256), lds, st, ranges, bucket, point_list);
-  } else if (cap <= 4096) {
-    hipLaunchKernelGGL(bin_tilesort_kernel<512>, dim3(ntiles), dim3(512), lds, st, ranges, bucket, point_list);
-  } else {
-    (void)hipFuncSetAttribute((const void*)bin_tilesort_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(bin_tilesort_kernel<1024>, dim3(ntiles), dim3(1024), lds, st, ranges, bucket, point_list);
+  // size classes by list length: (0,512] (512,2048] (2048,4096] (4096,16384]
+  hipLaunchKernelGGL(bin_tilesort_kernel<128>, dim3(ntiles), dim3(128), 512 * 8, st, ranges, bucket, point_list, 1, 513);
+  if (longest > 512)
+    hipLaunchKernelGGL(bin_tilesort_kernel<256>, dim3(ntiles), dim3(256), 2048 * 8, st, ranges, bucket, point_list, 513,
+                       2049);
+  if (longest > 2048)
+    hipLaunchKernelGGL(bin_tilesort_kernel<512>, dim3(ntiles), dim3(512), 4096 * 8, st, ranges, bucket, point_list, 2049,
+                       4097);
+  if (longest > 4096) {
+    (void)hipFuncSetAttribute((const void*)bin_tilesort_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              16384 * 8);
+    hipLaunchKernelGGL(bin_tilesort_kernel<1024>, dim3(ntiles), dim3(1024), 16384 * 8, st, ranges, bucket, point_list,
+                       4097, 16385);
   }
 }
 
