@@ -138,7 +138,7 @@ def main():
             counters.zero_()
             lib.rtgs_raster_set_counters(C.c_void_p(counters.data_ptr()))
             leaf = opt.params.detach().clone().requires_grad_(True)
-            loss = loss_fn(mo.activate(leaf))
+            loss = loss_fn(mo.activate_hip(leaf))
             lib.rtgs_raster_set_counters(None)
             loss.backward()
             torch.cuda.synchronize(dev)

@@ -138,6 +138,18 @@ int rtgs_fused_adam(float* params, const float* grads, float* exp_avg, float* ex
                     const float* lr_per_column, int64_t rows, int32_t cols, int32_t step,
                     float beta1, float beta2, float eps, void* stream);
 
+/* Map-state activations around the rasterizer, one streaming kernel each way.
+ * packed[n,59] raw parameters (xyz 0:3 | f_dc 3:6 | f_rest 6:51 | opacity 51 | scaling 52:55 |
+ * rotation 55:59, the PLY column order of SLAM/gaussian_pointcloud.py:407-466) -> the six
+ * contiguous rasterizer inputs: exp / sigmoid / normalize (gaussian_pointcloud.py:16-25),
+ * get_normal (:538-550), get_features (:573-577).  The backward maps the six input gradients
+ * of rtgs_raster_backward to the packed gradient (argmin of the scales is piecewise constant). */
+int rtgs_map_activate_forward(const float* packed, int64_t n, float* xyz, float* opacity, float* shs,
+                              float* scales, float* rotations, float* normal, void* stream);
+int rtgs_map_activate_backward(const float* packed, int64_t n, const float* g_xyz, const float* g_opacity,
+                               const float* g_shs, const float* g_scales, const float* g_rotations,
+                               const float* g_normal, float* g_packed, void* stream);
+
 const char* rtgs_version(void);
 
 #ifdef __cplusplus

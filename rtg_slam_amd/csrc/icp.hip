@@ -10,7 +10,7 @@
 
 namespace rtgs_icp {
 
-constexpr int MAX_BLOCKS = 256;     // one residual block per CU; the final kernel reads 8 x 32 partial rows
+constexpr int MAX_BLOCKS = 1024;    // residual workgroups (4 per CU: the gathers are latency-bound)
 constexpr int NACC = 28;            // 21 upper-triangular JtJ + 6 Jtr + 1 valid count
 constexpr int PSTRIDE = 32;         // floats per block partial
 
@@ -38,39 +38,49 @@ struct PyrDesc {
 };
 
 // ---- K10: max-pool depth pyramid + back-projection (SLAM/utils.py:511-521, :65-75) ------------
+// Grid-stride over 256-pixel chunks (a chunk never straddles two levels).  The per-level depth
+// min / max needed by compute_normal_map's invalid mask are reduced wave -> LDS -> ONE pair of
+// global atomics per workgroup and level (same-address global atomics cost ~12 ns each).
 __global__ void __launch_bounds__(256) icp_vertex_kernel(PyrDesc d, const float* __restrict__ depth,
                                                          const float* __restrict__ K, Scratch* sc) {
-  int l = 0;
-  while (l + 1 < d.levels && (int)blockIdx.x >= d.block_start[l + 1]) ++l;
-  const int Hl = d.Hl[l], Wl = d.Wl[l], sh = d.shift[l];
-  const int idx = ((int)blockIdx.x - d.block_start[l]) * 256 + (int)threadIdx.x;
-  float dmax = 0.f;
-  const bool live = idx < Hl * Wl;
-  if (live) {
-    const int y = idx / Wl, x = idx % Wl;
-    const int f = 1 << sh;
-    dmax = -INFINITY;
-    for (int a = 0; a < f; ++a)
-      for (int b = 0; b < f; ++b) dmax = fmaxf(dmax, depth[(size_t)(y * f + a) * d.W + (x * f + b)]);
-    const float ds = 1.f / (float)f;                       // K * downscale, K[2][2] = 1
-    const float fx = K[0] * ds, fy = K[4] * ds, cx = K[2] * ds, cy = K[5] * ds;
-    float* v = d.vertex[l] + (size_t)idx * 3;
-    v[0] = (((float)x - cx) / fx) * dmax;
-    v[1] = (((float)y - cy) / fy) * dmax;
-    v[2] = dmax;                                           // 1 * depth
-  }
-  // min / max of the level's depth for the invalid mask of compute_normal_map
-  uint32_t emin = 0xffffffffu, emaxinv = 0xffffffffu;
-  if (live) { emin = enc_f(dmax); emaxinv = ~emin; }
+  __shared__ uint32_t s_mm[2 * RTGS_ICP_MAX_LEVELS];
+  if (threadIdx.x < 2 * RTGS_ICP_MAX_LEVELS) s_mm[threadIdx.x] = 0xffffffffu;
+  __syncthreads();
+  const int total = d.block_start[d.levels];
+  for (int chunk = blockIdx.x; chunk < total; chunk += gridDim.x) {
+    int l = 0;
+    while (l + 1 < d.levels && chunk >= d.block_start[l + 1]) ++l;
+    const int Hl = d.Hl[l], Wl = d.Wl[l], sh = d.shift[l];
+    const int idx = (chunk - d.block_start[l]) * 256 + (int)threadIdx.x;
+    float dmax = 0.f;
+    const bool live = idx < Hl * Wl;
+    if (live) {
+      const int y = idx / Wl, x = idx % Wl;
+      const int f = 1 << sh;
+      dmax = -INFINITY;
+      for (int a = 0; a < f; ++a)
+        for (int b = 0; b < f; ++b) dmax = fmaxf(dmax, depth[(size_t)(y * f + a) * d.W + (x * f + b)]);
+      const float ds = 1.f / (float)f;                       // K * downscale, K[2][2] = 1
+      const float fx = K[0] * ds, fy = K[4] * ds, cx = K[2] * ds, cy = K[5] * ds;
+      float* v = d.vertex[l] + (size_t)idx * 3;
+      v[0] = (((float)x - cx) / fx) * dmax;
+      v[1] = (((float)y - cy) / fy) * dmax;
+      v[2] = dmax;                                           // 1 * depth
+    }
+    uint32_t emin = 0xffffffffu, emaxinv = 0xffffffffu;
+    if (live) { emin = enc_f(dmax); emaxinv = ~emin; }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {          // wave64 min via shuffles (6 steps, once per wave)
-    emin = min(emin, (uint32_t)__shfl_xor((int)emin, off));
-    emaxinv = min(emaxinv, (uint32_t)__shfl_xor((int)emaxinv, off));
+    for (int off = 32; off > 0; off >>= 1) {
+      emin = min(emin, (uint32_t)__shfl_xor((int)emin, off));
+      emaxinv = min(emaxinv, (uint32_t)__shfl_xor((int)emaxinv, off));
+    }
+    if ((threadIdx.x & 63) == 0 && emin != 0xffffffffu) {
+      atomicMin(&s_mm[2 * l], emin);
+      atomicMin(&s_mm[2 * l + 1], emaxinv);
+    }
   }
-  if ((threadIdx.x & 63) == 0 && emin != 0xffffffffu) {
-    atomicMin(&sc->minmax[2 * l], emin);
-    atomicMin(&sc->minmax[2 * l + 1], emaxinv);
-  }
+  __syncthreads();
+  if (threadIdx.x < 2 * d.levels && s_mm[threadIdx.x] != 0xffffffffu) atomicMin(&sc->minmax[threadIdx.x], s_mm[threadIdx.x]);
 }
 
 // ---- K11: Sobel normals (SLAM/utils.py:77-122): replicate pad, cross(dy, dx), / (|n| + 1e-8),
@@ -420,7 +430,7 @@ int rtgs_icp_build_pyramids(const float* depth, int32_t H, int32_t W, const floa
   }
   d.block_start[levels] = blocks;
   ICP_TRY(hipMemsetAsync(sc->minmax, 0xff, sizeof(sc->minmax), st));
-  hipLaunchKernelGGL(icp_vertex_kernel, dim3(blocks), dim3(256), 0, st, d, depth, K, sc);
+  hipLaunchKernelGGL(icp_vertex_kernel, dim3(blocks < 512 ? blocks : 512), dim3(256), 0, st, d, depth, K, sc);
   hipLaunchKernelGGL(icp_normal_kernel, dim3(blocks), dim3(256), 0, st, d, (const Scratch*)sc);
   ICP_TRY(hipGetLastError());
   return 0;

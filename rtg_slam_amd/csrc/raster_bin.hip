@@ -238,14 +238,30 @@ __global__ void __launch_bounds__(THREADS) bin_tilesort_kernel(const uint2* __re
   while (n2 < n) n2 <<= 1;
   for (int i = tid; i < n2; i += THREADS) s_key[i] = (i < n) ? bucket[r.x + i] : ~0ull;
   __syncthreads();
+  // each thread handles PER compare-exchanges per stage: all LDS reads are issued before the first
+  // write so the stage costs one LDS round trip instead of PER dependent ones
+  constexpr int PER = 4;
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < (n2 >> 1); i += THREADS) {
-        const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));     // index with bit j clear
-        const int b = a | j;
-        const unsigned long long ka = s_key[a], kb = s_key[b];
-        const bool up = (a & k) == 0;
-        if ((ka > kb) == up) { s_key[a] = kb; s_key[b] = ka; }
+      for (int i0 = tid; i0 < (n2 >> 1); i0 += THREADS * PER) {
+        unsigned long long ka[PER], kb[PER];
+        int ia[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int i = i0 + u * THREADS;
+          ia[u] = ((i & ~(j - 1)) << 1) | (i & (j - 1));         // index with bit j clear
+          if (i < (n2 >> 1)) { ka[u] = s_key[ia[u]]; kb[u] = s_key[ia[u] | j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int i = i0 + u * THREADS;
+          if (i < (n2 >> 1)) {
+            const bool up = (ia[u] & k) == 0;
+            const unsigned long long lo = ka[u] < kb[u] ? ka[u] : kb[u], hi = ka[u] < kb[u] ? kb[u] : ka[u];
+            s_key[ia[u]] = up ? lo : hi;
+            s_key[ia[u] | j] = up ? hi : lo;
+          }
+        }
       }
       __syncthreads();
     }

@@ -75,6 +75,53 @@ def activate(packed: torch.Tensor) -> Dict[str, torch.Tensor]:
                 shs=packed[:, 3:51].reshape(N, 16, 3), normal=normal)
 
 
+class _ActivateHip(torch.autograd.Function):
+    """`activate` as one HIP kernel each way (rtgs_map_activate_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, packed):
+        from . import _lib
+        lib = _lib.load()
+        if not packed.is_cuda:
+            raise RuntimeError("rtg_slam_amd.map_optim: activate_hip needs a HIP device tensor; no CPU path.")
+        packed = packed.contiguous()
+        N, dev = packed.shape[0], packed.device
+        f = dict(dtype=torch.float32, device=dev)
+        xyz, op, shs = torch.empty(N, 3, **f), torch.empty(N, 1, **f), torch.empty(N, 16, 3, **f)
+        sc, rot, nrm = torch.empty(N, 3, **f), torch.empty(N, 4, **f), torch.empty(N, 3, **f)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            rc = lib.rtgs_map_activate_forward(C.c_void_p(packed.data_ptr()), N, *(C.c_void_p(t.data_ptr()) for t in
+                                               (xyz, op, shs, sc, rot, nrm)), C.c_void_p(stream))
+        _lib.check(rc, "rtgs_map_activate_forward")
+        ctx.save_for_backward(packed)
+        return xyz, op, shs, sc, rot, nrm
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_op, g_shs, g_sc, g_rot, g_nrm):
+        from . import _lib
+        lib = _lib.load()
+        (packed,) = ctx.saved_tensors
+        N, dev = packed.shape[0], packed.device
+
+        def z(g, *shape):
+            return torch.zeros(*shape, dtype=torch.float32, device=dev) if g is None else g.contiguous()
+        gs = (z(g_xyz, N, 3), z(g_op, N, 1), z(g_shs, N, 16, 3), z(g_sc, N, 3), z(g_rot, N, 4), z(g_nrm, N, 3))
+        out = torch.empty_like(packed)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            rc = lib.rtgs_map_activate_backward(C.c_void_p(packed.data_ptr()), N, *(C.c_void_p(t.data_ptr()) for t in gs),
+                                                C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+        _lib.check(rc, "rtgs_map_activate_backward")
+        return out
+
+
+def activate_hip(packed: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Same mapping as `activate`, fused into one HIP kernel per direction."""
+    xyz, op, shs, sc, rot, nrm = _ActivateHip.apply(packed)
+    return dict(xyz=xyz, opacity=op, scales=sc, rotations=rot, shs=shs, normal=nrm)
+
+
 def shard_rows(N: int, world: int):
     """Row partition used for reduce-scatter / all-gather: equal shards of ceil(N/world) rows
     (the packed buffer is padded to world * rows_per_rank)."""
@@ -97,11 +144,12 @@ def _adam_hip(p, g, m, v, lr_col, step, eps):
 
 class ShardedMapOptimizer:
     def __init__(self, packed: torch.Tensor, lr_col: Optional[torch.Tensor] = None, eps: float = 1e-15,
-                 group=None, adam_fn: Optional[Callable] = None):
+                 group=None, adam_fn: Optional[Callable] = None, activate_fn: Optional[Callable] = None):
         """`adam_fn(p, g, m, v, lr_col, step, eps)` defaults to the HIP fused Adam (device tensors only -
         there is no CPU path in the product); the gloo tests inject a torch restatement."""
         self.group = group
         self.adam_fn = adam_fn if adam_fn is not None else _adam_hip
+        self.activate_fn = activate_fn if activate_fn is not None else activate_hip
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
@@ -129,9 +177,10 @@ class ShardedMapOptimizer:
         """loss_fn(gaussian_data) -> scalar loss of THIS rank's view.  Gradients are summed over
         ranks (the sum of per-view losses is what a single GPU looping over the views optimises)."""
         leaf = self.packed[:self.N].detach().requires_grad_(True)
-        loss = loss_fn(activate(leaf))
+        loss = loss_fn(self.activate_fn(leaf))
         (g,) = torch.autograd.grad(loss, leaf)
-        self.grad_full[:self.N] = g
+        if self.world > 1:
+            self.grad_full[:self.N] = g
         if self.world > 1 and self.backend == "gloo":
             # gloo (CPU tests) has no reduce-scatter: all-reduce and take the local rows
             dist.all_reduce(self.grad_full, op=dist.ReduceOp.SUM, group=self.group)
@@ -140,7 +189,7 @@ class ShardedMapOptimizer:
             dist.reduce_scatter_tensor(self.grad_shard, self.grad_full, op=dist.ReduceOp.SUM, group=self.group)
             gs = self.grad_shard
         else:
-            gs = self.grad_full
+            gs = g if self.Npad == self.N else torch.nn.functional.pad(g, (0, 0, 0, self.Npad - self.N))
         self.step_count += 1
         shard = self.packed[self.my_rows()]
         self.adam_fn(shard, gs, self.m, self.v, self.lr_col, self.step_count, self.eps)

@@ -154,3 +154,38 @@ def test_fallback_sort_path_is_equivalent():
         assert float((gd_a[k] - gd_b[k]).abs().max()) / sc < 1e-4, k
     out_o, gd_o, _ = ru.oracle_run(s, g, grads=grads)
     check_forward(out_b, out_o)
+
+
+def test_fused_activation_and_adam_match_torch():
+    """rtgs_map_activate_{forward,backward} vs the torch restatement `map_optim.activate` (autograd),
+    rtgs_fused_adam vs torch.optim.Adam arithmetic with per-column learning rates."""
+    from rtg_slam_amd import map_optim as mo
+    from tests.dist_util import adam_reference
+    dev = "cuda:0"
+    g = synth.random_gaussians(5000, SMALL, seed=11)
+    packed = mo.pack_from_activated({k: v.to(dev) for k, v in g.items()})
+    packed[:, 55:59] *= 1.7                      # un-normalised raw quaternions
+    a = packed.clone().requires_grad_(True)
+    b = packed.clone().requires_grad_(True)
+    ra, rb = mo.activate(a), mo.activate_hip(b)
+    gen = torch.Generator().manual_seed(1)
+    la = lb = 0
+    for k in ("xyz", "opacity", "scales", "rotations", "shs", "normal"):
+        assert float((ra[k] - rb[k]).abs().max()) < 2e-6, k
+        w = torch.randn(ra[k].shape, generator=gen).to(dev)
+        la = la + (ra[k] * w).sum()
+        lb = lb + (rb[k] * w).sum()
+    la.backward(); lb.backward()
+    scale = float(a.grad.abs().max())
+    assert float((a.grad - b.grad).abs().max()) < 1e-5 * scale
+    # Adam
+    lr = mo.default_lr_columns().to(dev)
+    p1, p2 = packed.clone(), packed.clone()
+    m1, v1 = torch.zeros_like(p1), torch.zeros_like(p1)
+    m2, v2 = torch.zeros_like(p1), torch.zeros_like(p1)
+    for step in (1, 2, 3):
+        gr = torch.randn(p1.shape, generator=gen).to(dev) * 0.01
+        mo._adam_hip(p1, gr, m1, v1, lr, step, 1e-15)
+        adam_reference(p2, gr, m2, v2, lr, step, 1e-15)
+    assert float((p1 - p2).abs().max()) < 1e-6
+    assert float((p1 - packed).abs().max()) > 1e-4
