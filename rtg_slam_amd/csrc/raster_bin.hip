@@ -238,35 +238,125 @@ __global__ void __launch_bounds__(THREADS) bin_tilesort_kernel(const uint2* __re
   while (n2 < n) n2 <<= 1;
   for (int i = tid; i < n2; i += THREADS) s_key[i] = (i < n) ? bucket[r.x + i] : ~0ull;
   __syncthreads();
-  // each thread handles PER compare-exchanges per stage: all LDS reads are issued before the first
-  // write so the stage costs one LDS round trip instead of PER dependent ones
-  constexpr int PER = 4;
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i0 = tid; i0 < (n2 >> 1); i0 += THREADS * PER) {
-        unsigned long long ka[PER], kb[PER];
-        int ia[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-          const int i = i0 + u * THREADS;
-          ia[u] = ((i & ~(j - 1)) << 1) | (i & (j - 1));         // index with bit j clear
-          if (i < (n2 >> 1)) { ka[u] = s_key[ia[u]]; kb[u] = s_key[ia[u] | j]; }
-        }
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-          const int i = i0 + u * THREADS;
-          if (i < (n2 >> 1)) {
-            const bool up = (ia[u] & k) == 0;
-            const unsigned long long lo = ka[u] < kb[u] ? ka[u] : kb[u], hi = ka[u] < kb[u] ? kb[u] : ka[u];
-            s_key[ia[u]] = up ? lo : hi;
-            s_key[ia[u] | j] = up ? hi : lo;
-          }
-        }
+      for (int i = tid; i < (n2 >> 1); i += THREADS) {
+        const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));     // index with bit j clear
+        const int b = a | j;
+        const unsigned long long ka = s_key[a], kb = s_key[b];
+        const bool up = (a & k) == 0;
+        if ((ka > kb) == up) { s_key[a] = kb; s_key[b] = ka; }
       }
       __syncthreads();
     }
   }
   for (int i = tid; i < n; i += THREADS) point_list[r.x + i] = (uint32_t)s_key[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS radix sort of one tile bucket: LSD over the bytes of the depth bits that actually vary inside
+// the tile (usually 3 of 4), stable within a pass (wave-ordered segments, ballot ranks), then a
+// fix-up that orders runs of bit-equal depths by Gaussian id (the bucket was filled by atomics, so
+// equal depths arrive in arbitrary order).  ~6 LDS operations per key and pass instead of the
+// ~1.5 x 78 stages of the bitonic network.
+// ---------------------------------------------------------------------------------------------
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) bin_tilesort_radix_kernel(const uint2* __restrict__ ranges,
+                                                                     const unsigned long long* __restrict__ bucket,
+                                                                     uint32_t* __restrict__ point_list, int lo, int hi,
+                                                                     int cap) {
+  constexpr int NW = THREADS / 64;
+  extern __shared__ unsigned long long s_dyn[];
+  unsigned long long* kA = s_dyn;
+  unsigned long long* kB = s_dyn + cap;
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_dyn + 2 * cap);      // [NW][256]
+  uint32_t* s_tot = s_cnt + NW * 256;                                   // [256]
+  __shared__ uint32_t s_or;
+  const uint2 r = ranges[blockIdx.x];
+  const int n = (int)(r.y - r.x);
+  if (n < lo || n >= hi) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) s_or = 0;
+  __syncthreads();
+  const uint32_t z0 = (uint32_t)(bucket[r.x] >> 32);
+  uint32_t vary = 0;
+  for (int i = tid; i < n; i += THREADS) {
+    const unsigned long long k = bucket[r.x + i];
+    kA[i] = k;
+    vary |= (uint32_t)(k >> 32) ^ z0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) vary |= (uint32_t)__shfl_xor((int)vary, off);
+  if (lane == 0 && vary) atomicOr(&s_or, vary);
+  __syncthreads();
+  const uint32_t vbits = s_or;
+  const int seg = ((n + NW - 1) / NW + 63) & ~63;        // keys per wave, multiple of 64
+  const int wlo = min(n, w * seg), whi = min(n, wlo + seg);
+  for (int pass = 0; pass < 4; ++pass) {
+    if (((vbits >> (8 * pass)) & 0xffu) == 0) continue;   // this byte is constant inside the tile
+    const int shift = 32 + 8 * pass;
+    for (int i = tid; i < NW * 256; i += THREADS) s_cnt[i] = 0;
+    __syncthreads();
+    for (int i = wlo + lane; i < whi; i += 64) atomicAdd(&s_cnt[w * 256 + (int)((kA[i] >> shift) & 0xff)], 1u);
+    __syncthreads();
+    if (tid < 256) {                                      // per digit: exclusive prefix over waves + digit total
+      uint32_t run = 0;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) { const uint32_t c = s_cnt[ww * 256 + tid]; s_cnt[ww * 256 + tid] = run; run += c; }
+      s_tot[tid] = run;
+    }
+    __syncthreads();
+    if (tid < 64) {                                       // exclusive scan of the 256 digit totals by one wave
+      uint32_t v0 = s_tot[4 * tid], v1 = s_tot[4 * tid + 1], v2 = s_tot[4 * tid + 2], v3 = s_tot[4 * tid + 3];
+      const uint32_t mine = v0 + v1 + v2 + v3;
+      uint32_t inc = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+        if (tid >= off) inc += o;
+      }
+      const uint32_t ex = inc - mine;
+      s_tot[4 * tid] = ex; s_tot[4 * tid + 1] = ex + v0; s_tot[4 * tid + 2] = ex + v0 + v1; s_tot[4 * tid + 3] = ex + v0 + v1 + v2;
+    }
+    __syncthreads();
+    for (int i0 = wlo; i0 < whi; i0 += 64) {
+      const int i = i0 + lane;
+      const bool act = i < whi;
+      const unsigned long long k = act ? kA[i] : 0ull;
+      const int d = (int)((k >> shift) & 0xff);
+      unsigned long long same = __builtin_amdgcn_ballot_w64(act);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64((d >> bit) & 1);
+        same &= ((d >> bit) & 1) ? m : ~m;
+      }
+      if (act) {
+        const unsigned long long below = same & ((1ull << lane) - 1ull);
+        const uint32_t base = s_cnt[w * 256 + d] + s_tot[d];
+        kB[base + (uint32_t)__popcll(below)] = k;
+        if ((same >> lane) == 1ull) s_cnt[w * 256 + d] += (uint32_t)__popcll(same);   // highest lane of the group
+      }
+    }
+    __syncthreads();
+    unsigned long long* tmp = kA; kA = kB; kB = tmp;
+  }
+  // runs of bit-equal depth: order by id (insertion sort by the run's first thread; runs are tiny and rare)
+  for (int i = tid; i < n; i += THREADS) {
+    const uint32_t z = (uint32_t)(kA[i] >> 32);
+    const bool start = (i == 0 || (uint32_t)(kA[i - 1] >> 32) != z) && (i + 1 < n && (uint32_t)(kA[i + 1] >> 32) == z);
+    if (start) {
+      int e = i + 1;
+      while (e < n && (uint32_t)(kA[e] >> 32) == z) ++e;
+      for (int a2 = i + 1; a2 < e; ++a2) {
+        const unsigned long long key = kA[a2];
+        int b2 = a2 - 1;
+        while (b2 >= i && kA[b2] > key) { kA[b2 + 1] = kA[b2]; --b2; }
+        kA[b2 + 1] = key;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += THREADS) point_list[r.x + i] = (uint32_t)kA[i];
 }
 
 // ------------------------------------------------------------------------------ launchers
@@ -299,21 +389,31 @@ void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_
   hipLaunchKernelGGL(bin_scatter_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii, mask,
                      cursor, bucket);
 }
+template <int THREADS>
+static void launch_radix(int ntiles, const uint2* ranges, const unsigned long long* bucket, uint32_t* point_list, int lo,
+                         int hi, int cap, hipStream_t st) {
+  const size_t lds = (size_t)cap * 16 + (size_t)(THREADS / 64 + 1) * 256 * sizeof(uint32_t);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)bin_tilesort_radix_kernel<THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  hipLaunchKernelGGL(bin_tilesort_radix_kernel<THREADS>, dim3(ntiles), dim3(THREADS), lds, st, ranges, bucket, point_list,
+                     lo, hi, cap);
+}
+
 void launch_bin_tilesort(int ntiles, uint32_t longest, const uint2* ranges, const unsigned long long* bucket,
                          uint32_t* point_list, hipStream_t st) {
-  // size classes by list length: (0,512] (512,2048] (2048,4096] (4096,16384]
-  hipLaunchKernelGGL(bin_tilesort_kernel<128>, dim3(ntiles), dim3(128), 512 * 8, st, ranges, bucket, point_list, 1, 513);
-  if (longest > 512)
-    hipLaunchKernelGGL(bin_tilesort_kernel<256>, dim3(ntiles), dim3(256), 2048 * 8, st, ranges, bucket, point_list, 513,
-                       2049);
-  if (longest > 2048)
-    hipLaunchKernelGGL(bin_tilesort_kernel<512>, dim3(ntiles), dim3(512), 4096 * 8, st, ranges, bucket, point_list, 2049,
-                       4097);
-  if (longest > 4096) {
+  // size classes by list length; every class runs with the LDS footprint its lists need:
+  //   (0,256]  bitonic, 128 threads      (256,1024] radix, 256 threads   (1024,3072] radix, 512 threads
+  //   (3072,8192] radix, 1024 threads    (8192,16384] bitonic in place, 1024 threads
+  hipLaunchKernelGGL(bin_tilesort_kernel<128>, dim3(ntiles), dim3(128), 256 * 8, st, ranges, bucket, point_list, 1, 257);
+  if (longest > 256) launch_radix<256>(ntiles, ranges, bucket, point_list, 257, 1025, 1024, st);
+  if (longest > 1024) launch_radix<512>(ntiles, ranges, bucket, point_list, 1025, 3073, 3072, st);
+  if (longest > 3072) launch_radix<1024>(ntiles, ranges, bucket, point_list, 3073, 8193, 8192, st);
+  if (longest > 8192) {
     (void)hipFuncSetAttribute((const void*)bin_tilesort_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               16384 * 8);
     hipLaunchKernelGGL(bin_tilesort_kernel<1024>, dim3(ntiles), dim3(1024), 16384 * 8, st, ranges, bucket, point_list,
-                       4097, 16385);
+                       8193, 16385);
   }
 }
 

@@ -189,3 +189,28 @@ def test_fused_activation_and_adam_match_torch():
         adam_reference(p2, gr, m2, v2, lr, step, 1e-15)
     assert float((p1 - p2).abs().max()) < 1e-6
     assert float((p1 - packed).abs().max()) > 1e-4
+
+
+def test_long_lists_and_depth_ties():
+    """Thousands of low-opacity Gaussians per tile (so pixels walk deep into the lists) with
+    bit-equal depths: exercises every LDS tile-sort class and the equal-depth -> id ordering."""
+    from rtg_slam_amd import _lib
+    lib = _lib.load()
+    cam = SMALL
+    g, s = ru.make_scene(24000, cam, seed=21, r_range=(0.01, 0.08))
+    g["opacity"] = torch.full_like(g["opacity"], 0.03)
+    for k in ru.FIELDS:                       # 3000 exact duplicates -> equal depth bits, different ids
+        g[k][21000:] = g[k][:3000]
+    out_a, _ = ru.hip_run(s, g)
+    st = (__import__("ctypes").c_int64 * 8)()
+    lib.rtgs_raster_last_stats(st)
+    assert st[6] == 1 and st[7] > 3072, (st[6], st[7])     # LDS path taken, longest list in the top radix class
+    lib.rtgs_raster_force_sort_path(1)
+    try:
+        out_b, _ = ru.hip_run(s, g)
+    finally:
+        lib.rtgs_raster_force_sort_path(0)
+    for a, b in zip(out_a, out_b):
+        assert torch.equal(a, b)
+    out_o, _, _ = ru.oracle_run(s, g)
+    check_forward(out_a, out_o)
