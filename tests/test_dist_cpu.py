@@ -1,0 +1,89 @@
+"""world_size-2 gloo test of the sharded map-optimisation step (rtg_slam_amd/map_optim.py): every
+rank renders its own view (CPU oracle injected as the render function), gradients are summed across
+ranks, Adam runs on the rank's row shard, updated rows are gathered.  Checked against a single
+process that sums both views' gradients and steps all rows."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _scene():
+    from rtg_slam_amd import synth
+    from rtg_slam_amd import map_optim as mo
+    from oracle import raster_oracle as ro
+    cam = synth.CameraSpec(32, 48, 40.0, 40.0, 23.5, 15.5)
+    g = synth.random_gaussians(101, cam, seed=3)        # odd count: exercises the shard padding
+    packed = mo.pack_from_activated(g)
+    views = []
+    for r in range(2):
+        c2w = synth.look_at_pose(seed=50 + r, max_angle_deg=3.0, max_trans=0.05)
+        view = torch.linalg.inv(c2w).float().t().contiguous()
+        views.append(ro.make_settings(cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, viewmatrix=view))
+    gen = torch.Generator().manual_seed(5)
+    gts = [(torch.rand(3, cam.H, cam.W, generator=gen), 1.0 + torch.rand(1, cam.H, cam.W, generator=gen)) for _ in range(2)]
+    return packed, views, gts
+
+
+def _loss_fn(settings, gt):
+    from oracle import raster_oracle as ro
+    from rtg_slam_amd import map_optim as mo
+
+    def fn(gd):
+        out = ro.rasterize(settings, gd["xyz"], gd["opacity"], gd["shs"], gd["scales"], gd["rotations"], gd["normal"])
+        return mo.slam_losses(out, gt[0], gt[1])
+    return fn
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from rtg_slam_amd import map_optim as mo
+    from tests.dist_util import adam_reference
+    packed, views, gts = _scene()
+    opt = mo.ShardedMapOptimizer(packed, adam_fn=adam_reference, activate_fn=mo.activate)
+    assert opt.world == 2 and opt.per == 51 and opt.Npad == 102
+    for _ in range(2):
+        opt.step(_loss_fn(views[rank], gts[rank]))
+    ret[rank] = opt.params.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_matches_single_process():
+    from rtg_slam_amd import map_optim as mo
+    from tests.dist_util import adam_reference
+    port = 29600 + (os.getpid() % 300)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    p0, p1 = ret[0], ret[1]
+    assert torch.equal(p0, p1), "all ranks hold the same gathered parameters"
+    # single-process reference: sum of both views' gradients, Adam on all rows
+    packed, views, gts = _scene()
+    p = packed.clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    lr = mo.default_lr_columns()
+    for step in (1, 2):
+        leaf = p.detach().clone().requires_grad_(True)
+        loss = _loss_fn(views[0], gts[0])(mo.activate(leaf)) + _loss_fn(views[1], gts[1])(mo.activate(leaf))
+        (g,) = torch.autograd.grad(loss, leaf)
+        adam_reference(p, g, m, v, lr, step, 1e-15)
+    assert float((p0 - p).abs().max()) < 1e-5
+    assert float((p0 - packed).abs().max()) > 1e-4, "the step moved the parameters"
+
+
+def test_shard_rows_partition():
+    from rtg_slam_amd import map_optim as mo
+    for N in (1, 7, 8, 1_200_000, 5_000_001):
+        for w in (1, 2, 4, 8):
+            per, npad = mo.shard_rows(N, w)
+            assert per * w == npad and npad >= N and npad - N < w

@@ -1,0 +1,92 @@
+"""CPU tests of the rasterizer oracle: committed golden, float64 finite differences, sentinels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_oracle as ro
+from rtg_slam_amd import synth
+from tests import raster_util as ru
+
+
+def test_oracle_matches_committed_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "raster_small.npz"))
+    cam = synth.CameraSpec(64, 96, 80.0, 80.0, 47.5, 31.5)
+    g = {k: torch.from_numpy(z[f"in_{k}"]) for k in ru.FIELDS}
+    s = ro.make_settings(cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, viewmatrix=torch.from_numpy(z["viewmatrix"]))
+    grads = (torch.from_numpy(z["g_color"]), torch.from_numpy(z["g_depth"]))
+    outs, gd, _ = ru.oracle_run(s, g, grads=grads)
+    for i, n in enumerate(["color", "depth", "cidx", "didx", "cw", "dw", "T"]):
+        ref = torch.from_numpy(z[f"out_{n}"])
+        if ref.dtype == torch.int32:
+            assert torch.equal(outs[i], ref), n
+        else:
+            assert float((outs[i] - ref).abs().max()) < 1e-6, n
+    for k in ru.FIELDS:
+        ref = torch.from_numpy(z[f"grad_{k}"])
+        assert float((gd[k] - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-9, k
+
+
+def test_oracle_autograd_vs_finite_differences_fp64():
+    """Central differences in float64 on a 12-Gaussian scene; a parameter whose perturbation flips a
+    discontinuous decision (alpha < 1/255, stop rule, depth gates) is skipped by comparing the index maps."""
+    cam = synth.CameraSpec(32, 32, 40.0, 40.0, 15.5, 15.5)
+    g, s = ru.make_scene(12, cam, seed=7, r_range=(0.02, 0.08))
+    dt = torch.float64
+    gen = torch.Generator().manual_seed(1)
+    wc = torch.randn(3, cam.H, cam.W, generator=gen, dtype=dt)
+    wd = torch.randn(1, cam.H, cam.W, generator=gen, dtype=dt)
+
+    def run(vals):
+        s2 = s._replace(bg=s.bg.to(dt), viewmatrix=s.viewmatrix.to(dt), campos=s.campos.to(dt))
+        out = ro.rasterize(s2, vals["xyz"], vals["opacity"], vals["shs"], vals["scales"], vals["rotations"], vals["normal"])
+        return (out[0] * wc).sum() + (out[1] * wd).sum(), out
+
+    base = {k: g[k].to(dt).clone().requires_grad_(True) for k in ru.FIELDS}
+    loss, out0 = run(base)
+    loss.backward()
+    checked = 0
+    rng = np.random.RandomState(0)
+    for k in ru.FIELDS:
+        flat = base[k].detach().reshape(-1)
+        for idx in rng.choice(flat.numel(), size=min(6, flat.numel()), replace=False):
+            eps = 1e-6
+            vals_p = {q: base[q].detach().clone() for q in ru.FIELDS}
+            vals_m = {q: base[q].detach().clone() for q in ru.FIELDS}
+            vals_p[k].reshape(-1)[idx] += eps
+            vals_m[k].reshape(-1)[idx] -= eps
+            lp, op = run(vals_p)
+            lm, om = run(vals_m)
+            if not (torch.equal(op[2], om[2]) and torch.equal(op[3], om[3]) and torch.equal(op[3], out0[3])):
+                continue
+            fd = float(lp - lm) / (2 * eps)
+            an = float(base[k].grad.reshape(-1)[idx])
+            assert abs(fd - an) <= 1e-4 * max(1.0, abs(an), abs(fd)), (k, int(idx), fd, an)
+            checked += 1
+    assert checked >= 20
+
+
+def test_oracle_sentinels():
+    cam = synth.CameraSpec(40, 50, 40.0, 40.0, 24.5, 19.5)
+    s = ro.make_settings(cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, bg=torch.tensor([0.1, 0.2, 0.3]))
+    e = torch.zeros(0, 3)
+    out = ro.rasterize(s, e, torch.zeros(0, 1), torch.zeros(0, 16, 3), e, torch.zeros(0, 4), e)
+    assert out[0].shape == (3, cam.H, cam.W) and torch.allclose(out[0][:, 0, 0], torch.tensor([0.1, 0.2, 0.3]))
+    assert torch.all(out[6] == 1) and torch.all(out[2] == -1) and torch.all(out[1] == 0)
+    g, s2 = ru.make_scene(60, cam, seed=2)
+    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+    out = ro.rasterize(s2, g["xyz"], g["opacity"], g["shs"], g["scales"], g["rotations"], g["normal"],
+                       torch.zeros(gy, gx, dtype=torch.int32))
+    assert torch.all(out[6] == 1) and torch.all(out[3] == -1) and float(out[0].abs().max()) == 0
+
+
+def test_scene_generator_is_deterministic_and_wellformed():
+    a = synth.random_gaussians(500, synth.CONFIG2, seed=2024)
+    b = synth.random_gaussians(500, synth.CONFIG2, seed=2024)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert torch.allclose(a["rotations"].norm(dim=-1), torch.ones(500), atol=1e-5)
+    assert torch.allclose(a["normal"].norm(dim=-1), torch.ones(500), atol=1e-5)
+    assert float(a["scales"].min()) >= 1e-4 * 0.99 and float(a["scales"].max()) <= 0.05 * 1.01
+    assert {round(float(x), 4) for x in np.unique(a["opacity"].numpy())} <= {0.1, 0.99}

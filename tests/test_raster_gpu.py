@@ -197,10 +197,10 @@ def test_long_lists_and_depth_ties():
     from rtg_slam_amd import _lib
     lib = _lib.load()
     cam = SMALL
-    g, s = ru.make_scene(24000, cam, seed=21, r_range=(0.01, 0.08))
+    g, s = ru.make_scene(60000, cam, seed=21, r_range=(0.02, 0.1))
     g["opacity"] = torch.full_like(g["opacity"], 0.03)
-    for k in ru.FIELDS:                       # 3000 exact duplicates -> equal depth bits, different ids
-        g[k][21000:] = g[k][:3000]
+    for k in ru.FIELDS:                       # 5000 exact duplicates -> equal depth bits, different ids
+        g[k][55000:] = g[k][:5000]
     out_a, _ = ru.hip_run(s, g)
     st = (__import__("ctypes").c_int64 * 8)()
     lib.rtgs_raster_last_stats(st)
@@ -214,3 +214,21 @@ def test_long_lists_and_depth_ties():
         assert torch.equal(a, b)
     out_o, _, _ = ru.oracle_run(s, g)
     check_forward(out_a, out_o)
+
+
+def test_matches_committed_golden(golden_dir):
+    """HIP path vs the committed oracle fixture (tests/golden/raster_small.npz)."""
+    import os
+    import numpy as np
+    from oracle import raster_oracle as ro
+    z = np.load(os.path.join(golden_dir, "raster_small.npz"))
+    cam = synth.CameraSpec(64, 96, 80.0, 80.0, 47.5, 31.5)
+    g = {k: torch.from_numpy(z[f"in_{k}"]) for k in ru.FIELDS}
+    s = ro.make_settings(cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, viewmatrix=torch.from_numpy(z["viewmatrix"]))
+    grads = (torch.from_numpy(z["g_color"]), torch.from_numpy(z["g_depth"]))
+    out_h, gd_h = ru.hip_run(s, g, grads=grads)
+    ref = tuple(torch.from_numpy(z[f"out_{n}"]) for n in ["color", "depth", "cidx", "didx", "cw", "dw", "T"])
+    check_forward(out_h, ref)
+    for k in ru.FIELDS:
+        r = torch.from_numpy(z[f"grad_{k}"])
+        assert float((gd_h[k] - r).abs().max()) / (float(r.abs().max()) + 1e-12) < 1e-3, k
