@@ -71,8 +71,9 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     const uint32_t* __restrict__ n_contrib, const int32_t* __restrict__ depth_index,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     SplatGrad* __restrict__ grads) {
-  __shared__ float4 s_rec[BLOCK * 4];
+  __shared__ float4 s_rec[BLOCK * 3];
   __shared__ int32_t s_id[BLOCK];
+  __shared__ float s_hy[BLOCK];
   __shared__ float s_grad[BLOCK * NG];
 
   const int tid = threadIdx.x;
@@ -102,6 +103,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
   uint32_t pos = 0;                       // list position of the next entry
   bool done = last == 0;
   const int gidx = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
+  const float strip_y0 = (float)(blockIdx.y * TILE + (tid >> 6) * 4), strip_y1 = strip_y0 + 3.f;
 
   for (int base = 0; base < n; base += BLOCK) {
     if (__syncthreads_and(done)) break;
@@ -110,9 +112,10 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
       const uint32_t id = point_list[range.x + base + tid];
       s_id[tid] = (int32_t)id;
       const float4* src = reinterpret_cast<const float4*>(splats + id);
-      s_rec[tid * 4 + 0] = src[0];
-      s_rec[tid * 4 + 1] = src[1];
-      s_rec[tid * 4 + 2] = src[2];
+      s_rec[tid * 3 + 0] = src[0];
+      s_rec[tid * 3 + 1] = src[1];
+      s_rec[tid * 3 + 2] = src[2];
+      s_hy[tid] = reinterpret_cast<const float*>(splats + id)[15];
     }
 #pragma unroll
     for (int k = 0; k < NG; ++k) s_grad[tid * NG + k] = 0.f;
@@ -125,22 +128,25 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
       for (int k = 0; k < 8; ++k) v[k] = 0.f;
       float vop = 0.f;
       bool valid = false;
+      const float4 r0 = s_rec[j * 3 + 0];
+      const float ehy = s_hy[j];
+      const bool strip_hit = !(r0.y + ehy < strip_y0 || r0.y - ehy > strip_y1);   // wave-uniform
       if (!done) {
-        const float4 r0 = s_rec[j * 4 + 0];
-        const float4 r1 = s_rec[j * 4 + 1];
+        const float4 r1 = s_rec[j * 3 + 1];
         const float dx = r0.x - pxf, dy = r0.y - pyf;
-        const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
+        const float power = strip_hit ? splat_power(r0.z, r0.w, r1.x, dx, dy) : 1.f;
         if (!(power > 0.f)) {
           const float G = splat_exp(power);
           const float oG = r1.y * G;
           const float alpha = fminf(0.99f, oG);
           if (!(alpha < 1.f / 255.f)) {
             valid = true;
-            const float4 r2 = s_rec[j * 4 + 2];
+            const float4 r2 = s_rec[j * 3 + 2];
             const float c0 = r1.z, c1 = r1.w, c2 = r2.x;
             const float w = alpha * T;
             S0 -= c0 * w; S1 -= c1 * w; S2 -= c2 * w;            // colour strictly behind this entry
-            const float ia = 1.f / (1.f - alpha);
+            const float oma = 1.f - alpha;
+            const float ia = __builtin_amdgcn_rcpf(oma);
             const float dL_dalpha = T * (c0 * g0 + c1 * g1 + c2 * g2) - (S0 * g0 + S1 * g1 + S2 * g2 + bgT) * ia;
             v[5] = w * g0; v[6] = w * g1; v[7] = w * g2;
             if (oG <= 0.99f) {                                   // d min(0.99, oG)/d(oG): autograd of clamp
@@ -152,7 +158,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
               v[3] = gdl * (-dx * dy);
               v[4] = gdl * (-0.5f * dy * dy);
             }
-            T *= (1.f - alpha);
+            T *= oma;
           }
         }
         ++pos;
@@ -161,9 +167,9 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
       const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
       if (vm == 0ull) continue;                                   // wave-uniform
       const float r8 = butterfly8(v, lane);
-      const float ro = group8_sum(vop);
+      const float ro = wave_sum_to_lane63(vop);
       atomicAdd(&s_grad[j * NG + gidx], r8);                      // 8 groups -> 8-way same-address add
-      if ((lane & 7) == 0) atomicAdd(&s_grad[j * NG + 8], ro);
+      if (lane == 63) atomicAdd(&s_grad[j * NG + 8], ro);
     }
     __syncthreads();
     if (tid < m) {

@@ -21,7 +21,7 @@ struct __attribute__((aligned(16))) Splat {
   float nx, ny, nz;    // camera-space plane normal
   float pd;            // plane offset n_c . p_c
   float z;             // camera-space depth of the centre
-  float pad0, pad1;
+  float hx, hy;        // half extents of the alpha >= 1/255 region (pixels, with margin); 0 = unknown
 };
 static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
 

@@ -160,7 +160,14 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   s.nx = ncx; s.ny = ncy; s.nz = ncz;
   s.pd = ncx * pcx + ncy * pcy + ncz * pcz;
   s.z = pcz;
-  s.pad0 = 0.f; s.pad1 = 0.f;
+  {
+    // |dx| <= sqrt(thr * Sigma2D_xx) wherever alpha >= 1/255 (thr = 2 ln(255 o)); Sigma2D = (ca cb; cb cc).
+    // 1 % + 0.5 px margin; a non-positive threshold means the Gaussian is invisible everywhere.
+    const float thr = 2.f * __logf(255.f * fmaxf(opac[i], 1e-12f));
+    const float m = fmaxf(thr, 0.f) * 1.01f;
+    s.hx = sqrtf(m * ca) + 0.5f;
+    s.hy = sqrtf(m * cc) + 0.5f;
+  }
   float4* dst = reinterpret_cast<float4*>(splats + i);
   const float4* src = reinterpret_cast<const float4*>(&s);
   dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
@@ -227,6 +234,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     unsigned long long* __restrict__ counters) {
   __shared__ float4 s_rec[BLOCK * 4];
   __shared__ int32_t s_id[BLOCK];
+  __shared__ float s_hy[BLOCK];
 
   const int tid = threadIdx.x;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
@@ -236,6 +244,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
   const float pxf = (float)px, pyf = (float)py;
   const uint2 range = ranges[tile];
   const int n = (int)(range.y - range.x);
+  const float strip_y0 = (float)(blockIdx.y * TILE + (tid >> 6) * 4), strip_y1 = strip_y0 + 3.f;
 
   bool done = !inside;
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
@@ -256,15 +265,20 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
       s_rec[tid * 4 + 0] = src[0];
       s_rec[tid * 4 + 1] = src[1];
       s_rec[tid * 4 + 2] = src[2];
-      s_rec[tid * 4 + 3] = src[3];
+      const float4 r3 = src[3];
+      s_rec[tid * 4 + 3] = r3;
+      s_hy[tid] = r3.w;
     }
     __syncthreads();
     for (int j = 0; j < m; ++j) {
       if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;   // whole wave finished
       if (done) continue;
       ++contributor;
-      ++evals;
       const float4 r0 = s_rec[j * 4 + 0];   // u v ca cb
+      // wave-uniform: the entry's alpha >= 1/255 region misses this wave's 16x4 pixel strip
+      const float ehy = s_hy[j];
+      if (r0.y + ehy < strip_y0 || r0.y - ehy > strip_y1) continue;
+      ++evals;
       const float4 r1 = s_rec[j * 4 + 1];   // cc o r g
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
