@@ -65,7 +65,9 @@ def main():
     N = args.gaussians
     g = synth.random_gaussians(N, cam, seed=2024)                 # same map on every rank
     packed = mo.pack_from_activated({k: v.to(dev) for k, v in g.items()})
-    opt = mo.ShardedMapOptimizer(packed)
+    # learning rates x1e-4: the targets are random images, at the reference's rates the map would
+    # inflate within a few hundred steps and the workload would drift; Adam does identical work.
+    opt = mo.ShardedMapOptimizer(packed, lr_col=mo.default_lr_columns() * 1e-4)
 
     # this rank's view: a small pose offset per rank (sliding-window views of one map)
     c2w = synth.look_at_pose(seed=100 + rank, max_angle_deg=2.0, max_trans=0.05) if world > 1 else torch.eye(4, dtype=torch.float64)
@@ -115,7 +117,7 @@ def main():
     # run the real workload for ~1.5 s before the W warm-up steps the contract asks for
     t_pre = time.perf_counter()
     n_pre = 0
-    while n_pre < 20 or time.perf_counter() - t_pre < 1.5:
+    while n_pre < 20 or (time.perf_counter() - t_pre < 1.5 and n_pre < 400):
         frame()
         n_pre += 1
         if n_pre % 20 == 0:

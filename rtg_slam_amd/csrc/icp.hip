@@ -17,7 +17,8 @@ constexpr int PSTRIDE = 32;         // floats per block partial
 struct Scratch {
   uint32_t minmax[2 * RTGS_ICP_MAX_LEVELS];   // per level: enc(min), ~enc(max)
   float partials[MAX_BLOCKS * PSTRIDE];
-  float k_level[16];
+  uint32_t ticket;                            // arrival counter of the residual kernel's workgroups
+  uint32_t pad[15];
 };
 
 __device__ __forceinline__ uint32_t enc_f(float f) {
@@ -148,96 +149,28 @@ __device__ __forceinline__ void block_write_partials(float (&acc)[NACC], float* 
   }
 }
 
-// ---- K12: residual + Jacobian + 6x6 reduction (icp.py:52-119) ---------------------------------
-// K points at the FULL-resolution intrinsics; `ds` is the level's downscale (icp.py:431-433).
-__global__ void __launch_bounds__(256) icp_reduce_kernel(
-    const float* __restrict__ vs, const float* __restrict__ ns, const float* __restrict__ vt,
-    const float* __restrict__ nt, int H, int W, const float* __restrict__ K, float ds,
-    const float* __restrict__ pose, float dist_thr, float cos_thr, float* __restrict__ partials) {
-  const float R00 = pose[0], R01 = pose[1], R02 = pose[2], t0 = pose[3];
-  const float R10 = pose[4], R11 = pose[5], R12 = pose[6], t1 = pose[7];
-  const float R20 = pose[8], R21 = pose[9], R22 = pose[10], t2 = pose[11];
-  const float fx = K[0] * ds, fy = K[4] * ds, cx = K[2] * ds, cy = K[5] * ds;
-  const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1);
-  const float hw = Wm1 / 2.f, hh = Hm1 / 2.f;
-  float acc[NACC];
-#pragma unroll
-  for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
-
-  const int n = H * W;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
-    const float v0 = vs[(size_t)idx * 3], v1 = vs[(size_t)idx * 3 + 1], v2 = vs[(size_t)idx * 3 + 2];
-    const float px = (R00 * v0 + R01 * v1 + R02 * v2) + t0;
-    const float py = (R10 * v0 + R11 * v1 + R12 * v2) + t1;
-    const float pz = (R20 * v0 + R21 * v1 + R22 * v2) + t2;
-    const float u = (px / pz) * fx + cx;
-    const float v = (py / pz) * fy + cy;
-    const bool inview = (u > 0.f) && (u < Wm1) && (v > 0.f) && (v < Hm1);
-    if (!inview || !(v2 > 0.f)) continue;
-    // grid_sample(nearest, border, align_corners=True) of warp_features (icp.py:132-148)
-    const float un = u / hw - 1.f, vn = v / hh - 1.f;
-    float ix = ((un + 1.f) / 2.f) * Wm1, iy = ((vn + 1.f) / 2.f) * Hm1;
-    ix = fminf(Wm1, fmaxf(ix, 0.f));
-    iy = fminf(Hm1, fmaxf(iy, 0.f));
-    const int xi = (int)nearbyintf(ix), yi = (int)nearbyintf(iy);
-    const size_t j = ((size_t)yi * W + xi) * 3;
-    const float q0 = vt[j], q1 = vt[j + 1], q2 = vt[j + 2];
-    if (!(q2 > 0.f)) continue;
-    const float m0 = nt[j], m1 = nt[j + 1], m2 = nt[j + 2];
-    const float n0 = ns[(size_t)idx * 3], n1 = ns[(size_t)idx * 3 + 1], n2 = ns[(size_t)idx * 3 + 2];
-    const float rn0 = R00 * n0 + R01 * n1 + R02 * n2;
-    const float rn1 = R10 * n0 + R11 * n1 + R12 * n2;
-    const float rn2 = R20 * n0 + R21 * n1 + R22 * n2;
-    if (!(rn0 * m0 + rn1 * m1 + rn2 * m2 > cos_thr)) continue;
-    const float d0 = px - q0, d1 = py - q1, d2 = pz - q2;
-    if (sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > dist_thr) continue;
-    const float r = m0 * d0 + m1 * d1 + m2 * d2;
-    float J[6];
-    J[0] = py * m2 - pz * m1;        // -(m^T [p]x) = p x m
-    J[1] = pz * m0 - px * m2;
-    J[2] = px * m1 - py * m0;
-    J[3] = m0; J[4] = m1; J[5] = m2;
-    int k = 0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
-    acc[27] += 1.f;
-  }
-  block_write_partials(acc, partials);
-}
-
-// ---- point2plane_loss (icp.py:7-13) at one level: sum(((R v1 + t - v0) . n0)^2) ---------------
-__global__ void __launch_bounds__(256) icp_p2p_kernel(const float* __restrict__ vs, const float* __restrict__ vt,
-                                                      const float* __restrict__ nt, int n,
-                                                      const float* __restrict__ pose, float* __restrict__ partials) {
-  const float R00 = pose[0], R01 = pose[1], R02 = pose[2], t0 = pose[3];
-  const float R10 = pose[4], R11 = pose[5], R12 = pose[6], t1 = pose[7];
-  const float R20 = pose[8], R21 = pose[9], R22 = pose[10], t2 = pose[11];
-  float acc[NACC];
-#pragma unroll
-  for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
-    const size_t j = (size_t)idx * 3;
-    const float v0 = vs[j], v1 = vs[j + 1], v2 = vs[j + 2];
-    const float px = (v0 * R00 + v1 * R01 + v2 * R02) + t0;
-    const float py = (v0 * R10 + v1 * R11 + v2 * R12) + t1;
-    const float pz = (v0 * R20 + v1 * R21 + v2 * R22) + t2;
-    const float l = (px - vt[j]) * nt[j] + (py - vt[j + 1]) * nt[j + 1] + (pz - vt[j + 2]) * nt[j + 2];
-    acc[0] += l * l;
-  }
-  block_write_partials(acc, partials);
-}
-
 // ---- K13: final reduction + damped 6x6 solve + SE(3) exp update, one workgroup ------------------
 enum { MODE_SOLVE = 0, MODE_EQUATIONS = 1, MODE_P2P = 2 };
 
-__global__ void __launch_bounds__(256) icp_final_kernel(const float* __restrict__ partials, int nblocks, int mode,
-                                                        float damping, float inv_pixels, float* __restrict__ pose,
-                                                        float* __restrict__ stats, float* __restrict__ JtJ_out,
-                                                        float* __restrict__ Jtr_out, float* __restrict__ nvalid_out) {
+struct FinalArgs {
+  int mode;
+  float damping, inv_pixels;
+  float* pose;
+  float* stats;
+  float* JtJ_out;
+  float* Jtr_out;
+  float* nvalid_out;
+};
+
+// Executed by ONE whole workgroup (256 threads): the last one to arrive in the residual kernel.
+__device__ __forceinline__ void final_stage(const float* __restrict__ partials, int nblocks, const FinalArgs& fa) {
+  const int mode = fa.mode;
+  const float damping = fa.damping, inv_pixels = fa.inv_pixels;
+  float* __restrict__ pose = fa.pose;
+  float* __restrict__ stats = fa.stats;
+  float* __restrict__ JtJ_out = fa.JtJ_out;
+  float* __restrict__ Jtr_out = fa.Jtr_out;
+  float* __restrict__ nvalid_out = fa.nvalid_out;
   __shared__ double s_sum[8 * PSTRIDE];
   const int grp = threadIdx.x >> 5, k = threadIdx.x & 31;
   double a = 0.0;
@@ -375,6 +308,116 @@ __global__ void __launch_bounds__(256) icp_final_kernel(const float* __restrict_
     }
 }
 
+// Publish this workgroup's partial row and elect the last arriver (agent-scope release / acquire,
+// cdna_hip_programming.md Guideline 16 counter form).  Returns true in every thread of the LAST
+// workgroup, after which plain loads of all partial rows are safe.  The ticket is re-armed by the
+// last workgroup (and zeroed once per track by a memset node on the stream).
+__device__ __forceinline__ bool arrive_and_elect_last(uint32_t* ticket) {
+  __shared__ uint32_t s_is_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t last = (t == gridDim.x - 1) ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_is_last = last;
+  }
+  __syncthreads();
+  return s_is_last != 0;
+}
+
+// ---- K12: residual + Jacobian + 6x6 reduction (icp.py:52-119) ---------------------------------
+// K points at the FULL-resolution intrinsics; `ds` is the level's downscale (icp.py:431-433).
+__global__ void __launch_bounds__(256) icp_reduce_kernel(
+    const float* __restrict__ vs, const float* __restrict__ ns, const float* __restrict__ vt,
+    const float* __restrict__ nt, int H, int W, const float* __restrict__ K, float ds,
+    const float* __restrict__ pose, float dist_thr, float cos_thr, float* __restrict__ partials,
+    uint32_t* __restrict__ ticket, FinalArgs fa) {
+  const float R00 = pose[0], R01 = pose[1], R02 = pose[2], t0 = pose[3];
+  const float R10 = pose[4], R11 = pose[5], R12 = pose[6], t1 = pose[7];
+  const float R20 = pose[8], R21 = pose[9], R22 = pose[10], t2 = pose[11];
+  const float fx = K[0] * ds, fy = K[4] * ds, cx = K[2] * ds, cy = K[5] * ds;
+  const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1);
+  const float hw = Wm1 / 2.f, hh = Hm1 / 2.f;
+  float acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+
+  const int n = H * W;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+    const float v0 = vs[(size_t)idx * 3], v1 = vs[(size_t)idx * 3 + 1], v2 = vs[(size_t)idx * 3 + 2];
+    const float px = (R00 * v0 + R01 * v1 + R02 * v2) + t0;
+    const float py = (R10 * v0 + R11 * v1 + R12 * v2) + t1;
+    const float pz = (R20 * v0 + R21 * v1 + R22 * v2) + t2;
+    const float u = (px / pz) * fx + cx;
+    const float v = (py / pz) * fy + cy;
+    const bool inview = (u > 0.f) && (u < Wm1) && (v > 0.f) && (v < Hm1);
+    if (!inview || !(v2 > 0.f)) continue;
+    // grid_sample(nearest, border, align_corners=True) of warp_features (icp.py:132-148)
+    const float un = u / hw - 1.f, vn = v / hh - 1.f;
+    float ix = ((un + 1.f) / 2.f) * Wm1, iy = ((vn + 1.f) / 2.f) * Hm1;
+    ix = fminf(Wm1, fmaxf(ix, 0.f));
+    iy = fminf(Hm1, fmaxf(iy, 0.f));
+    const int xi = (int)nearbyintf(ix), yi = (int)nearbyintf(iy);
+    const size_t j = ((size_t)yi * W + xi) * 3;
+    const float q0 = vt[j], q1 = vt[j + 1], q2 = vt[j + 2];
+    if (!(q2 > 0.f)) continue;
+    const float m0 = nt[j], m1 = nt[j + 1], m2 = nt[j + 2];
+    const float n0 = ns[(size_t)idx * 3], n1 = ns[(size_t)idx * 3 + 1], n2 = ns[(size_t)idx * 3 + 2];
+    const float rn0 = R00 * n0 + R01 * n1 + R02 * n2;
+    const float rn1 = R10 * n0 + R11 * n1 + R12 * n2;
+    const float rn2 = R20 * n0 + R21 * n1 + R22 * n2;
+    if (!(rn0 * m0 + rn1 * m1 + rn2 * m2 > cos_thr)) continue;
+    const float d0 = px - q0, d1 = py - q1, d2 = pz - q2;
+    if (sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > dist_thr) continue;
+    const float r = m0 * d0 + m1 * d1 + m2 * d2;
+    float J[6];
+    J[0] = py * m2 - pz * m1;        // -(m^T [p]x) = p x m
+    J[1] = pz * m0 - px * m2;
+    J[2] = px * m1 - py * m0;
+    J[3] = m0; J[4] = m1; J[5] = m2;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+    acc[27] += 1.f;
+  }
+  block_write_partials(acc, partials);
+  if (arrive_and_elect_last(ticket)) final_stage(partials, (int)gridDim.x, fa);
+}
+
+// ---- point2plane_loss (icp.py:7-13) at one level: sum(((R v1 + t - v0) . n0)^2) ---------------
+__global__ void __launch_bounds__(256) icp_p2p_kernel(const float* __restrict__ vs, const float* __restrict__ vt,
+                                                      const float* __restrict__ nt, int n,
+                                                      const float* __restrict__ pose, float* __restrict__ partials,
+                                                      uint32_t* __restrict__ ticket, FinalArgs fa) {
+  const float R00 = pose[0], R01 = pose[1], R02 = pose[2], t0 = pose[3];
+  const float R10 = pose[4], R11 = pose[5], R12 = pose[6], t1 = pose[7];
+  const float R20 = pose[8], R21 = pose[9], R22 = pose[10], t2 = pose[11];
+  float acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+    const size_t j = (size_t)idx * 3;
+    const float v0 = vs[j], v1 = vs[j + 1], v2 = vs[j + 2];
+    const float px = (v0 * R00 + v1 * R01 + v2 * R02) + t0;
+    const float py = (v0 * R10 + v1 * R11 + v2 * R12) + t1;
+    const float pz = (v0 * R20 + v1 * R21 + v2 * R22) + t2;
+    const float l = (px - vt[j]) * nt[j] + (py - vt[j + 1]) * nt[j + 1] + (pz - vt[j + 2]) * nt[j + 2];
+    acc[0] += l * l;
+  }
+  block_write_partials(acc, partials);
+  if (arrive_and_elect_last(ticket)) final_stage(partials, (int)gridDim.x, fa);
+}
+
 // ---- model-depth hole filling (icp.py:397-415) ------------------------------------------------
 __global__ void __launch_bounds__(256) icp_fill_kernel(float* __restrict__ rd, const float* __restrict__ fd,
                                                        const float* __restrict__ rn, const float* __restrict__ fn,
@@ -444,10 +487,10 @@ int rtgs_icp_step(const float* vs, const float* ns, const float* vt, const float
   hipStream_t st = (hipStream_t)stream;
   Scratch* sc = (Scratch*)scratch;
   const int g = grid_for(H * W);
+  ICP_TRY(hipMemsetAsync(&sc->ticket, 0, sizeof(uint32_t), st));
+  FinalArgs fa{(int)MODE_EQUATIONS, 0.f, 0.f, nullptr, nullptr, JtJ_out, Jtr_out, nvalid_out};
   hipLaunchKernelGGL(icp_reduce_kernel, dim3(g), dim3(256), 0, st, vs, ns, vt, nt, H, W, K, 1.0f, pose, dist_thr,
-                     cos_thr, sc->partials);
-  hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(256), 0, st, (const float*)sc->partials, g, (int)MODE_EQUATIONS,
-                     0.f, 0.f, (float*)nullptr, (float*)nullptr, JtJ_out, Jtr_out, nvalid_out);
+                     cos_thr, sc->partials, &sc->ticket, fa);
   ICP_TRY(hipGetLastError());
   return 0;
 }
@@ -458,26 +501,25 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
   hipStream_t st = (hipStream_t)stream;
   Scratch* sc = (Scratch*)scratch;
   ICP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
+  ICP_TRY(hipMemsetAsync(&sc->ticket, 0, sizeof(uint32_t), st));
   for (int l = 0; l < n_levels; ++l) {
     const rtgs_icp_level& L = lv[l];
     if (!L.vertex_src || !L.normal_src || !L.vertex_tgt || !L.normal_tgt || L.H <= 0 || L.W <= 0 || L.iters < 0)
       return -1;
     const int g = grid_for(L.H * L.W);
     const float inv = 1.f / ((float)L.H * (float)L.W);
-    for (int it = 0; it < L.iters; ++it) {
+    FinalArgs fa{(int)MODE_SOLVE, damping, inv, pose, stats, nullptr, nullptr, nullptr};
+    for (int it = 0; it < L.iters; ++it)   // ONE launch per Gauss-Newton iteration: residuals + solve + pose update
       hipLaunchKernelGGL(icp_reduce_kernel, dim3(g), dim3(256), 0, st, L.vertex_src, L.normal_src, L.vertex_tgt,
-                         L.normal_tgt, L.H, L.W, K, L.downscale, (const float*)pose, dist_thr, cos_thr, sc->partials);
-      hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(256), 0, st, (const float*)sc->partials, g, (int)MODE_SOLVE,
-                         damping, inv, pose, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr);
-    }
+                         L.normal_tgt, L.H, L.W, K, L.downscale, (const float*)pose, dist_thr, cos_thr, sc->partials,
+                         &sc->ticket, fa);
   }
   const rtgs_icp_level& F = lv[n_levels - 1];
   const int n = F.H * F.W;
   const int g = grid_for(n);
+  FinalArgs fp{(int)MODE_P2P, 0.f, 1.f / (float)n, pose, stats, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(icp_p2p_kernel, dim3(g), dim3(256), 0, st, F.vertex_src, F.vertex_tgt, F.normal_tgt, n,
-                     (const float*)pose, sc->partials);
-  hipLaunchKernelGGL(icp_final_kernel, dim3(1), dim3(256), 0, st, (const float*)sc->partials, g, (int)MODE_P2P, 0.f,
-                     1.f / (float)n, pose, stats, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                     (const float*)pose, sc->partials, &sc->ticket, fp);
   ICP_TRY(hipGetLastError());
   return 0;
 }

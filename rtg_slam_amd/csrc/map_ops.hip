@@ -23,13 +23,13 @@ __global__ void __launch_bounds__(256) activate_fwd_kernel(const float* __restri
                                                            float* __restrict__ shs, float* __restrict__ scales,
                                                            float* __restrict__ rots, float* __restrict__ normal) {
   // phase 1: the 51 pass-through columns (xyz + SH), coalesced over the flattened buffer
-  const int64_t total = n * COLS;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = e / COLS;
-    const int c = (int)(e - row * COLS);
+  const uint32_t total = (uint32_t)n * COLS;          // launcher guarantees n * 59 < 2^32
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const uint32_t row = e / COLS;                    // constant divisor: mul-hi, no 64-bit division
+    const uint32_t c = e - row * COLS;
     const float v = packed[e];
-    if (c < 3) xyz[row * 3 + c] = v;
-    else if (c < 51) shs[row * 48 + (c - 3)] = v;
+    if (c < 3) xyz[(size_t)row * 3 + c] = v;
+    else if (c < 51) shs[(size_t)row * 48 + (c - 3)] = v;
   }
   // phase 2: one lane per Gaussian for the activated columns
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -57,12 +57,12 @@ __global__ void __launch_bounds__(256) activate_bwd_kernel(const float* __restri
                                                            const float* __restrict__ g_shs, const float* __restrict__ g_sc,
                                                            const float* __restrict__ g_rot, const float* __restrict__ g_nrm,
                                                            float* __restrict__ g_packed) {
-  const int64_t total = n * COLS;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = e / COLS;
-    const int c = (int)(e - row * COLS);
-    if (c < 3) g_packed[e] = g_xyz[row * 3 + c];
-    else if (c < 51) g_packed[e] = g_shs[row * 48 + (c - 3)];
+  const uint32_t total = (uint32_t)n * COLS;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const uint32_t row = e / COLS;
+    const uint32_t c = e - row * COLS;
+    if (c < 3) g_packed[e] = g_xyz[(size_t)row * 3 + c];
+    else if (c < 51) g_packed[e] = g_shs[(size_t)row * 48 + (c - 3)];
   }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float* p = packed + i * COLS;
@@ -117,7 +117,8 @@ __global__ void __launch_bounds__(256) activate_bwd_kernel(const float* __restri
 
 extern "C" int rtgs_map_activate_forward(const float* packed, int64_t n, float* xyz, float* opacity, float* shs,
                                          float* scales, float* rotations, float* normal, void* stream) {
-  if (n < 0 || (n > 0 && (!packed || !xyz || !opacity || !shs || !scales || !rotations || !normal))) return -1;
+  if (n < 0 || n > 72000000 || (n > 0 && (!packed || !xyz || !opacity || !shs || !scales || !rotations || !normal)))
+    return -1;                                       // 72 M x 59 < 2^32 (32-bit flattened index)
   if (n == 0) return 0;
   int64_t blocks = (n * rtgs::COLS + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -129,7 +130,7 @@ extern "C" int rtgs_map_activate_forward(const float* packed, int64_t n, float* 
 extern "C" int rtgs_map_activate_backward(const float* packed, int64_t n, const float* g_xyz, const float* g_opacity,
                                           const float* g_shs, const float* g_scales, const float* g_rotations,
                                           const float* g_normal, float* g_packed, void* stream) {
-  if (n < 0 || (n > 0 && (!packed || !g_xyz || !g_opacity || !g_shs || !g_scales || !g_rotations || !g_normal || !g_packed)))
+  if (n < 0 || n > 72000000 || (n > 0 && (!packed || !g_xyz || !g_opacity || !g_shs || !g_scales || !g_rotations || !g_normal || !g_packed)))
     return -1;
   if (n == 0) return 0;
   int64_t blocks = (n * rtgs::COLS + 255) / 256;

@@ -213,10 +213,12 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   uint32_t longest = 0;
   bool sort_path = (size_t)ntiles > bin_lds_limit_tiles() || g_force_sort_path;
   if (P > 0) {
-    launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
-    DBG(s, st);
-    launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sat, splats, tiles_touched, radii,
-                          clamped, out_radii, st);
+    if (sort_path) {   // only the fallback path needs the 3-sigma-rect tile counts
+      launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
+      DBG(s, st);
+    }
+    launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sort_path ? sat : nullptr, splats,
+                          tiles_touched, radii, clamped, out_radii, st);
     DBG(s, st);
     prof_mark(EV_PRE, st);
     if (!sort_path) {
@@ -230,7 +232,13 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       HIP_TRY(hipStreamSynchronize(st));
       R = (int64_t)h[0];
       longest = h[1];
-      if ((int)longest > bin_sort_capacity()) sort_path = true;   // a tile list too long for the LDS sort
+      if ((int)longest > bin_sort_capacity()) {   // a tile list too long for the LDS sort: redo with rect counts
+        sort_path = true;
+        launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
+        launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sat, splats, tiles_touched,
+                              radii, clamped, out_radii, st);
+        DBG(s, st);
+      }
     }
     if (sort_path) {
       size_t tb = G.scan_temp_bytes;

@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256) fused_adam_kernel(float* __restrict__ p, 
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
     m[i] = mi; v[i] = vi;
-    const float lr = lr_col[(int)(i % C)];
+    const float lr = lr_col[(int)((unsigned long long)i % (unsigned)C)];
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] -= (lr / bc1) * (mi / denom);
   }

@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   tile_rect(u, v, radius, p.gx, p.gy, x0, y0, x1, y1);
   if ((x1 - x0) * (y1 - y0) == 0) return;
   const int sw = p.gx + 1;
-  const int touched = sat[y1 * sw + x1] - sat[y0 * sw + x1] - sat[y1 * sw + x0] + sat[y0 * sw + x0];
+  const int touched = sat ? sat[y1 * sw + x1] - sat[y0 * sw + x1] - sat[y1 * sw + x0] + sat[y0 * sw + x0]
+                          : (x1 - x0) * (y1 - y0);   // LDS binning path recounts exactly; this is a bound
 
   // view-dependent colour (utils/sh_utils.py:57-120 basis), clamped at 0
   float dxw = mx - p.campos[0], dyw = my - p.campos[1], dzw = mz - p.campos[2];
