@@ -10,7 +10,7 @@
 
 namespace rtgs_icp {
 
-constexpr int MAX_BLOCKS = 1024;    // residual workgroups (4 per CU: the gathers are latency-bound)
+constexpr int MAX_BLOCKS = 512;     // residual workgroups (2 per CU)
 constexpr int NACC = 28;            // 21 upper-triangular JtJ + 6 Jtr + 1 valid count
 constexpr int PSTRIDE = 32;         // floats per block partial
 
@@ -144,13 +144,19 @@ __device__ __forceinline__ void block_write_partials(float (&acc)[NACC], float* 
   __syncthreads();
   if (threadIdx.x < NACC) {
     const int k = threadIdx.x;
-    partials[(size_t)blockIdx.x * PSTRIDE + k] =
-        (s_part[k] + s_part[PSTRIDE + k]) + (s_part[2 * PSTRIDE + k] + s_part[3 * PSTRIDE + k]);
+    // write-through (sc1) store: visible to the electing workgroup without an L2 write-back fence
+    __hip_atomic_store(&partials[(size_t)blockIdx.x * PSTRIDE + k],
+                       (s_part[k] + s_part[PSTRIDE + k]) + (s_part[2 * PSTRIDE + k] + s_part[3 * PSTRIDE + k]),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 // ---- K13: final reduction + damped 6x6 solve + SE(3) exp update, one workgroup ------------------
 enum { MODE_SOLVE = 0, MODE_EQUATIONS = 1, MODE_P2P = 2 };
+
+__device__ __forceinline__ float ld_sc1(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 struct FinalArgs {
   int mode;
@@ -177,11 +183,11 @@ __device__ __forceinline__ void final_stage(const float* __restrict__ partials, 
   if (k < NACC) {
     int b = grp;
     for (; b + 24 < nblocks; b += 32) {              // 4 independent loads in flight
-      const float p0 = partials[(size_t)b * PSTRIDE + k], p1 = partials[(size_t)(b + 8) * PSTRIDE + k];
-      const float p2 = partials[(size_t)(b + 16) * PSTRIDE + k], p3 = partials[(size_t)(b + 24) * PSTRIDE + k];
+      const float p0 = ld_sc1(&partials[(size_t)b * PSTRIDE + k]), p1 = ld_sc1(&partials[(size_t)(b + 8) * PSTRIDE + k]);
+      const float p2 = ld_sc1(&partials[(size_t)(b + 16) * PSTRIDE + k]), p3 = ld_sc1(&partials[(size_t)(b + 24) * PSTRIDE + k]);
       a += ((double)p0 + (double)p1) + ((double)p2 + (double)p3);
     }
-    for (; b < nblocks; b += 8) a += (double)partials[(size_t)b * PSTRIDE + k];
+    for (; b < nblocks; b += 8) a += (double)ld_sc1(&partials[(size_t)b * PSTRIDE + k]);
   }
   s_sum[grp * PSTRIDE + k] = a;
   __syncthreads();
@@ -308,23 +314,19 @@ __device__ __forceinline__ void final_stage(const float* __restrict__ partials, 
     }
 }
 
-// Publish this workgroup's partial row and elect the last arriver (agent-scope release / acquire,
-// cdna_hip_programming.md Guideline 16 counter form).  Returns true in every thread of the LAST
-// workgroup, after which plain loads of all partial rows are safe.  The ticket is re-armed by the
-// last workgroup (and zeroed once per track by a memset node on the stream).
+// Publish this workgroup's partial row and elect the last arriver.  Hand-off form (cdna_hip_programming.md
+// Guideline 16, write-through variant): the producer stores its row with sc1 (agent-scope relaxed atomic
+// stores), drains them (vmcnt(0)), then takes a ticket; the last arriver reads every row with sc1 loads -
+// no L2 write-back / invalidate fence on either side.  The ticket is re-armed by the last workgroup
+// (and zeroed once per call by a memset node on the stream).
 __device__ __forceinline__ bool arrive_and_elect_last(uint32_t* ticket) {
   __shared__ uint32_t s_is_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t last = (t == gridDim.x - 1) ? 1u : 0u;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_is_last = last;
   }
   __syncthreads();

@@ -256,9 +256,15 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
   if (!touched) {   // exact zeros for Gaussians that reached no pixel (mapper.py:455)
     d_means[3 * i] = d_means[3 * i + 1] = d_means[3 * i + 2] = 0.f;
     d_opac[i] = 0.f;
-    for (int k = 0; k < p.M * 3; ++k) dsh[k] = 0.f;
+    if (p.M == 16) {
+      float4* d4 = reinterpret_cast<float4*>(dsh);
+#pragma unroll
+      for (int q = 0; q < 12; ++q) d4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (int k = 0; k < p.M * 3; ++k) dsh[k] = 0.f;
+    }
     d_scales[3 * i] = d_scales[3 * i + 1] = d_scales[3 * i + 2] = 0.f;
-    d_rots[4 * i] = d_rots[4 * i + 1] = d_rots[4 * i + 2] = d_rots[4 * i + 3] = 0.f;
+    reinterpret_cast<float4*>(d_rots)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     d_normal[3 * i] = d_normal[3 * i + 1] = d_normal[3 * i + 2] = 0.f;
     return;
   }
@@ -271,7 +277,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
   const float iz = 1.f / pcz, iz2 = iz * iz, iz3 = iz2 * iz;
 
   // ---- forward recompute: Sigma3D, T = J Wr, Sigma2D
-  const float qr = rots[4 * i], qx = rots[4 * i + 1], qy = rots[4 * i + 2], qz = rots[4 * i + 3];
+  const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
+  const float qr = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
   const float s0 = scales[3 * i] * p.scale_modifier, s1 = scales[3 * i + 1] * p.scale_modifier,
               s2 = scales[3 * i + 2] * p.scale_modifier;
   const float R[9] = {1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qr * qz), 2.f * (qx * qz + qr * qy),
@@ -366,10 +373,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
   const float G00 = dM[0] * s0, G01 = dM[1] * s1, G02 = dM[2] * s2;
   const float G10 = dM[3] * s0, G11 = dM[4] * s1, G12 = dM[5] * s2;
   const float G20 = dM[6] * s0, G21 = dM[7] * s1, G22 = dM[8] * s2;
-  d_rots[4 * i] = 2.f * (-qz * G01 + qy * G02 + qz * G10 - qx * G12 - qy * G20 + qx * G21);
-  d_rots[4 * i + 1] = 2.f * (qy * G01 + qz * G02 + qy * G10 - 2.f * qx * G11 - qr * G12 + qz * G20 + qr * G21 - 2.f * qx * G22);
-  d_rots[4 * i + 2] = 2.f * (-2.f * qy * G00 + qx * G01 + qr * G02 + qx * G10 + qz * G12 - qr * G20 + qz * G21 - 2.f * qy * G22);
-  d_rots[4 * i + 3] = 2.f * (-2.f * qz * G00 - qr * G01 + qx * G02 + qr * G10 - 2.f * qz * G11 + qy * G12 + qx * G20 + qy * G21);
+  reinterpret_cast<float4*>(d_rots)[i] = make_float4(
+      2.f * (-qz * G01 + qy * G02 + qz * G10 - qx * G12 - qy * G20 + qx * G21),
+      2.f * (qy * G01 + qz * G02 + qy * G10 - 2.f * qx * G11 - qr * G12 + qz * G20 + qr * G21 - 2.f * qx * G22),
+      2.f * (-2.f * qy * G00 + qx * G01 + qr * G02 + qx * G10 + qz * G12 - qr * G20 + qz * G21 - 2.f * qy * G22),
+      2.f * (-2.f * qz * G00 - qr * G01 + qx * G02 + qr * G10 - 2.f * qz * G11 + qy * G12 + qx * G20 + qy * G21));
 
   // ---- colour: rgb = max(SH(dir) + 0.5, 0)
   float ddx = mx - p.campos[0], ddy = my - p.campos[1], ddz = mz - p.campos[2];
@@ -378,7 +386,20 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
   const float x = ddx * il, y = ddy * il, z = ddz * il;
   const uint8_t cl = clamped[i];
   const float gc[3] = {(cl & 1) ? 0.f : g.dr, (cl & 2) ? 0.f : g.dg, (cl & 4) ? 0.f : g.db};
-  const float* sh = shs + (size_t)i * p.M * 3;
+  float shv[48];
+  if (p.M == 16) {
+    const float4* sh4 = reinterpret_cast<const float4*>(shs + (size_t)i * 48);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      const float4 t = sh4[q];
+      shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w;
+    }
+  } else {
+    const float* shp = shs + (size_t)i * p.M * 3;
+#pragma unroll
+    for (int q = 0; q < 48; ++q) shv[q] = (q < p.M * 3) ? shp[q] : 0.f;
+  }
+  const float* sh = shv;
   float dRdx = 0.f, dRdy = 0.f, dRdz = 0.f;   // dL/d(dir)
   const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
   float basis[16];
@@ -391,9 +412,21 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
   basis[13] = RTGS_SH_C3_4 * x * (4.f * zz - xx - yy); basis[14] = RTGS_SH_C3_5 * z * (xx - yy);
   basis[15] = RTGS_SH_C3_6 * x * (xx - 3.f * yy);
   const int ncoef = (p.deg + 1) * (p.deg + 1);
-  for (int k = 0; k < p.M; ++k) {
-    const float bk = (k < ncoef) ? basis[k] : 0.f;
-    dsh[3 * k] = bk * gc[0]; dsh[3 * k + 1] = bk * gc[1]; dsh[3 * k + 2] = bk * gc[2];
+  if (p.M == 16) {
+    float o[48];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float bk = (k < ncoef) ? basis[k] : 0.f;
+      o[3 * k] = bk * gc[0]; o[3 * k + 1] = bk * gc[1]; o[3 * k + 2] = bk * gc[2];
+    }
+    float4* d4 = reinterpret_cast<float4*>(dsh);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) d4[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+  } else {
+    for (int k = 0; k < p.M; ++k) {
+      const float bk = (k < ncoef) ? basis[k] : 0.f;
+      dsh[3 * k] = bk * gc[0]; dsh[3 * k + 1] = bk * gc[1]; dsh[3 * k + 2] = bk * gc[2];
+    }
   }
   // d(basis_k)/d(x,y,z) contracted with sum_c gc[c] * sh[k][c]
   auto shg = [&](int k) { return gc[0] * sh[3 * k] + gc[1] * sh[3 * k + 1] + gc[2] * sh[3 * k + 2]; };

@@ -64,7 +64,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   if (!(pcz > 0.2f)) return;
 
   // Sigma3D = (R S)(R S)^T
-  const float qr = rots[4 * i], qx = rots[4 * i + 1], qy = rots[4 * i + 2], qz = rots[4 * i + 3];
+  const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
+  const float qr = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
   const float sx = scales[3 * i] * p.scale_modifier, sy = scales[3 * i + 1] * p.scale_modifier,
               sz = scales[3 * i + 2] * p.scale_modifier;
   const float R00 = 1.f - 2.f * (qy * qy + qz * qz), R01 = 2.f * (qx * qy - qr * qz), R02 = 2.f * (qx * qz + qr * qy);
@@ -119,7 +120,22 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   float dxw = mx - p.campos[0], dyw = my - p.campos[1], dzw = mz - p.campos[2];
   const float il = 1.f / sqrtf(dxw * dxw + dyw * dyw + dzw * dzw);
   dxw *= il; dyw *= il; dzw *= il;
-  const float* sh = shs + (size_t)i * p.M * 3;
+  // SH block: 48 floats (192 B, 16-B aligned) per Gaussian when M == 16 -> twelve 16-B loads per lane
+  // (every 64-B line is consumed by 4 back-to-back loads) instead of 48 strided dword loads
+  float shv[48];
+  if (p.M == 16) {
+    const float4* sh4 = reinterpret_cast<const float4*>(shs + (size_t)i * 48);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      const float4 t = sh4[q];
+      shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w;
+    }
+  } else {
+    const float* shp = shs + (size_t)i * p.M * 3;
+#pragma unroll
+    for (int q = 0; q < 48; ++q) shv[q] = (q < p.M * 3) ? shp[q] : 0.f;
+  }
+  const float* sh = shv;
   float col[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
