@@ -274,9 +274,9 @@ __device__ __forceinline__ void final_stage(const float* __restrict__ partials, 
     double ta = 1.0, tb = 0.5, tc = 1.0 / 6.0;
 #pragma unroll
     for (int n = 1; n <= 10; ++n) {
-      ta *= -t2 / (double)((2 * n) * (2 * n + 1));
-      tb *= -t2 / (double)((2 * n + 1) * (2 * n + 2));
-      tc *= -t2 / (double)((2 * n + 2) * (2 * n + 3));
+      ta *= -t2 * (1.0 / (double)((2 * n) * (2 * n + 1)));        // reciprocals fold at compile time
+      tb *= -t2 * (1.0 / (double)((2 * n + 1) * (2 * n + 2)));
+      tc *= -t2 * (1.0 / (double)((2 * n + 2) * (2 * n + 3)));
       ka += ta; kb += tb; kc += tc;
     }
   } else {

@@ -24,6 +24,7 @@ constexpr int BIG_RECT = 32;    // rects above this many tiles are enumerated by
 
 struct BinG {
   float u, v, ca, cb, cc, thr;  // thr = 2 ln(255 o) with margin; < 0 -> never visible
+  float ica, icc;               // 1/ca, 1/cc
   int x0, y0, x1, y1;
   uint32_t zbits;
 };
@@ -39,7 +40,7 @@ __device__ __forceinline__ void bin_rect(float u, float v, int radius, int gx, i
 __device__ __forceinline__ bool load_bing(const RasterParams& p, const Splat* __restrict__ splats,
                                           const int32_t* __restrict__ radii, int i, BinG& g) {
   g.x0 = g.y0 = g.x1 = g.y1 = 0;
-  g.u = g.v = g.ca = g.cb = g.cc = 0.f; g.thr = -1.f; g.zbits = 0;
+  g.u = g.v = g.ca = g.cb = g.cc = 0.f; g.thr = -1.f; g.zbits = 0; g.ica = g.icc = 0.f;
   if (i >= p.P) return false;
   const int radius = radii[i];
   if (radius <= 0) return false;
@@ -53,6 +54,7 @@ __device__ __forceinline__ bool load_bing(const RasterParams& p, const Splat* __
   // q <= 2 ln(255 o) <=> alpha >= 1/255; margin: 1e-3 relative + 1e-2 absolute on q (float rounding
   // of power in blend is ~1e-6 relative).  Non-PD conics (never seen; det guard) keep every tile.
   g.thr = pd ? (2.f * __logf(255.f * o)) * 1.001f + 1e-2f : 3.0e38f;
+  g.ica = __builtin_amdgcn_rcpf(g.ca); g.icc = __builtin_amdgcn_rcpf(g.cc);   // only place the clamp points
   bin_rect(g.u, g.v, radius, p.gx, p.gy, g.x0, g.y0, g.x1, g.y1);
   return (g.x1 - g.x0) * (g.y1 - g.y0) > 0;
 }
@@ -63,7 +65,7 @@ __device__ __forceinline__ bool tile_visible(const BinG& g, int tx, int ty) {
   const float dy0 = g.v - (float)(ty * TILE + TILE - 1), dy1 = g.v - (float)(ty * TILE);
   if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
   float qmin = 3.4e38f;
-  const float ica = 1.f / g.ca, icc = 1.f / g.cc;
+  const float ica = g.ica, icc = g.icc;
 #pragma unroll
   for (int e = 0; e < 2; ++e) {                      // edges dx = const
     const float dx = e ? dx1 : dx0;
@@ -87,6 +89,8 @@ __device__ __forceinline__ BinG bcast(const BinG& g, int src) {
   o.cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.cb), src));
   o.cc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.cc), src));
   o.thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.thr), src));
+  o.ica = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.ica), src));
+  o.icc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.icc), src));
   o.x0 = __builtin_amdgcn_readlane(g.x0, src); o.y0 = __builtin_amdgcn_readlane(g.y0, src);
   o.x1 = __builtin_amdgcn_readlane(g.x1, src); o.y1 = __builtin_amdgcn_readlane(g.y1, src);
   o.zbits = (uint32_t)__builtin_amdgcn_readlane((int)g.zbits, src);
@@ -149,13 +153,21 @@ __device__ __forceinline__ void enumerate_instances(const RasterParams& p, const
 __global__ void __launch_bounds__(256) bin_count_kernel(RasterParams p, const Splat* __restrict__ splats,
                                                         const int32_t* __restrict__ radii,
                                                         const int32_t* __restrict__ mask,
-                                                        uint32_t* __restrict__ tile_count) {
+                                                        uint32_t* __restrict__ tile_count,
+                                                        uint32_t* __restrict__ vis_global) {
   extern __shared__ uint32_t s_cnt[];
   const int ntiles = p.gx * p.gy;
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
   __syncthreads();
   uint32_t vis[GPB / BLOCK];
+#pragma unroll
+  for (int k = 0; k < GPB / BLOCK; ++k) vis[k] = 0;
   enumerate_instances<false>(p, splats, radii, vis, [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
+#pragma unroll
+  for (int k = 0; k < GPB / BLOCK; ++k) {           // visibility bits of the small rects, replayed by bin_scatter
+    const int i = blockIdx.x * GPB + k * BLOCK + (int)threadIdx.x;
+    if (i < p.P) vis_global[i] = vis[k];
+  }
   __syncthreads();
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) {
     const uint32_t c = s_cnt[t];
@@ -197,15 +209,21 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(RasterParams p, const 
                                                           const int32_t* __restrict__ radii,
                                                           const int32_t* __restrict__ mask,
                                                           uint32_t* __restrict__ cursor,
+                                                          const uint32_t* __restrict__ vis_global,
                                                           unsigned long long* __restrict__ bucket) {
   extern __shared__ uint32_t s_mem[];
   const int ntiles = p.gx * p.gy;
   uint32_t* s_cnt = s_mem;
   uint32_t* s_base = s_mem + ntiles;
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
-  __syncthreads();
   uint32_t vis[GPB / BLOCK];
-  enumerate_instances<false>(p, splats, radii, vis, [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
+#pragma unroll
+  for (int k = 0; k < GPB / BLOCK; ++k) {
+    const int i = blockIdx.x * GPB + k * BLOCK + (int)threadIdx.x;
+    vis[k] = (i < p.P) ? vis_global[i] : 0u;
+  }
+  __syncthreads();
+  enumerate_instances<true>(p, splats, radii, vis, [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
   __syncthreads();
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) {
     const uint32_t c = s_cnt[t];
@@ -364,7 +382,7 @@ size_t bin_lds_limit_tiles() { return 16000; }       // 2 x 4 B x tiles must fit
 int bin_sort_capacity() { return 16384; }            // 16384 x 8 B = 128 KiB
 
 int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
-                     uint32_t* tile_count, hipStream_t st) {
+                     uint32_t* tile_count, uint32_t* vis_global, hipStream_t st) {
   const int ntiles = p.gx * p.gy;
   if (hipMemsetAsync(tile_count, 0, (size_t)ntiles * sizeof(uint32_t), st) != hipSuccess) return -1;
   if (p.P == 0) return 0;
@@ -372,7 +390,7 @@ int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* 
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(bin_count_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii, mask,
-                     tile_count);
+                     tile_count, vis_global);
   return 0;
 }
 void launch_bin_tilescan(int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* cursor, uint32_t* info,
@@ -380,14 +398,14 @@ void launch_bin_tilescan(int ntiles, const uint32_t* tile_count, uint2* ranges, 
   hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(1024), 0, st, ntiles, tile_count, ranges, cursor, info);
 }
 void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
-                        uint32_t* cursor, unsigned long long* bucket, hipStream_t st) {
+                        uint32_t* cursor, const uint32_t* vis_global, unsigned long long* bucket, hipStream_t st) {
   if (p.P == 0) return;
   const int ntiles = p.gx * p.gy;
   const size_t lds = 2 * (size_t)ntiles * sizeof(uint32_t);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(bin_scatter_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii, mask,
-                     cursor, bucket);
+                     cursor, vis_global, bucket);
 }
 template <int THREADS>
 static void launch_radix(int ntiles, const uint2* ranges, const unsigned long long* bucket, uint32_t* point_list, int lo,
