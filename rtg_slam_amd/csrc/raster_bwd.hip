@@ -71,10 +71,10 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     const uint32_t* __restrict__ n_contrib, const int32_t* __restrict__ depth_index,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     SplatGrad* __restrict__ grads) {
-  __shared__ float4 s_rec[BLOCK * 3];
-  __shared__ int32_t s_id[BLOCK];
-  __shared__ float s_hy[BLOCK];
-  __shared__ float s_grad[BLOCK * NG];
+  __shared__ float4 s_rec[BATCH * 3];
+  __shared__ int32_t s_id[BATCH];
+  __shared__ float s_hy[BATCH];
+  __shared__ float s_grad[BATCH * NG];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -100,14 +100,12 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
   }
   const float bgT = T_final * (p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2);
   float T = 1.f;
-  uint32_t pos = 0;                       // list position of the next entry
-  bool done = last == 0;
   const int gidx = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
   const float strip_y0 = (float)(blockIdx.y * TILE + (tid >> 6) * 4), strip_y1 = strip_y0 + 3.f;
 
-  for (int base = 0; base < n; base += BLOCK) {
-    if (__syncthreads_and(done)) break;
-    const int m = min(BLOCK, n - base);
+  for (int base = 0; base < n; base += BATCH) {
+    if (__syncthreads_and((uint32_t)base >= last)) break;
+    const int m = min(BATCH, n - base);
     if (tid < m) {
       const uint32_t id = point_list[range.x + base + tid];
       s_id[tid] = (int32_t)id;
@@ -117,57 +115,46 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
       s_rec[tid * 3 + 2] = src[2];
       s_hy[tid] = reinterpret_cast<const float*>(splats + id)[15];
     }
+    if (tid < BATCH) {
 #pragma unroll
-    for (int k = 0; k < NG; ++k) s_grad[tid * NG + k] = 0.f;
+      for (int k = 0; k < NG; ++k) s_grad[tid * NG + k] = 0.f;
+    }
     __syncthreads();
 
     for (int j = 0; j < m; ++j) {
-      if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;     // whole wave past its last contributor
-      float v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = 0.f;
-      float vop = 0.f;
-      bool valid = false;
+      const uint32_t pos = (uint32_t)(base + j);                 // list position of this entry (uniform)
+      if (__builtin_amdgcn_ballot_w64(pos < last) == 0ull) break; // whole wave past its last contributor
       const float4 r0 = s_rec[j * 3 + 0];
       const float ehy = s_hy[j];
-      const bool strip_hit = !(r0.y + ehy < strip_y0 || r0.y - ehy > strip_y1);   // wave-uniform
-      if (!done) {
-        const float4 r1 = s_rec[j * 3 + 1];
-        const float dx = r0.x - pxf, dy = r0.y - pyf;
-        const float power = strip_hit ? splat_power(r0.z, r0.w, r1.x, dx, dy) : 1.f;
-        if (!(power > 0.f)) {
-          const float G = splat_exp(power);
-          const float oG = r1.y * G;
-          const float alpha = fminf(0.99f, oG);
-          if (!(alpha < 1.f / 255.f)) {
-            valid = true;
-            const float4 r2 = s_rec[j * 3 + 2];
-            const float c0 = r1.z, c1 = r1.w, c2 = r2.x;
-            const float w = alpha * T;
-            S0 -= c0 * w; S1 -= c1 * w; S2 -= c2 * w;            // colour strictly behind this entry
-            const float oma = 1.f - alpha;
-            const float ia = __builtin_amdgcn_rcpf(oma);
-            const float dL_dalpha = T * (c0 * g0 + c1 * g1 + c2 * g2) - (S0 * g0 + S1 * g1 + S2 * g2 + bgT) * ia;
-            v[5] = w * g0; v[6] = w * g1; v[7] = w * g2;
-            if (oG <= 0.99f) {                                   // d min(0.99, oG)/d(oG): autograd of clamp
-              vop = G * dL_dalpha;
-              const float gdl = G * r1.y * dL_dalpha;
-              v[0] = gdl * (-r0.z * dx - r0.w * dy);
-              v[1] = gdl * (-r1.x * dy - r0.w * dx);
-              v[2] = gdl * (-0.5f * dx * dx);
-              v[3] = gdl * (-dx * dy);
-              v[4] = gdl * (-0.5f * dy * dy);
-            }
-            T *= oma;
-          }
-        }
-        ++pos;
-        if (pos >= last) done = true;
-      }
-      const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
-      if (vm == 0ull) continue;                                   // wave-uniform
+      if (r0.y + ehy < strip_y0 || r0.y - ehy > strip_y1) continue;   // wave-uniform strip test
+      const float4 r1 = s_rec[j * 3 + 1];
+      // branch-free per-lane evaluation
+      const float dx = r0.x - pxf, dy = r0.y - pyf;
+      const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
+      const float G = splat_exp(fminf(power, 0.f));
+      const float oG = r1.y * G;
+      const float alpha = fminf(0.99f, oG);
+      const bool valid = (pos < last) && !(power > 0.f) && !(alpha < 1.f / 255.f);
+      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;   // wave-uniform
+      const float4 r2 = s_rec[j * 3 + 2];
+      const float c0 = r1.z, c1 = r1.w, c2 = r2.x;
+      const float w = valid ? alpha * T : 0.f;
+      S0 -= c0 * w; S1 -= c1 * w; S2 -= c2 * w;                  // colour strictly behind this entry
+      const float oma = 1.f - alpha;
+      const float ia = __builtin_amdgcn_rcpf(oma);
+      const float dL_dalpha = T * (c0 * g0 + c1 * g1 + c2 * g2) - (S0 * g0 + S1 * g1 + S2 * g2 + bgT) * ia;
+      const float gda = (valid && oG <= 0.99f) ? G * dL_dalpha : 0.f;   // d min(0.99, oG)/d(oG): autograd of clamp
+      const float gdl = gda * r1.y;
+      float v[8];
+      v[0] = gdl * (-r0.z * dx - r0.w * dy);
+      v[1] = gdl * (-r1.x * dy - r0.w * dx);
+      v[2] = gdl * (-0.5f * dx * dx);
+      v[3] = gdl * (-dx * dy);
+      v[4] = gdl * (-0.5f * dy * dy);
+      v[5] = w * g0; v[6] = w * g1; v[7] = w * g2;
+      T = valid ? T * oma : T;
       const float r8 = butterfly8(v, lane);
-      const float ro = wave_sum_to_lane63(vop);
+      const float ro = wave_sum_to_lane63(gda);
       atomicAdd(&s_grad[j * NG + gidx], r8);                      // 8 groups -> 8-way same-address add
       if (lane == 63) atomicAdd(&s_grad[j * NG + 8], ro);
     }

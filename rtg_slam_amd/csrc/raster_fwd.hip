@@ -4,6 +4,7 @@
 // own CUDA sources are an un-vendored submodule (/root/reference/.gitmodules:1-4), its call
 // contract is /root/reference/SLAM/render.py:68-128.
 #include "raster_common.h"
+#include <stdlib.h>
 
 namespace rtgs {
 
@@ -249,9 +250,9 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
     float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
     unsigned long long* __restrict__ counters) {
-  __shared__ float4 s_rec[BLOCK * 4];
-  __shared__ int32_t s_id[BLOCK];
-  __shared__ float s_hy[BLOCK];
+  __shared__ float4 s_rec[BATCH * 4];
+  __shared__ int32_t s_id[BATCH];
+  __shared__ float s_hy[BATCH];
 
   const int tid = threadIdx.x;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
@@ -272,9 +273,9 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
   const float rnorm = sqrtf(rx * rx + ry * ry + 1.f);
   unsigned long long evals = 0;
 
-  for (int base = 0; base < n; base += BLOCK) {
+  for (int base = 0; base < n; base += BATCH) {
     if (__syncthreads_and(done)) break;
-    const int m = min(BLOCK, n - base);
+    const int m = min(BATCH, n - base);
     if (tid < m) {
       const uint32_t id = point_list[range.x + base + tid];
       s_id[tid] = (int32_t)id;
@@ -289,37 +290,44 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     __syncthreads();
     for (int j = 0; j < m; ++j) {
       if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;   // whole wave finished
-      if (done) continue;
-      ++contributor;
       const float4 r0 = s_rec[j * 4 + 0];   // u v ca cb
+      const float4 r1 = s_rec[j * 4 + 1];   // cc o r g
       // wave-uniform: the entry's alpha >= 1/255 region misses this wave's 16x4 pixel strip
       const float ehy = s_hy[j];
       if (r0.y + ehy < strip_y0 || r0.y - ehy > strip_y1) continue;
-      ++evals;
-      const float4 r1 = s_rec[j * 4 + 1];   // cc o r g
+      // branch-free per-lane evaluation (predication instead of nested exec-mask regions)
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
-      if (power > 0.f) continue;
-      const float alpha = fminf(0.99f, r1.y * splat_exp(power));
-      if (alpha < 1.f / 255.f) continue;
+      const float alpha = fminf(0.99f, r1.y * splat_exp(fminf(power, 0.f)));
+      const bool ok = !done && !(power > 0.f) && !(alpha < 1.f / 255.f);
       const float test_T = T * (1.f - alpha);
-      if (test_T < p.T_thr) { done = true; continue; }
+      const bool stop = ok && (test_T < p.T_thr);
+      const bool contrib = ok && !stop;
+      evals += done ? 0u : 1u;
+      done = done || stop;
+      if (__builtin_amdgcn_ballot_w64(contrib) == 0ull) continue;
       const float4 r2 = s_rec[j * 4 + 2];   // b nx ny nz
-      const float w = alpha * T;
+      const float w = contrib ? alpha * T : 0.f;
       C0 += r1.z * w; C1 += r1.w * w; C2 += r2.x * w;
-      if (w > best_w) { best_w = w; best_id = s_id[j]; }
-      if (d_id < 0 && alpha > p.opaque_thr) {
-        const float4 r3 = s_rec[j * 4 + 3];  // pd z - -
-        const float den = r2.y * rx + r2.z * ry + r2.w;
-        if (fabsf(den) / rnorm > p.normal_thr) {
-          const float zhit = r3.x / den;
-          if (zhit > 0.f && fabsf(zhit - r3.y) < p.depth_thr) { D = zhit; d_w = alpha; d_id = s_id[j]; }
+      const bool better = w > best_w;        // w == 0 for non-contributing lanes, best_w >= 0
+      const int gid = s_id[j];
+      best_w = better ? w : best_w;
+      best_id = better ? gid : best_id;
+      if (__builtin_amdgcn_ballot_w64(contrib && d_id < 0 && alpha > p.opaque_thr) != 0ull) {   // rare
+        if (contrib && d_id < 0 && alpha > p.opaque_thr) {
+          const float4 r3 = s_rec[j * 4 + 3];  // pd z hx hy
+          const float den = r2.y * rx + r2.z * ry + r2.w;
+          if (fabsf(den) / rnorm > p.normal_thr) {
+            const float zhit = r3.x / den;
+            if (zhit > 0.f && fabsf(zhit - r3.y) < p.depth_thr) { D = zhit; d_w = alpha; d_id = gid; }
+          }
         }
       }
-      T = test_T;
-      last_contributor = contributor;
+      T = contrib ? test_T : T;
+      last_contributor = contrib ? (uint32_t)(base + j + 1) : last_contributor;
     }
   }
+  contributor = last_contributor;   // accounting only (entries this pixel needed)
 
   if (inside) {
     const size_t pix = (size_t)py * p.W + px;
@@ -338,6 +346,119 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
   if (counters) {
     // work accounting for the roofline: entries any pixel of this tile consumed, and
     // (entry, pixel) pairs evaluated
+    __shared__ unsigned int s_max;
+    __shared__ unsigned long long s_ev;
+    if (tid == 0) { s_max = 0; s_ev = 0; }
+    __syncthreads();
+    atomicMax(&s_max, contributor);
+    atomicAdd(&s_ev, evals);
+    __syncthreads();
+    if (tid == 0) { atomicAdd(&counters[0], (unsigned long long)s_max); atomicAdd(&counters[1], s_ev); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6' blend_fwd, scalar-gather variant: the tile list and the 64-B Splat records are wave-uniform,
+// so every wave fetches them with SCALAR loads (s_load_dword / s_load_dwordx16 through the
+// constant cache) straight into SGPRs, four entries per round: no LDS, no workgroup barrier,
+// each wave walks at its own pace and stops when its 64 pixels are done.  Same arithmetic as
+// blend_fwd_kernel, bit for bit.
+// ---------------------------------------------------------------------------------------------
+struct SplatRegs { float4 r0, r1, r2, r3; };
+
+__device__ __forceinline__ SplatRegs load_uniform(const Splat* __restrict__ splats, uint32_t id) {
+  const float4* src = reinterpret_cast<const float4*>(splats + id);   // uniform address -> SMEM
+  SplatRegs s;
+  s.r0 = src[0]; s.r1 = src[1]; s.r2 = src[2]; s.r3 = src[3];
+  return s;
+}
+
+__global__ void __launch_bounds__(256) blend_fwd_scalar_kernel(
+    RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
+    int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
+    float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
+    unsigned long long* __restrict__ counters) {
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.y * p.gx + blockIdx.x;
+  const int px = blockIdx.x * TILE + (tid & 15);
+  const int py = blockIdx.y * TILE + (tid >> 4);
+  const bool inside = px < p.W && py < p.H;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint2 range = ranges[tile];
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
+  const int n = __builtin_amdgcn_readfirstlane((int)(range.y - range.x));
+  const float strip_y0 = (float)(blockIdx.y * TILE + (tid >> 6) * 4), strip_y1 = strip_y0 + 3.f;
+
+  bool done = !inside;
+  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  float best_w = 0.f; int best_id = -1;
+  float D = 0.f, d_w = 0.f; int d_id = -1;
+  uint32_t contributor = 0, last_contributor = 0;
+  const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
+  const float rnorm = sqrtf(rx * rx + ry * ry + 1.f);
+  unsigned long long evals = 0;
+
+  constexpr int U = 4;
+  for (int j0 = 0; j0 < n; j0 += U) {
+    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;     // whole wave finished
+    uint32_t ids[U];
+    SplatRegs recs[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      ids[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)point_list[lo + (uint32_t)min(j0 + k, n - 1)]);
+#pragma unroll
+    for (int k = 0; k < U; ++k) recs[k] = load_uniform(splats, ids[k]);
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (j0 + k >= n) break;
+      const float4 r0 = recs[k].r0, r1 = recs[k].r1, r2 = recs[k].r2, r3 = recs[k].r3;
+      if (r0.y + r3.w < strip_y0 || r0.y - r3.w > strip_y1) continue;   // wave-uniform strip test
+      const float dx = r0.x - pxf, dy = r0.y - pyf;
+      const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
+      const float alpha = fminf(0.99f, r1.y * splat_exp(fminf(power, 0.f)));
+      const bool ok = !done && !(power > 0.f) && !(alpha < 1.f / 255.f);
+      const float test_T = T * (1.f - alpha);
+      const bool stop = ok && (test_T < p.T_thr);
+      const bool contrib = ok && !stop;
+      evals += done ? 0u : 1u;
+      done = done || stop;
+      if (__builtin_amdgcn_ballot_w64(contrib) == 0ull) continue;
+      const float w = contrib ? alpha * T : 0.f;
+      C0 += r1.z * w; C1 += r1.w * w; C2 += r2.x * w;
+      const bool better = w > best_w;
+      best_w = better ? w : best_w;
+      best_id = better ? (int)ids[k] : best_id;
+      if (__builtin_amdgcn_ballot_w64(contrib && d_id < 0 && alpha > p.opaque_thr) != 0ull) {   // rare
+        if (contrib && d_id < 0 && alpha > p.opaque_thr) {
+          const float den = r2.y * rx + r2.z * ry + r2.w;
+          if (fabsf(den) / rnorm > p.normal_thr) {
+            const float zhit = r3.x / den;
+            if (zhit > 0.f && fabsf(zhit - r3.y) < p.depth_thr) { D = zhit; d_w = alpha; d_id = (int)ids[k]; }
+          }
+        }
+      }
+      T = contrib ? test_T : T;
+      last_contributor = contrib ? (uint32_t)(j0 + k + 1) : last_contributor;
+    }
+  }
+  contributor = last_contributor;
+
+  if (inside) {
+    const size_t pix = (size_t)py * p.W + px;
+    const size_t HW = (size_t)p.H * p.W;
+    out_color[pix] = C0 + T * p.bg[0];
+    out_color[HW + pix] = C1 + T * p.bg[1];
+    out_color[2 * HW + pix] = C2 + T * p.bg[2];
+    out_depth[pix] = D;
+    out_cidx[pix] = best_id;
+    out_didx[pix] = d_id;
+    out_cw[pix] = best_w;
+    out_dw[pix] = d_w;
+    out_T[pix] = T;
+    n_contrib[pix] = last_contributor;
+  }
+  if (counters) {
     __shared__ unsigned int s_max;
     __shared__ unsigned long long s_ev;
     if (tid == 0) { s_max = 0; s_ev = 0; }
@@ -375,6 +496,12 @@ void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t
                       float* out_color, float* out_depth, int32_t* out_cidx, int32_t* out_didx, float* out_cw,
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
                       hipStream_t st) {
+  static const int variant = [] { const char* e = getenv("RTGS_BLEND_FWD"); return e ? atoi(e) : 0; }();
+  if (variant == 1) {
+    hipLaunchKernelGGL(blend_fwd_scalar_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
+                       out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters);
+    return;
+  }
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
                      out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters);
 }
