@@ -238,6 +238,26 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint6
   if (i == R - 1) ranges[t].y = (uint32_t)R;
 }
 
+// Wave-uniform bounding box (float pixel coordinates) of the pixels of this wave that are still
+// walking.  Lane l of a wave is pixel (col = l & 15, row = l >> 4) of the wave's 16x4 strip, so the
+// box falls out of the 64-bit ballot with scalar bit operations; it is refreshed only when the
+// active set changes.  Entries whose alpha >= 1/255 region misses the box are skipped by the whole
+// wave - this is what keeps the walk of a few never-saturating pixels cheap.
+struct ActiveBox {
+  unsigned long long mask;
+  float x0, x1, y0, y1;
+};
+__device__ __forceinline__ void refresh_box(ActiveBox& b, unsigned long long m, int strip_px0, int strip_py0) {
+  b.mask = m;
+  const unsigned int cols = (unsigned int)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull);
+  const unsigned int rows = ((m & 0xffffull) ? 1u : 0u) | ((m & 0xffff0000ull) ? 2u : 0u) |
+                            ((m & 0xffff00000000ull) ? 4u : 0u) | ((m & 0xffff000000000000ull) ? 8u : 0u);
+  const int cx0 = __builtin_ctz(cols | 0x10000u), cx1 = 31 - __builtin_clz(cols | 1u);
+  const int ry0 = __builtin_ctz(rows | 0x10u), ry1 = 31 - __builtin_clz(rows | 1u);
+  b.x0 = (float)(strip_px0 + cx0); b.x1 = (float)(strip_px0 + cx1);
+  b.y0 = (float)(strip_py0 + ry0); b.y1 = (float)(strip_py0 + ry1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K6 blend_fwd: one workgroup (4 wave64) per 16x16 tile; list entries staged through LDS in
 // batches of 256 records (one 64-B gather per thread), then every pixel walks the batch with
@@ -252,7 +272,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     unsigned long long* __restrict__ counters) {
   __shared__ float4 s_rec[BATCH * 4];
   __shared__ int32_t s_id[BATCH];
-  __shared__ float s_hy[BATCH];
+  __shared__ float2 s_h[BATCH];
 
   const int tid = threadIdx.x;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
@@ -272,6 +292,8 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
   const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
   const float rnorm = sqrtf(rx * rx + ry * ry + 1.f);
   unsigned long long evals = 0;
+  ActiveBox box;
+  box.mask = 0ull; box.x0 = box.y0 = 0.f; box.x1 = box.y1 = -1.f;
 
   for (int base = 0; base < n; base += BATCH) {
     if (__syncthreads_and(done)) break;
@@ -285,16 +307,18 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
       s_rec[tid * 4 + 2] = src[2];
       const float4 r3 = src[3];
       s_rec[tid * 4 + 3] = r3;
-      s_hy[tid] = r3.w;
+      s_h[tid] = make_float2(r3.z, r3.w);
     }
     __syncthreads();
     for (int j = 0; j < m; ++j) {
-      if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;   // whole wave finished
+      const unsigned long long am = __builtin_amdgcn_ballot_w64(!done);
+      if (am == 0ull) break;                // whole wave finished
+      if (am != box.mask) refresh_box(box, am, blockIdx.x * TILE, blockIdx.y * TILE + (tid >> 6) * 4);
       const float4 r0 = s_rec[j * 4 + 0];   // u v ca cb
+      // wave-uniform: the entry's alpha >= 1/255 region misses every pixel of this wave still walking
+      const float2 eh = s_h[j];
+      if (r0.x + eh.x < box.x0 || r0.x - eh.x > box.x1 || r0.y + eh.y < box.y0 || r0.y - eh.y > box.y1) continue;
       const float4 r1 = s_rec[j * 4 + 1];   // cc o r g
-      // wave-uniform: the entry's alpha >= 1/255 region misses this wave's 16x4 pixel strip
-      const float ehy = s_hy[j];
-      if (r0.y + ehy < strip_y0 || r0.y - ehy > strip_y1) continue;
       // branch-free per-lane evaluation (predication instead of nested exec-mask regions)
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
@@ -400,6 +424,8 @@ __global__ void __launch_bounds__(256) blend_fwd_scalar_kernel(
   unsigned long long evals = 0;
 
   constexpr int U = 4;
+  ActiveBox box;
+  box.mask = 0ull; box.x0 = box.y0 = 0.f; box.x1 = box.y1 = -1.f;
   for (int j0 = 0; j0 < n; j0 += U) {
     if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;     // whole wave finished
     uint32_t ids[U];
@@ -413,7 +439,11 @@ __global__ void __launch_bounds__(256) blend_fwd_scalar_kernel(
     for (int k = 0; k < U; ++k) {
       if (j0 + k >= n) break;
       const float4 r0 = recs[k].r0, r1 = recs[k].r1, r2 = recs[k].r2, r3 = recs[k].r3;
-      if (r0.y + r3.w < strip_y0 || r0.y - r3.w > strip_y1) continue;   // wave-uniform strip test
+      const unsigned long long am = __builtin_amdgcn_ballot_w64(!done);
+      if (am == 0ull) break;
+      if (am != box.mask) refresh_box(box, am, blockIdx.x * TILE, blockIdx.y * TILE + (tid >> 6) * 4);
+      // wave-uniform: the entry's alpha >= 1/255 region misses every pixel of this wave still walking
+      if (r0.x + r3.z < box.x0 || r0.x - r3.z > box.x1 || r0.y + r3.w < box.y0 || r0.y - r3.w > box.y1) continue;
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
       const float alpha = fminf(0.99f, r1.y * splat_exp(fminf(power, 0.f)));
