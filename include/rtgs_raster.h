@@ -150,6 +150,16 @@ int rtgs_map_activate_backward(const float* packed, int64_t n, const float* g_xy
                                const float* g_shs, const float* g_scales, const float* g_rotations,
                                const float* g_normal, float* g_packed, void* stream);
 
+/* Single-GPU map step in ONE kernel: activation backward of the six rasterizer-input gradients,
+ * Adam on the packed parameters (same semantics as rtgs_fused_adam), and activation forward of
+ * the UPDATED parameters into the six rasterizer inputs of the next iteration.  Equivalent to
+ * rtgs_map_activate_backward + rtgs_fused_adam + rtgs_map_activate_forward. */
+int rtgs_map_fused_step(float* packed, float* exp_avg, float* exp_avg_sq, const float* lr_per_column,
+                        int64_t n, int32_t step, float beta1, float beta2, float eps, const float* g_xyz,
+                        const float* g_opacity, const float* g_shs, const float* g_scales,
+                        const float* g_rotations, const float* g_normal, float* xyz, float* opacity,
+                        float* shs, float* scales, float* rotations, float* normal, void* stream);
+
 const char* rtgs_version(void);
 
 #ifdef __cplusplus

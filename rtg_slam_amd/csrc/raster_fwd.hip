@@ -282,7 +282,6 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
   const float pxf = (float)px, pyf = (float)py;
   const uint2 range = ranges[tile];
   const int n = (int)(range.y - range.x);
-  const float strip_y0 = (float)(blockIdx.y * TILE + (tid >> 6) * 4), strip_y1 = strip_y0 + 3.f;
 
   bool done = !inside;
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
@@ -412,7 +411,6 @@ __global__ void __launch_bounds__(256) blend_fwd_scalar_kernel(
   const uint2 range = ranges[tile];
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
   const int n = __builtin_amdgcn_readfirstlane((int)(range.y - range.x));
-  const float strip_y0 = (float)(blockIdx.y * TILE + (tid >> 6) * 4), strip_y1 = strip_y0 + 3.f;
 
   bool done = !inside;
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;

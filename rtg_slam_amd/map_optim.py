@@ -165,6 +165,10 @@ class ShardedMapOptimizer:
         self.grad_full = torch.zeros(self.Npad, COLS, dtype=torch.float32, device=dev)
         self.grad_shard = torch.zeros(self.per, COLS, dtype=torch.float32, device=dev)
         self.step_count = 0
+        # single-GPU HIP path: activation backward + Adam + activation forward fused in one kernel; the
+        # activated tensors of the next iteration are produced by the step itself
+        self.fused = (self.world == 1 and adam_fn is None and activate_fn is None and packed.is_cuda)
+        self._act = None
 
     @property
     def params(self) -> torch.Tensor:
@@ -176,6 +180,8 @@ class ShardedMapOptimizer:
     def step(self, loss_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor]) -> torch.Tensor:
         """loss_fn(gaussian_data) -> scalar loss of THIS rank's view.  Gradients are summed over
         ranks (the sum of per-view losses is what a single GPU looping over the views optimises)."""
+        if self.fused:
+            return self._step_fused(loss_fn)
         leaf = self.packed[:self.N].detach().requires_grad_(True)
         loss = loss_fn(self.activate_fn(leaf))
         (g,) = torch.autograd.grad(loss, leaf)
@@ -200,6 +206,32 @@ class ShardedMapOptimizer:
         elif self.world > 1:
             dist.all_gather_into_tensor(self.packed, shard.clone(), group=self.group)
         return loss.detach()
+
+
+def _step_fused(self, loss_fn):
+    from . import _lib
+    lib = _lib.load()
+    dev = self.packed.device
+    keys = ("xyz", "opacity", "shs", "scales", "rotations", "normal")
+    if self._act is None:
+        with torch.no_grad():
+            self._act = {k: v.detach() for k, v in activate_hip(self.packed[:self.N]).items()}
+    leaves = {k: self._act[k].detach().requires_grad_(True) for k in keys}
+    loss = loss_fn(leaves)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)
+    grads = [torch.zeros_like(leaves[k]) if g is None else g.contiguous() for k, g in zip(keys, grads)]
+    self.step_count += 1
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    P = lambda t: C.c_void_p(t.data_ptr())
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_map_fused_step(P(self.packed), P(self.m), P(self.v), P(self.lr_col), self.N, self.step_count, 0.9,
+                                     0.999, float(self.eps), *(P(g) for g in grads),
+                                     *(P(self._act[k]) for k in keys), C.c_void_p(stream))
+    _lib.check(rc, "rtgs_map_fused_step")
+    return loss.detach()
+
+
+ShardedMapOptimizer._step_fused = _step_fused
 
 
 def slam_losses(render: Dict[str, torch.Tensor], gt_color: torch.Tensor, gt_depth: torch.Tensor,

@@ -232,3 +232,27 @@ def test_matches_committed_golden(golden_dir):
     for k in ru.FIELDS:
         r = torch.from_numpy(z[f"grad_{k}"])
         assert float((gd_h[k] - r).abs().max()) / (float(r.abs().max()) + 1e-12) < 1e-3, k
+
+
+def test_fused_map_step_matches_unfused():
+    """rtgs_map_fused_step == activate_bwd + fused_adam + activate_fwd (three optimisation steps)."""
+    from rtg_slam_amd import map_optim as mo
+    dev = "cuda:0"
+    g = synth.random_gaussians(3000, SMALL, seed=13)
+    packed = mo.pack_from_activated({k: v.to(dev) for k, v in g.items()})
+    gen = torch.Generator().manual_seed(2)
+    ws = {k: torch.randn(v.shape, generator=gen).to(dev) for k, v in mo.activate(packed).items()}
+
+    def loss_fn(gd):
+        return sum((gd[k] * ws[k]).sum() + (gd[k] ** 2).sum() * 0.1 for k in ws)
+
+    a = mo.ShardedMapOptimizer(packed.clone())                                        # fused
+    b = mo.ShardedMapOptimizer(packed.clone(), adam_fn=mo._adam_hip, activate_fn=mo.activate_hip)   # unfused HIP
+    assert a.fused and not b.fused
+    for _ in range(3):
+        la = a.step(loss_fn)
+        lb = b.step(loss_fn)
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    assert float((a.params - b.params).abs().max()) < 2e-6
+    assert float((a.m - b.m).abs().max()) < 1e-6 * (float(b.m.abs().max()) + 1)
+    assert float((a.params - packed).abs().max()) > 1e-4
