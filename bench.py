@@ -148,8 +148,10 @@ def main():
         for i in range(nprof):
             counters.zero_()
             lib.rtgs_raster_set_counters(C.c_void_p(counters.data_ptr()))
-            leaf = opt.params.detach().clone().requires_grad_(True)
-            loss = loss_fn(mo.activate_hip(leaf))
+            lv = {nm: opt.state[nm]["p"][:N].detach().clone().requires_grad_(True) for nm in ("xyz", "shs", "raw8")}
+            gd = mo.activate8_hip(lv["raw8"])
+            gd["xyz"], gd["shs"] = lv["xyz"], lv["shs"].view(N, 16, 3)
+            loss = loss_fn(gd)
             lib.rtgs_raster_set_counters(None)
             loss.backward()
             torch.cuda.synchronize(dev)

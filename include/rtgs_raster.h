@@ -138,27 +138,15 @@ int rtgs_fused_adam(float* params, const float* grads, float* exp_avg, float* ex
                     const float* lr_per_column, int64_t rows, int32_t cols, int32_t step,
                     float beta1, float beta2, float eps, void* stream);
 
-/* Map-state activations around the rasterizer, one streaming kernel each way.
- * packed[n,59] raw parameters (xyz 0:3 | f_dc 3:6 | f_rest 6:51 | opacity 51 | scaling 52:55 |
- * rotation 55:59, the PLY column order of SLAM/gaussian_pointcloud.py:407-466) -> the six
- * contiguous rasterizer inputs: exp / sigmoid / normalize (gaussian_pointcloud.py:16-25),
- * get_normal (:538-550), get_features (:573-577).  The backward maps the six input gradients
- * of rtgs_raster_backward to the packed gradient (argmin of the scales is piecewise constant). */
-int rtgs_map_activate_forward(const float* packed, int64_t n, float* xyz, float* opacity, float* shs,
-                              float* scales, float* rotations, float* normal, void* stream);
-int rtgs_map_activate_backward(const float* packed, int64_t n, const float* g_xyz, const float* g_opacity,
-                               const float* g_shs, const float* g_scales, const float* g_rotations,
-                               const float* g_normal, float* g_packed, void* stream);
-
-/* Single-GPU map step in ONE kernel: activation backward of the six rasterizer-input gradients,
- * Adam on the packed parameters (same semantics as rtgs_fused_adam), and activation forward of
- * the UPDATED parameters into the six rasterizer inputs of the next iteration.  Equivalent to
- * rtgs_map_activate_backward + rtgs_fused_adam + rtgs_map_activate_forward. */
-int rtgs_map_fused_step(float* packed, float* exp_avg, float* exp_avg_sq, const float* lr_per_column,
-                        int64_t n, int32_t step, float beta1, float beta2, float eps, const float* g_xyz,
-                        const float* g_opacity, const float* g_shs, const float* g_scales,
-                        const float* g_rotations, const float* g_normal, float* xyz, float* opacity,
-                        float* shs, float* scales, float* rotations, float* normal, void* stream);
+/* Block-SoA map state (what rtg_slam_amd/map_optim.py keeps): xyz[N,3] and shs[N,48] are stored
+ * exactly as the rasterizer reads them (no activation, no copy); only raw8[N,8] =
+ * (opacity | scaling xyz | rotation wxyz) is activated:
+ *   forward : raw8 -> opacity[N,1] scales[N,3] rotations[N,4] normal[N,3]
+ *   backward: the gradients of those four -> g_raw8[N,8]                                        */
+int rtgs_map_activate8_forward(const float* raw8, int64_t n, float* opacity, float* scales, float* rotations,
+                               float* normal, void* stream);
+int rtgs_map_activate8_backward(const float* raw8, int64_t n, const float* g_opacity, const float* g_scales,
+                                const float* g_rotations, const float* g_normal, float* g_raw8, void* stream);
 
 const char* rtgs_version(void);
 

@@ -1,22 +1,30 @@
 """One map-optimisation iteration (the body of RTG-SLAM's hot loop B,
 /root/reference/SLAM/multiprocess/mapper.py:176-205 -> :371-469) with the unstable-Gaussian set
-sharded across the GPUs of one node:
+sharded across the GPUs of one node.
 
-    every rank holds the full packed parameter buffer [N,59] (replicated: 236 B x N, trivial
-    next to 288 GB), renders ITS view forward+backward through the HIP rasterizer, the
-    per-Gaussian gradients of all ranks are summed with ONE reduce-scatter over RCCL/xGMI
-    (each rank receives the rows of its shard), the rank runs fused Adam on its N/world rows
-    (optimizer state is sharded, never replicated), and ONE all-gather returns the updated rows.
+Map state is block-SoA, three contiguous float32 tensors:
 
-Packed column layout (raw, pre-activation values; SLAM/gaussian_pointcloud.py:407-466 order):
-    xyz 0:3 | f_dc 3:6 | f_rest 6:51 | opacity 51:52 | scaling 52:55 | rotation 55:59
-Activations (gaussian_pointcloud.py:16-25, 502-595): exp / sigmoid / normalize, normal = column
-of R(q) for the smallest scale.  Learning rates: configs/replica_base.yaml:19-23,
+    xyz  [N,3]    used by the rasterizer as is                    (SLAM/gaussian_pointcloud.py _xyz)
+    shs  [N,48]   used by the rasterizer as is, viewed [N,16,3]   (_features_dc | _features_rest)
+    raw8 [N,8]    opacity | scaling xyz | rotation wxyz, raw      (_opacity, _scaling, _rotation)
+
+Only raw8 goes through an activation kernel (rtgs_map_activate8_*: sigmoid / exp / normalize and
+get_normal, gaussian_pointcloud.py:16-25, 538-550); xyz and the SH block are never copied, and the
+rasterizer's backward writes their gradients in exactly the layout Adam consumes.
+
+Per iteration and rank:  render this rank's view fwd+bwd  ->  for each of the three tensors:
+reduce-scatter of the gradient rows over RCCL (each rank receives the rows of its shard), fused
+Adam on the rank's N/world rows (optimizer state exists only for those rows), all-gather of the
+updated rows.  With one rank the collectives vanish.  Learning rates: configs/replica_base.yaml:19-23,
 gaussian_pointcloud.py:252-283; Adam eps 1e-15 (mapper.py:156).
 
-The render/loss closure and the Adam kernel are injected (HIP rasterizer + rtgs_fused_adam in
-production; the CPU oracle + a torch restatement in the world_size-2 gloo tests) so the
-sharding / collective logic is testable without a GPU.
+The render/loss closure, the Adam kernel and the activation are injected (HIP rasterizer +
+rtgs_fused_adam + rtgs_map_activate8 in production; the CPU oracle + torch restatements in the
+world_size-2 gloo tests) so the sharding / collective logic is testable without a GPU.
+
+The packed [N,59] row layout (xyz 0:3 | f_dc 3:6 | f_rest 6:51 | opacity 51 | scaling 52:55 |
+rotation 55:59 - the PLY column order of gaussian_pointcloud.py:407-466) is accepted by the
+constructor and returned by `.params` for interchange.
 """
 from __future__ import annotations
 
@@ -27,7 +35,7 @@ import torch
 import torch.distributed as dist
 
 COLS = 59
-SL = dict(xyz=(0, 3), f_dc=(3, 6), f_rest=(6, 51), opacity=(51, 52), scaling=(52, 55), rotation=(55, 59))
+BLOCKS = (("xyz", 0, 3), ("shs", 3, 51), ("raw8", 51, 59))
 
 
 def default_lr_columns(position_lr=1e-3, feature_lr=5e-4, opacity_lr=0.0, scaling_lr=4e-3, rotation_lr=1e-3):
@@ -62,69 +70,77 @@ def rotmat_cols(q: torch.Tensor):
     return torch.stack([c0, c1, c2], dim=1)          # [N, 3 (column), 3]
 
 
-def activate(packed: torch.Tensor) -> Dict[str, torch.Tensor]:
-    """Packed raw params -> the `gaussian_data` dict Renderer.render consumes (differentiable)."""
-    N = packed.shape[0]
-    scales = torch.exp(packed[:, 52:55])
-    rot = torch.nn.functional.normalize(packed[:, 55:59])
+def activate8(raw8: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Torch restatement (differentiable) of the raw8 activations: reference semantics, used by the
+    gloo tests and as the checker of the HIP kernels."""
+    N = raw8.shape[0]
+    scales = torch.exp(raw8[:, 1:4])
+    rot = torch.nn.functional.normalize(raw8[:, 4:8])
     cols = rotmat_cols(rot)
     k = scales.argmin(dim=1)
-    n = cols[torch.arange(N, device=packed.device), k]
+    n = cols[torch.arange(N, device=raw8.device), k]
     normal = n / (n.norm(dim=-1, keepdim=True) + 1e-8)
-    return dict(xyz=packed[:, 0:3], opacity=torch.sigmoid(packed[:, 51:52]), scales=scales, rotations=rot,
-                shs=packed[:, 3:51].reshape(N, 16, 3), normal=normal)
+    return dict(opacity=torch.sigmoid(raw8[:, 0:1]), scales=scales, rotations=rot, normal=normal)
 
 
-class _ActivateHip(torch.autograd.Function):
-    """`activate` as one HIP kernel each way (rtgs_map_activate_forward / _backward)."""
+def activate(packed: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Packed raw [N,59] -> the `gaussian_data` dict Renderer.render consumes (torch, differentiable)."""
+    N = packed.shape[0]
+    out = activate8(packed[:, 51:59])
+    out["xyz"] = packed[:, 0:3]
+    out["shs"] = packed[:, 3:51].reshape(N, 16, 3)
+    return out
+
+
+class _Activate8Hip(torch.autograd.Function):
+    """raw8 activations as one HIP kernel each way (rtgs_map_activate8_forward / _backward)."""
 
     @staticmethod
-    def forward(ctx, packed):
+    def forward(ctx, raw8):
         from . import _lib
         lib = _lib.load()
-        if not packed.is_cuda:
-            raise RuntimeError("rtg_slam_amd.map_optim: activate_hip needs a HIP device tensor; no CPU path.")
-        packed = packed.contiguous()
-        N, dev = packed.shape[0], packed.device
+        if not raw8.is_cuda:
+            raise RuntimeError("rtg_slam_amd.map_optim: activate8_hip needs a HIP device tensor; no CPU path.")
+        raw8 = raw8.contiguous()
+        N, dev = raw8.shape[0], raw8.device
         f = dict(dtype=torch.float32, device=dev)
-        xyz, op, shs = torch.empty(N, 3, **f), torch.empty(N, 1, **f), torch.empty(N, 16, 3, **f)
-        sc, rot, nrm = torch.empty(N, 3, **f), torch.empty(N, 4, **f), torch.empty(N, 3, **f)
+        op, sc, rot, nrm = torch.empty(N, 1, **f), torch.empty(N, 3, **f), torch.empty(N, 4, **f), torch.empty(N, 3, **f)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            rc = lib.rtgs_map_activate_forward(C.c_void_p(packed.data_ptr()), N, *(C.c_void_p(t.data_ptr()) for t in
-                                               (xyz, op, shs, sc, rot, nrm)), C.c_void_p(stream))
-        _lib.check(rc, "rtgs_map_activate_forward")
-        ctx.save_for_backward(packed)
-        return xyz, op, shs, sc, rot, nrm
+            rc = lib.rtgs_map_activate8_forward(C.c_void_p(raw8.data_ptr()), N, C.c_void_p(op.data_ptr()),
+                                                C.c_void_p(sc.data_ptr()), C.c_void_p(rot.data_ptr()),
+                                                C.c_void_p(nrm.data_ptr()), C.c_void_p(stream))
+        _lib.check(rc, "rtgs_map_activate8_forward")
+        ctx.save_for_backward(raw8)
+        return op, sc, rot, nrm
 
     @staticmethod
-    def backward(ctx, g_xyz, g_op, g_shs, g_sc, g_rot, g_nrm):
+    def backward(ctx, g_op, g_sc, g_rot, g_nrm):
         from . import _lib
         lib = _lib.load()
-        (packed,) = ctx.saved_tensors
-        N, dev = packed.shape[0], packed.device
+        (raw8,) = ctx.saved_tensors
+        N, dev = raw8.shape[0], raw8.device
 
         def z(g, *shape):
             return torch.zeros(*shape, dtype=torch.float32, device=dev) if g is None else g.contiguous()
-        gs = (z(g_xyz, N, 3), z(g_op, N, 1), z(g_shs, N, 16, 3), z(g_sc, N, 3), z(g_rot, N, 4), z(g_nrm, N, 3))
-        out = torch.empty_like(packed)
+        gs = (z(g_op, N, 1), z(g_sc, N, 3), z(g_rot, N, 4), z(g_nrm, N, 3))
+        out = torch.empty_like(raw8)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            rc = lib.rtgs_map_activate_backward(C.c_void_p(packed.data_ptr()), N, *(C.c_void_p(t.data_ptr()) for t in gs),
-                                                C.c_void_p(out.data_ptr()), C.c_void_p(stream))
-        _lib.check(rc, "rtgs_map_activate_backward")
+            rc = lib.rtgs_map_activate8_backward(C.c_void_p(raw8.data_ptr()), N, *(C.c_void_p(t.data_ptr()) for t in gs),
+                                                 C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+        _lib.check(rc, "rtgs_map_activate8_backward")
         return out
 
 
-def activate_hip(packed: torch.Tensor) -> Dict[str, torch.Tensor]:
-    """Same mapping as `activate`, fused into one HIP kernel per direction."""
-    xyz, op, shs, sc, rot, nrm = _ActivateHip.apply(packed)
-    return dict(xyz=xyz, opacity=op, scales=sc, rotations=rot, shs=shs, normal=nrm)
+def activate8_hip(raw8: torch.Tensor) -> Dict[str, torch.Tensor]:
+    op, sc, rot, nrm = _Activate8Hip.apply(raw8)
+    return dict(opacity=op, scales=sc, rotations=rot, normal=nrm)
 
 
 def shard_rows(N: int, world: int):
     """Row partition used for reduce-scatter / all-gather: equal shards of ceil(N/world) rows
-    (the packed buffer is padded to world * rows_per_rank)."""
+    (each tensor is padded to world * rows_per_rank rows)."""
     per = (N + world - 1) // world
     return per, per * world
 
@@ -145,34 +161,36 @@ def _adam_hip(p, g, m, v, lr_col, step, eps):
 class ShardedMapOptimizer:
     def __init__(self, packed: torch.Tensor, lr_col: Optional[torch.Tensor] = None, eps: float = 1e-15,
                  group=None, adam_fn: Optional[Callable] = None, activate_fn: Optional[Callable] = None):
-        """`adam_fn(p, g, m, v, lr_col, step, eps)` defaults to the HIP fused Adam (device tensors only -
-        there is no CPU path in the product); the gloo tests inject a torch restatement."""
+        """`packed` [N,59] raw parameters.  `adam_fn(p, g, m, v, lr_col, step, eps)` defaults to the HIP
+        fused Adam and `activate_fn(raw8) -> dict` to the HIP activation kernels (device tensors only -
+        there is no CPU path in the product); the gloo tests inject torch restatements."""
         self.group = group
         self.adam_fn = adam_fn if adam_fn is not None else _adam_hip
-        self.activate_fn = activate_fn if activate_fn is not None else activate_hip
+        self.activate_fn = activate_fn if activate_fn is not None else activate8_hip
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self.N = int(packed.shape[0])
         self.per, self.Npad = shard_rows(self.N, self.world)
         dev = packed.device
-        self.packed = torch.zeros(self.Npad, COLS, dtype=torch.float32, device=dev)
-        self.packed[:self.N] = packed
-        self.lr_col = (default_lr_columns() if lr_col is None else lr_col).to(dev).float().contiguous()
+        lr = (default_lr_columns() if lr_col is None else lr_col).to(dev).float()
         self.eps = eps
-        self.m = torch.zeros(self.per, COLS, dtype=torch.float32, device=dev)      # sharded state
-        self.v = torch.zeros(self.per, COLS, dtype=torch.float32, device=dev)
-        self.grad_full = torch.zeros(self.Npad, COLS, dtype=torch.float32, device=dev)
-        self.grad_shard = torch.zeros(self.per, COLS, dtype=torch.float32, device=dev)
+        self.state = {}
+        for name, c0, c1 in BLOCKS:
+            full = torch.zeros(self.Npad, c1 - c0, dtype=torch.float32, device=dev)
+            full[:self.N] = packed[:, c0:c1]
+            self.state[name] = dict(
+                p=full, lr=lr[c0:c1].contiguous(),
+                m=torch.zeros(self.per, c1 - c0, dtype=torch.float32, device=dev),      # sharded Adam state
+                v=torch.zeros(self.per, c1 - c0, dtype=torch.float32, device=dev),
+                gpad=(torch.zeros(self.Npad, c1 - c0, dtype=torch.float32, device=dev) if self.world > 1 else None),
+                gshard=(torch.zeros(self.per, c1 - c0, dtype=torch.float32, device=dev) if self.world > 1 else None))
         self.step_count = 0
-        # single-GPU HIP path: activation backward + Adam + activation forward fused in one kernel; the
-        # activated tensors of the next iteration are produced by the step itself
-        self.fused = (self.world == 1 and adam_fn is None and activate_fn is None and packed.is_cuda)
-        self._act = None
 
     @property
     def params(self) -> torch.Tensor:
-        return self.packed[:self.N]
+        """Packed [N,59] copy of the current parameters."""
+        return torch.cat([self.state[n]["p"][:self.N] for n, _, _ in BLOCKS], dim=1)
 
     def my_rows(self) -> slice:
         return slice(self.rank * self.per, (self.rank + 1) * self.per)
@@ -180,61 +198,43 @@ class ShardedMapOptimizer:
     def step(self, loss_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor]) -> torch.Tensor:
         """loss_fn(gaussian_data) -> scalar loss of THIS rank's view.  Gradients are summed over
         ranks (the sum of per-view losses is what a single GPU looping over the views optimises)."""
-        if self.fused:
-            return self._step_fused(loss_fn)
-        leaf = self.packed[:self.N].detach().requires_grad_(True)
-        loss = loss_fn(self.activate_fn(leaf))
-        (g,) = torch.autograd.grad(loss, leaf)
-        if self.world > 1:
-            self.grad_full[:self.N] = g
-        if self.world > 1 and self.backend == "gloo":
-            # gloo (CPU tests) has no reduce-scatter: all-reduce and take the local rows
-            dist.all_reduce(self.grad_full, op=dist.ReduceOp.SUM, group=self.group)
-            gs = self.grad_full[self.my_rows()].contiguous()
-        elif self.world > 1:
-            dist.reduce_scatter_tensor(self.grad_shard, self.grad_full, op=dist.ReduceOp.SUM, group=self.group)
-            gs = self.grad_shard
-        else:
-            gs = g if self.Npad == self.N else torch.nn.functional.pad(g, (0, 0, 0, self.Npad - self.N))
+        N = self.N
+        leaves = {n: self.state[n]["p"][:N].detach().requires_grad_(True) for n, _, _ in BLOCKS}
+        gd = self.activate_fn(leaves["raw8"])
+        gd["xyz"] = leaves["xyz"]
+        gd["shs"] = leaves["shs"].view(N, 16, 3)
+        loss = loss_fn(gd)
+        grads = torch.autograd.grad(loss, [leaves[n] for n, _, _ in BLOCKS], allow_unused=True)
         self.step_count += 1
-        shard = self.packed[self.my_rows()]
-        self.adam_fn(shard, gs, self.m, self.v, self.lr_col, self.step_count, self.eps)
-        if self.world > 1 and self.backend == "gloo":
-            parts = [torch.empty_like(shard) for _ in range(self.world)]
-            dist.all_gather(parts, shard.clone(), group=self.group)
-            self.packed.copy_(torch.cat(parts, dim=0))
-        elif self.world > 1:
-            dist.all_gather_into_tensor(self.packed, shard.clone(), group=self.group)
+        rows = self.my_rows()
+        for (name, _, _), g in zip(BLOCKS, grads):
+            st = self.state[name]
+            if g is None:
+                g = torch.zeros_like(leaves[name])
+            g = g.contiguous()
+            if self.world > 1:
+                st["gpad"][:N] = g
+                if self.backend == "gloo":      # gloo (CPU tests) has no reduce-scatter: all-reduce, take the local rows
+                    dist.all_reduce(st["gpad"], op=dist.ReduceOp.SUM, group=self.group)
+                    gs = st["gpad"][rows].contiguous()
+                else:
+                    dist.reduce_scatter_tensor(st["gshard"], st["gpad"], op=dist.ReduceOp.SUM, group=self.group)
+                    gs = st["gshard"]
+            else:
+                gs = g if self.Npad == N else torch.nn.functional.pad(g, (0, 0, 0, self.Npad - N))
+            shard = st["p"][rows]
+            self.adam_fn(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps)
+            if self.world > 1:
+                if self.backend == "gloo":
+                    parts = [torch.empty_like(shard) for _ in range(self.world)]
+                    dist.all_gather(parts, shard.clone(), group=self.group)
+                    st["p"].copy_(torch.cat(parts, dim=0))
+                else:
+                    dist.all_gather_into_tensor(st["p"], shard.clone(), group=self.group)
         return loss.detach()
 
 
-def _step_fused(self, loss_fn):
-    from . import _lib
-    lib = _lib.load()
-    dev = self.packed.device
-    keys = ("xyz", "opacity", "shs", "scales", "rotations", "normal")
-    if self._act is None:
-        with torch.no_grad():
-            self._act = {k: v.detach() for k, v in activate_hip(self.packed[:self.N]).items()}
-    leaves = {k: self._act[k].detach().requires_grad_(True) for k in keys}
-    loss = loss_fn(leaves)
-    grads = torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)
-    grads = [torch.zeros_like(leaves[k]) if g is None else g.contiguous() for k, g in zip(keys, grads)]
-    self.step_count += 1
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    P = lambda t: C.c_void_p(t.data_ptr())
-    with torch.cuda.device(dev):
-        rc = lib.rtgs_map_fused_step(P(self.packed), P(self.m), P(self.v), P(self.lr_col), self.N, self.step_count, 0.9,
-                                     0.999, float(self.eps), *(P(g) for g in grads),
-                                     *(P(self._act[k]) for k in keys), C.c_void_p(stream))
-    _lib.check(rc, "rtgs_map_fused_step")
-    return loss.detach()
-
-
-ShardedMapOptimizer._step_fused = _step_fused
-
-
-def slam_losses(render: Dict[str, torch.Tensor], gt_color: torch.Tensor, gt_depth: torch.Tensor,
+def slam_losses(render, gt_color: torch.Tensor, gt_depth: torch.Tensor,
                 color_weight: float = 0.8, depth_weight: float = 1.0) -> torch.Tensor:
     """Sync-free restatement of the live losses of mapper.py:402-442 (L1 colour over the render
     mask, masked L1 depth); `render` = (color[3,H,W], depth[1,H,W], ..., depth_index[1,H,W])."""

@@ -49,7 +49,7 @@ def _worker(rank, world, port, ret):
     from rtg_slam_amd import map_optim as mo
     from tests.dist_util import adam_reference
     packed, views, gts = _scene()
-    opt = mo.ShardedMapOptimizer(packed, adam_fn=adam_reference, activate_fn=mo.activate)
+    opt = mo.ShardedMapOptimizer(packed, adam_fn=adam_reference, activate_fn=mo.activate8)
     assert opt.world == 2 and opt.per == 51 and opt.Npad == 102
     for _ in range(2):
         opt.step(_loss_fn(views[rank], gts[rank]))
