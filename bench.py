@@ -100,7 +100,7 @@ def main():
                     tile_mask=tile_mask)
 
     def loss_fn(gd):
-        return mo.slam_losses(render(gd), gt_color, gt_depth)
+        return mo.slam_losses_hip(render(gd), gt_color, gt_depth)
 
     def frame():
         vp1, np1 = hicp.build_pyramids(d1, K, 3)

@@ -148,6 +148,15 @@ int rtgs_map_activate8_forward(const float* raw8, int64_t n, float* opacity, flo
 int rtgs_map_activate8_backward(const float* raw8, int64_t n, const float* g_opacity, const float* g_scales,
                                 const float* g_rotations, const float* g_normal, float* g_raw8, void* stream);
 
+/* Fused SLAM loss, the live terms of mapper.py:402-442:
+ *   L = color_weight * mean|C - C_gt| + depth_weight * sum(m |D - D_gt|) / max(sum m, 1),
+ *   m = (depth_index != -1) & (D_gt > 0).
+ * Writes the scalar loss and BOTH image gradients (dL/dC [3,H,W], dL/dD [1,H,W]) so the autograd
+ * graph of ~30 elementwise launches collapses into two kernels.  sums3_scratch: device float[3]. */
+int rtgs_slam_loss(const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
+                   const float* gt_depth, int32_t H, int32_t W, float color_weight, float depth_weight,
+                   float* sums3_scratch, float* loss_out, float* g_color, float* g_depth, void* stream);
+
 const char* rtgs_version(void);
 
 #ifdef __cplusplus

@@ -243,3 +243,36 @@ def slam_losses(render, gt_color: torch.Tensor, gt_depth: torch.Tensor,
     m = ((didx != -1) & (gt_depth > 0)).to(depth.dtype)
     depth_loss = ((depth - gt_depth).abs() * m).sum() / m.sum().clamp_min(1.0)
     return color_weight * color_loss + depth_weight * depth_loss
+
+
+class _SlamLossHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, depth, didx, gt_color, gt_depth, cw, dw):
+        from . import _lib
+        lib = _lib.load()
+        if not color.is_cuda:
+            raise RuntimeError("rtg_slam_amd.map_optim: slam_losses_hip needs HIP device tensors; no CPU path.")
+        dev = color.device
+        H, W = int(color.shape[1]), int(color.shape[2])
+        color, depth, didx = color.contiguous(), depth.contiguous(), didx.contiguous()
+        gt_color, gt_depth = gt_color.contiguous(), gt_depth.contiguous()
+        buf = torch.empty(4, dtype=torch.float32, device=dev)            # [0:3] partial sums, [3] loss
+        g_c, g_d = torch.empty_like(color), torch.empty_like(depth)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        P = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(dev):
+            rc = lib.rtgs_slam_loss(P(color), P(depth), P(didx), P(gt_color), P(gt_depth), H, W, float(cw), float(dw),
+                                    P(buf), C.c_void_p(buf.data_ptr() + 12), P(g_c), P(g_d), C.c_void_p(stream))
+        _lib.check(rc, "rtgs_slam_loss")
+        ctx.save_for_backward(g_c, g_d)
+        return buf[3]
+
+    @staticmethod
+    def backward(ctx, g):
+        g_c, g_d = ctx.saved_tensors
+        return g_c * g, g_d * g, None, None, None, None, None
+
+
+def slam_losses_hip(render, gt_color, gt_depth, color_weight: float = 0.8, depth_weight: float = 1.0) -> torch.Tensor:
+    """Same loss as `slam_losses`, value and both image gradients from two HIP kernels."""
+    return _SlamLossHip.apply(render[0], render[1], render[3], gt_color, gt_depth, color_weight, depth_weight)

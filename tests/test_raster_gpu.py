@@ -235,3 +235,22 @@ def test_matches_committed_golden(golden_dir):
     for k in ru.FIELDS:
         r = torch.from_numpy(z[f"grad_{k}"])
         assert float((gd_h[k] - r).abs().max()) / (float(r.abs().max()) + 1e-12) < 1e-3, k
+
+
+def test_fused_loss_matches_torch():
+    from rtg_slam_amd import map_optim as mo
+    dev = "cuda:0"
+    gen = torch.Generator().manual_seed(4)
+    H, W = 37, 53
+    color = torch.rand(3, H, W, generator=gen).to(dev).requires_grad_(True)
+    depth = (torch.rand(1, H, W, generator=gen) * 3).to(dev).requires_grad_(True)
+    didx = (torch.randint(-1, 5, (1, H, W), generator=gen, dtype=torch.int32)).to(dev)
+    gt_c = torch.rand(3, H, W, generator=gen).to(dev)
+    gt_d = (torch.rand(1, H, W, generator=gen) * 3 - 0.5).clamp_min(0).to(dev)
+    render = (color, depth, None, didx)
+    la = mo.slam_losses(render, gt_c, gt_d)
+    ga = torch.autograd.grad(la, [color, depth])
+    lb = mo.slam_losses_hip(render, gt_c, gt_d)
+    gb = torch.autograd.grad(lb * 2.0, [color, depth])
+    assert abs(float(la) - float(lb)) < 1e-6 * max(1.0, abs(float(la)))
+    assert float((ga[0] * 2 - gb[0]).abs().max()) < 1e-9 and float((ga[1] * 2 - gb[1]).abs().max()) < 1e-7
