@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtgs_hip.so")
+LIB_PATH = os.environ.get("RTGS_LIB_PATH") or os.path.join(_HERE, "librtgs_hip.so")   # env override: A/B of kernel variants
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 

@@ -177,29 +177,44 @@ __device__ __forceinline__ void final_stage(const float* __restrict__ partials, 
   float* __restrict__ JtJ_out = fa.JtJ_out;
   float* __restrict__ Jtr_out = fa.Jtr_out;
   float* __restrict__ nvalid_out = fa.nvalid_out;
-  __shared__ double s_sum[8 * PSTRIDE];
-  const int grp = threadIdx.x >> 5, k = threadIdx.x & 31;
-  double a = 0.0;
-  if (k < NACC) {
-    int b = grp;
-    for (; b + 24 < nblocks; b += 32) {              // 4 independent loads in flight
-      const float p0 = ld_sc1(&partials[(size_t)b * PSTRIDE + k]), p1 = ld_sc1(&partials[(size_t)(b + 8) * PSTRIDE + k]);
-      const float p2 = ld_sc1(&partials[(size_t)(b + 16) * PSTRIDE + k]), p3 = ld_sc1(&partials[(size_t)(b + 24) * PSTRIDE + k]);
-      a += ((double)p0 + (double)p1) + ((double)p2 + (double)p3);
+  // 256 threads = 32 row groups x 8 four-float columns: every thread issues all of its (<= 16 x 4)
+  // write-through loads before the first add, so the whole partial matrix costs ~2 memory round trips
+  __shared__ double s_sum[32 * PSTRIDE];
+  __shared__ double s_tot[PSTRIDE];
+  {
+    const int q = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (q < 7) {
+      constexpr int MAXR = (MAX_BLOCKS + 31) / 32;
+      float t[MAXR][4];
+#pragma unroll
+      for (int i = 0; i < MAXR; ++i) {
+        const int r = grp + 32 * i;
+        if (r < nblocks) {
+          const float* row = partials + (size_t)r * PSTRIDE + 4 * q;
+          t[i][0] = ld_sc1(row); t[i][1] = ld_sc1(row + 1); t[i][2] = ld_sc1(row + 2); t[i][3] = ld_sc1(row + 3);
+        } else {
+          t[i][0] = t[i][1] = t[i][2] = t[i][3] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MAXR; ++i) { a0 += (double)t[i][0]; a1 += (double)t[i][1]; a2 += (double)t[i][2]; a3 += (double)t[i][3]; }
     }
-    for (; b < nblocks; b += 8) a += (double)ld_sc1(&partials[(size_t)b * PSTRIDE + k]);
+    s_sum[grp * PSTRIDE + 4 * q] = a0; s_sum[grp * PSTRIDE + 4 * q + 1] = a1;
+    s_sum[grp * PSTRIDE + 4 * q + 2] = a2; s_sum[grp * PSTRIDE + 4 * q + 3] = a3;
   }
-  s_sum[grp * PSTRIDE + k] = a;
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) t += s_sum[g * PSTRIDE + threadIdx.x];
+    s_tot[threadIdx.x] = t;
+  }
   __syncthreads();
   if (threadIdx.x != 0) return;
   double S[NACC];
 #pragma unroll
-  for (int c = 0; c < NACC; ++c) {
-    double t = 0.0;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) t += s_sum[g * PSTRIDE + c];
-    S[c] = t;
-  }
+  for (int c = 0; c < NACC; ++c) S[c] = s_tot[c];
   if (mode == MODE_P2P) { stats[1] = (float)(S[0] * (double)inv_pixels); return; }
   double Hm[6][6], bvec[6];
 #pragma unroll
