@@ -1,0 +1,51 @@
+"""BASELINE.json config 4 in miniature: ICP front-end only on a synthetic TUM-shaped RGB-D stream -
+the drop-in IcpTracker chained over consecutive frames (frame-to-frame, as with icp_use_model_depth False)."""
+import numpy as np
+import pytest
+import torch
+
+from rtg_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class Args:
+    icp_downscales = [0.25, 0.5, 1.0]
+    icp_downscale_iters = [5, 5, 5]
+    icp_warmup_frames = 0
+    icp_use_model_depth = False
+    icp_distance_threshold = 0.1
+    icp_normal_threshold = 20
+    icp_damping = 1e-4
+    icp_sample_distance_threshold = 0.01
+    icp_sample_normal_threshold = 0.01
+    icp_fail_threshold = 0.02
+    verbose = False
+
+
+@pytest.mark.parametrize("cam,noise,tol", [(synth.TUM_FR1, False, 0.01), (synth.TUM_FR1, True, 0.03)])
+def test_tracking_a_stream(cam, noise, tol):
+    from rtg_slam_amd.icp import IcpTracker
+    dev = "cuda:0"
+    n = 12
+    base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
+    poses = [base @ p for p in synth.trajectory(n, seed=4)]
+    K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32, device=dev)
+    tr = IcpTracker(Args())
+    est = [np.eye(4)]
+    ok_all = True
+    for i in range(n):
+        d = synth.box_room_depth(cam, poses[i])
+        if noise:
+            d = synth.tum_noise(d, seed=10 + i, hole_frac=0.02)
+        tr.update_curr_status(d.to(dev), K)
+        if i > 0:
+            rel, ok = tr.predict_pose({"K": K, "frame_id": i})       # pose_t1_t0: c2w_t1 = c2w_t0 @ rel (tracker.py:282)
+            ok_all = ok_all and ok
+            est.append(est[-1] @ rel.astype(np.float64))
+        tr.move_last_status()
+    gt_rel = [np.linalg.inv(poses[0].numpy()) @ p.numpy() for p in poses]
+    err = max(np.linalg.norm(e[:3, 3] - g[:3, 3]) for e, g in zip(est, gt_rel))
+    assert err < tol, err                                    # metres of accumulated drift over 11 tracked frames
+    if not noise:
+        assert ok_all

@@ -1,0 +1,100 @@
+"""The reference's own `SLAM/render.py` (Renderer.render) runs UNCHANGED on top of this repository's
+`diff_gaussian_rasterization_depth` package.
+
+CPU part (build container only, needs /root/reference): import the reference module itself with its heavy
+imports stubbed and drive `Renderer.render` until it reaches the native op, which must refuse CPU tensors
+loudly - this proves the 19 settings keywords (render.py:68-88) and the 9 call keywords (:110-120) bind.
+GPU part: the same calling sequence restated (the reference tree does not exist on the GPU box),
+including the boolean-mask normal gather of render.py:130-133 on our int32 index map."""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+
+
+def _args():
+    return types.SimpleNamespace(renderer_opaque_threshold=0.6, renderer_normal_threshold=60, renderer_depth_threshold=1.0,
+                                 max_sh_degree=3, color_sigma=3.0, active_sh_degree=3)
+
+
+def _camera(cam, dev):
+    from oracle import raster_oracle as ro
+    s = ro.make_settings(cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy)
+    return types.SimpleNamespace(FoVx=2 * math.atan(cam.W / (2 * cam.fx)), FoVy=2 * math.atan(cam.H / (2 * cam.fy)),
+                                 image_height=cam.H, image_width=cam.W, world_view_transform=s.viewmatrix.to(dev),
+                                 full_proj_transform=s.projmatrix.to(dev), camera_center=s.campos.to(dev), cx=cam.cx, cy=cam.cy)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_renderer_binds_to_our_package():
+    from rtg_slam_amd import synth
+    for name in ["cv2", "open3d", "plyfile", "pytorch3d", "pytorch3d.loss", "pytorch3d.ops", "skimage", "skimage.color",
+                 "skimage.filters"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["cv2"].COLORMAP_JET = 2
+    sys.modules["plyfile"].PlyData = object; sys.modules["plyfile"].PlyElement = object
+    sys.modules["pytorch3d.loss"].chamfer_distance = None; sys.modules["pytorch3d.ops"].knn_points = None
+    sys.modules["skimage"].filters = sys.modules["skimage.filters"]; sys.modules["skimage.color"].rgb2gray = None
+    gu = types.ModuleType("utils.general_utils")
+    gu.devF = lambda t: t.float(); gu.devI = lambda t: t.int(); gu.devB = lambda t: t.bool()
+    gu.quaternion_from_axis_angle = None
+    gu.build_covariance_from_scaling_rotation = None; gu.inverse_sigmoid = None
+    pkg = types.ModuleType("utils"); pkg.__path__ = [os.path.join(REF, "utils")]
+    sys.modules.setdefault("utils", pkg); sys.modules["utils.general_utils"] = gu
+    cams = types.ModuleType("scene.cameras"); cams.Camera = object
+    scene = types.ModuleType("scene"); scene.__path__ = []
+    sys.modules.setdefault("scene", scene); sys.modules["scene.cameras"] = cams
+    if REF not in sys.path:
+        sys.path.append(REF)                       # appended: OUR diff_gaussian_rasterization_depth wins
+    import importlib
+    render_mod = importlib.import_module("SLAM.render")
+    import diff_gaussian_rasterization_depth as ours
+    assert render_mod.GaussianRasterizer_depth is ours.GaussianRasterizer
+    cam = synth.CameraSpec(32, 48, 40.0, 40.0, 23.5, 15.5)
+    g = synth.random_gaussians(20, cam, seed=1)
+    renderer = render_mod.Renderer(_args())
+    with pytest.raises(RuntimeError, match="HIP device"):      # reached the native op with every keyword bound
+        renderer.render(_camera(cam, "cpu"), g)
+
+
+@pytest.mark.gpu
+def test_render_call_sequence_on_gpu():
+    """SLAM/render.py:60-145 restated line by line against the HIP package."""
+    from diff_gaussian_rasterization_depth import GaussianRasterizationSettings, GaussianRasterizer
+    from rtg_slam_amd import synth
+    from tests import raster_util as ru
+    dev = "cuda:0"
+    cam = synth.CameraSpec(70, 101, 90.0, 85.0, 49.0, 36.0)
+    g = {k: v.to(dev) for k, v in synth.random_gaussians(800, cam, seed=5).items()}
+    args, vc = _args(), _camera(cam, dev)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(vc.image_height), image_width=int(vc.image_width), tanfovx=math.tan(vc.FoVx * 0.5),
+        tanfovy=math.tan(vc.FoVy * 0.5), bg=torch.tensor([0, 0, 0]).float().to(dev), scale_modifier=1.0,
+        viewmatrix=vc.world_view_transform, projmatrix=vc.full_proj_transform, sh_degree=args.active_sh_degree,
+        campos=vc.camera_center, opaque_threshold=args.renderer_opaque_threshold,
+        depth_threshold=args.renderer_depth_threshold, normal_threshold=np.cos(np.deg2rad(args.renderer_normal_threshold)),
+        color_sigma=args.color_sigma, prefiltered=False, debug=False, cx=vc.cx, cy=vc.cy, T_threshold=0.0001)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    tile_mask = torch.ones((vc.image_height + 15) // 16, (vc.image_width + 15) // 16, dtype=torch.int32).int().to(dev)
+    with torch.no_grad():                                  # SLAM/eval.py:241-251 renders under no_grad
+        res = rasterizer(means3D=g["xyz"], opacities=g["opacity"], shs=g["shs"], colors_precomp=None, scales=g["scales"],
+                         rotations=g["rotations"], cov3D_precomp=None, normal_w=g["normal"], tile_mask=tile_mask)
+    rendered_image, rendered_depth, color_index_map, depth_index_map = res[0], res[1], res[2], res[3]
+    color_hit_weight, depth_hit_weight, T_map = res[4], res[5], res[6]
+    render_normal = torch.zeros_like(rendered_image)
+    render_normal[:, depth_index_map[0] > -1] = g["normal"][depth_index_map[depth_index_map > -1].long()].permute(1, 0)
+    assert rendered_image.shape == (3, cam.H, cam.W) and T_map.shape == (1, cam.H, cam.W)
+    hit = depth_index_map[0] > -1
+    assert bool(hit.any())
+    assert torch.allclose(render_normal[:, hit].norm(dim=0), torch.ones(int(hit.sum()), device=dev), atol=1e-4)
+    assert torch.all(rendered_depth[0][hit] > 0) and torch.all(rendered_depth[0][~hit] == 0)
+    assert torch.all(depth_hit_weight[0][hit] > args.renderer_opaque_threshold)
+    assert torch.all(color_hit_weight[0][color_index_map[0] < 0] == 0)
+    # in-place hole filling on the rendered depth must be legal (icp.py:414 writes into it)
+    rendered_depth[0][~hit] = 1.0
