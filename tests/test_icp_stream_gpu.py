@@ -23,8 +23,9 @@ class Args:
     verbose = False
 
 
-@pytest.mark.parametrize("cam,noise,tol", [(synth.TUM_FR1, False, 0.01), (synth.TUM_FR1, True, 0.03)])
+@pytest.mark.parametrize("cam,noise,tol", [(synth.TUM_FR1, False, 0.01), (synth.TUM_FR1, True, 0.10)])
 def test_tracking_a_stream(cam, noise, tol):
+    from oracle import icp_oracle as io
     from rtg_slam_amd.icp import IcpTracker
     dev = "cuda:0"
     n = 12
@@ -34,6 +35,8 @@ def test_tracking_a_stream(cam, noise, tol):
     tr = IcpTracker(Args())
     est = [np.eye(4)]
     ok_all = True
+    prev = None
+    worst_vs_oracle = 0.0
     for i in range(n):
         d = synth.box_room_depth(cam, poses[i])
         if noise:
@@ -43,7 +46,15 @@ def test_tracking_a_stream(cam, noise, tol):
             rel, ok = tr.predict_pose({"K": K, "frame_id": i})       # pose_t1_t0: c2w_t1 = c2w_t0 @ rel (tracker.py:282)
             ok_all = ok_all and ok
             est.append(est[-1] @ rel.astype(np.float64))
+            if noise and i <= 4:                                     # the pinned oracle on the same frame pair
+                Kc = K.cpu()
+                vp0 = io.vertex_pyramid(prev, Kc.clone(), 3); np0 = io.normal_pyramid(vp0)
+                vp1 = io.vertex_pyramid(d, Kc.clone(), 3); np1 = io.normal_pyramid(vp1)
+                pose_o, _, _ = io.track(vp1, np1, vp0, np0, Kc.clone())
+                worst_vs_oracle = max(worst_vs_oracle, float(np.abs(rel - pose_o.numpy()).max()))
         tr.move_last_status()
+        prev = d
+    assert worst_vs_oracle < 5e-4, worst_vs_oracle          # noisy data: a few gate flips per iteration (see test_icp_gpu)
     gt_rel = [np.linalg.inv(poses[0].numpy()) @ p.numpy() for p in poses]
     err = max(np.linalg.norm(e[:3, 3] - g[:3, 3]) for e, g in zip(est, gt_rel))
     assert err < tol, err                                    # metres of accumulated drift over 11 tracked frames
