@@ -309,45 +309,76 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
       s_h[tid] = make_float2(r3.z, r3.w);
     }
     __syncthreads();
-    for (int j = 0; j < m; ++j) {
+    // Four entries per round: their records are read and their alphas evaluated back to back (independent
+    // instruction streams, one LDS wait), only the T recurrence is sequential.  A single wave issues roughly
+    // one dependent instruction every 8-15 cycles, so the walk is bound by the length of the dependent chain
+    // per entry (measured: ~1 700 cycles per entry in the one-entry-at-a-time form) - not by ALU throughput.
+    for (int j = 0; j < m; j += 4) {
       const unsigned long long am = __builtin_amdgcn_ballot_w64(!done);
       if (am == 0ull) break;                // whole wave finished
       if (am != box.mask) refresh_box(box, am, blockIdx.x * TILE, blockIdx.y * TILE + (tid >> 6) * 4);
-      const float4 r0 = s_rec[j * 4 + 0];   // u v ca cb
-      // wave-uniform: the entry's alpha >= 1/255 region misses every pixel of this wave still walking
-      const float2 eh = s_h[j];
-      if (r0.x + eh.x < box.x0 || r0.x - eh.x > box.x1 || r0.y + eh.y < box.y0 || r0.y - eh.y > box.y1) continue;
-      const float4 r1 = s_rec[j * 4 + 1];   // cc o r g
-      // branch-free per-lane evaluation (predication instead of nested exec-mask regions)
-      const float dx = r0.x - pxf, dy = r0.y - pyf;
-      const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
-      const float alpha = fminf(0.99f, r1.y * splat_exp(fminf(power, 0.f)));
-      const bool ok = !done && !(power > 0.f) && !(alpha < 1.f / 255.f);
-      const float test_T = T * (1.f - alpha);
-      const bool stop = ok && (test_T < p.T_thr);
-      const bool contrib = ok && !stop;
-      evals += done ? 0u : 1u;
-      done = done || stop;
-      if (__builtin_amdgcn_ballot_w64(contrib) == 0ull) continue;
-      const float4 r2 = s_rec[j * 4 + 2];   // b nx ny nz
-      const float w = contrib ? alpha * T : 0.f;
-      C0 += r1.z * w; C1 += r1.w * w; C2 += r2.x * w;
-      const bool better = w > best_w;        // w == 0 for non-contributing lanes, best_w >= 0
-      const int gid = s_id[j];
-      best_w = better ? w : best_w;
-      best_id = better ? gid : best_id;
-      if (__builtin_amdgcn_ballot_w64(contrib && d_id < 0 && alpha > p.opaque_thr) != 0ull) {   // rare
-        if (contrib && d_id < 0 && alpha > p.opaque_thr) {
-          const float4 r3 = s_rec[j * 4 + 3];  // pd z hx hy
-          const float den = r2.y * rx + r2.z * ry + r2.w;
-          if (fabsf(den) / rnorm > p.normal_thr) {
-            const float zhit = r3.x / den;
-            if (zhit > 0.f && fabsf(zhit - r3.y) < p.depth_thr) { D = zhit; d_w = alpha; d_id = gid; }
+      float4 r0[4], r1[4];
+      float alpha[4];
+      bool live[4];
+      int e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        e[k] = min(j + k, m - 1);           // past the end: re-read the last entry (finite data), masked out by live[]
+        r0[k] = s_rec[e[k] * 4 + 0];        // u v ca cb
+        r1[k] = s_rec[e[k] * 4 + 1];        // cc o r g
+        const float2 eh = s_h[e[k]];
+        // wave-uniform: entry exists and its alpha >= 1/255 region reaches a pixel of this wave still walking
+        live[k] = (j + k < m) && !(r0[k].x + eh.x < box.x0 || r0[k].x - eh.x > box.x1 || r0[k].y + eh.y < box.y0 ||
+                                   r0[k].y - eh.y > box.y1);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dx = r0[k].x - pxf, dy = r0[k].y - pyf;
+        const float power = splat_power(r0[k].z, r0[k].w, r1[k].x, dx, dy);
+        const float al = fminf(0.99f, r1[k].y * splat_exp(fminf(power, 0.f)));
+        alpha[k] = (live[k] && !(power > 0.f) && !(al < 1.f / 255.f)) ? al : 0.f;     // 0 = skipped
+      }
+      float w[4];
+      bool any_contrib = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {         // the sequential part: transmittance recurrence and the stop rule
+        const bool ok = !done && alpha[k] > 0.f;
+        const float test_T = T * (1.f - alpha[k]);
+        const bool stop = ok && (test_T < p.T_thr);
+        const bool contrib = ok && !stop;
+        evals += (!done && live[k]) ? 1u : 0u;
+        done = done || stop;
+        w[k] = contrib ? alpha[k] * T : 0.f;
+        T = contrib ? test_T : T;
+        last_contributor = contrib ? (uint32_t)(base + j + k + 1) : last_contributor;
+        any_contrib = any_contrib || contrib;
+      }
+      if (__builtin_amdgcn_ballot_w64(any_contrib) == 0ull) continue;
+      bool want_depth = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float cb = s_rec[e[k] * 4 + 2].x;
+        C0 += r1[k].z * w[k]; C1 += r1[k].w * w[k]; C2 += cb * w[k];
+        const bool better = w[k] > best_w;   // w == 0 for non-contributing lanes, best_w >= 0
+        const int gid = s_id[e[k]];
+        best_w = better ? w[k] : best_w;
+        best_id = better ? gid : best_id;
+        want_depth = want_depth || (w[k] > 0.f && alpha[k] > p.opaque_thr);
+      }
+      if (__builtin_amdgcn_ballot_w64(want_depth && d_id < 0) != 0ull) {   // rare: opaque-surface depth candidates
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (w[k] > 0.f && d_id < 0 && alpha[k] > p.opaque_thr) {
+            const float4 r2 = s_rec[e[k] * 4 + 2];  // b nx ny nz
+            const float4 r3 = s_rec[e[k] * 4 + 3];  // pd z hx hy
+            const float den = r2.y * rx + r2.z * ry + r2.w;
+            if (fabsf(den) / rnorm > p.normal_thr) {
+              const float zhit = r3.x / den;
+              if (zhit > 0.f && fabsf(zhit - r3.y) < p.depth_thr) { D = zhit; d_w = alpha[k]; d_id = s_id[e[k]]; }
+            }
           }
         }
       }
-      T = contrib ? test_T : T;
-      last_contributor = contrib ? (uint32_t)(base + j + 1) : last_contributor;
     }
   }
   contributor = last_contributor;   // accounting only (entries this pixel needed)
