@@ -25,10 +25,9 @@ void launch_preprocess_bwd(const RasterParams&, const float*, const float*, cons
 // process-wide (autograd runs backward on its own thread): last-call stats, counters, profiling
 size_t bin_lds_limit_tiles();
 int bin_sort_capacity();
-int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, uint32_t*,
-                     hipStream_t);
+int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, hipStream_t);
 void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, hipStream_t);
-void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, const uint32_t*,
+void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*,
                         unsigned long long*, hipStream_t);
 void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*, uint32_t*, hipStream_t);
 
@@ -224,8 +223,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
     prof_mark(EV_PRE, st);
     if (!sort_path) {
       // exact per-tile counts -> ranges; the one host sync of the forward sizes the instance arrays
-      // `offsets` (unused on this path) carries the per-Gaussian visibility bits from count to scatter
-      if (launch_bin_count(p, splats, radii, tile_mask, tile_count, offsets, st) != 0) return RTGS_E_HIP;
+      if (launch_bin_count(p, splats, radii, tile_mask, tile_count, st) != 0) return RTGS_E_HIP;
       launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, st);
       DBG(s, st);
       uint32_t h[2] = {0, 0};
@@ -266,7 +264,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   if (P == 0 || sort_path) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), st));
   if (R > 0 && !sort_path) {
     prof_mark(EV_BIN0, st);
-    launch_bin_scatter(p, splats, radii, tile_mask, cursor, offsets, (unsigned long long*)keys_a, st);
+    launch_bin_scatter(p, splats, radii, tile_mask, cursor, (unsigned long long*)keys_a, st);
     DBG(s, st);
     prof_mark(EV_EMIT, st);
     launch_bin_tilesort(ntiles, longest, ranges, (const unsigned long long*)keys_a, vals_b, st);

@@ -121,42 +121,69 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     }
     __syncthreads();
 
-    for (int j = 0; j < m; ++j) {
-      const uint32_t pos = (uint32_t)(base + j);                 // list position of this entry (uniform)
-      if (__builtin_amdgcn_ballot_w64(pos < last) == 0ull) break; // whole wave past its last contributor
-      const float4 r0 = s_rec[j * 3 + 0];
-      const float ehy = s_hy[j];
-      if (r0.y + ehy < strip_y0 || r0.y - ehy > strip_y1) continue;   // wave-uniform strip test
-      const float4 r1 = s_rec[j * 3 + 1];
-      // branch-free per-lane evaluation
-      const float dx = r0.x - pxf, dy = r0.y - pyf;
-      const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
-      const float G = splat_exp(fminf(power, 0.f));
-      const float oG = r1.y * G;
-      const float alpha = fminf(0.99f, oG);
-      const bool valid = (pos < last) && !(power > 0.f) && !(alpha < 1.f / 255.f);
-      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;   // wave-uniform
-      const float4 r2 = s_rec[j * 3 + 2];
-      const float c0 = r1.z, c1 = r1.w, c2 = r2.x;
-      const float w = valid ? alpha * T : 0.f;
-      S0 -= c0 * w; S1 -= c1 * w; S2 -= c2 * w;                  // colour strictly behind this entry
-      const float oma = 1.f - alpha;
-      const float ia = __builtin_amdgcn_rcpf(oma);
-      const float dL_dalpha = T * (c0 * g0 + c1 * g1 + c2 * g2) - (S0 * g0 + S1 * g1 + S2 * g2 + bgT) * ia;
-      const float gda = (valid && oG <= 0.99f) ? G * dL_dalpha : 0.f;   // d min(0.99, oG)/d(oG): autograd of clamp
-      const float gdl = gda * r1.y;
-      float v[8];
-      v[0] = gdl * (-r0.z * dx - r0.w * dy);
-      v[1] = gdl * (-r1.x * dy - r0.w * dx);
-      v[2] = gdl * (-0.5f * dx * dx);
-      v[3] = gdl * (-dx * dy);
-      v[4] = gdl * (-0.5f * dy * dy);
-      v[5] = w * g0; v[6] = w * g1; v[7] = w * g2;
-      T = valid ? T * oma : T;
-      const float r8 = butterfly8(v, lane);
-      const float ro = wave_sum_to_lane63(gda);
-      atomicAdd(&s_grad[j * NG + gidx], r8);                      // 8 groups -> 8-way same-address add
-      if (lane == 63) atomicAdd(&s_grad[j * NG + 8], ro);
+    // Two entries per round: records, alphas and the two 8-value butterflies are independent instruction
+    // streams (the single-wave dependent chain, not ALU throughput, bounds this walk); only the
+    // T / S recurrences are sequential.
+    for (int j = 0; j < m; j += 2) {
+      if (__builtin_amdgcn_ballot_w64((uint32_t)(base + j) < last) == 0ull) break;   // wave past its last contributor
+      float4 r0[2], r1[2];
+      float dx[2], dy[2], G[2], oG[2], alpha[2];
+      bool valid[2];
+      int e[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        e[k] = min(j + k, m - 1);                                 // past the end: re-read the last entry, masked out
+        r0[k] = s_rec[e[k] * 3 + 0];
+        r1[k] = s_rec[e[k] * 3 + 1];
+        const float ehy = s_hy[e[k]];
+        const bool live = (j + k < m) && !(r0[k].y + ehy < strip_y0 || r0[k].y - ehy > strip_y1);   // wave-uniform
+        dx[k] = r0[k].x - pxf; dy[k] = r0[k].y - pyf;
+        const float power = splat_power(r0[k].z, r0[k].w, r1[k].x, dx[k], dy[k]);
+        G[k] = splat_exp(fminf(power, 0.f));
+        oG[k] = r1[k].y * G[k];
+        alpha[k] = fminf(0.99f, oG[k]);
+        valid[k] = live && ((uint32_t)(base + j + k) < last) && !(power > 0.f) && !(alpha[k] < 1.f / 255.f);
+      }
+      const unsigned long long vm0 = __builtin_amdgcn_ballot_w64(valid[0]);
+      const unsigned long long vm1 = __builtin_amdgcn_ballot_w64(valid[1]);
+      if ((vm0 | vm1) == 0ull) continue;                          // wave-uniform
+      float gda[2], w[2], Tk[2], Sg[2], cg[2], ia[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {                               // sequential part: T and the colour behind
+        const float c0 = r1[k].z, c1 = r1[k].w, c2 = s_rec[e[k] * 3 + 2].x;
+        w[k] = valid[k] ? alpha[k] * T : 0.f;
+        S0 -= c0 * w[k]; S1 -= c1 * w[k]; S2 -= c2 * w[k];       // colour strictly behind this entry
+        Tk[k] = T;
+        const float oma = 1.f - alpha[k];
+        ia[k] = __builtin_amdgcn_rcpf(oma);
+        T = valid[k] ? T * oma : T;
+        Sg[k] = S0 * g0 + S1 * g1 + S2 * g2 + bgT;
+        cg[k] = c0 * g0 + c1 * g1 + c2 * g2;
+      }
+      float r8[2], ro[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float dL_dalpha = Tk[k] * cg[k] - Sg[k] * ia[k];
+        gda[k] = (valid[k] && oG[k] <= 0.99f) ? G[k] * dL_dalpha : 0.f;   // d min(0.99, oG)/d(oG): autograd of clamp
+        const float gdl = gda[k] * r1[k].y;
+        float v[8];
+        v[0] = gdl * (-r0[k].z * dx[k] - r0[k].w * dy[k]);
+        v[1] = gdl * (-r1[k].x * dy[k] - r0[k].w * dx[k]);
+        v[2] = gdl * (-0.5f * dx[k] * dx[k]);
+        v[3] = gdl * (-dx[k] * dy[k]);
+        v[4] = gdl * (-0.5f * dy[k] * dy[k]);
+        v[5] = w[k] * g0; v[6] = w[k] * g1; v[7] = w[k] * g2;
+        r8[k] = butterfly8(v, lane);
+        ro[k] = wave_sum_to_lane63(gda[k]);
+      }
+      if (vm0) {
+        atomicAdd(&s_grad[e[0] * NG + gidx], r8[0]);              // 8 groups -> 8-way same-address add
+        if (lane == 63) atomicAdd(&s_grad[e[0] * NG + 8], ro[0]);
+      }
+      if (vm1) {
+        atomicAdd(&s_grad[e[1] * NG + gidx], r8[1]);
+        if (lane == 63) atomicAdd(&s_grad[e[1] * NG + 8], ro[1]);
+      }
     }
     __syncthreads();
     if (tid < m) {
