@@ -254,3 +254,39 @@ def test_fused_loss_matches_torch():
     gb = torch.autograd.grad(lb * 2.0, [color, depth])
     assert abs(float(la) - float(lb)) < 1e-6 * max(1.0, abs(float(la)))
     assert float((ga[0] * 2 - gb[0]).abs().max()) < 1e-9 and float((ga[1] * 2 - gb[1]).abs().max()) < 1e-7
+
+
+def test_automatic_fallbacks():
+    """The two conditions that leave the LDS-resident binning path: a tile grid above 16 000 tiles and a single
+    tile list above 16 384 entries (the latter is discovered after counting and re-runs the preprocess)."""
+    import ctypes
+    from rtg_slam_amd import _lib
+    lib = _lib.load()
+    st = (ctypes.c_int64 * 8)()
+    # (a) 2064 x 2064 image -> 129 x 129 = 16 641 tiles
+    big = synth.CameraSpec(2064, 2064, 1500.0, 1500.0, 1031.5, 1031.5)
+    g, s = ru.make_scene(400, big, seed=31)
+    out_h, _ = ru.hip_run(s, g)
+    lib.rtgs_raster_last_stats(st)
+    assert st[6] == 0 and st[2] == 129 * 129
+    out_o, _, _ = ru.oracle_run(s, g)
+    check_forward(out_h, out_o)
+    # (b) 20 000 low-opacity discs piled onto one tile
+    cam = SMALL
+    g, s = ru.make_scene(20000, cam, seed=32)
+    z = 1.0 + 2.0 * torch.rand(20000)
+    g["xyz"][:, 0] = ((40.0 - cam.cx) / cam.fx) * z + 0.004 * torch.randn(20000)      # pixel (40, 24): middle of a tile
+    g["xyz"][:, 1] = ((24.0 - cam.cy) / cam.fy) * z + 0.004 * torch.randn(20000)
+    g["xyz"][:, 2] = z
+    g["scales"] = torch.full((20000, 3), 0.004)
+    g["opacity"] = torch.full((20000, 1), 0.02)
+    gen = torch.Generator().manual_seed(9)
+    grads = (torch.randn(3, cam.H, cam.W, generator=gen), torch.randn(1, cam.H, cam.W, generator=gen))
+    out_h, gd_h = ru.hip_run(s, g, grads=grads)
+    lib.rtgs_raster_last_stats(st)
+    assert st[6] == 0 and st[0] > 16384, (st[6], st[0], st[7])
+    out_o, gd_o, _ = ru.oracle_run(s, g, grads=grads)
+    check_forward(out_h, out_o)
+    for k in ru.FIELDS:
+        sc = float(gd_o[k].abs().max()) + 1e-12
+        assert float((gd_h[k] - gd_o[k]).abs().max()) / sc < 1e-3, k
