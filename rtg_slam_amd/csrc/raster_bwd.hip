@@ -49,6 +49,16 @@ __device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
   const float send = b2 ? x[0] : x[1];
   return keep + xor4(send);
 }
+// lanes 0..7 of the wave end up with the wave totals of the 8 butterfly quantities (lane l holds
+// quantity idx(l)): fold the two groups of a row (row_ror:8), the two rows of a half (ds_swizzle
+// xor 16) and the two halves (xor 32) - so the LDS add that follows has 8 DISTINCT addresses
+// (8 lanes x same address serialises inside the LDS atomic unit).
+__device__ __forceinline__ float fold_groups(float v) {
+  v += dpp_mov<0x128>(0.f, v);                                                       // row_ror:8  (lane ^ 8)
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));       // xor 16 within 32 lanes
+  v += __shfl_xor(v, 32);
+  return v;
+}
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   v += dpp_mov<0xB1>(0.f, v);               // quad_perm [1,0,3,2]
   v += dpp_mov<0x4E>(0.f, v);               // quad_perm [2,3,0,1]
@@ -74,7 +84,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
   __shared__ float4 s_rec[BATCH * 3];
   __shared__ int32_t s_id[BATCH];
   __shared__ float s_hy[BATCH];
-  __shared__ float s_grad[BATCH * NG];
+  __shared__ float s_grad[4 * BATCH * NG];      // one private copy per wave: plain stores, no LDS atomics
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -101,6 +111,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
   const float bgT = T_final * (p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2);
   float T = 1.f;
   const int gidx = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
+  float* const wgrad = s_grad + (tid >> 6) * BATCH * NG;
   const float strip_y0 = (float)(blockIdx.y * TILE + (tid >> 6) * 4), strip_y1 = strip_y0 + 3.f;
 
   for (int base = 0; base < n; base += BATCH) {
@@ -115,10 +126,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
       s_rec[tid * 3 + 2] = src[2];
       s_hy[tid] = reinterpret_cast<const float*>(splats + id)[15];
     }
-    if (tid < BATCH) {
-#pragma unroll
-      for (int k = 0; k < NG; ++k) s_grad[tid * NG + k] = 0.f;
-    }
+    for (int q = tid; q < 4 * BATCH * NG; q += BLOCK) s_grad[q] = 0.f;
     __syncthreads();
 
     // Two entries per round: records, alphas and the two 8-value butterflies are independent instruction
@@ -176,13 +184,16 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
         r8[k] = butterfly8(v, lane);
         ro[k] = wave_sum_to_lane63(gda[k]);
       }
+      // every (wave, entry, quantity) slot is written at most once per batch -> plain LDS stores
       if (vm0) {
-        atomicAdd(&s_grad[e[0] * NG + gidx], r8[0]);              // 8 groups -> 8-way same-address add
-        if (lane == 63) atomicAdd(&s_grad[e[0] * NG + 8], ro[0]);
+        const float t8 = fold_groups(r8[0]);
+        if (lane < 8) wgrad[e[0] * NG + gidx] = t8;
+        if (lane == 63) wgrad[e[0] * NG + 8] = ro[0];
       }
       if (vm1) {
-        atomicAdd(&s_grad[e[1] * NG + gidx], r8[1]);
-        if (lane == 63) atomicAdd(&s_grad[e[1] * NG + 8], ro[1]);
+        const float t8 = fold_groups(r8[1]);
+        if (lane < 8) wgrad[e[1] * NG + gidx] = t8;
+        if (lane == 63) wgrad[e[1] * NG + 8] = ro[1];
       }
     }
     __syncthreads();
@@ -190,7 +201,11 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
       float t[NG];
       bool any = false;
 #pragma unroll
-      for (int k = 0; k < NG; ++k) { t[k] = s_grad[tid * NG + k]; any |= (t[k] != 0.f); }
+      for (int k = 0; k < NG; ++k) {
+        t[k] = (s_grad[tid * NG + k] + s_grad[(BATCH + tid) * NG + k]) +
+               (s_grad[(2 * BATCH + tid) * NG + k] + s_grad[(3 * BATCH + tid) * NG + k]);
+        any |= (t[k] != 0.f);
+      }
       if (any) {
         float* dst = reinterpret_cast<float*>(grads + s_id[tid]);
         // SplatGrad order: du dv dca dcb dcc dop dr dg db
