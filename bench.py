@@ -50,10 +50,16 @@ def main():
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        # RTGS_DIST_BACKEND=gloo lets two ranks share one GPU (RCCL refuses that) to exercise this code path
+        # on a single-GPU box; the driver's multi-GPU runs use nccl (= RCCL over xGMI), one rank per GPU.
+        backend = os.environ.get("RTGS_DIST_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % ndev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", (local_rank % torch.cuda.device_count()) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     from rtg_slam_amd import _lib, synth, icp as hicp
