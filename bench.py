@@ -128,14 +128,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # untimed device pre-warm: a cold box starts at idle clocks and with an empty allocator cache;
-    # run the real workload for ~1.5 s before the W warm-up steps the contract asks for
-    t_pre = time.perf_counter()
-    n_pre = 0
-    while n_pre < 20 or (time.perf_counter() - t_pre < 1.5 and n_pre < 400):
+    # untimed device pre-warm: a cold box starts at idle clocks and with an empty allocator cache; run the
+    # real workload before the W warm-up steps the contract asks for.  The count is FIXED (never
+    # time-based): every rank must issue the same number of collectives.
+    for n_pre in range(200):
         frame()
-        n_pre += 1
-        if n_pre % 20 == 0:
+        if n_pre % 20 == 19:
             torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         frame()
