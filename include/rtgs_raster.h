@@ -104,7 +104,7 @@ int rtgs_raster_backward(const rtgs_raster_settings* settings, int32_t P, int32_
 size_t rtgs_raster_backward_scratch_bytes(int32_t P);
 
 /* Sizes the forward will request through the callbacks (for pre-allocation / accounting). */
-size_t rtgs_raster_geom_bytes(int32_t P);
+size_t rtgs_raster_geom_bytes(int32_t P, int32_t image_height, int32_t image_width);
 size_t rtgs_raster_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
 size_t rtgs_raster_image_bytes(int32_t image_height, int32_t image_width);
 

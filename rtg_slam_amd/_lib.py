@@ -51,7 +51,7 @@ _SIGNATURES = {
     "rtgs_raster_backward": (C.c_int, [C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6
                              + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P]),
     "rtgs_raster_backward_scratch_bytes": (C.c_size_t, [C.c_int32]),
-    "rtgs_raster_geom_bytes": (C.c_size_t, [C.c_int32]),
+    "rtgs_raster_geom_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rtgs_raster_binning_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "rtgs_raster_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "rtgs_raster_last_stats": (C.c_int, [C.POINTER(C.c_int64)]),

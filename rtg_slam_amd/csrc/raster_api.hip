@@ -152,9 +152,8 @@ extern "C" {
 
 const char* rtgs_version(void) { return "rtgs-hip 0.1.0 (gfx950)"; }
 
-size_t rtgs_raster_geom_bytes(int32_t P) {
-  // the SAT term depends on the image; callers that pre-allocate should add image tiles * 4 B.
-  return geom_layout(P, 512, 512).total;
+size_t rtgs_raster_geom_bytes(int32_t P, int32_t H, int32_t W) {
+  return geom_layout(P, (W + TILE - 1) / TILE, (H + TILE - 1) / TILE).total;
 }
 size_t rtgs_raster_binning_bytes(int64_t R, int32_t H, int32_t W) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;

@@ -90,6 +90,15 @@ def test_empty_and_all_masked():
     gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
     out_h, _ = ru.hip_run(s, g, tile_mask=torch.zeros(gy, gx, dtype=torch.int32))
     assert torch.all(out_h[6] == 1) and torch.all(out_h[1] == 0) and torch.all(out_h[3] == -1)
+    # every Gaussian culled (behind the camera): zero instances, blank maps, exactly-zero gradients
+    g2 = {k: v.clone() for k, v in g.items()}
+    g2["xyz"][:, 2] = -g2["xyz"][:, 2].abs() - 1.0
+    gen = torch.Generator().manual_seed(1)
+    grads = (torch.randn(3, cam.H, cam.W, generator=gen), torch.randn(1, cam.H, cam.W, generator=gen))
+    out_h, gd_h = ru.hip_run(s, g2, grads=grads)
+    assert torch.all(out_h[6] == 1) and torch.all(out_h[2] == -1) and float(out_h[0].abs().max()) == 0
+    for k in ru.FIELDS:
+        assert torch.all(gd_h[k] == 0), k
 
 
 def test_behind_camera_and_stacked_opaque():
