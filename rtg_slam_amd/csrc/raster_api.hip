@@ -25,9 +25,10 @@ void launch_preprocess_bwd(const RasterParams&, const float*, const float*, cons
 // process-wide (autograd runs backward on its own thread): last-call stats, counters, profiling
 size_t bin_lds_limit_tiles();
 int bin_sort_capacity();
-int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, hipStream_t);
+size_t bin_block_counts_bytes(int, int);
+int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, uint16_t*, hipStream_t);
 void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, hipStream_t);
-void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*,
+void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const uint16_t*, uint32_t*,
                         unsigned long long*, hipStream_t);
 void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*, uint32_t*, hipStream_t);
 
@@ -70,6 +71,7 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy) {
   L.tile_count = off; off = align_up(off + (size_t)gx * gy * sizeof(uint32_t));
   L.cursor = off; off = align_up(off + (size_t)gx * gy * sizeof(uint32_t));
   L.info = off; off = align_up(off + 4 * sizeof(uint32_t));
+  L.block_counts = off; off = align_up(off + bin_block_counts_bytes((int)Pn, gx * gy));
   size_t tb = 0;
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)Pn);
   L.scan_temp_bytes = tb;
@@ -209,6 +211,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   uint32_t* tile_count = (uint32_t*)(geom + G.tile_count);
   uint32_t* cursor = (uint32_t*)(geom + G.cursor);
   uint32_t* info = (uint32_t*)(geom + G.info);
+  uint16_t* block_counts = (uint16_t*)(geom + G.block_counts);
   uint32_t longest = 0;
   bool sort_path = (size_t)ntiles > bin_lds_limit_tiles() || g_force_sort_path;
   if (P > 0) {
@@ -222,7 +225,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
     prof_mark(EV_PRE, st);
     if (!sort_path) {
       // exact per-tile counts -> ranges; the one host sync of the forward sizes the instance arrays
-      if (launch_bin_count(p, splats, radii, tile_mask, tile_count, st) != 0) return RTGS_E_HIP;
+      if (launch_bin_count(p, splats, radii, tile_mask, tile_count, block_counts, st) != 0) return RTGS_E_HIP;
       launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, st);
       DBG(s, st);
       uint32_t h[2] = {0, 0};
@@ -263,7 +266,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   if (P == 0 || sort_path) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), st));
   if (R > 0 && !sort_path) {
     prof_mark(EV_BIN0, st);
-    launch_bin_scatter(p, splats, radii, tile_mask, cursor, (unsigned long long*)keys_a, st);
+    launch_bin_scatter(p, splats, radii, block_counts, cursor, (unsigned long long*)keys_a, st);
     DBG(s, st);
     prof_mark(EV_EMIT, st);
     launch_bin_tilesort(ntiles, longest, ranges, (const unsigned long long*)keys_a, vals_b, st);

@@ -50,7 +50,7 @@ struct RasterParams {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-  size_t splats, tiles_touched, offsets, radii, clamped, sat, tile_count, cursor, info, scan_temp, total;
+  size_t splats, tiles_touched, offsets, radii, clamped, sat, tile_count, cursor, info, block_counts, scan_temp, total;
   size_t scan_temp_bytes;
 };
 struct BinLayout {
