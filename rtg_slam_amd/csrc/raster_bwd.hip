@@ -114,9 +114,22 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
   float* const wgrad = s_grad + (tid >> 6) * BATCH * NG;
   const float strip_y0 = (float)(blockIdx.y * TILE + (tid >> 6) * 4), strip_y1 = strip_y0 + 3.f;
 
-  for (int base = 0; base < n; base += BATCH) {
-    if (__syncthreads_and((uint32_t)base >= last)) break;
-    const int m = min(BATCH, n - base);
+  // only entries below the tile's largest `last` were blended by any pixel: stage and zero no more than that
+  __shared__ unsigned int s_nmax;
+  if (tid == 0) s_nmax = 0;
+  __syncthreads();
+  {
+    unsigned int wl = last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wl = max(wl, (unsigned int)__shfl_xor((int)wl, off));
+    if (lane == 0) atomicMax(&s_nmax, wl);
+  }
+  __syncthreads();
+  const int nuse = min(n, (int)s_nmax);
+
+  for (int base = 0; base < nuse; base += BATCH) {
+    const int m = min(BATCH, nuse - base);
+    __syncthreads();                                   // previous batch fully flushed before its LDS is reused
     if (tid < m) {
       const uint32_t id = point_list[range.x + base + tid];
       s_id[tid] = (int32_t)id;
@@ -126,7 +139,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
       s_rec[tid * 3 + 2] = src[2];
       s_hy[tid] = reinterpret_cast<const float*>(splats + id)[15];
     }
-    for (int q = tid; q < 4 * BATCH * NG; q += BLOCK) s_grad[q] = 0.f;
+    for (int q = tid; q < 4 * BATCH * NG; q += BLOCK)
+      if ((q % (BATCH * NG)) < m * NG) s_grad[q] = 0.f;
     __syncthreads();
 
     // Two entries per round: records, alphas and the two 8-value butterflies are independent instruction
