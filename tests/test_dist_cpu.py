@@ -41,7 +41,32 @@ def _loss_fn(settings, gt):
     return fn
 
 
-def _worker(rank, world, port, ret):
+class _Done:
+    def wait(self):
+        return True
+
+
+def _emulate_rccl_collectives():
+    """reduce_scatter_tensor / all_gather_into_tensor (async) on top of gloo primitives, so the RCCL branch of
+    ShardedMapOptimizer.step (queue all reduce-scatters, Adam under the big one, async all-gathers) runs on CPU."""
+    def reduce_scatter_tensor(out, inp, op=None, group=None, async_op=False):
+        tmp = inp.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+        per = out.shape[0]
+        r = dist.get_rank(group)
+        out.copy_(tmp[r * per:(r + 1) * per])
+        return _Done()
+
+    def all_gather_into_tensor(out, inp, group=None, async_op=False):
+        parts = [torch.empty_like(inp) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, inp.clone(), group=group)
+        out.copy_(torch.cat(parts, dim=0))
+        return _Done()
+    dist.reduce_scatter_tensor = reduce_scatter_tensor
+    dist.all_gather_into_tensor = all_gather_into_tensor
+
+
+def _worker(rank, world, port, ret, rccl_branch=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,6 +75,9 @@ def _worker(rank, world, port, ret):
     from tests.dist_util import adam_reference
     packed, views, gts = _scene()
     opt = mo.ShardedMapOptimizer(packed, adam_fn=adam_reference, activate_fn=mo.activate8)
+    if rccl_branch:
+        _emulate_rccl_collectives()
+        opt.backend = "nccl"
     assert opt.world == 2 and opt.per == 51 and opt.Npad == 102
     for _ in range(2):
         opt.step(_loss_fn(views[rank], gts[rank]))
@@ -58,13 +86,17 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_sharded_step_matches_single_process():
+import pytest
+
+
+@pytest.mark.parametrize("rccl_branch", [False, True])
+def test_sharded_step_matches_single_process(rccl_branch):
     from rtg_slam_amd import map_optim as mo
     from tests.dist_util import adam_reference
-    port = 29600 + (os.getpid() % 300)
+    port = 29600 + (os.getpid() % 300) + (7 if rccl_branch else 0)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, ret, rccl_branch), nprocs=2, join=True)
     p0, p1 = ret[0], ret[1]
     assert torch.equal(p0, p1), "all ranks hold the same gathered parameters"
     # single-process reference: sum of both views' gradients, Adam on all rows
