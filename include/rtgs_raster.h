@@ -138,6 +138,14 @@ int rtgs_fused_adam(float* params, const float* grads, float* exp_avg, float* ex
                     const float* lr_per_column, int64_t rows, int32_t cols, int32_t step,
                     float beta1, float beta2, float eps, void* stream);
 
+/* Same arithmetic as rtgs_fused_adam, but a row whose gradient is all zero and whose moments never left zero
+ * (ever_touched[row] == 0, a caller-owned device byte per row, zero-initialised with the optimiser state) is
+ * skipped: dense Adam leaves such a row bit-identical, so results are unchanged while untouched rows cost one
+ * gradient read.  cols must be 3, 8 or 48 (the block tensors of the map). */
+int rtgs_fused_adam_rows(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                         const float* lr_per_column, uint8_t* ever_touched, int64_t rows, int32_t cols,
+                         int32_t step, float beta1, float beta2, float eps, void* stream);
+
 /* Block-SoA map state (what rtg_slam_amd/map_optim.py keeps): xyz[N,3] and shs[N,48] are stored
  * exactly as the rasterizer reads them (no activation, no copy); only raw8[N,8] =
  * (opacity | scaling xyz | rotation wxyz) is activated:

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "rtgs_raster_last_stats": (C.c_int, [C.POINTER(C.c_int64)]),
     "rtgs_raster_set_counters": (None, [_P]),
     "rtgs_fused_adam": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
+    "rtgs_fused_adam_rows": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
     "rtgs_map_activate8_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "rtgs_map_activate8_backward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "rtgs_slam_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P]),

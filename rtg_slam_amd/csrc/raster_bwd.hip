@@ -527,11 +527,18 @@ void launch_preprocess_bwd(const RasterParams& p, const float* means, const floa
 // SLAM/gaussian_pointcloud.py:245-284; torch.optim.Adam(eps=1e-15) semantics, mapper.py:156).
 // ---------------------------------------------------------------------------------------------
 namespace rtgs {
+// Contractions are spelled out (and automatic ones disabled) so that every kernel that inlines this helper
+// rounds identically - the row-skipping kernel must match the dense ones bit for bit.
 __device__ __forceinline__ float adam1(float p, float g, float& m, float& v, float lr, float beta1, float beta2,
                                        float eps, float bc1, float bc2_sqrt) {
-  m = beta1 * m + (1.f - beta1) * g;
-  v = beta2 * v + (1.f - beta2) * g * g;
-  return p - (lr / bc1) * (m / (sqrtf(v) / bc2_sqrt + eps));
+#pragma clang fp contract(off)
+  const float t1 = (1.f - beta1) * g;
+  const float t2 = ((1.f - beta2) * g) * g;
+  m = __builtin_fmaf(beta1, m, t1);
+  v = __builtin_fmaf(beta2, v, t2);
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  const float step = lr / bc1;
+  return __builtin_fmaf(-step, m / denom, p);
 }
 
 // 16 B per lane per stream (7 streams: p g m v in, p m v out); n_elems % 4 == 0 on this path
@@ -566,6 +573,57 @@ __global__ void __launch_bounds__(256) fused_adam_kernel(float* __restrict__ p, 
     m[i] = mi; v[i] = vi;
   }
 }
+
+// Row-skipping Adam: a row whose gradient is entirely zero AND whose moments have never left zero
+// (`ever[row] == 0`) is left untouched - for such a row dense Adam computes m = v = 0 and an update of
+// exactly 0, so the result is bit-identical to fused_adam_kernel while the untouched rows cost one read of
+// their gradient (4 B / parameter) instead of 28 B / parameter.  In RTG-SLAM only Gaussians that reach a
+// rendered pixel receive gradient (mapper.py:455 relies on the exact zeros) and the optimiser is re-created
+// for every local optimisation (mapper.py:156), so most rows of a large map stay in this state.
+template <int C>
+__global__ void __launch_bounds__(256) fused_adam_rows_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                              float* __restrict__ m, float* __restrict__ v,
+                                                              const float* __restrict__ lr_col, uint8_t* __restrict__ ever,
+                                                              long long rows, float beta1, float beta2, float eps,
+                                                              float bc1, float bc2_sqrt) {
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x) {
+    const size_t o = (size_t)r * C;
+    bool any = false;
+    if constexpr (C % 4 == 0) {
+      const float4* g4 = reinterpret_cast<const float4*>(g + o);
+#pragma unroll
+      for (int q = 0; q < C / 4; ++q) { const float4 t = g4[q]; any |= (t.x != 0.f) | (t.y != 0.f) | (t.z != 0.f) | (t.w != 0.f); }
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) any |= g[o + c] != 0.f;
+    }
+    if (!any && ever[r] == 0) continue;
+    ever[r] = 1;
+    if constexpr (C % 4 == 0) {
+      const float4* g4 = reinterpret_cast<const float4*>(g + o);
+      float4* p4 = reinterpret_cast<float4*>(p + o);
+      float4* m4 = reinterpret_cast<float4*>(m + o);
+      float4* v4 = reinterpret_cast<float4*>(v + o);
+#pragma unroll
+      for (int q = 0; q < C / 4; ++q) {
+        const float4 gi = g4[q], pi = p4[q];
+        float4 mi = m4[q], vi = v4[q], po;
+        po.x = adam1(pi.x, gi.x, mi.x, vi.x, lr_col[4 * q], beta1, beta2, eps, bc1, bc2_sqrt);
+        po.y = adam1(pi.y, gi.y, mi.y, vi.y, lr_col[4 * q + 1], beta1, beta2, eps, bc1, bc2_sqrt);
+        po.z = adam1(pi.z, gi.z, mi.z, vi.z, lr_col[4 * q + 2], beta1, beta2, eps, bc1, bc2_sqrt);
+        po.w = adam1(pi.w, gi.w, mi.w, vi.w, lr_col[4 * q + 3], beta1, beta2, eps, bc1, bc2_sqrt);
+        p4[q] = po; m4[q] = mi; v4[q] = vi;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float mi = m[o + c], vi = v[o + c];
+        p[o + c] = adam1(p[o + c], g[o + c], mi, vi, lr_col[c], beta1, beta2, eps, bc1, bc2_sqrt);
+        m[o + c] = mi; v[o + c] = vi;
+      }
+    }
+  }
+}
 }  // namespace rtgs
 
 extern "C" int rtgs_fused_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
@@ -586,5 +644,28 @@ extern "C" int rtgs_fused_adam(float* params, const float* grads, float* exp_avg
   else
     hipLaunchKernelGGL(rtgs::fused_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads,
                        exp_avg, exp_avg_sq, lr_per_column, n, (int)cols, beta1, beta2, eps, bc1, bc2s);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int rtgs_fused_adam_rows(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                    const float* lr_per_column, uint8_t* ever_touched, int64_t rows, int32_t cols,
+                                    int32_t step, float beta1, float beta2, float eps, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_per_column || !ever_touched || rows < 0 || step < 1) return -1;
+  if (cols != 3 && cols != 8 && cols != 48) return -1;      // the three block tensors of the map (xyz, raw8, SH)
+  if (rows == 0) return 0;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  long long blocks = (rows + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t st = (hipStream_t)stream;
+  if (cols == 3)
+    hipLaunchKernelGGL(rtgs::fused_adam_rows_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg,
+                       exp_avg_sq, lr_per_column, ever_touched, (long long)rows, beta1, beta2, eps, bc1, bc2s);
+  else if (cols == 8)
+    hipLaunchKernelGGL(rtgs::fused_adam_rows_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg,
+                       exp_avg_sq, lr_per_column, ever_touched, (long long)rows, beta1, beta2, eps, bc1, bc2s);
+  else
+    hipLaunchKernelGGL(rtgs::fused_adam_rows_kernel<48>, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg,
+                       exp_avg_sq, lr_per_column, ever_touched, (long long)rows, beta1, beta2, eps, bc1, bc2s);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -158,6 +158,20 @@ def _adam_hip(p, g, m, v, lr_col, step, eps):
     _lib.check(rc, "rtgs_fused_adam")
 
 
+def _adam_rows_hip(p, g, m, v, lr_col, step, eps, ever):
+    """Row-skipping fused Adam (rtgs_fused_adam_rows): bit-identical to the dense kernel, untouched rows skipped."""
+    from . import _lib
+    if not p.is_cuda:
+        raise RuntimeError("rtg_slam_amd.map_optim: fused Adam needs HIP device tensors; this build has no CPU path.")
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(p.device).cuda_stream
+    with torch.cuda.device(p.device):
+        rc = lib.rtgs_fused_adam_rows(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+                                      C.c_void_p(v.data_ptr()), C.c_void_p(lr_col.data_ptr()), C.c_void_p(ever.data_ptr()),
+                                      p.shape[0], p.shape[1], int(step), 0.9, 0.999, float(eps), C.c_void_p(stream))
+    _lib.check(rc, "rtgs_fused_adam_rows")
+
+
 class ShardedMapOptimizer:
     def __init__(self, packed: torch.Tensor, lr_col: Optional[torch.Tensor] = None, eps: float = 1e-15,
                  group=None, adam_fn: Optional[Callable] = None, activate_fn: Optional[Callable] = None):
@@ -165,6 +179,7 @@ class ShardedMapOptimizer:
         fused Adam and `activate_fn(raw8) -> dict` to the HIP activation kernels (device tensors only -
         there is no CPU path in the product); the gloo tests inject torch restatements."""
         self.group = group
+        self.row_skip = adam_fn is None and packed.is_cuda     # default HIP path: row-skipping Adam
         self.adam_fn = adam_fn if adam_fn is not None else _adam_hip
         self.activate_fn = activate_fn if activate_fn is not None else activate8_hip
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -183,6 +198,7 @@ class ShardedMapOptimizer:
                 p=full, lr=lr[c0:c1].contiguous(),
                 m=torch.zeros(self.per, c1 - c0, dtype=torch.float32, device=dev),      # sharded Adam state
                 v=torch.zeros(self.per, c1 - c0, dtype=torch.float32, device=dev),
+                ever=torch.zeros(self.per, dtype=torch.uint8, device=dev),
                 gpad=(torch.zeros(self.Npad, c1 - c0, dtype=torch.float32, device=dev) if self.world > 1 else None),
                 gshard=(torch.zeros(self.per, c1 - c0, dtype=torch.float32, device=dev) if self.world > 1 else None))
         self.step_count = 0
@@ -191,6 +207,12 @@ class ShardedMapOptimizer:
     def params(self) -> torch.Tensor:
         """Packed [N,59] copy of the current parameters."""
         return torch.cat([self.state[n]["p"][:self.N] for n, _, _ in BLOCKS], dim=1)
+
+    def _adam(self, st, shard, gs):
+        if self.row_skip:
+            _adam_rows_hip(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps, st["ever"])
+        else:
+            self.adam_fn(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps)
 
     def my_rows(self) -> slice:
         return slice(self.rank * self.per, (self.rank + 1) * self.per)
@@ -225,7 +247,7 @@ class ShardedMapOptimizer:
                 st = self.state[name]
                 rs[name].wait()                         # stream-side wait, the host does not block
                 shard = st["p"][rows]
-                self.adam_fn(shard, st["gshard"], st["m"], st["v"], st["lr"], self.step_count, self.eps)
+                self._adam(st, shard, st["gshard"])
                 if st.get("send") is None:
                     st["send"] = torch.empty_like(shard)
                 st["send"].copy_(shard)                 # all-gather input must not alias its output
@@ -244,7 +266,7 @@ class ShardedMapOptimizer:
             else:
                 gs = g if self.Npad == N else torch.nn.functional.pad(g, (0, 0, 0, self.Npad - N))
             shard = st["p"][rows]
-            self.adam_fn(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps)
+            self._adam(st, shard, gs)
             if self.world > 1:
                 parts = [torch.empty_like(shard) for _ in range(self.world)]
                 dist.all_gather(parts, shard.clone(), group=self.group)

@@ -299,3 +299,25 @@ def test_automatic_fallbacks():
     for k in ru.FIELDS:
         sc = float(gd_o[k].abs().max()) + 1e-12
         assert float((gd_h[k] - gd_o[k]).abs().max()) / sc < 1e-3, k
+
+
+def test_row_skipping_adam_is_bit_identical_to_dense():
+    """rtgs_fused_adam_rows vs rtgs_fused_adam on sparse gradients (changing support over the steps)."""
+    from rtg_slam_amd import map_optim as mo
+    dev = "cuda:0"
+    gen = torch.Generator().manual_seed(7)
+    for rows, cols, c0 in ((5003, 3, 0), (5003, 48, 3), (5003, 8, 51)):
+        lr = (mo.default_lr_columns()[c0:c0 + cols] + 1e-4).contiguous().to(dev)
+        p0 = torch.randn(rows, cols, generator=gen).to(dev)
+        pa, pb = p0.clone(), p0.clone()
+        ma, va = torch.zeros_like(pa), torch.zeros_like(pa)
+        mb, vb = torch.zeros_like(pa), torch.zeros_like(pa)
+        ever = torch.zeros(rows, dtype=torch.uint8, device=dev)
+        for step in range(1, 6):
+            g = torch.randn(rows, cols, generator=gen).to(dev)
+            keep = (torch.rand(rows, generator=gen) < 0.15).to(dev)
+            g = g * keep[:, None]
+            mo._adam_hip(pa, g, ma, va, lr, step, 1e-15)
+            mo._adam_rows_hip(pb, g, mb, vb, lr, step, 1e-15, ever)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), cols
+        assert 0 < int(ever.sum()) < rows
