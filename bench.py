@@ -103,7 +103,7 @@ def main():
     def render(gd):
         return rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None,
                     scales=gd["scales"], rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"],
-                    tile_mask=tile_mask)
+                    tile_mask=tile_mask, grad_rows=gd.get("grad_rows"))
 
     def loss_fn(gd):
         return mo.slam_losses_hip(render(gd), gt_color, gt_depth)
@@ -162,8 +162,10 @@ def main():
             counters.zero_()
             lib.rtgs_raster_set_counters(C.c_void_p(counters.data_ptr()))
             lv = {nm: opt.state[nm]["p"][:N].detach().clone().requires_grad_(True) for nm in ("xyz", "shs", "raw8")}
-            gd = mo.activate8_hip(lv["raw8"])
-            gd["xyz"], gd["shs"] = lv["xyz"], lv["shs"].view(N, 16, 3)
+            if opt.grad_rows is not None:         # same backward as opt.step(): persistent rows + row states
+                opt.grad_rows.begin_step()
+            gd = mo.activate8_hip(lv["raw8"], opt.grad_rows)
+            gd["xyz"], gd["shs"], gd["grad_rows"] = lv["xyz"], lv["shs"].view(N, 16, 3), opt.grad_rows
             loss = loss_fn(gd)
             lib.rtgs_raster_set_counters(None)
             loss.backward()
@@ -192,10 +194,13 @@ def main():
         acc30 = [0.0] * 8
         for i in range(4):
             lv = {nm: opt.state[nm]["p"][:N].detach().clone().requires_grad_(True) for nm in ("xyz", "shs", "raw8")}
-            gd = mo.activate8_hip(lv["raw8"])
+            if opt.grad_rows is not None:
+                opt.grad_rows.begin_step()
+            gd = mo.activate8_hip(lv["raw8"], opt.grad_rows)
             gd["xyz"], gd["shs"] = lv["xyz"], lv["shs"].view(N, 16, 3)
             out30 = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
-                         rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=m30)
+                         rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=m30,
+                         grad_rows=opt.grad_rows)
             mo.slam_losses_hip(out30, gt_color, gt_depth).backward()
             torch.cuda.synchronize(dev)
             ms = (C.c_float * 10)()
@@ -219,6 +224,14 @@ def main():
             "blend_bwd": 68 * consumed + 28 * Px + 36 * consumed,
             "preprocess_bwd": 248 * N + 64 * N + 236 * N,
         }
+        rows_touched = None
+        if opt.grad_rows is not None:
+            # row-state backward: 2 state bytes per Gaussian; only rows that change are read / written
+            # (inputs 248 B + SplatGrad 64 B read and 64 B re-zeroed + 236 B of gradient rows, also for rows being cleared)
+            st_rows = opt.grad_rows.row_state
+            rows_touched = int((st_rows == 1).sum())
+            rows_cleared = int((st_rows == 2).sum())
+            alg["preprocess_bwd"] = 2 * N + (248 + 128 + 236) * rows_touched + 236 * rows_cleared
         kernels = {}
         for nm, ms_ in zip(names, stage):
             if nm in alg and ms_ > 0:
@@ -253,7 +266,8 @@ def main():
                                    "second HIP stream) + 1 map-optimisation iteration (raster fwd + L1 colour/depth loss + "
                                    f"raster bwd + fused Adam) over {N} random Gaussians (SURVEY.md 8d generator, seed 2024), "
                                    "all tiles",
-                       "gaussians": N, "image": [cam.H, cam.W], "instances": R, "instances_consumed": consumed,
+                       "gaussians": N, "gaussians_with_gradient": rows_touched, "image": [cam.H, cam.W],
+                       "instances": R, "instances_consumed": consumed,
                        "pixel_pairs_evaluated": pairs,
                        "parallelism": f"dp{world}: replicated map, per-rank view, RCCL reduce-scatter grads + sharded Adam + all-gather"},
             "raster_fwd_ms": round(sum(stage[:6]), 4), "raster_bwd_ms": round(sum(stage[6:]), 4),

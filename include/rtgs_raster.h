@@ -103,6 +103,27 @@ int rtgs_raster_backward(const rtgs_raster_settings* settings, int32_t P, int32_
 
 size_t rtgs_raster_backward_scratch_bytes(int32_t P);
 
+/* Row-state backward (an extension, not part of the reference contract): same arithmetic, but for callers that
+ * keep the six gradient tensors, `grad_scratch` and one byte per Gaussian, `row_state[P]`, ALIVE between calls -
+ * all zero-initialised once by the caller.  Invariant on entry and exit: a gradient row is all-zero unless its
+ * state is 1, and grad_scratch is all-zero.  On exit row_state[i] is
+ *   1  row i received gradient in this call (values identical to rtgs_raster_backward's),
+ *   2  row i carried gradient from the previous call and was zeroed by this one,
+ *   0  row i was zero and stays zero (not written at all).
+ * A Gaussian that reaches no pixel then costs two byte reads instead of ~310 B of zero writes, and consumers
+ * (rtgs_map_activate8_backward_rows, rtgs_fused_adam_rows) skip state-0 rows the same way. */
+int rtgs_raster_backward_rows(const rtgs_raster_settings* settings, int32_t P, int32_t sh_coeffs,
+                              int64_t num_rendered,
+                              const float* means3D, const float* opacities, const float* shs,
+                              const float* scales, const float* rotations, const float* normal_w,
+                              const void* geom_buffer, const void* binning_buffer,
+                              const void* image_buffer, const float* out_color, const float* out_T,
+                              const int32_t* out_depth_index,
+                              const float* dL_dcolor, const float* dL_ddepth,
+                              float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
+                              float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
+                              void* grad_scratch, uint8_t* row_state, void* stream);
+
 /* Sizes the forward will request through the callbacks (for pre-allocation / accounting). */
 size_t rtgs_raster_geom_bytes(int32_t P, int32_t image_height, int32_t image_width);
 size_t rtgs_raster_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
@@ -141,10 +162,12 @@ int rtgs_fused_adam(float* params, const float* grads, float* exp_avg, float* ex
 /* Same arithmetic as rtgs_fused_adam, but a row whose gradient is all zero and whose moments never left zero
  * (ever_touched[row] == 0, a caller-owned device byte per row, zero-initialised with the optimiser state) is
  * skipped: dense Adam leaves such a row bit-identical, so results are unchanged while untouched rows cost one
- * gradient read.  cols must be 3, 8 or 48 (the block tensors of the map). */
+ * gradient read.  cols must be 3, 8 or 48 (the block tensors of the map).  `row_state` (nullable) is the byte
+ * array rtgs_raster_backward_rows maintains: when given, "gradient row is zero" is read from it (state != 1)
+ * instead of scanning the gradient. */
 int rtgs_fused_adam_rows(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                         const float* lr_per_column, uint8_t* ever_touched, int64_t rows, int32_t cols,
-                         int32_t step, float beta1, float beta2, float eps, void* stream);
+                         const float* lr_per_column, uint8_t* ever_touched, const uint8_t* row_state, int64_t rows,
+                         int32_t cols, int32_t step, float beta1, float beta2, float eps, void* stream);
 
 /* Block-SoA map state (what rtg_slam_amd/map_optim.py keeps): xyz[N,3] and shs[N,48] are stored
  * exactly as the rasterizer reads them (no activation, no copy); only raw8[N,8] =
@@ -155,6 +178,10 @@ int rtgs_map_activate8_forward(const float* raw8, int64_t n, float* opacity, flo
                                float* normal, void* stream);
 int rtgs_map_activate8_backward(const float* raw8, int64_t n, const float* g_opacity, const float* g_scales,
                                 const float* g_rotations, const float* g_normal, float* g_raw8, void* stream);
+/* Row-state variant: g_raw8 is persistent; state 1 rows are computed, state 2 rows zeroed, state 0 rows skipped. */
+int rtgs_map_activate8_backward_rows(const float* raw8, int64_t n, const float* g_opacity, const float* g_scales,
+                                     const float* g_rotations, const float* g_normal, const uint8_t* row_state,
+                                     float* g_raw8, void* stream);
 
 /* Fused SLAM loss, the live terms of mapper.py:402-442:
  *   L = color_weight * mean|C - C_gt| + depth_weight * sum(m |D - D_gt|) / max(sum m, 1),

@@ -50,6 +50,8 @@ _SIGNATURES = {
                                           C.POINTER(C.c_int64), _P]),
     "rtgs_raster_backward": (C.c_int, [C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6
                              + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P]),
+    "rtgs_raster_backward_rows": (C.c_int, [C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6
+                                  + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P, _P]),
     "rtgs_raster_backward_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "rtgs_raster_geom_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rtgs_raster_binning_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
@@ -57,9 +59,10 @@ _SIGNATURES = {
     "rtgs_raster_last_stats": (C.c_int, [C.POINTER(C.c_int64)]),
     "rtgs_raster_set_counters": (None, [_P]),
     "rtgs_fused_adam": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
-    "rtgs_fused_adam_rows": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
+    "rtgs_fused_adam_rows": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
     "rtgs_map_activate8_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "rtgs_map_activate8_backward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    "rtgs_map_activate8_backward_rows": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "rtgs_slam_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "rtgs_raster_set_profiling": (None, [C.c_int]),
     "rtgs_raster_force_sort_path": (None, [C.c_int]),

@@ -50,8 +50,14 @@ __global__ void __launch_bounds__(256) activate8_fwd_kernel(const float4* __rest
 __global__ void __launch_bounds__(256) activate8_bwd_kernel(const float4* __restrict__ raw8, int64_t n,
                                                             const float* __restrict__ g_op, const float* __restrict__ g_sc,
                                                             const float4* __restrict__ g_rot, const float* __restrict__ g_nrm,
+                                                            const uint8_t* __restrict__ row_state,
                                                             float4* __restrict__ g_raw8) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (row_state) {     // rtgs_raster_backward_rows protocol: 0 = row already zero, 2 = zeroed upstream by this pass
+      const uint8_t s = row_state[i];
+      if (s == 0) continue;
+      if (s == 2) { g_raw8[2 * i] = g_raw8[2 * i + 1] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+    }
     const float4 a = raw8[2 * i], q = raw8[2 * i + 1];
     const float sg = 1.f / (1.f + __expf(-a.x));
     const float s0 = __expf(a.y), s1 = __expf(a.z), s2 = __expf(a.w);
@@ -109,7 +115,21 @@ extern "C" int rtgs_map_activate8_backward(const float* raw8, int64_t n, const f
   int64_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(rtgs::activate8_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)raw8, n, g_opacity, g_scales, (const float4*)g_rotations, g_normal, (float4*)g_raw8);
+                     (const float4*)raw8, n, g_opacity, g_scales, (const float4*)g_rotations, g_normal,
+                     (const uint8_t*)nullptr, (float4*)g_raw8);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int rtgs_map_activate8_backward_rows(const float* raw8, int64_t n, const float* g_opacity, const float* g_scales,
+                                                const float* g_rotations, const float* g_normal, const uint8_t* row_state,
+                                                float* g_raw8, void* stream) {
+  if (n < 0 || (n > 0 && (!raw8 || !g_opacity || !g_scales || !g_rotations || !g_normal || !row_state || !g_raw8))) return -1;
+  if (n == 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rtgs::activate8_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)raw8, n, g_opacity, g_scales, (const float4*)g_rotations, g_normal, row_state,
+                     (float4*)g_raw8);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -17,10 +17,10 @@ void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
                       int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, hipStream_t);
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
-                      const uint32_t*, const int32_t*, const float*, const float*, SplatGrad*, hipStream_t);
+                      const uint32_t*, const int32_t*, const float*, const float*, SplatGrad*, uint8_t*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
-                           const float*, const int32_t*, const uint8_t*, const SplatGrad*, float*, float*, float*,
-                           float*, float*, float*, hipStream_t);
+                           const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
+                           float*, float*, float*, float*, hipStream_t);
 
 // process-wide (autograd runs backward on its own thread): last-call stats, counters, profiling
 size_t bin_lds_limit_tiles();
@@ -165,7 +165,11 @@ size_t rtgs_raster_image_bytes(int32_t H, int32_t W) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   return img_layout(H, W, gx * gy).total;
 }
-size_t rtgs_raster_backward_scratch_bytes(int32_t P) { return align_up((size_t)(P > 0 ? P : 1) * sizeof(SplatGrad)); }
+// [P x SplatGrad (64 B)] [P x touched byte]
+size_t rtgs_raster_backward_scratch_bytes(int32_t P) {
+  const size_t n = (size_t)(P > 0 ? P : 1);
+  return align_up(n * sizeof(SplatGrad)) + align_up(n);
+}
 
 int rtgs_raster_last_stats(int64_t* out) {
   if (!out) return RTGS_E_INVALID;
@@ -298,14 +302,14 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   return RTGS_OK;
 }
 
-int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
+static int backward_impl(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
                          const float* opacities, const float* shs, const float* scales, const float* rotations,
                          const float* normal_w, const void* geom_buffer, const void* binning_buffer,
                          const void* image_buffer, const float* out_color, const float* out_T,
                          const int32_t* out_didx,
                          const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
                          float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
-                         void* grad_scratch, void* stream) {
+                         void* grad_scratch, uint8_t* row_state, void* stream) {
   RasterParams p;
   int rc = make_params(s, P, M, p);
   if (rc != RTGS_OK) return rc;
@@ -325,21 +329,50 @@ int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, in
   SplatGrad* grads = (SplatGrad*)grad_scratch;
   for (int i = EV_B0; i < EV_N; ++i) g_ev_set[i] = false;
   prof_mark(EV_B0, st);
-  HIP_TRY(hipMemsetAsync(grads, 0, (size_t)P * sizeof(SplatGrad), st));
+  uint8_t* touched = (uint8_t*)grad_scratch + align_up((size_t)P * sizeof(SplatGrad));
+  // row-state mode: the caller zeroed the scratch once and preprocess_bwd re-zeroes every line it consumes
+  if (!row_state) HIP_TRY(hipMemsetAsync(grads, 0, rtgs_raster_backward_scratch_bytes(P), st));
   if (R > 0) {
     launch_blend_bwd(p, (const uint2*)(img + I.ranges), (const uint32_t*)(bin + B.vals_b),
                      (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
-                     dL_dcolor, dL_ddepth, grads, st);
+                     dL_dcolor, dL_ddepth, grads, touched, st);
     DBG(s, st);
   }
   prof_mark(EV_BBLEND, st);
   launch_preprocess_bwd(p, means3D, opacities, shs, scales, rotations, normal_w, (const int32_t*)(geom + G.radii),
-                        (const uint8_t*)(geom + G.clamped), grads, dL_dmeans3D, dL_dopacities, dL_dshs, dL_dscales,
-                        dL_drotations, dL_dnormal_w, st);
+                        (const uint8_t*)(geom + G.clamped), grads, touched, row_state, dL_dmeans3D, dL_dopacities,
+                        dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, st);
   prof_mark(EV_BPRE, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
   return RTGS_OK;
+}
+
+int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
+                         const float* opacities, const float* shs, const float* scales, const float* rotations,
+                         const float* normal_w, const void* geom_buffer, const void* binning_buffer,
+                         const void* image_buffer, const float* out_color, const float* out_T,
+                         const int32_t* out_didx,
+                         const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
+                         float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
+                         void* grad_scratch, void* stream) {
+  return backward_impl(s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer, binning_buffer,
+                       image_buffer, out_color, out_T, out_didx, dL_dcolor, dL_ddepth, dL_dmeans3D, dL_dopacities,
+                       dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, nullptr, stream);
+}
+
+int rtgs_raster_backward_rows(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
+                              const float* opacities, const float* shs, const float* scales, const float* rotations,
+                              const float* normal_w, const void* geom_buffer, const void* binning_buffer,
+                              const void* image_buffer, const float* out_color, const float* out_T,
+                              const int32_t* out_didx,
+                              const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
+                              float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
+                              void* grad_scratch, uint8_t* row_state, void* stream) {
+  if (P > 0 && !row_state) return RTGS_E_INVALID;
+  return backward_impl(s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer, binning_buffer,
+                       image_buffer, out_color, out_T, out_didx, dL_dcolor, dL_ddepth, dL_dmeans3D, dL_dopacities,
+                       dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, row_state, stream);
 }
 
 void rtgs_raster_set_profiling(int enable) { g_prof = enable != 0; }

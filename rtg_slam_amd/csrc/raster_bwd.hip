@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     const Splat* __restrict__ splats, const float* __restrict__ out_color, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const int32_t* __restrict__ depth_index,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-    SplatGrad* __restrict__ grads) {
+    SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched) {
   __shared__ float4 s_rec[BATCH * 3];
   __shared__ int32_t s_id[BATCH];
   __shared__ float s_hy[BATCH];
@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
         any |= (t[k] != 0.f);
       }
       if (any) {
+        touched[s_id[tid]] = 1;     // byte per Gaussian: lets the row-state backward skip untouched SplatGrad lines
         float* dst = reinterpret_cast<float*>(grads + s_id[tid]);
         // SplatGrad order: du dv dca dcb dcc dop dr dg db
         if (t[0] != 0.f) unsafeAtomicAdd(dst + 0, t[0]);
@@ -266,6 +267,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     const float s3 = wave_sum_to_lane63(mine ? a3 : 0.f);
     if (lane == 63) {
       float* dst = reinterpret_cast<float*>(grads + o);
+      touched[o] = 1;
       unsafeAtomicAdd(dst + 9, s0);
       unsafeAtomicAdd(dst + 10, s1);
       unsafeAtomicAdd(dst + 11, s2);
@@ -283,18 +285,41 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     RasterParams p, const float* __restrict__ means, const float* __restrict__ opac,
     const float* __restrict__ shs, const float* __restrict__ scales, const float* __restrict__ rots,
     const float* __restrict__ normal_w, const int32_t* __restrict__ radii,
-    const uint8_t* __restrict__ clamped, const SplatGrad* __restrict__ grads,
+    const uint8_t* __restrict__ clamped, SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched_b,
+    uint8_t* __restrict__ row_state,
     float* __restrict__ d_means, float* __restrict__ d_opac, float* __restrict__ d_shs,
     float* __restrict__ d_scales, float* __restrict__ d_rots, float* __restrict__ d_normal) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.P) return;
   float* dsh = d_shs + (size_t)i * p.M * 3;
-  const SplatGrad g = grads[i];
-  bool touched = radii[i] > 0;
+  // Row-state mode (rtgs_raster_backward_rows): the gradient buffers and the SplatGrad scratch persist between
+  // calls and rows whose state is not 1 are already zero, so an untouched Gaussian costs two byte reads here.
+  // Dense mode (row_state == nullptr): every row is written, as the reference's backward does.
+  SplatGrad g;
+  bool touched;
+  uint8_t old_state = 1;
+  if (row_state) {
+    old_state = row_state[i];
+    touched = touched_b[i] != 0;
+    if (touched) {
+      touched_b[i] = 0;
+      g = grads[i];
+      float4* z = reinterpret_cast<float4*>(grads + i);        // leave the scratch zero for the next call
+      z[0] = z[1] = z[2] = z[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    touched = radii[i] > 0;
+    if (touched) g = grads[i];
+  }
   if (touched) {
     touched = (g.du != 0.f) | (g.dv != 0.f) | (g.dca != 0.f) | (g.dcb != 0.f) | (g.dcc != 0.f) | (g.dop != 0.f) |
               (g.dr != 0.f) | (g.dg != 0.f) | (g.db != 0.f) | (g.dnx != 0.f) | (g.dny != 0.f) | (g.dnz != 0.f) |
               (g.dpd != 0.f);
+  }
+  if (row_state) {
+    if (touched) row_state[i] = 1;
+    else if (old_state != 0) row_state[i] = old_state == 1 ? 2 : 0;     // 2: zeroed by THIS call (consumers clean too)
+    if (!touched && old_state != 1) return;                              // row is already zero
   }
   if (!touched) {   // exact zeros for Gaussians that reached no pixel (mapper.py:455)
     d_means[3 * i] = d_means[3 * i + 1] = d_means[3 * i + 2] = 0.f;
@@ -506,17 +531,19 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 void launch_blend_bwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                       const float* out_color, const float* final_T, const uint32_t* n_contrib,
                       const int32_t* depth_index, const float* dL_dcolor, const float* dL_ddepth, SplatGrad* grads,
-                      hipStream_t st) {
+                      uint8_t* touched, hipStream_t st) {
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
-                     final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, grads);
+                     final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, grads, touched);
 }
 void launch_preprocess_bwd(const RasterParams& p, const float* means, const float* opac, const float* shs,
                            const float* scales, const float* rots, const float* normal_w, const int32_t* radii,
-                           const uint8_t* clamped, const SplatGrad* grads, float* d_means, float* d_opac,
-                           float* d_shs, float* d_scales, float* d_rots, float* d_normal, hipStream_t st) {
+                           const uint8_t* clamped, SplatGrad* grads, uint8_t* touched, uint8_t* row_state,
+                           float* d_means, float* d_opac, float* d_shs, float* d_scales, float* d_rots, float* d_normal,
+                           hipStream_t st) {
   if (p.P == 0) return;
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, opac, shs, scales,
-                     rots, normal_w, radii, clamped, grads, d_means, d_opac, d_shs, d_scales, d_rots, d_normal);
+                     rots, normal_w, radii, clamped, grads, touched, row_state, d_means, d_opac, d_shs, d_scales, d_rots,
+                     d_normal);
 }
 
 }  // namespace rtgs
@@ -584,12 +611,15 @@ template <int C>
 __global__ void __launch_bounds__(256) fused_adam_rows_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                               float* __restrict__ m, float* __restrict__ v,
                                                               const float* __restrict__ lr_col, uint8_t* __restrict__ ever,
+                                                              const uint8_t* __restrict__ row_state,
                                                               long long rows, float beta1, float beta2, float eps,
                                                               float bc1, float bc2_sqrt) {
   for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x) {
     const size_t o = (size_t)r * C;
     bool any = false;
-    if constexpr (C % 4 == 0) {
+    if (row_state) {             // the producer of g already knows which rows are non-zero: no gradient scan
+      any = row_state[r] == 1;
+    } else if constexpr (C % 4 == 0) {
       const float4* g4 = reinterpret_cast<const float4*>(g + o);
 #pragma unroll
       for (int q = 0; q < C / 4; ++q) { const float4 t = g4[q]; any |= (t.x != 0.f) | (t.y != 0.f) | (t.z != 0.f) | (t.w != 0.f); }
@@ -648,8 +678,9 @@ extern "C" int rtgs_fused_adam(float* params, const float* grads, float* exp_avg
 }
 
 extern "C" int rtgs_fused_adam_rows(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                                    const float* lr_per_column, uint8_t* ever_touched, int64_t rows, int32_t cols,
-                                    int32_t step, float beta1, float beta2, float eps, void* stream) {
+                                    const float* lr_per_column, uint8_t* ever_touched, const uint8_t* row_state,
+                                    int64_t rows, int32_t cols, int32_t step, float beta1, float beta2, float eps,
+                                    void* stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_per_column || !ever_touched || rows < 0 || step < 1) return -1;
   if (cols != 3 && cols != 8 && cols != 48) return -1;      // the three block tensors of the map (xyz, raw8, SH)
   if (rows == 0) return 0;
@@ -660,12 +691,12 @@ extern "C" int rtgs_fused_adam_rows(float* params, const float* grads, float* ex
   hipStream_t st = (hipStream_t)stream;
   if (cols == 3)
     hipLaunchKernelGGL(rtgs::fused_adam_rows_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg,
-                       exp_avg_sq, lr_per_column, ever_touched, (long long)rows, beta1, beta2, eps, bc1, bc2s);
+                       exp_avg_sq, lr_per_column, ever_touched, row_state, (long long)rows, beta1, beta2, eps, bc1, bc2s);
   else if (cols == 8)
     hipLaunchKernelGGL(rtgs::fused_adam_rows_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg,
-                       exp_avg_sq, lr_per_column, ever_touched, (long long)rows, beta1, beta2, eps, bc1, bc2s);
+                       exp_avg_sq, lr_per_column, ever_touched, row_state, (long long)rows, beta1, beta2, eps, bc1, bc2s);
   else
     hipLaunchKernelGGL(rtgs::fused_adam_rows_kernel<48>, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg,
-                       exp_avg_sq, lr_per_column, ever_touched, (long long)rows, beta1, beta2, eps, bc1, bc2s);
+                       exp_avg_sq, lr_per_column, ever_touched, row_state, (long long)rows, beta1, beta2, eps, bc1, bc2s);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -96,9 +96,10 @@ class _Activate8Hip(torch.autograd.Function):
     """raw8 activations as one HIP kernel each way (rtgs_map_activate8_forward / _backward)."""
 
     @staticmethod
-    def forward(ctx, raw8):
+    def forward(ctx, raw8, grad_rows=None):
         from . import _lib
         lib = _lib.load()
+        ctx.grad_rows = grad_rows
         if not raw8.is_cuda:
             raise RuntimeError("rtg_slam_amd.map_optim: activate8_hip needs a HIP device tensor; no CPU path.")
         raw8 = raw8.contiguous()
@@ -123,18 +124,30 @@ class _Activate8Hip(torch.autograd.Function):
 
         def z(g, *shape):
             return torch.zeros(*shape, dtype=torch.float32, device=dev) if g is None else g.contiguous()
+        arena = ctx.grad_rows
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if arena is not None and arena.calls == 1 and arena.P == N and all(
+                g is not None and g.data_ptr() == a.data_ptr()
+                for g, a in ((g_op, arena.d_opac), (g_sc, arena.d_scales), (g_rot, arena.d_rots), (g_nrm, arena.d_normal))):
+            # the four incoming gradients ARE the rasterizer's persistent rows: follow its row states
+            with torch.cuda.device(dev):
+                rc = lib.rtgs_map_activate8_backward_rows(
+                    C.c_void_p(raw8.data_ptr()), N, C.c_void_p(g_op.data_ptr()), C.c_void_p(g_sc.data_ptr()),
+                    C.c_void_p(g_rot.data_ptr()), C.c_void_p(g_nrm.data_ptr()), C.c_void_p(arena.row_state.data_ptr()),
+                    C.c_void_p(arena.d_raw8.data_ptr()), C.c_void_p(stream))
+            _lib.check(rc, "rtgs_map_activate8_backward_rows")
+            return arena.d_raw8, None
         gs = (z(g_op, N, 1), z(g_sc, N, 3), z(g_rot, N, 4), z(g_nrm, N, 3))
         out = torch.empty_like(raw8)
-        stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             rc = lib.rtgs_map_activate8_backward(C.c_void_p(raw8.data_ptr()), N, *(C.c_void_p(t.data_ptr()) for t in gs),
                                                  C.c_void_p(out.data_ptr()), C.c_void_p(stream))
         _lib.check(rc, "rtgs_map_activate8_backward")
-        return out
+        return out, None
 
 
-def activate8_hip(raw8: torch.Tensor) -> Dict[str, torch.Tensor]:
-    op, sc, rot, nrm = _Activate8Hip.apply(raw8)
+def activate8_hip(raw8: torch.Tensor, grad_rows=None) -> Dict[str, torch.Tensor]:
+    op, sc, rot, nrm = _Activate8Hip.apply(raw8, grad_rows)
     return dict(opacity=op, scales=sc, rotations=rot, normal=nrm)
 
 
@@ -158,7 +171,7 @@ def _adam_hip(p, g, m, v, lr_col, step, eps):
     _lib.check(rc, "rtgs_fused_adam")
 
 
-def _adam_rows_hip(p, g, m, v, lr_col, step, eps, ever):
+def _adam_rows_hip(p, g, m, v, lr_col, step, eps, ever, row_state=None):
     """Row-skipping fused Adam (rtgs_fused_adam_rows): bit-identical to the dense kernel, untouched rows skipped."""
     from . import _lib
     if not p.is_cuda:
@@ -168,6 +181,7 @@ def _adam_rows_hip(p, g, m, v, lr_col, step, eps, ever):
     with torch.cuda.device(p.device):
         rc = lib.rtgs_fused_adam_rows(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                       C.c_void_p(v.data_ptr()), C.c_void_p(lr_col.data_ptr()), C.c_void_p(ever.data_ptr()),
+                                      C.c_void_p(row_state.data_ptr() if row_state is not None else 0),
                                       p.shape[0], p.shape[1], int(step), 0.9, 0.999, float(eps), C.c_void_p(stream))
     _lib.check(rc, "rtgs_fused_adam_rows")
 
@@ -202,17 +216,28 @@ class ShardedMapOptimizer:
                 gpad=(torch.zeros(self.Npad, c1 - c0, dtype=torch.float32, device=dev) if self.world > 1 else None),
                 gshard=(torch.zeros(self.per, c1 - c0, dtype=torch.float32, device=dev) if self.world > 1 else None))
         self.step_count = 0
+        # Single-GPU HIP path: persistent gradient rows + row states (rasterizer.RowGradArena).  step() hands the
+        # arena to loss_fn as gd["grad_rows"]; a loss_fn that forwards it to the rasterizer (grad_rows=...) gets the
+        # row-state backward, one that ignores it gets the dense path - the results are identical.
+        self.grad_rows = None
+        if self.row_skip and self.world == 1 and activate_fn is None:
+            from .rasterizer import RowGradArena
+            self.grad_rows = RowGradArena(self.N, 16, dev)
 
     @property
     def params(self) -> torch.Tensor:
         """Packed [N,59] copy of the current parameters."""
         return torch.cat([self.state[n]["p"][:self.N] for n, _, _ in BLOCKS], dim=1)
 
-    def _adam(self, st, shard, gs):
+    def _adam(self, st, shard, gs, row_state=None):
         if self.row_skip:
-            _adam_rows_hip(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps, st["ever"])
+            _adam_rows_hip(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps, st["ever"], row_state)
         else:
             self.adam_fn(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps)
+
+    def _arena_grad(self, name):
+        a = self.grad_rows
+        return dict(xyz=a.d_means, shs=a.d_shs, raw8=a.d_raw8)[name]
 
     def my_rows(self) -> slice:
         return slice(self.rank * self.per, (self.rank + 1) * self.per)
@@ -222,7 +247,13 @@ class ShardedMapOptimizer:
         ranks (the sum of per-view losses is what a single GPU looping over the views optimises)."""
         N = self.N
         leaves = {n: self.state[n]["p"][:N].detach().requires_grad_(True) for n, _, _ in BLOCKS}
-        gd = self.activate_fn(leaves["raw8"])
+        arena = self.grad_rows
+        if arena is not None:
+            arena.begin_step()
+            gd = activate8_hip(leaves["raw8"], arena)
+            gd["grad_rows"] = arena
+        else:
+            gd = self.activate_fn(leaves["raw8"])
         gd["xyz"] = leaves["xyz"]
         gd["shs"] = leaves["shs"].view(N, 16, 3)
         loss = loss_fn(gd)
@@ -266,7 +297,10 @@ class ShardedMapOptimizer:
             else:
                 gs = g if self.Npad == N else torch.nn.functional.pad(g, (0, 0, 0, self.Npad - N))
             shard = st["p"][rows]
-            self._adam(st, shard, gs)
+            row_state = None
+            if arena is not None and arena.calls == 1 and gs.data_ptr() == self._arena_grad(name).data_ptr():
+                row_state = arena.row_state      # gs IS the rasterizer's persistent rows: their states are exact
+            self._adam(st, shard, gs, row_state)
             if self.world > 1:
                 parts = [torch.empty_like(shard) for _ in range(self.world)]
                 dist.all_gather(parts, shard.clone(), group=self.group)

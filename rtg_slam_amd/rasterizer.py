@@ -78,6 +78,32 @@ class _Arena:
             return 0
 
 
+class RowGradArena:
+    """Persistent gradient rows for `rtgs_raster_backward_rows` (include/rtgs_raster.h): the six gradient
+    tensors of the rasterizer, the raw8 gradient of the activation kernel, the SplatGrad scratch and one state
+    byte per Gaussian, all allocated (zero) once.  Pass it as `grad_rows=` to `GaussianRasterizer.forward`; the
+    first backward after `begin_step()` then touches only the rows that received gradient.  The tensors handed
+    to autograd ARE these buffers - they are overwritten by the next step."""
+
+    def __init__(self, P: int, M: int, device):
+        lib = _lib.load()
+        f = dict(dtype=torch.float32, device=device)
+        self.P, self.M = int(P), int(M)
+        self.d_means = torch.zeros(P, 3, **f)
+        self.d_opac = torch.zeros(P, 1, **f)
+        self.d_shs = torch.zeros(P, M, 3, **f)
+        self.d_scales = torch.zeros(P, 3, **f)
+        self.d_rots = torch.zeros(P, 4, **f)
+        self.d_normal = torch.zeros(P, 3, **f)
+        self.d_raw8 = torch.zeros(P, 8, **f)
+        self.scratch = torch.zeros(lib.rtgs_raster_backward_scratch_bytes(P), dtype=torch.uint8, device=device)
+        self.row_state = torch.zeros(max(P, 1), dtype=torch.uint8, device=device)
+        self.calls = 0           # rasterizer backward passes since begin_step(); the row states describe exactly one
+
+    def begin_step(self):
+        self.calls = 0
+
+
 def _require_device(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError(
@@ -87,7 +113,7 @@ def _require_device(t: torch.Tensor):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, opacities, shs, scales, rotations, normal_w, tile_mask, raster_settings):
+    def forward(ctx, means3D, opacities, shs, scales, rotations, normal_w, tile_mask, raster_settings, grad_rows=None):
         lib = _lib.load()
         _require_device(means3D)
         dev = means3D.device
@@ -126,6 +152,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = int(R.value)
         ctx.M = M
+        ctx.grad_rows = grad_rows
         ctx.save_for_backward(means3D, opacities, shs, scales, rotations, normal_w, geom.tensor, binning.tensor,
                               img.tensor, color, Tm, didx)
         ctx.mark_non_differentiable(cidx, didx, cw, dw, Tm)
@@ -142,6 +169,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         f = dict(dtype=torch.float32, device=dev)
         g_color = torch.zeros(3, H, W, **f) if g_color is None else _f32c(g_color)
         g_depth = torch.zeros(1, H, W, **f) if g_depth is None else _f32c(g_depth)
+        arena = ctx.grad_rows
+        if arena is not None:
+            first = arena.calls == 0
+            arena.calls += 1
+            if first and P > 0 and arena.P == P and arena.M == ctx.M and arena.d_means.device == dev:
+                keep = _Keep(rs, dev)
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                with torch.cuda.device(dev):
+                    rc = lib.rtgs_raster_backward_rows(
+                        C.byref(keep.c), P, ctx.M, ctx.num_rendered, _ptr(means3D), _ptr(opacities), _ptr(shs),
+                        _ptr(scales), _ptr(rotations), _ptr(normal_w), _ptr(geom), _ptr(binning), _ptr(img),
+                        _ptr(color), _ptr(Tm), _ptr(didx), _ptr(g_color), _ptr(g_depth), _ptr(arena.d_means),
+                        _ptr(arena.d_opac), _ptr(arena.d_shs), _ptr(arena.d_scales), _ptr(arena.d_rots),
+                        _ptr(arena.d_normal), _ptr(arena.scratch), _ptr(arena.row_state), C.c_void_p(stream))
+                _lib.check(rc, "rtgs_raster_backward_rows")
+                return (arena.d_means, arena.d_opac, arena.d_shs.view_as(shs), arena.d_scales, arena.d_rots,
+                        arena.d_normal, None, None, None)
         d_means = torch.empty_like(means3D)
         d_opac = torch.empty_like(opacities)
         d_shs = torch.empty_like(shs)
@@ -159,7 +203,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     _ptr(Tm), _ptr(didx), _ptr(g_color), _ptr(g_depth), _ptr(d_means), _ptr(d_opac), _ptr(d_shs),
                     _ptr(d_scales), _ptr(d_rots), _ptr(d_normal), _ptr(scratch), C.c_void_p(stream))
             _lib.check(rc, "rtgs_raster_backward")
-        return d_means, d_opac, d_shs, d_scales, d_rots, d_normal, None, None
+        return d_means, d_opac, d_shs, d_scales, d_rots, d_normal, None, None, None
 
 
 class GaussianRasterizer(nn.Module):
@@ -173,7 +217,7 @@ class GaussianRasterizer(nn.Module):
         self.raster_settings = raster_settings
 
     def forward(self, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, normal_w=None, tile_mask=None):
+                cov3D_precomp=None, normal_w=None, tile_mask=None, grad_rows: Optional[RowGradArena] = None):
         rs = self.raster_settings
         if colors_precomp is not None or cov3D_precomp is not None:
             raise NotImplementedError(
@@ -196,4 +240,4 @@ class GaussianRasterizer(nn.Module):
         if tile_mask is None:
             tile_mask = torch.ones((int(rs.image_height) + 15) // 16, (int(rs.image_width) + 15) // 16,
                                    dtype=torch.int32, device=means3D.device)
-        return _RasterizeGaussians.apply(means3D, opacities, shs, scales, rotations, normal_w, tile_mask, rs)
+        return _RasterizeGaussians.apply(means3D, opacities, shs, scales, rotations, normal_w, tile_mask, rs, grad_rows)

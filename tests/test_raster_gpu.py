@@ -321,3 +321,104 @@ def test_row_skipping_adam_is_bit_identical_to_dense():
             mo._adam_rows_hip(pb, g, mb, vb, lr, step, 1e-15, ever)
         assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), cols
         assert 0 < int(ever.sum()) < rows
+
+
+def test_row_state_backward_matches_dense_over_changing_views():
+    """rtgs_raster_backward_rows + the row-state activation / Adam kernels against the dense path, over a
+    sequence of views so that rows enter (state 1), leave (state 2) and stay out (state 0)."""
+    import ctypes as C
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    from rtg_slam_amd import _lib, map_optim as mo
+    from rtg_slam_amd.rasterizer import RowGradArena
+    lib = _lib.load()
+    dev = "cuda:0"
+    N = 6000
+    P = lambda t: C.c_void_p(t.data_ptr())
+    stream = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    arena = RowGradArena(N, 16, dev)
+    g0, _ = ru.make_scene(N, SMALL, seed=5, pose_seed=1)
+    raw8 = torch.randn(N, 8, generator=torch.Generator().manual_seed(3)).to(dev)
+    lr8 = (mo.default_lr_columns()[51:59] + 1e-4).contiguous().to(dev)
+    pa, pb = raw8.clone(), raw8.clone()
+    ma, va, mb, vb = (torch.zeros_like(raw8) for _ in range(4))
+    ever_a = torch.zeros(N, dtype=torch.uint8, device=dev)
+    ever_b = torch.zeros(N, dtype=torch.uint8, device=dev)
+    seen_states = set()
+    for step, pose in enumerate((1, 2, 3, 1), start=1):
+        _, s = ru.make_scene(N, SMALL, seed=5, pose_seed=pose)
+        gen = torch.Generator().manual_seed(40 + pose)
+        gc, gdp = torch.randn(3, SMALL.H, SMALL.W, generator=gen), torch.randn(1, SMALL.H, SMALL.W, generator=gen)
+        _, gd_dense = ru.hip_run(s, g0, grads=(gc, gdp), dev=dev)
+        leaves = {k: g0[k].detach().to(dev).clone().requires_grad_(True) for k in ru.FIELDS}
+        rast = GaussianRasterizer(raster_settings=ru.hip_settings(s, dev))
+        arena.begin_step()
+        outs = rast(means3D=leaves["xyz"], opacities=leaves["opacity"], shs=leaves["shs"], colors_precomp=None,
+                    scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None,
+                    normal_w=leaves["normal"], tile_mask=None, grad_rows=arena)
+        ((outs[0] * gc.to(dev)).sum() + (outs[1] * gdp.to(dev)).sum()).backward()
+        assert arena.calls == 1
+        assert leaves["xyz"].grad.data_ptr() == arena.d_means.data_ptr() or torch.equal(leaves["xyz"].grad, arena.d_means)
+        state = arena.row_state.cpu()
+        seen_states |= set(state.unique().tolist())
+        nz = torch.zeros(N, dtype=torch.bool)
+        for k in ru.FIELDS:
+            got, want = leaves[k].grad.detach().cpu(), gd_dense[k]
+            scale = float(want.abs().max()) + 1e-12
+            assert ru.frac_bad(got, want, 1e-3 * scale) < 1e-3, (k, step)
+            row_nz = got.reshape(N, -1).ne(0).any(1)
+            assert torch.equal(row_nz, want.reshape(N, -1).ne(0).any(1)), (k, step)
+            nz |= row_nz
+        assert torch.equal(nz, state == 1), step                    # state 1 <=> the row carries gradient
+        assert int(arena.scratch.count_nonzero()) == 0, step         # scratch handed back clean
+        # activation backward: row-state kernel vs dense kernel on the very same incoming gradients
+        dense8 = torch.empty(N, 8, device=dev)
+        assert lib.rtgs_map_activate8_backward(P(raw8), N, P(arena.d_opac), P(arena.d_scales), P(arena.d_rots),
+                                               P(arena.d_normal), P(dense8), stream()) == 0
+        assert lib.rtgs_map_activate8_backward_rows(P(raw8), N, P(arena.d_opac), P(arena.d_scales), P(arena.d_rots),
+                                                    P(arena.d_normal), P(arena.row_state), P(arena.d_raw8), stream()) == 0
+        assert torch.equal(dense8, arena.d_raw8), step
+        # Adam: gradient-scanning rows kernel vs state-driven rows kernel vs dense kernel
+        mo._adam_hip(pa, dense8, ma, va, lr8, step, 1e-15)
+        mo._adam_rows_hip(pb, arena.d_raw8, mb, vb, lr8, step, 1e-15, ever_b, arena.row_state)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), step
+    assert seen_states == {0, 1, 2}
+    del ever_a
+
+
+def test_optimizer_row_state_path_matches_dense_path():
+    """ShardedMapOptimizer with the persistent-row backward vs the same optimizer forced onto the dense
+    backward: same loss trajectory, parameters equal up to the atomics' summation-order noise."""
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    from rtg_slam_amd import map_optim as mo
+    dev = "cuda:0"
+    N = 5000
+    g, _ = ru.make_scene(N, SMALL, seed=9, pose_seed=1)
+    packed = mo.pack_from_activated({k: v.to(dev) for k, v in g.items()})
+    gen = torch.Generator().manual_seed(2)
+    gt_c = torch.rand(3, SMALL.H, SMALL.W, generator=gen).to(dev)
+    gt_d = (1.0 + torch.rand(1, SMALL.H, SMALL.W, generator=gen)).to(dev)
+    opts = [mo.ShardedMapOptimizer(packed.clone()), mo.ShardedMapOptimizer(packed.clone())]
+    assert opts[0].grad_rows is not None
+    opts[1].grad_rows = None
+    used = []
+    for step, pose in enumerate((1, 2, 3, 2, 1)):
+        _, s = ru.make_scene(N, SMALL, seed=9, pose_seed=pose)
+        rast = GaussianRasterizer(raster_settings=ru.hip_settings(s, dev))
+
+        def loss_fn(gd):
+            used.append(gd.get("grad_rows") is not None)
+            out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None,
+                       scales=gd["scales"], rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"],
+                       tile_mask=None, grad_rows=gd.get("grad_rows"))
+            return mo.slam_losses_hip(out, gt_c, gt_d)
+        la, lb = opts[0].step(loss_fn), opts[1].step(loss_fn)
+        assert opts[0].grad_rows.calls == 1
+        assert abs(float(la) - float(lb)) <= 1e-4 * max(1.0, abs(float(lb))), step
+    assert used == [True, False] * 5
+    pa, pb = opts[0].params.cpu(), opts[1].params.cpu()
+    # Adam's first steps move by +-lr whatever |g| is, so a gradient that cancels to ~0 in a different atomic order can
+    # flip a step: bound the fraction of such entries instead of demanding equality
+    assert ru.frac_bad(pa, pb, 1e-5) < 2e-3
+    moved = (pa - packed.cpu()).abs().max(dim=1).values > 0
+    assert 0 < int(moved.sum()) < N            # untouched rows never moved
+    assert torch.equal(moved, (pb - packed.cpu()).abs().max(dim=1).values > 0)
