@@ -157,6 +157,7 @@ def main():
         nprof = max(3, min(10, args.steps))
         icp_ms = 0.0
         consumed = pairs = 0
+        rows_touched = rows_cleared = None
         R = 0
         for i in range(nprof):
             counters.zero_()
@@ -179,6 +180,9 @@ def main():
             R = int(st[0])
             cc = counters.cpu()
             consumed, pairs = int(cc[0]), int(cc[1])
+            if opt.grad_rows is not None:
+                rows_touched = int((opt.grad_rows.row_state == 1).sum())
+                rows_cleared = int((opt.grad_rows.row_state == 2).sum())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             vp1, np1 = hicp.build_pyramids(d1, K, 3)
@@ -224,13 +228,9 @@ def main():
             "blend_bwd": 68 * consumed + 28 * Px + 36 * consumed,
             "preprocess_bwd": 248 * N + 64 * N + 236 * N,
         }
-        rows_touched = None
         if opt.grad_rows is not None:
             # row-state backward: 2 state bytes per Gaussian; only rows that change are read / written
             # (inputs 248 B + SplatGrad 64 B read and 64 B re-zeroed + 236 B of gradient rows, also for rows being cleared)
-            st_rows = opt.grad_rows.row_state
-            rows_touched = int((st_rows == 1).sum())
-            rows_cleared = int((st_rows == 2).sum())
             alg["preprocess_bwd"] = 2 * N + (248 + 128 + 236) * rows_touched + 236 * rows_cleared
         kernels = {}
         for nm, ms_ in zip(names, stage):

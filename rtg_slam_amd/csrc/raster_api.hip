@@ -10,7 +10,8 @@
 namespace rtgs {
 void launch_mask_sat(const int32_t*, int, int, int32_t*, hipStream_t);
 void launch_preprocess_fwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
-                           const float*, const int32_t*, Splat*, uint32_t*, int32_t*, uint8_t*, int32_t*, hipStream_t);
+                           const float*, const int32_t*, Splat*, uint32_t*, int32_t*, uint8_t*, int32_t*, uint32_t*, int,
+                           hipStream_t);
 void launch_emit_keys(const RasterParams&, const Splat*, const int32_t*, const uint32_t*, const int32_t*, uint64_t*,
                       uint32_t*, hipStream_t);
 void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
@@ -27,7 +28,7 @@ size_t bin_lds_limit_tiles();
 int bin_sort_capacity();
 size_t bin_block_counts_bytes(int, int);
 int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, uint16_t*, hipStream_t);
-void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, hipStream_t);
+void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, uint32_t*, hipStream_t);
 void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const uint16_t*, uint32_t*,
                         unsigned long long*, hipStream_t);
 void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*, uint32_t*, hipStream_t);
@@ -224,25 +225,27 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       DBG(s, st);
     }
     launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sort_path ? sat : nullptr, splats,
-                          tiles_touched, radii, clamped, out_radii, st);
+                          tiles_touched, radii, clamped, out_radii, sort_path ? nullptr : tile_count,
+                          sort_path ? 0 : ntiles, st);
     DBG(s, st);
     prof_mark(EV_PRE, st);
     if (!sort_path) {
       // exact per-tile counts -> ranges; the one host sync of the forward sizes the instance arrays
       if (launch_bin_count(p, splats, radii, tile_mask, tile_count, block_counts, st) != 0) return RTGS_E_HIP;
-      launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, st);
+      // the totals land in pinned host memory straight from the kernel (one slot per calling thread)
+      static thread_local uint32_t* t_info_host = nullptr;
+      if (!t_info_host) HIP_TRY(hipHostMalloc((void**)&t_info_host, 2 * sizeof(uint32_t), hipHostMallocDefault));
+      launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, t_info_host, st);
       DBG(s, st);
-      uint32_t h[2] = {0, 0};
-      HIP_TRY(hipMemcpyAsync(h, info, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       prof_mark(EV_SCAN, st);
       HIP_TRY(hipStreamSynchronize(st));
-      R = (int64_t)h[0];
-      longest = h[1];
+      R = (int64_t)t_info_host[0];
+      longest = t_info_host[1];
       if ((int)longest > bin_sort_capacity()) {   // a tile list too long for the LDS sort: redo with rect counts
         sort_path = true;
         launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
         launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sat, splats, tiles_touched,
-                              radii, clamped, out_radii, st);
+                              radii, clamped, out_radii, nullptr, 0, st);
         DBG(s, st);
       }
     }

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) bin_count_kernel(RasterParams p, const Sp
 // one workgroup: ranges[t] = [start, end), cursor[t] = start, info = {R, longest list}
 __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const uint32_t* __restrict__ tile_count,
                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
-                                                            uint32_t* __restrict__ info) {
+                                                            uint32_t* __restrict__ info, uint32_t* __restrict__ info_host) {
   __shared__ uint32_t s_sum[1024];
   __shared__ uint32_t s_max[1024];
   const int tid = threadIdx.x;
@@ -207,7 +207,12 @@ __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const ui
     cursor[t] = start;
     start += c;
   }
-  if (tid == 1023) { info[0] = s_sum[1023]; info[1] = s_max[1023]; }
+  if (tid == 1023) {
+    info[0] = s_sum[1023]; info[1] = s_max[1023];
+    if (info_host) {   // pinned host words the forward's one host sync reads: no device-to-host copy launch in between
+      info_host[0] = s_sum[1023]; info_host[1] = s_max[1023];
+    }
+  }
 }
 
 // The workgroup reads the per-tile counts bin_count left for it, reserves its slots with ONE global atomic
@@ -388,8 +393,7 @@ size_t bin_block_counts_bytes(int P, int ntiles) {
 
 int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
                      uint32_t* tile_count, uint16_t* block_counts, hipStream_t st) {
-  const int ntiles = p.gx * p.gy;
-  if (hipMemsetAsync(tile_count, 0, (size_t)ntiles * sizeof(uint32_t), st) != hipSuccess) return -1;
+  const int ntiles = p.gx * p.gy;      // tile_count was cleared by preprocess_fwd
   if (p.P == 0) return 0;
   const size_t lds = (size_t)ntiles * sizeof(uint32_t);
   if (lds > 48 * 1024)
@@ -399,8 +403,9 @@ int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* 
   return 0;
 }
 void launch_bin_tilescan(int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* cursor, uint32_t* info,
-                         hipStream_t st) {
-  hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(1024), 0, st, ntiles, tile_count, ranges, cursor, info);
+                         uint32_t* info_host, hipStream_t st) {
+  hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(1024), 0, st, ntiles, tile_count, ranges, cursor, info,
+                     info_host);
 }
 void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_t* radii, const uint16_t* block_counts,
                         uint32_t* cursor, unsigned long long* bucket, hipStream_t st) {

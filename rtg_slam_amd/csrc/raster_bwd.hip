@@ -614,44 +614,62 @@ __global__ void __launch_bounds__(256) fused_adam_rows_kernel(float* __restrict_
                                                               const uint8_t* __restrict__ row_state,
                                                               long long rows, float beta1, float beta2, float eps,
                                                               float bc1, float bc2_sqrt) {
-  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x) {
-    const size_t o = (size_t)r * C;
-    bool any = false;
-    if (row_state) {             // the producer of g already knows which rows are non-zero: no gradient scan
-      any = row_state[r] == 1;
-    } else if constexpr (C % 4 == 0) {
-      const float4* g4 = reinterpret_cast<const float4*>(g + o);
+  // Phase 1 (one lane per row): does the row need an update?  Phase 2: the wave compacts its live rows and
+  // sweeps them with LPR lanes per row, so the p/g/m/v accesses of a live row are contiguous 16-B (or 4-B) lanes.
+  constexpr bool VEC = (C % 4 == 0);
+  constexpr int LPR = VEC ? C / 4 : C;          // lanes per row
+  constexpr int RPP = 64 / LPR;                 // rows per pass
+  __shared__ int s_rows[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long wave0 = (long long)blockIdx.x * 4 + wv, nwaves = (long long)gridDim.x * 4;
+  for (long long base = wave0 * 64; base < rows; base += nwaves * 64) {
+    const long long r = base + lane;
+    bool need = false;
+    if (r < rows) {
+      bool any = false;
+      if (row_state) {             // the producer of g already knows which rows are non-zero: no gradient scan
+        any = row_state[r] == 1;
+      } else if constexpr (VEC) {
+        const float4* g4 = reinterpret_cast<const float4*>(g + (size_t)r * C);
 #pragma unroll
-      for (int q = 0; q < C / 4; ++q) { const float4 t = g4[q]; any |= (t.x != 0.f) | (t.y != 0.f) | (t.z != 0.f) | (t.w != 0.f); }
-    } else {
+        for (int q = 0; q < C / 4; ++q) { const float4 t = g4[q]; any |= (t.x != 0.f) | (t.y != 0.f) | (t.z != 0.f) | (t.w != 0.f); }
+      } else {
 #pragma unroll
-      for (int c = 0; c < C; ++c) any |= g[o + c] != 0.f;
-    }
-    if (!any && ever[r] == 0) continue;
-    ever[r] = 1;
-    if constexpr (C % 4 == 0) {
-      const float4* g4 = reinterpret_cast<const float4*>(g + o);
-      float4* p4 = reinterpret_cast<float4*>(p + o);
-      float4* m4 = reinterpret_cast<float4*>(m + o);
-      float4* v4 = reinterpret_cast<float4*>(v + o);
-#pragma unroll
-      for (int q = 0; q < C / 4; ++q) {
-        const float4 gi = g4[q], pi = p4[q];
-        float4 mi = m4[q], vi = v4[q], po;
-        po.x = adam1(pi.x, gi.x, mi.x, vi.x, lr_col[4 * q], beta1, beta2, eps, bc1, bc2_sqrt);
-        po.y = adam1(pi.y, gi.y, mi.y, vi.y, lr_col[4 * q + 1], beta1, beta2, eps, bc1, bc2_sqrt);
-        po.z = adam1(pi.z, gi.z, mi.z, vi.z, lr_col[4 * q + 2], beta1, beta2, eps, bc1, bc2_sqrt);
-        po.w = adam1(pi.w, gi.w, mi.w, vi.w, lr_col[4 * q + 3], beta1, beta2, eps, bc1, bc2_sqrt);
-        p4[q] = po; m4[q] = mi; v4[q] = vi;
+        for (int c = 0; c < C; ++c) any |= g[(size_t)r * C + c] != 0.f;
       }
-    } else {
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        float mi = m[o + c], vi = v[o + c];
-        p[o + c] = adam1(p[o + c], g[o + c], mi, vi, lr_col[c], beta1, beta2, eps, bc1, bc2_sqrt);
-        m[o + c] = mi; v[o + c] = vi;
+      need = any || ever[r] != 0;
+      if (need) ever[r] = 1;
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(need);
+    if (mask == 0ull) continue;
+    const int n = __popcll(mask);
+    if (need) s_rows[wv][__popcll(mask & ((1ull << lane) - 1ull))] = lane;
+    __builtin_amdgcn_wave_barrier();
+    const int slot = lane / LPR, sub = lane - slot * LPR;
+    for (int k0 = 0; k0 < n; k0 += RPP) {
+      const int k = k0 + slot;
+      if (slot < RPP && k < n) {
+        const size_t row = (size_t)(base + s_rows[wv][k]);
+        if constexpr (VEC) {
+          const size_t o = row * (C / 4) + sub;
+          const float4 gi = reinterpret_cast<const float4*>(g)[o], pi = reinterpret_cast<const float4*>(p)[o];
+          float4 mi = reinterpret_cast<float4*>(m)[o], vi = reinterpret_cast<float4*>(v)[o], po;
+          po.x = adam1(pi.x, gi.x, mi.x, vi.x, lr_col[4 * sub], beta1, beta2, eps, bc1, bc2_sqrt);
+          po.y = adam1(pi.y, gi.y, mi.y, vi.y, lr_col[4 * sub + 1], beta1, beta2, eps, bc1, bc2_sqrt);
+          po.z = adam1(pi.z, gi.z, mi.z, vi.z, lr_col[4 * sub + 2], beta1, beta2, eps, bc1, bc2_sqrt);
+          po.w = adam1(pi.w, gi.w, mi.w, vi.w, lr_col[4 * sub + 3], beta1, beta2, eps, bc1, bc2_sqrt);
+          reinterpret_cast<float4*>(p)[o] = po;
+          reinterpret_cast<float4*>(m)[o] = mi;
+          reinterpret_cast<float4*>(v)[o] = vi;
+        } else {
+          const size_t o = row * C + sub;
+          float mi = m[o], vi = v[o];
+          p[o] = adam1(p[o], g[o], mi, vi, lr_col[sub], beta1, beta2, eps, bc1, bc2_sqrt);
+          m[o] = mi; v[o] = vi;
+        }
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 }  // namespace rtgs
@@ -686,7 +704,7 @@ extern "C" int rtgs_fused_adam_rows(float* params, const float* grads, float* ex
   if (rows == 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-  long long blocks = (rows + 255) / 256;
+  long long blocks = (rows + 255) / 256;      // one wave per 64 rows
   if (blocks > 16384) blocks = 16384;
   hipStream_t st = (hipStream_t)stream;
   if (cols == 3)

@@ -50,8 +50,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     const float* __restrict__ shs, const float* __restrict__ scales, const float* __restrict__ rots,
     const float* __restrict__ normal_w, const int32_t* __restrict__ sat,
     Splat* __restrict__ splats, uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii,
-    uint8_t* __restrict__ clamped, int32_t* __restrict__ out_radii) {
+    uint8_t* __restrict__ clamped, int32_t* __restrict__ out_radii, uint32_t* __restrict__ zero_words, int zero_n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // clears the per-tile counters bin_count accumulates into (saves a memset launch on the critical path)
+  for (int t = i; t < zero_n; t += gridDim.x * blockDim.x) zero_words[t] = 0u;
   if (i >= p.P) return;
   tiles_touched[i] = 0;
   radii[i] = 0;
@@ -536,10 +538,10 @@ void launch_mask_sat(const int32_t* mask, int gx, int gy, int32_t* sat, hipStrea
 void launch_preprocess_fwd(const RasterParams& p, const float* means, const float* opac, const float* shs,
                            const float* scales, const float* rots, const float* normal_w, const int32_t* sat,
                            Splat* splats, uint32_t* tiles_touched, int32_t* radii, uint8_t* clamped,
-                           int32_t* out_radii, hipStream_t st) {
+                           int32_t* out_radii, uint32_t* zero_words, int zero_n, hipStream_t st) {
   if (p.P == 0) return;
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, opac, shs, scales,
-                     rots, normal_w, sat, splats, tiles_touched, radii, clamped, out_radii);
+                     rots, normal_w, sat, splats, tiles_touched, radii, clamped, out_radii, zero_words, zero_n);
 }
 void launch_emit_keys(const RasterParams& p, const Splat* splats, const int32_t* radii, const uint32_t* offsets,
                       const int32_t* mask, uint64_t* keys, uint32_t* vals, hipStream_t st) {

@@ -156,6 +156,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D, opacities, shs, scales, rotations, normal_w, geom.tensor, binning.tensor,
                               img.tensor, color, Tm, didx)
         ctx.mark_non_differentiable(cidx, didx, cw, dw, Tm)
+        ctx.set_materialize_grads(False)      # no zero tensors for the five non-differentiable outputs
         return color, depth, cidx, didx, cw, dw, Tm
 
     @staticmethod
