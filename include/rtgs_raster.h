@@ -145,8 +145,22 @@ void rtgs_raster_set_counters(void* counters);
  * durations in milliseconds (-1 = stage did not run):
  *   [0] preprocess_fwd (+ mask SAT)  [1] bin_count + tilescan (fallback: scan)  [2] bin_scatter
  *   (fallback: emit_keys)  [3] bin_tilesort (fallback: radix sort)  [4] tile_ranges (fallback only)
- *   [5] blend_fwd  [6] grad memset + blend_bwd  [7] preprocess_bwd */
+ *   [5] blend_fwd  [6] grad memset + blend_bwd  [7] preprocess_bwd
+ *   [8] near-slice binning (histogram, count, scan, scatter, sort)  [9] near-slice blend_fwd
+ * With the near-slice pass on, [1]..[5] describe the second pass (tiles the slice left unfinished). */
 void rtgs_raster_set_profiling(int enable);
+/* Near-slice (occlusion) pass of the forward.  The nearest Gaussians - as many depth bins as fit a budget of
+ * `budget_per_tile` x tiles instances - are binned, sorted and blended first; a tile whose every pixel reaches
+ * T < T_threshold inside that slice is final (the slice list is a prefix of the tile's full depth-ordered list, so
+ * the walk would have stopped there anyway); only the other tiles are binned against the whole map.  Outputs are
+ * bit-identical to the single-pass forward; the backward walks each tile's list of the pass that finished it.
+ * mode 0 = off, 1 = always, 2 = automatic (default: maps of >= 100 000 Gaussians, suspended for 16 calls after a
+ * call in which the slice finished fewer tiles than it left).  budget_per_tile <= 0 keeps the current budget
+ * (default 384).  Environment overrides at load time: RTGS_NEAR_SLICE, RTGS_NEAR_SLICE_BUDGET.
+ * rtgs_raster_last_slice_stats: [0] slice used by the last forward, [1] instances binned for the slice,
+ * [2] tiles it finished, [3] tiles left to the second pass. */
+void rtgs_raster_set_near_slice(int mode, int budget_per_tile);
+int rtgs_raster_last_slice_stats(int64_t* out4_host);
 /* Testing aid: force the fallback binning path (global 64-bit radix sort, rocPRIM) that is
  * otherwise taken only when the tile grid or one tile list exceeds the LDS-resident path. */
 void rtgs_raster_force_sort_path(int enable);

@@ -66,6 +66,8 @@ _SIGNATURES = {
     "rtgs_slam_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "rtgs_raster_set_profiling": (None, [C.c_int]),
     "rtgs_raster_force_sort_path": (None, [C.c_int]),
+    "rtgs_raster_set_near_slice": (None, [C.c_int, C.c_int]),
+    "rtgs_raster_last_slice_stats": (C.c_int, [C.POINTER(C.c_int64)]),
     "rtgs_raster_last_timings": (C.c_int, [C.POINTER(C.c_float)]),
     "rtgs_icp_build_pyramids": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "rtgs_icp_step": (C.c_int, [_P] * 4 + [C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P]),

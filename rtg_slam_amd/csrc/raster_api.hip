@@ -11,12 +11,12 @@ namespace rtgs {
 void launch_mask_sat(const int32_t*, int, int, int32_t*, hipStream_t);
 void launch_preprocess_fwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, Splat*, uint32_t*, int32_t*, uint8_t*, int32_t*, uint32_t*, int,
-                           hipStream_t);
+                           uint8_t*, hipStream_t);
 void launch_emit_keys(const RasterParams&, const Splat*, const int32_t*, const uint32_t*, const int32_t*, uint64_t*,
                       uint32_t*, hipStream_t);
 void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
-                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, hipStream_t);
+                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, hipStream_t);
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
                       const uint32_t*, const int32_t*, const float*, const float*, SplatGrad*, uint8_t*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
@@ -27,17 +27,27 @@ void launch_preprocess_bwd(const RasterParams&, const float*, const float*, cons
 size_t bin_lds_limit_tiles();
 int bin_sort_capacity();
 size_t bin_block_counts_bytes(int, int);
-int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, uint16_t*, hipStream_t);
-void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, uint32_t*, hipStream_t);
-void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const uint16_t*, uint32_t*,
-                        unsigned long long*, hipStream_t);
+int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, uint16_t*, SliceSel,
+                     hipStream_t);
+void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,
+                         hipStream_t);
+void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const int32_t*, const uint16_t*, uint32_t*,
+                        unsigned long long*, SliceSel, hipStream_t);
+void launch_slice_hist(int, const uint8_t*, const uint32_t*, uint32_t*, hipStream_t);
 void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*, uint32_t*, hipStream_t);
 
 static int64_t g_stats[8] = {0};
+// Near-slice (occlusion) pass: 0 = off, 1 = always, 2 = automatic (large maps; backs off for 16 calls after a call in
+// which the slice finished fewer tiles than it left).  RTGS_NEAR_SLICE / RTGS_NEAR_SLICE_BUDGET override at load time.
+static int g_slice_mode = [] { const char* e = getenv("RTGS_NEAR_SLICE"); return e ? atoi(e) : 2; }();
+static int g_slice_budget = [] { const char* e = getenv("RTGS_NEAR_SLICE_BUDGET"); return e ? atoi(e) : 384; }();
+static int g_slice_cooldown = 0;
+static int64_t g_slice_stats[4] = {0};     // used, near-slice instances, tiles finished, tiles left to pass 2
 static unsigned long long* g_counters = nullptr;
 
 // optional per-stage HIP-event timing (bench.py's roofline leg); off by default
-enum { EV_F0 = 0, EV_PRE, EV_SCAN, EV_BIN0, EV_EMIT, EV_SORT, EV_RANGES, EV_BLEND0, EV_BLEND, EV_B0, EV_BBLEND, EV_BPRE, EV_N };
+enum { EV_F0 = 0, EV_PRE, EV_SL_BIN, EV_SL_BLEND, EV_SCAN, EV_BIN0, EV_EMIT, EV_SORT, EV_RANGES, EV_BLEND0, EV_BLEND, EV_B0,
+       EV_BBLEND, EV_BPRE, EV_N };
 static bool g_prof = false;
 static bool g_force_sort_path = false;   // testing aid: take the global radix-sort binning path
 static bool g_ev_init = false;
@@ -73,6 +83,27 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy) {
   L.cursor = off; off = align_up(off + (size_t)gx * gy * sizeof(uint32_t));
   L.info = off; off = align_up(off + 4 * sizeof(uint32_t));
   L.block_counts = off; off = align_up(off + bin_block_counts_bytes((int)Pn, gx * gy));
+  {
+    const size_t nt = (size_t)gx * gy;
+    L.zero_begin = L.tile_count;                 // tile_count .. slice_ctr are contiguous and cleared by preprocess_fwd
+    off = L.tile_count + nt * sizeof(uint32_t);  // (re-lays cursor / info / block_counts behind the zeroed span)
+    L.tile_count1 = off; off += nt * sizeof(uint32_t);
+    L.ranges1_bwd = off; off += nt * sizeof(uint2);
+    L.slice_hist = off; off += SLICE_BINS * sizeof(uint32_t);
+    L.slice_ctr = off; off += 4 * sizeof(uint32_t);
+    L.zero_end = off; off = align_up(off);
+    L.cursor = off; off = align_up(off + nt * sizeof(uint32_t));
+    L.info = off; off = align_up(off + 4 * sizeof(uint32_t));
+    L.block_counts = off; off = align_up(off + bin_block_counts_bytes((int)Pn, gx * gy));
+    L.zbin = off; off = align_up(off + Pn);
+    L.cursor1 = off; off = align_up(off + nt * sizeof(uint32_t));
+    L.ranges1 = off; off = align_up(off + nt * sizeof(uint2));
+    L.mask2 = off; off = align_up(off + nt * sizeof(int32_t));
+    L.block_counts1 = off; off = align_up(off + bin_block_counts_bytes((int)Pn, gx * gy));
+    L.slice_cap = nt * (size_t)(g_slice_budget > 0 ? g_slice_budget : 1);
+    L.bucket1 = off; off = align_up(off + L.slice_cap * sizeof(uint64_t));
+    L.list1 = off; off = align_up(off + L.slice_cap * sizeof(uint32_t));
+  }
   size_t tb = 0;
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)Pn);
   L.scan_temp_bytes = tb;
@@ -210,42 +241,96 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   uint2* ranges = (uint2*)(img + I.ranges);
   uint32_t* n_contrib = (uint32_t*)(img + I.n_contrib);
 
-  int64_t R = 0;
+  int64_t R = 0, R1 = 0;
   for (int i = 0; i < EV_B0; ++i) g_ev_set[i] = false;
   prof_mark(EV_F0, st);
   uint32_t* tile_count = (uint32_t*)(geom + G.tile_count);
   uint32_t* cursor = (uint32_t*)(geom + G.cursor);
   uint32_t* info = (uint32_t*)(geom + G.info);
   uint16_t* block_counts = (uint16_t*)(geom + G.block_counts);
+  uint32_t* zero_words = (uint32_t*)(geom + G.zero_begin);
+  const int zero_n = (int)((G.zero_end - G.zero_begin) / sizeof(uint32_t));
+  uint32_t* tile_count1 = (uint32_t*)(geom + G.tile_count1);
+  uint2* ranges1_bwd = (uint2*)(geom + G.ranges1_bwd);
+  uint32_t* slice_hist = (uint32_t*)(geom + G.slice_hist);
+  uint32_t* slice_ctr = (uint32_t*)(geom + G.slice_ctr);
+  uint8_t* zbin = (uint8_t*)(geom + G.zbin);
+  uint2* ranges1 = (uint2*)(geom + G.ranges1);
+  int32_t* mask2 = (int32_t*)(geom + G.mask2);
+  uint32_t* list1 = (uint32_t*)(geom + G.list1);
   uint32_t longest = 0;
   bool sort_path = (size_t)ntiles > bin_lds_limit_tiles() || g_force_sort_path;
+  // near-slice pass: worth its fixed cost only on large maps; mode 1 forces it (tests)
+  bool sliced = !sort_path && P > 0 &&
+                (g_slice_mode == 1 || (g_slice_mode == 2 && P >= 100000 && ntiles >= 256 && g_slice_cooldown == 0));
+  if (g_slice_mode == 2 && g_slice_cooldown > 0) --g_slice_cooldown;
+  SlicePass pass{0, nullptr, nullptr, nullptr, nullptr};
+  const int32_t* mask_main = tile_mask;        // tile mask of the pass that ends in the host sync
+  uint32_t n_left = 0, n_fin = 0;
+  if (P == 0) HIP_TRY(hipMemsetAsync(zero_words, 0, (size_t)zero_n * sizeof(uint32_t), st));   // ranges1_bwd for the backward
   if (P > 0) {
     if (sort_path) {   // only the fallback path needs the 3-sigma-rect tile counts
       launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
       DBG(s, st);
     }
     launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sort_path ? sat : nullptr, splats,
-                          tiles_touched, radii, clamped, out_radii, sort_path ? nullptr : tile_count,
-                          sort_path ? 0 : ntiles, st);
+                          tiles_touched, radii, clamped, out_radii, zero_words, zero_n, sliced ? zbin : nullptr, st);
     DBG(s, st);
     prof_mark(EV_PRE, st);
+    if (sliced) {
+      // Pass 1: bin, sort and blend only the nearest Gaussians (as many depth bins as fit the instance budget).  Tiles
+      // whose every pixel saturates inside the slice are final; blend_fwd leaves a tile mask of the others.  No host
+      // sync: the arrays are sized by the budget, the sort classes are launched blind.
+      const SliceSel sel1{1, zbin, slice_hist, (uint32_t)G.slice_cap, slice_ctr};
+      launch_slice_hist(P, zbin, tiles_touched, slice_hist, st);
+      if (launch_bin_count(p, splats, radii, tile_mask, tile_count1, (uint16_t*)(geom + G.block_counts1), sel1, st) != 0)
+        return RTGS_E_HIP;
+      launch_bin_tilescan(ntiles, tile_count1, ranges1, (uint32_t*)(geom + G.cursor1), info + 2, nullptr, nullptr,
+                          nullptr, st);
+      launch_bin_scatter(p, splats, radii, tile_mask, (const uint16_t*)(geom + G.block_counts1),
+                         (uint32_t*)(geom + G.cursor1), (unsigned long long*)(geom + G.bucket1), sel1, st);
+      launch_bin_tilesort(ntiles, (uint32_t)SLICE_MAX_LIST, ranges1, (const unsigned long long*)(geom + G.bucket1), list1,
+                          st);
+      DBG(s, st);
+      prof_mark(EV_SL_BIN, st);
+      const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, slice_ctr};
+      launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
+                       n_contrib, g_counters, pass1, st);
+      DBG(s, st);
+      prof_mark(EV_SL_BLEND, st);
+      mask_main = mask2;
+      pass = SlicePass{2, nullptr, mask2, nullptr, nullptr};
+    }
     if (!sort_path) {
       // exact per-tile counts -> ranges; the one host sync of the forward sizes the instance arrays
-      if (launch_bin_count(p, splats, radii, tile_mask, tile_count, block_counts, st) != 0) return RTGS_E_HIP;
+      const SliceSel sel2{sliced ? 2 : 0, nullptr, nullptr, 0u, slice_ctr};
+      if (launch_bin_count(p, splats, radii, mask_main, tile_count, block_counts, sel2, st) != 0) return RTGS_E_HIP;
       // the totals land in pinned host memory straight from the kernel (one slot per calling thread)
       static thread_local uint32_t* t_info_host = nullptr;
-      if (!t_info_host) HIP_TRY(hipHostMalloc((void**)&t_info_host, 2 * sizeof(uint32_t), hipHostMallocDefault));
-      launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, t_info_host, st);
+      if (!t_info_host) HIP_TRY(hipHostMalloc((void**)&t_info_host, 8 * sizeof(uint32_t), hipHostMallocDefault));
+      launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, t_info_host, sliced ? slice_ctr : nullptr,
+                          sliced ? info + 2 : nullptr, st);
       DBG(s, st);
       prof_mark(EV_SCAN, st);
       HIP_TRY(hipStreamSynchronize(st));
       R = (int64_t)t_info_host[0];
       longest = t_info_host[1];
+      if (sliced) {
+        n_left = t_info_host[2]; n_fin = t_info_host[3];
+        R1 = (int64_t)t_info_host[4];        // total of the slice lists, finished or not (accounting only)
+        if (g_slice_mode == 2 && n_left > n_fin) g_slice_cooldown = 16;    // little occlusion here: stop paying for pass 1
+      }
       if ((int)longest > bin_sort_capacity()) {   // a tile list too long for the LDS sort: redo with rect counts
         sort_path = true;
+        if (sliced) {         // the global-sort path renders every tile itself: drop the slice's results
+          HIP_TRY(hipMemsetAsync(ranges1_bwd, 0, (size_t)ntiles * sizeof(uint2), st));
+          sliced = false; R1 = 0; n_left = n_fin = 0;
+          pass = SlicePass{0, nullptr, nullptr, nullptr, nullptr};
+          mask_main = tile_mask;
+        }
         launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
         launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sat, splats, tiles_touched,
-                              radii, clamped, out_radii, nullptr, 0, st);
+                              radii, clamped, out_radii, nullptr, 0, nullptr, st);
         DBG(s, st);
       }
     }
@@ -259,7 +344,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       R = (int64_t)total;
     }
   }
-  *num_rendered_host = R;
+  *num_rendered_host = R + R1;
 
   const BinLayout B = bin_layout(R, ntiles, sort_path);
   char* bin = (char*)binning_resize(binning_user, B.total);
@@ -273,7 +358,8 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   if (P == 0 || sort_path) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), st));
   if (R > 0 && !sort_path) {
     prof_mark(EV_BIN0, st);
-    launch_bin_scatter(p, splats, radii, block_counts, cursor, (unsigned long long*)keys_a, st);
+    launch_bin_scatter(p, splats, radii, mask_main, block_counts, cursor, (unsigned long long*)keys_a,
+                       SliceSel{sliced ? 2 : 0, nullptr, nullptr, 0u, slice_ctr}, st);
     DBG(s, st);
     prof_mark(EV_EMIT, st);
     launch_bin_tilesort(ntiles, longest, ranges, (const unsigned long long*)keys_a, vals_b, st);
@@ -294,14 +380,17 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
     prof_mark(EV_RANGES, st);
   }
   prof_mark(EV_BLEND0, st);
-  launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                   n_contrib, g_counters, st);
+  if (!sliced || n_left > 0)     // pass 2 (or the only pass); with every tile finished by the slice there is nothing to draw
+    launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
+                     n_contrib, g_counters, pass, st);
   prof_mark(EV_BLEND, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
   g_stats[0] = R; g_stats[1] = sort_bits; g_stats[2] = ntiles; g_stats[3] = (int64_t)G.total;
   g_stats[4] = (int64_t)B.total; g_stats[5] = (int64_t)I.total;
   g_stats[6] = sort_path ? 0 : 1; g_stats[7] = (int64_t)longest;
+  g_stats[0] = R + R1;
+  g_slice_stats[0] = sliced ? 1 : 0; g_slice_stats[1] = R1; g_slice_stats[2] = n_fin; g_slice_stats[3] = n_left;
   return RTGS_OK;
 }
 
@@ -336,6 +425,11 @@ static int backward_impl(const rtgs_raster_settings* s, int32_t P, int32_t M, in
   // row-state mode: the caller zeroed the scratch once and preprocess_bwd re-zeroes every line it consumes
   if (!row_state) HIP_TRY(hipMemsetAsync(grads, 0, rtgs_raster_backward_scratch_bytes(P), st));
   if (R > 0) {
+    // two-pass forward: tiles the near slice finished walk its lists (ranges1_bwd is all-empty otherwise, and a
+    // workgroup with an empty range returns at once); every other tile walks the main lists
+    launch_blend_bwd(p, (const uint2*)(geom + G.ranges1_bwd), (const uint32_t*)(geom + G.list1),
+                     (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
+                     dL_dcolor, dL_ddepth, grads, touched, st);
     launch_blend_bwd(p, (const uint2*)(img + I.ranges), (const uint32_t*)(bin + B.vals_b),
                      (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
                      dL_dcolor, dL_ddepth, grads, touched, st);
@@ -379,17 +473,30 @@ int rtgs_raster_backward_rows(const rtgs_raster_settings* s, int32_t P, int32_t 
 }
 
 void rtgs_raster_set_profiling(int enable) { g_prof = enable != 0; }
+void rtgs_raster_set_near_slice(int mode, int budget_per_tile) {
+  g_slice_mode = mode;
+  g_slice_cooldown = 0;
+  if (budget_per_tile > 0) g_slice_budget = budget_per_tile;
+}
+int rtgs_raster_last_slice_stats(int64_t* out) {
+  if (!out) return RTGS_E_INVALID;
+  memcpy(out, g_slice_stats, sizeof(g_slice_stats));
+  return RTGS_OK;
+}
 void rtgs_raster_force_sort_path(int enable) { g_force_sort_path = enable != 0; }
 
 int rtgs_raster_last_timings(float* ms) {
   if (!ms) return RTGS_E_INVALID;
   for (int i = 0; i < 10; ++i) ms[i] = -1.f;
   if (!g_ev_init) return RTGS_OK;
-  // [0] preprocess_fwd(+sat) [1] scan [2] emit_keys [3] radix sort [4] tile_ranges [5] blend_fwd
-  // [6] memset+blend_bwd [7] preprocess_bwd
-  const int pairs[8][2] = {{EV_F0, EV_PRE}, {EV_PRE, EV_SCAN}, {EV_BIN0, EV_EMIT}, {EV_EMIT, EV_SORT},
-                           {EV_SORT, EV_RANGES}, {EV_BLEND0, EV_BLEND}, {EV_B0, EV_BBLEND}, {EV_BBLEND, EV_BPRE}};
-  for (int i = 0; i < 8; ++i) {
+  // [0] preprocess_fwd(+sat) [1] count+scan of the main pass [2] scatter / emit_keys [3] sort [4] tile_ranges
+  // [5] blend_fwd of the main pass [6] blend_bwd (both launches) [7] preprocess_bwd
+  // [8] near slice: hist+count+scan+scatter+sort [9] near slice: blend_fwd
+  const int pre_end = g_ev_set[EV_SL_BLEND] ? EV_SL_BLEND : EV_PRE;
+  const int pairs[10][2] = {{EV_F0, EV_PRE}, {pre_end, EV_SCAN}, {EV_BIN0, EV_EMIT}, {EV_EMIT, EV_SORT},
+                            {EV_SORT, EV_RANGES}, {EV_BLEND0, EV_BLEND}, {EV_B0, EV_BBLEND}, {EV_BBLEND, EV_BPRE},
+                            {EV_PRE, EV_SL_BIN}, {EV_SL_BIN, EV_SL_BLEND}};
+  for (int i = 0; i < 10; ++i) {
     const int a = pairs[i][0], b = pairs[i][1];
     if (!g_ev_set[a] || !g_ev_set[b]) continue;
     if (hipEventSynchronize(g_ev[b]) != hipSuccess) return RTGS_E_HIP;

@@ -38,10 +38,12 @@ __device__ __forceinline__ void bin_rect(float u, float v, int radius, int gx, i
 }
 
 __device__ __forceinline__ bool load_bing(const RasterParams& p, const Splat* __restrict__ splats,
-                                          const int32_t* __restrict__ radii, int i, BinG& g) {
+                                          const int32_t* __restrict__ radii, const uint8_t* __restrict__ zbin, int cut,
+                                          int i, BinG& g) {
   g.x0 = g.y0 = g.x1 = g.y1 = 0;
   g.u = g.v = g.ca = g.cb = g.cc = 0.f; g.thr = -1.f; g.zbits = 0; g.ica = g.icc = 0.f;
   if (i >= p.P) return false;
+  if (zbin && (int)zbin[i] > cut) return false;      // not in the near slice (255 = invisible)
   const int radius = radii[i];
   if (radius <= 0) return false;
   const float4 r0 = reinterpret_cast<const float4*>(splats + i)[0];
@@ -107,16 +109,36 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
   return v;
 }
 
+// Cut bin of the near slice, recomputed by every workgroup from the 256-bin histogram (BLOCK threads, one bin each).
+__device__ __forceinline__ int slice_cut(const SliceSel& sel) {
+  __shared__ uint32_t s_wsum[BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t h = sel.hist[tid];
+  uint32_t incl = h;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) s_wsum[w] = incl;
+  __syncthreads();
+  unsigned long long cum = incl;
+  for (int k = 0; k < w; ++k) cum += s_wsum[k];
+  const int n_ok = __syncthreads_count(cum <= (unsigned long long)sel.cap);    // cum is monotone: a prefix of bins fits
+  return n_ok - 1;
+}
+
 template <class F>
 __device__ __forceinline__ void enumerate_balanced(const RasterParams& p, const Splat* __restrict__ splats,
-                                                   const int32_t* __restrict__ radii, WaveBin* wb, F f) {
+                                                   const int32_t* __restrict__ radii, const int32_t* __restrict__ mask,
+                                                   const uint8_t* __restrict__ zbin, int cut, WaveBin* wb, F f) {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const unsigned long long le_mask = lt_mask | (1ull << lane);
   for (int k = 0; k < GPB / BLOCK; ++k) {
     const int i = blockIdx.x * GPB + k * BLOCK + (int)threadIdx.x;
     BinG g;
-    const bool live = load_bing(p, splats, radii, i, g);
+    const bool live = load_bing(p, splats, radii, zbin, cut, i, g);
     const int w = g.x1 - g.x0;
     const uint32_t area = live ? (uint32_t)(w * (g.y1 - g.y0)) : 0u;
     const unsigned long long nz = __builtin_amdgcn_ballot_w64(area > 0u);
@@ -151,7 +173,8 @@ __device__ __forceinline__ void enumerate_balanced(const RasterParams& p, const 
         const int ry = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)bw));   // exact: margin 0.5/bw >> rcp error
         const int rx = (int)local - ry * (int)bw;
         const int tx = (int)(xy & 0xffffu) + rx, ty = (int)(xy >> 16) + ry;
-        if (tile_visible(b, tx, ty)) f(ty * p.gx + tx, r[10], r[11]);
+        const int t = ty * p.gx + tx;
+        if (mask[t] != 0 && tile_visible(b, tx, ty)) f(t, r[10], r[11]);
       }
       started += (uint32_t)__popcll(hm);
     }
@@ -162,19 +185,22 @@ __global__ void __launch_bounds__(256) bin_count_kernel(RasterParams p, const Sp
                                                         const int32_t* __restrict__ radii,
                                                         const int32_t* __restrict__ mask,
                                                         uint32_t* __restrict__ tile_count,
-                                                        uint16_t* __restrict__ block_counts) {
+                                                        uint16_t* __restrict__ block_counts, SliceSel sel) {
   extern __shared__ uint32_t s_cnt[];
   __shared__ WaveBin s_wb[BLOCK / 64];
   const int ntiles = p.gx * p.gy;
+  if (sel.mode == 2 && sel.ctr[0] == 0u) return;     // the near slice finished every tile: nothing left to bin
+  const int cut = sel.mode == 1 ? slice_cut(sel) : 0;
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
   __syncthreads();
-  enumerate_balanced(p, splats, radii, &s_wb[threadIdx.x >> 6], [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
+  enumerate_balanced(p, splats, radii, mask, sel.mode == 1 ? sel.zbin : nullptr, cut, &s_wb[threadIdx.x >> 6],
+                     [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
   __syncthreads();
   // the workgroup's row of per-tile counts is kept for bin_scatter (same Gaussian -> workgroup mapping),
   // which therefore needs only ONE enumeration sweep; a workgroup holds GPB <= 65535 Gaussians, so u16 fits
   uint16_t* row = block_counts + (size_t)blockIdx.x * ntiles;
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) {
-    const uint32_t c = (mask[t] != 0) ? s_cnt[t] : 0u;
+    const uint32_t c = s_cnt[t];                     // masked tiles were never counted
     row[t] = (uint16_t)c;
     if (c) atomicAdd(&tile_count[t], c);
   }
@@ -183,7 +209,9 @@ __global__ void __launch_bounds__(256) bin_count_kernel(RasterParams p, const Sp
 // one workgroup: ranges[t] = [start, end), cursor[t] = start, info = {R, longest list}
 __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const uint32_t* __restrict__ tile_count,
                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
-                                                            uint32_t* __restrict__ info, uint32_t* __restrict__ info_host) {
+                                                            uint32_t* __restrict__ info, uint32_t* __restrict__ info_host,
+                                                            const uint32_t* __restrict__ extra_src,
+                                                            const uint32_t* __restrict__ extra_src2) {
   __shared__ uint32_t s_sum[1024];
   __shared__ uint32_t s_max[1024];
   const int tid = threadIdx.x;
@@ -211,6 +239,8 @@ __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const ui
     info[0] = s_sum[1023]; info[1] = s_max[1023];
     if (info_host) {   // pinned host words the forward's one host sync reads: no device-to-host copy launch in between
       info_host[0] = s_sum[1023]; info_host[1] = s_max[1023];
+      if (extra_src) { info_host[2] = extra_src[0]; info_host[3] = extra_src[1]; }   // near-slice tile counters
+      if (extra_src2) info_host[4] = extra_src2[0];                                  // near-slice instance total
     }
   }
 }
@@ -221,12 +251,14 @@ __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const ui
 // atomic per instance 2.9x slower (7.9 M atomics on 3 225 cursors).
 __global__ void __launch_bounds__(256) bin_scatter_kernel(RasterParams p, const Splat* __restrict__ splats,
                                                           const int32_t* __restrict__ radii,
+                                                          const int32_t* __restrict__ mask,
                                                           const uint16_t* __restrict__ block_counts,
                                                           uint32_t* __restrict__ cursor,
-                                                          unsigned long long* __restrict__ bucket) {
+                                                          unsigned long long* __restrict__ bucket, SliceSel sel) {
   extern __shared__ uint32_t s_mem[];
   __shared__ WaveBin s_wb[BLOCK / 64];
   const int ntiles = p.gx * p.gy;
+  const int cut = sel.mode == 1 ? slice_cut(sel) : 0;
   uint32_t* s_cnt = s_mem;
   uint32_t* s_base = s_mem + ntiles;
   const uint16_t* row = block_counts + (size_t)blockIdx.x * ntiles;
@@ -236,7 +268,8 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(RasterParams p, const 
     s_cnt[t] = 0;
   }
   __syncthreads();
-  enumerate_balanced(p, splats, radii, &s_wb[threadIdx.x >> 6], [&](int t, uint32_t id, uint32_t zbits) {
+  enumerate_balanced(p, splats, radii, mask, sel.mode == 1 ? sel.zbin : nullptr, cut, &s_wb[threadIdx.x >> 6],
+                     [&](int t, uint32_t id, uint32_t zbits) {
     const uint32_t base = s_base[t];
     if (base != 0xffffffffu) {
       const uint32_t slot = base + atomicAdd(&s_cnt[t], 1u);
@@ -391,31 +424,54 @@ size_t bin_block_counts_bytes(int P, int ntiles) {
   return (size_t)((P + GPB - 1) / GPB) * (size_t)ntiles * sizeof(uint16_t);
 }
 
+// area-weighted depth histogram of the visible Gaussians (input of slice_cut)
+__global__ void __launch_bounds__(256) slice_hist_kernel(int P, const uint8_t* __restrict__ zbin,
+                                                         const uint32_t* __restrict__ rect_area,
+                                                         uint32_t* __restrict__ hist) {
+  __shared__ uint32_t s_h[SLICE_BINS];
+  s_h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
+    const uint32_t b = zbin[i];
+    if (b != 255u) atomicAdd(&s_h[b], rect_area[i]);
+  }
+  __syncthreads();
+  const uint32_t v = s_h[threadIdx.x];
+  if (v) atomicAdd(&hist[threadIdx.x], v);
+}
+void launch_slice_hist(int P, const uint8_t* zbin, const uint32_t* rect_area, uint32_t* hist, hipStream_t st) {
+  if (P == 0) return;
+  int blocks = (P + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(slice_hist_kernel, dim3(blocks), dim3(256), 0, st, P, zbin, rect_area, hist);
+}
+
 int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
-                     uint32_t* tile_count, uint16_t* block_counts, hipStream_t st) {
+                     uint32_t* tile_count, uint16_t* block_counts, SliceSel sel, hipStream_t st) {
   const int ntiles = p.gx * p.gy;      // tile_count was cleared by preprocess_fwd
   if (p.P == 0) return 0;
   const size_t lds = (size_t)ntiles * sizeof(uint32_t);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(bin_count_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii, mask,
-                     tile_count, block_counts);
+                     tile_count, block_counts, sel);
   return 0;
 }
 void launch_bin_tilescan(int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* cursor, uint32_t* info,
-                         uint32_t* info_host, hipStream_t st) {
+                         uint32_t* info_host, const uint32_t* extra_src, const uint32_t* extra_src2, hipStream_t st) {
   hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(1024), 0, st, ntiles, tile_count, ranges, cursor, info,
-                     info_host);
+                     info_host, extra_src, extra_src2);
 }
-void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_t* radii, const uint16_t* block_counts,
-                        uint32_t* cursor, unsigned long long* bucket, hipStream_t st) {
+void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
+                        const uint16_t* block_counts, uint32_t* cursor, unsigned long long* bucket, SliceSel sel,
+                        hipStream_t st) {
   if (p.P == 0) return;
   const int ntiles = p.gx * p.gy;
   const size_t lds = 2 * (size_t)ntiles * sizeof(uint32_t);
   if (lds > 32 * 1024)
     (void)hipFuncSetAttribute((const void*)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii,
-                     block_counts, cursor, bucket);
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii, mask,
+                     block_counts, cursor, bucket, sel);
 }
 template <int THREADS>
 static void launch_radix(int ntiles, const uint2* ranges, const unsigned long long* bucket, uint32_t* point_list, int lo,

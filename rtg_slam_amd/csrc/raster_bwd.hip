@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
   const size_t pix = (size_t)py * p.W + px;
   const size_t HW = (size_t)p.H * p.W;
   const int n = (int)(range.y - range.x);
+  if (n == 0) return;      // nothing was blended here (or the tile belongs to the other pass of a two-pass forward)
 
   const uint32_t last = inside ? n_contrib[pix] : 0u;
   const float T_final = inside ? final_T[pix] : 0.f;

@@ -52,7 +52,37 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 struct GeomLayout {
   size_t splats, tiles_touched, offsets, radii, clamped, sat, tile_count, cursor, info, block_counts, scan_temp, total;
   size_t scan_temp_bytes;
+  // near-slice pass (raster_api.hip): [zero_begin, zero_end) is cleared by preprocess_fwd on every call
+  size_t zero_begin, zero_end;
+  size_t tile_count1, ranges1_bwd, slice_hist, slice_ctr;           // inside the zeroed span (tile_count is too)
+  size_t zbin, cursor1, ranges1, mask2, block_counts1, bucket1, list1;
+  size_t slice_cap;                                                  // instance capacity of bucket1 / list1
 };
+
+// Near-slice selection: a Gaussian belongs to the slice iff its depth bin (monotone in the f32 depth bits, 32 bins
+// per octave from 0.2) is <= the cut every workgroup derives from the area histogram: the largest bin whose
+// cumulative 3-sigma-rect instance count still fits `cap`.
+constexpr int SLICE_BINS = 256;
+constexpr int SLICE_MAX_LIST = 3072;        // longest near-slice tile list that is sorted (longer: tile left to pass 2)
+struct SliceSel {
+  int mode;                      // 0 = every Gaussian; 1 = near slice only; 2 = every Gaussian, exit if no tile is unfinished
+  const uint8_t* zbin;           // [P] depth bin, 255 = not visible
+  const uint32_t* hist;          // [SLICE_BINS] rect-instance count per bin
+  uint32_t cap;
+  const uint32_t* ctr;           // ctr[0] = tiles the near slice left unfinished
+};
+// blend_fwd role in the two-pass forward
+struct SlicePass {
+  int mode;                      // 0 = single pass; 1 = near slice (records which tiles finished); 2 = remaining tiles only
+  const int32_t* user_mask;      // mode 1
+  int32_t* mask2;                // mode 1: written; mode 2: read
+  uint2* ranges_bwd;             // mode 1: range of a finished tile, (0,0) otherwise - what blend_bwd walks
+  uint32_t* ctr;                 // mode 1: ctr[0] += unfinished (unmasked) tiles, ctr[1] += finished tiles
+};
+__device__ __forceinline__ uint32_t slice_bin_of(float z) {
+  const int b = (int)(__float_as_uint(z) >> 18) - (int)(0x3E4CCCCDu >> 18);     // 0.2f
+  return (uint32_t)(b < 0 ? 0 : (b > SLICE_BINS - 2 ? SLICE_BINS - 2 : b));
+}
 struct BinLayout {
   size_t keys_a, keys_b, vals_a, vals_b, sort_temp, total;
   size_t sort_temp_bytes;

@@ -50,7 +50,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     const float* __restrict__ shs, const float* __restrict__ scales, const float* __restrict__ rots,
     const float* __restrict__ normal_w, const int32_t* __restrict__ sat,
     Splat* __restrict__ splats, uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii,
-    uint8_t* __restrict__ clamped, int32_t* __restrict__ out_radii, uint32_t* __restrict__ zero_words, int zero_n) {
+    uint8_t* __restrict__ clamped, int32_t* __restrict__ out_radii, uint32_t* __restrict__ zero_words, int zero_n,
+    uint8_t* __restrict__ zbin) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   // clears the per-tile counters bin_count accumulates into (saves a memset launch on the critical path)
   for (int t = i; t < zero_n; t += gridDim.x * blockDim.x) zero_words[t] = 0u;
@@ -58,6 +59,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   tiles_touched[i] = 0;
   radii[i] = 0;
   if (out_radii) out_radii[i] = 0;
+  if (zbin) zbin[i] = 255;
 
   const float* V = p.view;   // V[j*4+i] = W2C[i][j]
   const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
@@ -195,6 +197,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   radii[i] = radius;
   if (out_radii) out_radii[i] = radius;
   tiles_touched[i] = (uint32_t)touched;
+  if (zbin) zbin[i] = (uint8_t)slice_bin_of(pcz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -271,19 +274,21 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
     int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
     float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
-    unsigned long long* __restrict__ counters) {
+    unsigned long long* __restrict__ counters, SlicePass sp) {
   __shared__ float4 s_rec[BATCH * 4];
   __shared__ int32_t s_id[BATCH];
   __shared__ float2 s_h[BATCH];
 
   const int tid = threadIdx.x;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
+  if (sp.mode == 2 && sp.mask2[tile] == 0) return;     // finished by the near slice (or masked off): outputs stay
   const int px = blockIdx.x * TILE + (tid & 15);
   const int py = blockIdx.y * TILE + (tid >> 4);
   const bool inside = px < p.W && py < p.H;
   const float pxf = (float)px, pyf = (float)py;
   const uint2 range = ranges[tile];
-  const int n = (int)(range.y - range.x);
+  int n = (int)(range.y - range.x);
+  if (sp.mode == 1 && n > SLICE_MAX_LIST) n = 0;       // near-slice list too long to have been sorted: leave the tile to pass 2
 
   bool done = !inside;
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
@@ -384,6 +389,19 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     }
   }
   contributor = last_contributor;   // accounting only (entries this pixel needed)
+
+  if (sp.mode == 1) {
+    // A tile whose every pixel stopped inside the near slice is final: the slice's list is a prefix of the tile's full
+    // list (depth bins are monotone in depth), so nothing behind it would have been read.  Anything else is redone
+    // from scratch by pass 2.
+    const bool finished = __syncthreads_and(done) != 0;
+    if (tid == 0) {
+      const bool on = sp.user_mask[tile] != 0;
+      sp.mask2[tile] = (on && !finished) ? 1 : 0;
+      sp.ranges_bwd[tile] = finished ? range : make_uint2(0u, 0u);
+      if (on) atomicAdd(&sp.ctr[finished ? 1 : 0], 1u);
+    }
+  }
 
   if (inside) {
     const size_t pix = (size_t)py * p.W + px;
@@ -538,10 +556,10 @@ void launch_mask_sat(const int32_t* mask, int gx, int gy, int32_t* sat, hipStrea
 void launch_preprocess_fwd(const RasterParams& p, const float* means, const float* opac, const float* shs,
                            const float* scales, const float* rots, const float* normal_w, const int32_t* sat,
                            Splat* splats, uint32_t* tiles_touched, int32_t* radii, uint8_t* clamped,
-                           int32_t* out_radii, uint32_t* zero_words, int zero_n, hipStream_t st) {
+                           int32_t* out_radii, uint32_t* zero_words, int zero_n, uint8_t* zbin, hipStream_t st) {
   if (p.P == 0) return;
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, opac, shs, scales,
-                     rots, normal_w, sat, splats, tiles_touched, radii, clamped, out_radii, zero_words, zero_n);
+                     rots, normal_w, sat, splats, tiles_touched, radii, clamped, out_radii, zero_words, zero_n, zbin);
 }
 void launch_emit_keys(const RasterParams& p, const Splat* splats, const int32_t* radii, const uint32_t* offsets,
                       const int32_t* mask, uint64_t* keys, uint32_t* vals, hipStream_t st) {
@@ -556,15 +574,15 @@ void launch_tile_ranges(int64_t R, const uint64_t* keys, uint2* ranges, hipStrea
 void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                       float* out_color, float* out_depth, int32_t* out_cidx, int32_t* out_didx, float* out_cw,
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
-                      hipStream_t st) {
+                      SlicePass sp, hipStream_t st) {
   static const int variant = [] { const char* e = getenv("RTGS_BLEND_FWD"); return e ? atoi(e) : 0; }();
-  if (variant == 1) {
+  if (variant == 1 && sp.mode == 0) {
     hipLaunchKernelGGL(blend_fwd_scalar_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
                        out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters);
     return;
   }
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
-                     out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters);
+                     out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp);
 }
 
 }  // namespace rtgs

@@ -422,3 +422,69 @@ def test_optimizer_row_state_path_matches_dense_path():
     moved = (pa - packed.cpu()).abs().max(dim=1).values > 0
     assert 0 < int(moved.sum()) < N            # untouched rows never moved
     assert torch.equal(moved, (pb - packed.cpu()).abs().max(dim=1).values > 0)
+
+
+def _slice_stats(lib):
+    import ctypes as C
+    st = (C.c_int64 * 4)()
+    assert lib.rtgs_raster_last_slice_stats(st) == 0
+    return [int(v) for v in st]
+
+
+@pytest.mark.parametrize("cam,N,budget,masked", [(SMALL, 4000, 24, False), (ODD, 6000, 48, True), (SMALL, 4000, 4, False),
+                                               (ODD, 2500, 2000, False)])
+def test_near_slice_forward_is_bit_identical(cam, N, budget, masked):
+    """Two-pass forward (near slice first, the rest only for unfinished tiles) vs the single-pass forward:
+    every output bit-identical, gradients equal up to the atomics' summation order - for budgets that finish
+    none, some and all of the tiles, with and without a tile mask."""
+    from rtg_slam_amd import _lib
+    lib = _lib.load()
+    dev = "cuda:0"
+    # an opaque, overlapping scene: many tiles saturate early, some never do
+    g, s = ru.make_scene(N, cam, seed=21, pose_seed=2, r_range=(0.02, 0.12))
+    mask = None
+    if masked:
+        gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+        mask = (torch.rand(gy, gx, generator=torch.Generator().manual_seed(4)) < 0.7).int()
+    gen = torch.Generator().manual_seed(5)
+    grads = (torch.randn(3, cam.H, cam.W, generator=gen), torch.randn(1, cam.H, cam.W, generator=gen))
+    try:
+        lib.rtgs_raster_set_near_slice(0, 0)
+        out_a, gd_a = ru.hip_run(s, g, tile_mask=mask, grads=grads, dev=dev)
+        assert _slice_stats(lib)[0] == 0
+        lib.rtgs_raster_set_near_slice(1, budget)
+        out_b, gd_b = ru.hip_run(s, g, tile_mask=mask, grads=grads, dev=dev)
+        used, r1, fin, left = _slice_stats(lib)
+    finally:
+        lib.rtgs_raster_set_near_slice(2, 384)
+    assert used == 1
+    for k, (a, b) in enumerate(zip(out_a, out_b)):
+        assert torch.equal(a, b), (k, fin, left)
+    for k in ru.FIELDS:
+        scale = float(gd_a[k].abs().max()) + 1e-12
+        assert ru.frac_bad(gd_b[k], gd_a[k], 1e-4 * scale) < 1e-3, (k, fin, left)
+        assert torch.equal(gd_a[k].reshape(N, -1).ne(0).any(1), gd_b[k].reshape(N, -1).ne(0).any(1)), k
+    if budget == 4:
+        assert left > 0                # a starved slice leaves work for pass 2
+    if budget == 2000:
+        assert r1 > 0 and fin > 0      # a slice that holds every Gaussian finishes the saturating tiles
+    print("near slice:", dict(budget=budget, r1=r1, finished=fin, left=left))
+
+
+def test_near_slice_automatic_on_large_map():
+    """Automatic mode: a 200 k map takes the two-pass forward; result identical to the single pass."""
+    from rtg_slam_amd import _lib
+    lib = _lib.load()
+    cam = synth.CONFIG2
+    g, s = ru.make_scene(200_000, cam, seed=2024)
+    try:
+        lib.rtgs_raster_set_near_slice(2, 0)
+        out_b, _ = ru.hip_run(s, g)
+        used, r1, fin, left = _slice_stats(lib)
+        lib.rtgs_raster_set_near_slice(0, 0)
+        out_a, _ = ru.hip_run(s, g)
+    finally:
+        lib.rtgs_raster_set_near_slice(2, 384)
+    assert used == 1 and fin + left > 0
+    for k, (a, b) in enumerate(zip(out_a, out_b)):
+        assert torch.equal(a, b), (k, fin, left)
