@@ -108,18 +108,41 @@ def main():
     def loss_fn(gd):
         return mo.slam_losses_hip(render(gd), gt_color, gt_depth)
 
-    # Tracking and mapping are independent within a frame (RTG-SLAM runs them as two pipeline stages,
-    # SLAM/multiprocess/system.py): the launch-bound ICP kernels go to a second HIP stream and overlap the
-    # rasterizer; both streams are joined at the end of every frame.
+    # Tracking and mapping are independent within a frame (RTG-SLAM runs them as two pipeline stages in separate
+    # processes, SLAM/multiprocess/system.py).  Here the tracker's kernels go to a second HIP stream and are
+    # ENQUEUED by a helper thread (the C calls release the GIL), so neither the GPU nor the host serialises the two.
     icp_stream = torch.cuda.Stream(device=dev)
+    import queue
+    import threading
+    icp_req, icp_done = queue.SimpleQueue(), queue.SimpleQueue()
+
+    def icp_worker():
+        torch.cuda.set_device(dev)
+        while True:
+            if icp_req.get() is None:
+                return
+            try:
+                with torch.cuda.stream(icp_stream):
+                    vp1, np1 = hicp.build_pyramids(d1, K, 3)
+                    icp_done.put(hicp.icp_track(vp1, np1, vp0, np0, K, [0.25, 0.5, 1.0], [5, 5, 5], 0.1, cos_thr, 1e-4))
+            except Exception as e:          # surface in the main thread
+                icp_done.put(e)
+
+    threading.Thread(target=icp_worker, daemon=True).start()
+
+    def map_step():
+        if world == 1 and opt.grad_rows is not None:
+            return opt.step_slam(rs, gt_color, gt_depth, tile_mask)       # same kernels, one C call
+        return opt.step(loss_fn)
 
     def frame():
         main = torch.cuda.current_stream(dev)
         icp_stream.wait_stream(main)
-        with torch.cuda.stream(icp_stream):
-            vp1, np1 = hicp.build_pyramids(d1, K, 3)
-            out = hicp.icp_track(vp1, np1, vp0, np0, K, [0.25, 0.5, 1.0], [5, 5, 5], 0.1, cos_thr, 1e-4)
-        opt.step(loss_fn)
+        icp_req.put(1)
+        map_step()
+        out = icp_done.get()
+        if isinstance(out, Exception):
+            raise out
         main.wait_stream(icp_stream)
         return out
 

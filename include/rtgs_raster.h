@@ -206,6 +206,43 @@ int rtgs_slam_loss(const float* color, const float* depth, const int32_t* depth_
                    const float* gt_depth, int32_t H, int32_t W, float color_weight, float depth_weight,
                    float* sums3_scratch, float* loss_out, float* g_color, float* g_depth, void* stream);
 
+/* One map-optimisation iteration as a single call (the body of local_optimize's inner loop, mapper.py:176-205, with
+ * the live loss terms of mapper.py:402-442):
+ *   raw8 activation -> rtgs_raster_forward -> rtgs_slam_loss -> rtgs_raster_backward_rows ->
+ *   rtgs_map_activate8_backward_rows -> rtgs_fused_adam_rows on xyz[P,3], shs[P,48], raw8[P,8].
+ * Exactly the sequence the entry points above perform when called one by one (parameters are updated in place, the
+ * scalar loss is left in loss_scratch4[3]); it exists because the host cost of issuing ~40 launches through an
+ * autograd graph exceeds their GPU time on a large map.  Every pointer is a caller-owned DEVICE buffer; the
+ * gradient arena (d_*, grad_scratch, row_state) and the Adam state (m_*, v_*, ever_*) persist between calls and
+ * follow the rtgs_raster_backward_rows / rtgs_fused_adam_rows contracts.  The three resize callbacks are the ones
+ * rtgs_raster_forward takes and must ALSO answer a request of size 0 with the buffer of their last request. */
+typedef struct rtgs_map_step_args {
+  const rtgs_raster_settings* settings;
+  int32_t P, sh_coeffs;                                   /* sh_coeffs must be 16 */
+  float *xyz, *shs, *raw8;                                /* parameters, updated in place */
+  const int32_t* tile_mask;
+  const float *gt_color, *gt_depth;                       /* [3,H,W], [1,H,W] */
+  float color_weight, depth_weight;
+  float *opacity, *scales, *rotations, *normal;           /* activated values: [P,1] [P,3] [P,4] [P,3] */
+  float *out_color, *out_depth;                           /* the 7 outputs of the rasterizer (+ radii) */
+  int32_t *out_color_index, *out_depth_index;
+  float *out_color_weight, *out_depth_weight, *out_T;
+  int32_t* out_radii;
+  float *dL_dcolor, *dL_ddepth, *loss_scratch4;           /* loss_scratch4: [0:3] partial sums, [3] loss */
+  float *d_xyz, *d_opacity, *d_shs, *d_scales, *d_rotations, *d_normal, *d_raw8;
+  void* grad_scratch;                                     /* rtgs_raster_backward_scratch_bytes(P), zero-initialised */
+  uint8_t* row_state;                                     /* [P], zero-initialised */
+  float *m_xyz, *v_xyz, *m_shs, *v_shs, *m_raw8, *v_raw8;
+  const float *lr_xyz, *lr_shs, *lr_raw8;                 /* per-column learning rates: [3] [48] [8] */
+  uint8_t *ever_xyz, *ever_shs, *ever_raw8;               /* [P] each, zero-initialised */
+  int32_t step;                                           /* Adam step count, starts at 1 */
+  float beta1, beta2, eps;
+  rtgs_resize_fn geom_resize; void* geom_user;
+  rtgs_resize_fn binning_resize; void* binning_user;
+  rtgs_resize_fn image_resize; void* image_user;
+} rtgs_map_step_args;
+int rtgs_slam_map_step(const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
+
 const char* rtgs_version(void);
 
 #ifdef __cplusplus

@@ -43,6 +43,23 @@ _lock = threading.Lock()
 _lib = None
 
 _P = C.c_void_p
+class MapStepArgsC(C.Structure):
+    """Mirror of `rtgs_map_step_args` (include/rtgs_raster.h)."""
+    _fields_ = (
+        [("settings", C.POINTER(RasterSettingsC)), ("P", C.c_int32), ("sh_coeffs", C.c_int32)]
+        + [(n, C.c_void_p) for n in ("xyz", "shs", "raw8", "tile_mask", "gt_color", "gt_depth")]
+        + [("color_weight", C.c_float), ("depth_weight", C.c_float)]
+        + [(n, C.c_void_p) for n in (
+            "opacity", "scales", "rotations", "normal", "out_color", "out_depth", "out_color_index", "out_depth_index",
+            "out_color_weight", "out_depth_weight", "out_T", "out_radii", "dL_dcolor", "dL_ddepth", "loss_scratch4",
+            "d_xyz", "d_opacity", "d_shs", "d_scales", "d_rotations", "d_normal", "d_raw8", "grad_scratch", "row_state",
+            "m_xyz", "v_xyz", "m_shs", "v_shs", "m_raw8", "v_raw8", "lr_xyz", "lr_shs", "lr_raw8",
+            "ever_xyz", "ever_shs", "ever_raw8")]
+        + [("step", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+        + [("geom_resize", RESIZE_FN), ("geom_user", C.c_void_p), ("binning_resize", RESIZE_FN),
+           ("binning_user", C.c_void_p), ("image_resize", RESIZE_FN), ("image_user", C.c_void_p)])
+
+
 _SIGNATURES = {
     "rtgs_version": (C.c_char_p, []),
     "rtgs_raster_forward": (C.c_int, [C.POINTER(RasterSettingsC), C.c_int32, C.c_int32] + [_P] * 6 + [_P]
@@ -63,6 +80,7 @@ _SIGNATURES = {
     "rtgs_map_activate8_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "rtgs_map_activate8_backward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "rtgs_map_activate8_backward_rows": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "rtgs_slam_map_step": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_slam_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "rtgs_raster_set_profiling": (None, [C.c_int]),
     "rtgs_raster_force_sort_path": (None, [C.c_int]),

@@ -1,0 +1,46 @@
+// rtgs_slam_map_step: one map-optimisation iteration (the inner loop body of mapper.py:176-205 with the live loss
+// terms of mapper.py:402-442) enqueued by ONE call: raw8 activation -> rasterizer forward -> fused SLAM loss ->
+// row-state rasterizer backward -> activation backward -> row-skipping Adam on the three block tensors.
+// Nothing new is computed here - it is the sequence map_optim.ShardedMapOptimizer.step() issues through autograd,
+// without the per-launch Python / autograd cost (which exceeds the GPU time of the step on a 1.2 M map).
+#include "../../include/rtgs_raster.h"
+
+extern "C" int rtgs_slam_map_step(const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
+  if (!a || !num_rendered_host || !a->settings) return RTGS_E_INVALID;
+  const int32_t P = a->P, M = a->sh_coeffs;
+  if (P <= 0 || M != 16 || a->step < 1) return RTGS_E_INVALID;
+  if (!a->xyz || !a->shs || !a->raw8 || !a->tile_mask || !a->gt_color || !a->gt_depth) return RTGS_E_INVALID;
+  const int32_t H = a->settings->image_height, W = a->settings->image_width;
+  int rc = rtgs_map_activate8_forward(a->raw8, P, a->opacity, a->scales, a->rotations, a->normal, stream);
+  if (rc != 0) return RTGS_E_HIP;
+  rc = rtgs_raster_forward(a->settings, P, M, a->xyz, a->opacity, a->shs, a->scales, a->rotations, a->normal,
+                           a->tile_mask, a->out_color, a->out_depth, a->out_color_index, a->out_depth_index,
+                           a->out_color_weight, a->out_depth_weight, a->out_T, a->out_radii, a->geom_resize,
+                           a->geom_user, a->binning_resize, a->binning_user, a->image_resize, a->image_user,
+                           num_rendered_host, stream);
+  if (rc != RTGS_OK) return rc;
+  void* geom = a->geom_resize(a->geom_user, 0);          // size 0 = "hand me the buffer of the last request"
+  void* bin = a->binning_resize(a->binning_user, 0);
+  void* img = a->image_resize(a->image_user, 0);
+  if (!geom || !bin || !img) return RTGS_E_ALLOC;
+  rc = rtgs_slam_loss(a->out_color, a->out_depth, a->out_depth_index, a->gt_color, a->gt_depth, H, W, a->color_weight,
+                      a->depth_weight, a->loss_scratch4, a->loss_scratch4 + 3, a->dL_dcolor, a->dL_ddepth, stream);
+  if (rc != 0) return RTGS_E_HIP;
+  rc = rtgs_raster_backward_rows(a->settings, P, M, *num_rendered_host, a->xyz, a->opacity, a->shs, a->scales,
+                                 a->rotations, a->normal, geom, bin, img, a->out_color, a->out_T, a->out_depth_index,
+                                 a->dL_dcolor, a->dL_ddepth, a->d_xyz, a->d_opacity, a->d_shs, a->d_scales,
+                                 a->d_rotations, a->d_normal, a->grad_scratch, a->row_state, stream);
+  if (rc != RTGS_OK) return rc;
+  rc = rtgs_map_activate8_backward_rows(a->raw8, P, a->d_opacity, a->d_scales, a->d_rotations, a->d_normal,
+                                        a->row_state, a->d_raw8, stream);
+  if (rc != 0) return RTGS_E_HIP;
+  rc = rtgs_fused_adam_rows(a->xyz, a->d_xyz, a->m_xyz, a->v_xyz, a->lr_xyz, a->ever_xyz, a->row_state, P, 3, a->step,
+                            a->beta1, a->beta2, a->eps, stream);
+  if (rc != 0) return RTGS_E_HIP;
+  rc = rtgs_fused_adam_rows(a->shs, a->d_shs, a->m_shs, a->v_shs, a->lr_shs, a->ever_shs, a->row_state, P, 48, a->step,
+                            a->beta1, a->beta2, a->eps, stream);
+  if (rc != 0) return RTGS_E_HIP;
+  rc = rtgs_fused_adam_rows(a->raw8, a->d_raw8, a->m_raw8, a->v_raw8, a->lr_raw8, a->ever_raw8, a->row_state, P, 8,
+                            a->step, a->beta1, a->beta2, a->eps, stream);
+  return rc != 0 ? RTGS_E_HIP : RTGS_OK;
+}

@@ -451,8 +451,11 @@ int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* 
   const int ntiles = p.gx * p.gy;      // tile_count was cleared by preprocess_fwd
   if (p.P == 0) return 0;
   const size_t lds = (size_t)ntiles * sizeof(uint32_t);
-  if (lds > 48 * 1024)
+  static size_t granted = 48 * 1024;           // raise the dynamic-LDS limit once per size, not on every launch
+  if (lds > granted) {
     (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    granted = lds;
+  }
   hipLaunchKernelGGL(bin_count_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii, mask,
                      tile_count, block_counts, sel);
   return 0;
@@ -468,8 +471,11 @@ void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_
   if (p.P == 0) return;
   const int ntiles = p.gx * p.gy;
   const size_t lds = 2 * (size_t)ntiles * sizeof(uint32_t);
-  if (lds > 32 * 1024)
+  static size_t granted = 32 * 1024;
+  if (lds > granted) {
     (void)hipFuncSetAttribute((const void*)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    granted = lds;
+  }
   hipLaunchKernelGGL(bin_scatter_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii, mask,
                      block_counts, cursor, bucket, sel);
 }
@@ -477,9 +483,12 @@ template <int THREADS>
 static void launch_radix(int ntiles, const uint2* ranges, const unsigned long long* bucket, uint32_t* point_list, int lo,
                          int hi, int cap, hipStream_t st) {
   const size_t lds = (size_t)cap * 16 + (size_t)(THREADS / 64 + 1) * 256 * sizeof(uint32_t);
-  if (lds > 48 * 1024)
+  static size_t granted = 48 * 1024;           // one static per THREADS instantiation
+  if (lds > granted) {
     (void)hipFuncSetAttribute((const void*)bin_tilesort_radix_kernel<THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
+    granted = lds;
+  }
   hipLaunchKernelGGL(bin_tilesort_radix_kernel<THREADS>, dim3(ntiles), dim3(THREADS), lds, st, ranges, bucket, point_list,
                      lo, hi, cap);
 }
@@ -494,8 +503,12 @@ void launch_bin_tilesort(int ntiles, uint32_t longest, const uint2* ranges, cons
   if (longest > 1024) launch_radix<512>(ntiles, ranges, bucket, point_list, 1025, 3073, 3072, st);
   if (longest > 3072) launch_radix<1024>(ntiles, ranges, bucket, point_list, 3073, 8193, 8192, st);
   if (longest > 8192) {
-    (void)hipFuncSetAttribute((const void*)bin_tilesort_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              16384 * 8);
+    static bool granted = false;
+    if (!granted) {
+      (void)hipFuncSetAttribute((const void*)bin_tilesort_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                16384 * 8);
+      granted = true;
+    }
     hipLaunchKernelGGL(bin_tilesort_kernel<1024>, dim3(ntiles), dim3(1024), 16384 * 8, st, ranges, bucket, point_list,
                        8193, 16385);
   }

@@ -186,6 +186,26 @@ def _adam_rows_hip(p, g, m, v, lr_col, step, eps, ever, row_state=None):
     _lib.check(rc, "rtgs_fused_adam_rows")
 
 
+class _GrowArena:
+    """Resize-callback target that keeps its buffer between calls (grows geometrically); a request of size 0
+    returns the current buffer (the `rtgs_slam_map_step` contract)."""
+
+    def __init__(self, device):
+        from . import _lib
+        self.device = device
+        self.tensor = None
+        self.cb = _lib.RESIZE_FN(self._resize)
+
+    def _resize(self, _user, nbytes):
+        try:
+            nbytes = int(nbytes)
+            if self.tensor is None or self.tensor.numel() < nbytes:
+                self.tensor = torch.empty(max(int(nbytes * 1.25), 256), dtype=torch.uint8, device=self.device)
+            return self.tensor.data_ptr()
+        except Exception:
+            return 0
+
+
 class ShardedMapOptimizer:
     def __init__(self, packed: torch.Tensor, lr_col: Optional[torch.Tensor] = None, eps: float = 1e-15,
                  group=None, adam_fn: Optional[Callable] = None, activate_fn: Optional[Callable] = None):
@@ -220,6 +240,9 @@ class ShardedMapOptimizer:
         # arena to loss_fn as gd["grad_rows"]; a loss_fn that forwards it to the rasterizer (grad_rows=...) gets the
         # row-state backward, one that ignores it gets the dense path - the results are identical.
         self.grad_rows = None
+        self._slam_ws = None
+        self.last_render = None
+        self.last_num_rendered = 0
         if self.row_skip and self.world == 1 and activate_fn is None:
             from .rasterizer import RowGradArena
             self.grad_rows = RowGradArena(self.N, 16, dev)
@@ -234,6 +257,70 @@ class ShardedMapOptimizer:
             _adam_rows_hip(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps, st["ever"], row_state)
         else:
             self.adam_fn(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps)
+
+    # ------------------------------------------------------------------ one-call SLAM step (single GPU)
+    def step_slam(self, raster_settings, gt_color: torch.Tensor, gt_depth: torch.Tensor,
+                  tile_mask: Optional[torch.Tensor] = None, color_weight: float = 0.8,
+                  depth_weight: float = 1.0) -> torch.Tensor:
+        """One iteration with the built-in SLAM loss (`slam_losses`): identical kernels and results as
+        `step(lambda gd: slam_losses_hip(render(gd), gt_color, gt_depth))`, but enqueued by a single C call
+        (`rtgs_slam_map_step`) - no autograd graph, no per-launch Python.  Single-GPU HIP path only; with more
+        than one rank (or injected torch kernels) it falls back to `step`.  Returns the loss (0-dim device view,
+        overwritten by the next call); the rendered images of the step are in `self.last_render`."""
+        from . import _lib
+        from .rasterizer import GaussianRasterizer, _Keep
+        if self.grad_rows is None:
+            rast = GaussianRasterizer(raster_settings)
+
+            def loss_fn(gd):
+                out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], scales=gd["scales"],
+                           rotations=gd["rotations"], normal_w=gd["normal"], tile_mask=tile_mask)
+                return slam_losses_hip(out, gt_color, gt_depth, color_weight, depth_weight)
+            return self.step(loss_fn)
+        lib = _lib.load()
+        rs = raster_settings
+        N, st, a = self.N, self.state, self.grad_rows
+        dev = st["xyz"]["p"].device
+        H, W = int(rs.image_height), int(rs.image_width)
+        ws = self._slam_ws
+        if ws is None or ws["hw"] != (H, W):
+            f = dict(dtype=torch.float32, device=dev)
+            i = dict(dtype=torch.int32, device=dev)
+            ws = self._slam_ws = dict(
+                hw=(H, W), opacity=torch.empty(N, 1, **f), scales=torch.empty(N, 3, **f), rotations=torch.empty(N, 4, **f),
+                normal=torch.empty(N, 3, **f), color=torch.empty(3, H, W, **f), depth=torch.empty(1, H, W, **f),
+                cidx=torch.empty(1, H, W, **i), didx=torch.empty(1, H, W, **i), cw=torch.empty(1, H, W, **f),
+                dw=torch.empty(1, H, W, **f), T=torch.empty(1, H, W, **f), radii=torch.empty(N, **i),
+                g_color=torch.empty(3, H, W, **f), g_depth=torch.empty(1, H, W, **f), loss=torch.empty(4, **f),
+                ones=torch.ones((H + 15) // 16, (W + 15) // 16, **i),
+                arenas=[_GrowArena(dev), _GrowArena(dev), _GrowArena(dev)])
+        if tile_mask is None:
+            tile_mask = ws["ones"]
+        tile_mask = tile_mask.to(device=dev, dtype=torch.int32).contiguous()
+        gt_color, gt_depth = gt_color.contiguous(), gt_depth.contiguous()
+        keep = _Keep(rs, dev)
+        self.step_count += 1
+        P = lambda t: t.data_ptr()
+        geom, binning, img = ws["arenas"]
+        args = _lib.MapStepArgsC(
+            C.pointer(keep.c), N, 16, P(st["xyz"]["p"]), P(st["shs"]["p"]), P(st["raw8"]["p"]), P(tile_mask), P(gt_color),
+            P(gt_depth), float(color_weight), float(depth_weight), P(ws["opacity"]), P(ws["scales"]), P(ws["rotations"]),
+            P(ws["normal"]), P(ws["color"]), P(ws["depth"]), P(ws["cidx"]), P(ws["didx"]), P(ws["cw"]), P(ws["dw"]),
+            P(ws["T"]), P(ws["radii"]), P(ws["g_color"]), P(ws["g_depth"]), P(ws["loss"]), P(a.d_means), P(a.d_opac),
+            P(a.d_shs), P(a.d_scales), P(a.d_rots), P(a.d_normal), P(a.d_raw8), P(a.scratch), P(a.row_state),
+            P(st["xyz"]["m"]), P(st["xyz"]["v"]), P(st["shs"]["m"]), P(st["shs"]["v"]), P(st["raw8"]["m"]),
+            P(st["raw8"]["v"]), P(st["xyz"]["lr"]), P(st["shs"]["lr"]), P(st["raw8"]["lr"]), P(st["xyz"]["ever"]),
+            P(st["shs"]["ever"]), P(st["raw8"]["ever"]), int(self.step_count), 0.9, 0.999, float(self.eps),
+            geom.cb, None, binning.cb, None, img.cb, None)
+        R = C.c_int64(0)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            rc = lib.rtgs_slam_map_step(C.byref(args), C.byref(R), C.c_void_p(stream))
+        _lib.check(rc, "rtgs_slam_map_step")
+        a.calls = 1
+        self.last_render = (ws["color"], ws["depth"], ws["cidx"], ws["didx"], ws["cw"], ws["dw"], ws["T"])
+        self.last_num_rendered = int(R.value)
+        return ws["loss"][3]
 
     def _arena_grad(self, name):
         a = self.grad_rows

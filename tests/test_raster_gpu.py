@@ -488,3 +488,40 @@ def test_near_slice_automatic_on_large_map():
     assert used == 1 and fin + left > 0
     for k, (a, b) in enumerate(zip(out_a, out_b)):
         assert torch.equal(a, b), (k, fin, left)
+
+
+def test_one_call_slam_step_matches_autograd_step():
+    """ShardedMapOptimizer.step_slam (rtgs_slam_map_step, one C call) vs step(loss_fn) through autograd:
+    same loss values, parameters equal up to the atomics' summation order, same rows moved."""
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    from rtg_slam_amd import map_optim as mo
+    dev = "cuda:0"
+    N = 5000
+    g, _ = ru.make_scene(N, SMALL, seed=9, pose_seed=1)
+    packed = mo.pack_from_activated({k: v.to(dev) for k, v in g.items()})
+    gen = torch.Generator().manual_seed(2)
+    gt_c = torch.rand(3, SMALL.H, SMALL.W, generator=gen).to(dev)
+    gt_d = (1.0 + torch.rand(1, SMALL.H, SMALL.W, generator=gen)).to(dev)
+    gy, gx = (SMALL.H + 15) // 16, (SMALL.W + 15) // 16
+    mask = (torch.rand(gy, gx, generator=gen) < 0.8).int().to(dev)
+    oa, ob = mo.ShardedMapOptimizer(packed.clone()), mo.ShardedMapOptimizer(packed.clone())
+    for step, pose in enumerate((1, 2, 3, 2, 1)):
+        _, s = ru.make_scene(N, SMALL, seed=9, pose_seed=pose)
+        rs = ru.hip_settings(s, dev)
+        rast = GaussianRasterizer(raster_settings=rs)
+        tm = mask if step % 2 else None
+
+        def loss_fn(gd):
+            out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None,
+                       scales=gd["scales"], rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"],
+                       tile_mask=tm, grad_rows=gd.get("grad_rows"))
+            return mo.slam_losses_hip(out, gt_c, gt_d)
+        la = float(oa.step(loss_fn))
+        lb = float(ob.step_slam(rs, gt_c, gt_d, tm))
+        assert abs(la - lb) <= 1e-4 * max(1.0, abs(la)), step
+        assert ob.last_num_rendered > 0 and ob.last_render[0].shape == (3, SMALL.H, SMALL.W)
+    pa, pb = oa.params.cpu(), ob.params.cpu()
+    assert ru.frac_bad(pa, pb, 1e-5) < 2e-3
+    moved = (pa - packed.cpu()).abs().max(dim=1).values > 0
+    assert 0 < int(moved.sum()) < N
+    assert torch.equal(moved, (pb - packed.cpu()).abs().max(dim=1).values > 0)
