@@ -111,7 +111,7 @@ def main():
     # Tracking and mapping are independent within a frame (RTG-SLAM runs them as two pipeline stages in separate
     # processes, SLAM/multiprocess/system.py).  Here the tracker's kernels go to a second HIP stream and are
     # ENQUEUED by a helper thread (the C calls release the GIL), so neither the GPU nor the host serialises the two.
-    icp_stream = torch.cuda.Stream(device=dev)
+    icp_stream = torch.cuda.Stream(device=dev, priority=-1)      # short, latency-bound kernels: schedule them first
     import queue
     import threading
     icp_req, icp_done = queue.SimpleQueue(), queue.SimpleQueue()
@@ -176,11 +176,12 @@ def main():
         # ---- per-kernel stage timing (HIP events on the launch stream) + work counters ---------
         counters = torch.zeros(2, dtype=torch.int64, device=dev)
         lib.rtgs_raster_set_profiling(1)
-        acc = [0.0] * 8
+        acc = [0.0] * 10
         nprof = max(3, min(10, args.steps))
         icp_ms = 0.0
         consumed = pairs = 0
         rows_touched = rows_cleared = None
+        slice_stats = None
         R = 0
         for i in range(nprof):
             counters.zero_()
@@ -196,8 +197,12 @@ def main():
             torch.cuda.synchronize(dev)
             ms = (C.c_float * 10)()
             lib.rtgs_raster_last_timings(ms)
-            for k in range(8):
+            for k in range(10):
                 acc[k] += max(0.0, ms[k])
+            sl = (C.c_int64 * 4)()
+            lib.rtgs_raster_last_slice_stats(sl)
+            slice_stats = {"used": int(sl[0]), "instances": int(sl[1]), "tiles_finished": int(sl[2]),
+                           "tiles_left_to_pass2": int(sl[3])}
             st = (C.c_int64 * 8)()
             lib.rtgs_raster_last_stats(st)
             R = int(st[0])
@@ -218,7 +223,7 @@ def main():
         m30 = torch.zeros(gyx, dtype=torch.int32, device=dev)
         m30[torch.linspace(0, gyx - 1, int(0.3 * gyx)).long().to(dev)] = 1
         m30 = m30.view_as(tile_mask)
-        acc30 = [0.0] * 8
+        acc30 = [0.0] * 10
         for i in range(4):
             lv = {nm: opt.state[nm]["p"][:N].detach().clone().requires_grad_(True) for nm in ("xyz", "shs", "raw8")}
             if opt.grad_rows is not None:
@@ -233,12 +238,15 @@ def main():
             ms = (C.c_float * 10)()
             lib.rtgs_raster_last_timings(ms)
             if i >= 1:
-                for k in range(8):
+                for k in range(10):
                     acc30[k] += max(0.0, ms[k]) / 3
         lib.rtgs_raster_set_profiling(0)
         stage = [a / nprof for a in acc]
+        # With the near-slice pass on (rtgs_raster_set_near_slice), stages 1-5 are the SECOND pass (tiles the slice left
+        # unfinished - none in this scene) and stages 8-9 the slice itself.
         names = ["preprocess_fwd", "bin_count", "bin_scatter", "bin_tilesort", "tile_ranges_fallback_only",
-                 "blend_fwd", "blend_bwd", "preprocess_bwd"]
+                 "blend_fwd", "blend_bwd", "preprocess_bwd", "near_slice_binning", "near_slice_blend_fwd"]
+        sliced = bool(slice_stats and slice_stats["used"])
         Px = cam.H * cam.W
         Nv = N   # upper bound; culled rows write nothing
         # algorithmic bytes per launch (I := instances the tile walk consumes)
@@ -247,22 +255,31 @@ def main():
             "bin_count": 68 * N,
             "bin_scatter": 68 * N + 8 * R,
             "bin_tilesort": 12 * R,
-            "blend_fwd": 68 * consumed + 40 * Px,
+            ("near_slice_blend_fwd" if sliced else "blend_fwd"): 68 * consumed + 40 * Px,
             "blend_bwd": 68 * consumed + 28 * Px + 36 * consumed,
             "preprocess_bwd": 248 * N + 64 * N + 236 * N,
         }
+        if sliced:
+            # second pass: count exits at once when the slice finished every tile (reads the tile counters only)
+            R2 = R - slice_stats["instances"]
+            alg["bin_count"] = 68 * N if slice_stats["tiles_left_to_pass2"] else 0
+            alg["bin_scatter"] = 68 * N + 8 * R2
+            alg["bin_tilesort"] = 12 * R2
+            # slice: depth bin + rect area per Gaussian (histogram), depth bin per Gaussian twice (count, scatter),
+            # 8-B key write + 8-B read + 4-B write per slice instance; the slice's Splat reads are not counted
+            alg["near_slice_binning"] = 5 * N + 2 * N + 20 * slice_stats["instances"]
         if opt.grad_rows is not None:
             # row-state backward: 2 state bytes per Gaussian; only rows that change are read / written
             # (inputs 248 B + SplatGrad 64 B read and 64 B re-zeroed + 236 B of gradient rows, also for rows being cleared)
             alg["preprocess_bwd"] = 2 * N + (248 + 128 + 236) * rows_touched + 236 * rows_cleared
         kernels = {}
         for nm, ms_ in zip(names, stage):
-            if nm in alg and ms_ > 0:
+            if nm in alg and ms_ > 0 and alg[nm] > 0:
                 kernels[nm] = {"ms": round(ms_, 4), "alg_MB": round(alg[nm] / 1e6, 2),
                                "GBps": round(alg[nm] / (ms_ * 1e-3) / 1e9, 1)}
             else:
                 kernels[nm] = {"ms": round(ms_, 4)}
-        dom = max((n for n in names if n in alg), key=lambda n: stage[names.index(n)])
+        dom = max((n for n in names if n in alg and n != "near_slice_binning"), key=lambda n: stage[names.index(n)])
         dom_ms = stage[names.index(dom)]
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
         traffic = None
@@ -293,10 +310,10 @@ def main():
                        "instances": R, "instances_consumed": consumed,
                        "pixel_pairs_evaluated": pairs,
                        "parallelism": f"dp{world}: replicated map, per-rank view, RCCL reduce-scatter grads + sharded Adam + all-gather"},
-            "raster_fwd_ms": round(sum(stage[:6]), 4), "raster_bwd_ms": round(sum(stage[6:]), 4),
+            "raster_fwd_ms": round(sum(stage[:6]) + sum(stage[8:]), 4), "raster_bwd_ms": round(sum(stage[6:8]), 4),
             "raster_fwd_bwd_ms": round(sum(stage), 4), "icp_track_ms": round(icp_ms / nprof, 4),
             "raster_fwd_bwd_ms_30pct_tiles": round(sum(acc30), 4),
-            "kernels": kernels, "roofline": roofline, "cpu_baseline": cpu,
+            "near_slice": slice_stats, "kernels": kernels, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -30,7 +30,7 @@ size_t bin_block_counts_bytes(int, int);
 int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, uint16_t*, SliceSel,
                      hipStream_t);
 void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,
-                         hipStream_t);
+                         uint32_t, hipStream_t);
 void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const int32_t*, const uint16_t*, uint32_t*,
                         unsigned long long*, SliceSel, hipStream_t);
 void launch_slice_hist(int, const uint8_t*, const uint32_t*, uint32_t*, hipStream_t);
@@ -286,7 +286,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       if (launch_bin_count(p, splats, radii, tile_mask, tile_count1, (uint16_t*)(geom + G.block_counts1), sel1, st) != 0)
         return RTGS_E_HIP;
       launch_bin_tilescan(ntiles, tile_count1, ranges1, (uint32_t*)(geom + G.cursor1), info + 2, nullptr, nullptr,
-                          nullptr, st);
+                          nullptr, 0u, st);
       launch_bin_scatter(p, splats, radii, tile_mask, (const uint16_t*)(geom + G.block_counts1),
                          (uint32_t*)(geom + G.cursor1), (unsigned long long*)(geom + G.bucket1), sel1, st);
       launch_bin_tilesort(ntiles, (uint32_t)SLICE_MAX_LIST, ranges1, (const unsigned long long*)(geom + G.bucket1), list1,
@@ -307,12 +307,29 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       if (launch_bin_count(p, splats, radii, mask_main, tile_count, block_counts, sel2, st) != 0) return RTGS_E_HIP;
       // the totals land in pinned host memory straight from the kernel (one slot per calling thread)
       static thread_local uint32_t* t_info_host = nullptr;
-      if (!t_info_host) HIP_TRY(hipHostMalloc((void**)&t_info_host, 8 * sizeof(uint32_t), hipHostMallocDefault));
+      static thread_local uint32_t t_seq = 0;
+      if (!t_info_host) {
+        HIP_TRY(hipHostMalloc((void**)&t_info_host, 8 * sizeof(uint32_t), hipHostMallocCoherent));
+        memset(t_info_host, 0, 8 * sizeof(uint32_t));
+      }
+      if (++t_seq == 0u) t_seq = 1u;
       launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, t_info_host, sliced ? slice_ctr : nullptr,
-                          sliced ? info + 2 : nullptr, st);
+                          sliced ? info + 2 : nullptr, t_seq, st);
       DBG(s, st);
       prof_mark(EV_SCAN, st);
-      HIP_TRY(hipStreamSynchronize(st));
+      {
+        // Spin on the word the kernel publishes last (system-scope release store into coherent pinned memory): a few
+        // microseconds instead of the ~25 us a blocking hipStreamSynchronize takes to wake up.  Falls back to the
+        // blocking wait if the GPU is far behind (the spin is bounded).
+        volatile uint32_t* flag = t_info_host + 7;
+        bool seen = false;
+        for (long spin = 0; spin < 4000000L; ++spin) {
+          if (*flag == t_seq) { seen = true; break; }
+          __builtin_ia32_pause();
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(st));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      }
       R = (int64_t)t_info_host[0];
       longest = t_info_host[1];
       if (sliced) {

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const ui
                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
                                                             uint32_t* __restrict__ info, uint32_t* __restrict__ info_host,
                                                             const uint32_t* __restrict__ extra_src,
-                                                            const uint32_t* __restrict__ extra_src2) {
+                                                            const uint32_t* __restrict__ extra_src2, uint32_t seq) {
   __shared__ uint32_t s_sum[1024];
   __shared__ uint32_t s_max[1024];
   const int tid = threadIdx.x;
@@ -241,6 +241,8 @@ __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const ui
       info_host[0] = s_sum[1023]; info_host[1] = s_max[1023];
       if (extra_src) { info_host[2] = extra_src[0]; info_host[3] = extra_src[1]; }   // near-slice tile counters
       if (extra_src2) info_host[4] = extra_src2[0];                                  // near-slice instance total
+      // publish: the host spins on this word instead of paying a blocking stream sync's wake-up latency
+      __hip_atomic_store(&info_host[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -431,9 +433,24 @@ __global__ void __launch_bounds__(256) slice_hist_kernel(int P, const uint8_t* _
   __shared__ uint32_t s_h[SLICE_BINS];
   s_h[threadIdx.x] = 0;
   __syncthreads();
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
-    const uint32_t b = zbin[i];
-    if (b != 255u) atomicAdd(&s_h[b], rect_area[i]);
+  // 8 consecutive Gaussians per thread, all three loads in flight at once (the grid-stride form was a chain of
+  // dependent 1-byte loads: 19 us for 6 MB)
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i0 + 8 <= P) {
+    const uint2 zb = *reinterpret_cast<const uint2*>(zbin + i0);
+    const uint4 a0 = *reinterpret_cast<const uint4*>(rect_area + i0);
+    const uint4 a1 = *reinterpret_cast<const uint4*>(rect_area + i0 + 4);
+    const uint32_t ar[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t bsel = ((k < 4 ? zb.x : zb.y) >> (8 * (k & 3))) & 0xffu;
+      if (bsel != 255u && ar[k]) atomicAdd(&s_h[bsel], ar[k]);
+    }
+  } else {
+    for (int i = i0; i < P; ++i) {
+      const uint32_t bsel = zbin[i];
+      if (bsel != 255u) atomicAdd(&s_h[bsel], rect_area[i]);
+    }
   }
   __syncthreads();
   const uint32_t v = s_h[threadIdx.x];
@@ -441,9 +458,7 @@ __global__ void __launch_bounds__(256) slice_hist_kernel(int P, const uint8_t* _
 }
 void launch_slice_hist(int P, const uint8_t* zbin, const uint32_t* rect_area, uint32_t* hist, hipStream_t st) {
   if (P == 0) return;
-  int blocks = (P + 255) / 256;
-  if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(slice_hist_kernel, dim3(blocks), dim3(256), 0, st, P, zbin, rect_area, hist);
+  hipLaunchKernelGGL(slice_hist_kernel, dim3((P + 2047) / 2048), dim3(256), 0, st, P, zbin, rect_area, hist);
 }
 
 int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
@@ -461,9 +476,10 @@ int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* 
   return 0;
 }
 void launch_bin_tilescan(int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* cursor, uint32_t* info,
-                         uint32_t* info_host, const uint32_t* extra_src, const uint32_t* extra_src2, hipStream_t st) {
+                         uint32_t* info_host, const uint32_t* extra_src, const uint32_t* extra_src2, uint32_t seq,
+                         hipStream_t st) {
   hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(1024), 0, st, ntiles, tile_count, ranges, cursor, info,
-                     info_host, extra_src, extra_src2);
+                     info_host, extra_src, extra_src2, seq);
 }
 void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
                         const uint16_t* block_counts, uint32_t* cursor, unsigned long long* bucket, SliceSel sel,

@@ -279,6 +279,218 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// K7' blend_bwd, entry-per-lane form.  The walk above spends most of its instructions reducing 9 partials over
+// the 64 pixels of a wave for every entry.  Here the roles are swapped: a wave still owns a 16x4 pixel strip, but
+// its LANES hold 64 consecutive list entries and it loops over its 64 pixels.  For one pixel
+//   T_i      = T_in * prod_{j<i} (1 - a_j)          -> one inclusive DPP product scan (T_excl = T_incl / (1 - a_i))
+//   S_i . g  = A - Q_in - sum_{j<=i} a_j T_j (c_j . g)  -> one inclusive DPP sum scan of a scalar
+// (A = (C_total . g) + T_final (bg . g)), so two 6-step scans replace the 9-value reduction, and every lane
+// accumulates the 9 partials of ITS entry in registers over the pixel loop.  Per 64-entry chunk the four waves'
+// partials meet in LDS and the tile issues one global atomic per touched (Gaussian, quantity), as before.
+// Contributors are the entries below the pixel's n_contrib that pass the alpha tests - the forward's own rule; T is
+// re-associated by the scan, so it matches the forward to rounding (the walk above matches it bit for bit).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_incl_scan_mul(float v) {
+  v *= dpp_mov<0x111>(1.f, v);              // row_shr:1
+  v *= dpp_mov<0x112>(1.f, v);              // row_shr:2
+  v *= dpp_mov<0x114>(1.f, v);              // row_shr:4
+  v *= dpp_mov<0x118>(1.f, v);              // row_shr:8
+  v *= dpp_mov<0x142, 0xa>(1.f, v);         // row_bcast:15 into rows 1,3
+  v *= dpp_mov<0x143, 0xc>(1.f, v);         // row_bcast:31 into rows 2,3
+  return v;
+}
+__device__ __forceinline__ float wave_incl_scan_add(float v) {
+  v += dpp_mov<0x111>(0.f, v);
+  v += dpp_mov<0x112>(0.f, v);
+  v += dpp_mov<0x114>(0.f, v);
+  v += dpp_mov<0x118>(0.f, v);
+  v += dpp_mov<0x142, 0xa>(0.f, v);
+  v += dpp_mov<0x143, 0xc>(0.f, v);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) blend_bwd_lanes_kernel(
+    RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const Splat* __restrict__ splats, const float* __restrict__ out_color, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const int32_t* __restrict__ depth_index,
+    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+    SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched) {
+  __shared__ float4 s_pg[BLOCK];            // per pixel: g0 g1 g2 A
+  __shared__ float2 s_carry[BLOCK];         // per pixel: T_in, Q_in (prefix over the chunks already walked)
+  __shared__ uint32_t s_last[BLOCK];
+  __shared__ float s_acc[4 * 64 * NG];      // [wave][entry lane][quantity]
+  __shared__ unsigned int s_nmax;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int tile = blockIdx.y * p.gx + blockIdx.x;
+  const uint2 range = ranges[tile];
+  const int n = (int)(range.y - range.x);
+  if (n == 0) return;      // nothing was blended here (or the tile belongs to the other pass of a two-pass forward)
+  const int px = blockIdx.x * TILE + (tid & 15);
+  const int py = blockIdx.y * TILE + (tid >> 4);
+  const bool inside = px < p.W && py < p.H;
+  const float pxf = (float)px, pyf = (float)py;
+  const size_t pix = (size_t)py * p.W + px;
+  const size_t HW = (size_t)p.H * p.W;
+
+  // thread t prepares pixel t of the tile (pixel t belongs to wave t >> 6: rows 4 wv .. 4 wv + 3)
+  const uint32_t last = inside ? n_contrib[pix] : 0u;
+  {
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, A = 0.f;
+    if (inside) {
+      const float Tf = final_T[pix];
+      g0 = dL_dcolor[pix]; g1 = dL_dcolor[HW + pix]; g2 = dL_dcolor[2 * HW + pix];
+      // colour behind the (not yet started) walk, without background, dotted with g; + T_final (bg . g)
+      A = (out_color[pix] - Tf * p.bg[0]) * g0 + (out_color[HW + pix] - Tf * p.bg[1]) * g1 +
+          (out_color[2 * HW + pix] - Tf * p.bg[2]) * g2 + Tf * (p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2);
+    }
+    s_pg[tid] = make_float4(g0, g1, g2, A);
+    s_carry[tid] = make_float2(1.f, 0.f);
+    s_last[tid] = last;
+  }
+  if (tid == 0) s_nmax = 0;
+  __syncthreads();
+  unsigned int wl = last;                   // the wave's own deepest contributor
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) wl = max(wl, (unsigned int)__shfl_xor((int)wl, off));
+  if (lane == 0) atomicMax(&s_nmax, wl);
+  __syncthreads();
+  const int nuse = min(n, (int)s_nmax);
+  const float wave_py0 = (float)(blockIdx.y * TILE + wv * 4);
+  const float tile_px0 = (float)(blockIdx.x * TILE);
+
+  for (int base = 0; base < nuse; base += 64) {
+    const int m = min(64, nuse - base);
+    float acc[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) acc[k] = 0.f;
+    int id = 0;
+    if ((uint32_t)base < wl) {                                    // wave-uniform: some pixel of this wave reaches the chunk
+      // lane i <- entry base + i (lanes >= m idle: opacity 0 fails the alpha test)
+      float eu = 0.f, ev = 0.f, eca = 0.f, ecb = 0.f, ecc = 0.f, eo = 0.f, er = 0.f, eg = 0.f, eb = 0.f;
+      if (lane < m) {
+        id = (int)point_list[range.x + base + lane];
+        const float4* src = reinterpret_cast<const float4*>(splats + id);
+        const float4 a = src[0], b = src[1];
+        eu = a.x; ev = a.y; eca = a.z; ecb = a.w; ecc = b.x; eo = b.y; er = b.z; eg = b.w;
+        eb = reinterpret_cast<const float*>(splats + id)[8];
+      }
+      const uint32_t my_index = (uint32_t)(base + lane);
+      const bool more = base + 64 < nuse;                         // carries are needed only if another chunk follows
+#ifndef EXP_NO_WALK
+      for (int q = 0; q < 64; ++q) {
+        const int pl = wv * 64 + q;                               // pixel of the tile, wave-uniform
+        const uint32_t plast = s_last[pl];
+        if (plast <= (uint32_t)base) continue;                    // pixel stopped before this chunk (or is outside)
+        const float4 pg = s_pg[pl];
+        const float2 carry = s_carry[pl];
+        const float dx = eu - (tile_px0 + (float)(q & 15)), dy = ev - (wave_py0 + (float)(q >> 4));
+        const float power = splat_power(eca, ecb, ecc, dx, dy);
+        const float G = splat_exp(fminf(power, 0.f));
+        const float oG = eo * G;
+        const float alpha = fminf(0.99f, oG);
+        const bool valid = (my_index < plast) && !(power > 0.f) && !(alpha < 1.f / 255.f);
+        const float a = valid ? alpha : 0.f;
+        const float oma = 1.f - a;
+        const float ia = __builtin_amdgcn_rcpf(oma);
+        const float Tincl = carry.x * wave_incl_scan_mul(oma);
+        const float Tk = Tincl * ia;                              // transmittance in front of this entry
+        const float w = a * Tk;
+        const float cg = er * pg.x + eg * pg.y + eb * pg.z;
+        const float Qincl = carry.y + wave_incl_scan_add(w * cg);
+        const float Sg = pg.w - Qincl;                            // (colour strictly behind) . g + T_final (bg . g)
+        const float dL_dalpha = Tk * cg - Sg * ia;
+        const float gda = (valid && oG <= 0.99f) ? G * dL_dalpha : 0.f;   // d min(0.99, oG)/d(oG): autograd of clamp
+        const float gdl = gda * eo;
+        acc[0] += gdl * (-eca * dx - ecb * dy);
+        acc[1] += gdl * (-ecc * dy - ecb * dx);
+        acc[2] += gdl * (-0.5f * dx * dx);
+        acc[3] += gdl * (-dx * dy);
+        acc[4] += gdl * (-0.5f * dy * dy);
+        acc[5] += w * pg.x; acc[6] += w * pg.y; acc[7] += w * pg.z;
+        acc[8] += gda;
+        if (more && lane == 63) s_carry[pl] = make_float2(Tincl, Qincl);
+      }
+#endif
+    }
+    // meet in LDS: one slot per (wave, entry lane, quantity)
+#pragma unroll
+    for (int k = 0; k < NG; ++k) s_acc[(wv * 64 + lane) * NG + k] = acc[k];
+    __syncthreads();
+    if (tid < m) {
+      float t[NG];
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        t[k] = (s_acc[tid * NG + k] + s_acc[(64 + tid) * NG + k]) + (s_acc[(128 + tid) * NG + k] + s_acc[(192 + tid) * NG + k]);
+        any |= (t[k] != 0.f);
+      }
+#ifdef EXP_NO_FLUSH
+      any = false;
+#endif
+      if (any) {
+        // lanes 0..63 of wave 0 hold the ids of this chunk (wave 0 loaded them iff it walked the chunk)
+        const int gid = (int)point_list[range.x + base + tid];
+        touched[gid] = 1;
+        float* dst = reinterpret_cast<float*>(grads + gid);
+        // SplatGrad order: du dv dca dcb dcc dop dr dg db
+        if (t[0] != 0.f) unsafeAtomicAdd(dst + 0, t[0]);
+        if (t[1] != 0.f) unsafeAtomicAdd(dst + 1, t[1]);
+        if (t[2] != 0.f) unsafeAtomicAdd(dst + 2, t[2]);
+        if (t[3] != 0.f) unsafeAtomicAdd(dst + 3, t[3]);
+        if (t[4] != 0.f) unsafeAtomicAdd(dst + 4, t[4]);
+        if (t[8] != 0.f) unsafeAtomicAdd(dst + 5, t[8]);
+        if (t[5] != 0.f) unsafeAtomicAdd(dst + 6, t[5]);
+        if (t[6] != 0.f) unsafeAtomicAdd(dst + 7, t[6]);
+        if (t[7] != 0.f) unsafeAtomicAdd(dst + 8, t[7]);
+      }
+    }
+    __syncthreads();                                              // s_acc is rewritten by the next chunk
+  }
+
+  // opaque-surface depth: D = pd / (n_c . r), owner only (same grouping as blend_bwd_kernel)
+  int owner = -1;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (inside) {
+    owner = depth_index[pix];
+    const float gD = owner >= 0 ? dL_ddepth[pix] : 0.f;
+    if (gD == 0.f) owner = -1;
+    if (owner >= 0) {
+      const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
+      const float pd = reinterpret_cast<const float*>(splats + owner)[12];
+      const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
+      const float den = r2.y * rx + r2.z * ry + r2.w;
+      const float iden = 1.f / den;
+      const float k = -gD * (pd * iden) * iden;
+      a0 = k * rx; a1 = k * ry; a2 = k; a3 = gD * iden;
+    }
+  }
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(owner >= 0);
+#ifdef EXP_NO_OWNER
+  todo = 0;
+#endif
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int o = __builtin_amdgcn_readlane(owner, leader);
+    const bool mine = owner == o;
+    const float s0 = wave_sum_to_lane63(mine ? a0 : 0.f);
+    const float s1 = wave_sum_to_lane63(mine ? a1 : 0.f);
+    const float s2 = wave_sum_to_lane63(mine ? a2 : 0.f);
+    const float s3 = wave_sum_to_lane63(mine ? a3 : 0.f);
+    if (lane == 63) {
+      float* dst = reinterpret_cast<float*>(grads + o);
+      touched[o] = 1;
+      unsafeAtomicAdd(dst + 9, s0);
+      unsafeAtomicAdd(dst + 10, s1);
+      unsafeAtomicAdd(dst + 11, s2);
+      unsafeAtomicAdd(dst + 12, s3);
+    }
+    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K8 preprocess_bwd: one lane per Gaussian; recomputes the forward intermediates from the
 // inputs (cheaper than storing them) and applies the chain rule.
 // ---------------------------------------------------------------------------------------------
@@ -533,6 +745,14 @@ void launch_blend_bwd(const RasterParams& p, const uint2* ranges, const uint32_t
                       const float* out_color, const float* final_T, const uint32_t* n_contrib,
                       const int32_t* depth_index, const float* dL_dcolor, const float* dL_ddepth, SplatGrad* grads,
                       uint8_t* touched, hipStream_t st) {
+  // RTGS_BLEND_BWD=1 selects the entry-per-lane walk (fewer instructions, but its two dependent DPP scans per pixel
+  // make it ~25 % slower on MI355X than the pixel-per-lane walk: 144 vs 116 us on the 1.2 M scene)
+  static const int variant = [] { const char* e = getenv("RTGS_BLEND_BWD"); return e ? atoi(e) : 0; }();
+  if (variant == 1) {
+    hipLaunchKernelGGL(blend_bwd_lanes_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
+                       out_color, final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, grads, touched);
+    return;
+  }
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
                      final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, grads, touched);
 }
