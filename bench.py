@@ -260,6 +260,8 @@ def main():
             "preprocess_bwd": 248 * N + 64 * N + 236 * N,
         }
         if sliced:
+            # geometry-only pre-pass: means + scales + rotations in (40 B), radius x2 + rect area + depth bin + (u, v) out
+            alg["preprocess_fwd"] = (40 + 25) * N
             # second pass: count exits at once when the slice finished every tile (reads the tile counters only)
             R2 = R - slice_stats["instances"]
             alg["bin_count"] = 68 * N if slice_stats["tiles_left_to_pass2"] else 0
@@ -267,7 +269,8 @@ def main():
             alg["bin_tilesort"] = 12 * R2
             # slice: depth bin + rect area per Gaussian (histogram), depth bin per Gaussian twice (count, scatter),
             # 8-B key write + 8-B read + 4-B write per slice instance; the slice's Splat reads are not counted
-            alg["near_slice_binning"] = 5 * N + 2 * N + 20 * slice_stats["instances"]
+            # (work-list compaction, the slice's Splat shading, count, scatter, sort)
+            alg["near_slice_binning"] = 5 * N + N + 20 * slice_stats["instances"]
         if opt.grad_rows is not None:
             # row-state backward: 2 state bytes per Gaussian; only rows that change are read / written
             # (inputs 248 B + SplatGrad 64 B read and 64 B re-zeroed + 236 B of gradient rows, also for rows being cleared)

@@ -28,11 +28,17 @@ size_t bin_lds_limit_tiles();
 int bin_sort_capacity();
 size_t bin_block_counts_bytes(int, int);
 int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, uint16_t*, SliceSel,
-                     hipStream_t);
+                     SliceList, size_t, hipStream_t);
+size_t bin_slice_block_counts_bytes(int, size_t, int);
+void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, hipStream_t);
+void launch_preprocess_cull(const RasterParams&, const float*, const float*, const float*, uint32_t*, int32_t*, int32_t*,
+                            uint32_t*, int, uint8_t*, float2*, hipStream_t);
+void launch_preprocess_shade(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
+                             const float*, Splat*, int32_t*, uint8_t*, float2*, SliceList, SliceSel, size_t, hipStream_t);
 void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,
                          uint32_t, hipStream_t);
 void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const int32_t*, const uint16_t*, uint32_t*,
-                        unsigned long long*, SliceSel, hipStream_t);
+                        unsigned long long*, SliceSel, SliceList, size_t, hipStream_t);
 void launch_slice_hist(int, const uint8_t*, const uint32_t*, uint32_t*, hipStream_t);
 void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*, uint32_t*, hipStream_t);
 
@@ -89,7 +95,7 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy) {
     off = L.tile_count + nt * sizeof(uint32_t);  // (re-lays cursor / info / block_counts behind the zeroed span)
     L.tile_count1 = off; off += nt * sizeof(uint32_t);
     L.ranges1_bwd = off; off += nt * sizeof(uint2);
-    L.slice_hist = off; off += SLICE_BINS * sizeof(uint32_t);
+    L.slice_hist = off; off += 2 * SLICE_BINS * sizeof(uint32_t);
     L.slice_ctr = off; off += 4 * sizeof(uint32_t);
     L.zero_end = off; off = align_up(off);
     L.cursor = off; off = align_up(off + nt * sizeof(uint32_t));
@@ -99,8 +105,12 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy) {
     L.cursor1 = off; off = align_up(off + nt * sizeof(uint32_t));
     L.ranges1 = off; off = align_up(off + nt * sizeof(uint2));
     L.mask2 = off; off = align_up(off + nt * sizeof(int32_t));
-    L.block_counts1 = off; off = align_up(off + bin_block_counts_bytes((int)Pn, gx * gy));
     L.slice_cap = nt * (size_t)(g_slice_budget > 0 ? g_slice_budget : 1);
+    L.slice_max_list = L.slice_cap < 65536 ? L.slice_cap : 65536;   // every listed Gaussian covers >= 1 tile
+    if (L.slice_max_list > Pn) L.slice_max_list = Pn;
+    L.block_counts1 = off; off = align_up(off + bin_slice_block_counts_bytes((int)Pn, L.slice_max_list, gx * gy));
+    L.uv = off; off = align_up(off + Pn * sizeof(float2));
+    L.slice_ids = off; off = align_up(off + L.slice_max_list * sizeof(uint32_t));
     L.bucket1 = off; off = align_up(off + L.slice_cap * sizeof(uint64_t));
     L.list1 = off; off = align_up(off + L.slice_cap * sizeof(uint32_t));
   }
@@ -273,22 +283,34 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
       DBG(s, st);
     }
-    launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sort_path ? sat : nullptr, splats,
-                          tiles_touched, radii, clamped, out_radii, zero_words, zero_n, sliced ? zbin : nullptr, st);
+    const SliceSel sel1{1, zbin, slice_hist, (uint32_t)G.slice_cap, (uint32_t)G.slice_max_list, slice_ctr};
+    if (!sliced) {
+      launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sort_path ? sat : nullptr, splats,
+                            tiles_touched, radii, clamped, out_radii, zero_words, zero_n, nullptr, st);
+    } else {
+      // geometry of every Gaussian now, Splat records only where a list will read them
+      launch_preprocess_cull(p, means3D, scales, rotations, tiles_touched, radii, out_radii, zero_words, zero_n, zbin,
+                             (float2*)(geom + G.uv), st);
+    }
     DBG(s, st);
     prof_mark(EV_PRE, st);
     if (sliced) {
       // Pass 1: bin, sort and blend only the nearest Gaussians (as many depth bins as fit the instance budget).  Tiles
       // whose every pixel saturates inside the slice are final; blend_fwd leaves a tile mask of the others.  No host
       // sync: the arrays are sized by the budget, the sort classes are launched blind.
-      const SliceSel sel1{1, zbin, slice_hist, (uint32_t)G.slice_cap, slice_ctr};
+      const SliceList work{(const uint32_t*)(geom + G.slice_ids), slice_ctr + 2};
       launch_slice_hist(P, zbin, tiles_touched, slice_hist, st);
-      if (launch_bin_count(p, splats, radii, tile_mask, tile_count1, (uint16_t*)(geom + G.block_counts1), sel1, st) != 0)
+      launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, st);
+      launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
+                              (float2*)(geom + G.uv), work, sel1, G.slice_max_list, st);
+      if (launch_bin_count(p, splats, radii, tile_mask, tile_count1, (uint16_t*)(geom + G.block_counts1), sel1, work,
+                           G.slice_max_list, st) != 0)
         return RTGS_E_HIP;
       launch_bin_tilescan(ntiles, tile_count1, ranges1, (uint32_t*)(geom + G.cursor1), info + 2, nullptr, nullptr,
                           nullptr, 0u, st);
       launch_bin_scatter(p, splats, radii, tile_mask, (const uint16_t*)(geom + G.block_counts1),
-                         (uint32_t*)(geom + G.cursor1), (unsigned long long*)(geom + G.bucket1), sel1, st);
+                         (uint32_t*)(geom + G.cursor1), (unsigned long long*)(geom + G.bucket1), sel1, work,
+                         G.slice_max_list, st);
       launch_bin_tilesort(ntiles, (uint32_t)SLICE_MAX_LIST, ranges1, (const unsigned long long*)(geom + G.bucket1), list1,
                           st);
       DBG(s, st);
@@ -300,11 +322,15 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       prof_mark(EV_SL_BLEND, st);
       mask_main = mask2;
       pass = SlicePass{2, nullptr, mask2, nullptr, nullptr};
+      // pass 2 bins against the whole map: shade everything the slice did not (a no-op when no tile is left)
+      launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
+                              (float2*)(geom + G.uv), SliceList{nullptr, nullptr}, sel1, 0, st);
     }
     if (!sort_path) {
       // exact per-tile counts -> ranges; the one host sync of the forward sizes the instance arrays
-      const SliceSel sel2{sliced ? 2 : 0, nullptr, nullptr, 0u, slice_ctr};
-      if (launch_bin_count(p, splats, radii, mask_main, tile_count, block_counts, sel2, st) != 0) return RTGS_E_HIP;
+      const SliceSel sel2{sliced ? 2 : 0, nullptr, nullptr, 0u, 0u, slice_ctr};
+      if (launch_bin_count(p, splats, radii, mask_main, tile_count, block_counts, sel2, SliceList{nullptr, nullptr}, 0, st) != 0)
+        return RTGS_E_HIP;
       // the totals land in pinned host memory straight from the kernel (one slot per calling thread)
       static thread_local uint32_t* t_info_host = nullptr;
       static thread_local uint32_t t_seq = 0;
@@ -376,7 +402,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   if (R > 0 && !sort_path) {
     prof_mark(EV_BIN0, st);
     launch_bin_scatter(p, splats, radii, mask_main, block_counts, cursor, (unsigned long long*)keys_a,
-                       SliceSel{sliced ? 2 : 0, nullptr, nullptr, 0u, slice_ctr}, st);
+                       SliceSel{sliced ? 2 : 0, nullptr, nullptr, 0u, 0u, slice_ctr}, SliceList{nullptr, nullptr}, 0, st);
     DBG(s, st);
     prof_mark(EV_EMIT, st);
     launch_bin_tilesort(ntiles, longest, ranges, (const unsigned long long*)keys_a, vals_b, st);

@@ -21,6 +21,8 @@
 namespace rtgs {
 
 constexpr int GPB = 1024;       // Gaussians per workgroup in bin_count / bin_scatter
+constexpr int SLICE_GPB = 32;   // ... when they walk the near slice's short work list: 8 Gaussians per wave (each covers
+                                // tens of tiles, the candidates are spread over all 64 lanes), many workgroups
 
 struct BinG {
   float u, v, ca, cb, cc, thr;  // thr = 2 ln(255 o) with margin; < 0 -> never visible
@@ -109,34 +111,23 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
   return v;
 }
 
-// Cut bin of the near slice, recomputed by every workgroup from the 256-bin histogram (BLOCK threads, one bin each).
-__device__ __forceinline__ int slice_cut(const SliceSel& sel) {
-  __shared__ uint32_t s_wsum[BLOCK / 64];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const uint32_t h = sel.hist[tid];
-  uint32_t incl = h;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
-    if (lane >= off) incl += o;
-  }
-  if (lane == 63) s_wsum[w] = incl;
-  __syncthreads();
-  unsigned long long cum = incl;
-  for (int k = 0; k < w; ++k) cum += s_wsum[k];
-  const int n_ok = __syncthreads_count(cum <= (unsigned long long)sel.cap);    // cum is monotone: a prefix of bins fits
-  return n_ok - 1;
-}
-
 template <class F>
 __device__ __forceinline__ void enumerate_balanced(const RasterParams& p, const Splat* __restrict__ splats,
                                                    const int32_t* __restrict__ radii, const int32_t* __restrict__ mask,
-                                                   const uint8_t* __restrict__ zbin, int cut, WaveBin* wb, F f) {
+                                                   const uint8_t* __restrict__ zbin, int cut, SliceList list, int gpb,
+                                                   WaveBin* wb, F f) {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const unsigned long long le_mask = lt_mask | (1ull << lane);
-  for (int k = 0; k < GPB / BLOCK; ++k) {
-    const int i = blockIdx.x * GPB + k * BLOCK + (int)threadIdx.x;
+  const int n_list = list.ids ? (int)*list.count : 0;
+  const int iters = list.ids ? 1 : gpb / BLOCK;
+  for (int k = 0; k < iters; ++k) {
+    int i = blockIdx.x * gpb + k * BLOCK + (int)threadIdx.x;
+    if (list.ids) {               // slice work list (already filtered by depth bin): gpb / 4 consecutive ids per wave
+      const int per_wave = gpb / (BLOCK / 64);
+      const int j = blockIdx.x * gpb + (int)(threadIdx.x >> 6) * per_wave + lane;
+      i = (lane < per_wave && j < n_list) ? (int)list.ids[j] : p.P;
+    }
     BinG g;
     const bool live = load_bing(p, splats, radii, zbin, cut, i, g);
     const int w = g.x1 - g.x0;
@@ -185,15 +176,16 @@ __global__ void __launch_bounds__(256) bin_count_kernel(RasterParams p, const Sp
                                                         const int32_t* __restrict__ radii,
                                                         const int32_t* __restrict__ mask,
                                                         uint32_t* __restrict__ tile_count,
-                                                        uint16_t* __restrict__ block_counts, SliceSel sel) {
+                                                        uint16_t* __restrict__ block_counts, SliceSel sel, SliceList list,
+                                                        int gpb) {
   extern __shared__ uint32_t s_cnt[];
   __shared__ WaveBin s_wb[BLOCK / 64];
   const int ntiles = p.gx * p.gy;
   if (sel.mode == 2 && sel.ctr[0] == 0u) return;     // the near slice finished every tile: nothing left to bin
-  const int cut = sel.mode == 1 ? slice_cut(sel) : 0;
+  if (list.ids && blockIdx.x * gpb >= (int)*list.count) return;     // past the end of the slice work list
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
   __syncthreads();
-  enumerate_balanced(p, splats, radii, mask, sel.mode == 1 ? sel.zbin : nullptr, cut, &s_wb[threadIdx.x >> 6],
+  enumerate_balanced(p, splats, radii, mask, nullptr, 0, list, gpb, &s_wb[threadIdx.x >> 6],
                      [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
   __syncthreads();
   // the workgroup's row of per-tile counts is kept for bin_scatter (same Gaussian -> workgroup mapping),
@@ -256,11 +248,12 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(RasterParams p, const 
                                                           const int32_t* __restrict__ mask,
                                                           const uint16_t* __restrict__ block_counts,
                                                           uint32_t* __restrict__ cursor,
-                                                          unsigned long long* __restrict__ bucket, SliceSel sel) {
+                                                          unsigned long long* __restrict__ bucket, SliceSel sel,
+                                                          SliceList list, int gpb) {
   extern __shared__ uint32_t s_mem[];
   __shared__ WaveBin s_wb[BLOCK / 64];
   const int ntiles = p.gx * p.gy;
-  const int cut = sel.mode == 1 ? slice_cut(sel) : 0;
+  if (list.ids && blockIdx.x * gpb >= (int)*list.count) return;
   uint32_t* s_cnt = s_mem;
   uint32_t* s_base = s_mem + ntiles;
   const uint16_t* row = block_counts + (size_t)blockIdx.x * ntiles;
@@ -270,7 +263,7 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(RasterParams p, const 
     s_cnt[t] = 0;
   }
   __syncthreads();
-  enumerate_balanced(p, splats, radii, mask, sel.mode == 1 ? sel.zbin : nullptr, cut, &s_wb[threadIdx.x >> 6],
+  enumerate_balanced(p, splats, radii, mask, nullptr, 0, list, gpb, &s_wb[threadIdx.x >> 6],
                      [&](int t, uint32_t id, uint32_t zbits) {
     const uint32_t base = s_base[t];
     if (base != 0xffffffffu) {
@@ -425,17 +418,22 @@ int bin_sort_capacity() { return 16384; }            // 16384 x 8 B = 128 KiB
 size_t bin_block_counts_bytes(int P, int ntiles) {
   return (size_t)((P + GPB - 1) / GPB) * (size_t)ntiles * sizeof(uint16_t);
 }
+// rows of the slice pass: the work list holds at most slice_cap / 1 Gaussians, but never more than P
+size_t bin_slice_block_counts_bytes(int P, size_t max_list, int ntiles) {
+  const size_t n = max_list < (size_t)P ? max_list : (size_t)P;
+  return ((n + SLICE_GPB - 1) / SLICE_GPB) * (size_t)ntiles * sizeof(uint16_t);
+}
 
 // area-weighted depth histogram of the visible Gaussians (input of slice_cut)
 __global__ void __launch_bounds__(256) slice_hist_kernel(int P, const uint8_t* __restrict__ zbin,
                                                          const uint32_t* __restrict__ rect_area,
                                                          uint32_t* __restrict__ hist) {
-  __shared__ uint32_t s_h[SLICE_BINS];
-  s_h[threadIdx.x] = 0;
+  __shared__ uint32_t s_h[SLICE_BINS], s_c[SLICE_BINS];
+  s_h[threadIdx.x] = 0; s_c[threadIdx.x] = 0;
   __syncthreads();
   // 8 consecutive Gaussians per thread, all three loads in flight at once (the grid-stride form was a chain of
   // dependent 1-byte loads: 19 us for 6 MB)
-  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+  for (int i0 = (blockIdx.x * 256 + threadIdx.x) * 8; i0 < P; i0 += gridDim.x * 2048)
   if (i0 + 8 <= P) {
     const uint2 zb = *reinterpret_cast<const uint2*>(zbin + i0);
     const uint4 a0 = *reinterpret_cast<const uint4*>(rect_area + i0);
@@ -444,25 +442,71 @@ __global__ void __launch_bounds__(256) slice_hist_kernel(int P, const uint8_t* _
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const uint32_t bsel = ((k < 4 ? zb.x : zb.y) >> (8 * (k & 3))) & 0xffu;
-      if (bsel != 255u && ar[k]) atomicAdd(&s_h[bsel], ar[k]);
+      if (bsel != 255u) { atomicAdd(&s_h[bsel], ar[k]); atomicAdd(&s_c[bsel], 1u); }
     }
   } else {
     for (int i = i0; i < P; ++i) {
       const uint32_t bsel = zbin[i];
-      if (bsel != 255u) atomicAdd(&s_h[bsel], rect_area[i]);
+      if (bsel != 255u) { atomicAdd(&s_h[bsel], rect_area[i]); atomicAdd(&s_c[bsel], 1u); }
     }
   }
   __syncthreads();
-  const uint32_t v = s_h[threadIdx.x];
-  if (v) atomicAdd(&hist[threadIdx.x], v);
+  const uint32_t v = s_h[threadIdx.x], n = s_c[threadIdx.x];
+  if (n) { atomicAdd(&hist[threadIdx.x], v); atomicAdd(&hist[SLICE_BINS + threadIdx.x], n); }
 }
 void launch_slice_hist(int P, const uint8_t* zbin, const uint32_t* rect_area, uint32_t* hist, hipStream_t st) {
   if (P == 0) return;
-  hipLaunchKernelGGL(slice_hist_kernel, dim3((P + 2047) / 2048), dim3(256), 0, st, P, zbin, rect_area, hist);
+  int blocks = (P + 2047) / 2048;       // few workgroups: each ends with up to 256 same-address global atomics
+  if (blocks > 128) blocks = 128;
+  hipLaunchKernelGGL(slice_hist_kernel, dim3(blocks), dim3(256), 0, st, P, zbin, rect_area, hist);
+}
+
+// ids of the Gaussians in the near slice (depth bin <= cut), in arbitrary order (the tile sort orders by (depth, id));
+// count in *n_list.  Each workgroup stages the ids of its contiguous chunk in LDS and reserves its output range with
+// ONE global atomic (one atomic per wave serialised on a single address: 225 us for 1.2 M Gaussians).
+constexpr int COMPACT_CHUNK = 8192;
+__global__ void __launch_bounds__(256) slice_compact_kernel(int P, SliceSel sel, uint32_t* __restrict__ ids,
+                                                            uint32_t* __restrict__ n_list) {
+  __shared__ uint32_t s_ids[COMPACT_CHUNK];
+  __shared__ uint32_t s_n, s_base;
+  const int cut = slice_cut(sel);
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int begin = blockIdx.x * COMPACT_CHUNK;
+  for (int i0 = begin; i0 < begin + COMPACT_CHUNK && i0 < P; i0 += 256 * 4) {
+    const int i = i0 + (int)threadIdx.x * 4;
+    uint32_t zb4 = 0xffffffffu;
+    if (i + 4 <= P) zb4 = *reinterpret_cast<const uint32_t*>(sel.zbin + i);
+    else for (int k = 0; k < 4; ++k) if (i + k < P) zb4 = (zb4 & ~(0xffu << (8 * k))) | ((uint32_t)sel.zbin[i + k] << (8 * k));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int zb = (int)((zb4 >> (8 * k)) & 0xffu);
+      const bool in = zb != 255 && zb <= cut;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+      if (m == 0ull) continue;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (in) s_ids[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(i + k);
+    }
+  }
+  __syncthreads();
+  const uint32_t n = s_n;
+  if (n == 0u) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(n_list, n);
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n; k += 256) ids[s_base + k] = s_ids[k];
+}
+void launch_slice_compact(int P, SliceSel sel, uint32_t* ids, uint32_t* n_list, hipStream_t st) {
+  if (P == 0) return;
+  hipLaunchKernelGGL(slice_compact_kernel, dim3((P + COMPACT_CHUNK - 1) / COMPACT_CHUNK), dim3(256), 0, st, P, sel, ids,
+                     n_list);
 }
 
 int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
-                     uint32_t* tile_count, uint16_t* block_counts, SliceSel sel, hipStream_t st) {
+                     uint32_t* tile_count, uint16_t* block_counts, SliceSel sel, SliceList list, size_t max_items,
+                     hipStream_t st) {
   const int ntiles = p.gx * p.gy;      // tile_count was cleared by preprocess_fwd
   if (p.P == 0) return 0;
   const size_t lds = (size_t)ntiles * sizeof(uint32_t);
@@ -471,8 +515,10 @@ int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* 
     (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     granted = lds;
   }
-  hipLaunchKernelGGL(bin_count_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii, mask,
-                     tile_count, block_counts, sel);
+  const int gpb = list.ids ? SLICE_GPB : GPB;       // the slice list is short: small work items, many workgroups
+  const size_t n = list.ids && max_items < (size_t)p.P ? max_items : (size_t)p.P;
+  hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)((n + gpb - 1) / gpb)), dim3(BLOCK), lds, st, p, splats, radii, mask,
+                     tile_count, block_counts, sel, list, gpb);
   return 0;
 }
 void launch_bin_tilescan(int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* cursor, uint32_t* info,
@@ -483,7 +529,7 @@ void launch_bin_tilescan(int ntiles, const uint32_t* tile_count, uint2* ranges, 
 }
 void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
                         const uint16_t* block_counts, uint32_t* cursor, unsigned long long* bucket, SliceSel sel,
-                        hipStream_t st) {
+                        SliceList list, size_t max_items, hipStream_t st) {
   if (p.P == 0) return;
   const int ntiles = p.gx * p.gy;
   const size_t lds = 2 * (size_t)ntiles * sizeof(uint32_t);
@@ -492,8 +538,10 @@ void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_
     (void)hipFuncSetAttribute((const void*)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     granted = lds;
   }
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3((p.P + GPB - 1) / GPB), dim3(BLOCK), lds, st, p, splats, radii, mask,
-                     block_counts, cursor, bucket, sel);
+  const int gpb = list.ids ? SLICE_GPB : GPB;
+  const size_t n = list.ids && max_items < (size_t)p.P ? max_items : (size_t)p.P;
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)((n + gpb - 1) / gpb)), dim3(BLOCK), lds, st, p, splats, radii,
+                     mask, block_counts, cursor, bucket, sel, list, gpb);
 }
 template <int THREADS>
 static void launch_radix(int ntiles, const uint2* ranges, const unsigned long long* bucket, uint32_t* point_list, int lo,

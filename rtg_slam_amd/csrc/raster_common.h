@@ -55,8 +55,8 @@ struct GeomLayout {
   // near-slice pass (raster_api.hip): [zero_begin, zero_end) is cleared by preprocess_fwd on every call
   size_t zero_begin, zero_end;
   size_t tile_count1, ranges1_bwd, slice_hist, slice_ctr;           // inside the zeroed span (tile_count is too)
-  size_t zbin, cursor1, ranges1, mask2, block_counts1, bucket1, list1;
-  size_t slice_cap;                                                  // instance capacity of bucket1 / list1
+  size_t zbin, cursor1, ranges1, mask2, block_counts1, bucket1, list1, uv, slice_ids;
+  size_t slice_cap, slice_max_list;                                  // capacity of bucket1 / list1; of the work list
 };
 
 // Near-slice selection: a Gaussian belongs to the slice iff its depth bin (monotone in the f32 depth bits, 32 bins
@@ -67,8 +67,9 @@ constexpr int SLICE_MAX_LIST = 3072;        // longest near-slice tile list that
 struct SliceSel {
   int mode;                      // 0 = every Gaussian; 1 = near slice only; 2 = every Gaussian, exit if no tile is unfinished
   const uint8_t* zbin;           // [P] depth bin, 255 = not visible
-  const uint32_t* hist;          // [SLICE_BINS] rect-instance count per bin
-  uint32_t cap;
+  const uint32_t* hist;          // [2 * SLICE_BINS]: rect-instance count per bin, then Gaussian count per bin
+  uint32_t cap;                  // instance budget of the slice
+  uint32_t max_list;             // Gaussian budget of the slice (length of the work list)
   const uint32_t* ctr;           // ctr[0] = tiles the near slice left unfinished
 };
 // blend_fwd role in the two-pass forward
@@ -78,6 +79,12 @@ struct SlicePass {
   int32_t* mask2;                // mode 1: written; mode 2: read
   uint2* ranges_bwd;             // mode 1: range of a finished tile, (0,0) otherwise - what blend_bwd walks
   uint32_t* ctr;                 // mode 1: ctr[0] += unfinished (unmasked) tiles, ctr[1] += finished tiles
+};
+// Shading work list of the two-pass forward (preprocess_fwd_kernel<2>, bin_count / bin_scatter in slice mode):
+// the near slice's Gaussian ids, appended in arbitrary order by slice_compact_kernel.
+struct SliceList {
+  const uint32_t* ids;           // nullptr = no list (every Gaussian, by index)
+  const uint32_t* count;         // device word: number of ids
 };
 __device__ __forceinline__ uint32_t slice_bin_of(float z) {
   const int b = (int)(__float_as_uint(z) >> 18) - (int)(0x3E4CCCCDu >> 18);     // 0.2f
@@ -120,6 +127,26 @@ __device__ __forceinline__ float splat_power(float ca, float cb, float cc, float
 // both take identical skip decisions.
 __device__ __forceinline__ float splat_exp(float x) {
   return __builtin_amdgcn_exp2f(__fmul_rn(x, 1.4426950408889634f));
+}
+
+// Cut bin of the near slice, recomputed by every workgroup from the 256-bin histogram (needs BLOCK = 256 threads, one
+// bin each, all of them calling): the largest bin whose cumulative instance count still fits sel.cap.
+__device__ __forceinline__ int slice_cut(const SliceSel& sel) {
+  __shared__ uint32_t s_wsum[2][BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  uint32_t incl = sel.hist[tid], incl_n = sel.hist[SLICE_BINS + tid];
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, off), on = (uint32_t)__shfl_up((int)incl_n, off);
+    if (lane >= off) { incl += o; incl_n += on; }
+  }
+  if (lane == 63) { s_wsum[0][w] = incl; s_wsum[1][w] = incl_n; }
+  __syncthreads();
+  unsigned long long cum = incl, cum_n = incl_n;
+  for (int k = 0; k < w; ++k) { cum += s_wsum[0][k]; cum_n += s_wsum[1][k]; }
+  // both sums are monotone in the bin index: a prefix of bins fits the two budgets
+  const int n_ok = __syncthreads_count(cum <= (unsigned long long)sel.cap && cum_n <= (unsigned long long)sel.max_list);
+  return n_ok - 1;
 }
 
 }  // namespace rtgs

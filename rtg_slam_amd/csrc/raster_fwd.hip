@@ -45,21 +45,44 @@ __device__ __forceinline__ void tile_rect(float u, float v, int radius, int gx, 
 // K1 preprocess_fwd: one lane per Gaussian.  Reads 62 floats (248 B), writes one 64-B Splat +
 // radius + tiles_touched + clamp flags.
 // ---------------------------------------------------------------------------------------------
+// MODE 0: everything for every Gaussian (single-pass forward).
+// MODE 1: geometry only - depth cull, radius, tile rect, depth bin, (u, v) - for every Gaussian: 52 B read and
+//         21 B written per Gaussian instead of 248 B + 77 B.  The two-pass forward shades lazily:
+// MODE 2: the rest (conic, SH colour, plane, the 64-B Splat) for the Gaussians of a work list (the near slice),
+//         or - list.ids == nullptr - for every visible Gaussian NOT in the slice, and only if the slice left tiles
+//         unfinished.  (u, v) and the radius are taken from MODE 1 so that every kernel derives the same tile rect.
+template <int MODE>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     RasterParams p, const float* __restrict__ means, const float* __restrict__ opac,
     const float* __restrict__ shs, const float* __restrict__ scales, const float* __restrict__ rots,
     const float* __restrict__ normal_w, const int32_t* __restrict__ sat,
     Splat* __restrict__ splats, uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii,
     uint8_t* __restrict__ clamped, int32_t* __restrict__ out_radii, uint32_t* __restrict__ zero_words, int zero_n,
-    uint8_t* __restrict__ zbin) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  // clears the per-tile counters bin_count accumulates into (saves a memset launch on the critical path)
-  for (int t = i; t < zero_n; t += gridDim.x * blockDim.x) zero_words[t] = 0u;
-  if (i >= p.P) return;
-  tiles_touched[i] = 0;
-  radii[i] = 0;
-  if (out_radii) out_radii[i] = 0;
-  if (zbin) zbin[i] = 255;
+    uint8_t* __restrict__ zbin, float2* __restrict__ uv, SliceList list, SliceSel sel) {
+  // no automatic FMA contraction: the three instantiations must round identically (the two-pass forward is tested
+  // bit for bit against the single pass)
+#pragma clang fp contract(off)
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if constexpr (MODE != 2) {
+    // clears the per-tile counters bin_count accumulates into (saves a memset launch on the critical path)
+    for (int t = i; t < zero_n; t += gridDim.x * blockDim.x) zero_words[t] = 0u;
+    if (i >= p.P) return;
+    tiles_touched[i] = 0;
+    radii[i] = 0;
+    if (out_radii) out_radii[i] = 0;
+    if (zbin) zbin[i] = 255;
+  } else {
+    if (list.ids) {
+      if (i >= (int)*list.count) return;
+      i = (int)list.ids[i];
+    } else {
+      if (sel.ctr[0] == 0u) return;              // the slice finished every tile: nobody will read the other Splats
+      const int cut = slice_cut(sel);            // (all 256 threads of the workgroup call)
+      if (i >= p.P) return;
+      const int zb = (int)sel.zbin[i];
+      if (zb == 255 || zb <= cut) return;        // invisible, or shaded with the slice already
+    }
+  }
 
   const float* V = p.view;   // V[j*4+i] = W2C[i][j]
   const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
@@ -111,15 +134,29 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   const float idet = 1.f / det;
   const float mid = 0.5f * (ca + cc);
   const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-  const int radius = (int)ceilf(p.color_sigma * sqrtf(lam));
-  const float u = p.fx * pcx / pcz + p.cx;
-  const float v = p.fy * pcy / pcz + p.cy;
-  int x0, y0, x1, y1;
-  tile_rect(u, v, radius, p.gx, p.gy, x0, y0, x1, y1);
-  if ((x1 - x0) * (y1 - y0) == 0) return;
-  const int sw = p.gx + 1;
-  const int touched = sat ? sat[y1 * sw + x1] - sat[y0 * sw + x1] - sat[y1 * sw + x0] + sat[y0 * sw + x0]
-                          : (x1 - x0) * (y1 - y0);   // LDS binning path recounts exactly; this is a bound
+  int radius = (int)ceilf(p.color_sigma * sqrtf(lam));
+  float u = p.fx * pcx / pcz + p.cx;
+  float v = p.fy * pcy / pcz + p.cy;
+  int touched = 0;
+  if constexpr (MODE == 2) {
+    const float2 t = uv[i];
+    u = t.x; v = t.y; radius = radii[i];
+  } else {
+    int x0, y0, x1, y1;
+    tile_rect(u, v, radius, p.gx, p.gy, x0, y0, x1, y1);
+    if ((x1 - x0) * (y1 - y0) == 0) return;
+    const int sw = p.gx + 1;
+    touched = sat ? sat[y1 * sw + x1] - sat[y0 * sw + x1] - sat[y1 * sw + x0] + sat[y0 * sw + x0]
+                  : (x1 - x0) * (y1 - y0);   // LDS binning path recounts exactly; this is a bound
+  }
+  if constexpr (MODE == 1) {
+    radii[i] = radius;
+    if (out_radii) out_radii[i] = radius;
+    tiles_touched[i] = (uint32_t)touched;
+    zbin[i] = (uint8_t)slice_bin_of(pcz);
+    uv[i] = make_float2(u, v);
+    return;
+  }
 
   // view-dependent colour (utils/sh_utils.py:57-120 basis), clamped at 0
   float dxw = mx - p.campos[0], dyw = my - p.campos[1], dzw = mz - p.campos[2];
@@ -194,10 +231,12 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   const float4* src = reinterpret_cast<const float4*>(&s);
   dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
   clamped[i] = cl;
-  radii[i] = radius;
-  if (out_radii) out_radii[i] = radius;
-  tiles_touched[i] = (uint32_t)touched;
-  if (zbin) zbin[i] = (uint8_t)slice_bin_of(pcz);
+  if constexpr (MODE == 0) {
+    radii[i] = radius;
+    if (out_radii) out_radii[i] = radius;
+    tiles_touched[i] = (uint32_t)touched;
+    if (zbin) zbin[i] = (uint8_t)slice_bin_of(pcz);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -558,8 +597,30 @@ void launch_preprocess_fwd(const RasterParams& p, const float* means, const floa
                            Splat* splats, uint32_t* tiles_touched, int32_t* radii, uint8_t* clamped,
                            int32_t* out_radii, uint32_t* zero_words, int zero_n, uint8_t* zbin, hipStream_t st) {
   if (p.P == 0) return;
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, opac, shs, scales,
-                     rots, normal_w, sat, splats, tiles_touched, radii, clamped, out_radii, zero_words, zero_n, zbin);
+  hipLaunchKernelGGL(preprocess_fwd_kernel<0>, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, opac, shs, scales,
+                     rots, normal_w, sat, splats, tiles_touched, radii, clamped, out_radii, zero_words, zero_n, zbin,
+                     (float2*)nullptr, SliceList{nullptr, nullptr}, SliceSel{0, nullptr, nullptr, 0u, 0u, nullptr});
+}
+// two-pass forward, stage 1: geometry of every Gaussian
+void launch_preprocess_cull(const RasterParams& p, const float* means, const float* scales, const float* rots,
+                            uint32_t* tiles_touched, int32_t* radii, int32_t* out_radii, uint32_t* zero_words, int zero_n,
+                            uint8_t* zbin, float2* uv, hipStream_t st) {
+  if (p.P == 0) return;
+  hipLaunchKernelGGL(preprocess_fwd_kernel<1>, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, (const float*)nullptr,
+                     (const float*)nullptr, scales, rots, (const float*)nullptr, (const int32_t*)nullptr, (Splat*)nullptr,
+                     tiles_touched, radii, (uint8_t*)nullptr, out_radii, zero_words, zero_n, zbin, uv,
+                     SliceList{nullptr, nullptr}, SliceSel{0, nullptr, nullptr, 0u, 0u, nullptr});
+}
+// two-pass forward, stage 2: Splat records of the work list (max_items bounds its length), or of everything else
+void launch_preprocess_shade(const RasterParams& p, const float* means, const float* opac, const float* shs,
+                             const float* scales, const float* rots, const float* normal_w, Splat* splats,
+                             int32_t* radii, uint8_t* clamped, float2* uv, SliceList list, SliceSel sel, size_t max_items,
+                             hipStream_t st) {
+  if (p.P == 0) return;
+  const size_t n = list.ids ? (max_items < (size_t)p.P ? max_items : (size_t)p.P) : (size_t)p.P;
+  hipLaunchKernelGGL(preprocess_fwd_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, means, opac, shs,
+                     scales, rots, normal_w, (const int32_t*)nullptr, splats, (uint32_t*)nullptr, radii, clamped,
+                     (int32_t*)nullptr, (uint32_t*)nullptr, 0, (uint8_t*)nullptr, uv, list, sel);
 }
 void launch_emit_keys(const RasterParams& p, const Splat* splats, const int32_t* radii, const uint32_t* offsets,
                       const int32_t* mask, uint64_t* keys, uint32_t* vals, hipStream_t st) {
