@@ -202,7 +202,10 @@ extern "C" int rtgs_slam_loss(const float* color, const float* depth, const int3
   if (hipMemsetAsync(sums3_scratch, 0, 3 * sizeof(float), st) != hipSuccess) return -2;
   int64_t blocks = (hw + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(rtgs::slam_loss_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, color, depth, depth_index,
+  // the sums kernel ends with three same-address global atomics per workgroup (~20 ns each, serialised): keep it to
+  // 192 workgroups (1 024 of them cost 20 us for a 23 MB read)
+  const int64_t sum_blocks = blocks > 192 ? 192 : blocks;
+  hipLaunchKernelGGL(rtgs::slam_loss_sums_kernel, dim3((unsigned)sum_blocks), dim3(256), 0, st, color, depth, depth_index,
                      gt_color, gt_depth, hw, sums3_scratch);
   hipLaunchKernelGGL(rtgs::slam_loss_grads_kernel, dim3((unsigned)blocks), dim3(256), 0, st, color, depth, depth_index,
                      gt_color, gt_depth, hw, color_weight, depth_weight, (const float*)sums3_scratch, loss_out, g_color,

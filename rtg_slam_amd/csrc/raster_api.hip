@@ -31,6 +31,7 @@ int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const in
                      SliceList, size_t, hipStream_t);
 size_t bin_slice_block_counts_bytes(int, size_t, int);
 void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, hipStream_t);
+void launch_slice_publish(int, const int32_t*, const int32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, hipStream_t);
 void launch_preprocess_cull(const RasterParams&, const float*, const float*, const float*, uint32_t*, int32_t*, int32_t*,
                             uint32_t*, int, uint8_t*, float2*, hipStream_t);
 void launch_preprocess_shade(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
@@ -275,6 +276,25 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
                 (g_slice_mode == 1 || (g_slice_mode == 2 && P >= 100000 && ntiles >= 256 && g_slice_cooldown == 0));
   if (g_slice_mode == 2 && g_slice_cooldown > 0) --g_slice_cooldown;
   SlicePass pass{0, nullptr, nullptr, nullptr, nullptr};
+  // pinned host words the kernels publish totals into (one slot per calling thread), and the spin that waits for them:
+  // a few microseconds instead of the ~25 us a blocking hipStreamSynchronize takes to wake up (bounded; falls back)
+  static thread_local uint32_t* t_info_host = nullptr;
+  static thread_local uint32_t t_seq = 0;
+  if (!t_info_host) {
+    HIP_TRY(hipHostMalloc((void**)&t_info_host, 8 * sizeof(uint32_t), hipHostMallocCoherent));
+    memset(t_info_host, 0, 8 * sizeof(uint32_t));
+  }
+  auto wait_published = [&](uint32_t seq) -> int {
+    volatile uint32_t* flag = t_info_host + 7;
+    bool seen = false;
+    for (long spin = 0; spin < 4000000L; ++spin) {
+      if (*flag == seq) { seen = true; break; }
+      __builtin_ia32_pause();
+    }
+    if (!seen) HIP_TRY(hipStreamSynchronize(st));
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return RTGS_OK;
+  };
   const int32_t* mask_main = tile_mask;        // tile mask of the pass that ends in the host sync
   uint32_t n_left = 0, n_fin = 0;
   if (P == 0) HIP_TRY(hipMemsetAsync(zero_words, 0, (size_t)zero_n * sizeof(uint32_t), st));   // ranges1_bwd for the backward
@@ -315,54 +335,38 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
                           st);
       DBG(s, st);
       prof_mark(EV_SL_BIN, st);
-      const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, slice_ctr};
+      if (++t_seq == 0u) t_seq = 1u;
+      const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
       launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
                        n_contrib, g_counters, pass1, st);
+      launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, t_info_host, t_seq, st);
       DBG(s, st);
       prof_mark(EV_SL_BLEND, st);
-      mask_main = mask2;
-      pass = SlicePass{2, nullptr, mask2, nullptr, nullptr};
-      // pass 2 bins against the whole map: shade everything the slice did not (a no-op when no tile is left)
-      launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
-                              (float2*)(geom + G.uv), SliceList{nullptr, nullptr}, sel1, 0, st);
+      // the forward's host sync: the last tile of the slice publishes how many tiles are left
+      if ((rc = wait_published(t_seq)) != RTGS_OK) return rc;
+      n_left = t_info_host[2]; n_fin = t_info_host[3];
+      R1 = (int64_t)t_info_host[4];          // total of the slice lists, finished or not (accounting only)
+      if (g_slice_mode == 2 && n_left > n_fin) g_slice_cooldown = 16;      // little occlusion here: stop paying for pass 1
+      if (n_left > 0) {
+        mask_main = mask2;
+        pass = SlicePass{2, nullptr, mask2, nullptr, nullptr};
+        // pass 2 bins against the whole map: shade everything the slice did not
+        launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
+                                (float2*)(geom + G.uv), SliceList{nullptr, nullptr}, sel1, 0, st);
+      }
     }
-    if (!sort_path) {
+    if (!sort_path && !(sliced && n_left == 0)) {
       // exact per-tile counts -> ranges; the one host sync of the forward sizes the instance arrays
       const SliceSel sel2{sliced ? 2 : 0, nullptr, nullptr, 0u, 0u, slice_ctr};
       if (launch_bin_count(p, splats, radii, mask_main, tile_count, block_counts, sel2, SliceList{nullptr, nullptr}, 0, st) != 0)
         return RTGS_E_HIP;
-      // the totals land in pinned host memory straight from the kernel (one slot per calling thread)
-      static thread_local uint32_t* t_info_host = nullptr;
-      static thread_local uint32_t t_seq = 0;
-      if (!t_info_host) {
-        HIP_TRY(hipHostMalloc((void**)&t_info_host, 8 * sizeof(uint32_t), hipHostMallocCoherent));
-        memset(t_info_host, 0, 8 * sizeof(uint32_t));
-      }
       if (++t_seq == 0u) t_seq = 1u;
-      launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, t_info_host, sliced ? slice_ctr : nullptr,
-                          sliced ? info + 2 : nullptr, t_seq, st);
+      launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, t_info_host, nullptr, nullptr, t_seq, st);
       DBG(s, st);
       prof_mark(EV_SCAN, st);
-      {
-        // Spin on the word the kernel publishes last (system-scope release store into coherent pinned memory): a few
-        // microseconds instead of the ~25 us a blocking hipStreamSynchronize takes to wake up.  Falls back to the
-        // blocking wait if the GPU is far behind (the spin is bounded).
-        volatile uint32_t* flag = t_info_host + 7;
-        bool seen = false;
-        for (long spin = 0; spin < 4000000L; ++spin) {
-          if (*flag == t_seq) { seen = true; break; }
-          __builtin_ia32_pause();
-        }
-        if (!seen) HIP_TRY(hipStreamSynchronize(st));
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      }
+      if ((rc = wait_published(t_seq)) != RTGS_OK) return rc;
       R = (int64_t)t_info_host[0];
       longest = t_info_host[1];
-      if (sliced) {
-        n_left = t_info_host[2]; n_fin = t_info_host[3];
-        R1 = (int64_t)t_info_host[4];        // total of the slice lists, finished or not (accounting only)
-        if (g_slice_mode == 2 && n_left > n_fin) g_slice_cooldown = 16;    // little occlusion here: stop paying for pass 1
-      }
       if ((int)longest > bin_sort_capacity()) {   // a tile list too long for the LDS sort: redo with rect counts
         sort_path = true;
         if (sliced) {         // the global-sort path renders every tile itself: drop the slice's results

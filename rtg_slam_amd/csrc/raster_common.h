@@ -78,7 +78,7 @@ struct SlicePass {
   const int32_t* user_mask;      // mode 1
   int32_t* mask2;                // mode 1: written; mode 2: read
   uint2* ranges_bwd;             // mode 1: range of a finished tile, (0,0) otherwise - what blend_bwd walks
-  uint32_t* ctr;                 // mode 1: ctr[0] += unfinished (unmasked) tiles, ctr[1] += finished tiles
+  uint2* ranges_main;            // mode 1: the main pass's ranges, written empty (pass 2 overwrites them if it runs)
 };
 // Shading work list of the two-pass forward (preprocess_fwd_kernel<2>, bin_count / bin_scatter in slice mode):
 // the near slice's Gaussian ids, appended in arbitrary order by slice_compact_kernel.

@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
       const bool on = sp.user_mask[tile] != 0;
       sp.mask2[tile] = (on && !finished) ? 1 : 0;
       sp.ranges_bwd[tile] = finished ? range : make_uint2(0u, 0u);
-      if (on) atomicAdd(&sp.ctr[finished ? 1 : 0], 1u);
+      sp.ranges_main[tile] = make_uint2(0u, 0u);
     }
   }
 
@@ -632,6 +632,35 @@ void launch_tile_ranges(int64_t R, const uint64_t* keys, uint2* ranges, hipStrea
   if (R == 0) return;
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, R, keys, ranges);
 }
+// After the near slice's blend: count the tiles it finished / left (from the tile mask it wrote - per-tile atomics on
+// one counter would serialise: 3 225 of them cost 55 us) and publish the totals to the host, which spins on host[7].
+__global__ void __launch_bounds__(256) slice_publish_kernel(int ntiles, const int32_t* __restrict__ user_mask,
+                                                            const int32_t* __restrict__ mask2,
+                                                            const uint32_t* __restrict__ r1, uint32_t* __restrict__ ctr,
+                                                            uint32_t* __restrict__ host, uint32_t seq) {
+  int left = 0, fin = 0;
+  for (int t = threadIdx.x; t < ntiles; t += 256) {
+    const bool on = user_mask[t] != 0, l = mask2[t] != 0;
+    left += l ? 1 : 0;
+    fin += (on && !l) ? 1 : 0;
+  }
+  __shared__ int s_l[4], s_f[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { left += __shfl_xor(left, off); fin += __shfl_xor(fin, off); }
+  if ((threadIdx.x & 63) == 0) { s_l[threadIdx.x >> 6] = left; s_f[threadIdx.x >> 6] = fin; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t L = (uint32_t)(s_l[0] + s_l[1] + s_l[2] + s_l[3]), F = (uint32_t)(s_f[0] + s_f[1] + s_f[2] + s_f[3]);
+    ctr[0] = L; ctr[1] = F;                      // device copy: pass 2's kernels exit at once when nothing is left
+    host[2] = L; host[3] = F; host[4] = r1[0];
+    __hip_atomic_store(&host[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void launch_slice_publish(int ntiles, const int32_t* user_mask, const int32_t* mask2, const uint32_t* r1, uint32_t* ctr,
+                          uint32_t* host, uint32_t seq, hipStream_t st) {
+  hipLaunchKernelGGL(slice_publish_kernel, dim3(1), dim3(256), 0, st, ntiles, user_mask, mask2, r1, ctr, host, seq);
+}
+
 void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                       float* out_color, float* out_depth, int32_t* out_cidx, int32_t* out_didx, float* out_cw,
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
