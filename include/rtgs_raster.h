@@ -197,6 +197,16 @@ int rtgs_map_activate8_backward_rows(const float* raw8, int64_t n, const float* 
                                      const float* g_rotations, const float* g_normal, const uint8_t* row_state,
                                      float* g_raw8, void* stream);
 
+/* rtgs_map_activate8_backward_rows followed by rtgs_fused_adam_rows on xyz[rows,3], shs[rows,48] and raw8[rows,8], as
+ * ONE launch (the tail of rtgs_slam_map_step).  g_* are the persistent gradient rows of rtgs_raster_backward_rows,
+ * row_state its state bytes; g_raw8 is written for state 1 (value) and state 2 (zero) rows. */
+int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const float* g_opacity, const float* g_scales,
+                       const float* g_rotations, const float* g_normal, const float* g_xyz, const float* g_shs,
+                       float* g_raw8, const uint8_t* row_state, float* m_xyz, float* v_xyz, float* m_shs, float* v_shs,
+                       float* m_raw8, float* v_raw8, const float* lr_xyz, const float* lr_shs, const float* lr_raw8,
+                       uint8_t* ever_xyz, uint8_t* ever_shs, uint8_t* ever_raw8, int64_t rows, int32_t step, float beta1,
+                       float beta2, float eps, void* stream);
+
 /* Fused SLAM loss, the live terms of mapper.py:402-442:
  *   L = color_weight * mean|C - C_gt| + depth_weight * sum(m |D - D_gt|) / max(sum m, 1),
  *   m = (depth_index != -1) & (D_gt > 0).

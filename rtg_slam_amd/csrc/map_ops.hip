@@ -4,6 +4,7 @@
 // sigmoid / normalize, :538-550 get_normal).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "adam_common.h"
 
 namespace rtgs {
 
@@ -47,6 +48,42 @@ __global__ void __launch_bounds__(256) activate8_fwd_kernel(const float4* __rest
   }
 }
 
+// gradient of (opacity, scales, rotations, normal) w.r.t. the raw8 row (a = o s0 s1 s2, q = quaternion wxyz)
+__device__ __forceinline__ void activate8_bwd_row(const float4 a, const float4 q, float g_op, float gs0, float gs1, float gs2,
+                                                  const float4 gr, float gn0, float gn1, float gn2, float4& lo, float4& hi) {
+  const float sg = 1.f / (1.f + __expf(-a.x));
+  const float s0 = __expf(a.y), s1 = __expf(a.z), s2 = __expf(a.w);
+  const float nq = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+  const float inv = 1.f / nq;
+  const float r = q.x * inv, x = q.y * inv, y = q.z * inv, z = q.w * inv;
+  int k = 0;
+  float sm = s0;
+  if (s1 < sm) { sm = s1; k = 1; }
+  if (s2 < sm) { k = 2; }
+  float c[3];
+  rot_col(k, r, x, y, z, c);
+  const float m = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+  const float me = m + 1e-8f;
+  const float cg = c[0] * gn0 + c[1] * gn1 + c[2] * gn2;
+  const float kk = (m > 0.f) ? cg / (m * me * me) : 0.f;
+  const float dc0 = gn0 / me - c[0] * kk, dc1 = gn1 / me - c[1] * kk, dc2 = gn2 / me - c[2] * kk;
+  float dr, dx, dy, dz;
+  if (k == 0) {
+    dr = 2.f * (z * dc1 - y * dc2); dx = 2.f * (y * dc1 + z * dc2);
+    dy = 2.f * (-2.f * y * dc0 + x * dc1 - r * dc2); dz = 2.f * (-2.f * z * dc0 + r * dc1 + x * dc2);
+  } else if (k == 1) {
+    dr = 2.f * (-z * dc0 + x * dc2); dx = 2.f * (y * dc0 - 2.f * x * dc1 + r * dc2);
+    dy = 2.f * (x * dc0 + z * dc2); dz = 2.f * (-r * dc0 - 2.f * z * dc1 + y * dc2);
+  } else {
+    dr = 2.f * (y * dc0 - x * dc1); dx = 2.f * (z * dc0 - r * dc1 - 2.f * x * dc2);
+    dy = 2.f * (r * dc0 + z * dc1 - 2.f * y * dc2); dz = 2.f * (x * dc0 + y * dc1);
+  }
+  const float t0 = gr.x + dr, t1 = gr.y + dx, t2 = gr.z + dy, t3 = gr.w + dz;
+  const float dot = r * t0 + x * t1 + y * t2 + z * t3;
+  lo = make_float4(g_op * sg * (1.f - sg), gs0 * s0, gs1 * s1, gs2 * s2);
+  hi = make_float4((t0 - r * dot) * inv, (t1 - x * dot) * inv, (t2 - y * dot) * inv, (t3 - z * dot) * inv);
+}
+
 __global__ void __launch_bounds__(256) activate8_bwd_kernel(const float4* __restrict__ raw8, int64_t n,
                                                             const float* __restrict__ g_op, const float* __restrict__ g_sc,
                                                             const float4* __restrict__ g_rot, const float* __restrict__ g_nrm,
@@ -58,40 +95,11 @@ __global__ void __launch_bounds__(256) activate8_bwd_kernel(const float4* __rest
       if (s == 0) continue;
       if (s == 2) { g_raw8[2 * i] = g_raw8[2 * i + 1] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
     }
-    const float4 a = raw8[2 * i], q = raw8[2 * i + 1];
-    const float sg = 1.f / (1.f + __expf(-a.x));
-    const float s0 = __expf(a.y), s1 = __expf(a.z), s2 = __expf(a.w);
-    const float nq = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-    const float inv = 1.f / nq;
-    const float r = q.x * inv, x = q.y * inv, y = q.z * inv, z = q.w * inv;
-    int k = 0;
-    float sm = s0;
-    if (s1 < sm) { sm = s1; k = 1; }
-    if (s2 < sm) { k = 2; }
-    float c[3];
-    rot_col(k, r, x, y, z, c);
-    const float m = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-    const float me = m + 1e-8f;
-    const float gn0 = g_nrm[i * 3], gn1 = g_nrm[i * 3 + 1], gn2 = g_nrm[i * 3 + 2];
-    const float cg = c[0] * gn0 + c[1] * gn1 + c[2] * gn2;
-    const float kk = (m > 0.f) ? cg / (m * me * me) : 0.f;
-    const float dc0 = gn0 / me - c[0] * kk, dc1 = gn1 / me - c[1] * kk, dc2 = gn2 / me - c[2] * kk;
-    float dr, dx, dy, dz;
-    if (k == 0) {
-      dr = 2.f * (z * dc1 - y * dc2); dx = 2.f * (y * dc1 + z * dc2);
-      dy = 2.f * (-2.f * y * dc0 + x * dc1 - r * dc2); dz = 2.f * (-2.f * z * dc0 + r * dc1 + x * dc2);
-    } else if (k == 1) {
-      dr = 2.f * (-z * dc0 + x * dc2); dx = 2.f * (y * dc0 - 2.f * x * dc1 + r * dc2);
-      dy = 2.f * (x * dc0 + z * dc2); dz = 2.f * (-r * dc0 - 2.f * z * dc1 + y * dc2);
-    } else {
-      dr = 2.f * (y * dc0 - x * dc1); dx = 2.f * (z * dc0 - r * dc1 - 2.f * x * dc2);
-      dy = 2.f * (r * dc0 + z * dc1 - 2.f * y * dc2); dz = 2.f * (x * dc0 + y * dc1);
-    }
-    const float4 gr = g_rot[i];
-    const float t0 = gr.x + dr, t1 = gr.y + dx, t2 = gr.z + dy, t3 = gr.w + dz;
-    const float dot = r * t0 + x * t1 + y * t2 + z * t3;
-    g_raw8[2 * i] = make_float4(g_op[i] * sg * (1.f - sg), g_sc[i * 3] * s0, g_sc[i * 3 + 1] * s1, g_sc[i * 3 + 2] * s2);
-    g_raw8[2 * i + 1] = make_float4((t0 - r * dot) * inv, (t1 - x * dot) * inv, (t2 - y * dot) * inv, (t3 - z * dot) * inv);
+    float4 lo, hi;
+    activate8_bwd_row(raw8[2 * i], raw8[2 * i + 1], g_op[i], g_sc[i * 3], g_sc[i * 3 + 1], g_sc[i * 3 + 2], g_rot[i],
+                      g_nrm[i * 3], g_nrm[i * 3 + 1], g_nrm[i * 3 + 2], lo, hi);
+    g_raw8[2 * i] = lo;
+    g_raw8[2 * i + 1] = hi;
   }
 }
 
@@ -130,6 +138,127 @@ extern "C" int rtgs_map_activate8_backward_rows(const float* raw8, int64_t n, co
   hipLaunchKernelGGL(rtgs::activate8_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)raw8, n, g_opacity, g_scales, (const float4*)g_rotations, g_normal, row_state,
                      (float4*)g_raw8);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tail of the one-call map step (rtgs_slam_map_step): activation backward + Adam on xyz, SH and raw8 in ONE launch
+// instead of four (each of which is latency-bound when only a few thousand rows carry gradient).  Same arithmetic
+// as activate8_bwd_kernel and fused_adam_rows_kernel, same row-state protocol: state 1 rows are computed, state 2
+// rows of g_raw8 are zeroed, a row is stepped iff it carries gradient now or its moments have ever left zero.
+// ---------------------------------------------------------------------------------------------
+namespace rtgs {
+
+struct TailArgs {
+  const float4* raw8_in;          // = raw8 (read before it is stepped)
+  float *xyz, *shs, *raw8;
+  const float *g_op, *g_sc, *g_nrm, *g_xyz, *g_shs;
+  const float4* g_rot;
+  float4* g_raw8;
+  const uint8_t* row_state;
+  float *m_xyz, *v_xyz, *m_shs, *v_shs, *m_raw8, *v_raw8;
+  const float *lr_xyz, *lr_shs, *lr_raw8;
+  uint8_t *ever_xyz, *ever_shs, *ever_raw8;
+  long long rows;
+  float beta1, beta2, eps, bc1, bc2_sqrt;
+};
+
+__global__ void __launch_bounds__(256) map_tail_rows_kernel(TailArgs a) {
+  __shared__ int s_rows[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long wave0 = (long long)blockIdx.x * 4 + wv, nwaves = (long long)gridDim.x * 4;
+  for (long long base = wave0 * 64; base < a.rows; base += nwaves * 64) {
+    const long long r = base + lane;
+    bool need_sh = false;
+    if (r < a.rows) {
+      const uint8_t st = a.row_state[r];
+      const bool grad = st == 1;
+      if (st != 0) {                                             // raw8 gradient row: value (1) or zero (2)
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (grad)
+          activate8_bwd_row(a.raw8_in[2 * r], a.raw8_in[2 * r + 1], a.g_op[r], a.g_sc[r * 3], a.g_sc[r * 3 + 1],
+                            a.g_sc[r * 3 + 2], a.g_rot[r], a.g_nrm[r * 3], a.g_nrm[r * 3 + 1], a.g_nrm[r * 3 + 2], lo, hi);
+        a.g_raw8[2 * r] = lo; a.g_raw8[2 * r + 1] = hi;
+      }
+      if (grad || a.ever_raw8[r] != 0) {                         // raw8: 8 columns, this lane
+        a.ever_raw8[r] = 1;
+        const float4 g0 = a.g_raw8[2 * r], g1 = a.g_raw8[2 * r + 1];
+        float4* p4 = reinterpret_cast<float4*>(a.raw8) + 2 * r;
+        float4* m4 = reinterpret_cast<float4*>(a.m_raw8) + 2 * r;
+        float4* v4 = reinterpret_cast<float4*>(a.v_raw8) + 2 * r;
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        float4 pp[2] = {p4[0], p4[1]}, mm[2] = {m4[0], m4[1]}, vv[2] = {v4[0], v4[1]};
+        float* pf = reinterpret_cast<float*>(pp); float* mf = reinterpret_cast<float*>(mm); float* vf = reinterpret_cast<float*>(vv);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pf[c] = adam1(pf[c], gg[c], mf[c], vf[c], a.lr_raw8[c], a.beta1, a.beta2, a.eps, a.bc1, a.bc2_sqrt);
+        p4[0] = pp[0]; p4[1] = pp[1]; m4[0] = mm[0]; m4[1] = mm[1]; v4[0] = vv[0]; v4[1] = vv[1];
+      }
+      if (grad || a.ever_xyz[r] != 0) {                          // xyz: 3 columns, this lane
+        a.ever_xyz[r] = 1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const size_t o = (size_t)r * 3 + c;
+          float mi = a.m_xyz[o], vi = a.v_xyz[o];
+          a.xyz[o] = adam1(a.xyz[o], a.g_xyz[o], mi, vi, a.lr_xyz[c], a.beta1, a.beta2, a.eps, a.bc1, a.bc2_sqrt);
+          a.m_xyz[o] = mi; a.v_xyz[o] = vi;
+        }
+      }
+      need_sh = grad || a.ever_shs[r] != 0;
+      if (need_sh) a.ever_shs[r] = 1;
+    }
+    // SH: 48 columns = 12 lanes x float4 per live row, five rows per sweep (as fused_adam_rows_kernel<48>)
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(need_sh);
+    if (mask == 0ull) continue;
+    const int n = __popcll(mask);
+    if (need_sh) s_rows[wv][__popcll(mask & ((1ull << lane) - 1ull))] = lane;
+    __builtin_amdgcn_wave_barrier();
+    const int slot = lane / 12, sub = lane - slot * 12;
+    for (int k0 = 0; k0 < n; k0 += 5) {
+      const int k = k0 + slot;
+      if (slot < 5 && k < n) {
+        const size_t o = (size_t)(base + s_rows[wv][k]) * 12 + sub;
+        const float4 gi = reinterpret_cast<const float4*>(a.g_shs)[o], pi = reinterpret_cast<const float4*>(a.shs)[o];
+        float4 mi = reinterpret_cast<float4*>(a.m_shs)[o], vi = reinterpret_cast<float4*>(a.v_shs)[o], po;
+        po.x = adam1(pi.x, gi.x, mi.x, vi.x, a.lr_shs[4 * sub], a.beta1, a.beta2, a.eps, a.bc1, a.bc2_sqrt);
+        po.y = adam1(pi.y, gi.y, mi.y, vi.y, a.lr_shs[4 * sub + 1], a.beta1, a.beta2, a.eps, a.bc1, a.bc2_sqrt);
+        po.z = adam1(pi.z, gi.z, mi.z, vi.z, a.lr_shs[4 * sub + 2], a.beta1, a.beta2, a.eps, a.bc1, a.bc2_sqrt);
+        po.w = adam1(pi.w, gi.w, mi.w, vi.w, a.lr_shs[4 * sub + 3], a.beta1, a.beta2, a.eps, a.bc1, a.bc2_sqrt);
+        reinterpret_cast<float4*>(a.shs)[o] = po;
+        reinterpret_cast<float4*>(a.m_shs)[o] = mi;
+        reinterpret_cast<float4*>(a.v_shs)[o] = vi;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace rtgs
+
+extern "C" int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const float* g_opacity, const float* g_scales,
+                                  const float* g_rotations, const float* g_normal, const float* g_xyz, const float* g_shs,
+                                  float* g_raw8, const uint8_t* row_state, float* m_xyz, float* v_xyz, float* m_shs,
+                                  float* v_shs, float* m_raw8, float* v_raw8, const float* lr_xyz, const float* lr_shs,
+                                  const float* lr_raw8, uint8_t* ever_xyz, uint8_t* ever_shs, uint8_t* ever_raw8,
+                                  int64_t rows, int32_t step, float beta1, float beta2, float eps, void* stream) {
+  if (rows < 0 || step < 1) return -1;
+  if (rows == 0) return 0;
+  if (!xyz || !shs || !raw8 || !g_opacity || !g_scales || !g_rotations || !g_normal || !g_xyz || !g_shs || !g_raw8 ||
+      !row_state || !m_xyz || !v_xyz || !m_shs || !v_shs || !m_raw8 || !v_raw8 || !lr_xyz || !lr_shs || !lr_raw8 ||
+      !ever_xyz || !ever_shs || !ever_raw8)
+    return -1;
+  rtgs::TailArgs a;
+  a.raw8_in = (const float4*)raw8; a.xyz = xyz; a.shs = shs; a.raw8 = raw8;
+  a.g_op = g_opacity; a.g_sc = g_scales; a.g_nrm = g_normal; a.g_xyz = g_xyz; a.g_shs = g_shs;
+  a.g_rot = (const float4*)g_rotations; a.g_raw8 = (float4*)g_raw8; a.row_state = row_state;
+  a.m_xyz = m_xyz; a.v_xyz = v_xyz; a.m_shs = m_shs; a.v_shs = v_shs; a.m_raw8 = m_raw8; a.v_raw8 = v_raw8;
+  a.lr_xyz = lr_xyz; a.lr_shs = lr_shs; a.lr_raw8 = lr_raw8;
+  a.ever_xyz = ever_xyz; a.ever_shs = ever_shs; a.ever_raw8 = ever_raw8;
+  a.rows = rows; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.bc1 = 1.f - powf(beta1, (float)step);
+  a.bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  long long blocks = (rows + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(rtgs::map_tail_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

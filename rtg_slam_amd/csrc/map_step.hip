@@ -1,6 +1,6 @@
 // rtgs_slam_map_step: one map-optimisation iteration (the inner loop body of mapper.py:176-205 with the live loss
 // terms of mapper.py:402-442) enqueued by ONE call: raw8 activation -> rasterizer forward -> fused SLAM loss ->
-// row-state rasterizer backward -> activation backward -> row-skipping Adam on the three block tensors.
+// row-state rasterizer backward -> activation backward + row-skipping Adam on the three block tensors (one kernel).
 // Nothing new is computed here - it is the sequence map_optim.ShardedMapOptimizer.step() issues through autograd,
 // without the per-launch Python / autograd cost (which exceeds the GPU time of the step on a 1.2 M map).
 #include "../../include/rtgs_raster.h"
@@ -31,16 +31,10 @@ extern "C" int rtgs_slam_map_step(const rtgs_map_step_args* a, int64_t* num_rend
                                  a->dL_dcolor, a->dL_ddepth, a->d_xyz, a->d_opacity, a->d_shs, a->d_scales,
                                  a->d_rotations, a->d_normal, a->grad_scratch, a->row_state, stream);
   if (rc != RTGS_OK) return rc;
-  rc = rtgs_map_activate8_backward_rows(a->raw8, P, a->d_opacity, a->d_scales, a->d_rotations, a->d_normal,
-                                        a->row_state, a->d_raw8, stream);
-  if (rc != 0) return RTGS_E_HIP;
-  rc = rtgs_fused_adam_rows(a->xyz, a->d_xyz, a->m_xyz, a->v_xyz, a->lr_xyz, a->ever_xyz, a->row_state, P, 3, a->step,
-                            a->beta1, a->beta2, a->eps, stream);
-  if (rc != 0) return RTGS_E_HIP;
-  rc = rtgs_fused_adam_rows(a->shs, a->d_shs, a->m_shs, a->v_shs, a->lr_shs, a->ever_shs, a->row_state, P, 48, a->step,
-                            a->beta1, a->beta2, a->eps, stream);
-  if (rc != 0) return RTGS_E_HIP;
-  rc = rtgs_fused_adam_rows(a->raw8, a->d_raw8, a->m_raw8, a->v_raw8, a->lr_raw8, a->ever_raw8, a->row_state, P, 8,
-                            a->step, a->beta1, a->beta2, a->eps, stream);
+  // activation backward + Adam on the three block tensors, one launch
+  rc = rtgs_map_tail_rows(a->xyz, a->shs, a->raw8, a->d_opacity, a->d_scales, a->d_rotations, a->d_normal, a->d_xyz,
+                          a->d_shs, a->d_raw8, a->row_state, a->m_xyz, a->v_xyz, a->m_shs, a->v_shs, a->m_raw8, a->v_raw8,
+                          a->lr_xyz, a->lr_shs, a->lr_raw8, a->ever_xyz, a->ever_shs, a->ever_raw8, P, a->step, a->beta1,
+                          a->beta2, a->eps, stream);
   return rc != 0 ? RTGS_E_HIP : RTGS_OK;
 }

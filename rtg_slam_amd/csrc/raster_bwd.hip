@@ -3,6 +3,7 @@
 // and the per-Gaussian chain rule back to {means3D, opacities, shs, scales, rotations, normal_w}.
 // Math: SURVEY.md Appendix B "Backward"; checked against autograd of oracle/raster_oracle.py.
 #include "raster_common.h"
+#include "adam_common.h"
 
 namespace rtgs {
 
@@ -775,20 +776,6 @@ void launch_preprocess_bwd(const RasterParams& p, const float* means, const floa
 // SLAM/gaussian_pointcloud.py:245-284; torch.optim.Adam(eps=1e-15) semantics, mapper.py:156).
 // ---------------------------------------------------------------------------------------------
 namespace rtgs {
-// Contractions are spelled out (and automatic ones disabled) so that every kernel that inlines this helper
-// rounds identically - the row-skipping kernel must match the dense ones bit for bit.
-__device__ __forceinline__ float adam1(float p, float g, float& m, float& v, float lr, float beta1, float beta2,
-                                       float eps, float bc1, float bc2_sqrt) {
-#pragma clang fp contract(off)
-  const float t1 = (1.f - beta1) * g;
-  const float t2 = ((1.f - beta2) * g) * g;
-  m = __builtin_fmaf(beta1, m, t1);
-  v = __builtin_fmaf(beta2, v, t2);
-  const float denom = sqrtf(v) / bc2_sqrt + eps;
-  const float step = lr / bc1;
-  return __builtin_fmaf(-step, m / denom, p);
-}
-
 // 16 B per lane per stream (7 streams: p g m v in, p m v out); n_elems % 4 == 0 on this path
 __global__ void __launch_bounds__(256) fused_adam_vec4_kernel(float4* __restrict__ p, const float4* __restrict__ g,
                                                               float4* __restrict__ m, float4* __restrict__ v,
