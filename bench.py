@@ -111,7 +111,7 @@ def main():
     # Tracking and mapping are independent within a frame (RTG-SLAM runs them as two pipeline stages in separate
     # processes, SLAM/multiprocess/system.py).  Here the tracker's kernels go to a second HIP stream and are
     # ENQUEUED by a helper thread (the C calls release the GIL), so neither the GPU nor the host serialises the two.
-    icp_stream = torch.cuda.Stream(device=dev, priority=-1)      # short, latency-bound kernels: schedule them first
+    icp_stream = torch.cuda.Stream(device=dev)
     import queue
     import threading
     icp_req, icp_done = queue.SimpleQueue(), queue.SimpleQueue()
