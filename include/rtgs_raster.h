@@ -252,6 +252,20 @@ typedef struct rtgs_map_step_args {
   rtgs_resize_fn image_resize; void* image_user;
 } rtgs_map_step_args;
 int rtgs_slam_map_step(const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
+/* The same call without its last stage (rtgs_map_tail_rows): the gradient rows of this rank's view are in the arena,
+ * nothing has been stepped.  Multi-GPU callers exchange the rows (below) before they run the tail. */
+int rtgs_slam_map_step_front(const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
+
+/* Sparse gradient exchange for replicated multi-GPU optimisation: only rows that received gradient travel.
+ * rtgs_rows_pack compacts the state-1 rows of a row-state arena into out_rows[*, 64] (word 0 = Gaussian id as bits,
+ * 1..3 d_xyz, 4..51 d_shs, 52 d_opacity, 53..55 d_scales, 56..59 d_rotations, 60..62 d_normal) and their number into
+ * *out_count (device word).  rtgs_rows_apply writes a packed list back into an arena: mode 0 zeroes the listed rows,
+ * mode 1 adds them and marks the rows state 1.  A rank zeroes its own rows, then adds the lists of ranks 0..W-1 in that
+ * order - every replica sums in the same order - and runs rtgs_map_tail_rows. */
+int rtgs_rows_pack(const uint8_t* row_state, int32_t P, float* d_xyz, float* d_shs, float* d_opacity, float* d_scales,
+                   float* d_rotations, float* d_normal, float* out_rows, uint32_t* out_count, void* stream);
+int rtgs_rows_apply(const float* rows, int32_t n_rows, int32_t mode, float* d_xyz, float* d_shs, float* d_opacity,
+                    float* d_scales, float* d_rotations, float* d_normal, uint8_t* row_state, void* stream);
 
 const char* rtgs_version(void);
 

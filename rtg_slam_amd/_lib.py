@@ -81,6 +81,9 @@ _SIGNATURES = {
     "rtgs_map_activate8_backward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "rtgs_map_activate8_backward_rows": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "rtgs_map_tail_rows": (C.c_int, [_P] * 23 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
+    "rtgs_slam_map_step_front": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
+    "rtgs_rows_pack": (C.c_int, [_P, C.c_int32] + [_P] * 8 + [_P]),
+    "rtgs_rows_apply": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 7 + [_P]),
     "rtgs_slam_map_step": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_slam_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "rtgs_raster_set_profiling": (None, [C.c_int]),

@@ -263,6 +263,112 @@ extern "C" int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// Sparse gradient exchange of the replicated multi-GPU map step (map_optim.ShardedMapOptimizer.step_slam with more
+// than one rank): only the rows that received gradient travel.  A packed row is 64 words:
+//   [0] Gaussian id  [1..3] d_xyz  [4..51] d_shs  [52] d_opacity  [53..55] d_scales  [56..59] d_rotations
+//   [60..62] d_normal  [63] unused
+// rows_pack compacts the state-1 rows of the row-state arena (ids staged in LDS, one global atomic per workgroup);
+// rows_apply zeroes (mode 0) or adds (mode 1, also sets the row's state to 1) a packed list back into an arena.  Every
+// rank zeroes its own rows and then adds the lists of ranks 0..W-1 in that order, so all replicas sum in the same
+// order and stay bit-identical.
+// ---------------------------------------------------------------------------------------------
+namespace rtgs {
+
+constexpr int PACK_CHUNK = 8192;
+constexpr int ROW_WORDS = 64;
+
+struct ArenaPtrs {
+  float *d_xyz, *d_shs, *d_opac, *d_scales, *d_rots, *d_normal;
+};
+__device__ __forceinline__ float* arena_word(const ArenaPtrs& a, uint32_t id, int w) {
+  // w in [1, 62]
+  if (w < 4) return a.d_xyz + (size_t)id * 3 + (w - 1);
+  if (w < 52) return a.d_shs + (size_t)id * 48 + (w - 4);
+  if (w < 53) return a.d_opac + id;
+  if (w < 56) return a.d_scales + (size_t)id * 3 + (w - 53);
+  if (w < 60) return a.d_rots + (size_t)id * 4 + (w - 56);
+  return a.d_normal + (size_t)id * 3 + (w - 60);
+}
+
+__global__ void __launch_bounds__(256) rows_pack_kernel(const uint8_t* __restrict__ row_state, int P, ArenaPtrs a,
+                                                        float* __restrict__ out_rows, uint32_t* __restrict__ out_count) {
+  __shared__ uint32_t s_ids[PACK_CHUNK];
+  __shared__ uint32_t s_n, s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int begin = blockIdx.x * PACK_CHUNK;
+  for (int i = begin + (int)threadIdx.x; i < begin + PACK_CHUNK; i += 256) {     // uniform trip count per wave
+    const bool in = i < P && row_state[i] == 1;
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(in);
+    if (mk == 0ull) continue;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&s_n, (uint32_t)__popcll(mk));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (in) s_ids[base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)i;
+  }
+  __syncthreads();
+  const uint32_t n = s_n;
+  if (n == 0u) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(out_count, n);
+  __syncthreads();
+  const uint32_t base = s_base;
+  const int w = threadIdx.x & 63;
+  for (uint32_t k = threadIdx.x >> 6; k < n; k += 4) {                             // one wave per row, one word per lane
+    const uint32_t id = s_ids[k];
+    float v = 0.f;
+    if (w == 0) v = __uint_as_float(id);
+    else if (w < 63) v = *arena_word(a, id, w);
+    out_rows[(size_t)(base + k) * ROW_WORDS + w] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) rows_apply_kernel(const float* __restrict__ rows, int n_rows, int mode, ArenaPtrs a,
+                                                         uint8_t* __restrict__ row_state) {
+  const int w = threadIdx.x & 63;
+  for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_rows; k += gridDim.x * 4) {
+    const uint32_t id = __float_as_uint(rows[(size_t)k * ROW_WORDS]);
+    if (w == 0) { if (mode == 1) row_state[id] = 1; }
+    else if (w < 63) {
+      float* dst = arena_word(a, id, w);
+      if (mode == 0) *dst = 0.f;
+      else *dst += rows[(size_t)k * ROW_WORDS + w];          // ids are unique within one list: no atomics
+    }
+  }
+}
+
+}  // namespace rtgs
+
+extern "C" int rtgs_rows_pack(const uint8_t* row_state, int32_t P, float* d_xyz, float* d_shs, float* d_opacity,
+                              float* d_scales, float* d_rotations, float* d_normal, float* out_rows, uint32_t* out_count,
+                              void* stream) {
+  if (P < 0 || (P > 0 && (!row_state || !d_xyz || !d_shs || !d_opacity || !d_scales || !d_rotations || !d_normal ||
+                          !out_rows || !out_count)))
+    return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out_count, 0, sizeof(uint32_t), st) != hipSuccess) return -2;
+  if (P == 0) return 0;
+  const rtgs::ArenaPtrs a{d_xyz, d_shs, d_opacity, d_scales, d_rotations, d_normal};
+  hipLaunchKernelGGL(rtgs::rows_pack_kernel, dim3((P + rtgs::PACK_CHUNK - 1) / rtgs::PACK_CHUNK), dim3(256), 0, st,
+                     row_state, P, a, out_rows, out_count);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int rtgs_rows_apply(const float* rows, int32_t n_rows, int32_t mode, float* d_xyz, float* d_shs,
+                               float* d_opacity, float* d_scales, float* d_rotations, float* d_normal, uint8_t* row_state,
+                               void* stream) {
+  if (n_rows < 0 || (mode != 0 && mode != 1)) return -1;
+  if (n_rows == 0) return 0;
+  if (!rows || !d_xyz || !d_shs || !d_opacity || !d_scales || !d_rotations || !d_normal || !row_state) return -1;
+  const rtgs::ArenaPtrs a{d_xyz, d_shs, d_opacity, d_scales, d_rotations, d_normal};
+  int blocks = (n_rows + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rtgs::rows_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, n_rows, mode, a,
+                     row_state);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused SLAM loss (the live terms of mapper.py:402-442): L = cw * mean|C - C_gt| +
 // dw * sum(m |D - D_gt|) / max(sum m, 1),  m = (depth_index != -1) & (D_gt > 0).
 // Two launches: (1) block partial sums -> 3 device atomics, (2) loss value + both image gradients.

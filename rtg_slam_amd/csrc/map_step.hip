@@ -5,7 +5,8 @@
 // without the per-launch Python / autograd cost (which exceeds the GPU time of the step on a 1.2 M map).
 #include "../../include/rtgs_raster.h"
 
-extern "C" int rtgs_slam_map_step(const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
+// Everything up to and including the rasterizer backward: the gradient rows are in the arena, nothing is stepped yet.
+extern "C" int rtgs_slam_map_step_front(const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
   if (!a || !num_rendered_host || !a->settings) return RTGS_E_INVALID;
   const int32_t P = a->P, M = a->sh_coeffs;
   if (P <= 0 || M != 16 || a->step < 1) return RTGS_E_INVALID;
@@ -30,7 +31,13 @@ extern "C" int rtgs_slam_map_step(const rtgs_map_step_args* a, int64_t* num_rend
                                  a->rotations, a->normal, geom, bin, img, a->out_color, a->out_T, a->out_depth_index,
                                  a->dL_dcolor, a->dL_ddepth, a->d_xyz, a->d_opacity, a->d_shs, a->d_scales,
                                  a->d_rotations, a->d_normal, a->grad_scratch, a->row_state, stream);
+  return rc;
+}
+
+extern "C" int rtgs_slam_map_step(const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
+  int rc = rtgs_slam_map_step_front(a, num_rendered_host, stream);
   if (rc != RTGS_OK) return rc;
+  const int32_t P = a->P;
   // activation backward + Adam on the three block tensors, one launch
   rc = rtgs_map_tail_rows(a->xyz, a->shs, a->raw8, a->d_opacity, a->d_scales, a->d_rotations, a->d_normal, a->d_xyz,
                           a->d_shs, a->d_raw8, a->row_state, a->m_xyz, a->v_xyz, a->m_shs, a->v_shs, a->m_raw8, a->v_raw8,

@@ -243,7 +243,9 @@ class ShardedMapOptimizer:
         self._slam_ws = None
         self.last_render = None
         self.last_num_rendered = 0
-        if self.row_skip and self.world == 1 and activate_fn is None:
+        self._slam_state = None        # world > 1: full-size Adam state of the replicated sparse step (step_slam)
+        self._mode = None              # world > 1: "sharded" (step) or "replicated" (step_slam); they keep different state
+        if self.row_skip and activate_fn is None:
             from .rasterizer import RowGradArena
             self.grad_rows = RowGradArena(self.N, 16, dev)
 
@@ -264,9 +266,13 @@ class ShardedMapOptimizer:
                   depth_weight: float = 1.0) -> torch.Tensor:
         """One iteration with the built-in SLAM loss (`slam_losses`): identical kernels and results as
         `step(lambda gd: slam_losses_hip(render(gd), gt_color, gt_depth))`, but enqueued by a single C call
-        (`rtgs_slam_map_step`) - no autograd graph, no per-launch Python.  Single-GPU HIP path only; with more
-        than one rank (or injected torch kernels) it falls back to `step`.  Returns the loss (0-dim device view,
-        overwritten by the next call); the rendered images of the step are in `self.last_render`."""
+        (`rtgs_slam_map_step`) - no autograd graph, no per-launch Python.  With more than one rank the map and the
+        Adam state stay REPLICATED and only the gradient rows that exist travel: every rank renders its view, packs
+        the rows that received gradient (`rtgs_rows_pack`), the packed lists are all-gathered (a few MB instead of
+        the 283 MB of a dense reduce-scatter + all-gather at 1.2 M Gaussians), every rank adds all lists in rank order
+        and takes the same Adam step - the replicas stay bit-identical, no parameter all-gather is needed.  HIP path
+        only (injected torch kernels fall back to `step`).  Returns this rank's loss (0-dim device view, overwritten by
+        the next call); the rendered images of the step are in `self.last_render`."""
         from . import _lib
         from .rasterizer import GaussianRasterizer, _Keep
         if self.grad_rows is None:
@@ -281,6 +287,17 @@ class ShardedMapOptimizer:
         rs = raster_settings
         N, st, a = self.N, self.state, self.grad_rows
         dev = st["xyz"]["p"].device
+        if self.world > 1:
+            if self._mode == "sharded":
+                raise RuntimeError("ShardedMapOptimizer: step_slam() after step() on more than one rank - the two keep "
+                                   "different Adam state (replicated vs row-sharded); use one of them per optimizer")
+            self._mode = "replicated"
+            if self._slam_state is None:
+                self._slam_state = {
+                    n: dict(m=torch.zeros(N, c1 - c0, dtype=torch.float32, device=dev),
+                            v=torch.zeros(N, c1 - c0, dtype=torch.float32, device=dev),
+                            ever=torch.zeros(N, dtype=torch.uint8, device=dev)) for n, c0, c1 in BLOCKS}
+        ad = self._slam_state if self.world > 1 else st      # where m / v / ever live
         H, W = int(rs.image_height), int(rs.image_width)
         ws = self._slam_ws
         if ws is None or ws["hw"] != (H, W):
@@ -308,19 +325,71 @@ class ShardedMapOptimizer:
             P(ws["normal"]), P(ws["color"]), P(ws["depth"]), P(ws["cidx"]), P(ws["didx"]), P(ws["cw"]), P(ws["dw"]),
             P(ws["T"]), P(ws["radii"]), P(ws["g_color"]), P(ws["g_depth"]), P(ws["loss"]), P(a.d_means), P(a.d_opac),
             P(a.d_shs), P(a.d_scales), P(a.d_rots), P(a.d_normal), P(a.d_raw8), P(a.scratch), P(a.row_state),
-            P(st["xyz"]["m"]), P(st["xyz"]["v"]), P(st["shs"]["m"]), P(st["shs"]["v"]), P(st["raw8"]["m"]),
-            P(st["raw8"]["v"]), P(st["xyz"]["lr"]), P(st["shs"]["lr"]), P(st["raw8"]["lr"]), P(st["xyz"]["ever"]),
-            P(st["shs"]["ever"]), P(st["raw8"]["ever"]), int(self.step_count), 0.9, 0.999, float(self.eps),
+            P(ad["xyz"]["m"]), P(ad["xyz"]["v"]), P(ad["shs"]["m"]), P(ad["shs"]["v"]), P(ad["raw8"]["m"]),
+            P(ad["raw8"]["v"]), P(st["xyz"]["lr"]), P(st["shs"]["lr"]), P(st["raw8"]["lr"]), P(ad["xyz"]["ever"]),
+            P(ad["shs"]["ever"]), P(ad["raw8"]["ever"]), int(self.step_count), 0.9, 0.999, float(self.eps),
             geom.cb, None, binning.cb, None, img.cb, None)
         R = C.c_int64(0)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
-            rc = lib.rtgs_slam_map_step(C.byref(args), C.byref(R), C.c_void_p(stream))
-        _lib.check(rc, "rtgs_slam_map_step")
+        if self.world == 1:
+            with torch.cuda.device(dev):
+                rc = lib.rtgs_slam_map_step(C.byref(args), C.byref(R), C.c_void_p(stream))
+            _lib.check(rc, "rtgs_slam_map_step")
+        else:
+            with torch.cuda.device(dev):
+                rc = lib.rtgs_slam_map_step_front(C.byref(args), C.byref(R), C.c_void_p(stream))
+            _lib.check(rc, "rtgs_slam_map_step_front")
+            self._exchange_rows(lib, ws, a, dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            V = lambda t: C.c_void_p(t.data_ptr())
+            with torch.cuda.device(dev):
+                rc = lib.rtgs_map_tail_rows(
+                    V(st["xyz"]["p"]), V(st["shs"]["p"]), V(st["raw8"]["p"]), V(a.d_opac), V(a.d_scales), V(a.d_rots),
+                    V(a.d_normal), V(a.d_means), V(a.d_shs), V(a.d_raw8), V(a.row_state), V(ad["xyz"]["m"]),
+                    V(ad["xyz"]["v"]), V(ad["shs"]["m"]), V(ad["shs"]["v"]), V(ad["raw8"]["m"]), V(ad["raw8"]["v"]),
+                    V(st["xyz"]["lr"]), V(st["shs"]["lr"]), V(st["raw8"]["lr"]), V(ad["xyz"]["ever"]), V(ad["shs"]["ever"]),
+                    V(ad["raw8"]["ever"]), N, int(self.step_count), 0.9, 0.999, float(self.eps), C.c_void_p(stream))
+            _lib.check(rc, "rtgs_map_tail_rows")
         a.calls = 1
         self.last_render = (ws["color"], ws["depth"], ws["cidx"], ws["didx"], ws["cw"], ws["dw"], ws["T"])
         self.last_num_rendered = int(R.value)
         return ws["loss"][3]
+
+    def _exchange_rows(self, lib, ws, a, dev):
+        """All ranks' gradient rows into this rank's arena, summed in rank order (see step_slam)."""
+        N = self.N
+        if "rows" not in ws:
+            ws["rows"] = torch.empty(N, 64, dtype=torch.float32, device=dev)
+            ws["count"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        V = lambda t: C.c_void_p(t.data_ptr())
+        arena = (V(a.d_means), V(a.d_shs), V(a.d_opac), V(a.d_scales), V(a.d_rots), V(a.d_normal))
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        from . import _lib
+        with torch.cuda.device(dev):
+            rc = lib.rtgs_rows_pack(V(a.row_state), N, *arena, V(ws["rows"]), V(ws["count"]), stream)
+        _lib.check(rc, "rtgs_rows_pack")
+        counts_t = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(self.world)]
+        dist.all_gather(counts_t, ws["count"], group=self.group)
+        counts = [int(c) for c in torch.cat(counts_t).cpu()]            # host sync: sizes of the lists
+        maxc = max(counts)
+        if maxc == 0:
+            return
+        mine = ws["rows"][:maxc]
+        if self.backend == "gloo":
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine.contiguous(), group=self.group)
+        else:
+            buf = torch.empty(self.world, maxc, 64, dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(buf, mine.contiguous(), group=self.group)
+            parts = [buf[r] for r in range(self.world)]
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            rc = lib.rtgs_rows_apply(V(ws["rows"]), counts[self.rank], 0, *arena, V(a.row_state), stream)
+            _lib.check(rc, "rtgs_rows_apply")
+            for r in range(self.world):                               # same order on every rank: bit-identical replicas
+                rc = lib.rtgs_rows_apply(V(parts[r]), counts[r], 1, *arena, V(a.row_state), stream)
+                _lib.check(rc, "rtgs_rows_apply")
+        ws["_keep"] = parts                                           # alive until the kernels that read them have run
 
     def _arena_grad(self, name):
         a = self.grad_rows
@@ -333,6 +402,11 @@ class ShardedMapOptimizer:
         """loss_fn(gaussian_data) -> scalar loss of THIS rank's view.  Gradients are summed over
         ranks (the sum of per-view losses is what a single GPU looping over the views optimises)."""
         N = self.N
+        if self.world > 1:
+            if self._mode == "replicated":
+                raise RuntimeError("ShardedMapOptimizer: step() after step_slam() on more than one rank - the two keep "
+                                   "different Adam state (row-sharded vs replicated); use one of them per optimizer")
+            self._mode = "sharded"
         leaves = {n: self.state[n]["p"][:N].detach().requires_grad_(True) for n, _, _ in BLOCKS}
         arena = self.grad_rows
         if arena is not None:

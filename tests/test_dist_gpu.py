@@ -37,6 +37,7 @@ def _setup(dev):
             out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
                        rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=None)
             return mo.slam_losses(out, gt_c, gt_d)
+        fn.spec = (rs, gt_c, gt_d)
         fns.append(fn)
     return packed, fns
 
@@ -74,3 +75,52 @@ def test_two_ranks_one_gpu_match_single_process():
     d = float((ret[0] - ref.params.cpu()).abs().max())
     assert d < 2e-5, d
     assert float((ret[0] - packed.cpu()).abs().max()) > 1e-4
+
+
+def _worker_slam(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtg_slam_amd import map_optim as mo
+    dev = torch.device("cuda", 0)
+    packed, fns = _setup(dev)
+    opt = mo.ShardedMapOptimizer(packed)
+    rs, gt_c, gt_d = fns[rank].spec
+    losses = []
+    for _ in range(3):
+        losses.append(float(opt.step_slam(rs, gt_c, gt_d)))        # replicated map, sparse row exchange
+    ret[rank] = (opt.params.cpu(), losses)
+    try:
+        opt.step(fns[rank])
+        ret[f"mixed{rank}"] = "no error"
+    except RuntimeError as e:
+        ret[f"mixed{rank}"] = str(e)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sparse_slam_step_matches_single_process():
+    """step_slam with two ranks: only the gradient rows that exist are exchanged, every rank takes the same Adam
+    step.  Replicas bit-identical; result equal to one process optimising the sum of both views."""
+    sys.path.insert(0, ROOT)
+    from rtg_slam_amd import map_optim as mo
+    port = 29300 + (os.getpid() % 200)
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_slam, args=(2, port, ret), nprocs=2, join=True)
+    (p0, l0), (p1, l1) = ret[0], ret[1]
+    assert torch.equal(p0, p1)
+    assert "different Adam state" in ret["mixed0"]            # step() after step_slam() on > 1 rank is refused
+    dev = torch.device("cuda", 0)
+    packed, fns = _setup(dev)
+    ref = mo.ShardedMapOptimizer(packed)
+    for _ in range(3):
+        ref.step(lambda gd: fns[0](gd) + fns[1](gd))
+    rp = ref.params.cpu()
+    bad = float(((p0 - rp).abs() > 2e-5).float().mean())
+    assert bad < 2e-3, bad                                     # Adam's +-lr first steps: a gradient ~0 may flip
+    moved = (p0 - packed.cpu()).abs().max(dim=1).values > 0
+    assert 0 < int(moved.sum()) < packed.shape[0]
+    assert torch.equal(moved, (rp - packed.cpu()).abs().max(dim=1).values > 0)
