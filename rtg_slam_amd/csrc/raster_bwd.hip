@@ -366,12 +366,11 @@ __global__ void __launch_bounds__(256) blend_bwd_lanes_kernel(
     float acc[NG];
 #pragma unroll
     for (int k = 0; k < NG; ++k) acc[k] = 0.f;
-    int id = 0;
     if ((uint32_t)base < wl) {                                    // wave-uniform: some pixel of this wave reaches the chunk
       // lane i <- entry base + i (lanes >= m idle: opacity 0 fails the alpha test)
       float eu = 0.f, ev = 0.f, eca = 0.f, ecb = 0.f, ecc = 0.f, eo = 0.f, er = 0.f, eg = 0.f, eb = 0.f;
       if (lane < m) {
-        id = (int)point_list[range.x + base + lane];
+        const int id = (int)point_list[range.x + base + lane];
         const float4* src = reinterpret_cast<const float4*>(splats + id);
         const float4 a = src[0], b = src[1];
         eu = a.x; ev = a.y; eca = a.z; ecb = a.w; ecc = b.x; eo = b.y; er = b.z; eg = b.w;
@@ -379,7 +378,6 @@ __global__ void __launch_bounds__(256) blend_bwd_lanes_kernel(
       }
       const uint32_t my_index = (uint32_t)(base + lane);
       const bool more = base + 64 < nuse;                         // carries are needed only if another chunk follows
-#ifndef EXP_NO_WALK
       for (int q = 0; q < 64; ++q) {
         const int pl = wv * 64 + q;                               // pixel of the tile, wave-uniform
         const uint32_t plast = s_last[pl];
@@ -413,7 +411,6 @@ __global__ void __launch_bounds__(256) blend_bwd_lanes_kernel(
         acc[8] += gda;
         if (more && lane == 63) s_carry[pl] = make_float2(Tincl, Qincl);
       }
-#endif
     }
     // meet in LDS: one slot per (wave, entry lane, quantity)
 #pragma unroll
@@ -427,9 +424,6 @@ __global__ void __launch_bounds__(256) blend_bwd_lanes_kernel(
         t[k] = (s_acc[tid * NG + k] + s_acc[(64 + tid) * NG + k]) + (s_acc[(128 + tid) * NG + k] + s_acc[(192 + tid) * NG + k]);
         any |= (t[k] != 0.f);
       }
-#ifdef EXP_NO_FLUSH
-      any = false;
-#endif
       if (any) {
         // lanes 0..63 of wave 0 hold the ids of this chunk (wave 0 loaded them iff it walked the chunk)
         const int gid = (int)point_list[range.x + base + tid];
@@ -468,9 +462,6 @@ __global__ void __launch_bounds__(256) blend_bwd_lanes_kernel(
     }
   }
   unsigned long long todo = __builtin_amdgcn_ballot_w64(owner >= 0);
-#ifdef EXP_NO_OWNER
-  todo = 0;
-#endif
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const int o = __builtin_amdgcn_readlane(owner, leader);
