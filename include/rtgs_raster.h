@@ -267,6 +267,10 @@ int rtgs_rows_pack(const uint8_t* row_state, int32_t P, float* d_xyz, float* d_s
 int rtgs_rows_apply(const float* rows, int32_t n_rows, int32_t mode, float* d_xyz, float* d_shs, float* d_opacity,
                     float* d_scales, float* d_rotations, float* d_normal, uint8_t* row_state, void* stream);
 
+/* sizeof of the two structs above, for bindings that mirror them (rtg_slam_amd/_lib.py checks both at load time). */
+size_t rtgs_map_step_args_size(void);
+size_t rtgs_raster_settings_size(void);
+
 const char* rtgs_version(void);
 
 #ifdef __cplusplus

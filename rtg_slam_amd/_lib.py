@@ -84,6 +84,8 @@ _SIGNATURES = {
     "rtgs_slam_map_step_front": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_rows_pack": (C.c_int, [_P, C.c_int32] + [_P] * 8 + [_P]),
     "rtgs_rows_apply": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 7 + [_P]),
+    "rtgs_map_step_args_size": (C.c_size_t, []),
+    "rtgs_raster_settings_size": (C.c_size_t, []),
     "rtgs_slam_map_step": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_slam_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "rtgs_raster_set_profiling": (None, [C.c_int]),
@@ -120,6 +122,11 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        for what, mirror, size in (("rtgs_map_step_args", MapStepArgsC, lib.rtgs_map_step_args_size()),
+                                   ("rtgs_raster_settings", RasterSettingsC, lib.rtgs_raster_settings_size())):
+            if C.sizeof(mirror) != size:
+                raise RuntimeError(f"rtg_slam_amd: ctypes mirror of {what} is {C.sizeof(mirror)} B, the library says "
+                                   f"{size} B - include/rtgs_raster.h and rtg_slam_amd/_lib.py are out of step")
         _lib = lib
     return _lib
 

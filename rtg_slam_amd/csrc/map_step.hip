@@ -45,3 +45,8 @@ extern "C" int rtgs_slam_map_step(const rtgs_map_step_args* a, int64_t* num_rend
                           a->beta2, a->eps, stream);
   return rc != 0 ? RTGS_E_HIP : RTGS_OK;
 }
+
+// Layout guards for foreign-function bindings (ctypes / cgo / JNI mirrors of the two structs): compare with sizeof on the
+// binding's side at load time.
+extern "C" size_t rtgs_map_step_args_size(void) { return sizeof(rtgs_map_step_args); }
+extern "C" size_t rtgs_raster_settings_size(void) { return sizeof(rtgs_raster_settings); }

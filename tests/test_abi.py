@@ -48,3 +48,20 @@ def test_cpu_tensors_are_rejected_loudly():
     with pytest.raises(RuntimeError, match="HIP device"):
         rast(means3D=g["xyz"], opacities=g["opacity"], shs=g["shs"], colors_precomp=None, scales=g["scales"],
              rotations=g["rotations"], cov3D_precomp=None, normal_w=g["normal"], tile_mask=None)
+
+
+def test_ctypes_mirrors_match_the_c_structs():
+    """Layout guard: the two structs that cross the C ABI have the size their ctypes mirrors have (also enforced at
+    load time), and the optimiser's one-call step refuses CPU tensors like every other entry point."""
+    import ctypes as C
+    import pytest
+    import torch
+    from rtg_slam_amd import _lib, map_optim as mo
+    lib = _lib.load()
+    assert C.sizeof(_lib.MapStepArgsC) == lib.rtgs_map_step_args_size()
+    assert C.sizeof(_lib.RasterSettingsC) == lib.rtgs_raster_settings_size()
+    packed = torch.zeros(8, mo.COLS)
+    opt = mo.ShardedMapOptimizer(packed)           # CPU tensors: no arena, HIP kernels unavailable
+    assert opt.grad_rows is None
+    with pytest.raises(RuntimeError, match="HIP device"):
+        opt.step(lambda gd: gd["xyz"].sum())
