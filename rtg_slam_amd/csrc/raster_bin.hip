@@ -4,8 +4,11 @@
 //                global add per block x tile)
 //   bin_tilescan exclusive scan over tiles  -> ranges, cursors, total R, longest list
 //   bin_scatter  (depth bits << 32 | id) into the tile's bucket (LDS-aggregated slot reservation)
-//   bin_tilesort one workgroup per tile: in-LDS bitonic sort of the bucket by (depth, id)
-//                -> point_list (ids, front to back)
+//   bin_tilesort one workgroup per tile: in-LDS sort of the bucket by (depth, id) - bitonic or LSD radix by
+//                size class -> point_list (ids, front to back)
+//   slice_hist / slice_compact   the near-slice pass of the two-pass forward (raster_api.hip): area / count
+//                histograms over monotone depth bins, and the work list of the Gaussians in front of the cut;
+//                bin_count / bin_scatter then walk that list instead of all Gaussians
 //
 // Replaces the upstream design's duplicateWithKeys + 64-bit global radix sort + identifyTileRanges
 // (6+ passes over 12 B x instances) with one 8-B write, one 8-B read and one 4-B write per

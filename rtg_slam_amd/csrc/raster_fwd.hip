@@ -1,5 +1,6 @@
-// Forward kernels of the gfx950 rasterizer: per-Gaussian preprocess, (Gaussian, tile) instance
-// emission, tile ranges and the per-tile front-to-back alpha blend with opaque-surface depth.
+// Forward kernels of the gfx950 rasterizer: per-Gaussian preprocess (one pass, or geometry / lazy shading for the
+// two-pass forward), (Gaussian, tile) instance emission and tile ranges of the fallback path, and the per-tile
+// front-to-back alpha blend with opaque-surface depth.
 // Arithmetic follows SURVEY.md Appendix B (frozen in oracle/raster_oracle.py); the reference's
 // own CUDA sources are an un-vendored submodule (/root/reference/.gitmodules:1-4), its call
 // contract is /root/reference/SLAM/render.py:68-128.

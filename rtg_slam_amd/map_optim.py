@@ -12,11 +12,13 @@ Only raw8 goes through an activation kernel (rtgs_map_activate8_*: sigmoid / exp
 get_normal, gaussian_pointcloud.py:16-25, 538-550); xyz and the SH block are never copied, and the
 rasterizer's backward writes their gradients in exactly the layout Adam consumes.
 
-Per iteration and rank:  render this rank's view fwd+bwd  ->  for each of the three tensors:
-reduce-scatter of the gradient rows over RCCL (each rank receives the rows of its shard), fused
+`step(loss_fn)`, per iteration and rank:  render this rank's view fwd+bwd  ->  for each of the three
+tensors: reduce-scatter of the gradient rows over RCCL (each rank receives the rows of its shard), fused
 Adam on the rank's N/world rows (optimizer state exists only for those rows), all-gather of the
-updated rows.  With one rank the collectives vanish.  Learning rates: configs/replica_base.yaml:19-23,
-gaussian_pointcloud.py:252-283; Adam eps 1e-15 (mapper.py:156).
+updated rows.  With one rank the collectives vanish.  `step_slam(...)` is the same iteration with the
+built-in SLAM loss, enqueued by one C call; with several ranks it keeps map and Adam state replicated
+and exchanges only the gradient rows that exist.  Learning rates:
+configs/replica_base.yaml:19-23, gaussian_pointcloud.py:252-283; Adam eps 1e-15 (mapper.py:156).
 
 The render/loss closure, the Adam kernel and the activation are injected (HIP rasterizer +
 rtgs_fused_adam + rtgs_map_activate8 in production; the CPU oracle + torch restatements in the
