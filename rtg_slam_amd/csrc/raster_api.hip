@@ -303,7 +303,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
       DBG(s, st);
     }
-    const SliceSel sel1{1, zbin, slice_hist, (uint32_t)G.slice_cap, (uint32_t)G.slice_max_list, slice_ctr};
+    const SliceSel sel1{1, zbin, slice_hist, (uint32_t)G.slice_cap, (uint32_t)G.slice_max_list, slice_ctr, nullptr, nullptr};
     if (!sliced) {
       launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sort_path ? sat : nullptr, splats,
                             tiles_touched, radii, clamped, out_radii, zero_words, zero_n, nullptr, st);
@@ -350,14 +350,19 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       if (n_left > 0) {
         mask_main = mask2;
         pass = SlicePass{2, nullptr, mask2, nullptr, nullptr};
-        // pass 2 bins against the whole map: shade everything the slice did not
+        // pass 2 bins against the whole map, but only Gaussians whose tile rect holds an unfinished tile (summed-area
+        // table of the pass-2 mask) are shaded and enumerated
+        launch_mask_sat(mask2, p.gx, p.gy, sat, st);
+        SliceSel sel_rest = sel1;
+        sel_rest.sat = sat; sel_rest.uv = (const float2*)(geom + G.uv);
         launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
-                                (float2*)(geom + G.uv), SliceList{nullptr, nullptr}, sel1, 0, st);
+                                (float2*)(geom + G.uv), SliceList{nullptr, nullptr}, sel_rest, 0, st);
       }
     }
     if (!sort_path && !(sliced && n_left == 0)) {
       // exact per-tile counts -> ranges; the one host sync of the forward sizes the instance arrays
-      const SliceSel sel2{sliced ? 2 : 0, nullptr, nullptr, 0u, 0u, slice_ctr};
+      const SliceSel sel2{sliced ? 2 : 0, nullptr, nullptr, 0u, 0u, slice_ctr, sliced ? sat : nullptr,
+                          (const float2*)(geom + G.uv)};
       if (launch_bin_count(p, splats, radii, mask_main, tile_count, block_counts, sel2, SliceList{nullptr, nullptr}, 0, st) != 0)
         return RTGS_E_HIP;
       if (++t_seq == 0u) t_seq = 1u;
@@ -406,7 +411,9 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   if (R > 0 && !sort_path) {
     prof_mark(EV_BIN0, st);
     launch_bin_scatter(p, splats, radii, mask_main, block_counts, cursor, (unsigned long long*)keys_a,
-                       SliceSel{sliced ? 2 : 0, nullptr, nullptr, 0u, 0u, slice_ctr}, SliceList{nullptr, nullptr}, 0, st);
+                       SliceSel{sliced ? 2 : 0, nullptr, nullptr, 0u, 0u, slice_ctr, sliced ? sat : nullptr,
+                                (const float2*)(geom + G.uv)},
+                       SliceList{nullptr, nullptr}, 0, st);
     DBG(s, st);
     prof_mark(EV_EMIT, st);
     launch_bin_tilesort(ntiles, longest, ranges, (const unsigned long long*)keys_a, vals_b, st);

@@ -44,13 +44,19 @@ __device__ __forceinline__ void bin_rect(float u, float v, int radius, int gx, i
 
 __device__ __forceinline__ bool load_bing(const RasterParams& p, const Splat* __restrict__ splats,
                                           const int32_t* __restrict__ radii, const uint8_t* __restrict__ zbin, int cut,
-                                          int i, BinG& g) {
+                                          const int32_t* __restrict__ sat, const float2* __restrict__ uv, int i, BinG& g) {
   g.x0 = g.y0 = g.x1 = g.y1 = 0;
   g.u = g.v = g.ca = g.cb = g.cc = 0.f; g.thr = -1.f; g.zbits = 0; g.ica = g.icc = 0.f;
   if (i >= p.P) return false;
   if (zbin && (int)zbin[i] > cut) return false;      // not in the near slice (255 = invisible)
   const int radius = radii[i];
   if (radius <= 0) return false;
+  if (sat) {      // second pass: does the rect hold an unfinished tile at all?  (before the Splat is touched)
+    const float2 c = uv[i];
+    int x0, y0, x1, y1;
+    bin_rect(c.x, c.y, radius, p.gx, p.gy, x0, y0, x1, y1);
+    if ((x1 - x0) * (y1 - y0) <= 0 || sat_count(sat, p.gx, x0, y0, x1, y1) == 0) return false;
+  }
   const float4 r0 = reinterpret_cast<const float4*>(splats + i)[0];
   const float4 r1 = reinterpret_cast<const float4*>(splats + i)[1];
   g.u = r0.x; g.v = r0.y; g.ca = r0.z; g.cb = r0.w; g.cc = r1.x;
@@ -118,6 +124,7 @@ template <class F>
 __device__ __forceinline__ void enumerate_balanced(const RasterParams& p, const Splat* __restrict__ splats,
                                                    const int32_t* __restrict__ radii, const int32_t* __restrict__ mask,
                                                    const uint8_t* __restrict__ zbin, int cut, SliceList list, int gpb,
+                                                   const int32_t* __restrict__ sat, const float2* __restrict__ uv,
                                                    WaveBin* wb, F f) {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -132,7 +139,7 @@ __device__ __forceinline__ void enumerate_balanced(const RasterParams& p, const 
       i = (lane < per_wave && j < n_list) ? (int)list.ids[j] : p.P;
     }
     BinG g;
-    const bool live = load_bing(p, splats, radii, zbin, cut, i, g);
+    const bool live = load_bing(p, splats, radii, zbin, cut, sat, uv, i, g);
     const int w = g.x1 - g.x0;
     const uint32_t area = live ? (uint32_t)(w * (g.y1 - g.y0)) : 0u;
     const unsigned long long nz = __builtin_amdgcn_ballot_w64(area > 0u);
@@ -188,8 +195,8 @@ __global__ void __launch_bounds__(256) bin_count_kernel(RasterParams p, const Sp
   if (list.ids && blockIdx.x * gpb >= (int)*list.count) return;     // past the end of the slice work list
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
   __syncthreads();
-  enumerate_balanced(p, splats, radii, mask, nullptr, 0, list, gpb, &s_wb[threadIdx.x >> 6],
-                     [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
+  enumerate_balanced(p, splats, radii, mask, nullptr, 0, list, gpb, sel.mode == 2 ? sel.sat : nullptr, sel.uv,
+                     &s_wb[threadIdx.x >> 6], [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
   __syncthreads();
   // the workgroup's row of per-tile counts is kept for bin_scatter (same Gaussian -> workgroup mapping),
   // which therefore needs only ONE enumeration sweep; a workgroup holds GPB <= 65535 Gaussians, so u16 fits
@@ -266,8 +273,8 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(RasterParams p, const 
     s_cnt[t] = 0;
   }
   __syncthreads();
-  enumerate_balanced(p, splats, radii, mask, nullptr, 0, list, gpb, &s_wb[threadIdx.x >> 6],
-                     [&](int t, uint32_t id, uint32_t zbits) {
+  enumerate_balanced(p, splats, radii, mask, nullptr, 0, list, gpb, sel.mode == 2 ? sel.sat : nullptr, sel.uv,
+                     &s_wb[threadIdx.x >> 6], [&](int t, uint32_t id, uint32_t zbits) {
     const uint32_t base = s_base[t];
     if (base != 0xffffffffu) {
       const uint32_t slot = base + atomicAdd(&s_cnt[t], 1u);

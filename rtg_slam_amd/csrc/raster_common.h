@@ -71,7 +71,17 @@ struct SliceSel {
   uint32_t cap;                  // instance budget of the slice
   uint32_t max_list;             // Gaussian budget of the slice (length of the work list)
   const uint32_t* ctr;           // ctr[0] = tiles the near slice left unfinished
+  // mode 2 only: Gaussian-level reject against the unfinished-tile mask.  sat = summed-area table of that mask
+  // ((gx+1) x (gy+1), launch_mask_sat), uv = projected centres of the geometry pre-pass.  A Gaussian whose tile rect
+  // holds no unfinished tile is neither shaded nor enumerated (its Splat record may be unwritten - never touch it).
+  const int32_t* sat;
+  const float2* uv;
 };
+// number of unfinished tiles inside the tile rect [x0,x1) x [y0,y1)
+__device__ __forceinline__ int sat_count(const int32_t* __restrict__ sat, int gx, int x0, int y0, int x1, int y1) {
+  const int sw = gx + 1;
+  return sat[y1 * sw + x1] - sat[y0 * sw + x1] - sat[y1 * sw + x0] + sat[y0 * sw + x0];
+}
 // blend_fwd role in the two-pass forward
 struct SlicePass {
   int mode;                      // 0 = single pass; 1 = near slice (records which tiles finished); 2 = remaining tiles only

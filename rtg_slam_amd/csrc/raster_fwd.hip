@@ -82,6 +82,12 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       if (i >= p.P) return;
       const int zb = (int)sel.zbin[i];
       if (zb == 255 || zb <= cut) return;        // invisible, or shaded with the slice already
+      if (sel.sat) {                              // no unfinished tile under its rect: bin_count will not read it either
+        const float2 c = uv[i];
+        int x0, y0, x1, y1;
+        tile_rect(c.x, c.y, radii[i], p.gx, p.gy, x0, y0, x1, y1);
+        if (sat_count(sel.sat, p.gx, x0, y0, x1, y1) == 0) return;
+      }
     }
   }
 
@@ -600,7 +606,7 @@ void launch_preprocess_fwd(const RasterParams& p, const float* means, const floa
   if (p.P == 0) return;
   hipLaunchKernelGGL(preprocess_fwd_kernel<0>, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, opac, shs, scales,
                      rots, normal_w, sat, splats, tiles_touched, radii, clamped, out_radii, zero_words, zero_n, zbin,
-                     (float2*)nullptr, SliceList{nullptr, nullptr}, SliceSel{0, nullptr, nullptr, 0u, 0u, nullptr});
+                     (float2*)nullptr, SliceList{nullptr, nullptr}, SliceSel{0, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr});
 }
 // two-pass forward, stage 1: geometry of every Gaussian
 void launch_preprocess_cull(const RasterParams& p, const float* means, const float* scales, const float* rots,
@@ -610,7 +616,7 @@ void launch_preprocess_cull(const RasterParams& p, const float* means, const flo
   hipLaunchKernelGGL(preprocess_fwd_kernel<1>, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, (const float*)nullptr,
                      (const float*)nullptr, scales, rots, (const float*)nullptr, (const int32_t*)nullptr, (Splat*)nullptr,
                      tiles_touched, radii, (uint8_t*)nullptr, out_radii, zero_words, zero_n, zbin, uv,
-                     SliceList{nullptr, nullptr}, SliceSel{0, nullptr, nullptr, 0u, 0u, nullptr});
+                     SliceList{nullptr, nullptr}, SliceSel{0, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr});
 }
 // two-pass forward, stage 2: Splat records of the work list (max_items bounds its length), or of everything else
 void launch_preprocess_shade(const RasterParams& p, const float* means, const float* opac, const float* shs,
