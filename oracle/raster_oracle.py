@@ -239,7 +239,7 @@ def rasterize(s: OracleSettings, means3D, opacities, shs, scales, rotations, nor
     cw = torch.zeros(1, gy * TILE, gx * TILE, dtype=dt)
     dw = torch.zeros(1, gy * TILE, gx * TILE, dtype=dt)
     Tmap = torch.ones(1, gy * TILE, gx * TILE, dtype=dt)
-    aux = dict(num_rendered=0, consumed=0, evaluated_pairs=0)
+    aux = dict(num_rendered=0, consumed=0, evaluated_pairs=0, tile_terminated={})
 
     color_parts = {}
     depth_parts = {}
@@ -326,6 +326,7 @@ def rasterize(s: OracleSettings, means3D, opacities, shs, scales, rotations, nor
                 T = torch.where(any_stop, T_before.gather(0, first_stop[None, :])[0], T_after[-1])
                 done = done | any_stop
 
+            aux["tile_terminated"][t] = bool(done.all())     # every pixel of the tile hit the stop rule (or is off-image)
             ys, xs = ty * TILE, tx * TILE
             color_parts[t] = (C + T[:, None] * bg[None, :]).t().reshape(3, TILE, TILE)
             depth_parts[t] = D.reshape(1, TILE, TILE)

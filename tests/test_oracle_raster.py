@@ -90,3 +90,35 @@ def test_scene_generator_is_deterministic_and_wellformed():
     assert torch.allclose(a["normal"].norm(dim=-1), torch.ones(500), atol=1e-5)
     assert float(a["scales"].min()) >= 1e-4 * 0.99 and float(a["scales"].max()) <= 0.05 * 1.01
     assert {round(float(x), 4) for x in np.unique(a["opacity"].numpy())} <= {0.1, 0.99}
+
+
+def test_depth_prefix_renders_terminated_tiles_identically():
+    """The property the HIP forward's near-slice pass rests on, checked on the oracle: render only
+    the Gaussians in front of a depth cut; every tile whose pixels all terminated inside that subset comes out exactly
+    as in the render of the whole map (the subset's tile list is a prefix of the full depth-ordered list)."""
+    cam = synth.CameraSpec(64, 96, 80.0, 80.0, 47.5, 31.5)
+    g = synth.random_gaussians(3000, cam, seed=21, r_range=(0.03, 0.15))
+    s = ro.make_settings(cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy)
+    args = lambda d: (d["xyz"], d["opacity"], d["shs"], d["scales"], d["rotations"], d["normal"])
+    full = ro.rasterize(s, *args(g))
+    z = g["xyz"][:, 2]                                          # identity camera: view depth
+    checked = 0
+    for q in (0.15, 0.4):
+        keep = z <= torch.quantile(z, q)
+        ids = torch.nonzero(keep).reshape(-1)
+        sub_g = {k: v[keep] for k, v in g.items()}
+        sub, aux = ro.rasterize(s, *args(sub_g), return_aux=True)
+        done_tiles = [t for t, ok in aux["tile_terminated"].items() if ok]
+        assert 0 < len(done_tiles) < len(aux["tile_terminated"]) or q > 0.3
+        gx = (cam.W + 15) // 16
+        for t in done_tiles:
+            ty, tx = divmod(t, gx)
+            sl = (slice(None), slice(ty * 16, min(ty * 16 + 16, cam.H)), slice(tx * 16, min(tx * 16 + 16, cam.W)))
+            for k in (0, 1, 4, 5, 6):                           # colour, depth, weights, T
+                assert torch.equal(sub[k][sl], full[k][sl]), (q, t, k)
+            for k in (2, 3):                                    # index maps: subset ids -> map ids
+                si = sub[k][sl].long()
+                mapped = torch.where(si >= 0, ids[si.clamp_min(0)], si)
+                assert torch.equal(mapped.to(torch.int32), full[k][sl]), (q, t, k)
+            checked += 1
+    assert checked > 0
