@@ -119,3 +119,25 @@ def test_shard_rows_partition():
         for w in (1, 2, 4, 8):
             per, npad = mo.shard_rows(N, w)
             assert per * w == npad and npad >= N and npad - N < w
+
+
+def test_adam_leaves_never_touched_rows_bitwise_unchanged():
+    """The invariant the row-skipping HIP Adam relies on (rtgs_fused_adam_rows): a row whose gradient is zero and whose
+    moments never left zero is a fixed point of the dense update, whatever the step count and eps."""
+    from tests.dist_util import adam_reference
+    from rtg_slam_amd import map_optim as mo
+    gen = torch.Generator().manual_seed(0)
+    p = torch.randn(64, 59, generator=gen)
+    g = torch.randn(64, 59, generator=gen)
+    live = torch.rand(64, generator=gen) < 0.3
+    g[~live] = 0.0
+    g[3] = -0.0                                              # negative zero is a zero gradient too
+    live[3] = False
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    p0 = p.clone()
+    lr = mo.default_lr_columns() + 1e-3
+    for step in range(1, 6):
+        adam_reference(p, g, m, v, lr, step, 1e-15)
+    assert torch.equal(p[~live], p0[~live])
+    assert not m[~live].any() and not v[~live].any()
+    assert (p[live] != p0[live]).any()
