@@ -31,7 +31,9 @@ Frozen decisions (each one is a choice, because the source is absent):
   * the 1.3*tanfov clamp of t.x/t.z, t.y/t.z makes t.x / t.y constants in the
     backward pass (upstream 3DGS behaviour)
   * alpha = min(0.99, o*G); skip power > 0 or alpha < 1/255; stop BEFORE the
-    Gaussian that would drive T below T_threshold
+    Gaussian that would drive T below T_threshold; in the backward pass the
+    clamp is transparent (d alpha / d(oG) = 1 also where oG > 0.99), as in the
+    upstream 3DGS backward the module derives from
   * colour index/weight = first arg-max of alpha*T over blended Gaussians
   * depth = ray/plane intersection of the FIRST blended Gaussian with
     alpha > opaque_threshold, |cos(ray, n)| > normal_threshold, z_hit > 0 and
@@ -284,7 +286,10 @@ def rasterize(s: OracleSettings, means3D, opacities, shs, scales, rotations, nor
                 power = (-0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy)
                          - con[:, 1:2] * dx * dy)
                 o = pre["opacity"][ids][:, None]
-                alpha = torch.clamp(o * torch.exp(power), max=0.99)
+                raw = o * torch.exp(power.clamp(max=0.0))
+                # alpha = min(0.99, o G); the clamp's gradient is PASSED THROUGH (upstream 3DGS backward computes
+                # dL/dG = o dL/dalpha, dL/do = G dL/dalpha with no clamp mask - SURVEY.md Appendix B "Backward")
+                alpha = raw + (raw.clamp(max=0.99) - raw).detach()
                 ok = (power <= 0) & (alpha >= 1.0 / 255.0) & (~done)[None, :]
                 a_eff = torch.where(ok, alpha, torch.zeros_like(alpha))
                 one_m = 1.0 - a_eff

@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const float dL_dalpha = Tk[k] * cg[k] - Sg[k] * ia[k];
-        gda[k] = (valid[k] && oG[k] <= 0.99f) ? G[k] * dL_dalpha : 0.f;   // d min(0.99, oG)/d(oG): autograd of clamp
+        gda[k] = valid[k] ? G[k] * dL_dalpha : 0.f;   // clamp of alpha is transparent in the backward (upstream 3DGS)
         const float gdl = gda[k] * r1[k].y;
         float v[8];
         v[0] = gdl * (-r0[k].z * dx[k] - r0[k].w * dy[k]);
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256) blend_bwd_lanes_kernel(
         const float Qincl = carry.y + wave_incl_scan_add(w * cg);
         const float Sg = pg.w - Qincl;                            // (colour strictly behind) . g + T_final (bg . g)
         const float dL_dalpha = Tk * cg - Sg * ia;
-        const float gda = (valid && oG <= 0.99f) ? G * dL_dalpha : 0.f;   // d min(0.99, oG)/d(oG): autograd of clamp
+        const float gda = valid ? G * dL_dalpha : 0.f;   // clamp of alpha is transparent in the backward (upstream 3DGS)
         const float gdl = gda * eo;
         acc[0] += gdl * (-eca * dx - ecb * dy);
         acc[1] += gdl * (-ecc * dy - ecb * dx);

@@ -1,0 +1,141 @@
+"""Parity of the HIP rasterizer at BASELINE.json's own sizes, and against the independent pixel reference.
+
+* configs[1]: 200 000 Gaussians, 640x480, forward + backward vs oracle/raster_oracle.py;
+* the headline scene: 1 200 000 Gaussians, 1200x680, forward + backward vs the oracle;
+  both on a tile-masked subset (the oracle blends only masked tiles, so it stays a few seconds of CPU), with the
+  near-slice two-pass forward off, forced on and in automatic mode - the HIP path that produces the headline
+  number is compared with the ORACLE, not only with the single-pass HIP forward;
+* the unmasked HIP render of the same scene is bit-identical to the masked one on the masked tiles (so the
+  oracle comparison on the subset speaks for the full-image render);
+* small scenes against oracle/raster_pixel_ref.py (float64, per pixel, no tiles, hand-written backward), including
+  opacity 1.0 where o G > 0.99 and the alpha clamp is active.
+
+Tolerances: north_star - 1e-4 abs on RGB / depth, 1e-3 relative (to the tensor max) on gradients; discontinuous
+decisions bound the FRACTION of differing pixels (<= 2e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from rtg_slam_amd import synth
+from tests import raster_util as ru
+
+pytestmark = pytest.mark.gpu
+
+SMALL = synth.CameraSpec(64, 96, 80.0, 80.0, 47.5, 31.5)
+ODD = synth.CameraSpec(70, 101, 90.0, 85.0, 49.0, 36.0)
+
+
+def _spread_mask(cam, n_tiles):
+    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+    m = torch.zeros(gy * gx, dtype=torch.int32)
+    m[torch.linspace(0, gy * gx - 1, n_tiles).long()] = 1
+    return m.view(gy, gx)
+
+
+def _grads(cam, seed):
+    gen = torch.Generator().manual_seed(seed)
+    return torch.randn(3, cam.H, cam.W, generator=gen), torch.randn(1, cam.H, cam.W, generator=gen)
+
+
+_cache = {}
+
+
+def _big_case(name):
+    """(scene, settings, mask, upstream grads, oracle outputs, oracle grads), oracle evaluated once per size."""
+    if name not in _cache:
+        cam, N, n_tiles = {"config2": (synth.CONFIG2, 200_000, 96), "headline": (synth.REPLICA, 1_200_000, 128)}[name]
+        g, s = ru.make_scene(N, cam, seed=2024)
+        mask = _spread_mask(cam, n_tiles)
+        grads = _grads(cam, 11)
+        out_o, gd_o, aux = ru.oracle_run(s, g, tile_mask=mask, grads=grads)
+        assert aux["num_rendered"] > 0
+        _cache[name] = (cam, g, s, mask, grads, out_o, gd_o)
+    return _cache[name]
+
+
+def _check_maps(out_h, out_o, max_bad=2e-3):
+    names = ["color", "depth", "color_index", "depth_index", "color_weight", "depth_weight", "T"]
+    for k in (0, 1, 4, 5, 6):
+        bad = ru.frac_bad(out_h[k], out_o[k], 1e-4)
+        assert bad <= max_bad, (names[k], bad)
+    for k in (2, 3):
+        assert float((out_h[k] != out_o[k]).float().mean()) <= max_bad, names[k]
+
+
+def _check_grads(gd_h, gd_o):
+    for k in ru.FIELDS:
+        ref = gd_o[k]
+        scale = float(ref.abs().max()) + 1e-12
+        # a pixel that flips a discontinuous decision moves the gradient of the few Gaussians it sees: bound the
+        # fraction of rows outside tolerance instead of the max
+        row_err = (gd_h[k] - ref).abs().reshape(ref.shape[0], -1).max(dim=1).values / scale
+        touched = ref.reshape(ref.shape[0], -1).abs().sum(1) > 0
+        assert float((row_err > 1e-3).float().sum()) <= max(2.0, 2e-3 * float(touched.sum())), (k, float(row_err.max()))
+        untouched = ~touched
+        assert float(gd_h[k].reshape(ref.shape[0], -1)[untouched].abs().max() if untouched.any() else 0.0) <= 1e-3 * scale, k
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("name", ["config2", "headline"])
+def test_parity_at_baseline_sizes(name, mode):
+    from rtg_slam_amd import _lib
+    lib = _lib.load()
+    cam, g, s, mask, grads, out_o, gd_o = _big_case(name)
+    try:
+        lib.rtgs_raster_set_near_slice(mode, 0)
+        out_h, gd_h = ru.hip_run(s, g, tile_mask=mask, grads=grads)
+        import ctypes as C
+        st = (C.c_int64 * 4)()
+        lib.rtgs_raster_last_slice_stats(st)
+        if mode == 0:
+            assert st[0] == 0
+        if mode == 1:
+            assert st[0] == 1
+    finally:
+        lib.rtgs_raster_set_near_slice(2, 384)
+    _check_maps(out_h, out_o)
+    _check_grads(gd_h, gd_o)
+    print(name, "mode", mode, "slice stats", [int(v) for v in st])
+
+
+@pytest.mark.parametrize("name", ["config2", "headline"])
+def test_unmasked_render_equals_masked_render_on_the_masked_tiles(name):
+    cam, g, s, mask, grads, out_o, _ = _big_case(name)
+    out_full, _ = ru.hip_run(s, g)
+    out_mask, _ = ru.hip_run(s, g, tile_mask=mask)
+    pix = torch.nn.functional.interpolate(mask[None, None].float(), scale_factor=16, mode="nearest")[0, 0, :cam.H, :cam.W] > 0
+    for k, (a, b) in enumerate(zip(out_full, out_mask)):
+        assert torch.equal(a[:, pix], b[:, pix]), k
+    # and the full render agrees with the oracle there too (bit-identical to the masked render, which is checked above)
+    for k in (0, 1, 6):
+        assert ru.frac_bad(out_full[k][:, pix], out_o[k][:, pix], 1e-4) <= 2e-3, k
+
+
+def _pixel_ref(s, g, mask, grads):
+    from oracle import raster_pixel_ref as pr
+    out_p, gd_p = pr.render(s, g["xyz"], g["opacity"], g["shs"], g["scales"], g["rotations"], g["normal"], mask,
+                            g_color=grads[0], g_depth=grads[1])
+    out_p = tuple(torch.from_numpy(np.ascontiguousarray(o)) for o in out_p)
+    out_p = tuple(o.float() if o.dtype == torch.float64 else o for o in out_p)
+    gd_p = {k: torch.from_numpy(v).float().reshape(g[k].shape) for k, v in gd_p.items()}
+    return out_p, gd_p
+
+
+@pytest.mark.parametrize("cam,N,seed,pose,opaque", [(SMALL, 300, 1, None, False), (ODD, 1500, 2, 7, False),
+                                                    (SMALL, 80, 8, None, True), (ODD, 2000, 4, 3, True)])
+def test_hip_matches_independent_pixel_reference(cam, N, seed, pose, opaque):
+    """HIP (float32) vs the float64 per-pixel evaluator that shares no code with raster_oracle.py.  `opaque`
+    scenes set every opacity to 1.0 so that o G > 0.99 near the centres: the clamp's gradient passes through."""
+    kw = dict(r_range=(0.2, 0.6)) if (opaque and N < 200) else {}
+    g, s = ru.make_scene(N, cam, seed=seed, pose_seed=pose, **kw)
+    if opaque:
+        g["opacity"] = torch.ones_like(g["opacity"])
+    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+    mask = None if seed % 2 else (torch.rand(gy, gx, generator=torch.Generator().manual_seed(seed)) < 0.7).int()
+    grads = _grads(cam, seed)
+    out_p, gd_p = _pixel_ref(s, g, mask, grads)
+    out_h, gd_h = ru.hip_run(s, g, tile_mask=mask, grads=grads)
+    _check_maps(out_h, out_p)
+    _check_grads(gd_h, gd_p)
+    if opaque:
+        assert int((out_p[4] >= 0.99 - 1e-6).sum()) > 0          # the clamp was active somewhere
