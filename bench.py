@@ -6,9 +6,8 @@ BASELINE.json (1.2 M Gaussians, 1200x680):
     1 ICP frame-to-model track (3 pyramid levels x 5 Gauss-Newton iterations, SLAM/icp.py)
   + 1 map-optimisation iteration (rasterizer forward, L1 colour + depth loss, rasterizer
     backward, fused Adam) over the whole Gaussian set (mapper.py:176-205).
-`value` = frames / s over all ranks (weak scaling: every rank tracks and renders its own view of
-the replicated map; per-Gaussian gradients are reduce-scattered over RCCL, Adam runs on the
-rank's row shard, updated rows are all-gathered).
+`value` = frames / s over all ranks (weak scaling: every rank tracks and renders its own view; see
+`config.parallelism` in the JSON line and DESIGN.md section 5 for what is exchanged).
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) with `roofline` for the
 dominant kernel and `cpu_baseline` (oracle on the host cores, bounded sample).
@@ -38,6 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gaussians", type=int, default=1_200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-surface", action="store_true", help="skip the surface-shaped 1.2 M scene leg")
     ap.add_argument("--cpu-tiles", type=int, default=128, help="tiles blended by the CPU oracle sample")
     return ap.parse_args()
 
@@ -175,117 +175,49 @@ def main():
 
     result = None
     if rank == 0:
-        # ---- per-kernel stage timing (HIP events on the launch stream) + work counters ---------
-        counters = torch.zeros(2, dtype=torch.int64, device=dev)
         lib.rtgs_raster_set_profiling(1)
-        acc = [0.0] * 10
-        nprof = max(3, min(10, args.steps))
+        prof = profile_scene(lib, mo, rast, opt, N, cam, tile_mask, gt_color, gt_depth, dev, max(3, min(10, args.steps)))
         icp_ms = 0.0
-        consumed = pairs = 0
-        rows_touched = rows_cleared = None
-        slice_stats = None
-        R = 0
-        for i in range(nprof):
-            counters.zero_()
-            lib.rtgs_raster_set_counters(C.c_void_p(counters.data_ptr()))
-            lv = {nm: opt.state[nm]["p"][:N].detach().clone().requires_grad_(True) for nm in ("xyz", "shs", "raw8")}
-            if opt.grad_rows is not None:         # same backward as opt.step(): persistent rows + row states
-                opt.grad_rows.begin_step()
-            gd = mo.activate8_hip(lv["raw8"], opt.grad_rows)
-            gd["xyz"], gd["shs"], gd["grad_rows"] = lv["xyz"], lv["shs"].view(N, 16, 3), opt.grad_rows
-            loss = loss_fn(gd)
-            lib.rtgs_raster_set_counters(None)
-            loss.backward()
-            torch.cuda.synchronize(dev)
-            ms = (C.c_float * 10)()
-            lib.rtgs_raster_last_timings(ms)
-            for k in range(10):
-                acc[k] += max(0.0, ms[k])
-            sl = (C.c_int64 * 4)()
-            lib.rtgs_raster_last_slice_stats(sl)
-            slice_stats = {"used": int(sl[0]), "instances": int(sl[1]), "tiles_finished": int(sl[2]),
-                           "tiles_left_to_pass2": int(sl[3])}
-            st = (C.c_int64 * 8)()
-            lib.rtgs_raster_last_stats(st)
-            R = int(st[0])
-            cc = counters.cpu()
-            consumed, pairs = int(cc[0]), int(cc[1])
-            if opt.grad_rows is not None:
-                rows_touched = int((opt.grad_rows.row_state == 1).sum())
-                rows_cleared = int((opt.grad_rows.row_state == 2).sum())
+        for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             vp1, np1 = hicp.build_pyramids(d1, K, 3)
             hicp.icp_track(vp1, np1, vp0, np0, K, [0.25, 0.5, 1.0], [5, 5, 5], 0.1, cos_thr, 1e-4)
             e1.record()
             torch.cuda.synchronize(dev)
-            icp_ms += e0.elapsed_time(e1)
+            icp_ms += e0.elapsed_time(e1) / 5
         # the op as local_optimize uses it: ~30 % of the tiles switched on
         gyx = tile_mask.numel()
         m30 = torch.zeros(gyx, dtype=torch.int32, device=dev)
         m30[torch.linspace(0, gyx - 1, int(0.3 * gyx)).long().to(dev)] = 1
-        m30 = m30.view_as(tile_mask)
-        acc30 = [0.0] * 10
-        for i in range(4):
-            lv = {nm: opt.state[nm]["p"][:N].detach().clone().requires_grad_(True) for nm in ("xyz", "shs", "raw8")}
-            if opt.grad_rows is not None:
-                opt.grad_rows.begin_step()
-            gd = mo.activate8_hip(lv["raw8"], opt.grad_rows)
-            gd["xyz"], gd["shs"] = lv["xyz"], lv["shs"].view(N, 16, 3)
-            out30 = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
-                         rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=m30,
-                         grad_rows=opt.grad_rows)
-            mo.slam_losses_hip(out30, gt_color, gt_depth).backward()
+        prof30 = profile_scene(lib, mo, rast, opt, N, cam, m30.view_as(tile_mask), gt_color, gt_depth, dev, 4)
+        # A SURFACE-shaped map of the same size (what RTG-SLAM's mapper builds: one layer of opaque discs on the room's
+        # walls, synth.surface_gaussians) - reported beside the headline scene, whose depth complexity the near slice,
+        # the row-state backward and the row-skipping Adam exploit
+        surface = None
+        if not args.no_surface:
+            gs = synth.surface_gaussians(N, cam, seed=7)
+            opt_s = mo.ShardedMapOptimizer(mo.pack_from_activated({k: v.to(dev) for k, v in gs.items()}),
+                                           lr_col=mo.default_lr_columns() * 1e-4)
+            gt_d_s = synth.box_room_depth(cam, torch.eye(4, dtype=torch.float64), bump=0.0).to(dev).reshape(1, cam.H, cam.W)
+            for _ in range(20):
+                opt_s.step_slam(rs, gt_color, gt_d_s, tile_mask)
             torch.cuda.synchronize(dev)
-            ms = (C.c_float * 10)()
-            lib.rtgs_raster_last_timings(ms)
-            if i >= 1:
-                for k in range(10):
-                    acc30[k] += max(0.0, ms[k]) / 3
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                opt_s.step_slam(rs, gt_color, gt_d_s, tile_mask)
+            torch.cuda.synchronize(dev)
+            map_iter_ms = 1e3 * (time.perf_counter() - ts) / args.steps
+            surface = profile_scene(lib, mo, rast, opt_s, N, cam, tile_mask, gt_color, gt_d_s, dev, 5)
+            surface["map_iteration_ms"] = round(map_iter_ms, 4)
+            surface["workload"] = (f"{N} opaque discs on the walls of the 5 x 3 x 6 m box room (one layer, opacity 0.99, radius = "
+                                   "sqrt(area / N) clipped to [0.001, 0.05] m), camera inside, all tiles")
+            del opt_s
         lib.rtgs_raster_set_profiling(0)
-        stage = [a / nprof for a in acc]
-        # With the near-slice pass on (rtgs_raster_set_near_slice), stages 1-5 are the SECOND pass (tiles the slice left
-        # unfinished - none in this scene) and stages 8-9 the slice itself.
-        names = ["preprocess_fwd", "bin_count", "bin_scatter", "bin_tilesort", "tile_ranges_fallback_only",
-                 "blend_fwd", "blend_bwd", "preprocess_bwd", "near_slice_binning", "near_slice_blend_fwd"]
-        sliced = bool(slice_stats and slice_stats["used"])
-        Px = cam.H * cam.W
-        Nv = N   # upper bound; culled rows write nothing
-        # algorithmic bytes per launch (I := instances the tile walk consumes)
-        alg = {
-            "preprocess_fwd": 248 * N + 64 * Nv,
-            "bin_count": 68 * N,
-            "bin_scatter": 68 * N + 8 * R,
-            "bin_tilesort": 12 * R,
-            ("near_slice_blend_fwd" if sliced else "blend_fwd"): 68 * consumed + 40 * Px,
-            "blend_bwd": 68 * consumed + 28 * Px + 36 * consumed,
-            "preprocess_bwd": 248 * N + 64 * N + 236 * N,
-        }
-        if sliced:
-            # geometry-only pre-pass: means + scales + rotations in (40 B), radius x2 + rect area + depth bin + (u, v) out
-            alg["preprocess_fwd"] = (40 + 25) * N
-            # second pass: count exits at once when the slice finished every tile (reads the tile counters only)
-            R2 = R - slice_stats["instances"]
-            alg["bin_count"] = 68 * N if slice_stats["tiles_left_to_pass2"] else 0
-            alg["bin_scatter"] = 68 * N + 8 * R2
-            alg["bin_tilesort"] = 12 * R2
-            # slice: depth bin + rect area per Gaussian (histogram), depth bin per Gaussian twice (count, scatter),
-            # 8-B key write + 8-B read + 4-B write per slice instance; the slice's Splat reads are not counted
-            # (work-list compaction, the slice's Splat shading, count, scatter, sort)
-            alg["near_slice_binning"] = 5 * N + N + 20 * slice_stats["instances"]
-        if opt.grad_rows is not None:
-            # row-state backward: 2 state bytes per Gaussian; only rows that change are read / written
-            # (inputs 248 B + SplatGrad 64 B read and 64 B re-zeroed + 236 B of gradient rows, also for rows being cleared)
-            alg["preprocess_bwd"] = 2 * N + (248 + 128 + 236) * rows_touched + 236 * rows_cleared
-        kernels = {}
-        for nm, ms_ in zip(names, stage):
-            if nm in alg and ms_ > 0 and alg[nm] > 0:
-                kernels[nm] = {"ms": round(ms_, 4), "alg_MB": round(alg[nm] / 1e6, 2),
-                               "GBps": round(alg[nm] / (ms_ * 1e-3) / 1e9, 1)}
-            else:
-                kernels[nm] = {"ms": round(ms_, 4)}
-        dom = max((n for n in names if n in alg and n != "near_slice_binning"), key=lambda n: stage[names.index(n)])
-        dom_ms = stage[names.index(dom)]
+        stage, names, kernels = prof["stage"], prof["names"], prof["kernels"]
+        rows_touched, R, consumed, pairs, slice_stats = (prof["rows_touched"], prof["instances"], prof["consumed"],
+                                                        prof["pairs"], prof["near_slice"])
+        dom, dom_ms, alg = prof["dominant"], prof["dominant_ms"], prof["alg"]
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -316,14 +248,106 @@ def main():
                        "pixel_pairs_evaluated": pairs,
                        "parallelism": f"dp{world}: replicated map and Adam state, per-rank view, RCCL all-gather of the gradient rows that exist (sparse), identical Adam step on every rank"},
             "raster_fwd_ms": round(sum(stage[:6]) + sum(stage[8:]), 4), "raster_bwd_ms": round(sum(stage[6:8]), 4),
-            "raster_fwd_bwd_ms": round(sum(stage), 4), "icp_track_ms": round(icp_ms / nprof, 4),
-            "raster_fwd_bwd_ms_30pct_tiles": round(sum(acc30), 4),
+            "raster_fwd_bwd_ms": round(sum(stage), 4), "icp_track_ms": round(icp_ms, 4),
+            "raster_fwd_bwd_ms_30pct_tiles": round(sum(prof30["stage"]), 4),
             "near_slice": slice_stats, "kernels": kernels, "roofline": roofline, "cpu_baseline": cpu,
+            "surface_scene": None if surface is None else {k: surface[k] for k in (
+                "workload", "map_iteration_ms", "raster_fwd_ms", "raster_bwd_ms", "raster_fwd_bwd_ms", "instances", "consumed",
+                "consumed_fraction", "rows_touched", "near_slice", "kernels")},
         }
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def profile_scene(lib, mo, rast, opt, N, cam, tile_mask, gt_color, gt_depth, dev, nprof):
+    """Per-stage HIP-event timings (on the launch stream, inside the library), work counters and algorithmic-byte
+    rooflines of the rasterizer forward + backward on the optimiser's current map, through the autograd path."""
+    counters = torch.zeros(2, dtype=torch.int64, device=dev)
+    acc = [0.0] * 10
+    consumed = pairs = R = 0
+    rows_touched = rows_cleared = 0
+    slice_stats = None
+    for i in range(nprof + 1):                                     # first pass is a warm-up
+        counters.zero_()
+        lib.rtgs_raster_set_counters(C.c_void_p(counters.data_ptr()))
+        lv = {nm: opt.state[nm]["p"][:N].detach().clone().requires_grad_(True) for nm in ("xyz", "shs", "raw8")}
+        opt.grad_rows.begin_step()                                 # same backward as opt.step(): persistent rows + row states
+        gd = mo.activate8_hip(lv["raw8"], opt.grad_rows)
+        gd["xyz"], gd["shs"] = lv["xyz"], lv["shs"].view(N, 16, 3)
+        out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
+                   rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=tile_mask,
+                   grad_rows=opt.grad_rows)
+        loss = mo.slam_losses_hip(out, gt_color, gt_depth)
+        lib.rtgs_raster_set_counters(None)
+        loss.backward()
+        torch.cuda.synchronize(dev)
+        if i == 0:
+            continue
+        ms = (C.c_float * 10)()
+        lib.rtgs_raster_last_timings(ms)
+        for k in range(10):
+            acc[k] += max(0.0, ms[k]) / nprof
+        sl = (C.c_int64 * 4)()
+        lib.rtgs_raster_last_slice_stats(sl)
+        slice_stats = {"used": int(sl[0]), "instances": int(sl[1]), "tiles_finished": int(sl[2]),
+                       "tiles_left_to_pass2": int(sl[3])}
+        st = (C.c_int64 * 8)()
+        lib.rtgs_raster_last_stats(st)
+        R = int(st[0])
+        cc = counters.cpu()
+        consumed, pairs = int(cc[0]), int(cc[1])
+        rows_touched = int((opt.grad_rows.row_state == 1).sum())
+        rows_cleared = int((opt.grad_rows.row_state == 2).sum())
+    stage = acc
+    # With the near-slice pass on, stages 1-5 are the SECOND pass (tiles the slice left unfinished) and 8-9 the slice.
+    names = ["preprocess_fwd", "bin_count", "bin_scatter", "bin_tilesort", "tile_ranges_fallback_only",
+             "blend_fwd", "blend_bwd", "preprocess_bwd", "near_slice_binning", "near_slice_blend_fwd"]
+    sliced = bool(slice_stats and slice_stats["used"])
+    pass2 = bool(sliced and slice_stats["tiles_left_to_pass2"])
+    Px = cam.H * cam.W
+    # algorithmic bytes per launch (SURVEY.md 8d; I := instances the tile walks consume)
+    alg = {
+        "preprocess_fwd": 248 * N + 64 * N,
+        "bin_count": 68 * N,
+        "bin_scatter": 68 * N + 8 * R,
+        "bin_tilesort": 12 * R,
+        "blend_fwd": 68 * consumed + 40 * Px,
+        "blend_bwd": 68 * consumed + 28 * Px + 36 * consumed,
+        "preprocess_bwd": 2 * N + (248 + 128 + 236) * rows_touched + 236 * rows_cleared,
+    }
+    if sliced:
+        # geometry-only pre-pass: means + scales + rotations in (40 B), radius x2 + rect area + depth bin + (u, v) out
+        alg["preprocess_fwd"] = (40 + 25) * N
+        R2 = R - slice_stats["instances"]
+        alg["bin_count"] = 68 * N if pass2 else 0
+        alg["bin_scatter"] = (68 * N + 8 * R2) if pass2 else 0
+        alg["bin_tilesort"] = 12 * R2
+        # the tile walks of both passes share the consumed-instance counter: attribute it to the pass that dominates
+        if pass2 and stage[5] > stage[9]:
+            alg["near_slice_blend_fwd"] = 40 * Px
+        else:
+            alg["near_slice_blend_fwd"] = alg.pop("blend_fwd")
+            if pass2:
+                alg["blend_fwd"] = 40 * Px
+        # slice: depth bin + rect area + radius per Gaussian (histograms), depth bin per Gaussian twice, 8-B key write +
+        # 8-B read + 4-B write per slice instance
+        alg["near_slice_binning"] = 9 * N + N + 20 * slice_stats["instances"]
+    kernels = {}
+    for nm, ms_ in zip(names, stage):
+        if nm in alg and ms_ > 0 and alg[nm] > 0:
+            kernels[nm] = {"ms": round(ms_, 4), "alg_MB": round(alg[nm] / 1e6, 2), "GBps": round(alg[nm] / (ms_ * 1e-3) / 1e9, 1),
+                           "frac_of_hbm_peak": round(alg[nm] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        else:
+            kernels[nm] = {"ms": round(ms_, 4)}
+    blend_like = [n for n in names if n in alg and n != "near_slice_binning" and stage[names.index(n)] > 0]
+    dom = max(blend_like, key=lambda n: stage[names.index(n)])
+    return {"stage": stage, "names": names, "kernels": kernels, "alg": alg, "dominant": dom,
+            "dominant_ms": stage[names.index(dom)], "instances": R, "consumed": consumed, "pairs": pairs,
+            "consumed_fraction": round(consumed / max(R, 1), 4), "rows_touched": rows_touched, "near_slice": slice_stats,
+            "raster_fwd_ms": round(sum(stage[:6]) + sum(stage[8:]), 4), "raster_bwd_ms": round(sum(stage[6:8]), 4),
+            "raster_fwd_bwd_ms": round(sum(stage), 4)}
 
 
 def cpu_baseline(g, cam, n_tiles, d0, d1, n_sample=150_000):

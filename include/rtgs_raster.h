@@ -56,6 +56,17 @@ typedef struct rtgs_raster_settings {
   float T_threshold;
 } rtgs_raster_settings;
 
+/* Context: everything the library remembers between calls - the near-slice mode and budget, the statistics /
+ * counters / stage timings of the last forward and backward, the pinned words of the forward's host sync.  The plain
+ * entry points below use ONE process-wide default context and are meant for a single calling thread (plus autograd's
+ * backward thread, which runs strictly after its forward).  A process that renders from several threads creates one
+ * context per thread (rtgs_ctx_create) and calls the *_ctx variants, which take the context as first argument and
+ * are otherwise identical; ctx == NULL selects the default context.  A context belongs to one device.  New contexts
+ * start from the default context's near-slice mode and budget (environment: RTGS_NEAR_SLICE, RTGS_NEAR_SLICE_BUDGET). */
+typedef struct rtgs_ctx rtgs_ctx;
+rtgs_ctx* rtgs_ctx_create(void);
+void rtgs_ctx_destroy(rtgs_ctx* ctx);
+
 /* Resize callback: return a device allocation of at least `bytes` bytes, 256-byte aligned,
  * that stays alive until the matching backward has run (mirrors the resize-lambdas over
  * torch::empty byte tensors of the reference binding). */
@@ -103,6 +114,29 @@ int rtgs_raster_backward(const rtgs_raster_settings* settings, int32_t P, int32_
 
 size_t rtgs_raster_backward_scratch_bytes(int32_t P);
 
+int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* settings, int32_t P, int32_t sh_coeffs,
+                            const float* means3D, const float* opacities, const float* shs,
+                            const float* scales, const float* rotations, const float* normal_w,
+                            const int32_t* tile_mask,
+                            float* out_color, float* out_depth, int32_t* out_color_index,
+                            int32_t* out_depth_index, float* out_color_weight,
+                            float* out_depth_weight, float* out_T, int32_t* out_radii,
+                            rtgs_resize_fn geom_resize, void* geom_user,
+                            rtgs_resize_fn binning_resize, void* binning_user,
+                            rtgs_resize_fn image_resize, void* image_user,
+                            int64_t* num_rendered_host, void* stream);
+int rtgs_raster_backward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* settings, int32_t P, int32_t sh_coeffs,
+                             int64_t num_rendered,
+                             const float* means3D, const float* opacities, const float* shs,
+                             const float* scales, const float* rotations, const float* normal_w,
+                             const void* geom_buffer, const void* binning_buffer,
+                             const void* image_buffer, const float* out_color, const float* out_T,
+                             const int32_t* out_depth_index,
+                             const float* dL_dcolor, const float* dL_ddepth,
+                             float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
+                             float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
+                             void* grad_scratch, void* stream);
+
 /* Row-state backward (an extension, not part of the reference contract): same arithmetic, but for callers that
  * keep the six gradient tensors, `grad_scratch` and one byte per Gaussian, `row_state[P]`, ALIVE between calls -
  * all zero-initialised once by the caller.  Invariant on entry and exit: a gradient row is all-zero unless its
@@ -124,23 +158,39 @@ int rtgs_raster_backward_rows(const rtgs_raster_settings* settings, int32_t P, i
                               float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
                               void* grad_scratch, uint8_t* row_state, void* stream);
 
-/* Sizes the forward will request through the callbacks (for pre-allocation / accounting). */
+int rtgs_raster_backward_rows_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* settings, int32_t P, int32_t sh_coeffs,
+                                  int64_t num_rendered,
+                                  const float* means3D, const float* opacities, const float* shs,
+                                  const float* scales, const float* rotations, const float* normal_w,
+                                  const void* geom_buffer, const void* binning_buffer,
+                                  const void* image_buffer, const float* out_color, const float* out_T,
+                                  const int32_t* out_depth_index,
+                                  const float* dL_dcolor, const float* dL_ddepth,
+                                  float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
+                                  float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
+                                  void* grad_scratch, uint8_t* row_state, void* stream);
+
+/* Sizes the forward will request through the callbacks (for pre-allocation / accounting).  The geometry buffer's size
+ * depends on the context's near-slice budget; its layout is such that a backward never needs to know that budget. */
 size_t rtgs_raster_geom_bytes(int32_t P, int32_t image_height, int32_t image_width);
+size_t rtgs_raster_geom_bytes_ctx(rtgs_ctx* ctx, int32_t P, int32_t image_height, int32_t image_width);
 size_t rtgs_raster_binning_bytes(int64_t num_rendered, int32_t image_height, int32_t image_width);
 size_t rtgs_raster_image_bytes(int32_t image_height, int32_t image_width);
 
-/* Per-call statistics of the LAST forward in this process (host values, for roofline
+/* Per-call statistics of the LAST forward of the context (host values, for roofline
  * accounting): [0] num_rendered, [1] sort bits (fallback path), [2] tiles, [3..5] scratch bytes,
  * [6] 1 = LDS tile-sort binning / 0 = global radix-sort fallback, [7] longest tile list. */
 int rtgs_raster_last_stats(int64_t* stats8_host);
+int rtgs_raster_last_stats_ctx(rtgs_ctx* ctx, int64_t* stats8_host);
 
 /* Device-side counters of work actually done by blend_fwd (instances consumed before the
  * per-tile early exit).  `counters` = device int64[2] zeroed by the caller, or NULL to
- * disable.  Process-wide, sticky until reset with NULL (measurement aid, not thread-safe). */
+ * disable.  Per context, sticky until reset with NULL (measurement aid). */
 void rtgs_raster_set_counters(void* counters);
+void rtgs_raster_set_counters_ctx(rtgs_ctx* ctx, void* counters);
 
-/* Optional per-stage HIP-event timing of the calls made by this process (off by default;
- * measurement aid for single-threaded benches - autograd may run backward on another thread).
+/* Optional per-stage HIP-event timing of the calls made through the context (off by default;
+ * measurement aid - the backward of a forward must use the same context for its stages to show up).
  * rtgs_raster_last_timings fills ms10_host[0..7] with the last forward/backward's stage
  * durations in milliseconds (-1 = stage did not run):
  *   [0] preprocess_fwd (+ mask SAT)  [1] bin_count + tilescan (fallback: scan)  [2] bin_scatter
@@ -149,22 +199,29 @@ void rtgs_raster_set_counters(void* counters);
  *   [8] near-slice binning (histogram, count, scan, scatter, sort)  [9] near-slice blend_fwd
  * With the near-slice pass on, [1]..[5] describe the second pass (tiles the slice left unfinished). */
 void rtgs_raster_set_profiling(int enable);
+void rtgs_raster_set_profiling_ctx(rtgs_ctx* ctx, int enable);
 /* Near-slice (occlusion) pass of the forward.  The nearest Gaussians - as many depth bins as fit a budget of
  * `budget_per_tile` x tiles instances - are binned, sorted and blended first; a tile whose every pixel reaches
  * T < T_threshold inside that slice is final (the slice list is a prefix of the tile's full depth-ordered list, so
  * the walk would have stopped there anyway); only the other tiles are binned against the whole map.  Outputs are
  * bit-identical to the single-pass forward; the backward walks each tile's list of the pass that finished it.
- * mode 0 = off, 1 = always, 2 = automatic (default: maps of >= 100 000 Gaussians, suspended for 16 calls after a
- * call in which the slice finished fewer tiles than it left).  budget_per_tile <= 0 keeps the current budget
- * (default 384).  Environment overrides at load time: RTGS_NEAR_SLICE, RTGS_NEAR_SLICE_BUDGET.
+ * mode 0 = off, 1 = always, 2 = automatic (default): considered for maps of >= 100 000 Gaussians on >= 256 tiles, and
+ * there the kernels decide from the depth histograms of THIS call (no history): the slice runs only if its Gaussians
+ * carry enough optical depth to saturate the image (sum of radius^2 >= 24 per pixel) and the map holds at least twice
+ * the slice's instances; otherwise the slice is empty and every tile goes to the second pass.  budget_per_tile <= 0
+ * keeps the current budget (default 384).  Environment overrides at load time: RTGS_NEAR_SLICE, RTGS_NEAR_SLICE_BUDGET.
  * rtgs_raster_last_slice_stats: [0] slice used by the last forward, [1] instances binned for the slice,
  * [2] tiles it finished, [3] tiles left to the second pass. */
 void rtgs_raster_set_near_slice(int mode, int budget_per_tile);
+void rtgs_raster_set_near_slice_ctx(rtgs_ctx* ctx, int mode, int budget_per_tile);
 int rtgs_raster_last_slice_stats(int64_t* out4_host);
+int rtgs_raster_last_slice_stats_ctx(rtgs_ctx* ctx, int64_t* out4_host);
 /* Testing aid: force the fallback binning path (global 64-bit radix sort, rocPRIM) that is
  * otherwise taken only when the tile grid or one tile list exceeds the LDS-resident path. */
 void rtgs_raster_force_sort_path(int enable);
+void rtgs_raster_force_sort_path_ctx(rtgs_ctx* ctx, int enable);
 int rtgs_raster_last_timings(float* ms10_host);
+int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms10_host);
 
 /* Fused Adam over a packed [rows, cols] float32 parameter shard with one learning rate per
  * column (the six Adam groups of SLAM/gaussian_pointcloud.py:245-284; torch.optim.Adam
@@ -255,6 +312,8 @@ int rtgs_slam_map_step(const rtgs_map_step_args* args, int64_t* num_rendered_hos
 /* The same call without its last stage (rtgs_map_tail_rows): the gradient rows of this rank's view are in the arena,
  * nothing has been stepped.  Multi-GPU callers exchange the rows (below) before they run the tail. */
 int rtgs_slam_map_step_front(const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
+int rtgs_slam_map_step_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
+int rtgs_slam_map_step_front_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
 
 /* Sparse gradient exchange for replicated multi-GPU optimisation: only rows that received gradient travel.
  * rtgs_rows_pack compacts the state-1 rows of a row-state arena into out_rows[*, 64] (word 0 = Gaussian id as bits,

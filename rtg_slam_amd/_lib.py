@@ -93,6 +93,24 @@ _SIGNATURES = {
     "rtgs_raster_set_near_slice": (None, [C.c_int, C.c_int]),
     "rtgs_raster_last_slice_stats": (C.c_int, [C.POINTER(C.c_int64)]),
     "rtgs_raster_last_timings": (C.c_int, [C.POINTER(C.c_float)]),
+    "rtgs_ctx_create": (C.c_void_p, []),
+    "rtgs_ctx_destroy": (None, [_P]),
+    "rtgs_raster_forward_ctx": (C.c_int, [_P, C.POINTER(RasterSettingsC), C.c_int32, C.c_int32] + [_P] * 6 + [_P]
+                                + [_P] * 8 + [RESIZE_FN, _P, RESIZE_FN, _P, RESIZE_FN, _P, C.POINTER(C.c_int64), _P]),
+    "rtgs_raster_backward_ctx": (C.c_int, [_P, C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6
+                                 + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P]),
+    "rtgs_raster_backward_rows_ctx": (C.c_int, [_P, C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6
+                                      + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P, _P]),
+    "rtgs_raster_geom_bytes_ctx": (C.c_size_t, [_P, C.c_int32, C.c_int32, C.c_int32]),
+    "rtgs_raster_last_stats_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "rtgs_raster_set_counters_ctx": (None, [_P, _P]),
+    "rtgs_raster_set_profiling_ctx": (None, [_P, C.c_int]),
+    "rtgs_raster_force_sort_path_ctx": (None, [_P, C.c_int]),
+    "rtgs_raster_set_near_slice_ctx": (None, [_P, C.c_int, C.c_int]),
+    "rtgs_raster_last_slice_stats_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "rtgs_raster_last_timings_ctx": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "rtgs_slam_map_step_ctx": (C.c_int, [_P, C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
+    "rtgs_slam_map_step_front_ctx": (C.c_int, [_P, C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_icp_build_pyramids": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "rtgs_icp_step": (C.c_int, [_P] * 4 + [C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "rtgs_icp_track": (C.c_int, [C.POINTER(IcpLevelC), C.c_int32, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P]),

@@ -6,7 +6,8 @@
 #include "../../include/rtgs_raster.h"
 
 // Everything up to and including the rasterizer backward: the gradient rows are in the arena, nothing is stepped yet.
-extern "C" int rtgs_slam_map_step_front(const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
+extern "C" int rtgs_slam_map_step_front_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* num_rendered_host,
+                                            void* stream) {
   if (!a || !num_rendered_host || !a->settings) return RTGS_E_INVALID;
   const int32_t P = a->P, M = a->sh_coeffs;
   if (P <= 0 || M != 16 || a->step < 1) return RTGS_E_INVALID;
@@ -14,7 +15,7 @@ extern "C" int rtgs_slam_map_step_front(const rtgs_map_step_args* a, int64_t* nu
   const int32_t H = a->settings->image_height, W = a->settings->image_width;
   int rc = rtgs_map_activate8_forward(a->raw8, P, a->opacity, a->scales, a->rotations, a->normal, stream);
   if (rc != 0) return RTGS_E_HIP;
-  rc = rtgs_raster_forward(a->settings, P, M, a->xyz, a->opacity, a->shs, a->scales, a->rotations, a->normal,
+  rc = rtgs_raster_forward_ctx(ctx, a->settings, P, M, a->xyz, a->opacity, a->shs, a->scales, a->rotations, a->normal,
                            a->tile_mask, a->out_color, a->out_depth, a->out_color_index, a->out_depth_index,
                            a->out_color_weight, a->out_depth_weight, a->out_T, a->out_radii, a->geom_resize,
                            a->geom_user, a->binning_resize, a->binning_user, a->image_resize, a->image_user,
@@ -27,15 +28,19 @@ extern "C" int rtgs_slam_map_step_front(const rtgs_map_step_args* a, int64_t* nu
   rc = rtgs_slam_loss(a->out_color, a->out_depth, a->out_depth_index, a->gt_color, a->gt_depth, H, W, a->color_weight,
                       a->depth_weight, a->loss_scratch4, a->loss_scratch4 + 3, a->dL_dcolor, a->dL_ddepth, stream);
   if (rc != 0) return RTGS_E_HIP;
-  rc = rtgs_raster_backward_rows(a->settings, P, M, *num_rendered_host, a->xyz, a->opacity, a->shs, a->scales,
+  rc = rtgs_raster_backward_rows_ctx(ctx, a->settings, P, M, *num_rendered_host, a->xyz, a->opacity, a->shs, a->scales,
                                  a->rotations, a->normal, geom, bin, img, a->out_color, a->out_T, a->out_depth_index,
                                  a->dL_dcolor, a->dL_ddepth, a->d_xyz, a->d_opacity, a->d_shs, a->d_scales,
                                  a->d_rotations, a->d_normal, a->grad_scratch, a->row_state, stream);
   return rc;
 }
 
-extern "C" int rtgs_slam_map_step(const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
-  int rc = rtgs_slam_map_step_front(a, num_rendered_host, stream);
+extern "C" int rtgs_slam_map_step_front(const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
+  return rtgs_slam_map_step_front_ctx(nullptr, a, num_rendered_host, stream);
+}
+
+extern "C" int rtgs_slam_map_step_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
+  int rc = rtgs_slam_map_step_front_ctx(ctx, a, num_rendered_host, stream);
   if (rc != RTGS_OK) return rc;
   const int32_t P = a->P;
   // activation backward + Adam on the three block tensors, one launch
@@ -44,6 +49,10 @@ extern "C" int rtgs_slam_map_step(const rtgs_map_step_args* a, int64_t* num_rend
                           a->lr_xyz, a->lr_shs, a->lr_raw8, a->ever_xyz, a->ever_shs, a->ever_raw8, P, a->step, a->beta1,
                           a->beta2, a->eps, stream);
   return rc != 0 ? RTGS_E_HIP : RTGS_OK;
+}
+
+extern "C" int rtgs_slam_map_step(const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
+  return rtgs_slam_map_step_ctx(nullptr, a, num_rendered_host, stream);
 }
 
 // Layout guards for foreign-function bindings (ctypes / cgo / JNI mirrors of the two structs): compare with sizeof on the

@@ -5,6 +5,8 @@
 
 #include <hipcub/hipcub.hpp>
 #include <math.h>
+#include <new>
+#include <stdlib.h>
 #include <string.h>
 
 namespace rtgs {
@@ -23,7 +25,6 @@ void launch_preprocess_bwd(const RasterParams&, const float*, const float*, cons
                            const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
                            float*, float*, float*, float*, hipStream_t);
 
-// process-wide (autograd runs backward on its own thread): last-call stats, counters, profiling
 size_t bin_lds_limit_tiles();
 int bin_sort_capacity();
 size_t bin_block_counts_bytes(int, int);
@@ -40,34 +41,54 @@ void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, uin
                          uint32_t, hipStream_t);
 void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const int32_t*, const uint16_t*, uint32_t*,
                         unsigned long long*, SliceSel, SliceList, size_t, hipStream_t);
-void launch_slice_hist(int, const uint8_t*, const uint32_t*, uint32_t*, hipStream_t);
+void launch_slice_hist(int, const uint8_t*, const uint32_t*, const int32_t*, uint32_t*, unsigned long long*, hipStream_t);
 void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*, uint32_t*, hipStream_t);
 
-static int64_t g_stats[8] = {0};
-// Near-slice (occlusion) pass: 0 = off, 1 = always, 2 = automatic (large maps; backs off for 16 calls after a call in
-// which the slice finished fewer tiles than it left).  RTGS_NEAR_SLICE / RTGS_NEAR_SLICE_BUDGET override at load time.
-static int g_slice_mode = [] { const char* e = getenv("RTGS_NEAR_SLICE"); return e ? atoi(e) : 2; }();
-static int g_slice_budget = [] { const char* e = getenv("RTGS_NEAR_SLICE_BUDGET"); return e ? atoi(e) : 384; }();
-static int g_slice_cooldown = 0;
-static int64_t g_slice_stats[4] = {0};     // used, near-slice instances, tiles finished, tiles left to pass 2
-static unsigned long long* g_counters = nullptr;
+}  // namespace rtgs
 
-// optional per-stage HIP-event timing (bench.py's roofline leg); off by default
+// Everything a forward / backward remembers between calls lives in a context (include/rtgs_raster.h: rtgs_ctx).  The
+// plain entry points use one process-wide default context; callers that render from several threads create one
+// context per thread.
 enum { EV_F0 = 0, EV_PRE, EV_SL_BIN, EV_SL_BLEND, EV_SCAN, EV_BIN0, EV_EMIT, EV_SORT, EV_RANGES, EV_BLEND0, EV_BLEND, EV_B0,
        EV_BBLEND, EV_BPRE, EV_N };
-static bool g_prof = false;
-static bool g_force_sort_path = false;   // testing aid: take the global radix-sort binning path
-static bool g_ev_init = false;
-static hipEvent_t g_ev[EV_N];
-static bool g_ev_set[EV_N] = {false};
-static void prof_mark(int which, hipStream_t st) {
-  if (!g_prof) return;
-  if (!g_ev_init) {
-    for (int i = 0; i < EV_N; ++i) (void)hipEventCreate(&g_ev[i]);
-    g_ev_init = true;
+struct rtgs_ctx {
+  int64_t stats[8] = {0};
+  // Near-slice (occlusion) pass: 0 = off, 1 = always, 2 = automatic (large maps; the kernels themselves decide from
+  // the depth histograms whether the slice is worth running - raster_common.h: slice_cut).
+  int slice_mode = 2;
+  int slice_budget = 384;
+  int64_t slice_stats[4] = {0};     // used, near-slice instances, tiles finished, tiles left to pass 2
+  unsigned long long* counters = nullptr;
+  bool prof = false;                // optional per-stage HIP-event timing (bench.py's roofline leg)
+  bool force_sort_path = false;     // testing aid: take the global radix-sort binning path
+  bool ev_init = false;
+  hipEvent_t ev[EV_N];
+  bool ev_set[EV_N] = {false};
+  uint32_t* info_host = nullptr;    // pinned words the kernels publish totals into (the forward's host sync)
+  uint32_t seq = 0;
+};
+
+namespace rtgs {
+
+static rtgs_ctx* default_ctx() {
+  static rtgs_ctx* c = [] {
+    rtgs_ctx* n = new rtgs_ctx();
+    if (const char* e = getenv("RTGS_NEAR_SLICE")) n->slice_mode = atoi(e);
+    if (const char* e = getenv("RTGS_NEAR_SLICE_BUDGET")) { const int b = atoi(e); if (b > 0) n->slice_budget = b; }
+    return n;
+  }();
+  return c;
+}
+static inline rtgs_ctx* use(rtgs_ctx* c) { return c ? c : default_ctx(); }
+
+static void prof_mark(rtgs_ctx* c, int which, hipStream_t st) {
+  if (!c->prof) return;
+  if (!c->ev_init) {
+    for (int i = 0; i < EV_N; ++i) (void)hipEventCreate(&c->ev[i]);
+    c->ev_init = true;
   }
-  (void)hipEventRecord(g_ev[which], st);
-  g_ev_set[which] = true;
+  (void)hipEventRecord(c->ev[which], st);
+  c->ev_set[which] = true;
 }
 
 static int bits_for(uint32_t n) {   // bits needed to represent values in [0, n)
@@ -76,7 +97,9 @@ static int bits_for(uint32_t n) {   // bits needed to represent values in [0, n)
   return b < 1 ? 1 : b;
 }
 
-static GeomLayout geom_layout(int32_t P, int gx, int gy) {
+// Offsets the BACKWARD reads (splats, radii, clamped, ranges1_bwd, list1) do not depend on `budget`: everything sized
+// by the near-slice budget sits behind them, so a backward never needs to know the budget of its forward.
+static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
   GeomLayout L{};
   size_t off = 0;
   const size_t Pn = (size_t)(P > 0 ? P : 1);
@@ -97,6 +120,7 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy) {
     L.tile_count1 = off; off += nt * sizeof(uint32_t);
     L.ranges1_bwd = off; off += nt * sizeof(uint2);
     L.slice_hist = off; off += 2 * SLICE_BINS * sizeof(uint32_t);
+    L.slice_cover = off; off += SLICE_BINS * sizeof(unsigned long long);
     L.slice_ctr = off; off += 4 * sizeof(uint32_t);
     L.zero_end = off; off = align_up(off);
     L.cursor = off; off = align_up(off + nt * sizeof(uint32_t));
@@ -106,14 +130,14 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy) {
     L.cursor1 = off; off = align_up(off + nt * sizeof(uint32_t));
     L.ranges1 = off; off = align_up(off + nt * sizeof(uint2));
     L.mask2 = off; off = align_up(off + nt * sizeof(int32_t));
-    L.slice_cap = nt * (size_t)(g_slice_budget > 0 ? g_slice_budget : 1);
+    L.uv = off; off = align_up(off + Pn * sizeof(float2));
+    L.slice_cap = nt * (size_t)(budget > 0 ? budget : 1);
     L.slice_max_list = L.slice_cap < 65536 ? L.slice_cap : 65536;   // every listed Gaussian covers >= 1 tile
     if (L.slice_max_list > Pn) L.slice_max_list = Pn;
+    L.list1 = off; off = align_up(off + L.slice_cap * sizeof(uint32_t));      // last budget-independent OFFSET
     L.block_counts1 = off; off = align_up(off + bin_slice_block_counts_bytes((int)Pn, L.slice_max_list, gx * gy));
-    L.uv = off; off = align_up(off + Pn * sizeof(float2));
     L.slice_ids = off; off = align_up(off + L.slice_max_list * sizeof(uint32_t));
     L.bucket1 = off; off = align_up(off + L.slice_cap * sizeof(uint64_t));
-    L.list1 = off; off = align_up(off + L.slice_cap * sizeof(uint32_t));
   }
   size_t tb = 0;
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)Pn);
@@ -195,11 +219,24 @@ using namespace rtgs;
 
 extern "C" {
 
-const char* rtgs_version(void) { return "rtgs-hip 0.1.0 (gfx950)"; }
+const char* rtgs_version(void) { return "rtgs-hip 0.2.0 (gfx950)"; }
 
-size_t rtgs_raster_geom_bytes(int32_t P, int32_t H, int32_t W) {
-  return geom_layout(P, (W + TILE - 1) / TILE, (H + TILE - 1) / TILE).total;
+rtgs_ctx* rtgs_ctx_create(void) {
+  rtgs_ctx* c = new (std::nothrow) rtgs_ctx();
+  if (c) { c->slice_mode = default_ctx()->slice_mode; c->slice_budget = default_ctx()->slice_budget; }
+  return c;
 }
+void rtgs_ctx_destroy(rtgs_ctx* c) {
+  if (!c || c == default_ctx()) return;
+  if (c->ev_init) for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(c->ev[i]);
+  if (c->info_host) (void)hipHostFree(c->info_host);
+  delete c;
+}
+
+size_t rtgs_raster_geom_bytes_ctx(rtgs_ctx* c, int32_t P, int32_t H, int32_t W) {
+  return geom_layout(P, (W + TILE - 1) / TILE, (H + TILE - 1) / TILE, use(c)->slice_budget).total;
+}
+size_t rtgs_raster_geom_bytes(int32_t P, int32_t H, int32_t W) { return rtgs_raster_geom_bytes_ctx(nullptr, P, H, W); }
 size_t rtgs_raster_binning_bytes(int64_t R, int32_t H, int32_t W) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   return bin_layout(R, gx * gy, true).total;
@@ -214,20 +251,21 @@ size_t rtgs_raster_backward_scratch_bytes(int32_t P) {
   return align_up(n * sizeof(SplatGrad)) + align_up(n);
 }
 
-int rtgs_raster_last_stats(int64_t* out) {
+int rtgs_raster_last_stats_ctx(rtgs_ctx* c, int64_t* out) {
   if (!out) return RTGS_E_INVALID;
-  memcpy(out, g_stats, sizeof(g_stats));
+  memcpy(out, use(c)->stats, sizeof(use(c)->stats));
   return RTGS_OK;
 }
-void rtgs_raster_set_counters(void* c) { g_counters = (unsigned long long*)c; }
+void rtgs_raster_set_counters_ctx(rtgs_ctx* c, void* counters) { use(c)->counters = (unsigned long long*)counters; }
 
-int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, const float* means3D,
-                        const float* opacities, const float* shs, const float* scales, const float* rotations,
-                        const float* normal_w, const int32_t* tile_mask, float* out_color, float* out_depth,
-                        int32_t* out_cidx, int32_t* out_didx, float* out_cw, float* out_dw, float* out_T,
-                        int32_t* out_radii, rtgs_resize_fn geom_resize, void* geom_user,
-                        rtgs_resize_fn binning_resize, void* binning_user, rtgs_resize_fn image_resize,
-                        void* image_user, int64_t* num_rendered_host, void* stream) {
+int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P, int32_t M, const float* means3D,
+                            const float* opacities, const float* shs, const float* scales, const float* rotations,
+                            const float* normal_w, const int32_t* tile_mask, float* out_color, float* out_depth,
+                            int32_t* out_cidx, int32_t* out_didx, float* out_cw, float* out_dw, float* out_T,
+                            int32_t* out_radii, rtgs_resize_fn geom_resize, void* geom_user,
+                            rtgs_resize_fn binning_resize, void* binning_user, rtgs_resize_fn image_resize,
+                            void* image_user, int64_t* num_rendered_host, void* stream) {
+  rtgs_ctx* c = use(ctx);
   RasterParams p;
   int rc = make_params(s, P, M, p);
   if (rc != RTGS_OK) return rc;
@@ -238,7 +276,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = p.gx * p.gy;
 
-  const GeomLayout G = geom_layout(P, p.gx, p.gy);
+  const GeomLayout G = geom_layout(P, p.gx, p.gy, c->slice_budget);
   char* geom = (char*)geom_resize(geom_user, G.total);
   const ImgLayout I = img_layout(p.H, p.W, ntiles);
   char* img = (char*)image_resize(image_user, I.total);
@@ -253,8 +291,8 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   uint32_t* n_contrib = (uint32_t*)(img + I.n_contrib);
 
   int64_t R = 0, R1 = 0;
-  for (int i = 0; i < EV_B0; ++i) g_ev_set[i] = false;
-  prof_mark(EV_F0, st);
+  for (int i = 0; i < EV_B0; ++i) c->ev_set[i] = false;
+  prof_mark(c, EV_F0, st);
   uint32_t* tile_count = (uint32_t*)(geom + G.tile_count);
   uint32_t* cursor = (uint32_t*)(geom + G.cursor);
   uint32_t* info = (uint32_t*)(geom + G.info);
@@ -264,28 +302,28 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   uint32_t* tile_count1 = (uint32_t*)(geom + G.tile_count1);
   uint2* ranges1_bwd = (uint2*)(geom + G.ranges1_bwd);
   uint32_t* slice_hist = (uint32_t*)(geom + G.slice_hist);
+  unsigned long long* slice_cover = (unsigned long long*)(geom + G.slice_cover);
   uint32_t* slice_ctr = (uint32_t*)(geom + G.slice_ctr);
   uint8_t* zbin = (uint8_t*)(geom + G.zbin);
   uint2* ranges1 = (uint2*)(geom + G.ranges1);
   int32_t* mask2 = (int32_t*)(geom + G.mask2);
   uint32_t* list1 = (uint32_t*)(geom + G.list1);
   uint32_t longest = 0;
-  bool sort_path = (size_t)ntiles > bin_lds_limit_tiles() || g_force_sort_path;
-  // near-slice pass: worth its fixed cost only on large maps; mode 1 forces it (tests)
-  bool sliced = !sort_path && P > 0 &&
-                (g_slice_mode == 1 || (g_slice_mode == 2 && P >= 100000 && ntiles >= 256 && g_slice_cooldown == 0));
-  if (g_slice_mode == 2 && g_slice_cooldown > 0) --g_slice_cooldown;
+  bool sort_path = (size_t)ntiles > bin_lds_limit_tiles() || c->force_sort_path;
+  // near-slice pass: mode 1 forces it (tests); automatic mode considers it on large maps only, and there the kernels
+  // decide from the depth histograms whether it runs (an empty slice sends every tile to the second pass)
+  const bool slice_auto = c->slice_mode == 2;
+  bool sliced = !sort_path && P > 0 && (c->slice_mode == 1 || (slice_auto && P >= 100000 && ntiles >= 256));
   SlicePass pass{0, nullptr, nullptr, nullptr, nullptr};
-  // pinned host words the kernels publish totals into (one slot per calling thread), and the spin that waits for them:
-  // a few microseconds instead of the ~25 us a blocking hipStreamSynchronize takes to wake up (bounded; falls back)
-  static thread_local uint32_t* t_info_host = nullptr;
-  static thread_local uint32_t t_seq = 0;
-  if (!t_info_host) {
-    HIP_TRY(hipHostMalloc((void**)&t_info_host, 8 * sizeof(uint32_t), hipHostMallocCoherent));
-    memset(t_info_host, 0, 8 * sizeof(uint32_t));
+  // pinned host words the kernels publish totals into, and the spin that waits for them: a few microseconds instead
+  // of the ~25 us a blocking hipStreamSynchronize takes to wake up (bounded; falls back)
+  if (!c->info_host) {
+    HIP_TRY(hipHostMalloc((void**)&c->info_host, 8 * sizeof(uint32_t), hipHostMallocCoherent));
+    memset(c->info_host, 0, 8 * sizeof(uint32_t));
   }
+  uint32_t* const info_host = c->info_host;
   auto wait_published = [&](uint32_t seq) -> int {
-    volatile uint32_t* flag = t_info_host + 7;
+    volatile uint32_t* flag = info_host + 7;
     bool seen = false;
     for (long spin = 0; spin < 4000000L; ++spin) {
       if (*flag == seq) { seen = true; break; }
@@ -303,7 +341,8 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       launch_mask_sat(tile_mask, p.gx, p.gy, sat, st);
       DBG(s, st);
     }
-    const SliceSel sel1{1, zbin, slice_hist, (uint32_t)G.slice_cap, (uint32_t)G.slice_max_list, slice_ctr, nullptr, nullptr};
+    const SliceSel sel1{1, zbin, slice_hist, (uint32_t)G.slice_cap, (uint32_t)G.slice_max_list, slice_ctr, nullptr, nullptr,
+                        slice_cover, (uint32_t)ntiles * (uint32_t)(TILE * TILE), slice_auto ? 1 : 0};
     if (!sliced) {
       launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sort_path ? sat : nullptr, splats,
                             tiles_touched, radii, clamped, out_radii, zero_words, zero_n, nullptr, st);
@@ -313,13 +352,13 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
                              (float2*)(geom + G.uv), st);
     }
     DBG(s, st);
-    prof_mark(EV_PRE, st);
+    prof_mark(c, EV_PRE, st);
     if (sliced) {
       // Pass 1: bin, sort and blend only the nearest Gaussians (as many depth bins as fit the instance budget).  Tiles
       // whose every pixel saturates inside the slice are final; blend_fwd leaves a tile mask of the others.  No host
       // sync: the arrays are sized by the budget, the sort classes are launched blind.
       const SliceList work{(const uint32_t*)(geom + G.slice_ids), slice_ctr + 2};
-      launch_slice_hist(P, zbin, tiles_touched, slice_hist, st);
+      launch_slice_hist(P, zbin, tiles_touched, radii, slice_hist, slice_cover, st);
       launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, st);
       launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
                               (float2*)(geom + G.uv), work, sel1, G.slice_max_list, st);
@@ -334,19 +373,18 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       launch_bin_tilesort(ntiles, (uint32_t)SLICE_MAX_LIST, ranges1, (const unsigned long long*)(geom + G.bucket1), list1,
                           st);
       DBG(s, st);
-      prof_mark(EV_SL_BIN, st);
-      if (++t_seq == 0u) t_seq = 1u;
+      prof_mark(c, EV_SL_BIN, st);
+      if (++c->seq == 0u) c->seq = 1u;
       const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
       launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                       n_contrib, g_counters, pass1, st);
-      launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, t_info_host, t_seq, st);
+                       n_contrib, c->counters, pass1, st);
+      launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, st);
       DBG(s, st);
-      prof_mark(EV_SL_BLEND, st);
+      prof_mark(c, EV_SL_BLEND, st);
       // the forward's host sync: the last tile of the slice publishes how many tiles are left
-      if ((rc = wait_published(t_seq)) != RTGS_OK) return rc;
-      n_left = t_info_host[2]; n_fin = t_info_host[3];
-      R1 = (int64_t)t_info_host[4];          // total of the slice lists, finished or not (accounting only)
-      if (g_slice_mode == 2 && n_left > n_fin) g_slice_cooldown = 16;      // little occlusion here: stop paying for pass 1
+      if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
+      n_left = info_host[2]; n_fin = info_host[3];
+      R1 = (int64_t)info_host[4];          // total of the slice lists, finished or not (accounting only)
       if (n_left > 0) {
         mask_main = mask2;
         pass = SlicePass{2, nullptr, mask2, nullptr, nullptr};
@@ -362,16 +400,16 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
     if (!sort_path && !(sliced && n_left == 0)) {
       // exact per-tile counts -> ranges; the one host sync of the forward sizes the instance arrays
       const SliceSel sel2{sliced ? 2 : 0, nullptr, nullptr, 0u, 0u, slice_ctr, sliced ? sat : nullptr,
-                          (const float2*)(geom + G.uv)};
+                          (const float2*)(geom + G.uv), nullptr, 0u, 0};
       if (launch_bin_count(p, splats, radii, mask_main, tile_count, block_counts, sel2, SliceList{nullptr, nullptr}, 0, st) != 0)
         return RTGS_E_HIP;
-      if (++t_seq == 0u) t_seq = 1u;
-      launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, t_info_host, nullptr, nullptr, t_seq, st);
+      if (++c->seq == 0u) c->seq = 1u;
+      launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, info_host, nullptr, nullptr, c->seq, st);
       DBG(s, st);
-      prof_mark(EV_SCAN, st);
-      if ((rc = wait_published(t_seq)) != RTGS_OK) return rc;
-      R = (int64_t)t_info_host[0];
-      longest = t_info_host[1];
+      prof_mark(c, EV_SCAN, st);
+      if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
+      R = (int64_t)info_host[0];
+      longest = info_host[1];
       if ((int)longest > bin_sort_capacity()) {   // a tile list too long for the LDS sort: redo with rect counts
         sort_path = true;
         if (sliced) {         // the global-sort path renders every tile itself: drop the slice's results
@@ -391,7 +429,7 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
       HIP_TRY(hipcub::DeviceScan::InclusiveSum(geom + G.scan_temp, tb, tiles_touched, offsets, P, st));
       uint32_t total = 0;
       HIP_TRY(hipMemcpyAsync(&total, offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      prof_mark(EV_SCAN, st);
+      prof_mark(c, EV_SCAN, st);
       HIP_TRY(hipStreamSynchronize(st));
       R = (int64_t)total;
     }
@@ -409,46 +447,45 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
   const int sort_bits = 32 + bits_for((uint32_t)ntiles);
   if (P == 0 || sort_path) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), st));
   if (R > 0 && !sort_path) {
-    prof_mark(EV_BIN0, st);
+    prof_mark(c, EV_BIN0, st);
     launch_bin_scatter(p, splats, radii, mask_main, block_counts, cursor, (unsigned long long*)keys_a,
                        SliceSel{sliced ? 2 : 0, nullptr, nullptr, 0u, 0u, slice_ctr, sliced ? sat : nullptr,
-                                (const float2*)(geom + G.uv)},
+                                (const float2*)(geom + G.uv), nullptr, 0u, 0},
                        SliceList{nullptr, nullptr}, 0, st);
     DBG(s, st);
-    prof_mark(EV_EMIT, st);
+    prof_mark(c, EV_EMIT, st);
     launch_bin_tilesort(ntiles, longest, ranges, (const unsigned long long*)keys_a, vals_b, st);
     DBG(s, st);
-    prof_mark(EV_SORT, st);
+    prof_mark(c, EV_SORT, st);
   } else if (R > 0) {
-    prof_mark(EV_BIN0, st);
+    prof_mark(c, EV_BIN0, st);
     launch_emit_keys(p, splats, radii, offsets, tile_mask, keys_a, vals_a, st);
     DBG(s, st);
-    prof_mark(EV_EMIT, st);
+    prof_mark(c, EV_EMIT, st);
     size_t tb = B.sort_temp_bytes;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin + B.sort_temp, tb, keys_a, keys_b, vals_a, vals_b, (int)R, 0,
                                                sort_bits, st));
     DBG(s, st);
-    prof_mark(EV_SORT, st);
+    prof_mark(c, EV_SORT, st);
     launch_tile_ranges(R, keys_b, ranges, st);
     DBG(s, st);
-    prof_mark(EV_RANGES, st);
+    prof_mark(c, EV_RANGES, st);
   }
-  prof_mark(EV_BLEND0, st);
+  prof_mark(c, EV_BLEND0, st);
   if (!sliced || n_left > 0)     // pass 2 (or the only pass); with every tile finished by the slice there is nothing to draw
     launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                     n_contrib, g_counters, pass, st);
-  prof_mark(EV_BLEND, st);
+                     n_contrib, c->counters, pass, st);
+  prof_mark(c, EV_BLEND, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
-  g_stats[0] = R; g_stats[1] = sort_bits; g_stats[2] = ntiles; g_stats[3] = (int64_t)G.total;
-  g_stats[4] = (int64_t)B.total; g_stats[5] = (int64_t)I.total;
-  g_stats[6] = sort_path ? 0 : 1; g_stats[7] = (int64_t)longest;
-  g_stats[0] = R + R1;
-  g_slice_stats[0] = sliced ? 1 : 0; g_slice_stats[1] = R1; g_slice_stats[2] = n_fin; g_slice_stats[3] = n_left;
+  c->stats[0] = R + R1; c->stats[1] = sort_bits; c->stats[2] = ntiles; c->stats[3] = (int64_t)G.total;
+  c->stats[4] = (int64_t)B.total; c->stats[5] = (int64_t)I.total;
+  c->stats[6] = sort_path ? 0 : 1; c->stats[7] = (int64_t)longest;
+  c->slice_stats[0] = sliced ? 1 : 0; c->slice_stats[1] = R1; c->slice_stats[2] = n_fin; c->slice_stats[3] = n_left;
   return RTGS_OK;
 }
 
-static int backward_impl(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
+static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
                          const float* opacities, const float* shs, const float* scales, const float* rotations,
                          const float* normal_w, const void* geom_buffer, const void* binning_buffer,
                          const void* image_buffer, const float* out_color, const float* out_T,
@@ -456,6 +493,7 @@ static int backward_impl(const rtgs_raster_settings* s, int32_t P, int32_t M, in
                          const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
                          float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
                          void* grad_scratch, uint8_t* row_state, void* stream) {
+  rtgs_ctx* c = use(ctx);
   RasterParams p;
   int rc = make_params(s, P, M, p);
   if (rc != RTGS_OK) return rc;
@@ -466,15 +504,15 @@ static int backward_impl(const rtgs_raster_settings* s, int32_t P, int32_t M, in
     return RTGS_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = p.gx * p.gy;
-  const GeomLayout G = geom_layout(P, p.gx, p.gy);
-  const BinLayout B = bin_layout(R, ntiles, false);   // point_list sits at offset 0 in both layouts
+  const GeomLayout G = geom_layout(P, p.gx, p.gy, 1);   // only budget-independent offsets are read here
+  const BinLayout B = bin_layout(R, ntiles, false);     // point_list sits at offset 0 in both layouts
   const ImgLayout I = img_layout(p.H, p.W, ntiles);
   const char* geom = (const char*)geom_buffer;
   const char* bin = (const char*)binning_buffer;
   const char* img = (const char*)image_buffer;
   SplatGrad* grads = (SplatGrad*)grad_scratch;
-  for (int i = EV_B0; i < EV_N; ++i) g_ev_set[i] = false;
-  prof_mark(EV_B0, st);
+  for (int i = EV_B0; i < EV_N; ++i) c->ev_set[i] = false;
+  prof_mark(c, EV_B0, st);
   uint8_t* touched = (uint8_t*)grad_scratch + align_up((size_t)P * sizeof(SplatGrad));
   // row-state mode: the caller zeroed the scratch once and preprocess_bwd re-zeroes every line it consumes
   if (!row_state) HIP_TRY(hipMemsetAsync(grads, 0, rtgs_raster_backward_scratch_bytes(P), st));
@@ -489,75 +527,118 @@ static int backward_impl(const rtgs_raster_settings* s, int32_t P, int32_t M, in
                      dL_dcolor, dL_ddepth, grads, touched, st);
     DBG(s, st);
   }
-  prof_mark(EV_BBLEND, st);
+  prof_mark(c, EV_BBLEND, st);
   launch_preprocess_bwd(p, means3D, opacities, shs, scales, rotations, normal_w, (const int32_t*)(geom + G.radii),
                         (const uint8_t*)(geom + G.clamped), grads, touched, row_state, dL_dmeans3D, dL_dopacities,
                         dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, st);
-  prof_mark(EV_BPRE, st);
+  prof_mark(c, EV_BPRE, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
   return RTGS_OK;
 }
 
-int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
-                         const float* opacities, const float* shs, const float* scales, const float* rotations,
-                         const float* normal_w, const void* geom_buffer, const void* binning_buffer,
-                         const void* image_buffer, const float* out_color, const float* out_T,
-                         const int32_t* out_didx,
-                         const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
-                         float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
-                         void* grad_scratch, void* stream) {
-  return backward_impl(s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer, binning_buffer,
+int rtgs_raster_backward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R,
+                             const float* means3D, const float* opacities, const float* shs, const float* scales,
+                             const float* rotations, const float* normal_w, const void* geom_buffer,
+                             const void* binning_buffer, const void* image_buffer, const float* out_color,
+                             const float* out_T, const int32_t* out_didx, const float* dL_dcolor, const float* dL_ddepth,
+                             float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs, float* dL_dscales,
+                             float* dL_drotations, float* dL_dnormal_w, void* grad_scratch, void* stream) {
+  return backward_impl(ctx, s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer, binning_buffer,
                        image_buffer, out_color, out_T, out_didx, dL_dcolor, dL_ddepth, dL_dmeans3D, dL_dopacities,
                        dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, nullptr, stream);
 }
 
-int rtgs_raster_backward_rows(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
-                              const float* opacities, const float* shs, const float* scales, const float* rotations,
-                              const float* normal_w, const void* geom_buffer, const void* binning_buffer,
-                              const void* image_buffer, const float* out_color, const float* out_T,
-                              const int32_t* out_didx,
-                              const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
-                              float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
-                              void* grad_scratch, uint8_t* row_state, void* stream) {
+int rtgs_raster_backward_rows_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R,
+                                  const float* means3D, const float* opacities, const float* shs, const float* scales,
+                                  const float* rotations, const float* normal_w, const void* geom_buffer,
+                                  const void* binning_buffer, const void* image_buffer, const float* out_color,
+                                  const float* out_T, const int32_t* out_didx, const float* dL_dcolor,
+                                  const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
+                                  float* dL_dscales, float* dL_drotations, float* dL_dnormal_w, void* grad_scratch,
+                                  uint8_t* row_state, void* stream) {
   if (P > 0 && !row_state) return RTGS_E_INVALID;
-  return backward_impl(s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer, binning_buffer,
+  return backward_impl(ctx, s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer, binning_buffer,
                        image_buffer, out_color, out_T, out_didx, dL_dcolor, dL_ddepth, dL_dmeans3D, dL_dopacities,
                        dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, row_state, stream);
 }
 
-void rtgs_raster_set_profiling(int enable) { g_prof = enable != 0; }
-void rtgs_raster_set_near_slice(int mode, int budget_per_tile) {
-  g_slice_mode = mode;
-  g_slice_cooldown = 0;
-  if (budget_per_tile > 0) g_slice_budget = budget_per_tile;
+void rtgs_raster_set_profiling_ctx(rtgs_ctx* c, int enable) { use(c)->prof = enable != 0; }
+void rtgs_raster_set_near_slice_ctx(rtgs_ctx* c, int mode, int budget_per_tile) {
+  use(c)->slice_mode = mode;
+  if (budget_per_tile > 0) use(c)->slice_budget = budget_per_tile;
 }
-int rtgs_raster_last_slice_stats(int64_t* out) {
+int rtgs_raster_last_slice_stats_ctx(rtgs_ctx* c, int64_t* out) {
   if (!out) return RTGS_E_INVALID;
-  memcpy(out, g_slice_stats, sizeof(g_slice_stats));
+  memcpy(out, use(c)->slice_stats, sizeof(use(c)->slice_stats));
   return RTGS_OK;
 }
-void rtgs_raster_force_sort_path(int enable) { g_force_sort_path = enable != 0; }
+void rtgs_raster_force_sort_path_ctx(rtgs_ctx* c, int enable) { use(c)->force_sort_path = enable != 0; }
 
-int rtgs_raster_last_timings(float* ms) {
+int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms) {
+  rtgs_ctx* c = use(ctx);
   if (!ms) return RTGS_E_INVALID;
   for (int i = 0; i < 10; ++i) ms[i] = -1.f;
-  if (!g_ev_init) return RTGS_OK;
+  if (!c->ev_init) return RTGS_OK;
   // [0] preprocess_fwd(+sat) [1] count+scan of the main pass [2] scatter / emit_keys [3] sort [4] tile_ranges
   // [5] blend_fwd of the main pass [6] blend_bwd (both launches) [7] preprocess_bwd
   // [8] near slice: hist+count+scan+scatter+sort [9] near slice: blend_fwd
-  const int pre_end = g_ev_set[EV_SL_BLEND] ? EV_SL_BLEND : EV_PRE;
+  const int pre_end = c->ev_set[EV_SL_BLEND] ? EV_SL_BLEND : EV_PRE;
   const int pairs[10][2] = {{EV_F0, EV_PRE}, {pre_end, EV_SCAN}, {EV_BIN0, EV_EMIT}, {EV_EMIT, EV_SORT},
                             {EV_SORT, EV_RANGES}, {EV_BLEND0, EV_BLEND}, {EV_B0, EV_BBLEND}, {EV_BBLEND, EV_BPRE},
                             {EV_PRE, EV_SL_BIN}, {EV_SL_BIN, EV_SL_BLEND}};
   for (int i = 0; i < 10; ++i) {
     const int a = pairs[i][0], b = pairs[i][1];
-    if (!g_ev_set[a] || !g_ev_set[b]) continue;
-    if (hipEventSynchronize(g_ev[b]) != hipSuccess) return RTGS_E_HIP;
+    if (!c->ev_set[a] || !c->ev_set[b]) continue;
+    if (hipEventSynchronize(c->ev[b]) != hipSuccess) return RTGS_E_HIP;
     float t = 0.f;
-    if (hipEventElapsedTime(&t, g_ev[a], g_ev[b]) == hipSuccess) ms[i] = t;
+    if (hipEventElapsedTime(&t, c->ev[a], c->ev[b]) == hipSuccess) ms[i] = t;
   }
   return RTGS_OK;
 }
+
+// ---- the plain entry points: the same calls on the process-wide default context ----------------------------------
+int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, const float* means3D,
+                        const float* opacities, const float* shs, const float* scales, const float* rotations,
+                        const float* normal_w, const int32_t* tile_mask, float* out_color, float* out_depth,
+                        int32_t* out_cidx, int32_t* out_didx, float* out_cw, float* out_dw, float* out_T,
+                        int32_t* out_radii, rtgs_resize_fn geom_resize, void* geom_user,
+                        rtgs_resize_fn binning_resize, void* binning_user, rtgs_resize_fn image_resize,
+                        void* image_user, int64_t* num_rendered_host, void* stream) {
+  return rtgs_raster_forward_ctx(nullptr, s, P, M, means3D, opacities, shs, scales, rotations, normal_w, tile_mask,
+                                 out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, out_radii, geom_resize,
+                                 geom_user, binning_resize, binning_user, image_resize, image_user, num_rendered_host, stream);
+}
+int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
+                         const float* opacities, const float* shs, const float* scales, const float* rotations,
+                         const float* normal_w, const void* geom_buffer, const void* binning_buffer,
+                         const void* image_buffer, const float* out_color, const float* out_T, const int32_t* out_didx,
+                         const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
+                         float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
+                         void* grad_scratch, void* stream) {
+  return backward_impl(nullptr, s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer,
+                       binning_buffer, image_buffer, out_color, out_T, out_didx, dL_dcolor, dL_ddepth, dL_dmeans3D,
+                       dL_dopacities, dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, nullptr, stream);
+}
+int rtgs_raster_backward_rows(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
+                              const float* opacities, const float* shs, const float* scales, const float* rotations,
+                              const float* normal_w, const void* geom_buffer, const void* binning_buffer,
+                              const void* image_buffer, const float* out_color, const float* out_T,
+                              const int32_t* out_didx, const float* dL_dcolor, const float* dL_ddepth,
+                              float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs, float* dL_dscales,
+                              float* dL_drotations, float* dL_dnormal_w, void* grad_scratch, uint8_t* row_state,
+                              void* stream) {
+  return rtgs_raster_backward_rows_ctx(nullptr, s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w,
+                                       geom_buffer, binning_buffer, image_buffer, out_color, out_T, out_didx, dL_dcolor,
+                                       dL_ddepth, dL_dmeans3D, dL_dopacities, dL_dshs, dL_dscales, dL_drotations,
+                                       dL_dnormal_w, grad_scratch, row_state, stream);
+}
+int rtgs_raster_last_stats(int64_t* out) { return rtgs_raster_last_stats_ctx(nullptr, out); }
+void rtgs_raster_set_counters(void* counters) { rtgs_raster_set_counters_ctx(nullptr, counters); }
+void rtgs_raster_set_profiling(int enable) { rtgs_raster_set_profiling_ctx(nullptr, enable); }
+void rtgs_raster_set_near_slice(int mode, int budget) { rtgs_raster_set_near_slice_ctx(nullptr, mode, budget); }
+int rtgs_raster_last_slice_stats(int64_t* out) { return rtgs_raster_last_slice_stats_ctx(nullptr, out); }
+void rtgs_raster_force_sort_path(int enable) { rtgs_raster_force_sort_path_ctx(nullptr, enable); }
+int rtgs_raster_last_timings(float* ms) { return rtgs_raster_last_timings_ctx(nullptr, ms); }
 
 }  // extern "C"

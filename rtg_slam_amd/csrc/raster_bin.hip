@@ -20,8 +20,28 @@
 // blend_fwd, so removing it changes no output.  The test is the minimum of the conic form over
 // the tile's pixel-centre box against 2 ln(255 o), with a safety margin far above float rounding.
 #include "raster_common.h"
+#include <mutex>
 
 namespace rtgs {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember, per device, the largest
+// dynamic-LDS size already granted, so the attribute is raised once per size and device instead of on every launch
+// (several devices or threads in one process are safe).
+struct LdsGrant {
+  std::mutex m;
+  size_t got[64];
+  explicit LdsGrant(size_t base) { for (size_t& g : got) g = base; }
+  void ensure(const void* fn, size_t lds) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); return; }
+    std::lock_guard<std::mutex> lk(m);
+    if (lds > got[dev]) {
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      got[dev] = lds;
+    }
+  }
+};
 
 constexpr int GPB = 1024;       // Gaussians per workgroup in bin_count / bin_scatter
 constexpr int SLICE_GPB = 32;   // ... when they walk the near slice's short work list: 8 Gaussians per wave (each covers
@@ -434,41 +454,58 @@ size_t bin_slice_block_counts_bytes(int P, size_t max_list, int ntiles) {
   return ((n + SLICE_GPB - 1) / SLICE_GPB) * (size_t)ntiles * sizeof(uint16_t);
 }
 
-// area-weighted depth histogram of the visible Gaussians (input of slice_cut)
+// depth histograms of the visible Gaussians (input of slice_cut): 3-sigma-rect instances, Gaussians, and
+// sum(radius^2) per bin (the "cover" the automatic mode's decision uses)
 __global__ void __launch_bounds__(256) slice_hist_kernel(int P, const uint8_t* __restrict__ zbin,
                                                          const uint32_t* __restrict__ rect_area,
-                                                         uint32_t* __restrict__ hist) {
-  __shared__ uint32_t s_h[SLICE_BINS], s_c[SLICE_BINS];
-  s_h[threadIdx.x] = 0; s_c[threadIdx.x] = 0;
+                                                         const int32_t* __restrict__ radii,
+                                                         uint32_t* __restrict__ hist,
+                                                         unsigned long long* __restrict__ cover) {
+  __shared__ uint32_t s_h[SLICE_BINS], s_c[SLICE_BINS], s_r[SLICE_BINS];
+  s_h[threadIdx.x] = 0; s_c[threadIdx.x] = 0; s_r[threadIdx.x] = 0;
   __syncthreads();
-  // 8 consecutive Gaussians per thread, all three loads in flight at once (the grid-stride form was a chain of
-  // dependent 1-byte loads: 19 us for 6 MB)
+  // 8 consecutive Gaussians per thread, all loads in flight at once (the grid-stride form was a chain of
+  // dependent 1-byte loads: 19 us for 6 MB).  radius^2 is capped at 2^16 per Gaussian: a workgroup sums at most
+  // ~10^4 of them into a 32-bit LDS word.
   for (int i0 = (blockIdx.x * 256 + threadIdx.x) * 8; i0 < P; i0 += gridDim.x * 2048)
   if (i0 + 8 <= P) {
     const uint2 zb = *reinterpret_cast<const uint2*>(zbin + i0);
     const uint4 a0 = *reinterpret_cast<const uint4*>(rect_area + i0);
     const uint4 a1 = *reinterpret_cast<const uint4*>(rect_area + i0 + 4);
+    const int4 r0 = *reinterpret_cast<const int4*>(radii + i0);
+    const int4 r1 = *reinterpret_cast<const int4*>(radii + i0 + 4);
     const uint32_t ar[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const int rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const uint32_t bsel = ((k < 4 ? zb.x : zb.y) >> (8 * (k & 3))) & 0xffu;
-      if (bsel != 255u) { atomicAdd(&s_h[bsel], ar[k]); atomicAdd(&s_c[bsel], 1u); }
+      if (bsel != 255u) {
+        const uint32_t r = (uint32_t)min(rr[k], 256);
+        atomicAdd(&s_h[bsel], ar[k]); atomicAdd(&s_c[bsel], 1u); atomicAdd(&s_r[bsel], r * r);
+      }
     }
   } else {
     for (int i = i0; i < P; ++i) {
       const uint32_t bsel = zbin[i];
-      if (bsel != 255u) { atomicAdd(&s_h[bsel], rect_area[i]); atomicAdd(&s_c[bsel], 1u); }
+      if (bsel != 255u) {
+        const uint32_t r = (uint32_t)min(radii[i], 256);
+        atomicAdd(&s_h[bsel], rect_area[i]); atomicAdd(&s_c[bsel], 1u); atomicAdd(&s_r[bsel], r * r);
+      }
     }
   }
   __syncthreads();
   const uint32_t v = s_h[threadIdx.x], n = s_c[threadIdx.x];
-  if (n) { atomicAdd(&hist[threadIdx.x], v); atomicAdd(&hist[SLICE_BINS + threadIdx.x], n); }
+  if (n) {
+    atomicAdd(&hist[threadIdx.x], v); atomicAdd(&hist[SLICE_BINS + threadIdx.x], n);
+    atomicAdd(&cover[threadIdx.x], (unsigned long long)s_r[threadIdx.x]);
+  }
 }
-void launch_slice_hist(int P, const uint8_t* zbin, const uint32_t* rect_area, uint32_t* hist, hipStream_t st) {
+void launch_slice_hist(int P, const uint8_t* zbin, const uint32_t* rect_area, const int32_t* radii, uint32_t* hist,
+                       unsigned long long* cover, hipStream_t st) {
   if (P == 0) return;
   int blocks = (P + 2047) / 2048;       // few workgroups: each ends with up to 256 same-address global atomics
   if (blocks > 128) blocks = 128;
-  hipLaunchKernelGGL(slice_hist_kernel, dim3(blocks), dim3(256), 0, st, P, zbin, rect_area, hist);
+  hipLaunchKernelGGL(slice_hist_kernel, dim3(blocks), dim3(256), 0, st, P, zbin, rect_area, radii, hist, cover);
 }
 
 // ids of the Gaussians in the near slice (depth bin <= cut), in arbitrary order (the tile sort orders by (depth, id));
@@ -520,11 +557,8 @@ int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* 
   const int ntiles = p.gx * p.gy;      // tile_count was cleared by preprocess_fwd
   if (p.P == 0) return 0;
   const size_t lds = (size_t)ntiles * sizeof(uint32_t);
-  static size_t granted = 48 * 1024;           // raise the dynamic-LDS limit once per size, not on every launch
-  if (lds > granted) {
-    (void)hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    granted = lds;
-  }
+  static LdsGrant grant(48 * 1024);
+  grant.ensure((const void*)bin_count_kernel, lds);
   const int gpb = list.ids ? SLICE_GPB : GPB;       // the slice list is short: small work items, many workgroups
   const size_t n = list.ids && max_items < (size_t)p.P ? max_items : (size_t)p.P;
   hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)((n + gpb - 1) / gpb)), dim3(BLOCK), lds, st, p, splats, radii, mask,
@@ -543,11 +577,8 @@ void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_
   if (p.P == 0) return;
   const int ntiles = p.gx * p.gy;
   const size_t lds = 2 * (size_t)ntiles * sizeof(uint32_t);
-  static size_t granted = 32 * 1024;
-  if (lds > granted) {
-    (void)hipFuncSetAttribute((const void*)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    granted = lds;
-  }
+  static LdsGrant grant(32 * 1024);
+  grant.ensure((const void*)bin_scatter_kernel, lds);
   const int gpb = list.ids ? SLICE_GPB : GPB;
   const size_t n = list.ids && max_items < (size_t)p.P ? max_items : (size_t)p.P;
   hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)((n + gpb - 1) / gpb)), dim3(BLOCK), lds, st, p, splats, radii,
@@ -557,12 +588,8 @@ template <int THREADS>
 static void launch_radix(int ntiles, const uint2* ranges, const unsigned long long* bucket, uint32_t* point_list, int lo,
                          int hi, int cap, hipStream_t st) {
   const size_t lds = (size_t)cap * 16 + (size_t)(THREADS / 64 + 1) * 256 * sizeof(uint32_t);
-  static size_t granted = 48 * 1024;           // one static per THREADS instantiation
-  if (lds > granted) {
-    (void)hipFuncSetAttribute((const void*)bin_tilesort_radix_kernel<THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    granted = lds;
-  }
+  static LdsGrant grant(48 * 1024);            // one static per THREADS instantiation
+  grant.ensure((const void*)bin_tilesort_radix_kernel<THREADS>, lds);
   hipLaunchKernelGGL(bin_tilesort_radix_kernel<THREADS>, dim3(ntiles), dim3(THREADS), lds, st, ranges, bucket, point_list,
                      lo, hi, cap);
 }
@@ -577,12 +604,8 @@ void launch_bin_tilesort(int ntiles, uint32_t longest, const uint2* ranges, cons
   if (longest > 1024) launch_radix<512>(ntiles, ranges, bucket, point_list, 1025, 3073, 3072, st);
   if (longest > 3072) launch_radix<1024>(ntiles, ranges, bucket, point_list, 3073, 8193, 8192, st);
   if (longest > 8192) {
-    static bool granted = false;
-    if (!granted) {
-      (void)hipFuncSetAttribute((const void*)bin_tilesort_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                16384 * 8);
-      granted = true;
-    }
+    static LdsGrant grant(48 * 1024);
+    grant.ensure((const void*)bin_tilesort_kernel<1024>, 16384 * 8);
     hipLaunchKernelGGL(bin_tilesort_kernel<1024>, dim3(ntiles), dim3(1024), 16384 * 8, st, ranges, bucket, point_list,
                        8193, 16385);
   }

@@ -54,7 +54,7 @@ struct GeomLayout {
   size_t scan_temp_bytes;
   // near-slice pass (raster_api.hip): [zero_begin, zero_end) is cleared by preprocess_fwd on every call
   size_t zero_begin, zero_end;
-  size_t tile_count1, ranges1_bwd, slice_hist, slice_ctr;           // inside the zeroed span (tile_count is too)
+  size_t tile_count1, ranges1_bwd, slice_hist, slice_cover, slice_ctr;   // inside the zeroed span (tile_count is too)
   size_t zbin, cursor1, ranges1, mask2, block_counts1, bucket1, list1, uv, slice_ids;
   size_t slice_cap, slice_max_list;                                  // capacity of bucket1 / list1; of the work list
 };
@@ -64,6 +64,8 @@ struct GeomLayout {
 // cumulative 3-sigma-rect instance count still fits `cap`.
 constexpr int SLICE_BINS = 256;
 constexpr int SLICE_MAX_LIST = 3072;        // longest near-slice tile list that is sorted (longer: tile left to pass 2)
+constexpr float SLICE_MIN_COVER = 24.f;     // automatic mode: sum(radius^2) of the slice per pixel of the image, at least
+constexpr float SLICE_MIN_RATIO = 2.f;      // automatic mode: instances of the whole map / instances of the slice, at least
 struct SliceSel {
   int mode;                      // 0 = every Gaussian; 1 = near slice only; 2 = every Gaussian, exit if no tile is unfinished
   const uint8_t* zbin;           // [P] depth bin, 255 = not visible
@@ -76,6 +78,12 @@ struct SliceSel {
   // holds no unfinished tile is neither shaded nor enumerated (its Splat record may be unwritten - never touch it).
   const int32_t* sat;
   const float2* uv;
+  // automatic mode (decide != 0): the workgroups also decide, from the histograms alone, whether the slice is worth
+  // running at all; if not, the cut is -1 (empty slice, every tile goes to the second pass).  cover[bin] = sum of
+  // radius^2 (pixels^2) of the bin's Gaussians: ~ the optical depth x pixels they can deposit.
+  const unsigned long long* cover;   // [SLICE_BINS]
+  uint32_t npix;                     // pixels of the tile grid
+  int decide;
 };
 // number of unfinished tiles inside the tile rect [x0,x1) x [y0,y1)
 __device__ __forceinline__ int sat_count(const int32_t* __restrict__ sat, int gx, int x0, int y0, int x1, int y1) {
@@ -156,7 +164,26 @@ __device__ __forceinline__ int slice_cut(const SliceSel& sel) {
   for (int k = 0; k < w; ++k) { cum += s_wsum[0][k]; cum_n += s_wsum[1][k]; }
   // both sums are monotone in the bin index: a prefix of bins fits the two budgets
   const int n_ok = __syncthreads_count(cum <= (unsigned long long)sel.cap && cum_n <= (unsigned long long)sel.max_list);
-  return n_ok - 1;
+  const int cut = n_ok - 1;
+  if (!sel.decide || cut < 0) return cut;
+  // Is the slice worth its fixed cost?  (a) it must be able to saturate the image: every pixel needs an optical depth
+  // of -ln(T_threshold) ~ 9 before its walk stops, so the slice's Gaussians must carry a multiple of that per pixel
+  // (a single-layer surface map fails here: the nearest bins cover only the nearest part of the surface);  (b) it
+  // must leave most of the map behind it, or the second pass saves nothing.  Same inputs, same reduction order in
+  // every workgroup and kernel that calls this -> the same decision everywhere.
+  __shared__ float s_dec[3][BLOCK / 64];
+  float cov = tid <= cut ? (float)sel.cover[tid] : 0.f;
+  float ins = tid <= cut ? (float)sel.hist[tid] : 0.f;
+  float tot = (float)sel.hist[tid];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { cov += __shfl_xor(cov, off); ins += __shfl_xor(ins, off); tot += __shfl_xor(tot, off); }
+  if (lane == 0) { s_dec[0][w] = cov; s_dec[1][w] = ins; s_dec[2][w] = tot; }
+  __syncthreads();
+  cov = (s_dec[0][0] + s_dec[0][1]) + (s_dec[0][2] + s_dec[0][3]);
+  ins = (s_dec[1][0] + s_dec[1][1]) + (s_dec[1][2] + s_dec[1][3]);
+  tot = (s_dec[2][0] + s_dec[2][1]) + (s_dec[2][2] + s_dec[2][3]);
+  const bool use = cov >= SLICE_MIN_COVER * (float)sel.npix && tot >= SLICE_MIN_RATIO * ins;
+  return use ? cut : -1;
 }
 
 }  // namespace rtgs

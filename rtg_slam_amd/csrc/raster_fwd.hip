@@ -436,20 +436,22 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
   }
   contributor = last_contributor;   // accounting only (entries this pixel needed)
 
+  bool write_out = true;
   if (sp.mode == 1) {
     // A tile whose every pixel stopped inside the near slice is final: the slice's list is a prefix of the tile's full
     // list (depth bins are monotone in depth), so nothing behind it would have been read.  Anything else is redone
-    // from scratch by pass 2.
+    // from scratch by pass 2 (which overwrites every output of the tile: nothing is written for it here).
     const bool finished = __syncthreads_and(done) != 0;
+    const bool on = sp.user_mask[tile] != 0;
     if (tid == 0) {
-      const bool on = sp.user_mask[tile] != 0;
       sp.mask2[tile] = (on && !finished) ? 1 : 0;
       sp.ranges_bwd[tile] = finished ? range : make_uint2(0u, 0u);
       sp.ranges_main[tile] = make_uint2(0u, 0u);
     }
+    write_out = finished || !on;
   }
 
-  if (inside) {
+  if (inside && write_out) {
     const size_t pix = (size_t)py * p.W + px;
     const size_t HW = (size_t)p.H * p.W;
     out_color[pix] = C0 + T * p.bg[0];

@@ -276,7 +276,7 @@ class ShardedMapOptimizer:
         only (injected torch kernels fall back to `step`).  Returns this rank's loss (0-dim device view, overwritten by
         the next call); the rendered images of the step are in `self.last_render`."""
         from . import _lib
-        from .rasterizer import GaussianRasterizer, _Keep
+        from .rasterizer import GaussianRasterizer, _Keep, current_context
         if self.grad_rows is None:
             rast = GaussianRasterizer(raster_settings)
 
@@ -335,11 +335,11 @@ class ShardedMapOptimizer:
         stream = torch.cuda.current_stream(dev).cuda_stream
         if self.world == 1:
             with torch.cuda.device(dev):
-                rc = lib.rtgs_slam_map_step(C.byref(args), C.byref(R), C.c_void_p(stream))
+                rc = lib.rtgs_slam_map_step_ctx(current_context().ptr, C.byref(args), C.byref(R), C.c_void_p(stream))
             _lib.check(rc, "rtgs_slam_map_step")
         else:
             with torch.cuda.device(dev):
-                rc = lib.rtgs_slam_map_step_front(C.byref(args), C.byref(R), C.c_void_p(stream))
+                rc = lib.rtgs_slam_map_step_front_ctx(current_context().ptr, C.byref(args), C.byref(R), C.c_void_p(stream))
             _lib.check(rc, "rtgs_slam_map_step_front")
             self._exchange_rows(lib, ws, a, dev)
             stream = torch.cuda.current_stream(dev).cuda_stream

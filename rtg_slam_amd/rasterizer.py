@@ -5,6 +5,7 @@ plumbing only; all arithmetic runs in the HIP kernels of rtg_slam_amd/csrc."""
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import NamedTuple, Optional
 
 import torch
@@ -34,6 +35,77 @@ class GaussianRasterizationSettings(NamedTuple):
     cx: float
     cy: float
     T_threshold: float
+
+
+class RasterContext:
+    """A library context (include/rtgs_raster.h: rtgs_ctx): near-slice mode / budget, last-call statistics, stage
+    timings, work counters.  `RasterContext()` wraps the process-wide DEFAULT context (what the plain C entry points
+    use); `RasterContext.create()` makes a private one.  One context serves one rendering thread (the autograd
+    backward of a forward runs on the forward's context)."""
+
+    def __init__(self, handle=None, owned=False):
+        self.handle = handle            # None = the library's default context
+        self._owned = owned
+
+    @classmethod
+    def create(cls) -> "RasterContext":
+        h = _lib.load().rtgs_ctx_create()
+        if not h:
+            raise RuntimeError("rtgs_ctx_create failed")
+        return cls(h, owned=True)
+
+    def __del__(self):
+        try:
+            if self._owned and self.handle:
+                _lib.load().rtgs_ctx_destroy(C.c_void_p(self.handle))
+                self.handle = None
+        except Exception:
+            pass
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.handle)
+
+    def set_near_slice(self, mode: int, budget_per_tile: int = 0):
+        _lib.load().rtgs_raster_set_near_slice_ctx(self.ptr, int(mode), int(budget_per_tile))
+
+    def force_sort_path(self, enable: bool):
+        _lib.load().rtgs_raster_force_sort_path_ctx(self.ptr, int(bool(enable)))
+
+    def set_profiling(self, enable: bool):
+        _lib.load().rtgs_raster_set_profiling_ctx(self.ptr, int(bool(enable)))
+
+    def set_counters(self, counters: Optional[torch.Tensor]):
+        _lib.load().rtgs_raster_set_counters_ctx(self.ptr, C.c_void_p(counters.data_ptr() if counters is not None else 0))
+
+    def last_stats(self):
+        out = (C.c_int64 * 8)()
+        _lib.check(_lib.load().rtgs_raster_last_stats_ctx(self.ptr, out), "rtgs_raster_last_stats")
+        return [int(v) for v in out]
+
+    def last_slice_stats(self):
+        out = (C.c_int64 * 4)()
+        _lib.check(_lib.load().rtgs_raster_last_slice_stats_ctx(self.ptr, out), "rtgs_raster_last_slice_stats")
+        return dict(used=int(out[0]), instances=int(out[1]), tiles_finished=int(out[2]), tiles_left_to_pass2=int(out[3]))
+
+    def last_timings(self):
+        out = (C.c_float * 10)()
+        _lib.check(_lib.load().rtgs_raster_last_timings_ctx(self.ptr, out), "rtgs_raster_last_timings")
+        return [float(v) for v in out]
+
+
+_tls = threading.local()
+
+
+def current_context() -> RasterContext:
+    """The context ops of the calling thread use when none is passed: the library's default context on the main
+    thread, a private one (created on first use) on every other thread - so two threads never share statistics,
+    pinned sync words or near-slice settings by accident."""
+    c = getattr(_tls, "ctx", None)
+    if c is None:
+        c = RasterContext() if threading.current_thread() is threading.main_thread() else RasterContext.create()
+        _tls.ctx = c
+    return c
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -113,8 +185,10 @@ def _require_device(t: torch.Tensor):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, opacities, shs, scales, rotations, normal_w, tile_mask, raster_settings, grad_rows=None):
+    def forward(ctx, means3D, opacities, shs, scales, rotations, normal_w, tile_mask, raster_settings, grad_rows=None,
+                context=None):
         lib = _lib.load()
+        rctx = context if context is not None else current_context()
         _require_device(means3D)
         dev = means3D.device
         rs = raster_settings
@@ -143,8 +217,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         R = C.c_int64(0)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            rc = lib.rtgs_raster_forward(
-                C.byref(keep.c), P, M, _ptr(means3D), _ptr(opacities), _ptr(shs), _ptr(scales), _ptr(rotations),
+            rc = lib.rtgs_raster_forward_ctx(
+                rctx.ptr, C.byref(keep.c), P, M, _ptr(means3D), _ptr(opacities), _ptr(shs), _ptr(scales), _ptr(rotations),
                 _ptr(normal_w), _ptr(tile_mask), _ptr(color), _ptr(depth), _ptr(cidx), _ptr(didx), _ptr(cw),
                 _ptr(dw), _ptr(Tm), _ptr(radii), geom.cb, None, binning.cb, None, img.cb, None, C.byref(R),
                 C.c_void_p(stream))
@@ -153,6 +227,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = int(R.value)
         ctx.M = M
         ctx.grad_rows = grad_rows
+        ctx.rctx = rctx
         ctx.save_for_backward(means3D, opacities, shs, scales, rotations, normal_w, geom.tensor, binning.tensor,
                               img.tensor, color, Tm, didx)
         ctx.mark_non_differentiable(cidx, didx, cw, dw, Tm)
@@ -178,15 +253,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 keep = _Keep(rs, dev)
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 with torch.cuda.device(dev):
-                    rc = lib.rtgs_raster_backward_rows(
-                        C.byref(keep.c), P, ctx.M, ctx.num_rendered, _ptr(means3D), _ptr(opacities), _ptr(shs),
+                    rc = lib.rtgs_raster_backward_rows_ctx(
+                        ctx.rctx.ptr, C.byref(keep.c), P, ctx.M, ctx.num_rendered, _ptr(means3D), _ptr(opacities), _ptr(shs),
                         _ptr(scales), _ptr(rotations), _ptr(normal_w), _ptr(geom), _ptr(binning), _ptr(img),
                         _ptr(color), _ptr(Tm), _ptr(didx), _ptr(g_color), _ptr(g_depth), _ptr(arena.d_means),
                         _ptr(arena.d_opac), _ptr(arena.d_shs), _ptr(arena.d_scales), _ptr(arena.d_rots),
                         _ptr(arena.d_normal), _ptr(arena.scratch), _ptr(arena.row_state), C.c_void_p(stream))
                 _lib.check(rc, "rtgs_raster_backward_rows")
                 return (arena.d_means, arena.d_opac, arena.d_shs.view_as(shs), arena.d_scales, arena.d_rots,
-                        arena.d_normal, None, None, None)
+                        arena.d_normal, None, None, None, None)
         d_means = torch.empty_like(means3D)
         d_opac = torch.empty_like(opacities)
         d_shs = torch.empty_like(shs)
@@ -198,13 +273,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             keep = _Keep(rs, dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             with torch.cuda.device(dev):
-                rc = lib.rtgs_raster_backward(
-                    C.byref(keep.c), P, ctx.M, ctx.num_rendered, _ptr(means3D), _ptr(opacities), _ptr(shs),
+                rc = lib.rtgs_raster_backward_ctx(
+                    ctx.rctx.ptr, C.byref(keep.c), P, ctx.M, ctx.num_rendered, _ptr(means3D), _ptr(opacities), _ptr(shs),
                     _ptr(scales), _ptr(rotations), _ptr(normal_w), _ptr(geom), _ptr(binning), _ptr(img), _ptr(color),
                     _ptr(Tm), _ptr(didx), _ptr(g_color), _ptr(g_depth), _ptr(d_means), _ptr(d_opac), _ptr(d_shs),
                     _ptr(d_scales), _ptr(d_rots), _ptr(d_normal), _ptr(scratch), C.c_void_p(stream))
             _lib.check(rc, "rtgs_raster_backward")
-        return d_means, d_opac, d_shs, d_scales, d_rots, d_normal, None, None, None
+        return d_means, d_opac, d_shs, d_scales, d_rots, d_normal, None, None, None, None
 
 
 class GaussianRasterizer(nn.Module):
@@ -218,7 +293,8 @@ class GaussianRasterizer(nn.Module):
         self.raster_settings = raster_settings
 
     def forward(self, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, normal_w=None, tile_mask=None, grad_rows: Optional[RowGradArena] = None):
+                cov3D_precomp=None, normal_w=None, tile_mask=None, grad_rows: Optional[RowGradArena] = None,
+                context: Optional[RasterContext] = None):
         rs = self.raster_settings
         if colors_precomp is not None or cov3D_precomp is not None:
             raise NotImplementedError(
@@ -241,4 +317,5 @@ class GaussianRasterizer(nn.Module):
         if tile_mask is None:
             tile_mask = torch.ones((int(rs.image_height) + 15) // 16, (int(rs.image_width) + 15) // 16,
                                    dtype=torch.int32, device=means3D.device)
-        return _RasterizeGaussians.apply(means3D, opacities, shs, scales, rotations, normal_w, tile_mask, rs, grad_rows)
+        return _RasterizeGaussians.apply(means3D, opacities, shs, scales, rotations, normal_w, tile_mask, rs, grad_rows,
+                                         context)

@@ -125,6 +125,59 @@ def random_gaussians(N: int, cam: CameraSpec, seed: int = 2024, z_range=(0.5, 5.
     return out
 
 
+def surface_gaussians(N: int, cam: CameraSpec, seed: int = 2024, half=(2.5, 1.5, 3.0),
+                      c2w: torch.Tensor | None = None) -> Dict[str, torch.Tensor]:
+    """A single-layer SURFACE map, the shape RTG-SLAM's mapper actually builds (mapper.py:715-829 samples new
+    Gaussians on depth-map pixels, gaussian_pointcloud.py:366-405 sets their radius to the spacing of their three
+    nearest neighbours): N discs spread uniformly over the six walls of the box room of `box_room_depth`
+    (|x|<hx, |y|<hy, |z|<hz, camera inside), flat against the wall (normal = smallest axis, xyz_factor [1,1,0.1]),
+    radius = sqrt(area / N) clipped to [min_radius, max_radius] = [0.001, 0.05] (configs/base.yaml:32-36),
+    opacity init_opacity = 0.99, smooth position-dependent colour.  Only the part of the room inside the frustum is
+    visible from one view, as in a real map.  `cam` is unused by the geometry (kept for a uniform signature)."""
+    g = torch.Generator().manual_seed(seed)
+    U = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64)
+    hx, hy, hz = half
+    areas = torch.tensor([4 * hy * hz, 4 * hy * hz, 4 * hx * hz, 4 * hx * hz, 4 * hx * hy, 4 * hx * hy], dtype=torch.float64)
+    wall = torch.multinomial(areas / areas.sum(), N, replacement=True, generator=g)
+    a, b = 2 * U(N) - 1, 2 * U(N) - 1
+    ax = wall // 2                                     # axis the wall is perpendicular to
+    sgn = (wall % 2).double() * 2 - 1                  # which of the two walls
+    hv = torch.tensor([hx, hy, hz], dtype=torch.float64)
+    o0 = torch.tensor([1, 0, 0])[ax]                   # the two in-plane axes
+    o1 = torch.tensor([2, 2, 1])[ax]
+    xyz = torch.zeros(N, 3, dtype=torch.float64)
+    idx = torch.arange(N)
+    xyz[idx, ax] = sgn * hv[ax]
+    xyz[idx, o0] = a * hv[o0]
+    xyz[idx, o1] = b * hv[o1]
+    n = torch.zeros(N, 3, dtype=torch.float64)
+    n[idx, ax] = -sgn                                  # into the room
+    t1 = torch.zeros(N, 3, dtype=torch.float64)
+    t1[idx, o0] = 1.0
+    spin = 2 * math.pi * U(N)
+    t2 = torch.linalg.cross(n, t1)
+    a1 = torch.cos(spin)[:, None] * t1 + torch.sin(spin)[:, None] * t2
+    a2 = torch.linalg.cross(n, a1)
+    R = torch.stack([a1, a2, n], dim=-1)               # columns = local axes, det +1
+    r = float(min(0.05, max(0.001, math.sqrt(float(areas.sum()) / N))))
+    rr = r * (0.85 + 0.3 * U(N))
+    scales = torch.stack([rr, rr * (0.8 + 0.2 * U(N)), 0.1 * rr], -1)
+    opacity = torch.full((N, 1), 0.99, dtype=torch.float64)
+    col = 0.5 + 0.35 * torch.stack([torch.sin(1.3 * xyz[:, 0] + 0.7 * xyz[:, 2]), torch.cos(1.1 * xyz[:, 1] - 0.4 * xyz[:, 0]),
+                                    torch.sin(0.9 * xyz[:, 2] + 0.5 * xyz[:, 1])], -1)
+    dc = ((col - 0.5) / SH_C0)[:, None, :]
+    rest = 0.02 * torch.randn(N, 15, 3, generator=g, dtype=torch.float64)
+    shs = torch.cat([dc, rest], dim=1)
+    if c2w is not None:
+        c2w = c2w.double()
+        xyz = xyz @ c2w[:3, :3].t() + c2w[:3, 3]
+        R = c2w[:3, :3] @ R
+    out = dict(xyz=xyz, opacity=opacity, scales=scales, rotations=rotmat_to_quat(R), shs=shs)
+    out = {k: t.to(torch.float32).contiguous() for k, t in out.items()}
+    out["normal"] = normal_from_scale_rot(out["scales"], out["rotations"]).contiguous()
+    return out
+
+
 def look_at_pose(seed: int = 0, max_angle_deg: float = 10.0, max_trans: float = 0.2) -> torch.Tensor:
     """A random camera-to-world pose near identity (float64 4x4)."""
     g = torch.Generator().manual_seed(seed)
