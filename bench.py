@@ -264,7 +264,7 @@ def main():
 def profile_scene(lib, mo, rast, opt, N, cam, tile_mask, gt_color, gt_depth, dev, nprof):
     """Per-stage HIP-event timings (on the launch stream, inside the library), work counters and algorithmic-byte
     rooflines of the rasterizer forward + backward on the optimiser's current map, through the autograd path."""
-    counters = torch.zeros(2, dtype=torch.int64, device=dev)
+    counters = torch.zeros(2 * tile_mask.numel(), dtype=torch.int64, device=dev)
     acc = [0.0] * 10
     consumed = pairs = R = 0
     rows_touched = rows_cleared = 0
@@ -296,7 +296,7 @@ def profile_scene(lib, mo, rast, opt, N, cam, tile_mask, gt_color, gt_depth, dev
         st = (C.c_int64 * 8)()
         lib.rtgs_raster_last_stats(st)
         R = int(st[0])
-        cc = counters.cpu()
+        cc = counters.view(-1, 2).sum(0).cpu()
         consumed, pairs = int(cc[0]), int(cc[1])
         rows_touched = int((opt.grad_rows.row_state == 1).sum())
         rows_cleared = int((opt.grad_rows.row_state == 2).sum())

@@ -63,11 +63,15 @@ typedef struct rtgs_icp_level {
   const float* normal_tgt;
 } rtgs_icp_level;
 
-/* Runs the whole multi-level Gauss-Newton loop on the device.
+/* Runs the whole multi-level Gauss-Newton loop on the device - ONE persistent kernel (a workgroup per CU, a grid
+ * barrier per iteration, every workgroup takes the same step on its own copy of the pose; RTGS_ICP_PERSISTENT=0
+ * selects one launch per iteration instead).
  *   pose_inout: device float[16], initial guess in, estimate out (pose_t1_t0)
  *   stats_out : device float[4] = { valid_ratio of the last iteration (icp.py:46-47),
  *               point2plane loss at the last level (icp.py:443-447), number of solves that
- *               hit a non-SPD system (pose left unchanged for that iteration), 0 } */
+ *               hit a non-SPD system (pose left unchanged for that iteration),
+ *               1 if the persistent kernel gave up waiting at a grid barrier (pose_inout is then unchanged; the
+ *               wait is bounded so that a scheduling pathology cannot hang the device), else 0 } */
 int rtgs_icp_track(const rtgs_icp_level* levels_host, int32_t n_levels, const float* K,
                    float distance_threshold, float cos_normal_threshold, float damping,
                    float* pose_inout, float* stats_out, void* scratch, void* stream);

@@ -95,7 +95,9 @@ int rtgs_raster_forward(const rtgs_raster_settings* settings, int32_t P, int32_t
                         int64_t* num_rendered_host, void* stream);
 
 /* Backward: consumes the three scratch buffers of the matching forward plus the forward's
- * out_color, out_T and out_depth_index.  Writes (never accumulates into) the gradient tensors:
+ * out_color, out_T and out_depth_index.  The geometry and binning buffers are scratch of the forward / backward PAIR:
+ * the backward writes into them too (per-Gaussian slot counters, per-(Gaussian, tile) gradient partials), so one
+ * forward's buffers serve ONE backward at a time.  Writes (never accumulates into) the gradient tensors:
  *   dL_dmeans3D[P,3] dL_dopacities[P,1] dL_dshs[P,sh_coeffs,3] dL_dscales[P,3]
  *   dL_drotations[P,4] dL_dnormal_w[P,3]
  * Rows of Gaussians that touched no rendered pixel are exactly 0 (mapper.py:455 relies on it).
@@ -104,7 +106,7 @@ int rtgs_raster_backward(const rtgs_raster_settings* settings, int32_t P, int32_
                          int64_t num_rendered,
                          const float* means3D, const float* opacities, const float* shs,
                          const float* scales, const float* rotations, const float* normal_w,
-                         const void* geom_buffer, const void* binning_buffer,
+                         void* geom_buffer, void* binning_buffer,
                          const void* image_buffer, const float* out_color, const float* out_T,
                          const int32_t* out_depth_index,
                          const float* dL_dcolor, const float* dL_ddepth,
@@ -114,6 +116,10 @@ int rtgs_raster_backward(const rtgs_raster_settings* settings, int32_t P, int32_
 
 size_t rtgs_raster_backward_scratch_bytes(int32_t P);
 
+/* flags of rtgs_raster_forward_ctx (the plain rtgs_raster_forward passes 0) */
+#define RTGS_FWD_NO_BACKWARD 1   /* no backward will follow: skip the backward's bookkeeping (a scan over the Gaussians and
+                                    the gradient-slot allocation inside the binning buffer).  A backward called anyway
+                                    is still correct - it falls back to global atomics. */
 int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* settings, int32_t P, int32_t sh_coeffs,
                             const float* means3D, const float* opacities, const float* shs,
                             const float* scales, const float* rotations, const float* normal_w,
@@ -124,12 +130,12 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* settings,
                             rtgs_resize_fn geom_resize, void* geom_user,
                             rtgs_resize_fn binning_resize, void* binning_user,
                             rtgs_resize_fn image_resize, void* image_user,
-                            int64_t* num_rendered_host, void* stream);
+                            int64_t* num_rendered_host, int32_t flags, void* stream);
 int rtgs_raster_backward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* settings, int32_t P, int32_t sh_coeffs,
                              int64_t num_rendered,
                              const float* means3D, const float* opacities, const float* shs,
                              const float* scales, const float* rotations, const float* normal_w,
-                             const void* geom_buffer, const void* binning_buffer,
+                             void* geom_buffer, void* binning_buffer,
                              const void* image_buffer, const float* out_color, const float* out_T,
                              const int32_t* out_depth_index,
                              const float* dL_dcolor, const float* dL_ddepth,
@@ -150,7 +156,7 @@ int rtgs_raster_backward_rows(const rtgs_raster_settings* settings, int32_t P, i
                               int64_t num_rendered,
                               const float* means3D, const float* opacities, const float* shs,
                               const float* scales, const float* rotations, const float* normal_w,
-                              const void* geom_buffer, const void* binning_buffer,
+                              void* geom_buffer, void* binning_buffer,
                               const void* image_buffer, const float* out_color, const float* out_T,
                               const int32_t* out_depth_index,
                               const float* dL_dcolor, const float* dL_ddepth,
@@ -162,7 +168,7 @@ int rtgs_raster_backward_rows_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* set
                                   int64_t num_rendered,
                                   const float* means3D, const float* opacities, const float* shs,
                                   const float* scales, const float* rotations, const float* normal_w,
-                                  const void* geom_buffer, const void* binning_buffer,
+                                  void* geom_buffer, void* binning_buffer,
                                   const void* image_buffer, const float* out_color, const float* out_T,
                                   const int32_t* out_depth_index,
                                   const float* dL_dcolor, const float* dL_ddepth,
@@ -183,9 +189,10 @@ size_t rtgs_raster_image_bytes(int32_t image_height, int32_t image_width);
 int rtgs_raster_last_stats(int64_t* stats8_host);
 int rtgs_raster_last_stats_ctx(rtgs_ctx* ctx, int64_t* stats8_host);
 
-/* Device-side counters of work actually done by blend_fwd (instances consumed before the
- * per-tile early exit).  `counters` = device int64[2] zeroed by the caller, or NULL to
- * disable.  Per context, sticky until reset with NULL (measurement aid). */
+/* Device-side counters of work actually done by blend_fwd: per tile, [2 t] = list entries the tile's walk consumed
+ * before every pixel had terminated, [2 t + 1] = (entry, pixel) pairs evaluated.  `counters` = device uint64[2 x tiles]
+ * (written, not accumulated, by each forward), or NULL to disable.  Per context, sticky until reset with NULL
+ * (measurement aid). */
 void rtgs_raster_set_counters(void* counters);
 void rtgs_raster_set_counters_ctx(rtgs_ctx* ctx, void* counters);
 

@@ -142,12 +142,20 @@ def gauss_newton_update(JtJ, Jtr, pose, damping):
     return se3_exp(xi) @ pose
 
 
-def icp_level(pose, v_src, v_tgt, n_src, n_tgt, K, iters, dist_thr, cos_thr, damping):
+def icp_level(pose, v_src, v_tgt, n_src, n_tgt, K, iters, dist_thr, cos_thr, damping, exact_sums=False):
+    """`exact_sums`: the per-pixel arithmetic (projection, association, gates, residual, Jacobian) stays the
+    reference's float32, but the 27 sums over the pixels and the 6x6 solve are done in float64 - the reference
+    algorithm without the rounding noise of its own float32 reductions (which an ill-conditioned, noisy frame
+    amplifies).  The HIP tracker reduces in float64 too, so this is the variant it should match most closely."""
     valid = None
     for _ in range(iters):
         res, J, valid = residuals_jacobian(v_src, v_tgt, n_src, n_tgt, pose, K, dist_thr, cos_thr)
-        JtJ, Jtr = normal_equations(J, res)
-        pose = gauss_newton_update(JtJ, Jtr, pose, damping)
+        if exact_sums:
+            JtJ, Jtr = normal_equations(J.double(), res.double())
+            pose = gauss_newton_update(JtJ, Jtr, pose.double(), damping).float()
+        else:
+            JtJ, Jtr = normal_equations(J, res)
+            pose = gauss_newton_update(JtJ, Jtr, pose, damping)
     H, W = v_src.shape[:2]
     return pose, valid.sum() / H / W
 
@@ -158,7 +166,7 @@ def p2p_loss(p_t0, p_t1, n_t0):
 
 
 def track(vp_t1, np_t1, vp_t0, np_t0, K, downscales=(0.25, 0.5, 1.0), iters=(5, 5, 5),
-          dist_thr=0.1, normal_thr_deg=20.0, damping=1e-4):
+          dist_thr=0.1, normal_thr_deg=20.0, damping=1e-4, exact_sums=False):
     """Level loop + loss of predict_pose; source = current frame t1, target = t0 (icp.py:438-441)."""
     cos_thr = math.cos(math.radians(normal_thr_deg))
     pose = torch.eye(4, dtype=torch.float32)
@@ -166,7 +174,8 @@ def track(vp_t1, np_t1, vp_t0, np_t0, K, downscales=(0.25, 0.5, 1.0), iters=(5, 
     for l, ds in enumerate(downscales):
         Kl = K * ds
         Kl[2, 2] = 1.0
-        pose, ratio = icp_level(pose, vp_t1[l], vp_t0[l], np_t1[l], np_t0[l], Kl, iters[l], dist_thr, cos_thr, damping)
+        pose, ratio = icp_level(pose, vp_t1[l], vp_t0[l], np_t1[l], np_t0[l], Kl, iters[l], dist_thr, cos_thr, damping,
+                                exact_sums)
     loss = p2p_loss(vp_t0[-1], vp_t1[-1] @ pose[:3, :3].t() + pose[:3, 3], np_t0[-1])
     return pose, float(ratio), float(loss)
 

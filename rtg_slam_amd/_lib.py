@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTGS_LIB_PATH") or os.path.join(_HERE, "librtgs_hip.so")   # env override: A/B of kernel variants
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+FWD_NO_BACKWARD = 1          # RTGS_FWD_NO_BACKWARD (include/rtgs_raster.h)
 
 
 class RasterSettingsC(C.Structure):
@@ -96,7 +97,8 @@ _SIGNATURES = {
     "rtgs_ctx_create": (C.c_void_p, []),
     "rtgs_ctx_destroy": (None, [_P]),
     "rtgs_raster_forward_ctx": (C.c_int, [_P, C.POINTER(RasterSettingsC), C.c_int32, C.c_int32] + [_P] * 6 + [_P]
-                                + [_P] * 8 + [RESIZE_FN, _P, RESIZE_FN, _P, RESIZE_FN, _P, C.POINTER(C.c_int64), _P]),
+                                + [_P] * 8 + [RESIZE_FN, _P, RESIZE_FN, _P, RESIZE_FN, _P, C.POINTER(C.c_int64),
+                                              C.c_int32, _P]),
     "rtgs_raster_backward_ctx": (C.c_int, [_P, C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6
                                  + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P]),
     "rtgs_raster_backward_rows_ctx": (C.c_int, [_P, C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6

@@ -7,6 +7,7 @@
 #include "../../include/rtgs_icp.h"
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace rtgs_icp {
 
@@ -18,7 +19,7 @@ struct Scratch {
   uint32_t minmax[2 * RTGS_ICP_MAX_LEVELS];   // per level: enc(min), ~enc(max)
   float partials[MAX_BLOCKS * PSTRIDE];
   uint32_t ticket;                            // arrival counter of the residual kernel's workgroups
-  uint32_t pad[15];
+  uint32_t pad[15];                           // pad[0]: abort flag of the persistent track kernel
 };
 
 __device__ __forceinline__ uint32_t enc_f(float f) {
@@ -104,11 +105,14 @@ __global__ void __launch_bounds__(256) icp_normal_kernel(PyrDesc d, const Scratc
     gx[c] = -a00 + a02 - 2.f * a10 + 2.f * a12 - a20 + a22;
     gy[c] = -a00 - 2.f * a01 - a02 + a20 + 2.f * a21 + a22;
   }
-  // cross(dy, dx)
-  float nx = gy[1] * gx[2] - gy[2] * gx[1];
-  float ny = gy[2] * gx[0] - gy[0] * gx[2];
-  float nz = gy[0] * gx[1] - gy[1] * gx[0];
-  const float mag = sqrtf(nx * nx + ny * ny + nz * nz) + 1e-8f;
+  // cross(dy, dx), rounded as torch.cross rounds it: a b - c d = fma(a, b, -(c d)); and |n| as torch.norm does:
+  // sqrt(fma(z, z, fma(y, y, x x))) - both probed against torch 2.10 CPU, bit for bit (the Sobel sums above already
+  // follow conv2d's row-major tap order).  With that the normal pyramid equals the reference's exactly, and with it
+  // every gate decision of the tracker that tests a normal.
+  float nx = __fmaf_rn(gy[1], gx[2], -(gy[2] * gx[1]));
+  float ny = __fmaf_rn(gy[2], gx[0], -(gy[0] * gx[2]));
+  float nz = __fmaf_rn(gy[0], gx[1], -(gy[1] * gx[0]));
+  const float mag = sqrtf(__fmaf_rn(nz, nz, __fmaf_rn(ny, ny, nx * nx))) + 1e-8f;
   nx /= mag; ny /= mag; nz /= mag;
   const float dep = V[(size_t)idx * 3 + 2];
   const float dmin = dec_f(sc->minmax[2 * l]), dmax = dec_f(~sc->minmax[2 * l + 1]);
@@ -168,19 +172,11 @@ struct FinalArgs {
   float* nvalid_out;
 };
 
-// Executed by ONE whole workgroup (256 threads): the last one to arrive in the residual kernel.
-__device__ __forceinline__ void final_stage(const float* __restrict__ partials, int nblocks, const FinalArgs& fa) {
-  const int mode = fa.mode;
-  const float damping = fa.damping, inv_pixels = fa.inv_pixels;
-  float* __restrict__ pose = fa.pose;
-  float* __restrict__ stats = fa.stats;
-  float* __restrict__ JtJ_out = fa.JtJ_out;
-  float* __restrict__ Jtr_out = fa.Jtr_out;
-  float* __restrict__ nvalid_out = fa.nvalid_out;
-  // 256 threads = 32 row groups x 8 four-float columns: every thread issues all of its (<= 16 x 4)
-  // write-through loads before the first add, so the whole partial matrix costs ~2 memory round trips
-  __shared__ double s_sum[32 * PSTRIDE];
-  __shared__ double s_tot[PSTRIDE];
+// Sum of the per-workgroup partial rows in float64, by ONE whole workgroup (256 threads); the 28 totals land in
+// s_tot (shared, PSTRIDE doubles) and are visible to every thread on return.
+// 256 threads = 32 row groups x 8 four-float columns: every thread issues all of its (<= 16 x 4) write-through loads
+// before the first add, so the whole partial matrix costs ~2 memory round trips.
+__device__ __forceinline__ void sum_partials(const float* __restrict__ partials, int nblocks, double* s_sum, double* s_tot) {
   {
     const int q = threadIdx.x & 7, grp = threadIdx.x >> 3;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -211,11 +207,12 @@ __device__ __forceinline__ void final_stage(const float* __restrict__ partials, 
     s_tot[threadIdx.x] = t;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  double S[NACC];
-#pragma unroll
-  for (int c = 0; c < NACC; ++c) S[c] = s_tot[c];
-  if (mode == MODE_P2P) { stats[1] = (float)(S[0] * (double)inv_pixels); return; }
+}
+
+// One Gauss-Newton update from the 28 sums, by ONE thread: lev_mar_H damping (icp.py:248-256), xi = -H^-1 J^T r
+// through a register-resident Cholesky (icp.py:328-334 inverts H on the CPU), pose <- exp(xi) @ pose (icp.py:271-310,
+// :259-268).  Returns false (pose untouched) when the damped H is not positive definite.
+__device__ __forceinline__ bool gn_update(const double (&S)[NACC], float damping, float* pose) {
   double Hm[6][6], bvec[6];
 #pragma unroll
   for (int r = 0; r < 6; ++r)
@@ -226,25 +223,14 @@ __device__ __forceinline__ void final_stage(const float* __restrict__ partials, 
     }
 #pragma unroll
   for (int r = 0; r < 6; ++r) bvec[r] = S[21 + r];
-  if (mode == MODE_EQUATIONS) {
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) JtJ_out[r * 6 + c] = (float)Hm[r][c];
-      Jtr_out[r] = (float)bvec[r];
-    }
-    nvalid_out[0] = (float)S[27];
-    return;
-  }
-  stats[0] = (float)(S[27] * (double)inv_pixels);            // valid_ratio (icp.py:46-47)
-  // lev_mar_H (icp.py:248-256): H += trace(H) * damping * I
   double tr = 0.0;
 #pragma unroll
   for (int r = 0; r < 6; ++r) tr += Hm[r][r];
 #pragma unroll
   for (int r = 0; r < 6; ++r) Hm[r][r] += tr * (double)damping;
-  // Cholesky H = L L^T, fully unrolled so every array stays in registers (no scratch)
-  double L[6][6];
+  // Cholesky H = L L^T, fully unrolled so every array stays in registers (no scratch); the diagonal is kept as its
+  // reciprocal (one division per row instead of one per entry)
+  double L[6][6], inv[6];
   bool spd = true;
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
@@ -256,26 +242,27 @@ __device__ __forceinline__ void final_stage(const float* __restrict__ partials, 
       if (r == c) {
         spd = spd && (s > 0.0);
         L[r][r] = sqrt(s > 0.0 ? s : 1.0);
+        inv[r] = 1.0 / L[r][r];
       } else {
-        L[r][c] = s / L[c][c];
+        L[r][c] = s * inv[c];
       }
     }
   }
-  if (!spd) { stats[2] += 1.f; return; }
+  if (!spd) return false;
   double yv[6], xi[6];
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     double s = -bvec[r];                                     // xi = -H^-1 Jtr (icp.py:328-334)
 #pragma unroll
     for (int m = 0; m < r; ++m) s -= L[r][m] * yv[m];
-    yv[r] = s / L[r][r];
+    yv[r] = s * inv[r];
   }
 #pragma unroll
   for (int r = 5; r >= 0; --r) {
     double s = yv[r];
 #pragma unroll
     for (int m = r + 1; m < 6; ++m) s -= L[m][r] * xi[m];
-    xi[r] = s / L[r][r];
+    xi[r] = s * inv[r];
   }
   // exp_se3 (icp.py:271-310): Rodrigues + left Jacobian.  The three coefficients sin(t)/t,
   // (1-cos t)/t^2, (t-sin t)/t^3 are evaluated by their Maclaurin series in double (|xi_w| of an
@@ -327,6 +314,34 @@ __device__ __forceinline__ void final_stage(const float* __restrict__ partials, 
       if (c == 3) o += E[r][3];
       pose[r * 4 + c] = (float)o;
     }
+  return true;
+}
+
+// Executed by ONE whole workgroup (256 threads): the last one to arrive in the residual kernel.
+__device__ __forceinline__ void final_stage(const float* __restrict__ partials, int nblocks, const FinalArgs& fa) {
+  __shared__ double s_sum[32 * PSTRIDE];
+  __shared__ double s_tot[PSTRIDE];
+  sum_partials(partials, nblocks, s_sum, s_tot);
+  if (threadIdx.x != 0) return;
+  double S[NACC];
+#pragma unroll
+  for (int c = 0; c < NACC; ++c) S[c] = s_tot[c];
+  if (fa.mode == MODE_P2P) { fa.stats[1] = (float)(S[0] * (double)fa.inv_pixels); return; }
+  if (fa.mode == MODE_EQUATIONS) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        fa.JtJ_out[r * 6 + c] = (float)S[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+      }
+      fa.Jtr_out[r] = (float)S[21 + r];
+    }
+    fa.nvalid_out[0] = (float)S[27];
+    return;
+  }
+  fa.stats[0] = (float)(S[27] * (double)fa.inv_pixels);            // valid_ratio (icp.py:46-47)
+  if (!gn_update(S, fa.damping, fa.pose)) fa.stats[2] += 1.f;
 }
 
 // Publish this workgroup's partial row and elect the last arriver.  Hand-off form (cdna_hip_programming.md
@@ -349,64 +364,104 @@ __device__ __forceinline__ bool arrive_and_elect_last(uint32_t* ticket) {
 }
 
 // ---- K12: residual + Jacobian + 6x6 reduction (icp.py:52-119) ---------------------------------
+struct LevelGeom {
+  float R00, R01, R02, t0, R10, R11, R12, t1, R20, R21, R22, t2;
+  float fx, fy, cx, cy, Wm1, Hm1, hw, hh, dist_thr, cos_thr;
+  int W;
+};
+
+// One source pixel: transform, project, nearest-neighbour association, the three gates, and the rank-1 update of the
+// 27 sums + valid count.  The float32 op sequence of the gating arithmetic follows the reference's (icp.py:52-104,
+// warp_features :132-148) so that associations and gate decisions match it bit for bit.
+__device__ __forceinline__ void accumulate_pixel(const LevelGeom& g, float v0, float v1, float v2, float n0, float n1,
+                                                 float n2, const float* __restrict__ vt, const float* __restrict__ nt,
+                                                 float (&acc)[NACC]) {
+  const float px = (g.R00 * v0 + g.R01 * v1 + g.R02 * v2) + g.t0;
+  const float py = (g.R10 * v0 + g.R11 * v1 + g.R12 * v2) + g.t1;
+  const float pz = (g.R20 * v0 + g.R21 * v1 + g.R22 * v2) + g.t2;
+  const float u = (px / pz) * g.fx + g.cx;
+  const float v = (py / pz) * g.fy + g.cy;
+  const bool inview = (u > 0.f) && (u < g.Wm1) && (v > 0.f) && (v < g.Hm1);
+  if (!inview || !(v2 > 0.f)) return;
+  // grid_sample(nearest, border, align_corners=True) of warp_features (icp.py:132-148)
+  const float un = u / g.hw - 1.f, vn = v / g.hh - 1.f;
+  float ix = ((un + 1.f) / 2.f) * g.Wm1, iy = ((vn + 1.f) / 2.f) * g.Hm1;
+  ix = fminf(g.Wm1, fmaxf(ix, 0.f));
+  iy = fminf(g.Hm1, fmaxf(iy, 0.f));
+  const int xi = (int)nearbyintf(ix), yi = (int)nearbyintf(iy);
+  const size_t j = ((size_t)yi * g.W + xi) * 3;
+  const float q0 = vt[j], q1 = vt[j + 1], q2 = vt[j + 2];
+  if (!(q2 > 0.f)) return;
+  const float m0 = nt[j], m1 = nt[j + 1], m2 = nt[j + 2];
+  const float rn0 = g.R00 * n0 + g.R01 * n1 + g.R02 * n2;
+  const float rn1 = g.R10 * n0 + g.R11 * n1 + g.R12 * n2;
+  const float rn2 = g.R20 * n0 + g.R21 * n1 + g.R22 * n2;
+  if (!(rn0 * m0 + rn1 * m1 + rn2 * m2 > g.cos_thr)) return;
+  const float d0 = px - q0, d1 = py - q1, d2 = pz - q2;
+  if (sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > g.dist_thr) return;
+  const float r = m0 * d0 + m1 * d1 + m2 * d2;
+  float J[6];
+  J[0] = py * m2 - pz * m1;        // -(m^T [p]x) = p x m
+  J[1] = pz * m0 - px * m2;
+  J[2] = px * m1 - py * m0;
+  J[3] = m0; J[4] = m1; J[5] = m2;
+  int k = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
+  acc[27] += 1.f;
+}
+
+__device__ __forceinline__ LevelGeom make_geom(const float* pose, const float* __restrict__ K, float ds, int H, int W,
+                                               float dist_thr, float cos_thr) {
+  LevelGeom g;
+  g.R00 = pose[0]; g.R01 = pose[1]; g.R02 = pose[2]; g.t0 = pose[3];
+  g.R10 = pose[4]; g.R11 = pose[5]; g.R12 = pose[6]; g.t1 = pose[7];
+  g.R20 = pose[8]; g.R21 = pose[9]; g.R22 = pose[10]; g.t2 = pose[11];
+  g.fx = K[0] * ds; g.fy = K[4] * ds; g.cx = K[2] * ds; g.cy = K[5] * ds;
+  g.Wm1 = (float)(W - 1); g.Hm1 = (float)(H - 1);
+  g.hw = g.Wm1 / 2.f; g.hh = g.Hm1 / 2.f;
+  g.dist_thr = dist_thr; g.cos_thr = cos_thr; g.W = W;
+  return g;
+}
+
+// The source maps are [n,3] float32: a lane takes FOUR consecutive pixels = 48 contiguous bytes per map = three 16-B
+// loads (the 12-B pixel stride rules out one vector load per pixel); the remaining n % 4 pixels go to one lane each.
+__device__ __forceinline__ void accumulate_range(const LevelGeom& g, const float* __restrict__ vs,
+                                                 const float* __restrict__ ns, const float* __restrict__ vt,
+                                                 const float* __restrict__ nt, int n, int first, int stride,
+                                                 float (&acc)[NACC]) {
+  const int n4 = n >> 2;
+  const float4* vs4 = reinterpret_cast<const float4*>(vs);
+  const float4* ns4 = reinterpret_cast<const float4*>(ns);
+  for (int q = first; q < n4; q += stride) {
+    const float4 a0 = vs4[3 * q], a1 = vs4[3 * q + 1], a2 = vs4[3 * q + 2];
+    const float4 b0 = ns4[3 * q], b1 = ns4[3 * q + 1], b2 = ns4[3 * q + 2];
+    accumulate_pixel(g, a0.x, a0.y, a0.z, b0.x, b0.y, b0.z, vt, nt, acc);
+    accumulate_pixel(g, a0.w, a1.x, a1.y, b0.w, b1.x, b1.y, vt, nt, acc);
+    accumulate_pixel(g, a1.z, a1.w, a2.x, b1.z, b1.w, b2.x, vt, nt, acc);
+    accumulate_pixel(g, a2.y, a2.z, a2.w, b2.y, b2.z, b2.w, vt, nt, acc);
+  }
+  const int idx = 4 * n4 + first;
+  if (idx < n)
+    accumulate_pixel(g, vs[(size_t)idx * 3], vs[(size_t)idx * 3 + 1], vs[(size_t)idx * 3 + 2], ns[(size_t)idx * 3],
+                     ns[(size_t)idx * 3 + 1], ns[(size_t)idx * 3 + 2], vt, nt, acc);
+}
+
 // K points at the FULL-resolution intrinsics; `ds` is the level's downscale (icp.py:431-433).
 __global__ void __launch_bounds__(256) icp_reduce_kernel(
     const float* __restrict__ vs, const float* __restrict__ ns, const float* __restrict__ vt,
     const float* __restrict__ nt, int H, int W, const float* __restrict__ K, float ds,
     const float* __restrict__ pose, float dist_thr, float cos_thr, float* __restrict__ partials,
     uint32_t* __restrict__ ticket, FinalArgs fa) {
-  const float R00 = pose[0], R01 = pose[1], R02 = pose[2], t0 = pose[3];
-  const float R10 = pose[4], R11 = pose[5], R12 = pose[6], t1 = pose[7];
-  const float R20 = pose[8], R21 = pose[9], R22 = pose[10], t2 = pose[11];
-  const float fx = K[0] * ds, fy = K[4] * ds, cx = K[2] * ds, cy = K[5] * ds;
-  const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1);
-  const float hw = Wm1 / 2.f, hh = Hm1 / 2.f;
+  const LevelGeom g = make_geom(pose, K, ds, H, W, dist_thr, cos_thr);
   float acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
-
-  const int n = H * W;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
-    const float v0 = vs[(size_t)idx * 3], v1 = vs[(size_t)idx * 3 + 1], v2 = vs[(size_t)idx * 3 + 2];
-    const float px = (R00 * v0 + R01 * v1 + R02 * v2) + t0;
-    const float py = (R10 * v0 + R11 * v1 + R12 * v2) + t1;
-    const float pz = (R20 * v0 + R21 * v1 + R22 * v2) + t2;
-    const float u = (px / pz) * fx + cx;
-    const float v = (py / pz) * fy + cy;
-    const bool inview = (u > 0.f) && (u < Wm1) && (v > 0.f) && (v < Hm1);
-    if (!inview || !(v2 > 0.f)) continue;
-    // grid_sample(nearest, border, align_corners=True) of warp_features (icp.py:132-148)
-    const float un = u / hw - 1.f, vn = v / hh - 1.f;
-    float ix = ((un + 1.f) / 2.f) * Wm1, iy = ((vn + 1.f) / 2.f) * Hm1;
-    ix = fminf(Wm1, fmaxf(ix, 0.f));
-    iy = fminf(Hm1, fmaxf(iy, 0.f));
-    const int xi = (int)nearbyintf(ix), yi = (int)nearbyintf(iy);
-    const size_t j = ((size_t)yi * W + xi) * 3;
-    const float q0 = vt[j], q1 = vt[j + 1], q2 = vt[j + 2];
-    if (!(q2 > 0.f)) continue;
-    const float m0 = nt[j], m1 = nt[j + 1], m2 = nt[j + 2];
-    const float n0 = ns[(size_t)idx * 3], n1 = ns[(size_t)idx * 3 + 1], n2 = ns[(size_t)idx * 3 + 2];
-    const float rn0 = R00 * n0 + R01 * n1 + R02 * n2;
-    const float rn1 = R10 * n0 + R11 * n1 + R12 * n2;
-    const float rn2 = R20 * n0 + R21 * n1 + R22 * n2;
-    if (!(rn0 * m0 + rn1 * m1 + rn2 * m2 > cos_thr)) continue;
-    const float d0 = px - q0, d1 = py - q1, d2 = pz - q2;
-    if (sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > dist_thr) continue;
-    const float r = m0 * d0 + m1 * d1 + m2 * d2;
-    float J[6];
-    J[0] = py * m2 - pz * m1;        // -(m^T [p]x) = p x m
-    J[1] = pz * m0 - px * m2;
-    J[2] = px * m1 - py * m0;
-    J[3] = m0; J[4] = m1; J[5] = m2;
-    int k = 0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * r;
-    acc[27] += 1.f;
-  }
+  accumulate_range(g, vs, ns, vt, nt, H * W, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, acc);
   block_write_partials(acc, partials);
   if (arrive_and_elect_last(ticket)) final_stage(partials, (int)gridDim.x, fa);
 }
@@ -433,6 +488,124 @@ __global__ void __launch_bounds__(256) icp_p2p_kernel(const float* __restrict__ 
   }
   block_write_partials(acc, partials);
   if (arrive_and_elect_last(ticket)) final_stage(partials, (int)gridDim.x, fa);
+}
+
+// ---- the whole track as ONE persistent kernel ---------------------------------------------------
+// IcpTracker.predict_pose's level loop (icp.py:428-447: 3 levels x 5 Gauss-Newton iterations, then the p2p loss) used
+// to be 16 dependent launches, each with a whole-grid fan-in to a last-arriver workgroup and a fan-out through the next
+// launch.  Here the workgroups stay resident (one per CU) and meet at a grid barrier per iteration:
+//   every workgroup: partial sums of its pixels -> write-through row -> ticket -> spin until all rows are in ->
+//   EVERY workgroup sums all rows (float64, same order everywhere) and takes the same Gauss-Newton step on its own
+//   LDS copy of the pose.
+// One global round trip per iteration instead of three (fan-in, solve, fan-out), no launch gaps, and nothing for the
+// other stream's kernels to squeeze between.  Rows are double-buffered by iteration parity (a fast workgroup may write
+// iteration e+1 while a slow one still reads e).  The spin is bounded: a workgroup that waits too long raises an abort
+// flag and everybody leaves (stats[3] = 1; the host reports it) - a scheduling pathology must not hang the device.
+struct TrackLevel {
+  const float *vs, *ns, *vt, *nt;
+  int H, W, iters;
+  float ds;
+};
+struct TrackArgs {
+  TrackLevel lv[RTGS_ICP_MAX_LEVELS];
+  int n_levels;
+  const float* K;
+  float dist_thr, cos_thr, damping;
+  float* pose;
+  float* stats;
+  float* partials;
+  uint32_t* ticket;
+  uint32_t* abort_flag;
+};
+
+__device__ __forceinline__ bool grid_arrive_wait(uint32_t* ticket, uint32_t target, uint32_t* abort_flag, float* stats) {
+  __shared__ int s_ok;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this workgroup's write-through row is out
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+      if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+      if ((spin & 63) == 63 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok) {
+      __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      stats[3] = 1.f;
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+
+__global__ void __launch_bounds__(256) icp_track_kernel(TrackArgs a) {
+  __shared__ float s_pose[16];
+  __shared__ float s_stat[4];
+  __shared__ double s_sum[32 * PSTRIDE];
+  __shared__ double s_tot[PSTRIDE];
+  const int G = (int)gridDim.x;
+  if (threadIdx.x < 16) s_pose[threadIdx.x] = a.pose[threadIdx.x];
+  if (threadIdx.x < 4) s_stat[threadIdx.x] = 0.f;
+  __syncthreads();
+  uint32_t epoch = 0;
+  float acc[NACC];
+  for (int l = 0; l < a.n_levels; ++l) {
+    const TrackLevel L = a.lv[l];
+    const int n = L.H * L.W;
+    const float inv = 1.f / ((float)L.H * (float)L.W);
+    for (int it = 0; it < L.iters; ++it) {
+      const LevelGeom g = make_geom(s_pose, a.K, L.ds, L.H, L.W, a.dist_thr, a.cos_thr);
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+      accumulate_range(g, L.vs, L.ns, L.vt, L.nt, n, (int)(blockIdx.x * 256 + threadIdx.x), G * 256, acc);
+      float* rows = a.partials + (size_t)(epoch & 1u) * G * PSTRIDE;
+      block_write_partials(acc, rows);
+      ++epoch;
+      if (!grid_arrive_wait(a.ticket, epoch * (uint32_t)G, a.abort_flag, a.stats)) return;
+      sum_partials(rows, G, s_sum, s_tot);
+      if (threadIdx.x == 0) {
+        double S[NACC];
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) S[c] = s_tot[c];
+        s_stat[0] = (float)(S[27] * (double)inv);                // valid_ratio of this iteration (icp.py:46-47)
+        if (!gn_update(S, a.damping, s_pose)) s_stat[2] += 1.f;
+      }
+      __syncthreads();
+    }
+  }
+  // point2plane_loss (icp.py:7-13, :443-447) of the final pose at the finest level, no association
+  {
+    const TrackLevel F = a.lv[a.n_levels - 1];
+    const int n = F.H * F.W;
+    const float R00 = s_pose[0], R01 = s_pose[1], R02 = s_pose[2], t0 = s_pose[3];
+    const float R10 = s_pose[4], R11 = s_pose[5], R12 = s_pose[6], t1 = s_pose[7];
+    const float R20 = s_pose[8], R21 = s_pose[9], R22 = s_pose[10], t2 = s_pose[11];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    for (int idx = (int)(blockIdx.x * 256 + threadIdx.x); idx < n; idx += G * 256) {
+      const size_t j = (size_t)idx * 3;
+      const float v0 = F.vs[j], v1 = F.vs[j + 1], v2 = F.vs[j + 2];
+      const float px = (v0 * R00 + v1 * R01 + v2 * R02) + t0;
+      const float py = (v0 * R10 + v1 * R11 + v2 * R12) + t1;
+      const float pz = (v0 * R20 + v1 * R21 + v2 * R22) + t2;
+      const float lp = (px - F.vt[j]) * F.nt[j] + (py - F.vt[j + 1]) * F.nt[j + 1] + (pz - F.vt[j + 2]) * F.nt[j + 2];
+      acc[0] += lp * lp;
+    }
+    float* rows = a.partials + (size_t)(epoch & 1u) * G * PSTRIDE;
+    block_write_partials(acc, rows);
+    ++epoch;
+    if (!grid_arrive_wait(a.ticket, epoch * (uint32_t)G, a.abort_flag, a.stats)) return;
+    if (blockIdx.x != 0) return;
+    sum_partials(rows, G, s_sum, s_tot);
+    if (threadIdx.x < 12) a.pose[threadIdx.x] = s_pose[threadIdx.x];
+    if (threadIdx.x == 0) {
+      a.stats[0] = s_stat[0];
+      a.stats[1] = (float)(s_tot[0] * (1.0 / (double)n));
+      a.stats[2] = s_stat[2];
+    }
+  }
 }
 
 // ---- model-depth hole filling (icp.py:397-415) ------------------------------------------------
@@ -517,12 +690,34 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
   if (!lv || n_levels < 1 || n_levels > RTGS_ICP_MAX_LEVELS || !K || !pose || !stats || !scratch) return -1;
   hipStream_t st = (hipStream_t)stream;
   Scratch* sc = (Scratch*)scratch;
-  ICP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
-  ICP_TRY(hipMemsetAsync(&sc->ticket, 0, sizeof(uint32_t), st));
   for (int l = 0; l < n_levels; ++l) {
     const rtgs_icp_level& L = lv[l];
     if (!L.vertex_src || !L.normal_src || !L.vertex_tgt || !L.normal_tgt || L.H <= 0 || L.W <= 0 || L.iters < 0)
       return -1;
+  }
+  ICP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
+  ICP_TRY(hipMemsetAsync(&sc->ticket, 0, 2 * sizeof(uint32_t), st));       // ticket + abort flag
+  // RTGS_ICP_PERSISTENT=0 keeps the one-launch-per-iteration form (A/B measurements, and a way out should a driver
+  // ever refuse to co-schedule one workgroup per CU)
+  static const bool persistent = [] { const char* e = getenv("RTGS_ICP_PERSISTENT"); return !e || atoi(e) != 0; }();
+  if (persistent) {
+    int dev = 0, cus = 0;
+    ICP_TRY(hipGetDevice(&dev));
+    ICP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int G = cus > 0 ? cus : 64;
+    if (G > MAX_BLOCKS / 2) G = MAX_BLOCKS / 2;                             // two row buffers share `partials`
+    TrackArgs a{};
+    for (int l = 0; l < n_levels; ++l)
+      a.lv[l] = TrackLevel{lv[l].vertex_src, lv[l].normal_src, lv[l].vertex_tgt, lv[l].normal_tgt, lv[l].H, lv[l].W,
+                           lv[l].iters, lv[l].downscale};
+    a.n_levels = n_levels; a.K = K; a.dist_thr = dist_thr; a.cos_thr = cos_thr; a.damping = damping;
+    a.pose = pose; a.stats = stats; a.partials = sc->partials; a.ticket = &sc->ticket; a.abort_flag = &sc->pad[0];
+    hipLaunchKernelGGL(icp_track_kernel, dim3(G), dim3(256), 0, st, a);
+    ICP_TRY(hipGetLastError());
+    return 0;
+  }
+  for (int l = 0; l < n_levels; ++l) {
+    const rtgs_icp_level& L = lv[l];
     const int g = grid_for(L.H * L.W);
     const float inv = 1.f / ((float)L.H * (float)L.W);
     FinalArgs fa{(int)MODE_SOLVE, damping, inv, pose, stats, nullptr, nullptr, nullptr};

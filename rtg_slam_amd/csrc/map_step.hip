@@ -19,7 +19,7 @@ extern "C" int rtgs_slam_map_step_front_ctx(rtgs_ctx* ctx, const rtgs_map_step_a
                            a->tile_mask, a->out_color, a->out_depth, a->out_color_index, a->out_depth_index,
                            a->out_color_weight, a->out_depth_weight, a->out_T, a->out_radii, a->geom_resize,
                            a->geom_user, a->binning_resize, a->binning_user, a->image_resize, a->image_user,
-                           num_rendered_host, stream);
+                           num_rendered_host, 0, stream);
   if (rc != RTGS_OK) return rc;
   void* geom = a->geom_resize(a->geom_user, 0);          // size 0 = "hand me the buffer of the last request"
   void* bin = a->binning_resize(a->binning_user, 0);

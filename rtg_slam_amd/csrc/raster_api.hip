@@ -20,7 +20,9 @@ void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
                       int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, hipStream_t);
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
-                      const uint32_t*, const int32_t*, const float*, const float*, SplatGrad*, uint8_t*, hipStream_t);
+                      const uint32_t*, const int32_t*, const float*, const float*, const uint32_t*, uint32_t*,
+                      const BwdInfo*, SplatGrad*, uint8_t*, hipStream_t);
+void launch_grad_reduce(int, const uint8_t*, const uint32_t*, const uint32_t*, const BwdInfo*, SplatGrad*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
                            float*, float*, float*, float*, hipStream_t);
@@ -38,7 +40,7 @@ void launch_preprocess_cull(const RasterParams&, const float*, const float*, con
 void launch_preprocess_shade(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                              const float*, Splat*, int32_t*, uint8_t*, float2*, SliceList, SliceSel, size_t, hipStream_t);
 void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,
-                         uint32_t, hipStream_t);
+                         const uint32_t*, const uint32_t*, uint32_t, hipStream_t);
 void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const int32_t*, const uint16_t*, uint32_t*,
                         unsigned long long*, SliceSel, SliceList, size_t, hipStream_t);
 void launch_slice_hist(int, const uint8_t*, const uint32_t*, const int32_t*, uint32_t*, unsigned long long*, hipStream_t);
@@ -97,6 +99,23 @@ static int bits_for(uint32_t n) {   // bits needed to represent values in [0, n)
   return b < 1 ? 1 : b;
 }
 
+// Rect area of the Gaussians of the near slice, 0 for all others: input of the gradient-slot scan when the slice
+// finished every tile (only its Gaussians can then receive gradient, and their slots fit the slice's instance budget).
+struct SliceAreaOp {
+  const uint8_t* zbin;
+  const uint32_t* area;
+  const int32_t* cut;        // device word written by slice_compact
+  __host__ __device__ uint32_t operator()(int i) const {
+    const int zb = (int)zbin[i];
+    return (zb != 255 && zb <= *cut) ? area[i] : 0u;
+  }
+};
+using SliceAreaIter = hipcub::TransformInputIterator<uint32_t, SliceAreaOp, hipcub::CountingInputIterator<int>>;
+
+__global__ void bwd_info_kernel(BwdInfo* dst, SplatGrad* slot_grads, uint32_t slots, uint32_t use_slots) {
+  dst->slot_grads = slot_grads; dst->slots = slots; dst->use_slots = use_slots;
+}
+
 // Offsets the BACKWARD reads (splats, radii, clamped, ranges1_bwd, list1) do not depend on `budget`: everything sized
 // by the near-slice budget sits behind them, so a backward never needs to know the budget of its forward.
 static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
@@ -131,6 +150,7 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
     L.ranges1 = off; off = align_up(off + nt * sizeof(uint2));
     L.mask2 = off; off = align_up(off + nt * sizeof(int32_t));
     L.uv = off; off = align_up(off + Pn * sizeof(float2));
+    L.slot_count = off; off = align_up(off + Pn * sizeof(uint32_t));
     L.slice_cap = nt * (size_t)(budget > 0 ? budget : 1);
     L.slice_max_list = L.slice_cap < 65536 ? L.slice_cap : 65536;   // every listed Gaussian covers >= 1 tile
     if (L.slice_max_list > Pn) L.slice_max_list = Pn;
@@ -139,21 +159,31 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
     L.slice_ids = off; off = align_up(off + L.slice_max_list * sizeof(uint32_t));
     L.bucket1 = off; off = align_up(off + L.slice_cap * sizeof(uint64_t));
   }
-  size_t tb = 0;
+  size_t tb = 0, tb2 = 0, tb3 = 0;
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)Pn);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)Pn);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, SliceAreaIter(hipcub::CountingInputIterator<int>(0), SliceAreaOp{}),
+                                         (uint32_t*)nullptr, (int)Pn);
+  if (tb2 > tb) tb = tb2;
+  if (tb3 > tb) tb = tb3;
   L.scan_temp_bytes = tb;
   L.scan_temp = off; off = align_up(off + tb);
   L.total = off;
   return L;
 }
 
-static BinLayout bin_layout(int64_t R, int ntiles, bool sort_path) {
+static BinLayout bin_layout(int64_t R, int ntiles, bool sort_path, size_t slots) {
   BinLayout L{};
   size_t off = 0;
   const size_t Rn = (size_t)(R > 0 ? R : 1);
   L.vals_b = off; off = align_up(off + Rn * sizeof(uint32_t));     // point_list: offset 0 in BOTH layouts
   L.keys_a = off; off = align_up(off + Rn * sizeof(uint64_t));     // tile buckets / unsorted keys
-  if (!sort_path) { L.keys_b = L.vals_a = L.sort_temp = off; L.sort_temp_bytes = 0; L.total = off; return L; }
+  if (!sort_path) {
+    L.keys_b = L.vals_a = L.sort_temp = off; L.sort_temp_bytes = 0;
+    if (slots > 0) { L.slot_grads = off; off = align_up(off + slots * sizeof(SplatGrad)); }   // BwdInfo
+    L.total = off;
+    return L;
+  }
   L.keys_b = off; off = align_up(off + Rn * sizeof(uint64_t));
   L.vals_a = off; off = align_up(off + Rn * sizeof(uint32_t));
   size_t tb = 0;
@@ -170,6 +200,7 @@ static ImgLayout img_layout(int H, int W, int ntiles) {
   size_t off = 0;
   L.ranges = off; off = align_up(off + (size_t)ntiles * sizeof(uint2));
   L.n_contrib = off; off = align_up(off + (size_t)H * W * sizeof(uint32_t));
+  L.bwd_info = off; off = align_up(off + sizeof(BwdInfo));
   L.total = off;
   return L;
 }
@@ -239,7 +270,7 @@ size_t rtgs_raster_geom_bytes_ctx(rtgs_ctx* c, int32_t P, int32_t H, int32_t W) 
 size_t rtgs_raster_geom_bytes(int32_t P, int32_t H, int32_t W) { return rtgs_raster_geom_bytes_ctx(nullptr, P, H, W); }
 size_t rtgs_raster_binning_bytes(int64_t R, int32_t H, int32_t W) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  return bin_layout(R, gx * gy, true).total;
+  return bin_layout(R, gx * gy, true, 0).total;
 }
 size_t rtgs_raster_image_bytes(int32_t H, int32_t W) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
@@ -264,7 +295,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                             int32_t* out_cidx, int32_t* out_didx, float* out_cw, float* out_dw, float* out_T,
                             int32_t* out_radii, rtgs_resize_fn geom_resize, void* geom_user,
                             rtgs_resize_fn binning_resize, void* binning_user, rtgs_resize_fn image_resize,
-                            void* image_user, int64_t* num_rendered_host, void* stream) {
+                            void* image_user, int64_t* num_rendered_host, int32_t flags, void* stream) {
   rtgs_ctx* c = use(ctx);
   RasterParams p;
   int rc = make_params(s, P, M, p);
@@ -309,6 +340,14 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   int32_t* mask2 = (int32_t*)(geom + G.mask2);
   uint32_t* list1 = (uint32_t*)(geom + G.list1);
   uint32_t longest = 0;
+  // gradient slots of the backward (BwdInfo): gbase = exclusive scan of the rect areas, into `offsets`
+  const bool want_bwd = !(flags & RTGS_FWD_NO_BACKWARD);
+  uint32_t slots = 0;
+  auto scan_all = [&]() -> int {
+    size_t tb = G.scan_temp_bytes;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(geom + G.scan_temp, tb, tiles_touched, offsets, P, st));
+    return RTGS_OK;
+  };
   bool sort_path = (size_t)ntiles > bin_lds_limit_tiles() || c->force_sort_path;
   // near-slice pass: mode 1 forces it (tests); automatic mode considers it on large maps only, and there the kernels
   // decide from the depth histograms whether it runs (an empty slice sends every tile to the second pass)
@@ -346,6 +385,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
     if (!sliced) {
       launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, sort_path ? sat : nullptr, splats,
                             tiles_touched, radii, clamped, out_radii, zero_words, zero_n, nullptr, st);
+      if (!sort_path && want_bwd && (rc = scan_all()) != RTGS_OK) return rc;
     } else {
       // geometry of every Gaussian now, Splat records only where a list will read them
       launch_preprocess_cull(p, means3D, scales, rotations, tiles_touched, radii, out_radii, zero_words, zero_n, zbin,
@@ -366,7 +406,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                            G.slice_max_list, st) != 0)
         return RTGS_E_HIP;
       launch_bin_tilescan(ntiles, tile_count1, ranges1, (uint32_t*)(geom + G.cursor1), info + 2, nullptr, nullptr,
-                          nullptr, 0u, st);
+                          nullptr, nullptr, nullptr, 0u, st);
       launch_bin_scatter(p, splats, radii, tile_mask, (const uint16_t*)(geom + G.block_counts1),
                          (uint32_t*)(geom + G.cursor1), (unsigned long long*)(geom + G.bucket1), sel1, work,
                          G.slice_max_list, st);
@@ -395,6 +435,15 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         sel_rest.sat = sat; sel_rest.uv = (const float2*)(geom + G.uv);
         launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
                                 (float2*)(geom + G.uv), SliceList{nullptr, nullptr}, sel_rest, 0, st);
+        if (want_bwd && (rc = scan_all()) != RTGS_OK) return rc;
+      } else if (want_bwd) {
+        // every tile is final: only the slice's Gaussians can receive gradient, and the sum of their rect areas is
+        // within the slice's instance budget by construction of the cut - no host round trip for the size
+        size_t tb = G.scan_temp_bytes;
+        const SliceAreaOp op{zbin, tiles_touched, (const int32_t*)(slice_ctr + 3)};
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(geom + G.scan_temp, tb, SliceAreaIter(hipcub::CountingInputIterator<int>(0), op),
+                                                 offsets, P, st));
+        slots = (uint32_t)G.slice_cap;
       }
     }
     if (!sort_path && !(sliced && n_left == 0)) {
@@ -404,12 +453,14 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       if (launch_bin_count(p, splats, radii, mask_main, tile_count, block_counts, sel2, SliceList{nullptr, nullptr}, 0, st) != 0)
         return RTGS_E_HIP;
       if (++c->seq == 0u) c->seq = 1u;
-      launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, info_host, nullptr, nullptr, c->seq, st);
+      launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, info_host, nullptr, nullptr,
+                          want_bwd ? offsets + (P - 1) : nullptr, want_bwd ? tiles_touched + (P - 1) : nullptr, c->seq, st);
       DBG(s, st);
       prof_mark(c, EV_SCAN, st);
       if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
       R = (int64_t)info_host[0];
       longest = info_host[1];
+      slots = info_host[5];
       if ((int)longest > bin_sort_capacity()) {   // a tile list too long for the LDS sort: redo with rect counts
         sort_path = true;
         if (sliced) {         // the global-sort path renders every tile itself: drop the slice's results
@@ -436,9 +487,12 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   }
   *num_rendered_host = R + R1;
 
-  const BinLayout B = bin_layout(R, ntiles, sort_path);
+  const bool use_slots = want_bwd && !sort_path && slots > 0 && slots <= SLOTS_MAX;
+  const BinLayout B = bin_layout(R, ntiles, sort_path, use_slots ? (size_t)slots : 0);
   char* bin = (char*)binning_resize(binning_user, B.total);
   if (!bin) return RTGS_E_ALLOC;
+  hipLaunchKernelGGL(bwd_info_kernel, dim3(1), dim3(1), 0, st, (BwdInfo*)(img + I.bwd_info),
+                     (SplatGrad*)(bin + B.slot_grads), use_slots ? slots : 0u, use_slots ? 1u : 0u);
   uint64_t* keys_a = (uint64_t*)(bin + B.keys_a);
   uint64_t* keys_b = (uint64_t*)(bin + B.keys_b);
   uint32_t* vals_a = (uint32_t*)(bin + B.vals_a);
@@ -487,13 +541,13 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
 
 static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
                          const float* opacities, const float* shs, const float* scales, const float* rotations,
-                         const float* normal_w, const void* geom_buffer, const void* binning_buffer,
+                         const float* normal_w, void* geom_buffer, void* binning_buffer,
                          const void* image_buffer, const float* out_color, const float* out_T,
                          const int32_t* out_didx,
                          const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
                          float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
                          void* grad_scratch, uint8_t* row_state, void* stream) {
-  rtgs_ctx* c = use(ctx);
+  rtgs_ctx* c = use(ctx);   // NOTE: the geometry buffer is written here (slot counters): it is scratch of the pair
   RasterParams p;
   int rc = make_params(s, P, M, p);
   if (rc != RTGS_OK) return rc;
@@ -505,7 +559,7 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = p.gx * p.gy;
   const GeomLayout G = geom_layout(P, p.gx, p.gy, 1);   // only budget-independent offsets are read here
-  const BinLayout B = bin_layout(R, ntiles, false);     // point_list sits at offset 0 in both layouts
+  const BinLayout B = bin_layout(R, ntiles, false, 0);  // point_list sits at offset 0 in every layout
   const ImgLayout I = img_layout(p.H, p.W, ntiles);
   const char* geom = (const char*)geom_buffer;
   const char* bin = (const char*)binning_buffer;
@@ -516,19 +570,26 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
   uint8_t* touched = (uint8_t*)grad_scratch + align_up((size_t)P * sizeof(SplatGrad));
   // row-state mode: the caller zeroed the scratch once and preprocess_bwd re-zeroes every line it consumes
   if (!row_state) HIP_TRY(hipMemsetAsync(grads, 0, rtgs_raster_backward_scratch_bytes(P), st));
+  const BwdInfo* binfo = (const BwdInfo*)(img + I.bwd_info);
+  const uint32_t* gbase = (const uint32_t*)(geom + G.offsets);
+  const int32_t* radii = (const int32_t*)(geom + G.radii);
+  uint32_t* slot_count = (uint32_t*)(geom + G.slot_count);      // scratch of the backward inside the geometry buffer
   if (R > 0) {
+    HIP_TRY(hipMemsetAsync(slot_count, 0, (size_t)P * sizeof(uint32_t), st));
     // two-pass forward: tiles the near slice finished walk its lists (ranges1_bwd is all-empty otherwise, and a
     // workgroup with an empty range returns at once); every other tile walks the main lists
     launch_blend_bwd(p, (const uint2*)(geom + G.ranges1_bwd), (const uint32_t*)(geom + G.list1),
                      (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
-                     dL_dcolor, dL_ddepth, grads, touched, st);
+                     dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, st);
     launch_blend_bwd(p, (const uint2*)(img + I.ranges), (const uint32_t*)(bin + B.vals_b),
                      (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
-                     dL_dcolor, dL_ddepth, grads, touched, st);
+                     dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, st);
+    // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
+    launch_grad_reduce(P, touched, gbase, slot_count, binfo, grads, st);
     DBG(s, st);
   }
   prof_mark(c, EV_BBLEND, st);
-  launch_preprocess_bwd(p, means3D, opacities, shs, scales, rotations, normal_w, (const int32_t*)(geom + G.radii),
+  launch_preprocess_bwd(p, means3D, opacities, shs, scales, rotations, normal_w, radii,
                         (const uint8_t*)(geom + G.clamped), grads, touched, row_state, dL_dmeans3D, dL_dopacities,
                         dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, st);
   prof_mark(c, EV_BPRE, st);
@@ -539,8 +600,8 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
 
 int rtgs_raster_backward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R,
                              const float* means3D, const float* opacities, const float* shs, const float* scales,
-                             const float* rotations, const float* normal_w, const void* geom_buffer,
-                             const void* binning_buffer, const void* image_buffer, const float* out_color,
+                             const float* rotations, const float* normal_w, void* geom_buffer,
+                             void* binning_buffer, const void* image_buffer, const float* out_color,
                              const float* out_T, const int32_t* out_didx, const float* dL_dcolor, const float* dL_ddepth,
                              float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs, float* dL_dscales,
                              float* dL_drotations, float* dL_dnormal_w, void* grad_scratch, void* stream) {
@@ -551,8 +612,8 @@ int rtgs_raster_backward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32
 
 int rtgs_raster_backward_rows_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R,
                                   const float* means3D, const float* opacities, const float* shs, const float* scales,
-                                  const float* rotations, const float* normal_w, const void* geom_buffer,
-                                  const void* binning_buffer, const void* image_buffer, const float* out_color,
+                                  const float* rotations, const float* normal_w, void* geom_buffer,
+                                  void* binning_buffer, const void* image_buffer, const float* out_color,
                                   const float* out_T, const int32_t* out_didx, const float* dL_dcolor,
                                   const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
                                   float* dL_dscales, float* dL_drotations, float* dL_dnormal_w, void* grad_scratch,
@@ -607,11 +668,11 @@ int rtgs_raster_forward(const rtgs_raster_settings* s, int32_t P, int32_t M, con
                         void* image_user, int64_t* num_rendered_host, void* stream) {
   return rtgs_raster_forward_ctx(nullptr, s, P, M, means3D, opacities, shs, scales, rotations, normal_w, tile_mask,
                                  out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, out_radii, geom_resize,
-                                 geom_user, binning_resize, binning_user, image_resize, image_user, num_rendered_host, stream);
+                                 geom_user, binning_resize, binning_user, image_resize, image_user, num_rendered_host, 0, stream);
 }
 int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
                          const float* opacities, const float* shs, const float* scales, const float* rotations,
-                         const float* normal_w, const void* geom_buffer, const void* binning_buffer,
+                         const float* normal_w, void* geom_buffer, void* binning_buffer,
                          const void* image_buffer, const float* out_color, const float* out_T, const int32_t* out_didx,
                          const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
                          float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
@@ -622,7 +683,7 @@ int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, in
 }
 int rtgs_raster_backward_rows(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
                               const float* opacities, const float* shs, const float* scales, const float* rotations,
-                              const float* normal_w, const void* geom_buffer, const void* binning_buffer,
+                              const float* normal_w, void* geom_buffer, void* binning_buffer,
                               const void* image_buffer, const float* out_color, const float* out_T,
                               const int32_t* out_didx, const float* dL_dcolor, const float* dL_ddepth,
                               float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs, float* dL_dscales,

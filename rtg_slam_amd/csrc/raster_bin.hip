@@ -54,14 +54,6 @@ struct BinG {
   uint32_t zbits;
 };
 
-__device__ __forceinline__ void bin_rect(float u, float v, int radius, int gx, int gy, int& x0, int& y0, int& x1, int& y1) {
-  const float r = (float)radius;      // identical to tile_rect() of raster_fwd.hip
-  x0 = min(gx, max(0, (int)((u - r) / (float)TILE)));
-  y0 = min(gy, max(0, (int)((v - r) / (float)TILE)));
-  x1 = min(gx, max(0, (int)((u + r + (float)(TILE - 1)) / (float)TILE)));
-  y1 = min(gy, max(0, (int)((v + r + (float)(TILE - 1)) / (float)TILE)));
-}
-
 __device__ __forceinline__ bool load_bing(const RasterParams& p, const Splat* __restrict__ splats,
                                           const int32_t* __restrict__ radii, const uint8_t* __restrict__ zbin, int cut,
                                           const int32_t* __restrict__ sat, const float2* __restrict__ uv, int i, BinG& g) {
@@ -74,7 +66,7 @@ __device__ __forceinline__ bool load_bing(const RasterParams& p, const Splat* __
   if (sat) {      // second pass: does the rect hold an unfinished tile at all?  (before the Splat is touched)
     const float2 c = uv[i];
     int x0, y0, x1, y1;
-    bin_rect(c.x, c.y, radius, p.gx, p.gy, x0, y0, x1, y1);
+    tile_rect_of(c.x, c.y, radius, p.gx, p.gy, x0, y0, x1, y1);
     if ((x1 - x0) * (y1 - y0) <= 0 || sat_count(sat, p.gx, x0, y0, x1, y1) == 0) return false;
   }
   const float4 r0 = reinterpret_cast<const float4*>(splats + i)[0];
@@ -88,7 +80,7 @@ __device__ __forceinline__ bool load_bing(const RasterParams& p, const Splat* __
   // of power in blend is ~1e-6 relative).  Non-PD conics (never seen; det guard) keep every tile.
   g.thr = pd ? (2.f * __logf(255.f * o)) * 1.001f + 1e-2f : 3.0e38f;
   g.ica = __builtin_amdgcn_rcpf(g.ca); g.icc = __builtin_amdgcn_rcpf(g.cc);   // only place the clamp points
-  bin_rect(g.u, g.v, radius, p.gx, p.gy, g.x0, g.y0, g.x1, g.y1);
+  tile_rect_of(g.u, g.v, radius, p.gx, p.gy, g.x0, g.y0, g.x1, g.y1);
   return (g.x1 - g.x0) * (g.y1 - g.y0) > 0;
 }
 
@@ -233,7 +225,9 @@ __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const ui
                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ cursor,
                                                             uint32_t* __restrict__ info, uint32_t* __restrict__ info_host,
                                                             const uint32_t* __restrict__ extra_src,
-                                                            const uint32_t* __restrict__ extra_src2, uint32_t seq) {
+                                                            const uint32_t* __restrict__ extra_src2,
+                                                            const uint32_t* __restrict__ slot_a,
+                                                            const uint32_t* __restrict__ slot_b, uint32_t seq) {
   __shared__ uint32_t s_sum[1024];
   __shared__ uint32_t s_max[1024];
   const int tid = threadIdx.x;
@@ -263,6 +257,8 @@ __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const ui
       info_host[0] = s_sum[1023]; info_host[1] = s_max[1023];
       if (extra_src) { info_host[2] = extra_src[0]; info_host[3] = extra_src[1]; }   // near-slice tile counters
       if (extra_src2) info_host[4] = extra_src2[0];                                  // near-slice instance total
+      // size of the backward's gradient-slot space: last exclusive-scan value + last rect area
+      info_host[5] = (slot_a ? slot_a[0] : 0u) + (slot_b ? slot_b[0] : 0u);
       // publish: the host spins on this word instead of paying a blocking stream sync's wake-up latency
       __hip_atomic_store(&info_host[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -338,8 +334,7 @@ __global__ void __launch_bounds__(THREADS) bin_tilesort_kernel(const uint2* __re
 // ---------------------------------------------------------------------------------------------
 // LDS radix sort of one tile bucket: LSD over the bytes of the depth bits that actually vary inside
 // the tile (usually 3 of 4), stable within a pass (wave-ordered segments, ballot ranks), then a
-// fix-up that orders runs of bit-equal depths by Gaussian id (the bucket was filled by atomics, so
-// equal depths arrive in arbitrary order).  ~6 LDS operations per key and pass instead of the
+// parallel fix-up that orders runs of bit-equal depths by Gaussian id.  ~6 LDS operations per key and pass instead of the
 // ~1.5 x 78 stages of the bitonic network.
 // ---------------------------------------------------------------------------------------------
 template <int THREADS>
@@ -422,22 +417,31 @@ __global__ void __launch_bounds__(THREADS) bin_tilesort_radix_kernel(const uint2
     __syncthreads();
     unsigned long long* tmp = kA; kA = kB; kB = tmp;
   }
-  // runs of bit-equal depth: order by id (insertion sort by the run's first thread; runs are tiny and rare)
-  for (int i = tid; i < n; i += THREADS) {
-    const uint32_t z = (uint32_t)(kA[i] >> 32);
-    const bool start = (i == 0 || (uint32_t)(kA[i - 1] >> 32) != z) && (i + 1 < n && (uint32_t)(kA[i + 1] >> 32) == z);
-    if (start) {
-      int e = i + 1;
-      while (e < n && (uint32_t)(kA[e] >> 32) == z) ++e;
-      for (int a2 = i + 1; a2 < e; ++a2) {
-        const unsigned long long key = kA[a2];
-        int b2 = a2 - 1;
-        while (b2 >= i && kA[b2] > key) { kA[b2 + 1] = kA[b2]; --b2; }
-        kA[b2 + 1] = key;
-      }
+  // Runs of bit-equal depth (the bucket was filled by atomics, so equal depths arrive in arbitrary order): order them
+  // by Gaussian id.  Usually there is none.  Otherwise every key finds its run with two binary searches over the
+  // depth-sorted array and its rank inside the run by counting the smaller ids (broadcast LDS reads) - O(run) per key
+  // and fully parallel, whatever the run length (a wall seen head-on puts hundreds of bit-equal depths into one tile).
+  bool tie = false;
+  for (int i = tid + 1; i < n; i += THREADS) tie |= (uint32_t)(kA[i] >> 32) == (uint32_t)(kA[i - 1] >> 32);
+  if (__syncthreads_or(tie)) {
+    for (int i = tid; i < n; i += THREADS) {
+      const unsigned long long key = kA[i];
+      const uint32_t z = (uint32_t)(key >> 32);
+      int lo = 0, hi = i;                       // first index with depth == z
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)(kA[mid] >> 32) < z) lo = mid + 1; else hi = mid; }
+      const int first = lo;
+      lo = i; hi = n;                           // one past the last index with depth == z
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)(kA[mid] >> 32) <= z) lo = mid + 1; else hi = mid; }
+      int rank = first;
+      if (lo - first > 1)
+        for (int j = first; j < lo; ++j) rank += (kA[j] < key) ? 1 : 0;
+      else
+        rank = i;
+      kB[rank] = key;
     }
+    __syncthreads();
+    unsigned long long* tmp = kA; kA = kB; kB = tmp;
   }
-  __syncthreads();
   for (int i = tid; i < n; i += THREADS) point_list[r.x + i] = (uint32_t)kA[i];
 }
 
@@ -517,6 +521,7 @@ __global__ void __launch_bounds__(256) slice_compact_kernel(int P, SliceSel sel,
   __shared__ uint32_t s_ids[COMPACT_CHUNK];
   __shared__ uint32_t s_n, s_base;
   const int cut = slice_cut(sel);
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int32_t*>(n_list)[1] = cut;   // slice_ctr[3]: for the slot scan
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -566,10 +571,10 @@ int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* 
   return 0;
 }
 void launch_bin_tilescan(int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* cursor, uint32_t* info,
-                         uint32_t* info_host, const uint32_t* extra_src, const uint32_t* extra_src2, uint32_t seq,
-                         hipStream_t st) {
+                         uint32_t* info_host, const uint32_t* extra_src, const uint32_t* extra_src2,
+                         const uint32_t* slot_a, const uint32_t* slot_b, uint32_t seq, hipStream_t st) {
   hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(1024), 0, st, ntiles, tile_count, ranges, cursor, info,
-                     info_host, extra_src, extra_src2, seq);
+                     info_host, extra_src, extra_src2, slot_a, slot_b, seq);
 }
 void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
                         const uint16_t* block_counts, uint32_t* cursor, unsigned long long* bucket, SliceSel sel,

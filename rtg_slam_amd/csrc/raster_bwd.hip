@@ -15,8 +15,11 @@ namespace rtgs {
 //   dL/da_k  = T_k (c_k . g) - (S_k . g) / (1 - a_k) - T_final (bg . g) / (1 - a_k)
 // Per entry the 9 per-Gaussian partials are reduced inside the wave with a 3-step multi-value
 // DPP butterfly (lanes end up holding one of 8 quantities, summed over their 8-lane group) and
-// land in an LDS accumulator with one ds_add_f32; the tile flushes one global atomic per
-// touched (Gaussian, quantity).
+// land in a wave-private LDS accumulator; the tile then stores ONE 64-byte gradient slot per touched
+// (Gaussian, tile) pair with plain stores (one integer atomic picks the slot; grad_reduce sums a Gaussian's
+// slots) - no global float atomics.  The opaque-depth gradient rides along: a pixel hands its four plane partials over when
+// the walk reaches its owner's entry.  (Fallback when the slot space would be too large: one global
+// atomic per (tile, Gaussian, quantity).)
 // ---------------------------------------------------------------------------------------------
 constexpr int NG = 9;   // du dv dca dcb dcc dr dg db | dop
 
@@ -81,11 +84,14 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     const Splat* __restrict__ splats, const float* __restrict__ out_color, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const int32_t* __restrict__ depth_index,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+    const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
     SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched) {
   __shared__ float4 s_rec[BATCH * 3];
   __shared__ int32_t s_id[BATCH];
   __shared__ float s_hy[BATCH];
+  __shared__ uint32_t s_slot[BATCH];
   __shared__ float s_grad[4 * BATCH * NG];      // one private copy per wave: plain stores, no LDS atomics
+  __shared__ float s_dep[BATCH * 4];            // depth-plane partials of the batch's entries (rare: LDS float adds)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -99,16 +105,34 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
   const size_t HW = (size_t)p.H * p.W;
   const int n = (int)(range.y - range.x);
   if (n == 0) return;      // nothing was blended here (or the tile belongs to the other pass of a two-pass forward)
+  const bool use_slots = info->use_slots != 0;
+  SplatGrad* const slot_grads = info->slot_grads;
 
   const uint32_t last = inside ? n_contrib[pix] : 0u;
   const float T_final = inside ? final_T[pix] : 0.f;
   float g0 = 0.f, g1 = 0.f, g2 = 0.f, S0 = 0.f, S1 = 0.f, S2 = 0.f;
+  // opaque-surface depth: D = pd / (n_c . r); only the pixel's owner Gaussian receives it.  The four partials are
+  // computed up front and handed over when the walk reaches the owner's entry (it is one of this pixel's contributors).
+  int owner = -1;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (inside) {
     g0 = dL_dcolor[pix]; g1 = dL_dcolor[HW + pix]; g2 = dL_dcolor[2 * HW + pix];
     // colour behind the (not yet started) walk = everything the pixel accumulated, without background
     S0 = out_color[pix] - T_final * p.bg[0];
     S1 = out_color[HW + pix] - T_final * p.bg[1];
     S2 = out_color[2 * HW + pix] - T_final * p.bg[2];
+    owner = depth_index[pix];
+    const float gD = owner >= 0 ? dL_ddepth[pix] : 0.f;
+    if (gD == 0.f) owner = -1;
+    if (owner >= 0) {
+      const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
+      const float pd = reinterpret_cast<const float*>(splats + owner)[12];
+      const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
+      const float den = r2.y * rx + r2.z * ry + r2.w;
+      const float iden = 1.f / den;
+      const float k = -gD * (pd * iden) * iden;
+      a0 = k * rx; a1 = k * ry; a2 = k; a3 = gD * iden;
+    }
   }
   const float bgT = T_final * (p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2);
   float T = 1.f;
@@ -136,13 +160,16 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
       const uint32_t id = point_list[range.x + base + tid];
       s_id[tid] = (int32_t)id;
       const float4* src = reinterpret_cast<const float4*>(splats + id);
-      s_rec[tid * 3 + 0] = src[0];
+      const float4 q0 = src[0];
+      s_rec[tid * 3 + 0] = q0;
       s_rec[tid * 3 + 1] = src[1];
       s_rec[tid * 3 + 2] = src[2];
       s_hy[tid] = reinterpret_cast<const float*>(splats + id)[15];
+      if (use_slots) s_slot[tid] = gbase[id];          // first slot of the Gaussian's run
     }
     for (int q = tid; q < 4 * BATCH * NG; q += BLOCK)
       if ((q % (BATCH * NG)) < m * NG) s_grad[q] = 0.f;
+    s_dep[tid] = 0.f; s_dep[BLOCK + tid] = 0.f;
     __syncthreads();
 
     // Two entries per round: records, alphas and the two 8-value butterflies are independent instruction
@@ -151,8 +178,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     for (int j = 0; j < m; j += 2) {
       if (__builtin_amdgcn_ballot_w64((uint32_t)(base + j) < last) == 0ull) break;   // wave past its last contributor
       float4 r0[2], r1[2];
-      float dx[2], dy[2], G[2], oG[2], alpha[2];
-      bool valid[2];
+      float dx[2], dy[2], G[2], alpha[2];
+      bool valid[2], own[2];
       int e[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -164,9 +191,9 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
         dx[k] = r0[k].x - pxf; dy[k] = r0[k].y - pyf;
         const float power = splat_power(r0[k].z, r0[k].w, r1[k].x, dx[k], dy[k]);
         G[k] = splat_exp(fminf(power, 0.f));
-        oG[k] = r1[k].y * G[k];
-        alpha[k] = fminf(0.99f, oG[k]);
+        alpha[k] = fminf(0.99f, r1[k].y * G[k]);
         valid[k] = live && ((uint32_t)(base + j + k) < last) && !(power > 0.f) && !(alpha[k] < 1.f / 255.f);
+        own[k] = (j + k < m) && (owner == s_id[e[k]]);
       }
       const unsigned long long vm0 = __builtin_amdgcn_ballot_w64(valid[0]);
       const unsigned long long vm1 = __builtin_amdgcn_ballot_w64(valid[1]);
@@ -211,10 +238,24 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
         if (lane < 8) wgrad[e[1] * NG + gidx] = t8;
         if (lane == 63) wgrad[e[1] * NG + 8] = ro[1];
       }
+      // depth owners among this wave's pixels (each pixel owns at most one entry of the whole list: rare per round)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (__builtin_amdgcn_ballot_w64(own[k]) != 0ull) {
+          const float s0 = wave_sum_to_lane63(own[k] ? a0 : 0.f);
+          const float s1 = wave_sum_to_lane63(own[k] ? a1 : 0.f);
+          const float s2 = wave_sum_to_lane63(own[k] ? a2 : 0.f);
+          const float s3 = wave_sum_to_lane63(own[k] ? a3 : 0.f);
+          if (lane == 63) {
+            atomicAdd(&s_dep[e[k] * 4 + 0], s0); atomicAdd(&s_dep[e[k] * 4 + 1], s1);
+            atomicAdd(&s_dep[e[k] * 4 + 2], s2); atomicAdd(&s_dep[e[k] * 4 + 3], s3);
+          }
+        }
+      }
     }
     __syncthreads();
     if (tid < m) {
-      float t[NG];
+      float t[NG + 4];
       bool any = false;
 #pragma unroll
       for (int k = 0; k < NG; ++k) {
@@ -222,263 +263,96 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
                (s_grad[(2 * BATCH + tid) * NG + k] + s_grad[(3 * BATCH + tid) * NG + k]);
         any |= (t[k] != 0.f);
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { t[NG + k] = s_dep[tid * 4 + k]; any |= (t[NG + k] != 0.f); }
       if (any) {
-        touched[s_id[tid]] = 1;     // byte per Gaussian: lets the row-state backward skip untouched SplatGrad lines
-        float* dst = reinterpret_cast<float*>(grads + s_id[tid]);
-        // SplatGrad order: du dv dca dcb dcc dop dr dg db
-        if (t[0] != 0.f) unsafeAtomicAdd(dst + 0, t[0]);
-        if (t[1] != 0.f) unsafeAtomicAdd(dst + 1, t[1]);
-        if (t[2] != 0.f) unsafeAtomicAdd(dst + 2, t[2]);
-        if (t[3] != 0.f) unsafeAtomicAdd(dst + 3, t[3]);
-        if (t[4] != 0.f) unsafeAtomicAdd(dst + 4, t[4]);
-        if (t[8] != 0.f) unsafeAtomicAdd(dst + 5, t[8]);
-        if (t[5] != 0.f) unsafeAtomicAdd(dst + 6, t[5]);
-        if (t[6] != 0.f) unsafeAtomicAdd(dst + 7, t[6]);
-        if (t[7] != 0.f) unsafeAtomicAdd(dst + 8, t[7]);
+        touched[s_id[tid]] = 1;     // byte per Gaussian: grad_reduce / the row-state backward skip untouched Gaussians
+        if (use_slots) {
+          // SplatGrad order: du dv dca dcb | dcc dop dr dg | db dnx dny dnz | dpd - - -
+          // next free slot of the run: at most one tile per rect tile asks, so the run (= rect area) cannot overflow
+          const uint32_t slot = s_slot[tid] + atomicAdd(&slot_count[s_id[tid]], 1u);
+          float4* dst = reinterpret_cast<float4*>(slot_grads + slot);
+          dst[0] = make_float4(t[0], t[1], t[2], t[3]);
+          dst[1] = make_float4(t[4], t[8], t[5], t[6]);
+          dst[2] = make_float4(t[7], t[9], t[10], t[11]);
+          dst[3] = make_float4(t[12], 0.f, 0.f, 0.f);
+        } else {
+          float* dst = reinterpret_cast<float*>(grads + s_id[tid]);
+          if (t[0] != 0.f) unsafeAtomicAdd(dst + 0, t[0]);
+          if (t[1] != 0.f) unsafeAtomicAdd(dst + 1, t[1]);
+          if (t[2] != 0.f) unsafeAtomicAdd(dst + 2, t[2]);
+          if (t[3] != 0.f) unsafeAtomicAdd(dst + 3, t[3]);
+          if (t[4] != 0.f) unsafeAtomicAdd(dst + 4, t[4]);
+          if (t[8] != 0.f) unsafeAtomicAdd(dst + 5, t[8]);
+          if (t[5] != 0.f) unsafeAtomicAdd(dst + 6, t[5]);
+          if (t[6] != 0.f) unsafeAtomicAdd(dst + 7, t[6]);
+          if (t[7] != 0.f) unsafeAtomicAdd(dst + 8, t[7]);
+          if (t[9] != 0.f) unsafeAtomicAdd(dst + 9, t[9]);
+          if (t[10] != 0.f) unsafeAtomicAdd(dst + 10, t[10]);
+          if (t[11] != 0.f) unsafeAtomicAdd(dst + 11, t[11]);
+          if (t[12] != 0.f) unsafeAtomicAdd(dst + 12, t[12]);
+        }
       }
     }
-  }
-
-  // opaque-surface depth: D = pd / (n_c . r), owner only.  Neighbouring pixels share owners (one
-  // opaque disc owns hundreds of pixels), so lanes are grouped by owner and each group issues ONE
-  // set of 4 atomics instead of one per pixel (same-address atomics serialise at ~12 ns each).
-  int owner = -1;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (inside) {
-    owner = depth_index[pix];
-    const float gD = owner >= 0 ? dL_ddepth[pix] : 0.f;
-    if (gD == 0.f) owner = -1;
-    if (owner >= 0) {
-      const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
-      const float pd = reinterpret_cast<const float*>(splats + owner)[12];
-      const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
-      const float den = r2.y * rx + r2.z * ry + r2.w;
-      const float iden = 1.f / den;
-      const float k = -gD * (pd * iden) * iden;
-      a0 = k * rx; a1 = k * ry; a2 = k; a3 = gD * iden;
-    }
-  }
-  unsigned long long todo = __builtin_amdgcn_ballot_w64(owner >= 0);
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int o = __builtin_amdgcn_readlane(owner, leader);
-    const bool mine = owner == o;
-    const float s0 = wave_sum_to_lane63(mine ? a0 : 0.f);
-    const float s1 = wave_sum_to_lane63(mine ? a1 : 0.f);
-    const float s2 = wave_sum_to_lane63(mine ? a2 : 0.f);
-    const float s3 = wave_sum_to_lane63(mine ? a3 : 0.f);
-    if (lane == 63) {
-      float* dst = reinterpret_cast<float*>(grads + o);
-      touched[o] = 1;
-      unsafeAtomicAdd(dst + 9, s0);
-      unsafeAtomicAdd(dst + 10, s1);
-      unsafeAtomicAdd(dst + 11, s2);
-      unsafeAtomicAdd(dst + 12, s3);
-    }
-    todo &= ~__builtin_amdgcn_ballot_w64(mine);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K7' blend_bwd, entry-per-lane form.  The walk above spends most of its instructions reducing 9 partials over
-// the 64 pixels of a wave for every entry.  Here the roles are swapped: a wave still owns a 16x4 pixel strip, but
-// its LANES hold 64 consecutive list entries and it loops over its 64 pixels.  For one pixel
-//   T_i      = T_in * prod_{j<i} (1 - a_j)          -> one inclusive DPP product scan (T_excl = T_incl / (1 - a_i))
-//   S_i . g  = A - Q_in - sum_{j<=i} a_j T_j (c_j . g)  -> one inclusive DPP sum scan of a scalar
-// (A = (C_total . g) + T_final (bg . g)), so two 6-step scans replace the 9-value reduction, and every lane
-// accumulates the 9 partials of ITS entry in registers over the pixel loop.  Per 64-entry chunk the four waves'
-// partials meet in LDS and the tile issues one global atomic per touched (Gaussian, quantity), as before.
-// Contributors are the entries below the pixel's n_contrib that pass the alpha tests - the forward's own rule; T is
-// re-associated by the scan, so it matches the forward to rounding (the walk above matches it bit for bit).
+// Gradient slots (BwdInfo, raster_common.h): grad_reduce sums, for every Gaussian a tile flagged as touched, the
+// slots its run holds into its SplatGrad record.  16 lanes per slot, lane = component of the 64-byte record: a slot is
+// one coalesced 64-B read and the sum needs no cross-lane step inside a group.  Runs of up to 8 slots (the common case
+// on a surface map) are summed by one group, four Gaussians in flight per wave; longer runs (near, screen-filling
+// Gaussians: dozens to hundreds of tiles) get the whole wave, four slots per step.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_incl_scan_mul(float v) {
-  v *= dpp_mov<0x111>(1.f, v);              // row_shr:1
-  v *= dpp_mov<0x112>(1.f, v);              // row_shr:2
-  v *= dpp_mov<0x114>(1.f, v);              // row_shr:4
-  v *= dpp_mov<0x118>(1.f, v);              // row_shr:8
-  v *= dpp_mov<0x142, 0xa>(1.f, v);         // row_bcast:15 into rows 1,3
-  v *= dpp_mov<0x143, 0xc>(1.f, v);         // row_bcast:31 into rows 2,3
-  return v;
-}
-__device__ __forceinline__ float wave_incl_scan_add(float v) {
-  v += dpp_mov<0x111>(0.f, v);
-  v += dpp_mov<0x112>(0.f, v);
-  v += dpp_mov<0x114>(0.f, v);
-  v += dpp_mov<0x118>(0.f, v);
-  v += dpp_mov<0x142, 0xa>(0.f, v);
-  v += dpp_mov<0x143, 0xc>(0.f, v);
-  return v;
-}
-
-__global__ void __launch_bounds__(256) blend_bwd_lanes_kernel(
-    RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const Splat* __restrict__ splats, const float* __restrict__ out_color, const float* __restrict__ final_T,
-    const uint32_t* __restrict__ n_contrib, const int32_t* __restrict__ depth_index,
-    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-    SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched) {
-  __shared__ float4 s_pg[BLOCK];            // per pixel: g0 g1 g2 A
-  __shared__ float2 s_carry[BLOCK];         // per pixel: T_in, Q_in (prefix over the chunks already walked)
-  __shared__ uint32_t s_last[BLOCK];
-  __shared__ float s_acc[4 * 64 * NG];      // [wave][entry lane][quantity]
-  __shared__ unsigned int s_nmax;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
-  const int tile = blockIdx.y * p.gx + blockIdx.x;
-  const uint2 range = ranges[tile];
-  const int n = (int)(range.y - range.x);
-  if (n == 0) return;      // nothing was blended here (or the tile belongs to the other pass of a two-pass forward)
-  const int px = blockIdx.x * TILE + (tid & 15);
-  const int py = blockIdx.y * TILE + (tid >> 4);
-  const bool inside = px < p.W && py < p.H;
-  const float pxf = (float)px, pyf = (float)py;
-  const size_t pix = (size_t)py * p.W + px;
-  const size_t HW = (size_t)p.H * p.W;
-
-  // thread t prepares pixel t of the tile (pixel t belongs to wave t >> 6: rows 4 wv .. 4 wv + 3)
-  const uint32_t last = inside ? n_contrib[pix] : 0u;
-  {
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, A = 0.f;
-    if (inside) {
-      const float Tf = final_T[pix];
-      g0 = dL_dcolor[pix]; g1 = dL_dcolor[HW + pix]; g2 = dL_dcolor[2 * HW + pix];
-      // colour behind the (not yet started) walk, without background, dotted with g; + T_final (bg . g)
-      A = (out_color[pix] - Tf * p.bg[0]) * g0 + (out_color[HW + pix] - Tf * p.bg[1]) * g1 +
-          (out_color[2 * HW + pix] - Tf * p.bg[2]) * g2 + Tf * (p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2);
+__global__ void __launch_bounds__(256) grad_reduce_kernel(int P, const uint8_t* __restrict__ touched,
+                                                          const uint32_t* __restrict__ gbase,
+                                                          const uint32_t* __restrict__ count,
+                                                          const BwdInfo* __restrict__ info,
+                                                          SplatGrad* __restrict__ grads) {
+  if (info->use_slots == 0) return;
+  __shared__ uint8_t s_small[4][64], s_big[4][64];
+  const float* __restrict__ slots = reinterpret_cast<const float*>(info->slot_grads);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int grp = lane >> 4, c = lane & 15;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const long long wave0 = (long long)blockIdx.x * 4 + wv, nwaves = (long long)gridDim.x * 4;
+  for (long long base = wave0 * 64; base < P; base += nwaves * 64) {
+    const long long i = base + lane;
+    const bool t = i < P && touched[i] != 0;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(t);
+    if (mask == 0ull) continue;
+    const bool big = t && count[i] > 8u;
+    const unsigned long long mbig = __builtin_amdgcn_ballot_w64(big), msmall = mask & ~mbig;
+    if (t) {
+      if (big) s_big[wv][__popcll(mbig & lt)] = (uint8_t)lane;
+      else s_small[wv][__popcll(msmall & lt)] = (uint8_t)lane;
     }
-    s_pg[tid] = make_float4(g0, g1, g2, A);
-    s_carry[tid] = make_float2(1.f, 0.f);
-    s_last[tid] = last;
-  }
-  if (tid == 0) s_nmax = 0;
-  __syncthreads();
-  unsigned int wl = last;                   // the wave's own deepest contributor
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) wl = max(wl, (unsigned int)__shfl_xor((int)wl, off));
-  if (lane == 0) atomicMax(&s_nmax, wl);
-  __syncthreads();
-  const int nuse = min(n, (int)s_nmax);
-  const float wave_py0 = (float)(blockIdx.y * TILE + wv * 4);
-  const float tile_px0 = (float)(blockIdx.x * TILE);
-
-  for (int base = 0; base < nuse; base += 64) {
-    const int m = min(64, nuse - base);
-    float acc[NG];
-#pragma unroll
-    for (int k = 0; k < NG; ++k) acc[k] = 0.f;
-    if ((uint32_t)base < wl) {                                    // wave-uniform: some pixel of this wave reaches the chunk
-      // lane i <- entry base + i (lanes >= m idle: opacity 0 fails the alpha test)
-      float eu = 0.f, ev = 0.f, eca = 0.f, ecb = 0.f, ecc = 0.f, eo = 0.f, er = 0.f, eg = 0.f, eb = 0.f;
-      if (lane < m) {
-        const int id = (int)point_list[range.x + base + lane];
-        const float4* src = reinterpret_cast<const float4*>(splats + id);
-        const float4 a = src[0], b = src[1];
-        eu = a.x; ev = a.y; eca = a.z; ecb = a.w; ecc = b.x; eo = b.y; er = b.z; eg = b.w;
-        eb = reinterpret_cast<const float*>(splats + id)[8];
-      }
-      const uint32_t my_index = (uint32_t)(base + lane);
-      const bool more = base + 64 < nuse;                         // carries are needed only if another chunk follows
-      for (int q = 0; q < 64; ++q) {
-        const int pl = wv * 64 + q;                               // pixel of the tile, wave-uniform
-        const uint32_t plast = s_last[pl];
-        if (plast <= (uint32_t)base) continue;                    // pixel stopped before this chunk (or is outside)
-        const float4 pg = s_pg[pl];
-        const float2 carry = s_carry[pl];
-        const float dx = eu - (tile_px0 + (float)(q & 15)), dy = ev - (wave_py0 + (float)(q >> 4));
-        const float power = splat_power(eca, ecb, ecc, dx, dy);
-        const float G = splat_exp(fminf(power, 0.f));
-        const float oG = eo * G;
-        const float alpha = fminf(0.99f, oG);
-        const bool valid = (my_index < plast) && !(power > 0.f) && !(alpha < 1.f / 255.f);
-        const float a = valid ? alpha : 0.f;
-        const float oma = 1.f - a;
-        const float ia = __builtin_amdgcn_rcpf(oma);
-        const float Tincl = carry.x * wave_incl_scan_mul(oma);
-        const float Tk = Tincl * ia;                              // transmittance in front of this entry
-        const float w = a * Tk;
-        const float cg = er * pg.x + eg * pg.y + eb * pg.z;
-        const float Qincl = carry.y + wave_incl_scan_add(w * cg);
-        const float Sg = pg.w - Qincl;                            // (colour strictly behind) . g + T_final (bg . g)
-        const float dL_dalpha = Tk * cg - Sg * ia;
-        const float gda = valid ? G * dL_dalpha : 0.f;   // clamp of alpha is transparent in the backward (upstream 3DGS)
-        const float gdl = gda * eo;
-        acc[0] += gdl * (-eca * dx - ecb * dy);
-        acc[1] += gdl * (-ecc * dy - ecb * dx);
-        acc[2] += gdl * (-0.5f * dx * dx);
-        acc[3] += gdl * (-dx * dy);
-        acc[4] += gdl * (-0.5f * dy * dy);
-        acc[5] += w * pg.x; acc[6] += w * pg.y; acc[7] += w * pg.z;
-        acc[8] += gda;
-        if (more && lane == 63) s_carry[pl] = make_float2(Tincl, Qincl);
-      }
+    __builtin_amdgcn_wave_barrier();
+    const int nbig = __popcll(mbig), nsmall = __popcll(msmall);
+    for (int k = 0; k < nbig; ++k) {
+      const size_t id = (size_t)(base + s_big[wv][k]);
+      const size_t b0 = gbase[id];
+      const uint32_t n = count[id];
+      float a0 = 0.f, a1 = 0.f;
+      uint32_t q = grp;
+      for (; q + 4 < n; q += 8) { a0 += slots[(b0 + q) * 16 + c]; a1 += slots[(b0 + q + 4) * 16 + c]; }
+      if (q < n) a0 += slots[(b0 + q) * 16 + c];
+      float acc = a0 + a1;
+      acc += __shfl_xor(acc, 16);
+      acc += __shfl_xor(acc, 32);
+      if (lane < 16) reinterpret_cast<float*>(grads + id)[c] = acc;
     }
-    // meet in LDS: one slot per (wave, entry lane, quantity)
-#pragma unroll
-    for (int k = 0; k < NG; ++k) s_acc[(wv * 64 + lane) * NG + k] = acc[k];
-    __syncthreads();
-    if (tid < m) {
-      float t[NG];
-      bool any = false;
-#pragma unroll
-      for (int k = 0; k < NG; ++k) {
-        t[k] = (s_acc[tid * NG + k] + s_acc[(64 + tid) * NG + k]) + (s_acc[(128 + tid) * NG + k] + s_acc[(192 + tid) * NG + k]);
-        any |= (t[k] != 0.f);
-      }
-      if (any) {
-        // lanes 0..63 of wave 0 hold the ids of this chunk (wave 0 loaded them iff it walked the chunk)
-        const int gid = (int)point_list[range.x + base + tid];
-        touched[gid] = 1;
-        float* dst = reinterpret_cast<float*>(grads + gid);
-        // SplatGrad order: du dv dca dcb dcc dop dr dg db
-        if (t[0] != 0.f) unsafeAtomicAdd(dst + 0, t[0]);
-        if (t[1] != 0.f) unsafeAtomicAdd(dst + 1, t[1]);
-        if (t[2] != 0.f) unsafeAtomicAdd(dst + 2, t[2]);
-        if (t[3] != 0.f) unsafeAtomicAdd(dst + 3, t[3]);
-        if (t[4] != 0.f) unsafeAtomicAdd(dst + 4, t[4]);
-        if (t[8] != 0.f) unsafeAtomicAdd(dst + 5, t[8]);
-        if (t[5] != 0.f) unsafeAtomicAdd(dst + 6, t[5]);
-        if (t[6] != 0.f) unsafeAtomicAdd(dst + 7, t[6]);
-        if (t[7] != 0.f) unsafeAtomicAdd(dst + 8, t[7]);
-      }
+    for (int k0 = 0; k0 < nsmall; k0 += 4) {
+      const int k = k0 + grp;
+      const bool act = k < nsmall;
+      const size_t id = (size_t)(base + (act ? s_small[wv][k] : 0));
+      const size_t b0 = act ? gbase[id] : 0u;
+      const uint32_t n = act ? count[id] : 0u;
+      float acc = 0.f;
+      for (uint32_t q = 0; q < n; ++q) acc += slots[(b0 + q) * 16 + c];
+      if (act) reinterpret_cast<float*>(grads + id)[c] = acc;
     }
-    __syncthreads();                                              // s_acc is rewritten by the next chunk
-  }
-
-  // opaque-surface depth: D = pd / (n_c . r), owner only (same grouping as blend_bwd_kernel)
-  int owner = -1;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (inside) {
-    owner = depth_index[pix];
-    const float gD = owner >= 0 ? dL_ddepth[pix] : 0.f;
-    if (gD == 0.f) owner = -1;
-    if (owner >= 0) {
-      const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
-      const float pd = reinterpret_cast<const float*>(splats + owner)[12];
-      const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
-      const float den = r2.y * rx + r2.z * ry + r2.w;
-      const float iden = 1.f / den;
-      const float k = -gD * (pd * iden) * iden;
-      a0 = k * rx; a1 = k * ry; a2 = k; a3 = gD * iden;
-    }
-  }
-  unsigned long long todo = __builtin_amdgcn_ballot_w64(owner >= 0);
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int o = __builtin_amdgcn_readlane(owner, leader);
-    const bool mine = owner == o;
-    const float s0 = wave_sum_to_lane63(mine ? a0 : 0.f);
-    const float s1 = wave_sum_to_lane63(mine ? a1 : 0.f);
-    const float s2 = wave_sum_to_lane63(mine ? a2 : 0.f);
-    const float s3 = wave_sum_to_lane63(mine ? a3 : 0.f);
-    if (lane == 63) {
-      float* dst = reinterpret_cast<float*>(grads + o);
-      touched[o] = 1;
-      unsafeAtomicAdd(dst + 9, s0);
-      unsafeAtomicAdd(dst + 10, s1);
-      unsafeAtomicAdd(dst + 11, s2);
-      unsafeAtomicAdd(dst + 12, s3);
-    }
-    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -735,18 +609,17 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 
 void launch_blend_bwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                       const float* out_color, const float* final_T, const uint32_t* n_contrib,
-                      const int32_t* depth_index, const float* dL_dcolor, const float* dL_ddepth, SplatGrad* grads,
-                      uint8_t* touched, hipStream_t st) {
-  // RTGS_BLEND_BWD=1 selects the entry-per-lane walk (fewer instructions, but its two dependent DPP scans per pixel
-  // make it ~25 % slower on MI355X than the pixel-per-lane walk: 144 vs 116 us on the 1.2 M scene)
-  static const int variant = [] { const char* e = getenv("RTGS_BLEND_BWD"); return e ? atoi(e) : 0; }();
-  if (variant == 1) {
-    hipLaunchKernelGGL(blend_bwd_lanes_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
-                       out_color, final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, grads, touched);
-    return;
-  }
+                      const int32_t* depth_index, const float* dL_dcolor, const float* dL_ddepth, const uint32_t* gbase,
+                      uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched, hipStream_t st) {
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
-                     final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, grads, touched);
+                     final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched);
+}
+void launch_grad_reduce(int P, const uint8_t* touched, const uint32_t* gbase, const uint32_t* count, const BwdInfo* info,
+                        SplatGrad* grads, hipStream_t st) {
+  if (P == 0) return;
+  int blocks = (P + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(blocks), dim3(256), 0, st, P, touched, gbase, count, info, grads);
 }
 void launch_preprocess_bwd(const RasterParams& p, const float* means, const float* opac, const float* shs,
                            const float* scales, const float* rots, const float* normal_w, const int32_t* radii,

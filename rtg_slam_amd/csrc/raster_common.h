@@ -56,6 +56,7 @@ struct GeomLayout {
   size_t zero_begin, zero_end;
   size_t tile_count1, ranges1_bwd, slice_hist, slice_cover, slice_ctr;   // inside the zeroed span (tile_count is too)
   size_t zbin, cursor1, ranges1, mask2, block_counts1, bucket1, list1, uv, slice_ids;
+  size_t slot_count;                 // [P] u32: slots taken per Gaussian (backward; zeroed by it)
   size_t slice_cap, slice_max_list;                                  // capacity of bucket1 / list1; of the work list
 };
 
@@ -111,10 +112,37 @@ __device__ __forceinline__ uint32_t slice_bin_of(float z) {
 struct BinLayout {
   size_t keys_a, keys_b, vals_a, vals_b, sort_temp, total;
   size_t sort_temp_bytes;
+  size_t slot_grads;                 // backward partial slots (see BwdInfo); 0 slots = not laid out
 };
 struct ImgLayout {
-  size_t ranges, n_contrib, total;
+  size_t ranges, n_contrib, bwd_info, total;
 };
+
+// What the backward needs to know about the forward that produced its buffers, left in the image buffer by the
+// forward (device memory: the backward never reads it on the host).
+//
+// Gradient partials without global float atomics: every Gaussian owns a run of 64-byte slots, one per tile of its
+// rect (gbase = exclusive scan of the rect areas); a tile that has gradient for the Gaussian takes the next free slot of
+// the run (ONE integer atomic on the Gaussian's counter instead of nine float atomics on its record) and stores its
+// partial there with plain stores; grad_reduce then sums the first `count` slots of every touched Gaussian.  The slot
+// space is allocated with the binning buffer (its size is known at the forward's host sync); if it would be too large
+// the backward falls back to float atomics on the SplatGrad records.
+struct BwdInfo {
+  SplatGrad* slot_grads;       // [slots]
+  uint32_t slots;              // capacity
+  uint32_t use_slots;          // 0 = accumulate into SplatGrad records with global atomics
+};
+constexpr uint32_t SLOTS_MAX = 12u << 20;   // 12 Mi slots = 768 MiB of partials; above that: atomics
+
+// Tile rectangle of a Gaussian: C (int) truncation then clamp - identical to
+// floor-and-clamp on the clamped range.  ONE definition for preprocess, binning and the backward's slot index.
+__device__ __forceinline__ void tile_rect_of(float u, float v, int radius, int gx, int gy, int& x0, int& y0, int& x1, int& y1) {
+  const float r = (float)radius;
+  x0 = min(gx, max(0, (int)((u - r) / (float)TILE)));
+  y0 = min(gy, max(0, (int)((v - r) / (float)TILE)));
+  x1 = min(gx, max(0, (int)((u + r + (float)(TILE - 1)) / (float)TILE)));
+  y1 = min(gy, max(0, (int)((v + r + (float)(TILE - 1)) / (float)TILE)));
+}
 
 // Pinned SH constants (utils/sh_utils.py:26-45 of the reference).
 #define RTGS_SH_C0 0.28209479177387814f

@@ -32,16 +32,6 @@ __global__ void __launch_bounds__(256) mask_sat_kernel(const int32_t* __restrict
   }
 }
 
-__device__ __forceinline__ void tile_rect(float u, float v, int radius, int gx, int gy,
-                                          int& x0, int& y0, int& x1, int& y1) {
-  // C (int) truncation then clamp, identical to floor-and-clamp on the clamped range
-  const float r = (float)radius;
-  x0 = min(gx, max(0, (int)((u - r) / (float)TILE)));
-  y0 = min(gy, max(0, (int)((v - r) / (float)TILE)));
-  x1 = min(gx, max(0, (int)((u + r + (float)(TILE - 1)) / (float)TILE)));
-  y1 = min(gy, max(0, (int)((v + r + (float)(TILE - 1)) / (float)TILE)));
-}
-
 // ---------------------------------------------------------------------------------------------
 // K1 preprocess_fwd: one lane per Gaussian.  Reads 62 floats (248 B), writes one 64-B Splat +
 // radius + tiles_touched + clamp flags.
@@ -85,7 +75,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       if (sel.sat) {                              // no unfinished tile under its rect: bin_count will not read it either
         const float2 c = uv[i];
         int x0, y0, x1, y1;
-        tile_rect(c.x, c.y, radii[i], p.gx, p.gy, x0, y0, x1, y1);
+        tile_rect_of(c.x, c.y, radii[i], p.gx, p.gy, x0, y0, x1, y1);
         if (sat_count(sel.sat, p.gx, x0, y0, x1, y1) == 0) return;
       }
     }
@@ -150,7 +140,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     u = t.x; v = t.y; radius = radii[i];
   } else {
     int x0, y0, x1, y1;
-    tile_rect(u, v, radius, p.gx, p.gy, x0, y0, x1, y1);
+    tile_rect_of(u, v, radius, p.gx, p.gy, x0, y0, x1, y1);
     if ((x1 - x0) * (y1 - y0) == 0) return;
     const int sw = p.gx + 1;
     touched = sat ? sat[y1 * sw + x1] - sat[y0 * sw + x1] - sat[y1 * sw + x0] + sat[y0 * sw + x0]
@@ -263,7 +253,7 @@ __global__ void __launch_bounds__(256) emit_keys_kernel(
   const float u = splats[i].u, v = splats[i].v;
   const uint32_t zbits = __float_as_uint(splats[i].z);
   int x0, y0, x1, y1;
-  tile_rect(u, v, radius, p.gx, p.gy, x0, y0, x1, y1);
+  tile_rect_of(u, v, radius, p.gx, p.gy, x0, y0, x1, y1);
   for (int y = y0; y < y1; ++y)
     for (int x = x0; x < x1; ++x) {
       const int t = y * p.gx + x;
@@ -475,7 +465,13 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     atomicMax(&s_max, contributor);
     atomicAdd(&s_ev, evals);
     __syncthreads();
-    if (tid == 0) { atomicAdd(&counters[0], (unsigned long long)s_max); atomicAdd(&counters[1], s_ev); }
+    // one slot pair per tile, plain stores (3 225 same-address atomics cost ~80 us - more than the kernel itself);
+    // the second pass of a two-pass forward adds to what the first wrote for the tile
+    if (tid == 0) {
+      const bool add = sp.mode == 2;
+      counters[2 * tile] = (add ? counters[2 * tile] : 0ull) + (unsigned long long)s_max;
+      counters[2 * tile + 1] = (add ? counters[2 * tile + 1] : 0ull) + s_ev;
+    }
   }
 }
 
@@ -593,7 +589,13 @@ __global__ void __launch_bounds__(256) blend_fwd_scalar_kernel(
     atomicMax(&s_max, contributor);
     atomicAdd(&s_ev, evals);
     __syncthreads();
-    if (tid == 0) { atomicAdd(&counters[0], (unsigned long long)s_max); atomicAdd(&counters[1], s_ev); }
+    // one slot pair per tile, plain stores (3 225 same-address atomics cost ~80 us - more than the kernel itself);
+    // the second pass of a two-pass forward adds to what the first wrote for the tile
+    if (tid == 0) {
+      const bool add = 0 == 2;
+      counters[2 * tile] = (add ? counters[2 * tile] : 0ull) + (unsigned long long)s_max;
+      counters[2 * tile + 1] = (add ? counters[2 * tile + 1] : 0ull) + s_ev;
+    }
   }
 }
 

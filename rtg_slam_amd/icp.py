@@ -95,7 +95,7 @@ def icp_track(vertex_src: Sequence[torch.Tensor], normal_src, vertex_tgt, normal
               downscales: Sequence[float], iters: Sequence[int], dist_thr: float, cos_thr: float,
               damping: float, pose0: torch.Tensor | None = None) -> torch.Tensor:
     """The level loop of IcpTracker.predict_pose (icp.py:428-447) on the device.
-    Returns a device float32[20]: pose (16, row-major) + [valid_ratio, p2p_loss, n_singular, 0]."""
+    Returns a device float32[20]: pose (16, row-major) + [valid_ratio, p2p_loss, n_singular, aborted]."""
     lib = _lib.load()
     dev = vertex_src[0].device
     _require_device(vertex_src[0])
@@ -202,6 +202,9 @@ class IcpTracker:
                         self.normal_pyramid_t0, K, self.icp_downscales, self.icp_downscale_iters,
                         self.icp_distance_threshold, self.icp_normal_threshold, self.icp_damping)
         host = out.cpu().numpy()                      # the single device->host copy of the frame
+        if host[19] != 0:
+            raise RuntimeError("rtgs_icp_track: the persistent tracking kernel timed out at a grid barrier "
+                               "(set RTGS_ICP_PERSISTENT=0 to use one launch per Gauss-Newton iteration)")
         pose_t1_t0 = host[:16].reshape(4, 4).copy()
         self.last_valid_ratio = float(host[16])
         self.last_p2ploss = float(host[17])

@@ -221,7 +221,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 rctx.ptr, C.byref(keep.c), P, M, _ptr(means3D), _ptr(opacities), _ptr(shs), _ptr(scales), _ptr(rotations),
                 _ptr(normal_w), _ptr(tile_mask), _ptr(color), _ptr(depth), _ptr(cidx), _ptr(didx), _ptr(cw),
                 _ptr(dw), _ptr(Tm), _ptr(radii), geom.cb, None, binning.cb, None, img.cb, None, C.byref(R),
-                C.c_void_p(stream))
+                0 if any(ctx.needs_input_grad[:6]) else _lib.FWD_NO_BACKWARD, C.c_void_p(stream))
         _lib.check(rc, "rtgs_raster_forward")
         ctx.raster_settings = rs
         ctx.num_rendered = int(R.value)

@@ -26,8 +26,10 @@ def test_pyramids_vs_reference(golden_dir, name):
         vp, npyr = icp.build_pyramids(g[f"depth{tag}"].to(DEV), g["K"].to(DEV), 3)
         for l in range(3):
             assert torch.equal(vp[l].cpu(), g[f"v{tag}_{l}"]), "vertex maps bit-exact"
+            # Sobel taps in conv2d's order, cross and norm rounded as torch rounds them: the normal maps are the
+            # reference's bit for bit (so no gate of the tracker can flip on a last-ulp normal difference)
             d = (npyr[l].cpu() - g[f"n{tag}_{l}"]).abs().amax(dim=-1)
-            assert float((d > 1e-4).float().mean()) < 1e-3, (l, float(d.max()))
+            assert torch.equal(npyr[l].cpu(), g[f"n{tag}_{l}"]), (l, float(d.max()), float((d > 0).float().mean()))
 
 
 @pytest.mark.parametrize("name", ["small_clean", "small_noisy"])
@@ -103,12 +105,60 @@ def test_tracker_class_vs_oracle_full_size(cam, noise):
     vp0 = io.vertex_pyramid(d0, K.clone(), 3); np0 = io.normal_pyramid(vp0)
     vp1 = io.vertex_pyramid(d1, K.clone(), 3); np1 = io.normal_pyramid(vp1)
     pose_o, ratio_o, loss_o = io.track(vp1, np1, vp0, np0, K.clone())
+    pose_x, _, _ = io.track(vp1, np1, vp0, np0, K.clone(), exact_sums=True)
     assert pose.shape == (4, 4) and pose.dtype == np.float32
-    # noisy depth with holes: normals differ in the last ulp between conv2d and the fused stencil, which
-    # flips a few gate decisions per iteration; the un-converged 15-iteration pose inherits that
-    assert float(np.abs(pose - pose_o.numpy()).max()) < (5e-4 if noise else 2e-5)
+    # Normals are bit-identical to the reference's and no gate flips (test_no_gate_flips_...), so the only difference
+    # left is HOW the 27 sums are reduced.  The kernel reduces in float64; against the reference algorithm with exact
+    # (float64) sums it holds 2e-5 on both frames.  The reference's own float32 reductions are the noisier side: on
+    # the ill-conditioned noisy frame (5 % of the pixels pass the gates, the iteration is still wandering after 15
+    # steps) they move its 15-iteration pose by ~1e-4: the SAME torch-CPU oracle gives t_x = -0.0279093 in the build
+    # container and -0.0280408 on the MI355X box's host (another BLAS reduction order), the exact-sum variant
+    # -0.0278665 on both, the kernel -0.0278793.  So: 3e-5 against the exact-sum oracle on both frames, and against
+    # the float32 oracle no further than that oracle's own distance from exact sums.
+    err_x = float(np.abs(pose - pose_x.numpy()).max())
+    err_o = float(np.abs(pose - pose_o.numpy()).max())
+    ref_noise = float((pose_o - pose_x).abs().max())
+    print(f"noise={noise}: |hip - exact-sum oracle| = {err_x:.2e}, |hip - f32 oracle| = {err_o:.2e}, "
+          f"|f32 oracle - exact-sum oracle| = {ref_noise:.2e}")
+    assert err_x < 3e-5, (err_x, err_o, ref_noise)
+    assert err_o < 2e-5 + 1.5 * ref_noise, (err_x, err_o, ref_noise)
     assert abs(tr.last_valid_ratio - ratio_o) < 1e-3
     assert ok == (not (loss_o > 0.02))
     if not noise:
         rel = (torch.linalg.inv(poses[0]) @ poses[1]).float().numpy()
         assert float(np.abs(pose - rel).max()) < 5e-3
+
+
+def test_no_gate_flips_on_the_noisy_full_size_frame():
+    """bound the per-iteration gate flips on the noisy TUM-shaped frame.  Along the oracle's own
+    15-iteration pose sequence, the HIP normal equations at every iterate have EXACTLY the oracle's number of valid
+    correspondences (association, depth, distance and normal gates all agree) and match its sums to 1e-4 relative;
+    the pyramids the two sides work on are bit-identical."""
+    from rtg_slam_amd import icp
+    cam = synth.TUM_FR1
+    poses = synth.trajectory(2, seed=9)
+    base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
+    d0 = synth.tum_noise(synth.box_room_depth(cam, base @ poses[0]), 1)
+    d1 = synth.tum_noise(synth.box_room_depth(cam, base @ poses[1]), 2)
+    K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32)
+    vp0 = io.vertex_pyramid(d0, K.clone(), 3); np0 = io.normal_pyramid(vp0)
+    vp1 = io.vertex_pyramid(d1, K.clone(), 3); np1 = io.normal_pyramid(vp1)
+    hv0, hn0 = icp.build_pyramids(d0.to(DEV), K.to(DEV), 3)
+    hv1, hn1 = icp.build_pyramids(d1.to(DEV), K.to(DEV), 3)
+    for l in range(3):
+        for a, b in ((hv0[l], vp0[l]), (hn0[l], np0[l]), (hv1[l], vp1[l]), (hn1[l], np1[l])):
+            assert torch.equal(a.cpu(), b), l
+    cos_thr = float(np.cos(np.deg2rad(20.0)))
+    pose = torch.eye(4)
+    flips = 0
+    for l, ds in enumerate([0.25, 0.5, 1.0]):
+        Kl = K * ds
+        Kl[2, 2] = 1.0
+        for _ in range(5):
+            res, J, valid = io.residuals_jacobian(vp1[l], vp0[l], np1[l], np0[l], pose, Kl, 0.1, cos_thr)
+            JtJ_o, Jtr_o = io.normal_equations(J, res)
+            JtJ, Jtr, nv = icp.icp_step(hv1[l], hn1[l], hv0[l], hn0[l], Kl, pose, 0.1, cos_thr)
+            flips += abs(int(nv.item()) - int(valid.sum()))
+            assert float((JtJ.cpu() - JtJ_o).abs().max()) <= 1e-4 * float(JtJ_o.abs().max())
+            pose = io.gauss_newton_update(JtJ_o, Jtr_o, pose, 1e-4)
+    assert flips == 0, flips

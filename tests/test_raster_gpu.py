@@ -525,3 +525,34 @@ def test_one_call_slam_step_matches_autograd_step():
     moved = (pa - packed.cpu()).abs().max(dim=1).values > 0
     assert 0 < int(moved.sum()) < N
     assert torch.equal(moved, (pb - packed.cpu()).abs().max(dim=1).values > 0)
+
+
+def test_wall_of_bit_equal_depths():
+    """A wall seen head-on: hundreds of Gaussians per tile share ONE float32 depth, so the tile order is decided by the
+    Gaussian index alone.  Every LDS sort class (bitonic <= 256, radix above) and the global-sort fallback agree with
+    the oracle's stable (depth, index) order."""
+    from rtg_slam_amd import _lib
+    lib = _lib.load()
+    cam = SMALL
+    g = synth.surface_gaussians(40000, cam, seed=3, half=(0.6, 0.4, 1.0))      # a small room: the front wall fills the view
+    _, s = ru.make_scene(1, cam, seed=1)
+    z = (g["xyz"][:, 2] == 1.0)
+    assert int(z.sum()) > 3000                                               # thousands of bit-equal depths
+    gen = torch.Generator().manual_seed(3)
+    grads = (torch.randn(3, cam.H, cam.W, generator=gen), torch.randn(1, cam.H, cam.W, generator=gen))
+    out_a, gd_a = ru.hip_run(s, g, grads=grads)
+    st = (__import__("ctypes").c_int64 * 8)()
+    lib.rtgs_raster_last_stats(st)
+    assert st[6] == 1 and st[7] > 256, (st[6], st[7])                        # LDS path, lists in the radix classes
+    lib.rtgs_raster_force_sort_path(1)
+    try:
+        out_b, _ = ru.hip_run(s, g)
+    finally:
+        lib.rtgs_raster_force_sort_path(0)
+    for a, b in zip(out_a, out_b):
+        assert torch.equal(a, b)
+    out_o, gd_o, _ = ru.oracle_run(s, g, grads=grads)
+    check_forward(out_a, out_o)
+    for k in ru.FIELDS:
+        sc = float(gd_o[k].abs().max()) + 1e-12
+        assert float((gd_a[k] - gd_o[k]).abs().max()) / sc < 1e-3, k
