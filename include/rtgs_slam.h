@@ -1,0 +1,84 @@
+/*
+ * rtgs_slam.h - C ABI of the callers and data producers either side of RTG-SLAM's hot path (R9, f-1, f-3),
+ * MI355X (gfx950) build.  Same conventions as rtgs_raster.h: device pointers, dense row-major float32 / int32 / uint8,
+ * inputs borrowed, enqueued on `stream` (hipStream_t as void*), 0 = success / negative = error.
+ *
+ * What each entry point replaces in the reference:
+ *   tile-mask producers      SLAM/utils.py:681-734 (pixelmask2tilemask, transmission2tilemask, colorerror2tilemask)
+ *                            and the render-range step of mapper.py:471-508
+ *   rtgs_knn3                simple_knn._C.distCUDA2 (un-vendored CUDA submodule; call site gaussian_pointcloud.py:376)
+ *   rtgs_accumulate_error    cuda_utils._C.accumulate_gaussian_error (un-vendored; call site mapper.py:541-565)
+ *   frame preprocessing      tracker.py:97-159 -> SLAM/utils.py:65-139 (vertex / normal / confidence maps),
+ *                            SLAM/utils.py:550-589 (bilateral filter), SLAM/utils.py:141-183 (sample_pixels' mask)
+ */
+#ifndef RTGS_SLAM_H
+#define RTGS_SLAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- tile masks (16 x 16 tiles unless `stride` says otherwise; the grid is ceil(H/stride) x ceil(W/stride), pixels
+ *      beyond the image count as 0 exactly as the reference's zero padding) -------------------------------------- */
+
+/* Per-tile SUM of a pixel map: src_kind 0 = uint8 mask (non-zero = 1), 1 = float32.  tile_sum[gy*gx] float32. */
+int rtgs_tile_sum(const void* src, int32_t src_kind, int32_t H, int32_t W, int32_t stride, float* tile_sum, void* stream);
+
+/* transmission2tilemask: tile on iff mean(mask) > ratio, i.e. sum > ratio * stride^2 (mask sums are exact integers). */
+int rtgs_transmission2tilemask(const uint8_t* pixelmask, int32_t H, int32_t W, int32_t stride, float ratio,
+                               int32_t* tile_mask, float* tile_sum_scratch, void* stream);
+/* pixelmask2tilemask: tile on iff any pixel is. */
+int rtgs_pixelmask2tilemask(const uint8_t* pixelmask, int32_t H, int32_t W, int32_t stride, int32_t* tile_mask,
+                            float* tile_sum_scratch, void* stream);
+/* colorerror2tilemask: the k = (int)(tiles * top_ratio) tiles with the largest mean error are on (ties at the k-th value:
+ * lower tile index first).  Up to 16 384 tiles. */
+int rtgs_colorerror2tilemask(const float* color_error, int32_t H, int32_t W, int32_t stride, float top_ratio,
+                             int32_t* tile_mask, float* tile_sum_scratch, void* stream);
+/* The render-range step of mapper.py:471-508 in one call, straight from the rasterizer's T_map:
+ *   render_mask = (T_map != 1)  [uint8, H*W],  tile_mask = transmission2tilemask(render_mask, 16, ratio),
+ *   *count_out = number of set pixels (device uint32; render_ratio = count / pixels). */
+int rtgs_render_range(const float* T_map, int32_t H, int32_t W, float ratio, uint8_t* render_mask, int32_t* tile_mask,
+                      uint32_t* count_out, float* tile_sum_scratch, void* stream);
+
+/* ---- simple_knn.distCUDA2 ------------------------------------------------------------------------------------- */
+/* For each of the N points (float32 [N,3]): its three nearest OTHER points.  mean_dist2[N] = mean of the three squared
+ * distances (d^2 = dx*dx + dy*dy + dz*dz in float32), idx[N,3] int32 ascending by distance, dist2[N,3] (may be NULL).
+ * Exact (Morton order + bounding-box pruning, no approximation).  Fewer than three other points: FLT_MAX / -1.
+ * scratch: rtgs_knn3_scratch_bytes(N) bytes. */
+size_t rtgs_knn3_scratch_bytes(int32_t N);
+int rtgs_knn3(const float* points, int32_t N, float* mean_dist2, int32_t* idx, float* dist2, void* scratch, void* stream);
+
+/* ---- cuda_utils.accumulate_gaussian_error --------------------------------------------------------------------- */
+/* FROZEN semantics (the CUDA source is absent; mapper.py:541-571 is the evidence): colour error goes to the Gaussian in
+ * color_index, depth and normal error to the Gaussian in depth_index (-1 = nobody).  Outputs [P]: mean (mean != 0) or
+ * sum of each error over the attributed pixels (0 where none), and outlier_count = attributed pixels over threshold.
+ * scratch: 2 * P floats (pixel counts). */
+int rtgs_accumulate_error(int32_t H, int32_t W, int32_t P, const float* color_err, const float* depth_err,
+                          const float* normal_err, const int32_t* color_index, const int32_t* depth_index, float thr_c,
+                          float thr_d, float thr_n, int32_t mean, float* g_color, float* g_depth, float* g_normal,
+                          int32_t* outlier_count, float* scratch, void* stream);
+
+/* ---- frame preprocessing --------------------------------------------------------------------------------------- */
+/* bilateralFilter_torch(depth, radius, sigma_color, sigma_space) - SLAM/utils.py:550-589. */
+int rtgs_bilateral_filter(const float* depth, int32_t H, int32_t W, int32_t radius, float sigma_color, float sigma_space,
+                          float* out, void* stream);
+/* The map part of Tracker.map_preprocess (tracker.py:114-131) after the optional filter: range mask, vertex / normal /
+ * confidence maps, invalid-confidence mask zeroing all four.  K: device float[9].  Outputs: depth_out[H,W],
+ * vertex_out[H,W,3], normal_out[H,W,3], conf_out[H,W], bad_out[H,W] uint8.  scratch: H*W*3 floats + 16 bytes. */
+size_t rtgs_frame_preprocess_scratch_bytes(int32_t H, int32_t W);
+int rtgs_frame_preprocess(const float* depth_in, int32_t H, int32_t W, const float* K, float min_depth, float max_depth,
+                          float invalid_confidence_thresh, float* depth_out, float* vertex_out, float* normal_out,
+                          float* conf_out, uint8_t* bad_out, void* scratch, void* stream);
+/* Candidate pixels of sample_pixels (SLAM/utils.py:141-183): select_mask (NULL = all) minus pixels whose normal sums to
+ * exactly 0, compacted IN INDEX ORDER: indices_out[*count_out] int32 flat pixel indices.  scratch: rtgs_compact_scratch_bytes. */
+size_t rtgs_compact_scratch_bytes(int32_t n);
+int rtgs_sample_candidates(const float* normal_map, const uint8_t* select_mask, int32_t H, int32_t W, int32_t* indices_out,
+                           int32_t* count_out, uint8_t* flags_scratch, void* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGS_SLAM_H */

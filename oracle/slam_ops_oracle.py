@@ -1,0 +1,222 @@
+"""CPU restatements (plain torch) of the callers and data producers either side of the hot path - SURVEY.md 8 rows R9
+and (f-1)..(f-3).  TEST INFRASTRUCTURE ONLY: imported by tests/ (and bench.py's cpu_baseline leg), never by the product.
+
+Pinned: every function that restates in-tree reference Python is checked against the reference itself, imported from
+/root/reference through oracle/ref_shim.py, in tests/test_oracle_slam_ops.py (build container), and the vectors that
+test produces travel to the GPU box as tests/golden/slam_ops.npz (oracle/gen_slam_ops_golden.py).
+
+Unpinned (source absent from the reference tree; semantics FROZEN here from the call sites):
+  * simple_knn._C.distCUDA2          - un-vendored submodule; call site SLAM/gaussian_pointcloud.py:376-389
+  * cuda_utils._C.accumulate_gaussian_error - un-vendored submodule; call site SLAM/multiprocess/mapper.py:541-565
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------ R9: tile-mask producers (SLAM/utils.py:681-734)
+def _pad_to(x: torch.Tensor, stride: int, value=0):
+    H, W = x.shape[:2]
+    return F.pad(x, (0, (W + stride - 1) // stride * stride - W, 0, (H + stride - 1) // stride * stride - H), value=value)
+
+
+def pixelmask2tilemask(pixelmask: torch.Tensor, stride: int = 16) -> torch.Tensor:
+    """SLAM/utils.py:681-692: a tile is on if ANY of its pixels is (max-pool)."""
+    p = _pad_to(pixelmask, stride)[None, None].float()
+    return F.max_pool2d(p, stride, stride)[0, 0].int()
+
+
+def transmission2tilemask(pixelmask: torch.Tensor, stride: int = 16, tile_mask_ratio: float = 0.5) -> torch.Tensor:
+    """SLAM/utils.py:695-705: a tile is on if more than `tile_mask_ratio` of its (zero-padded) pixels are."""
+    p = _pad_to(pixelmask, stride)[None, None].float()
+    return (F.avg_pool2d(p, stride, stride)[0, 0] > tile_mask_ratio).int()
+
+
+def colorerror2tilemask(color_error: torch.Tensor, stride: int = 16, top_ratio: float = 0.4) -> torch.Tensor:
+    """SLAM/utils.py:708-734: the int(tiles * top_ratio) tiles with the largest mean (zero-padded) error."""
+    p = _pad_to(color_error, stride, value=0)[None, None].float()
+    mean = F.avg_pool2d(p, stride, stride)[0, 0]
+    k = int(mean.numel() * top_ratio)
+    _, idx = torch.topk(mean.reshape(-1), k=k)
+    out = torch.zeros(mean.numel(), dtype=torch.int32)
+    out[idx] = 1
+    return out.reshape(mean.shape)
+
+
+def tile_mean(x: torch.Tensor, stride: int = 16) -> torch.Tensor:
+    return F.avg_pool2d(_pad_to(x, stride, value=0)[None, None].float(), stride, stride)[0, 0]
+
+
+# ------------------------------------------------------------------ (f-1) simple_knn.distCUDA2  [FROZEN, unpinned]
+def dist2_knn(points: torch.Tensor, chunk: int = 2048):
+    """For every point: squared distances to its three nearest OTHER points (ascending), their indices, and the mean
+    of the three - what `simple_knn._C.distCUDA2` returns in RTG-SLAM's fork: `(mean_dist2[N], idx[N,3])`
+    (gaussian_pointcloud.py:376-389 indexes `total_xyz[knn_indices[:, k]]`).  Brute force; d^2 = dx*dx + dy*dy + dz*dz
+    in float32, in that order.  Fewer than three other points: the missing distances are FLT_MAX, indices -1."""
+    N = points.shape[0]
+    p = points.float()
+    best_d = torch.full((N, 3), torch.finfo(torch.float32).max)
+    best_i = torch.full((N, 3), -1, dtype=torch.int64)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    for s in range(0, N, chunk):
+        e = min(N, s + chunk)
+        dx, dy, dz = x[s:e, None] - x[None, :], y[s:e, None] - y[None, :], z[s:e, None] - z[None, :]
+        d = dx * dx + dy * dy + dz * dz
+        d[torch.arange(e - s), torch.arange(s, e)] = float("inf")
+        k = min(3, N - 1)
+        if k > 0:
+            v, i = torch.topk(d, k=k, dim=1, largest=False)
+            best_d[s:e, :k], best_i[s:e, :k] = v, i
+    return best_d.sum(1) / 3.0, best_i.int(), best_d
+
+
+# ------------------------------------------------------------------ (f-1) cuda_utils.accumulate_gaussian_error  [FROZEN]
+def accumulate_gaussian_error(H, W, P, color_err, depth_err, normal_err, color_index, depth_index, thr_c, thr_d, thr_n,
+                              mean=True):
+    """FROZEN definition (mapper.py:541-565 is the only evidence): colour error is attributed to the Gaussian in
+    `color_index`, depth and normal error to the Gaussian in `depth_index`; index -1 = nobody.  Per Gaussian: the mean
+    (flag True; the sum if False) of each error over the pixels attributed to it, 0 where none, and
+    outlier_count = number of attributed pixels whose error exceeds its threshold (colour, depth and normal counted
+    together).  The caller compares the means with 2x the add_*_thres (mapper.py:567-571)."""
+    ce, de, ne = color_err.reshape(-1).float(), depth_err.reshape(-1).float(), normal_err.reshape(-1).float()
+    ci, di = color_index.reshape(-1).long(), depth_index.reshape(-1).long()
+    sums = [torch.zeros(P) for _ in range(3)]
+    cnts = [torch.zeros(P) for _ in range(2)]
+    out = torch.zeros(P, dtype=torch.int32)
+    mc, md = ci >= 0, di >= 0
+    sums[0].index_add_(0, ci[mc], ce[mc]); cnts[0].index_add_(0, ci[mc], torch.ones(int(mc.sum())))
+    sums[1].index_add_(0, di[md], de[md]); sums[2].index_add_(0, di[md], ne[md])
+    cnts[1].index_add_(0, di[md], torch.ones(int(md.sum())))
+    out.index_add_(0, ci[mc], (ce[mc] > thr_c).int())
+    out.index_add_(0, di[md], (de[md] > thr_d).int() + (ne[md] > thr_n).int())
+    if mean:
+        return (sums[0] / cnts[0].clamp_min(1), sums[1] / cnts[1].clamp_min(1), sums[2] / cnts[1].clamp_min(1), out)
+    return sums[0], sums[1], sums[2], out
+
+
+# ------------------------------------------------------------------ (f-3) frame preprocessing (tracker.py:97-159)
+def bilateral_filter(depth: torch.Tensor, radius: int, sigma_color: float, sigma_space: float) -> torch.Tensor:
+    """SLAM/utils.py:550-589: taps inside the disc i^2 + j^2 <= radius^2, weight exp(spatial + range) where the range
+    term is the squared depth difference to the CENTRE, taps whose depth is 0 ignored, zero padding, 0 where no tap
+    counted."""
+    h, w = depth.shape[:2]
+    d = depth.reshape(h, w).float()
+    pad = F.pad(d, (radius, radius, radius, radius))
+    wsum, psum = torch.zeros_like(d), torch.zeros_like(d)
+    for i in range(-radius, radius + 1):
+        for j in range(-radius, radius + 1):
+            if i * i + j * j > radius * radius:
+                continue
+            tap = pad[radius + i:radius + i + h, radius + j:radius + j + w]
+            wgt = torch.exp(-(i * i + j * j) / (2 * sigma_space ** 2) + -((d - tap) ** 2) / (2 * sigma_color ** 2))
+            wgt = wgt * (tap != 0)
+            wsum += wgt
+            psum += wgt * tap
+    out = psum / wsum
+    out[wsum == 0] = 0
+    return out.reshape(h, w, 1)
+
+
+def confidence_map(normal_map: torch.Tensor, K: torch.Tensor) -> torch.Tensor:
+    """SLAM/utils.py:124-139: |cos| between the normal and the (normalised, +1e-8) viewing ray of the pixel."""
+    H, W, _ = normal_map.shape
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    ray = torch.ones(H, W, 3)
+    ray[..., 0] = (xs - K[0, 2]) / K[0, 0]
+    ray[..., 1] = (ys - K[1, 2]) / K[1, 1]
+    ray = ray / (ray.norm(dim=-1, keepdim=True) + 1e-8)
+    return F.cosine_similarity(normal_map, ray, dim=-1).abs()[..., None]
+
+
+def frame_preprocess(depth_map, K, min_depth=0.3, max_depth=5.0, depth_filter=False, invalid_confidence_thresh=0.2):
+    """The map part of Tracker.map_preprocess (tracker.py:104-131): optional bilateral filter (radius 5, sigma 2 / 2),
+    range mask, vertex / normal / confidence maps, and the invalid-confidence mask zeroing all four."""
+    from oracle import icp_oracle as io
+    d = bilateral_filter(depth_map, 5, 2, 2) if depth_filter else depth_map.clone().float()
+    d[~((d > min_depth) & (d < max_depth))] = 0.0
+    vertex = io.vertex_map(d, K)
+    normal = io.normal_map(vertex)
+    conf = confidence_map(normal, K)
+    bad = (normal == 0).all(dim=-1) | (conf < invalid_confidence_thresh)[..., 0]
+    d, normal, vertex, conf = d.clone(), normal.clone(), vertex.clone(), conf.clone()
+    d[bad] = 0
+    normal[bad] = 0
+    vertex[bad] = 0
+    conf[bad] = 0
+    return dict(depth_map=d, normal_map_c=normal, vertex_map_c=vertex, confidence_map=conf, invalid_confidence_mask=bad)
+
+
+def sample_pixels_mask(normal_map: torch.Tensor, select_mask: torch.Tensor | None) -> torch.Tensor:
+    """The deterministic half of sample_pixels (SLAM/utils.py:141-183): which pixels are candidates - select_mask
+    (all ones if None) minus the pixels whose normal sums to exactly 0.  The other half is a uniform draw without
+    replacement (torch.randperm) of min(n, #candidates) of them."""
+    H, W = normal_map.shape[:2]
+    m = torch.ones(H, W, dtype=torch.bool) if select_mask is None else select_mask.reshape(H, W).bool().clone()
+    m[normal_map.sum(dim=-1) == 0] = False
+    return m
+
+
+# ------------------------------------------------------------------ (f-2) loss of one optimisation step (mapper.py:371-445)
+def _gauss_window(size=11, sigma=1.5):
+    g = torch.tensor([math.exp(-((x - size // 2) ** 2) / float(2 * sigma ** 2)) for x in range(size)])
+    g = g / g.sum()
+    return (g[:, None] @ g[None, :]).float()
+
+
+def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11) -> torch.Tensor:
+    """utils/loss_utils.py:58-100: 11x11 Gaussian window (sigma 1.5), zero padding, per channel, mean of the map."""
+    C = img1.shape[-3]
+    win = _gauss_window(window_size).to(img1.dtype)[None, None].expand(C, 1, window_size, window_size).contiguous()
+    a, b = img1.reshape(1, C, *img1.shape[-2:]), img2.reshape(1, C, *img2.shape[-2:])
+    pad = window_size // 2
+    conv = lambda t: F.conv2d(t, win, padding=pad, groups=C)
+    mu1, mu2 = conv(a), conv(b)
+    s11, s22, s12 = conv(a * a) - mu1 * mu1, conv(b * b) - mu2 * mu2, conv(a * b) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s11 + s22 + C2))
+    return m.mean()
+
+
+def slam_loss(render, gt_color, gt_depth, gt_normal=None, render_mask=None, color_weight=0.8, depth_weight=1.0,
+              ssim_weight=0.2, normal_weight=0.0, add_depth_thres=0.1, render_normal=None):
+    """The image terms of Mapping.loss_update (mapper.py:402-448); `render` = the rasterizer's 7-tuple, channels first;
+    gt_color [3,H,W], gt_depth [1,H,W], render_mask bool [H,W] or None.  Returns (total, dict of terms).
+      * render_mask None -> all pixels, and the SSIM term 1 - ssim(render, gt) is live (:411-415);
+      * colour: L1 mean over the masked pixels (x3 channels) (:421);
+      * depth: mean |D - D_gt| over depth_index != -1 & D_gt > 0 & (D - D_gt) < add_depth_thres & render_mask (:423-431)
+        - the threshold is on the SIGNED error, as the reference writes it; nan if the mask is empty, as torch's mean;
+      * normal: mean (1 - cos) over render_mask & depth_index != -1 & gt normal != 0 (:433-442), only if weighted."""
+    color, depth, didx = render[0], render[1], render[3]
+    H, W = color.shape[-2:]
+    ssim_loss = color.new_zeros(())
+    if render_mask is None:
+        mask = torch.ones(H, W, dtype=torch.bool)
+        ssim_loss = 1 - ssim(color, gt_color)
+    else:
+        mask = render_mask.bool()
+    color_loss = (color - gt_color).abs()[:, mask].mean()
+    depth_loss = color.new_zeros(())
+    if depth_weight > 0:
+        err = depth[0] - gt_depth[0]
+        vm = (didx[0] != -1) & (gt_depth[0] > 0) & (err < add_depth_thres) & mask
+        depth_loss = err.abs()[vm].mean()
+    normal_loss = color.new_zeros(())
+    if normal_weight > 0 and render_normal is not None and gt_normal is not None:
+        cosd = 1 - F.cosine_similarity(render_normal, gt_normal, dim=0)
+        vn = mask & (didx[0] != -1) & ~((gt_normal == 0).all(dim=0))
+        normal_loss = cosd[vn].mean()
+    total = depth_weight * depth_loss + normal_weight * normal_loss + color_weight * color_loss + ssim_weight * ssim_loss
+    return total, dict(color=color_loss, depth=depth_loss, ssim=ssim_loss, normal=normal_loss)
+
+
+def attach_loss(opacity_act, scaling, xyz, rotation, init_scaling, init_xyz, init_rotation):
+    """mapper.py:384-401: Gaussians whose activated opacity is below 0.9 are tied to their initial raw scaling, position
+    and raw rotation: 1000 x (mean-squared difference of each), means over the selected rows x columns."""
+    m = (opacity_act < 0.9).reshape(-1)
+    if int(m.sum()) == 0:
+        return xyz.new_zeros(())
+    l2 = lambda a, b: ((a - b) ** 2).mean()
+    return 1000 * (l2(scaling[m], init_scaling[m]) + l2(xyz[m], init_xyz[m]) + l2(rotation[m], init_rotation[m]))

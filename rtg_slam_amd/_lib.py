@@ -1,4 +1,4 @@
-"""ctypes binding of the C-ABI library (include/rtgs_raster.h, include/rtgs_icp.h).
+"""ctypes binding of the C-ABI library (include/rtgs_raster.h, include/rtgs_icp.h, include/rtgs_slam.h).
 
 The library is the product: there is NO fallback.  If `librtgs_hip.so` is missing or fails to
 load, importing any op raises (build it with `python -c "import __graft_entry__ as g; g.build()"`
@@ -118,6 +118,22 @@ _SIGNATURES = {
     "rtgs_icp_track": (C.c_int, [C.POINTER(IcpLevelC), C.c_int32, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P]),
     "rtgs_icp_fill_model_depth": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, _P]),
     "rtgs_icp_scratch_bytes": (C.c_size_t, []),
+    # include/rtgs_slam.h
+    "rtgs_tile_sum": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "rtgs_transmission2tilemask": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
+    "rtgs_pixelmask2tilemask": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "rtgs_colorerror2tilemask": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
+    "rtgs_render_range": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P, _P]),
+    "rtgs_knn3_scratch_bytes": (C.c_size_t, [C.c_int32]),
+    "rtgs_knn3": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    "rtgs_accumulate_error": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_float, C.c_float,
+                                        C.c_float, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "rtgs_bilateral_filter": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P]),
+    "rtgs_frame_preprocess_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "rtgs_frame_preprocess": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P,
+                                        _P, _P]),
+    "rtgs_compact_scratch_bytes": (C.c_size_t, [C.c_int32]),
+    "rtgs_sample_candidates": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -20,6 +20,8 @@ struct Scratch {
   float partials[MAX_BLOCKS * PSTRIDE];
   uint32_t ticket;                            // arrival counter of the residual kernel's workgroups
   uint32_t pad[15];                           // pad[0]: abort flag of the persistent track kernel
+  double sums[24 * 8 * PSTRIDE];              // persistent track: 8 rows of float64 totals per grid barrier
+  unsigned long long dbg[96];                 // RTGS_ICP_DEBUG_TIMING=1: wall-clock stamps of workgroup 0 (5 per barrier)
 };
 
 __device__ __forceinline__ uint32_t enc_f(float f) {
@@ -152,6 +154,26 @@ __device__ __forceinline__ void block_write_partials(float (&acc)[NACC], float* 
     __hip_atomic_store(&partials[(size_t)blockIdx.x * PSTRIDE + k],
                        (s_part[k] + s_part[PSTRIDE + k]) + (s_part[2 * PSTRIDE + k] + s_part[3 * PSTRIDE + k]),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Persistent track: the workgroup's 28 sums go straight into a row of float64 totals with native f64 atomics - nobody
+// has to read 256 partial rows back.  Same-address atomics serialise at ~17 ns each, so the workgroups spread over 8
+// rows (32 adds per address instead of 256); readers add the 8 rows in a fixed order.  The order of the adds inside
+// a row varies from run to run at the 1e-16 level, which the float32 pose does not see.
+__device__ __forceinline__ void block_add_totals(float (&acc)[NACC], double* __restrict__ totals) {
+  __shared__ float s_part2[4 * PSTRIDE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    const float r = wave_sum63(acc[k]);
+    if (lane == 63) s_part2[wave * PSTRIDE + k] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    const int k = threadIdx.x;
+    const float v = (s_part2[k] + s_part2[PSTRIDE + k]) + (s_part2[2 * PSTRIDE + k] + s_part2[3 * PSTRIDE + k]);
+    if (v != 0.f) unsafeAtomicAdd(&totals[k], (double)v);
   }
 }
 
@@ -498,8 +520,8 @@ __global__ void __launch_bounds__(256) icp_p2p_kernel(const float* __restrict__ 
 //   EVERY workgroup sums all rows (float64, same order everywhere) and takes the same Gauss-Newton step on its own
 //   LDS copy of the pose.
 // One global round trip per iteration instead of three (fan-in, solve, fan-out), no launch gaps, and nothing for the
-// other stream's kernels to squeeze between.  Rows are double-buffered by iteration parity (a fast workgroup may write
-// iteration e+1 while a slow one still reads e).  The spin is bounded: a workgroup that waits too long raises an abort
+// other stream's kernels to squeeze between.  The sums of an iteration meet in a row of float64 totals (native f64
+// atomics; a fresh row per barrier, zeroed by the host).  The spin is bounded: a workgroup that waits too long raises an abort
 // flag and everybody leaves (stats[3] = 1; the host reports it) - a scheduling pathology must not hang the device.
 struct TrackLevel {
   const float *vs, *ns, *vt, *nt;
@@ -513,9 +535,10 @@ struct TrackArgs {
   float dist_thr, cos_thr, damping;
   float* pose;
   float* stats;
-  float* partials;
+  double* sums;                // [barriers][8][PSTRIDE], zeroed by the host
   uint32_t* ticket;
   uint32_t* abort_flag;
+  unsigned long long* dbg;     // nullptr = no timing stamps
 };
 
 __device__ __forceinline__ bool grid_arrive_wait(uint32_t* ticket, uint32_t target, uint32_t* abort_flag, float* stats) {
@@ -528,7 +551,7 @@ __device__ __forceinline__ bool grid_arrive_wait(uint32_t* ticket, uint32_t targ
     for (int spin = 0; spin < (1 << 22); ++spin) {
       if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
       if ((spin & 63) == 63 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
     }
     if (!ok) {
       __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -540,10 +563,16 @@ __device__ __forceinline__ bool grid_arrive_wait(uint32_t* ticket, uint32_t targ
   return s_ok != 0;
 }
 
+__device__ __forceinline__ double load_totals(const double* totals, int k) {
+  double t[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) t[r] = __hip_atomic_load(&totals[r * PSTRIDE + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+}
+
 __global__ void __launch_bounds__(256) icp_track_kernel(TrackArgs a) {
   __shared__ float s_pose[16];
   __shared__ float s_stat[4];
-  __shared__ double s_sum[32 * PSTRIDE];
   __shared__ double s_tot[PSTRIDE];
   const int G = (int)gridDim.x;
   if (threadIdx.x < 16) s_pose[threadIdx.x] = a.pose[threadIdx.x];
@@ -556,21 +585,28 @@ __global__ void __launch_bounds__(256) icp_track_kernel(TrackArgs a) {
     const int n = L.H * L.W;
     const float inv = 1.f / ((float)L.H * (float)L.W);
     for (int it = 0; it < L.iters; ++it) {
+      const bool stamp = a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && epoch < 19;
+      if (stamp) a.dbg[5 * epoch] = wall_clock64();
       const LevelGeom g = make_geom(s_pose, a.K, L.ds, L.H, L.W, a.dist_thr, a.cos_thr);
 #pragma unroll
       for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
       accumulate_range(g, L.vs, L.ns, L.vt, L.nt, n, (int)(blockIdx.x * 256 + threadIdx.x), G * 256, acc);
-      float* rows = a.partials + (size_t)(epoch & 1u) * G * PSTRIDE;
-      block_write_partials(acc, rows);
+      double* totals = a.sums + (size_t)epoch * 8 * PSTRIDE;
+      if (stamp) a.dbg[5 * epoch + 1] = wall_clock64();
+      block_add_totals(acc, totals + (blockIdx.x & 7u) * PSTRIDE);
       ++epoch;
       if (!grid_arrive_wait(a.ticket, epoch * (uint32_t)G, a.abort_flag, a.stats)) return;
-      sum_partials(rows, G, s_sum, s_tot);
+      if (stamp) a.dbg[5 * epoch - 3] = wall_clock64();
+      if (threadIdx.x < NACC) s_tot[threadIdx.x] = load_totals(totals, threadIdx.x);
+      __syncthreads();
+      if (stamp) a.dbg[5 * epoch - 2] = wall_clock64();
       if (threadIdx.x == 0) {
         double S[NACC];
 #pragma unroll
         for (int c = 0; c < NACC; ++c) S[c] = s_tot[c];
         s_stat[0] = (float)(S[27] * (double)inv);                // valid_ratio of this iteration (icp.py:46-47)
         if (!gn_update(S, a.damping, s_pose)) s_stat[2] += 1.f;
+        if (stamp) a.dbg[5 * epoch - 1] = wall_clock64();
       }
       __syncthreads();
     }
@@ -593,16 +629,15 @@ __global__ void __launch_bounds__(256) icp_track_kernel(TrackArgs a) {
       const float lp = (px - F.vt[j]) * F.nt[j] + (py - F.vt[j + 1]) * F.nt[j + 1] + (pz - F.vt[j + 2]) * F.nt[j + 2];
       acc[0] += lp * lp;
     }
-    float* rows = a.partials + (size_t)(epoch & 1u) * G * PSTRIDE;
-    block_write_partials(acc, rows);
+    double* totals = a.sums + (size_t)epoch * 8 * PSTRIDE;
+    block_add_totals(acc, totals + (blockIdx.x & 7u) * PSTRIDE);
     ++epoch;
     if (!grid_arrive_wait(a.ticket, epoch * (uint32_t)G, a.abort_flag, a.stats)) return;
     if (blockIdx.x != 0) return;
-    sum_partials(rows, G, s_sum, s_tot);
     if (threadIdx.x < 12) a.pose[threadIdx.x] = s_pose[threadIdx.x];
     if (threadIdx.x == 0) {
       a.stats[0] = s_stat[0];
-      a.stats[1] = (float)(s_tot[0] * (1.0 / (double)n));
+      a.stats[1] = (float)(load_totals(totals, 0) * (1.0 / (double)n));
       a.stats[2] = s_stat[2];
     }
   }
@@ -705,13 +740,19 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
     ICP_TRY(hipGetDevice(&dev));
     ICP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     int G = cus > 0 ? cus : 64;
-    if (G > MAX_BLOCKS / 2) G = MAX_BLOCKS / 2;                             // two row buffers share `partials`
+    if (G > MAX_BLOCKS) G = MAX_BLOCKS;
     TrackArgs a{};
     for (int l = 0; l < n_levels; ++l)
       a.lv[l] = TrackLevel{lv[l].vertex_src, lv[l].normal_src, lv[l].vertex_tgt, lv[l].normal_tgt, lv[l].H, lv[l].W,
                            lv[l].iters, lv[l].downscale};
     a.n_levels = n_levels; a.K = K; a.dist_thr = dist_thr; a.cos_thr = cos_thr; a.damping = damping;
-    a.pose = pose; a.stats = stats; a.partials = sc->partials; a.ticket = &sc->ticket; a.abort_flag = &sc->pad[0];
+    a.pose = pose; a.stats = stats; a.sums = sc->sums; a.ticket = &sc->ticket; a.abort_flag = &sc->pad[0];
+    int n_barriers = 1;
+    for (int l = 0; l < n_levels; ++l) n_barriers += lv[l].iters;
+    if (n_barriers > 24) return -1;                                        // rows of Scratch::sums
+    ICP_TRY(hipMemsetAsync(sc->sums, 0, (size_t)n_barriers * 8 * PSTRIDE * sizeof(double), st));
+    static const bool dbg_timing = [] { const char* e = getenv("RTGS_ICP_DEBUG_TIMING"); return e && atoi(e) != 0; }();
+    a.dbg = dbg_timing ? sc->dbg : nullptr;
     hipLaunchKernelGGL(icp_track_kernel, dim3(G), dim3(256), 0, st, a);
     ICP_TRY(hipGetLastError());
     return 0;

@@ -1,0 +1,629 @@
+// gfx950 kernels + C ABI of the SLAM-side ops around the hot path (include/rtgs_slam.h): tile-mask producers, the
+// 3-nearest-neighbour search behind simple_knn.distCUDA2, the per-Gaussian error accumulation behind
+// cuda_utils.accumulate_gaussian_error, and the frame preprocessing of Tracker.map_preprocess.
+// Compiled with -ffp-contract=off: the float32 op order of distances / stencils follows the reference's torch code
+// (oracle/slam_ops_oracle.py restates it; tests compare bit for bit where torch's rounding is reproducible).
+#include "../../include/rtgs_slam.h"
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <float.h>
+#include <math.h>
+
+namespace rtgs_slam {
+
+__device__ __forceinline__ uint32_t enc_f(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);        // monotone: a < b <=> enc(a) < enc(b)
+}
+__device__ __forceinline__ float dec_f(uint32_t e) {
+  return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ tile masks
+// one workgroup per tile; KIND 0 = uint8 mask, 1 = float32, 2 = float32 T_map (pixel on iff T != 1; also writes the mask)
+template <int KIND>
+__global__ void __launch_bounds__(256) tile_sum_kernel(const void* __restrict__ src, int H, int W, int stride, int gx,
+                                                       float* __restrict__ tile_sum, uint8_t* __restrict__ mask_out) {
+  const int tx = blockIdx.x % gx, ty = blockIdx.x / gx;
+  float acc = 0.f;
+  for (int q = threadIdx.x; q < stride * stride; q += 256) {
+    const int x = tx * stride + q % stride, y = ty * stride + q / stride;
+    if (x < W && y < H) {
+      const size_t i = (size_t)y * W + x;
+      if constexpr (KIND == 0) acc += reinterpret_cast<const uint8_t*>(src)[i] ? 1.f : 0.f;
+      if constexpr (KIND == 1) acc += reinterpret_cast<const float*>(src)[i];
+      if constexpr (KIND == 2) {
+        const bool on = reinterpret_cast<const float*>(src)[i] != 1.f;
+        mask_out[i] = on ? 1 : 0;
+        acc += on ? 1.f : 0.f;
+      }
+    }
+  }
+  __shared__ float s[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// mode 0: mean > ratio (transmission2tilemask); mode 1: any (pixelmask2tilemask).  Also the total of the sums.
+__global__ void __launch_bounds__(1024) tile_threshold_kernel(const float* __restrict__ tile_sum, int ntiles, float area,
+                                                              float ratio, int mode, int32_t* __restrict__ mask,
+                                                              uint32_t* __restrict__ count_out) {
+  float tot = 0.f;
+  for (int t = threadIdx.x; t < ntiles; t += 1024) {
+    const float s = tile_sum[t];
+    mask[t] = mode == 0 ? ((s / area) > ratio ? 1 : 0) : (s > 0.f ? 1 : 0);
+    tot += s;
+  }
+  if (!count_out) return;
+  __shared__ float sh[16];
+  tot = wave_sum(tot);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    count_out[0] = (uint32_t)(t + 0.5f);                    // sums of 0/1 pixels: exact integers in float32 up to 2^24
+  }
+}
+
+// top-k tiles by mean value: 4-pass MSB radix select of the k-th largest key in LDS, then ties in index order
+constexpr int TOPK_MAX = 16384;
+__global__ void __launch_bounds__(1024) tile_topk_kernel(const float* __restrict__ tile_sum, int ntiles, float area, int k,
+                                                         int32_t* __restrict__ mask) {
+  __shared__ uint32_t s_key[TOPK_MAX];
+  __shared__ uint32_t s_hist[256];
+  __shared__ uint32_t s_scan[1024];
+  __shared__ uint32_t s_prefix, s_k;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < ntiles; t += 1024) s_key[t] = enc_f(tile_sum[t] / area);
+  if (tid == 0) { s_prefix = 0u; s_k = (uint32_t)k; }
+  __syncthreads();
+  if (k <= 0) { for (int t = tid; t < ntiles; t += 1024) mask[t] = 0; return; }
+  if (k >= ntiles) { for (int t = tid; t < ntiles; t += 1024) mask[t] = 1; return; }
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = 8 * pass;
+    if (tid < 256) s_hist[tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = s_prefix, himask = pass == 3 ? 0u : (0xffffffffu << (shift + 8));
+    for (int t = tid; t < ntiles; t += 1024) {
+      const uint32_t key = s_key[t];
+      if ((key & himask) == prefix) atomicAdd(&s_hist[(key >> shift) & 0xffu], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {                                          // walk the digits from the top until k keys are covered
+      uint32_t need = s_k, d = 255;
+      for (;; --d) {
+        const uint32_t c = s_hist[d];
+        if (c >= need) break;
+        need -= c;
+        if (d == 0) break;
+      }
+      s_k = need;
+      s_prefix = prefix | (d << shift);
+    }
+    __syncthreads();
+  }
+  const uint32_t kth = s_prefix;                             // key of the k-th largest value; s_k = how many ties to take
+  const uint32_t take = s_k;
+  const int per = (ntiles + 1023) / 1024;
+  const int lo = min(ntiles, tid * per), hi = min(ntiles, lo + per);
+  uint32_t ties = 0;
+  for (int t = lo; t < hi; ++t) ties += s_key[t] == kth ? 1u : 0u;
+  s_scan[tid] = ties;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t a = tid >= off ? s_scan[tid - off] : 0u;
+    __syncthreads();
+    s_scan[tid] += a;
+    __syncthreads();
+  }
+  uint32_t rank = s_scan[tid] - ties;
+  for (int t = lo; t < hi; ++t) {
+    const uint32_t key = s_key[t];
+    int on = key > kth ? 1 : 0;
+    if (key == kth) { on = rank < take ? 1 : 0; ++rank; }
+    mask[t] = on;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 3-NN search
+constexpr int KNN_BOX = 1024;
+
+__global__ void __launch_bounds__(256) knn_bbox_kernel(const float* __restrict__ pts, int N, uint32_t* __restrict__ bbox) {
+  uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const uint32_t e = enc_f(pts[(size_t)i * 3 + c]); mn[c] = min(mn[c], e); mx[c] = max(mx[c], e); }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[c] = min(mn[c], (uint32_t)__shfl_xor((int)mn[c], off));
+      mx[c] = max(mx[c], (uint32_t)__shfl_xor((int)mx[c], off));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&bbox[c], mn[c]); atomicMax(&bbox[3 + c], mx[c]); }
+  }
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t x) {   // 10 bits -> every third bit
+  x = (x | (x << 16)) & 0x030000FFu;
+  x = (x | (x << 8)) & 0x0300F00Fu;
+  x = (x | (x << 4)) & 0x030C30C3u;
+  x = (x | (x << 2)) & 0x09249249u;
+  return x;
+}
+__global__ void __launch_bounds__(256) knn_morton_kernel(const float* __restrict__ pts, int N, const uint32_t* __restrict__ bbox,
+                                                         uint32_t* __restrict__ codes, uint32_t* __restrict__ order) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  uint32_t q[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float lo = dec_f(bbox[c]), hi = dec_f(bbox[3 + c]);
+    const float ext = hi - lo;
+    const float t = ext > 0.f ? (pts[(size_t)i * 3 + c] - lo) / ext : 0.f;
+    q[c] = (uint32_t)fminf(1023.f, fmaxf(0.f, t * 1023.f));
+  }
+  codes[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+  order[i] = (uint32_t)i;
+}
+
+// points gathered into Morton order as float4 (w unused) + the AABB of every run of KNN_BOX sorted points
+__global__ void __launch_bounds__(256) knn_gather_kernel(const float* __restrict__ pts, int N, const uint32_t* __restrict__ order,
+                                                         float4* __restrict__ sorted, float* __restrict__ boxes) {
+  const int b = blockIdx.x;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int q = threadIdx.x; q < KNN_BOX; q += 256) {
+    const int i = b * KNN_BOX + q;
+    if (i < N) {
+      const uint32_t o = order[i];
+      const float x = pts[(size_t)o * 3], y = pts[(size_t)o * 3 + 1], z = pts[(size_t)o * 3 + 2];
+      sorted[i] = make_float4(x, y, z, 0.f);
+      mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+      mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+    }
+  }
+  __shared__ float s[4][6];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], off)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off)); }
+    if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6][c] = mn[c]; s[threadIdx.x >> 6][3 + c] = mx[c]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int c = threadIdx.x;
+    float v = s[0][c];
+    for (int w = 1; w < 4; ++w) v = c < 3 ? fminf(v, s[w][c]) : fmaxf(v, s[w][c]);
+    boxes[b * 6 + c] = v;
+  }
+}
+
+__device__ __forceinline__ void knn_insert(float d, int j, float (&bd)[3], int (&bj)[3]) {
+  if (d < bd[2]) {
+    if (d < bd[1]) {
+      bd[2] = bd[1]; bj[2] = bj[1];
+      if (d < bd[0]) { bd[1] = bd[0]; bj[1] = bj[0]; bd[0] = d; bj[0] = j; }
+      else { bd[1] = d; bj[1] = j; }
+    } else { bd[2] = d; bj[2] = j; }
+  }
+}
+__device__ __forceinline__ float dist2(const float4 a, const float4 b) {
+  const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+// one lane per point, in Morton order (the lanes of a wave are neighbours in space, so they prune the same boxes)
+__global__ void __launch_bounds__(256) knn_search_kernel(const float4* __restrict__ sorted, int N, const uint32_t* __restrict__ order,
+                                                         const float* __restrict__ boxes, int nboxes,
+                                                         float* __restrict__ mean_dist2, int32_t* __restrict__ idx,
+                                                         float* __restrict__ dist_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < N;
+  const float4 p = live ? sorted[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float bd[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  int bj[3] = {-1, -1, -1};
+  if (live) {
+    // start from the neighbours in Morton order: a tight bound before any box is opened
+    for (int j = max(0, i - 3); j <= min(N - 1, i + 3); ++j)
+      if (j != i) knn_insert(dist2(p, sorted[j]), j, bd, bj);
+  }
+  for (int b = 0; b < nboxes; ++b) {
+    const float* bx = boxes + b * 6;                            // wave-uniform: scalar loads
+    const float ex = fmaxf(0.f, fmaxf(bx[0] - p.x, p.x - bx[3]));
+    const float ey = fmaxf(0.f, fmaxf(bx[1] - p.y, p.y - bx[4]));
+    const float ez = fmaxf(0.f, fmaxf(bx[2] - p.z, p.z - bx[5]));
+    // a lower bound of the distance to anything in the box, with slack for its rounding: never prunes a true neighbour
+    const float lower = ((ex * ex + ey * ey) + ez * ez) * 0.9999f;
+    const bool open = live && lower < bd[2];
+    if (__builtin_amdgcn_ballot_w64(open) == 0ull) continue;
+    if (open) {
+      const int j0 = b * KNN_BOX, j1 = min(N, j0 + KNN_BOX);
+      for (int j = j0; j < j1; ++j) {
+        if (j == i) continue;
+        const int already = (j == bj[0]) | (j == bj[1]) | (j == bj[2]);    // the +-3 seeds
+        if (!already) knn_insert(dist2(p, sorted[j]), j, bd, bj);
+      }
+    }
+  }
+  if (!live) return;
+  const uint32_t o = order[i];
+  mean_dist2[o] = ((bd[0] + bd[1]) + bd[2]) / 3.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    idx[(size_t)o * 3 + k] = bj[k] >= 0 ? (int32_t)order[bj[k]] : -1;
+    if (dist_out) dist_out[(size_t)o * 3 + k] = bd[k];
+  }
+}
+
+struct KnnLayout {
+  size_t bbox, codes, codes_sorted, order_in, order, sorted, boxes, cub, total, cub_bytes;
+};
+static KnnLayout knn_layout(int N) {
+  KnnLayout L{};
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t n = (size_t)(N > 0 ? N : 1);
+  size_t off = 0;
+  L.bbox = off; off = al(off + 6 * sizeof(uint32_t));
+  L.codes = off; off = al(off + n * 4);
+  L.codes_sorted = off; off = al(off + n * 4);
+  L.order_in = off; off = al(off + n * 4);
+  L.order = off; off = al(off + n * 4);
+  L.sorted = off; off = al(off + n * sizeof(float4));
+  L.boxes = off; off = al(off + ((n + KNN_BOX - 1) / KNN_BOX) * 6 * sizeof(float));
+  size_t tb = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                           (uint32_t*)nullptr, (int)n, 0, 30);
+  L.cub_bytes = tb;
+  L.cub = off; off = al(off + tb);
+  L.total = off;
+  return L;
+}
+
+// ------------------------------------------------------------------------------------------------ error accumulation
+// Lanes of a wave that point at the same Gaussian are summed first (an opaque disc owns runs of neighbouring pixels), so
+// a group costs one set of atomics instead of one per pixel.
+__global__ void __launch_bounds__(256) accumulate_error_kernel(int n, const float* __restrict__ ce, const float* __restrict__ de,
+                                                               const float* __restrict__ ne, const int32_t* __restrict__ ci,
+                                                               const int32_t* __restrict__ di, float thr_c, float thr_d,
+                                                               float thr_n, float* __restrict__ g_c, float* __restrict__ g_d,
+                                                               float* __restrict__ g_n, int32_t* __restrict__ outl,
+                                                               float* __restrict__ cnt_c, float* __restrict__ cnt_d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool live = i < n;
+  const int ic = live ? ci[i] : -1, id = live ? di[i] : -1;
+  const float ec = live ? ce[i] : 0.f, ed = live ? de[i] : 0.f, en = live ? ne[i] : 0.f;
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(ic >= 0);
+  while (todo) {
+    const int g = __builtin_amdgcn_readlane(ic, __ffsll((long long)todo) - 1);
+    const bool mine = ic == g;
+    const float s = wave_sum(mine ? ec : 0.f), c = wave_sum(mine ? 1.f : 0.f), o = wave_sum((mine && ec > thr_c) ? 1.f : 0.f);
+    if (lane == 0) { unsafeAtomicAdd(&g_c[g], s); unsafeAtomicAdd(&cnt_c[g], c); if (o > 0.f) atomicAdd(&outl[g], (int)o); }
+    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+  }
+  todo = __builtin_amdgcn_ballot_w64(id >= 0);
+  while (todo) {
+    const int g = __builtin_amdgcn_readlane(id, __ffsll((long long)todo) - 1);
+    const bool mine = id == g;
+    const float s = wave_sum(mine ? ed : 0.f), sn = wave_sum(mine ? en : 0.f), c = wave_sum(mine ? 1.f : 0.f);
+    const float o = wave_sum(mine ? ((ed > thr_d ? 1.f : 0.f) + (en > thr_n ? 1.f : 0.f)) : 0.f);
+    if (lane == 0) {
+      unsafeAtomicAdd(&g_d[g], s); unsafeAtomicAdd(&g_n[g], sn); unsafeAtomicAdd(&cnt_d[g], c);
+      if (o > 0.f) atomicAdd(&outl[g], (int)o);
+    }
+    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+  }
+}
+__global__ void __launch_bounds__(256) error_mean_kernel(int P, float* __restrict__ g_c, float* __restrict__ g_d,
+                                                         float* __restrict__ g_n, const float* __restrict__ cnt_c,
+                                                         const float* __restrict__ cnt_d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const float cc = fmaxf(cnt_c[i], 1.f), cd = fmaxf(cnt_d[i], 1.f);
+  g_c[i] = g_c[i] / cc; g_d[i] = g_d[i] / cd; g_n[i] = g_n[i] / cd;
+}
+
+// ------------------------------------------------------------------------------------------------ frame preprocessing
+constexpr int BF_MAXR = 8;
+__global__ void __launch_bounds__(256) bilateral_kernel(const float* __restrict__ depth, int H, int W, int radius,
+                                                        float inv2ss, float two_sc2, float* __restrict__ out) {
+  __shared__ float s_t[(16 + 2 * BF_MAXR) * (16 + 2 * BF_MAXR)];
+  const int tw = 16 + 2 * radius;
+  const int x0 = blockIdx.x * 16 - radius, y0 = blockIdx.y * 16 - radius;
+  for (int q = threadIdx.x; q < tw * tw; q += 256) {
+    const int x = x0 + q % tw, y = y0 + q / tw;
+    s_t[q] = (x >= 0 && x < W && y >= 0 && y < H) ? depth[(size_t)y * W + x] : 0.f;      // zero padding
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const int x = blockIdx.x * 16 + lx, y = blockIdx.y * 16 + ly;
+  if (x >= W || y >= H) return;
+  const float d = s_t[(ly + radius) * tw + lx + radius];
+  float wsum = 0.f, psum = 0.f;
+  for (int i = -radius; i <= radius; ++i)
+    for (int j = -radius; j <= radius; ++j) {
+      if (i * i + j * j > radius * radius) continue;
+      const float tap = s_t[(ly + radius + i) * tw + lx + radius + j];
+      const float sw = -(float)(i * i + j * j) * inv2ss;
+      const float df = d - tap;
+      const float cw = -(df * df) / two_sc2;
+      const float w = tap != 0.f ? expf(sw + cw) : 0.f;
+      wsum += w;
+      psum += w * tap;
+    }
+  out[(size_t)y * W + x] = wsum == 0.f ? 0.f : psum / wsum;
+}
+
+// range mask + back-projection (SLAM/utils.py:65-75) + min / max of the masked depth (for compute_normal_map's mask)
+__global__ void __launch_bounds__(256) frame_vertex_kernel(const float* __restrict__ depth, int H, int W, const float* __restrict__ K,
+                                                           float dmin, float dmax, float* __restrict__ vertex,
+                                                           uint32_t* __restrict__ mm) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t emin = 0xffffffffu, emax = 0u;
+  if (i < H * W) {
+    float d = depth[i];
+    if (!((d > dmin) && (d < dmax))) d = 0.f;
+    const int x = i % W, y = i / W;
+    vertex[(size_t)i * 3] = (((float)x - K[2]) / K[0]) * d;
+    vertex[(size_t)i * 3 + 1] = (((float)y - K[5]) / K[4]) * d;
+    vertex[(size_t)i * 3 + 2] = d;
+    emin = emax = enc_f(d);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    emin = min(emin, (uint32_t)__shfl_xor((int)emin, off));
+    emax = max(emax, (uint32_t)__shfl_xor((int)emax, off));
+  }
+  __shared__ uint32_t s[2][4];
+  if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = emin; s[1][threadIdx.x >> 6] = emax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMin(&mm[0], min(min(s[0][0], s[0][1]), min(s[0][2], s[0][3])));
+    atomicMax(&mm[1], max(max(s[1][0], s[1][1]), max(s[1][2], s[1][3])));
+  }
+}
+
+// Sobel normal (replicate pad, conv2d tap order, torch.cross / torch.norm rounding - see icp.hip), |cos| to the viewing
+// ray (SLAM/utils.py:124-139), invalid-confidence mask, and the four zeroed output maps (tracker.py:121-131)
+__global__ void __launch_bounds__(256) frame_normal_kernel(const float* __restrict__ V, int H, int W, const float* __restrict__ K,
+                                                           const uint32_t* __restrict__ mm, float conf_thr,
+                                                           float* __restrict__ depth_out, float* __restrict__ vertex_out,
+                                                           float* __restrict__ normal_out, float* __restrict__ conf_out,
+                                                           uint8_t* __restrict__ bad_out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= H * W) return;
+  const int y = idx / W, x = idx % W;
+  const int ym = max(y - 1, 0), yp = min(y + 1, H - 1), xm = max(x - 1, 0), xp = min(x + 1, W - 1);
+  float gx[3], gy[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a00 = V[((size_t)ym * W + xm) * 3 + c], a01 = V[((size_t)ym * W + x) * 3 + c], a02 = V[((size_t)ym * W + xp) * 3 + c];
+    const float a10 = V[((size_t)y * W + xm) * 3 + c], a12 = V[((size_t)y * W + xp) * 3 + c];
+    const float a20 = V[((size_t)yp * W + xm) * 3 + c], a21 = V[((size_t)yp * W + x) * 3 + c], a22 = V[((size_t)yp * W + xp) * 3 + c];
+    gx[c] = -a00 + a02 - 2.f * a10 + 2.f * a12 - a20 + a22;
+    gy[c] = -a00 - 2.f * a01 - a02 + a20 + 2.f * a21 + a22;
+  }
+  float nx = __fmaf_rn(gy[1], gx[2], -(gy[2] * gx[1]));
+  float ny = __fmaf_rn(gy[2], gx[0], -(gy[0] * gx[2]));
+  float nz = __fmaf_rn(gy[0], gx[1], -(gy[1] * gx[0]));
+  const float mag = sqrtf(__fmaf_rn(nz, nz, __fmaf_rn(ny, ny, nx * nx))) + 1e-8f;
+  nx /= mag; ny /= mag; nz /= mag;
+  const float vx = V[(size_t)idx * 3], vy = V[(size_t)idx * 3 + 1], d = V[(size_t)idx * 3 + 2];
+  if (d <= dec_f(mm[0]) || d >= dec_f(mm[1])) { nx = 0.f; ny = 0.f; nz = 0.f; }
+  // viewing ray, normalised with +1e-8 (compute_confidence_map), then F.cosine_similarity(eps = 1e-8)
+  float rx = ((float)x - K[2]) / K[0], ry = ((float)y - K[5]) / K[4], rz = 1.f;
+  const float rm = sqrtf(__fmaf_rn(rz, rz, __fmaf_rn(ry, ry, rx * rx))) + 1e-8f;
+  rx /= rm; ry /= rm; rz /= rm;
+  const float na = fmaxf(sqrtf(__fmaf_rn(nz, nz, __fmaf_rn(ny, ny, nx * nx))), 1e-8f);
+  const float nb = fmaxf(sqrtf(__fmaf_rn(rz, rz, __fmaf_rn(ry, ry, rx * rx))), 1e-8f);
+  const float cs = ((nx / na) * (rx / nb) + (ny / na) * (ry / nb)) + (nz / na) * (rz / nb);
+  const float conf = fabsf(cs);
+  const bool bad = (nx == 0.f && ny == 0.f && nz == 0.f) || (conf < conf_thr);
+  depth_out[idx] = bad ? 0.f : d;
+  vertex_out[(size_t)idx * 3] = bad ? 0.f : vx; vertex_out[(size_t)idx * 3 + 1] = bad ? 0.f : vy; vertex_out[(size_t)idx * 3 + 2] = bad ? 0.f : d;
+  normal_out[(size_t)idx * 3] = bad ? 0.f : nx; normal_out[(size_t)idx * 3 + 1] = bad ? 0.f : ny; normal_out[(size_t)idx * 3 + 2] = bad ? 0.f : nz;
+  conf_out[idx] = bad ? 0.f : conf;
+  bad_out[idx] = bad ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) sample_flags_kernel(const float* __restrict__ normal, const uint8_t* __restrict__ select,
+                                                           int n, uint8_t* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float s = (normal[(size_t)i * 3] + normal[(size_t)i * 3 + 1]) + normal[(size_t)i * 3 + 2];
+  flags[i] = ((!select || select[i] != 0) && s != 0.f) ? 1 : 0;
+}
+
+static inline int grid1(long long n) { return (int)((n + 255) / 256); }
+
+}  // namespace rtgs_slam
+
+using namespace rtgs_slam;
+
+#define SLAM_TRY(expr)                    \
+  do {                                    \
+    if ((expr) != hipSuccess) return -2;  \
+  } while (0)
+
+extern "C" {
+
+int rtgs_tile_sum(const void* src, int32_t src_kind, int32_t H, int32_t W, int32_t stride, float* tile_sum, void* stream) {
+  if (!src || !tile_sum || H <= 0 || W <= 0 || stride <= 0 || (src_kind != 0 && src_kind != 1)) return -1;
+  const int gx = (W + stride - 1) / stride, gy = (H + stride - 1) / stride;
+  hipStream_t st = (hipStream_t)stream;
+  if (src_kind == 0)
+    hipLaunchKernelGGL(tile_sum_kernel<0>, dim3(gx * gy), dim3(256), 0, st, src, H, W, stride, gx, tile_sum, (uint8_t*)nullptr);
+  else
+    hipLaunchKernelGGL(tile_sum_kernel<1>, dim3(gx * gy), dim3(256), 0, st, src, H, W, stride, gx, tile_sum, (uint8_t*)nullptr);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_transmission2tilemask(const uint8_t* pixelmask, int32_t H, int32_t W, int32_t stride, float ratio,
+                               int32_t* tile_mask, float* tile_sum_scratch, void* stream) {
+  if (!tile_mask || !tile_sum_scratch) return -1;
+  int rc = rtgs_tile_sum(pixelmask, 0, H, W, stride, tile_sum_scratch, stream);
+  if (rc) return rc;
+  const int nt = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
+  hipLaunchKernelGGL(tile_threshold_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)tile_sum_scratch, nt,
+                     (float)(stride * stride), ratio, 0, tile_mask, (uint32_t*)nullptr);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_pixelmask2tilemask(const uint8_t* pixelmask, int32_t H, int32_t W, int32_t stride, int32_t* tile_mask,
+                            float* tile_sum_scratch, void* stream) {
+  if (!tile_mask || !tile_sum_scratch) return -1;
+  int rc = rtgs_tile_sum(pixelmask, 0, H, W, stride, tile_sum_scratch, stream);
+  if (rc) return rc;
+  const int nt = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
+  hipLaunchKernelGGL(tile_threshold_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)tile_sum_scratch, nt,
+                     (float)(stride * stride), 0.f, 1, tile_mask, (uint32_t*)nullptr);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_colorerror2tilemask(const float* color_error, int32_t H, int32_t W, int32_t stride, float top_ratio,
+                             int32_t* tile_mask, float* tile_sum_scratch, void* stream) {
+  if (!tile_mask || !tile_sum_scratch) return -1;
+  const int nt = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
+  if (nt > TOPK_MAX) return -1;
+  int rc = rtgs_tile_sum(color_error, 1, H, W, stride, tile_sum_scratch, stream);
+  if (rc) return rc;
+  const int k = (int)((double)nt * (double)top_ratio);          // int(torch.numel(...) * top_ratio)
+  hipLaunchKernelGGL(tile_topk_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)tile_sum_scratch, nt,
+                     (float)(stride * stride), k, tile_mask);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_render_range(const float* T_map, int32_t H, int32_t W, float ratio, uint8_t* render_mask, int32_t* tile_mask,
+                      uint32_t* count_out, float* tile_sum_scratch, void* stream) {
+  if (!T_map || !render_mask || !tile_mask || !count_out || !tile_sum_scratch || H <= 0 || W <= 0) return -1;
+  const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(tile_sum_kernel<2>, dim3(gx * gy), dim3(256), 0, st, (const void*)T_map, H, W, 16, gx, tile_sum_scratch,
+                     render_mask);
+  hipLaunchKernelGGL(tile_threshold_kernel, dim3(1), dim3(1024), 0, st, (const float*)tile_sum_scratch, gx * gy, 256.f, ratio,
+                     0, tile_mask, count_out);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+size_t rtgs_knn3_scratch_bytes(int32_t N) { return knn_layout(N).total; }
+
+int rtgs_knn3(const float* points, int32_t N, float* mean_dist2, int32_t* idx, float* dist2_out, void* scratch, void* stream) {
+  if (N < 0 || (N > 0 && (!points || !mean_dist2 || !idx || !scratch))) return -1;
+  if (N == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const KnnLayout L = knn_layout(N);
+  char* s = (char*)scratch;
+  uint32_t* bbox = (uint32_t*)(s + L.bbox);
+  uint32_t* codes = (uint32_t*)(s + L.codes);
+  uint32_t* codes_sorted = (uint32_t*)(s + L.codes_sorted);
+  uint32_t* order_in = (uint32_t*)(s + L.order_in);
+  uint32_t* order = (uint32_t*)(s + L.order);
+  float4* sorted = (float4*)(s + L.sorted);
+  float* boxes = (float*)(s + L.boxes);
+  SLAM_TRY(hipMemsetAsync(bbox, 0xff, 3 * sizeof(uint32_t), st));
+  SLAM_TRY(hipMemsetAsync(bbox + 3, 0, 3 * sizeof(uint32_t), st));
+  int g = grid1(N);
+  hipLaunchKernelGGL(knn_bbox_kernel, dim3(g > 1024 ? 1024 : g), dim3(256), 0, st, points, N, bbox);
+  hipLaunchKernelGGL(knn_morton_kernel, dim3(g), dim3(256), 0, st, points, N, (const uint32_t*)bbox, codes, order_in);
+  size_t tb = L.cub_bytes;
+  SLAM_TRY(hipcub::DeviceRadixSort::SortPairs(s + L.cub, tb, codes, codes_sorted, order_in, order, N, 0, 30, st));
+  const int nboxes = (N + KNN_BOX - 1) / KNN_BOX;
+  hipLaunchKernelGGL(knn_gather_kernel, dim3(nboxes), dim3(256), 0, st, points, N, (const uint32_t*)order, sorted, boxes);
+  hipLaunchKernelGGL(knn_search_kernel, dim3(g), dim3(256), 0, st, (const float4*)sorted, N, (const uint32_t*)order,
+                     (const float*)boxes, nboxes, mean_dist2, idx, dist2_out);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_accumulate_error(int32_t H, int32_t W, int32_t P, const float* color_err, const float* depth_err,
+                          const float* normal_err, const int32_t* color_index, const int32_t* depth_index, float thr_c,
+                          float thr_d, float thr_n, int32_t mean, float* g_color, float* g_depth, float* g_normal,
+                          int32_t* outlier_count, float* scratch, void* stream) {
+  if (H <= 0 || W <= 0 || P < 0) return -1;
+  if (P == 0) return 0;
+  if (!color_err || !depth_err || !normal_err || !color_index || !depth_index || !g_color || !g_depth || !g_normal ||
+      !outlier_count || !scratch)
+    return -1;
+  hipStream_t st = (hipStream_t)stream;
+  SLAM_TRY(hipMemsetAsync(g_color, 0, (size_t)P * 4, st));
+  SLAM_TRY(hipMemsetAsync(g_depth, 0, (size_t)P * 4, st));
+  SLAM_TRY(hipMemsetAsync(g_normal, 0, (size_t)P * 4, st));
+  SLAM_TRY(hipMemsetAsync(outlier_count, 0, (size_t)P * 4, st));
+  SLAM_TRY(hipMemsetAsync(scratch, 0, (size_t)P * 8, st));
+  const int n = H * W;
+  hipLaunchKernelGGL(accumulate_error_kernel, dim3(grid1(n)), dim3(256), 0, st, n, color_err, depth_err, normal_err,
+                     color_index, depth_index, thr_c, thr_d, thr_n, g_color, g_depth, g_normal, outlier_count, scratch,
+                     scratch + P);
+  if (mean)
+    hipLaunchKernelGGL(error_mean_kernel, dim3(grid1(P)), dim3(256), 0, st, P, g_color, g_depth, g_normal,
+                       (const float*)scratch, (const float*)(scratch + P));
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_bilateral_filter(const float* depth, int32_t H, int32_t W, int32_t radius, float sigma_color, float sigma_space,
+                          float* out, void* stream) {
+  if (!depth || !out || H <= 0 || W <= 0 || radius < 0 || radius > BF_MAXR || !(sigma_color > 0.f) || !(sigma_space > 0.f))
+    return -1;
+  const float inv2ss = (float)(1.0 / (2.0 * (double)sigma_space * (double)sigma_space));
+  const float two_sc2 = (float)(2.0 * (double)sigma_color * (double)sigma_color);
+  hipLaunchKernelGGL(bilateral_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, depth, H, W,
+                     radius, inv2ss, two_sc2, out);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+size_t rtgs_frame_preprocess_scratch_bytes(int32_t H, int32_t W) { return (size_t)H * W * 3 * sizeof(float) + 256; }
+
+int rtgs_frame_preprocess(const float* depth_in, int32_t H, int32_t W, const float* K, float min_depth, float max_depth,
+                          float invalid_confidence_thresh, float* depth_out, float* vertex_out, float* normal_out,
+                          float* conf_out, uint8_t* bad_out, void* scratch, void* stream) {
+  if (!depth_in || !K || !depth_out || !vertex_out || !normal_out || !conf_out || !bad_out || !scratch || H <= 0 || W <= 0)
+    return -1;
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* mm = (uint32_t*)scratch;
+  float* V = (float*)((char*)scratch + 256);
+  SLAM_TRY(hipMemsetAsync(mm, 0xff, sizeof(uint32_t), st));
+  SLAM_TRY(hipMemsetAsync(mm + 1, 0, sizeof(uint32_t), st));
+  const int n = H * W;
+  hipLaunchKernelGGL(frame_vertex_kernel, dim3(grid1(n)), dim3(256), 0, st, depth_in, H, W, K, min_depth, max_depth, V, mm);
+  hipLaunchKernelGGL(frame_normal_kernel, dim3(grid1(n)), dim3(256), 0, st, (const float*)V, H, W, K, (const uint32_t*)mm,
+                     invalid_confidence_thresh, depth_out, vertex_out, normal_out, conf_out, bad_out);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+size_t rtgs_compact_scratch_bytes(int32_t n) {
+  size_t tb = 0;
+  (void)hipcub::DeviceSelect::Flagged(nullptr, tb, hipcub::CountingInputIterator<int32_t>(0), (const uint8_t*)nullptr,
+                                      (int32_t*)nullptr, (int32_t*)nullptr, n > 0 ? n : 1);
+  return tb + 256;
+}
+
+int rtgs_sample_candidates(const float* normal_map, const uint8_t* select_mask, int32_t H, int32_t W, int32_t* indices_out,
+                           int32_t* count_out, uint8_t* flags_scratch, void* scratch, void* stream) {
+  if (!normal_map || !indices_out || !count_out || !flags_scratch || !scratch || H <= 0 || W <= 0) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const int n = H * W;
+  hipLaunchKernelGGL(sample_flags_kernel, dim3(grid1(n)), dim3(256), 0, st, normal_map, select_mask, n, flags_scratch);
+  size_t tb = rtgs_compact_scratch_bytes(n) - 256;
+  SLAM_TRY(hipcub::DeviceSelect::Flagged(scratch, tb, hipcub::CountingInputIterator<int32_t>(0), (const uint8_t*)flags_scratch,
+                                         indices_out, count_out, n, st));
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+"""Host side of the SLAM-side ops around the hot path (include/rtgs_slam.h), under the reference's own function names
+and signatures so that its callers bind unchanged:
+
+    pixelmask2tilemask / transmission2tilemask / colorerror2tilemask      SLAM/utils.py:681-734
+    render_range                                                           mapper.py:471-508 (T_map -> masks, fused)
+    distCUDA2                (also importable as simple_knn._C.distCUDA2)   gaussian_pointcloud.py:3, 376
+    accumulate_gaussian_error (also cuda_utils._C.accumulate_gaussian_error) mapper.py:15, 541-565
+    bilateralFilter_torch / frame_preprocess / sample_pixels               SLAM/utils.py:550-589, tracker.py:104-131,
+                                                                           SLAM/utils.py:141-183
+torch supplies device memory and the current HIP stream; there is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _dev(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("rtg_slam_amd.slam_ops: tensors must live on a HIP device; this build has no CPU path.")
+    return t.device
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _u8(mask: torch.Tensor) -> torch.Tensor:
+    return (mask != 0).to(torch.uint8).contiguous() if mask.dtype != torch.uint8 else mask.contiguous()
+
+
+def _grid(H, W, stride):
+    return (H + stride - 1) // stride, (W + stride - 1) // stride
+
+
+def pixelmask2tilemask(pixelmask: torch.Tensor, stride: int = 16) -> torch.Tensor:
+    lib, dev = _lib.load(), _dev(pixelmask)
+    H, W = int(pixelmask.shape[0]), int(pixelmask.shape[1])
+    gy, gx = _grid(H, W, stride)
+    out = torch.empty(gy, gx, dtype=torch.int32, device=dev)
+    tmp = torch.empty(gy * gx, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_pixelmask2tilemask(_p(_u8(pixelmask)), H, W, int(stride), _p(out), _p(tmp), _stream(dev))
+    _lib.check(rc, "rtgs_pixelmask2tilemask")
+    return out
+
+
+def transmission2tilemask(pixelmask: torch.Tensor, stride: int = 16, tile_mask_ratio: float = 0.5) -> torch.Tensor:
+    lib, dev = _lib.load(), _dev(pixelmask)
+    H, W = int(pixelmask.shape[0]), int(pixelmask.shape[1])
+    gy, gx = _grid(H, W, stride)
+    out = torch.empty(gy, gx, dtype=torch.int32, device=dev)
+    tmp = torch.empty(gy * gx, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_transmission2tilemask(_p(_u8(pixelmask)), H, W, int(stride), float(tile_mask_ratio), _p(out), _p(tmp),
+                                            _stream(dev))
+    _lib.check(rc, "rtgs_transmission2tilemask")
+    return out
+
+
+def colorerror2tilemask(color_error: torch.Tensor, stride: int = 16, top_ratio: float = 0.4) -> torch.Tensor:
+    lib, dev = _lib.load(), _dev(color_error)
+    H, W = int(color_error.shape[0]), int(color_error.shape[1])
+    gy, gx = _grid(H, W, stride)
+    out = torch.empty(gy, gx, dtype=torch.int32, device=dev)
+    tmp = torch.empty(gy * gx, dtype=torch.float32, device=dev)
+    err = color_error.float().contiguous()
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_colorerror2tilemask(_p(err), H, W, int(stride), float(top_ratio), _p(out), _p(tmp), _stream(dev))
+    _lib.check(rc, "rtgs_colorerror2tilemask")
+    return out
+
+
+def render_range(T_map: torch.Tensor, tile_mask_ratio: float = 0.5):
+    """mapper.py:500-508 in one call: (render_mask bool[H,W], tile_mask int32[gy,gx], count uint32[1] on device);
+    render_ratio = count / (H*W) - left on the device so the caller decides when (if ever) to synchronise."""
+    lib, dev = _lib.load(), _dev(T_map)
+    H, W = int(T_map.shape[-2]), int(T_map.shape[-1])
+    T = T_map.float().contiguous()
+    gy, gx = _grid(H, W, 16)
+    mask = torch.empty(H, W, dtype=torch.uint8, device=dev)
+    tile = torch.empty(gy, gx, dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    tmp = torch.empty(gy * gx, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_render_range(_p(T), H, W, float(tile_mask_ratio), _p(mask), _p(tile), _p(count), _p(tmp), _stream(dev))
+    _lib.check(rc, "rtgs_render_range")
+    return mask.bool(), tile, count
+
+
+def distCUDA2(points: torch.Tensor, return_dist2: bool = False):
+    """`simple_knn._C.distCUDA2` of RTG-SLAM's fork: (mean squared distance to the 3 nearest other points [N],
+    their indices [N,3] int32).  Exact."""
+    lib, dev = _lib.load(), _dev(points)
+    pts = points.float().contiguous()
+    N = int(pts.shape[0])
+    mean = torch.empty(N, dtype=torch.float32, device=dev)
+    idx = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    d3 = torch.empty(N, 3, dtype=torch.float32, device=dev) if return_dist2 else None
+    scratch = torch.empty(lib.rtgs_knn3_scratch_bytes(N), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_knn3(_p(pts), N, _p(mean), _p(idx), _p(d3), _p(scratch), _stream(dev))
+    _lib.check(rc, "rtgs_knn3")
+    return (mean, idx, d3) if return_dist2 else (mean, idx)
+
+
+def accumulate_gaussian_error(H, W, P, color_error, depth_error, normal_error, color_index, depth_index, color_thres,
+                              depth_thres, normal_thres, mean=True):
+    """`cuda_utils._C.accumulate_gaussian_error` (frozen semantics, include/rtgs_slam.h) ->
+    (gaussian_color_error[P], gaussian_depth_error[P], gaussian_normal_error[P], outlier_count[P] int32)."""
+    lib, dev = _lib.load(), _dev(color_error)
+    H, W, P = int(H), int(W), int(P)
+    f = lambda t: t.float().contiguous()
+    i = lambda t: t.to(torch.int32).contiguous()
+    ce, de, ne, ci, di = f(color_error), f(depth_error), f(normal_error), i(color_index), i(depth_index)
+    for t in (ce, de, ne, ci, di):
+        if t.numel() != H * W:
+            raise RuntimeError(f"accumulate_gaussian_error: expected {H}x{W} maps, got {tuple(t.shape)}")
+    gc, gd, gn = (torch.empty(P, dtype=torch.float32, device=dev) for _ in range(3))
+    oc = torch.empty(P, dtype=torch.int32, device=dev)
+    scratch = torch.empty(2 * max(P, 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_accumulate_error(H, W, P, _p(ce), _p(de), _p(ne), _p(ci), _p(di), float(color_thres),
+                                       float(depth_thres), float(normal_thres), int(bool(mean)), _p(gc), _p(gd), _p(gn),
+                                       _p(oc), _p(scratch), _stream(dev))
+    _lib.check(rc, "rtgs_accumulate_error")
+    return gc, gd, gn, oc
+
+
+def bilateralFilter_torch(depth: torch.Tensor, radius: int, sigma_color: float, sigma_space: float) -> torch.Tensor:
+    lib, dev = _lib.load(), _dev(depth)
+    H, W = int(depth.shape[0]), int(depth.shape[1])
+    d = depth.reshape(H, W).float().contiguous()
+    out = torch.empty(H, W, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_bilateral_filter(_p(d), H, W, int(radius), float(sigma_color), float(sigma_space), _p(out), _stream(dev))
+    _lib.check(rc, "rtgs_bilateral_filter")
+    return out.reshape(H, W, 1)
+
+
+def frame_preprocess(depth_map: torch.Tensor, K: torch.Tensor, min_depth: float = 0.3, max_depth: float = 5.0,
+                     depth_filter: bool = False, invalid_confidence_thresh: float = 0.2):
+    """The map part of Tracker.map_preprocess (tracker.py:104-131): dict with depth_map [H,W,1], vertex_map_c [H,W,3],
+    normal_map_c [H,W,3], confidence_map [H,W,1], invalid_confidence_mask bool [H,W]."""
+    lib, dev = _lib.load(), _dev(depth_map)
+    H, W = int(depth_map.shape[0]), int(depth_map.shape[1])
+    d = depth_map.reshape(H, W).float().contiguous()
+    if depth_filter:
+        d = bilateralFilter_torch(d, 5, 2, 2).reshape(H, W)
+    Kd = K.to(device=dev, dtype=torch.float32).contiguous()
+    f = dict(dtype=torch.float32, device=dev)
+    dout, vout, nout, cout = torch.empty(H, W, 1, **f), torch.empty(H, W, 3, **f), torch.empty(H, W, 3, **f), torch.empty(H, W, 1, **f)
+    bad = torch.empty(H, W, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(lib.rtgs_frame_preprocess_scratch_bytes(H, W), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_frame_preprocess(_p(d), H, W, _p(Kd), float(min_depth), float(max_depth), float(invalid_confidence_thresh),
+                                       _p(dout), _p(vout), _p(nout), _p(cout), _p(bad), _p(scratch), _stream(dev))
+    _lib.check(rc, "rtgs_frame_preprocess")
+    return dict(depth_map=dout, vertex_map_c=vout, normal_map_c=nout, confidence_map=cout, invalid_confidence_mask=bad.bool())
+
+
+def sample_candidates(normal_map: torch.Tensor, select_mask: Optional[torch.Tensor] = None):
+    """Flat indices (ascending) of the pixels sample_pixels may draw from, and their number (device int32[1])."""
+    lib, dev = _lib.load(), _dev(normal_map)
+    H, W = int(normal_map.shape[0]), int(normal_map.shape[1])
+    n = normal_map.float().contiguous()
+    sel = None if select_mask is None else _u8(select_mask.reshape(H, W))
+    idx = torch.empty(H * W, dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    flags = torch.empty(H * W, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(lib.rtgs_compact_scratch_bytes(H * W), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_sample_candidates(_p(n), _p(sel), H, W, _p(idx), _p(count), _p(flags), _p(scratch), _stream(dev))
+    _lib.check(rc, "rtgs_sample_candidates")
+    return idx, count
+
+
+def sample_pixels(vertex_map, normal_map, color_map, uniform_sample_num, select_mask=None, generator=None):
+    """SLAM/utils.py:141-183: a uniform draw without replacement of min(uniform_sample_num, #candidates) pixels among
+    select_mask (all if None) minus zero-normal pixels -> (points [n,3], normals [n,3], colors [n,3])."""
+    assert uniform_sample_num >= 0
+    dev = _dev(vertex_map)
+    if uniform_sample_num == 0:
+        e = torch.empty(0, device=dev)
+        return e, e.clone(), e.clone()
+    idx, count = sample_candidates(normal_map, select_mask)
+    n_cand = int(count.item())                       # the reference synchronises here too (boolean-mask indexing)
+    n = min(int(uniform_sample_num), n_cand)
+    pick = idx[:n_cand][torch.randperm(n_cand, device=dev, generator=generator)[:n]].long()
+    return (vertex_map.reshape(-1, 3)[pick].view(n, 3), normal_map.reshape(-1, 3)[pick].view(n, 3),
+            color_map.reshape(-1, 3)[pick].view(n, 3))

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for h in ("rtgs_raster.h", "rtgs_icp.h"):
+    for h in ("rtgs_raster.h", "rtgs_icp.h", "rtgs_slam.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(rtgs_[a-z0-9_]+)\s*\(", src))
@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_product_path_has_no_oracle_or_cpu_fallback():
-    for d in ("rtg_slam_amd", "diff_gaussian_rasterization_depth"):
+    for d in ("rtg_slam_amd", "diff_gaussian_rasterization_depth", "simple_knn", "cuda_utils"):
         for fn in os.listdir(os.path.join(ROOT, d)):
             if fn.endswith(".py"):
                 src = open(os.path.join(ROOT, d, fn)).read()

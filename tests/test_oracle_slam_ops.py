@@ -1,0 +1,109 @@
+"""oracle/slam_ops_oracle.py against the REFERENCE's outputs (tests/golden/slam_ops.npz, written by
+oracle/gen_slam_ops_golden.py from /root/reference's own SLAM/utils.py and utils/loss_utils.py), plus properties of the
+two frozen (unpinned) definitions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slam_ops_oracle as so
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    z = np.load(os.path.join(golden_dir, "slam_ops.npz"))
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def test_golden_is_what_the_reference_produces_today(gold):
+    """In the build container: regenerate from the reference and compare with the committed file."""
+    from oracle import ref_shim
+    if not ref_shim.available():
+        pytest.skip("reference tree only exists in the build container")
+    from oracle import gen_slam_ops_golden as gen
+    fresh = gen.reference_outputs()
+    for k, v in fresh.items():
+        assert np.array_equal(np.asarray(v), gold[k].numpy()), k
+
+
+def test_tile_mask_producers(gold):
+    pm, err = gold["pixelmask"], gold["color_error"]
+    assert torch.equal(so.transmission2tilemask(pm, 16, 0.5), gold["t2t"])
+    assert torch.equal(so.pixelmask2tilemask(pm, 16), gold["p2t"])
+    assert torch.equal(so.colorerror2tilemask(err, 16, 0.4), gold["c2t"])
+    assert int(gold["c2t"].sum()) == int(35 * 0.4)
+
+
+def test_bilateral_and_frame_preprocess(gold):
+    assert torch.equal(so.bilateral_filter(gold["depth"], 5, 2, 2), gold["bilateral"])
+    for tag, filt in (("raw", False), ("filt", True)):
+        out = so.frame_preprocess(gold["depth"], gold["K"], 0.3, 5.0, filt, 0.2)
+        assert torch.equal(out["depth_map"], gold[f"pre_{tag}_depth"]), tag
+        assert torch.equal(out["invalid_confidence_mask"], gold[f"pre_{tag}_bad"]), tag
+        assert torch.equal(out["vertex_map_c"], gold[f"pre_{tag}_vertex"]), tag
+        assert torch.equal(out["normal_map_c"], gold[f"pre_{tag}_normal"]), tag
+        assert float((out["confidence_map"] - gold[f"pre_{tag}_conf"]).abs().max()) < 1e-6, tag
+
+
+def test_ssim_and_l1_l2(gold):
+    a, b = gold["ssim_a"], gold["ssim_b"]
+    assert abs(float(so.ssim(a, b)) - float(gold["ssim"])) < 1e-6
+    assert abs(float((a - b).abs().mean()) - float(gold["l1"])) < 1e-7
+    assert abs(float(((a - b) ** 2).mean()) - float(gold["l2"])) < 1e-7
+
+
+def test_loss_restates_mapper_loss_update():
+    """The loss against the lines of mapper.py:402-448 re-evaluated literally on HWC tensors, as the reference does
+    (permute(1,2,0), boolean-mask indexing), for both the masked and the unmasked (SSIM) branch."""
+    from oracle import ref_shim
+    g = torch.Generator().manual_seed(5)
+    H, W = 37, 53
+    color = torch.rand(3, H, W, generator=g)
+    depth = torch.rand(1, H, W, generator=g) * 3
+    didx = torch.randint(-1, 4, (1, H, W), generator=g, dtype=torch.int32)
+    gt_c = torch.rand(3, H, W, generator=g)
+    gt_d = (torch.rand(1, H, W, generator=g) * 3 - 0.4).clamp_min(0)
+    render = (color, depth, None, didx)
+    for masked in (False, True):
+        rm = (torch.rand(H, W, generator=g) < 0.6) if masked else None
+        total, terms = so.slam_loss(render, gt_c, gt_d, render_mask=rm)
+        image, dep, dix = color.permute(1, 2, 0), depth.permute(1, 2, 0), didx.permute(1, 2, 0)
+        cm, dm = gt_c.permute(1, 2, 0), gt_d.permute(1, 2, 0)
+        if rm is None:
+            render_mask = torch.ones(image.shape[:2]).bool()
+            if ref_shim.available():
+                ssim_loss = 1 - ref_shim.load("utils.loss_utils").ssim(image.permute(2, 0, 1), cm.permute(2, 0, 1))
+            else:
+                ssim_loss = 1 - so.ssim(color, gt_c)
+        else:
+            render_mask, ssim_loss = rm.bool(), torch.tensor(0.0)
+        color_loss = torch.abs(image[render_mask] - cm[render_mask]).mean()
+        depth_error = dep - dm
+        valid = (dix != -1).squeeze() & (dm > 0).squeeze() & (depth_error < 0.1).squeeze() & render_mask
+        depth_loss = torch.abs(depth_error[valid]).mean()
+        want = 1.0 * depth_loss + 0.8 * color_loss + 0.2 * ssim_loss
+        assert abs(float(total) - float(want)) < 1e-6, masked
+        assert abs(float(terms["depth"]) - float(depth_loss)) < 1e-7
+
+
+def test_knn_definition_and_error_accumulation_properties():
+    g = torch.Generator().manual_seed(3)
+    p = torch.randn(500, 3, generator=g)
+    mean, idx, d3 = so.dist2_knn(p)
+    d = torch.cdist(p.double(), p.double()) ** 2
+    d.fill_diagonal_(float("inf"))
+    want = torch.sort(d, dim=1).values[:, :3]
+    assert float((d3.double() - want).abs().max()) < 1e-5
+    assert torch.allclose(mean, d3.sum(1) / 3)
+    assert torch.all(idx != torch.arange(500)[:, None]) and torch.all(((p[idx[:, 0].long()] - p) ** 2).sum(1).sub(d3[:, 0]).abs() < 1e-5)
+    # accumulate_gaussian_error: a pixel with index -1 contributes to nobody; means and counts by hand
+    H, W, P = 4, 5, 3
+    ce = torch.arange(20, dtype=torch.float32).reshape(H, W, 1) / 10
+    de = torch.ones(H, W, 1) * 0.3
+    ne = torch.zeros(H, W, 1)
+    ci = torch.full((H, W, 1), -1, dtype=torch.int32); ci[0, :, 0] = 1; ci[1, 0, 0] = 2
+    di = torch.full((H, W, 1), -1, dtype=torch.int32); di[2, :3, 0] = 0
+    gc, gd, gn, oc = so.accumulate_gaussian_error(H, W, P, ce, de, ne, ci, di, 0.25, 0.2, 1000, True)
+    assert torch.allclose(gc, torch.tensor([0.0, 0.2, 0.5])) and torch.allclose(gd, torch.tensor([0.3, 0.0, 0.0]))
+    assert oc.tolist() == [3, 2, 1] and float(gn.abs().max()) == 0

@@ -98,3 +98,24 @@ def test_render_call_sequence_on_gpu():
     assert torch.all(color_hit_weight[0][color_index_map[0] < 0] == 0)
     # in-place hole filling on the rendered depth must be legal (icp.py:414 writes into it)
     rendered_depth[0][~hit] = 1.0
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_mapper_and_pointcloud_import_on_our_packages():
+    """`SLAM/gaussian_pointcloud.py` does `from simple_knn._C import distCUDA2` and
+    `SLAM/multiprocess/mapper.py` does `from cuda_utils._C import accumulate_gaussian_error` at module scope; with this
+    repository's `simple_knn`, `cuda_utils` and `diff_gaussian_rasterization_depth` packages on the path both reference
+    modules import (their other heavy imports stubbed) and bind to OUR ops."""
+    from oracle import ref_shim
+    gp = ref_shim.load("SLAM.gaussian_pointcloud")
+    mp = ref_shim.load("SLAM.multiprocess.mapper")
+    from rtg_slam_amd import slam_ops
+    import diff_gaussian_rasterization_depth as ours
+    assert gp.distCUDA2 is slam_ops.distCUDA2
+    assert mp.accumulate_gaussian_error is slam_ops.accumulate_gaussian_error
+    assert mp.Renderer.__module__ == "SLAM.render"
+    assert sys.modules["SLAM.render"].GaussianRasterizer_depth is ours.GaussianRasterizer
+    assert hasattr(mp, "Mapping") and hasattr(gp, "GaussianPointCloud")
+    # the ops refuse CPU tensors loudly (no silent fallback behind the reference's call sites)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        gp.distCUDA2(torch.rand(10, 3))

@@ -1,0 +1,174 @@
+"""HIP SLAM-side ops (include/rtgs_slam.h, rtg_slam_amd/slam_ops.py) against the REFERENCE's outputs
+(tests/golden/slam_ops.npz, written from /root/reference's own SLAM/utils.py by oracle/gen_slam_ops_golden.py) and,
+at larger sizes, against oracle/slam_ops_oracle.py (which is pinned to the same golden file on CPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slam_ops_oracle as so
+from rtg_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    z = np.load(os.path.join(golden_dir, "slam_ops.npz"))
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def test_tile_mask_producers_vs_reference(gold):
+    from rtg_slam_amd import slam_ops as ops
+    pm, err = gold["pixelmask"].to(DEV), gold["color_error"].to(DEV)
+    assert torch.equal(ops.transmission2tilemask(pm, 16, 0.5).cpu(), gold["t2t"])
+    assert torch.equal(ops.pixelmask2tilemask(pm, 16).cpu(), gold["p2t"])
+    assert torch.equal(ops.colorerror2tilemask(err, 16, 0.4).cpu(), gold["c2t"])
+    # Replica size, several ratios / strides, vs the pinned oracle
+    g = torch.Generator().manual_seed(2)
+    H, W = 680, 1200
+    pm = torch.rand(H, W, generator=g) < torch.linspace(0.1, 0.9, W)[None, :]
+    err = torch.rand(H, W, generator=g) ** 2 * torch.linspace(0.2, 1.0, H)[:, None]
+    for ratio in (0.25, 0.5, 0.75):
+        assert torch.equal(ops.transmission2tilemask(pm.to(DEV), 16, ratio).cpu(), so.transmission2tilemask(pm, 16, ratio))
+    assert torch.equal(ops.pixelmask2tilemask(pm.to(DEV), 8).cpu(), so.pixelmask2tilemask(pm, 8))
+    for top in (0.1, 0.4, 0.9):
+        got, want = ops.colorerror2tilemask(err.to(DEV), 16, top).cpu(), so.colorerror2tilemask(err, 16, top)
+        assert int(got.sum()) == int(want.sum()) == int(got.numel() * top)
+        # tile means are float sums in another order: the two top-k sets may swap tiles whose means tie to ~1e-7
+        assert int((got != want).sum()) <= 2
+    # ties: many equal tiles, k cuts through them -> exactly k on, lower tile index first
+    flat = torch.zeros(64, 64)
+    flat[:16, :32] = 1.0
+    got = ops.colorerror2tilemask(flat.to(DEV), 16, 0.5).cpu().reshape(-1)
+    assert got.tolist() == [1] * 8 + [0] * 8        # k = 8: the 2 tiles of mean 1, then 6 of the 14 zero-mean ties, in index order
+
+
+def test_render_range_from_T_map():
+    """mapper.py:500-508: render_mask = (T_map != 1); tile_mask = transmission2tilemask(render_mask, 16, 0.5)."""
+    from rtg_slam_amd import slam_ops as ops
+    g = torch.Generator().manual_seed(3)
+    H, W = 70, 101
+    T = torch.ones(1, H, W)
+    blob = torch.rand(H, W, generator=g) < 0.4
+    T[0][blob] = torch.rand(int(blob.sum()), generator=g) * 0.99
+    mask, tile, count = ops.render_range(T.to(DEV), 0.5)
+    assert torch.equal(mask.cpu(), T[0] != 1)
+    assert torch.equal(tile.cpu(), so.transmission2tilemask(T[0] != 1, 16, 0.5))
+    assert int(count.item()) == int((T[0] != 1).sum())
+
+
+@pytest.mark.parametrize("kind,N", [("uniform", 5000), ("surface", 20000), ("clustered", 8000), ("dups", 3000), ("tiny", 3)])
+def test_knn3_is_exact(kind, N):
+    from rtg_slam_amd import slam_ops as ops
+    g = torch.Generator().manual_seed(N)
+    if kind == "uniform":
+        p = torch.rand(N, 3, generator=g) * 4 - 2
+    elif kind == "surface":
+        p = synth.surface_gaussians(N, synth.CONFIG2, seed=5)["xyz"]
+    elif kind == "clustered":
+        c = torch.randn(20, 3, generator=g) * 3
+        p = c[torch.randint(0, 20, (N,), generator=g)] + 0.01 * torch.randn(N, 3, generator=g)
+        p[:50] += 100.0                                               # far outliers: rings of boxes must not miss them
+    elif kind == "dups":
+        p = torch.rand(N // 2, 3, generator=g).repeat(2, 1)           # every point has an exact duplicate (distance 0)
+    else:
+        p = torch.tensor([[0.0, 0, 0], [1, 0, 0], [0, 2, 0]])
+    mean, idx, d3 = ops.distCUDA2(p.to(DEV), return_dist2=True)
+    mean_o, idx_o, d3_o = so.dist2_knn(p)
+    assert torch.equal(d3.cpu(), d3_o), kind                          # same float32 distances, bit for bit
+    assert torch.equal(mean.cpu(), mean_o)
+    idx = idx.cpu().long()
+    if N > 3:
+        assert torch.all(idx != torch.arange(N)[:, None]) and torch.all((idx >= 0) & (idx < N))
+        for k in range(3):                                            # indices may differ on ties: check they realise the distance
+            q = p[idx[:, k]]
+            dx, dy, dz = p[:, 0] - q[:, 0], p[:, 1] - q[:, 1], p[:, 2] - q[:, 2]
+            assert torch.equal(dx * dx + dy * dy + dz * dz, d3_o[:, k]), (kind, k)
+    else:
+        assert idx[0].tolist()[:2] == [1, 2] and idx[0, 2] == -1 and float(d3[0, 2]) == torch.finfo(torch.float32).max
+
+
+def test_knn3_large_map_subset_check():
+    """400 k points: brute force is too slow on the CPU for all rows; check 3 000 random rows against all points."""
+    from rtg_slam_amd import slam_ops as ops
+    N = 400_000
+    p = synth.surface_gaussians(N, synth.REPLICA, seed=9)["xyz"]
+    mean, idx, d3 = ops.distCUDA2(p.to(DEV), return_dist2=True)
+    rows = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:3000]
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    dx, dy, dz = x[rows, None] - x[None, :], y[rows, None] - y[None, :], z[rows, None] - z[None, :]
+    d = dx * dx + dy * dy + dz * dz
+    d[torch.arange(3000), rows] = float("inf")
+    want = torch.topk(d, 3, dim=1, largest=False).values
+    assert torch.equal(d3.cpu()[rows], want)
+    assert torch.equal(mean.cpu()[rows], want.sum(1) / 3.0)
+
+
+def test_accumulate_gaussian_error_vs_oracle():
+    from cuda_utils._C import accumulate_gaussian_error
+    g = torch.Generator().manual_seed(4)
+    H, W, P = 120, 160, 900
+    ce, de, ne = torch.rand(H, W, 1, generator=g), torch.rand(H, W, 1, generator=g) * 0.3, torch.rand(H, W, 1, generator=g)
+    # index maps with runs (an opaque disc owns neighbouring pixels) and holes
+    ci = (torch.arange(H * W) // 37 % P).reshape(H, W, 1).int()
+    di = (torch.arange(H * W) // 11 % (P - 100)).reshape(H, W, 1).int()
+    ci[torch.rand(H, W, 1, generator=g) < 0.2] = -1
+    di[torch.rand(H, W, 1, generator=g) < 0.3] = -1
+    for mean in (True, False):
+        got = accumulate_gaussian_error(H, W, P, ce.to(DEV), de.to(DEV), ne.to(DEV), ci.to(DEV), di.to(DEV), 0.6, 0.2, 0.9, mean)
+        want = so.accumulate_gaussian_error(H, W, P, ce, de, ne, ci, di, 0.6, 0.2, 0.9, mean)
+        for a, b in zip(got[:3], want[:3]):
+            assert float((a.cpu() - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+        assert torch.equal(got[3].cpu(), want[3])
+        assert float(got[1][P - 100:].abs().max()) == 0              # Gaussians nobody points at stay exactly 0
+
+
+def test_bilateral_and_frame_preprocess_vs_reference(gold):
+    from rtg_slam_amd import slam_ops as ops
+    depth, K = gold["depth"].to(DEV), gold["K"].to(DEV)
+    bf = ops.bilateralFilter_torch(depth, 5, 2, 2).cpu()
+    ref = gold["bilateral"]
+    assert bf.shape == ref.shape
+    assert float((bf - ref).abs().max()) <= 2e-6 * float(ref.abs().max())        # expf on the GPU vs torch.exp
+    assert torch.equal(bf == 0, ref == 0)
+    for tag, filt in (("raw", False), ("filt", True)):
+        out = {k: v.cpu() for k, v in ops.frame_preprocess(depth, K, 0.3, 5.0, filt, 0.2).items()}
+        bad, bad_ref = out["invalid_confidence_mask"], gold[f"pre_{tag}_bad"]
+        flips = bad != bad_ref                                           # confidence within an ulp of the 0.2 threshold
+        assert float(flips.float().mean()) <= (0.0 if not filt else 2e-3), tag
+        ok = ~flips
+        tol = 0.0 if not filt else 3e-6                                  # the filtered depth itself carries the expf ulp
+        for name, key in (("depth_map", "depth"), ("vertex_map_c", "vertex")):
+            d = (out[name] - gold[f"pre_{tag}_{key}"]).abs().amax(dim=-1)
+            assert float(d[ok].max()) <= tol * 5.0, (tag, name)
+        dn = (out["normal_map_c"] - gold[f"pre_{tag}_normal"]).abs().amax(dim=-1)
+        if not filt:
+            assert float(dn[ok].max()) == 0.0                            # Sobel / cross / norm rounded as torch rounds them
+        else:
+            assert float((dn[ok] > 1e-3).float().mean()) < 1e-3
+        dc = (out["confidence_map"] - gold[f"pre_{tag}_conf"]).abs()[..., 0]
+        assert float(dc[ok].max()) <= (1e-6 if not filt else 1e-3)
+
+
+def test_sample_pixels_candidates_and_draw(gold):
+    from rtg_slam_amd import slam_ops as ops
+    normal = gold["pre_raw_normal"]
+    H, W = normal.shape[:2]
+    sel = torch.rand(H, W, 1, generator=torch.Generator().manual_seed(6)) < 0.5
+    for s in (None, sel):
+        idx, count = ops.sample_candidates(normal.to(DEV), None if s is None else s.to(DEV))
+        want = torch.nonzero(so.sample_pixels_mask(normal, s).reshape(-1)).reshape(-1)
+        assert int(count.item()) == want.numel()
+        assert torch.equal(idx[:want.numel()].cpu().long(), want)        # ascending pixel order
+    vertex, color = gold["pre_raw_vertex"].to(DEV), torch.rand(H, W, 3).to(DEV)
+    pts, nrm, col = ops.sample_pixels(vertex, normal.to(DEV), color, 500, sel.to(DEV))
+    assert pts.shape == (500, 3) and nrm.shape == (500, 3) and col.shape == (500, 3)
+    assert torch.all(nrm.sum(-1) != 0)                                   # never a zero-normal pixel
+    # without replacement: 500 distinct vertices (the room's vertices are all distinct)
+    assert torch.unique(pts, dim=0).shape[0] == 500
+    n_all = int(so.sample_pixels_mask(normal, sel).sum())
+    pts, _, _ = ops.sample_pixels(vertex, normal.to(DEV), color, 10 ** 9, sel.to(DEV))
+    assert pts.shape[0] == n_all                                         # asks for more than there is: gets them all
