@@ -105,9 +105,6 @@ def main():
                     scales=gd["scales"], rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"],
                     tile_mask=tile_mask, grad_rows=gd.get("grad_rows"))
 
-    def loss_fn(gd):
-        return mo.slam_losses_hip(render(gd), gt_color, gt_depth)
-
     # Tracking and mapping are independent within a frame (RTG-SLAM runs them as two pipeline stages in separate
     # processes, SLAM/multiprocess/system.py).  Here the tracker's kernels go to a second HIP stream and are
     # ENQUEUED by a helper thread (the C calls release the GIL), so neither the GPU nor the host serialises the two.
@@ -130,12 +127,23 @@ def main():
 
     threading.Thread(target=icp_worker, daemon=True).start()
 
+    # the render mask of the optimisation (mapper.py:500-508: evaluate_render_range renders once before the loop,
+    # render_mask = T_map != 1, and hands it to every loss_update) - computed the same way, once, by the HIP producer
+    from rtg_slam_amd import slam_ops
+    with torch.no_grad():
+        gd0 = mo.activate8_hip(opt.state["raw8"]["p"][:N])
+        T0 = rast(means3D=opt.state["xyz"]["p"][:N], opacities=gd0["opacity"], shs=opt.state["shs"]["p"][:N].view(N, 16, 3),
+                  colors_precomp=None, scales=gd0["scales"], rotations=gd0["rotations"], cov3D_precomp=None,
+                  normal_w=gd0["normal"], tile_mask=tile_mask)[6]
+    render_mask, _, _ = slam_ops.render_range(T0, 0.5)
+    render_mask = render_mask.to(torch.uint8)
+    del gd0, T0
+    opt.begin_local_optimization()
+
     def map_step():
-        if opt.grad_rows is not None:
-            # same kernels as step(loss_fn), enqueued by one C call; with more than one rank the replicas exchange
-            # only the gradient rows that exist (a few MB) instead of reducing 283 MB of dense gradients
-            return opt.step_slam(rs, gt_color, gt_depth, tile_mask)
-        return opt.step(loss_fn)
+        # same kernels as step(loss_fn), enqueued by one C call; with more than one rank the replicas exchange
+        # only the gradient rows that exist (a few MB) instead of reducing 283 MB of dense gradients
+        return opt.step_slam(rs, gt_color, gt_depth, tile_mask, render_mask=render_mask)
 
     def frame():
         main = torch.cuda.current_stream(dev)
@@ -200,12 +208,14 @@ def main():
             opt_s = mo.ShardedMapOptimizer(mo.pack_from_activated({k: v.to(dev) for k, v in gs.items()}),
                                            lr_col=mo.default_lr_columns() * 1e-4)
             gt_d_s = synth.box_room_depth(cam, torch.eye(4, dtype=torch.float64), bump=0.0).to(dev).reshape(1, cam.H, cam.W)
+            rm_s = torch.ones(cam.H, cam.W, dtype=torch.uint8, device=dev)
+            opt_s.begin_local_optimization()
             for _ in range(20):
-                opt_s.step_slam(rs, gt_color, gt_d_s, tile_mask)
+                opt_s.step_slam(rs, gt_color, gt_d_s, tile_mask, render_mask=rm_s)
             torch.cuda.synchronize(dev)
             ts = time.perf_counter()
             for _ in range(args.steps):
-                opt_s.step_slam(rs, gt_color, gt_d_s, tile_mask)
+                opt_s.step_slam(rs, gt_color, gt_d_s, tile_mask, render_mask=rm_s)
             torch.cuda.synchronize(dev)
             map_iter_ms = 1e3 * (time.perf_counter() - ts) / args.steps
             surface = profile_scene(lib, mo, rast, opt_s, N, cam, tile_mask, gt_color, gt_d_s, dev, 5)
@@ -240,7 +250,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic Replica-shaped SLAM frame: ICP track (3 levels x 5 GN iters, 1200x680, on a "
-                                   "second HIP stream) + 1 map-optimisation iteration (raster fwd + L1 colour/depth loss + "
+                                   "second HIP stream) + 1 map-optimisation iteration (raster fwd + masked L1 colour / gated depth loss + attach regulariser + "
                                    f"raster bwd + fused Adam) over {N} random Gaussians (SURVEY.md 8d generator, seed 2024), "
                                    "all tiles",
                        "gaussians": N, "gaussians_with_gradient": rows_touched, "image": [cam.H, cam.W],
@@ -279,7 +289,7 @@ def profile_scene(lib, mo, rast, opt, N, cam, tile_mask, gt_color, gt_depth, dev
         out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
                    rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=tile_mask,
                    grad_rows=opt.grad_rows)
-        loss = mo.slam_losses_hip(out, gt_color, gt_depth)
+        loss = mo.slam_losses_hip(out, gt_color, gt_depth, render_mask=torch.ones_like(gt_depth[0], dtype=torch.uint8))
         lib.rtgs_raster_set_counters(None)
         loss.backward()
         torch.cuda.synchronize(dev)

@@ -63,9 +63,11 @@ typedef struct rtgs_icp_level {
   const float* normal_tgt;
 } rtgs_icp_level;
 
-/* Runs the whole multi-level Gauss-Newton loop on the device - ONE persistent kernel (a workgroup per CU, a grid
- * barrier per iteration, every workgroup takes the same step on its own copy of the pose; RTGS_ICP_PERSISTENT=0
- * selects one launch per iteration instead).
+/* Runs the whole multi-level Gauss-Newton loop on the device, pose resident there, no host synchronisation:
+ * one launch per Gauss-Newton iteration by default, or - flags & RTGS_ICP_FLAG_PERSISTENT - ONE persistent kernel (a
+ * workgroup per CU, a grid barrier per iteration, every workgroup takes the same step on its own copy of the pose).
+ * Same arithmetic; the persistent form is ~8 % faster with the device to itself, the default form coexists better with
+ * kernels of other streams.  Environment override: RTGS_ICP_PERSISTENT=0/1.
  *   pose_inout: device float[16], initial guess in, estimate out (pose_t1_t0)
  *   stats_out : device float[4] = { valid_ratio of the last iteration (icp.py:46-47),
  *               point2plane loss at the last level (icp.py:443-447), number of solves that
@@ -74,7 +76,8 @@ typedef struct rtgs_icp_level {
  *               wait is bounded so that a scheduling pathology cannot hang the device), else 0 } */
 int rtgs_icp_track(const rtgs_icp_level* levels_host, int32_t n_levels, const float* K,
                    float distance_threshold, float cos_normal_threshold, float damping,
-                   float* pose_inout, float* stats_out, void* scratch, void* stream);
+                   float* pose_inout, float* stats_out, void* scratch, int32_t flags, void* stream);
+#define RTGS_ICP_FLAG_PERSISTENT 1
 
 /* In-place model-depth hole filling (icp.py:397-415): render_depth[H,W] takes frame_depth where
  * |render - frame| > dist_thr, or render == 0, or 1 - cos(render_normal, frame_normal) >

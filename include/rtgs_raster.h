@@ -261,34 +261,60 @@ int rtgs_map_activate8_backward_rows(const float* raw8, int64_t n, const float* 
                                      const float* g_rotations, const float* g_normal, const uint8_t* row_state,
                                      float* g_raw8, void* stream);
 
+/* Attach regulariser of Mapping.loss_update (mapper.py:384-401): Gaussians whose INITIAL activated opacity
+ * sigmoid(init_raw8[:,0]) is below 0.9 are tied to their initial raw scaling, position and raw rotation,
+ *   attach = 1000 * ( mean (scaling - scaling0)^2 + mean (xyz - xyz0)^2 + mean (rotation - rotation0)^2 ),
+ * means over the selected rows x columns.  rtgs_attach_prepare counts the selected rows and evaluates the loss
+ * (attach_info[0..1] = {n_selected, loss}): call it once when the snapshot is taken (the selection, hence n_selected,
+ * is fixed by the snapshot) and again whenever the loss VALUE is wanted for reporting; rtgs_map_tail_rows adds the
+ * regulariser's gradient to the selected rows using attach_info[0]. */
+typedef struct rtgs_attach {
+  const float* init_xyz;      /* [rows,3]  snapshot taken when the local optimisation starts (history_stat / init_stat) */
+  const float* init_raw8;     /* [rows,8]  opacity | scaling | rotation, raw */
+  float* attach_info;         /* device float[6]: [0] n_selected, [1] loss (written by rtgs_attach_prepare), [2..5] scratch */
+} rtgs_attach;
+int rtgs_attach_prepare(const float* xyz, const float* raw8, const rtgs_attach* attach, int64_t rows, void* stream);
+
 /* rtgs_map_activate8_backward_rows followed by rtgs_fused_adam_rows on xyz[rows,3], shs[rows,48] and raw8[rows,8], as
  * ONE launch (the tail of rtgs_slam_map_step).  g_* are the persistent gradient rows of rtgs_raster_backward_rows,
- * row_state its state bytes; g_raw8 is written for state 1 (value) and state 2 (zero) rows. */
+ * row_state its state bytes; g_raw8 is written for state 1 (value) and state 2 (zero) rows.
+ *   attach     (nullable) adds the attach regulariser's gradient to the selected rows (rtgs_attach_prepare must have run)
+ *   confidence (nullable) float[rows]: += 1 for every row whose f_dc gradient is non-zero (mapper.py:454-456) */
 int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const float* g_opacity, const float* g_scales,
                        const float* g_rotations, const float* g_normal, const float* g_xyz, const float* g_shs,
                        float* g_raw8, const uint8_t* row_state, float* m_xyz, float* v_xyz, float* m_shs, float* v_shs,
                        float* m_raw8, float* v_raw8, const float* lr_xyz, const float* lr_shs, const float* lr_raw8,
                        uint8_t* ever_xyz, uint8_t* ever_shs, uint8_t* ever_raw8, int64_t rows, int32_t step, float beta1,
-                       float beta2, float eps, void* stream);
+                       float beta2, float eps, const rtgs_attach* attach, float* confidence, void* stream);
 
-/* Fused SLAM loss, the live terms of mapper.py:402-442:
- *   L = color_weight * mean|C - C_gt| + depth_weight * sum(m |D - D_gt|) / max(sum m, 1),
- *   m = (depth_index != -1) & (D_gt > 0).
- * Writes the scalar loss and BOTH image gradients (dL/dC [3,H,W], dL/dD [1,H,W]) so the autograd
- * graph of ~30 elementwise launches collapses into two kernels.  sums3_scratch: device float[3]. */
+/* Fused SLAM loss: the image terms of Mapping.loss_update (mapper.py:402-448) - value and BOTH image gradients
+ * (dL/dC [3,H,W], dL/dD [1,H,W]), so the autograd graph of ~40 elementwise launches collapses into a few kernels.
+ *   mask   = render_mask (uint8 [H,W]), or every pixel when NULL - and only then the SSIM term is live (:411-417)
+ *   colour = mean over mask x 3 channels of |C - C_gt|                                                  (:421)
+ *   depth  = mean over {depth_index != -1, D_gt > 0, (D - D_gt) < add_depth_thres, mask} of |D - D_gt|  (:423-431; the
+ *            threshold is on the signed error as written there; an empty set contributes 0 where torch gives nan)
+ *   ssim   = 1 - mean SSIM(C, C_gt), 11x11 Gaussian window, sigma 1.5, zero padding (utils/loss_utils.py:58-100)
+ *   total  = depth_weight depth + color_weight colour + ssim_weight ssim
+ * The normal term (normal_weight, 0 in every shipped config) is not part of this kernel.
+ * loss_out4: device float[4] = {total, colour, depth, ssim}.  scratch: rtgs_slam_loss_scratch_bytes(H, W, with_ssim). */
+typedef struct rtgs_loss_cfg {
+  float color_weight, depth_weight, ssim_weight, add_depth_thres;
+  const uint8_t* render_mask;
+} rtgs_loss_cfg;
+size_t rtgs_slam_loss_scratch_bytes(int32_t H, int32_t W, int32_t with_ssim);
 int rtgs_slam_loss(const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
-                   const float* gt_depth, int32_t H, int32_t W, float color_weight, float depth_weight,
-                   float* sums3_scratch, float* loss_out, float* g_color, float* g_depth, void* stream);
+                   const float* gt_depth, int32_t H, int32_t W, const rtgs_loss_cfg* cfg, void* scratch,
+                   float* loss_out4, float* g_color, float* g_depth, void* stream);
 
 /* One map-optimisation iteration as a single call (the body of local_optimize's inner loop, mapper.py:176-205, with
- * the live loss terms of mapper.py:402-442):
+ * loss_update's image terms, attach regulariser, Adam step and confidence increment, mapper.py:371-456):
  *   raw8 activation -> rtgs_raster_forward -> rtgs_slam_loss -> rtgs_raster_backward_rows ->
- *   rtgs_map_activate8_backward_rows -> rtgs_fused_adam_rows on xyz[P,3], shs[P,48], raw8[P,8].
+ *   rtgs_map_tail_rows (activation backward + attach gradient + Adam on xyz[P,3], shs[P,48], raw8[P,8] + confidence).
  * Exactly the sequence the entry points above perform when called one by one (parameters are updated in place, the
- * scalar loss is left in loss_scratch4[3]); it exists because the host cost of issuing ~40 launches through an
- * autograd graph exceeds their GPU time on a large map.  Every pointer is a caller-owned DEVICE buffer; the
- * gradient arena (d_*, grad_scratch, row_state) and the Adam state (m_*, v_*, ever_*) persist between calls and
- * follow the rtgs_raster_backward_rows / rtgs_fused_adam_rows contracts.  The three resize callbacks are the ones
+ * losses are left in loss4); it exists because the host cost of issuing ~40 launches through an autograd graph
+ * exceeds their GPU time on a large map.  Every pointer is a caller-owned DEVICE buffer; the gradient arena (d_*,
+ * grad_scratch, row_state) and the Adam state (m_*, v_*, ever_*) persist between calls and follow the
+ * rtgs_raster_backward_rows / rtgs_fused_adam_rows contracts.  The three resize callbacks are the ones
  * rtgs_raster_forward takes and must ALSO answer a request of size 0 with the buffer of their last request. */
 typedef struct rtgs_map_step_args {
   const rtgs_raster_settings* settings;
@@ -296,13 +322,14 @@ typedef struct rtgs_map_step_args {
   float *xyz, *shs, *raw8;                                /* parameters, updated in place */
   const int32_t* tile_mask;
   const float *gt_color, *gt_depth;                       /* [3,H,W], [1,H,W] */
-  float color_weight, depth_weight;
+  rtgs_loss_cfg loss;                                     /* weights, depth gate, render mask */
+  void* loss_scratch;                                     /* rtgs_slam_loss_scratch_bytes(H, W, render_mask == NULL) */
   float *opacity, *scales, *rotations, *normal;           /* activated values: [P,1] [P,3] [P,4] [P,3] */
   float *out_color, *out_depth;                           /* the 7 outputs of the rasterizer (+ radii) */
   int32_t *out_color_index, *out_depth_index;
   float *out_color_weight, *out_depth_weight, *out_T;
   int32_t* out_radii;
-  float *dL_dcolor, *dL_ddepth, *loss_scratch4;           /* loss_scratch4: [0:3] partial sums, [3] loss */
+  float *dL_dcolor, *dL_ddepth, *loss4;                   /* loss4: {total, colour, depth, ssim} */
   float *d_xyz, *d_opacity, *d_shs, *d_scales, *d_rotations, *d_normal, *d_raw8;
   void* grad_scratch;                                     /* rtgs_raster_backward_scratch_bytes(P), zero-initialised */
   uint8_t* row_state;                                     /* [P], zero-initialised */
@@ -311,6 +338,8 @@ typedef struct rtgs_map_step_args {
   uint8_t *ever_xyz, *ever_shs, *ever_raw8;               /* [P] each, zero-initialised */
   int32_t step;                                           /* Adam step count, starts at 1 */
   float beta1, beta2, eps;
+  const rtgs_attach* attach;                              /* nullable */
+  float* confidence;                                      /* nullable, float[P] */
   rtgs_resize_fn geom_resize; void* geom_user;
   rtgs_resize_fn binning_resize; void* binning_user;
   rtgs_resize_fn image_resize; void* image_user;

@@ -44,19 +44,33 @@ _lock = threading.Lock()
 _lib = None
 
 _P = C.c_void_p
+
+
+class LossCfgC(C.Structure):
+    """Mirror of `rtgs_loss_cfg` (include/rtgs_raster.h)."""
+    _fields_ = [("color_weight", C.c_float), ("depth_weight", C.c_float), ("ssim_weight", C.c_float),
+                ("add_depth_thres", C.c_float), ("render_mask", C.c_void_p)]
+
+
+class AttachC(C.Structure):
+    """Mirror of `rtgs_attach` (include/rtgs_raster.h)."""
+    _fields_ = [("init_xyz", C.c_void_p), ("init_raw8", C.c_void_p), ("attach_info", C.c_void_p)]
+
+
 class MapStepArgsC(C.Structure):
     """Mirror of `rtgs_map_step_args` (include/rtgs_raster.h)."""
     _fields_ = (
         [("settings", C.POINTER(RasterSettingsC)), ("P", C.c_int32), ("sh_coeffs", C.c_int32)]
         + [(n, C.c_void_p) for n in ("xyz", "shs", "raw8", "tile_mask", "gt_color", "gt_depth")]
-        + [("color_weight", C.c_float), ("depth_weight", C.c_float)]
+        + [("loss", LossCfgC), ("loss_scratch", C.c_void_p)]
         + [(n, C.c_void_p) for n in (
             "opacity", "scales", "rotations", "normal", "out_color", "out_depth", "out_color_index", "out_depth_index",
-            "out_color_weight", "out_depth_weight", "out_T", "out_radii", "dL_dcolor", "dL_ddepth", "loss_scratch4",
+            "out_color_weight", "out_depth_weight", "out_T", "out_radii", "dL_dcolor", "dL_ddepth", "loss4",
             "d_xyz", "d_opacity", "d_shs", "d_scales", "d_rotations", "d_normal", "d_raw8", "grad_scratch", "row_state",
             "m_xyz", "v_xyz", "m_shs", "v_shs", "m_raw8", "v_raw8", "lr_xyz", "lr_shs", "lr_raw8",
             "ever_xyz", "ever_shs", "ever_raw8")]
         + [("step", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+        + [("attach", C.POINTER(AttachC)), ("confidence", C.c_void_p)]
         + [("geom_resize", RESIZE_FN), ("geom_user", C.c_void_p), ("binning_resize", RESIZE_FN),
            ("binning_user", C.c_void_p), ("image_resize", RESIZE_FN), ("image_user", C.c_void_p)])
 
@@ -81,14 +95,17 @@ _SIGNATURES = {
     "rtgs_map_activate8_forward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "rtgs_map_activate8_backward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "rtgs_map_activate8_backward_rows": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
-    "rtgs_map_tail_rows": (C.c_int, [_P] * 23 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, _P]),
+    "rtgs_map_tail_rows": (C.c_int, [_P] * 23 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                     C.POINTER(AttachC), _P, _P]),
+    "rtgs_attach_prepare": (C.c_int, [_P, _P, C.POINTER(AttachC), C.c_int64, _P]),
+    "rtgs_slam_loss_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rtgs_slam_map_step_front": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_rows_pack": (C.c_int, [_P, C.c_int32] + [_P] * 8 + [_P]),
     "rtgs_rows_apply": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 7 + [_P]),
     "rtgs_map_step_args_size": (C.c_size_t, []),
     "rtgs_raster_settings_size": (C.c_size_t, []),
     "rtgs_slam_map_step": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
-    "rtgs_slam_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
+    "rtgs_slam_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(LossCfgC), _P, _P, _P, _P, _P]),
     "rtgs_raster_set_profiling": (None, [C.c_int]),
     "rtgs_raster_force_sort_path": (None, [C.c_int]),
     "rtgs_raster_set_near_slice": (None, [C.c_int, C.c_int]),
@@ -115,7 +132,8 @@ _SIGNATURES = {
     "rtgs_slam_map_step_front_ctx": (C.c_int, [_P, C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_icp_build_pyramids": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "rtgs_icp_step": (C.c_int, [_P] * 4 + [C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
-    "rtgs_icp_track": (C.c_int, [C.POINTER(IcpLevelC), C.c_int32, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P]),
+    "rtgs_icp_track": (C.c_int, [C.POINTER(IcpLevelC), C.c_int32, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P,
+                                 C.c_int32, _P]),
     "rtgs_icp_fill_model_depth": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, _P]),
     "rtgs_icp_scratch_bytes": (C.c_size_t, []),
     # include/rtgs_slam.h

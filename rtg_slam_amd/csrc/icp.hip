@@ -721,7 +721,7 @@ int rtgs_icp_step(const float* vs, const float* ns, const float* vt, const float
 }
 
 int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, float dist_thr, float cos_thr,
-                   float damping, float* pose, float* stats, void* scratch, void* stream) {
+                   float damping, float* pose, float* stats, void* scratch, int32_t flags, void* stream) {
   if (!lv || n_levels < 1 || n_levels > RTGS_ICP_MAX_LEVELS || !K || !pose || !stats || !scratch) return -1;
   hipStream_t st = (hipStream_t)stream;
   Scratch* sc = (Scratch*)scratch;
@@ -732,9 +732,13 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
   }
   ICP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
   ICP_TRY(hipMemsetAsync(&sc->ticket, 0, 2 * sizeof(uint32_t), st));       // ticket + abort flag
-  // RTGS_ICP_PERSISTENT=0 keeps the one-launch-per-iteration form (A/B measurements, and a way out should a driver
-  // ever refuse to co-schedule one workgroup per CU)
-  static const bool persistent = [] { const char* e = getenv("RTGS_ICP_PERSISTENT"); return !e || atoi(e) != 0; }();
+  // Two forms, same arithmetic.  One launch per Gauss-Newton iteration (default): 16 short kernels that leave the GPU
+  // to whatever else is queued between them - measured best when the tracker overlaps the map optimisation on another
+  // stream (1 690 vs 1 511 frames/s in bench.py).  One persistent kernel (RTGS_ICP_FLAG_PERSISTENT, or the environment
+  // override RTGS_ICP_PERSISTENT=1/0): ~8 % faster when the tracker has the device to itself (287 vs 312 us per
+  // 1200x680 track), but its resident, mostly waiting workgroups slow co-running kernels down.
+  static const int env_persistent = [] { const char* e = getenv("RTGS_ICP_PERSISTENT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  const bool persistent = env_persistent >= 0 ? env_persistent == 1 : (flags & RTGS_ICP_FLAG_PERSISTENT) != 0;
   if (persistent) {
     int dev = 0, cus = 0;
     ICP_TRY(hipGetDevice(&dev));

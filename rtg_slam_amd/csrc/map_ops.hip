@@ -2,7 +2,9 @@
 // raw map parameters into the rasterizer's inputs, and their backward, each as ONE streaming
 // kernel instead of ~40 elementwise / gather launches (SLAM/gaussian_pointcloud.py:16-25 exp /
 // sigmoid / normalize, :538-550 get_normal).
+#include "../../include/rtgs_raster.h"
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include "adam_common.h"
 
@@ -161,7 +163,16 @@ struct TailArgs {
   uint8_t *ever_xyz, *ever_shs, *ever_raw8;
   long long rows;
   float beta1, beta2, eps, bc1, bc2_sqrt;
+  // attach regulariser (mapper.py:384-401) and confidence increment (:454-456), both optional
+  const float* init_xyz;
+  const float4* init_raw8;
+  const float* attach_info;       // [0] = number of selected rows
+  float* confidence;
 };
+
+__device__ __forceinline__ bool attach_selected(const float4 init_lo) {
+  return 1.f / (1.f + __expf(-init_lo.x)) < 0.9f;                // opacity_activation(init_stat["opacity"]) < 0.9
+}
 
 __global__ void __launch_bounds__(256) map_tail_rows_kernel(TailArgs a) {
   __shared__ int s_rows[4][64];
@@ -172,12 +183,35 @@ __global__ void __launch_bounds__(256) map_tail_rows_kernel(TailArgs a) {
     bool need_sh = false;
     if (r < a.rows) {
       const uint8_t st = a.row_state[r];
-      const bool grad = st == 1;
-      if (st != 0) {                                             // raw8 gradient row: value (1) or zero (2)
+      const bool rgrad = st == 1;                                // gradient from the rasterizer
+      float4 at_lo = make_float4(0.f, 0.f, 0.f, 0.f), at_hi = at_lo;
+      float at_x = 0.f, at_y = 0.f, at_z = 0.f;
+      bool sel = false;
+      // a row that was never stepped still equals its snapshot: its attach gradient is exactly 0 and it is skipped
+      // without reading the snapshot (the common case: most low-opacity Gaussians never see a render gradient)
+      if (a.init_raw8 && (rgrad || a.ever_raw8[r] != 0 || a.ever_xyz[r] != 0)) {
+        const float4 i_lo = a.init_raw8[2 * r];
+        sel = attach_selected(i_lo);
+        if (sel) {
+          // d/dp of 1000 * mean_{selected rows x cols} (p - p0)^2 = 2000 (p - p0) / (n_sel * cols)
+          const float4 i_hi = a.init_raw8[2 * r + 1], c_lo = a.raw8_in[2 * r], c_hi = a.raw8_in[2 * r + 1];
+          const float n = fmaxf(a.attach_info[0], 1.f);
+          const float k3 = 2000.f / (n * 3.f), k4 = 2000.f / (n * 4.f);
+          at_lo = make_float4(0.f, k3 * (c_lo.y - i_lo.y), k3 * (c_lo.z - i_lo.z), k3 * (c_lo.w - i_lo.w));
+          at_hi = make_float4(k4 * (c_hi.x - i_hi.x), k4 * (c_hi.y - i_hi.y), k4 * (c_hi.z - i_hi.z), k4 * (c_hi.w - i_hi.w));
+          at_x = k3 * (a.xyz[(size_t)r * 3] - a.init_xyz[(size_t)r * 3]);
+          at_y = k3 * (a.xyz[(size_t)r * 3 + 1] - a.init_xyz[(size_t)r * 3 + 1]);
+          at_z = k3 * (a.xyz[(size_t)r * 3 + 2] - a.init_xyz[(size_t)r * 3 + 2]);
+        }
+      }
+      const bool grad = rgrad || sel;
+      if (st != 0 || sel) {                                      // raw8 gradient row: value (1 / attached) or zero (2)
         float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-        if (grad)
+        if (rgrad)
           activate8_bwd_row(a.raw8_in[2 * r], a.raw8_in[2 * r + 1], a.g_op[r], a.g_sc[r * 3], a.g_sc[r * 3 + 1],
                             a.g_sc[r * 3 + 2], a.g_rot[r], a.g_nrm[r * 3], a.g_nrm[r * 3 + 1], a.g_nrm[r * 3 + 2], lo, hi);
+        lo.y += at_lo.y; lo.z += at_lo.z; lo.w += at_lo.w;
+        hi.x += at_hi.x; hi.y += at_hi.y; hi.z += at_hi.z; hi.w += at_hi.w;
         a.g_raw8[2 * r] = lo; a.g_raw8[2 * r + 1] = hi;
       }
       if (grad || a.ever_raw8[r] != 0) {                         // raw8: 8 columns, this lane
@@ -195,15 +229,20 @@ __global__ void __launch_bounds__(256) map_tail_rows_kernel(TailArgs a) {
       }
       if (grad || a.ever_xyz[r] != 0) {                          // xyz: 3 columns, this lane
         a.ever_xyz[r] = 1;
+        const float at[3] = {at_x, at_y, at_z};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const size_t o = (size_t)r * 3 + c;
           float mi = a.m_xyz[o], vi = a.v_xyz[o];
-          a.xyz[o] = adam1(a.xyz[o], a.g_xyz[o], mi, vi, a.lr_xyz[c], a.beta1, a.beta2, a.eps, a.bc1, a.bc2_sqrt);
+          a.xyz[o] = adam1(a.xyz[o], (rgrad ? a.g_xyz[o] : 0.f) + at[c], mi, vi, a.lr_xyz[c], a.beta1, a.beta2, a.eps, a.bc1, a.bc2_sqrt);
           a.m_xyz[o] = mi; a.v_xyz[o] = vi;
         }
       }
-      need_sh = grad || a.ever_shs[r] != 0;
+      if (a.confidence && rgrad) {                               // confidence += 1 where the f_dc gradient is non-zero
+        const size_t o = (size_t)r * 48;
+        if (a.g_shs[o] != 0.f || a.g_shs[o + 1] != 0.f || a.g_shs[o + 2] != 0.f) a.confidence[r] += 1.f;
+      }
+      need_sh = rgrad || a.ever_shs[r] != 0;
       if (need_sh) a.ever_shs[r] = 1;
     }
     // SH: 48 columns = 12 lanes x float4 per live row, five rows per sweep (as fused_adam_rows_kernel<48>)
@@ -234,12 +273,65 @@ __global__ void __launch_bounds__(256) map_tail_rows_kernel(TailArgs a) {
 
 }  // namespace rtgs
 
+namespace rtgs {
+// number of attach-selected rows and the value of the regulariser: info[0] += n, info[1] = loss (second launch)
+__global__ void __launch_bounds__(256) attach_sums_kernel(const float* __restrict__ xyz, const float4* __restrict__ raw8,
+                                                          const float* __restrict__ init_xyz, const float4* __restrict__ init_raw8,
+                                                          long long rows, float* __restrict__ sums4) {
+  float n = 0.f, ss = 0.f, sx = 0.f, sr = 0.f;
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x) {
+    const float4 i_lo = init_raw8[2 * r];
+    if (!attach_selected(i_lo)) continue;
+    const float4 i_hi = init_raw8[2 * r + 1], c_lo = raw8[2 * r], c_hi = raw8[2 * r + 1];
+    n += 1.f;
+    ss += (c_lo.y - i_lo.y) * (c_lo.y - i_lo.y) + (c_lo.z - i_lo.z) * (c_lo.z - i_lo.z) + (c_lo.w - i_lo.w) * (c_lo.w - i_lo.w);
+    sr += (c_hi.x - i_hi.x) * (c_hi.x - i_hi.x) + (c_hi.y - i_hi.y) * (c_hi.y - i_hi.y) + (c_hi.z - i_hi.z) * (c_hi.z - i_hi.z) +
+          (c_hi.w - i_hi.w) * (c_hi.w - i_hi.w);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float d = xyz[(size_t)r * 3 + c] - init_xyz[(size_t)r * 3 + c]; sx += d * d; }
+  }
+  float v[4] = {n, ss, sx, sr};
+  __shared__ float sh[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) unsafeAtomicAdd(&sums4[threadIdx.x], (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]));
+}
+__global__ void attach_finish_kernel(const float* __restrict__ sums4, float* __restrict__ info) {
+  const float n = sums4[0];
+  info[0] = n;
+  info[1] = n > 0.f ? 1000.f * (sums4[1] / (n * 3.f) + sums4[2] / (n * 3.f) + sums4[3] / (n * 4.f)) : 0.f;
+}
+}  // namespace rtgs
+
+// attach->attach_info must point at 6 floats: [0] n_selected, [1] loss, [2..5] scratch sums
+extern "C" int rtgs_attach_prepare(const float* xyz, const float* raw8, const rtgs_attach* attach, int64_t rows, void* stream) {
+  if (!attach || !attach->init_xyz || !attach->init_raw8 || !attach->attach_info || rows < 0) return -1;
+  if (rows > 0 && (!xyz || !raw8)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  float* info = attach->attach_info;
+  if (hipMemsetAsync(info, 0, 6 * sizeof(float), st) != hipSuccess) return -2;
+  if (rows > 0) {
+    long long blocks = (rows + 255) / 256;
+    if (blocks > 192) blocks = 192;
+    hipLaunchKernelGGL(rtgs::attach_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xyz, (const float4*)raw8,
+                       attach->init_xyz, (const float4*)attach->init_raw8, (long long)rows, info + 2);
+  }
+  hipLaunchKernelGGL(rtgs::attach_finish_kernel, dim3(1), dim3(1), 0, st, (const float*)(info + 2), info);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const float* g_opacity, const float* g_scales,
                                   const float* g_rotations, const float* g_normal, const float* g_xyz, const float* g_shs,
                                   float* g_raw8, const uint8_t* row_state, float* m_xyz, float* v_xyz, float* m_shs,
                                   float* v_shs, float* m_raw8, float* v_raw8, const float* lr_xyz, const float* lr_shs,
                                   const float* lr_raw8, uint8_t* ever_xyz, uint8_t* ever_shs, uint8_t* ever_raw8,
-                                  int64_t rows, int32_t step, float beta1, float beta2, float eps, void* stream) {
+                                  int64_t rows, int32_t step, float beta1, float beta2, float eps,
+                                  const rtgs_attach* attach, float* confidence, void* stream) {
   if (rows < 0 || step < 1) return -1;
   if (rows == 0) return 0;
   if (!xyz || !shs || !raw8 || !g_opacity || !g_scales || !g_rotations || !g_normal || !g_xyz || !g_shs || !g_raw8 ||
@@ -254,6 +346,11 @@ extern "C" int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const flo
   a.lr_xyz = lr_xyz; a.lr_shs = lr_shs; a.lr_raw8 = lr_raw8;
   a.ever_xyz = ever_xyz; a.ever_shs = ever_shs; a.ever_raw8 = ever_raw8;
   a.rows = rows; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.init_xyz = nullptr; a.init_raw8 = nullptr; a.attach_info = nullptr; a.confidence = confidence;
+  if (attach) {
+    if (!attach->init_xyz || !attach->init_raw8 || !attach->attach_info) return -1;
+    a.init_xyz = attach->init_xyz; a.init_raw8 = (const float4*)attach->init_raw8; a.attach_info = attach->attach_info;
+  }
   a.bc1 = 1.f - powf(beta1, (float)step);
   a.bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
   long long blocks = (rows + 255) / 256;
@@ -369,10 +466,17 @@ extern "C" int rtgs_rows_apply(const float* rows, int32_t n_rows, int32_t mode, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused SLAM loss (the live terms of mapper.py:402-442): L = cw * mean|C - C_gt| +
-// dw * sum(m |D - D_gt|) / max(sum m, 1),  m = (depth_index != -1) & (D_gt > 0).
-// Two launches: (1) block partial sums -> 3 device atomics, (2) loss value + both image gradients.
-// Replaces ~30 elementwise / reduction launches of the autograd graph (and their host overhead).
+// Fused SLAM loss: the image terms of Mapping.loss_update (mapper.py:402-448), value and both image gradients.
+//   mask       = render_mask, or every pixel when it is NULL - and only then the SSIM term is live (:411-417)
+//   colour     = mean over mask (x 3 channels) of |C - C_gt|                                          (:421)
+//   depth      = mean over {depth_index != -1, D_gt > 0, (D - D_gt) < add_depth_thres, mask} of |D - D_gt|  (:423-431)
+//                (the threshold is on the SIGNED error, as written there; an empty set contributes 0 - torch's mean
+//                 of an empty selection is nan)
+//   ssim       = 1 - mean(ssim_map), 11x11 Gaussian window sigma 1.5, zero padding (utils/loss_utils.py:58-100)
+//   total      = depth_weight depth + color_weight colour + ssim_weight ssim
+// (normal_weight is 0 in every shipped config, configs/base.yaml:81: the normal term is left to the autograd path.)
+// Launches: block partial sums -> a few device atomics; [SSIM forward: per-pixel statistics and the three derivative
+// maps]; gradients (+ SSIM backward: the derivative maps convolved with the same window).
 // ---------------------------------------------------------------------------------------------
 namespace rtgs {
 
@@ -382,68 +486,204 @@ __device__ __forceinline__ float wave_sum_shfl(float v) {
   return v;
 }
 
+// sums: [0] sum |dC| over mask  [1] sum |dD| over valid  [2] #valid  [3] #mask pixels  [4] sum of the SSIM map
 __global__ void __launch_bounds__(256) slam_loss_sums_kernel(const float* __restrict__ color, const float* __restrict__ depth,
                                                              const int32_t* __restrict__ didx, const float* __restrict__ gt_c,
-                                                             const float* __restrict__ gt_d, int64_t hw, float* __restrict__ sums) {
-  float s_c = 0.f, s_d = 0.f, s_m = 0.f;
+                                                             const float* __restrict__ gt_d, const uint8_t* __restrict__ rmask,
+                                                             int64_t hw, float depth_thr, float* __restrict__ sums) {
+  float s_c = 0.f, s_d = 0.f, s_m = 0.f, s_n = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool m = !rmask || rmask[i] != 0;
+    if (!m) continue;
+    s_n += 1.f;
     s_c += fabsf(color[i] - gt_c[i]) + fabsf(color[hw + i] - gt_c[hw + i]) + fabsf(color[2 * hw + i] - gt_c[2 * hw + i]);
-    const float g = gt_d[i];
-    if (didx[i] != -1 && g > 0.f) { s_d += fabsf(depth[i] - g); s_m += 1.f; }
+    const float g = gt_d[i], e = depth[i] - g;
+    if (didx[i] != -1 && g > 0.f && e < depth_thr) { s_d += fabsf(e); s_m += 1.f; }
   }
-  s_c = wave_sum_shfl(s_c); s_d = wave_sum_shfl(s_d); s_m = wave_sum_shfl(s_m);
-  __shared__ float sh[3][4];
+  s_c = wave_sum_shfl(s_c); s_d = wave_sum_shfl(s_d); s_m = wave_sum_shfl(s_m); s_n = wave_sum_shfl(s_n);
+  __shared__ float sh[4][4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) { sh[0][w] = s_c; sh[1][w] = s_d; sh[2][w] = s_m; }
+  if (lane == 0) { sh[0][w] = s_c; sh[1][w] = s_d; sh[2][w] = s_m; sh[3][w] = s_n; }
   __syncthreads();
-  if (threadIdx.x < 3) {
+  if (threadIdx.x < 4) {
     const float t = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
     unsafeAtomicAdd(&sums[threadIdx.x], t);
   }
 }
 
+struct SsimWin { float g[11]; };
+constexpr int SS_R = 5, SS_T = 16 + 2 * SS_R;     // window radius, tile + halo edge
+
+// SSIM forward of one 16x16 tile: windowed means / second moments by a separable pass through LDS, the map value, and
+// its derivatives w.r.t. the three windowed quantities that depend on the rendered image:
+//   dA = dS/d mu1 (total, through sigma1^2 and sigma12 too), dB = dS/d conv(x1^2), dC = dS/d conv(x1 x2).
+__global__ void __launch_bounds__(256) ssim_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int H, int W,
+                                                       SsimWin win, float* __restrict__ dmaps, float* __restrict__ sums) {
+  __shared__ float s_a[SS_T * SS_T], s_b[SS_T * SS_T];
+  __shared__ float s_h[5][SS_T * 16];
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const int px = blockIdx.x * 16 + lx, py = blockIdx.y * 16 + ly;
+  const size_t HW = (size_t)H * W;
+  float ssum = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    __syncthreads();
+    for (int q = threadIdx.x; q < SS_T * SS_T; q += 256) {
+      const int x = (int)blockIdx.x * 16 - SS_R + q % SS_T, y = (int)blockIdx.y * 16 - SS_R + q / SS_T;
+      const bool in = x >= 0 && x < W && y >= 0 && y < H;
+      s_a[q] = in ? x1[c * HW + (size_t)y * W + x] : 0.f;
+      s_b[q] = in ? x2[c * HW + (size_t)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < SS_T * 16; q += 256) {         // horizontal pass: SS_T rows x 16 columns
+      const int r = q / 16, col = q % 16;
+      float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float a = s_a[r * SS_T + col + k], b = s_b[r * SS_T + col + k], w = win.g[k];
+        m1 += w * a; m2 += w * b; e11 += w * (a * a); e22 += w * (b * b); e12 += w * (a * b);
+      }
+      s_h[0][q] = m1; s_h[1][q] = m2; s_h[2][q] = e11; s_h[3][q] = e22; s_h[4][q] = e12;
+    }
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = win.g[k];
+      const int q = (ly + k) * 16 + lx;
+      m1 += w * s_h[0][q]; m2 += w * s_h[1][q]; e11 += w * s_h[2][q]; e22 += w * s_h[3][q]; e12 += w * s_h[4][q];
+    }
+    if (px < W && py < H) {
+      const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+      const float s1 = e11 - m1 * m1, s2 = e22 - m2 * m2, s12 = e12 - m1 * m2;
+      const float n1 = 2.f * m1 * m2 + C1, n2 = 2.f * s12 + C2, d1 = m1 * m1 + m2 * m2 + C1, d2 = s1 + s2 + C2;
+      const float S = (n1 * n2) / (d1 * d2);
+      ssum += S;
+      const float dB = -S / d2;                                  // via sigma1^2 in d2
+      const float dC = 2.f * n1 / (d1 * d2);                     // via sigma12 in n2
+      const float dA = (2.f * m2 * n2 - 2.f * m2 * n1) / (d1 * d2) - S * (2.f * m1 / d1 - 2.f * m1 / d2);
+      const size_t o = c * HW + (size_t)py * W + px;
+      dmaps[o] = dA; dmaps[3 * HW + o] = dB; dmaps[6 * HW + o] = dC;
+    }
+  }
+  ssum = wave_sum_shfl(ssum);
+  __shared__ float s_w[4];
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = ssum;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(&sums[4], (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+}
+
+// g_color += k * (conv(dA) + 2 x1 conv(dB) + x2 conv(dC)),  k = ssim_weight * d(1 - mean S)/dS = -ssim_weight / (3 H W)
+__global__ void __launch_bounds__(256) ssim_bwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int H, int W,
+                                                       SsimWin win, const float* __restrict__ dmaps, float k,
+                                                       float* __restrict__ g_color) {
+  __shared__ float s_t[3][SS_T * SS_T];
+  __shared__ float s_h[3][SS_T * 16];
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const int px = blockIdx.x * 16 + lx, py = blockIdx.y * 16 + ly;
+  const size_t HW = (size_t)H * W;
+  for (int c = 0; c < 3; ++c) {
+    __syncthreads();
+    for (int q = threadIdx.x; q < SS_T * SS_T; q += 256) {
+      const int x = (int)blockIdx.x * 16 - SS_R + q % SS_T, y = (int)blockIdx.y * 16 - SS_R + q / SS_T;
+      const bool in = x >= 0 && x < W && y >= 0 && y < H;
+      const size_t o = c * HW + (size_t)y * W + x;
+      s_t[0][q] = in ? dmaps[o] : 0.f; s_t[1][q] = in ? dmaps[3 * HW + o] : 0.f; s_t[2][q] = in ? dmaps[6 * HW + o] : 0.f;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < SS_T * 16; q += 256) {
+      const int r = q / 16, col = q % 16;
+      float a = 0.f, b = 0.f, cc = 0.f;
+#pragma unroll
+      for (int t = 0; t < 11; ++t) {
+        const float w = win.g[t];
+        a += w * s_t[0][r * SS_T + col + t]; b += w * s_t[1][r * SS_T + col + t]; cc += w * s_t[2][r * SS_T + col + t];
+      }
+      s_h[0][q] = a; s_h[1][q] = b; s_h[2][q] = cc;
+    }
+    __syncthreads();
+    float a = 0.f, b = 0.f, cc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 11; ++t) {
+      const float w = win.g[t];
+      const int q = (ly + t) * 16 + lx;
+      a += w * s_h[0][q]; b += w * s_h[1][q]; cc += w * s_h[2][q];
+    }
+    if (px < W && py < H) {
+      const size_t o = c * HW + (size_t)py * W + px;
+      g_color[o] += k * (a + 2.f * x1[o] * b + x2[o] * cc);
+    }
+  }
+}
+
+// loss4: [0] total [1] colour [2] depth [3] ssim term (1 - mean S, or 0)
 __global__ void __launch_bounds__(256) slam_loss_grads_kernel(const float* __restrict__ color, const float* __restrict__ depth,
                                                               const int32_t* __restrict__ didx, const float* __restrict__ gt_c,
-                                                              const float* __restrict__ gt_d, int64_t hw, float cw, float dw,
-                                                              const float* __restrict__ sums, float* __restrict__ loss,
+                                                              const float* __restrict__ gt_d, const uint8_t* __restrict__ rmask,
+                                                              int64_t hw, float cw, float dw, float sw, float depth_thr,
+                                                              const float* __restrict__ sums, float* __restrict__ loss4,
                                                               float* __restrict__ g_color, float* __restrict__ g_depth) {
-  const float inv_c = 1.f / (3.f * (float)hw);
+  const float inv_c = 1.f / (3.f * fmaxf(sums[3], 1.f));
   const float inv_m = 1.f / fmaxf(sums[2], 1.f);
-  if (blockIdx.x == 0 && threadIdx.x == 0) loss[0] = cw * sums[0] * inv_c + dw * sums[1] * inv_m;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const float lc = sums[0] * inv_c, ld = sums[1] * inv_m, ls = sw != 0.f ? 1.f - sums[4] / (3.f * (float)hw) : 0.f;
+    loss4[1] = lc; loss4[2] = ld; loss4[3] = ls;
+    loss4[0] = dw * ld + cw * lc + sw * ls;
+  }
   const float kc = cw * inv_c, kd = dw * inv_m;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool m = !rmask || rmask[i] != 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float d = color[c * hw + i] - gt_c[c * hw + i];
-      g_color[c * hw + i] = d > 0.f ? kc : (d < 0.f ? -kc : 0.f);       // sign(0) = 0 as torch.abs' backward
+      g_color[c * hw + i] = !m ? 0.f : (d > 0.f ? kc : (d < 0.f ? -kc : 0.f));     // sign(0) = 0 as torch.abs' backward
     }
-    const float g = gt_d[i];
+    const float g = gt_d[i], e = depth[i] - g;
     float gd = 0.f;
-    if (didx[i] != -1 && g > 0.f) { const float d = depth[i] - g; gd = d > 0.f ? kd : (d < 0.f ? -kd : 0.f); }
+    if (m && didx[i] != -1 && g > 0.f && e < depth_thr) gd = e > 0.f ? kd : (e < 0.f ? -kd : 0.f);
     g_depth[i] = gd;
   }
 }
 
 }  // namespace rtgs
 
+extern "C" size_t rtgs_slam_loss_scratch_bytes(int32_t H, int32_t W, int32_t with_ssim) {
+  return 8 * sizeof(float) + (with_ssim ? (size_t)9 * (size_t)H * (size_t)W * sizeof(float) : 0);
+}
+
 extern "C" int rtgs_slam_loss(const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
-                              const float* gt_depth, int32_t H, int32_t W, float color_weight, float depth_weight,
-                              float* sums3_scratch, float* loss_out, float* g_color, float* g_depth, void* stream) {
-  if (!color || !depth || !depth_index || !gt_color || !gt_depth || !sums3_scratch || !loss_out || !g_color || !g_depth ||
+                              const float* gt_depth, int32_t H, int32_t W, const rtgs_loss_cfg* cfg, void* scratch,
+                              float* loss_out4, float* g_color, float* g_depth, void* stream) {
+  if (!color || !depth || !depth_index || !gt_color || !gt_depth || !cfg || !scratch || !loss_out4 || !g_color || !g_depth ||
       H <= 0 || W <= 0)
     return -1;
   hipStream_t st = (hipStream_t)stream;
   const int64_t hw = (int64_t)H * W;
-  if (hipMemsetAsync(sums3_scratch, 0, 3 * sizeof(float), st) != hipSuccess) return -2;
+  float* sums = (float*)scratch;
+  float* dmaps = sums + 8;
+  const bool ssim = cfg->render_mask == nullptr && cfg->ssim_weight != 0.f;
+  if (hipMemsetAsync(sums, 0, 8 * sizeof(float), st) != hipSuccess) return -2;
   int64_t blocks = (hw + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  // the sums kernel ends with three same-address global atomics per workgroup (~20 ns each, serialised): keep it to
+  // the sums kernel ends with four same-address global atomics per workgroup (~20 ns each, serialised): keep it to
   // 192 workgroups (1 024 of them cost 20 us for a 23 MB read)
   const int64_t sum_blocks = blocks > 192 ? 192 : blocks;
   hipLaunchKernelGGL(rtgs::slam_loss_sums_kernel, dim3((unsigned)sum_blocks), dim3(256), 0, st, color, depth, depth_index,
-                     gt_color, gt_depth, hw, sums3_scratch);
+                     gt_color, gt_depth, cfg->render_mask, hw, cfg->add_depth_thres, sums);
+  rtgs::SsimWin win;
+  if (ssim) {
+    double g[11], tot = 0.0;
+    float gf[11], totf = 0.f;
+    for (int i = 0; i < 11; ++i) { g[i] = exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); gf[i] = (float)g[i]; totf += gf[i]; tot += g[i]; }
+    (void)tot;
+    for (int i = 0; i < 11; ++i) win.g[i] = gf[i] / totf;        // torch.Tensor([...]) / sum, in float32 (loss_utils.py:39-46)
+    hipLaunchKernelGGL(rtgs::ssim_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, st, color, gt_color, H, W, win,
+                       dmaps, sums);
+  }
   hipLaunchKernelGGL(rtgs::slam_loss_grads_kernel, dim3((unsigned)blocks), dim3(256), 0, st, color, depth, depth_index,
-                     gt_color, gt_depth, hw, color_weight, depth_weight, (const float*)sums3_scratch, loss_out, g_color,
-                     g_depth);
+                     gt_color, gt_depth, cfg->render_mask, hw, cfg->color_weight, cfg->depth_weight,
+                     ssim ? cfg->ssim_weight : 0.f, cfg->add_depth_thres, (const float*)sums, loss_out4, g_color, g_depth);
+  if (ssim)
+    hipLaunchKernelGGL(rtgs::ssim_bwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, st, color, gt_color, H, W, win,
+                       (const float*)dmaps, -cfg->ssim_weight / (3.f * (float)hw), g_color);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -25,8 +25,9 @@ extern "C" int rtgs_slam_map_step_front_ctx(rtgs_ctx* ctx, const rtgs_map_step_a
   void* bin = a->binning_resize(a->binning_user, 0);
   void* img = a->image_resize(a->image_user, 0);
   if (!geom || !bin || !img) return RTGS_E_ALLOC;
-  rc = rtgs_slam_loss(a->out_color, a->out_depth, a->out_depth_index, a->gt_color, a->gt_depth, H, W, a->color_weight,
-                      a->depth_weight, a->loss_scratch4, a->loss_scratch4 + 3, a->dL_dcolor, a->dL_ddepth, stream);
+  if (!a->loss_scratch || !a->loss4) return RTGS_E_INVALID;
+  rc = rtgs_slam_loss(a->out_color, a->out_depth, a->out_depth_index, a->gt_color, a->gt_depth, H, W, &a->loss,
+                      a->loss_scratch, a->loss4, a->dL_dcolor, a->dL_ddepth, stream);
   if (rc != 0) return RTGS_E_HIP;
   rc = rtgs_raster_backward_rows_ctx(ctx, a->settings, P, M, *num_rendered_host, a->xyz, a->opacity, a->shs, a->scales,
                                  a->rotations, a->normal, geom, bin, img, a->out_color, a->out_T, a->out_depth_index,
@@ -43,11 +44,11 @@ extern "C" int rtgs_slam_map_step_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* a
   int rc = rtgs_slam_map_step_front_ctx(ctx, a, num_rendered_host, stream);
   if (rc != RTGS_OK) return rc;
   const int32_t P = a->P;
-  // activation backward + Adam on the three block tensors, one launch
+  // activation backward (+ attach gradient) + Adam on the three block tensors (+ confidence increment), one launch
   rc = rtgs_map_tail_rows(a->xyz, a->shs, a->raw8, a->d_opacity, a->d_scales, a->d_rotations, a->d_normal, a->d_xyz,
                           a->d_shs, a->d_raw8, a->row_state, a->m_xyz, a->v_xyz, a->m_shs, a->v_shs, a->m_raw8, a->v_raw8,
                           a->lr_xyz, a->lr_shs, a->lr_raw8, a->ever_xyz, a->ever_shs, a->ever_raw8, P, a->step, a->beta1,
-                          a->beta2, a->eps, stream);
+                          a->beta2, a->eps, a->attach, a->confidence, stream);
   return rc != 0 ? RTGS_E_HIP : RTGS_OK;
 }
 

@@ -93,7 +93,7 @@ def icp_step(v_src, n_src, v_tgt, n_tgt, K, pose, dist_thr: float, cos_thr: floa
 
 def icp_track(vertex_src: Sequence[torch.Tensor], normal_src, vertex_tgt, normal_tgt, K: torch.Tensor,
               downscales: Sequence[float], iters: Sequence[int], dist_thr: float, cos_thr: float,
-              damping: float, pose0: torch.Tensor | None = None) -> torch.Tensor:
+              damping: float, pose0: torch.Tensor | None = None, persistent: bool = False) -> torch.Tensor:
     """The level loop of IcpTracker.predict_pose (icp.py:428-447) on the device.
     Returns a device float32[20]: pose (16, row-major) + [valid_ratio, p2p_loss, n_singular, aborted]."""
     lib = _lib.load()
@@ -117,7 +117,7 @@ def icp_track(vertex_src: Sequence[torch.Tensor], normal_src, vertex_tgt, normal
     with torch.cuda.device(dev):
         rc = lib.rtgs_icp_track(lv, n, _vp(K), float(dist_thr), float(cos_thr), float(damping),
                                 C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr() + 64),
-                                _vp(_get_scratch(dev)), C.c_void_p(stream))
+                                _vp(_get_scratch(dev)), 1 if persistent else 0, C.c_void_p(stream))
     _lib.check(rc, "rtgs_icp_track")
     return out
 
@@ -157,6 +157,7 @@ class IcpTracker:
         self.icp_sample_normal_threshold = args.icp_sample_normal_threshold
         self.icp_fail_threshold = args.icp_fail_threshold
         self.verbose = getattr(args, "verbose", False)
+        self.persistent = bool(getattr(args, "icp_persistent", False))     # extension: one persistent kernel per track
         n = len(self.icp_downscales)
         # the reference's pyramid builder pools by 2^(n-1-l) (icp.py:374); its level loop scales K
         # by icp_downscales[l] (icp.py:431-433) - the two agree for the shipped [0.25, 0.5, 1.0]
@@ -200,7 +201,8 @@ class IcpTracker:
                 self.last_model_depth, self.K, len(self.icp_downscales))
         out = icp_track(self.vertex_pyramid_t1, self.normal_pyramid_t1, self.vertex_pyramid_t0,
                         self.normal_pyramid_t0, K, self.icp_downscales, self.icp_downscale_iters,
-                        self.icp_distance_threshold, self.icp_normal_threshold, self.icp_damping)
+                        self.icp_distance_threshold, self.icp_normal_threshold, self.icp_damping,
+                        persistent=self.persistent)
         host = out.cpu().numpy()                      # the single device->host copy of the frame
         if host[19] != 0:
             raise RuntimeError("rtgs_icp_track: the persistent tracking kernel timed out at a grid barrier "

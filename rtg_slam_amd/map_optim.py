@@ -31,6 +31,7 @@ constructor and returned by `.params` for interchange.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Callable, Dict, Optional
 
 import torch
@@ -246,6 +247,7 @@ class ShardedMapOptimizer:
         self.last_render = None
         self.last_num_rendered = 0
         self._slam_state = None        # world > 1: full-size Adam state of the replicated sparse step (step_slam)
+        self.attach_init = None        # begin_local_optimization(): snapshot for the attach regulariser
         self._mode = None              # world > 1: "sharded" (step) or "replicated" (step_slam); they keep different state
         if self.row_skip and activate_fn is None:
             from .rasterizer import RowGradArena
@@ -263,9 +265,39 @@ class ShardedMapOptimizer:
             self.adam_fn(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps)
 
     # ------------------------------------------------------------------ one-call SLAM step (single GPU)
+    def begin_local_optimization(self):
+        """Snapshot the raw parameters the attach regulariser ties low-opacity Gaussians to (`history_stat` /
+        `init_stat` of mapper.py:147-153, 660-666) and re-create the Adam state, as the reference does for every
+        local / global optimisation (mapper.py:156: a new torch.optim.Adam per call)."""
+        N, st = self.N, self.state
+        self.attach_init = dict(xyz=st["xyz"]["p"][:N].clone(), raw8=st["raw8"]["p"][:N].clone(),
+                                info=torch.zeros(6, dtype=torch.float32, device=st["xyz"]["p"].device))
+        for holder in (self.state, self._slam_state or {}):
+            for n in holder:
+                for k in ("m", "v", "ever"):
+                    holder[n][k].zero_()
+        self.step_count = 0
+        if st["xyz"]["p"].is_cuda:
+            self.attach_loss()                 # counts the selected rows once: the selection is fixed by the snapshot
+
+    def attach_loss(self) -> torch.Tensor:
+        """Value of the attach regulariser at the current parameters (mapper.py:384-401; `scale_loss` of the
+        reference's report) - a device scalar.  The one-call step applies its gradient without evaluating it."""
+        from . import _lib
+        lib = _lib.load()
+        ai, st, N = self.attach_init, self.state, self.N
+        dev = st["xyz"]["p"].device
+        attach = _lib.AttachC(ai["xyz"].data_ptr(), ai["raw8"].data_ptr(), ai["info"].data_ptr())
+        with torch.cuda.device(dev):
+            rc = lib.rtgs_attach_prepare(C.c_void_p(st["xyz"]["p"].data_ptr()), C.c_void_p(st["raw8"]["p"].data_ptr()),
+                                         C.byref(attach), N, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(rc, "rtgs_attach_prepare")
+        return ai["info"][1]
+
     def step_slam(self, raster_settings, gt_color: torch.Tensor, gt_depth: torch.Tensor,
                   tile_mask: Optional[torch.Tensor] = None, color_weight: float = 0.8,
-                  depth_weight: float = 1.0) -> torch.Tensor:
+                  depth_weight: float = 1.0, ssim_weight: float = 0.2, add_depth_thres: float = 0.1,
+                  render_mask: Optional[torch.Tensor] = None, confidence: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One iteration with the built-in SLAM loss (`slam_losses`): identical kernels and results as
         `step(lambda gd: slam_losses_hip(render(gd), gt_color, gt_depth))`, but enqueued by a single C call
         (`rtgs_slam_map_step`) - no autograd graph, no per-launch Python.  With more than one rank the map and the
@@ -283,7 +315,8 @@ class ShardedMapOptimizer:
             def loss_fn(gd):
                 out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], scales=gd["scales"],
                            rotations=gd["rotations"], normal_w=gd["normal"], tile_mask=tile_mask)
-                return slam_losses_hip(out, gt_color, gt_depth, color_weight, depth_weight)
+                return slam_losses_hip(out, gt_color, gt_depth, color_weight, depth_weight, ssim_weight, add_depth_thres,
+                                       render_mask)
             return self.step(loss_fn)
         lib = _lib.load()
         rs = raster_settings
@@ -311,25 +344,37 @@ class ShardedMapOptimizer:
                 cidx=torch.empty(1, H, W, **i), didx=torch.empty(1, H, W, **i), cw=torch.empty(1, H, W, **f),
                 dw=torch.empty(1, H, W, **f), T=torch.empty(1, H, W, **f), radii=torch.empty(N, **i),
                 g_color=torch.empty(3, H, W, **f), g_depth=torch.empty(1, H, W, **f), loss=torch.empty(4, **f),
+                loss_scratch=None,
                 ones=torch.ones((H + 15) // 16, (W + 15) // 16, **i),
                 arenas=[_GrowArena(dev), _GrowArena(dev), _GrowArena(dev)])
         if tile_mask is None:
             tile_mask = ws["ones"]
         tile_mask = tile_mask.to(device=dev, dtype=torch.int32).contiguous()
         gt_color, gt_depth = gt_color.contiguous(), gt_depth.contiguous()
+        rm = None if render_mask is None else (render_mask if render_mask.dtype == torch.uint8 else (render_mask != 0).to(torch.uint8)).contiguous()
+        need = lib.rtgs_slam_loss_scratch_bytes(H, W, int(rm is None))
+        if ws["loss_scratch"] is None or ws["loss_scratch"].numel() < need:
+            ws["loss_scratch"] = torch.empty(need, dtype=torch.uint8, device=dev)
+        attach = None
+        if getattr(self, "attach_init", None) is not None:
+            ai = self.attach_init
+            attach = _lib.AttachC(ai["xyz"].data_ptr(), ai["raw8"].data_ptr(), ai["info"].data_ptr())
         keep = _Keep(rs, dev)
         self.step_count += 1
         P = lambda t: t.data_ptr()
         geom, binning, img = ws["arenas"]
         args = _lib.MapStepArgsC(
             C.pointer(keep.c), N, 16, P(st["xyz"]["p"]), P(st["shs"]["p"]), P(st["raw8"]["p"]), P(tile_mask), P(gt_color),
-            P(gt_depth), float(color_weight), float(depth_weight), P(ws["opacity"]), P(ws["scales"]), P(ws["rotations"]),
+            P(gt_depth), _lib.LossCfgC(float(color_weight), float(depth_weight), float(ssim_weight), float(add_depth_thres),
+                                       rm.data_ptr() if rm is not None else None),
+            P(ws["loss_scratch"]), P(ws["opacity"]), P(ws["scales"]), P(ws["rotations"]),
             P(ws["normal"]), P(ws["color"]), P(ws["depth"]), P(ws["cidx"]), P(ws["didx"]), P(ws["cw"]), P(ws["dw"]),
             P(ws["T"]), P(ws["radii"]), P(ws["g_color"]), P(ws["g_depth"]), P(ws["loss"]), P(a.d_means), P(a.d_opac),
             P(a.d_shs), P(a.d_scales), P(a.d_rots), P(a.d_normal), P(a.d_raw8), P(a.scratch), P(a.row_state),
             P(ad["xyz"]["m"]), P(ad["xyz"]["v"]), P(ad["shs"]["m"]), P(ad["shs"]["v"]), P(ad["raw8"]["m"]),
             P(ad["raw8"]["v"]), P(st["xyz"]["lr"]), P(st["shs"]["lr"]), P(st["raw8"]["lr"]), P(ad["xyz"]["ever"]),
             P(ad["shs"]["ever"]), P(ad["raw8"]["ever"]), int(self.step_count), 0.9, 0.999, float(self.eps),
+            C.pointer(attach) if attach is not None else None, P(confidence) if confidence is not None else None,
             geom.cb, None, binning.cb, None, img.cb, None)
         R = C.c_int64(0)
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -350,12 +395,15 @@ class ShardedMapOptimizer:
                     V(a.d_normal), V(a.d_means), V(a.d_shs), V(a.d_raw8), V(a.row_state), V(ad["xyz"]["m"]),
                     V(ad["xyz"]["v"]), V(ad["shs"]["m"]), V(ad["shs"]["v"]), V(ad["raw8"]["m"]), V(ad["raw8"]["v"]),
                     V(st["xyz"]["lr"]), V(st["shs"]["lr"]), V(st["raw8"]["lr"]), V(ad["xyz"]["ever"]), V(ad["shs"]["ever"]),
-                    V(ad["raw8"]["ever"]), N, int(self.step_count), 0.9, 0.999, float(self.eps), C.c_void_p(stream))
+                    V(ad["raw8"]["ever"]), N, int(self.step_count), 0.9, 0.999, float(self.eps),
+                    C.byref(attach) if attach is not None else None,
+                    V(confidence) if confidence is not None else None, C.c_void_p(stream))
             _lib.check(rc, "rtgs_map_tail_rows")
         a.calls = 1
         self.last_render = (ws["color"], ws["depth"], ws["cidx"], ws["didx"], ws["cw"], ws["dw"], ws["T"])
         self.last_num_rendered = int(R.value)
-        return ws["loss"][3]
+        self.last_losses = ws["loss"]               # device float[4]: total, colour, depth, ssim (mapper.py:458-466)
+        return ws["loss"][0]
 
     def _exchange_rows(self, lib, ws, a, dev):
         """All ranks' gradient rows into this rank's arena, summed in rank order (see step_slam)."""
@@ -471,20 +519,46 @@ class ShardedMapOptimizer:
         return loss.detach()
 
 
-def slam_losses(render, gt_color: torch.Tensor, gt_depth: torch.Tensor,
-                color_weight: float = 0.8, depth_weight: float = 1.0) -> torch.Tensor:
-    """Sync-free restatement of the live losses of mapper.py:402-442 (L1 colour over the render
-    mask, masked L1 depth); `render` = (color[3,H,W], depth[1,H,W], ..., depth_index[1,H,W])."""
+def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11) -> torch.Tensor:
+    """utils/loss_utils.py:58-100 (11x11 Gaussian window, sigma 1.5, zero padding, mean of the map), torch ops."""
+    Cn = img1.shape[-3]
+    g = torch.tensor([math.exp(-((x - window_size // 2) ** 2) / float(2 * 1.5 ** 2)) for x in range(window_size)])
+    g = (g / g.sum()).to(img1)
+    win = (g[:, None] @ g[None, :])[None, None].expand(Cn, 1, window_size, window_size).contiguous()
+    a, b = img1.reshape(1, Cn, *img1.shape[-2:]), img2.reshape(1, Cn, *img2.shape[-2:])
+    conv = lambda t: torch.nn.functional.conv2d(t, win, padding=window_size // 2, groups=Cn)
+    mu1, mu2 = conv(a), conv(b)
+    s11, s22, s12 = conv(a * a) - mu1 * mu1, conv(b * b) - mu2 * mu2, conv(a * b) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s11 + s22 + C2))).mean()
+
+
+def slam_losses(render, gt_color: torch.Tensor, gt_depth: torch.Tensor, color_weight: float = 0.8,
+                depth_weight: float = 1.0, ssim_weight: float = 0.2, add_depth_thres: float = 0.1,
+                render_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Sync-free torch restatement of the image terms of Mapping.loss_update (mapper.py:402-448); `render` = the
+    rasterizer's tuple (color[3,H,W], depth[1,H,W], ..., depth_index[1,H,W] at [3]).
+      render_mask None -> every pixel AND the SSIM term 1 - ssim(render, gt) is live (:411-417); otherwise bool [H,W]
+      colour: mean |C - C_gt| over the mask (:421); depth: mean |D - D_gt| over depth_index != -1 & D_gt > 0 &
+      (D - D_gt) < add_depth_thres & mask (:423-431; an empty set gives 0 here, nan in the reference).
+    Weights: configs/base.yaml:78-81.  The HIP kernel `slam_losses_hip` computes the same thing."""
     color, depth, didx = render[0], render[1], render[3]
-    color_loss = (color - gt_color).abs().mean()
-    m = ((didx != -1) & (gt_depth > 0)).to(depth.dtype)
-    depth_loss = ((depth - gt_depth).abs() * m).sum() / m.sum().clamp_min(1.0)
-    return color_weight * color_loss + depth_weight * depth_loss
+    if render_mask is None:
+        m = torch.ones_like(depth[0])
+        ssim_loss = 1 - ssim(color, gt_color)
+    else:
+        m = render_mask.to(depth.dtype)
+        ssim_loss = 0.0
+    color_loss = ((color - gt_color).abs() * m).sum() / (3 * m.sum().clamp_min(1.0))
+    err = depth[0] - gt_depth[0]
+    vm = ((didx[0] != -1) & (gt_depth[0] > 0) & (err < add_depth_thres)).to(depth.dtype) * m
+    depth_loss = (err.abs() * vm).sum() / vm.sum().clamp_min(1.0)
+    return depth_weight * depth_loss + color_weight * color_loss + ssim_weight * ssim_loss
 
 
 class _SlamLossHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, color, depth, didx, gt_color, gt_depth, cw, dw):
+    def forward(ctx, color, depth, didx, gt_color, gt_depth, cw, dw, sw, thr, render_mask):
         from . import _lib
         lib = _lib.load()
         if not color.is_cuda:
@@ -493,23 +567,29 @@ class _SlamLossHip(torch.autograd.Function):
         H, W = int(color.shape[1]), int(color.shape[2])
         color, depth, didx = color.contiguous(), depth.contiguous(), didx.contiguous()
         gt_color, gt_depth = gt_color.contiguous(), gt_depth.contiguous()
-        buf = torch.empty(4, dtype=torch.float32, device=dev)            # [0:3] partial sums, [3] loss
+        rm = None if render_mask is None else (render_mask != 0).to(torch.uint8).contiguous()
+        loss4 = torch.empty(4, dtype=torch.float32, device=dev)
+        scratch = torch.empty(lib.rtgs_slam_loss_scratch_bytes(H, W, int(rm is None)), dtype=torch.uint8, device=dev)
         g_c, g_d = torch.empty_like(color), torch.empty_like(depth)
+        cfg = _lib.LossCfgC(float(cw), float(dw), float(sw), float(thr), rm.data_ptr() if rm is not None else None)
         stream = torch.cuda.current_stream(dev).cuda_stream
         P = lambda t: C.c_void_p(t.data_ptr())
         with torch.cuda.device(dev):
-            rc = lib.rtgs_slam_loss(P(color), P(depth), P(didx), P(gt_color), P(gt_depth), H, W, float(cw), float(dw),
-                                    P(buf), C.c_void_p(buf.data_ptr() + 12), P(g_c), P(g_d), C.c_void_p(stream))
+            rc = lib.rtgs_slam_loss(P(color), P(depth), P(didx), P(gt_color), P(gt_depth), H, W, C.byref(cfg), P(scratch),
+                                    P(loss4), P(g_c), P(g_d), C.c_void_p(stream))
         _lib.check(rc, "rtgs_slam_loss")
         ctx.save_for_backward(g_c, g_d)
-        return buf[3]
+        ctx.terms = loss4                      # [total, colour, depth, ssim] for reporting (mapper.py:458-466)
+        return loss4[0]
 
     @staticmethod
     def backward(ctx, g):
         g_c, g_d = ctx.saved_tensors
-        return g_c * g, g_d * g, None, None, None, None, None
+        return g_c * g, g_d * g, None, None, None, None, None, None, None, None
 
 
-def slam_losses_hip(render, gt_color, gt_depth, color_weight: float = 0.8, depth_weight: float = 1.0) -> torch.Tensor:
-    """Same loss as `slam_losses`, value and both image gradients from two HIP kernels."""
-    return _SlamLossHip.apply(render[0], render[1], render[3], gt_color, gt_depth, color_weight, depth_weight)
+def slam_losses_hip(render, gt_color, gt_depth, color_weight: float = 0.8, depth_weight: float = 1.0,
+                    ssim_weight: float = 0.2, add_depth_thres: float = 0.1, render_mask=None) -> torch.Tensor:
+    """Same loss as `slam_losses`: value and both image gradients from the fused HIP kernels (rtgs_slam_loss)."""
+    return _SlamLossHip.apply(render[0], render[1], render[3], gt_color, gt_depth, color_weight, depth_weight, ssim_weight,
+                              add_depth_thres, render_mask)

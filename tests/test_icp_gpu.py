@@ -49,13 +49,16 @@ def test_icp_step_vs_reference(golden_dir, name):
         assert float((Jtr.cpu() - rj).abs().max()) <= 1e-4 * float(rj.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("name", ["small_clean", "small_noisy"])
-def test_track_vs_reference(golden_dir, name):
+def test_track_vs_reference(golden_dir, name, persistent):
+    """Both forms of the track (one launch per iteration / one persistent kernel) against the reference's own pose."""
     from rtg_slam_amd import icp
     g = load(golden_dir, name)
     mk = lambda p: [g[f"{p}_{l}"].to(DEV) for l in range(3)]
     out = icp.icp_track(mk("v1"), mk("n1"), mk("v0"), mk("n0"), g["K"], [0.25, 0.5, 1.0], [5, 5, 5], 0.1,
-                        float(np.cos(np.deg2rad(20.0))), 1e-4).cpu()
+                        float(np.cos(np.deg2rad(20.0))), 1e-4, persistent=persistent).cpu()
+    assert float(out[19]) == 0
     pose = out[:16].reshape(4, 4)
     assert float((pose - g["pose_final"]).abs().max()) < 1e-5
     assert abs(float(out[16]) - float(g["valid_ratio"])) < 1e-4
@@ -86,8 +89,9 @@ class Args:
     verbose = False
 
 
-@pytest.mark.parametrize("cam,noise", [(synth.TUM_FR1, True), (synth.REPLICA, False)])
-def test_tracker_class_vs_oracle_full_size(cam, noise):
+@pytest.mark.parametrize("cam,noise,persistent", [(synth.TUM_FR1, True, False), (synth.REPLICA, False, False),
+                                                  (synth.TUM_FR1, True, True), (synth.REPLICA, False, True)])
+def test_tracker_class_vs_oracle_full_size(cam, noise, persistent):
     """IcpTracker API (SLAM/icp.py:357-452) on Replica / TUM shaped frames vs the pinned oracle."""
     from rtg_slam_amd.icp import IcpTracker
     poses = synth.trajectory(2, seed=9)
@@ -97,7 +101,9 @@ def test_tracker_class_vs_oracle_full_size(cam, noise):
     if noise:
         d0, d1 = synth.tum_noise(d0, 1), synth.tum_noise(d1, 2)
     K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32)
-    tr = IcpTracker(Args())
+    args = Args()
+    args.icp_persistent = persistent
+    tr = IcpTracker(args)
     tr.update_curr_status(d0.to(DEV), K.to(DEV))
     tr.move_last_status()
     tr.update_curr_status(d1.to(DEV), K.to(DEV))

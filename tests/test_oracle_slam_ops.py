@@ -107,3 +107,21 @@ def test_knn_definition_and_error_accumulation_properties():
     gc, gd, gn, oc = so.accumulate_gaussian_error(H, W, P, ce, de, ne, ci, di, 0.25, 0.2, 1000, True)
     assert torch.allclose(gc, torch.tensor([0.0, 0.2, 0.5])) and torch.allclose(gd, torch.tensor([0.3, 0.0, 0.0]))
     assert oc.tolist() == [3, 2, 1] and float(gn.abs().max()) == 0
+
+
+def test_product_torch_loss_equals_the_oracle_restatement():
+    """rtg_slam_amd.map_optim.slam_losses / ssim (the sync-free torch form the gloo tests and the HIP kernel are checked
+    against) vs oracle/slam_ops_oracle.py's restatement of mapper.py:402-448, masked and unmasked."""
+    from rtg_slam_amd import map_optim as mo
+    g = torch.Generator().manual_seed(8)
+    H, W = 37, 53
+    color, depth = torch.rand(3, H, W, generator=g), torch.rand(1, H, W, generator=g) * 3
+    didx = torch.randint(-1, 4, (1, H, W), generator=g, dtype=torch.int32)
+    gt_c = torch.rand(3, H, W, generator=g)
+    gt_d = (depth + 0.3 * torch.randn(1, H, W, generator=g)).clamp_min(0)
+    render = (color, depth, None, didx)
+    assert abs(float(mo.ssim(color, gt_c)) - float(so.ssim(color, gt_c))) < 1e-7
+    for rm in (None, torch.rand(H, W, generator=g) < 0.5):
+        a = mo.slam_losses(render, gt_c, gt_d, render_mask=rm)
+        b, _ = so.slam_loss(render, gt_c, gt_d, render_mask=rm)
+        assert abs(float(a) - float(b)) < 1e-6

@@ -246,7 +246,11 @@ def test_matches_committed_golden(golden_dir):
         assert float((gd_h[k] - r).abs().max()) / (float(r.abs().max()) + 1e-12) < 1e-3, k
 
 
-def test_fused_loss_matches_torch():
+@pytest.mark.parametrize("masked", [False, True])
+def test_fused_loss_matches_torch(masked):
+    """rtgs_slam_loss (HIP) vs map_optim.slam_losses (torch; pinned to the oracle's restatement of mapper.py:402-448 and
+    to the reference's own ssim in tests/test_oracle_slam_ops.py / test_dist_cpu.py): value, the four reported terms and
+    both image gradients - with a render mask (masked L1 + gated depth) and without (all pixels + the SSIM term)."""
     from rtg_slam_amd import map_optim as mo
     dev = "cuda:0"
     gen = torch.Generator().manual_seed(4)
@@ -255,14 +259,76 @@ def test_fused_loss_matches_torch():
     depth = (torch.rand(1, H, W, generator=gen) * 3).to(dev).requires_grad_(True)
     didx = (torch.randint(-1, 5, (1, H, W), generator=gen, dtype=torch.int32)).to(dev)
     gt_c = torch.rand(3, H, W, generator=gen).to(dev)
-    gt_d = (torch.rand(1, H, W, generator=gen) * 3 - 0.5).clamp_min(0).to(dev)
+    gt_d = (depth.detach() + 0.3 * torch.randn(1, H, W, generator=gen).to(dev)).clamp_min(0)      # errors on both sides of 0.1
+    gt_d[0, ::5] = 0
+    rm = (torch.rand(H, W, generator=gen) < 0.6).to(dev) if masked else None
     render = (color, depth, None, didx)
-    la = mo.slam_losses(render, gt_c, gt_d)
+    la = mo.slam_losses(render, gt_c, gt_d, render_mask=rm)
     ga = torch.autograd.grad(la, [color, depth])
-    lb = mo.slam_losses_hip(render, gt_c, gt_d)
+    lb = mo.slam_losses_hip(render, gt_c, gt_d, render_mask=rm)
     gb = torch.autograd.grad(lb * 2.0, [color, depth])
-    assert abs(float(la) - float(lb)) < 1e-6 * max(1.0, abs(float(la)))
-    assert float((ga[0] * 2 - gb[0]).abs().max()) < 1e-9 and float((ga[1] * 2 - gb[1]).abs().max()) < 1e-7
+    assert abs(float(la.detach()) - float(lb.detach())) < 2e-6 * max(1.0, abs(float(la.detach())))
+    sc = float(ga[0].abs().max())
+    assert float((ga[0] * 2 - gb[0]).abs().max()) < (1e-5 * sc if not masked else 1e-9)       # SSIM gradient: conv order
+    assert float((ga[1] * 2 - gb[1]).abs().max()) < 1e-7
+    if masked:
+        assert float(gb[0][:, ~rm].abs().max()) == 0 and float(gb[1][0][~rm].abs().max()) == 0
+    else:
+        from oracle import slam_ops_oracle as so
+        want = 1 - so.ssim(color.detach().cpu(), gt_c.cpu())
+        terms = lb.grad_fn.terms.cpu() if hasattr(lb.grad_fn, "terms") else None
+        assert terms is None or abs(float(terms[3]) - float(want)) < 2e-6
+
+
+def test_step_slam_attach_regulariser_and_confidence():
+    """The one-call step with the remaining pieces of loss_update: attach regulariser on Gaussians whose initial opacity
+    is below 0.9 (mapper.py:384-401) and the confidence increment from non-zero f_dc gradients (:454-456), against the
+    autograd path with the same loss written in torch."""
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    from rtg_slam_amd import map_optim as mo
+    dev = "cuda:0"
+    N = 4000
+    g, s = ru.make_scene(N, SMALL, seed=9, pose_seed=1)            # opacity 0.99 w.p. 0.8 else 0.1: ~20 % are attached
+    packed = mo.pack_from_activated({k: v.to(dev) for k, v in g.items()})
+    gen = torch.Generator().manual_seed(2)
+    gt_c = torch.rand(3, SMALL.H, SMALL.W, generator=gen).to(dev)
+    gt_d = (1.0 + torch.rand(1, SMALL.H, SMALL.W, generator=gen)).to(dev)
+    rm = (torch.rand(SMALL.H, SMALL.W, generator=gen) < 0.7).to(dev)
+    rs = ru.hip_settings(s, dev)
+    rast = GaussianRasterizer(raster_settings=rs)
+    oa, ob = mo.ShardedMapOptimizer(packed.clone()), mo.ShardedMapOptimizer(packed.clone())
+    ob.begin_local_optimization()
+    init = packed.clone()
+    sel = torch.sigmoid(init[:, 51]) < 0.9
+    assert 0 < int(sel.sum()) < N
+    conf = torch.zeros(N, device=dev)
+    conf_ref = torch.zeros(N, device=dev)
+    for step in range(4):
+        # autograd reference: image loss + attach regulariser in torch on the same leaves, dense fused Adam
+        leaves = {n: oa.state[n]["p"][:N].detach().clone().requires_grad_(True) for n in ("xyz", "shs", "raw8")}
+        gd = mo.activate8_hip(leaves["raw8"])
+        gd["xyz"], gd["shs"] = leaves["xyz"], leaves["shs"].view(N, 16, 3)
+        out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
+                   rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=None)
+        l2 = lambda a, b: ((a - b) ** 2).mean()
+        attach = 1000 * (l2(leaves["raw8"][sel][:, 1:4], init[sel][:, 52:55]) + l2(leaves["xyz"][sel], init[sel][:, 0:3])
+                         + l2(leaves["raw8"][sel][:, 4:8], init[sel][:, 55:59]))
+        total = mo.slam_losses_hip(out, gt_c, gt_d, render_mask=rm) + attach
+        grads = torch.autograd.grad(total, [leaves["xyz"], leaves["shs"], leaves["raw8"]])
+        conf_ref += (grads[1].view(N, 16, 3)[:, 0].abs() != 0).any(-1).float()
+        oa.step_count += 1
+        for (name, _, _), gr in zip(mo.BLOCKS, grads):
+            st = oa.state[name]
+            mo._adam_hip(st["p"][:N], gr.contiguous(), st["m"], st["v"], st["lr"], oa.step_count, oa.eps)
+        att_b = float(ob.attach_loss())                              # value at the parameters the step starts from
+        lb = ob.step_slam(rs, gt_c, gt_d, None, render_mask=rm, confidence=conf)
+        assert abs(float(lb) - float((total - attach).detach())) <= 1e-4 * max(1.0, abs(float(total.detach()))), step
+        assert abs(att_b - float(attach.detach())) <= 1e-3 * max(1e-9, abs(float(attach.detach()))) + 1e-12, step
+    pa, pb = oa.params.cpu(), ob.params.cpu()
+    assert ru.frac_bad(pa, pb, 1e-5) < 2e-3
+    assert torch.equal(conf.cpu(), conf_ref.cpu()) and 0 < float(conf.max()) <= 4
+    moved = (pb - packed.cpu()).abs().max(dim=1).values > 0
+    assert bool(moved[sel.cpu()].any())
 
 
 def test_automatic_fallbacks():

@@ -34,7 +34,7 @@ for _ in range(iters):
     torch.cuda.synchronize()
     tp += e0.elapsed_time(e1) / iters
     tt += e1.elapsed_time(e2) / iters
-print(f"persistent={os.environ.get('RTGS_ICP_PERSISTENT', '1')} {cam.H}x{cam.W}: pyramids {tp * 1e3:.0f} us, track {tt * 1e3:.0f} us, stats {out[16:].tolist()}")
+print(f"persistent={os.environ.get('RTGS_ICP_PERSISTENT', '0 (default)')} {cam.H}x{cam.W}: pyramids {tp * 1e3:.0f} us, track {tt * 1e3:.0f} us, stats {out[16:].tolist()}")
 
 if os.environ.get("RTGS_ICP_DEBUG_TIMING"):
     import numpy as np

@@ -26,15 +26,17 @@ rs = GaussianRasterizationSettings(
     T_threshold=1e-4)
 gt_color = torch.rand(3, cam.H, cam.W, generator=torch.Generator().manual_seed(7)).to(dev)
 gt_depth = synth.box_room_depth(cam, torch.eye(4, dtype=torch.float64), bump=0.0).to(dev).reshape(1, cam.H, cam.W)
+rm = torch.ones(cam.H, cam.W, dtype=torch.uint8, device=dev)
+opt.begin_local_optimization()
 for _ in range(20):
-    opt.step_slam(rs, gt_color, gt_depth, None)
+    opt.step_slam(rs, gt_color, gt_depth, None, render_mask=rm)
 torch.cuda.synchronize()
 lib.rtgs_raster_set_profiling(1)
 acc = [0.0] * 10
 import time
 t0 = time.perf_counter()
 for _ in range(iters):
-    opt.step_slam(rs, gt_color, gt_depth, None)
+    opt.step_slam(rs, gt_color, gt_depth, None, render_mask=rm)
     ms = (C.c_float * 10)()
     lib.rtgs_raster_last_timings(ms)
     for k in range(10):
