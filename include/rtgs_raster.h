@@ -198,12 +198,13 @@ void rtgs_raster_set_counters_ctx(rtgs_ctx* ctx, void* counters);
 
 /* Optional per-stage HIP-event timing of the calls made through the context (off by default;
  * measurement aid - the backward of a forward must use the same context for its stages to show up).
- * rtgs_raster_last_timings fills ms10_host[0..7] with the last forward/backward's stage
+ * rtgs_raster_last_timings fills ms12_host[0..11] with the last forward/backward's stage
  * durations in milliseconds (-1 = stage did not run):
  *   [0] preprocess_fwd (+ mask SAT)  [1] bin_count + tilescan (fallback: scan)  [2] bin_scatter
  *   (fallback: emit_keys)  [3] bin_tilesort (fallback: radix sort)  [4] tile_ranges (fallback only)
- *   [5] blend_fwd  [6] grad memset + blend_bwd  [7] preprocess_bwd
+ *   [5] blend_fwd  [6] slot-counter memset + blend_bwd (both launches)  [7] preprocess_bwd
  *   [8] near-slice binning (histogram, count, scan, scatter, sort)  [9] near-slice blend_fwd
+ *   [10] grad_reduce (sum of the gradient slots per Gaussian)  [11] unused
  * With the near-slice pass on, [1]..[5] describe the second pass (tiles the slice left unfinished). */
 void rtgs_raster_set_profiling(int enable);
 void rtgs_raster_set_profiling_ctx(rtgs_ctx* ctx, int enable);
@@ -227,8 +228,8 @@ int rtgs_raster_last_slice_stats_ctx(rtgs_ctx* ctx, int64_t* out4_host);
  * otherwise taken only when the tile grid or one tile list exceeds the LDS-resident path. */
 void rtgs_raster_force_sort_path(int enable);
 void rtgs_raster_force_sort_path_ctx(rtgs_ctx* ctx, int enable);
-int rtgs_raster_last_timings(float* ms10_host);
-int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms10_host);
+int rtgs_raster_last_timings(float* ms12_host);
+int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms12_host);
 
 /* Fused Adam over a packed [rows, cols] float32 parameter shard with one learning rate per
  * column (the six Adam groups of SLAM/gaussian_pointcloud.py:245-284; torch.optim.Adam
@@ -279,13 +280,15 @@ int rtgs_attach_prepare(const float* xyz, const float* raw8, const rtgs_attach* 
  * ONE launch (the tail of rtgs_slam_map_step).  g_* are the persistent gradient rows of rtgs_raster_backward_rows,
  * row_state its state bytes; g_raw8 is written for state 1 (value) and state 2 (zero) rows.
  *   attach     (nullable) adds the attach regulariser's gradient to the selected rows (rtgs_attach_prepare must have run)
- *   confidence (nullable) float[rows]: += 1 for every row whose f_dc gradient is non-zero (mapper.py:454-456) */
+ *   confidence (nullable) float[rows]: += 1 for every row whose f_dc gradient is non-zero (mapper.py:454-456)
+ *   skip_flag  (nullable) device word: non-zero = do nothing (an overflowed multi-GPU exchange, see rtgs_rows_overflow) */
 int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const float* g_opacity, const float* g_scales,
                        const float* g_rotations, const float* g_normal, const float* g_xyz, const float* g_shs,
                        float* g_raw8, const uint8_t* row_state, float* m_xyz, float* v_xyz, float* m_shs, float* v_shs,
                        float* m_raw8, float* v_raw8, const float* lr_xyz, const float* lr_shs, const float* lr_raw8,
                        uint8_t* ever_xyz, uint8_t* ever_shs, uint8_t* ever_raw8, int64_t rows, int32_t step, float beta1,
-                       float beta2, float eps, const rtgs_attach* attach, float* confidence, void* stream);
+                       float beta2, float eps, const rtgs_attach* attach, float* confidence, const uint32_t* skip_flag,
+                       void* stream);
 
 /* Fused SLAM loss: the image terms of Mapping.loss_update (mapper.py:402-448) - value and BOTH image gradients
  * (dL/dC [3,H,W], dL/dD [1,H,W]), so the autograd graph of ~40 elementwise launches collapses into a few kernels.
@@ -305,6 +308,15 @@ size_t rtgs_slam_loss_scratch_bytes(int32_t H, int32_t W, int32_t with_ssim);
 int rtgs_slam_loss(const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
                    const float* gt_depth, int32_t H, int32_t W, const rtgs_loss_cfg* cfg, void* scratch,
                    float* loss_out4, float* g_color, float* g_depth, void* stream);
+/* The two halves of rtgs_slam_loss.  _sums leaves {sum |dC|, sum |dD|, #valid-depth, #mask, sum SSIM} in
+ * ((float*)scratch)[0..4]; _grads turns them into the loss values and both image gradients.  A multi-GPU caller that
+ * splits ONE view into tile bands all-reduces those five floats in between (the normalisers count pixels of the whole
+ * image); such a caller must pass a render mask (the SSIM window crosses band boundaries). */
+int rtgs_slam_loss_sums(const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
+                        const float* gt_depth, int32_t H, int32_t W, const rtgs_loss_cfg* cfg, void* scratch, void* stream);
+int rtgs_slam_loss_grads(const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
+                         const float* gt_depth, int32_t H, int32_t W, const rtgs_loss_cfg* cfg, void* scratch,
+                         float* loss_out4, float* g_color, float* g_depth, void* stream);
 
 /* One map-optimisation iteration as a single call (the body of local_optimize's inner loop, mapper.py:176-205, with
  * loss_update's image terms, attach regulariser, Adam step and confidence increment, mapper.py:371-456):
@@ -351,16 +363,25 @@ int rtgs_slam_map_step_front(const rtgs_map_step_args* args, int64_t* num_render
 int rtgs_slam_map_step_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
 int rtgs_slam_map_step_front_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
 
-/* Sparse gradient exchange for replicated multi-GPU optimisation: only rows that received gradient travel.
- * rtgs_rows_pack compacts the state-1 rows of a row-state arena into out_rows[*, 64] (word 0 = Gaussian id as bits,
- * 1..3 d_xyz, 4..51 d_shs, 52 d_opacity, 53..55 d_scales, 56..59 d_rotations, 60..62 d_normal) and their number into
- * *out_count (device word).  rtgs_rows_apply writes a packed list back into an arena: mode 0 zeroes the listed rows,
- * mode 1 adds them and marks the rows state 1.  A rank zeroes its own rows, then adds the lists of ranks 0..W-1 in that
- * order - every replica sums in the same order - and runs rtgs_map_tail_rows. */
+/* Sparse gradient exchange for multi-GPU optimisation: only rows that received gradient travel, in fixed-capacity lists
+ * whose length rides in band - no host synchronisation before the collective.
+ *   list = [1 + capacity] rows x 64 float words.  Row 0: [0] number of rows the sender had (uint32 bits; > capacity =
+ *   overflow, the list is then incomplete), [1] capacity.  Data row: [0] Gaussian id (uint32 bits), 1..3 d_xyz, 4..51
+ *   d_shs, 52 d_opacity, 53..55 d_scales, 56..59 d_rotations, 60..62 d_normal.
+ * rtgs_rows_pack compacts the state-1 rows of a row-state arena into such a list (count_scratch: device uint32).
+ * rtgs_rows_overflow reads the headers of `world` gathered lists (laid out back to back) and writes
+ * flag_and_counts[0] = 1 if any sender overflowed, [1 + r] = rank r's count.  rtgs_rows_apply writes a list back into an
+ * arena - mode 0 zeroes the listed rows, mode 1 adds them and marks the rows state 1 - and does nothing when *skip_flag
+ * is non-zero (pass the overflow flag; NULL = never skip).  A rank zeroes its own rows, then adds the lists of ranks
+ * 0..W-1 in that order - every replica sums in the same order - and runs rtgs_map_tail_rows with the same skip_flag.
+ * After an overflow nothing was changed on any rank; the host enlarges the capacity and repeats the exchange. */
 int rtgs_rows_pack(const uint8_t* row_state, int32_t P, float* d_xyz, float* d_shs, float* d_opacity, float* d_scales,
-                   float* d_rotations, float* d_normal, float* out_rows, uint32_t* out_count, void* stream);
-int rtgs_rows_apply(const float* rows, int32_t n_rows, int32_t mode, float* d_xyz, float* d_shs, float* d_opacity,
-                    float* d_scales, float* d_rotations, float* d_normal, uint8_t* row_state, void* stream);
+                   float* d_rotations, float* d_normal, float* out_list, int32_t capacity, uint32_t* count_scratch,
+                   void* stream);
+int rtgs_rows_overflow(const float* gathered_lists, int32_t world, int32_t capacity, uint32_t* flag_and_counts, void* stream);
+int rtgs_rows_apply(const float* list, int32_t capacity, int32_t mode, float* d_xyz, float* d_shs, float* d_opacity,
+                    float* d_scales, float* d_rotations, float* d_normal, uint8_t* row_state, const uint32_t* skip_flag,
+                    void* stream);
 
 /* sizeof of the two structs above, for bindings that mirror them (rtg_slam_amd/_lib.py checks both at load time). */
 size_t rtgs_map_step_args_size(void);

@@ -96,16 +96,19 @@ _SIGNATURES = {
     "rtgs_map_activate8_backward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "rtgs_map_activate8_backward_rows": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "rtgs_map_tail_rows": (C.c_int, [_P] * 23 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float,
-                                     C.POINTER(AttachC), _P, _P]),
+                                     C.POINTER(AttachC), _P, _P, _P]),
     "rtgs_attach_prepare": (C.c_int, [_P, _P, C.POINTER(AttachC), C.c_int64, _P]),
     "rtgs_slam_loss_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rtgs_slam_map_step_front": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
-    "rtgs_rows_pack": (C.c_int, [_P, C.c_int32] + [_P] * 8 + [_P]),
-    "rtgs_rows_apply": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 7 + [_P]),
+    "rtgs_rows_pack": (C.c_int, [_P, C.c_int32] + [_P] * 7 + [C.c_int32, _P, _P]),
+    "rtgs_rows_overflow": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    "rtgs_rows_apply": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 7 + [_P, _P]),
     "rtgs_map_step_args_size": (C.c_size_t, []),
     "rtgs_raster_settings_size": (C.c_size_t, []),
     "rtgs_slam_map_step": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_slam_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(LossCfgC), _P, _P, _P, _P, _P]),
+    "rtgs_slam_loss_sums": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(LossCfgC), _P, _P]),
+    "rtgs_slam_loss_grads": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(LossCfgC), _P, _P, _P, _P, _P]),
     "rtgs_raster_set_profiling": (None, [C.c_int]),
     "rtgs_raster_force_sort_path": (None, [C.c_int]),
     "rtgs_raster_set_near_slice": (None, [C.c_int, C.c_int]),

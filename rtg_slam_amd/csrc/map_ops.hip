@@ -168,6 +168,7 @@ struct TailArgs {
   const float4* init_raw8;
   const float* attach_info;       // [0] = number of selected rows
   float* confidence;
+  const uint32_t* skip_flag;      // multi-GPU: non-zero = the gradient exchange of this step overflowed, do nothing
 };
 
 __device__ __forceinline__ bool attach_selected(const float4 init_lo) {
@@ -176,6 +177,7 @@ __device__ __forceinline__ bool attach_selected(const float4 init_lo) {
 
 __global__ void __launch_bounds__(256) map_tail_rows_kernel(TailArgs a) {
   __shared__ int s_rows[4][64];
+  if (a.skip_flag && a.skip_flag[0] != 0u) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long wave0 = (long long)blockIdx.x * 4 + wv, nwaves = (long long)gridDim.x * 4;
   for (long long base = wave0 * 64; base < a.rows; base += nwaves * 64) {
@@ -331,7 +333,8 @@ extern "C" int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const flo
                                   float* v_shs, float* m_raw8, float* v_raw8, const float* lr_xyz, const float* lr_shs,
                                   const float* lr_raw8, uint8_t* ever_xyz, uint8_t* ever_shs, uint8_t* ever_raw8,
                                   int64_t rows, int32_t step, float beta1, float beta2, float eps,
-                                  const rtgs_attach* attach, float* confidence, void* stream) {
+                                  const rtgs_attach* attach, float* confidence, const uint32_t* skip_flag,
+                                  void* stream) {
   if (rows < 0 || step < 1) return -1;
   if (rows == 0) return 0;
   if (!xyz || !shs || !raw8 || !g_opacity || !g_scales || !g_rotations || !g_normal || !g_xyz || !g_shs || !g_raw8 ||
@@ -347,6 +350,7 @@ extern "C" int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const flo
   a.ever_xyz = ever_xyz; a.ever_shs = ever_shs; a.ever_raw8 = ever_raw8;
   a.rows = rows; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
   a.init_xyz = nullptr; a.init_raw8 = nullptr; a.attach_info = nullptr; a.confidence = confidence;
+  a.skip_flag = skip_flag;
   if (attach) {
     if (!attach->init_xyz || !attach->init_raw8 || !attach->attach_info) return -1;
     a.init_xyz = attach->init_xyz; a.init_raw8 = (const float4*)attach->init_raw8; a.attach_info = attach->attach_info;
@@ -360,14 +364,20 @@ extern "C" int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sparse gradient exchange of the replicated multi-GPU map step (map_optim.ShardedMapOptimizer.step_slam with more
-// than one rank): only the rows that received gradient travel.  A packed row is 64 words:
-//   [0] Gaussian id  [1..3] d_xyz  [4..51] d_shs  [52] d_opacity  [53..55] d_scales  [56..59] d_rotations
-//   [60..62] d_normal  [63] unused
+// Sparse gradient exchange of the multi-GPU map step (map_optim.ShardedMapOptimizer.step_slam with more than one
+// rank): only the rows that received gradient travel, in fixed-capacity lists whose length rides IN BAND - the host
+// never reads a count before it launches the collective.  A list is [1 + capacity] rows of 64 words:
+//   row 0 (header)  [0] number of rows the sender HAD (may exceed the capacity: the list then holds the first
+//                       `capacity` of them and is useless - see overflow below)   [1] capacity
+//   data row        [0] Gaussian id  [1..3] d_xyz  [4..51] d_shs  [52] d_opacity  [53..55] d_scales  [56..59] d_rotations
+//                   [60..62] d_normal  [63] unused
 // rows_pack compacts the state-1 rows of the row-state arena (ids staged in LDS, one global atomic per workgroup);
-// rows_apply zeroes (mode 0) or adds (mode 1, also sets the row's state to 1) a packed list back into an arena.  Every
-// rank zeroes its own rows and then adds the lists of ranks 0..W-1 in that order, so all replicas sum in the same
-// order and stay bit-identical.
+// rows_overflow looks at the W gathered headers and raises a device flag if any sender overflowed; rows_apply zeroes
+// (mode 0) or adds (mode 1, also sets the row's state to 1) a list into an arena - and does nothing when the flag is
+// up, as does the Adam tail: an overflowing step leaves parameters, arena and states untouched on every rank (all see
+// the same headers), and the host - which learns of it one step later, from an asynchronous copy - repeats the
+// exchange with a larger capacity.  Every rank zeroes its own rows and then adds the lists of ranks 0..W-1 in that
+// order, so all replicas sum in the same order and stay bit-identical.
 // ---------------------------------------------------------------------------------------------
 namespace rtgs {
 
@@ -388,7 +398,8 @@ __device__ __forceinline__ float* arena_word(const ArenaPtrs& a, uint32_t id, in
 }
 
 __global__ void __launch_bounds__(256) rows_pack_kernel(const uint8_t* __restrict__ row_state, int P, ArenaPtrs a,
-                                                        float* __restrict__ out_rows, uint32_t* __restrict__ out_count) {
+                                                        float* __restrict__ list, uint32_t capacity,
+                                                        uint32_t* __restrict__ out_count) {
   __shared__ uint32_t s_ids[PACK_CHUNK];
   __shared__ uint32_t s_n, s_base;
   if (threadIdx.x == 0) s_n = 0;
@@ -412,18 +423,37 @@ __global__ void __launch_bounds__(256) rows_pack_kernel(const uint8_t* __restric
   const uint32_t base = s_base;
   const int w = threadIdx.x & 63;
   for (uint32_t k = threadIdx.x >> 6; k < n; k += 4) {                             // one wave per row, one word per lane
+    if (base + k >= capacity) break;                                               // overflow: the header will tell
     const uint32_t id = s_ids[k];
     float v = 0.f;
     if (w == 0) v = __uint_as_float(id);
     else if (w < 63) v = *arena_word(a, id, w);
-    out_rows[(size_t)(base + k) * ROW_WORDS + w] = v;
+    list[(size_t)(1 + base + k) * ROW_WORDS + w] = v;
   }
 }
+__global__ void rows_header_kernel(float* __restrict__ list, const uint32_t* __restrict__ count, uint32_t capacity) {
+  list[0] = __uint_as_float(count[0]);
+  list[1] = __uint_as_float(capacity);
+}
 
-__global__ void __launch_bounds__(256) rows_apply_kernel(const float* __restrict__ rows, int n_rows, int mode, ArenaPtrs a,
-                                                         uint8_t* __restrict__ row_state) {
+// flag_out[0] = 1 if any of the W gathered lists overflowed its capacity, else 0; flag_out[1 + r] = count of rank r
+__global__ void rows_overflow_kernel(const float* __restrict__ gathered, int W, uint32_t capacity, uint32_t* __restrict__ flag_out) {
+  uint32_t over = 0;
+  for (int r = 0; r < W; ++r) {
+    const uint32_t c = __float_as_uint(gathered[(size_t)r * (1 + capacity) * ROW_WORDS]);
+    flag_out[1 + r] = c;
+    over |= c > capacity ? 1u : 0u;
+  }
+  flag_out[0] = over;
+}
+
+__global__ void __launch_bounds__(256) rows_apply_kernel(const float* __restrict__ list, uint32_t capacity, int mode, ArenaPtrs a,
+                                                         uint8_t* __restrict__ row_state, const uint32_t* __restrict__ skip_flag) {
+  if (skip_flag && skip_flag[0] != 0u) return;
+  const uint32_t n = min(__float_as_uint(list[0]), capacity);
+  const float* rows = list + ROW_WORDS;
   const int w = threadIdx.x & 63;
-  for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_rows; k += gridDim.x * 4) {
+  for (uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n; k += gridDim.x * 4) {
     const uint32_t id = __float_as_uint(rows[(size_t)k * ROW_WORDS]);
     if (w == 0) { if (mode == 1) row_state[id] = 1; }
     else if (w < 63) {
@@ -437,31 +467,40 @@ __global__ void __launch_bounds__(256) rows_apply_kernel(const float* __restrict
 }  // namespace rtgs
 
 extern "C" int rtgs_rows_pack(const uint8_t* row_state, int32_t P, float* d_xyz, float* d_shs, float* d_opacity,
-                              float* d_scales, float* d_rotations, float* d_normal, float* out_rows, uint32_t* out_count,
-                              void* stream) {
-  if (P < 0 || (P > 0 && (!row_state || !d_xyz || !d_shs || !d_opacity || !d_scales || !d_rotations || !d_normal ||
-                          !out_rows || !out_count)))
-    return -1;
+                              float* d_scales, float* d_rotations, float* d_normal, float* out_list, int32_t capacity,
+                              uint32_t* count_scratch, void* stream) {
+  if (P < 0 || capacity < 1 || !out_list || !count_scratch) return -1;
+  if (P > 0 && (!row_state || !d_xyz || !d_shs || !d_opacity || !d_scales || !d_rotations || !d_normal)) return -1;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(out_count, 0, sizeof(uint32_t), st) != hipSuccess) return -2;
-  if (P == 0) return 0;
-  const rtgs::ArenaPtrs a{d_xyz, d_shs, d_opacity, d_scales, d_rotations, d_normal};
-  hipLaunchKernelGGL(rtgs::rows_pack_kernel, dim3((P + rtgs::PACK_CHUNK - 1) / rtgs::PACK_CHUNK), dim3(256), 0, st,
-                     row_state, P, a, out_rows, out_count);
+  if (hipMemsetAsync(count_scratch, 0, sizeof(uint32_t), st) != hipSuccess) return -2;
+  if (P > 0) {
+    const rtgs::ArenaPtrs a{d_xyz, d_shs, d_opacity, d_scales, d_rotations, d_normal};
+    hipLaunchKernelGGL(rtgs::rows_pack_kernel, dim3((P + rtgs::PACK_CHUNK - 1) / rtgs::PACK_CHUNK), dim3(256), 0, st,
+                       row_state, P, a, out_list, (uint32_t)capacity, count_scratch);
+  }
+  hipLaunchKernelGGL(rtgs::rows_header_kernel, dim3(1), dim3(1), 0, st, out_list, (const uint32_t*)count_scratch,
+                     (uint32_t)capacity);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-extern "C" int rtgs_rows_apply(const float* rows, int32_t n_rows, int32_t mode, float* d_xyz, float* d_shs,
+extern "C" int rtgs_rows_overflow(const float* gathered, int32_t world, int32_t capacity, uint32_t* flag_and_counts,
+                                  void* stream) {
+  if (!gathered || world < 1 || world > 64 || capacity < 1 || !flag_and_counts) return -1;
+  hipLaunchKernelGGL(rtgs::rows_overflow_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, gathered, world, (uint32_t)capacity,
+                     flag_and_counts);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int rtgs_rows_apply(const float* list, int32_t capacity, int32_t mode, float* d_xyz, float* d_shs,
                                float* d_opacity, float* d_scales, float* d_rotations, float* d_normal, uint8_t* row_state,
-                               void* stream) {
-  if (n_rows < 0 || (mode != 0 && mode != 1)) return -1;
-  if (n_rows == 0) return 0;
-  if (!rows || !d_xyz || !d_shs || !d_opacity || !d_scales || !d_rotations || !d_normal || !row_state) return -1;
+                               const uint32_t* skip_flag, void* stream) {
+  if (capacity < 1 || (mode != 0 && mode != 1)) return -1;
+  if (!list || !d_xyz || !d_shs || !d_opacity || !d_scales || !d_rotations || !d_normal || !row_state) return -1;
   const rtgs::ArenaPtrs a{d_xyz, d_shs, d_opacity, d_scales, d_rotations, d_normal};
-  int blocks = (n_rows + 3) / 4;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(rtgs::rows_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, n_rows, mode, a,
-                     row_state);
+  int blocks = (capacity + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rtgs::rows_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, list, (uint32_t)capacity, mode,
+                     a, row_state, skip_flag);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -650,40 +689,68 @@ extern "C" size_t rtgs_slam_loss_scratch_bytes(int32_t H, int32_t W, int32_t wit
   return 8 * sizeof(float) + (with_ssim ? (size_t)9 * (size_t)H * (size_t)W * sizeof(float) : 0);
 }
 
-extern "C" int rtgs_slam_loss(const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
-                              const float* gt_depth, int32_t H, int32_t W, const rtgs_loss_cfg* cfg, void* scratch,
-                              float* loss_out4, float* g_color, float* g_depth, void* stream) {
+static void ssim_window(rtgs::SsimWin& win) {
+  float gf[11], totf = 0.f;
+  for (int i = 0; i < 11; ++i) { gf[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); totf += gf[i]; }
+  for (int i = 0; i < 11; ++i) win.g[i] = gf[i] / totf;          // torch.Tensor([...]) / sum, in float32 (loss_utils.py:39-46)
+}
+
+// First half: the five sums (scratch[0..4]); with the SSIM term live also the per-pixel derivative maps.
+extern "C" int rtgs_slam_loss_sums(const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
+                                   const float* gt_depth, int32_t H, int32_t W, const rtgs_loss_cfg* cfg, void* scratch,
+                                   void* stream) {
+  if (!color || !depth || !depth_index || !gt_color || !gt_depth || !cfg || !scratch || H <= 0 || W <= 0) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t hw = (int64_t)H * W;
+  float* sums = (float*)scratch;
+  const bool ssim = cfg->render_mask == nullptr && cfg->ssim_weight != 0.f;
+  if (hipMemsetAsync(sums, 0, 8 * sizeof(float), st) != hipSuccess) return -2;
+  int64_t blocks = (hw + 255) / 256;
+  // the sums kernel ends with four same-address global atomics per workgroup (~20 ns each, serialised): keep it to
+  // 192 workgroups (1 024 of them cost 20 us for a 23 MB read)
+  if (blocks > 192) blocks = 192;
+  hipLaunchKernelGGL(rtgs::slam_loss_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, color, depth, depth_index,
+                     gt_color, gt_depth, cfg->render_mask, hw, cfg->add_depth_thres, sums);
+  if (ssim) {
+    rtgs::SsimWin win;
+    ssim_window(win);
+    hipLaunchKernelGGL(rtgs::ssim_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, st, color, gt_color, H, W, win,
+                       sums + 8, sums);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Second half: loss values and both image gradients from the sums in scratch[0..4] - which a multi-GPU caller that
+// splits ONE view across ranks all-reduces in between (the normalisers are counts over the whole image).
+extern "C" int rtgs_slam_loss_grads(const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
+                                    const float* gt_depth, int32_t H, int32_t W, const rtgs_loss_cfg* cfg, void* scratch,
+                                    float* loss_out4, float* g_color, float* g_depth, void* stream) {
   if (!color || !depth || !depth_index || !gt_color || !gt_depth || !cfg || !scratch || !loss_out4 || !g_color || !g_depth ||
       H <= 0 || W <= 0)
     return -1;
   hipStream_t st = (hipStream_t)stream;
   const int64_t hw = (int64_t)H * W;
   float* sums = (float*)scratch;
-  float* dmaps = sums + 8;
   const bool ssim = cfg->render_mask == nullptr && cfg->ssim_weight != 0.f;
-  if (hipMemsetAsync(sums, 0, 8 * sizeof(float), st) != hipSuccess) return -2;
   int64_t blocks = (hw + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  // the sums kernel ends with four same-address global atomics per workgroup (~20 ns each, serialised): keep it to
-  // 192 workgroups (1 024 of them cost 20 us for a 23 MB read)
-  const int64_t sum_blocks = blocks > 192 ? 192 : blocks;
-  hipLaunchKernelGGL(rtgs::slam_loss_sums_kernel, dim3((unsigned)sum_blocks), dim3(256), 0, st, color, depth, depth_index,
-                     gt_color, gt_depth, cfg->render_mask, hw, cfg->add_depth_thres, sums);
-  rtgs::SsimWin win;
-  if (ssim) {
-    double g[11], tot = 0.0;
-    float gf[11], totf = 0.f;
-    for (int i = 0; i < 11; ++i) { g[i] = exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); gf[i] = (float)g[i]; totf += gf[i]; tot += g[i]; }
-    (void)tot;
-    for (int i = 0; i < 11; ++i) win.g[i] = gf[i] / totf;        // torch.Tensor([...]) / sum, in float32 (loss_utils.py:39-46)
-    hipLaunchKernelGGL(rtgs::ssim_fwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, st, color, gt_color, H, W, win,
-                       dmaps, sums);
-  }
   hipLaunchKernelGGL(rtgs::slam_loss_grads_kernel, dim3((unsigned)blocks), dim3(256), 0, st, color, depth, depth_index,
                      gt_color, gt_depth, cfg->render_mask, hw, cfg->color_weight, cfg->depth_weight,
                      ssim ? cfg->ssim_weight : 0.f, cfg->add_depth_thres, (const float*)sums, loss_out4, g_color, g_depth);
-  if (ssim)
+  if (ssim) {
+    rtgs::SsimWin win;
+    ssim_window(win);
     hipLaunchKernelGGL(rtgs::ssim_bwd_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, st, color, gt_color, H, W, win,
-                       (const float*)dmaps, -cfg->ssim_weight / (3.f * (float)hw), g_color);
+                       (const float*)(sums + 8), -cfg->ssim_weight / (3.f * (float)hw), g_color);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int rtgs_slam_loss(const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
+                              const float* gt_depth, int32_t H, int32_t W, const rtgs_loss_cfg* cfg, void* scratch,
+                              float* loss_out4, float* g_color, float* g_depth, void* stream) {
+  int rc = rtgs_slam_loss_sums(color, depth, depth_index, gt_color, gt_depth, H, W, cfg, scratch, stream);
+  if (rc != 0) return rc;
+  return rtgs_slam_loss_grads(color, depth, depth_index, gt_color, gt_depth, H, W, cfg, scratch, loss_out4, g_color, g_depth,
+                              stream);
 }

@@ -48,7 +48,7 @@ extern "C" int rtgs_slam_map_step_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* a
   rc = rtgs_map_tail_rows(a->xyz, a->shs, a->raw8, a->d_opacity, a->d_scales, a->d_rotations, a->d_normal, a->d_xyz,
                           a->d_shs, a->d_raw8, a->row_state, a->m_xyz, a->v_xyz, a->m_shs, a->v_shs, a->m_raw8, a->v_raw8,
                           a->lr_xyz, a->lr_shs, a->lr_raw8, a->ever_xyz, a->ever_shs, a->ever_raw8, P, a->step, a->beta1,
-                          a->beta2, a->eps, a->attach, a->confidence, stream);
+                          a->beta2, a->eps, a->attach, a->confidence, nullptr, stream);
   return rc != 0 ? RTGS_E_HIP : RTGS_OK;
 }
 

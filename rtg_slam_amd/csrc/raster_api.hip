@@ -52,7 +52,7 @@ void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*,
 // plain entry points use one process-wide default context; callers that render from several threads create one
 // context per thread.
 enum { EV_F0 = 0, EV_PRE, EV_SL_BIN, EV_SL_BLEND, EV_SCAN, EV_BIN0, EV_EMIT, EV_SORT, EV_RANGES, EV_BLEND0, EV_BLEND, EV_B0,
-       EV_BBLEND, EV_BPRE, EV_N };
+       EV_BWALK, EV_BBLEND, EV_BPRE, EV_N };
 struct rtgs_ctx {
   int64_t stats[8] = {0};
   // Near-slice (occlusion) pass: 0 = off, 1 = always, 2 = automatic (large maps; the kernels themselves decide from
@@ -584,6 +584,7 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
     launch_blend_bwd(p, (const uint2*)(img + I.ranges), (const uint32_t*)(bin + B.vals_b),
                      (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
                      dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, st);
+    prof_mark(c, EV_BWALK, st);
     // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
     launch_grad_reduce(P, touched, gbase, slot_count, binfo, grads, st);
     DBG(s, st);
@@ -639,16 +640,16 @@ void rtgs_raster_force_sort_path_ctx(rtgs_ctx* c, int enable) { use(c)->force_so
 int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms) {
   rtgs_ctx* c = use(ctx);
   if (!ms) return RTGS_E_INVALID;
-  for (int i = 0; i < 10; ++i) ms[i] = -1.f;
+  for (int i = 0; i < 12; ++i) ms[i] = -1.f;
   if (!c->ev_init) return RTGS_OK;
   // [0] preprocess_fwd(+sat) [1] count+scan of the main pass [2] scatter / emit_keys [3] sort [4] tile_ranges
-  // [5] blend_fwd of the main pass [6] blend_bwd (both launches) [7] preprocess_bwd
-  // [8] near slice: hist+count+scan+scatter+sort [9] near slice: blend_fwd
+  // [5] blend_fwd of the main pass [6] slot-counter memset + blend_bwd (both launches) [7] preprocess_bwd
+  // [8] near slice: hist+count+scan+scatter+sort [9] near slice: blend_fwd [10] grad_reduce [11] unused
   const int pre_end = c->ev_set[EV_SL_BLEND] ? EV_SL_BLEND : EV_PRE;
-  const int pairs[10][2] = {{EV_F0, EV_PRE}, {pre_end, EV_SCAN}, {EV_BIN0, EV_EMIT}, {EV_EMIT, EV_SORT},
-                            {EV_SORT, EV_RANGES}, {EV_BLEND0, EV_BLEND}, {EV_B0, EV_BBLEND}, {EV_BBLEND, EV_BPRE},
-                            {EV_PRE, EV_SL_BIN}, {EV_SL_BIN, EV_SL_BLEND}};
-  for (int i = 0; i < 10; ++i) {
+  const int pairs[11][2] = {{EV_F0, EV_PRE}, {pre_end, EV_SCAN}, {EV_BIN0, EV_EMIT}, {EV_EMIT, EV_SORT},
+                            {EV_SORT, EV_RANGES}, {EV_BLEND0, EV_BLEND}, {EV_B0, EV_BWALK}, {EV_BBLEND, EV_BPRE},
+                            {EV_PRE, EV_SL_BIN}, {EV_SL_BIN, EV_SL_BLEND}, {EV_BWALK, EV_BBLEND}};
+  for (int i = 0; i < 11; ++i) {
     const int a = pairs[i][0], b = pairs[i][1];
     if (!c->ev_set[a] || !c->ev_set[b]) continue;
     if (hipEventSynchronize(c->ev[b]) != hipSuccess) return RTGS_E_HIP;

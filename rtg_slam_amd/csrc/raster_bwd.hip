@@ -57,11 +57,28 @@ __device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
 // quantity idx(l)): fold the two groups of a row (row_ror:8), the two rows of a half (ds_swizzle
 // xor 16) and the two halves (xor 32) - so the LDS add that follows has 8 DISTINCT addresses
 // (8 lanes x same address serialises inside the LDS atomic unit).
+__device__ __forceinline__ float xor16_sum(float v) {     // v[l] + v[l ^ 16]: gfx950 v_permlane16_swap, a VALU op (no LDS pipe)
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {     // v[l] + v[l ^ 32]: v_permlane32_swap
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float fold_groups(float v) {
   v += dpp_mov<0x128>(0.f, v);                                                       // row_ror:8  (lane ^ 8)
-  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));       // xor 16 within 32 lanes
-  v += __shfl_xor(v, 32);
-  return v;
+  return xor32_sum(xor16_sum(v));
+}
+// Wave totals of TWO values at once (the opacity partials of the two entries of a round): after the first exchange a
+// lane holds the pair sum of d[lane & 1]; the remaining five steps only combine lanes of equal parity.  Every lane
+// ends up with the wave total of d[lane & 1] - six cross-lane steps for both values instead of twelve.
+__device__ __forceinline__ float wave_sum_pair(float d0, float d1, int lane) {
+  const bool odd = lane & 1;
+  float v = (odd ? d1 : d0) + dpp_mov<0xB1>(0.f, odd ? d0 : d1);                    // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_mov<0x4E>(0.f, v);                                                        // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_mov<0x124>(0.f, v);                                                       // row_ror:4
+  v += dpp_mov<0x128>(0.f, v);                                                       // row_ror:8: all 8 same-parity lanes of the row
+  return xor32_sum(xor16_sum(v));
 }
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   v += dpp_mov<0xB1>(0.f, v);               // quad_perm [1,0,3,2]
@@ -211,32 +228,33 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
         Sg[k] = S0 * g0 + S1 * g1 + S2 * g2 + bgT;
         cg[k] = c0 * g0 + c1 * g1 + c2 * g2;
       }
-      float r8[2], ro[2];
+      float r8[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const float dL_dalpha = Tk[k] * cg[k] - Sg[k] * ia[k];
         gda[k] = valid[k] ? G[k] * dL_dalpha : 0.f;   // clamp of alpha is transparent in the backward (upstream 3DGS)
         const float gdl = gda[k] * r1[k].y;
+        // moments of gdl over the pixels: the conic enters once per entry (in the flush), not once per pixel
         float v[8];
-        v[0] = gdl * (-r0[k].z * dx[k] - r0[k].w * dy[k]);
-        v[1] = gdl * (-r1[k].x * dy[k] - r0[k].w * dx[k]);
-        v[2] = gdl * (-0.5f * dx[k] * dx[k]);
-        v[3] = gdl * (-dx[k] * dy[k]);
-        v[4] = gdl * (-0.5f * dy[k] * dy[k]);
+        v[0] = gdl * dx[k];
+        v[1] = gdl * dy[k];
+        v[2] = v[0] * dx[k];
+        v[3] = v[0] * dy[k];
+        v[4] = v[1] * dy[k];
         v[5] = w[k] * g0; v[6] = w[k] * g1; v[7] = w[k] * g2;
         r8[k] = butterfly8(v, lane);
-        ro[k] = wave_sum_to_lane63(gda[k]);
       }
+      const float ro = wave_sum_pair(gda[0], gda[1], lane);
       // every (wave, entry, quantity) slot is written at most once per batch -> plain LDS stores
       if (vm0) {
         const float t8 = fold_groups(r8[0]);
         if (lane < 8) wgrad[e[0] * NG + gidx] = t8;
-        if (lane == 63) wgrad[e[0] * NG + 8] = ro[0];
+        if (lane == 0) wgrad[e[0] * NG + 8] = ro;
       }
       if (vm1) {
         const float t8 = fold_groups(r8[1]);
         if (lane < 8) wgrad[e[1] * NG + gidx] = t8;
-        if (lane == 63) wgrad[e[1] * NG + 8] = ro[1];
+        if (lane == 1) wgrad[e[1] * NG + 8] = ro;
       }
       // depth owners among this wave's pixels (each pixel owns at most one entry of the whole list: rare per round)
 #pragma unroll
@@ -266,6 +284,18 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k) { t[NG + k] = s_dep[tid * 4 + k]; any |= (t[NG + k] != 0.f); }
       if (any) {
+        // t[0..4] hold the moments sum(gdl dx), sum(gdl dy), sum(gdl dx^2), sum(gdl dx dy), sum(gdl dy^2) with
+        // d = centre - pixel; d alpha / d(u, v, conic) of G = exp(-1/2 (ca dx^2 + cc dy^2) - cb dx dy):
+        {
+          const float4 q0 = s_rec[tid * 3 + 0];            // u v ca cb
+          const float ccn = s_rec[tid * 3 + 1].x;          // cc
+          const float mx = t[0], my = t[1];
+          t[0] = -(q0.z * mx + q0.w * my);                 // du
+          t[1] = -(ccn * my + q0.w * mx);                  // dv
+          t[2] = -0.5f * t[2];                             // dca
+          t[3] = -t[3];                                    // dcb
+          t[4] = -0.5f * t[4];                             // dcc
+        }
         touched[s_id[tid]] = 1;     // byte per Gaussian: grad_reduce / the row-state backward skip untouched Gaussians
         if (use_slots) {
           // SplatGrad order: du dv dca dcb | dcc dop dr dg | db dnx dny dnz | dpd - - -

@@ -248,6 +248,9 @@ class ShardedMapOptimizer:
         self.last_num_rendered = 0
         self._slam_state = None        # world > 1: full-size Adam state of the replicated sparse step (step_slam)
         self.attach_init = None        # begin_local_optimization(): snapshot for the attach regulariser
+        self._row_capacity = 16384     # world > 1: rows per rank in the sparse gradient exchange (grows on overflow)
+        self._pending = None           # world > 1: the last exchange, until its overflow flag has been looked at
+        self.overflow_redos = 0
         self._mode = None              # world > 1: "sharded" (step) or "replicated" (step_slam); they keep different state
         if self.row_skip and activate_fn is None:
             from .rasterizer import RowGradArena
@@ -256,6 +259,7 @@ class ShardedMapOptimizer:
     @property
     def params(self) -> torch.Tensor:
         """Packed [N,59] copy of the current parameters."""
+        self.flush()
         return torch.cat([self.state[n]["p"][:self.N] for n, _, _ in BLOCKS], dim=1)
 
     def _adam(self, st, shard, gs, row_state=None):
@@ -269,6 +273,7 @@ class ShardedMapOptimizer:
         """Snapshot the raw parameters the attach regulariser ties low-opacity Gaussians to (`history_stat` /
         `init_stat` of mapper.py:147-153, 660-666) and re-create the Adam state, as the reference does for every
         local / global optimisation (mapper.py:156: a new torch.optim.Adam per call)."""
+        self.flush()
         N, st = self.N, self.state
         self.attach_init = dict(xyz=st["xyz"]["p"][:N].clone(), raw8=st["raw8"]["p"][:N].clone(),
                                 info=torch.zeros(6, dtype=torch.float32, device=st["xyz"]["p"].device))
@@ -297,7 +302,8 @@ class ShardedMapOptimizer:
     def step_slam(self, raster_settings, gt_color: torch.Tensor, gt_depth: torch.Tensor,
                   tile_mask: Optional[torch.Tensor] = None, color_weight: float = 0.8,
                   depth_weight: float = 1.0, ssim_weight: float = 0.2, add_depth_thres: float = 0.1,
-                  render_mask: Optional[torch.Tensor] = None, confidence: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  render_mask: Optional[torch.Tensor] = None, confidence: Optional[torch.Tensor] = None,
+                  tile_band: bool = False) -> torch.Tensor:
         """One iteration with the built-in SLAM loss (`slam_losses`): identical kernels and results as
         `step(lambda gd: slam_losses_hip(render(gd), gt_color, gt_depth))`, but enqueued by a single C call
         (`rtgs_slam_map_step`) - no autograd graph, no per-launch Python.  With more than one rank the map and the
@@ -327,6 +333,7 @@ class ShardedMapOptimizer:
                 raise RuntimeError("ShardedMapOptimizer: step_slam() after step() on more than one rank - the two keep "
                                    "different Adam state (replicated vs row-sharded); use one of them per optimizer")
             self._mode = "replicated"
+            self._resolve_pending()            # before this step's backward overwrites the arena
             if self._slam_state is None:
                 self._slam_state = {
                     n: dict(m=torch.zeros(N, c1 - c0, dtype=torch.float32, device=dev),
@@ -378,7 +385,15 @@ class ShardedMapOptimizer:
             geom.cb, None, binning.cb, None, img.cb, None)
         R = C.c_int64(0)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        if self.world == 1:
+        if tile_band and self.world > 1:
+            # ONE view split across the ranks: this rank renders, and differentiates, only its band of
+            # tiles; the loss normalisers are all-reduced; the partial gradient rows are summed by the same exchange
+            if rm is None:
+                raise RuntimeError("step_slam(tile_band=True) needs a render_mask (the SSIM window of the unmasked loss "
+                                   "crosses band boundaries; the reference always passes one, mapper.py:196-203)")
+            self._front_tileband(lib, args, ws, keep, tile_mask, rm, R, dev)
+            self._exchange_and_tail(dict(step=int(self.step_count), attach=attach, confidence=confidence, keep=(keep, attach)))
+        elif self.world == 1:
             with torch.cuda.device(dev):
                 rc = lib.rtgs_slam_map_step_ctx(current_context().ptr, C.byref(args), C.byref(R), C.c_void_p(stream))
             _lib.check(rc, "rtgs_slam_map_step")
@@ -386,60 +401,144 @@ class ShardedMapOptimizer:
             with torch.cuda.device(dev):
                 rc = lib.rtgs_slam_map_step_front_ctx(current_context().ptr, C.byref(args), C.byref(R), C.c_void_p(stream))
             _lib.check(rc, "rtgs_slam_map_step_front")
-            self._exchange_rows(lib, ws, a, dev)
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            V = lambda t: C.c_void_p(t.data_ptr())
-            with torch.cuda.device(dev):
-                rc = lib.rtgs_map_tail_rows(
-                    V(st["xyz"]["p"]), V(st["shs"]["p"]), V(st["raw8"]["p"]), V(a.d_opac), V(a.d_scales), V(a.d_rots),
-                    V(a.d_normal), V(a.d_means), V(a.d_shs), V(a.d_raw8), V(a.row_state), V(ad["xyz"]["m"]),
-                    V(ad["xyz"]["v"]), V(ad["shs"]["m"]), V(ad["shs"]["v"]), V(ad["raw8"]["m"]), V(ad["raw8"]["v"]),
-                    V(st["xyz"]["lr"]), V(st["shs"]["lr"]), V(st["raw8"]["lr"]), V(ad["xyz"]["ever"]), V(ad["shs"]["ever"]),
-                    V(ad["raw8"]["ever"]), N, int(self.step_count), 0.9, 0.999, float(self.eps),
-                    C.byref(attach) if attach is not None else None,
-                    V(confidence) if confidence is not None else None, C.c_void_p(stream))
-            _lib.check(rc, "rtgs_map_tail_rows")
+            self._exchange_and_tail(dict(step=int(self.step_count), attach=attach, confidence=confidence, keep=(keep, attach)))
         a.calls = 1
         self.last_render = (ws["color"], ws["depth"], ws["cidx"], ws["didx"], ws["cw"], ws["dw"], ws["T"])
         self.last_num_rendered = int(R.value)
         self.last_losses = ws["loss"]               # device float[4]: total, colour, depth, ssim (mapper.py:458-466)
         return ws["loss"][0]
 
-    def _exchange_rows(self, lib, ws, a, dev):
-        """All ranks' gradient rows into this rank's arena, summed in rank order (see step_slam)."""
+    def band_tile_mask(self, tile_mask: torch.Tensor, with_region: bool = False):
+        """This rank's share of the switched-on tiles: contiguous runs in row-major order with (almost) equal tile
+        counts - computed with device ops only, identically on every rank.  `with_region` also returns the rank's
+        REGION: every tile, on or off, belongs to exactly one rank, so that loss pixels inside switched-off tiles (the
+        render mask may hold some, mapper.py:500-505) are counted by exactly one rank too."""
+        on = (tile_mask.reshape(-1) != 0)
+        cum = torch.cumsum(on.to(torch.int64), 0) - on.to(torch.int64)
+        owner = ((cum * self.world) // on.sum().clamp_min(1)).clamp_max(self.world - 1)
+        mine = owner == self.rank
+        band = (on & mine).to(torch.int32).reshape(tile_mask.shape).contiguous()
+        return (band, mine.reshape(tile_mask.shape)) if with_region else band
+
+    def _front_tileband(self, lib, args, ws, keep, tile_mask, rm, R, dev):
+        from . import _lib
+        from .rasterizer import current_context
         N = self.N
-        if "rows" not in ws:
-            ws["rows"] = torch.empty(N, 64, dtype=torch.float32, device=dev)
-            ws["count"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        H, W = ws["hw"]
+        key = (tile_mask.data_ptr(), rm.data_ptr(), tuple(tile_mask.shape))
+        if ws.get("band_key") != key:                 # masks are fixed over a local optimisation: derive the band once
+            band, region = self.band_tile_mask(tile_mask, with_region=True)
+            pix = region.repeat_interleave(16, 0).repeat_interleave(16, 1)[:H, :W].to(torch.uint8)
+            ws["band"], ws["band_rm"], ws["band_key"] = band, (pix * (rm != 0).to(torch.uint8)).contiguous(), key
+        band, band_rm = ws["band"], ws["band_rm"]
+        V = lambda t: C.c_void_p(t.data_ptr())
+        st = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        geom, binning, img = ws["arenas"]
+        x = self.state
+        a = self.grad_rows
+        cfg = _lib.LossCfgC(args.loss.color_weight, args.loss.depth_weight, args.loss.ssim_weight, args.loss.add_depth_thres,
+                            band_rm.data_ptr())
+        ctx = current_context().ptr
+        with torch.cuda.device(dev):
+            _lib.check(lib.rtgs_map_activate8_forward(V(x["raw8"]["p"]), N, V(ws["opacity"]), V(ws["scales"]), V(ws["rotations"]),
+                                                      V(ws["normal"]), st()), "rtgs_map_activate8_forward")
+            _lib.check(lib.rtgs_raster_forward_ctx(
+                ctx, C.byref(keep.c), N, 16, V(x["xyz"]["p"]), V(ws["opacity"]), V(x["shs"]["p"]), V(ws["scales"]),
+                V(ws["rotations"]), V(ws["normal"]), V(band), V(ws["color"]), V(ws["depth"]), V(ws["cidx"]), V(ws["didx"]),
+                V(ws["cw"]), V(ws["dw"]), V(ws["T"]), V(ws["radii"]), geom.cb, None, binning.cb, None, img.cb, None,
+                C.byref(R), 0, st()), "rtgs_raster_forward")
+            _lib.check(lib.rtgs_slam_loss_sums(V(ws["color"]), V(ws["depth"]), V(ws["didx"]), C.c_void_p(args.gt_color),
+                                               C.c_void_p(args.gt_depth), H, W, C.byref(cfg), V(ws["loss_scratch"]), st()),
+                       "rtgs_slam_loss_sums")
+        sums = ws["loss_scratch"][:32].view(torch.float32)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)        # 8 floats: the normalisers are global
+        with torch.cuda.device(dev):
+            _lib.check(lib.rtgs_slam_loss_grads(V(ws["color"]), V(ws["depth"]), V(ws["didx"]), C.c_void_p(args.gt_color),
+                                                C.c_void_p(args.gt_depth), H, W, C.byref(cfg), V(ws["loss_scratch"]),
+                                                V(ws["loss"]), V(ws["g_color"]), V(ws["g_depth"]), st()), "rtgs_slam_loss_grads")
+            _lib.check(lib.rtgs_raster_backward_rows_ctx(
+                ctx, C.byref(keep.c), N, 16, R.value, V(x["xyz"]["p"]), V(ws["opacity"]), V(x["shs"]["p"]), V(ws["scales"]),
+                V(ws["rotations"]), V(ws["normal"]), V(geom.tensor), V(binning.tensor), V(img.tensor), V(ws["color"]), V(ws["T"]),
+                V(ws["didx"]), V(ws["g_color"]), V(ws["g_depth"]), V(a.d_means), V(a.d_opac), V(a.d_shs), V(a.d_scales),
+                V(a.d_rots), V(a.d_normal), V(a.scratch), V(a.row_state), st()), "rtgs_raster_backward_rows")
+
+    # ------------------------------------------------------------------ sparse exchange (world > 1), no host sync
+    def _exchange_and_tail(self, job):
+        """All ranks' gradient rows into this rank's arena, summed in rank order, then the Adam tail - every size the
+        collective needs is fixed up front (`self._row_capacity` rows per rank, the real count rides in the list's
+        header).  If a rank had more rows than fit, a device flag makes EVERY rank skip the apply and the tail of this
+        step (all ranks read the same headers); the flag and the counts are copied to pinned host memory without
+        waiting, and `_resolve_pending` - run before the next step touches the arena - repeats the exchange with a
+        larger capacity.  Steady state: zero host synchronisations per step."""
+        from . import _lib
+        lib = _lib.load()
+        N, st, a, ws = self.N, self.state, self.grad_rows, self._slam_ws
+        ad = self._slam_state
+        dev = st["xyz"]["p"].device
+        W, cap = self.world, int(self._row_capacity)
+        if ws.get("cap") != cap:
+            ws["list"] = torch.empty((1 + cap) * 64, dtype=torch.float32, device=dev)
+            ws["gathered"] = torch.empty(W * (1 + cap) * 64, dtype=torch.float32, device=dev)
+            ws["flag"] = torch.zeros(2 + W, dtype=torch.int32, device=dev)
+            ws["flag_host"] = torch.zeros(2 + W, dtype=torch.int32).pin_memory()
+            ws["cap"] = cap
         V = lambda t: C.c_void_p(t.data_ptr())
         arena = (V(a.d_means), V(a.d_shs), V(a.d_opac), V(a.d_scales), V(a.d_rots), V(a.d_normal))
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        from . import _lib
+        flag = ws["flag"]
+        count_scratch = C.c_void_p(flag.data_ptr() + 4 * (1 + W))
+        stream = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
-            rc = lib.rtgs_rows_pack(V(a.row_state), N, *arena, V(ws["rows"]), V(ws["count"]), stream)
-        _lib.check(rc, "rtgs_rows_pack")
-        counts_t = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(self.world)]
-        dist.all_gather(counts_t, ws["count"], group=self.group)
-        counts = [int(c) for c in torch.cat(counts_t).cpu()]            # host sync: sizes of the lists
-        maxc = max(counts)
-        if maxc == 0:
-            return
-        mine = ws["rows"][:maxc]
+            _lib.check(lib.rtgs_rows_pack(V(a.row_state), N, *arena, V(ws["list"]), cap, count_scratch, stream()), "rtgs_rows_pack")
         if self.backend == "gloo":
-            parts = [torch.empty_like(mine) for _ in range(self.world)]
-            dist.all_gather(parts, mine.contiguous(), group=self.group)
+            parts = [torch.empty_like(ws["list"]) for _ in range(W)]
+            dist.all_gather(parts, ws["list"], group=self.group)
+            ws["gathered"].copy_(torch.cat(parts))
         else:
-            buf = torch.empty(self.world, maxc, 64, dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(buf, mine.contiguous(), group=self.group)
-            parts = [buf[r] for r in range(self.world)]
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            dist.all_gather_into_tensor(ws["gathered"], ws["list"], group=self.group)
+        stride = (1 + cap) * 64 * 4
+        att = job["attach"]
+        conf = job["confidence"]
         with torch.cuda.device(dev):
-            rc = lib.rtgs_rows_apply(V(ws["rows"]), counts[self.rank], 0, *arena, V(a.row_state), stream)
-            _lib.check(rc, "rtgs_rows_apply")
-            for r in range(self.world):                               # same order on every rank: bit-identical replicas
-                rc = lib.rtgs_rows_apply(V(parts[r]), counts[r], 1, *arena, V(a.row_state), stream)
-                _lib.check(rc, "rtgs_rows_apply")
-        ws["_keep"] = parts                                           # alive until the kernels that read them have run
+            _lib.check(lib.rtgs_rows_overflow(V(ws["gathered"]), W, cap, V(flag), stream()), "rtgs_rows_overflow")
+            own = C.c_void_p(ws["gathered"].data_ptr() + self.rank * stride)
+            _lib.check(lib.rtgs_rows_apply(own, cap, 0, *arena, V(a.row_state), V(flag), stream()), "rtgs_rows_apply")
+            for r in range(W):                                        # same order on every rank: bit-identical replicas
+                lst = C.c_void_p(ws["gathered"].data_ptr() + r * stride)
+                _lib.check(lib.rtgs_rows_apply(lst, cap, 1, *arena, V(a.row_state), V(flag), stream()), "rtgs_rows_apply")
+            rc = lib.rtgs_map_tail_rows(
+                V(st["xyz"]["p"]), V(st["shs"]["p"]), V(st["raw8"]["p"]), V(a.d_opac), V(a.d_scales), V(a.d_rots),
+                V(a.d_normal), V(a.d_means), V(a.d_shs), V(a.d_raw8), V(a.row_state), V(ad["xyz"]["m"]),
+                V(ad["xyz"]["v"]), V(ad["shs"]["m"]), V(ad["shs"]["v"]), V(ad["raw8"]["m"]), V(ad["raw8"]["v"]),
+                V(st["xyz"]["lr"]), V(st["shs"]["lr"]), V(st["raw8"]["lr"]), V(ad["xyz"]["ever"]), V(ad["shs"]["ever"]),
+                V(ad["raw8"]["ever"]), N, job["step"], 0.9, 0.999, float(self.eps),
+                C.byref(att) if att is not None else None, V(conf) if conf is not None else None, V(flag), stream())
+            _lib.check(rc, "rtgs_map_tail_rows")
+        ws["flag_host"].copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._pending = dict(event=ev, job=job)
+
+    def _resolve_pending(self):
+        """Did the last exchange overflow?  (Its flag was copied to pinned memory a whole step ago.)  If so nothing was
+        applied anywhere: enlarge the capacity - every rank computes the same value from the same counts - and repeat."""
+        while self._pending is not None:
+            pend, self._pending = self._pending, None
+            pend["event"].synchronize()
+            host = self._slam_ws["flag_host"]
+            if int(host[0]) == 0:
+                return
+            need = int(host[1:1 + self.world].max())
+            cap = 1024
+            while cap < 2 * need:
+                cap *= 2
+            self._row_capacity = cap
+            self.overflow_redos += 1
+            self._exchange_and_tail(pend["job"])
+
+    def flush(self):
+        """Make the parameters final: resolves a pending (possibly overflowed) multi-GPU exchange."""
+        if self.world > 1:
+            self._resolve_pending()
 
     def _arena_grad(self, name):
         a = self.grad_rows

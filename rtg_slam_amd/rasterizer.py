@@ -89,7 +89,7 @@ class RasterContext:
         return dict(used=int(out[0]), instances=int(out[1]), tiles_finished=int(out[2]), tiles_left_to_pass2=int(out[3]))
 
     def last_timings(self):
-        out = (C.c_float * 10)()
+        out = (C.c_float * 12)()
         _lib.check(_lib.load().rtgs_raster_last_timings_ctx(self.ptr, out), "rtgs_raster_last_timings")
         return [float(v) for v in out]
 

@@ -141,3 +141,24 @@ def test_adam_leaves_never_touched_rows_bitwise_unchanged():
     assert torch.equal(p[~live], p0[~live])
     assert not m[~live].any() and not v[~live].any()
     assert (p[live] != p0[live]).any()
+
+
+def test_tile_band_partition_of_the_switched_on_tiles():
+    """ShardedMapOptimizer.band_tile_mask (pure torch): for any world size the ranks' bands are disjoint, cover exactly
+    the switched-on tiles, are balanced to within one tile, and the REGIONS partition every tile, on or off."""
+    import types
+    from rtg_slam_amd import map_optim as mo
+    g = torch.Generator().manual_seed(3)
+    for world in (1, 2, 3, 8):
+        for frac in (1.0, 0.3, 0.02):
+            tm = (torch.rand(43, 75, generator=g) < frac).int()
+            bands, regions = [], []
+            for r in range(world):
+                me = types.SimpleNamespace(world=world, rank=r)
+                b, reg = mo.ShardedMapOptimizer.band_tile_mask(me, tm, with_region=True)
+                bands.append(b); regions.append(reg)
+            tot = torch.stack(bands).sum(0)
+            assert torch.equal(tot, tm)
+            assert torch.equal(torch.stack(regions).int().sum(0), torch.ones_like(tm))
+            counts = [int(b.sum()) for b in bands]
+            assert max(counts) - min(counts) <= 1, (world, frac, counts)

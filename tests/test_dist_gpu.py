@@ -124,3 +124,63 @@ def test_two_ranks_sparse_slam_step_matches_single_process():
     moved = (p0 - packed.cpu()).abs().max(dim=1).values > 0
     assert 0 < int(moved.sum()) < packed.shape[0]
     assert torch.equal(moved, (rp - packed.cpu()).abs().max(dim=1).values > 0)
+
+
+def _worker_band(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtg_slam_amd import map_optim as mo
+    dev = torch.device("cuda", 0)
+    packed, fns = _setup(dev)
+    rs, gt_c, gt_d = fns[0].spec                                    # ONE view, split into tile bands across the ranks
+    H, W = gt_c.shape[1:]
+    rm = (torch.rand(H, W, generator=torch.Generator().manual_seed(9)) < 0.8).to(dev)
+    tm = torch.ones((H + 15) // 16, (W + 15) // 16, dtype=torch.int32, device=dev)
+    tm[0, 0] = 0
+    opt = mo.ShardedMapOptimizer(packed)
+    opt._row_capacity = 32                                          # far too small: the first exchange must overflow
+    opt.begin_local_optimization()
+    losses = []
+    for _ in range(3):
+        losses.append(float(opt.step_slam(rs, gt_c, gt_d, tm, render_mask=rm, tile_band=True)))
+    band = opt.band_tile_mask(tm).cpu()
+    ret[rank] = (opt.params.cpu(), losses, band, opt.overflow_redos, opt._row_capacity)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_band_split_of_one_view_and_overflow_redo():
+    """ONE view, each rank renders and differentiates its band of tiles, loss normalisers all-reduced,
+    gradient rows summed by the sparse exchange - equal to a single process stepping on the whole view.  The exchange
+    starts with a capacity that is too small: the overflow is detected on the device, nothing is applied, and the host
+    repeats it with a larger capacity one call later (no synchronisation in the steady state)."""
+    sys.path.insert(0, ROOT)
+    from rtg_slam_amd import map_optim as mo
+    port = 29500 + (os.getpid() % 200)
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_band, args=(2, port, ret), nprocs=2, join=True)
+    (p0, l0, b0, redo0, cap0), (p1, l1, b1, redo1, cap1) = ret[0], ret[1]
+    assert torch.equal(p0, p1) and l0 == l1                          # replicas bit-identical, same (global) loss
+    assert redo0 >= 1 and redo0 == redo1 and cap0 == cap1 > 32
+    assert int((b0 & b1).sum()) == 0 and abs(int(b0.sum()) - int(b1.sum())) <= 1      # disjoint, balanced bands
+    dev = torch.device("cuda", 0)
+    packed, fns = _setup(dev)
+    rs, gt_c, gt_d = fns[0].spec
+    H, W = gt_c.shape[1:]
+    rm = (torch.rand(H, W, generator=torch.Generator().manual_seed(9)) < 0.8).to(dev)
+    tm = torch.ones((H + 15) // 16, (W + 15) // 16, dtype=torch.int32, device=dev)
+    tm[0, 0] = 0
+    assert int((b0 | b1).sum()) == int(tm.sum())
+    ref = mo.ShardedMapOptimizer(packed)
+    ref.begin_local_optimization()
+    lr = [float(ref.step_slam(rs, gt_c, gt_d, tm, render_mask=rm)) for _ in range(3)]
+    for a, b in zip(l0, lr):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b))
+    rp = ref.params.cpu()
+    assert float(((p0 - rp).abs() > 2e-5).float().mean()) < 2e-3
+    moved = (p0 - packed.cpu()).abs().max(dim=1).values > 0
+    assert torch.equal(moved, (rp - packed.cpu()).abs().max(dim=1).values > 0)

@@ -26,7 +26,7 @@ for name, frac in (("all", 1.0), ("half", 0.5), ("quarter", 0.25), ("1/16", 1/16
                    rotations=leaves["rotations"], cov3D_precomp=None, normal_w=leaves["normal"], tile_mask=mask)
         ((out[0]*gc).sum() + (out[1]*gd).sum()).backward()
         torch.cuda.synchronize()
-        ms = (C.c_float*10)(); lib.rtgs_raster_last_timings(ms)
+        ms = (C.c_float*12)(); lib.rtgs_raster_last_timings(ms)
         if it >= 2:
             for q in range(8): acc[q] += max(0.0, ms[q])/4
     st = (C.c_int64*8)(); lib.rtgs_raster_last_stats(st)

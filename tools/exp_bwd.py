@@ -19,7 +19,7 @@ for it in range(8):
                rotations=leaves["rotations"], cov3D_precomp=None, normal_w=leaves["normal"], tile_mask=None)
     ((out[0]*gc).sum() + (out[1]*gd).sum()).backward()
     torch.cuda.synchronize()
-    ms = (C.c_float*10)(); lib.rtgs_raster_last_timings(ms)
+    ms = (C.c_float*12)(); lib.rtgs_raster_last_timings(ms)
     if it >= 3:
         for q in range(10): acc[q] += max(0.0, ms[q])/5
 print(f"{os.environ.get('RTGS_LIB_PATH','default'):40s} bwd_env={os.environ.get('RTGS_BLEND_BWD','-')} | slice_bin {acc[8]:.3f} slice_blend {acc[9]:.3f} blend_bwd(+memset) {acc[6]:.3f} pre_bwd {acc[7]:.3f}")

@@ -32,16 +32,16 @@ for _ in range(20):
     opt.step_slam(rs, gt_color, gt_depth, None, render_mask=rm)
 torch.cuda.synchronize()
 lib.rtgs_raster_set_profiling(1)
-acc = [0.0] * 10
+acc = [0.0] * 11
 import time
 t0 = time.perf_counter()
 for _ in range(iters):
     opt.step_slam(rs, gt_color, gt_depth, None, render_mask=rm)
-    ms = (C.c_float * 10)()
+    ms = (C.c_float * 12)()
     lib.rtgs_raster_last_timings(ms)
-    for k in range(10):
+    for k in range(11):
         acc[k] += max(0.0, ms[k]) / iters
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / iters * 1e3
-names = ["preprocess_fwd", "bin_count", "bin_scatter", "bin_tilesort", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "slice_bin", "slice_blend"]
+names = ["preprocess_fwd", "bin_count", "bin_scatter", "bin_tilesort", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "slice_bin", "slice_blend", "grad_reduce"]
 print(which, f"iter {dt:.3f} ms (with per-iteration sync) |", " ".join(f"{n}={v * 1e3:.0f}us" for n, v in zip(names, acc)))
