@@ -22,7 +22,7 @@ void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const 
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
                       const uint32_t*, const int32_t*, const float*, const float*, const uint32_t*, uint32_t*,
                       const BwdInfo*, SplatGrad*, uint8_t*, hipStream_t);
-void launch_grad_reduce(int, const uint8_t*, const uint32_t*, const uint32_t*, const BwdInfo*, SplatGrad*, hipStream_t);
+void launch_grad_reduce(int, const uint8_t*, const uint32_t*, uint32_t*, const BwdInfo*, SplatGrad*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
                            float*, float*, float*, float*, hipStream_t);
@@ -33,7 +33,7 @@ size_t bin_block_counts_bytes(int, int);
 int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, uint16_t*, SliceSel,
                      SliceList, size_t, hipStream_t);
 size_t bin_slice_block_counts_bytes(int, size_t, int);
-void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, hipStream_t);
+void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, hipStream_t);
 void launch_slice_publish(int, const int32_t*, const int32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, hipStream_t);
 void launch_preprocess_cull(const RasterParams&, const float*, const float*, const float*, uint32_t*, int32_t*, int32_t*,
                             uint32_t*, int, uint8_t*, float2*, hipStream_t);
@@ -68,6 +68,9 @@ struct rtgs_ctx {
   bool ev_set[EV_N] = {false};
   uint32_t* info_host = nullptr;    // pinned words the kernels publish totals into (the forward's host sync)
   uint32_t seq = 0;
+  // what the most recent forward on this context left for its backward (see backward_impl)
+  const void* hint_geom = nullptr;
+  bool hint_slice_lists = true, hint_main_lists = true;
 };
 
 namespace rtgs {
@@ -99,19 +102,6 @@ static int bits_for(uint32_t n) {   // bits needed to represent values in [0, n)
   return b < 1 ? 1 : b;
 }
 
-// Rect area of the Gaussians of the near slice, 0 for all others: input of the gradient-slot scan when the slice
-// finished every tile (only its Gaussians can then receive gradient, and their slots fit the slice's instance budget).
-struct SliceAreaOp {
-  const uint8_t* zbin;
-  const uint32_t* area;
-  const int32_t* cut;        // device word written by slice_compact
-  __host__ __device__ uint32_t operator()(int i) const {
-    const int zb = (int)zbin[i];
-    return (zb != 255 && zb <= *cut) ? area[i] : 0u;
-  }
-};
-using SliceAreaIter = hipcub::TransformInputIterator<uint32_t, SliceAreaOp, hipcub::CountingInputIterator<int>>;
-
 __global__ void bwd_info_kernel(BwdInfo* dst, SplatGrad* slot_grads, uint32_t slots, uint32_t use_slots) {
   dst->slot_grads = slot_grads; dst->slots = slots; dst->use_slots = use_slots;
 }
@@ -140,7 +130,8 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
     L.ranges1_bwd = off; off += nt * sizeof(uint2);
     L.slice_hist = off; off += 2 * SLICE_BINS * sizeof(uint32_t);
     L.slice_cover = off; off += SLICE_BINS * sizeof(unsigned long long);
-    L.slice_ctr = off; off += 4 * sizeof(uint32_t);
+    L.slice_ctr = off; off += 8 * sizeof(uint32_t);   // [0] unfinished tiles [2] slice list length [3] cut [4] slot cursor
+    L.slot_count = off; off += Pn * sizeof(uint32_t);   // zero between calls: cleared here, and again by grad_reduce
     L.zero_end = off; off = align_up(off);
     L.cursor = off; off = align_up(off + nt * sizeof(uint32_t));
     L.info = off; off = align_up(off + 4 * sizeof(uint32_t));
@@ -150,7 +141,6 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
     L.ranges1 = off; off = align_up(off + nt * sizeof(uint2));
     L.mask2 = off; off = align_up(off + nt * sizeof(int32_t));
     L.uv = off; off = align_up(off + Pn * sizeof(float2));
-    L.slot_count = off; off = align_up(off + Pn * sizeof(uint32_t));
     L.slice_cap = nt * (size_t)(budget > 0 ? budget : 1);
     L.slice_max_list = L.slice_cap < 65536 ? L.slice_cap : 65536;   // every listed Gaussian covers >= 1 tile
     if (L.slice_max_list > Pn) L.slice_max_list = Pn;
@@ -159,13 +149,10 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
     L.slice_ids = off; off = align_up(off + L.slice_max_list * sizeof(uint32_t));
     L.bucket1 = off; off = align_up(off + L.slice_cap * sizeof(uint64_t));
   }
-  size_t tb = 0, tb2 = 0, tb3 = 0;
+  size_t tb = 0, tb2 = 0;
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)Pn);
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)Pn);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, SliceAreaIter(hipcub::CountingInputIterator<int>(0), SliceAreaOp{}),
-                                         (uint32_t*)nullptr, (int)Pn);
   if (tb2 > tb) tb = tb2;
-  if (tb3 > tb) tb = tb3;
   L.scan_temp_bytes = tb;
   L.scan_temp = off; off = align_up(off + tb);
   L.total = off;
@@ -399,7 +386,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       // sync: the arrays are sized by the budget, the sort classes are launched blind.
       const SliceList work{(const uint32_t*)(geom + G.slice_ids), slice_ctr + 2};
       launch_slice_hist(P, zbin, tiles_touched, radii, slice_hist, slice_cover, st);
-      launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, st);
+      launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, tiles_touched, offsets, slice_ctr + 4, st);
       launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
                               (float2*)(geom + G.uv), work, sel1, G.slice_max_list, st);
       if (launch_bin_count(p, splats, radii, tile_mask, tile_count1, (uint16_t*)(geom + G.block_counts1), sel1, work,
@@ -437,12 +424,9 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                                 (float2*)(geom + G.uv), SliceList{nullptr, nullptr}, sel_rest, 0, st);
         if (want_bwd && (rc = scan_all()) != RTGS_OK) return rc;
       } else if (want_bwd) {
-        // every tile is final: only the slice's Gaussians can receive gradient, and the sum of their rect areas is
-        // within the slice's instance budget by construction of the cut - no host round trip for the size
-        size_t tb = G.scan_temp_bytes;
-        const SliceAreaOp op{zbin, tiles_touched, (const int32_t*)(slice_ctr + 3)};
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(geom + G.scan_temp, tb, SliceAreaIter(hipcub::CountingInputIterator<int>(0), op),
-                                                 offsets, P, st));
+        // every tile is final: only the slice's Gaussians can receive gradient; slice_compact already laid their slot
+        // runs out (gbase in `offsets`), and the sum of their rect areas is within the slice's instance budget by
+        // construction of the cut - no scan over the map, no host round trip for the size
         slots = (uint32_t)G.slice_cap;
       }
     }
@@ -536,6 +520,8 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   c->stats[4] = (int64_t)B.total; c->stats[5] = (int64_t)I.total;
   c->stats[6] = sort_path ? 0 : 1; c->stats[7] = (int64_t)longest;
   c->slice_stats[0] = sliced ? 1 : 0; c->slice_stats[1] = R1; c->slice_stats[2] = n_fin; c->slice_stats[3] = n_left;
+  // which of the two list sets the backward of THIS forward has to walk (host-side hint, keyed by the geometry buffer)
+  c->hint_geom = geom; c->hint_slice_lists = sliced && n_fin > 0; c->hint_main_lists = R > 0;
   return RTGS_OK;
 }
 
@@ -575,15 +561,18 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
   const int32_t* radii = (const int32_t*)(geom + G.radii);
   uint32_t* slot_count = (uint32_t*)(geom + G.slot_count);      // scratch of the backward inside the geometry buffer
   if (R > 0) {
-    HIP_TRY(hipMemsetAsync(slot_count, 0, (size_t)P * sizeof(uint32_t), st));
     // two-pass forward: tiles the near slice finished walk its lists (ranges1_bwd is all-empty otherwise, and a
     // workgroup with an empty range returns at once); every other tile walks the main lists
-    launch_blend_bwd(p, (const uint2*)(geom + G.ranges1_bwd), (const uint32_t*)(geom + G.list1),
-                     (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
-                     dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, st);
-    launch_blend_bwd(p, (const uint2*)(img + I.ranges), (const uint32_t*)(bin + B.vals_b),
-                     (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
-                     dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, st);
+    // (a launch whose every workgroup would find an empty range is skipped when this context still remembers the forward)
+    const bool hinted = c->hint_geom == geom_buffer;
+    if (!hinted || c->hint_slice_lists)
+      launch_blend_bwd(p, (const uint2*)(geom + G.ranges1_bwd), (const uint32_t*)(geom + G.list1),
+                       (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
+                       dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, st);
+    if (!hinted || c->hint_main_lists)
+      launch_blend_bwd(p, (const uint2*)(img + I.ranges), (const uint32_t*)(bin + B.vals_b),
+                       (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
+                       dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, st);
     prof_mark(c, EV_BWALK, st);
     // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
     launch_grad_reduce(P, touched, gbase, slot_count, binfo, grads, st);

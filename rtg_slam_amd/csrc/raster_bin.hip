@@ -517,14 +517,16 @@ void launch_slice_hist(int P, const uint8_t* zbin, const uint32_t* rect_area, co
 // ONE global atomic (one atomic per wave serialised on a single address: 225 us for 1.2 M Gaussians).
 constexpr int COMPACT_CHUNK = 8192;
 __global__ void __launch_bounds__(256) slice_compact_kernel(int P, SliceSel sel, uint32_t* __restrict__ ids,
-                                                            uint32_t* __restrict__ n_list) {
+                                                            uint32_t* __restrict__ n_list,
+                                                            const uint32_t* __restrict__ rect_area,
+                                                            uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_cursor) {
   __shared__ uint32_t s_ids[COMPACT_CHUNK];
-  __shared__ uint32_t s_n, s_base;
+  __shared__ uint32_t s_n, s_base, s_tot, s_gb, s_run, s_w[4];
   const int cut = slice_cut(sel);
-  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int32_t*>(n_list)[1] = cut;   // slice_ctr[3]: for the slot scan
-  if (threadIdx.x == 0) s_n = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int32_t*>(n_list)[1] = cut;   // slice_ctr[3]
+  if (threadIdx.x == 0) { s_n = 0; s_tot = 0; s_run = 0; }
   __syncthreads();
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int begin = blockIdx.x * COMPACT_CHUNK;
   for (int i0 = begin; i0 < begin + COMPACT_CHUNK && i0 < P; i0 += 256 * 4) {
     const int i = i0 + (int)threadIdx.x * 4;
@@ -546,14 +548,43 @@ __global__ void __launch_bounds__(256) slice_compact_kernel(int P, SliceSel sel,
   __syncthreads();
   const uint32_t n = s_n;
   if (n == 0u) return;
-  if (threadIdx.x == 0) s_base = atomicAdd(n_list, n);
+  // The slice's Gaussians also get their runs of gradient slots here (BwdInfo: one slot per tile of the rect): the
+  // workgroup reserves the sum of its rect areas with one atomic and lays its Gaussians out inside - if the slice
+  // finishes every tile these are the only Gaussians in play and no scan over the map is needed (the total is within
+  // the slice's instance budget by construction of the cut); otherwise the full scan overwrites gbase later.
+  uint32_t mine = 0;
+  for (uint32_t k = threadIdx.x; k < n; k += 256) mine += rect_area[s_ids[k]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off);
+  if (lane == 0) atomicAdd(&s_tot, mine);
   __syncthreads();
-  for (uint32_t k = threadIdx.x; k < n; k += 256) ids[s_base + k] = s_ids[k];
+  if (threadIdx.x == 0) { s_base = atomicAdd(n_list, n); s_gb = atomicAdd(slot_cursor, s_tot); }
+  __syncthreads();
+  for (uint32_t k0 = 0; k0 < n; k0 += 256) {
+    const uint32_t k = k0 + threadIdx.x;
+    const uint32_t id = k < n ? s_ids[k] : 0u;
+    const uint32_t a = k < n ? rect_area[id] : 0u;
+    uint32_t incl = a;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    uint32_t pre = s_run;
+    for (int q = 0; q < w; ++q) pre += s_w[q];
+    if (k < n) { gbase[id] = s_gb + pre + incl - a; ids[s_base + k] = id; }
+    __syncthreads();
+    if (threadIdx.x == 0) s_run += (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    __syncthreads();
+  }
 }
-void launch_slice_compact(int P, SliceSel sel, uint32_t* ids, uint32_t* n_list, hipStream_t st) {
+void launch_slice_compact(int P, SliceSel sel, uint32_t* ids, uint32_t* n_list, const uint32_t* rect_area, uint32_t* gbase,
+                          uint32_t* slot_cursor, hipStream_t st) {
   if (P == 0) return;
   hipLaunchKernelGGL(slice_compact_kernel, dim3((P + COMPACT_CHUNK - 1) / COMPACT_CHUNK), dim3(256), 0, st, P, sel, ids,
-                     n_list);
+                     n_list, rect_area, gbase, slot_cursor);
 }
 
 int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,

@@ -32,31 +32,37 @@ __device__ __forceinline__ float xor4(float v) {     // value of lane l^4 (withi
   return dpp_mov<0x114, 0xf, 0xa>(t, v);             // row_shr:4 into banks 1,3  (lane l <- l-4)
 }
 
-// in: v[0..7] per lane.  out: lane l holds sum over its aligned 8-lane group of quantity
-// idx(l) = ((l&1)<<2) | (l&2) | ((l>>2)&1).
+// in: v[0..7] per lane.  out: lane l holds, summed over its 8-lane group {l ^ 8, l ^ 4, l ^ 1 combinations}, quantity
+// idx(l) = ((l >> 3) & 1) << 2 | ((l >> 2) & 1) << 1 | (l & 1).
+// The two wide steps (4 and 2 results) exchange at lane distance 8 and 4, where DPP BANK masks (groups of four lanes)
+// pick which half of a pair keeps which quantity: two v_add_f32_dpp per result and no v_cndmask (the quad_perm form of
+// the same step costs three).  Hand-scheduled so that no DPP source is read within two wait states of its write.
 __device__ __forceinline__ float butterfly8(const float (&v)[8], int lane) {
-  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
-  float w[4], x[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float keep = b0 ? v[i + 4] : v[i];
-    const float send = b0 ? v[i] : v[i + 4];
-    w[i] = keep + dpp_mov<0xB1>(0.f, send);          // quad_perm [1,0,3,2]: lane l^1
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float keep = b1 ? w[i + 2] : w[i];
-    const float send = b1 ? w[i] : w[i + 2];
-    x[i] = keep + dpp_mov<0x4E>(0.f, send);          // quad_perm [2,3,0,1]: lane l^2
-  }
-  const float keep = b2 ? x[1] : x[0];
-  const float send = b2 ? x[0] : x[1];
-  return keep + xor4(send);
+  float w0, w1, w2, w3, x0, x1;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %2, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %2, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %1, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %1, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %3, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %3, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %4, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %4, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %5, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %5, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(x0), "=&v"(x1)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+  const bool b0 = lane & 1;
+  const float keep = b0 ? x1 : x0;
+  const float send = b0 ? x0 : x1;
+  return keep + dpp_mov<0xB1>(0.f, send);              // quad_perm [1,0,3,2]: lane l^1
 }
-// lanes 0..7 of the wave end up with the wave totals of the 8 butterfly quantities (lane l holds
-// quantity idx(l)): fold the two groups of a row (row_ror:8), the two rows of a half (ds_swizzle
-// xor 16) and the two halves (xor 32) - so the LDS add that follows has 8 DISTINCT addresses
-// (8 lanes x same address serialises inside the LDS atomic unit).
+// the 8 lanes of row 0 with (lane & 2) == 0 end up with the wave totals of the 8 butterfly quantities (lane l holds
+// quantity idx(l)): fold the two groups of a row (lane ^ 2), the two rows of a half (xor 16) and the two halves
+// (xor 32) - so the LDS store that follows has 8 DISTINCT addresses.
 __device__ __forceinline__ float xor16_sum(float v) {     // v[l] + v[l ^ 16]: gfx950 v_permlane16_swap, a VALU op (no LDS pipe)
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -66,7 +72,7 @@ __device__ __forceinline__ float xor32_sum(float v) {     // v[l] + v[l ^ 32]: v
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float fold_groups(float v) {
-  v += dpp_mov<0x128>(0.f, v);                                                       // row_ror:8  (lane ^ 8)
+  v += dpp_mov<0x4E>(0.f, v);                                                        // quad_perm [2,3,0,1]: lane ^ 2
   return xor32_sum(xor16_sum(v));
 }
 // Wave totals of TWO values at once (the opacity partials of the two entries of a round): after the first exchange a
@@ -103,10 +109,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
     SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched) {
-  __shared__ float4 s_rec[BATCH * 3];
-  __shared__ int32_t s_id[BATCH];
-  __shared__ float s_hy[BATCH];
-  __shared__ uint32_t s_slot[BATCH];
+  __shared__ float4 s_rec[BATCH * 3];           // u v ca cb | cc o r g | b hy id slot: three 16-B broadcast reads per entry
   __shared__ float s_grad[4 * BATCH * NG];      // one private copy per wave: plain stores, no LDS atomics
   __shared__ float s_dep[BATCH * 4];            // depth-plane partials of the batch's entries (rare: LDS float adds)
 
@@ -153,7 +156,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
   }
   const float bgT = T_final * (p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2);
   float T = 1.f;
-  const int gidx = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
+  const int gidx = (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) | (lane & 1);   // butterfly8's quantity of this lane
+  const bool gstore = (lane & 0x32) == 0;            // the 8 lanes that hold the wave totals after fold_groups
   float* const wgrad = s_grad + (tid >> 6) * BATCH * NG;
   const float strip_y0 = (float)(blockIdx.y * TILE + (tid >> 6) * 4), strip_y1 = strip_y0 + 3.f;
 
@@ -175,14 +179,13 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     __syncthreads();                                   // previous batch fully flushed before its LDS is reused
     if (tid < m) {
       const uint32_t id = point_list[range.x + base + tid];
-      s_id[tid] = (int32_t)id;
       const float4* src = reinterpret_cast<const float4*>(splats + id);
-      const float4 q0 = src[0];
-      s_rec[tid * 3 + 0] = q0;
+      s_rec[tid * 3 + 0] = src[0];
       s_rec[tid * 3 + 1] = src[1];
-      s_rec[tid * 3 + 2] = src[2];
-      s_hy[tid] = reinterpret_cast<const float*>(splats + id)[15];
-      if (use_slots) s_slot[tid] = gbase[id];          // first slot of the Gaussian's run
+      const float b = reinterpret_cast<const float*>(splats + id)[8];
+      const float hy = reinterpret_cast<const float*>(splats + id)[15];
+      const uint32_t slot0 = use_slots ? gbase[id] : 0u;       // first slot of the Gaussian's run
+      s_rec[tid * 3 + 2] = make_float4(b, hy, __uint_as_float(id), __uint_as_float(slot0));
     }
     for (int q = tid; q < 4 * BATCH * NG; q += BLOCK)
       if ((q % (BATCH * NG)) < m * NG) s_grad[q] = 0.f;
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
     // T / S recurrences are sequential.
     for (int j = 0; j < m; j += 2) {
       if (__builtin_amdgcn_ballot_w64((uint32_t)(base + j) < last) == 0ull) break;   // wave past its last contributor
-      float4 r0[2], r1[2];
+      float4 r0[2], r1[2], r2[2];
       float dx[2], dy[2], G[2], alpha[2];
       bool valid[2], own[2];
       int e[2];
@@ -203,14 +206,16 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
         e[k] = min(j + k, m - 1);                                 // past the end: re-read the last entry, masked out
         r0[k] = s_rec[e[k] * 3 + 0];
         r1[k] = s_rec[e[k] * 3 + 1];
-        const float ehy = s_hy[e[k]];
-        const bool live = (j + k < m) && !(r0[k].y + ehy < strip_y0 || r0[k].y - ehy > strip_y1);   // wave-uniform
+        r2[k] = s_rec[e[k] * 3 + 2];
+        const float ehy = r2[k].y;
+        const bool in_batch = j + k < m;
+        const bool live = in_batch & !((r0[k].y + ehy < strip_y0) | (r0[k].y - ehy > strip_y1));     // wave-uniform, branch-free
         dx[k] = r0[k].x - pxf; dy[k] = r0[k].y - pyf;
         const float power = splat_power(r0[k].z, r0[k].w, r1[k].x, dx[k], dy[k]);
         G[k] = splat_exp(fminf(power, 0.f));
         alpha[k] = fminf(0.99f, r1[k].y * G[k]);
-        valid[k] = live && ((uint32_t)(base + j + k) < last) && !(power > 0.f) && !(alpha[k] < 1.f / 255.f);
-        own[k] = (j + k < m) && (owner == s_id[e[k]]);
+        valid[k] = live & ((uint32_t)(base + j + k) < last) & !(power > 0.f) & !(alpha[k] < 1.f / 255.f);
+        own[k] = in_batch & (owner == (int)__float_as_uint(r2[k].z));
       }
       const unsigned long long vm0 = __builtin_amdgcn_ballot_w64(valid[0]);
       const unsigned long long vm1 = __builtin_amdgcn_ballot_w64(valid[1]);
@@ -218,7 +223,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
       float gda[2], w[2], Tk[2], Sg[2], cg[2], ia[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {                               // sequential part: T and the colour behind
-        const float c0 = r1[k].z, c1 = r1[k].w, c2 = s_rec[e[k] * 3 + 2].x;
+        const float c0 = r1[k].z, c1 = r1[k].w, c2 = r2[k].x;
         w[k] = valid[k] ? alpha[k] * T : 0.f;
         S0 -= c0 * w[k]; S1 -= c1 * w[k]; S2 -= c2 * w[k];       // colour strictly behind this entry
         Tk[k] = T;
@@ -248,12 +253,12 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
       // every (wave, entry, quantity) slot is written at most once per batch -> plain LDS stores
       if (vm0) {
         const float t8 = fold_groups(r8[0]);
-        if (lane < 8) wgrad[e[0] * NG + gidx] = t8;
+        if (gstore) wgrad[e[0] * NG + gidx] = t8;
         if (lane == 0) wgrad[e[0] * NG + 8] = ro;
       }
       if (vm1) {
         const float t8 = fold_groups(r8[1]);
-        if (lane < 8) wgrad[e[1] * NG + gidx] = t8;
+        if (gstore) wgrad[e[1] * NG + gidx] = t8;
         if (lane == 1) wgrad[e[1] * NG + 8] = ro;
       }
       // depth owners among this wave's pixels (each pixel owns at most one entry of the whole list: rare per round)
@@ -296,18 +301,19 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
           t[3] = -t[3];                                    // dcb
           t[4] = -0.5f * t[4];                             // dcc
         }
-        touched[s_id[tid]] = 1;     // byte per Gaussian: grad_reduce / the row-state backward skip untouched Gaussians
+        const uint32_t gid = __float_as_uint(s_rec[tid * 3 + 2].z);
+        touched[gid] = 1;     // byte per Gaussian: grad_reduce / the row-state backward skip untouched Gaussians
         if (use_slots) {
           // SplatGrad order: du dv dca dcb | dcc dop dr dg | db dnx dny dnz | dpd - - -
           // next free slot of the run: at most one tile per rect tile asks, so the run (= rect area) cannot overflow
-          const uint32_t slot = s_slot[tid] + atomicAdd(&slot_count[s_id[tid]], 1u);
+          const uint32_t slot = __float_as_uint(s_rec[tid * 3 + 2].w) + atomicAdd(&slot_count[gid], 1u);
           float4* dst = reinterpret_cast<float4*>(slot_grads + slot);
           dst[0] = make_float4(t[0], t[1], t[2], t[3]);
           dst[1] = make_float4(t[4], t[8], t[5], t[6]);
           dst[2] = make_float4(t[7], t[9], t[10], t[11]);
           dst[3] = make_float4(t[12], 0.f, 0.f, 0.f);
         } else {
-          float* dst = reinterpret_cast<float*>(grads + s_id[tid]);
+          float* dst = reinterpret_cast<float*>(grads + gid);
           if (t[0] != 0.f) unsafeAtomicAdd(dst + 0, t[0]);
           if (t[1] != 0.f) unsafeAtomicAdd(dst + 1, t[1]);
           if (t[2] != 0.f) unsafeAtomicAdd(dst + 2, t[2]);
@@ -336,7 +342,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) grad_reduce_kernel(int P, const uint8_t* __restrict__ touched,
                                                           const uint32_t* __restrict__ gbase,
-                                                          const uint32_t* __restrict__ count,
+                                                          uint32_t* __restrict__ count,
                                                           const BwdInfo* __restrict__ info,
                                                           SplatGrad* __restrict__ grads) {
   if (info->use_slots == 0) return;
@@ -371,6 +377,7 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(int P, const uint8_t* 
       acc += __shfl_xor(acc, 16);
       acc += __shfl_xor(acc, 32);
       if (lane < 16) reinterpret_cast<float*>(grads + id)[c] = acc;
+      if (lane == 0) count[id] = 0u;          // the counters are zero between calls (the forward clears them too)
     }
     for (int k0 = 0; k0 < nsmall; k0 += 4) {
       const int k = k0 + grp;
@@ -381,6 +388,7 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(int P, const uint8_t* 
       float acc = 0.f;
       for (uint32_t q = 0; q < n; ++q) acc += slots[(b0 + q) * 16 + c];
       if (act) reinterpret_cast<float*>(grads + id)[c] = acc;
+      if (act && c == 0) count[id] = 0u;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -644,7 +652,7 @@ void launch_blend_bwd(const RasterParams& p, const uint2* ranges, const uint32_t
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
                      final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched);
 }
-void launch_grad_reduce(int P, const uint8_t* touched, const uint32_t* gbase, const uint32_t* count, const BwdInfo* info,
+void launch_grad_reduce(int P, const uint8_t* touched, const uint32_t* gbase, uint32_t* count, const BwdInfo* info,
                         SplatGrad* grads, hipStream_t st) {
   if (P == 0) return;
   int blocks = (P + 255) / 256;

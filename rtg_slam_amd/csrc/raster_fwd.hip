@@ -311,9 +311,8 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
     float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
     unsigned long long* __restrict__ counters, SlicePass sp) {
-  __shared__ float4 s_rec[BATCH * 4];
-  __shared__ int32_t s_id[BATCH];
-  __shared__ float2 s_h[BATCH];
+  __shared__ float4 s_rec[BATCH * 4];     // u v ca cb | cc o r g | b hx hy id | nx ny nz pd: the walk reads the first three
+  __shared__ float s_z[BATCH];            // centre depth (opaque-surface test only)
 
   const int tid = threadIdx.x;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
@@ -342,14 +341,14 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     const int m = min(BATCH, n - base);
     if (tid < m) {
       const uint32_t id = point_list[range.x + base + tid];
-      s_id[tid] = (int32_t)id;
       const float4* src = reinterpret_cast<const float4*>(splats + id);
       s_rec[tid * 4 + 0] = src[0];
       s_rec[tid * 4 + 1] = src[1];
-      s_rec[tid * 4 + 2] = src[2];
-      const float4 r3 = src[3];
-      s_rec[tid * 4 + 3] = r3;
-      s_h[tid] = make_float2(r3.z, r3.w);
+      const float4 q2 = src[2];               // b nx ny nz
+      const float4 q3 = src[3];               // pd z hx hy
+      s_rec[tid * 4 + 2] = make_float4(q2.x, q3.z, q3.w, __uint_as_float(id));
+      s_rec[tid * 4 + 3] = make_float4(q2.y, q2.z, q2.w, q3.x);
+      s_z[tid] = q3.y;
     }
     __syncthreads();
     // Four entries per round: their records are read and their alphas evaluated back to back (independent
@@ -360,7 +359,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
       const unsigned long long am = __builtin_amdgcn_ballot_w64(!done);
       if (am == 0ull) break;                // whole wave finished
       if (am != box.mask) refresh_box(box, am, blockIdx.x * TILE, blockIdx.y * TILE + (tid >> 6) * 4);
-      float4 r0[4], r1[4];
+      float4 r0[4], r1[4], r2[4];
       float alpha[4];
       bool live[4];
       int e[4];
@@ -369,10 +368,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
         e[k] = min(j + k, m - 1);           // past the end: re-read the last entry (finite data), masked out by live[]
         r0[k] = s_rec[e[k] * 4 + 0];        // u v ca cb
         r1[k] = s_rec[e[k] * 4 + 1];        // cc o r g
-        const float2 eh = s_h[e[k]];
+        r2[k] = s_rec[e[k] * 4 + 2];        // b hx hy id
         // wave-uniform: entry exists and its alpha >= 1/255 region reaches a pixel of this wave still walking
-        live[k] = (j + k < m) && !(r0[k].x + eh.x < box.x0 || r0[k].x - eh.x > box.x1 || r0[k].y + eh.y < box.y0 ||
-                                   r0[k].y - eh.y > box.y1);
+        live[k] = (j + k < m) & !((r0[k].x + r2[k].y < box.x0) | (r0[k].x - r2[k].y > box.x1) | (r0[k].y + r2[k].z < box.y0) |
+                                  (r0[k].y - r2[k].z > box.y1));
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -400,10 +399,9 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
       bool want_depth = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float cb = s_rec[e[k] * 4 + 2].x;
-        C0 += r1[k].z * w[k]; C1 += r1[k].w * w[k]; C2 += cb * w[k];
+        C0 += r1[k].z * w[k]; C1 += r1[k].w * w[k]; C2 += r2[k].x * w[k];
         const bool better = w[k] > best_w;   // w == 0 for non-contributing lanes, best_w >= 0
-        const int gid = s_id[e[k]];
+        const int gid = (int)__float_as_uint(r2[k].w);
         best_w = better ? w[k] : best_w;
         best_id = better ? gid : best_id;
         want_depth = want_depth || (w[k] > 0.f && alpha[k] > p.opaque_thr);
@@ -412,12 +410,11 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (w[k] > 0.f && d_id < 0 && alpha[k] > p.opaque_thr) {
-            const float4 r2 = s_rec[e[k] * 4 + 2];  // b nx ny nz
-            const float4 r3 = s_rec[e[k] * 4 + 3];  // pd z hx hy
-            const float den = r2.y * rx + r2.z * ry + r2.w;
+            const float4 r3 = s_rec[e[k] * 4 + 3];  // nx ny nz pd
+            const float den = r3.x * rx + r3.y * ry + r3.z;
             if (fabsf(den) / rnorm > p.normal_thr) {
-              const float zhit = r3.x / den;
-              if (zhit > 0.f && fabsf(zhit - r3.y) < p.depth_thr) { D = zhit; d_w = alpha[k]; d_id = s_id[e[k]]; }
+              const float zhit = r3.w / den;
+              if (zhit > 0.f && fabsf(zhit - s_z[e[k]]) < p.depth_thr) { D = zhit; d_w = alpha[k]; d_id = (int)__float_as_uint(r2[k].w); }
             }
           }
         }
