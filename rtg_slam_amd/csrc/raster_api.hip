@@ -33,7 +33,7 @@ size_t bin_block_counts_bytes(int, int);
 int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, uint16_t*, SliceSel,
                      SliceList, size_t, hipStream_t);
 size_t bin_slice_block_counts_bytes(int, size_t, int);
-void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, hipStream_t);
+void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, hipStream_t);
 void launch_slice_publish(int, const int32_t*, const int32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, hipStream_t);
 void launch_preprocess_cull(const RasterParams&, const float*, const float*, const float*, uint32_t*, int32_t*, int32_t*,
                             uint32_t*, int, uint8_t*, float2*, hipStream_t);
@@ -71,6 +71,11 @@ struct rtgs_ctx {
   // what the most recent forward on this context left for its backward (see backward_impl)
   const void* hint_geom = nullptr;
   bool hint_slice_lists = true, hint_main_lists = true;
+  // Automatic near-slice mode: whether a call takes the slice is decided on the device from that call's histograms and
+  // never depends on history.  Only HOW the host learns it does: after a call that declined, the next one asks for the
+  // decision (one extra pinned-flag sync, ~10 us) before it launches the slice's kernels instead of launching them
+  // blind over an empty work list (~50 us of empty launches on a surface map).
+  bool ask_first = false;
 };
 
 namespace rtgs {
@@ -341,6 +346,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   const bool slice_auto = c->slice_mode == 2;
   bool sliced = !sort_path && P > 0 && (c->slice_mode == 1 || (slice_auto && P >= 100000 && ntiles >= 256));
   SlicePass pass{0, nullptr, nullptr, nullptr, nullptr};
+  bool declined = false, considered = false;
   // pinned host words the kernels publish totals into, and the spin that waits for them: a few microseconds instead
   // of the ~25 us a blocking hipStreamSynchronize takes to wake up (bounded; falls back)
   if (!c->info_host) {
@@ -384,9 +390,28 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       // Pass 1: bin, sort and blend only the nearest Gaussians (as many depth bins as fit the instance budget).  Tiles
       // whose every pixel saturates inside the slice are final; blend_fwd leaves a tile mask of the others.  No host
       // sync: the arrays are sized by the budget, the sort classes are launched blind.
-      const SliceList work{(const uint32_t*)(geom + G.slice_ids), slice_ctr + 2};
       launch_slice_hist(P, zbin, tiles_touched, radii, slice_hist, slice_cover, st);
-      launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, tiles_touched, offsets, slice_ctr + 4, st);
+      const bool ask = slice_auto && c->ask_first;
+      if (ask && ++c->seq == 0u) c->seq = 1u;
+      launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, tiles_touched, offsets, slice_ctr + 4,
+                           ask ? info_host : nullptr, c->seq, st);
+      if (ask) {
+        if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
+        declined = (int32_t)info_host[6] < 0;
+      }
+    }
+    if (sliced && declined) {
+      // the kernels declined the slice and the host knows: shade every visible Gaussian and go on as a single pass
+      SliceSel sel_all = sel1;
+      sel_all.ctr = nullptr;
+      launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
+                              (float2*)(geom + G.uv), SliceList{nullptr, nullptr}, sel_all, 0, st);
+      if (want_bwd && (rc = scan_all()) != RTGS_OK) return rc;
+      sliced = false;
+      considered = true;
+    }
+    if (sliced) {
+      const SliceList work{(const uint32_t*)(geom + G.slice_ids), slice_ctr + 2};
       launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
                               (float2*)(geom + G.uv), work, sel1, G.slice_max_list, st);
       if (launch_bin_count(p, splats, radii, tile_mask, tile_count1, (uint16_t*)(geom + G.block_counts1), sel1, work,
@@ -519,7 +544,9 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   c->stats[0] = R + R1; c->stats[1] = sort_bits; c->stats[2] = ntiles; c->stats[3] = (int64_t)G.total;
   c->stats[4] = (int64_t)B.total; c->stats[5] = (int64_t)I.total;
   c->stats[6] = sort_path ? 0 : 1; c->stats[7] = (int64_t)longest;
-  c->slice_stats[0] = sliced ? 1 : 0; c->slice_stats[1] = R1; c->slice_stats[2] = n_fin; c->slice_stats[3] = n_left;
+  c->slice_stats[0] = (sliced || considered) ? 1 : 0; c->slice_stats[1] = R1; c->slice_stats[2] = n_fin;
+  c->slice_stats[3] = considered ? (int64_t)ntiles : (int64_t)n_left;      // declined: every tile goes to the single pass
+  if (slice_auto && (sliced || considered)) c->ask_first = considered || (R1 == 0 && n_fin == 0);
   // which of the two list sets the backward of THIS forward has to walk (host-side hint, keyed by the geometry buffer)
   c->hint_geom = geom; c->hint_slice_lists = sliced && n_fin > 0; c->hint_main_lists = R > 0;
   return RTGS_OK;

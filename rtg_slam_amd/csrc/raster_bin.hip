@@ -519,11 +519,18 @@ constexpr int COMPACT_CHUNK = 8192;
 __global__ void __launch_bounds__(256) slice_compact_kernel(int P, SliceSel sel, uint32_t* __restrict__ ids,
                                                             uint32_t* __restrict__ n_list,
                                                             const uint32_t* __restrict__ rect_area,
-                                                            uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_cursor) {
+                                                            uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_cursor,
+                                                            uint32_t* __restrict__ host, uint32_t seq) {
   __shared__ uint32_t s_ids[COMPACT_CHUNK];
   __shared__ uint32_t s_n, s_base, s_tot, s_gb, s_run, s_w[4];
   const int cut = slice_cut(sel);
-  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int32_t*>(n_list)[1] = cut;   // slice_ctr[3]
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    reinterpret_cast<int32_t*>(n_list)[1] = cut;   // slice_ctr[3]
+    if (host) {   // the host asked to hear the decision before it launches the slice's kernels (raster_api.hip)
+      host[6] = (uint32_t)cut;
+      __hip_atomic_store(&host[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   if (threadIdx.x == 0) { s_n = 0; s_tot = 0; s_run = 0; }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -581,10 +588,10 @@ __global__ void __launch_bounds__(256) slice_compact_kernel(int P, SliceSel sel,
   }
 }
 void launch_slice_compact(int P, SliceSel sel, uint32_t* ids, uint32_t* n_list, const uint32_t* rect_area, uint32_t* gbase,
-                          uint32_t* slot_cursor, hipStream_t st) {
+                          uint32_t* slot_cursor, uint32_t* host, uint32_t seq, hipStream_t st) {
   if (P == 0) return;
   hipLaunchKernelGGL(slice_compact_kernel, dim3((P + COMPACT_CHUNK - 1) / COMPACT_CHUNK), dim3(256), 0, st, P, sel, ids,
-                     n_list, rect_area, gbase, slot_cursor);
+                     n_list, rect_area, gbase, slot_cursor, host, seq);
 }
 
 int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       if (i >= (int)*list.count) return;
       i = (int)list.ids[i];
     } else {
-      if (sel.ctr[0] == 0u) return;              // the slice finished every tile: nobody will read the other Splats
+      if (sel.ctr && sel.ctr[0] == 0u) return;   // the slice finished every tile: nobody will read the other Splats
       const int cut = slice_cut(sel);            // (all 256 threads of the workgroup call)
       if (i >= p.P) return;
       const int zb = (int)sel.zbin[i];

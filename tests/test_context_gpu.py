@@ -105,7 +105,9 @@ def test_backward_does_not_depend_on_the_budget_in_force():
 
 def test_automatic_mode_decides_per_call_not_from_history():
     """Automatic near-slice mode on a depth-complex 200 k map runs the slice on EVERY call (no cooldown state), and
-    on a single-layer surface map of the same size never does; outputs equal the single-pass forward either way."""
+    on a single-layer surface map of the same size never does - whatever was rendered before (the host only changes HOW
+    it learns the decision: after a declined call it asks before launching the slice's kernels); outputs equal the
+    single-pass forward in every case, gradients too."""
     from rtg_slam_amd.rasterizer import RasterContext
     cam = synth.CONFIG2
     ctx = RasterContext.create()
@@ -115,18 +117,25 @@ def test_automatic_mode_decides_per_call_not_from_history():
     gen = torch.Generator().manual_seed(1)
     grads = (torch.randn(3, cam.H, cam.W, generator=gen), torch.randn(1, cam.H, cam.W, generator=gen))
     g, s = ru.make_scene(200_000, cam, seed=2024)
-    ref, _ = _run(s, g, grads, context=off)
-    for _ in range(3):
-        out, _ = _run(s, g, grads, context=ctx)
-        st = ctx.last_slice_stats()
-        assert st["used"] == 1 and st["tiles_finished"] > st["tiles_left_to_pass2"], st
-        for a, b in zip(out, ref):
-            assert torch.equal(a, b)
     gs = synth.surface_gaussians(200_000, cam, seed=7)
-    ref, _ = _run(s, gs, grads, context=off)
-    for _ in range(2):
-        out, _ = _run(s, gs, grads, context=ctx)
+    ref_c, gd_c = _run(s, g, grads, context=off)
+    ref_s, gd_s = _run(s, gs, grads, context=off)
+
+    def check(scene, ref, gd_ref, taken):
+        out, gd = _run(s, scene, grads, context=ctx)
         st = ctx.last_slice_stats()
-        assert st["instances"] == 0 and st["tiles_finished"] == 0, st      # the kernels declined the slice
+        if taken:
+            assert st["used"] == 1 and st["tiles_finished"] > st["tiles_left_to_pass2"], st
+        else:
+            assert st["used"] == 1 and st["instances"] == 0 and st["tiles_finished"] == 0, st   # the kernels declined
         for a, b in zip(out, ref):
             assert torch.equal(a, b)
+        for k in ru.FIELDS:
+            sc = float(gd_ref[k].abs().max()) + 1e-12
+            assert float((gd[k] - gd_ref[k]).abs().max()) / sc < 1e-4, k
+
+    # taken blind x2, declined blind, declined asked x2, taken asked, taken blind, declined blind
+    for scene, ref, gd_ref, taken in [(g, ref_c, gd_c, True), (g, ref_c, gd_c, True), (gs, ref_s, gd_s, False),
+                                      (gs, ref_s, gd_s, False), (gs, ref_s, gd_s, False), (g, ref_c, gd_c, True),
+                                      (g, ref_c, gd_c, True), (gs, ref_s, gd_s, False)]:
+        check(scene, ref, gd_ref, taken)
