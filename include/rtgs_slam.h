@@ -10,6 +10,7 @@
  *   rtgs_accumulate_error    cuda_utils._C.accumulate_gaussian_error (un-vendored; call site mapper.py:541-565)
  *   frame preprocessing      tracker.py:97-159 -> SLAM/utils.py:65-139 (vertex / normal / confidence maps),
  *                            SLAM/utils.py:550-589 (bilateral filter), SLAM/utils.py:141-183 (sample_pixels' mask)
+ *   rtgs_gather_rows3        the normal-map gather of Renderer.render, SLAM/render.py:130-133
  */
 #ifndef RTGS_SLAM_H
 #define RTGS_SLAM_H
@@ -77,6 +78,13 @@ int rtgs_frame_preprocess(const float* depth_in, int32_t H, int32_t W, const flo
 size_t rtgs_compact_scratch_bytes(int32_t n);
 int rtgs_sample_candidates(const float* normal_map, const uint8_t* select_mask, int32_t H, int32_t W, int32_t* indices_out,
                            int32_t* count_out, uint8_t* flags_scratch, void* scratch, void* stream);
+
+/* ---- Renderer.render's normal map (SLAM/render.py:130-133) ----------------------------------------------------- */
+/* out[3,n]: out[:, p] = rows[index[p]] (rows float32 [N,3]) where index[p] >= 0, zeros elsewhere - the reference's two
+ * boolean-mask indexings (two device-to-host syncs per render) as one kernel.  scatter = its backward: grad_rows[index[p]] +=
+ * g[:, p] (accumulates; caller zeroes). */
+int rtgs_gather_rows3(const float* rows, const int32_t* index, int32_t n, float* out, void* stream);
+int rtgs_scatter_rows3(const float* g, const int32_t* index, int32_t n, float* grad_rows, void* stream);
 
 #ifdef __cplusplus
 }

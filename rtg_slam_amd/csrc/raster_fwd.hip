@@ -13,22 +13,31 @@ namespace rtgs {
 // tile-mask summed-area table: sat[(y+1)*(gx+1)+(x+1)] = #{mask != 0 in [0..y]x[0..x]}
 // One workgroup; the grid is at most a few thousand tiles (43x75 for Replica).
 // ---------------------------------------------------------------------------------------------
+constexpr int SAT_LDS = 12288;     // entries staged in LDS (Replica: 76 x 44 = 3 344); larger grids work in global memory
 __global__ void __launch_bounds__(256) mask_sat_kernel(const int32_t* __restrict__ mask, int gx, int gy,
                                                        int32_t* __restrict__ sat) {
-  const int sw = gx + 1;
-  for (int i = threadIdx.x; i < (gy + 1) * sw; i += blockDim.x) {
+  __shared__ int32_t s_sat[SAT_LDS];
+  const int sw = gx + 1, n = (gy + 1) * sw;
+  // the two prefix passes are chains of dependent read-modify-writes: in LDS a step costs ~100 cycles, in global
+  // memory ~2 000 (the global form took 25 us for 43 x 75 tiles)
+  int32_t* const w = n <= SAT_LDS ? s_sat : sat;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int y = i / sw, x = i % sw;
-    sat[i] = (y == 0 || x == 0) ? 0 : (mask[(y - 1) * gx + (x - 1)] != 0);
+    w[i] = (y == 0 || x == 0) ? 0 : (mask[(y - 1) * gx + (x - 1)] != 0);
   }
   __syncthreads();
   for (int y = 1 + threadIdx.x; y <= gy; y += blockDim.x) {      // row prefix
     int acc = 0;
-    for (int x = 1; x <= gx; ++x) { acc += sat[y * sw + x]; sat[y * sw + x] = acc; }
+    for (int x = 1; x <= gx; ++x) { acc += w[y * sw + x]; w[y * sw + x] = acc; }
   }
   __syncthreads();
   for (int x = 1 + threadIdx.x; x <= gx; x += blockDim.x) {      // column prefix
     int acc = 0;
-    for (int y = 1; y <= gy; ++y) { acc += sat[y * sw + x]; sat[y * sw + x] = acc; }
+    for (int y = 1; y <= gy; ++y) { acc += w[y * sw + x]; w[y * sw + x] = acc; }
+  }
+  if (w != sat) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sat[i] = w[i];
   }
 }
 

@@ -453,6 +453,32 @@ using namespace rtgs_slam;
     if ((expr) != hipSuccess) return -2;  \
   } while (0)
 
+
+namespace {
+// Renderer.render's normal map (SLAM/render.py:130-133): out[:, p] = rows[index[p]] where index[p] >= 0, else 0.
+__global__ void __launch_bounds__(256) gather_rows3_kernel(const float* __restrict__ rows, const int32_t* __restrict__ index, int n,
+                                                           float* __restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int id = index[p];
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (id >= 0) { x = rows[3 * (size_t)id]; y = rows[3 * (size_t)id + 1]; z = rows[3 * (size_t)id + 2]; }
+  out[p] = x; out[(size_t)n + p] = y; out[2 * (size_t)n + p] = z;
+}
+// its backward: grad_rows[index[p]] += g[:, p]
+__global__ void __launch_bounds__(256) scatter_rows3_kernel(const float* __restrict__ g, const int32_t* __restrict__ index, int n,
+                                                            float* __restrict__ grad_rows) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int id = index[p];
+  if (id < 0) return;
+  const float x = g[p], y = g[(size_t)n + p], z = g[2 * (size_t)n + p];
+  if (x != 0.f) atomicAdd(grad_rows + 3 * (size_t)id, x);
+  if (y != 0.f) atomicAdd(grad_rows + 3 * (size_t)id + 1, y);
+  if (z != 0.f) atomicAdd(grad_rows + 3 * (size_t)id + 2, z);
+}
+}  // namespace
+
 extern "C" {
 
 int rtgs_tile_sum(const void* src, int32_t src_kind, int32_t H, int32_t W, int32_t stride, float* tile_sum, void* stream) {
@@ -622,6 +648,24 @@ int rtgs_sample_candidates(const float* normal_map, const uint8_t* select_mask, 
   size_t tb = rtgs_compact_scratch_bytes(n) - 256;
   SLAM_TRY(hipcub::DeviceSelect::Flagged(scratch, tb, hipcub::CountingInputIterator<int32_t>(0), (const uint8_t*)flags_scratch,
                                          indices_out, count_out, n, st));
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+
+int rtgs_gather_rows3(const float* rows, const int32_t* index, int32_t n, float* out, void* stream) {
+  if (!index || !out || n < 0) return -1;
+  if (n == 0) return 0;
+  if (!rows) return -1;
+  hipLaunchKernelGGL(gather_rows3_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, rows, index, n, out);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+int rtgs_scatter_rows3(const float* g, const int32_t* index, int32_t n, float* grad_rows, void* stream) {
+  if (!g || !index || n < 0) return -1;
+  if (n == 0) return 0;
+  if (!grad_rows) return -1;
+  hipLaunchKernelGGL(scatter_rows3_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, g, index, n, grad_rows);
   SLAM_TRY(hipGetLastError());
   return 0;
 }

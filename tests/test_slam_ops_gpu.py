@@ -172,3 +172,48 @@ def test_sample_pixels_candidates_and_draw(gold):
     n_all = int(so.sample_pixels_mask(normal, sel).sum())
     pts, _, _ = ops.sample_pixels(vertex, normal.to(DEV), color, 10 ** 9, sel.to(DEV))
     assert pts.shape[0] == n_all                                         # asks for more than there is: gets them all
+
+
+def test_renderer_wrapper_matches_the_reference_wrapper_logic():
+    """rtg_slam_amd.render.Renderer (interface of SLAM/render.py:21-145): same result dict as the reference wrapper's
+    own lines restated with torch indexing, including the normal map of render.py:130-133 and its gradient to `normal`."""
+    import math
+    from types import SimpleNamespace
+    from tests import raster_util as ru
+    from rtg_slam_amd import synth
+    from rtg_slam_amd.render import Renderer
+    dev = "cuda:0"
+    cam = synth.CameraSpec(136, 200, 180.0, 175.0, 99.5, 67.5)
+    N = 6000
+    g, s = ru.make_scene(N, cam, seed=31, pose_seed=2, r_range=(0.02, 0.1))
+    args = SimpleNamespace(renderer_opaque_threshold=s.opaque_threshold,
+                           renderer_normal_threshold=math.degrees(math.acos(s.normal_threshold)),
+                           renderer_depth_threshold=s.depth_threshold, max_sh_degree=3, color_sigma=s.color_sigma,
+                           active_sh_degree=-1)
+    view = SimpleNamespace(FoVx=2 * math.atan(s.tanfovx), FoVy=2 * math.atan(s.tanfovy), image_height=s.image_height,
+                           image_width=s.image_width, world_view_transform=s.viewmatrix.to(dev),
+                           full_proj_transform=s.projmatrix.to(dev), camera_center=s.campos.to(dev), cx=s.cx, cy=s.cy)
+    gd = {k: g[k].to(dev) for k in ru.FIELDS}
+    gd["normal"] = gd["normal"].clone().requires_grad_(True)
+    r = Renderer(args)
+    gy, gx = (s.image_height + 15) // 16, (s.image_width + 15) // 16
+    mask = (torch.rand(gy, gx, generator=torch.Generator().manual_seed(3)) < 0.8).int().to(dev)
+    for tm in (None, mask):
+        out = r.render(view, gd, tile_mask=tm)
+        assert set(out) == {"render", "depth", "normal", "color_index_map", "depth_index_map", "color_hit_weight",
+                            "depth_hit_weight", "T_map"}
+        ref = ru.hip_run(s, g, tile_mask=tm, dev=dev)[0]
+        for key, k in (("render", 0), ("depth", 1), ("color_index_map", 2), ("depth_index_map", 3), ("color_hit_weight", 4),
+                       ("depth_hit_weight", 5), ("T_map", 6)):
+            assert torch.equal(out[key].detach().cpu(), ref[k]), key
+        # render.py:130-133, literally
+        idx = out["depth_index_map"]
+        want = torch.zeros_like(out["render"])
+        nrm = gd["normal"].detach().clone().requires_grad_(True)
+        want[:, idx[0] > -1] = nrm[idx[idx > -1].long()].permute(1, 0)
+        assert torch.equal(out["normal"].detach(), want.detach())
+        assert int((idx > -1).sum()) > 100
+        w = torch.randn(3, s.image_height, s.image_width, generator=torch.Generator().manual_seed(5)).to(dev)
+        (g_hip,) = torch.autograd.grad((out["normal"] * w).sum(), gd["normal"], retain_graph=True)
+        (g_ref,) = torch.autograd.grad((want * w).sum(), nrm)
+        assert float((g_hip - g_ref).abs().max()) <= 1e-5 * float(g_ref.abs().max() + 1e-12)
