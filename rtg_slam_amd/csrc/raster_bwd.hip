@@ -102,7 +102,7 @@ __device__ __forceinline__ float group8_sum(float v) {   // every lane: sum over
   return v;
 }
 
-__global__ void __launch_bounds__(256) blend_bwd_kernel(
+__global__ void __launch_bounds__(256, 6) blend_bwd_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, const float* __restrict__ out_color, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const int32_t* __restrict__ depth_index,
@@ -569,20 +569,6 @@ __device__ __forceinline__ void preprocess_bwd_one(
   const float x = ddx * il, y = ddy * il, z = ddz * il;
   const uint8_t cl = clamped[i];
   const float gc[3] = {(cl & 1) ? 0.f : g.dr, (cl & 2) ? 0.f : g.dg, (cl & 4) ? 0.f : g.db};
-  float shv[48];
-  if (p.M == 16) {
-    const float4* sh4 = reinterpret_cast<const float4*>(shs + (size_t)i * 48);
-#pragma unroll
-    for (int q = 0; q < 12; ++q) {
-      const float4 t = sh4[q];
-      shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w;
-    }
-  } else {
-    const float* shp = shs + (size_t)i * p.M * 3;
-#pragma unroll
-    for (int q = 0; q < 48; ++q) shv[q] = (q < p.M * 3) ? shp[q] : 0.f;
-  }
-  const float* sh = shv;
   float dRdx = 0.f, dRdy = 0.f, dRdz = 0.f;   // dL/d(dir)
   const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
   float basis[16];
@@ -611,6 +597,21 @@ __device__ __forceinline__ void preprocess_bwd_one(
       dsh[3 * k] = bk * gc[0]; dsh[3 * k + 1] = bk * gc[1]; dsh[3 * k + 2] = bk * gc[2];
     }
   }
+  // (the SH block is read only now, after the 48 gradient values above are stored and dead)
+  float shv[48];
+  if (p.M == 16) {
+    const float4* sh4 = reinterpret_cast<const float4*>(shs + (size_t)i * 48);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      const float4 t = sh4[q];
+      shv[4 * q] = t.x; shv[4 * q + 1] = t.y; shv[4 * q + 2] = t.z; shv[4 * q + 3] = t.w;
+    }
+  } else {
+    const float* shp = shs + (size_t)i * p.M * 3;
+#pragma unroll
+    for (int q = 0; q < 48; ++q) shv[q] = (q < p.M * 3) ? shp[q] : 0.f;
+  }
+  const float* sh = shv;
   // d(basis_k)/d(x,y,z) contracted with sum_c gc[c] * sh[k][c]
   auto shg = [&](int k) { return gc[0] * sh[3 * k] + gc[1] * sh[3 * k + 1] + gc[2] * sh[3 * k + 2]; };
   if (p.deg > 0) {
