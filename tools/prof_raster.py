@@ -44,4 +44,7 @@ for _ in range(iters):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / iters * 1e3
 names = ["preprocess_fwd", "bin_count", "bin_scatter", "bin_tilesort", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "slice_bin", "slice_blend", "grad_reduce"]
+sl = (C.c_int64 * 4)()
+lib.rtgs_raster_last_slice_stats(sl)
+print("near slice: used %d instances %d tiles finished %d left %d" % tuple(sl))
 print(which, f"iter {dt:.3f} ms (with per-iteration sync) |", " ".join(f"{n}={v * 1e3:.0f}us" for n, v in zip(names, acc)))
