@@ -208,6 +208,12 @@ class IcpTracker:
             raise RuntimeError("rtgs_icp_track: the persistent tracking kernel timed out at a grid barrier "
                                "(set RTGS_ICP_PERSISTENT=0 to use one launch per Gauss-Newton iteration)")
         pose_t1_t0 = host[:16].reshape(4, 4).copy()
+        if host[18] != 0 or not np.isfinite(pose_t1_t0).all():
+            # no valid correspondence at some iteration: J^T J = 0, the damped system H + trace(H) * damping * I stays
+            # singular (the kernel counts the Gauss-Newton steps it had to skip in stats[2]) - the reference raises here
+            # too (torch.inverse of a singular matrix, icp.py:313-325)
+            raise RuntimeError("rtgs_icp_track: singular normal equations (no valid correspondences); "
+                               "the reference's torch.inverse raises on the same input")
         self.last_valid_ratio = float(host[16])
         self.last_p2ploss = float(host[17])
         if self.verbose:

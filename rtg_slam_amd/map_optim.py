@@ -251,6 +251,7 @@ class ShardedMapOptimizer:
         self._row_capacity = 16384     # world > 1: rows per rank in the sparse gradient exchange (grows on overflow)
         self._pending = None           # world > 1: the last exchange, until its overflow flag has been looked at
         self.overflow_redos = 0
+        self._cap_peak, self._cap_steps, self._shrink_every = 0, 0, 32   # ... and shrinks when it stays mostly empty
         self._mode = None              # world > 1: "sharded" (step) or "replicated" (step_slam); they keep different state
         if self.row_skip and activate_fn is None:
             from .rasterizer import RowGradArena
@@ -525,13 +526,23 @@ class ShardedMapOptimizer:
             pend, self._pending = self._pending, None
             pend["event"].synchronize()
             host = self._slam_ws["flag_host"]
-            if int(host[0]) == 0:
-                return
             need = int(host[1:1 + self.world].max())
+            if int(host[0]) == 0:
+                # The all-gather moves `capacity` rows per rank whatever the lists hold: when the fullest list of the last
+                # `_shrink_every` exchanges used less than a quarter of it, halve it (never below twice that peak).  Every
+                # rank reads the same counts, so every rank takes the same decision at the same step.
+                self._cap_peak = max(self._cap_peak, need)
+                self._cap_steps += 1
+                if self._cap_steps >= self._shrink_every:
+                    if 4 * self._cap_peak <= self._row_capacity and self._row_capacity > 1024:
+                        self._row_capacity = max(1024, self._row_capacity // 2)
+                    self._cap_peak, self._cap_steps = 0, 0
+                return
             cap = 1024
             while cap < 2 * need:
                 cap *= 2
             self._row_capacity = cap
+            self._cap_peak, self._cap_steps = 0, 0
             self.overflow_redos += 1
             self._exchange_and_tail(pend["job"])
 

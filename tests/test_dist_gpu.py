@@ -86,11 +86,14 @@ def _worker_slam(rank, world, port, ret):
     dev = torch.device("cuda", 0)
     packed, fns = _setup(dev)
     opt = mo.ShardedMapOptimizer(packed)
+    opt._row_capacity, opt._shrink_every = 1 << 16, 1              # far too large: must shrink (same steps on every rank)
     rs, gt_c, gt_d = fns[rank].spec
     losses = []
     for _ in range(3):
         losses.append(float(opt.step_slam(rs, gt_c, gt_d)))        # replicated map, sparse row exchange
+    opt.flush()
     ret[rank] = (opt.params.cpu(), losses)
+    ret[f"cap{rank}"] = opt._row_capacity
     try:
         opt.step(fns[rank])
         ret[f"mixed{rank}"] = "no error"
@@ -112,6 +115,7 @@ def test_two_ranks_sparse_slam_step_matches_single_process():
     mp.spawn(_worker_slam, args=(2, port, ret), nprocs=2, join=True)
     (p0, l0), (p1, l1) = ret[0], ret[1]
     assert torch.equal(p0, p1)
+    assert ret["cap0"] == ret["cap1"] < (1 << 16)             # a mostly empty exchange buffer halves itself, in step
     assert "different Adam state" in ret["mixed0"]            # step() after step_slam() on > 1 rank is refused
     dev = torch.device("cuda", 0)
     packed, fns = _setup(dev)

@@ -168,3 +168,32 @@ def test_no_gate_flips_on_the_noisy_full_size_frame():
             assert float((JtJ.cpu() - JtJ_o).abs().max()) <= 1e-4 * float(JtJ_o.abs().max())
             pose = io.gauss_newton_update(JtJ_o, Jtr_o, pose, 1e-4)
     assert flips == 0, flips
+
+
+@pytest.mark.parametrize("persistent", [False, True])
+def test_frame_without_correspondences_raises_like_the_reference(persistent):
+    """An empty current frame (depth 0 everywhere): no pixel passes the gates, J^T J = 0 and the damped system
+    (H += trace(H) * damping * I, icp.py:248-256) stays singular.  The reference raises from torch.inverse
+    (icp.py:313-325, pinned by the oracle); the drop-in raises a RuntimeError too instead of returning a NaN pose."""
+    from rtg_slam_amd.icp import IcpTracker
+    cam = synth.CameraSpec(120, 160, 130.0, 130.0, 79.5, 59.5)
+    base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
+    d0 = synth.box_room_depth(cam, base)
+    d1 = torch.zeros_like(d0)
+    K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32)
+    vp0 = io.vertex_pyramid(d0, K.clone(), 3); np0 = io.normal_pyramid(vp0)
+    vp1 = io.vertex_pyramid(d1, K.clone(), 3); np1 = io.normal_pyramid(vp1)
+    with pytest.raises(RuntimeError):
+        io.track(vp1, np1, vp0, np0, K.clone())
+    args = Args()
+    args.icp_persistent = persistent
+    tr = IcpTracker(args)
+    tr.update_curr_status(d0.to(DEV), K.to(DEV))
+    tr.move_last_status()
+    tr.update_curr_status(d1.to(DEV), K.to(DEV))
+    with pytest.raises(RuntimeError):
+        tr.predict_pose({"K": K.to(DEV), "frame_id": 1})
+    # and the tracker is still usable afterwards
+    tr.update_curr_status(d0.to(DEV), K.to(DEV))
+    pose, ok = tr.predict_pose({"K": K.to(DEV), "frame_id": 2})
+    assert np.isfinite(pose).all()
