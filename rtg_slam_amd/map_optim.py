@@ -154,6 +154,15 @@ def activate8_hip(raw8: torch.Tensor, grad_rows=None) -> Dict[str, torch.Tensor]
     return dict(opacity=op, scales=sc, rotations=rot, normal=nrm)
 
 
+def activate_packed(packed: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """The `gaussian_data` dict of SLAM/render.py:93-98 from packed raw parameters [N,59] (HIP activation kernels)."""
+    N = packed.shape[0]
+    gd = activate8_hip(packed[:, 51:59].contiguous())
+    gd["xyz"] = packed[:, 0:3].contiguous()
+    gd["shs"] = packed[:, 3:51].contiguous().view(N, 16, 3)
+    return gd
+
+
 def shard_rows(N: int, world: int):
     """Row partition used for reduce-scatter / all-gather: equal shards of ceil(N/world) rows
     (each tensor is padded to world * rows_per_rank rows)."""

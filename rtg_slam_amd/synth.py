@@ -240,6 +240,20 @@ def box_room_depth(cam: CameraSpec, c2w: torch.Tensor, half=(2.5, 1.5, 3.0),
     return depth.to(torch.float32)[..., None].contiguous()
 
 
+def box_room_color(cam: CameraSpec, c2w: torch.Tensor, depth: torch.Tensor) -> torch.Tensor:
+    """Colour image [3,H,W] of the box room: a smooth function of the WORLD point every pixel sees (the same one
+    `surface_gaussians` paints its discs with), so colour is consistent across views.  `depth` = box_room_depth."""
+    H, W = cam.H, cam.W
+    c2w = c2w.double()
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    z = depth.reshape(H, W).double()
+    pc = torch.stack([(xs - cam.cx) / cam.fx * z, (ys - cam.cy) / cam.fy * z, z], -1)
+    pw = pc @ c2w[:3, :3].t() + c2w[:3, 3]
+    col = 0.5 + 0.35 * torch.stack([torch.sin(1.3 * pw[..., 0] + 0.7 * pw[..., 2]), torch.cos(1.1 * pw[..., 1] - 0.4 * pw[..., 0]),
+                                    torch.sin(0.9 * pw[..., 2] + 0.5 * pw[..., 1])], 0)
+    return col.to(torch.float32).contiguous()
+
+
 def tum_noise(depth: torch.Tensor, seed: int = 0, hole_frac: float = 0.05, scale: float = 5000.0) -> torch.Tensor:
     """sigma_z = 0.0012 + 0.0019 (z-0.4)^2, 5 % holes, 1/5000 m quantisation."""
     g = torch.Generator().manual_seed(seed)

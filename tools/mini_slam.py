@@ -1,0 +1,149 @@
+"""A minimal RTG-SLAM-shaped loop on a synthetic RGB-D stream, built ONLY from this repository's drop-in pieces - the
+shape of BASELINE.json configs[2] ("ICP tracking + online optimisation, 1 GPU"), with the reference's call order
+(slam.py:56-90): map_preprocess -> tracking (IcpTracker.predict_pose, frame-to-model) -> mapping (new Gaussians where the
+map does not cover the frame yet, a few optimisation iterations) -> update_last_status with the renders of the new map.
+
+TEST / DEMO INFRASTRUCTURE: the policies of the reference's Mapping / Tracker classes (stable / unstable sets, keyframes,
+global optimisation, ORB backend) are out of scope and deliberately absent; what runs here are the
+kernels:  slam_ops.frame_preprocess / sample_pixels / render_range / distCUDA2,  icp.IcpTracker,  render.Renderer,
+map_optim.ShardedMapOptimizer.step_slam.
+
+    python tools/mini_slam.py [frames] [downscale]        # prints per-frame pose error, PSNR, depth L1, timings"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rtg_slam_amd import synth, slam_ops, map_optim as mo
+from rtg_slam_amd.icp import IcpTracker
+from rtg_slam_amd.render import Renderer
+
+ARGS = SimpleNamespace(                                   # configs/base.yaml values the pieces read
+    renderer_opaque_threshold=0.6, renderer_normal_threshold=60.0, renderer_depth_threshold=1.0, max_sh_degree=3,
+    color_sigma=3.0, active_sh_degree=-1,
+    icp_downscales=[0.25, 0.5, 1.0], icp_downscale_iters=[5, 5, 5], icp_warmup_frames=0, icp_use_model_depth=True,
+    icp_distance_threshold=0.1, icp_normal_threshold=20.0, icp_damping=1e-4, icp_sample_distance_threshold=0.01,
+    icp_sample_normal_threshold=0.01, icp_fail_threshold=0.02, verbose=False)
+
+
+def _camera(cam, c2w, dev):
+    """The attributes Renderer.render reads (render.py:66-86)."""
+    w2c = torch.linalg.inv(c2w.double()).float()
+    view = w2c.t().contiguous().to(dev)
+    return SimpleNamespace(FoVx=2 * math.atan(cam.W / (2 * cam.fx)), FoVy=2 * math.atan(cam.H / (2 * cam.fy)),
+                           image_height=cam.H, image_width=cam.W, world_view_transform=view, full_proj_transform=view,
+                           camera_center=c2w[:3, 3].float().to(dev), cx=cam.cx, cy=cam.cy)
+
+
+def gaussians_from_pixels(points_w, normals_w, colors, min_radius=0.001, max_radius=0.05):
+    """New flat Gaussians on sampled depth pixels (gaussian_pointcloud.py:305-405): normal = smallest axis
+    (xyz_factor [1,1,0.1]), in-plane radius = spacing of the three nearest neighbours (simple_knn), opacity 0.99."""
+    n = torch.nn.functional.normalize(normals_w, dim=-1)
+    e = torch.zeros_like(n)
+    e[torch.arange(n.shape[0], device=n.device), n.abs().argmin(dim=1)] = 1.0
+    a1 = torch.nn.functional.normalize(torch.linalg.cross(n, e), dim=-1)
+    a2 = torch.linalg.cross(n, a1)
+    R = torch.stack([a1, a2, n], dim=-1)
+    d2, _ = slam_ops.distCUDA2(points_w)
+    r = torch.sqrt(d2.clamp_min(1e-12)).clamp(min_radius, max_radius)
+    scales = torch.stack([r, r, 0.1 * r], -1)
+    shs = torch.zeros(points_w.shape[0], 16, 3, device=points_w.device)
+    shs[:, 0] = (colors - 0.5) / synth.SH_C0
+    return dict(xyz=points_w.contiguous(), opacity=torch.full((points_w.shape[0], 1), 0.99, device=points_w.device),
+                scales=scales, rotations=synth.rotmat_to_quat(R.cpu().double()).float().to(points_w.device), shs=shs)
+
+
+def run(cam, n_frames=8, iters_per_frame=10, first_frame_iters=30, samples_first=40000, samples_new=4000, seed=5,
+        dev=torch.device("cuda", 0), log=None):
+    poses_gt = synth.trajectory(n_frames, seed=seed)
+    base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
+    poses_gt = [base @ p for p in poses_gt]
+    K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32, device=dev)
+    tracker, renderer = IcpTracker(ARGS), Renderer(ARGS)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    packed, opt = None, None
+    pose_es, stats = [], []
+    for fid in range(n_frames):
+        depth = synth.box_room_depth(cam, poses_gt[fid])
+        color = synth.box_room_color(cam, poses_gt[fid], depth).to(dev)
+        depth = depth.to(dev)
+        t0 = time.perf_counter()
+        fm = slam_ops.frame_preprocess(depth, K, 0.3, 8.0, False, 0.2)           # tracker.py:97-159
+        tracker.update_curr_status(fm["depth_map"], K)
+        if fid == 0:
+            c2w = poses_gt[0].clone()                                             # the stream's origin
+        else:
+            rel, ok = tracker.predict_pose({"K": K, "frame_id": fid})             # pose_t1_t0
+            c2w = pose_es[-1] @ torch.from_numpy(rel.astype(np.float64))
+        tracker.move_last_status()
+        pose_es.append(c2w)
+        t_track = time.perf_counter() - t0
+        Rw, tw = c2w[:3, :3].float().to(dev), c2w[:3, 3].float().to(dev)
+        vertex_w = fm["vertex_map_c"] @ Rw.t() + tw
+        normal_w = fm["normal_map_c"] @ Rw.t()
+        view = _camera(cam, c2w, dev)
+        # ---- mapping: cover what the map does not explain yet, then optimise on this frame
+        if packed is None:
+            sel, n_new = None, samples_first
+        else:
+            with torch.no_grad():
+                out = renderer.render(view, mo.activate_packed(packed))
+            seen, _, _ = slam_ops.render_range(out["T_map"], 0.5)                 # T_map != 1
+            sel = (seen == 0) | ((out["depth"][0] - fm["depth_map"][..., 0]).abs() > 0.05)
+            n_new = samples_new
+        pts, nrm, col = slam_ops.sample_pixels(vertex_w, normal_w, color.permute(1, 2, 0).contiguous(), n_new, sel, gen)
+        if pts.shape[0] >= 4:
+            new = mo.pack_from_activated(gaussians_from_pixels(pts, nrm, col))
+            packed = new if packed is None else torch.cat([packed, new], 0)
+        opt = mo.ShardedMapOptimizer(packed)
+        opt.begin_local_optimization()
+        rs = renderer_settings(renderer, view, dev)
+        gt_depth = fm["depth_map"].permute(2, 0, 1).contiguous()
+        for _ in range(first_frame_iters if fid == 0 else iters_per_frame):
+            opt.step_slam(rs, color, gt_depth, None)
+        packed = opt.params
+        with torch.no_grad():
+            out = renderer.render(view, mo.activate_packed(packed))
+        render_depth = out["depth"].permute(1, 2, 0).contiguous()
+        tracker.update_last_status(None, render_depth, fm["depth_map"], out["normal"].permute(1, 2, 0).contiguous(), normal_w)
+        torch.cuda.synchronize(dev)
+        t_all = time.perf_counter() - t0
+        valid = fm["depth_map"][..., 0] > 0
+        mse = float(((out["render"] - color) ** 2).mean())
+        psnr = 10 * math.log10(1.0 / max(mse, 1e-12))
+        d_l1 = float((out["depth"][0] - fm["depth_map"][..., 0]).abs()[valid & (out["depth"][0] > 0)].mean())
+        err_t = float((c2w[:3, 3] - poses_gt[fid][:3, 3]).norm())
+        err_r = math.degrees(math.acos(max(-1.0, min(1.0, (float(torch.trace(c2w[:3, :3].t() @ poses_gt[fid][:3, :3])) - 1) / 2))))
+        stats.append(dict(frame=fid, gaussians=int(packed.shape[0]), trans_err_m=err_t, rot_err_deg=err_r, psnr=psnr,
+                          depth_l1_m=d_l1, covered=float((out["T_map"][0] != 1).float().mean()), track_ms=1e3 * t_track,
+                          frame_ms=1e3 * t_all))
+        if log:
+            log(stats[-1])
+    return stats
+
+
+def renderer_settings(renderer, view, dev):
+    from rtg_slam_amd.rasterizer import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=view.image_height, image_width=view.image_width, tanfovx=math.tan(view.FoVx * 0.5),
+        tanfovy=math.tan(view.FoVy * 0.5), bg=torch.zeros(3, device=dev), scale_modifier=1.0,
+        viewmatrix=view.world_view_transform, projmatrix=view.full_proj_transform, sh_degree=renderer.active_sh_degree,
+        campos=view.camera_center, opaque_threshold=renderer.renderer_opaque_threshold,
+        depth_threshold=renderer.renderer_depth_threshold, normal_threshold=renderer.renderer_normal_threshold,
+        color_sigma=renderer.color_sigma, prefiltered=False, debug=False, cx=view.cx, cy=view.cy, T_threshold=0.0001)
+
+
+if __name__ == "__main__":
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    down = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    c = synth.REPLICA
+    cam = synth.CameraSpec(c.H // down, c.W // down, c.fx / down, c.fy / down, (c.cx + 0.5) / down - 0.5, (c.cy + 0.5) / down - 0.5)
+    run(cam, n_frames=frames, samples_first=400000 // (down * down), samples_new=40000 // (down * down),
+        log=lambda s: print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items()}))
