@@ -1,10 +1,11 @@
 """CPU emulation of the near slice's automatic decision (raster_common.h: slice_cut) on a scene, from the oracle's
 per-Gaussian stage: which bin the cut lands on, the slice's share of the instances and its cover per pixel.
-usage: python tools/slice_decision_sim.py [headline|config2|surface|surface200k|surface5m]"""
+usage: python tests/diag/slice_decision_sim.py [headline|config2|surface|surface200k|surface5m]"""
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import raster_oracle as ro
 from rtg_slam_amd import synth
 
