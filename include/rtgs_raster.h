@@ -202,7 +202,7 @@ void rtgs_raster_set_counters_ctx(rtgs_ctx* ctx, void* counters);
  * durations in milliseconds (-1 = stage did not run):
  *   [0] preprocess_fwd (+ mask SAT)  [1] bin_count + tilescan (fallback: scan)  [2] bin_scatter
  *   (fallback: emit_keys)  [3] bin_tilesort (fallback: radix sort)  [4] tile_ranges (fallback only)
- *   [5] blend_fwd  [6] slot-counter memset + blend_bwd (both launches)  [7] preprocess_bwd
+ *   [5] blend_fwd  [6] blend_bwd (the launches that have lists to walk)  [7] preprocess_bwd
  *   [8] near-slice binning (histogram, count, scan, scatter, sort)  [9] near-slice blend_fwd
  *   [10] grad_reduce (sum of the gradient slots per Gaussian)  [11] unused
  * With the near-slice pass on, [1]..[5] describe the second pass (tiles the slice left unfinished). */

@@ -659,7 +659,7 @@ int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms) {
   for (int i = 0; i < 12; ++i) ms[i] = -1.f;
   if (!c->ev_init) return RTGS_OK;
   // [0] preprocess_fwd(+sat) [1] count+scan of the main pass [2] scatter / emit_keys [3] sort [4] tile_ranges
-  // [5] blend_fwd of the main pass [6] slot-counter memset + blend_bwd (both launches) [7] preprocess_bwd
+  // [5] blend_fwd of the main pass [6] blend_bwd (the launches that have lists to walk) [7] preprocess_bwd
   // [8] near slice: hist+count+scan+scatter+sort [9] near slice: blend_fwd [10] grad_reduce [11] unused
   const int pre_end = c->ev_set[EV_SL_BLEND] ? EV_SL_BLEND : EV_PRE;
   const int pairs[11][2] = {{EV_F0, EV_PRE}, {pre_end, EV_SCAN}, {EV_BIN0, EV_EMIT}, {EV_EMIT, EV_SORT},
