@@ -481,174 +481,6 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// K6' blend_fwd, scalar-gather variant: the tile list and the 64-B Splat records are wave-uniform,
-// so every wave fetches them with SCALAR loads (s_load_dword / s_load_dwordx16 through the
-// constant cache) straight into SGPRs, four entries per round: no LDS, no workgroup barrier,
-// each wave walks at its own pace and stops when its 64 pixels are done.  Same arithmetic as
-// blend_fwd_kernel, bit for bit.
-// ---------------------------------------------------------------------------------------------
-struct SplatRegs { float4 r0, r1, r2, r3; };
-
-__device__ __forceinline__ SplatRegs load_uniform(const Splat* __restrict__ splats, uint32_t id) {
-  const float4* src = reinterpret_cast<const float4*>(splats + id);   // uniform address -> SMEM
-  SplatRegs s;
-  s.r0 = src[0]; s.r1 = src[1]; s.r2 = src[2]; s.r3 = src[3];
-  return s;
-}
-
-__global__ void __launch_bounds__(256) blend_fwd_scalar_kernel(
-    RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
-    int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
-    float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
-    unsigned long long* __restrict__ counters) {
-  const int tid = threadIdx.x;
-  const int tile = blockIdx.y * p.gx + blockIdx.x;
-  const int px = blockIdx.x * TILE + (tid & 15);
-  const int py = blockIdx.y * TILE + (tid >> 4);
-  const bool inside = px < p.W && py < p.H;
-  const float pxf = (float)px, pyf = (float)py;
-  const uint2 range = ranges[tile];
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
-  const int n = __builtin_amdgcn_readfirstlane((int)(range.y - range.x));
-
-  bool done = !inside;
-  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-  float best_w = 0.f; int best_id = -1;
-  float D = 0.f, d_w = 0.f; int d_id = -1;
-  uint32_t contributor = 0, last_contributor = 0;
-  const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
-  const float rnorm = sqrtf(rx * rx + ry * ry + 1.f);
-  unsigned long long evals = 0;
-
-  constexpr int U = 4;
-  ActiveBox box;
-  box.mask = 0ull; box.x0 = box.y0 = 0.f; box.x1 = box.y1 = -1.f;
-  for (int j0 = 0; j0 < n; j0 += U) {
-    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;     // whole wave finished
-    uint32_t ids[U];
-    SplatRegs recs[U];
-#pragma unroll
-    for (int k = 0; k < U; ++k)
-      ids[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)point_list[lo + (uint32_t)min(j0 + k, n - 1)]);
-#pragma unroll
-    for (int k = 0; k < U; ++k) recs[k] = load_uniform(splats, ids[k]);
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      if (j0 + k >= n) break;
-      const float4 r0 = recs[k].r0, r1 = recs[k].r1, r2 = recs[k].r2, r3 = recs[k].r3;
-      const unsigned long long am = __builtin_amdgcn_ballot_w64(!done);
-      if (am == 0ull) break;
-      if (am != box.mask) refresh_box(box, am, blockIdx.x * TILE, blockIdx.y * TILE + (tid >> 6) * 4);
-      // wave-uniform: the entry's alpha >= 1/255 region misses every pixel of this wave still walking
-      if (r0.x + r3.z < box.x0 || r0.x - r3.z > box.x1 || r0.y + r3.w < box.y0 || r0.y - r3.w > box.y1) continue;
-      const float dx = r0.x - pxf, dy = r0.y - pyf;
-      const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
-      const float alpha = fminf(0.99f, r1.y * splat_exp(fminf(power, 0.f)));
-      const bool ok = !done && !(power > 0.f) && !(alpha < 1.f / 255.f);
-      const float test_T = T * (1.f - alpha);
-      const bool stop = ok && (test_T < p.T_thr);
-      const bool contrib = ok && !stop;
-      evals += done ? 0u : 1u;
-      done = done || stop;
-      if (__builtin_amdgcn_ballot_w64(contrib) == 0ull) continue;
-      const float w = contrib ? alpha * T : 0.f;
-      C0 += r1.z * w; C1 += r1.w * w; C2 += r2.x * w;
-      const bool better = w > best_w;
-      best_w = better ? w : best_w;
-      best_id = better ? (int)ids[k] : best_id;
-      if (__builtin_amdgcn_ballot_w64(contrib && d_id < 0 && alpha > p.opaque_thr) != 0ull) {   // rare
-        if (contrib && d_id < 0 && alpha > p.opaque_thr) {
-          const float den = r2.y * rx + r2.z * ry + r2.w;
-          if (fabsf(den) / rnorm > p.normal_thr) {
-            const float zhit = r3.x / den;
-            if (zhit > 0.f && fabsf(zhit - r3.y) < p.depth_thr) { D = zhit; d_w = alpha; d_id = (int)ids[k]; }
-          }
-        }
-      }
-      T = contrib ? test_T : T;
-      last_contributor = contrib ? (uint32_t)(j0 + k + 1) : last_contributor;
-    }
-  }
-  contributor = last_contributor;
-
-  if (inside) {
-    const size_t pix = (size_t)py * p.W + px;
-    const size_t HW = (size_t)p.H * p.W;
-    out_color[pix] = C0 + T * p.bg[0];
-    out_color[HW + pix] = C1 + T * p.bg[1];
-    out_color[2 * HW + pix] = C2 + T * p.bg[2];
-    out_depth[pix] = D;
-    out_cidx[pix] = best_id;
-    out_didx[pix] = d_id;
-    out_cw[pix] = best_w;
-    out_dw[pix] = d_w;
-    out_T[pix] = T;
-    n_contrib[pix] = last_contributor;
-  }
-  if (counters) {
-    __shared__ unsigned int s_max;
-    __shared__ unsigned long long s_ev;
-    if (tid == 0) { s_max = 0; s_ev = 0; }
-    __syncthreads();
-    atomicMax(&s_max, contributor);
-    atomicAdd(&s_ev, evals);
-    __syncthreads();
-    // one slot pair per tile, plain stores (3 225 same-address atomics cost ~80 us - more than the kernel itself);
-    // the second pass of a two-pass forward adds to what the first wrote for the tile
-    if (tid == 0) {
-      const bool add = 0 == 2;
-      counters[2 * tile] = (add ? counters[2 * tile] : 0ull) + (unsigned long long)s_max;
-      counters[2 * tile + 1] = (add ? counters[2 * tile + 1] : 0ull) + s_ev;
-    }
-  }
-}
-
-// ------------------------------------------------------------------ host-side launch helpers
-void launch_mask_sat(const int32_t* mask, int gx, int gy, int32_t* sat, hipStream_t st) {
-  hipLaunchKernelGGL(mask_sat_kernel, dim3(1), dim3(256), 0, st, mask, gx, gy, sat);
-}
-void launch_preprocess_fwd(const RasterParams& p, const float* means, const float* opac, const float* shs,
-                           const float* scales, const float* rots, const float* normal_w, const int32_t* sat,
-                           Splat* splats, uint32_t* tiles_touched, int32_t* radii, uint8_t* clamped,
-                           int32_t* out_radii, uint32_t* zero_words, int zero_n, uint8_t* zbin, hipStream_t st) {
-  if (p.P == 0) return;
-  hipLaunchKernelGGL(preprocess_fwd_kernel<0>, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, opac, shs, scales,
-                     rots, normal_w, sat, splats, tiles_touched, radii, clamped, out_radii, zero_words, zero_n, zbin,
-                     (float2*)nullptr, SliceList{nullptr, nullptr}, SliceSel{0, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr});
-}
-// two-pass forward, stage 1: geometry of every Gaussian
-void launch_preprocess_cull(const RasterParams& p, const float* means, const float* scales, const float* rots,
-                            uint32_t* tiles_touched, int32_t* radii, int32_t* out_radii, uint32_t* zero_words, int zero_n,
-                            uint8_t* zbin, float2* uv, hipStream_t st) {
-  if (p.P == 0) return;
-  hipLaunchKernelGGL(preprocess_fwd_kernel<1>, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, (const float*)nullptr,
-                     (const float*)nullptr, scales, rots, (const float*)nullptr, (const int32_t*)nullptr, (Splat*)nullptr,
-                     tiles_touched, radii, (uint8_t*)nullptr, out_radii, zero_words, zero_n, zbin, uv,
-                     SliceList{nullptr, nullptr}, SliceSel{0, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr});
-}
-// two-pass forward, stage 2: Splat records of the work list (max_items bounds its length), or of everything else
-void launch_preprocess_shade(const RasterParams& p, const float* means, const float* opac, const float* shs,
-                             const float* scales, const float* rots, const float* normal_w, Splat* splats,
-                             int32_t* radii, uint8_t* clamped, float2* uv, SliceList list, SliceSel sel, size_t max_items,
-                             hipStream_t st) {
-  if (p.P == 0) return;
-  const size_t n = list.ids ? (max_items < (size_t)p.P ? max_items : (size_t)p.P) : (size_t)p.P;
-  hipLaunchKernelGGL(preprocess_fwd_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, means, opac, shs,
-                     scales, rots, normal_w, (const int32_t*)nullptr, splats, (uint32_t*)nullptr, radii, clamped,
-                     (int32_t*)nullptr, (uint32_t*)nullptr, 0, (uint8_t*)nullptr, uv, list, sel);
-}
-void launch_emit_keys(const RasterParams& p, const Splat* splats, const int32_t* radii, const uint32_t* offsets,
-                      const int32_t* mask, uint64_t* keys, uint32_t* vals, hipStream_t st) {
-  if (p.P == 0) return;
-  hipLaunchKernelGGL(emit_keys_kernel, dim3((p.P + 255) / 256), dim3(256), 0, st, p, splats, radii, offsets, mask,
-                     keys, vals);
-}
-void launch_tile_ranges(int64_t R, const uint64_t* keys, uint2* ranges, hipStream_t st) {
-  if (R == 0) return;
-  hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, R, keys, ranges);
-}
 // After the near slice's blend: count the tiles it finished / left (from the tile mask it wrote - per-tile atomics on
 // one counter would serialise: 3 225 of them cost 55 us) and publish the totals to the host, which spins on host[7].
 __global__ void __launch_bounds__(256) slice_publish_kernel(int ntiles, const int32_t* __restrict__ user_mask,
@@ -682,12 +514,6 @@ void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t
                       float* out_color, float* out_depth, int32_t* out_cidx, int32_t* out_didx, float* out_cw,
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
                       SlicePass sp, hipStream_t st) {
-  static const int variant = [] { const char* e = getenv("RTGS_BLEND_FWD"); return e ? atoi(e) : 0; }();
-  if (variant == 1 && sp.mode == 0) {
-    hipLaunchKernelGGL(blend_fwd_scalar_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
-                       out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters);
-    return;
-  }
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
                      out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp);
 }
