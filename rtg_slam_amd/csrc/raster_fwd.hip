@@ -481,6 +481,50 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------ host-side launch helpers
+void launch_mask_sat(const int32_t* mask, int gx, int gy, int32_t* sat, hipStream_t st) {
+  hipLaunchKernelGGL(mask_sat_kernel, dim3(1), dim3(256), 0, st, mask, gx, gy, sat);
+}
+void launch_preprocess_fwd(const RasterParams& p, const float* means, const float* opac, const float* shs,
+                           const float* scales, const float* rots, const float* normal_w, const int32_t* sat,
+                           Splat* splats, uint32_t* tiles_touched, int32_t* radii, uint8_t* clamped,
+                           int32_t* out_radii, uint32_t* zero_words, int zero_n, uint8_t* zbin, hipStream_t st) {
+  if (p.P == 0) return;
+  hipLaunchKernelGGL(preprocess_fwd_kernel<0>, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, opac, shs, scales,
+                     rots, normal_w, sat, splats, tiles_touched, radii, clamped, out_radii, zero_words, zero_n, zbin,
+                     (float2*)nullptr, SliceList{nullptr, nullptr}, SliceSel{0, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr});
+}
+// two-pass forward, stage 1: geometry of every Gaussian
+void launch_preprocess_cull(const RasterParams& p, const float* means, const float* scales, const float* rots,
+                            uint32_t* tiles_touched, int32_t* radii, int32_t* out_radii, uint32_t* zero_words, int zero_n,
+                            uint8_t* zbin, float2* uv, hipStream_t st) {
+  if (p.P == 0) return;
+  hipLaunchKernelGGL(preprocess_fwd_kernel<1>, dim3((p.P + 255) / 256), dim3(256), 0, st, p, means, (const float*)nullptr,
+                     (const float*)nullptr, scales, rots, (const float*)nullptr, (const int32_t*)nullptr, (Splat*)nullptr,
+                     tiles_touched, radii, (uint8_t*)nullptr, out_radii, zero_words, zero_n, zbin, uv,
+                     SliceList{nullptr, nullptr}, SliceSel{0, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr});
+}
+// two-pass forward, stage 2: Splat records of the work list (max_items bounds its length), or of everything else
+void launch_preprocess_shade(const RasterParams& p, const float* means, const float* opac, const float* shs,
+                             const float* scales, const float* rots, const float* normal_w, Splat* splats,
+                             int32_t* radii, uint8_t* clamped, float2* uv, SliceList list, SliceSel sel, size_t max_items,
+                             hipStream_t st) {
+  if (p.P == 0) return;
+  const size_t n = list.ids ? (max_items < (size_t)p.P ? max_items : (size_t)p.P) : (size_t)p.P;
+  hipLaunchKernelGGL(preprocess_fwd_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, means, opac, shs,
+                     scales, rots, normal_w, (const int32_t*)nullptr, splats, (uint32_t*)nullptr, radii, clamped,
+                     (int32_t*)nullptr, (uint32_t*)nullptr, 0, (uint8_t*)nullptr, uv, list, sel);
+}
+void launch_emit_keys(const RasterParams& p, const Splat* splats, const int32_t* radii, const uint32_t* offsets,
+                      const int32_t* mask, uint64_t* keys, uint32_t* vals, hipStream_t st) {
+  if (p.P == 0) return;
+  hipLaunchKernelGGL(emit_keys_kernel, dim3((p.P + 255) / 256), dim3(256), 0, st, p, splats, radii, offsets, mask,
+                     keys, vals);
+}
+void launch_tile_ranges(int64_t R, const uint64_t* keys, uint2* ranges, hipStream_t st) {
+  if (R == 0) return;
+  hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, R, keys, ranges);
+}
 // After the near slice's blend: count the tiles it finished / left (from the tile mask it wrote - per-tile atomics on
 // one counter would serialise: 3 225 of them cost 55 us) and publish the totals to the host, which spins on host[7].
 __global__ void __launch_bounds__(256) slice_publish_kernel(int ntiles, const int32_t* __restrict__ user_mask,
