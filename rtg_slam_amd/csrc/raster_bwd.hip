@@ -366,17 +366,48 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(int P, const uint8_t* 
     __builtin_amdgcn_wave_barrier();
     const int nbig = __popcll(mbig), nsmall = __popcll(msmall);
     for (int k = 0; k < nbig; ++k) {
+      // long run (a near, screen-filling Gaussian: hundreds of tiles): four lanes per slot (one 16-B load each), sixteen
+      // slots per load instruction, four instructions in flight - the run is the kernel's critical path, so what counts
+      // is bytes in flight per wave, not lanes per slot
       const size_t id = (size_t)(base + s_big[wv][k]);
       const size_t b0 = gbase[id];
       const uint32_t n = count[id];
-      float a0 = 0.f, a1 = 0.f;
-      uint32_t q = grp;
-      for (; q + 4 < n; q += 8) { a0 += slots[(b0 + q) * 16 + c]; a1 += slots[(b0 + q + 4) * 16 + c]; }
-      if (q < n) a0 += slots[(b0 + q) * 16 + c];
-      float acc = a0 + a1;
-      acc += __shfl_xor(acc, 16);
-      acc += __shfl_xor(acc, 32);
-      if (lane < 16) reinterpret_cast<float*>(grads + id)[c] = acc;
+      if (n <= 48u) {        // medium run: sixteen lanes per slot, four slots per step, two shuffles at the end
+        float m0 = 0.f, m1 = 0.f;
+        uint32_t q = grp;
+        for (; q + 4 < n; q += 8) { m0 += slots[(b0 + q) * 16 + c]; m1 += slots[(b0 + q + 4) * 16 + c]; }
+        if (q < n) m0 += slots[(b0 + q) * 16 + c];
+        float acc = m0 + m1;
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (lane < 16) reinterpret_cast<float*>(grads + id)[c] = acc;
+        if (lane == 0) count[id] = 0u;
+        continue;
+      }
+      const float4* __restrict__ s4 = reinterpret_cast<const float4*>(slots);
+      const uint32_t sub = (uint32_t)lane & 3u, sg = (uint32_t)lane >> 2;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+      uint32_t q = sg;
+      for (; q + 48 < n; q += 64) {
+        const float4 t0 = s4[(b0 + q) * 4 + sub], t1 = s4[(b0 + q + 16) * 4 + sub];
+        const float4 t2 = s4[(b0 + q + 32) * 4 + sub], t3 = s4[(b0 + q + 48) * 4 + sub];
+        a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w;
+        a1.x += t1.x; a1.y += t1.y; a1.z += t1.z; a1.w += t1.w;
+        a2.x += t2.x; a2.y += t2.y; a2.z += t2.z; a2.w += t2.w;
+        a3.x += t3.x; a3.y += t3.y; a3.z += t3.z; a3.w += t3.w;
+      }
+      for (; q < n; q += 16) {
+        const float4 t0 = s4[(b0 + q) * 4 + sub];
+        a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w;
+      }
+      float4 acc = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                               (a0.w + a1.w) + (a2.w + a3.w));
+#pragma unroll
+      for (int off = 4; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+        acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+      }
+      if (lane < 4) reinterpret_cast<float4*>(grads + id)[sub] = acc;
       if (lane == 0) count[id] = 0u;          // the counters are zero between calls (the forward clears them too)
     }
     for (int k0 = 0; k0 < nsmall; k0 += 4) {
