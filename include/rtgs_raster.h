@@ -281,14 +281,20 @@ int rtgs_attach_prepare(const float* xyz, const float* raw8, const rtgs_attach* 
  * row_state its state bytes; g_raw8 is written for state 1 (value) and state 2 (zero) rows.
  *   attach     (nullable) adds the attach regulariser's gradient to the selected rows (rtgs_attach_prepare must have run)
  *   confidence (nullable) float[rows]: += 1 for every row whose f_dc gradient is non-zero (mapper.py:454-456)
- *   skip_flag  (nullable) device word: non-zero = do nothing (an overflowed multi-GPU exchange, see rtgs_rows_overflow) */
+ *   skip_flag  (nullable) device word: non-zero = do nothing (an overflowed multi-GPU exchange, see rtgs_rows_overflow)
+ *   refresh    (nullable) the caller's activated copies of raw8 (what rtgs_map_activate8_forward wrote): every row whose
+ *              raw8 is stepped is re-activated in place, so they stay equal to a full activation pass of the new raw8
+ *              (only rows that moved are touched - a few thousand of 1.2 M on a depth-complex map) */
+typedef struct rtgs_activated {
+  float *opacity, *scales, *rotations, *normal;           /* [rows,1] [rows,3] [rows,4] [rows,3] */
+} rtgs_activated;
 int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const float* g_opacity, const float* g_scales,
                        const float* g_rotations, const float* g_normal, const float* g_xyz, const float* g_shs,
                        float* g_raw8, const uint8_t* row_state, float* m_xyz, float* v_xyz, float* m_shs, float* v_shs,
                        float* m_raw8, float* v_raw8, const float* lr_xyz, const float* lr_shs, const float* lr_raw8,
                        uint8_t* ever_xyz, uint8_t* ever_shs, uint8_t* ever_raw8, int64_t rows, int32_t step, float beta1,
                        float beta2, float eps, const rtgs_attach* attach, float* confidence, const uint32_t* skip_flag,
-                       void* stream);
+                       const rtgs_activated* refresh, void* stream);
 
 /* Fused SLAM loss: the image terms of Mapping.loss_update (mapper.py:402-448) - value and BOTH image gradients
  * (dL/dC [3,H,W], dL/dD [1,H,W]), so the autograd graph of ~40 elementwise launches collapses into a few kernels.
@@ -320,7 +326,7 @@ int rtgs_slam_loss_grads(const float* color, const float* depth, const int32_t* 
 
 /* One map-optimisation iteration as a single call (the body of local_optimize's inner loop, mapper.py:176-205, with
  * loss_update's image terms, attach regulariser, Adam step and confidence increment, mapper.py:371-456):
- *   raw8 activation -> rtgs_raster_forward -> rtgs_slam_loss -> rtgs_raster_backward_rows ->
+ *   raw8 activation (skipped when activated_valid) -> rtgs_raster_forward -> rtgs_slam_loss -> rtgs_raster_backward_rows ->
  *   rtgs_map_tail_rows (activation backward + attach gradient + Adam on xyz[P,3], shs[P,48], raw8[P,8] + confidence).
  * Exactly the sequence the entry points above perform when called one by one (parameters are updated in place, the
  * losses are left in loss4); it exists because the host cost of issuing ~40 launches through an autograd graph
@@ -352,6 +358,10 @@ typedef struct rtgs_map_step_args {
   float beta1, beta2, eps;
   const rtgs_attach* attach;                              /* nullable */
   float* confidence;                                      /* nullable, float[P] */
+  int32_t activated_valid;                                /* non-zero: opacity / scales / rotations / normal already hold
+                                                             the activation of raw8 (a previous call of this function left
+                                                             them so: its tail re-activates the rows it steps) - the full
+                                                             activation pass is skipped.  0 after any other change of raw8. */
   rtgs_resize_fn geom_resize; void* geom_user;
   rtgs_resize_fn binning_resize; void* binning_user;
   rtgs_resize_fn image_resize; void* image_user;

@@ -57,6 +57,11 @@ class AttachC(C.Structure):
     _fields_ = [("init_xyz", C.c_void_p), ("init_raw8", C.c_void_p), ("attach_info", C.c_void_p)]
 
 
+class ActivatedC(C.Structure):
+    """Mirror of `rtgs_activated` (include/rtgs_raster.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("opacity", "scales", "rotations", "normal")]
+
+
 class MapStepArgsC(C.Structure):
     """Mirror of `rtgs_map_step_args` (include/rtgs_raster.h)."""
     _fields_ = (
@@ -70,7 +75,7 @@ class MapStepArgsC(C.Structure):
             "m_xyz", "v_xyz", "m_shs", "v_shs", "m_raw8", "v_raw8", "lr_xyz", "lr_shs", "lr_raw8",
             "ever_xyz", "ever_shs", "ever_raw8")]
         + [("step", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
-        + [("attach", C.POINTER(AttachC)), ("confidence", C.c_void_p)]
+        + [("attach", C.POINTER(AttachC)), ("confidence", C.c_void_p), ("activated_valid", C.c_int32)]
         + [("geom_resize", RESIZE_FN), ("geom_user", C.c_void_p), ("binning_resize", RESIZE_FN),
            ("binning_user", C.c_void_p), ("image_resize", RESIZE_FN), ("image_user", C.c_void_p)])
 
@@ -96,7 +101,7 @@ _SIGNATURES = {
     "rtgs_map_activate8_backward": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "rtgs_map_activate8_backward_rows": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "rtgs_map_tail_rows": (C.c_int, [_P] * 23 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float,
-                                     C.POINTER(AttachC), _P, _P, _P]),
+                                     C.POINTER(AttachC), _P, _P, C.POINTER(ActivatedC), _P]),
     "rtgs_attach_prepare": (C.c_int, [_P, _P, C.POINTER(AttachC), C.c_int64, _P]),
     "rtgs_slam_loss_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rtgs_slam_map_step_front": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),

@@ -28,26 +28,32 @@ __device__ __forceinline__ void rot_col(int k, float r, float x, float y, float 
 // ---------------------------------------------------------------------------------------------
 namespace rtgs {
 
+// one row: a = (o, s0, s1, s2) raw, q = raw quaternion (w, x, y, z).  ONE definition for the full activation pass and
+// for the rows the tail kernel re-activates after stepping them (bit-identical by construction).
+__device__ __forceinline__ void activate8_row_store(const float4 a, const float4 q, int64_t i, float* __restrict__ opacity,
+                                                    float* __restrict__ scales, float4* __restrict__ rots,
+                                                    float* __restrict__ normal) {
+  opacity[i] = 1.f / (1.f + __expf(-a.x));
+  const float s0 = __expf(a.y), s1 = __expf(a.z), s2 = __expf(a.w);
+  scales[i * 3] = s0; scales[i * 3 + 1] = s1; scales[i * 3 + 2] = s2;
+  const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+  const float r = q.x * inv, x = q.y * inv, y = q.z * inv, z = q.w * inv;
+  rots[i] = make_float4(r, x, y, z);
+  int k = 0;
+  float sm = s0;
+  if (s1 < sm) { sm = s1; k = 1; }
+  if (s2 < sm) { k = 2; }
+  float c[3];
+  rot_col(k, r, x, y, z, c);
+  const float m = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + 1e-8f;
+  normal[i * 3] = c[0] / m; normal[i * 3 + 1] = c[1] / m; normal[i * 3 + 2] = c[2] / m;
+}
+
 __global__ void __launch_bounds__(256) activate8_fwd_kernel(const float4* __restrict__ raw8, int64_t n,
                                                             float* __restrict__ opacity, float* __restrict__ scales,
                                                             float4* __restrict__ rots, float* __restrict__ normal) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float4 a = raw8[2 * i], q = raw8[2 * i + 1];          // (o, s0, s1, s2), (qw, qx, qy, qz)
-    opacity[i] = 1.f / (1.f + __expf(-a.x));
-    const float s0 = __expf(a.y), s1 = __expf(a.z), s2 = __expf(a.w);
-    scales[i * 3] = s0; scales[i * 3 + 1] = s1; scales[i * 3 + 2] = s2;
-    const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-    const float r = q.x * inv, x = q.y * inv, y = q.z * inv, z = q.w * inv;
-    rots[i] = make_float4(r, x, y, z);
-    int k = 0;
-    float sm = s0;
-    if (s1 < sm) { sm = s1; k = 1; }
-    if (s2 < sm) { k = 2; }
-    float c[3];
-    rot_col(k, r, x, y, z, c);
-    const float m = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + 1e-8f;
-    normal[i * 3] = c[0] / m; normal[i * 3 + 1] = c[1] / m; normal[i * 3 + 2] = c[2] / m;
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    activate8_row_store(raw8[2 * i], raw8[2 * i + 1], i, opacity, scales, rots, normal);   // (o, s0, s1, s2), (qw, qx, qy, qz)
 }
 
 // gradient of (opacity, scales, rotations, normal) w.r.t. the raw8 row (a = o s0 s1 s2, q = quaternion wxyz)
@@ -169,6 +175,9 @@ struct TailArgs {
   const float* attach_info;       // [0] = number of selected rows
   float* confidence;
   const uint32_t* skip_flag;      // multi-GPU: non-zero = the gradient exchange of this step overflowed, do nothing
+  // optional: the caller's activated copies of raw8, re-activated for every row whose raw8 is stepped
+  float *act_opacity, *act_scales, *act_normal;
+  float4* act_rots;
 };
 
 __device__ __forceinline__ bool attach_selected(const float4 init_lo) {
@@ -232,6 +241,8 @@ __global__ void __launch_bounds__(256) map_tail_rows_kernel(TailArgs a) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) pf[c] = adam1(pf[c], gg[c], mf[c], vf[c], a.lr_raw8[c], a.beta1, a.beta2, a.eps, a.bc1, a.bc2_sqrt);
         p4[0] = pp[0]; p4[1] = pp[1]; m4[0] = mm[0]; m4[1] = mm[1]; v4[0] = vv[0]; v4[1] = vv[1];
+        // keep the caller's activated arrays in step with the rows that moved: no full activation pass next iteration
+        if (a.act_opacity) activate8_row_store(pp[0], pp[1], r, a.act_opacity, a.act_scales, a.act_rots, a.act_normal);
       }
       if (grad || e_xyz != 0) {                                  // xyz: 3 columns, this lane
         if (e_xyz == 0) a.ever_xyz[r] = 1;
@@ -341,7 +352,7 @@ extern "C" int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const flo
                                   const float* lr_raw8, uint8_t* ever_xyz, uint8_t* ever_shs, uint8_t* ever_raw8,
                                   int64_t rows, int32_t step, float beta1, float beta2, float eps,
                                   const rtgs_attach* attach, float* confidence, const uint32_t* skip_flag,
-                                  void* stream) {
+                                  const rtgs_activated* refresh, void* stream) {
   if (rows < 0 || step < 1) return -1;
   if (rows == 0) return 0;
   if (!xyz || !shs || !raw8 || !g_opacity || !g_scales || !g_rotations || !g_normal || !g_xyz || !g_shs || !g_raw8 ||
@@ -358,6 +369,12 @@ extern "C" int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const flo
   a.rows = rows; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
   a.init_xyz = nullptr; a.init_raw8 = nullptr; a.attach_info = nullptr; a.confidence = confidence;
   a.skip_flag = skip_flag;
+  a.act_opacity = a.act_scales = a.act_normal = nullptr; a.act_rots = nullptr;
+  if (refresh) {
+    if (!refresh->opacity || !refresh->scales || !refresh->rotations || !refresh->normal) return -1;
+    a.act_opacity = refresh->opacity; a.act_scales = refresh->scales; a.act_normal = refresh->normal;
+    a.act_rots = (float4*)refresh->rotations;
+  }
   if (attach) {
     if (!attach->init_xyz || !attach->init_raw8 || !attach->attach_info) return -1;
     a.init_xyz = attach->init_xyz; a.init_raw8 = (const float4*)attach->init_raw8; a.attach_info = attach->attach_info;

@@ -13,8 +13,11 @@ extern "C" int rtgs_slam_map_step_front_ctx(rtgs_ctx* ctx, const rtgs_map_step_a
   if (P <= 0 || M != 16 || a->step < 1) return RTGS_E_INVALID;
   if (!a->xyz || !a->shs || !a->raw8 || !a->tile_mask || !a->gt_color || !a->gt_depth) return RTGS_E_INVALID;
   const int32_t H = a->settings->image_height, W = a->settings->image_width;
-  int rc = rtgs_map_activate8_forward(a->raw8, P, a->opacity, a->scales, a->rotations, a->normal, stream);
-  if (rc != 0) return RTGS_E_HIP;
+  int rc = 0;
+  if (!a->activated_valid) {
+    rc = rtgs_map_activate8_forward(a->raw8, P, a->opacity, a->scales, a->rotations, a->normal, stream);
+    if (rc != 0) return RTGS_E_HIP;
+  }
   rc = rtgs_raster_forward_ctx(ctx, a->settings, P, M, a->xyz, a->opacity, a->shs, a->scales, a->rotations, a->normal,
                            a->tile_mask, a->out_color, a->out_depth, a->out_color_index, a->out_depth_index,
                            a->out_color_weight, a->out_depth_weight, a->out_T, a->out_radii, a->geom_resize,
@@ -44,11 +47,13 @@ extern "C" int rtgs_slam_map_step_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* a
   int rc = rtgs_slam_map_step_front_ctx(ctx, a, num_rendered_host, stream);
   if (rc != RTGS_OK) return rc;
   const int32_t P = a->P;
-  // activation backward (+ attach gradient) + Adam on the three block tensors (+ confidence increment), one launch
+  // activation backward (+ attach gradient) + Adam on the three block tensors (+ confidence increment), one launch;
+  // the rows it steps are re-activated, so the next call may skip the full activation pass (activated_valid)
+  const rtgs_activated act{a->opacity, a->scales, a->rotations, a->normal};
   rc = rtgs_map_tail_rows(a->xyz, a->shs, a->raw8, a->d_opacity, a->d_scales, a->d_rotations, a->d_normal, a->d_xyz,
                           a->d_shs, a->d_raw8, a->row_state, a->m_xyz, a->v_xyz, a->m_shs, a->v_shs, a->m_raw8, a->v_raw8,
                           a->lr_xyz, a->lr_shs, a->lr_raw8, a->ever_xyz, a->ever_shs, a->ever_raw8, P, a->step, a->beta1,
-                          a->beta2, a->eps, a->attach, a->confidence, nullptr, stream);
+                          a->beta2, a->eps, a->attach, a->confidence, nullptr, &act, stream);
   return rc != 0 ? RTGS_E_HIP : RTGS_OK;
 }
 

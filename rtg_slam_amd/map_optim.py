@@ -261,6 +261,7 @@ class ShardedMapOptimizer:
         self._pending = None           # world > 1: the last exchange, until its overflow flag has been looked at
         self.overflow_redos = 0
         self._cap_peak, self._cap_steps, self._shrink_every = 0, 0, 32   # ... and shrinks when it stays mostly empty
+        self._act_valid = False        # step_slam's activated copies of raw8 are current (its tail re-activates moved rows)
         self._mode = None              # world > 1: "sharded" (step) or "replicated" (step_slam); they keep different state
         if self.row_skip and activate_fn is None:
             from .rasterizer import RowGradArena
@@ -364,6 +365,7 @@ class ShardedMapOptimizer:
                 loss_scratch=None,
                 ones=torch.ones((H + 15) // 16, (W + 15) // 16, **i),
                 arenas=[_GrowArena(dev), _GrowArena(dev), _GrowArena(dev)])
+            self._act_valid = False
         if tile_mask is None:
             tile_mask = ws["ones"]
         tile_mask = tile_mask.to(device=dev, dtype=torch.int32).contiguous()
@@ -392,7 +394,7 @@ class ShardedMapOptimizer:
             P(ad["raw8"]["v"]), P(st["xyz"]["lr"]), P(st["shs"]["lr"]), P(st["raw8"]["lr"]), P(ad["xyz"]["ever"]),
             P(ad["shs"]["ever"]), P(ad["raw8"]["ever"]), int(self.step_count), 0.9, 0.999, float(self.eps),
             C.pointer(attach) if attach is not None else None, P(confidence) if confidence is not None else None,
-            geom.cb, None, binning.cb, None, img.cb, None)
+            int(self._act_valid), geom.cb, None, binning.cb, None, img.cb, None)
         R = C.c_int64(0)
         stream = torch.cuda.current_stream(dev).cuda_stream
         if tile_band and self.world > 1:
@@ -413,6 +415,7 @@ class ShardedMapOptimizer:
             _lib.check(rc, "rtgs_slam_map_step_front")
             self._exchange_and_tail(dict(step=int(self.step_count), attach=attach, confidence=confidence, keep=(keep, attach)))
         a.calls = 1
+        self._act_valid = True                      # every tail below re-activated the rows it stepped
         self.last_render = (ws["color"], ws["depth"], ws["cidx"], ws["didx"], ws["cw"], ws["dw"], ws["T"])
         self.last_num_rendered = int(R.value)
         self.last_losses = ws["loss"]               # device float[4]: total, colour, depth, ssim (mapper.py:458-466)
@@ -450,8 +453,9 @@ class ShardedMapOptimizer:
                             band_rm.data_ptr())
         ctx = current_context().ptr
         with torch.cuda.device(dev):
-            _lib.check(lib.rtgs_map_activate8_forward(V(x["raw8"]["p"]), N, V(ws["opacity"]), V(ws["scales"]), V(ws["rotations"]),
-                                                      V(ws["normal"]), st()), "rtgs_map_activate8_forward")
+            if not self._act_valid:
+                _lib.check(lib.rtgs_map_activate8_forward(V(x["raw8"]["p"]), N, V(ws["opacity"]), V(ws["scales"]),
+                                                          V(ws["rotations"]), V(ws["normal"]), st()), "rtgs_map_activate8_forward")
             _lib.check(lib.rtgs_raster_forward_ctx(
                 ctx, C.byref(keep.c), N, 16, V(x["xyz"]["p"]), V(ws["opacity"]), V(x["shs"]["p"]), V(ws["scales"]),
                 V(ws["rotations"]), V(ws["normal"]), V(band), V(ws["color"]), V(ws["depth"]), V(ws["cidx"]), V(ws["didx"]),
@@ -521,7 +525,9 @@ class ShardedMapOptimizer:
                 V(ad["xyz"]["v"]), V(ad["shs"]["m"]), V(ad["shs"]["v"]), V(ad["raw8"]["m"]), V(ad["raw8"]["v"]),
                 V(st["xyz"]["lr"]), V(st["shs"]["lr"]), V(st["raw8"]["lr"]), V(ad["xyz"]["ever"]), V(ad["shs"]["ever"]),
                 V(ad["raw8"]["ever"]), N, job["step"], 0.9, 0.999, float(self.eps),
-                C.byref(att) if att is not None else None, V(conf) if conf is not None else None, V(flag), stream())
+                C.byref(att) if att is not None else None, V(conf) if conf is not None else None, V(flag),
+                C.byref(_lib.ActivatedC(ws["opacity"].data_ptr(), ws["scales"].data_ptr(), ws["rotations"].data_ptr(),
+                                        ws["normal"].data_ptr())), stream())
             _lib.check(rc, "rtgs_map_tail_rows")
         ws["flag_host"].copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
@@ -571,6 +577,7 @@ class ShardedMapOptimizer:
         """loss_fn(gaussian_data) -> scalar loss of THIS rank's view.  Gradients are summed over
         ranks (the sum of per-view losses is what a single GPU looping over the views optimises)."""
         N = self.N
+        self._act_valid = False            # raw8 moves without step_slam's tail: its activated copies go stale
         if self.world > 1:
             if self._mode == "replicated":
                 raise RuntimeError("ShardedMapOptimizer: step() after step_slam() on more than one rank - the two keep "

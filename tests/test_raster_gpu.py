@@ -324,6 +324,12 @@ def test_step_slam_attach_regulariser_and_confidence():
         lb = ob.step_slam(rs, gt_c, gt_d, None, render_mask=rm, confidence=conf)
         assert abs(float(lb) - float((total - attach).detach())) <= 1e-4 * max(1.0, abs(float(total.detach()))), step
         assert abs(att_b - float(attach.detach())) <= 1e-3 * max(1e-9, abs(float(attach.detach()))) + 1e-12, step
+    # step_slam skips the full activation pass after its first call: its tail re-activates the rows it steps, and
+    # the persistent activated arrays must equal a fresh activation of the current raw8 bit for bit
+    fresh = mo.activate8_hip(ob.state["raw8"]["p"][:N])
+    for k in ("opacity", "scales", "rotations", "normal"):
+        assert torch.equal(ob._slam_ws[k], fresh[k].reshape(ob._slam_ws[k].shape)), k
+    assert ob._act_valid
     pa, pb = oa.params.cpu(), ob.params.cpu()
     assert ru.frac_bad(pa, pb, 1e-5) < 2e-3
     assert torch.equal(conf.cpu(), conf_ref.cpu()) and 0 < float(conf.max()) <= 4
@@ -586,6 +592,12 @@ def test_one_call_slam_step_matches_autograd_step():
         lb = float(ob.step_slam(rs, gt_c, gt_d, tm))
         assert abs(la - lb) <= 1e-4 * max(1.0, abs(la)), step
         assert ob.last_num_rendered > 0 and ob.last_render[0].shape == (3, SMALL.H, SMALL.W)
+    # step_slam skips the full activation pass after its first call: its tail re-activates the rows it steps, and
+    # the persistent activated arrays must equal a fresh activation of the current raw8 bit for bit
+    fresh = mo.activate8_hip(ob.state["raw8"]["p"][:N])
+    for k in ("opacity", "scales", "rotations", "normal"):
+        assert torch.equal(ob._slam_ws[k], fresh[k].reshape(ob._slam_ws[k].shape)), k
+    assert ob._act_valid
     pa, pb = oa.params.cpu(), ob.params.cpu()
     assert ru.frac_bad(pa, pb, 1e-5) < 2e-3
     moved = (pa - packed.cpu()).abs().max(dim=1).values > 0
