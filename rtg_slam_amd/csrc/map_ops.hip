@@ -550,18 +550,57 @@ __device__ __forceinline__ float wave_sum_shfl(float v) {
 }
 
 // sums: [0] sum |dC| over mask  [1] sum |dD| over valid  [2] #valid  [3] #mask pixels  [4] sum of the SSIM map
+// V pixels per lane and step: V = 4 reads every plane with 16-B loads (the image must then hold a multiple of four
+// pixels); V = 1 is the general form.  The pixel order of the per-lane sums differs between the two, as it does between
+// grid sizes: the loss value is a float sum either way.
+template <int V> struct PixVec;
+template <> struct PixVec<1> {
+  float v[1];
+  __device__ __forceinline__ void load(const float* p, int64_t i) { v[0] = p[i]; }
+  __device__ __forceinline__ void store(float* p, int64_t i) const { p[i] = v[0]; }
+};
+template <> struct PixVec<4> {
+  float v[4];
+  __device__ __forceinline__ void load(const float* p, int64_t i) {
+    const float4 t = *reinterpret_cast<const float4*>(p + i); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ __forceinline__ void store(float* p, int64_t i) const { *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <int V>
+__device__ __forceinline__ void load_flags(const uint8_t* __restrict__ rmask, const int32_t* __restrict__ didx, int64_t i, bool (&m)[V],
+                                           bool (&hit)[V]) {
+  if constexpr (V == 4) {
+    const uint32_t mm = rmask ? *reinterpret_cast<const uint32_t*>(rmask + i) : 0x01010101u;
+    const int4 d = *reinterpret_cast<const int4*>(didx + i);
+    m[0] = (mm & 0xffu) != 0; m[1] = (mm & 0xff00u) != 0; m[2] = (mm & 0xff0000u) != 0; m[3] = (mm & 0xff000000u) != 0;
+    hit[0] = d.x != -1; hit[1] = d.y != -1; hit[2] = d.z != -1; hit[3] = d.w != -1;
+  } else {
+    m[0] = !rmask || rmask[i] != 0;
+    hit[0] = didx[i] != -1;
+  }
+}
+
+template <int V>
 __global__ void __launch_bounds__(256) slam_loss_sums_kernel(const float* __restrict__ color, const float* __restrict__ depth,
                                                              const int32_t* __restrict__ didx, const float* __restrict__ gt_c,
                                                              const float* __restrict__ gt_d, const uint8_t* __restrict__ rmask,
                                                              int64_t hw, float depth_thr, float* __restrict__ sums) {
   float s_c = 0.f, s_d = 0.f, s_m = 0.f, s_n = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
-    const bool m = !rmask || rmask[i] != 0;
-    if (!m) continue;
-    s_n += 1.f;
-    s_c += fabsf(color[i] - gt_c[i]) + fabsf(color[hw + i] - gt_c[hw + i]) + fabsf(color[2 * hw + i] - gt_c[2 * hw + i]);
-    const float g = gt_d[i], e = depth[i] - g;
-    if (didx[i] != -1 && g > 0.f && e < depth_thr) { s_d += fabsf(e); s_m += 1.f; }
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < hw; i += (int64_t)gridDim.x * blockDim.x * V) {
+    bool m[V], hit[V];
+    load_flags<V>(rmask, didx, i, m, hit);
+    PixVec<V> c0, c1, c2, t0, t1, t2, dp, gd;
+    c0.load(color, i); c1.load(color + hw, i); c2.load(color + 2 * hw, i);
+    t0.load(gt_c, i); t1.load(gt_c + hw, i); t2.load(gt_c + 2 * hw, i);
+    dp.load(depth, i); gd.load(gt_d, i);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      if (!m[k]) continue;
+      s_n += 1.f;
+      s_c += fabsf(c0.v[k] - t0.v[k]) + fabsf(c1.v[k] - t1.v[k]) + fabsf(c2.v[k] - t2.v[k]);
+      const float g = gd.v[k], e = dp.v[k] - g;
+      if (hit[k] && g > 0.f && e < depth_thr) { s_d += fabsf(e); s_m += 1.f; }
+    }
   }
   s_c = wave_sum_shfl(s_c); s_d = wave_sum_shfl(s_d); s_m = wave_sum_shfl(s_m); s_n = wave_sum_shfl(s_n);
   __shared__ float sh[4][4];
@@ -679,6 +718,7 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(const float* __restrict__
 }
 
 // loss4: [0] total [1] colour [2] depth [3] ssim term (1 - mean S, or 0)
+template <int V>
 __global__ void __launch_bounds__(256) slam_loss_grads_kernel(const float* __restrict__ color, const float* __restrict__ depth,
                                                               const int32_t* __restrict__ didx, const float* __restrict__ gt_c,
                                                               const float* __restrict__ gt_d, const uint8_t* __restrict__ rmask,
@@ -693,18 +733,38 @@ __global__ void __launch_bounds__(256) slam_loss_grads_kernel(const float* __res
     loss4[0] = dw * ld + cw * lc + sw * ls;
   }
   const float kc = cw * inv_c, kd = dw * inv_m;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
-    const bool m = !rmask || rmask[i] != 0;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < hw; i += (int64_t)gridDim.x * blockDim.x * V) {
+    bool m[V], hit[V];
+    load_flags<V>(rmask, didx, i, m, hit);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float d = color[c * hw + i] - gt_c[c * hw + i];
-      g_color[c * hw + i] = !m ? 0.f : (d > 0.f ? kc : (d < 0.f ? -kc : 0.f));     // sign(0) = 0 as torch.abs' backward
+      PixVec<V> a, b, o;
+      a.load(color + c * hw, i); b.load(gt_c + c * hw, i);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const float d = a.v[k] - b.v[k];
+        o.v[k] = !m[k] ? 0.f : (d > 0.f ? kc : (d < 0.f ? -kc : 0.f));     // sign(0) = 0 as torch.abs' backward
+      }
+      o.store(g_color + c * hw, i);
     }
-    const float g = gt_d[i], e = depth[i] - g;
-    float gd = 0.f;
-    if (m && didx[i] != -1 && g > 0.f && e < depth_thr) gd = e > 0.f ? kd : (e < 0.f ? -kd : 0.f);
-    g_depth[i] = gd;
+    PixVec<V> dp, gt, o;
+    dp.load(depth, i); gt.load(gt_d, i);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float g = gt.v[k], e = dp.v[k] - g;
+      o.v[k] = (m[k] && hit[k] && g > 0.f && e < depth_thr) ? (e > 0.f ? kd : (e < 0.f ? -kd : 0.f)) : 0.f;
+    }
+    o.store(g_depth, i);
   }
+}
+
+// 16-B path: a multiple of four pixels (so every plane starts 16-B aligned relative to its tensor) and aligned bases
+static inline bool loss_vec4_ok(int64_t hw, const void* a, const void* b, const void* c, const void* d, const void* e,
+                                const void* mask, const void* f, const void* g) {
+  if (hw % 4 != 0) return false;
+  const void* ptrs[7] = {a, b, c, d, e, f, g};
+  for (const void* p : ptrs) if (p && ((uintptr_t)p & 15u) != 0) return false;
+  return !mask || ((uintptr_t)mask & 3u) == 0;
 }
 
 }  // namespace rtgs
@@ -733,8 +793,12 @@ extern "C" int rtgs_slam_loss_sums(const float* color, const float* depth, const
   // the sums kernel ends with four same-address global atomics per workgroup (~20 ns each, serialised): keep it to
   // 192 workgroups (1 024 of them cost 20 us for a 23 MB read)
   if (blocks > 192) blocks = 192;
-  hipLaunchKernelGGL(rtgs::slam_loss_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, color, depth, depth_index,
-                     gt_color, gt_depth, cfg->render_mask, hw, cfg->add_depth_thres, sums);
+  if (rtgs::loss_vec4_ok(hw, color, depth, depth_index, gt_color, gt_depth, cfg->render_mask, nullptr, nullptr))
+    hipLaunchKernelGGL(rtgs::slam_loss_sums_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, color, depth, depth_index,
+                       gt_color, gt_depth, cfg->render_mask, hw, cfg->add_depth_thres, sums);
+  else
+    hipLaunchKernelGGL(rtgs::slam_loss_sums_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, color, depth, depth_index,
+                       gt_color, gt_depth, cfg->render_mask, hw, cfg->add_depth_thres, sums);
   if (ssim) {
     rtgs::SsimWin win;
     ssim_window(win);
@@ -758,9 +822,17 @@ extern "C" int rtgs_slam_loss_grads(const float* color, const float* depth, cons
   const bool ssim = cfg->render_mask == nullptr && cfg->ssim_weight != 0.f;
   int64_t blocks = (hw + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(rtgs::slam_loss_grads_kernel, dim3((unsigned)blocks), dim3(256), 0, st, color, depth, depth_index,
-                     gt_color, gt_depth, cfg->render_mask, hw, cfg->color_weight, cfg->depth_weight,
-                     ssim ? cfg->ssim_weight : 0.f, cfg->add_depth_thres, (const float*)sums, loss_out4, g_color, g_depth);
+  if (rtgs::loss_vec4_ok(hw, color, depth, depth_index, gt_color, gt_depth, cfg->render_mask, g_color, g_depth)) {
+    blocks = (hw / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(rtgs::slam_loss_grads_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, color, depth, depth_index,
+                       gt_color, gt_depth, cfg->render_mask, hw, cfg->color_weight, cfg->depth_weight,
+                       ssim ? cfg->ssim_weight : 0.f, cfg->add_depth_thres, (const float*)sums, loss_out4, g_color, g_depth);
+  } else {
+    hipLaunchKernelGGL(rtgs::slam_loss_grads_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, color, depth, depth_index,
+                       gt_color, gt_depth, cfg->render_mask, hw, cfg->color_weight, cfg->depth_weight,
+                       ssim ? cfg->ssim_weight : 0.f, cfg->add_depth_thres, (const float*)sums, loss_out4, g_color, g_depth);
+  }
   if (ssim) {
     rtgs::SsimWin win;
     ssim_window(win);

@@ -246,15 +246,15 @@ def test_matches_committed_golden(golden_dir):
         assert float((gd_h[k] - r).abs().max()) / (float(r.abs().max()) + 1e-12) < 1e-3, k
 
 
-@pytest.mark.parametrize("masked", [False, True])
-def test_fused_loss_matches_torch(masked):
+@pytest.mark.parametrize("masked,H,W", [(False, 37, 53), (True, 37, 53), (False, 40, 52), (True, 40, 52)])
+def test_fused_loss_matches_torch(masked, H, W):
     """rtgs_slam_loss (HIP) vs map_optim.slam_losses (torch; pinned to the oracle's restatement of mapper.py:402-448 and
     to the reference's own ssim in tests/test_oracle_slam_ops.py / test_dist_cpu.py): value, the four reported terms and
     both image gradients - with a render mask (masked L1 + gated depth) and without (all pixels + the SSIM term)."""
     from rtg_slam_amd import map_optim as mo
     dev = "cuda:0"
     gen = torch.Generator().manual_seed(4)
-    H, W = 37, 53
+    # 37 x 53 pixels: the general (one pixel per lane) kernels; 40 x 52, a multiple of four: the 16-B load path
     color = torch.rand(3, H, W, generator=gen).to(dev).requires_grad_(True)
     depth = (torch.rand(1, H, W, generator=gen) * 3).to(dev).requires_grad_(True)
     didx = (torch.randint(-1, 5, (1, H, W), generator=gen, dtype=torch.int32)).to(dev)
