@@ -33,6 +33,8 @@ size_t bin_block_counts_bytes(int, int);
 int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, uint16_t*, SliceSel,
                      SliceList, size_t, hipStream_t);
 size_t bin_slice_block_counts_bytes(int, size_t, int);
+size_t bin_list_block_counts_bytes(int, int);
+void launch_visible_compact(int, const uint8_t*, uint32_t*, uint32_t*, hipStream_t);
 void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, hipStream_t);
 void launch_slice_publish(int, const int32_t*, const int32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, hipStream_t);
 void launch_preprocess_cull(const RasterParams&, const float*, const float*, const float*, uint32_t*, int32_t*, int32_t*,
@@ -135,7 +137,7 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
     L.ranges1_bwd = off; off += nt * sizeof(uint2);
     L.slice_hist = off; off += 2 * SLICE_BINS * sizeof(uint32_t);
     L.slice_cover = off; off += SLICE_BINS * sizeof(unsigned long long);
-    L.slice_ctr = off; off += 8 * sizeof(uint32_t);   // [0] unfinished tiles [2] slice list length [3] cut [4] slot cursor
+    L.slice_ctr = off; off += 8 * sizeof(uint32_t);   // [0] unfinished tiles [2] slice list length [3] cut [4] slot cursor [5] visible-list length
     L.slot_count = off; off += Pn * sizeof(uint32_t);   // zero between calls: cleared here, and again by grad_reduce
     L.zero_end = off; off = align_up(off);
     L.cursor = off; off = align_up(off + nt * sizeof(uint32_t));
@@ -149,6 +151,8 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
     L.slice_cap = nt * (size_t)(budget > 0 ? budget : 1);
     L.slice_max_list = L.slice_cap < 65536 ? L.slice_cap : 65536;   // every listed Gaussian covers >= 1 tile
     if (L.slice_max_list > Pn) L.slice_max_list = Pn;
+    L.vis_ids = off; off = align_up(off + Pn * sizeof(uint32_t));             // work list of every visible Gaussian
+    L.block_counts_vis = off; off = align_up(off + bin_list_block_counts_bytes((int)Pn, gx * gy));
     L.list1 = off; off = align_up(off + L.slice_cap * sizeof(uint32_t));      // last budget-independent OFFSET
     L.block_counts1 = off; off = align_up(off + bin_slice_block_counts_bytes((int)Pn, L.slice_max_list, gx * gy));
     L.slice_ids = off; off = align_up(off + L.slice_max_list * sizeof(uint32_t));
@@ -347,6 +351,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   bool sliced = !sort_path && P > 0 && (c->slice_mode == 1 || (slice_auto && P >= 100000 && ntiles >= 256));
   SlicePass pass{0, nullptr, nullptr, nullptr, nullptr};
   bool declined = false, considered = false;
+  SliceList vis{nullptr, nullptr};             // every visible Gaussian, when the declined single pass built the list
   // pinned host words the kernels publish totals into, and the spin that waits for them: a few microseconds instead
   // of the ~25 us a blocking hipStreamSynchronize takes to wake up (bounded; falls back)
   if (!c->info_host) {
@@ -402,10 +407,11 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
     }
     if (sliced && declined) {
       // the kernels declined the slice and the host knows: shade every visible Gaussian and go on as a single pass
-      SliceSel sel_all = sel1;
-      sel_all.ctr = nullptr;
+      // ... through a compact list of the visible ones (dense lanes in the shade / count / scatter kernels)
+      vis = SliceList{(const uint32_t*)(geom + G.vis_ids), slice_ctr + 5};
+      launch_visible_compact(P, zbin, (uint32_t*)(geom + G.vis_ids), slice_ctr + 5, st);
       launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
-                              (float2*)(geom + G.uv), SliceList{nullptr, nullptr}, sel_all, 0, st);
+                              (float2*)(geom + G.uv), vis, sel1, (size_t)P, st);
       if (want_bwd && (rc = scan_all()) != RTGS_OK) return rc;
       sliced = false;
       considered = true;
@@ -459,7 +465,8 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       // exact per-tile counts -> ranges; the one host sync of the forward sizes the instance arrays
       const SliceSel sel2{sliced ? 2 : 0, nullptr, nullptr, 0u, 0u, slice_ctr, sliced ? sat : nullptr,
                           (const float2*)(geom + G.uv), nullptr, 0u, 0};
-      if (launch_bin_count(p, splats, radii, mask_main, tile_count, block_counts, sel2, SliceList{nullptr, nullptr}, 0, st) != 0)
+      if (launch_bin_count(p, splats, radii, mask_main, tile_count,
+                           vis.ids ? (uint16_t*)(geom + G.block_counts_vis) : block_counts, sel2, vis, (size_t)P, st) != 0)
         return RTGS_E_HIP;
       if (++c->seq == 0u) c->seq = 1u;
       launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, info_host, nullptr, nullptr,
@@ -511,10 +518,11 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   if (P == 0 || sort_path) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), st));
   if (R > 0 && !sort_path) {
     prof_mark(c, EV_BIN0, st);
-    launch_bin_scatter(p, splats, radii, mask_main, block_counts, cursor, (unsigned long long*)keys_a,
+    launch_bin_scatter(p, splats, radii, mask_main, vis.ids ? (const uint16_t*)(geom + G.block_counts_vis) : block_counts, cursor,
+                       (unsigned long long*)keys_a,
                        SliceSel{sliced ? 2 : 0, nullptr, nullptr, 0u, 0u, slice_ctr, sliced ? sat : nullptr,
                                 (const float2*)(geom + G.uv), nullptr, 0u, 0},
-                       SliceList{nullptr, nullptr}, 0, st);
+                       vis, (size_t)P, st);
     DBG(s, st);
     prof_mark(c, EV_EMIT, st);
     launch_bin_tilesort(ntiles, longest, ranges, (const unsigned long long*)keys_a, vals_b, st);

@@ -449,6 +449,16 @@ __global__ void __launch_bounds__(THREADS) bin_tilesort_radix_kernel(const uint2
 size_t bin_lds_limit_tiles() { return 16000; }       // 2 x 4 B x tiles must fit the 160 KiB LDS
 int bin_sort_capacity() { return 16384; }            // 16384 x 8 B = 128 KiB
 
+// Gaussians per workgroup: the whole map by index -> GPB; the near slice's short list (<= 65 536 ids, each covering tens
+// of tiles) -> small work items, many workgroups; the list of every visible Gaussian -> one wave's worth per wave
+constexpr int LIST_GPB = 256;
+static inline int list_gpb(const SliceList& list, size_t max_items) {
+  return !list.ids ? GPB : (max_items > 65536 ? LIST_GPB : SLICE_GPB);
+}
+size_t bin_list_block_counts_bytes(int P, int ntiles) {          // rows of the visible-list mode
+  const size_t rows = P > 65536 ? ((size_t)P + LIST_GPB - 1) / LIST_GPB : ((size_t)P + SLICE_GPB - 1) / SLICE_GPB;
+  return rows * (size_t)ntiles * sizeof(uint16_t);
+}
 size_t bin_block_counts_bytes(int P, int ntiles) {
   return (size_t)((P + GPB - 1) / GPB) * (size_t)ntiles * sizeof(uint16_t);
 }
@@ -594,6 +604,45 @@ void launch_slice_compact(int P, SliceSel sel, uint32_t* ids, uint32_t* n_list, 
                      n_list, rect_area, gbase, slot_cursor, host, seq);
 }
 
+// Every visible Gaussian (zbin != 255), compacted into a work list: when the near slice is declined and the host knows
+// it, the single pass that follows shades / counts / scatters through this list with dense lanes instead of sweeping
+// all P Gaussians with one lane in six active (a surface map shows ~18 % of its Gaussians to a view).
+__global__ void __launch_bounds__(256) visible_compact_kernel(int P, const uint8_t* __restrict__ zbin, uint32_t* __restrict__ ids,
+                                                              uint32_t* __restrict__ n_list) {
+  __shared__ uint32_t s_ids[COMPACT_CHUNK];
+  __shared__ uint32_t s_n, s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int begin = blockIdx.x * COMPACT_CHUNK;
+  for (int i0 = begin; i0 < begin + COMPACT_CHUNK && i0 < P; i0 += 256 * 4) {
+    const int i = i0 + (int)threadIdx.x * 4;
+    uint32_t zb4 = 0xffffffffu;
+    if (i + 4 <= P) zb4 = *reinterpret_cast<const uint32_t*>(zbin + i);
+    else for (int k = 0; k < 4; ++k) if (i + k < P) zb4 = (zb4 & ~(0xffu << (8 * k))) | ((uint32_t)zbin[i + k] << (8 * k));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool in = ((zb4 >> (8 * k)) & 0xffu) != 255u;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+      if (m == 0ull) continue;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (in) s_ids[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(i + k);
+    }
+  }
+  __syncthreads();
+  const uint32_t n = s_n;
+  if (n == 0u) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(n_list, n);
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n; k += 256) ids[s_base + k] = s_ids[k];
+}
+void launch_visible_compact(int P, const uint8_t* zbin, uint32_t* ids, uint32_t* n_list, hipStream_t st) {
+  if (P == 0) return;
+  hipLaunchKernelGGL(visible_compact_kernel, dim3((P + COMPACT_CHUNK - 1) / COMPACT_CHUNK), dim3(256), 0, st, P, zbin, ids, n_list);
+}
+
 int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
                      uint32_t* tile_count, uint16_t* block_counts, SliceSel sel, SliceList list, size_t max_items,
                      hipStream_t st) {
@@ -602,7 +651,7 @@ int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* 
   const size_t lds = (size_t)ntiles * sizeof(uint32_t);
   static LdsGrant grant(48 * 1024);
   grant.ensure((const void*)bin_count_kernel, lds);
-  const int gpb = list.ids ? SLICE_GPB : GPB;       // the slice list is short: small work items, many workgroups
+  const int gpb = list_gpb(list, max_items);
   const size_t n = list.ids && max_items < (size_t)p.P ? max_items : (size_t)p.P;
   hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)((n + gpb - 1) / gpb)), dim3(BLOCK), lds, st, p, splats, radii, mask,
                      tile_count, block_counts, sel, list, gpb);
@@ -622,7 +671,7 @@ void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_
   const size_t lds = 2 * (size_t)ntiles * sizeof(uint32_t);
   static LdsGrant grant(32 * 1024);
   grant.ensure((const void*)bin_scatter_kernel, lds);
-  const int gpb = list.ids ? SLICE_GPB : GPB;
+  const int gpb = list_gpb(list, max_items);
   const size_t n = list.ids && max_items < (size_t)p.P ? max_items : (size_t)p.P;
   hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)((n + gpb - 1) / gpb)), dim3(BLOCK), lds, st, p, splats, radii,
                      mask, block_counts, cursor, bucket, sel, list, gpb);

@@ -56,6 +56,7 @@ struct GeomLayout {
   size_t zero_begin, zero_end;
   size_t tile_count1, ranges1_bwd, slice_hist, slice_cover, slice_ctr;   // inside the zeroed span (tile_count is too)
   size_t zbin, cursor1, ranges1, mask2, block_counts1, bucket1, list1, uv, slice_ids;
+  size_t vis_ids, block_counts_vis;   // list of every visible Gaussian + its per-workgroup tile counts (declined single pass)
   size_t slot_count;                 // [P] u32: slots taken per Gaussian (backward; zeroed by it)
   size_t slice_cap, slice_max_list;                                  // capacity of bucket1 / list1; of the work list
 };
