@@ -34,7 +34,7 @@ int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const in
                      SliceList, size_t, hipStream_t);
 size_t bin_slice_block_counts_bytes(int, size_t, int);
 size_t bin_list_block_counts_bytes(int, int);
-void launch_visible_compact(int, const uint8_t*, uint32_t*, uint32_t*, hipStream_t);
+void launch_visible_compact(int, const uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, hipStream_t);
 void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, hipStream_t);
 void launch_slice_publish(int, const int32_t*, const int32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, hipStream_t);
 void launch_preprocess_cull(const RasterParams&, const float*, const float*, const float*, uint32_t*, int32_t*, int32_t*,
@@ -137,7 +137,7 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
     L.ranges1_bwd = off; off += nt * sizeof(uint2);
     L.slice_hist = off; off += 2 * SLICE_BINS * sizeof(uint32_t);
     L.slice_cover = off; off += SLICE_BINS * sizeof(unsigned long long);
-    L.slice_ctr = off; off += 8 * sizeof(uint32_t);   // [0] unfinished tiles [2] slice list length [3] cut [4] slot cursor [5] visible-list length
+    L.slice_ctr = off; off += 8 * sizeof(uint32_t);   // [0] unfinished tiles [2] slice list length [3] cut [4] slot cursor of the slice, or visible-list length with [5] its slot cursor
     L.slot_count = off; off += Pn * sizeof(uint32_t);   // zero between calls: cleared here, and again by grad_reduce
     L.zero_end = off; off = align_up(off);
     L.cursor = off; off = align_up(off + nt * sizeof(uint32_t));
@@ -408,11 +408,10 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
     if (sliced && declined) {
       // the kernels declined the slice and the host knows: shade every visible Gaussian and go on as a single pass
       // ... through a compact list of the visible ones (dense lanes in the shade / count / scatter kernels)
-      vis = SliceList{(const uint32_t*)(geom + G.vis_ids), slice_ctr + 5};
-      launch_visible_compact(P, zbin, (uint32_t*)(geom + G.vis_ids), slice_ctr + 5, st);
+      vis = SliceList{(const uint32_t*)(geom + G.vis_ids), slice_ctr + 4};
+      launch_visible_compact(P, zbin, (uint32_t*)(geom + G.vis_ids), slice_ctr + 4, tiles_touched, offsets, slice_ctr + 5, st);
       launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
                               (float2*)(geom + G.uv), vis, sel1, (size_t)P, st);
-      if (want_bwd && (rc = scan_all()) != RTGS_OK) return rc;
       sliced = false;
       considered = true;
     }
@@ -470,7 +469,9 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         return RTGS_E_HIP;
       if (++c->seq == 0u) c->seq = 1u;
       launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, info_host, nullptr, nullptr,
-                          want_bwd ? offsets + (P - 1) : nullptr, want_bwd ? tiles_touched + (P - 1) : nullptr, c->seq, st);
+                          // size of the gradient-slot space: the cursor visible_compact advanced, or the end of the full scan
+                          want_bwd ? (vis.ids ? slice_ctr + 5 : offsets + (P - 1)) : nullptr,
+                          want_bwd && !vis.ids ? tiles_touched + (P - 1) : nullptr, c->seq, st);
       DBG(s, st);
       prof_mark(c, EV_SCAN, st);
       if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;

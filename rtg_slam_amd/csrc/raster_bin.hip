@@ -607,15 +607,18 @@ void launch_slice_compact(int P, SliceSel sel, uint32_t* ids, uint32_t* n_list, 
 // Every visible Gaussian (zbin != 255), compacted into a work list: when the near slice is declined and the host knows
 // it, the single pass that follows shades / counts / scatters through this list with dense lanes instead of sweeping
 // all P Gaussians with one lane in six active (a surface map shows ~18 % of its Gaussians to a view).
+constexpr int VIS_CHUNK = 8192;      // ids per workgroup: few workgroups - each ends in ONE same-address atomic (~25 ns, serialised)
 __global__ void __launch_bounds__(256) visible_compact_kernel(int P, const uint8_t* __restrict__ zbin, uint32_t* __restrict__ ids,
-                                                              uint32_t* __restrict__ n_list) {
-  __shared__ uint32_t s_ids[COMPACT_CHUNK];
-  __shared__ uint32_t s_n, s_base;
-  if (threadIdx.x == 0) s_n = 0;
+                                                              uint32_t* __restrict__ n_list,
+                                                              const uint32_t* __restrict__ rect_area,
+                                                              uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_cursor) {
+  __shared__ uint32_t s_ids[VIS_CHUNK];
+  __shared__ uint32_t s_n, s_base, s_tot, s_gb, s_run, s_w[4];
+  if (threadIdx.x == 0) { s_n = 0; s_tot = 0; s_run = 0; }
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int begin = blockIdx.x * COMPACT_CHUNK;
-  for (int i0 = begin; i0 < begin + COMPACT_CHUNK && i0 < P; i0 += 256 * 4) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int begin = blockIdx.x * VIS_CHUNK;
+  for (int i0 = begin; i0 < begin + VIS_CHUNK && i0 < P; i0 += 256 * 4) {
     const int i = i0 + (int)threadIdx.x * 4;
     uint32_t zb4 = 0xffffffffu;
     if (i + 4 <= P) zb4 = *reinterpret_cast<const uint32_t*>(zbin + i);
@@ -634,13 +637,48 @@ __global__ void __launch_bounds__(256) visible_compact_kernel(int P, const uint8
   __syncthreads();
   const uint32_t n = s_n;
   if (n == 0u) return;
-  if (threadIdx.x == 0) s_base = atomicAdd(n_list, n);
+  // gradient-slot runs of the listed Gaussians (one slot per tile of the rect), as slice_compact lays them out for
+  // the slice: one atomic per workgroup reserves the chunk's total, a scan inside places the runs - replaces a
+  // scan over the whole map (gbase is only ever read for Gaussians some tile lists, i.e. visible ones)
+  uint32_t mine = 0;
+  for (uint32_t k = threadIdx.x; k < n; k += 256) mine += rect_area[s_ids[k]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off);
+  if (lane == 0) atomicAdd(&s_tot, mine);
   __syncthreads();
-  for (uint32_t k = threadIdx.x; k < n; k += 256) ids[s_base + k] = s_ids[k];
+  if (threadIdx.x == 0) {
+    // list length and slot cursor are neighbours (slot_cursor = n_list + 1, n_list 8-byte aligned): ONE 64-bit atomic for
+    // both; the cursor sits in the high word, so a (pathological) overflow of the slot total cannot reach the count
+    const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(n_list),
+                                             ((unsigned long long)s_tot << 32) | (unsigned long long)n);
+    s_base = (uint32_t)old; s_gb = (uint32_t)(old >> 32);
+  }
+  __syncthreads();
+  for (uint32_t k0 = 0; k0 < n; k0 += 256) {
+    const uint32_t k = k0 + threadIdx.x;
+    const uint32_t id = k < n ? s_ids[k] : 0u;
+    const uint32_t a = k < n ? rect_area[id] : 0u;
+    uint32_t incl = a;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    uint32_t pre = s_run;
+    for (int q = 0; q < w; ++q) pre += s_w[q];
+    if (k < n) { gbase[id] = s_gb + pre + incl - a; ids[s_base + k] = id; }
+    __syncthreads();
+    if (threadIdx.x == 0) s_run += (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    __syncthreads();
+  }
 }
-void launch_visible_compact(int P, const uint8_t* zbin, uint32_t* ids, uint32_t* n_list, hipStream_t st) {
+void launch_visible_compact(int P, const uint8_t* zbin, uint32_t* ids, uint32_t* n_list, const uint32_t* rect_area,
+                            uint32_t* gbase, uint32_t* slot_cursor, hipStream_t st) {
   if (P == 0) return;
-  hipLaunchKernelGGL(visible_compact_kernel, dim3((P + COMPACT_CHUNK - 1) / COMPACT_CHUNK), dim3(256), 0, st, P, zbin, ids, n_list);
+  hipLaunchKernelGGL(visible_compact_kernel, dim3((P + VIS_CHUNK - 1) / VIS_CHUNK), dim3(256), 0, st, P, zbin, ids, n_list,
+                     rect_area, gbase, slot_cursor);
 }
 
 int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
