@@ -659,9 +659,27 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11) -> torch
     return (((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s11 + s22 + C2))).mean()
 
 
+def normal_loss_term(render, normal_w: torch.Tensor, gt_normal: torch.Tensor, render_mask: Optional[torch.Tensor] = None):
+    """The normal term of Mapping.loss_update (mapper.py:433-442; `normal_weight`, 0 in every shipped config):
+    mean over {mask & depth_index != -1 & gt normal not all-zero} of 1 - cos(render normal, gt normal), where the
+    render normal of a pixel is the world normal of the Gaussian that owns its depth (render.py:130-133).  `render` =
+    the rasterizer's tuple, `normal_w` [N,3] the `normal` of gaussian_data (receives the gradient through the gather
+    kernel), `gt_normal` [H,W,3].  An empty set gives 0 (nan in the reference).  HIP tensors only."""
+    from .render import gather_normal_map
+    didx = render[3]
+    rn = gather_normal_map(normal_w, didx).permute(1, 2, 0)
+    cos_dist = 1 - torch.nn.functional.cosine_similarity(rn, gt_normal, dim=-1)
+    valid = (didx[0] != -1) & ~(gt_normal == 0).all(dim=-1)
+    if render_mask is not None:
+        valid = valid & (render_mask != 0)
+    v = valid.to(cos_dist.dtype)
+    return (cos_dist * v).sum() / v.sum().clamp_min(1.0)
+
+
 def slam_losses(render, gt_color: torch.Tensor, gt_depth: torch.Tensor, color_weight: float = 0.8,
                 depth_weight: float = 1.0, ssim_weight: float = 0.2, add_depth_thres: float = 0.1,
-                render_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                render_mask: Optional[torch.Tensor] = None, normal_weight: float = 0.0,
+                normal_w: Optional[torch.Tensor] = None, gt_normal: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Sync-free torch restatement of the image terms of Mapping.loss_update (mapper.py:402-448); `render` = the
     rasterizer's tuple (color[3,H,W], depth[1,H,W], ..., depth_index[1,H,W] at [3]).
       render_mask None -> every pixel AND the SSIM term 1 - ssim(render, gt) is live (:411-417); otherwise bool [H,W]
@@ -679,7 +697,10 @@ def slam_losses(render, gt_color: torch.Tensor, gt_depth: torch.Tensor, color_we
     err = depth[0] - gt_depth[0]
     vm = ((didx[0] != -1) & (gt_depth[0] > 0) & (err < add_depth_thres)).to(depth.dtype) * m
     depth_loss = (err.abs() * vm).sum() / vm.sum().clamp_min(1.0)
-    return depth_weight * depth_loss + color_weight * color_loss + ssim_weight * ssim_loss
+    total = depth_weight * depth_loss + color_weight * color_loss + ssim_weight * ssim_loss
+    if normal_weight > 0:
+        total = total + normal_weight * normal_loss_term(render, normal_w, gt_normal, render_mask)
+    return total
 
 
 class _SlamLossHip(torch.autograd.Function):
@@ -715,7 +736,12 @@ class _SlamLossHip(torch.autograd.Function):
 
 
 def slam_losses_hip(render, gt_color, gt_depth, color_weight: float = 0.8, depth_weight: float = 1.0,
-                    ssim_weight: float = 0.2, add_depth_thres: float = 0.1, render_mask=None) -> torch.Tensor:
-    """Same loss as `slam_losses`: value and both image gradients from the fused HIP kernels (rtgs_slam_loss)."""
-    return _SlamLossHip.apply(render[0], render[1], render[3], gt_color, gt_depth, color_weight, depth_weight, ssim_weight,
-                              add_depth_thres, render_mask)
+                    ssim_weight: float = 0.2, add_depth_thres: float = 0.1, render_mask=None, normal_weight: float = 0.0,
+                    normal_w=None, gt_normal=None) -> torch.Tensor:
+    """Same loss as `slam_losses`: value and both image gradients from the fused HIP kernels (rtgs_slam_loss); the
+    normal term (off in every shipped config) is added through the gather kernel when `normal_weight > 0`."""
+    total = _SlamLossHip.apply(render[0], render[1], render[3], gt_color, gt_depth, color_weight, depth_weight, ssim_weight,
+                               add_depth_thres, render_mask)
+    if normal_weight > 0:
+        total = total + normal_weight * normal_loss_term(render, normal_w, gt_normal, render_mask)
+    return total

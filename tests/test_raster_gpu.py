@@ -634,3 +634,41 @@ def test_wall_of_bit_equal_depths():
     for k in ru.FIELDS:
         sc = float(gd_o[k].abs().max()) + 1e-12
         assert float((gd_a[k] - gd_o[k]).abs().max()) / sc < 1e-3, k
+
+
+def test_normal_loss_term_matches_oracle():
+    """The normal term of Mapping.loss_update (mapper.py:433-442, `normal_weight`): value against the oracle's
+    restatement, gradient to the Gaussians' normals against autograd through torch indexing (render.py:130-133)."""
+    from rtg_slam_amd import map_optim as mo
+    from oracle import slam_ops_oracle as so
+    dev = "cuda:0"
+    cam = SMALL
+    N = 1500
+    g, s = ru.make_scene(N, cam, seed=12, pose_seed=3, r_range=(0.03, 0.12))
+    out_h, _ = ru.hip_run(s, g)
+    render = tuple(o.to(dev) for o in out_h)
+    gen = torch.Generator().manual_seed(8)
+    gt_n = torch.nn.functional.normalize(torch.randn(cam.H, cam.W, 3, generator=gen), dim=-1)
+    gt_n[::7, ::5] = 0.0                                         # invalid normals are excluded
+    mask = torch.rand(cam.H, cam.W, generator=gen) < 0.8
+    gt_c = torch.rand(3, cam.H, cam.W, generator=gen)
+    gt_d = out_h[1] + 0.02 * torch.randn(1, cam.H, cam.W, generator=gen)
+    assert int((out_h[3] >= 0).sum()) > 200
+    for rm in (None, mask):
+        nw = g["normal"].to(dev).clone().requires_grad_(True)
+        total = mo.slam_losses_hip(render, gt_c.to(dev), gt_d.to(dev), render_mask=None if rm is None else rm.to(dev),
+                                   normal_weight=0.3, normal_w=nw, gt_normal=gt_n.to(dev))
+        base = mo.slam_losses_hip(render, gt_c.to(dev), gt_d.to(dev), render_mask=None if rm is None else rm.to(dev))
+        # oracle: render normal by literal indexing, channels first
+        idx = out_h[3]
+        rn = torch.zeros(3, cam.H, cam.W)
+        nref = g["normal"].clone().requires_grad_(True)
+        rn[:, idx[0] > -1] = nref[idx[idx > -1].long()].permute(1, 0)
+        tot_o, terms = so.slam_loss(out_h, gt_c, gt_d, gt_normal=gt_n.permute(2, 0, 1), render_mask=rm, normal_weight=0.3,
+                                    render_normal=rn)
+        assert abs(float(total.detach()) - float(tot_o.detach())) < 1e-5 * max(1.0, abs(float(tot_o.detach())))
+        assert abs((float(total.detach()) - float(base)) - 0.3 * float(terms["normal"].detach())) < 1e-5
+        (g_hip,) = torch.autograd.grad(total, nw)
+        (g_ref,) = torch.autograd.grad(0.3 * terms["normal"], nref)
+        assert float(g_ref.abs().max()) > 0
+        assert float((g_hip.cpu() - g_ref).abs().max()) <= 1e-4 * float(g_ref.abs().max())
