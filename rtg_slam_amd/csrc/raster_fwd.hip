@@ -314,6 +314,10 @@ __device__ __forceinline__ void refresh_box(ActiveBox& b, unsigned long long m, 
 // LDS broadcast reads.  Per-wave ballot ends a wave's walk as soon as its 64 pixels are done;
 // __syncthreads_and ends the tile.
 // ---------------------------------------------------------------------------------------------
+#ifndef RTGS_FWD_U
+#define RTGS_FWD_U 4
+#endif
+constexpr int FWD_U = RTGS_FWD_U;     // entries per round of the forward walk
 __global__ void __launch_bounds__(256) blend_fwd_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -364,16 +368,16 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     // instruction streams, one LDS wait), only the T recurrence is sequential.  A single wave issues roughly
     // one dependent instruction every 8-15 cycles, so the walk is bound by the length of the dependent chain
     // per entry (measured: ~1 700 cycles per entry in the one-entry-at-a-time form) - not by ALU throughput.
-    for (int j = 0; j < m; j += 4) {
+    for (int j = 0; j < m; j += FWD_U) {
       const unsigned long long am = __builtin_amdgcn_ballot_w64(!done);
       if (am == 0ull) break;                // whole wave finished
       if (am != box.mask) refresh_box(box, am, blockIdx.x * TILE, blockIdx.y * TILE + (tid >> 6) * 4);
-      float4 r0[4], r1[4], r2[4];
-      float alpha[4];
-      bool live[4];
-      int e[4];
+      float4 r0[FWD_U], r1[FWD_U], r2[FWD_U];
+      float alpha[FWD_U];
+      bool live[FWD_U];
+      int e[FWD_U];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < FWD_U; ++k) {
         e[k] = min(j + k, m - 1);           // past the end: re-read the last entry (finite data), masked out by live[]
         r0[k] = s_rec[e[k] * 4 + 0];        // u v ca cb
         r1[k] = s_rec[e[k] * 4 + 1];        // cc o r g
@@ -383,16 +387,16 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
                                   (r0[k].y - r2[k].z > box.y1));
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < FWD_U; ++k) {
         const float dx = r0[k].x - pxf, dy = r0[k].y - pyf;
         const float power = splat_power(r0[k].z, r0[k].w, r1[k].x, dx, dy);
         const float al = fminf(0.99f, r1[k].y * splat_exp(fminf(power, 0.f)));
         alpha[k] = (live[k] && !(power > 0.f) && !(al < 1.f / 255.f)) ? al : 0.f;     // 0 = skipped
       }
-      float w[4];
+      float w[FWD_U];
       bool any_contrib = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {         // the sequential part: transmittance recurrence and the stop rule
+      for (int k = 0; k < FWD_U; ++k) {         // the sequential part: transmittance recurrence and the stop rule
         const bool ok = !done && alpha[k] > 0.f;
         const float test_T = T * (1.f - alpha[k]);
         const bool stop = ok && (test_T < p.T_thr);
@@ -407,7 +411,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
       if (__builtin_amdgcn_ballot_w64(any_contrib) == 0ull) continue;
       bool want_depth = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < FWD_U; ++k) {
         C0 += r1[k].z * w[k]; C1 += r1[k].w * w[k]; C2 += r2[k].x * w[k];
         const bool better = w[k] > best_w;   // w == 0 for non-contributing lanes, best_w >= 0
         const int gid = (int)__float_as_uint(r2[k].w);
@@ -417,7 +421,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
       }
       if (__builtin_amdgcn_ballot_w64(want_depth && d_id < 0) != 0ull) {   // rare: opaque-surface depth candidates
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < FWD_U; ++k) {
           if (w[k] > 0.f && d_id < 0 && alpha[k] > p.opaque_thr) {
             const float4 r3 = s_rec[e[k] * 4 + 3];  // nx ny nz pd
             const float den = r3.x * rx + r3.y * ry + r3.z;
