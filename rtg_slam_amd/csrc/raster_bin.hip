@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const ui
       // size of the backward's gradient-slot space: last exclusive-scan value + last rect area
       info_host[5] = (slot_a ? slot_a[0] : 0u) + (slot_b ? slot_b[0] : 0u);
       // publish: the host spins on this word instead of paying a blocking stream sync's wake-up latency
-      __hip_atomic_store(&info_host[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      publish_to_host(&info_host[7], seq);
     }
   }
 }
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(256) slice_compact_kernel(int P, SliceSel sel,
     reinterpret_cast<int32_t*>(n_list)[1] = cut;   // slice_ctr[3]
     if (host) {   // the host asked to hear the decision before it launches the slice's kernels (raster_api.hip)
       host[6] = (uint32_t)cut;
-      __hip_atomic_store(&host[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      publish_to_host(&host[7], seq);
     }
   }
   if (threadIdx.x == 0) { s_n = 0; s_tot = 0; s_run = 0; }

@@ -176,6 +176,16 @@ __device__ __forceinline__ float splat_exp(float x) {
   return __builtin_amdgcn_exp2f(__fmul_rn(x, 1.4426950408889634f));
 }
 
+// Publish a word to pinned host memory after the plain stores before it (the forward's host sync spins on it).
+// Written as fence -> explicit drain -> relaxed store: ROCm 7.2 can drop the s_waitcnt after buffer_wbl2 of a release
+// STORE when it believes the wave's vmcnt scoreboard is empty (MI355X_MICROARCH.md, compiler hazard), and the flag
+// would then overtake the payload.
+__device__ __forceinline__ void publish_to_host(uint32_t* flag, uint32_t value) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Cut bin of the near slice, recomputed by every workgroup from the 256-bin histogram (needs BLOCK = 256 threads, one
 // bin each, all of them calling): the largest bin whose cumulative instance count still fits sel.cap.
 __device__ __forceinline__ int slice_cut(const SliceSel& sel) {
