@@ -355,20 +355,31 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   // pinned host words the kernels publish totals into, and the spin that waits for them: a few microseconds instead
   // of the ~25 us a blocking hipStreamSynchronize takes to wake up (bounded; falls back)
   if (!c->info_host) {
-    HIP_TRY(hipHostMalloc((void**)&c->info_host, 8 * sizeof(uint32_t), hipHostMallocCoherent));
-    memset(c->info_host, 0, 8 * sizeof(uint32_t));
+    HIP_TRY(hipHostMalloc((void**)&c->info_host, HOST_WORDS * sizeof(uint32_t), hipHostMallocCoherent));
+    memset(c->info_host, 0, HOST_WORDS * sizeof(uint32_t));
   }
   uint32_t* const info_host = c->info_host;
+  // The payload is accepted only when the sequence word AND the checksum over (sequence, payload) agree with what was
+  // read: whatever order the device's writes become visible in, a torn view is re-read (raster_common.h: publish_to_host).
+  // `pub` receives a consistent snapshot of the seven payload words.
+  uint32_t pub[7] = {0, 0, 0, 0, 0, 0, 0};
   auto wait_published = [&](uint32_t seq) -> int {
-    volatile uint32_t* flag = info_host + 7;
-    bool seen = false;
+    volatile uint32_t* h = info_host;
+    auto snapshot_ok = [&]() -> bool {
+      if (h[7] != seq) return false;
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      uint32_t w[7];
+      for (int k = 0; k < 7; ++k) w[k] = h[k];
+      if (h[8] != host_checksum(seq, w)) return false;
+      for (int k = 0; k < 7; ++k) pub[k] = w[k];
+      return true;
+    };
     for (long spin = 0; spin < 4000000L; ++spin) {
-      if (*flag == seq) { seen = true; break; }
+      if (snapshot_ok()) return RTGS_OK;
       __builtin_ia32_pause();
     }
-    if (!seen) HIP_TRY(hipStreamSynchronize(st));
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    return RTGS_OK;
+    HIP_TRY(hipStreamSynchronize(st));           // the kernel has certainly finished: everything is visible now
+    return snapshot_ok() ? RTGS_OK : RTGS_E_HIP;
   };
   const int32_t* mask_main = tile_mask;        // tile mask of the pass that ends in the host sync
   uint32_t n_left = 0, n_fin = 0;
@@ -402,7 +413,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                            ask ? info_host : nullptr, c->seq, st);
       if (ask) {
         if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
-        declined = (int32_t)info_host[6] < 0;
+        declined = (int32_t)pub[6] < 0;
       }
     }
     if (sliced && declined) {
@@ -440,8 +451,8 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       prof_mark(c, EV_SL_BLEND, st);
       // the forward's host sync: the last tile of the slice publishes how many tiles are left
       if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
-      n_left = info_host[2]; n_fin = info_host[3];
-      R1 = (int64_t)info_host[4];          // total of the slice lists, finished or not (accounting only)
+      n_left = pub[2]; n_fin = pub[3];
+      R1 = (int64_t)pub[4];          // total of the slice lists, finished or not (accounting only)
       if (n_left > 0) {
         mask_main = mask2;
         pass = SlicePass{2, nullptr, mask2, nullptr, nullptr};
@@ -475,9 +486,9 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       DBG(s, st);
       prof_mark(c, EV_SCAN, st);
       if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
-      R = (int64_t)info_host[0];
-      longest = info_host[1];
-      slots = info_host[5];
+      R = (int64_t)pub[0];
+      longest = pub[1];
+      slots = pub[5];
       if ((int)longest > bin_sort_capacity()) {   // a tile list too long for the LDS sort: redo with rect counts
         sort_path = true;
         if (sliced) {         // the global-sort path renders every tile itself: drop the slice's results

@@ -254,13 +254,12 @@ __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const ui
   if (tid == 1023) {
     info[0] = s_sum[1023]; info[1] = s_max[1023];
     if (info_host) {   // pinned host words the forward's one host sync reads: no device-to-host copy launch in between
-      info_host[0] = s_sum[1023]; info_host[1] = s_max[1023];
-      if (extra_src) { info_host[2] = extra_src[0]; info_host[3] = extra_src[1]; }   // near-slice tile counters
-      if (extra_src2) info_host[4] = extra_src2[0];                                  // near-slice instance total
-      // size of the backward's gradient-slot space: last exclusive-scan value + last rect area
-      info_host[5] = (slot_a ? slot_a[0] : 0u) + (slot_b ? slot_b[0] : 0u);
-      // publish: the host spins on this word instead of paying a blocking stream sync's wake-up latency
-      publish_to_host(&info_host[7], seq);
+      const uint32_t w[7] = {s_sum[1023], s_max[1023], extra_src ? extra_src[0] : 0u, extra_src ? extra_src[1] : 0u,   // near-slice tile counters
+                             extra_src2 ? extra_src2[0] : 0u,                                                  // near-slice instance total
+                             // size of the backward's gradient-slot space: last exclusive-scan value + last rect area
+                             (slot_a ? slot_a[0] : 0u) + (slot_b ? slot_b[0] : 0u), 0u};
+      // publish: the host spins on the sequence word instead of paying a blocking stream sync's wake-up latency
+      publish_to_host(info_host, w, seq);
     }
   }
 }
@@ -537,8 +536,8 @@ __global__ void __launch_bounds__(256) slice_compact_kernel(int P, SliceSel sel,
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     reinterpret_cast<int32_t*>(n_list)[1] = cut;   // slice_ctr[3]
     if (host) {   // the host asked to hear the decision before it launches the slice's kernels (raster_api.hip)
-      host[6] = (uint32_t)cut;
-      publish_to_host(&host[7], seq);
+      const uint32_t w[7] = {0u, 0u, 0u, 0u, 0u, 0u, (uint32_t)cut};
+      publish_to_host(host, w, seq);
     }
   }
   if (threadIdx.x == 0) { s_n = 0; s_tot = 0; s_run = 0; }

@@ -176,14 +176,28 @@ __device__ __forceinline__ float splat_exp(float x) {
   return __builtin_amdgcn_exp2f(__fmul_rn(x, 1.4426950408889634f));
 }
 
-// Publish a word to pinned host memory after the plain stores before it (the forward's host sync spins on it).
-// Written as fence -> explicit drain -> relaxed store: ROCm 7.2 can drop the s_waitcnt after buffer_wbl2 of a release
-// STORE when it believes the wave's vmcnt scoreboard is empty (MI355X_MICROARCH.md, compiler hazard), and the flag
-// would then overtake the payload.
-__device__ __forceinline__ void publish_to_host(uint32_t* flag, uint32_t value) {
+// The forward's host sync: a kernel publishes up to seven payload words into pinned host memory, the host spins on the
+// sequence word.  host[0..6] = payload, host[7] = sequence, host[8] = checksum of (sequence, payload).
+//  * fence -> explicit drain -> relaxed store: ROCm 7.2 can drop the s_waitcnt after buffer_wbl2 of a release STORE when
+//    it believes the wave's vmcnt scoreboard is empty (MI355X_MICROARCH.md, compiler hazard) - the flag would overtake
+//    the payload;
+//  * the checksum makes the host independent of the order in which the writes become visible to it (the words travel
+//    as separate PCIe writes; relaxed ordering on that path is a platform setting): it accepts the payload only when
+//    sequence AND checksum match what it reads, and re-reads otherwise (raster_api.hip: wait_published).
+constexpr int HOST_WORDS = 16;
+__host__ __device__ __forceinline__ uint32_t host_checksum(uint32_t seq, const uint32_t (&w)[7]) {
+  uint32_t h = seq * 2654435761u;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) h = (h ^ w[k]) * 16777619u;
+  return h;
+}
+__device__ __forceinline__ void publish_to_host(uint32_t* host, const uint32_t (&w)[7], uint32_t seq) {
+#pragma unroll
+  for (int k = 0; k < 7; ++k) host[k] = w[k];
+  host[8] = host_checksum(seq, w);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&host[7], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Cut bin of the near slice, recomputed by every workgroup from the 256-bin histogram (needs BLOCK = 256 threads, one

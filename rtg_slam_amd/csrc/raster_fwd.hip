@@ -549,8 +549,8 @@ __global__ void __launch_bounds__(256) slice_publish_kernel(int ntiles, const in
   if (threadIdx.x == 0) {
     const uint32_t L = (uint32_t)(s_l[0] + s_l[1] + s_l[2] + s_l[3]), F = (uint32_t)(s_f[0] + s_f[1] + s_f[2] + s_f[3]);
     ctr[0] = L; ctr[1] = F;                      // device copy: pass 2's kernels exit at once when nothing is left
-    host[2] = L; host[3] = F; host[4] = r1[0];
-    publish_to_host(&host[7], seq);
+    const uint32_t w[7] = {0u, 0u, L, F, r1[0], 0u, 0u};
+    publish_to_host(host, w, seq);
   }
 }
 void launch_slice_publish(int ntiles, const int32_t* user_mask, const int32_t* mask2, const uint32_t* r1, uint32_t* ctr,
