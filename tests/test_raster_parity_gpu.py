@@ -43,8 +43,11 @@ _cache = {}
 def _big_case(name):
     """(scene, settings, mask, upstream grads, oracle outputs, oracle grads), oracle evaluated once per size."""
     if name not in _cache:
-        cam, N, n_tiles = {"config2": (synth.CONFIG2, 200_000, 96), "headline": (synth.REPLICA, 1_200_000, 128)}[name]
+        cam, N, n_tiles = {"config2": (synth.CONFIG2, 200_000, 96), "headline": (synth.REPLICA, 1_200_000, 128),
+                           "surface": (synth.REPLICA, 1_200_000, 128)}[name]
         g, s = ru.make_scene(N, cam, seed=2024)
+        if name == "surface":          # the single-layer map of bench.py's surface leg: the near slice declines itself
+            g = synth.surface_gaussians(N, cam, seed=7)
         mask = _spread_mask(cam, n_tiles)
         grads = _grads(cam, 11)
         out_o, gd_o, aux = ru.oracle_run(s, g, tile_mask=mask, grads=grads)
@@ -139,3 +142,35 @@ def test_hip_matches_independent_pixel_reference(cam, N, seed, pose, opaque):
     _check_grads(gd_h, gd_p)
     if opaque:
         assert int((out_p[4] >= 0.99 - 1e-6).sum()) > 0          # the clamp was active somewhere
+
+
+def test_parity_on_the_surface_map_through_the_declined_slice_paths():
+    """The 1.2 M-disc surface map of bench.py's second leg against the oracle: the automatic near slice declines it on
+    the device; the FIRST call learns that after launching the slice's (empty) kernels, the SECOND asks first and
+    renders through the compact list of visible Gaussians (visible_compact) - both, and the slice switched off, must
+    agree with the oracle, forward and backward."""
+    from rtg_slam_amd.rasterizer import RasterContext
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    cam, g, s, mask, grads, out_o, gd_o = _big_case("surface")
+    dev = "cuda:0"
+
+    def run(ctx):
+        leaves = {k: g[k].detach().to(dev).clone().requires_grad_(True) for k in ru.FIELDS}
+        rast = GaussianRasterizer(raster_settings=ru.hip_settings(s, dev))
+        outs = rast(means3D=leaves["xyz"], opacities=leaves["opacity"], shs=leaves["shs"], colors_precomp=None,
+                    scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None, normal_w=leaves["normal"],
+                    tile_mask=mask.to(dev), context=ctx)
+        ((outs[0] * grads[0].to(dev)).sum() + (outs[1] * grads[1].to(dev)).sum()).backward()
+        return tuple(o.detach().cpu() for o in outs), {k: leaves[k].grad.detach().cpu() for k in ru.FIELDS}
+
+    auto = RasterContext.create()
+    auto.set_near_slice(2, 0)
+    off = RasterContext.create()
+    off.set_near_slice(0, 0)
+    for label, ctx in (("off", off), ("auto, blind", auto), ("auto, asked", auto), ("auto, asked again", auto)):
+        out_h, gd_h = run(ctx)
+        if ctx is auto:
+            st = ctx.last_slice_stats()
+            assert st["used"] == 1 and st["instances"] == 0 and st["tiles_finished"] == 0, (label, st)
+        _check_maps(out_h, out_o)
+        _check_grads(gd_h, gd_o)
