@@ -318,14 +318,18 @@ __device__ __forceinline__ void refresh_box(ActiveBox& b, unsigned long long m, 
 #define RTGS_FWD_U 4
 #endif
 constexpr int FWD_U = RTGS_FWD_U;     // entries per round of the forward walk
+#ifndef RTGS_FWD_BATCH
+#define RTGS_FWD_BATCH 256
+#endif
+constexpr int FWD_BATCH = RTGS_FWD_BATCH;   // list entries staged through LDS per refill
 __global__ void __launch_bounds__(256) blend_fwd_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
     int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
     float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
     unsigned long long* __restrict__ counters, SlicePass sp) {
-  __shared__ float4 s_rec[BATCH * 4];     // u v ca cb | cc o r g | b hx hy id | nx ny nz pd: the walk reads the first three
-  __shared__ float s_z[BATCH];            // centre depth (opaque-surface test only)
+  __shared__ float4 s_rec[FWD_BATCH * 4];     // u v ca cb | cc o r g | b hx hy id | nx ny nz pd: the walk reads the first three
+  __shared__ float s_z[FWD_BATCH];            // centre depth (opaque-surface test only)
 
   const int tid = threadIdx.x;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
@@ -349,9 +353,9 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
   ActiveBox box;
   box.mask = 0ull; box.x0 = box.y0 = 0.f; box.x1 = box.y1 = -1.f;
 
-  for (int base = 0; base < n; base += BATCH) {
+  for (int base = 0; base < n; base += FWD_BATCH) {
     if (__syncthreads_and(done)) break;
-    const int m = min(BATCH, n - base);
+    const int m = min(FWD_BATCH, n - base);
     if (tid < m) {
       const uint32_t id = point_list[range.x + base + tid];
       const float4* src = reinterpret_cast<const float4*>(splats + id);
