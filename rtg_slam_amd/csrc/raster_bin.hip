@@ -44,7 +44,10 @@ struct LdsGrant {
 };
 
 constexpr int GPB = 1024;       // Gaussians per workgroup in bin_count / bin_scatter
-constexpr int SLICE_GPB = 32;   // ... when they walk the near slice's short work list: 8 Gaussians per wave (each covers
+#ifndef RTGS_SLICE_GPB
+#define RTGS_SLICE_GPB 32
+#endif
+constexpr int SLICE_GPB = RTGS_SLICE_GPB;   // ... when they walk the near slice's short work list: 8 Gaussians per wave (each covers
                                 // tens of tiles, the candidates are spread over all 64 lanes), many workgroups
 
 struct BinG {

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_kernel(
     }
     for (int q = tid; q < 4 * BATCH * NG; q += BLOCK)
       if ((q % (BATCH * NG)) < m * NG) s_grad[q] = 0.f;
-    s_dep[tid] = 0.f; s_dep[BLOCK + tid] = 0.f;
+    for (int q = tid; q < BATCH * 4; q += BLOCK) s_dep[q] = 0.f;
     __syncthreads();
 
     // Two entries per round: records, alphas and the two 8-value butterflies are independent instruction

@@ -10,7 +10,10 @@ namespace rtgs {
 constexpr int TILE = 16;
 constexpr int BLOCK = TILE * TILE;   // 256 threads = 4 wave64, each wave a 16x4 pixel strip
 constexpr int WAVE = 64;
-constexpr int BATCH = 128;           // tile-list entries staged through LDS per round (<= BLOCK)
+#ifndef RTGS_BWD_BATCH
+#define RTGS_BWD_BATCH 128
+#endif
+constexpr int BATCH = RTGS_BWD_BATCH;   // tile-list entries blend_bwd stages through LDS per round (<= BLOCK)
 
 // One 64-byte record per Gaussian: everything blend_fwd / blend_bwd need, so that a list
 // entry costs exactly one aligned 64-B gather.
