@@ -230,6 +230,15 @@ void rtgs_raster_force_sort_path(int enable);
 void rtgs_raster_force_sort_path_ctx(rtgs_ctx* ctx, int enable);
 int rtgs_raster_last_timings(float* ms12_host);
 int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms12_host);
+/* The backward's tile walk.  blend_fwd measures, per tile, how much of the tile's list each of its sixteen 4x4 pixel
+ * blocks needs, and leaves one word per tile in the image buffer: tiles whose blocks share the list (large footprints)
+ * take the tile-uniform strip walk, tiles whose blocks need less than 45 % of it on average (a surface map of small
+ * discs) the row-granular walk.  mode 0 = that per-tile choice (default), 1 = strip walk everywhere, 2 = row-granular
+ * walk everywhere (testing / A-B; RTGS_BWD_WALK at load time).  Gradients of the two walks agree to float rounding.
+ * rtgs_raster_image_offsets: byte offsets inside the image buffer - [0] tile ranges (uint2 per tile), [1] n_contrib
+ * (u32 per pixel), [2] BwdInfo, [3] tile walk (u32 per tile, 1 = row-granular), [4] total size. */
+void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* ctx, int mode);
+int rtgs_raster_image_offsets(int32_t image_height, int32_t image_width, size_t* out5_host);
 
 /* Fused Adam over a packed [rows, cols] float32 parameter shard with one learning rate per
  * column (the six Adam groups of SLAM/gaussian_pointcloud.py:245-284; torch.optim.Adam

@@ -242,6 +242,7 @@ def rasterize(s: OracleSettings, means3D, opacities, shs, scales, rotations, nor
     dw = torch.zeros(1, gy * TILE, gx * TILE, dtype=dt)
     Tmap = torch.ones(1, gy * TILE, gx * TILE, dtype=dt)
     aux = dict(num_rendered=0, consumed=0, evaluated_pairs=0, tile_terminated={})
+    n_blended = torch.zeros(gy * TILE, gx * TILE, dtype=torch.int32)     # entries each pixel blended (diagnostic)
 
     color_parts = {}
     depth_parts = {}
@@ -271,6 +272,7 @@ def rasterize(s: OracleSettings, means3D, opacities, shs, scales, rotations, nor
             d_id = torch.full((TILE * TILE,), -1, dtype=torch.int64)
             d_w = torch.zeros(TILE * TILE, dtype=dt)
             d_found = torch.zeros(TILE * TILE, dtype=torch.bool)
+            nb = torch.zeros(TILE * TILE, dtype=torch.int32)
 
             lo, hi = int(ranges[t, 0]), int(ranges[t, 1])
             pos = lo
@@ -300,6 +302,7 @@ def rasterize(s: OracleSettings, means3D, opacities, shs, scales, rotations, nor
                 contrib = ok & alive
                 wgt = torch.where(contrib, a_eff * T_before, torch.zeros_like(a_eff))
                 C = C + (wgt[:, :, None] * pre["rgb"][ids][:, None, :]).sum(0)
+                nb += contrib.sum(0).to(torch.int32)
 
                 # colour arg-max (first max wins)
                 wd = wgt.detach()
@@ -340,6 +343,7 @@ def rasterize(s: OracleSettings, means3D, opacities, shs, scales, rotations, nor
             cw[0, ys:ys + TILE, xs:xs + TILE] = best_w.detach().reshape(TILE, TILE)
             dw[0, ys:ys + TILE, xs:xs + TILE] = d_w.detach().reshape(TILE, TILE)
             Tmap[0, ys:ys + TILE, xs:xs + TILE] = T.detach().reshape(TILE, TILE)
+            n_blended[ys:ys + TILE, xs:xs + TILE] = nb.reshape(TILE, TILE)
 
     if color_parts:
         # assemble differentiably: one scatter of all rendered tiles
@@ -358,6 +362,7 @@ def rasterize(s: OracleSettings, means3D, opacities, shs, scales, rotations, nor
            didx[:, :H, :W].contiguous(), cw[:, :H, :W].contiguous(), dw[:, :H, :W].contiguous(),
            Tmap[:, :H, :W].contiguous())
     if return_aux:
+        aux["n_blended"] = n_blended[:H, :W].contiguous()
         return out, aux
     return out
 

@@ -18,10 +18,10 @@ void launch_emit_keys(const RasterParams&, const Splat*, const int32_t*, const u
                       uint32_t*, hipStream_t);
 void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
-                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, hipStream_t);
+                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, hipStream_t);
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
                       const uint32_t*, const int32_t*, const float*, const float*, const uint32_t*, uint32_t*,
-                      const BwdInfo*, SplatGrad*, uint8_t*, hipStream_t);
+                      const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, hipStream_t);
 void launch_grad_reduce(int, const uint8_t*, const uint32_t*, uint32_t*, const BwdInfo*, SplatGrad*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
@@ -65,6 +65,7 @@ struct rtgs_ctx {
   unsigned long long* counters = nullptr;
   bool prof = false;                // optional per-stage HIP-event timing (bench.py's roofline leg)
   bool force_sort_path = false;     // testing aid: take the global radix-sort binning path
+  int bwd_walk = 0;                 // 0 = blend_fwd chooses per tile; 1 = strip walk everywhere; 2 = row-granular walk everywhere
   bool ev_init = false;
   hipEvent_t ev[EV_N];
   bool ev_set[EV_N] = {false};
@@ -87,6 +88,7 @@ static rtgs_ctx* default_ctx() {
     rtgs_ctx* n = new rtgs_ctx();
     if (const char* e = getenv("RTGS_NEAR_SLICE")) n->slice_mode = atoi(e);
     if (const char* e = getenv("RTGS_NEAR_SLICE_BUDGET")) { const int b = atoi(e); if (b > 0) n->slice_budget = b; }
+    if (const char* e = getenv("RTGS_BWD_WALK")) { const int m = atoi(e); n->bwd_walk = (m == 1 || m == 2) ? m : 0; }
     return n;
   }();
   return c;
@@ -197,6 +199,7 @@ static ImgLayout img_layout(int H, int W, int ntiles) {
   L.ranges = off; off = align_up(off + (size_t)ntiles * sizeof(uint2));
   L.n_contrib = off; off = align_up(off + (size_t)H * W * sizeof(uint32_t));
   L.bwd_info = off; off = align_up(off + sizeof(BwdInfo));
+  L.tile_mode = off; off = align_up(off + (size_t)ntiles * sizeof(uint32_t));
   L.total = off;
   return L;
 }
@@ -250,7 +253,7 @@ const char* rtgs_version(void) { return "rtgs-hip 0.2.0 (gfx950)"; }
 
 rtgs_ctx* rtgs_ctx_create(void) {
   rtgs_ctx* c = new (std::nothrow) rtgs_ctx();
-  if (c) { c->slice_mode = default_ctx()->slice_mode; c->slice_budget = default_ctx()->slice_budget; }
+  if (c) { c->slice_mode = default_ctx()->slice_mode; c->slice_budget = default_ctx()->slice_budget; c->bwd_walk = default_ctx()->bwd_walk; }
   return c;
 }
 void rtgs_ctx_destroy(rtgs_ctx* c) {
@@ -316,6 +319,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   int32_t* sat = (int32_t*)(geom + G.sat);
   uint2* ranges = (uint2*)(img + I.ranges);
   uint32_t* n_contrib = (uint32_t*)(img + I.n_contrib);
+  uint32_t* const tile_mode = (flags & RTGS_FWD_NO_BACKWARD) ? nullptr : (uint32_t*)(img + I.tile_mode);
 
   int64_t R = 0, R1 = 0;
   for (int i = 0; i < EV_B0; ++i) c->ev_set[i] = false;
@@ -445,7 +449,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       if (++c->seq == 0u) c->seq = 1u;
       const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
       launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                       n_contrib, c->counters, pass1, st);
+                       n_contrib, c->counters, pass1, tile_mode, st);
       launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, st);
       DBG(s, st);
       prof_mark(c, EV_SL_BLEND, st);
@@ -557,7 +561,9 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   prof_mark(c, EV_BLEND0, st);
   if (!sliced || n_left > 0)     // pass 2 (or the only pass); with every tile finished by the slice there is nothing to draw
     launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                     n_contrib, c->counters, pass, st);
+                     n_contrib, c->counters, pass, tile_mode, st);
+  if (tile_mode && c->bwd_walk != 0)      // testing / A-B aid: one walk for every tile
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tile_mode, c->bwd_walk == 2 ? 1 : 0, (size_t)ntiles, st));
   prof_mark(c, EV_BLEND, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
@@ -607,6 +613,7 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
   const uint32_t* gbase = (const uint32_t*)(geom + G.offsets);
   const int32_t* radii = (const int32_t*)(geom + G.radii);
   uint32_t* slot_count = (uint32_t*)(geom + G.slot_count);      // scratch of the backward inside the geometry buffer
+  const uint32_t* tile_mode = (const uint32_t*)(img + I.tile_mode);   // per tile: which of the two walks (blend_fwd decided)
   if (R > 0) {
     // two-pass forward: tiles the near slice finished walk its lists (ranges1_bwd is all-empty otherwise, and a
     // workgroup with an empty range returns at once); every other tile walks the main lists
@@ -615,11 +622,11 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
     if (!hinted || c->hint_slice_lists)
       launch_blend_bwd(p, (const uint2*)(geom + G.ranges1_bwd), (const uint32_t*)(geom + G.list1),
                        (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
-                       dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, st);
+                       dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode, c->bwd_walk == 1 ? 1 : (c->bwd_walk == 2 ? 2 : 3), st);
     if (!hinted || c->hint_main_lists)
       launch_blend_bwd(p, (const uint2*)(img + I.ranges), (const uint32_t*)(bin + B.vals_b),
                        (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
-                       dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, st);
+                       dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode, c->bwd_walk == 1 ? 1 : (c->bwd_walk == 2 ? 2 : 3), st);
     prof_mark(c, EV_BWALK, st);
     // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
     launch_grad_reduce(P, touched, gbase, slot_count, binfo, grads, st);
@@ -672,6 +679,14 @@ int rtgs_raster_last_slice_stats_ctx(rtgs_ctx* c, int64_t* out) {
   return RTGS_OK;
 }
 void rtgs_raster_force_sort_path_ctx(rtgs_ctx* c, int enable) { use(c)->force_sort_path = enable != 0; }
+void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode == 1 || mode == 2) ? mode : 0; }
+int rtgs_raster_image_offsets(int32_t H, int32_t W, size_t* out) {
+  if (!out || H <= 0 || W <= 0) return RTGS_E_INVALID;
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const ImgLayout I = img_layout(H, W, gx * gy);
+  out[0] = I.ranges; out[1] = I.n_contrib; out[2] = I.bwd_info; out[3] = I.tile_mode; out[4] = I.total;
+  return RTGS_OK;
+}
 
 int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms) {
   rtgs_ctx* c = use(ctx);

@@ -21,7 +21,6 @@ namespace rtgs {
 // the walk reaches its owner's entry.  (Fallback when the slot space would be too large: one global
 // atomic per (tile, Gaussian, quantity).)
 // ---------------------------------------------------------------------------------------------
-constexpr int NG = 9;   // du dv dca dcb dcc dr dg db | dop
 
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 __device__ __forceinline__ float dpp_mov(float old, float v) {
@@ -102,15 +101,23 @@ __device__ __forceinline__ float group8_sum(float v) {   // every lane: sum over
   return v;
 }
 
-__global__ void __launch_bounds__(256, 6) blend_bwd_kernel(
+// ---------------------------------------------------------------------------------------------
+// Two walks, chosen PER TILE by blend_fwd (tile_mode, raster_common.h): tiles whose lists are shared by their 4x4
+// blocks (large footprints: every block needs nearly every entry) take the TILE-UNIFORM strip walk below - one entry
+// for all 64 lanes of a wave, 64-lane reductions, plain LDS stores; tiles whose blocks need a fraction of the list
+// (a surface map of small discs) take the ROW-GRANULAR walk further down.
+// ---------------------------------------------------------------------------------------------
+constexpr int NGS = 9;   // du dv dca dcb dcc dr dg db | dop
+
+__global__ void __launch_bounds__(256, 6) blend_bwd_strip_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, const float* __restrict__ out_color, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const int32_t* __restrict__ depth_index,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
-    SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched) {
+    SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode) {
   __shared__ float4 s_rec[BATCH * 3];           // u v ca cb | cc o r g | b hy id slot: three 16-B broadcast reads per entry
-  __shared__ float s_grad[4 * BATCH * NG];      // one private copy per wave: plain stores, no LDS atomics
+  __shared__ float s_grad[4 * BATCH * NGS];      // one private copy per wave: plain stores, no LDS atomics
   __shared__ float s_dep[BATCH * 4];            // depth-plane partials of the batch's entries (rare: LDS float adds)
 
   const int tid = threadIdx.x;
@@ -120,6 +127,7 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_kernel(
   const int py = blockIdx.y * TILE + (tid >> 4);
   const bool inside = px < p.W && py < p.H;
   const float pxf = (float)px, pyf = (float)py;
+  if ((tile_mode[tile] & 1u) != 0u) return;       // this tile's lists are block-sparse: blend_bwd_rows_kernel walks it
   const uint2 range = ranges[tile];
   const size_t pix = (size_t)py * p.W + px;
   const size_t HW = (size_t)p.H * p.W;
@@ -158,7 +166,7 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_kernel(
   float T = 1.f;
   const int gidx = (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) | (lane & 1);   // butterfly8's quantity of this lane
   const bool gstore = (lane & 0x32) == 0;            // the 8 lanes that hold the wave totals after fold_groups
-  float* const wgrad = s_grad + (tid >> 6) * BATCH * NG;
+  float* const wgrad = s_grad + (tid >> 6) * BATCH * NGS;
   const float strip_y0 = (float)(blockIdx.y * TILE + (tid >> 6) * 4), strip_y1 = strip_y0 + 3.f;
 
   // only entries below the tile's largest `last` were blended by any pixel: stage and zero no more than that
@@ -187,8 +195,8 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_kernel(
       const uint32_t slot0 = use_slots ? gbase[id] : 0u;       // first slot of the Gaussian's run
       s_rec[tid * 3 + 2] = make_float4(b, hy, __uint_as_float(id), __uint_as_float(slot0));
     }
-    for (int q = tid; q < 4 * BATCH * NG; q += BLOCK)
-      if ((q % (BATCH * NG)) < m * NG) s_grad[q] = 0.f;
+    for (int q = tid; q < 4 * BATCH * NGS; q += BLOCK)
+      if ((q % (BATCH * NGS)) < m * NGS) s_grad[q] = 0.f;
     for (int q = tid; q < BATCH * 4; q += BLOCK) s_dep[q] = 0.f;
     __syncthreads();
 
@@ -253,13 +261,13 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_kernel(
       // every (wave, entry, quantity) slot is written at most once per batch -> plain LDS stores
       if (vm0) {
         const float t8 = fold_groups(r8[0]);
-        if (gstore) wgrad[e[0] * NG + gidx] = t8;
-        if (lane == 0) wgrad[e[0] * NG + 8] = ro;
+        if (gstore) wgrad[e[0] * NGS + gidx] = t8;
+        if (lane == 0) wgrad[e[0] * NGS + 8] = ro;
       }
       if (vm1) {
         const float t8 = fold_groups(r8[1]);
-        if (gstore) wgrad[e[1] * NG + gidx] = t8;
-        if (lane == 1) wgrad[e[1] * NG + 8] = ro;
+        if (gstore) wgrad[e[1] * NGS + gidx] = t8;
+        if (lane == 1) wgrad[e[1] * NGS + 8] = ro;
       }
       // depth owners among this wave's pixels (each pixel owns at most one entry of the whole list: rare per round)
 #pragma unroll
@@ -278,16 +286,16 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_kernel(
     }
     __syncthreads();
     if (tid < m) {
-      float t[NG + 4];
+      float t[NGS + 4];
       bool any = false;
 #pragma unroll
-      for (int k = 0; k < NG; ++k) {
-        t[k] = (s_grad[tid * NG + k] + s_grad[(BATCH + tid) * NG + k]) +
-               (s_grad[(2 * BATCH + tid) * NG + k] + s_grad[(3 * BATCH + tid) * NG + k]);
+      for (int k = 0; k < NGS; ++k) {
+        t[k] = (s_grad[tid * NGS + k] + s_grad[(BATCH + tid) * NGS + k]) +
+               (s_grad[(2 * BATCH + tid) * NGS + k] + s_grad[(3 * BATCH + tid) * NGS + k]);
         any |= (t[k] != 0.f);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { t[NG + k] = s_dep[tid * 4 + k]; any |= (t[NG + k] != 0.f); }
+      for (int k = 0; k < 4; ++k) { t[NGS + k] = s_dep[tid * 4 + k]; any |= (t[NGS + k] != 0.f); }
       if (any) {
         // t[0..4] hold the moments sum(gdl dx), sum(gdl dy), sum(gdl dx^2), sum(gdl dx dy), sum(gdl dy^2) with
         // d = centre - pixel; d alpha / d(u, v, conic) of G = exp(-1/2 (ca dx^2 + cc dy^2) - cb dx dy):
@@ -307,6 +315,266 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_kernel(
           // SplatGrad order: du dv dca dcb | dcc dop dr dg | db dnx dny dnz | dpd - - -
           // next free slot of the run: at most one tile per rect tile asks, so the run (= rect area) cannot overflow
           const uint32_t slot = __float_as_uint(s_rec[tid * 3 + 2].w) + atomicAdd(&slot_count[gid], 1u);
+          float4* dst = reinterpret_cast<float4*>(slot_grads + slot);
+          dst[0] = make_float4(t[0], t[1], t[2], t[3]);
+          dst[1] = make_float4(t[4], t[8], t[5], t[6]);
+          dst[2] = make_float4(t[7], t[9], t[10], t[11]);
+          dst[3] = make_float4(t[12], 0.f, 0.f, 0.f);
+        } else {
+          float* dst = reinterpret_cast<float*>(grads + gid);
+          if (t[0] != 0.f) unsafeAtomicAdd(dst + 0, t[0]);
+          if (t[1] != 0.f) unsafeAtomicAdd(dst + 1, t[1]);
+          if (t[2] != 0.f) unsafeAtomicAdd(dst + 2, t[2]);
+          if (t[3] != 0.f) unsafeAtomicAdd(dst + 3, t[3]);
+          if (t[4] != 0.f) unsafeAtomicAdd(dst + 4, t[4]);
+          if (t[8] != 0.f) unsafeAtomicAdd(dst + 5, t[8]);
+          if (t[5] != 0.f) unsafeAtomicAdd(dst + 6, t[5]);
+          if (t[6] != 0.f) unsafeAtomicAdd(dst + 7, t[6]);
+          if (t[7] != 0.f) unsafeAtomicAdd(dst + 8, t[7]);
+          if (t[9] != 0.f) unsafeAtomicAdd(dst + 9, t[9]);
+          if (t[10] != 0.f) unsafeAtomicAdd(dst + 10, t[10]);
+          if (t[11] != 0.f) unsafeAtomicAdd(dst + 11, t[11]);
+          if (t[12] != 0.f) unsafeAtomicAdd(dst + 12, t[12]);
+        }
+      }
+    }
+  }
+}
+
+
+constexpr int NACC = 13;                 // per-entry accumulator: 5 moments, 3 colour, opacity | 4 depth-plane partials
+constexpr int ACC_STRIDE = 16;           // floats per accumulator row (one 64-B line: the address is a shift)
+constexpr int BWD_CHUNKS = BATCH / 32;   // 32-entry words of a block's sub-list
+#ifndef RTGS_BWD_U
+#define RTGS_BWD_U 1
+#endif
+constexpr int BU = RTGS_BWD_U;           // entries a row takes per pass (independent instruction streams; only T / S are sequential)
+
+// Row totals (16 lanes) of TWO values at once: after the first exchange a lane holds the pair sum of d[lane & 1]; the
+// remaining three steps only combine lanes of equal parity.  Every lane ends up with the row total of d[lane & 1].
+__device__ __forceinline__ float row_sum_pair(float d0, float d1, int lane) {
+  const bool odd = lane & 1;
+  float v = (odd ? d1 : d0) + dpp_mov<0xB1>(0.f, odd ? d0 : d1);                    // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_mov<0x4E>(0.f, v);                                                        // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_mov<0x124>(0.f, v);                                                       // row_ror:4
+  v += dpp_mov<0x128>(0.f, v);                                                       // row_ror:8
+  return v;
+}
+
+// ROW-GRANULAR walk (see blend_fwd): a wave owns an 8x8 quadrant of the tile, each DPP row of 16 lanes a 4x4 pixel
+// block that walks its own sub-list of the staged batch (bit masks built by the staging threads), BU entries per pass.
+// The per-entry partials are reduced inside the row with DPP only - the 3-step multi-value butterfly leaves 8
+// quantities on 8 lanes, one more quad step completes the 16-lane sum - and reach the entries' LDS accumulators with
+// ds_add_f32 (the 8 quantities of the pass's first entry ride on the lanes with (lane & 2) == 0, those of the second
+// on the others: one instruction; a second one carries the two opacity sums).  No cross-row step, no per-wave copies.
+__global__ void __launch_bounds__(256, 6) blend_bwd_rows_kernel(
+    RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const Splat* __restrict__ splats, const float* __restrict__ out_color, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const int32_t* __restrict__ depth_index,
+    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+    const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
+    SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode) {
+  __shared__ float4 s_rec[BATCH * 4];           // u v ca cb | cc o r g | b id slot - | - : one 64-B line per entry
+  __shared__ float s_acc[BATCH * ACC_STRIDE];   // per-entry partial sums of the tile (LDS float adds)
+  __shared__ uint32_t s_live[16][BWD_CHUNKS];   // per 4x4 block: the staged entries that reach it
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int tile = blockIdx.y * p.gx + blockIdx.x;
+  if ((tile_mode[tile] & 1u) == 0u) return;       // shared lists: blend_bwd_strip_kernel walks this tile
+  const int bx = ((wv & 1) << 1) | ((lane >> 4) & 1), by = (wv & 2) | (lane >> 5);
+  const int blk = by * 4 + bx;
+  const int px = blockIdx.x * TILE + bx * 4 + (lane & 3);
+  const int py = blockIdx.y * TILE + by * 4 + ((lane >> 2) & 3);
+  const int rsh = lane & 48;
+  const bool inside = px < p.W && py < p.H;
+  const float pxf = (float)px, pyf = (float)py;
+  const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
+  const uint2 range = ranges[tile];
+  const size_t pix = (size_t)py * p.W + px;
+  const size_t HW = (size_t)p.H * p.W;
+  const int n = (int)(range.y - range.x);
+  if (n == 0) return;      // nothing was blended here (or the tile belongs to the other pass of a two-pass forward)
+  const bool use_slots = info->use_slots != 0;
+  SplatGrad* const slot_grads = info->slot_grads;
+
+  const uint32_t last = inside ? n_contrib[pix] : 0u;
+  const float T_final = inside ? final_T[pix] : 0.f;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f, S0 = 0.f, S1 = 0.f, S2 = 0.f;
+  // opaque-surface depth: D = pd / (n_c . r); only the pixel's owner Gaussian receives it.  The four partials are
+  // computed up front and handed over when the walk reaches the owner's entry (it is one of this pixel's contributors).
+  int owner = -1;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (inside) {
+    g0 = dL_dcolor[pix]; g1 = dL_dcolor[HW + pix]; g2 = dL_dcolor[2 * HW + pix];
+    // colour behind the (not yet started) walk = everything the pixel accumulated, without background
+    S0 = out_color[pix] - T_final * p.bg[0];
+    S1 = out_color[HW + pix] - T_final * p.bg[1];
+    S2 = out_color[2 * HW + pix] - T_final * p.bg[2];
+    owner = depth_index[pix];
+    const float gD = owner >= 0 ? dL_ddepth[pix] : 0.f;
+    if (gD == 0.f) owner = -1;
+    if (owner >= 0) {
+      const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
+      const float pd = reinterpret_cast<const float*>(splats + owner)[12];
+      const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
+      const float den = r2.y * rx + r2.z * ry + r2.w;
+      const float iden = 1.f / den;
+      const float k = -gD * (pd * iden) * iden;
+      a0 = k * rx; a1 = k * ry; a2 = k; a3 = gD * iden;
+    }
+  }
+  const float bgT = T_final * (p.bg[0] * g0 + p.bg[1] * g1 + p.bg[2] * g2);
+  float T = 1.f;
+  const int gidx = (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) | (lane & 1);   // butterfly8's quantity of this lane
+  const bool second = (lane & 2) != 0;               // this lane carries the pass's second entry to LDS (BU == 2)
+
+  // a block walks no further than its last contributor; the tile stages no further than its largest
+  uint32_t row_last = last;
+  row_last = max(row_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)row_last, 0xB1, 0xf, 0xf, false));    // lane ^ 1
+  row_last = max(row_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)row_last, 0x4E, 0xf, 0xf, false));    // lane ^ 2
+  row_last = max(row_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)row_last, 0x124, 0xf, 0xf, false));   // row_ror:4
+  row_last = max(row_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)row_last, 0x128, 0xf, 0xf, false));   // row_ror:8
+  __shared__ unsigned int s_nmax;
+  if (tid == 0) s_nmax = 0;
+  __syncthreads();
+  {
+    unsigned int wl = row_last;
+    wl = max(wl, (unsigned int)__shfl_xor((int)wl, 16));
+    wl = max(wl, (unsigned int)__shfl_xor((int)wl, 32));
+    if (lane == 0) atomicMax(&s_nmax, wl);
+  }
+  __syncthreads();
+  const int nuse = min(n, (int)s_nmax);
+
+  for (int base = 0; base < nuse; base += BATCH) {
+    const int m = min(BATCH, nuse - base);
+    __syncthreads();                                   // previous batch fully flushed before its LDS is reused
+    if (wv < (BATCH + 63) / 64) {                      // the staging waves (wave-uniform: they ballot)
+      uint32_t reach = 0;
+      if (tid < m) {
+        const uint32_t id = point_list[range.x + base + tid];
+        const float4* src = reinterpret_cast<const float4*>(splats + id);
+        const float4 q0 = src[0];
+        s_rec[tid * 4 + 0] = q0;
+        s_rec[tid * 4 + 1] = src[1];
+        const float b = reinterpret_cast<const float*>(splats + id)[8];
+        const float2 hxy = reinterpret_cast<const float2*>(splats + id)[7];
+        const uint32_t slot0 = use_slots ? gbase[id] : 0u;       // first slot of the Gaussian's run
+        s_rec[tid * 4 + 2] = make_float4(b, __uint_as_float(id), __uint_as_float(slot0), 0.f);
+        reach = blocks_reached(q0.x, q0.y, hxy.x, hxy.y, tx0, ty0);
+      }
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64((reach >> b) & 1u);
+        if (lane == 0) { s_live[b][2 * wv] = (uint32_t)bal; s_live[b][2 * wv + 1] = (uint32_t)(bal >> 32); }
+      }
+    }
+    for (int q = tid; q < m * ACC_STRIDE; q += BLOCK) s_acc[q] = 0.f;
+    __syncthreads();
+
+    const int nch = (m + 31) >> 5;
+    int c = -1;
+    uint32_t cur = 0u;                               // row-uniform: the unread part of the current word of the sub-list
+    for (;;) {
+      int e[BU];
+      bool has[BU];
+#pragma unroll
+      for (int k = 0; k < BU; ++k) {
+        while (cur == 0u && c + 1 < nch) { ++c; cur = s_live[blk][c]; }
+        e[k] = (c << 5) + (cur != 0u ? __builtin_ctz(cur) : 0);
+        has[k] = cur != 0u && (uint32_t)(base + e[k]) < row_last;      // positions increase: past row_last the block is through
+        cur = has[k] ? (cur & (cur - 1u)) : 0u;
+        if (!has[k]) { e[k] = 0; c = nch; }
+      }
+      if (__builtin_amdgcn_ballot_w64(has[0]) == 0ull) break;
+      float4 r0[BU], r1[BU];
+      float2 r2[BU];
+      float dx[BU], dy[BU], G[BU], alpha[BU];
+      bool valid[BU];
+#pragma unroll
+      for (int k = 0; k < BU; ++k) {
+        r0[k] = s_rec[e[k] * 4 + 0];
+        r1[k] = s_rec[e[k] * 4 + 1];
+        r2[k] = *reinterpret_cast<const float2*>(&s_rec[e[k] * 4 + 2]);      // b id
+        dx[k] = r0[k].x - pxf; dy[k] = r0[k].y - pyf;
+        const float power = splat_power(r0[k].z, r0[k].w, r1[k].x, dx[k], dy[k]);
+        G[k] = splat_exp(fminf(power, 0.f));
+        alpha[k] = fminf(0.99f, r1[k].y * G[k]);
+        valid[k] = has[k] & ((uint32_t)(base + e[k]) < last) & !(power > 0.f) & !(alpha[k] < 1.f / 255.f);
+      }
+      unsigned long long vm[BU], vany = 0ull;
+#pragma unroll
+      for (int k = 0; k < BU; ++k) { vm[k] = __builtin_amdgcn_ballot_w64(valid[k]); vany |= vm[k]; }
+      if (vany == 0ull) continue;                                   // wave-uniform
+      float gda[BU], r8[BU];
+#pragma unroll
+      for (int k = 0; k < BU; ++k) {                               // sequential part: T and the colour behind
+        const float c0 = r1[k].z, c1 = r1[k].w, c2 = r2[k].x;
+        const float w = valid[k] ? alpha[k] * T : 0.f;
+        S0 -= c0 * w; S1 -= c1 * w; S2 -= c2 * w;                   // colour strictly behind this entry
+        const float oma = 1.f - alpha[k];
+        const float dL_dalpha = T * (c0 * g0 + c1 * g1 + c2 * g2) - (S0 * g0 + S1 * g1 + S2 * g2 + bgT) * __builtin_amdgcn_rcpf(oma);
+        T = valid[k] ? T * oma : T;
+        gda[k] = valid[k] ? G[k] * dL_dalpha : 0.f;                 // clamp of alpha is transparent in the backward (upstream 3DGS)
+        const float gdl = gda[k] * r1[k].y;
+        // moments of gdl over the pixels: the conic enters once per entry (in the flush), not once per pixel
+        float v[8];
+        v[0] = gdl * dx[k];
+        v[1] = gdl * dy[k];
+        v[2] = v[0] * dx[k];
+        v[3] = v[0] * dy[k];
+        v[4] = v[1] * dy[k];
+        v[5] = w * g0; v[6] = w * g1; v[7] = w * g2;
+        r8[k] = butterfly8(v, lane);                                // sums over the lane's 8-lane group
+        r8[k] += dpp_mov<0x4E>(0.f, r8[k]);                         // quad_perm [2,3,0,1]: the other group of the row
+      }
+      if constexpr (BU == 2) {
+        const float ro = row_sum_pair(gda[0], gda[1], lane);        // lane parity = entry
+        const bool rv0 = (uint32_t)((vm[0] >> rsh) & 0xffffull) != 0u, rv1 = (uint32_t)((vm[1] >> rsh) & 0xffffull) != 0u;
+        if (second ? rv1 : rv0) atomicAdd(&s_acc[(second ? e[1] : e[0]) * ACC_STRIDE + gidx], second ? r8[1] : r8[0]);
+        if ((lane & 14) == 0 && ((lane & 1) ? rv1 : rv0)) atomicAdd(&s_acc[((lane & 1) ? e[1] : e[0]) * ACC_STRIDE + 8], ro);
+      } else {
+        float ro = gda[0] + dpp_mov<0xB1>(0.f, gda[0]);
+        ro += dpp_mov<0x4E>(0.f, ro);
+        ro += dpp_mov<0x124>(0.f, ro);
+        ro += dpp_mov<0x128>(0.f, ro);
+        const bool rv0 = (uint32_t)((vm[0] >> rsh) & 0xffffull) != 0u;
+        if (rv0 && (!second || (lane & 15) == 2)) atomicAdd(&s_acc[e[0] * ACC_STRIDE + (second ? 8 : gidx)], second ? ro : r8[0]);
+      }
+      // depth owners (each pixel owns at most one entry of the whole list): straight to the accumulator
+#pragma unroll
+      for (int k = 0; k < BU; ++k)
+        if (has[k] && owner == (int)__float_as_uint(r2[k].y)) {
+          float* const acc = &s_acc[e[k] * ACC_STRIDE];
+          atomicAdd(acc + 9, a0); atomicAdd(acc + 10, a1); atomicAdd(acc + 11, a2); atomicAdd(acc + 12, a3);
+        }
+    }
+    __syncthreads();
+    if (tid < m) {
+      float t[NACC];
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) { t[k] = s_acc[tid * ACC_STRIDE + k]; any |= (t[k] != 0.f); }
+      if (any) {
+        // t[0..4] hold the moments sum(gdl dx), sum(gdl dy), sum(gdl dx^2), sum(gdl dx dy), sum(gdl dy^2) with
+        // d = centre - pixel; d alpha / d(u, v, conic) of G = exp(-1/2 (ca dx^2 + cc dy^2) - cb dx dy):
+        {
+          const float4 q0 = s_rec[tid * 4 + 0];            // u v ca cb
+          const float ccn = s_rec[tid * 4 + 1].x;          // cc
+          const float mx = t[0], my = t[1];
+          t[0] = -(q0.z * mx + q0.w * my);                 // du
+          t[1] = -(ccn * my + q0.w * mx);                  // dv
+          t[2] = -0.5f * t[2];                             // dca
+          t[3] = -t[3];                                    // dcb
+          t[4] = -0.5f * t[4];                             // dcc
+        }
+        const uint32_t gid = __float_as_uint(s_rec[tid * 4 + 2].y);
+        touched[gid] = 1;     // byte per Gaussian: grad_reduce / the row-state backward skip untouched Gaussians
+        if (use_slots) {
+          // SplatGrad order: du dv dca dcb | dcc dop dr dg | db dnx dny dnz | dpd - - -
+          // next free slot of the run: at most one tile per rect tile asks, so the run (= rect area) cannot overflow
+          const uint32_t slot = __float_as_uint(s_rec[tid * 4 + 2].z) + atomicAdd(&slot_count[gid], 1u);
           float4* dst = reinterpret_cast<float4*>(slot_grads + slot);
           dst[0] = make_float4(t[0], t[1], t[2], t[3]);
           dst[1] = make_float4(t[4], t[8], t[5], t[6]);
@@ -723,9 +991,15 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 void launch_blend_bwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                       const float* out_color, const float* final_T, const uint32_t* n_contrib,
                       const int32_t* depth_index, const float* dL_dcolor, const float* dL_ddepth, const uint32_t* gbase,
-                      uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched, hipStream_t st) {
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
-                     final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched);
+                      uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
+                      const uint32_t* tile_mode, int which, hipStream_t st) {
+  // which: bit 0 = tiles on the strip walk exist (or unknown), bit 1 = tiles on the row-granular walk exist (or unknown)
+  if (which & 1)
+    hipLaunchKernelGGL(blend_bwd_strip_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
+                       final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched, tile_mode);
+  if (which & 2)
+    hipLaunchKernelGGL(blend_bwd_rows_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
+                       final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched, tile_mode);
 }
 void launch_grad_reduce(int P, const uint8_t* touched, const uint32_t* gbase, uint32_t* count, const BwdInfo* info,
                         SplatGrad* grads, hipStream_t st) {

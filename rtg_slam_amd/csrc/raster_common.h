@@ -119,8 +119,15 @@ struct BinLayout {
   size_t slot_grads;                 // backward partial slots (see BwdInfo); 0 slots = not laid out
 };
 struct ImgLayout {
-  size_t ranges, n_contrib, bwd_info, total;
+  size_t ranges, n_contrib, bwd_info, tile_mode, total;
 };
+// blend_fwd leaves one word per tile for its backward: bit 0 set = the tile's 4x4 blocks each need only a fraction of
+// the tile's list (row-granular walk), clear = they share it (tile-uniform strip walk); bits 8.. hold the measured share
+// in 1/1000.  See raster_bwd.hip.
+#ifndef RTGS_ROWS_MAX_SHARE
+#define RTGS_ROWS_MAX_SHARE 0.6f
+#endif
+constexpr float ROWS_MAX_SHARE = RTGS_ROWS_MAX_SHARE;
 
 // What the backward needs to know about the forward that produced its buffers, left in the image buffer by the
 // forward (device memory: the backward never reads it on the host).
@@ -146,6 +153,20 @@ __device__ __forceinline__ void tile_rect_of(float u, float v, int radius, int g
   y0 = min(gy, max(0, (int)((v - r) / (float)TILE)));
   x1 = min(gx, max(0, (int)((u + r + (float)(TILE - 1)) / (float)TILE)));
   y1 = min(gy, max(0, (int)((v + r + (float)(TILE - 1)) / (float)TILE)));
+}
+
+// Row-granular tile walks (blend_fwd / blend_bwd): which of the 16 4x4 pixel blocks of a tile (bit b = block
+// (b & 3, b >> 2)) the alpha >= 1/255 bounding box of a splat reaches.  Pixel centres of block column i are
+// tx0 + 4 i .. tx0 + 4 i + 3.  ONE definition: the backward must evaluate every (entry, pixel) pair the forward blended.
+__device__ __forceinline__ uint32_t blocks_reached(float u, float v, float hx, float hy, float tx0, float ty0) {
+  uint32_t xm = 0, ym = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo_x = tx0 + 4.f * (float)i, lo_y = ty0 + 4.f * (float)i;
+    xm |= (!((u + hx < lo_x) | (u - hx > lo_x + 3.f))) ? (1u << i) : 0u;
+    ym |= (!((v + hy < lo_y) | (v - hy > lo_y + 3.f))) ? (0x000fu << (4 * i)) : 0u;
+  }
+  return (xm * 0x1111u) & ym;
 }
 
 // Pinned SH constants (utils/sh_utils.py:26-45 of the reference).

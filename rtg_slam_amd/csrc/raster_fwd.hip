@@ -288,56 +288,43 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint6
   if (i == R - 1) ranges[t].y = (uint32_t)R;
 }
 
-// Wave-uniform bounding box (float pixel coordinates) of the pixels of this wave that are still
-// walking.  Lane l of a wave is pixel (col = l & 15, row = l >> 4) of the wave's 16x4 strip, so the
-// box falls out of the 64-bit ballot with scalar bit operations; it is refreshed only when the
-// active set changes.  Entries whose alpha >= 1/255 region misses the box are skipped by the whole
-// wave - this is what keeps the walk of a few never-saturating pixels cheap.
-struct ActiveBox {
-  unsigned long long mask;
-  float x0, x1, y0, y1;
-};
-__device__ __forceinline__ void refresh_box(ActiveBox& b, unsigned long long m, int strip_px0, int strip_py0) {
-  b.mask = m;
-  const unsigned int cols = (unsigned int)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull);
-  const unsigned int rows = ((m & 0xffffull) ? 1u : 0u) | ((m & 0xffff0000ull) ? 2u : 0u) |
-                            ((m & 0xffff00000000ull) ? 4u : 0u) | ((m & 0xffff000000000000ull) ? 8u : 0u);
-  const int cx0 = __builtin_ctz(cols | 0x10000u), cx1 = 31 - __builtin_clz(cols | 1u);
-  const int ry0 = __builtin_ctz(rows | 0x10u), ry1 = 31 - __builtin_clz(rows | 1u);
-  b.x0 = (float)(strip_px0 + cx0); b.x1 = (float)(strip_px0 + cx1);
-  b.y0 = (float)(strip_py0 + ry0); b.y1 = (float)(strip_py0 + ry1);
-}
+// ---------------------------------------------------------------------------------------------
+// K6 blend_fwd: one workgroup (4 wave64) per 16x16 tile, list entries staged through LDS in batches of 256 records
+// (one 64-B gather per thread).  The walk is ROW-GRANULAR: a wave owns an 8x8 quadrant, each of its four DPP rows
+// (16 lanes) a 4x4 pixel block, and every row walks ITS OWN sub-list of the batch - the entries whose alpha >= 1/255
+// bounding box reaches its block.  The sub-lists are bit masks built at staging time (the staging thread holds the
+// record in registers and tests it against the 16 blocks of the tile; one ballot per block).  On a surface map of
+// ~12-pixel discs a block needs about a third of its tile's list, so a wave makes a third of the passes a
+// tile-uniform walk makes, and the lanes that evaluate an entry are mostly inside it (SQ counters, profiles/: the
+// tile-uniform walk was VALU-issue bound with 23 % of the lanes lit).  Pixels are independent in the forward, so
+// nothing crosses lanes; per pixel the entries still arrive in list order, hence bit-identical outputs.
+// ---------------------------------------------------------------------------------------------
+constexpr int FWD_BATCH = BLOCK;                // list entries staged through LDS per refill (one per thread)
+constexpr int FWD_CHUNKS = FWD_BATCH / 32;      // 32-entry words of a block's sub-list
 
-// ---------------------------------------------------------------------------------------------
-// K6 blend_fwd: one workgroup (4 wave64) per 16x16 tile; list entries staged through LDS in
-// batches of 256 records (one 64-B gather per thread), then every pixel walks the batch with
-// LDS broadcast reads.  Per-wave ballot ends a wave's walk as soon as its 64 pixels are done;
-// __syncthreads_and ends the tile.
-// ---------------------------------------------------------------------------------------------
-#ifndef RTGS_FWD_U
-#define RTGS_FWD_U 4
-#endif
-constexpr int FWD_U = RTGS_FWD_U;     // entries per round of the forward walk
-#ifndef RTGS_FWD_BATCH
-#define RTGS_FWD_BATCH 256
-#endif
-constexpr int FWD_BATCH = RTGS_FWD_BATCH;   // list entries staged through LDS per refill
 __global__ void __launch_bounds__(256) blend_fwd_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
     int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
     float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
-    unsigned long long* __restrict__ counters, SlicePass sp) {
-  __shared__ float4 s_rec[FWD_BATCH * 4];     // u v ca cb | cc o r g | b hx hy id | nx ny nz pd: the walk reads the first three
+    unsigned long long* __restrict__ counters, SlicePass sp, uint32_t* __restrict__ tile_mode) {
+  __shared__ float4 s_rec[FWD_BATCH * 4];     // u v ca cb | cc o r g | b - - id | nx ny nz pd: the walk reads the first three
   __shared__ float s_z[FWD_BATCH];            // centre depth (opaque-surface test only)
+  __shared__ uint32_t s_live[16][FWD_CHUNKS]; // per 4x4 block: the staged entries that reach it
 
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
   if (sp.mode == 2 && sp.mask2[tile] == 0) return;     // finished by the near slice (or masked off): outputs stay
-  const int px = blockIdx.x * TILE + (tid & 15);
-  const int py = blockIdx.y * TILE + (tid >> 4);
+  // wave = 8x8 quadrant, DPP row = 4x4 block, lane = pixel of the block
+  const int bx = ((wv & 1) << 1) | ((lane >> 4) & 1), by = (wv & 2) | (lane >> 5);
+  const int blk = by * 4 + bx;
+  const int px = blockIdx.x * TILE + bx * 4 + (lane & 3);
+  const int py = blockIdx.y * TILE + by * 4 + ((lane >> 2) & 3);
+  const int rsh = lane & 48;                            // first lane of this lane's row
   const bool inside = px < p.W && py < p.H;
   const float pxf = (float)px, pyf = (float)py;
+  const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
   const uint2 range = ranges[tile];
   int n = (int)(range.y - range.x);
   if (sp.mode == 1 && n > SLICE_MAX_LIST) n = 0;       // near-slice list too long to have been sorted: leave the tile to pass 2
@@ -346,99 +333,85 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   float best_w = 0.f; int best_id = -1;
   float D = 0.f, d_w = 0.f; int d_id = -1;
-  uint32_t contributor = 0, last_contributor = 0;
-  const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
-  const float rnorm = sqrtf(rx * rx + ry * ry + 1.f);
-  unsigned long long evals = 0;
-  ActiveBox box;
-  box.mask = 0ull; box.x0 = box.y0 = 0.f; box.x1 = box.y1 = -1.f;
+  uint32_t last_contributor = 0;
+  uint32_t evals = 0;
+  uint32_t reach_sum = 0, staged = 0;        // wave-uniform: (block, entry) pairs of the sub-lists / entries this wave staged
 
   for (int base = 0; base < n; base += FWD_BATCH) {
     if (__syncthreads_and(done)) break;
     const int m = min(FWD_BATCH, n - base);
-    if (tid < m) {
-      const uint32_t id = point_list[range.x + base + tid];
-      const float4* src = reinterpret_cast<const float4*>(splats + id);
-      s_rec[tid * 4 + 0] = src[0];
-      s_rec[tid * 4 + 1] = src[1];
-      const float4 q2 = src[2];               // b nx ny nz
-      const float4 q3 = src[3];               // pd z hx hy
-      s_rec[tid * 4 + 2] = make_float4(q2.x, q3.z, q3.w, __uint_as_float(id));
-      s_rec[tid * 4 + 3] = make_float4(q2.y, q2.z, q2.w, q3.x);
-      s_z[tid] = q3.y;
+    {
+      uint32_t reach = 0;
+      if (tid < m) {
+        const uint32_t id = point_list[range.x + base + tid];
+        const float4* src = reinterpret_cast<const float4*>(splats + id);
+        const float4 q0 = src[0];
+        s_rec[tid * 4 + 0] = q0;
+        s_rec[tid * 4 + 1] = src[1];
+        const float4 q2 = src[2];               // b nx ny nz
+        const float4 q3 = src[3];               // pd z hx hy
+        s_rec[tid * 4 + 2] = make_float4(q2.x, 0.f, 0.f, __uint_as_float(id));
+        s_rec[tid * 4 + 3] = make_float4(q2.y, q2.z, q2.w, q3.x);
+        s_z[tid] = q3.y;
+        reach = blocks_reached(q0.x, q0.y, q3.z, q3.w, tx0, ty0);
+      }
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64((reach >> b) & 1u);
+        if (lane == 0) { s_live[b][2 * wv] = (uint32_t)bal; s_live[b][2 * wv + 1] = (uint32_t)(bal >> 32); }
+        reach_sum += (uint32_t)__popcll(bal);
+      }
+      staged += (uint32_t)max(0, min(64, m - wv * 64));
     }
     __syncthreads();
-    // Four entries per round: their records are read and their alphas evaluated back to back (independent
-    // instruction streams, one LDS wait), only the T recurrence is sequential.  A single wave issues roughly
-    // one dependent instruction every 8-15 cycles, so the walk is bound by the length of the dependent chain
-    // per entry (measured: ~1 700 cycles per entry in the one-entry-at-a-time form) - not by ALU throughput.
-    for (int j = 0; j < m; j += FWD_U) {
+    const int nch = (m + 31) >> 5;
+    int c = -1;
+    uint32_t cur = 0u;                               // row-uniform: the unread part of the current word of the sub-list
+    for (;;) {
+      while (cur == 0u && c + 1 < nch) { ++c; cur = s_live[blk][c]; }
       const unsigned long long am = __builtin_amdgcn_ballot_w64(!done);
-      if (am == 0ull) break;                // whole wave finished
-      if (am != box.mask) refresh_box(box, am, blockIdx.x * TILE, blockIdx.y * TILE + (tid >> 6) * 4);
-      float4 r0[FWD_U], r1[FWD_U], r2[FWD_U];
-      float alpha[FWD_U];
-      bool live[FWD_U];
-      int e[FWD_U];
-#pragma unroll
-      for (int k = 0; k < FWD_U; ++k) {
-        e[k] = min(j + k, m - 1);           // past the end: re-read the last entry (finite data), masked out by live[]
-        r0[k] = s_rec[e[k] * 4 + 0];        // u v ca cb
-        r1[k] = s_rec[e[k] * 4 + 1];        // cc o r g
-        r2[k] = s_rec[e[k] * 4 + 2];        // b hx hy id
-        // wave-uniform: entry exists and its alpha >= 1/255 region reaches a pixel of this wave still walking
-        live[k] = (j + k < m) & !((r0[k].x + r2[k].y < box.x0) | (r0[k].x - r2[k].y > box.x1) | (r0[k].y + r2[k].z < box.y0) |
-                                  (r0[k].y - r2[k].z > box.y1));
-      }
-#pragma unroll
-      for (int k = 0; k < FWD_U; ++k) {
-        const float dx = r0[k].x - pxf, dy = r0[k].y - pyf;
-        const float power = splat_power(r0[k].z, r0[k].w, r1[k].x, dx, dy);
-        const float al = fminf(0.99f, r1[k].y * splat_exp(fminf(power, 0.f)));
-        alpha[k] = (live[k] && !(power > 0.f) && !(al < 1.f / 255.f)) ? al : 0.f;     // 0 = skipped
-      }
-      float w[FWD_U];
-      bool any_contrib = false;
-#pragma unroll
-      for (int k = 0; k < FWD_U; ++k) {         // the sequential part: transmittance recurrence and the stop rule
-        const bool ok = !done && alpha[k] > 0.f;
-        const float test_T = T * (1.f - alpha[k]);
-        const bool stop = ok && (test_T < p.T_thr);
-        const bool contrib = ok && !stop;
-        evals += (!done && live[k]) ? 1u : 0u;
-        done = done || stop;
-        w[k] = contrib ? alpha[k] * T : 0.f;
-        T = contrib ? test_T : T;
-        last_contributor = contrib ? (uint32_t)(base + j + k + 1) : last_contributor;
-        any_contrib = any_contrib || contrib;
-      }
-      if (__builtin_amdgcn_ballot_w64(any_contrib) == 0ull) continue;
-      bool want_depth = false;
-#pragma unroll
-      for (int k = 0; k < FWD_U; ++k) {
-        C0 += r1[k].z * w[k]; C1 += r1[k].w * w[k]; C2 += r2[k].x * w[k];
-        const bool better = w[k] > best_w;   // w == 0 for non-contributing lanes, best_w >= 0
-        const int gid = (int)__float_as_uint(r2[k].w);
-        best_w = better ? w[k] : best_w;
-        best_id = better ? gid : best_id;
-        want_depth = want_depth || (w[k] > 0.f && alpha[k] > p.opaque_thr);
-      }
-      if (__builtin_amdgcn_ballot_w64(want_depth && d_id < 0) != 0ull) {   // rare: opaque-surface depth candidates
-#pragma unroll
-        for (int k = 0; k < FWD_U; ++k) {
-          if (w[k] > 0.f && d_id < 0 && alpha[k] > p.opaque_thr) {
-            const float4 r3 = s_rec[e[k] * 4 + 3];  // nx ny nz pd
-            const float den = r3.x * rx + r3.y * ry + r3.z;
-            if (fabsf(den) / rnorm > p.normal_thr) {
-              const float zhit = r3.w / den;
-              if (zhit > 0.f && fabsf(zhit - s_z[e[k]]) < p.depth_thr) { D = zhit; d_w = alpha[k]; d_id = (int)__float_as_uint(r2[k].w); }
-            }
+      const bool row_alive = (uint32_t)((am >> rsh) & 0xffffull) != 0u;
+      const bool has = cur != 0u && row_alive;
+      if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;     // every row of the wave is through its sub-list (or finished)
+      const int e = has ? (c << 5) + __builtin_ctz(cur) : 0;
+      cur &= cur - 1u;
+      const float4 r0 = s_rec[e * 4 + 0];        // u v ca cb
+      const float4 r1 = s_rec[e * 4 + 1];        // cc o r g
+      const float4 r2 = s_rec[e * 4 + 2];        // b - - id
+      const float dx = r0.x - pxf, dy = r0.y - pyf;
+      const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
+      const float al = fminf(0.99f, r1.y * splat_exp(fminf(power, 0.f)));
+      const bool ok = has && !done && !(power > 0.f) && !(al < 1.f / 255.f);
+      const float test_T = T * (1.f - al);
+      const bool stop = ok && (test_T < p.T_thr);
+      const bool contrib = ok && !stop;
+      evals += (has && !done) ? 1u : 0u;
+      done = done || stop;
+      const float w = contrib ? al * T : 0.f;
+      T = contrib ? test_T : T;
+      last_contributor = contrib ? (uint32_t)(base + e + 1) : last_contributor;
+      if (__builtin_amdgcn_ballot_w64(contrib) == 0ull) continue;
+      C0 += r1.z * w; C1 += r1.w * w; C2 += r2.x * w;
+      const bool better = w > best_w;            // w == 0 for non-contributing lanes, best_w >= 0
+      const int gid = (int)__float_as_uint(r2.w);
+      best_w = better ? w : best_w;
+      best_id = better ? gid : best_id;
+      const bool want_depth = contrib && d_id < 0 && al > p.opaque_thr;
+      if (__builtin_amdgcn_ballot_w64(want_depth) != 0ull) {   // rare: opaque-surface depth candidates
+        if (want_depth) {
+          // the pixel's ray, recomputed here (a handful of times per pixel) rather than held in registers across the walk
+          const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
+          const float rnorm = sqrtf(rx * rx + ry * ry + 1.f);
+          const float4 r3 = s_rec[e * 4 + 3];    // nx ny nz pd
+          const float den = r3.x * rx + r3.y * ry + r3.z;
+          if (fabsf(den) / rnorm > p.normal_thr) {
+            const float zhit = r3.w / den;
+            if (zhit > 0.f && fabsf(zhit - s_z[e]) < p.depth_thr) { D = zhit; d_w = al; d_id = gid; }
           }
         }
       }
     }
   }
-  contributor = last_contributor;   // accounting only (entries this pixel needed)
 
   bool write_out = true;
   if (sp.mode == 1) {
@@ -469,6 +442,20 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     out_T[pix] = T;
     n_contrib[pix] = last_contributor;
   }
+  if (tile_mode) {
+    // which walk the tile's backward takes (raster_bwd.hip): row-granular when its 4x4 blocks need, on average, less than
+    // ROWS_MAX_SHARE of the entries staged - measured here on the sub-lists themselves, no heuristic about the scene
+    __shared__ uint32_t s_share[2];
+    if (tid == 0) { s_share[0] = 0u; s_share[1] = 0u; }
+    __syncthreads();
+    if (lane == 0) { atomicAdd(&s_share[0], reach_sum); atomicAdd(&s_share[1], staged); }
+    __syncthreads();
+    if (tid == 0) {
+      // bit 0 = the walk; bits 8.. = the measured share in 1/1000 (diagnostics)
+      const float share = s_share[1] ? (float)s_share[0] / (16.f * (float)s_share[1]) : 1.f;
+      tile_mode[tile] = (share < ROWS_MAX_SHARE ? 1u : 0u) | ((uint32_t)(share * 1000.f) << 8);
+    }
+  }
   if (counters) {
     // work accounting for the roofline: entries any pixel of this tile consumed, and
     // (entry, pixel) pairs evaluated
@@ -476,8 +463,8 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
     __shared__ unsigned long long s_ev;
     if (tid == 0) { s_max = 0; s_ev = 0; }
     __syncthreads();
-    atomicMax(&s_max, contributor);
-    atomicAdd(&s_ev, evals);
+    atomicMax(&s_max, last_contributor);
+    atomicAdd(&s_ev, (unsigned long long)evals);
     __syncthreads();
     // one slot pair per tile, plain stores (3 225 same-address atomics cost ~80 us - more than the kernel itself);
     // the second pass of a two-pass forward adds to what the first wrote for the tile
@@ -565,9 +552,9 @@ void launch_slice_publish(int ntiles, const int32_t* user_mask, const int32_t* m
 void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                       float* out_color, float* out_depth, int32_t* out_cidx, int32_t* out_didx, float* out_cw,
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
-                      SlicePass sp, hipStream_t st) {
+                      SlicePass sp, uint32_t* tile_mode, hipStream_t st) {
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
-                     out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp);
+                     out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp, tile_mode);
 }
 
 }  // namespace rtgs

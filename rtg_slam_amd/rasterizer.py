@@ -72,6 +72,10 @@ class RasterContext:
     def force_sort_path(self, enable: bool):
         _lib.load().rtgs_raster_force_sort_path_ctx(self.ptr, int(bool(enable)))
 
+    def set_bwd_walk(self, mode: int):
+        """0 = blend_fwd chooses the backward's walk per tile (default), 1 = strip walk, 2 = row-granular walk."""
+        _lib.load().rtgs_raster_set_bwd_walk_ctx(self.ptr, int(mode))
+
     def set_profiling(self, enable: bool):
         _lib.load().rtgs_raster_set_profiling_ctx(self.ptr, int(bool(enable)))
 
@@ -92,6 +96,19 @@ class RasterContext:
         out = (C.c_float * 12)()
         _lib.check(_lib.load().rtgs_raster_last_timings_ctx(self.ptr, out), "rtgs_raster_last_timings")
         return [float(v) for v in out]
+
+
+def image_buffer_views(img: torch.Tensor, H: int, W: int):
+    """Views into a forward's image buffer (tests / diagnostics; layout: rtgs_raster_image_offsets): tile ranges
+    int32[tiles, 2], n_contrib int32[H*W], the backward's walk per tile int32[tiles] (1 = row-granular) and the share of
+    the tile's list its 4x4 blocks need on average (what the choice is made from)."""
+    off = (C.c_size_t * 5)()
+    _lib.check(_lib.load().rtgs_raster_image_offsets(int(H), int(W), off), "rtgs_raster_image_offsets")
+    nt = ((H + 15) // 16) * ((W + 15) // 16)
+    view = lambda o, nbytes, dt: img[int(o):int(o) + nbytes].view(dt)
+    word = view(off[3], nt * 4, torch.int32)
+    return dict(ranges=view(off[0], nt * 8, torch.int32).view(nt, 2), n_contrib=view(off[1], H * W * 4, torch.int32),
+                tile_mode=word & 1, tile_share=(word >> 8).float() / 1000.0)
 
 
 _tls = threading.local()
