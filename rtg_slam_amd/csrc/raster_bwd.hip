@@ -457,12 +457,13 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_rows_kernel(
         const float4* src = reinterpret_cast<const float4*>(splats + id);
         const float4 q0 = src[0];
         s_rec[tid * 4 + 0] = q0;
-        s_rec[tid * 4 + 1] = src[1];
+        const float4 q1 = src[1];
+        s_rec[tid * 4 + 1] = q1;
         const float b = reinterpret_cast<const float*>(splats + id)[8];
         const float2 hxy = reinterpret_cast<const float2*>(splats + id)[7];
         const uint32_t slot0 = use_slots ? gbase[id] : 0u;       // first slot of the Gaussian's run
         s_rec[tid * 4 + 2] = make_float4(b, __uint_as_float(id), __uint_as_float(slot0), 0.f);
-        reach = blocks_reached(q0.x, q0.y, hxy.x, hxy.y, tx0, ty0);
+        reach = blocks_reached(q0.x, q0.y, hxy.x, hxy.y, q0.z, q0.w, q1.x, q1.y, tx0, ty0);
       }
 #pragma unroll
       for (int b = 0; b < 16; ++b) {

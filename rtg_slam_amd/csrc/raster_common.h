@@ -156,17 +156,46 @@ __device__ __forceinline__ void tile_rect_of(float u, float v, int radius, int g
 }
 
 // Row-granular tile walks (blend_fwd / blend_bwd): which of the 16 4x4 pixel blocks of a tile (bit b = block
-// (b & 3, b >> 2)) the alpha >= 1/255 bounding box of a splat reaches.  Pixel centres of block column i are
-// tx0 + 4 i .. tx0 + 4 i + 3.  ONE definition: the backward must evaluate every (entry, pixel) pair the forward blended.
-__device__ __forceinline__ uint32_t blocks_reached(float u, float v, float hx, float hy, float tx0, float ty0) {
+// (b & 3, b >> 2)) a splat can reach with alpha >= 1/255.  Pixel centres of block column i are tx0 + 4 i .. tx0 + 4 i + 3.
+// Two conservative tests, both must pass:
+//  * the bounding box of the alpha >= 1/255 ellipse (hx, hy of the Splat record: 1 % + 0.5 px margin);
+//  * the ellipse itself: q(d) = ca dx^2 + 2 cb dx dy + cc dy^2 <= tau = 2 ln(255 o) somewhere on the block.  q is convex,
+//    so its minimum over a rectangle that does not contain the centre sits on one of the two edges facing the centre:
+//    with (ex, ey) the rectangle's point nearest the centre per axis, the candidates are the minimum along the line
+//    dx = ex (dy = -cb ex / cc clamped to the rectangle) and along dy = ey.  1 % + 0.02 margin on tau covers the
+//    rounding of the blend's own power / exp evaluation.  On both bench scenes the ellipse test removes a quarter of
+//    the (block, entry) pairs the box test lets through (the blocks at the corners of the box).
+// ONE definition: the backward must evaluate every (entry, pixel) pair the forward blended.
+__device__ __forceinline__ uint32_t blocks_reached(float u, float v, float hx, float hy, float ca, float cb, float cc,
+                                                   float o, float tx0, float ty0) {
+  const float tau = 1.01f * fmaxf(2.f * __logf(255.f * fmaxf(o, 1e-12f)), 0.f) + 0.02f;
+  const float kc = -cb / cc, ka = -cb / ca, twob = 2.f * cb;
+  float ex[4], lox[4];
   uint32_t xm = 0, ym = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float lo_x = tx0 + 4.f * (float)i, lo_y = ty0 + 4.f * (float)i;
     xm |= (!((u + hx < lo_x) | (u - hx > lo_x + 3.f))) ? (1u << i) : 0u;
     ym |= (!((v + hy < lo_y) | (v - hy > lo_y + 3.f))) ? (0x000fu << (4 * i)) : 0u;
+    lox[i] = lo_x - u;
+    ex[i] = __builtin_amdgcn_fmed3f(0.f, lox[i], lox[i] + 3.f);      // nearest offset to the centre inside the block, per axis
   }
-  return (xm * 0x1111u) & ym;
+  uint32_t em = 0;
+#pragma unroll 1
+  for (int j = 0; j < 4; ++j) {                                       // not unrolled: the staging threads are short of registers
+    const float loy = ty0 + 4.f * (float)j - v;
+    const float ey = __builtin_amdgcn_fmed3f(0.f, loy, loy + 3.f);
+    const float dxu = ka * ey, cey2 = cc * ey * ey, tbey = twob * ey;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dy1 = __builtin_amdgcn_fmed3f(kc * ex[i], loy, loy + 3.f);
+      const float q1 = fmaf(dy1, fmaf(cc, dy1, twob * ex[i]), ca * ex[i] * ex[i]);
+      const float dx2 = __builtin_amdgcn_fmed3f(dxu, lox[i], lox[i] + 3.f);
+      const float q2 = fmaf(dx2, fmaf(ca, dx2, tbey), cey2);
+      em |= (fminf(q1, q2) <= tau) ? ((1u << i) << (4 * j)) : 0u;
+    }
+  }
+  return (xm * 0x1111u) & ym & em;
 }
 
 // Pinned SH constants (utils/sh_utils.py:26-45 of the reference).

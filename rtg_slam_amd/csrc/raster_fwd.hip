@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint6
 constexpr int FWD_BATCH = BLOCK;                // list entries staged through LDS per refill (one per thread)
 constexpr int FWD_CHUNKS = FWD_BATCH / 32;      // 32-entry words of a block's sub-list
 
-__global__ void __launch_bounds__(256) blend_fwd_kernel(
+__global__ void __launch_bounds__(256, 6) blend_fwd_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
     int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
@@ -347,13 +347,14 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(
         const float4* src = reinterpret_cast<const float4*>(splats + id);
         const float4 q0 = src[0];
         s_rec[tid * 4 + 0] = q0;
-        s_rec[tid * 4 + 1] = src[1];
+        const float4 q1 = src[1];
+        s_rec[tid * 4 + 1] = q1;
         const float4 q2 = src[2];               // b nx ny nz
         const float4 q3 = src[3];               // pd z hx hy
         s_rec[tid * 4 + 2] = make_float4(q2.x, 0.f, 0.f, __uint_as_float(id));
         s_rec[tid * 4 + 3] = make_float4(q2.y, q2.z, q2.w, q3.x);
         s_z[tid] = q3.y;
-        reach = blocks_reached(q0.x, q0.y, q3.z, q3.w, tx0, ty0);
+        reach = blocks_reached(q0.x, q0.y, q3.z, q3.w, q0.z, q0.w, q1.x, q1.y, tx0, ty0);
       }
 #pragma unroll
       for (int b = 0; b < 16; ++b) {
