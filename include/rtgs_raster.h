@@ -120,6 +120,22 @@ size_t rtgs_raster_backward_scratch_bytes(int32_t P);
 #define RTGS_FWD_NO_BACKWARD 1   /* no backward will follow: skip the backward's bookkeeping (a scan over the Gaussians and
                                     the gradient-slot allocation inside the binning buffer).  A backward called anyway
                                     is still correct - it falls back to global atomics. */
+#define RTGS_FWD_SPECULATE 2     /* Speculative sizing - NO host wait inside the call (upstream reads num_rendered back in
+                                    the middle of its forward; so does the plain call, through pinned memory).  The host
+                                    assumes this call looks like the last verified forward on the context (same pass
+                                    structure, instance / longest-list / gradient-slot totals within 12-25 % of the last
+                                    ones), sizes the binning buffer and picks the sort classes from that, and enqueues
+                                    everything.  The kernel that learns the real numbers checks them against those
+                                    capacities and raises a device word when they do not hold; every later kernel of the
+                                    forward AND of its backward that could overrun a buffer or change persistent state
+                                    returns at once on that word.  The caller MUST call rtgs_raster_forward_verify_ctx
+                                    before trusting any result or launching another forward on the context, pass
+                                    rtgs_raster_spec_fail_ptr_ctx() as the skip flag of whatever it runs on the
+                                    gradients (rtgs_map_tail_rows), and redo forward + consumers without this flag when
+                                    verify returns 1.  Ignored (plain call) when the context has no verified history for
+                                    this (P, H, W) or the pass structure is not one it can guess.  Used by
+                                    rtgs_slam_map_step; outputs and num_rendered of a verified call equal the plain
+                                    call's (num_rendered_host holds the last call's number until verify). */
 int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* settings, int32_t P, int32_t sh_coeffs,
                             const float* means3D, const float* opacities, const float* shs,
                             const float* scales, const float* rotations, const float* normal_w,
@@ -238,6 +254,16 @@ int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms12_host);
  * rtgs_raster_image_offsets: byte offsets inside the image buffer - [0] tile ranges (uint2 per tile), [1] n_contrib
  * (u32 per pixel), [2] BwdInfo, [3] tile walk (u32 per tile, 1 = row-granular), [4] total size. */
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* ctx, int mode);
+/* Speculative forward (RTGS_FWD_SPECULATE).  verify: 0 = the guessed sizes held (or nothing was pending), 1 = they did
+ * not - nothing persistent was changed, redo without the flag; < 0 = error.  It waits (spinning on pinned memory) only
+ * until the kernel that publishes the totals has run.  spec_fail_ptr: device word (non-zero = failed) while a
+ * speculative forward is pending, else NULL.  set_speculation 0 makes RTGS_FWD_SPECULATE a no-op on the context
+ * (RTGS_SPECULATE=0 at load time).  speculation_stats: [0] speculative forwards, [1] of which failed, [2] requests that
+ * could not speculate (no history / different shape). */
+int rtgs_raster_forward_verify_ctx(rtgs_ctx* ctx, int64_t* num_rendered_host);
+const uint32_t* rtgs_raster_spec_fail_ptr_ctx(rtgs_ctx* ctx);
+void rtgs_raster_set_speculation_ctx(rtgs_ctx* ctx, int enable);
+int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3_host);
 int rtgs_raster_image_offsets(int32_t image_height, int32_t image_width, size_t* out5_host);
 
 /* Fused Adam over a packed [rows, cols] float32 parameter shard with one learning rate per

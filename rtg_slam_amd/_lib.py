@@ -134,6 +134,10 @@ _SIGNATURES = {
     "rtgs_raster_set_profiling_ctx": (None, [_P, C.c_int]),
     "rtgs_raster_force_sort_path_ctx": (None, [_P, C.c_int]),
     "rtgs_raster_set_bwd_walk_ctx": (None, [_P, C.c_int]),
+    "rtgs_raster_forward_verify_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "rtgs_raster_spec_fail_ptr_ctx": (C.c_void_p, [_P]),
+    "rtgs_raster_set_speculation_ctx": (None, [_P, C.c_int]),
+    "rtgs_raster_speculation_stats_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "rtgs_raster_image_offsets": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "rtgs_raster_set_near_slice_ctx": (None, [_P, C.c_int, C.c_int]),
     "rtgs_raster_last_slice_stats_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),

@@ -6,8 +6,8 @@
 #include "../../include/rtgs_raster.h"
 
 // Everything up to and including the rasterizer backward: the gradient rows are in the arena, nothing is stepped yet.
-extern "C" int rtgs_slam_map_step_front_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* num_rendered_host,
-                                            void* stream) {
+static int map_step_front(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* num_rendered_host, int32_t fwd_flags,
+                          void* stream) {
   if (!a || !num_rendered_host || !a->settings) return RTGS_E_INVALID;
   const int32_t P = a->P, M = a->sh_coeffs;
   if (P <= 0 || M != 16 || a->step < 1) return RTGS_E_INVALID;
@@ -22,7 +22,7 @@ extern "C" int rtgs_slam_map_step_front_ctx(rtgs_ctx* ctx, const rtgs_map_step_a
                            a->tile_mask, a->out_color, a->out_depth, a->out_color_index, a->out_depth_index,
                            a->out_color_weight, a->out_depth_weight, a->out_T, a->out_radii, a->geom_resize,
                            a->geom_user, a->binning_resize, a->binning_user, a->image_resize, a->image_user,
-                           num_rendered_host, 0, stream);
+                           num_rendered_host, fwd_flags, stream);
   if (rc != RTGS_OK) return rc;
   void* geom = a->geom_resize(a->geom_user, 0);          // size 0 = "hand me the buffer of the last request"
   void* bin = a->binning_resize(a->binning_user, 0);
@@ -39,12 +39,20 @@ extern "C" int rtgs_slam_map_step_front_ctx(rtgs_ctx* ctx, const rtgs_map_step_a
   return rc;
 }
 
+extern "C" int rtgs_slam_map_step_front_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* num_rendered_host,
+                                            void* stream) {
+  return map_step_front(ctx, a, num_rendered_host, 0, stream);     // the caller runs the tail: nothing to guard it with
+}
+
 extern "C" int rtgs_slam_map_step_front(const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
   return rtgs_slam_map_step_front_ctx(nullptr, a, num_rendered_host, stream);
 }
 
-extern "C" int rtgs_slam_map_step_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
-  int rc = rtgs_slam_map_step_front_ctx(ctx, a, num_rendered_host, stream);
+// One pass over the step.  With `speculate` the forward does not wait for the host in the middle (RTGS_FWD_SPECULATE):
+// the whole iteration is enqueued back to back, the tail is guarded by the forward's device word, and the totals are
+// verified at the end - while the GPU is still busy with the backward.
+static int map_step_once(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* num_rendered_host, bool speculate, void* stream) {
+  int rc = map_step_front(ctx, a, num_rendered_host, speculate ? RTGS_FWD_SPECULATE : 0, stream);
   if (rc != RTGS_OK) return rc;
   const int32_t P = a->P;
   // activation backward (+ attach gradient) + Adam on the three block tensors (+ confidence increment), one launch;
@@ -53,8 +61,17 @@ extern "C" int rtgs_slam_map_step_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* a
   rc = rtgs_map_tail_rows(a->xyz, a->shs, a->raw8, a->d_opacity, a->d_scales, a->d_rotations, a->d_normal, a->d_xyz,
                           a->d_shs, a->d_raw8, a->row_state, a->m_xyz, a->v_xyz, a->m_shs, a->v_shs, a->m_raw8, a->v_raw8,
                           a->lr_xyz, a->lr_shs, a->lr_raw8, a->ever_xyz, a->ever_shs, a->ever_raw8, P, a->step, a->beta1,
-                          a->beta2, a->eps, a->attach, a->confidence, nullptr, &act, stream);
+                          a->beta2, a->eps, a->attach, a->confidence, rtgs_raster_spec_fail_ptr_ctx(ctx), &act, stream);
   return rc != 0 ? RTGS_E_HIP : RTGS_OK;
+}
+
+extern "C" int rtgs_slam_map_step_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {
+  int rc = map_step_once(ctx, a, num_rendered_host, true, stream);
+  const int v = rtgs_raster_forward_verify_ctx(ctx, num_rendered_host);      // no-op when the forward did not speculate
+  if (rc != RTGS_OK) return rc;
+  if (v < 0) return v;
+  if (v == 1) rc = map_step_once(ctx, a, num_rendered_host, false, stream);  // the guess did not hold: nothing was changed, redo
+  return rc;
 }
 
 extern "C" int rtgs_slam_map_step(const rtgs_map_step_args* a, int64_t* num_rendered_host, void* stream) {

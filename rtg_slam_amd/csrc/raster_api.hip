@@ -22,7 +22,7 @@ void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const 
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
                       const uint32_t*, const int32_t*, const float*, const float*, const uint32_t*, uint32_t*,
                       const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, hipStream_t);
-void launch_grad_reduce(int, const uint8_t*, const uint32_t*, uint32_t*, const BwdInfo*, SplatGrad*, hipStream_t);
+void launch_grad_reduce(int, const uint8_t*, const uint32_t*, uint32_t*, const BwdInfo*, SplatGrad*, const uint32_t*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
                            float*, float*, float*, float*, hipStream_t);
@@ -34,19 +34,19 @@ int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const in
                      SliceList, size_t, hipStream_t);
 size_t bin_slice_block_counts_bytes(int, size_t, int);
 size_t bin_list_block_counts_bytes(int, int);
-void launch_visible_compact(int, const uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, hipStream_t);
-void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, hipStream_t);
-void launch_slice_publish(int, const int32_t*, const int32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, hipStream_t);
+void launch_visible_compact(int, const uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, hipStream_t);
+void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, hipStream_t);
+void launch_slice_publish(int, const int32_t*, const int32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, hipStream_t);
 void launch_preprocess_cull(const RasterParams&, const float*, const float*, const float*, uint32_t*, int32_t*, int32_t*,
                             uint32_t*, int, uint8_t*, float2*, hipStream_t);
 void launch_preprocess_shade(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                              const float*, Splat*, int32_t*, uint8_t*, float2*, SliceList, SliceSel, size_t, hipStream_t);
 void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*,
-                         const uint32_t*, const uint32_t*, uint32_t, hipStream_t);
+                         const uint32_t*, const uint32_t*, uint32_t, SpecCaps, hipStream_t);
 void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const int32_t*, const uint16_t*, uint32_t*,
                         unsigned long long*, SliceSel, SliceList, size_t, hipStream_t);
 void launch_slice_hist(int, const uint8_t*, const uint32_t*, const int32_t*, uint32_t*, unsigned long long*, hipStream_t);
-void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*, uint32_t*, hipStream_t);
+void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*, uint32_t*, const uint32_t*, hipStream_t);
 
 }  // namespace rtgs
 
@@ -79,6 +79,27 @@ struct rtgs_ctx {
   // decision (one extra pinned-flag sync, ~10 us) before it launches the slice's kernels instead of launching them
   // blind over an empty work list (~50 us of empty launches on a surface map).
   bool ask_first = false;
+  // ---- speculative forward (RTGS_FWD_SPECULATE; see rtgs_raster.h) ----
+  // What the last verified forward on this context looked like: the shape the next speculative one assumes.
+  struct Plan {
+    bool valid = false;
+    int32_t P = 0, H = 0, W = 0;
+    int kind = -1;                  // 0 = single pass, 1 = near slice finished every tile, 2 = slice declined, single pass over the visible list
+    int slice_mode = 0, slice_budget = 0;
+    uint32_t R = 0, R1 = 0, longest = 0, slots = 0, n_fin = 0;
+  } plan;
+  struct Spec {
+    bool pending = false;           // a speculative forward awaits rtgs_raster_forward_verify
+    int kind = -1;
+    uint32_t seq = 0, capR = 0, capL = 0, capS = 0;
+    const void* geom = nullptr;     // geometry buffer of that forward (the backward guards itself only for this one)
+    const uint32_t* fail_dev = nullptr;
+    void* stream = nullptr;
+    int32_t ntiles = 0;
+    int64_t G_total = 0, B_total = 0, I_total = 0;
+  } spec;
+  bool speculation = true;
+  int64_t spec_stats[3] = {0, 0, 0};   // speculative forwards, failed ones, forwards that could not speculate
 };
 
 namespace rtgs {
@@ -88,6 +109,7 @@ static rtgs_ctx* default_ctx() {
     rtgs_ctx* n = new rtgs_ctx();
     if (const char* e = getenv("RTGS_NEAR_SLICE")) n->slice_mode = atoi(e);
     if (const char* e = getenv("RTGS_NEAR_SLICE_BUDGET")) { const int b = atoi(e); if (b > 0) n->slice_budget = b; }
+    if (const char* e = getenv("RTGS_SPECULATE")) n->speculation = atoi(e) != 0;
     if (const char* e = getenv("RTGS_BWD_WALK")) { const int m = atoi(e); n->bwd_walk = (m == 1 || m == 2) ? m : 0; }
     return n;
   }();
@@ -109,6 +131,36 @@ static int bits_for(uint32_t n) {   // bits needed to represent values in [0, n)
   int b = 0;
   while ((1ull << b) < (unsigned long long)n) ++b;
   return b < 1 ? 1 : b;
+}
+
+// The forward's host sync: spin on the pinned words a kernel publishes (raster_common.h: publish_to_host).  The payload is
+// accepted only when the sequence word AND the checksum over (sequence, payload) agree with what was read: whatever order
+// the device's writes become visible in, a torn view is re-read.  `pub` receives a consistent snapshot of the payload.
+static int wait_published_words(uint32_t* info_host, uint32_t seq, hipStream_t st, uint32_t (&pub)[7]) {
+  volatile uint32_t* h = info_host;
+  auto snapshot_ok = [&]() -> bool {
+    if (h[7] != seq) return false;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    uint32_t w[7];
+    for (int k = 0; k < 7; ++k) w[k] = h[k];
+    if (h[8] != host_checksum(seq, w)) return false;
+    for (int k = 0; k < 7; ++k) pub[k] = w[k];
+    return true;
+  };
+  for (long spin = 0; spin < 4000000L; ++spin) {
+    if (snapshot_ok()) return RTGS_OK;
+    __builtin_ia32_pause();
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) return RTGS_E_HIP;   // the kernel has certainly finished: everything is visible now
+  return snapshot_ok() ? RTGS_OK : RTGS_E_HIP;
+}
+
+// sort-class ceiling (launch_bin_tilesort) that covers lists of `longest` entries with a quarter of headroom
+static uint32_t sort_class_cap(uint32_t longest) {
+  const uint64_t want = (uint64_t)longest + longest / 4 + 16;
+  const uint32_t classes[5] = {256u, 1024u, 3072u, 8192u, 16384u};
+  for (uint32_t c : classes) if (want <= c) return c;
+  return 16384u;
 }
 
 __global__ void bwd_info_kernel(BwdInfo* dst, SplatGrad* slot_grads, uint32_t slots, uint32_t use_slots) {
@@ -221,6 +273,7 @@ static int make_params(const rtgs_raster_settings* s, int32_t P, int32_t M, Rast
   p.opaque_thr = s->opaque_threshold; p.depth_thr = s->depth_threshold; p.normal_thr = s->normal_threshold;
   p.color_sigma = s->color_sigma; p.T_thr = s->T_threshold;
   p.view = s->viewmatrix; p.campos = s->campos; p.bg = s->bg;
+  p.spec_fail = nullptr;
   return RTGS_OK;
 }
 
@@ -253,7 +306,7 @@ const char* rtgs_version(void) { return "rtgs-hip 0.2.0 (gfx950)"; }
 
 rtgs_ctx* rtgs_ctx_create(void) {
   rtgs_ctx* c = new (std::nothrow) rtgs_ctx();
-  if (c) { c->slice_mode = default_ctx()->slice_mode; c->slice_budget = default_ctx()->slice_budget; c->bwd_walk = default_ctx()->bwd_walk; }
+  if (c) { c->slice_mode = default_ctx()->slice_mode; c->slice_budget = default_ctx()->slice_budget; c->bwd_walk = default_ctx()->bwd_walk; c->speculation = default_ctx()->speculation; }
   return c;
 }
 void rtgs_ctx_destroy(rtgs_ctx* c) {
@@ -363,30 +416,137 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
     memset(c->info_host, 0, HOST_WORDS * sizeof(uint32_t));
   }
   uint32_t* const info_host = c->info_host;
-  // The payload is accepted only when the sequence word AND the checksum over (sequence, payload) agree with what was
-  // read: whatever order the device's writes become visible in, a torn view is re-read (raster_common.h: publish_to_host).
-  // `pub` receives a consistent snapshot of the seven payload words.
   uint32_t pub[7] = {0, 0, 0, 0, 0, 0, 0};
-  auto wait_published = [&](uint32_t seq) -> int {
-    volatile uint32_t* h = info_host;
-    auto snapshot_ok = [&]() -> bool {
-      if (h[7] != seq) return false;
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      uint32_t w[7];
-      for (int k = 0; k < 7; ++k) w[k] = h[k];
-      if (h[8] != host_checksum(seq, w)) return false;
-      for (int k = 0; k < 7; ++k) pub[k] = w[k];
-      return true;
-    };
-    for (long spin = 0; spin < 4000000L; ++spin) {
-      if (snapshot_ok()) return RTGS_OK;
-      __builtin_ia32_pause();
-    }
-    HIP_TRY(hipStreamSynchronize(st));           // the kernel has certainly finished: everything is visible now
-    return snapshot_ok() ? RTGS_OK : RTGS_E_HIP;
-  };
+  auto wait_published = [&](uint32_t seq) -> int { return wait_published_words(info_host, seq, st, pub); };
   const int32_t* mask_main = tile_mask;        // tile mask of the pass that ends in the host sync
   uint32_t n_left = 0, n_fin = 0;
+
+  // ------------------------------------------------------------------------------------------------------------------
+  // Speculative forward (RTGS_FWD_SPECULATE): no host wait inside the call.  The host assumes the call looks like the last
+  // verified one on this context - same kind of pass structure, instance / list / slot totals within a margin of the last
+  // ones - sizes the binning buffer and picks the sort classes from that, and enqueues EVERYTHING; the kernel that learns
+  // the real numbers (bin_tilescan, or slice_publish) checks them against the capacities and raises a device word if they
+  // do not hold, on which every later kernel that could overrun a buffer or touch persistent state returns at once.
+  // rtgs_raster_forward_verify reads the published numbers afterwards (the GPU is busy with the rest of the step by
+  // then) and tells the caller whether to redo the step without speculation.  Results are those of the plain call.
+  // ------------------------------------------------------------------------------------------------------------------
+  if (c->spec.pending) return RTGS_E_INVALID;          // the previous speculative forward was never verified
+  c->spec.geom = nullptr; c->spec.fail_dev = nullptr;
+  {
+    const rtgs_ctx::Plan& pl = c->plan;
+    const bool eligible = (flags & RTGS_FWD_SPECULATE) && c->speculation && want_bwd && P > 0 && !sort_path && !s->debug &&
+                          pl.valid && pl.P == P && pl.H == p.H && pl.W == p.W && pl.slice_mode == c->slice_mode &&
+                          pl.slice_budget == c->slice_budget && (pl.kind == 0 ? !sliced : (pl.kind == 1 || pl.kind == 2) && sliced);
+    const uint32_t capR = pl.R + pl.R / 8u + 8192u, capL = sort_class_cap(pl.longest), capS = pl.slots + pl.slots / 8u + 8192u;
+    if ((flags & RTGS_FWD_SPECULATE) && !(eligible && (pl.kind == 1 || capS <= SLOTS_MAX))) ++c->spec_stats[2];
+    if (eligible && (pl.kind == 1 || capS <= SLOTS_MAX)) {
+      uint32_t* const fail = slice_ctr + 6;            // inside the span every forward clears
+      const SliceSel sel1{1, zbin, slice_hist, (uint32_t)G.slice_cap, (uint32_t)G.slice_max_list, slice_ctr, nullptr, nullptr,
+                          slice_cover, (uint32_t)ntiles * (uint32_t)(TILE * TILE), slice_auto ? 1 : 0};
+      const SpecCaps nocaps{nullptr, 0u, 0u, 0u, nullptr};
+      if (++c->seq == 0u) c->seq = 1u;
+      size_t b_total = 0;
+      if (pl.kind == 1) {
+        // the near slice finished every tile last time: pass 1 only, the slot space is the slice's instance budget
+        launch_preprocess_cull(p, means3D, scales, rotations, tiles_touched, radii, out_radii, zero_words, zero_n, zbin,
+                               (float2*)(geom + G.uv), st);
+        prof_mark(c, EV_PRE, st);
+        launch_slice_hist(P, zbin, tiles_touched, radii, slice_hist, slice_cover, st);
+        launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, tiles_touched, offsets, slice_ctr + 4,
+                             nullptr, 0u, nullptr, st);
+        const SliceList work{(const uint32_t*)(geom + G.slice_ids), slice_ctr + 2};
+        launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
+                                (float2*)(geom + G.uv), work, sel1, G.slice_max_list, st);
+        if (launch_bin_count(p, splats, radii, tile_mask, tile_count1, (uint16_t*)(geom + G.block_counts1), sel1, work,
+                             G.slice_max_list, st) != 0)
+          return RTGS_E_HIP;
+        launch_bin_tilescan(ntiles, tile_count1, ranges1, (uint32_t*)(geom + G.cursor1), info + 2, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, 0u, nocaps, st);
+        launch_bin_scatter(p, splats, radii, tile_mask, (const uint16_t*)(geom + G.block_counts1),
+                           (uint32_t*)(geom + G.cursor1), (unsigned long long*)(geom + G.bucket1), sel1, work,
+                           G.slice_max_list, st);
+        launch_bin_tilesort(ntiles, (uint32_t)SLICE_MAX_LIST, ranges1, (const unsigned long long*)(geom + G.bucket1), list1,
+                            nullptr, st);
+        prof_mark(c, EV_SL_BIN, st);
+        const uint32_t sl = (uint32_t)G.slice_cap;
+        const bool use_sl = sl > 0 && sl <= SLOTS_MAX;
+        const BinLayout B = bin_layout(0, ntiles, false, use_sl ? (size_t)sl : 0);
+        char* bin = (char*)binning_resize(binning_user, B.total);
+        if (!bin) return RTGS_E_ALLOC;
+        b_total = B.total;
+        hipLaunchKernelGGL(bwd_info_kernel, dim3(1), dim3(1), 0, st, (BwdInfo*)(img + I.bwd_info),
+                           (SplatGrad*)(bin + B.slot_grads), use_sl ? sl : 0u, use_sl ? 1u : 0u);
+        const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
+        launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
+                         n_contrib, c->counters, pass1, tile_mode, st);
+        launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, fail, st);
+        prof_mark(c, EV_SL_BLEND, st);
+        prof_mark(c, EV_BLEND0, st); prof_mark(c, EV_BLEND, st);
+        c->hint_slice_lists = true; c->hint_main_lists = false;
+        c->slice_stats[0] = 1; c->slice_stats[1] = pl.R1; c->slice_stats[2] = pl.n_fin; c->slice_stats[3] = 0;
+      } else {
+        const BinLayout B = bin_layout((int64_t)capR, ntiles, false, (size_t)capS);
+        char* bin = (char*)binning_resize(binning_user, B.total);
+        if (!bin) return RTGS_E_ALLOC;
+        b_total = B.total;
+        RasterParams pg = p;                       // the guarded kernels' view of the parameters
+        pg.spec_fail = fail;
+        SliceList vl{nullptr, nullptr};
+        if (pl.kind == 2) {
+          // the kernels declined the slice last time: assume they do again, single pass over the visible list
+          launch_preprocess_cull(p, means3D, scales, rotations, tiles_touched, radii, out_radii, zero_words, zero_n, zbin,
+                                 (float2*)(geom + G.uv), st);
+          prof_mark(c, EV_PRE, st);
+          launch_slice_hist(P, zbin, tiles_touched, radii, slice_hist, slice_cover, st);
+          launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, tiles_touched, offsets, slice_ctr + 4,
+                               nullptr, 0u, fail, st);
+          vl = SliceList{(const uint32_t*)(geom + G.vis_ids), slice_ctr + 4};
+          launch_visible_compact(P, zbin, (uint32_t*)(geom + G.vis_ids), slice_ctr + 4, tiles_touched, offsets, slice_ctr + 5, fail, st);
+          launch_preprocess_shade(pg, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
+                                  (float2*)(geom + G.uv), vl, sel1, (size_t)P, st);
+        } else {
+          launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, nullptr, splats, tiles_touched, radii,
+                                clamped, out_radii, zero_words, zero_n, nullptr, st);
+          if ((rc = scan_all()) != RTGS_OK) return rc;
+          prof_mark(c, EV_PRE, st);
+        }
+        const SliceSel sel2{0, nullptr, nullptr, 0u, 0u, slice_ctr, nullptr, (const float2*)(geom + G.uv), nullptr, 0u, 0};
+        if (launch_bin_count(pg, splats, radii, tile_mask, tile_count, vl.ids ? (uint16_t*)(geom + G.block_counts_vis) : block_counts,
+                             sel2, vl, (size_t)P, st) != 0)
+          return RTGS_E_HIP;
+        const SpecCaps caps{fail, capR, capL, capS, pl.kind == 2 ? (const int32_t*)(slice_ctr + 3) : nullptr};
+        launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, info_host, nullptr, nullptr,
+                            vl.ids ? slice_ctr + 5 : offsets + (P - 1), vl.ids ? nullptr : tiles_touched + (P - 1), c->seq, caps, st);
+        prof_mark(c, EV_SCAN, st);
+        hipLaunchKernelGGL(bwd_info_kernel, dim3(1), dim3(1), 0, st, (BwdInfo*)(img + I.bwd_info),
+                           (SplatGrad*)(bin + B.slot_grads), capS, 1u);
+        prof_mark(c, EV_BIN0, st);
+        launch_bin_scatter(pg, splats, radii, tile_mask, vl.ids ? (const uint16_t*)(geom + G.block_counts_vis) : block_counts,
+                           cursor, (unsigned long long*)(bin + B.keys_a), sel2, vl, (size_t)P, st);
+        prof_mark(c, EV_EMIT, st);
+        launch_bin_tilesort(ntiles, capL, ranges, (const unsigned long long*)(bin + B.keys_a), (uint32_t*)(bin + B.vals_b), fail, st);
+        prof_mark(c, EV_SORT, st);
+        prof_mark(c, EV_BLEND0, st);
+        launch_blend_fwd(pg, ranges, (uint32_t*)(bin + B.vals_b), splats, out_color, out_depth, out_cidx, out_didx, out_cw,
+                         out_dw, out_T, n_contrib, c->counters, SlicePass{0, nullptr, nullptr, nullptr, nullptr}, tile_mode, st);
+        prof_mark(c, EV_BLEND, st);
+        c->hint_slice_lists = false; c->hint_main_lists = true;
+        c->slice_stats[0] = pl.kind == 2 ? 1 : 0; c->slice_stats[1] = 0; c->slice_stats[2] = 0;
+        c->slice_stats[3] = pl.kind == 2 ? (int64_t)ntiles : 0;
+      }
+      if (tile_mode && c->bwd_walk != 0)
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tile_mode, c->bwd_walk == 2 ? 1 : 0, (size_t)ntiles, st));
+      HIP_TRY(hipGetLastError());
+      c->hint_geom = geom;
+      c->spec.pending = true; c->spec.kind = pl.kind; c->spec.seq = c->seq; c->spec.capR = capR; c->spec.capL = capL;
+      c->spec.capS = capS; c->spec.geom = geom; c->spec.fail_dev = fail; c->spec.stream = stream; c->spec.ntiles = ntiles;
+      c->spec.G_total = (int64_t)G.total; c->spec.B_total = (int64_t)b_total; c->spec.I_total = (int64_t)I.total;
+      ++c->spec_stats[0];
+      *num_rendered_host = (int64_t)pl.R + (int64_t)pl.R1;      // the last verified call's; the exact number comes with verify
+      if (*num_rendered_host < 1) *num_rendered_host = 1;
+      return RTGS_OK;
+    }
+  }
   if (P == 0) HIP_TRY(hipMemsetAsync(zero_words, 0, (size_t)zero_n * sizeof(uint32_t), st));   // ranges1_bwd for the backward
   if (P > 0) {
     if (sort_path) {   // only the fallback path needs the 3-sigma-rect tile counts
@@ -414,7 +574,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       const bool ask = slice_auto && c->ask_first;
       if (ask && ++c->seq == 0u) c->seq = 1u;
       launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, tiles_touched, offsets, slice_ctr + 4,
-                           ask ? info_host : nullptr, c->seq, st);
+                           ask ? info_host : nullptr, c->seq, nullptr, st);
       if (ask) {
         if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
         declined = (int32_t)pub[6] < 0;
@@ -424,7 +584,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       // the kernels declined the slice and the host knows: shade every visible Gaussian and go on as a single pass
       // ... through a compact list of the visible ones (dense lanes in the shade / count / scatter kernels)
       vis = SliceList{(const uint32_t*)(geom + G.vis_ids), slice_ctr + 4};
-      launch_visible_compact(P, zbin, (uint32_t*)(geom + G.vis_ids), slice_ctr + 4, tiles_touched, offsets, slice_ctr + 5, st);
+      launch_visible_compact(P, zbin, (uint32_t*)(geom + G.vis_ids), slice_ctr + 4, tiles_touched, offsets, slice_ctr + 5, nullptr, st);
       launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
                               (float2*)(geom + G.uv), vis, sel1, (size_t)P, st);
       sliced = false;
@@ -438,19 +598,19 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                            G.slice_max_list, st) != 0)
         return RTGS_E_HIP;
       launch_bin_tilescan(ntiles, tile_count1, ranges1, (uint32_t*)(geom + G.cursor1), info + 2, nullptr, nullptr,
-                          nullptr, nullptr, nullptr, 0u, st);
+                          nullptr, nullptr, nullptr, 0u, SpecCaps{nullptr, 0u, 0u, 0u, nullptr}, st);
       launch_bin_scatter(p, splats, radii, tile_mask, (const uint16_t*)(geom + G.block_counts1),
                          (uint32_t*)(geom + G.cursor1), (unsigned long long*)(geom + G.bucket1), sel1, work,
                          G.slice_max_list, st);
       launch_bin_tilesort(ntiles, (uint32_t)SLICE_MAX_LIST, ranges1, (const unsigned long long*)(geom + G.bucket1), list1,
-                          st);
+                          nullptr, st);
       DBG(s, st);
       prof_mark(c, EV_SL_BIN, st);
       if (++c->seq == 0u) c->seq = 1u;
       const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
       launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
                        n_contrib, c->counters, pass1, tile_mode, st);
-      launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, st);
+      launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, nullptr, st);
       DBG(s, st);
       prof_mark(c, EV_SL_BLEND, st);
       // the forward's host sync: the last tile of the slice publishes how many tiles are left
@@ -486,7 +646,8 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, info_host, nullptr, nullptr,
                           // size of the gradient-slot space: the cursor visible_compact advanced, or the end of the full scan
                           want_bwd ? (vis.ids ? slice_ctr + 5 : offsets + (P - 1)) : nullptr,
-                          want_bwd && !vis.ids ? tiles_touched + (P - 1) : nullptr, c->seq, st);
+                          want_bwd && !vis.ids ? tiles_touched + (P - 1) : nullptr, c->seq,
+                          SpecCaps{nullptr, 0u, 0u, 0u, nullptr}, st);
       DBG(s, st);
       prof_mark(c, EV_SCAN, st);
       if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
@@ -541,7 +702,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                        vis, (size_t)P, st);
     DBG(s, st);
     prof_mark(c, EV_EMIT, st);
-    launch_bin_tilesort(ntiles, longest, ranges, (const unsigned long long*)keys_a, vals_b, st);
+    launch_bin_tilesort(ntiles, longest, ranges, (const unsigned long long*)keys_a, vals_b, nullptr, st);
     DBG(s, st);
     prof_mark(c, EV_SORT, st);
   } else if (R > 0) {
@@ -575,6 +736,14 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   if (slice_auto && (sliced || considered)) c->ask_first = considered || (R1 == 0 && n_fin == 0);
   // which of the two list sets the backward of THIS forward has to walk (host-side hint, keyed by the geometry buffer)
   c->hint_geom = geom; c->hint_slice_lists = sliced && n_fin > 0; c->hint_main_lists = R > 0;
+  {
+    // what a speculative forward on this context may assume next time (rtgs_raster_forward_verify keeps it current)
+    rtgs_ctx::Plan& pl = c->plan;
+    pl.kind = (sliced && n_left == 0) ? 1 : (considered ? 2 : (!sliced && !sort_path && P > 0 ? 0 : -1));
+    pl.valid = pl.kind >= 0 && want_bwd && R <= 0xffffffffll;
+    pl.P = P; pl.H = p.H; pl.W = p.W; pl.slice_mode = c->slice_mode; pl.slice_budget = c->slice_budget;
+    pl.R = (uint32_t)R; pl.R1 = (uint32_t)R1; pl.longest = longest; pl.slots = slots; pl.n_fin = n_fin;
+  }
   return RTGS_OK;
 }
 
@@ -591,6 +760,8 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
   int rc = make_params(s, P, M, p);
   if (rc != RTGS_OK) return rc;
   if (P == 0) return RTGS_OK;
+  // the backward of a speculative forward guards itself with that forward's device word (see rtgs_raster_forward_verify)
+  if (c->spec.geom == geom_buffer && c->spec.fail_dev) p.spec_fail = c->spec.fail_dev;
   if (!means3D || !opacities || !shs || !scales || !rotations || !normal_w || !geom_buffer || !binning_buffer ||
       !image_buffer || !out_color || !out_T || !out_didx || !dL_dcolor || !dL_ddepth || !dL_dmeans3D || !dL_dopacities || !dL_dshs ||
       !dL_dscales || !dL_drotations || !dL_dnormal_w || !grad_scratch || R < 0)
@@ -629,7 +800,7 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
                        dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode, c->bwd_walk == 1 ? 1 : (c->bwd_walk == 2 ? 2 : 3), st);
     prof_mark(c, EV_BWALK, st);
     // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
-    launch_grad_reduce(P, touched, gbase, slot_count, binfo, grads, st);
+    launch_grad_reduce(P, touched, gbase, slot_count, binfo, grads, p.spec_fail, st);
     DBG(s, st);
   }
   prof_mark(c, EV_BBLEND, st);
@@ -679,6 +850,41 @@ int rtgs_raster_last_slice_stats_ctx(rtgs_ctx* c, int64_t* out) {
   return RTGS_OK;
 }
 void rtgs_raster_force_sort_path_ctx(rtgs_ctx* c, int enable) { use(c)->force_sort_path = enable != 0; }
+int rtgs_raster_forward_verify_ctx(rtgs_ctx* ctx, int64_t* num_rendered_host) {
+  rtgs_ctx* c = use(ctx);
+  if (!c->spec.pending) return 0;
+  c->spec.pending = false;
+  uint32_t pub[7] = {0, 0, 0, 0, 0, 0, 0};
+  const int rc = wait_published_words(c->info_host, c->spec.seq, (hipStream_t)c->spec.stream, pub);
+  if (rc != RTGS_OK) { c->plan.valid = false; return rc; }
+  rtgs_ctx::Plan& pl = c->plan;
+  bool ok;
+  if (c->spec.kind == 1) {
+    const uint32_t n_left = pub[2];
+    ok = n_left == 0u;
+    pl.R1 = pub[4]; pl.n_fin = pub[3]; pl.R = 0; pl.longest = 0;
+    c->slice_stats[1] = pub[4]; c->slice_stats[2] = pub[3]; c->slice_stats[3] = n_left;
+  } else {
+    ok = pub[0] <= c->spec.capR && pub[1] <= c->spec.capL && pub[5] <= c->spec.capS && (c->spec.kind != 2 || (int32_t)pub[6] < 0);
+    pl.R = pub[0]; pl.longest = pub[1]; pl.slots = pub[5]; pl.R1 = 0;
+  }
+  c->stats[0] = (int64_t)pl.R + (int64_t)pl.R1; c->stats[1] = 32 + bits_for((uint32_t)c->spec.ntiles); c->stats[2] = c->spec.ntiles;
+  c->stats[3] = c->spec.G_total; c->stats[4] = c->spec.B_total; c->stats[5] = c->spec.I_total; c->stats[6] = 1;
+  c->stats[7] = (int64_t)pl.longest;
+  if (num_rendered_host) *num_rendered_host = c->stats[0] > 0 ? c->stats[0] : 1;
+  if (!ok) { pl.valid = false; ++c->spec_stats[1]; }
+  return ok ? 0 : 1;
+}
+const uint32_t* rtgs_raster_spec_fail_ptr_ctx(rtgs_ctx* ctx) {
+  rtgs_ctx* c = use(ctx);
+  return c->spec.pending ? c->spec.fail_dev : nullptr;
+}
+void rtgs_raster_set_speculation_ctx(rtgs_ctx* ctx, int enable) { use(ctx)->speculation = enable != 0; }
+int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
+  if (!out3) return RTGS_E_INVALID;
+  memcpy(out3, use(ctx)->spec_stats, sizeof(use(ctx)->spec_stats));
+  return RTGS_OK;
+}
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode == 1 || mode == 2) ? mode : 0; }
 int rtgs_raster_image_offsets(int32_t H, int32_t W, size_t* out) {
   if (!out || H <= 0 || W <= 0) return RTGS_E_INVALID;

@@ -206,6 +206,7 @@ __global__ void __launch_bounds__(256) bin_count_kernel(RasterParams p, const Sp
   extern __shared__ uint32_t s_cnt[];
   __shared__ WaveBin s_wb[BLOCK / 64];
   const int ntiles = p.gx * p.gy;
+  if (spec_failed(p.spec_fail)) return;              // speculative forward already known to be wrong: its lists are not valid
   if (sel.mode == 2 && sel.ctr[0] == 0u) return;     // the near slice finished every tile: nothing left to bin
   if (list.ids && blockIdx.x * gpb >= (int)*list.count) return;     // past the end of the slice work list
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
@@ -230,7 +231,8 @@ __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const ui
                                                             const uint32_t* __restrict__ extra_src,
                                                             const uint32_t* __restrict__ extra_src2,
                                                             const uint32_t* __restrict__ slot_a,
-                                                            const uint32_t* __restrict__ slot_b, uint32_t seq) {
+                                                            const uint32_t* __restrict__ slot_b, uint32_t seq,
+                                                            SpecCaps caps) {
   __shared__ uint32_t s_sum[1024];
   __shared__ uint32_t s_max[1024];
   const int tid = threadIdx.x;
@@ -256,11 +258,16 @@ __global__ void __launch_bounds__(1024) bin_tilescan_kernel(int ntiles, const ui
   }
   if (tid == 1023) {
     info[0] = s_sum[1023]; info[1] = s_max[1023];
+    const uint32_t slots_total = (slot_a ? slot_a[0] : 0u) + (slot_b ? slot_b[0] : 0u);
+    const int32_t cut = caps.cut ? *caps.cut : 0;
+    if (caps.fail)      // speculative forward: do the sizes the host guessed hold?  (and, if it assumed so, was the slice declined?)
+      *caps.fail = (*caps.fail != 0u || s_sum[1023] > caps.R || s_max[1023] > caps.longest || slots_total > caps.slots ||
+                    (caps.cut && cut >= 0)) ? 1u : 0u;
     if (info_host) {   // pinned host words the forward's one host sync reads: no device-to-host copy launch in between
       const uint32_t w[7] = {s_sum[1023], s_max[1023], extra_src ? extra_src[0] : 0u, extra_src ? extra_src[1] : 0u,   // near-slice tile counters
                              extra_src2 ? extra_src2[0] : 0u,                                                  // near-slice instance total
                              // size of the backward's gradient-slot space: last exclusive-scan value + last rect area
-                             (slot_a ? slot_a[0] : 0u) + (slot_b ? slot_b[0] : 0u), 0u};
+                             slots_total, (uint32_t)cut};
       // publish: the host spins on the sequence word instead of paying a blocking stream sync's wake-up latency
       publish_to_host(info_host, w, seq);
     }
@@ -281,6 +288,7 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(RasterParams p, const 
   extern __shared__ uint32_t s_mem[];
   __shared__ WaveBin s_wb[BLOCK / 64];
   const int ntiles = p.gx * p.gy;
+  if (spec_failed(p.spec_fail)) return;            // the bucket array was sized by a guess that did not hold
   if (list.ids && blockIdx.x * gpb >= (int)*list.count) return;
   uint32_t* s_cnt = s_mem;
   uint32_t* s_base = s_mem + ntiles;
@@ -307,8 +315,10 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(RasterParams p, const 
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) bin_tilesort_kernel(const uint2* __restrict__ ranges,
                                                                const unsigned long long* __restrict__ bucket,
-                                                               uint32_t* __restrict__ point_list, int lo, int hi) {
+                                                               uint32_t* __restrict__ point_list, int lo, int hi,
+                                                               const uint32_t* __restrict__ spec_fail) {
   extern __shared__ unsigned long long s_key[];
+  if (spec_failed(spec_fail)) return;
   const uint2 r = ranges[blockIdx.x];
   const int n = (int)(r.y - r.x);
   if (n < lo || n >= hi) return;
@@ -343,7 +353,7 @@ template <int THREADS>
 __global__ void __launch_bounds__(THREADS) bin_tilesort_radix_kernel(const uint2* __restrict__ ranges,
                                                                      const unsigned long long* __restrict__ bucket,
                                                                      uint32_t* __restrict__ point_list, int lo, int hi,
-                                                                     int cap) {
+                                                                     int cap, const uint32_t* __restrict__ spec_fail) {
   constexpr int NW = THREADS / 64;
   extern __shared__ unsigned long long s_dyn[];
   unsigned long long* kA = s_dyn;
@@ -351,6 +361,7 @@ __global__ void __launch_bounds__(THREADS) bin_tilesort_radix_kernel(const uint2
   uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_dyn + 2 * cap);      // [NW][256]
   uint32_t* s_tot = s_cnt + NW * 256;                                   // [256]
   __shared__ uint32_t s_or;
+  if (spec_failed(spec_fail)) return;
   const uint2 r = ranges[blockIdx.x];
   const int n = (int)(r.y - r.x);
   if (n < lo || n >= hi) return;
@@ -532,12 +543,16 @@ __global__ void __launch_bounds__(256) slice_compact_kernel(int P, SliceSel sel,
                                                             uint32_t* __restrict__ n_list,
                                                             const uint32_t* __restrict__ rect_area,
                                                             uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_cursor,
-                                                            uint32_t* __restrict__ host, uint32_t seq) {
+                                                            uint32_t* __restrict__ host, uint32_t seq,
+                                                            uint32_t* __restrict__ fail_if_taken) {
   __shared__ uint32_t s_ids[COMPACT_CHUNK];
   __shared__ uint32_t s_n, s_base, s_tot, s_gb, s_run, s_w[4];
   const int cut = slice_cut(sel);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     reinterpret_cast<int32_t*>(n_list)[1] = cut;   // slice_ctr[3]
+    // speculative forward that assumed "declined": raise the word NOW - the kernels the host already queued for the
+    // declined single pass (visible_compact, shade, bin_count) share counter words with the slice and must not run
+    if (fail_if_taken && cut >= 0) *fail_if_taken = 1u;
     if (host) {   // the host asked to hear the decision before it launches the slice's kernels (raster_api.hip)
       const uint32_t w[7] = {0u, 0u, 0u, 0u, 0u, 0u, (uint32_t)cut};
       publish_to_host(host, w, seq);
@@ -600,10 +615,10 @@ __global__ void __launch_bounds__(256) slice_compact_kernel(int P, SliceSel sel,
   }
 }
 void launch_slice_compact(int P, SliceSel sel, uint32_t* ids, uint32_t* n_list, const uint32_t* rect_area, uint32_t* gbase,
-                          uint32_t* slot_cursor, uint32_t* host, uint32_t seq, hipStream_t st) {
+                          uint32_t* slot_cursor, uint32_t* host, uint32_t seq, uint32_t* fail_if_taken, hipStream_t st) {
   if (P == 0) return;
   hipLaunchKernelGGL(slice_compact_kernel, dim3((P + COMPACT_CHUNK - 1) / COMPACT_CHUNK), dim3(256), 0, st, P, sel, ids,
-                     n_list, rect_area, gbase, slot_cursor, host, seq);
+                     n_list, rect_area, gbase, slot_cursor, host, seq, fail_if_taken);
 }
 
 // Every visible Gaussian (zbin != 255), compacted into a work list: when the near slice is declined and the host knows
@@ -613,8 +628,10 @@ constexpr int VIS_CHUNK = 8192;      // ids per workgroup: few workgroups - each
 __global__ void __launch_bounds__(256) visible_compact_kernel(int P, const uint8_t* __restrict__ zbin, uint32_t* __restrict__ ids,
                                                               uint32_t* __restrict__ n_list,
                                                               const uint32_t* __restrict__ rect_area,
-                                                              uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_cursor) {
+                                                              uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_cursor,
+                                                              const uint32_t* __restrict__ spec_fail) {
   __shared__ uint32_t s_ids[VIS_CHUNK];
+  if (spec_failed(spec_fail)) return;
   __shared__ uint32_t s_n, s_base, s_tot, s_gb, s_run, s_w[4];
   if (threadIdx.x == 0) { s_n = 0; s_tot = 0; s_run = 0; }
   __syncthreads();
@@ -677,10 +694,10 @@ __global__ void __launch_bounds__(256) visible_compact_kernel(int P, const uint8
   }
 }
 void launch_visible_compact(int P, const uint8_t* zbin, uint32_t* ids, uint32_t* n_list, const uint32_t* rect_area,
-                            uint32_t* gbase, uint32_t* slot_cursor, hipStream_t st) {
+                            uint32_t* gbase, uint32_t* slot_cursor, const uint32_t* spec_fail, hipStream_t st) {
   if (P == 0) return;
   hipLaunchKernelGGL(visible_compact_kernel, dim3((P + VIS_CHUNK - 1) / VIS_CHUNK), dim3(256), 0, st, P, zbin, ids, n_list,
-                     rect_area, gbase, slot_cursor);
+                     rect_area, gbase, slot_cursor, spec_fail);
 }
 
 int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
@@ -699,9 +716,9 @@ int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* 
 }
 void launch_bin_tilescan(int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* cursor, uint32_t* info,
                          uint32_t* info_host, const uint32_t* extra_src, const uint32_t* extra_src2,
-                         const uint32_t* slot_a, const uint32_t* slot_b, uint32_t seq, hipStream_t st) {
+                         const uint32_t* slot_a, const uint32_t* slot_b, uint32_t seq, SpecCaps caps, hipStream_t st) {
   hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(1024), 0, st, ntiles, tile_count, ranges, cursor, info,
-                     info_host, extra_src, extra_src2, slot_a, slot_b, seq);
+                     info_host, extra_src, extra_src2, slot_a, slot_b, seq, caps);
 }
 void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
                         const uint16_t* block_counts, uint32_t* cursor, unsigned long long* bucket, SliceSel sel,
@@ -718,28 +735,28 @@ void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_
 }
 template <int THREADS>
 static void launch_radix(int ntiles, const uint2* ranges, const unsigned long long* bucket, uint32_t* point_list, int lo,
-                         int hi, int cap, hipStream_t st) {
+                         int hi, int cap, const uint32_t* spec_fail, hipStream_t st) {
   const size_t lds = (size_t)cap * 16 + (size_t)(THREADS / 64 + 1) * 256 * sizeof(uint32_t);
   static LdsGrant grant(48 * 1024);            // one static per THREADS instantiation
   grant.ensure((const void*)bin_tilesort_radix_kernel<THREADS>, lds);
   hipLaunchKernelGGL(bin_tilesort_radix_kernel<THREADS>, dim3(ntiles), dim3(THREADS), lds, st, ranges, bucket, point_list,
-                     lo, hi, cap);
+                     lo, hi, cap, spec_fail);
 }
 
 void launch_bin_tilesort(int ntiles, uint32_t longest, const uint2* ranges, const unsigned long long* bucket,
-                         uint32_t* point_list, hipStream_t st) {
+                         uint32_t* point_list, const uint32_t* spec_fail, hipStream_t st) {
   // size classes by list length; every class runs with the LDS footprint its lists need:
   //   (0,256]  bitonic, 128 threads      (256,1024] radix, 256 threads   (1024,3072] radix, 512 threads
   //   (3072,8192] radix, 1024 threads    (8192,16384] bitonic in place, 1024 threads
-  hipLaunchKernelGGL(bin_tilesort_kernel<128>, dim3(ntiles), dim3(128), 256 * 8, st, ranges, bucket, point_list, 1, 257);
-  if (longest > 256) launch_radix<256>(ntiles, ranges, bucket, point_list, 257, 1025, 1024, st);
-  if (longest > 1024) launch_radix<512>(ntiles, ranges, bucket, point_list, 1025, 3073, 3072, st);
-  if (longest > 3072) launch_radix<1024>(ntiles, ranges, bucket, point_list, 3073, 8193, 8192, st);
+  hipLaunchKernelGGL(bin_tilesort_kernel<128>, dim3(ntiles), dim3(128), 256 * 8, st, ranges, bucket, point_list, 1, 257, spec_fail);
+  if (longest > 256) launch_radix<256>(ntiles, ranges, bucket, point_list, 257, 1025, 1024, spec_fail, st);
+  if (longest > 1024) launch_radix<512>(ntiles, ranges, bucket, point_list, 1025, 3073, 3072, spec_fail, st);
+  if (longest > 3072) launch_radix<1024>(ntiles, ranges, bucket, point_list, 3073, 8193, 8192, spec_fail, st);
   if (longest > 8192) {
     static LdsGrant grant(48 * 1024);
     grant.ensure((const void*)bin_tilesort_kernel<1024>, 16384 * 8);
     hipLaunchKernelGGL(bin_tilesort_kernel<1024>, dim3(ntiles), dim3(1024), 16384 * 8, st, ranges, bucket, point_list,
-                       8193, 16385);
+                       8193, 16385, spec_fail);
   }
 }
 

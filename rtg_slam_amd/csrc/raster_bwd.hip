@@ -127,6 +127,7 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_strip_kernel(
   const int py = blockIdx.y * TILE + (tid >> 4);
   const bool inside = px < p.W && py < p.H;
   const float pxf = (float)px, pyf = (float)py;
+  if (spec_failed(p.spec_fail)) return;     // the forward's speculative sizes did not hold: the host redoes the step
   if ((tile_mode[tile] & 1u) != 0u) return;       // this tile's lists are block-sparse: blend_bwd_rows_kernel walks it
   const uint2 range = ranges[tile];
   const size_t pix = (size_t)py * p.W + px;
@@ -381,6 +382,7 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_rows_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
+  if (spec_failed(p.spec_fail)) return;     // the forward's speculative sizes did not hold: the host redoes the step
   if ((tile_mode[tile] & 1u) == 0u) return;       // shared lists: blend_bwd_strip_kernel walks this tile
   const int bx = ((wv & 1) << 1) | ((lane >> 4) & 1), by = (wv & 2) | (lane >> 5);
   const int blk = by * 4 + bx;
@@ -613,7 +615,8 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(int P, const uint8_t* 
                                                           const uint32_t* __restrict__ gbase,
                                                           uint32_t* __restrict__ count,
                                                           const BwdInfo* __restrict__ info,
-                                                          SplatGrad* __restrict__ grads) {
+                                                          SplatGrad* __restrict__ grads, const uint32_t* __restrict__ spec_fail) {
+  if (spec_failed(spec_fail)) return;
   if (info->use_slots == 0) return;
   __shared__ uint8_t s_small[4][64], s_big[4][64];
   const float* __restrict__ slots = reinterpret_cast<const float*>(info->slot_grads);
@@ -958,6 +961,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     uint8_t* __restrict__ row_state,
     float* __restrict__ d_means, float* __restrict__ d_opac, float* __restrict__ d_shs,
     float* __restrict__ d_scales, float* __restrict__ d_rots, float* __restrict__ d_normal) {
+  if (spec_failed(p.spec_fail)) return;     // nothing persistent (gradient rows, row states) may change in a failed speculation
   if (!row_state) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < p.P)
@@ -1003,11 +1007,11 @@ void launch_blend_bwd(const RasterParams& p, const uint2* ranges, const uint32_t
                        final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched, tile_mode);
 }
 void launch_grad_reduce(int P, const uint8_t* touched, const uint32_t* gbase, uint32_t* count, const BwdInfo* info,
-                        SplatGrad* grads, hipStream_t st) {
+                        SplatGrad* grads, const uint32_t* spec_fail, hipStream_t st) {
   if (P == 0) return;
   int blocks = (P + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(blocks), dim3(256), 0, st, P, touched, gbase, count, info, grads);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(blocks), dim3(256), 0, st, P, touched, gbase, count, info, grads, spec_fail);
 }
 void launch_preprocess_bwd(const RasterParams& p, const float* means, const float* opac, const float* shs,
                            const float* scales, const float* rots, const float* normal_w, const int32_t* radii,

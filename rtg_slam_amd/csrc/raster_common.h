@@ -48,6 +48,19 @@ struct RasterParams {
   const float* view;     // [16] W2C transposed
   const float* campos;   // [3]
   const float* bg;       // [3]
+  // Speculative forward (raster_api.hip): device word that is non-zero when the sizes the host guessed for this call
+  // did not hold; kernels that would overrun a buffer or change persistent state return at once.  nullptr = not
+  // speculative.
+  const uint32_t* spec_fail;
+};
+__device__ __forceinline__ bool spec_failed(const uint32_t* f) { return f != nullptr && *f != 0u; }
+// What bin_tilescan checks for a speculative forward (all pointers nullptr = not speculative): the instance total, the
+// longest tile list and the gradient-slot total against the capacities the host allocated / launched for, and - when
+// the host assumed the near slice would be declined again - that the cut the kernels derived is negative.
+struct SpecCaps {
+  uint32_t* fail;
+  uint32_t R, longest, slots;
+  const int32_t* cut;
 };
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

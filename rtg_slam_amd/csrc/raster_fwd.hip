@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     if (out_radii) out_radii[i] = 0;
     if (zbin) zbin[i] = 255;
   } else {
+    if (spec_failed(p.spec_fail)) return;      // speculative forward already known to be wrong: the work list is not valid
     if (list.ids) {
       if (i >= (int)*list.count) return;
       i = (int)list.ids[i];
@@ -315,6 +316,7 @@ __global__ void __launch_bounds__(256, 6) blend_fwd_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
+  if (spec_failed(p.spec_fail)) return;                // lists were not built (speculative sizes did not hold): redone by the host
   if (sp.mode == 2 && sp.mask2[tile] == 0) return;     // finished by the near slice (or masked off): outputs stay
   // wave = 8x8 quadrant, DPP row = 4x4 block, lane = pixel of the block
   const int bx = ((wv & 1) << 1) | ((lane >> 4) & 1), by = (wv & 2) | (lane >> 5);
@@ -526,7 +528,8 @@ void launch_tile_ranges(int64_t R, const uint64_t* keys, uint2* ranges, hipStrea
 __global__ void __launch_bounds__(256) slice_publish_kernel(int ntiles, const int32_t* __restrict__ user_mask,
                                                             const int32_t* __restrict__ mask2,
                                                             const uint32_t* __restrict__ r1, uint32_t* __restrict__ ctr,
-                                                            uint32_t* __restrict__ host, uint32_t seq) {
+                                                            uint32_t* __restrict__ host, uint32_t seq,
+                                                            uint32_t* __restrict__ spec_fail) {
   int left = 0, fin = 0;
   for (int t = threadIdx.x; t < ntiles; t += 256) {
     const bool on = user_mask[t] != 0, l = mask2[t] != 0;
@@ -541,13 +544,14 @@ __global__ void __launch_bounds__(256) slice_publish_kernel(int ntiles, const in
   if (threadIdx.x == 0) {
     const uint32_t L = (uint32_t)(s_l[0] + s_l[1] + s_l[2] + s_l[3]), F = (uint32_t)(s_f[0] + s_f[1] + s_f[2] + s_f[3]);
     ctr[0] = L; ctr[1] = F;                      // device copy: pass 2's kernels exit at once when nothing is left
+    if (spec_fail) *spec_fail = L != 0u ? 1u : 0u;   // speculative forward: the host assumed the slice finishes every tile
     const uint32_t w[7] = {0u, 0u, L, F, r1[0], 0u, 0u};
     publish_to_host(host, w, seq);
   }
 }
 void launch_slice_publish(int ntiles, const int32_t* user_mask, const int32_t* mask2, const uint32_t* r1, uint32_t* ctr,
-                          uint32_t* host, uint32_t seq, hipStream_t st) {
-  hipLaunchKernelGGL(slice_publish_kernel, dim3(1), dim3(256), 0, st, ntiles, user_mask, mask2, r1, ctr, host, seq);
+                          uint32_t* host, uint32_t seq, uint32_t* spec_fail, hipStream_t st) {
+  hipLaunchKernelGGL(slice_publish_kernel, dim3(1), dim3(256), 0, st, ntiles, user_mask, mask2, r1, ctr, host, seq, spec_fail);
 }
 
 void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,

@@ -76,6 +76,15 @@ class RasterContext:
         """0 = blend_fwd chooses the backward's walk per tile (default), 1 = strip walk, 2 = row-granular walk."""
         _lib.load().rtgs_raster_set_bwd_walk_ctx(self.ptr, int(mode))
 
+    def set_speculation(self, enable: bool):
+        """Speculative sizing of the forward inside the one-call map step (RTGS_FWD_SPECULATE); default on."""
+        _lib.load().rtgs_raster_set_speculation_ctx(self.ptr, int(bool(enable)))
+
+    def speculation_stats(self):
+        out = (C.c_int64 * 3)()
+        _lib.check(_lib.load().rtgs_raster_speculation_stats_ctx(self.ptr, out), "rtgs_raster_speculation_stats")
+        return dict(speculative=int(out[0]), failed=int(out[1]), not_eligible=int(out[2]))
+
     def set_profiling(self, enable: bool):
         _lib.load().rtgs_raster_set_profiling_ctx(self.ptr, int(bool(enable)))
 
