@@ -140,5 +140,78 @@ def main():
               "loss", float(save["p2p_loss"]), os.path.getsize(path) // 1024, "KiB")
 
 
+def bits_checksum(t: torch.Tensor) -> int:
+    """Order-independent, exact checksum of a float32 tensor: the sum of its bit patterns as int64."""
+    return int(t.contiguous().view(torch.int32).to(torch.int64).sum())
+
+
+def full_size_cases():
+    """Full-size frames (Replica 680x1200 clean, TUM 480x640 noisy) through the REFERENCE's own tracker.  Only OUTPUTS
+    are committed (tests/golden/icp_full_*.npz, a few KiB): the inputs regenerate from the seeds - the frames are the
+    ones tests/test_icp_gpu.py::test_tracker_class_* builds (trajectory seed 9, base pose seed 3, noise seeds 1 / 2).
+    Also recorded: the reference's own pose with 1 and with 8 torch threads (its float32 reductions are summed in a
+    different order) - how far the REFERENCE moves against itself on each frame."""
+    ref_icp, ref_utils = import_reference_icp()
+    sys.path.insert(0, ROOT)
+    from rtg_slam_amd import synth
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    cos_thr = float(np.cos(np.deg2rad(20.0)))
+    for name, cam, noise in (("full_replica_clean", synth.REPLICA, False), ("full_tum_noisy", synth.TUM_FR1, True)):
+        poses = synth.trajectory(2, seed=9)
+        base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
+        d0 = synth.box_room_depth(cam, base @ poses[0])
+        d1 = synth.box_room_depth(cam, base @ poses[1])
+        if noise:
+            d0, d1 = synth.tum_noise(d0, 1), synth.tum_noise(d1, 2)
+        K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32)
+        save = dict(cam=np.array([cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy], dtype=np.float64), K=K.numpy(),
+                    depth_checksum=np.array([bits_checksum(d0), bits_checksum(d1)], dtype=np.int64))
+        for threads in (8, 1):
+            torch.set_num_threads(threads)
+            builder = ref_icp.ImagePyramids([2, 1, 0], "max")
+            vp0 = ref_utils.build_vertex_pyramid(d0, builder, K.clone())
+            np0 = ref_utils.build_normal_pyramid(vp0)
+            vp1 = ref_utils.build_vertex_pyramid(d1, builder, K.clone())
+            np1 = ref_utils.build_normal_pyramid(vp1)
+            if threads == 8:
+                g = torch.Generator().manual_seed(17)
+                xi = (torch.rand(6, generator=g) - 0.5) * torch.tensor([0.02, 0.02, 0.02, 0.03, 0.03, 0.03])
+                pose_probe = ref_icp.exp_se3(xi)
+                save["pose_probe"] = pose_probe.numpy()
+                for l, ds in enumerate([0.25, 0.5, 1.0]):
+                    Kl = K * ds
+                    Kl[2, 2] = 1.0
+                    mask0 = vp1[l][..., -1] > 0
+                    res, J, valid = ref_icp.ICP.compute_residuals_jacobian(vp1[l], vp0[l], np1[l], np0[l], mask0,
+                                                                           pose_probe, Kl, 0.1, cos_thr)
+                    save[f"JtJ_{l}"] = ref_icp.ICP.compute_jtj(J).numpy()
+                    save[f"Jtr_{l}"] = ref_icp.ICP.compute_jtr(J, res).numpy()
+                    save[f"nvalid_{l}"] = np.array(int(valid.sum()))
+                    # exact checksums (sum of the float32 bit patterns) of the pyramids the reference worked on
+                    save[f"pyr_checksum_{l}"] = np.array([bits_checksum(vp1[l]), bits_checksum(np1[l]), bits_checksum(vp0[l]),
+                                                          bits_checksum(np0[l])], dtype=np.int64)
+            pose = torch.eye(4)
+            ratio = None
+            iter_poses = []
+            for l, ds in enumerate([0.25, 0.5, 1.0]):
+                Kl = K * ds
+                Kl[2, 2] = 1.0
+                tracker = ref_icp.ICP(5, damping=1e-4, distance_threshold=0.1, normal_threshold=20)
+                pose, ratio = tracker.icp(pose, vp1[l], vp0[l], np1[l], np0[l], Kl)
+                iter_poses.append(pose.numpy().copy())
+            tag = "" if threads == 8 else "_1thread"
+            save["pose_final" + tag] = pose.numpy()
+            save["level_poses" + tag] = np.stack(iter_poses)
+            save["valid_ratio" + tag] = np.array(float(ratio))
+            save["p2p_loss" + tag] = np.array(float(ref_icp.point2plane_loss(vp0[-1], vp1[-1] @ pose[:3, :3].T + pose[:3, 3],
+                                                                             np0[-1])))
+        torch.set_num_threads(8)
+        path = os.path.join(out_dir, f"icp_{name}.npz")
+        np.savez_compressed(path, **save)
+        print(name, "reference vs itself (8 vs 1 threads):", float(np.abs(save["pose_final"] - save["pose_final_1thread"]).max()),
+              "valid", float(save["valid_ratio"]), "loss", float(save["p2p_loss"]), os.path.getsize(path), "B")
+
+
 if __name__ == "__main__":
     main()
+    full_size_cases()

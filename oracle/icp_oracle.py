@@ -115,7 +115,14 @@ def residuals_jacobian(v_src, v_tgt, n_src, n_tgt, pose, K, dist_thr, cos_thr):
 
 
 def normal_equations(J: torch.Tensor, res: torch.Tensor):
-    return J.t() @ J, J.t() @ res
+    """compute_jtj / compute_jtr (SLAM/icp.py:107-119), literally: the per-pixel 6x6 (6x1) products are materialised
+    by bmm and summed by torch.sum over the pixel axis - the same float32 reduction the reference performs (a J^T J
+    GEMM sums in another order: 4e-5 on the final pose of the noisy full-size frame)."""
+    jac = J.reshape(-1, 1, 6)
+    jacT = jac.transpose(-1, -2)
+    jtj = torch.bmm(jacT, jac).sum(0)
+    jtr = torch.bmm(jacT, res.reshape(-1, 1, 1)).sum(0)
+    return jtj, jtr.reshape(6)
 
 
 def se3_exp(xi: torch.Tensor) -> torch.Tensor:

@@ -135,6 +135,54 @@ def test_tracker_class_vs_oracle_full_size(cam, noise, persistent):
         assert float(np.abs(pose - rel).max()) < 5e-3
 
 
+FULL_TOL = {"full_replica_clean": 1e-5, "full_tum_noisy": 5e-5}
+
+
+@pytest.mark.parametrize("name,cam,noise", [("full_replica_clean", synth.REPLICA, False), ("full_tum_noisy", synth.TUM_FR1, True)])
+def test_full_size_vs_reference_outputs(golden_dir, name, cam, noise):
+    """Full-size frames against outputs of the REFERENCE's own tracker (oracle/gen_icp_golden.py::full_size_cases runs
+    /root/reference/SLAM/icp.py on these frames; only its outputs are committed, the frames regenerate from the seeds).
+    Pyramids: bit-identical (exact checksums - the sum of the float32 bit patterns - of all four maps per level).  Normal equations at a probe pose: the
+    reference's valid count exactly, sums to 1e-4.  The 15-iteration pose: north_star's 1e-5 on the clean Replica-shaped
+    frame; on the noisy TUM-shaped frame (5 % of the pixels pass the gates, the iteration is ill-conditioned) the kernel's
+    float64 sums and the reference's float32 sums end 3e-5 apart - stated here and in DESIGN.md, not hidden behind
+    another oracle.  (The reference against ITSELF with 1 vs 8 torch threads moves by 1e-8 on these frames.)"""
+    from rtg_slam_amd import icp
+    g = load(golden_dir, name)
+    poses = synth.trajectory(2, seed=9)
+    base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
+    d0 = synth.box_room_depth(cam, base @ poses[0])
+    d1 = synth.box_room_depth(cam, base @ poses[1])
+    if noise:
+        d0, d1 = synth.tum_noise(d0, 1), synth.tum_noise(d1, 2)
+    bits = lambda t: int(t.detach().cpu().contiguous().view(torch.int32).to(torch.int64).sum())   # exact, order-independent
+    assert bits(d0) == int(g["depth_checksum"][0]) and bits(d1) == int(g["depth_checksum"][1])
+    K = g["K"]
+    hv0, hn0 = icp.build_pyramids(d0.to(DEV), K.to(DEV), 3)
+    hv1, hn1 = icp.build_pyramids(d1.to(DEV), K.to(DEV), 3)
+    cos_thr = float(np.cos(np.deg2rad(20.0)))
+    for l, ds in enumerate([0.25, 0.5, 1.0]):
+        cs = [bits(t) for t in (hv1[l], hn1[l], hv0[l], hn0[l])]
+        assert cs == [int(x) for x in g[f"pyr_checksum_{l}"]], (l, cs, g[f"pyr_checksum_{l}"])
+        Kl = K * ds
+        Kl[2, 2] = 1.0
+        JtJ, Jtr, nv = icp.icp_step(hv1[l], hn1[l], hv0[l], hn0[l], Kl, g["pose_probe"], 0.1, cos_thr)
+        assert int(nv.item()) == int(g[f"nvalid_{l}"])
+        ref = g[f"JtJ_{l}"]
+        assert float((JtJ.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+        rj = g[f"Jtr_{l}"].reshape(-1)
+        assert float((Jtr.cpu() - rj).abs().max()) <= 1e-4 * float(rj.abs().max()) + 1e-6
+    for persistent in (False, True):
+        out = icp.icp_track(hv1, hn1, hv0, hn0, K, [0.25, 0.5, 1.0], [5, 5, 5], 0.1, cos_thr, 1e-4, persistent=persistent).cpu()
+        pose = out[:16].reshape(4, 4)
+        err = float((pose - g["pose_final"]).abs().max())
+        print(f"{name} persistent={persistent}: |hip - reference pose| = {err:.2e} (reference 8 vs 1 threads "
+              f"{float((g['pose_final'] - g['pose_final_1thread']).abs().max()):.1e})")
+        assert err < FULL_TOL[name], err
+        assert abs(float(out[16]) - float(g["valid_ratio"])) < 1e-3
+        assert abs(float(out[17]) - float(g["p2p_loss"])) <= 2e-4 * max(1.0, float(g["p2p_loss"]))
+
+
 def test_no_gate_flips_on_the_noisy_full_size_frame():
     """bound the per-iteration gate flips on the noisy TUM-shaped frame.  Along the oracle's own
     15-iteration pose sequence, the HIP normal equations at every iterate have EXACTLY the oracle's number of valid

@@ -122,3 +122,34 @@ def test_depth_prefix_renders_terminated_tiles_identically():
                 assert torch.equal(mapped.to(torch.int32), full[k][sl]), (q, t, k)
             checked += 1
     assert checked > 0
+
+
+@pytest.mark.parametrize("N,seed,pose,masked,opaque", [(300, 1, None, False, False), (800, 2, 7, True, False), (200, 3, 4, False, True)])
+def test_hand_written_tile_backward_equals_autograd(N, seed, pose, masked, opaque):
+    """oracle/raster_oracle_fast.py (no autograd graph over the tiles; the blend's backward written out by hand, one
+    autograd pass through the per-Gaussian stage) against raster_oracle.rasterize + autograd, float64: the same maps to
+    1e-12 and the same gradients to 1e-9 of the tensor max - it is what makes a WHOLE-image parity test at 1.2 M
+    Gaussians affordable (tests/test_raster_parity_gpu.py)."""
+    from oracle import raster_oracle_fast as rf
+    from rtg_slam_amd import synth
+    from tests import raster_util as ru
+    cam = synth.CameraSpec(70, 101, 90.0, 85.0, 49.0, 36.0)
+    g, s = ru.make_scene(N, cam, seed=seed, pose_seed=pose)
+    if opaque:
+        g["opacity"] = torch.ones_like(g["opacity"])
+    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+    mask = (torch.rand(gy, gx, generator=torch.Generator().manual_seed(seed)) < 0.7).int() if masked else None
+    gen = torch.Generator().manual_seed(seed + 5)
+    grads = (torch.randn(3, cam.H, cam.W, generator=gen).double(), torch.randn(1, cam.H, cam.W, generator=gen).double())
+    out_a, gd_a, _ = ru.oracle_run(s, g, tile_mask=mask, grads=grads, dtype=torch.float64)
+    g64 = {k: g[k].double() for k in ru.FIELDS}
+    s64 = s._replace(bg=s.bg.double(), viewmatrix=s.viewmatrix.double(), campos=s.campos.double())
+    out_f, gd_f = rf.forward_backward(s64, g64["xyz"], g64["opacity"], g64["shs"], g64["scales"], g64["rotations"],
+                                      g64["normal"], mask, grads[0], grads[1])
+    for k in (0, 1, 4, 5, 6):
+        assert float((out_a[k] - out_f[k]).abs().max()) < 1e-12, k
+    for k in (2, 3):
+        assert torch.equal(out_a[k], out_f[k]), k
+    for k in ru.FIELDS:
+        scale = float(gd_a[k].abs().max()) + 1e-300
+        assert float((gd_a[k] - gd_f[k]).abs().max()) / scale < 1e-9, (k, float((gd_a[k] - gd_f[k]).abs().max()) / scale)

@@ -174,3 +174,24 @@ def test_parity_on_the_surface_map_through_the_declined_slice_paths():
             assert st["used"] == 1 and st["instances"] == 0 and st["tiles_finished"] == 0, (label, st)
         _check_maps(out_h, out_o)
         _check_grads(gd_h, gd_o)
+
+
+@pytest.mark.parametrize("name", ["headline", "surface"])
+def test_whole_image_parity_at_the_headline_size(name):
+    """EVERY tile of the 1200x680 render of the two 1.2 M bench scenes against the oracle, forward and backward - not a
+    tile-masked subset.  The oracle side is oracle/raster_oracle_fast.py: raster_oracle.py's own per-Gaussian stage and
+    binning, the tile blend without an autograd graph and its backward written out by hand (pinned to raster_oracle.py +
+    autograd in float64 by tests/test_oracle_raster.py) - about a minute of CPU per scene, where autograd over the
+    chunked tile walk needs ~20 (and tens of GB).  The HIP side is ONE unmasked forward + backward: the path bench.py
+    times, near slice in automatic mode, per-tile choice of the backward walk."""
+    from oracle import raster_oracle_fast as rf
+    cam = synth.REPLICA
+    g, s = ru.make_scene(1_200_000, cam, seed=2024)
+    if name == "surface":
+        g = synth.surface_gaussians(1_200_000, cam, seed=7)
+    grads = _grads(cam, 11)
+    out_h, gd_h = ru.hip_run(s, g, grads=grads)
+    out_o, gd_o = rf.forward_backward(s, g["xyz"], g["opacity"], g["shs"], g["scales"], g["rotations"], g["normal"], None,
+                                      grads[0], grads[1])
+    _check_maps(out_h, out_o)
+    _check_grads(gd_h, gd_o)
