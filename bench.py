@@ -46,14 +46,53 @@ def parse():
                          "row shard, all-gather of the updated rows [weak]; tileband = ONE view split into tile bands, "
                          "loss normalisers all-reduced, gradient rows summed by the sparse exchange [strong]")
     ap.add_argument("--prewarm", type=int, default=200, help="untimed frames before the warm-up (clocks, allocator)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps frames: `value` is the FIRST (the contract's "
+                                                           "block), the others give median and spread")
+    ap.add_argument("--surface-map", action="store_true", help="headline leg on the single-layer surface map instead of the "
+                                                               "SURVEY 8d volume generator")
+    ap.add_argument("--no-schedule", action="store_true", help="skip the reference-schedule leg (6 frames: 6 tracks + "
+                                                               "Gaussian adding + 50 map iterations over a 5-frame window)")
     return ap.parse_args()
+
+
+def source_hash():
+    """sha256 over the kernel sources: PMC-derived numbers in profiles/ carry the hash they were measured at."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rtg_slam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one per GPU, RCCL) and relay rank 0's
+    line - a bare run must never measure one rank and call it N."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    rccl_ranks = 0
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -63,9 +102,14 @@ def main():
         ndev = torch.cuda.device_count()
         torch.cuda.set_device(local_rank % ndev)
         if backend == "nccl":
+            if ndev < world:
+                raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, {ndev} visible "
+                                 "(RTGS_DIST_BACKEND=gloo shares one GPU for a functional check only)")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank % ndev))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == backend
+        rccl_ranks = world if backend == "nccl" else 0
     dev = torch.device("cuda", (local_rank % torch.cuda.device_count()) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -76,7 +120,8 @@ def main():
 
     cam = synth.REPLICA
     N = args.gaussians
-    g = synth.random_gaussians(N, cam, seed=2024)                 # same map on every rank
+    # same map on every rank
+    g = synth.surface_gaussians(N, cam, seed=7) if args.surface_map else synth.random_gaussians(N, cam, seed=2024)
     packed = mo.pack_from_activated({k: v.to(dev) for k, v in g.items()})
     # learning rates x1e-4: the targets are random images, at the reference's rates the map would
     # inflate within a few hundred steps and the workload would drift; Adam does identical work.
@@ -113,26 +158,14 @@ def main():
                     tile_mask=tile_mask, grad_rows=gd.get("grad_rows"))
 
     # Tracking and mapping are independent within a frame (RTG-SLAM runs them as two pipeline stages in separate
-    # processes, SLAM/multiprocess/system.py).  Here the tracker's kernels go to a second HIP stream and are
-    # ENQUEUED by a helper thread (the C calls release the GIL), so neither the GPU nor the host serialises the two.
-    icp_stream = torch.cuda.Stream(device=dev)
-    import queue
-    import threading
-    icp_req, icp_done = queue.SimpleQueue(), queue.SimpleQueue()
+    # processes, SLAM/multiprocess/system.py): the tracker's kernels go to a second HIP stream, enqueued by a helper
+    # thread - rtg_slam_amd/pipeline.py
+    from rtg_slam_amd.pipeline import TrackMapPipeline
+    pipe = TrackMapPipeline(dev)
 
-    def icp_worker():
-        torch.cuda.set_device(dev)
-        while True:
-            if icp_req.get() is None:
-                return
-            try:
-                with torch.cuda.stream(icp_stream):
-                    vp1, np1 = hicp.build_pyramids(d1, K, 3)
-                    icp_done.put(hicp.icp_track(vp1, np1, vp0, np0, K, [0.25, 0.5, 1.0], [5, 5, 5], 0.1, cos_thr, 1e-4))
-            except Exception as e:          # surface in the main thread
-                icp_done.put(e)
-
-    threading.Thread(target=icp_worker, daemon=True).start()
+    def track_stage():
+        vp1, np1 = hicp.build_pyramids(d1, K, 3)
+        return hicp.icp_track(vp1, np1, vp0, np0, K, [0.25, 0.5, 1.0], [5, 5, 5], 0.1, cos_thr, 1e-4)
 
     # the render mask of the optimisation (mapper.py:500-508: evaluate_render_range renders once before the loop,
     # render_mask = T_map != 1, and hands it to every loss_update) - computed the same way, once, by the HIP producer
@@ -147,7 +180,9 @@ def main():
     del gd0, T0
     opt.begin_local_optimization()
 
-    mode = args.mode if world > 1 else "single"
+    # --mode sharded is honoured on one GPU too (the N = 1 anchor of BASELINE configs[4]'s curve: dense gradients,
+    # Adam through the autograd path); the other modes collapse to the plain one-call step
+    mode = args.mode if (world > 1 or args.mode == "sharded") else "single"
 
     def loss_fn(gd):
         return mo.slam_losses_hip(render(gd), gt_color, gt_depth, render_mask=render_mask)
@@ -162,15 +197,9 @@ def main():
         return opt.step_slam(rs, gt_color, gt_depth, tile_mask, render_mask=render_mask, tile_band=(mode == "tileband"))
 
     def frame():
-        main = torch.cuda.current_stream(dev)
-        icp_stream.wait_stream(main)
-        icp_req.put(1)
+        pipe.track(track_stage)
         map_step()
-        out = icp_done.get()
-        if isinstance(out, Exception):
-            raise out
-        main.wait_stream(icp_stream)
-        return out
+        return pipe.result()
 
     def barrier():
         if world > 1:
@@ -201,6 +230,21 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # further timed blocks (same K): run-to-run spread on this box.  `value` stays the contract's first block.
+    block_ms = [1e3 * dt / args.steps]
+    for _ in range(max(0, args.repeats - 1)):
+        barrier()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            frame()
+        barrier()
+        db = time.perf_counter() - tb
+        if world > 1:
+            t = torch.tensor([db], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            db = float(t.item())
+        block_ms.append(1e3 * db / args.steps)
 
     opt.flush()
     # Strong scaling of ONE view (a single SLAM stream has one frame per step): every rank takes a band of the tiles of
@@ -281,16 +325,43 @@ def main():
                                                         prof["pairs"], prof["near_slice"])
         dom, dom_ms, alg = prof["dominant"], prof["dominant_ms"], prof["alg"]
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        # PMC-derived numbers (separate rocprofv3 --pmc passes, tools/measure_round.sh) are only quoted when they were
+        # measured on THESE kernel sources: the files carry the hash of rtg_slam_amd/csrc they were collected at.
+        traffic, valu = None, None
+        src = source_hash()
+        dom_pmc = {"blend_bwd": "blend_bwd_strip", "near_slice_blend_fwd": "blend_fwd"}.get(dom, dom)
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):     # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(tpath):     # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("_source_sha16") == src:
+                    traffic = (tj.get(dom_pmc) or tj.get(dom) or {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(dom_ms, 4), "alg_bytes_per_launch": int(alg[dom])}
+        vpath = os.path.join(ROOT, "profiles", "valu_latest.json")
+        if os.path.exists(vpath):     # SQ_INSTS_VALU per launch of the dominant kernel (tools/pmc_sq.py)
+            try:
+                vj = json.load(open(vpath))
+                if vj.get("_source_sha16") == src and dom_pmc in vj:
+                    insts = float(vj[dom_pmc]["SQ_INSTS_VALU"])
+                    # a wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.08
+                    # quad-cycle-normalised on every kernel profiled): peak = 1024 SIMDs x 2.4 GHz / 4
+                    peak = 1024 * 2.4e9 / 4
+                    valu = {"wave_insts_per_launch": int(insts), "achieved_Ginst_s": round(insts / (dom_ms * 1e-3) / 1e9, 1),
+                            "peak_Ginst_s": round(peak / 1e9, 1), "frac": round(insts / (dom_ms * 1e-3) / peak, 4),
+                            "valu_active_frac_of_busy_pmc": vj[dom_pmc].get("valu_active_frac"),
+                            "source": "profiles/valu_latest.json (rocprofv3 --pmc SQ_INSTS_VALU ..., own pass), duration live"}
+            except Exception:
+                valu = None
+        hbm_frac = achieved / HBM_PEAK_GBS
+        roofline = {"kernel": dom, "bound": "valu" if (valu and valu["frac"] > hbm_frac) else "hbm",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic,
+                    "avg_launch_ms": round(dom_ms, 4), "alg_bytes_per_launch": int(alg[dom]), "valu": valu,
+                    "note": "achieved / peak / frac are the HBM roofline north_star asks for (algorithmic bytes over the live "
+                            "launch time); `bound` names what the SQ counters say limits the kernel - VALU issue when the "
+                            "`valu` block is present and its fraction exceeds the HBM one.  traffic / valu are null when "
+                            "profiles/*_latest.json were not measured on the current kernel sources", "source_sha16": src}
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
@@ -305,15 +376,22 @@ def main():
                            "exchange, identical Adam step on every replica"}[mode]
         frames_per_step = 1 if mode == "tileband" else world
         fps = frames_per_step * args.steps / dt
+        sched = None
+        if world == 1 and not args.no_schedule and not args.no_surface:
+            sched = reference_schedule_leg(cam, N, dev)
+        bs = sorted(block_ms)
         result = {
             "metric": "slam_frames_per_sec", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "strong" if mode == "tileband" else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic Replica-shaped SLAM frame: ICP track (3 levels x 5 GN iters, 1200x680, on a "
-                                   "second HIP stream) + 1 map-optimisation iteration (raster fwd + masked L1 colour / gated depth loss + attach regulariser + "
-                                   f"raster bwd + fused Adam) over {N} random Gaussians (SURVEY.md 8d generator, seed 2024), "
-                                   "all tiles",
+            "config": {"workload": "one UNIT per step = 1 ICP track (3 levels x 5 GN iters, 1200x680, on a second HIP stream) "
+                                   "+ 1 map-optimisation iteration (raster fwd + masked L1 colour / gated depth loss + attach "
+                                   f"regulariser + raster bwd + fused Adam) over {N} "
+                                   + ("opaque wall discs (single-layer surface map)" if args.surface_map else
+                                      "random Gaussians (SURVEY.md 8d generator, seed 2024)") +
+                                   ", all tiles.  `value` counts these units; the reference's Replica schedule runs 50 iterations "
+                                   "every 6th frame (~8.3 per frame): see frames_per_sec_replica_schedule",
                        "gaussians": N, "gaussians_with_gradient": rows_touched, "image": [cam.H, cam.W],
                        "instances": R, "instances_consumed": consumed,
                        "pixel_pairs_evaluated": pairs,
@@ -322,6 +400,12 @@ def main():
             "raster_fwd_bwd_ms": round(sum(stage), 4), "icp_track_ms": round(icp_ms, 4),
             "raster_fwd_bwd_ms_30pct_tiles": round(sum(prof30["stage"]), 4),
             "cold_first_frame_ms": round(cold_ms, 2), "prewarm_frames": args.prewarm,
+            "repeats": {"blocks": len(block_ms), "ms_per_step": [round(x, 4) for x in block_ms],
+                        "median_ms_per_step": round(bs[len(bs) // 2], 4), "min": round(bs[0], 4), "max": round(bs[-1], 4),
+                        "median_frames_per_sec": round(frames_per_step * 1e3 / bs[len(bs) // 2], 2)},
+            "rccl_ranks": rccl_ranks,
+            "frames_per_sec_replica_schedule": None if sched is None else sched["frames_per_sec"],
+            "replica_schedule": sched,
             "strong_scaling_one_view": strong,
             "near_slice": slice_stats, "kernels": kernels, "roofline": roofline, "cpu_baseline": cpu,
             "surface_scene": None if surface is None else {k: surface[k] for k in (
@@ -332,6 +416,97 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def reference_schedule_leg(cam, N, dev, cycles=3, iters=50, every=6, window=5, n_new=40800):
+    """The reference's Replica schedule as a measured workload (slam.py main loop; mapper.py:97-110, 157-205;
+    configs/replica_base.yaml:9-18): EVERY frame is preprocessed (tracker.py:97-159), tracked frame-to-model
+    (IcpTracker.predict_pose + update_last_status with a render of the map at the new pose), and `uniform_sample_num`
+    = 40 800 new Gaussians are built for it (sample_pixels + distCUDA2 radii, gaussian_pointcloud.py:366-405); every 6th
+    frame the map is optimised: a fresh Adam state (mapper.py:156), evaluate_render_range on each of the 5 window frames
+    (one render + T_map -> render / tile masks), then 50 loss_update iterations on a random frame of the window (the last
+    frame in the second half, mapper.py:176-183).  1200x680, the 1.2 M single-layer surface map, one GPU, one stream,
+    sequential like slam.py.  The new Gaussians are computed and discarded so that the map stays at N (appending would
+    only change N between cycles); dataset IO and the keyframe / stable-set policies are out of scope."""
+    import numpy as np
+    from types import SimpleNamespace
+    from rtg_slam_amd import synth, slam_ops, map_optim as mo
+    from rtg_slam_amd.icp import IcpTracker
+    from rtg_slam_amd.render import Renderer
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import mini_slam as ms
+    gs = synth.surface_gaussians(N, cam, seed=7)
+    packed = mo.pack_from_activated({k: v.to(dev) for k, v in gs.items()})
+    n_frames = every * (cycles + 1)
+    base = torch.eye(4, dtype=torch.float64)
+    poses = [base @ p for p in synth.trajectory(n_frames, seed=21)]
+    K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32, device=dev)
+    frames = []
+    for c2w in poses:                                            # "dataset": rendered up front, outside the timed region
+        d = synth.box_room_depth(cam, c2w)
+        frames.append((d.to(dev), synth.box_room_color(cam, c2w, d).to(dev)))
+    tracker, renderer = IcpTracker(ms.ARGS), Renderer(ms.ARGS)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    rng = np.random.RandomState(5)
+    lr = mo.default_lr_columns() * 1e-4          # as in the headline leg: random-ish targets must not inflate the map
+    state = dict(params=packed, win=[], c2w=poses[0].clone(), iters=0)
+
+    def one_frame(fid):
+        depth, color = frames[fid]
+        fm = slam_ops.frame_preprocess(depth, K, 0.3, 8.0, False, 0.2)
+        tracker.update_curr_status(fm["depth_map"], K)
+        if fid > 0:
+            rel, _ = tracker.predict_pose({"K": K, "frame_id": fid})
+            state["c2w"] = state["c2w"] @ torch.from_numpy(rel.astype(np.float64))
+        tracker.move_last_status()
+        c2w = state["c2w"]
+        Rw, tw = c2w[:3, :3].float().to(dev), c2w[:3, 3].float().to(dev)
+        vertex_w = fm["vertex_map_c"] @ Rw.t() + tw
+        normal_w = fm["normal_map_c"] @ Rw.t()
+        view = ms._camera(cam, c2w, dev)
+        # gaussians_add: uniform_sample_num new Gaussians from the frame's pixels, radius from the 3 nearest neighbours
+        pts, nrm, col = slam_ops.sample_pixels(vertex_w, normal_w, color.permute(1, 2, 0).contiguous(), n_new, None, gen)
+        new = mo.pack_from_activated(ms.gaussians_from_pixels(pts, nrm, col))
+        del new
+        rs = ms.renderer_settings(renderer, view, dev)
+        state["win"] = (state["win"] + [(rs, color, fm["depth_map"].permute(2, 0, 1).contiguous(), view)])[-window:]
+        if (fid + 1) % every == 0 or fid == 0:
+            opt = mo.ShardedMapOptimizer(state["params"], lr_col=lr)          # Adam re-created per local_optimize
+            opt.begin_local_optimization()
+            masks = []
+            for (rs_w, _, _, view_w) in state["win"]:                          # evaluate_render_range (mapper.py:471-508)
+                with torch.no_grad():
+                    out = renderer.render(view_w, mo.activate_packed(opt.params))
+                rm, tm, _ = slam_ops.render_range(out["T_map"], 0.5)
+                masks.append((rm.to(torch.uint8), tm))
+            for it in range(iters):
+                j = len(state["win"]) - 1 if it > iters / 2 else int(rng.randint(0, len(state["win"])))
+                rs_w, col_w, dep_w, _ = state["win"][j]
+                opt.step_slam(rs_w, col_w, dep_w, masks[j][1], render_mask=masks[j][0])
+            state["params"] = opt.params
+            state["iters"] += iters
+        with torch.no_grad():                                                  # model depth / normals for the next track
+            out = renderer.render(view, mo.activate_packed(state["params"]))
+        tracker.update_last_status(None, out["depth"].permute(1, 2, 0).contiguous(), fm["depth_map"],
+                                   out["normal"].permute(1, 2, 0).contiguous(), normal_w)
+
+    for fid in range(every):                                                   # one untimed cycle
+        one_frame(fid)
+    torch.cuda.synchronize(dev)
+    it0 = state["iters"]
+    t0 = time.perf_counter()
+    for fid in range(every, n_frames):
+        one_frame(fid)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    nf = n_frames - every
+    err = float((state["c2w"][:3, 3] - poses[-1][:3, 3]).norm())
+    return {"frames_per_sec": round(nf / dt, 2), "ms_per_frame": round(1e3 * dt / nf, 3), "frames": nf,
+            "map_iterations": state["iters"] - it0, "iterations_per_frame": round((state["iters"] - it0) / nf, 2),
+            "gaussians": N, "image": [cam.H, cam.W], "new_gaussians_per_frame_built": n_new, "window": window,
+            "final_translation_error_m": round(err, 5),
+            "what": "reference Replica schedule (replica_base.yaml: gaussian_update_frame 6, gaussian_update_iter 50, "
+                    "memory_length 5, uniform_sample_num 40800), sequential single stream, 1.2 M surface map"}
 
 
 def profile_scene(lib, mo, rast, opt, N, cam, tile_mask, gt_color, gt_depth, dev, nprof):

@@ -46,8 +46,12 @@ def main():
         out[s] = {"rocprof_kernel": name.split("(")[0], "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                   "hbm_bytes_per_launch": int((2 * f + w) * 1024),
                   "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024, mean over the launches of the run"}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import source_hash
+    out["_source_sha16"] = source_hash()       # bench.py quotes these numbers only for the kernel sources they were measured on
     json.dump(out, open(sys.argv[3], "w"), indent=1)
-    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+    for k, v in sorted(((k, v) for k, v in out.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print(f"{k:40s} {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch")
 
 
