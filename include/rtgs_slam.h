@@ -35,9 +35,13 @@ int rtgs_transmission2tilemask(const uint8_t* pixelmask, int32_t H, int32_t W, i
 int rtgs_pixelmask2tilemask(const uint8_t* pixelmask, int32_t H, int32_t W, int32_t stride, int32_t* tile_mask,
                             float* tile_sum_scratch, void* stream);
 /* colorerror2tilemask: the k = (int)(tiles * top_ratio) tiles with the largest mean error are on (ties at the k-th value:
- * lower tile index first).  Up to 16 384 tiles. */
+ * lower tile index first).  Any number of tiles.  The reference computes int(numel * top_ratio) in double
+ * (SLAM/utils.py:708-734); top_ratio crosses this ABI as float32, where e.g. 0.7 is 0.69999999 and k can come out one
+ * short - a binding that holds the ratio in double computes k itself and calls the _k form (the Python host does). */
 int rtgs_colorerror2tilemask(const float* color_error, int32_t H, int32_t W, int32_t stride, float top_ratio,
                              int32_t* tile_mask, float* tile_sum_scratch, void* stream);
+int rtgs_colorerror2tilemask_k(const float* color_error, int32_t H, int32_t W, int32_t stride, int32_t top_k,
+                               int32_t* tile_mask, float* tile_sum_scratch, void* stream);
 /* The render-range step of mapper.py:471-508 in one call, straight from the rasterizer's T_map:
  *   render_mask = (T_map != 1)  [uint8, H*W],  tile_mask = transmission2tilemask(render_mask, 16, ratio),
  *   *count_out = number of set pixels (device uint32; render_ratio = count / pixels). */

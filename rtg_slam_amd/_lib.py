@@ -155,6 +155,7 @@ _SIGNATURES = {
     "rtgs_transmission2tilemask": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
     "rtgs_pixelmask2tilemask": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "rtgs_colorerror2tilemask": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
+    "rtgs_colorerror2tilemask_k": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "rtgs_render_range": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P, _P]),
     "rtgs_knn3_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "rtgs_knn3": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),

@@ -3,7 +3,8 @@
 #include "../../include/rtgs_raster.h"
 #include "raster_common.h"
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <math.h>
 #include <new>
 #include <stdlib.h>
@@ -213,8 +214,8 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
     L.bucket1 = off; off = align_up(off + L.slice_cap * sizeof(uint64_t));
   }
   size_t tb = 0, tb2 = 0;
-  (void)hipcub::DeviceScan::InclusiveSum(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)Pn);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)Pn);
+  (void)rocprim::inclusive_scan(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, Pn, rocprim::plus<uint32_t>());
+  (void)rocprim::exclusive_scan(nullptr, tb2, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, Pn, rocprim::plus<uint32_t>());
   if (tb2 > tb) tb = tb2;
   L.scan_temp_bytes = tb;
   L.scan_temp = off; off = align_up(off + tb);
@@ -237,8 +238,8 @@ static BinLayout bin_layout(int64_t R, int ntiles, bool sort_path, size_t slots)
   L.keys_b = off; off = align_up(off + Rn * sizeof(uint64_t));
   L.vals_a = off; off = align_up(off + Rn * sizeof(uint32_t));
   size_t tb = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                     (uint32_t*)nullptr, (int)Rn, 0, 32 + bits_for((uint32_t)ntiles));
+  (void)rocprim::radix_sort_pairs(nullptr, tb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, Rn, 0u, (unsigned)(32 + bits_for((uint32_t)ntiles)));
   L.sort_temp_bytes = tb;
   L.sort_temp = off; off = align_up(off + tb);
   L.total = off;
@@ -398,7 +399,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   uint32_t slots = 0;
   auto scan_all = [&]() -> int {
     size_t tb = G.scan_temp_bytes;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(geom + G.scan_temp, tb, tiles_touched, offsets, P, st));
+    HIP_TRY(rocprim::exclusive_scan(geom + G.scan_temp, tb, tiles_touched, offsets, 0u, (size_t)P, rocprim::plus<uint32_t>(), st));
     return RTGS_OK;
   };
   bool sort_path = (size_t)ntiles > bin_lds_limit_tiles() || c->force_sort_path;
@@ -670,7 +671,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
     }
     if (sort_path) {
       size_t tb = G.scan_temp_bytes;
-      HIP_TRY(hipcub::DeviceScan::InclusiveSum(geom + G.scan_temp, tb, tiles_touched, offsets, P, st));
+      HIP_TRY(rocprim::inclusive_scan(geom + G.scan_temp, tb, tiles_touched, offsets, (size_t)P, rocprim::plus<uint32_t>(), st));
       uint32_t total = 0;
       HIP_TRY(hipMemcpyAsync(&total, offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       prof_mark(c, EV_SCAN, st);
@@ -711,8 +712,8 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
     DBG(s, st);
     prof_mark(c, EV_EMIT, st);
     size_t tb = B.sort_temp_bytes;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(bin + B.sort_temp, tb, keys_a, keys_b, vals_a, vals_b, (int)R, 0,
-                                               sort_bits, st));
+    HIP_TRY(rocprim::radix_sort_pairs(bin + B.sort_temp, tb, keys_a, keys_b, vals_a, vals_b, (size_t)R, 0u,
+                                      (unsigned)sort_bits, st));
     DBG(s, st);
     prof_mark(c, EV_SORT, st);
     launch_tile_ranges(R, keys_b, ranges, st);

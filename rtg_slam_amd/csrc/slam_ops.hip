@@ -5,7 +5,9 @@
 // (oracle/slam_ops_oracle.py restates it; tests compare bit for bit where torch's rounding is reproducible).
 #include "../../include/rtgs_slam.h"
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <float.h>
 #include <math.h>
 
@@ -73,16 +75,16 @@ __global__ void __launch_bounds__(1024) tile_threshold_kernel(const float* __res
   }
 }
 
-// top-k tiles by mean value: 4-pass MSB radix select of the k-th largest key in LDS, then ties in index order
-constexpr int TOPK_MAX = 16384;
+// top-k tiles by mean value: 4-pass MSB radix select of the k-th largest key, then ties in index order.  The keys are
+// recomputed from the tile sums on every pass (a few thousand L2-resident floats) instead of being cached in LDS: no
+// 64-KB static LDS block (which only gfx950 could hold) and no limit on the number of tiles.
 __global__ void __launch_bounds__(1024) tile_topk_kernel(const float* __restrict__ tile_sum, int ntiles, float area, int k,
                                                          int32_t* __restrict__ mask) {
-  __shared__ uint32_t s_key[TOPK_MAX];
   __shared__ uint32_t s_hist[256];
   __shared__ uint32_t s_scan[1024];
   __shared__ uint32_t s_prefix, s_k;
   const int tid = threadIdx.x;
-  for (int t = tid; t < ntiles; t += 1024) s_key[t] = enc_f(tile_sum[t] / area);
+  auto key_of = [&](int t) { return enc_f(tile_sum[t] / area); };
   if (tid == 0) { s_prefix = 0u; s_k = (uint32_t)k; }
   __syncthreads();
   if (k <= 0) { for (int t = tid; t < ntiles; t += 1024) mask[t] = 0; return; }
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(1024) tile_topk_kernel(const float* __restrict
     __syncthreads();
     const uint32_t prefix = s_prefix, himask = pass == 3 ? 0u : (0xffffffffu << (shift + 8));
     for (int t = tid; t < ntiles; t += 1024) {
-      const uint32_t key = s_key[t];
+      const uint32_t key = key_of(t);
       if ((key & himask) == prefix) atomicAdd(&s_hist[(key >> shift) & 0xffu], 1u);
     }
     __syncthreads();
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(1024) tile_topk_kernel(const float* __restrict
   const int per = (ntiles + 1023) / 1024;
   const int lo = min(ntiles, tid * per), hi = min(ntiles, lo + per);
   uint32_t ties = 0;
-  for (int t = lo; t < hi; ++t) ties += s_key[t] == kth ? 1u : 0u;
+  for (int t = lo; t < hi; ++t) ties += key_of(t) == kth ? 1u : 0u;
   s_scan[tid] = ties;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(1024) tile_topk_kernel(const float* __restrict
   }
   uint32_t rank = s_scan[tid] - ties;
   for (int t = lo; t < hi; ++t) {
-    const uint32_t key = s_key[t];
+    const uint32_t key = key_of(t);
     int on = key > kth ? 1 : 0;
     if (key == kth) { on = rank < take ? 1 : 0; ++rank; }
     mask[t] = on;
@@ -279,8 +281,8 @@ static KnnLayout knn_layout(int N) {
   L.sorted = off; off = al(off + n * sizeof(float4));
   L.boxes = off; off = al(off + ((n + KNN_BOX - 1) / KNN_BOX) * 6 * sizeof(float));
   size_t tb = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                           (uint32_t*)nullptr, (int)n, 0, 30);
+  (void)rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, n, 0u, 30u);
   L.cub_bytes = tb;
   L.cub = off; off = al(off + tb);
   L.total = off;
@@ -295,11 +297,14 @@ __global__ void __launch_bounds__(256) accumulate_error_kernel(int n, const floa
                                                                const int32_t* __restrict__ di, float thr_c, float thr_d,
                                                                float thr_n, float* __restrict__ g_c, float* __restrict__ g_d,
                                                                float* __restrict__ g_n, int32_t* __restrict__ outl,
-                                                               float* __restrict__ cnt_c, float* __restrict__ cnt_d) {
+                                                               float* __restrict__ cnt_c, float* __restrict__ cnt_d, int P) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool live = i < n;
-  const int ic = live ? ci[i] : -1, id = live ? di[i] : -1;
+  // indices outside [0, P) (stale index maps after a delete, or P passed as a subset count) are ignored like -1
+  int ic = live ? ci[i] : -1, id = live ? di[i] : -1;
+  if ((unsigned)ic >= (unsigned)P) ic = -1;
+  if ((unsigned)id >= (unsigned)P) id = -1;
   const float ec = live ? ce[i] : 0.f, ed = live ? de[i] : 0.f, en = live ? ne[i] : 0.f;
   unsigned long long todo = __builtin_amdgcn_ballot_w64(ic >= 0);
   while (todo) {
@@ -517,18 +522,26 @@ int rtgs_pixelmask2tilemask(const uint8_t* pixelmask, int32_t H, int32_t W, int3
   return 0;
 }
 
-int rtgs_colorerror2tilemask(const float* color_error, int32_t H, int32_t W, int32_t stride, float top_ratio,
-                             int32_t* tile_mask, float* tile_sum_scratch, void* stream) {
-  if (!tile_mask || !tile_sum_scratch) return -1;
+int rtgs_colorerror2tilemask_k(const float* color_error, int32_t H, int32_t W, int32_t stride, int32_t top_k,
+                               int32_t* tile_mask, float* tile_sum_scratch, void* stream) {
+  if (!tile_mask || !tile_sum_scratch || stride <= 0 || H <= 0 || W <= 0) return -1;
   const int nt = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
-  if (nt > TOPK_MAX) return -1;
   int rc = rtgs_tile_sum(color_error, 1, H, W, stride, tile_sum_scratch, stream);
   if (rc) return rc;
-  const int k = (int)((double)nt * (double)top_ratio);          // int(torch.numel(...) * top_ratio)
   hipLaunchKernelGGL(tile_topk_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)tile_sum_scratch, nt,
-                     (float)(stride * stride), k, tile_mask);
+                     (float)(stride * stride), (int)top_k, tile_mask);
   SLAM_TRY(hipGetLastError());
   return 0;
+}
+
+int rtgs_colorerror2tilemask(const float* color_error, int32_t H, int32_t W, int32_t stride, float top_ratio,
+                             int32_t* tile_mask, float* tile_sum_scratch, void* stream) {
+  if (stride <= 0 || H <= 0 || W <= 0) return -1;
+  const int nt = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
+  // NOTE: top_ratio crossed the ABI as float32; a caller that holds the ratio in double (the reference computes
+  // int(numel * top_ratio) in double: 0.7 -> 0.69999999f can lose one tile) should compute k itself and call _k
+  return rtgs_colorerror2tilemask_k(color_error, H, W, stride, (int32_t)((double)nt * (double)top_ratio), tile_mask,
+                                    tile_sum_scratch, stream);
 }
 
 int rtgs_render_range(const float* T_map, int32_t H, int32_t W, float ratio, uint8_t* render_mask, int32_t* tile_mask,
@@ -565,7 +578,7 @@ int rtgs_knn3(const float* points, int32_t N, float* mean_dist2, int32_t* idx, f
   hipLaunchKernelGGL(knn_bbox_kernel, dim3(g > 1024 ? 1024 : g), dim3(256), 0, st, points, N, bbox);
   hipLaunchKernelGGL(knn_morton_kernel, dim3(g), dim3(256), 0, st, points, N, (const uint32_t*)bbox, codes, order_in);
   size_t tb = L.cub_bytes;
-  SLAM_TRY(hipcub::DeviceRadixSort::SortPairs(s + L.cub, tb, codes, codes_sorted, order_in, order, N, 0, 30, st));
+  SLAM_TRY(rocprim::radix_sort_pairs(s + L.cub, tb, codes, codes_sorted, order_in, order, (size_t)N, 0u, 30u, st));
   const int nboxes = (N + KNN_BOX - 1) / KNN_BOX;
   hipLaunchKernelGGL(knn_gather_kernel, dim3(nboxes), dim3(256), 0, st, points, N, (const uint32_t*)order, sorted, boxes);
   hipLaunchKernelGGL(knn_search_kernel, dim3(g), dim3(256), 0, st, (const float4*)sorted, N, (const uint32_t*)order,
@@ -592,7 +605,7 @@ int rtgs_accumulate_error(int32_t H, int32_t W, int32_t P, const float* color_er
   const int n = H * W;
   hipLaunchKernelGGL(accumulate_error_kernel, dim3(grid1(n)), dim3(256), 0, st, n, color_err, depth_err, normal_err,
                      color_index, depth_index, thr_c, thr_d, thr_n, g_color, g_depth, g_normal, outlier_count, scratch,
-                     scratch + P);
+                     scratch + P, (int)P);
   if (mean)
     hipLaunchKernelGGL(error_mean_kernel, dim3(grid1(P)), dim3(256), 0, st, P, g_color, g_depth, g_normal,
                        (const float*)scratch, (const float*)(scratch + P));
@@ -634,8 +647,8 @@ int rtgs_frame_preprocess(const float* depth_in, int32_t H, int32_t W, const flo
 
 size_t rtgs_compact_scratch_bytes(int32_t n) {
   size_t tb = 0;
-  (void)hipcub::DeviceSelect::Flagged(nullptr, tb, hipcub::CountingInputIterator<int32_t>(0), (const uint8_t*)nullptr,
-                                      (int32_t*)nullptr, (int32_t*)nullptr, n > 0 ? n : 1);
+  (void)rocprim::select(nullptr, tb, rocprim::counting_iterator<int32_t>(0), (const uint8_t*)nullptr, (int32_t*)nullptr,
+                        (int32_t*)nullptr, (size_t)(n > 0 ? n : 1));
   return tb + 256;
 }
 
@@ -646,8 +659,8 @@ int rtgs_sample_candidates(const float* normal_map, const uint8_t* select_mask, 
   const int n = H * W;
   hipLaunchKernelGGL(sample_flags_kernel, dim3(grid1(n)), dim3(256), 0, st, normal_map, select_mask, n, flags_scratch);
   size_t tb = rtgs_compact_scratch_bytes(n) - 256;
-  SLAM_TRY(hipcub::DeviceSelect::Flagged(scratch, tb, hipcub::CountingInputIterator<int32_t>(0), (const uint8_t*)flags_scratch,
-                                         indices_out, count_out, n, st));
+  SLAM_TRY(rocprim::select(scratch, tb, rocprim::counting_iterator<int32_t>(0), (const uint8_t*)flags_scratch, indices_out,
+                           count_out, (size_t)n, st));
   SLAM_TRY(hipGetLastError());
   return 0;
 }

@@ -205,8 +205,20 @@ class IcpTracker:
                         persistent=self.persistent)
         host = out.cpu().numpy()                      # the single device->host copy of the frame
         if host[19] != 0:
-            raise RuntimeError("rtgs_icp_track: the persistent tracking kernel timed out at a grid barrier "
-                               "(set RTGS_ICP_PERSISTENT=0 to use one launch per Gauss-Newton iteration)")
+            # the persistent kernel needs all of its workgroups co-resident for its grid barrier; when another stream (the
+            # mapper) holds the CUs the bounded spin gives up - the pose was not touched, so take the track again with one
+            # launch per Gauss-Newton iteration instead of failing the frame
+            if not getattr(self, "_warned_persistent", False):
+                import warnings
+                warnings.warn("rtgs_icp_track: the persistent tracking kernel timed out at a grid barrier (device shared "
+                              "with another stream?); falling back to one launch per Gauss-Newton iteration")
+                self._warned_persistent = True
+            out = icp_track(self.vertex_pyramid_t1, self.normal_pyramid_t1, self.vertex_pyramid_t0,
+                            self.normal_pyramid_t0, K, self.icp_downscales, self.icp_downscale_iters,
+                            self.icp_distance_threshold, self.icp_normal_threshold, self.icp_damping, persistent=False)
+            host = out.cpu().numpy()
+            if host[19] != 0:
+                raise RuntimeError("rtgs_icp_track failed with and without the persistent kernel")
         pose_t1_t0 = host[:16].reshape(4, 4).copy()
         if host[18] != 0 or not np.isfinite(pose_t1_t0).all():
             # no valid correspondence at some iteration: J^T J = 0, the damped system H + trace(H) * damping * I stays

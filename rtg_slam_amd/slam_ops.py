@@ -72,8 +72,9 @@ def colorerror2tilemask(color_error: torch.Tensor, stride: int = 16, top_ratio: 
     out = torch.empty(gy, gx, dtype=torch.int32, device=dev)
     tmp = torch.empty(gy * gx, dtype=torch.float32, device=dev)
     err = color_error.float().contiguous()
+    k = int(gy * gx * top_ratio)        # in double, as the reference's int(torch.numel(...) * top_ratio) (SLAM/utils.py:708-734)
     with torch.cuda.device(dev):
-        rc = lib.rtgs_colorerror2tilemask(_p(err), H, W, int(stride), float(top_ratio), _p(out), _p(tmp), _stream(dev))
+        rc = lib.rtgs_colorerror2tilemask_k(_p(err), H, W, int(stride), k, _p(out), _p(tmp), _stream(dev))
     _lib.check(rc, "rtgs_colorerror2tilemask")
     return out
 
@@ -97,7 +98,9 @@ def render_range(T_map: torch.Tensor, tile_mask_ratio: float = 0.5):
 
 def distCUDA2(points: torch.Tensor, return_dist2: bool = False):
     """`simple_knn._C.distCUDA2` of RTG-SLAM's fork: (mean squared distance to the 3 nearest other points [N],
-    their indices [N,3] int32).  Exact."""
+    their indices [N,3] int32).  Exact.  With fewer than 4 points the missing neighbours come back as index -1 with
+    distance FLT_MAX (and the mean accordingly): a caller that indexes with the result, as gaussian_pointcloud.py:376-389
+    does, must not pass fewer than 4 points - a -1 would silently wrap to the last row."""
     lib, dev = _lib.load(), _dev(points)
     pts = points.float().contiguous()
     N = int(pts.shape[0])

@@ -12,6 +12,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+from tests import torch_doubles as td  # noqa: E402
 
 
 def _scene():
@@ -37,7 +38,7 @@ def _loss_fn(settings, gt):
 
     def fn(gd):
         out = ro.rasterize(settings, gd["xyz"], gd["opacity"], gd["shs"], gd["scales"], gd["rotations"], gd["normal"])
-        return mo.slam_losses(out, gt[0], gt[1])
+        return td.slam_losses(out, gt[0], gt[1])
     return fn
 
 
@@ -74,7 +75,7 @@ def _worker(rank, world, port, ret, rccl_branch=False):
     from rtg_slam_amd import map_optim as mo
     from tests.dist_util import adam_reference
     packed, views, gts = _scene()
-    opt = mo.ShardedMapOptimizer(packed, adam_fn=adam_reference, activate_fn=mo.activate8)
+    opt = mo.ShardedMapOptimizer(packed, adam_fn=adam_reference, activate_fn=td.activate8)
     if rccl_branch:
         _emulate_rccl_collectives()
         opt.backend = "nccl"
@@ -106,7 +107,7 @@ def test_sharded_step_matches_single_process(rccl_branch):
     lr = mo.default_lr_columns()
     for step in (1, 2):
         leaf = p.detach().clone().requires_grad_(True)
-        loss = _loss_fn(views[0], gts[0])(mo.activate(leaf)) + _loss_fn(views[1], gts[1])(mo.activate(leaf))
+        loss = _loss_fn(views[0], gts[0])(td.activate(leaf)) + _loss_fn(views[1], gts[1])(td.activate(leaf))
         (g,) = torch.autograd.grad(loss, leaf)
         adam_reference(p, g, m, v, lr, step, 1e-15)
     assert float((p0 - p).abs().max()) < 1e-5

@@ -15,6 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _setup(dev):
     import math
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from tests import torch_doubles as td
     from rtg_slam_amd import synth
     from rtg_slam_amd import map_optim as mo
     from rtg_slam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
@@ -36,7 +39,7 @@ def _setup(dev):
         def fn(gd, rast=rast, gt_c=gt_c, gt_d=gt_d):
             out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
                        rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=None)
-            return mo.slam_losses(out, gt_c, gt_d)
+            return td.slam_losses(out, gt_c, gt_d)
         fn.spec = (rs, gt_c, gt_d)
         fns.append(fn)
     return packed, fns
@@ -143,12 +146,16 @@ def _worker_band(rank, world, port, ret):
     rm = (torch.rand(H, W, generator=torch.Generator().manual_seed(9)) < 0.8).to(dev)
     tm = torch.ones((H + 15) // 16, (W + 15) // 16, dtype=torch.int32, device=dev)
     tm[0, 0] = 0
+    # a DIFFERENT bool render mask every other step (the reference optimises a random frame of its window per
+    # iteration, mapper.py:176-183): each becomes a fresh uint8 temporary inside step_slam, which the caching allocator
+    # may hand the same address - the band's loss mask must follow the content, not the pointer
+    rm2 = (torch.rand(H, W, generator=torch.Generator().manual_seed(10)) < 0.5).to(dev)
     opt = mo.ShardedMapOptimizer(packed)
     opt._row_capacity = 32                                          # far too small: the first exchange must overflow
     opt.begin_local_optimization()
     losses = []
-    for _ in range(3):
-        losses.append(float(opt.step_slam(rs, gt_c, gt_d, tm, render_mask=rm, tile_band=True)))
+    for i in range(4):
+        losses.append(float(opt.step_slam(rs, gt_c, gt_d, tm, render_mask=(rm2 if i % 2 else rm), tile_band=True)))
     band = opt.band_tile_mask(tm).cpu()
     ret[rank] = (opt.params.cpu(), losses, band, opt.overflow_redos, opt._row_capacity)
     dist.barrier()
@@ -179,9 +186,10 @@ def test_tile_band_split_of_one_view_and_overflow_redo():
     tm = torch.ones((H + 15) // 16, (W + 15) // 16, dtype=torch.int32, device=dev)
     tm[0, 0] = 0
     assert int((b0 | b1).sum()) == int(tm.sum())
+    rm2 = (torch.rand(H, W, generator=torch.Generator().manual_seed(10)) < 0.5).to(dev)
     ref = mo.ShardedMapOptimizer(packed)
     ref.begin_local_optimization()
-    lr = [float(ref.step_slam(rs, gt_c, gt_d, tm, render_mask=rm)) for _ in range(3)]
+    lr = [float(ref.step_slam(rs, gt_c, gt_d, tm, render_mask=(rm2 if i % 2 else rm))) for i in range(4)]
     for a, b in zip(l0, lr):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b))
     rp = ref.params.cpu()

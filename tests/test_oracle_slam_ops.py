@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import torch_doubles as td
+
 from oracle import slam_ops_oracle as so
 
 
@@ -120,8 +122,8 @@ def test_product_torch_loss_equals_the_oracle_restatement():
     gt_c = torch.rand(3, H, W, generator=g)
     gt_d = (depth + 0.3 * torch.randn(1, H, W, generator=g)).clamp_min(0)
     render = (color, depth, None, didx)
-    assert abs(float(mo.ssim(color, gt_c)) - float(so.ssim(color, gt_c))) < 1e-7
+    assert abs(float(td.ssim(color, gt_c)) - float(so.ssim(color, gt_c))) < 1e-7
     for rm in (None, torch.rand(H, W, generator=g) < 0.5):
-        a = mo.slam_losses(render, gt_c, gt_d, render_mask=rm)
+        a = td.slam_losses(render, gt_c, gt_d, render_mask=rm)
         b, _ = so.slam_loss(render, gt_c, gt_d, render_mask=rm)
         assert abs(float(a) - float(b)) < 1e-6

@@ -7,6 +7,8 @@ pretending it is zero."""
 import pytest
 import torch
 
+from tests import torch_doubles as td
+
 from rtg_slam_amd import synth
 from tests import raster_util as ru
 
@@ -177,7 +179,7 @@ def test_fused_activation_and_adam_match_torch():
     raw8 = packed[:, 51:59].contiguous()
     a = raw8.clone().requires_grad_(True)
     b = raw8.clone().requires_grad_(True)
-    ra, rb = mo.activate8(a), mo.activate8_hip(b)
+    ra, rb = td.activate8(a), mo.activate8_hip(b)
     gen = torch.Generator().manual_seed(1)
     la = lb = 0
     for k in ("opacity", "scales", "rotations", "normal"):
@@ -263,7 +265,7 @@ def test_fused_loss_matches_torch(masked, H, W):
     gt_d[0, ::5] = 0
     rm = (torch.rand(H, W, generator=gen) < 0.6).to(dev) if masked else None
     render = (color, depth, None, didx)
-    la = mo.slam_losses(render, gt_c, gt_d, render_mask=rm)
+    la = td.slam_losses(render, gt_c, gt_d, render_mask=rm)
     ga = torch.autograd.grad(la, [color, depth])
     lb = mo.slam_losses_hip(render, gt_c, gt_d, render_mask=rm)
     gb = torch.autograd.grad(lb * 2.0, [color, depth])
