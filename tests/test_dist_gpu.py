@@ -45,15 +45,26 @@ def _setup(dev):
     return packed, fns
 
 
+def _init(rank, world):
+    """RTGS_TEST_BACKEND=nccl: one rank per GPU over RCCL (needs >= `world` GPUs); default: gloo, both ranks on GPU 0."""
+    backend = os.environ.get("RTGS_TEST_BACKEND", "gloo")
+    if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        return torch.device("cuda", rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return torch.device("cuda", 0)
+
+
 def _worker(rank, world, port, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world)
     from rtg_slam_amd import map_optim as mo
-    dev = torch.device("cuda", 0)
     packed, fns = _setup(dev)
-    opt = mo.ShardedMapOptimizer(packed)          # HIP activations + HIP Adam, gloo collectives
+    opt = mo.ShardedMapOptimizer(packed)          # HIP activations + HIP Adam, gloo (or RCCL) collectives
     for _ in range(2):
         opt.step(fns[rank])
     ret[rank] = opt.params.cpu()
@@ -84,9 +95,8 @@ def _worker_slam(rank, world, port, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world)
     from rtg_slam_amd import map_optim as mo
-    dev = torch.device("cuda", 0)
     packed, fns = _setup(dev)
     opt = mo.ShardedMapOptimizer(packed)
     opt._row_capacity, opt._shrink_every = 1 << 16, 1              # far too large: must shrink (same steps on every rank)
@@ -137,9 +147,8 @@ def _worker_band(rank, world, port, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world)
     from rtg_slam_amd import map_optim as mo
-    dev = torch.device("cuda", 0)
     packed, fns = _setup(dev)
     rs, gt_c, gt_d = fns[0].spec                                    # ONE view, split into tile bands across the ranks
     H, W = gt_c.shape[1:]
@@ -196,3 +205,14 @@ def test_tile_band_split_of_one_view_and_overflow_redo():
     assert float(((p0 - rp).abs() > 2e-5).float().mean()) < 2e-3
     moved = (p0 - packed.cpu()).abs().max(dim=1).values > 0
     assert torch.equal(moved, (rp - packed.cpu()).abs().max(dim=1).values > 0)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="real RCCL needs two GPUs (the development lease has one)")
+def test_the_three_multi_gpu_forms_on_real_rccl(monkeypatch):
+    """The same three comparisons with backend "nccl" (= RCCL over xGMI), one rank per GPU: dense-sharded step,
+    sparse row exchange, tile-band split with overflow redo.  Skipped on a 1-GPU box; the driver's multi-GPU tier
+    runs it."""
+    monkeypatch.setenv("RTGS_TEST_BACKEND", "nccl")
+    test_two_ranks_one_gpu_match_single_process()
+    test_two_ranks_sparse_slam_step_matches_single_process()
+    test_tile_band_split_of_one_view_and_overflow_redo()

@@ -74,3 +74,34 @@ def test_trajectories_and_performance_json(tmp_path):
     d = json.load(open(str(tmp_path / "performance.json")))
     assert abs(d["mapping"] - 0.15) < 1e-12 and abs(d["fps"] - 1 / 0.15) < 1e-9 and d["gpu_memory"] == 1234.0
     assert abs(d["tracking"] - 0.1) < 1e-12
+
+
+def test_model_ply_bytes_equal_the_reference_writers_recipe(tmp_path):
+    """Byte for byte against the reference writer's own recipe (gaussian_pointcloud.py:424-466), re-enacted here without
+    `plyfile` (absent from this image): the attribute table is concatenated in its order (xyz, zero normals,
+    f_dc.transpose(1,2).flatten, f_rest.transpose(1,2).flatten, opacity, scaling, rotation, confidence), copied into a
+    structured array of ('name', 'f4') fields by `elements[:] = list(map(tuple, attributes))`, and serialised the way
+    plyfile's PlyData([PlyElement.describe(elements, 'vertex')]).write does for a native little-endian array: the
+    header lines `ply / format binary_little_endian 1.0 / element vertex N / property float <name> ... / end_header`
+    followed by elements.tobytes()."""
+    m = _model(33, seed=4)
+    xyz = m["xyz"].numpy()
+    normals = np.zeros_like(xyz)
+    f_dc = m["features_dc"].transpose(1, 2).flatten(start_dim=1).contiguous().numpy()
+    f_rest = m["features_rest"].transpose(1, 2).flatten(start_dim=1).contiguous().numpy()
+    for include_confidence in (True, False):
+        names = ["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(3)] + [f"f_rest_{i}" for i in range(45)]
+        names += ["opacity"] + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)]
+        cols = [xyz, normals, f_dc, f_rest, m["opacity"].numpy(), m["scaling"].numpy(), m["rotation"].numpy()]
+        if include_confidence:
+            names.append("confidence")
+            cols.append(m["confidence"].numpy())
+        attributes = np.concatenate(cols, axis=1)
+        elements = np.empty(xyz.shape[0], dtype=[(n, "f4") for n in names])
+        elements[:] = list(map(tuple, attributes))
+        header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % xyz.shape[0]
+        header += "".join(f"property float {n}\n" for n in names) + "end_header\n"
+        want = header.encode("ascii") + elements.tobytes()
+        p = str(tmp_path / f"m{int(include_confidence)}.ply")
+        io.save_model_ply(p, **m, include_confidence=include_confidence)
+        assert open(p, "rb").read() == want

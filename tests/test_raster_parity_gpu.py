@@ -195,3 +195,22 @@ def test_whole_image_parity_at_the_headline_size(name):
                                       grads[0], grads[1])
     _check_maps(out_h, out_o)
     _check_grads(gd_h, gd_o)
+
+
+@pytest.mark.parametrize("kind", ["volume", "surface"])
+def test_parity_at_config5_size(kind):
+    """BASELINE.json configs[4]'s map size on ONE GPU (the N = 1 anchor of the 1 -> 8 curve): 5 000 000 Gaussians,
+    1200x680, forward + backward against the oracle on a spread of 64 tiles (the oracle's per-Gaussian stage alone is
+    ~15 s of CPU at this size), volume generator and single-layer surface map."""
+    cam = synth.REPLICA
+    N = 5_000_000
+    g, s = ru.make_scene(N, cam, seed=2024)
+    if kind == "surface":
+        g = synth.surface_gaussians(N, cam, seed=7)
+    mask = _spread_mask(cam, 64)
+    grads = _grads(cam, 11)
+    out_o, gd_o, aux = ru.oracle_run(s, g, tile_mask=mask, grads=grads)
+    assert aux["num_rendered"] > 0
+    out_h, gd_h = ru.hip_run(s, g, tile_mask=mask, grads=grads)
+    _check_maps(out_h, out_o)
+    _check_grads(gd_h, gd_o)
