@@ -450,15 +450,25 @@ def reference_schedule_leg(cam, N, dev, cycles=3, iters=50, every=6, window=5, n
     rng = np.random.RandomState(5)
     lr = mo.default_lr_columns() * 1e-4          # as in the headline leg: random-ish targets must not inflate the map
     state = dict(params=packed, win=[], c2w=poses[0].clone(), iters=0)
+    prof = {} if os.environ.get("RTGS_SCHED_PROFILE") else None     # diagnosis only: per-stage wall time WITH syncs
+
+    def mark(name, t):
+        if prof is not None:
+            torch.cuda.synchronize(dev)
+            prof[name] = prof.get(name, 0.0) + (time.perf_counter() - t)
+        return time.perf_counter()
 
     def one_frame(fid):
         depth, color = frames[fid]
+        tm_ = time.perf_counter()
         fm = slam_ops.frame_preprocess(depth, K, 0.3, 8.0, False, 0.2)
+        tm_ = mark("frame_preprocess", tm_)
         tracker.update_curr_status(fm["depth_map"], K)
         if fid > 0:
             rel, _ = tracker.predict_pose({"K": K, "frame_id": fid})
             state["c2w"] = state["c2w"] @ torch.from_numpy(rel.astype(np.float64))
         tracker.move_last_status()
+        tm_ = mark("track", tm_)
         c2w = state["c2w"]
         Rw, tw = c2w[:3, :3].float().to(dev), c2w[:3, 3].float().to(dev)
         vertex_w = fm["vertex_map_c"] @ Rw.t() + tw
@@ -468,6 +478,7 @@ def reference_schedule_leg(cam, N, dev, cycles=3, iters=50, every=6, window=5, n
         pts, nrm, col = slam_ops.sample_pixels(vertex_w, normal_w, color.permute(1, 2, 0).contiguous(), n_new, None, gen)
         new = mo.pack_from_activated(ms.gaussians_from_pixels(pts, nrm, col))
         del new
+        tm_ = mark("gaussians_add", tm_)
         rs = ms.renderer_settings(renderer, view, dev)
         state["win"] = (state["win"] + [(rs, color, fm["depth_map"].permute(2, 0, 1).contiguous(), view)])[-window:]
         if (fid + 1) % every == 0 or fid == 0:
@@ -479,16 +490,19 @@ def reference_schedule_leg(cam, N, dev, cycles=3, iters=50, every=6, window=5, n
                     out = renderer.render(view_w, mo.activate_packed(opt.params))
                 rm, tm, _ = slam_ops.render_range(out["T_map"], 0.5)
                 masks.append((rm.to(torch.uint8), tm))
+            tm_ = mark("optimizer_setup_and_render_range", tm_)
             for it in range(iters):
                 j = len(state["win"]) - 1 if it > iters / 2 else int(rng.randint(0, len(state["win"])))
                 rs_w, col_w, dep_w, _ = state["win"][j]
                 opt.step_slam(rs_w, col_w, dep_w, masks[j][1], render_mask=masks[j][0])
             state["params"] = opt.params
             state["iters"] += iters
+            tm_ = mark("map_iterations", tm_)
         with torch.no_grad():                                                  # model depth / normals for the next track
             out = renderer.render(view, mo.activate_packed(state["params"]))
         tracker.update_last_status(None, out["depth"].permute(1, 2, 0).contiguous(), fm["depth_map"],
                                    out["normal"].permute(1, 2, 0).contiguous(), normal_w)
+        mark("model_render_for_tracker", tm_)
 
     for fid in range(every):                                                   # one untimed cycle
         one_frame(fid)
@@ -500,8 +514,12 @@ def reference_schedule_leg(cam, N, dev, cycles=3, iters=50, every=6, window=5, n
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     nf = n_frames - every
+    if prof is not None:
+        print("schedule leg, ms per frame by stage (with syncs):",
+              {k: round(1e3 * v / n_frames, 3) for k, v in prof.items()}, file=sys.stderr)
     err = float((state["c2w"][:3, 3] - poses[-1][:3, 3]).norm())
-    return {"frames_per_sec": round(nf / dt, 2), "ms_per_frame": round(1e3 * dt / nf, 3), "frames": nf,
+    from rtg_slam_amd.rasterizer import current_context
+    return {"frames_per_sec": round(nf / dt, 2), "speculation": current_context().speculation_stats(), "ms_per_frame": round(1e3 * dt / nf, 3), "frames": nf,
             "map_iterations": state["iters"] - it0, "iterations_per_frame": round((state["iters"] - it0) / nf, 2),
             "gaussians": N, "image": [cam.H, cam.W], "new_gaussians_per_frame_built": n_new, "window": window,
             "final_translation_error_m": round(err, 5),

@@ -22,9 +22,12 @@ import torch
 
 
 class TrackMapPipeline:
-    def __init__(self, device: torch.device, tracker_stream: Optional[torch.cuda.Stream] = None):
+    def __init__(self, device: torch.device, tracker_stream: Optional[torch.cuda.Stream] = None, tracker_priority: int = -1):
         self.device = torch.device(device)
-        self.tracker_stream = tracker_stream if tracker_stream is not None else torch.cuda.Stream(device=self.device)
+        # The tracker's kernels are short and sit on the frame's critical path (16 dependent launches); on a high-priority
+        # stream they are dispatched ahead of the mapper's queued workgroups instead of waiting behind them.
+        self.tracker_stream = (tracker_stream if tracker_stream is not None
+                               else torch.cuda.Stream(device=self.device, priority=tracker_priority))
         self._req: "queue.SimpleQueue[Optional[Callable[[], Any]]]" = queue.SimpleQueue()
         self._done: "queue.SimpleQueue[Any]" = queue.SimpleQueue()
         self._pending = 0

@@ -46,7 +46,7 @@ def rotmat_to_quat(R: torch.Tensor) -> torch.Tensor:
     w2 = torch.stack([R[:, 0, 2] - R[:, 2, 0], R[:, 0, 1] + R[:, 1, 0], q[:, 2], R[:, 1, 2] + R[:, 2, 1]], -1)
     w3 = torch.stack([R[:, 1, 0] - R[:, 0, 1], R[:, 0, 2] + R[:, 2, 0], R[:, 1, 2] + R[:, 2, 1], q[:, 3]], -1)
     cand = torch.stack([w0, w1, w2, w3], dim=1)                     # [P,4,4]
-    out = cand[torch.arange(R.shape[0]), k]
+    out = cand[torch.arange(R.shape[0], device=R.device), k]
     out = out / out.norm(dim=-1, keepdim=True)
     return torch.where(out[:, :1] < 0, -out, out)
 

@@ -57,7 +57,7 @@ def gaussians_from_pixels(points_w, normals_w, colors, min_radius=0.001, max_rad
     shs = torch.zeros(points_w.shape[0], 16, 3, device=points_w.device)
     shs[:, 0] = (colors - 0.5) / synth.SH_C0
     return dict(xyz=points_w.contiguous(), opacity=torch.full((points_w.shape[0], 1), 0.99, device=points_w.device),
-                scales=scales, rotations=synth.rotmat_to_quat(R.cpu().double()).float().to(points_w.device), shs=shs)
+                scales=scales, rotations=synth.rotmat_to_quat(R.double()).float(), shs=shs)     # on the device: no host round trip
 
 
 def run(cam, n_frames=8, iters_per_frame=10, first_frame_iters=30, samples_first=40000, samples_new=4000, seed=5,
