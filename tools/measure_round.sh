@@ -1,22 +1,30 @@
+# One gpurun call that produces everything profiles/ quotes for a round:
+#   bash tools/measure_round.sh r03            -> gpurun_out/r03/*
+# GPU tests, the default bench line, kernel traces (bench, map iteration of both scenes, ICP), gap traces, and the PMC
+# passes - FETCH_SIZE and WRITE_SIZE in separate runs (TCC slots), two SQ counter sets - each with --kernel-trace only.
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02b
+TAG=${1:-r03}
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest_gpu.txt
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
+  timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest_gpu.txt
+fi
 python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_bench -o bench -- python $R/bench.py --no-cpu-baseline > $O/ks_bench.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_head -o head -- python $R/tools/prof_raster.py headline 50 > $O/ks_head.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_surf -o surf -- python $R/tools/prof_raster.py surface 50 > $O/ks_surf.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f_head -o f -- python $R/tools/prof_raster.py headline 5 > $O/pmc_f_head.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w_head -o w -- python $R/tools/prof_raster.py headline 5 > $O/pmc_w_head.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f_surf -o f -- python $R/tools/prof_raster.py surface 5 > $O/pmc_f_surf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w_surf -o w -- python $R/tools/prof_raster.py surface 5 > $O/pmc_w_surf.log 2>&1
-cd $R
-find $O -name "*counter_collection.csv" | head
-python tools/traffic_from_pmc.py $(find $O/pmc_f_head -name "*counter_collection.csv") $(find $O/pmc_w_head -name "*counter_collection.csv") $O/traffic_head.json
-python tools/traffic_from_pmc.py $(find $O/pmc_f_surf -name "*counter_collection.csv") $(find $O/pmc_w_surf -name "*counter_collection.csv") $O/traffic_surf.json
-# keep the merge small: drop raw traces
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_bench -o bench -- python $R/bench.py --no-cpu-baseline --no-schedule > $O/ks_bench.log 2>&1
+for w in headline surface; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$w -o k -- python $R/tools/prof_raster.py $w 50 > $O/ks_$w.log 2>&1
+  python $R/tools/gap_trace.py $(find $O/ks_$w -name "*kernel_trace.csv" | head -1) map_tail_rows 25 > $O/gaps_$w.txt
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f_$w -o f -- python $R/tools/prof_raster.py $w 5 > $O/pmc_f_$w.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w_$w -o w -- python $R/tools/prof_raster.py $w 5 > $O/pmc_w_$w.log 2>&1
+  python $R/tools/traffic_from_pmc.py $(find $O/pmc_f_$w -name "*counter_collection.csv" | head -1) $(find $O/pmc_w_$w -name "*counter_collection.csv" | head -1) $O/traffic_$w.json > $O/traffic_$w.txt
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_icp -o k -- python $R/tools/prof_icp.py replica 40 > $O/ks_icp.log 2>&1
+bash $R/tools/r3_pmc_sq.sh $TAG/sq > $O/pmc_sq.log 2>&1
+python $R/tools/valu_from_pmc.py $O/sq/pmc_sq_surface.csv $O/sq/pmc_sq_headline.csv $O/valu.json
+for w in headline surface; do python $R/tools/pmc_summary.py $O/sq/pmc_sq_$w.csv > $O/sq_summary_$w.txt; done
+# keep the merge small: raw traces out, the --stats tables stay
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete
-cat $O/pytest_gpu.txt; tail -c 600 $O/bench.json; du -sh $O
+cat $O/pytest_gpu.txt; tail -c 800 $O/bench.json; cat $O/gaps_headline.txt | head -3; cat $O/gaps_surface.txt | head -3; du -sh $O
