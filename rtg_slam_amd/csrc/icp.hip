@@ -87,6 +87,109 @@ __global__ void __launch_bounds__(256) icp_vertex_kernel(PyrDesc d, const float*
   if (threadIdx.x < 2 * d.levels && s_mm[threadIdx.x] != 0xffffffffu) atomicMin(&sc->minmax[threadIdx.x], s_mm[threadIdx.x]);
 }
 
+// ---- K10, three levels in ONE pass: a lane owns a 4x4 block of the full-resolution depth (four 16-B row loads when the
+// width allows) and writes its 16 full-resolution vertices, its four half-resolution ones and its quarter-resolution
+// one - the depth image is read once instead of three times with 16-/4-element strided loops, and the stores of a lane
+// are 48-byte runs.  Same arithmetic as icp_vertex_kernel (max is exact in any order), same min / max reduction.
+__device__ __forceinline__ void vertex_of(float* __restrict__ out, int x, int y, float d, float fx, float fy, float cx, float cy) {
+  out[0] = (((float)x - cx) / fx) * d;
+  out[1] = (((float)y - cy) / fy) * d;
+  out[2] = d;
+}
+__global__ void __launch_bounds__(256) icp_vertex3_kernel(PyrDesc d, const float* __restrict__ depth,
+                                                          const float* __restrict__ K, Scratch* sc) {
+  __shared__ uint32_t s_mm[6];
+  if (threadIdx.x < 6) s_mm[threadIdx.x] = 0xffffffffu;
+  __syncthreads();
+  const int H = d.H, W = d.W, bw = (W + 3) >> 2, bh = (H + 3) >> 2;
+  const int H1 = d.Hl[1], W1 = d.Wl[1], H0 = d.Hl[0], W0 = d.Wl[0];
+  uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mxi[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+  for (int b = blockIdx.x * 256 + (int)threadIdx.x; b < bw * bh; b += gridDim.x * 256) {
+    const int by = b / bw, bx = b % bw;
+    const int x0 = bx * 4, y0 = by * 4;
+    float t[4][4];
+    const bool full = (x0 + 4 <= W) && (y0 + 4 <= H);
+    if (full && (W & 3) == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float4 r = *reinterpret_cast<const float4*>(depth + (size_t)(y0 + a) * W + x0);
+        t[a][0] = r.x; t[a][1] = r.y; t[a][2] = r.z; t[a][3] = r.w;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          t[a][c] = (y0 + a < H && x0 + c < W) ? depth[(size_t)(y0 + a) * W + (x0 + c)] : -INFINITY;
+    }
+    // level 2 (full resolution): K * 1
+    {
+      const float ds = 1.f / (float)1;
+      const float fx = K[0] * ds, fy = K[4] * ds, cx = K[2] * ds, cy = K[5] * ds;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        if (y0 + a >= H) continue;
+        float* row = d.vertex[2] + ((size_t)(y0 + a) * W + x0) * 3;
+        float o[12];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vertex_of(o + 3 * c, x0 + c, y0 + a, t[a][c], fx, fy, cx, cy);
+        if (full && (W & 3) == 0) {
+          float4* r4 = reinterpret_cast<float4*>(row);
+          r4[0] = make_float4(o[0], o[1], o[2], o[3]); r4[1] = make_float4(o[4], o[5], o[6], o[7]);
+          r4[2] = make_float4(o[8], o[9], o[10], o[11]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (x0 + c < W) { row[3 * c] = o[3 * c]; row[3 * c + 1] = o[3 * c + 1]; row[3 * c + 2] = o[3 * c + 2]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (x0 + c < W) { const uint32_t e = enc_f(t[a][c]); mn[2] = min(mn[2], e); mxi[2] = min(mxi[2], ~e); }
+      }
+    }
+    // level 1 (MaxPool 2x2, floor mode): K * 0.5
+    float h[2][2];
+    {
+      const float ds = 1.f / (float)2;
+      const float fx = K[0] * ds, fy = K[4] * ds, cx = K[2] * ds, cy = K[5] * ds;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float m = -INFINITY;
+          m = fmaxf(m, t[2 * j][2 * i]); m = fmaxf(m, t[2 * j][2 * i + 1]);
+          m = fmaxf(m, t[2 * j + 1][2 * i]); m = fmaxf(m, t[2 * j + 1][2 * i + 1]);
+          h[j][i] = m;
+          const int y1 = 2 * by + j, x1 = 2 * bx + i;
+          if (y1 < H1 && x1 < W1) {
+            vertex_of(d.vertex[1] + ((size_t)y1 * W1 + x1) * 3, x1, y1, m, fx, fy, cx, cy);
+            const uint32_t e = enc_f(m); mn[1] = min(mn[1], e); mxi[1] = min(mxi[1], ~e);
+          }
+        }
+    }
+    // level 0 (MaxPool 4x4): K * 0.25
+    if (by < H0 && bx < W0) {
+      const float ds = 1.f / (float)4;
+      const float fx = K[0] * ds, fy = K[4] * ds, cx = K[2] * ds, cy = K[5] * ds;
+      const float m = fmaxf(fmaxf(h[0][0], h[0][1]), fmaxf(h[1][0], h[1][1]));
+      vertex_of(d.vertex[0] + ((size_t)by * W0 + bx) * 3, bx, by, m, fx, fy, cx, cy);
+      const uint32_t e = enc_f(m); mn[0] = min(mn[0], e); mxi[0] = min(mxi[0], ~e);
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    uint32_t a = mn[l], bq = mxi[l];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a = min(a, (uint32_t)__shfl_xor((int)a, off));
+      bq = min(bq, (uint32_t)__shfl_xor((int)bq, off));
+    }
+    if ((threadIdx.x & 63) == 0 && a != 0xffffffffu) { atomicMin(&s_mm[2 * l], a); atomicMin(&s_mm[2 * l + 1], bq); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6 && s_mm[threadIdx.x] != 0xffffffffu) atomicMin(&sc->minmax[threadIdx.x], s_mm[threadIdx.x]);
+}
+
 // ---- K11: Sobel normals (SLAM/utils.py:77-122): replicate pad, cross(dy, dx), / (|n| + 1e-8),
 //      zero where depth <= min or depth >= max --------------------------------------------------
 __global__ void __launch_bounds__(256) icp_normal_kernel(PyrDesc d, const Scratch* sc) {
@@ -698,7 +801,12 @@ int rtgs_icp_build_pyramids(const float* depth, int32_t H, int32_t W, const floa
   }
   d.block_start[levels] = blocks;
   ICP_TRY(hipMemsetAsync(sc->minmax, 0xff, sizeof(sc->minmax), st));
-  hipLaunchKernelGGL(icp_vertex_kernel, dim3(blocks < 512 ? blocks : 512), dim3(256), 0, st, d, depth, K, sc);
+  if (levels == 3) {        // the shipped configuration (icp_downscales [0.25, 0.5, 1.0]): all three levels in one pass
+    const int nb = ((H + 3) / 4) * ((W + 3) / 4);
+    hipLaunchKernelGGL(icp_vertex3_kernel, dim3(grid_for(nb)), dim3(256), 0, st, d, depth, K, sc);
+  } else {
+    hipLaunchKernelGGL(icp_vertex_kernel, dim3(blocks < 512 ? blocks : 512), dim3(256), 0, st, d, depth, K, sc);
+  }
   hipLaunchKernelGGL(icp_normal_kernel, dim3(blocks), dim3(256), 0, st, d, (const Scratch*)sc);
   ICP_TRY(hipGetLastError());
   return 0;
@@ -763,7 +871,10 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
   }
   for (int l = 0; l < n_levels; ++l) {
     const rtgs_icp_level& L = lv[l];
-    const int g = grid_for(L.H * L.W);
+    // a lane takes FOUR pixels (accumulate_range): one workgroup per 1024 pixels - at the coarse levels that is 50 / 200
+    // workgroups instead of 200 / 512 with three lanes in four idle, and as many fewer tickets and partial rows for the
+    // last arriver to collect
+    const int g = grid_for((L.H * L.W + 3) / 4);
     const float inv = 1.f / ((float)L.H * (float)L.W);
     FinalArgs fa{(int)MODE_SOLVE, damping, inv, pose, stats, nullptr, nullptr, nullptr};
     for (int it = 0; it < L.iters; ++it)   // ONE launch per Gauss-Newton iteration: residuals + solve + pose update

@@ -245,3 +245,22 @@ def test_frame_without_correspondences_raises_like_the_reference(persistent):
     tr.update_curr_status(d0.to(DEV), K.to(DEV))
     pose, ok = tr.predict_pose({"K": K.to(DEV), "frame_id": 2})
     assert np.isfinite(pose).all()
+
+
+@pytest.mark.parametrize("H,W", [(101, 135), (98, 130), (97, 128), (64, 66)])
+def test_pyramids_on_sizes_that_are_not_multiples_of_four(H, W):
+    """The one-pass three-level vertex kernel (a lane per 4x4 block) on ragged sizes: MaxPool2d floor mode drops the odd
+    rows / columns at the coarse levels while the full-resolution level keeps every pixel - bit-identical to the pinned
+    oracle (itself bit-identical to the reference's pyramids, tests/test_oracle_icp.py)."""
+    from rtg_slam_amd import icp
+    cam = synth.CameraSpec(H, W, 120.0, 118.0, (W - 1) / 2.0, (H - 1) / 2.0)
+    base = synth.look_at_pose(seed=5, max_angle_deg=5, max_trans=0.3)
+    d = synth.tum_noise(synth.box_room_depth(cam, base), 3)
+    K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32)
+    vp = io.vertex_pyramid(d, K.clone(), 3)
+    npyr = io.normal_pyramid(vp)
+    hv, hn = icp.build_pyramids(d.to(DEV), K.to(DEV), 3)
+    for l in range(3):
+        assert hv[l].shape == vp[l].shape
+        assert torch.equal(hv[l].cpu(), vp[l]), l
+        assert torch.equal(hn[l].cpu(), npyr[l]), l
