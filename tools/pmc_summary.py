@@ -16,7 +16,7 @@ def main():
     d = load(sys.argv[1])
     for k in (sys.argv[2:] or sorted(d)):
         c = d[k]
-        if "SQ_INSTS_VALU" not in c or "SQ_THREAD_CYCLES_VALU" not in c:
+        if not c.get("SQ_INSTS_VALU") or not c.get("SQ_ACTIVE_INST_VALU") or "SQ_THREAD_CYCLES_VALU" not in c:
             continue
         # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md); 1024 SIMDs, 32 SEs
         act = c["SQ_ACTIVE_INST_VALU"] * 4 / 1024
