@@ -207,10 +207,12 @@ def test_parity_at_config5_size(kind):
     g, s = ru.make_scene(N, cam, seed=2024)
     if kind == "surface":
         g = synth.surface_gaussians(N, cam, seed=7)
+    from oracle import raster_oracle_fast as rf
     mask = _spread_mask(cam, 64)
     grads = _grads(cam, 11)
-    out_o, gd_o, aux = ru.oracle_run(s, g, tile_mask=mask, grads=grads)
-    assert aux["num_rendered"] > 0
+    out_o, gd_o = rf.forward_backward(s, g["xyz"], g["opacity"], g["shs"], g["scales"], g["rotations"], g["normal"], mask,
+                                      grads[0], grads[1])
+    assert float(out_o[6].min()) < 1.0          # something was rendered
     out_h, gd_h = ru.hip_run(s, g, tile_mask=mask, grads=grads)
     _check_maps(out_h, out_o)
     _check_grads(gd_h, gd_o)

@@ -1,2 +1,2 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r03
-python bench.py > gpurun_out/r03/bench_final.json 2> gpurun_out/r03/bench_final.err; tail -c 600 gpurun_out/r03/bench_final.json
+cd $GRAFT_REPO_ROOT
+timeout 1800 python -m pytest tests -m gpu -q --durations=25 2>&1 | tail -40
