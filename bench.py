@@ -330,8 +330,9 @@ def main():
         traffic, valu = None, None
         src = source_hash()
         dom_pmc = {"blend_bwd": "blend_bwd_strip", "near_slice_blend_fwd": "blend_fwd"}.get(dom, dom)
+        same_workload = N == 1_200_000 and not args.surface_map       # the PMC passes ran the default headline workload
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):     # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes
+        if same_workload and os.path.exists(tpath):     # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes
             try:
                 tj = json.load(open(tpath))
                 if tj.get("_source_sha16") == src:
@@ -339,7 +340,7 @@ def main():
             except Exception:
                 traffic = None
         vpath = os.path.join(ROOT, "profiles", "valu_latest.json")
-        if os.path.exists(vpath):     # SQ_INSTS_VALU per launch of the dominant kernel (tools/pmc_sq.py)
+        if same_workload and os.path.exists(vpath):     # SQ_INSTS_VALU per launch of the dominant kernel (tools/pmc_sq.py)
             try:
                 vj = json.load(open(vpath))
                 if vj.get("_source_sha16") == src and dom_pmc in vj:
@@ -361,7 +362,8 @@ def main():
                     "note": "achieved / peak / frac are the HBM roofline north_star asks for (algorithmic bytes over the live "
                             "launch time); `bound` names what the SQ counters say limits the kernel - VALU issue when the "
                             "`valu` block is present and its fraction exceeds the HBM one.  traffic / valu are null when "
-                            "profiles/*_latest.json were not measured on the current kernel sources", "source_sha16": src}
+                            "profiles/*_latest.json were not measured on the current kernel sources or the workload is not "
+                            "the default one", "source_sha16": src}
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
