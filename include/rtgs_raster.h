@@ -339,7 +339,7 @@ int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const float* g_opaci
  *            threshold is on the signed error as written there; an empty set contributes 0 where torch gives nan)
  *   ssim   = 1 - mean SSIM(C, C_gt), 11x11 Gaussian window, sigma 1.5, zero padding (utils/loss_utils.py:58-100)
  *   total  = depth_weight depth + color_weight colour + ssim_weight ssim
- * The normal term (normal_weight, 0 in every shipped config) is not part of this kernel.
+ * The normal term (normal_weight, 0 in every shipped config) is not part of this kernel: rtgs_slam_normal_loss.
  * loss_out4: device float[4] = {total, colour, depth, ssim}.  scratch: rtgs_slam_loss_scratch_bytes(H, W, with_ssim). */
 typedef struct rtgs_loss_cfg {
   float color_weight, depth_weight, ssim_weight, add_depth_thres;
@@ -400,7 +400,19 @@ typedef struct rtgs_map_step_args {
   rtgs_resize_fn geom_resize; void* geom_user;
   rtgs_resize_fn binning_resize; void* binning_user;
   rtgs_resize_fn image_resize; void* image_user;
+  /* The normal term of loss_update (mapper.py:433-442; normal_weight is 0 in every shipped config): when
+   * normal_weight > 0 and gt_normal != NULL, total += normal_weight * mean over {render mask & depth_index != -1 &
+   * gt normal not all-zero} of 1 - cosine_similarity(normal of the pixel's depth owner, gt normal), and its gradient
+   * is added to the owners' d_normal rows (rtgs_slam_normal_loss below) between the rasterizer backward and the tail. */
+  float normal_weight;
+  const float* gt_normal;                                 /* [H,W,3] world normals of the frame (image_input["normal_map"]) */
 } rtgs_map_step_args;
+/* The normal term on its own: value added to loss4[0], gradient added to d_normal[owner] with the row marked live in
+ * row_state (nullable: dense gradients) - a row that carried no gradient is all-zero by the arena's invariant, so marking
+ * it keeps the invariant.  scratch: 2 floats.  skip_flag (nullable): non-zero = do nothing (speculative forward). */
+int rtgs_slam_normal_loss(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
+                          const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight, float* scratch2,
+                          float* loss_out4, float* d_normal, uint8_t* row_state, const uint32_t* skip_flag, void* stream);
 int rtgs_slam_map_step(const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
 /* The same call without its last stage (rtgs_map_tail_rows): the gradient rows of this rank's view are in the arena,
  * nothing has been stepped.  Multi-GPU callers exchange the rows (below) before they run the tail. */

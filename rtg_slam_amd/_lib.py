@@ -77,7 +77,8 @@ class MapStepArgsC(C.Structure):
         + [("step", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
         + [("attach", C.POINTER(AttachC)), ("confidence", C.c_void_p), ("activated_valid", C.c_int32)]
         + [("geom_resize", RESIZE_FN), ("geom_user", C.c_void_p), ("binning_resize", RESIZE_FN),
-           ("binning_user", C.c_void_p), ("image_resize", RESIZE_FN), ("image_user", C.c_void_p)])
+           ("binning_user", C.c_void_p), ("image_resize", RESIZE_FN), ("image_user", C.c_void_p)]
+        + [("normal_weight", C.c_float), ("gt_normal", C.c_void_p)])
 
 
 _SIGNATURES = {
@@ -112,6 +113,7 @@ _SIGNATURES = {
     "rtgs_raster_settings_size": (C.c_size_t, []),
     "rtgs_slam_map_step": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_slam_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(LossCfgC), _P, _P, _P, _P, _P]),
+    "rtgs_slam_normal_loss": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P, _P, _P]),
     "rtgs_slam_loss_sums": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(LossCfgC), _P, _P]),
     "rtgs_slam_loss_grads": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(LossCfgC), _P, _P, _P, _P, _P]),
     "rtgs_raster_set_profiling": (None, [C.c_int]),

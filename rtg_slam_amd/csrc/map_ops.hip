@@ -537,7 +537,7 @@ extern "C" int rtgs_rows_apply(const float* list, int32_t capacity, int32_t mode
 //                 of an empty selection is nan)
 //   ssim       = 1 - mean(ssim_map), 11x11 Gaussian window sigma 1.5, zero padding (utils/loss_utils.py:58-100)
 //   total      = depth_weight depth + color_weight colour + ssim_weight ssim
-// (normal_weight is 0 in every shipped config, configs/base.yaml:81: the normal term is left to the autograd path.)
+// (normal_weight is 0 in every shipped config, configs/base.yaml:81: the normal term is its own pair of kernels below.)
 // Launches: block partial sums -> a few device atomics; [SSIM forward: per-pixel statistics and the three derivative
 // maps]; gradients (+ SSIM backward: the derivative maps convolved with the same window).
 // ---------------------------------------------------------------------------------------------
@@ -849,4 +849,91 @@ extern "C" int rtgs_slam_loss(const float* color, const float* depth, const int3
   if (rc != 0) return rc;
   return rtgs_slam_loss_grads(color, depth, depth_index, gt_color, gt_depth, H, W, cfg, scratch, loss_out4, g_color, g_depth,
                               stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The normal term of Mapping.loss_update (mapper.py:433-442): 1 - F.cosine_similarity(render normal, gt normal) averaged
+// over {render mask & depth_index != -1 & gt normal not all-zero}; the render normal of a pixel is the world normal of
+// the Gaussian that owns its depth (render.py:130-133), so the gradient goes to that Gaussian's d_normal row.
+// ---------------------------------------------------------------------------------------------
+namespace rtgs {
+
+__device__ __forceinline__ bool normal_pixel(const float* __restrict__ normal_w, const int32_t* __restrict__ didx,
+                                             const float* __restrict__ gtn, const uint8_t* __restrict__ mask, int64_t i,
+                                             int& owner, float (&n)[3], float (&g)[3]) {
+  owner = didx[i];
+  if (owner < 0 || (mask && mask[i] == 0)) return false;
+  g[0] = gtn[3 * i]; g[1] = gtn[3 * i + 1]; g[2] = gtn[3 * i + 2];
+  if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f) return false;
+  n[0] = normal_w[3 * (int64_t)owner]; n[1] = normal_w[3 * (int64_t)owner + 1]; n[2] = normal_w[3 * (int64_t)owner + 2];
+  return true;
+}
+
+__global__ void __launch_bounds__(256) normal_loss_sums_kernel(const float* __restrict__ normal_w, const int32_t* __restrict__ didx,
+                                                               const float* __restrict__ gtn, const uint8_t* __restrict__ mask,
+                                                               int64_t hw, float* __restrict__ sums2,
+                                                               const uint32_t* __restrict__ skip) {
+  if (skip && skip[0] != 0u) return;
+  float s = 0.f, c = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+    int owner; float n[3], g[3];
+    if (!normal_pixel(normal_w, didx, gtn, mask, i, owner, n, g)) continue;
+    // F.cosine_similarity(dim=-1, eps=1e-8): x1 . x2 / (max(|x1|, eps) * max(|x2|, eps))
+    const float nn = fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-8f);
+    const float gg = fmaxf(sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), 1e-8f);
+    s += 1.f - (n[0] * g[0] + n[1] * g[1] + n[2] * g[2]) / (nn * gg);
+    c += 1.f;
+  }
+  s = wave_sum_shfl(s); c = wave_sum_shfl(c);
+  __shared__ float sh[2][4];
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(&sums2[0], (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]));
+    unsafeAtomicAdd(&sums2[1], (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]));
+  }
+}
+
+__global__ void __launch_bounds__(256) normal_loss_grads_kernel(const float* __restrict__ normal_w, const int32_t* __restrict__ didx,
+                                                                const float* __restrict__ gtn, const uint8_t* __restrict__ mask,
+                                                                int64_t hw, float weight, const float* __restrict__ sums2,
+                                                                float* __restrict__ loss4, float* __restrict__ d_normal,
+                                                                uint8_t* __restrict__ row_state,
+                                                                const uint32_t* __restrict__ skip) {
+  if (skip && skip[0] != 0u) return;
+  const float cnt = fmaxf(sums2[1], 1.f);                         // an empty set gives 0 (nan in the reference)
+  if (blockIdx.x == 0 && threadIdx.x == 0) loss4[0] += weight * (sums2[0] / cnt);
+  const float k = weight / cnt;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+    int owner; float n[3], g[3];
+    if (!normal_pixel(normal_w, didx, gtn, mask, i, owner, n, g)) continue;
+    const float nr = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), gr = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    const float nn = fmaxf(nr, 1e-8f), gg = fmaxf(gr, 1e-8f);
+    const float dot = n[0] * g[0] + n[1] * g[1] + n[2] * g[2];
+    // d/dn of -(n . g) / (nn gg), nn = max(|n|, eps): the norm term only where it is not clamped
+    const float a = 1.f / (nn * gg), b = nr > 1e-8f ? dot / (nn * nn * nn * gg) : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) unsafeAtomicAdd(&d_normal[3 * (int64_t)owner + c], -k * (g[c] * a - n[c] * b));
+    if (row_state && row_state[owner] != 1) row_state[owner] = 1;   // idempotent; the row was all-zero (arena invariant)
+  }
+}
+
+}  // namespace rtgs
+
+extern "C" int rtgs_slam_normal_loss(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
+                                     const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight, float* scratch2,
+                                     float* loss_out4, float* d_normal, uint8_t* row_state, const uint32_t* skip_flag,
+                                     void* stream) {
+  if (!normal_w || !depth_index || !gt_normal || !scratch2 || !loss_out4 || !d_normal || H <= 0 || W <= 0) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t hw = (int64_t)H * W;
+  int blocks = (int)((hw + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (hipMemsetAsync(scratch2, 0, 2 * sizeof(float), st) != hipSuccess) return -2;
+  hipLaunchKernelGGL(rtgs::normal_loss_sums_kernel, dim3(blocks), dim3(256), 0, st, normal_w, depth_index, gt_normal, render_mask,
+                     hw, scratch2, skip_flag);
+  hipLaunchKernelGGL(rtgs::normal_loss_grads_kernel, dim3(blocks), dim3(256), 0, st, normal_w, depth_index, gt_normal,
+                     render_mask, hw, normal_weight, (const float*)scratch2, loss_out4, d_normal, row_state, skip_flag);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }

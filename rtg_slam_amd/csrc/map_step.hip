@@ -36,7 +36,16 @@ static int map_step_front(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* n
                                  a->rotations, a->normal, geom, bin, img, a->out_color, a->out_T, a->out_depth_index,
                                  a->dL_dcolor, a->dL_ddepth, a->d_xyz, a->d_opacity, a->d_shs, a->d_scales,
                                  a->d_rotations, a->d_normal, a->grad_scratch, a->row_state, stream);
-  return rc;
+  if (rc != RTGS_OK) return rc;
+  if (a->normal_weight > 0.f && a->gt_normal) {
+    // the normal term (mapper.py:433-442): value into loss4[0], gradient into the depth owners' d_normal rows; the two
+    // floats it needs are words 5-6 of the loss scratch's 8-float header (the image loss uses 0-4 and is done by now)
+    rc = rtgs_slam_normal_loss(a->normal, a->out_depth_index, a->gt_normal, a->loss.render_mask, H, W, a->normal_weight,
+                               reinterpret_cast<float*>(a->loss_scratch) + 5, a->loss4, a->d_normal, a->row_state,
+                               rtgs_raster_spec_fail_ptr_ctx(ctx), stream);
+    if (rc != 0) return RTGS_E_HIP;
+  }
+  return RTGS_OK;
 }
 
 extern "C" int rtgs_slam_map_step_front_ctx(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* num_rendered_host,

@@ -284,7 +284,8 @@ class ShardedMapOptimizer:
                   tile_mask: Optional[torch.Tensor] = None, color_weight: float = 0.8,
                   depth_weight: float = 1.0, ssim_weight: float = 0.2, add_depth_thres: float = 0.1,
                   render_mask: Optional[torch.Tensor] = None, confidence: Optional[torch.Tensor] = None,
-                  tile_band: bool = False) -> torch.Tensor:
+                  tile_band: bool = False, normal_weight: float = 0.0,
+                  gt_normal: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One iteration with the built-in SLAM loss (`slam_losses`): identical kernels and results as
         `step(lambda gd: slam_losses_hip(render(gd), gt_color, gt_depth))`, but enqueued by a single C call
         (`rtgs_slam_map_step`) - no autograd graph, no per-launch Python.  With more than one rank the map and the
@@ -303,7 +304,7 @@ class ShardedMapOptimizer:
                 out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], scales=gd["scales"],
                            rotations=gd["rotations"], normal_w=gd["normal"], tile_mask=tile_mask)
                 return slam_losses_hip(out, gt_color, gt_depth, color_weight, depth_weight, ssim_weight, add_depth_thres,
-                                       render_mask)
+                                       render_mask, normal_weight if gt_normal is not None else 0.0, gd["normal"], gt_normal)
             return self.step(loss_fn)
         lib = _lib.load()
         rs = raster_settings
@@ -340,6 +341,15 @@ class ShardedMapOptimizer:
             tile_mask = ws["ones"]
         tile_mask = tile_mask.to(device=dev, dtype=torch.int32).contiguous()
         gt_color, gt_depth = gt_color.contiguous(), gt_depth.contiguous()
+        if normal_weight > 0 and gt_normal is not None:
+            # the normal term (mapper.py:433-442) runs inside the one-call step on one GPU; the multi-GPU forms exchange
+            # gradient rows before the tail and do not carry it yet
+            if self.world > 1:
+                raise RuntimeError("step_slam(normal_weight > 0) is single-GPU; use step(loss_fn) with slam_losses_hip(..., "
+                                   "normal_weight=...) on several ranks")
+            gt_normal = gt_normal.to(device=dev, dtype=torch.float32).contiguous()      # [H, W, 3]
+        else:
+            gt_normal = None
         rm = None if render_mask is None else (render_mask if render_mask.dtype == torch.uint8 else (render_mask != 0).to(torch.uint8)).contiguous()
         need = lib.rtgs_slam_loss_scratch_bytes(H, W, int(rm is None))
         if ws["loss_scratch"] is None or ws["loss_scratch"].numel() < need:
@@ -364,7 +374,8 @@ class ShardedMapOptimizer:
             P(ad["raw8"]["v"]), P(st["xyz"]["lr"]), P(st["shs"]["lr"]), P(st["raw8"]["lr"]), P(ad["xyz"]["ever"]),
             P(ad["shs"]["ever"]), P(ad["raw8"]["ever"]), int(self.step_count), 0.9, 0.999, float(self.eps),
             C.pointer(attach) if attach is not None else None, P(confidence) if confidence is not None else None,
-            int(self._act_valid), geom.cb, None, binning.cb, None, img.cb, None)
+            int(self._act_valid), geom.cb, None, binning.cb, None, img.cb, None,
+            float(normal_weight) if gt_normal is not None else 0.0, P(gt_normal) if gt_normal is not None else None)
         R = C.c_int64(0)
         stream = torch.cuda.current_stream(dev).cuda_stream
         if tile_band and self.world > 1:

@@ -674,3 +674,44 @@ def test_normal_loss_term_matches_oracle():
         (g_ref,) = torch.autograd.grad(0.3 * terms["normal"], nref)
         assert float(g_ref.abs().max()) > 0
         assert float((g_hip.cpu() - g_ref).abs().max()) <= 1e-4 * float(g_ref.abs().max())
+
+
+def test_one_call_step_with_the_normal_term_matches_the_autograd_step():
+    """`normal_weight > 0` inside rtgs_slam_map_step (rtgs_slam_normal_loss: value into the total, gradient into the depth
+    owners' d_normal rows of the row-state arena) vs step(loss_fn) with slam_losses_hip(..., normal_weight) through
+    autograd and the gather kernel: same loss values, same parameters, same rows moved - with and without a render mask
+    (i.e. without and with the SSIM term)."""
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    from rtg_slam_amd import map_optim as mo
+    dev = "cuda:0"
+    N = 4000
+    g, _ = ru.make_scene(N, SMALL, seed=9, pose_seed=1, r_range=(0.03, 0.12))
+    packed = mo.pack_from_activated({k: v.to(dev) for k, v in g.items()})
+    gen = torch.Generator().manual_seed(2)
+    gt_c = torch.rand(3, SMALL.H, SMALL.W, generator=gen).to(dev)
+    gt_d = (1.0 + torch.rand(1, SMALL.H, SMALL.W, generator=gen)).to(dev)
+    gt_n = torch.nn.functional.normalize(torch.randn(SMALL.H, SMALL.W, 3, generator=gen), dim=-1)
+    gt_n[::7, ::5] = 0.0
+    gt_n = gt_n.to(dev)
+    rmask = (torch.rand(SMALL.H, SMALL.W, generator=gen) < 0.8).to(dev)
+    for rm in (None, rmask):
+        oa, ob = mo.ShardedMapOptimizer(packed.clone()), mo.ShardedMapOptimizer(packed.clone())
+        for step, pose in enumerate((1, 2, 3, 2)):
+            _, s = ru.make_scene(N, SMALL, seed=9, pose_seed=pose)
+            rs = ru.hip_settings(s, dev)
+            rast = GaussianRasterizer(raster_settings=rs)
+
+            def loss_fn(gd):
+                out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None,
+                           scales=gd["scales"], rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"],
+                           tile_mask=None, grad_rows=gd.get("grad_rows"))
+                return mo.slam_losses_hip(out, gt_c, gt_d, render_mask=rm, normal_weight=0.3, normal_w=gd["normal"], gt_normal=gt_n)
+            la = float(oa.step(loss_fn))
+            lb = float(ob.step_slam(rs, gt_c, gt_d, None, render_mask=rm, normal_weight=0.3, gt_normal=gt_n))
+            lc = float(mo.ShardedMapOptimizer(ob.params.clone()).step_slam(rs, gt_c, gt_d, None, render_mask=rm))
+            assert abs(la - lb) <= 1e-4 * max(1.0, abs(la)), (step, la, lb)
+            assert abs(lb - lc) > 1e-4, "the normal term must be in the total"
+        pa, pb = oa.params.cpu(), ob.params.cpu()
+        assert ru.frac_bad(pa, pb, 1e-5) < 2e-3
+        moved = (pa - packed.cpu()).abs().max(dim=1).values > 0
+        assert torch.equal(moved, (pb - packed.cpu()).abs().max(dim=1).values > 0)
