@@ -1,5 +1,5 @@
 # Final pass of the round on the final kernel sources: PMC re-stamp (FETCH / WRITE / SQ, headline + surface), smoke, full
-# GPU suite, then the bench line with the fresh stamps.   bash tools/r3_final.sh
+# GPU suite, then the bench line with the fresh stamps.   bash tools/final_pass.sh
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03f; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -8,7 +8,7 @@ for w in headline surface; do
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w_$w -o w -- python $R/tools/prof_raster.py $w 5 > $O/pmc_w_$w.log 2>&1
   python $R/tools/traffic_from_pmc.py $(find $O/pmc_f_$w -name "*counter_collection.csv" | head -1) $(find $O/pmc_w_$w -name "*counter_collection.csv" | head -1) $O/traffic_$w.json > $O/traffic_$w.txt
 done
-bash $R/tools/r3_pmc_sq.sh r03f/sq > $O/pmc_sq.log 2>&1
+bash $R/tools/pmc_sq_passes.sh r03f/sq > $O/pmc_sq.log 2>&1
 python $R/tools/valu_from_pmc.py $O/sq/pmc_sq_surface.csv $O/sq/pmc_sq_headline.csv $O/valu.json
 cp $O/traffic_headline.json $R/profiles/traffic_latest.json; cp $O/valu.json $R/profiles/valu_latest.json
 cd $R

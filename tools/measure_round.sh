@@ -22,7 +22,7 @@ for w in headline surface; do
   python $R/tools/traffic_from_pmc.py $(find $O/pmc_f_$w -name "*counter_collection.csv" | head -1) $(find $O/pmc_w_$w -name "*counter_collection.csv" | head -1) $O/traffic_$w.json > $O/traffic_$w.txt
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_icp -o k -- python $R/tools/prof_icp.py replica 40 > $O/ks_icp.log 2>&1
-bash $R/tools/r3_pmc_sq.sh $TAG/sq > $O/pmc_sq.log 2>&1
+bash $R/tools/pmc_sq_passes.sh $TAG/sq > $O/pmc_sq.log 2>&1
 python $R/tools/valu_from_pmc.py $O/sq/pmc_sq_surface.csv $O/sq/pmc_sq_headline.csv $O/valu.json
 for w in headline surface; do python $R/tools/pmc_summary.py $O/sq/pmc_sq_$w.csv > $O/sq_summary_$w.txt; done
 # keep the merge small: raw traces out, the --stats tables stay

@@ -1,5 +1,5 @@
 # SQ counter passes over the map iteration of both 1.2 M scenes (own runs, --pmc only + kernel trace):
-#   bash tools/r3_pmc_sq.sh <tag>      -> gpurun_out/<tag>/pmc_sq_{headline,surface}.csv
+#   bash tools/pmc_sq_passes.sh <tag>      -> gpurun_out/<tag>/pmc_sq_{headline,surface}.csv
 set -x
 R=$GRAFT_REPO_ROOT; TAG=${1:-r3pmc}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
