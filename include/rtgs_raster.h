@@ -258,7 +258,7 @@ void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* ctx, int mode);
  * not - nothing persistent was changed, redo without the flag; < 0 = error.  It waits (spinning on pinned memory) only
  * until the kernel that publishes the totals has run.  spec_fail_ptr: device word (non-zero = failed) while a
  * speculative forward is pending, else NULL.  set_speculation 0 makes RTGS_FWD_SPECULATE a no-op on the context
- * (RTGS_SPECULATE=0 at load time).  speculation_stats: [0] speculative forwards, [1] of which failed, [2] requests that
+ * (RTGS_SPECULATE=0 at load time); either value also forgets the context's history (the next forward runs plainly).  speculation_stats: [0] speculative forwards, [1] of which failed, [2] requests that
  * could not speculate (no history / different shape). */
 int rtgs_raster_forward_verify_ctx(rtgs_ctx* ctx, int64_t* num_rendered_host);
 const uint32_t* rtgs_raster_spec_fail_ptr_ctx(rtgs_ctx* ctx);

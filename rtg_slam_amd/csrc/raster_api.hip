@@ -88,6 +88,16 @@ struct rtgs_ctx {
     int kind = -1;                  // 0 = single pass, 1 = near slice finished every tile, 2 = slice declined, single pass over the visible list
     int slice_mode = 0, slice_budget = 0;
     uint32_t R = 0, R1 = 0, longest = 0, slots = 0, n_fin = 0;
+    // slowly decaying maxima of the three totals: the capacities of the next speculative call come from these, so that
+    // an optimisation that alternates between the views of a window (mapper.py:176-183 picks a random frame per
+    // iteration) does not fail its guess every time it returns to the larger view
+    uint32_t R_hi = 0, longest_hi = 0, slots_hi = 0;
+    void note(uint32_t r, uint32_t l, uint32_t s) {
+      R = r; longest = l; slots = s;
+      R_hi = r > R_hi - R_hi / 16 ? r : R_hi - R_hi / 16;
+      longest_hi = l > longest_hi - longest_hi / 16 ? l : longest_hi - longest_hi / 16;
+      slots_hi = s > slots_hi - slots_hi / 16 ? s : slots_hi - slots_hi / 16;
+    }
   } plan;
   struct Spec {
     bool pending = false;           // a speculative forward awaits rtgs_raster_forward_verify
@@ -438,7 +448,8 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
     const bool eligible = (flags & RTGS_FWD_SPECULATE) && c->speculation && want_bwd && P > 0 && !sort_path && !s->debug &&
                           pl.valid && pl.P == P && pl.H == p.H && pl.W == p.W && pl.slice_mode == c->slice_mode &&
                           pl.slice_budget == c->slice_budget && (pl.kind == 0 ? !sliced : (pl.kind == 1 || pl.kind == 2) && sliced);
-    const uint32_t capR = pl.R + pl.R / 8u + 8192u, capL = sort_class_cap(pl.longest), capS = pl.slots + pl.slots / 8u + 8192u;
+    const uint32_t capR = pl.R_hi + pl.R_hi / 8u + 8192u, capL = sort_class_cap(pl.longest_hi),
+                   capS = pl.slots_hi + pl.slots_hi / 8u + 8192u;
     if ((flags & RTGS_FWD_SPECULATE) && !(eligible && (pl.kind == 1 || capS <= SLOTS_MAX))) ++c->spec_stats[2];
     if (eligible && (pl.kind == 1 || capS <= SLOTS_MAX)) {
       uint32_t* const fail = slice_ctr + 6;            // inside the span every forward clears
@@ -740,10 +751,13 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   {
     // what a speculative forward on this context may assume next time (rtgs_raster_forward_verify keeps it current)
     rtgs_ctx::Plan& pl = c->plan;
+    const bool same_shape = pl.valid && pl.P == P && pl.H == p.H && pl.W == p.W;
     pl.kind = (sliced && n_left == 0) ? 1 : (considered ? 2 : (!sliced && !sort_path && P > 0 ? 0 : -1));
     pl.valid = pl.kind >= 0 && want_bwd && R <= 0xffffffffll;
     pl.P = P; pl.H = p.H; pl.W = p.W; pl.slice_mode = c->slice_mode; pl.slice_budget = c->slice_budget;
-    pl.R = (uint32_t)R; pl.R1 = (uint32_t)R1; pl.longest = longest; pl.slots = slots; pl.n_fin = n_fin;
+    if (!same_shape || !pl.valid) { pl.R_hi = pl.longest_hi = pl.slots_hi = 0; }     // another map / image: start the maxima over
+    pl.note((uint32_t)R, longest, slots);
+    pl.R1 = (uint32_t)R1; pl.n_fin = n_fin;
   }
   return RTGS_OK;
 }
@@ -867,7 +881,7 @@ int rtgs_raster_forward_verify_ctx(rtgs_ctx* ctx, int64_t* num_rendered_host) {
     c->slice_stats[1] = pub[4]; c->slice_stats[2] = pub[3]; c->slice_stats[3] = n_left;
   } else {
     ok = pub[0] <= c->spec.capR && pub[1] <= c->spec.capL && pub[5] <= c->spec.capS && (c->spec.kind != 2 || (int32_t)pub[6] < 0);
-    pl.R = pub[0]; pl.longest = pub[1]; pl.slots = pub[5]; pl.R1 = 0;
+    pl.note(pub[0], pub[1], pub[5]); pl.R1 = 0;
   }
   c->stats[0] = (int64_t)pl.R + (int64_t)pl.R1; c->stats[1] = 32 + bits_for((uint32_t)c->spec.ntiles); c->stats[2] = c->spec.ntiles;
   c->stats[3] = c->spec.G_total; c->stats[4] = c->spec.B_total; c->stats[5] = c->spec.I_total; c->stats[6] = 1;
@@ -880,7 +894,11 @@ const uint32_t* rtgs_raster_spec_fail_ptr_ctx(rtgs_ctx* ctx) {
   rtgs_ctx* c = use(ctx);
   return c->spec.pending ? c->spec.fail_dev : nullptr;
 }
-void rtgs_raster_set_speculation_ctx(rtgs_ctx* ctx, int enable) { use(ctx)->speculation = enable != 0; }
+void rtgs_raster_set_speculation_ctx(rtgs_ctx* ctx, int enable) {
+  rtgs_ctx* c = use(ctx);
+  c->speculation = enable != 0;
+  c->plan = rtgs_ctx::Plan();          // forget the history: the next forward runs plainly and starts it over
+}
 int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
   if (!out3) return RTGS_E_INVALID;
   memcpy(out3, use(ctx)->spec_stats, sizeof(use(ctx)->spec_stats));

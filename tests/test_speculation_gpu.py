@@ -85,12 +85,13 @@ def test_speculative_steps_equal_plain_steps(kind):
 def test_a_failed_guess_changes_nothing_and_is_redone():
     cam = MID
     g = synth.surface_gaussians(150_000, cam, seed=5)
-    # the instance total jumps by far more than the 12 % margin every other step; the view changes too
-    masks, poses = _masks(cam, [0.15, 1.0, 0.1, 1.0, 1.0, 0.2]), [1, 3, 5]
+    # three steps on a few tiles build the history (the first two cannot speculate: the slice's decision has to be
+    # learnt first), then the instance total jumps by far more than the 12 % margin; the view changes too
+    masks, poses = _masks(cam, [0.15, 0.15, 0.15, 1.0, 0.15, 1.0]), [1, 3, 5]
     on = _run(g, cam, masks, poses, True, 12)
     off = _run(g, cam, masks, poses, False, 12)
     _same(on, off)
-    assert on[2]["failed"] >= 2, on[2]
+    assert on[2]["failed"] >= 1, on[2]      # the jump to the full mask; afterwards the decaying maximum covers the loop
 
 
 def test_pass_structure_change_is_caught():
@@ -128,4 +129,17 @@ def test_pass_structure_change_is_caught():
             assert abs(a - b) <= 1e-5 * max(1.0, abs(a))
         else:
             assert ru.frac_bad(a, b, 2e-6) < 1e-3
-    assert res[True][1]["failed"] >= 2, res[True][1]
+    assert res[True][1]["failed"] >= 1, res[True][1]
+
+
+def test_alternating_views_do_not_keep_failing():
+    """An optimisation that alternates between two views whose instance totals differ by more than the 12 % margin (a random
+    frame of the window per iteration, mapper.py:176-183): the capacities follow a slowly decaying maximum of the totals,
+    so the guess fails once, when the larger view is first met, and not every time the loop returns to it."""
+    cam = MID
+    g = synth.surface_gaussians(150_000, cam, seed=5)
+    masks, poses = _masks(cam, [0.6, 1.0]), [1]
+    on = _run(g, cam, masks, poses, True, 16)
+    off = _run(g, cam, masks, poses, False, 16)
+    _same(on, off)
+    assert on[2]["speculative"] >= 12 and on[2]["failed"] <= 2, on[2]
