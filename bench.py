@@ -38,14 +38,16 @@ def parse():
     ap.add_argument("--gaussians", type=int, default=1_200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-surface", action="store_true", help="skip the surface-shaped 1.2 M scene leg")
-    ap.add_argument("--cpu-tiles", type=int, default=128, help="tiles blended by the CPU oracle sample")
     ap.add_argument("--mode", choices=["sparse", "sharded", "tileband"], default="sparse",
                     help="multi-GPU form of the map step (ignored on one GPU): sparse = every rank renders its own view, "
                          "gradient rows that exist are all-gathered (in-band counts, no host sync), identical Adam step on "
                          "every replica [weak scaling]; sharded = dense reduce-scatter of the gradients, Adam on the rank's "
                          "row shard, all-gather of the updated rows [weak]; tileband = ONE view split into tile bands, "
                          "loss normalisers all-reduced, gradient rows summed by the sparse exchange [strong]")
-    ap.add_argument("--prewarm", type=int, default=200, help="untimed frames before the warm-up (clocks, allocator)")
+    ap.add_argument("--prewarm", type=int, default=3000,
+                    help="untimed frames of the real workload before the warm-up: a FIXED count (every rank issues the same "
+                         "collectives), >= 1.5 s of GPU work - a fresh box needs that long to reach its steady clocks (the "
+                         "driver's first block of round 3 ran 25 %% slower than its later ones after 0.1 s of pre-warm)")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps frames: `value` is the FIRST (the contract's "
                                                            "block), the others give median and spread")
     ap.add_argument("--surface-map", action="store_true", help="headline leg on the single-layer surface map instead of the "
@@ -367,7 +369,7 @@ def main():
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
-            cpu = cpu_baseline(g, cam, args.cpu_tiles, d0, d1, dev)
+            cpu = cpu_baseline(g, cam, d0, d1, dev)
 
         par = {"single": "1 GPU",
                "sparse": f"dp{world}: replicated map and Adam state, one view per rank, RCCL all-gather of the gradient rows that "
@@ -382,6 +384,7 @@ def main():
         if world == 1 and not args.no_schedule and not args.no_surface:
             sched = reference_schedule_leg(cam, N, dev)
         bs = sorted(block_ms)
+        spread = (bs[-1] - bs[0]) / bs[len(bs) // 2]
         result = {
             "metric": "slam_frames_per_sec", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -402,7 +405,8 @@ def main():
             "raster_fwd_bwd_ms": round(sum(stage), 4), "icp_track_ms": round(icp_ms, 4),
             "raster_fwd_bwd_ms_30pct_tiles": round(sum(prof30["stage"]), 4),
             "cold_first_frame_ms": round(cold_ms, 2), "prewarm_frames": args.prewarm,
-            "repeats": {"blocks": len(block_ms), "ms_per_step": [round(x, 4) for x in block_ms],
+            "unstable": bool(spread > 0.05),
+            "repeats": {"blocks": len(block_ms), "spread_over_median": round(spread, 4), "ms_per_step": [round(x, 4) for x in block_ms],
                         "median_ms_per_step": round(bs[len(bs) // 2], 4), "min": round(bs[0], 4), "max": round(bs[-1], 4),
                         "median_frames_per_sec": round(frames_per_step * 1e3 / bs[len(bs) // 2], 2)},
             "rccl_ranks": rccl_ranks,
@@ -619,14 +623,13 @@ def profile_scene(lib, mo, rast, opt, N, cam, tile_mask, gt_color, gt_depth, dev
             "raster_fwd_bwd_ms": round(sum(stage), 4)}
 
 
-def cpu_baseline(g, cam, n_tiles, d0, d1, dev, n_sample=150_000):
+def cpu_baseline(g, cam, d0, d1, dev):
     """The oracle (PyTorch-CPU restatement; the reference has no CPU render path and its rasterizer source is absent)
     on the host cores.  Two legs:
       * `value`: the SAME unit as `value` of the bench line, MEASURED, nothing scaled: rasterizer forward + backward of
         the whole 1.2 M / 1200x680 frame (oracle/raster_oracle_fast.py: raster_oracle's per-Gaussian stage and binning,
         the tile blend and its hand-written backward over all tiles - the form the whole-image parity test uses) plus
-        one full-size ICP track with the pinned ICP oracle; about 30-40 s of CPU.  (Rounds 1-2 extrapolated a bounded
-        sample of tiles and Gaussians; `--cpu-tiles` is ignored now.)
+        one full-size ICP track with the pinned ICP oracle; about 30-40 s of CPU (nothing extrapolated).
       * `config2_measured`: BASELINE.json configs[1] (200 000 Gaussians, 640x480, all tiles, forward + backward)
         through raster_oracle.py + autograd, next to the HIP time for the very same call."""
     from oracle import raster_oracle as ro
@@ -678,6 +681,7 @@ def cpu_baseline(g, cam, n_tiles, d0, d1, dev, n_sample=150_000):
     c2_err = float((oh[0].detach().cpu() - o2[0].detach()).abs().max())
     return {"value": round(1.0 / (raster_full + icp_s), 5), "unit": "frames/s", "cores": threads, "kind": "port",
             "extrapolated": False,
+            "threads_by_stage": {"per_gaussian_stage_and_autograd": threads, "tile_blend_loop": min(threads, 4), "icp": threads},
             "note": "measured, nothing scaled; the tile loop of the oracle caps torch's intra-op threads at 4 (its tensors are "
                     "[<= 128, 256]: more threads are slower), the per-Gaussian stage and the ICP use `cores`.  The reference's "
                     "own CPU ICP (SLAM/icp.py) cannot run on this box (no /root/reference here) - oracle/icp_oracle.py is "

@@ -123,8 +123,8 @@ size_t rtgs_raster_backward_scratch_bytes(int32_t P);
 #define RTGS_FWD_SPECULATE 2     /* Speculative sizing - NO host wait inside the call (upstream reads num_rendered back in
                                     the middle of its forward; so does the plain call, through pinned memory).  The host
                                     assumes this call looks like the last verified forward on the context (same pass
-                                    structure, instance / longest-list / gradient-slot totals within 12-25 % of the last
-                                    ones), sizes the binning buffer and picks the sort classes from that, and enqueues
+                                    structure; capacities = the decaying maxima of the instance / gradient-slot totals + 12.5 %
+                                    + 8192, the sort-class ceiling above the longest list + 25 %: raster_api.hip), sizes the binning buffer and picks the sort classes from that, and enqueues
                                     everything.  The kernel that learns the real numbers checks them against those
                                     capacities and raises a device word when they do not hold; every later kernel of the
                                     forward AND of its backward that could overrun a buffer or change persistent state
@@ -248,7 +248,7 @@ int rtgs_raster_last_timings(float* ms12_host);
 int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms12_host);
 /* The backward's tile walk.  blend_fwd measures, per tile, how much of the tile's list each of its sixteen 4x4 pixel
  * blocks needs, and leaves one word per tile in the image buffer: tiles whose blocks share the list (large footprints)
- * take the tile-uniform strip walk, tiles whose blocks need less than 45 % of it on average (a surface map of small
+ * take the tile-uniform strip walk, tiles whose blocks need less than ROWS_MAX_SHARE (raster_common.h: 60 %) of it on average (a surface map of small
  * discs) the row-granular walk.  mode 0 = that per-tile choice (default), 1 = strip walk everywhere, 2 = row-granular
  * walk everywhere (testing / A-B; RTGS_BWD_WALK at load time).  Gradients of the two walks agree to float rounding.
  * rtgs_raster_image_offsets: byte offsets inside the image buffer - [0] tile ranges (uint2 per tile), [1] n_contrib

@@ -145,6 +145,32 @@ def bits_checksum(t: torch.Tensor) -> int:
     return int(t.contiguous().view(torch.int32).to(torch.int64).sum())
 
 
+def reference_track(ref_icp, ref_utils, vp1, np1, vp0, np0, K, cos_thr, f64, pose0=None):
+    """The level loop of predict_pose (icp.py:428-447) spelled out per iteration with the reference's own static methods
+    (ICP.icp's body, icp.py:33-48).  f64=False reproduces ICP.icp bit for bit; f64=True runs compute_jtj / compute_jtr /
+    GN_solver on float64 copies of the float32 residuals and Jacobians."""
+    pose = torch.eye(4) if pose0 is None else pose0.clone()
+    for l, ds in enumerate([0.25, 0.5, 1.0]):
+        Kl = K * ds
+        Kl[2, 2] = 1.0
+        mask0 = vp1[l][..., -1] > 0.0
+        for _ in range(5):
+            res, J, _valid = ref_icp.ICP.compute_residuals_jacobian(vp1[l], vp0[l], np1[l], np0[l], mask0, pose, Kl, 0.1, cos_thr)
+            if not f64:
+                pose = ref_icp.ICP.GN_solver(ref_icp.ICP.compute_jtj(J), ref_icp.ICP.compute_jtr(J, res), pose, damping=1e-4)
+                continue
+            JtJ, Jtr = ref_icp.ICP.compute_jtj(J.double()), ref_icp.ICP.compute_jtr(J.double(), res.double())
+            keep = ref_utils.devF
+            torch.set_default_dtype(torch.float64)          # exp_se3 / invH build their constants with the default dtype
+            ref_utils.devF = lambda t: t.double()
+            try:
+                pose = ref_icp.ICP.GN_solver(JtJ, Jtr, pose.double(), damping=1e-4).float()
+            finally:
+                torch.set_default_dtype(torch.float32)
+                ref_utils.devF = keep
+    return pose.numpy()
+
+
 def full_size_cases():
     """Full-size frames (Replica 680x1200 clean, TUM 480x640 noisy) through the REFERENCE's own tracker.  Only OUTPUTS
     are committed (tests/golden/icp_full_*.npz, a few KiB): the inputs regenerate from the seeds - the frames are the
@@ -206,8 +232,31 @@ def full_size_cases():
             save["p2p_loss" + tag] = np.array(float(ref_icp.point2plane_loss(vp0[-1], vp1[-1] @ pose[:3, :3].T + pose[:3, 3],
                                                                              np0[-1])))
         torch.set_num_threads(8)
+        # How well is the 15-iteration pose DEFINED?  Two more runs of the reference's own functions on these pyramids
+        # (VERDICT r3 item 1a):
+        #  * pose_final_f64solve: compute_residuals_jacobian in float32 exactly as the reference runs it (same
+        #    associations and gates), then compute_jtj / compute_jtr / GN_solver (lev_mar_H, inverse, exp_se3, compose)
+        #    on float64 tensors; the pose returns to float32 between iterations.  This is the reference algorithm with
+        #    its linear algebra carried out exactly - what the HIP kernel does (float64 sums, Cholesky, exp).
+        #  * pose_sensitivity: the float32 reference started from the identity with ONE translation entry moved by
+        #    +-1e-7 (six runs): how far its own answer moves under a perturbation of float32-rounding size.  On the
+        #    noisy frame that is ~1e-4 (gate flips amplify it): north_star's 1e-5 is below what the reference itself
+        #    defines there, and the test's tolerance on that frame is this recorded number, not a chosen one.
+        save["pose_final_f64solve"] = reference_track(ref_icp, ref_utils, vp1, np1, vp0, np0, K, cos_thr, f64=True)
+        base_pose = reference_track(ref_icp, ref_utils, vp1, np1, vp0, np0, K, cos_thr, f64=False)
+        assert np.array_equal(base_pose, save["pose_final"]), "per-iteration loop must reproduce ICP.icp bit for bit"
+        moves = []
+        for axis in range(3):
+            for sign in (1.0, -1.0):
+                p0 = torch.eye(4)
+                p0[axis, 3] = sign * 1e-7
+                moves.append(float(np.abs(reference_track(ref_icp, ref_utils, vp1, np1, vp0, np0, K, cos_thr, f64=False,
+                                                          pose0=p0) - base_pose).max()))
+        save["pose_sensitivity"] = np.array(moves)
         path = os.path.join(out_dir, f"icp_{name}.npz")
         np.savez_compressed(path, **save)
+        print(name, "|f32 ref - f64-solve ref| =", float(np.abs(save["pose_final_f64solve"] - save["pose_final"]).max()),
+              "moves under +-1e-7:", ["%.1e" % m for m in moves])
         print(name, "reference vs itself (8 vs 1 threads):", float(np.abs(save["pose_final"] - save["pose_final_1thread"]).max()),
               "valid", float(save["valid_ratio"]), "loss", float(save["p2p_loss"]), os.path.getsize(path), "B")
 

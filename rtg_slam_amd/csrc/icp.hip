@@ -801,7 +801,11 @@ int rtgs_icp_build_pyramids(const float* depth, int32_t H, int32_t W, const floa
   }
   d.block_start[levels] = blocks;
   ICP_TRY(hipMemsetAsync(sc->minmax, 0xff, sizeof(sc->minmax), st));
-  if (levels == 3) {        // the shipped configuration (icp_downscales [0.25, 0.5, 1.0]): all three levels in one pass
+  // the one-pass kernel moves 16-byte rows: it needs the depth image and the vertex maps 16-byte aligned (torch
+  // allocations are; a view with a storage offset may not be) - anything else takes the scalar kernel
+  uintptr_t align_bits = (uintptr_t)depth;
+  for (int l = 0; l < levels; ++l) align_bits |= (uintptr_t)vertex_out[l];
+  if (levels == 3 && (align_bits & 15u) == 0) {   // the shipped configuration (icp_downscales [0.25, 0.5, 1.0]): all three levels in one pass
     const int nb = ((H + 3) / 4) * ((W + 3) / 4);
     hipLaunchKernelGGL(icp_vertex3_kernel, dim3(grid_for(nb)), dim3(256), 0, st, d, depth, K, sc);
   } else {

@@ -383,7 +383,9 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   int32_t* sat = (int32_t*)(geom + G.sat);
   uint2* ranges = (uint2*)(img + I.ranges);
   uint32_t* n_contrib = (uint32_t*)(img + I.n_contrib);
-  uint32_t* const tile_mode = (flags & RTGS_FWD_NO_BACKWARD) ? nullptr : (uint32_t*)(img + I.tile_mode);
+  // always written, also under RTGS_FWD_NO_BACKWARD: a backward that is called anyway (slower, atomics) must not meet stale
+  // walk choices of an earlier forward in a recycled image buffer
+  uint32_t* const tile_mode = (uint32_t*)(img + I.tile_mode);
 
   int64_t R = 0, R1 = 0;
   for (int i = 0; i < EV_B0; ++i) c->ev_set[i] = false;
@@ -752,7 +754,9 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
     // what a speculative forward on this context may assume next time (rtgs_raster_forward_verify keeps it current)
     rtgs_ctx::Plan& pl = c->plan;
     const bool same_shape = pl.valid && pl.P == P && pl.H == p.H && pl.W == p.W;
-    pl.kind = (sliced && n_left == 0) ? 1 : (considered ? 2 : (!sliced && !sort_path && P > 0 ? 0 : -1));
+    // from the FINAL state of this call: a forward that fell back to the global sort (a list longer than the LDS sort
+    // holds) leaves no plan - speculating on it would fail its guard word on every step and run every step twice
+    pl.kind = sort_path ? -1 : ((sliced && n_left == 0) ? 1 : (considered ? 2 : (!sliced && P > 0 ? 0 : -1)));
     pl.valid = pl.kind >= 0 && want_bwd && R <= 0xffffffffll;
     pl.P = P; pl.H = p.H; pl.W = p.W; pl.slice_mode = c->slice_mode; pl.slice_budget = c->slice_budget;
     if (!same_shape || !pl.valid) { pl.R_hi = pl.longest_hi = pl.slots_hi = 0; }     // another map / image: start the maxima over

@@ -14,6 +14,7 @@ import torch
 
 from rtg_slam_amd import rasterizer as rz
 from rtg_slam_amd import synth
+from tests import margins
 from tests import raster_util as ru
 
 pytestmark = pytest.mark.gpu
@@ -88,6 +89,10 @@ def test_the_two_walks_agree_and_match_the_oracle(kind, N, cam, depth, masked):
         assert torch.equal(rows(gd_r[k]), rows(gd_s[k])), k      # untouched Gaussians: exact zeros on both walks
         assert torch.equal(rows(gd_a[k]), rows(gd_s[k])), k
     _, gd_o, _ = ru.oracle_run(s, g, tile_mask=mask, grads=grads)
+    margins.record("max gradient error relative to the tensor max",
+                   **{k: {"rows_vs_strip": _rel(gd_r[k], gd_s[k]), "auto_vs_strip": _rel(gd_a[k], gd_s[k]),
+                          "rows_vs_oracle": _rel(gd_r[k], gd_o[k]), "strip_vs_oracle": _rel(gd_s[k], gd_o[k])}
+                      for k in ru.FIELDS})
     for k in ru.FIELDS:
         assert _rel(gd_r[k], gd_o[k]) < 1e-3, k
         assert _rel(gd_s[k], gd_o[k]) < 1e-3, k

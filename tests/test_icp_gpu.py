@@ -8,6 +8,7 @@ import torch
 
 from oracle import icp_oracle as io
 from rtg_slam_amd import synth
+from tests import margins
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -135,7 +136,13 @@ def test_tracker_class_vs_oracle_full_size(cam, noise, persistent):
         assert float(np.abs(pose - rel).max()) < 5e-3
 
 
-FULL_TOL = {"full_replica_clean": 1e-5, "full_tum_noisy": 5e-5}
+def full_tol(g):
+    """Tolerance of the 15-iteration pose against the reference's float32 output, DERIVED from the golden file:
+    north_star's 1e-5, unless the reference itself is not defined that sharply on the frame - its own answer moves by
+    `pose_sensitivity` when ONE entry of its initial pose moves by +-1e-7 (six runs of the reference's code,
+    oracle/gen_icp_golden.py); the smallest of those six moves is the bound then.  Clean Replica-shaped frame: the
+    reference moves by 4e-8..1.4e-7 -> 1e-5.  Noisy TUM-shaped frame: 3.7e-5..2.9e-4 -> 3.7e-5."""
+    return max(1e-5, float(np.min(np.asarray(g["pose_sensitivity"]))))
 
 
 @pytest.mark.parametrize("name,cam,noise", [("full_replica_clean", synth.REPLICA, False), ("full_tum_noisy", synth.TUM_FR1, True)])
@@ -176,9 +183,21 @@ def test_full_size_vs_reference_outputs(golden_dir, name, cam, noise):
         out = icp.icp_track(hv1, hn1, hv0, hn0, K, [0.25, 0.5, 1.0], [5, 5, 5], 0.1, cos_thr, 1e-4, persistent=persistent).cpu()
         pose = out[:16].reshape(4, 4)
         err = float((pose - g["pose_final"]).abs().max())
-        print(f"{name} persistent={persistent}: |hip - reference pose| = {err:.2e} (reference 8 vs 1 threads "
-              f"{float((g['pose_final'] - g['pose_final_1thread']).abs().max()):.1e})")
-        assert err < FULL_TOL[name], err
+        # the reference algorithm with its normal equations summed and solved in float64 (reference code on float64
+        # tensors, per-pixel stage in float32 as always): the answer the kernel's float64 sums / Cholesky aim at
+        err64 = float((pose - g["pose_final_f64solve"]).abs().max())
+        ref64 = float((g["pose_final"] - g["pose_final_f64solve"]).abs().max())
+        tol = full_tol(g)
+        margins.record(f"persistent={persistent}", hip_vs_reference_f32=err, hip_vs_reference_f64solve=err64,
+                       reference_f32_vs_reference_f64solve=ref64, tolerance_derived_from_reference_sensitivity=tol,
+                       reference_moves_under_1e7_perturbation=[float(x) for x in g["pose_sensitivity"]],
+                       reference_8_vs_1_threads=float((g['pose_final'] - g['pose_final_1thread']).abs().max()))
+        print(f"{name} persistent={persistent}: |hip - reference pose| = {err:.2e}, |hip - f64-solve reference| = {err64:.2e}, "
+              f"|reference - f64-solve reference| = {ref64:.2e}, tol {tol:.1e}")
+        assert err < tol, (err, tol)
+        # the kernel sits at least as close to the exactly-solved reference as the float32 reference does (1e-6: where
+        # both distances are rounding noise, as on the clean frame)
+        assert err64 < max(1e-6, ref64), (err64, ref64)
         assert abs(float(out[16]) - float(g["valid_ratio"])) < 1e-3
         assert abs(float(out[17]) - float(g["p2p_loss"])) <= 2e-4 * max(1.0, float(g["p2p_loss"]))
 

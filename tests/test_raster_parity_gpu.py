@@ -17,6 +17,7 @@ import pytest
 import torch
 
 from rtg_slam_amd import synth
+from tests import margins
 from tests import raster_util as ru
 
 pytestmark = pytest.mark.gpu
@@ -56,16 +57,29 @@ def _big_case(name):
     return _cache[name]
 
 
-def _check_maps(out_h, out_o, max_bad=2e-3):
+def _check_maps(out_h, out_o, max_bad=2e-3, tag="maps"):
     names = ["color", "depth", "color_index", "depth_index", "color_weight", "depth_weight", "T"]
+    seen = {}
     for k in (0, 1, 4, 5, 6):
         bad = ru.frac_bad(out_h[k], out_o[k], 1e-4)
-        assert bad <= max_bad, (names[k], bad)
+        err = (out_h[k] - out_o[k]).abs()
+        # the bulk of the error (all but the flipped pixels): the 99.9th percentile would need a sort of 816 k values;
+        # the mean over the pixels INSIDE the tolerance says the same thing cheaply
+        inside = err <= 1e-4
+        seen[names[k]] = {"frac_over_1e-4": bad, "max_abs_err": float(err.max()),
+                          "max_abs_err_of_pixels_inside_tol": float(err[inside].max()) if inside.any() else 0.0}
     for k in (2, 3):
-        assert float((out_h[k] != out_o[k]).float().mean()) <= max_bad, names[k]
+        seen[names[k]] = {"frac_different": float((out_h[k] != out_o[k]).float().mean())}
+    margins.record(tag, **seen)
+    for k in (0, 1, 4, 5, 6):
+        assert seen[names[k]]["frac_over_1e-4"] <= max_bad, (names[k], seen[names[k]])
+    for k in (2, 3):
+        assert seen[names[k]]["frac_different"] <= max_bad, names[k]
 
 
-def _check_grads(gd_h, gd_o):
+def _check_grads(gd_h, gd_o, tag="grads"):
+    seen = {}
+    fails = []
     for k in ru.FIELDS:
         ref = gd_o[k]
         scale = float(ref.abs().max()) + 1e-12
@@ -73,9 +87,19 @@ def _check_grads(gd_h, gd_o):
         # fraction of rows outside tolerance instead of the max
         row_err = (gd_h[k] - ref).abs().reshape(ref.shape[0], -1).max(dim=1).values / scale
         touched = ref.reshape(ref.shape[0], -1).abs().sum(1) > 0
-        assert float((row_err > 1e-3).float().sum()) <= max(2.0, 2e-3 * float(touched.sum())), (k, float(row_err.max()))
         untouched = ~touched
-        assert float(gd_h[k].reshape(ref.shape[0], -1)[untouched].abs().max() if untouched.any() else 0.0) <= 1e-3 * scale, k
+        leak = float(gd_h[k].reshape(ref.shape[0], -1)[untouched].abs().max() if untouched.any() else 0.0) / scale
+        n_over = float((row_err > 1e-3).float().sum())
+        allowed = max(2.0, 2e-3 * float(touched.sum()))
+        srt = torch.sort(row_err, descending=True).values
+        seen[k] = {"max_rel_err": float(row_err.max()), "rows_over_1e-3": n_over, "rows_allowed": allowed,
+                   "touched_rows": float(touched.sum()),
+                   "max_rel_err_without_the_3_worst_rows": float(srt[3]) if srt.numel() > 3 else 0.0,
+                   "untouched_rows_max_rel": leak}
+        if n_over > allowed or leak > 1e-3:
+            fails.append((k, seen[k]))
+    margins.record(tag, **seen)
+    assert not fails, fails
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
@@ -172,8 +196,8 @@ def test_parity_on_the_surface_map_through_the_declined_slice_paths():
         if ctx is auto:
             st = ctx.last_slice_stats()
             assert st["used"] == 1 and st["instances"] == 0 and st["tiles_finished"] == 0, (label, st)
-        _check_maps(out_h, out_o)
-        _check_grads(gd_h, gd_o)
+        _check_maps(out_h, out_o, tag="maps [" + label + "]")
+        _check_grads(gd_h, gd_o, tag="grads [" + label + "]")
 
 
 @pytest.mark.parametrize("name", ["headline", "surface"])
