@@ -3,7 +3,7 @@ two HIP streams of one process.  What the two-process original guarantees throug
 therefore guarantee through stream events:
 
 * a frame processed through the pipeline gives the SAME pose and the SAME map update as running tracker and mapper one
-  after the other (bit for bit: the kernels are deterministic, only their interleaving changes);
+  after the other (pose and rendered maps bit for bit; gradients to the rounding of their slot-summation order);
 * the tracker stage sees everything the caller enqueued before `track()` (the frame's inputs, the previous map update)
   and the caller's later work sees the tracker's results after `result()`;
 * results come back in submission order with two frames in flight;
@@ -107,7 +107,9 @@ def test_pipelined_frames_equal_sequential_execution():
         assert np.array_equal(pa, pb) and oka == okb
         assert torch.equal(ia, ib)
         for k in ru.FIELDS:
-            assert torch.equal(ga[k], gb[k]), k
+            # the gradient slots of a Gaussian are taken in arrival order of its tiles (one integer atomic each): their sum
+            # is order-dependent in the last bits from run to run, pipelined or not
+            assert float((ga[k] - gb[k]).abs().max()) <= 1e-5 * float(ga[k].abs().max()), k
     assert any(float(np.abs(p[0] - np.eye(4)).max()) > 1e-4 for p in a)        # the stream really moves
 
 
