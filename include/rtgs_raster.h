@@ -249,10 +249,13 @@ int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms12_host);
 /* The backward's tile walk.  blend_fwd measures, per tile, how much of the tile's list each of its sixteen 4x4 pixel
  * blocks needs, and leaves one word per tile in the image buffer: tiles whose blocks share the list (large footprints)
  * take the tile-uniform strip walk, tiles whose blocks need less than ROWS_MAX_SHARE (raster_common.h: 60 %) of it on average (a surface map of small
- * discs) the row-granular walk.  mode 0 = that per-tile choice (default), 1 = strip walk everywhere, 2 = row-granular
- * walk everywhere (testing / A-B; RTGS_BWD_WALK at load time).  Gradients of the two walks agree to float rounding.
+ * discs) the row-granular walk.  A third walk (raster_bwd_mfma.hip) gives a lane one (pixel, ENTRY) pair - 16 entries
+ * x 4 pixels per wave step - and reduces over the pixels on the matrix cores (v_mfma_f32_16x16x4_f32).
+ * mode 0 = per-tile choice (default), 1 = strip walk everywhere, 2 = row-granular walk everywhere, 3 = MFMA walk
+ * everywhere (testing / A-B; RTGS_BWD_WALK at load time).  Gradients of the walks agree to float rounding.
  * rtgs_raster_image_offsets: byte offsets inside the image buffer - [0] tile ranges (uint2 per tile), [1] n_contrib
- * (u32 per pixel), [2] BwdInfo, [3] tile walk (u32 per tile, 1 = row-granular), [4] total size. */
+ * (u32 per pixel), [2] BwdInfo, [3] tile walk (u32 per tile: bits 0..1 = 0 strip / 1 row-granular / 2 MFMA), [4] total
+ * size, [5] list position of every pixel's depth owner (u32 per pixel). */
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* ctx, int mode);
 /* Speculative forward (RTGS_FWD_SPECULATE).  verify: 0 = the guessed sizes held (or nothing was pending), 1 = they did
  * not - nothing persistent was changed, redo without the flag; < 0 = error.  It waits (spinning on pinned memory) only
@@ -264,7 +267,7 @@ int rtgs_raster_forward_verify_ctx(rtgs_ctx* ctx, int64_t* num_rendered_host);
 const uint32_t* rtgs_raster_spec_fail_ptr_ctx(rtgs_ctx* ctx);
 void rtgs_raster_set_speculation_ctx(rtgs_ctx* ctx, int enable);
 int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3_host);
-int rtgs_raster_image_offsets(int32_t image_height, int32_t image_width, size_t* out5_host);
+int rtgs_raster_image_offsets(int32_t image_height, int32_t image_width, size_t* out6_host);
 
 /* Fused Adam over a packed [rows, cols] float32 parameter shard with one learning rate per
  * column (the six Adam groups of SLAM/gaussian_pointcloud.py:245-284; torch.optim.Adam

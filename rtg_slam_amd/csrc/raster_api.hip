@@ -19,10 +19,13 @@ void launch_emit_keys(const RasterParams&, const Splat*, const int32_t*, const u
                       uint32_t*, hipStream_t);
 void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
-                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, hipStream_t);
+                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, uint32_t*, hipStream_t);
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
                       const uint32_t*, const int32_t*, const float*, const float*, const uint32_t*, uint32_t*,
-                      const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, hipStream_t);
+                      const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, uint32_t, hipStream_t);
+void launch_blend_bwd_mfma(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const uint32_t*,
+                           const int32_t*, const uint32_t*, const float*, const float*, const uint32_t*, uint32_t*,
+                           const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, hipStream_t);
 void launch_grad_reduce(int, const uint8_t*, const uint32_t*, uint32_t*, const BwdInfo*, SplatGrad*, const uint32_t*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
@@ -66,7 +69,7 @@ struct rtgs_ctx {
   unsigned long long* counters = nullptr;
   bool prof = false;                // optional per-stage HIP-event timing (bench.py's roofline leg)
   bool force_sort_path = false;     // testing aid: take the global radix-sort binning path
-  int bwd_walk = 0;                 // 0 = blend_fwd chooses per tile; 1 = strip walk everywhere; 2 = row-granular walk everywhere
+  int bwd_walk = 0;                 // 0 = blend_fwd chooses per tile; 1 = strip walk everywhere; 2 = row-granular walk everywhere; 3 = MFMA walk everywhere
   bool ev_init = false;
   hipEvent_t ev[EV_N];
   bool ev_set[EV_N] = {false};
@@ -121,7 +124,7 @@ static rtgs_ctx* default_ctx() {
     if (const char* e = getenv("RTGS_NEAR_SLICE")) n->slice_mode = atoi(e);
     if (const char* e = getenv("RTGS_NEAR_SLICE_BUDGET")) { const int b = atoi(e); if (b > 0) n->slice_budget = b; }
     if (const char* e = getenv("RTGS_SPECULATE")) n->speculation = atoi(e) != 0;
-    if (const char* e = getenv("RTGS_BWD_WALK")) { const int m = atoi(e); n->bwd_walk = (m == 1 || m == 2) ? m : 0; }
+    if (const char* e = getenv("RTGS_BWD_WALK")) { const int m = atoi(e); n->bwd_walk = (m >= 1 && m <= 3) ? m : 0; }
     return n;
   }();
   return c;
@@ -263,6 +266,7 @@ static ImgLayout img_layout(int H, int W, int ntiles) {
   L.n_contrib = off; off = align_up(off + (size_t)H * W * sizeof(uint32_t));
   L.bwd_info = off; off = align_up(off + sizeof(BwdInfo));
   L.tile_mode = off; off = align_up(off + (size_t)ntiles * sizeof(uint32_t));
+  L.depth_pos = off; off = align_up(off + (size_t)H * W * sizeof(uint32_t));
   L.total = off;
   return L;
 }
@@ -383,6 +387,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   int32_t* sat = (int32_t*)(geom + G.sat);
   uint2* ranges = (uint2*)(img + I.ranges);
   uint32_t* n_contrib = (uint32_t*)(img + I.n_contrib);
+  uint32_t* depth_pos = (uint32_t*)(img + I.depth_pos);
   // always written, also under RTGS_FWD_NO_BACKWARD: a backward that is called anyway (slower, atomics) must not meet stale
   // walk choices of an earlier forward in a recycled image buffer
   uint32_t* const tile_mode = (uint32_t*)(img + I.tile_mode);
@@ -492,7 +497,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                            (SplatGrad*)(bin + B.slot_grads), use_sl ? sl : 0u, use_sl ? 1u : 0u);
         const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
         launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                         n_contrib, c->counters, pass1, tile_mode, st);
+                         n_contrib, c->counters, pass1, tile_mode, depth_pos, st);
         launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, fail, st);
         prof_mark(c, EV_SL_BLEND, st);
         prof_mark(c, EV_BLEND0, st); prof_mark(c, EV_BLEND, st);
@@ -542,14 +547,14 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         prof_mark(c, EV_SORT, st);
         prof_mark(c, EV_BLEND0, st);
         launch_blend_fwd(pg, ranges, (uint32_t*)(bin + B.vals_b), splats, out_color, out_depth, out_cidx, out_didx, out_cw,
-                         out_dw, out_T, n_contrib, c->counters, SlicePass{0, nullptr, nullptr, nullptr, nullptr}, tile_mode, st);
+                         out_dw, out_T, n_contrib, c->counters, SlicePass{0, nullptr, nullptr, nullptr, nullptr}, tile_mode, depth_pos, st);
         prof_mark(c, EV_BLEND, st);
         c->hint_slice_lists = false; c->hint_main_lists = true;
         c->slice_stats[0] = pl.kind == 2 ? 1 : 0; c->slice_stats[1] = 0; c->slice_stats[2] = 0;
         c->slice_stats[3] = pl.kind == 2 ? (int64_t)ntiles : 0;
       }
       if (tile_mode && c->bwd_walk != 0)
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tile_mode, c->bwd_walk == 2 ? 1 : 0, (size_t)ntiles, st));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tile_mode, c->bwd_walk - 1, (size_t)ntiles, st));
       HIP_TRY(hipGetLastError());
       c->hint_geom = geom;
       c->spec.pending = true; c->spec.kind = pl.kind; c->spec.seq = c->seq; c->spec.capR = capR; c->spec.capL = capL;
@@ -623,7 +628,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       if (++c->seq == 0u) c->seq = 1u;
       const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
       launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                       n_contrib, c->counters, pass1, tile_mode, st);
+                       n_contrib, c->counters, pass1, tile_mode, depth_pos, st);
       launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, nullptr, st);
       DBG(s, st);
       prof_mark(c, EV_SL_BLEND, st);
@@ -736,9 +741,9 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   prof_mark(c, EV_BLEND0, st);
   if (!sliced || n_left > 0)     // pass 2 (or the only pass); with every tile finished by the slice there is nothing to draw
     launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                     n_contrib, c->counters, pass, tile_mode, st);
+                     n_contrib, c->counters, pass, tile_mode, depth_pos, st);
   if (tile_mode && c->bwd_walk != 0)      // testing / A-B aid: one walk for every tile
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tile_mode, c->bwd_walk == 2 ? 1 : 0, (size_t)ntiles, st));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tile_mode, c->bwd_walk - 1, (size_t)ntiles, st));
   prof_mark(c, EV_BLEND, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
@@ -809,14 +814,22 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
     // workgroup with an empty range returns at once); every other tile walks the main lists
     // (a launch whose every workgroup would find an empty range is skipped when this context still remembers the forward)
     const bool hinted = c->hint_geom == geom_buffer;
-    if (!hinted || c->hint_slice_lists)
-      launch_blend_bwd(p, (const uint2*)(geom + G.ranges1_bwd), (const uint32_t*)(geom + G.list1),
-                       (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
-                       dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode, c->bwd_walk == 1 ? 1 : (c->bwd_walk == 2 ? 2 : 3), st);
-    if (!hinted || c->hint_main_lists)
-      launch_blend_bwd(p, (const uint2*)(img + I.ranges), (const uint32_t*)(bin + B.vals_b),
-                       (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib), out_didx,
-                       dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode, c->bwd_walk == 1 ? 1 : (c->bwd_walk == 2 ? 2 : 3), st);
+    // bit 0 strip, bit 1 row-granular, bit 2 MFMA walk: a forced walk launches only its kernel
+    const int which = c->bwd_walk == 0 ? 3 : (1 << (c->bwd_walk - 1));
+    const uint32_t n_train = (uint32_t)P;
+    const uint32_t* depth_pos = (const uint32_t*)(img + I.depth_pos);
+    for (int set = 0; set < 2; ++set) {
+      if (hinted && !(set == 0 ? c->hint_slice_lists : c->hint_main_lists)) continue;
+      const uint2* rg = set == 0 ? (const uint2*)(geom + G.ranges1_bwd) : (const uint2*)(img + I.ranges);
+      const uint32_t* pl = set == 0 ? (const uint32_t*)(geom + G.list1) : (const uint32_t*)(bin + B.vals_b);
+      if (which & 3)
+        launch_blend_bwd(p, rg, pl, (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib),
+                         out_didx, dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode, which & 3, n_train, st);
+      if (which & 4)
+        launch_blend_bwd_mfma(p, rg, pl, (const Splat*)(geom + G.splats), out_color, (const uint32_t*)(img + I.n_contrib),
+                              out_didx, depth_pos, dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode,
+                              n_train, st);
+    }
     prof_mark(c, EV_BWALK, st);
     // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
     launch_grad_reduce(P, touched, gbase, slot_count, binfo, grads, p.spec_fail, st);
@@ -908,12 +921,12 @@ int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
   memcpy(out3, use(ctx)->spec_stats, sizeof(use(ctx)->spec_stats));
   return RTGS_OK;
 }
-void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode == 1 || mode == 2) ? mode : 0; }
+void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode >= 1 && mode <= 3) ? mode : 0; }
 int rtgs_raster_image_offsets(int32_t H, int32_t W, size_t* out) {
   if (!out || H <= 0 || W <= 0) return RTGS_E_INVALID;
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const ImgLayout I = img_layout(H, W, gx * gy);
-  out[0] = I.ranges; out[1] = I.n_contrib; out[2] = I.bwd_info; out[3] = I.tile_mode; out[4] = I.total;
+  out[0] = I.ranges; out[1] = I.n_contrib; out[2] = I.bwd_info; out[3] = I.tile_mode; out[4] = I.total; out[5] = I.depth_pos;
   return RTGS_OK;
 }
 

@@ -1,0 +1,374 @@
+// K7 blend_bwd, third walk: ENTRY-PER-LANE with the pixel reduction on the matrix cores.
+//
+// The strip and row-granular walks (raster_bwd.hip) give a lane one PIXEL and an instruction one ENTRY: every entry
+// then costs a cross-lane reduction of nine partials (a third of the instructions of kernels that are VALU-issue
+// bound, profiles/r03_pmc_sq_*).  Here a wave step covers 16 ENTRIES x 4 PIXELS:
+//
+//     lane l = (k = l >> 4, n = l & 15)  <->  pixel k of a 2x2 quad, n-th entry of a group of 16 list entries
+//
+// which is exactly the B-operand lane map of v_mfma_f32_16x16x4_f32 (B[k][n]).  The sums over pixels
+//     sum_p gda[p][e] * {1, x_p, y_p, x_p^2, x_p y_p, y_p^2}      (dL/dopacity and the five moments behind du dv dconic)
+//     sum_p  w [p][e] * {g_r, g_g, g_b}[p]                         (dL/dcolour)
+// are contractions over the pixel index: two MFMAs per step with the per-pixel factors as A operands
+// (A[m][k] = feature m of pixel k), accumulated IN THE ACCUMULATOR REGISTERS over the 16 quads of the wave's 8x8
+// quadrant - no butterfly, no per-entry LDS traffic; one flush of 9 x 16 sums per (wave, 16 entries).  What is
+// sequential along a ray - T_k = prod (1 - a_m), the colour behind - becomes two in-row prefix scans over the 16
+// entries (DPP row_shr:1/2/4/8, four instructions each) with a per-pixel carry between groups:
+//     T_k  = Tc * exclusive_prod(1 - a)           Q_k = Qc - inclusive_sum((c . g) a T),   Qc(0) = C_pixel . g
+//     dL/da_k = T_k (c_k . g) - Q_k / (1 - a_k)                                   (front to back)
+// Per-pixel values (g, last contributor, carries) live in the lane whose n equals the quad's index and reach the 16
+// entry lanes of their row through DPP row_newbcast as an OPERAND of the instruction that uses them.
+//
+// A wave walks only the entries that reach its quadrant (compacted at staging time from the forward's exact
+// block test), 16 at a time, and skips the quads whose four pixels are past their last contributor.  The opaque-depth
+// partials do not ride the walk at all: blend_fwd leaves the list position of every pixel's depth owner and the
+// owners' four partials go straight to the entry accumulators once per batch.
+//
+// alpha, the skip tests and the contributor set are evaluated exactly as the forward does (same dx, splat_power,
+// splat_exp, list positions against n_contrib); T differs from the forward's in rounding only (product order).
+#include "raster_common.h"
+
+namespace rtgs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MB = 256;            // list entries staged per batch: one per thread
+constexpr int MACC = 16;           // floats of an entry's LDS accumulator (one 64-B line)
+// accumulator columns: 0 m0 = sum gda | 1 mx 2 my 3 mxx | 4 mxy 5 myy | 6 7 8 colour | 9..12 depth plane | 13..15 unused
+
+template <int CTRL>
+__device__ __forceinline__ float dppf(float old, float v) {      // lanes without a source keep `old`
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ float bcast(float v) {                // lane N of the own row of 16 (every lane has a source)
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + N, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ uint32_t bcast_u(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x150 + N, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float row_scan_mul(float v) {         // inclusive prefix product over the row's 16 lanes
+  v *= dppf<0x111>(1.f, v);
+  v *= dppf<0x112>(1.f, v);
+  v *= dppf<0x114>(1.f, v);
+  v *= dppf<0x118>(1.f, v);
+  return v;
+}
+__device__ __forceinline__ float row_scan_add(float v) {         // inclusive prefix sum
+  v += dppf<0x111>(0.f, v);
+  v += dppf<0x112>(0.f, v);
+  v += dppf<0x114>(0.f, v);
+  v += dppf<0x118>(0.f, v);
+  return v;
+}
+
+// Everything a lane holds during the walk of one group of 16 entries.
+struct MfmaWalk {
+  // entry n of the group (constant over the 16 steps)
+  float u, v, ca, cb, cc, o, cr, cg_, cbl;
+  uint32_t pos;                    // list position (0x7fffffff: no entry in this lane)
+  // pixel (quad = n, k) held by this lane: broadcast to the row when the walk is at quad n
+  float G0, G1, G2, Tc, Qc;
+  uint32_t last;
+  // pixel coordinates of the lane's k for the four quad columns / rows
+  float pxc[4], pyc[4];
+  float A1[16];                    // MFMA A operand of the moments: feature (lane & 15) of pixel (quad s, k)
+  float X[4];                      // colour gradients of 5 quads per register, 3 lanes each (A operand by rotation)
+  f32x4 C1, C2;
+  int n;                           // lane & 15
+
+  template <int S>
+  __device__ __forceinline__ void step(uint32_t stepmask) {
+    if (!((stepmask >> S) & 1u)) return;                     // wave-uniform: the quad's four pixels are through
+    const float dx = u - pxc[S & 3], dy = v - pyc[S >> 2];
+    const float power = splat_power(ca, cb, cc, dx, dy);
+    const float G = splat_exp(fminf(power, 0.f));
+    const float alpha = fminf(0.99f, o * G);
+    const uint32_t lastp = bcast_u<S>(last);
+    const bool valid = (pos < lastp) & !(power > 0.f) & !(alpha < 1.f / 255.f);
+    if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;  // nothing blended here: carries stay
+    const float a = valid ? alpha : 0.f;
+    const float Gv = valid ? G : 0.f;
+    // Hand-scheduled (the compiler neither folds the row broadcasts / shifts into the arithmetic that uses them nor keeps
+    // the scans to one instruction per step): every DPP source below is written at least two issue slots before it is
+    // read (s_nop where nothing useful fits).  row_shr without bound_ctrl: a lane without a source keeps its value, which
+    // makes `x op= x[lane - d]` an in-place Kogge-Stone step.
+    //   incl  = prod_{m <= n} (1 - a_m)          Tk = Tc[quad] * incl[n - 1]        w = a Tk
+    //   cg    = c . g[quad]                      sinc = sum_{m <= n} cg_m w_m        Qk = Qc[quad] - sinc
+    //   gda   = Gv (Tk cg - Qk / (1 - a))        (the alpha clamp is transparent in the backward)
+    float incl, sinc, gda, w, cg, ia, t0;
+    asm volatile(
+        "v_sub_f32 %[incl], 1.0, %[a]\n\t"
+        "v_mul_f32_dpp %[cg], %[G0], %[cr] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
+        "v_rcp_f32 %[ia], %[incl]\n\t"
+        "v_fmac_f32_dpp %[cg], %[G1], %[cgn] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[cg], %[G2], %[cb] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32 %[t0], 1.0\n\t"
+        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_mov_b32_dpp %[t0], %[incl] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %[t0], %[Tc], %[t0] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"      // Tk (DPP source: Tc)
+        "v_mul_f32 %[w], %[a], %[t0]\n\t"
+        "v_mul_f32 %[sinc], %[cg], %[w]\n\t"
+        "v_mul_f32 %[gda], %[t0], %[cg]\n\t"                                                        // Tk cg
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_sub_f32_dpp %[t0], %[Qc], %[sinc] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"    // Qk (reads sinc as a plain operand)
+        "v_fma_f32 %[gda], -%[t0], %[ia], %[gda]\n\t"                                               // Tk cg - Qk / (1 - a)
+        "v_mul_f32 %[gda], %[Gv], %[gda]\n\t"
+        "s_nop 1\n\t"       // VALU write -> MFMA read of gda: two wait states (the compiler cannot see into this block)
+        : [incl] "=&v"(incl), [sinc] "=&v"(sinc), [gda] "=&v"(gda), [w] "=&v"(w), [cg] "=&v"(cg), [ia] "=&v"(ia), [t0] "=&v"(t0)
+        : [a] "v"(a), [Gv] "v"(Gv), [cr] "v"(cr), [cgn] "v"(cg_), [cb] "v"(cbl), [G0] "v"(G0), [G1] "v"(G1), [G2] "v"(G2),
+          [Tc] "v"(Tc), [Qc] "v"(Qc), [S] "n"(S));
+    C1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[S], gda, C1, 0, 0, 0);
+    constexpr int R = S / 5, Tq = S % 5;
+    float a2 = X[R];
+    if constexpr (Tq != 0)                                                // row_ror:(16 - 3 Tq): lane m reads lane m + 3 Tq
+      a2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(X[R]), 0x120 + 16 - 3 * Tq, 0xf, 0xf, false));
+    C2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, w, C2, 0, 0, 0);
+    // the quad's carries move past this group: lane n == S of every row owns them
+    constexpr unsigned long long MINE = 0x0001000100010001ull << S;
+    float tn, qn;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mul_f32_dpp %[tn], %[incl], %[Tc] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_subrev_f32_dpp %[qn], %[sinc], %[Qc] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32 %[Tc], %[Tc], %[tn], %[mine]\n\t"
+        "v_cndmask_b32 %[Qc], %[Qc], %[qn], %[mine]\n\t"
+        : [tn] "=&v"(tn), [qn] "=&v"(qn), [Tc] "+v"(Tc), [Qc] "+v"(Qc)
+        : [incl] "v"(incl), [sinc] "v"(sinc), [mine] "s"(MINE));
+  }
+  __device__ __forceinline__ void run16(uint32_t sm) {
+    step<0>(sm); step<1>(sm); step<2>(sm); step<3>(sm); step<4>(sm); step<5>(sm); step<6>(sm); step<7>(sm);
+    step<8>(sm); step<9>(sm); step<10>(sm); step<11>(sm); step<12>(sm); step<13>(sm); step<14>(sm); step<15>(sm);
+  }
+};
+
+__global__ void __launch_bounds__(256, 4) blend_bwd_mfma_kernel(
+    RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const Splat* __restrict__ splats, const float* __restrict__ out_color, const uint32_t* __restrict__ n_contrib,
+    const int32_t* __restrict__ depth_index, const uint32_t* __restrict__ depth_pos,
+    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
+    const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
+    SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode,
+    uint32_t n_train) {
+  __shared__ float4 s_rec[MB * 3];              // u v ca cb | cc o r g | b id slot0 -
+  __shared__ float s_acc[MB * MACC];            // per-entry sums of the tile (LDS float adds: one flush per wave and group)
+  __shared__ uint8_t s_sub[4][MB];              // per quadrant: the staged entries that reach it, in list order
+  __shared__ uint32_t s_cnt[4][4];              // [quadrant][staging wave]
+  __shared__ unsigned int s_nmax;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int tile = blockIdx.y * p.gx + blockIdx.x;
+  if (spec_failed(p.spec_fail)) return;
+  if ((tile_mode[tile] & 3u) != 2u) return;     // another walk has this tile
+  const uint2 range = ranges[tile];
+  const int nlist = (int)(range.y - range.x);
+  if (nlist == 0) return;
+  const bool use_slots = info->use_slots != 0;
+  SplatGrad* const slot_grads = info->slot_grads;
+
+  // wave = 8x8 quadrant, step = 2x2 quad s of it, DPP row k = pixel of the quad; THIS lane's own pixel is (quad n, k)
+  const int n = lane & 15, k = lane >> 4;
+  const int qx0 = (wv & 1) * 8, qy0 = (wv >> 1) * 8;
+  const int lx = qx0 + 2 * (n & 3) + (k & 1), ly = qy0 + 2 * (n >> 2) + (k >> 1);
+  const int px = blockIdx.x * TILE + lx, py = blockIdx.y * TILE + ly;
+  const bool inside = px < p.W && py < p.H;
+  const size_t pix = (size_t)py * p.W + px;
+  const size_t HW = (size_t)p.H * p.W;
+  const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
+  const float cxT = tx0 + 7.5f, cyT = ty0 + 7.5f;     // moments are taken about the tile centre
+
+  MfmaWalk W;
+  W.n = n;
+  W.last = inside ? n_contrib[pix] : 0u;
+  W.G0 = W.G1 = W.G2 = 0.f;
+  W.Tc = 1.f; W.Qc = 0.f;
+  uint32_t dpos = 0xffffffffu;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (inside) {
+    W.G0 = dL_dcolor[pix]; W.G1 = dL_dcolor[HW + pix]; W.G2 = dL_dcolor[2 * HW + pix];
+    // (colour behind the walk) . g + T_final (bg . g) before the first entry = the pixel's output colour . g
+    W.Qc = out_color[pix] * W.G0 + out_color[HW + pix] * W.G1 + out_color[2 * HW + pix] * W.G2;
+    // opaque-surface depth: D = pd / (n_c . r); only the pixel's owner receives it
+    const int owner = depth_index[pix];
+    const float gD = owner >= 0 ? dL_ddepth[pix] : 0.f;
+    if (owner >= 0 && gD != 0.f) {
+      const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
+      const float pd = reinterpret_cast<const float*>(splats + owner)[12];
+      const float rx = ((float)px - p.cx) / p.fx, ry = ((float)py - p.cy) / p.fy;
+      const float den = r2.y * rx + r2.z * ry + r2.w;
+      const float iden = 1.f / den;
+      const float kk = -gD * (pd * iden) * iden;
+      a0 = kk * rx; a1 = kk * ry; a2 = kk; a3 = gD * iden;
+      dpos = depth_pos[pix];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    W.pxc[j] = (float)(blockIdx.x * TILE + qx0 + 2 * j + (k & 1));
+    W.pyc[j] = (float)(blockIdx.y * TILE + qy0 + 2 * j + (k >> 1));
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const float x = W.pxc[s & 3] - cxT, y = W.pyc[s >> 2] - cyT;
+    W.A1[s] = n == 0 ? 1.f : n == 1 ? x : n == 2 ? y : n == 3 ? x * x : n == 4 ? x * y : n == 5 ? y * y : 0.f;
+  }
+  // colour gradients as A operands: X[r] lane (k, 3 t + c) = g_c of pixel (quad 5 r + t, k); through LDS once
+  {
+    float* tmp = s_acc;                          // [wave][k][quad][3]
+    tmp[((wv * 4 + k) * 16 + n) * 3 + 0] = W.G0;
+    tmp[((wv * 4 + k) * 16 + n) * 3 + 1] = W.G1;
+    tmp[((wv * 4 + k) * 16 + n) * 3 + 2] = W.G2;
+    if (tid == 0) s_nmax = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = 5 * r + n / 3;
+      W.X[r] = (n < 15 && q < 16) ? tmp[((wv * 4 + k) * 16 + q) * 3 + n % 3] : 0.f;
+    }
+  }
+  // the tile stages no further than its last contributor; a wave walks no further than its own
+  uint32_t wave_last = W.last;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, off));
+  if (lane == 0) atomicMax(&s_nmax, wave_last);
+  __syncthreads();
+  const int nuse = min(nlist, (int)s_nmax);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+
+  for (int base = 0; base < nuse; base += MB) {
+    const int m = min(MB, nuse - base);
+    __syncthreads();                                   // previous batch flushed (and the X staging read)
+    // ---- stage one record per thread, test it against the 16 blocks, count per quadrant
+    uint32_t reach = 0;
+    if (tid < m) {
+      const uint32_t id = point_list[range.x + base + tid];
+      const float4* src = reinterpret_cast<const float4*>(splats + id);
+      const float4 q0 = src[0];
+      s_rec[tid * 3 + 0] = q0;
+      const float4 q1 = src[1];
+      s_rec[tid * 3 + 1] = q1;
+      const float b = reinterpret_cast<const float*>(splats + id)[8];
+      const float2 hxy = reinterpret_cast<const float2*>(splats + id)[7];
+      const uint32_t slot0 = use_slots ? gbase[id] : 0u;
+      s_rec[tid * 3 + 2] = make_float4(b, __uint_as_float(id), __uint_as_float(slot0), 0.f);
+      reach = blocks_reached(q0.x, q0.y, hxy.x, hxy.y, q0.z, q0.w, q1.x, q1.y, tx0, ty0);
+    }
+    // quadrant q = blocks (2 qx .. 2 qx + 1, 2 qy .. 2 qy + 1): bits 0x0033 << (2 qx + 8 qy)
+    unsigned long long bal[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bal[q] = __builtin_amdgcn_ballot_w64((reach & (0x0033u << (2 * (q & 1) + 8 * (q >> 1)))) != 0u);
+      if (lane == 0) s_cnt[q][wv] = (uint32_t)__popcll(bal[q]);
+    }
+    for (int q = tid; q < m * MACC; q += BLOCK) s_acc[q] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t off = 0;
+      for (int w2 = 0; w2 < wv; ++w2) off += s_cnt[q][w2];
+      if ((bal[q] >> lane) & 1ull) s_sub[q][off + (uint32_t)__popcll(bal[q] & lt)] = (uint8_t)tid;
+    }
+    // depth owners whose entry is in this batch (each pixel owns at most one entry of the whole list)
+    if (dpos >= (uint32_t)base && dpos < (uint32_t)(base + m)) {
+      float* const acc = &s_acc[(dpos - (uint32_t)base) * MACC];
+      atomicAdd(acc + 9, a0); atomicAdd(acc + 10, a1); atomicAdd(acc + 11, a2); atomicAdd(acc + 12, a3);
+    }
+    __syncthreads();
+
+    // ---- the wave walks its quadrant's sub-list, 16 entries at a time
+    const int cnt = (int)(s_cnt[wv][0] + s_cnt[wv][1] + s_cnt[wv][2] + s_cnt[wv][3]);
+    for (int g0 = 0; g0 < cnt; g0 += 16) {
+      const bool have = g0 + n < cnt;
+      const int e = have ? (int)s_sub[wv][g0 + n] : 0;
+      W.pos = have ? (uint32_t)(base + e) : 0x7fffffffu;
+      const uint32_t first_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.pos);
+      if (first_pos >= wave_last) break;                 // positions increase: the wave is through
+      // quads with a pixel that still blends at or behind the group's first entry
+      const unsigned long long lb = __builtin_amdgcn_ballot_w64(W.last > first_pos);
+      const uint32_t stepmask = (uint32_t)((lb | (lb >> 16) | (lb >> 32) | (lb >> 48)) & 0xffffull);
+      if (stepmask == 0u) continue;
+      const float4 r0 = s_rec[e * 3 + 0], r1 = s_rec[e * 3 + 1];
+      const float rb = s_rec[e * 3 + 2].x;
+      W.u = r0.x; W.v = r0.y; W.ca = r0.z; W.cb = r0.w; W.cc = r1.x; W.o = r1.y; W.cr = r1.z; W.cg_ = r1.w; W.cbl = rb;
+      W.C1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      W.C2 = f32x4{0.f, 0.f, 0.f, 0.f};
+      W.run16(stepmask);
+      // flush: lane (k, n) holds rows 4 k + i of column n.  C1 rows 0..5 = m0 mx my mxx | mxy myy; C2 rows 0..2 = colour
+      if (have) {
+        float* const acc = &s_acc[e * MACC];
+        if (k == 0) {
+          atomicAdd(acc + 0, W.C1[0]); atomicAdd(acc + 1, W.C1[1]); atomicAdd(acc + 2, W.C1[2]); atomicAdd(acc + 3, W.C1[3]);
+          atomicAdd(acc + 6, W.C2[0]); atomicAdd(acc + 7, W.C2[1]); atomicAdd(acc + 8, W.C2[2]);
+        } else if (k == 1) {
+          atomicAdd(acc + 4, W.C1[0]); atomicAdd(acc + 5, W.C1[1]);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- one thread per staged entry: moments -> d(u, v, conic), slot store
+    if (tid < m) {
+      float t[13];
+      bool any = false;
+#pragma unroll
+      for (int q = 0; q < 13; ++q) { t[q] = s_acc[tid * MACC + q]; any |= (t[q] != 0.f); }
+      const uint32_t gid = __float_as_uint(s_rec[tid * 3 + 2].y);
+      if (any && gid < n_train) {
+        const float4 q0 = s_rec[tid * 3 + 0];            // u v ca cb
+        const float4 q1 = s_rec[tid * 3 + 1];            // cc o r g
+        // sums over the pixels of gdl = o gda times powers of d = centre - pixel, from the moments about the tile centre
+        const float ut = q0.x - cxT, vt = q0.y - cyT, o = q1.y;
+        const float m0 = t[0], mx = t[1], my = t[2], mxx = t[3], mxy = t[4], myy = t[5];
+        const float sx = o * (ut * m0 - mx), sy = o * (vt * m0 - my);
+        const float sxx = o * (ut * (ut * m0 - 2.f * mx) + mxx);
+        const float sxy = o * (ut * (vt * m0 - my) - vt * mx + mxy);
+        const float syy = o * (vt * (vt * m0 - 2.f * my) + myy);
+        const float du = -(q0.z * sx + q0.w * sy), dv = -(q1.x * sy + q0.w * sx);
+        const float dca = -0.5f * sxx, dcb = -sxy, dcc = -0.5f * syy, dop = m0;
+        touched[gid] = 1;
+        if (use_slots) {
+          // SplatGrad order: du dv dca dcb | dcc dop dr dg | db dnx dny dnz | dpd - - -
+          const uint32_t slot = __float_as_uint(s_rec[tid * 3 + 2].z) + atomicAdd(&slot_count[gid], 1u);
+          float4* dst = reinterpret_cast<float4*>(slot_grads + slot);
+          dst[0] = make_float4(du, dv, dca, dcb);
+          dst[1] = make_float4(dcc, dop, t[6], t[7]);
+          dst[2] = make_float4(t[8], t[9], t[10], t[11]);
+          dst[3] = make_float4(t[12], 0.f, 0.f, 0.f);
+        } else {
+          float* dst = reinterpret_cast<float*>(grads + gid);
+          const float vals[13] = {du, dv, dca, dcb, dcc, dop, t[6], t[7], t[8], t[9], t[10], t[11], t[12]};
+#pragma unroll
+          for (int q = 0; q < 13; ++q)
+            if (vals[q] != 0.f) unsafeAtomicAdd(dst + q, vals[q]);
+        }
+      }
+    }
+  }
+}
+
+void launch_blend_bwd_mfma(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
+                           const float* out_color, const uint32_t* n_contrib, const int32_t* depth_index,
+                           const uint32_t* depth_pos, const float* dL_dcolor, const float* dL_ddepth, const uint32_t* gbase,
+                           uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
+                           const uint32_t* tile_mode, uint32_t n_train, hipStream_t st) {
+  hipLaunchKernelGGL(blend_bwd_mfma_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
+                     n_contrib, depth_index, depth_pos, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched,
+                     tile_mode, n_train);
+}
+
+}  // namespace rtgs

@@ -132,11 +132,11 @@ struct BinLayout {
   size_t slot_grads;                 // backward partial slots (see BwdInfo); 0 slots = not laid out
 };
 struct ImgLayout {
-  size_t ranges, n_contrib, bwd_info, tile_mode, total;
+  size_t ranges, n_contrib, bwd_info, tile_mode, depth_pos, total;
 };
-// blend_fwd leaves one word per tile for its backward: bit 0 set = the tile's 4x4 blocks each need only a fraction of
-// the tile's list (row-granular walk), clear = they share it (tile-uniform strip walk); bits 8.. hold the measured share
-// in 1/1000.  See raster_bwd.hip.
+// blend_fwd leaves one word per tile for its backward: bits 0..1 = the walk - 0 tile-uniform strip walk (the tile's 4x4
+// blocks share its list), 1 row-granular walk (each block needs only a fraction of it), 2 entry-per-lane MFMA walk
+// (raster_bwd_mfma.hip); bits 8.. hold the measured share in 1/1000.  See raster_bwd.hip.
 #ifndef RTGS_ROWS_MAX_SHARE
 #define RTGS_ROWS_MAX_SHARE 0.6f
 #endif

@@ -308,7 +308,8 @@ __global__ void __launch_bounds__(256, 6) blend_fwd_kernel(
     const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
     int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
     float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
-    unsigned long long* __restrict__ counters, SlicePass sp, uint32_t* __restrict__ tile_mode) {
+    unsigned long long* __restrict__ counters, SlicePass sp, uint32_t* __restrict__ tile_mode,
+    uint32_t* __restrict__ depth_pos) {
   __shared__ float4 s_rec[FWD_BATCH * 4];     // u v ca cb | cc o r g | b - - id | nx ny nz pd: the walk reads the first three
   __shared__ float s_z[FWD_BATCH];            // centre depth (opaque-surface test only)
   __shared__ uint32_t s_live[16][FWD_CHUNKS]; // per 4x4 block: the staged entries that reach it
@@ -335,6 +336,7 @@ __global__ void __launch_bounds__(256, 6) blend_fwd_kernel(
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   float best_w = 0.f; int best_id = -1;
   float D = 0.f, d_w = 0.f; int d_id = -1;
+  uint32_t d_pos = 0u;                       // list position of the depth owner (the backward's MFMA walk hands the owner its partials by position)
   uint32_t last_contributor = 0;
   uint32_t evals = 0;
   uint32_t reach_sum = 0, staged = 0;        // wave-uniform: (block, entry) pairs of the sub-lists / entries this wave staged
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__(256, 6) blend_fwd_kernel(
           const float den = r3.x * rx + r3.y * ry + r3.z;
           if (fabsf(den) / rnorm > p.normal_thr) {
             const float zhit = r3.w / den;
-            if (zhit > 0.f && fabsf(zhit - s_z[e]) < p.depth_thr) { D = zhit; d_w = al; d_id = gid; }
+            if (zhit > 0.f && fabsf(zhit - s_z[e]) < p.depth_thr) { D = zhit; d_w = al; d_id = gid; d_pos = (uint32_t)(base + e); }
           }
         }
       }
@@ -444,6 +446,7 @@ __global__ void __launch_bounds__(256, 6) blend_fwd_kernel(
     out_dw[pix] = d_w;
     out_T[pix] = T;
     n_contrib[pix] = last_contributor;
+    depth_pos[pix] = d_pos;
   }
   if (tile_mode) {
     // which walk the tile's backward takes (raster_bwd.hip): row-granular when its 4x4 blocks need, on average, less than
@@ -557,9 +560,10 @@ void launch_slice_publish(int ntiles, const int32_t* user_mask, const int32_t* m
 void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                       float* out_color, float* out_depth, int32_t* out_cidx, int32_t* out_didx, float* out_cw,
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
-                      SlicePass sp, uint32_t* tile_mode, hipStream_t st) {
+                      SlicePass sp, uint32_t* tile_mode, uint32_t* depth_pos, hipStream_t st) {
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
-                     out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp, tile_mode);
+                     out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp, tile_mode,
+                     depth_pos);
 }
 
 }  // namespace rtgs

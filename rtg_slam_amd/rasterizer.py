@@ -109,15 +109,17 @@ class RasterContext:
 
 def image_buffer_views(img: torch.Tensor, H: int, W: int):
     """Views into a forward's image buffer (tests / diagnostics; layout: rtgs_raster_image_offsets): tile ranges
-    int32[tiles, 2], n_contrib int32[H*W], the backward's walk per tile int32[tiles] (1 = row-granular) and the share of
+    int32[tiles, 2], n_contrib int32[H*W], the backward's walk per tile int32[tiles] (0 strip, 1 row-granular, 2 MFMA), the list position
+    of every pixel's depth owner int32[H*W] and the share of
     the tile's list its 4x4 blocks need on average (what the choice is made from)."""
-    off = (C.c_size_t * 5)()
+    off = (C.c_size_t * 6)()
     _lib.check(_lib.load().rtgs_raster_image_offsets(int(H), int(W), off), "rtgs_raster_image_offsets")
     nt = ((H + 15) // 16) * ((W + 15) // 16)
     view = lambda o, nbytes, dt: img[int(o):int(o) + nbytes].view(dt)
     word = view(off[3], nt * 4, torch.int32)
     return dict(ranges=view(off[0], nt * 8, torch.int32).view(nt, 2), n_contrib=view(off[1], H * W * 4, torch.int32),
-                tile_mode=word & 1, tile_share=(word >> 8).float() / 1000.0)
+                tile_mode=word & 3, tile_share=(word >> 8).float() / 1000.0,
+                depth_pos=view(off[5], H * W * 4, torch.int32))
 
 
 _tls = threading.local()

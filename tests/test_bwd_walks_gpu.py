@@ -79,23 +79,28 @@ def test_the_two_walks_agree_and_match_the_oracle(kind, N, cam, depth, masked):
     out_s, gd_s, m_s = _run(s, g, grads, 1, mask)
     out_r, gd_r, m_r = _run(s, g, grads, 2, mask)
     out_a, gd_a, m_a = _run(s, g, grads, 0, mask)
-    assert int(m_s.sum()) == 0 and int(m_r.sum()) == m_r.numel()
+    out_m, gd_m, m_m = _run(s, g, grads, 3, mask)              # entry-per-lane MFMA walk on every tile
+    assert int(m_s.sum()) == 0 and int(m_r.sum()) == m_r.numel() and bool((m_m == 2).all())
     for a, b in zip(out_s, out_r):
         assert torch.equal(a, b)                       # the forward does not depend on the backward's walk
     for k in ru.FIELDS:
         assert _rel(gd_r[k], gd_s[k]) < 1e-4, k
         assert _rel(gd_a[k], gd_s[k]) < 1e-4, k
+        assert _rel(gd_m[k], gd_s[k]) < 1e-4, (k, _rel(gd_m[k], gd_s[k]))
         rows = lambda t: t.reshape(t.shape[0], -1).abs().sum(1) == 0
-        assert torch.equal(rows(gd_r[k]), rows(gd_s[k])), k      # untouched Gaussians: exact zeros on both walks
+        assert torch.equal(rows(gd_r[k]), rows(gd_s[k])), k      # untouched Gaussians: exact zeros on every walk
         assert torch.equal(rows(gd_a[k]), rows(gd_s[k])), k
+        assert torch.equal(rows(gd_m[k]), rows(gd_s[k])), k
     _, gd_o, _ = ru.oracle_run(s, g, tile_mask=mask, grads=grads)
     margins.record("max gradient error relative to the tensor max",
                    **{k: {"rows_vs_strip": _rel(gd_r[k], gd_s[k]), "auto_vs_strip": _rel(gd_a[k], gd_s[k]),
+                          "mfma_vs_strip": _rel(gd_m[k], gd_s[k]), "mfma_vs_oracle": _rel(gd_m[k], gd_o[k]),
                           "rows_vs_oracle": _rel(gd_r[k], gd_o[k]), "strip_vs_oracle": _rel(gd_s[k], gd_o[k])}
                       for k in ru.FIELDS})
     for k in ru.FIELDS:
         assert _rel(gd_r[k], gd_o[k]) < 1e-3, k
         assert _rel(gd_s[k], gd_o[k]) < 1e-3, k
+        assert _rel(gd_m[k], gd_o[k]) < 1e-3, k
 
 
 def test_per_tile_choice_follows_the_footprints():
@@ -115,8 +120,10 @@ def test_walks_under_the_forced_near_slice():
     g, s = ru.make_scene(20_000, cam, seed=9)
     grads = _grads(cam, 3)
     _, gd_r, _ = _run(s, g, grads, 2, None, slice_mode=(1, 48))
+    _, gd_m, _ = _run(s, g, grads, 3, None, slice_mode=(1, 48))
     _, gd_s, _ = _run(s, g, grads, 1, None, slice_mode=(1, 48))
     _, gd_0, _ = _run(s, g, grads, 1, None, slice_mode=(0, 0))
     for k in ru.FIELDS:
         assert _rel(gd_r[k], gd_s[k]) < 1e-4, k
+        assert _rel(gd_m[k], gd_s[k]) < 1e-4, k
         assert _rel(gd_r[k], gd_0[k]) < 1e-4, k
