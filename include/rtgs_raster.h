@@ -246,16 +246,17 @@ void rtgs_raster_force_sort_path(int enable);
 void rtgs_raster_force_sort_path_ctx(rtgs_ctx* ctx, int enable);
 int rtgs_raster_last_timings(float* ms12_host);
 int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms12_host);
-/* The backward's tile walk.  blend_fwd measures, per tile, how much of the tile's list each of its sixteen 4x4 pixel
- * blocks needs, and leaves one word per tile in the image buffer: tiles whose blocks share the list (large footprints)
- * take the tile-uniform strip walk, tiles whose blocks need less than ROWS_MAX_SHARE (raster_common.h: 60 %) of it on average (a surface map of small
- * discs) the row-granular walk.  A third walk (raster_bwd_mfma.hip) gives a lane one (pixel, ENTRY) pair - 16 entries
- * x 4 pixels per wave step - and reduces over the pixels on the matrix cores (v_mfma_f32_16x16x4_f32).
- * mode 0 = per-tile choice (default), 1 = strip walk everywhere, 2 = row-granular walk everywhere, 3 = MFMA walk
- * everywhere (testing / A-B; RTGS_BWD_WALK at load time).  Gradients of the walks agree to float rounding.
+/* The backward's tile walk.  Three kernels exist (raster_bwd.hip, raster_bwd_mfma.hip):
+ *  - MFMA walk (default): a lane holds one (pixel, ENTRY) pair - 16 entries x 4 pixels per wave step - T and the colour
+ *    behind are in-row DPP scans, and the sums over the pixels run on the matrix cores (v_mfma_f32_16x16x4_f32);
+ *  - strip walk: pixel per lane, one entry per wave pass, tile-uniform (large footprints);
+ *  - row-granular walk: pixel per lane, every 4x4 block walks its own sub-list (small footprints).
+ * mode 0 (default) and 3 = MFMA walk on every tile; 1 = strip walk; 2 = row-granular walk; 4 = per-tile choice between
+ * strip and row-granular from the share of the tile's list its 4x4 blocks need (ROWS_MAX_SHARE, raster_common.h) - the
+ * round-3 behaviour, kept for A-B runs.  RTGS_BWD_WALK at load time.  Gradients of the walks agree to float rounding.
  * rtgs_raster_image_offsets: byte offsets inside the image buffer - [0] tile ranges (uint2 per tile), [1] n_contrib
- * (u32 per pixel), [2] BwdInfo, [3] tile walk (u32 per tile: bits 0..1 = 0 strip / 1 row-granular / 2 MFMA), [4] total
- * size, [5] list position of every pixel's depth owner (u32 per pixel). */
+ * (u32 per pixel), [2] BwdInfo, [3] tile walk (u32 per tile: bits 0..1 = 0 strip / 1 row-granular / 2 MFMA, bits 8.. the
+ * measured share in 1/1000), [4] total size, [5] list position of every pixel's depth owner (u32 per pixel). */
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* ctx, int mode);
 /* Speculative forward (RTGS_FWD_SPECULATE).  verify: 0 = the guessed sizes held (or nothing was pending), 1 = they did
  * not - nothing persistent was changed, redo without the flag; < 0 = error.  It waits (spinning on pinned memory) only

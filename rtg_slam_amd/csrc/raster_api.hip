@@ -19,12 +19,12 @@ void launch_emit_keys(const RasterParams&, const Splat*, const int32_t*, const u
                       uint32_t*, hipStream_t);
 void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
-                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, uint32_t*, hipStream_t);
+                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, uint32_t*, uint32_t*, int, hipStream_t);
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
                       const uint32_t*, const int32_t*, const float*, const float*, const uint32_t*, uint32_t*,
                       const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, uint32_t, hipStream_t);
 void launch_blend_bwd_mfma(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const uint32_t*,
-                           const int32_t*, const uint32_t*, const float*, const float*, const uint32_t*, uint32_t*,
+                           const int32_t*, const uint32_t*, const uint32_t*, const float*, const float*, const uint32_t*, uint32_t*,
                            const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, hipStream_t);
 void launch_grad_reduce(int, const uint8_t*, const uint32_t*, uint32_t*, const BwdInfo*, SplatGrad*, const uint32_t*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
@@ -69,7 +69,7 @@ struct rtgs_ctx {
   unsigned long long* counters = nullptr;
   bool prof = false;                // optional per-stage HIP-event timing (bench.py's roofline leg)
   bool force_sort_path = false;     // testing aid: take the global radix-sort binning path
-  int bwd_walk = 0;                 // 0 = blend_fwd chooses per tile; 1 = strip walk everywhere; 2 = row-granular walk everywhere; 3 = MFMA walk everywhere
+  int bwd_walk = 0;                 // 0 / 3 = MFMA walk (default); 1 = strip walk everywhere; 2 = row-granular walk everywhere; 4 = per-tile choice between those two
   bool ev_init = false;
   hipEvent_t ev[EV_N];
   bool ev_set[EV_N] = {false};
@@ -78,6 +78,7 @@ struct rtgs_ctx {
   // what the most recent forward on this context left for its backward (see backward_impl)
   const void* hint_geom = nullptr;
   bool hint_slice_lists = true, hint_main_lists = true;
+  int hint_walk = -2;               // what that forward wrote into tile_mode (-1 per-tile choice, 0 strip, 1 rows, 2 MFMA)
   // Automatic near-slice mode: whether a call takes the slice is decided on the device from that call's histograms and
   // never depends on history.  Only HOW the host learns it does: after a call that declined, the next one asks for the
   // decision (one extra pinned-flag sync, ~10 us) before it launches the slice's kernels instead of launching them
@@ -124,7 +125,7 @@ static rtgs_ctx* default_ctx() {
     if (const char* e = getenv("RTGS_NEAR_SLICE")) n->slice_mode = atoi(e);
     if (const char* e = getenv("RTGS_NEAR_SLICE_BUDGET")) { const int b = atoi(e); if (b > 0) n->slice_budget = b; }
     if (const char* e = getenv("RTGS_SPECULATE")) n->speculation = atoi(e) != 0;
-    if (const char* e = getenv("RTGS_BWD_WALK")) { const int m = atoi(e); n->bwd_walk = (m >= 1 && m <= 3) ? m : 0; }
+    if (const char* e = getenv("RTGS_BWD_WALK")) { const int m = atoi(e); n->bwd_walk = (m >= 1 && m <= 4) ? m : 0; }
     return n;
   }();
   return c;
@@ -267,6 +268,7 @@ static ImgLayout img_layout(int H, int W, int ntiles) {
   L.bwd_info = off; off = align_up(off + sizeof(BwdInfo));
   L.tile_mode = off; off = align_up(off + (size_t)ntiles * sizeof(uint32_t));
   L.depth_pos = off; off = align_up(off + (size_t)H * W * sizeof(uint32_t));
+  L.tile_last = off; off = align_up(off + (size_t)ntiles * sizeof(uint32_t));
   L.total = off;
   return L;
 }
@@ -388,9 +390,13 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   uint2* ranges = (uint2*)(img + I.ranges);
   uint32_t* n_contrib = (uint32_t*)(img + I.n_contrib);
   uint32_t* depth_pos = (uint32_t*)(img + I.depth_pos);
+  uint32_t* tile_last = (uint32_t*)(img + I.tile_last);
   // always written, also under RTGS_FWD_NO_BACKWARD: a backward that is called anyway (slower, atomics) must not meet stale
   // walk choices of an earlier forward in a recycled image buffer
   uint32_t* const tile_mode = (uint32_t*)(img + I.tile_mode);
+  // what blend_fwd writes there: the MFMA walk (2) by default, a forced pixel-per-lane walk (0 strip, 1 rows), or their
+  // per-tile choice from the measured list share (-1: bwd_walk 4)
+  const int fwd_walk = c->bwd_walk == 0 || c->bwd_walk == 3 ? 2 : (c->bwd_walk == 4 ? -1 : c->bwd_walk - 1);
 
   int64_t R = 0, R1 = 0;
   for (int i = 0; i < EV_B0; ++i) c->ev_set[i] = false;
@@ -497,7 +503,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                            (SplatGrad*)(bin + B.slot_grads), use_sl ? sl : 0u, use_sl ? 1u : 0u);
         const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
         launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                         n_contrib, c->counters, pass1, tile_mode, depth_pos, st);
+                         n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, st);
         launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, fail, st);
         prof_mark(c, EV_SL_BLEND, st);
         prof_mark(c, EV_BLEND0, st); prof_mark(c, EV_BLEND, st);
@@ -547,16 +553,14 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         prof_mark(c, EV_SORT, st);
         prof_mark(c, EV_BLEND0, st);
         launch_blend_fwd(pg, ranges, (uint32_t*)(bin + B.vals_b), splats, out_color, out_depth, out_cidx, out_didx, out_cw,
-                         out_dw, out_T, n_contrib, c->counters, SlicePass{0, nullptr, nullptr, nullptr, nullptr}, tile_mode, depth_pos, st);
+                         out_dw, out_T, n_contrib, c->counters, SlicePass{0, nullptr, nullptr, nullptr, nullptr}, tile_mode, depth_pos, tile_last, fwd_walk, st);
         prof_mark(c, EV_BLEND, st);
         c->hint_slice_lists = false; c->hint_main_lists = true;
         c->slice_stats[0] = pl.kind == 2 ? 1 : 0; c->slice_stats[1] = 0; c->slice_stats[2] = 0;
         c->slice_stats[3] = pl.kind == 2 ? (int64_t)ntiles : 0;
       }
-      if (tile_mode && c->bwd_walk != 0)
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tile_mode, c->bwd_walk - 1, (size_t)ntiles, st));
       HIP_TRY(hipGetLastError());
-      c->hint_geom = geom;
+      c->hint_geom = geom; c->hint_walk = fwd_walk;
       c->spec.pending = true; c->spec.kind = pl.kind; c->spec.seq = c->seq; c->spec.capR = capR; c->spec.capL = capL;
       c->spec.capS = capS; c->spec.geom = geom; c->spec.fail_dev = fail; c->spec.stream = stream; c->spec.ntiles = ntiles;
       c->spec.G_total = (int64_t)G.total; c->spec.B_total = (int64_t)b_total; c->spec.I_total = (int64_t)I.total;
@@ -628,7 +632,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       if (++c->seq == 0u) c->seq = 1u;
       const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
       launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                       n_contrib, c->counters, pass1, tile_mode, depth_pos, st);
+                       n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, st);
       launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, nullptr, st);
       DBG(s, st);
       prof_mark(c, EV_SL_BLEND, st);
@@ -741,9 +745,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   prof_mark(c, EV_BLEND0, st);
   if (!sliced || n_left > 0)     // pass 2 (or the only pass); with every tile finished by the slice there is nothing to draw
     launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                     n_contrib, c->counters, pass, tile_mode, depth_pos, st);
-  if (tile_mode && c->bwd_walk != 0)      // testing / A-B aid: one walk for every tile
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tile_mode, c->bwd_walk - 1, (size_t)ntiles, st));
+                     n_contrib, c->counters, pass, tile_mode, depth_pos, tile_last, fwd_walk, st);
   prof_mark(c, EV_BLEND, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
@@ -754,7 +756,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   c->slice_stats[3] = considered ? (int64_t)ntiles : (int64_t)n_left;      // declined: every tile goes to the single pass
   if (slice_auto && (sliced || considered)) c->ask_first = considered || (R1 == 0 && n_fin == 0);
   // which of the two list sets the backward of THIS forward has to walk (host-side hint, keyed by the geometry buffer)
-  c->hint_geom = geom; c->hint_slice_lists = sliced && n_fin > 0; c->hint_main_lists = R > 0;
+  c->hint_geom = geom; c->hint_slice_lists = sliced && n_fin > 0; c->hint_main_lists = R > 0; c->hint_walk = fwd_walk;
   {
     // what a speculative forward on this context may assume next time (rtgs_raster_forward_verify keeps it current)
     rtgs_ctx::Plan& pl = c->plan;
@@ -815,7 +817,10 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
     // (a launch whose every workgroup would find an empty range is skipped when this context still remembers the forward)
     const bool hinted = c->hint_geom == geom_buffer;
     // bit 0 strip, bit 1 row-granular, bit 2 MFMA walk: a forced walk launches only its kernel
-    const int which = c->bwd_walk == 0 ? 3 : (1 << (c->bwd_walk - 1));
+    // the kernels to launch follow what the FORWARD wrote into tile_mode (remembered with its geometry buffer), not the
+    // context's setting at backward time; a backward this context does not remember launches all three - each kernel
+    // takes only the tiles that carry its walk
+    const int which = !hinted ? 7 : (c->hint_walk == 2 ? 4 : (c->hint_walk == -1 ? 3 : (c->hint_walk == 0 ? 1 : 2)));
     const uint32_t n_train = (uint32_t)P;
     const uint32_t* depth_pos = (const uint32_t*)(img + I.depth_pos);
     for (int set = 0; set < 2; ++set) {
@@ -827,8 +832,8 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
                          out_didx, dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode, which & 3, n_train, st);
       if (which & 4)
         launch_blend_bwd_mfma(p, rg, pl, (const Splat*)(geom + G.splats), out_color, (const uint32_t*)(img + I.n_contrib),
-                              out_didx, depth_pos, dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode,
-                              n_train, st);
+                              out_didx, depth_pos, (const uint32_t*)(img + I.tile_last), dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads,
+                              touched, tile_mode, n_train, st);
     }
     prof_mark(c, EV_BWALK, st);
     // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
@@ -921,7 +926,7 @@ int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
   memcpy(out3, use(ctx)->spec_stats, sizeof(use(ctx)->spec_stats));
   return RTGS_OK;
 }
-void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode >= 1 && mode <= 3) ? mode : 0; }
+void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode >= 1 && mode <= 4) ? mode : 0; }
 int rtgs_raster_image_offsets(int32_t H, int32_t W, size_t* out) {
   if (!out || H <= 0 || W <= 0) return RTGS_E_INVALID;
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;

@@ -27,14 +27,15 @@
 // alpha, the skip tests and the contributor set are evaluated exactly as the forward does (same dx, splat_power,
 // splat_exp, list positions against n_contrib); T differs from the forward's in rounding only (product order).
 #include "raster_common.h"
+#include <stdlib.h>
 
 namespace rtgs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MB = 256;            // list entries staged per batch: one per thread
-constexpr int MACC = 16;           // floats of an entry's LDS accumulator (one 64-B line)
-// accumulator columns: 0 m0 = sum gda | 1 mx 2 my 3 mxx | 4 mxy 5 myy | 6 7 8 colour | 9..12 depth plane | 13..15 unused
+constexpr int MACC = 13;           // floats of an entry's LDS accumulator (odd stride: conflict-free; 16 would cost the fifth workgroup per CU)
+// accumulator columns: 0 m0 = sum gda | 1 mx 2 my 3 mxx | 4 mxy 5 myy | 6 7 8 colour | 9..12 depth plane
 
 template <int CTRL>
 __device__ __forceinline__ float dppf(float old, float v) {      // lanes without a source keep `old`
@@ -73,7 +74,7 @@ struct MfmaWalk {
   uint32_t last;
   // pixel coordinates of the lane's k for the four quad columns / rows
   float pxc[4], pyc[4];
-  float A1[16];                    // MFMA A operand of the moments: feature (lane & 15) of pixel (quad s, k)
+  float fP[4], fQ[4];              // MFMA A operand of the moments = fP[quad column] * fQ[quad row]: feature (lane & 15) of pixel (quad s, k)
   float X[4];                      // colour gradients of 5 quads per register, 3 lanes each (A operand by rotation)
   f32x4 C1, C2;
   int n;                           // lane & 15
@@ -81,10 +82,32 @@ struct MfmaWalk {
   template <int S>
   __device__ __forceinline__ void step(uint32_t stepmask) {
     if (!((stepmask >> S) & 1u)) return;                     // wave-uniform: the quad's four pixels are through
-    const float dx = u - pxc[S & 3], dy = v - pyc[S >> 2];
-    const float power = splat_power(ca, cb, cc, dx, dy);
-    const float G = splat_exp(fminf(power, 0.f));
-    const float alpha = fminf(0.99f, o * G);
+    // alpha exactly as blend_fwd evaluates it (splat_power / splat_exp, raster_common.h: same operations, same order,
+    // same roundings - the skip decisions below must be the forward's).  In a volatile block: left to itself the
+    // compiler hoists the shared subexpressions of the 16 unrolled steps (4 dx, 4 dy and their products) out of the
+    // group loop and pays for it with 40 more registers - one wave per SIMD less.
+    float power, G, alpha;
+    {
+      float dx, dy, t1, t2;
+      asm volatile(
+          "v_sub_f32 %[dx], %[u], %[px]\n\t"
+          "v_sub_f32 %[dy], %[v], %[py]\n\t"
+          "v_mul_f32 %[t1], %[ca], %[dx]\n\t"
+          "v_mul_f32 %[t2], %[cc], %[dy]\n\t"
+          "v_mul_f32 %[t2], %[t2], %[dy]\n\t"
+          "v_fma_f32 %[t1], %[t1], %[dx], %[t2]\n\t"          // q = fma(ca dx, dx, (cc dy) dy)
+          "v_mul_f32 %[t2], %[cb], %[dx]\n\t"
+          "v_mul_f32 %[t2], %[t2], %[dy]\n\t"
+          "v_fma_f32 %[pw], -0.5, %[t1], -%[t2]\n\t"          // power = fma(-0.5, q, -(cb dx) dy)
+          "v_min_f32 %[t1], 0, %[pw]\n\t"
+          "v_mul_f32 %[t1], 0x3fb8aa3b, %[t1]\n\t"            // * log2(e), as splat_exp
+          "v_exp_f32 %[G], %[t1]\n\t"
+          "s_nop 0\n\t"                                       // transcendental result -> next VALU
+          "v_mul_f32 %[al], %[o], %[G]\n\t"
+          "v_min_f32 %[al], 0x3f7d70a4, %[al]\n\t"            // min(0.99, o G)
+          : [dx] "=&v"(dx), [dy] "=&v"(dy), [t1] "=&v"(t1), [t2] "=&v"(t2), [pw] "=&v"(power), [G] "=&v"(G), [al] "=&v"(alpha)
+          : [u] "v"(u), [v] "v"(v), [ca] "v"(ca), [cb] "v"(cb), [cc] "v"(cc), [o] "v"(o), [px] "v"(pxc[S & 3]), [py] "v"(pyc[S >> 2]));
+    }
     const uint32_t lastp = bcast_u<S>(last);
     const bool valid = (pos < lastp) & !(power > 0.f) & !(alpha < 1.f / 255.f);
     if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;  // nothing blended here: carries stay
@@ -97,9 +120,10 @@ struct MfmaWalk {
     //   incl  = prod_{m <= n} (1 - a_m)          Tk = Tc[quad] * incl[n - 1]        w = a Tk
     //   cg    = c . g[quad]                      sinc = sum_{m <= n} cg_m w_m        Qk = Qc[quad] - sinc
     //   gda   = Gv (Tk cg - Qk / (1 - a))        (the alpha clamp is transparent in the backward)
-    float incl, sinc, gda, w, cg, ia, t0;
+    float incl, sinc, gda, w, cg, ia, t0, a1;
     asm volatile(
         "v_sub_f32 %[incl], 1.0, %[a]\n\t"
+        "v_mul_f32 %[a1], %[fp], %[fq]\n\t"                                                         // A operand of the moments
         "v_mul_f32_dpp %[cg], %[G0], %[cr] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
         "v_rcp_f32 %[ia], %[incl]\n\t"
         "v_fmac_f32_dpp %[cg], %[G1], %[cgn] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
@@ -129,10 +153,11 @@ struct MfmaWalk {
         "v_fma_f32 %[gda], -%[t0], %[ia], %[gda]\n\t"                                               // Tk cg - Qk / (1 - a)
         "v_mul_f32 %[gda], %[Gv], %[gda]\n\t"
         "s_nop 1\n\t"       // VALU write -> MFMA read of gda: two wait states (the compiler cannot see into this block)
-        : [incl] "=&v"(incl), [sinc] "=&v"(sinc), [gda] "=&v"(gda), [w] "=&v"(w), [cg] "=&v"(cg), [ia] "=&v"(ia), [t0] "=&v"(t0)
+        : [incl] "=&v"(incl), [sinc] "=&v"(sinc), [gda] "=&v"(gda), [w] "=&v"(w), [cg] "=&v"(cg), [ia] "=&v"(ia), [t0] "=&v"(t0),
+          [a1] "=&v"(a1)
         : [a] "v"(a), [Gv] "v"(Gv), [cr] "v"(cr), [cgn] "v"(cg_), [cb] "v"(cbl), [G0] "v"(G0), [G1] "v"(G1), [G2] "v"(G2),
-          [Tc] "v"(Tc), [Qc] "v"(Qc), [S] "n"(S));
-    C1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[S], gda, C1, 0, 0, 0);
+          [Tc] "v"(Tc), [Qc] "v"(Qc), [fp] "v"(fP[S & 3]), [fq] "v"(fQ[S >> 2]), [S] "n"(S));
+    C1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, gda, C1, 0, 0, 0);
     constexpr int R = S / 5, Tq = S % 5;
     float a2 = X[R];
     if constexpr (Tq != 0)                                                // row_ror:(16 - 3 Tq): lane m reads lane m + 3 Tq
@@ -156,107 +181,147 @@ struct MfmaWalk {
   }
 };
 
-__global__ void __launch_bounds__(256, 4) blend_bwd_mfma_kernel(
+// Sum of v over the wave's 64 lanes, in every lane (DPP inside the rows, four readlanes across them).
+__device__ __forceinline__ float wave_total(float v) {
+  v += dppf<0xB1>(0.f, v);                 // quad_perm [1,0,3,2]
+  v += dppf<0x4E>(0.f, v);                 // quad_perm [2,3,0,1]
+  v += dppf<0x141>(0.f, v);                // row_half_mirror
+  v += dppf<0x140>(0.f, v);                // row_mirror: every lane of a row holds the row sum
+  return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
+}
+// The opaque-depth partials of the wave's pixels whose owner entry is staged (rel = its index in the batch), summed per
+// owner BEFORE they reach LDS: neighbouring pixels share their owner (a near Gaussian owns a whole quadrant), and 64
+// same-address LDS float adds serialise - measured 21 us of the headline launch when every lane added for itself.
+__device__ __forceinline__ void depth_adds(bool pend, uint32_t rel, float d0, float d1, float d2, float d3, float* s_acc, int lane) {
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(pend);
+  while (todo != 0ull) {
+    const int leader = __builtin_ctzll(todo);
+    const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)rel, leader);
+    const bool mine = pend && rel == key;
+    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+    const float t0 = wave_total(mine ? d0 : 0.f), t1 = wave_total(mine ? d1 : 0.f);
+    const float t2 = wave_total(mine ? d2 : 0.f), t3 = wave_total(mine ? d3 : 0.f);
+    if (lane < 4) atomicAdd(&s_acc[key * MACC + 9 + lane], lane == 0 ? t0 : lane == 1 ? t1 : lane == 2 ? t2 : t3);
+  }
+}
+
+__global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, const float* __restrict__ out_color, const uint32_t* __restrict__ n_contrib,
-    const int32_t* __restrict__ depth_index, const uint32_t* __restrict__ depth_pos,
+    const int32_t* __restrict__ depth_index, const uint32_t* __restrict__ depth_pos, const uint32_t* __restrict__ tile_last,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
     SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode,
-    uint32_t n_train) {
+    uint32_t n_train, uint32_t dbg) {
   __shared__ float4 s_rec[MB * 3];              // u v ca cb | cc o r g | b id slot0 -
   __shared__ float s_acc[MB * MACC];            // per-entry sums of the tile (LDS float adds: one flush per wave and group)
+  __shared__ float s_g[4][4][16][3];            // [wave][k][quad][channel]: colour gradients on their way into X
   __shared__ uint8_t s_sub[4][MB];              // per quadrant: the staged entries that reach it, in list order
   __shared__ uint32_t s_cnt[4][4];              // [quadrant][staging wave]
-  __shared__ unsigned int s_nmax;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
-  if (spec_failed(p.spec_fail)) return;
-  if ((tile_mode[tile] & 3u) != 2u) return;     // another walk has this tile
-  const uint2 range = ranges[tile];
-  const int nlist = (int)(range.y - range.x);
-  if (nlist == 0) return;
-  const bool use_slots = info->use_slots != 0;
-  SplatGrad* const slot_grads = info->slot_grads;
-
   // wave = 8x8 quadrant, step = 2x2 quad s of it, DPP row k = pixel of the quad; THIS lane's own pixel is (quad n, k)
   const int n = lane & 15, k = lane >> 4;
   const int qx0 = (wv & 1) * 8, qy0 = (wv >> 1) * 8;
-  const int lx = qx0 + 2 * (n & 3) + (k & 1), ly = qy0 + 2 * (n >> 2) + (k >> 1);
-  const int px = blockIdx.x * TILE + lx, py = blockIdx.y * TILE + ly;
+  const int px = blockIdx.x * TILE + qx0 + 2 * (n & 3) + (k & 1), py = blockIdx.y * TILE + qy0 + 2 * (n >> 2) + (k >> 1);
   const bool inside = px < p.W && py < p.H;
-  const size_t pix = (size_t)py * p.W + px;
-  const size_t HW = (size_t)p.H * p.W;
+  const uint32_t HW = (uint32_t)(p.H * p.W);
+  const uint32_t pix = inside ? (uint32_t)(py * p.W + px) : 0u;       // clamped: the loads below carry no branch
+
+  // This phase is latency: every load whose address is known is issued before the first one is waited for - the
+  // per-tile words (one scalar round trip, not four dependent ones) and the per-pixel values.
+  const uint32_t tmode = tile_mode[tile];
+  const uint2 range = ranges[tile];
+  const uint32_t tlast = tile_last[tile];               // the tile's last contributor (left by blend_fwd)
+  const bool failed = spec_failed(p.spec_fail);
+  const uint32_t use_slots_w = info->use_slots;
+  SplatGrad* const slot_grads = info->slot_grads;
+  const uint32_t last_ld = n_contrib[pix];
+  const float g0 = dL_dcolor[pix], g1 = dL_dcolor[HW + pix], g2 = dL_dcolor[2 * HW + pix];
+  const float oc0 = out_color[pix], oc1 = out_color[HW + pix], oc2 = out_color[2 * HW + pix];
+  const int owner_ld = depth_index[pix];
+  const float gD_ld = dL_ddepth[pix];
+  const uint32_t dpos_ld = depth_pos[pix];
+  // the tile stages no further than its last contributor: no reduction of n_contrib, no barrier before the first gather
+  const int nuse = min((int)(range.y - range.x), (int)tlast);
+  const bool act = !failed & ((tmode & 3u) == 2u) & (nuse > 0);      // else: another walk has this tile, or nothing to do
+  // first batch: the gather's two dependent hops start now, under the per-pixel loads still in flight
+  const int m0n = min(MB, nuse);
+  const uint32_t id0 = (act && tid < m0n) ? point_list[range.x + tid] : 0u;
+  // (keeps the loads above the exit: sunk below it - where their first use is - they would start one scalar round trip
+  // per test later, and this phase is nothing but round trips)
+  asm volatile("" ::"v"(last_ld), "v"(g0), "v"(g1), "v"(g2), "v"(oc0), "v"(oc1), "v"(oc2), "v"(owner_ld), "v"(gD_ld), "v"(dpos_ld), "v"(id0),
+               "s"(use_slots_w), "s"(slot_grads));
+  if (!act) return;
+  const bool use_slots = use_slots_w != 0;
+
   const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
   const float cxT = tx0 + 7.5f, cyT = ty0 + 7.5f;     // moments are taken about the tile centre
 
   MfmaWalk W;
   W.n = n;
-  W.last = inside ? n_contrib[pix] : 0u;
-  W.G0 = W.G1 = W.G2 = 0.f;
-  W.Tc = 1.f; W.Qc = 0.f;
-  uint32_t dpos = 0xffffffffu;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (inside) {
-    W.G0 = dL_dcolor[pix]; W.G1 = dL_dcolor[HW + pix]; W.G2 = dL_dcolor[2 * HW + pix];
-    // (colour behind the walk) . g + T_final (bg . g) before the first entry = the pixel's output colour . g
-    W.Qc = out_color[pix] * W.G0 + out_color[HW + pix] * W.G1 + out_color[2 * HW + pix] * W.G2;
-    // opaque-surface depth: D = pd / (n_c . r); only the pixel's owner receives it
-    const int owner = depth_index[pix];
-    const float gD = owner >= 0 ? dL_ddepth[pix] : 0.f;
-    if (owner >= 0 && gD != 0.f) {
-      const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
-      const float pd = reinterpret_cast<const float*>(splats + owner)[12];
-      const float rx = ((float)px - p.cx) / p.fx, ry = ((float)py - p.cy) / p.fy;
-      const float den = r2.y * rx + r2.z * ry + r2.w;
-      const float iden = 1.f / den;
-      const float kk = -gD * (pd * iden) * iden;
-      a0 = kk * rx; a1 = kk * ry; a2 = kk; a3 = gD * iden;
-      dpos = depth_pos[pix];
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    W.pxc[j] = (float)(blockIdx.x * TILE + qx0 + 2 * j + (k & 1));
-    W.pyc[j] = (float)(blockIdx.y * TILE + qy0 + 2 * j + (k >> 1));
-  }
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const float x = W.pxc[s & 3] - cxT, y = W.pyc[s >> 2] - cyT;
-    W.A1[s] = n == 0 ? 1.f : n == 1 ? x : n == 2 ? y : n == 3 ? x * x : n == 4 ? x * y : n == 5 ? y * y : 0.f;
-  }
-  // colour gradients as A operands: X[r] lane (k, 3 t + c) = g_c of pixel (quad 5 r + t, k); through LDS once
-  {
-    float* tmp = s_acc;                          // [wave][k][quad][3]
-    tmp[((wv * 4 + k) * 16 + n) * 3 + 0] = W.G0;
-    tmp[((wv * 4 + k) * 16 + n) * 3 + 1] = W.G1;
-    tmp[((wv * 4 + k) * 16 + n) * 3 + 2] = W.G2;
-    if (tid == 0) s_nmax = 0;
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = 5 * r + n / 3;
-      W.X[r] = (n < 15 && q < 16) ? tmp[((wv * 4 + k) * 16 + q) * 3 + n % 3] : 0.f;
-    }
-  }
-  // the tile stages no further than its last contributor; a wave walks no further than its own
+  W.last = inside ? last_ld : 0u;
+  W.G0 = inside ? g0 : 0.f; W.G1 = inside ? g1 : 0.f; W.G2 = inside ? g2 : 0.f;
+  W.Tc = 1.f;
+  // (colour behind the walk) . g + T_final (bg . g) before the first entry = the pixel's output colour . g
+  W.Qc = oc0 * W.G0 + oc1 * W.G1 + oc2 * W.G2;
+  // list position of this pixel's depth owner, if it has one with gradient
+  const bool has_owner = inside && owner_ld >= 0 && gD_ld != 0.f;
+  const uint32_t dpos = has_owner ? dpos_ld : 0xffffffffu;
+  for (int q = tid; q < m0n * MACC; q += BLOCK) s_acc[q] = 0.f;
+  s_g[wv][k][n][0] = W.G0; s_g[wv][k][n][1] = W.G1; s_g[wv][k][n][2] = W.G2;
+  // a wave walks no further than its own last contributor
   uint32_t wave_last = W.last;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, off));
-  if (lane == 0) atomicMax(&s_nmax, wave_last);
-  __syncthreads();
-  const int nuse = min(nlist, (int)s_nmax);
   const unsigned long long lt = (1ull << lane) - 1ull;
+  __syncthreads();                                     // the first batch's accumulators are zero
+  // Opaque-surface depth: D = pd / (n_c . r); only the pixel's owner receives it.  A pixel owns
+  // at most one entry of the whole list: its four partials go to that entry's accumulator in the batch that stages it -
+  // for the first batch here, with the owner's record fetched beside the gather (later batches: inside the loop).
+  {
+    const bool pend = dpos < (uint32_t)m0n && !(dbg & 2u);
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    if (pend) {
+      const float4 r2 = reinterpret_cast<const float4*>(splats + owner_ld)[2];   // b nx ny nz
+      const float pd = reinterpret_cast<const float*>(splats + owner_ld)[12];
+      const float rx = ((float)px - p.cx) / p.fx, ry = ((float)py - p.cy) / p.fy;
+      const float iden = 1.f / (r2.y * rx + r2.z * ry + r2.w);
+      const float kk = -gD_ld * (pd * iden) * iden;
+      d0 = kk * rx; d1 = kk * ry; d2 = kk; d3 = gD_ld * iden;
+    }
+    depth_adds(pend, dpos, d0, d1, d2, d3, s_acc, lane);
+  }
 
   for (int base = 0; base < nuse; base += MB) {
     const int m = min(MB, nuse - base);
-    __syncthreads();                                   // previous batch flushed (and the X staging read)
-    // ---- stage one record per thread, test it against the 16 blocks, count per quadrant
+    if (base > 0) {
+      __syncthreads();                                 // previous batch flushed before its LDS is reused
+      for (int q = tid; q < m * MACC; q += BLOCK) s_acc[q] = 0.f;
+      __syncthreads();
+      const bool pend = dpos >= (uint32_t)base && dpos < (uint32_t)(base + m);
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+      if (pend) {
+        const int owner = depth_index[pix];
+        const float gD = dL_ddepth[pix];
+        const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
+        const float pd = reinterpret_cast<const float*>(splats + owner)[12];
+        const float rx = ((float)px - p.cx) / p.fx, ry = ((float)py - p.cy) / p.fy;
+        const float iden = 1.f / (r2.y * rx + r2.z * ry + r2.w);
+        const float kk = -gD * (pd * iden) * iden;
+        d0 = kk * rx; d1 = kk * ry; d2 = kk; d3 = gD * iden;
+      }
+      depth_adds(pend, dpos - (uint32_t)base, d0, d1, d2, d3, s_acc, lane);
+    }
+    // ---- stage one record per thread, test it against the four quadrants, count per quadrant
     uint32_t reach = 0;
+    float txl = tx0, tyl = ty0;                        // laundered: the block test's per-tile constants must not be hoisted
+    asm volatile("" : "+v"(txl), "+v"(tyl));           // out of the batch loop (they would be live through the walk)
     if (tid < m) {
-      const uint32_t id = point_list[range.x + base + tid];
+      const uint32_t id = base == 0 ? id0 : point_list[range.x + base + tid];
       const float4* src = reinterpret_cast<const float4*>(splats + id);
       const float4 q0 = src[0];
       s_rec[tid * 3 + 0] = q0;
@@ -266,16 +331,14 @@ __global__ void __launch_bounds__(256, 4) blend_bwd_mfma_kernel(
       const float2 hxy = reinterpret_cast<const float2*>(splats + id)[7];
       const uint32_t slot0 = use_slots ? gbase[id] : 0u;
       s_rec[tid * 3 + 2] = make_float4(b, __uint_as_float(id), __uint_as_float(slot0), 0.f);
-      reach = blocks_reached(q0.x, q0.y, hxy.x, hxy.y, q0.z, q0.w, q1.x, q1.y, tx0, ty0);
+      reach = quads_reached(q0.x, q0.y, hxy.x, hxy.y, q0.z, q0.w, q1.x, q1.y, txl, tyl);
     }
-    // quadrant q = blocks (2 qx .. 2 qx + 1, 2 qy .. 2 qy + 1): bits 0x0033 << (2 qx + 8 qy)
     unsigned long long bal[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      bal[q] = __builtin_amdgcn_ballot_w64((reach & (0x0033u << (2 * (q & 1) + 8 * (q >> 1)))) != 0u);
+      bal[q] = __builtin_amdgcn_ballot_w64(((reach >> q) & 1u) != 0u);
       if (lane == 0) s_cnt[q][wv] = (uint32_t)__popcll(bal[q]);
     }
-    for (int q = tid; q < m * MACC; q += BLOCK) s_acc[q] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -283,16 +346,32 @@ __global__ void __launch_bounds__(256, 4) blend_bwd_mfma_kernel(
       for (int w2 = 0; w2 < wv; ++w2) off += s_cnt[q][w2];
       if ((bal[q] >> lane) & 1ull) s_sub[q][off + (uint32_t)__popcll(bal[q] & lt)] = (uint8_t)tid;
     }
-    // depth owners whose entry is in this batch (each pixel owns at most one entry of the whole list)
-    if (dpos >= (uint32_t)base && dpos < (uint32_t)(base + m)) {
-      float* const acc = &s_acc[(dpos - (uint32_t)base) * MACC];
-      atomicAdd(acc + 9, a0); atomicAdd(acc + 10, a1); atomicAdd(acc + 11, a2); atomicAdd(acc + 12, a3);
-    }
     __syncthreads();
 
     // ---- the wave walks its quadrant's sub-list, 16 entries at a time
     const int cnt = (int)(s_cnt[wv][0] + s_cnt[wv][1] + s_cnt[wv][2] + s_cnt[wv][3]);
-    for (int g0 = 0; g0 < cnt; g0 += 16) {
+    {
+      // Per-lane constants of the walk, (re)built per batch from the laundered lane coordinates: held across the batch
+      // loop they would be live through the staging above (whose block test is register-hungry) and cost a wave per SIMD.
+      int kq = k, nq = n;
+      asm volatile("" : "+v"(kq), "+v"(nq));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        W.pxc[j] = (float)(blockIdx.x * TILE + qx0 + 2 * j + (kq & 1));
+        W.pyc[j] = (float)(blockIdx.y * TILE + qy0 + 2 * j + (kq >> 1));
+        // features 1 x y x^2 xy y^2 of the pixel, factored into a column and a row term per lane (lane & 15 = feature)
+        const float x = W.pxc[j] - cxT, y = W.pyc[j] - cyT;
+        W.fP[j] = (nq == 1 || nq == 4) ? x : nq == 3 ? x * x : nq <= 5 ? 1.f : 0.f;
+        W.fQ[j] = (nq == 2 || nq == 4) ? y : nq == 5 ? y * y : 1.f;
+      }
+      // colour gradients as A operands: X[r] lane (k, 3 t + c) = g_c of pixel (quad 5 r + t, k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = 5 * r + nq / 3;
+        W.X[r] = (nq < 15 && q < 16) ? s_g[wv][kq][q][nq % 3] : 0.f;
+      }
+    }
+    for (int g0 = 0; g0 < cnt && !(dbg & 1u); g0 += 16) {
       const bool have = g0 + n < cnt;
       const int e = have ? (int)s_sub[wv][g0 + n] : 0;
       W.pos = have ? (uint32_t)(base + e) : 0x7fffffffu;
@@ -328,7 +407,7 @@ __global__ void __launch_bounds__(256, 4) blend_bwd_mfma_kernel(
 #pragma unroll
       for (int q = 0; q < 13; ++q) { t[q] = s_acc[tid * MACC + q]; any |= (t[q] != 0.f); }
       const uint32_t gid = __float_as_uint(s_rec[tid * 3 + 2].y);
-      if (any && gid < n_train) {
+      if (any && gid < n_train && !(dbg & 4u)) {          // a frozen row (id >= n_train) takes no slot
         const float4 q0 = s_rec[tid * 3 + 0];            // u v ca cb
         const float4 q1 = s_rec[tid * 3 + 1];            // cc o r g
         // sums over the pixels of gdl = o gda times powers of d = centre - pixel, from the moments about the tile centre
@@ -363,12 +442,13 @@ __global__ void __launch_bounds__(256, 4) blend_bwd_mfma_kernel(
 
 void launch_blend_bwd_mfma(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                            const float* out_color, const uint32_t* n_contrib, const int32_t* depth_index,
-                           const uint32_t* depth_pos, const float* dL_dcolor, const float* dL_ddepth, const uint32_t* gbase,
-                           uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
+                           const uint32_t* depth_pos, const uint32_t* tile_last, const float* dL_dcolor, const float* dL_ddepth,
+                           const uint32_t* gbase, uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
                            const uint32_t* tile_mode, uint32_t n_train, hipStream_t st) {
+  static const uint32_t dbg = getenv("RTGS_MFMA_DEBUG") ? (uint32_t)atoi(getenv("RTGS_MFMA_DEBUG")) : 0u;   // experiments only
   hipLaunchKernelGGL(blend_bwd_mfma_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
-                     n_contrib, depth_index, depth_pos, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched,
-                     tile_mode, n_train);
+                     n_contrib, depth_index, depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched,
+                     tile_mode, n_train, dbg);
 }
 
 }  // namespace rtgs

@@ -132,7 +132,7 @@ struct BinLayout {
   size_t slot_grads;                 // backward partial slots (see BwdInfo); 0 slots = not laid out
 };
 struct ImgLayout {
-  size_t ranges, n_contrib, bwd_info, tile_mode, depth_pos, total;
+  size_t ranges, n_contrib, bwd_info, tile_mode, depth_pos, tile_last, total;
 };
 // blend_fwd leaves one word per tile for its backward: bits 0..1 = the walk - 0 tile-uniform strip walk (the tile's 4x4
 // blocks share its list), 1 row-granular walk (each block needs only a fraction of it), 2 entry-per-lane MFMA walk
@@ -209,6 +209,34 @@ __device__ __forceinline__ uint32_t blocks_reached(float u, float v, float hx, f
     }
   }
   return (xm * 0x1111u) & ym & em;
+}
+
+// The same two tests for the four 8x8 QUADRANTS of a tile (bit q = quadrant (q & 1, q >> 1); pixel centres of quadrant
+// column i are tx0 + 8 i .. tx0 + 8 i + 7): what the backward's MFMA walk compacts its per-wave sub-lists from.  A
+// quadrant is the union of four blocks, so this mask covers every block blocks_reached() reports.
+__device__ __forceinline__ uint32_t quads_reached(float u, float v, float hx, float hy, float ca, float cb, float cc,
+                                                  float o, float tx0, float ty0) {
+  const float tau = 1.01f * fmaxf(2.f * __logf(255.f * fmaxf(o, 1e-12f)), 0.f) + 0.02f;
+  const float kc = -cb / cc, ka = -cb / ca, twob = 2.f * cb;
+  uint32_t m = 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float loy = ty0 + 8.f * (float)j - v;
+    const bool yin = !((hy < loy) | (-hy > loy + 7.f));
+    const float ey = __builtin_amdgcn_fmed3f(0.f, loy, loy + 7.f);      // nearest offset to the centre inside the quadrant
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float lox = tx0 + 8.f * (float)i - u;
+      const bool xin = !((hx < lox) | (-hx > lox + 7.f));
+      const float ex = __builtin_amdgcn_fmed3f(0.f, lox, lox + 7.f);
+      const float dy1 = __builtin_amdgcn_fmed3f(kc * ex, loy, loy + 7.f);
+      const float q1 = fmaf(dy1, fmaf(cc, dy1, twob * ex), ca * ex * ex);
+      const float dx2 = __builtin_amdgcn_fmed3f(ka * ey, lox, lox + 7.f);
+      const float q2 = fmaf(dx2, fmaf(ca, dx2, twob * ey), cc * ey * ey);
+      m |= (xin & yin & (fminf(q1, q2) <= tau)) ? (1u << (2 * j + i)) : 0u;
+    }
+  }
+  return m;
 }
 
 // Pinned SH constants (utils/sh_utils.py:26-45 of the reference).

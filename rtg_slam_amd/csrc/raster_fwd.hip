@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256, 6) blend_fwd_kernel(
     int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
     float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
     unsigned long long* __restrict__ counters, SlicePass sp, uint32_t* __restrict__ tile_mode,
-    uint32_t* __restrict__ depth_pos) {
+    uint32_t* __restrict__ depth_pos, uint32_t* __restrict__ tile_last, int walk) {
   __shared__ float4 s_rec[FWD_BATCH * 4];     // u v ca cb | cc o r g | b - - id | nx ny nz pd: the walk reads the first three
   __shared__ float s_z[FWD_BATCH];            // centre depth (opaque-surface test only)
   __shared__ uint32_t s_live[16][FWD_CHUNKS]; // per 4x4 block: the staged entries that reach it
@@ -448,18 +448,26 @@ __global__ void __launch_bounds__(256, 6) blend_fwd_kernel(
     n_contrib[pix] = last_contributor;
     depth_pos[pix] = d_pos;
   }
-  if (tile_mode) {
-    // which walk the tile's backward takes (raster_bwd.hip): row-granular when its 4x4 blocks need, on average, less than
-    // ROWS_MAX_SHARE of the entries staged - measured here on the sub-lists themselves, no heuristic about the scene
+  {
+    // For the backward: which walk the tile takes (raster_bwd.hip) - row-granular when its 4x4 blocks need, on average,
+    // less than ROWS_MAX_SHARE of the entries staged, measured here on the sub-lists themselves, no heuristic about the
+    // scene - and the tile's last contributor (the backward stages no further; it would otherwise have to reduce
+    // n_contrib over the tile before it can issue its first gather).
     __shared__ uint32_t s_share[2];
-    if (tid == 0) { s_share[0] = 0u; s_share[1] = 0u; }
+    __shared__ unsigned int s_tl;
+    if (tid == 0) { s_share[0] = 0u; s_share[1] = 0u; s_tl = 0u; }
     __syncthreads();
-    if (lane == 0) { atomicAdd(&s_share[0], reach_sum); atomicAdd(&s_share[1], staged); }
+    uint32_t wl = last_contributor;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, off));
+    if (lane == 0) { atomicAdd(&s_share[0], reach_sum); atomicAdd(&s_share[1], staged); atomicMax(&s_tl, wl); }
     __syncthreads();
-    if (tid == 0) {
-      // bit 0 = the walk; bits 8.. = the measured share in 1/1000 (diagnostics)
+    if (tid == 0 && write_out) {
+      // bits 0..1 = the walk; bits 8.. = the measured share in 1/1000 (diagnostics)
       const float share = s_share[1] ? (float)s_share[0] / (16.f * (float)s_share[1]) : 1.f;
-      tile_mode[tile] = (share < ROWS_MAX_SHARE ? 1u : 0u) | ((uint32_t)(share * 1000.f) << 8);
+      // walk < 0: the choice between the two pixel-per-lane walks from the share; else the walk the context asks for
+      tile_mode[tile] = (walk >= 0 ? (uint32_t)walk : (share < ROWS_MAX_SHARE ? 1u : 0u)) | ((uint32_t)(share * 1000.f) << 8);
+      tile_last[tile] = s_tl;
     }
   }
   if (counters) {
@@ -560,10 +568,10 @@ void launch_slice_publish(int ntiles, const int32_t* user_mask, const int32_t* m
 void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                       float* out_color, float* out_depth, int32_t* out_cidx, int32_t* out_didx, float* out_cw,
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
-                      SlicePass sp, uint32_t* tile_mode, uint32_t* depth_pos, hipStream_t st) {
+                      SlicePass sp, uint32_t* tile_mode, uint32_t* depth_pos, uint32_t* tile_last, int walk, hipStream_t st) {
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
                      out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp, tile_mode,
-                     depth_pos);
+                     depth_pos, tile_last, walk);
 }
 
 }  // namespace rtgs

@@ -1,6 +1,6 @@
-"""The backward's two tile walks (raster_bwd.hip): the tile-uniform strip walk and the row-granular walk (every 4x4
-pixel block of a tile walks its own sub-list).  blend_fwd chooses per tile from the measured share of the list the
-blocks need; here both are forced on every tile of the same scenes and compared
+"""The backward's three tile walks: the entry-per-lane MFMA walk (raster_bwd_mfma.hip, the default), the tile-uniform
+strip walk and the row-granular walk (raster_bwd.hip; mode 4 chooses between those two per tile from the measured share of
+the list the 4x4 blocks need).  Here each is forced on every tile of the same scenes and compared
 
 * with each other (same per-pixel arithmetic, different summation order: 1e-4 of the tensor max),
 * with the oracle (1e-3 of the tensor max, north_star),
@@ -78,9 +78,10 @@ def test_the_two_walks_agree_and_match_the_oracle(kind, N, cam, depth, masked):
         mask = (torch.rand(gy, gx, generator=torch.Generator().manual_seed(4)) < 0.6).int()
     out_s, gd_s, m_s = _run(s, g, grads, 1, mask)
     out_r, gd_r, m_r = _run(s, g, grads, 2, mask)
-    out_a, gd_a, m_a = _run(s, g, grads, 0, mask)
+    out_a, gd_a, m_a = _run(s, g, grads, 4, mask)              # per-tile choice between strip and rows (round 3's default)
+    out_d, gd_d, m_d = _run(s, g, grads, 0, mask)              # the default: MFMA walk
     out_m, gd_m, m_m = _run(s, g, grads, 3, mask)              # entry-per-lane MFMA walk on every tile
-    assert int(m_s.sum()) == 0 and int(m_r.sum()) == m_r.numel() and bool((m_m == 2).all())
+    assert int(m_s.sum()) == 0 and int(m_r.sum()) == m_r.numel() and bool((m_m == 2).all()) and bool((m_d == 2).all())
     for a, b in zip(out_s, out_r):
         assert torch.equal(a, b)                       # the forward does not depend on the backward's walk
     for k in ru.FIELDS:
@@ -106,12 +107,12 @@ def test_the_two_walks_agree_and_match_the_oracle(kind, N, cam, depth, masked):
 def test_per_tile_choice_follows_the_footprints():
     cam = MID
     g, s = _scene("surface", 60_000, cam)
-    _, _, mode = _run(s, g, _grads(cam, 1), 0)
+    _, _, mode = _run(s, g, _grads(cam, 1), 4)
     assert float(mode.float().mean()) > 0.8, "small discs: the blocks of a tile need a fraction of its list"
     # the same map with every disc blown up to cover whole tiles: the blocks share the list
     g2 = dict(g)
     g2["scales"] = g["scales"] * 12.0
-    _, _, mode2 = _run(s, g2, _grads(cam, 1), 0)
+    _, _, mode2 = _run(s, g2, _grads(cam, 1), 4)
     assert float(mode2.float().mean()) < 0.2
 
 
