@@ -191,6 +191,20 @@ int rtgs_raster_backward_rows_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* set
                                   float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
                                   float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
                                   void* grad_scratch, uint8_t* row_state, void* stream);
+/* rtgs_raster_backward_rows_ctx restricted to the trainable rows [train_begin, train_end): Gaussians outside the range
+ * take part in the blend (the forward rendered them) but receive NOTHING - no gradient slot, no record, their rows of the
+ * gradient tensors and of row_state are not touched (they stay zero from the allocation).  (0, P) = every row. */
+int rtgs_raster_backward_range_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* settings, int32_t P, int32_t sh_coeffs,
+                                  int64_t num_rendered,
+                                  const float* means3D, const float* opacities, const float* shs,
+                                  const float* scales, const float* rotations, const float* normal_w,
+                                  void* geom_buffer, void* binning_buffer,
+                                  const void* image_buffer, const float* out_color, const float* out_T,
+                                  const int32_t* out_depth_index,
+                                  const float* dL_dcolor, const float* dL_ddepth,
+                                  float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
+                                  float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
+                                  void* grad_scratch, uint8_t* row_state, int32_t train_begin, int32_t train_end, void* stream);
 
 /* Sizes the forward will request through the callbacks (for pre-allocation / accounting).  The geometry buffer's size
  * depends on the context's near-slice budget; its layout is such that a backward never needs to know that budget. */
@@ -410,6 +424,13 @@ typedef struct rtgs_map_step_args {
    * is added to the owners' d_normal rows (rtgs_slam_normal_loss below) between the rasterizer backward and the tail. */
   float normal_weight;
   const float* gt_normal;                                 /* [H,W,3] world normals of the frame (image_input["normal_map"]) */
+  /* The TRAINABLE rows [train_begin, train_end) (0, 0 = every row).  RTG-SLAM renders cat(unstable, stable) but only the
+   * unstable Gaussians are parameters of the optimisation (mapper.py:143-156 parametrizes self.pointcloud only,
+   * :1026-1108 concatenates the stable rows without requires_grad): rows outside the range are rendered, never
+   * differentiated (no gradient slot, no SplatGrad record, row_state stays 0), never stepped.  With a range the Adam
+   * state m_* / v_* / ever_*, attach->init_* and confidence cover ONLY those rows: element 0 belongs to row train_begin.
+   * Everything else (parameters, activated arrays, gradient rows, row_state) is indexed by the row itself. */
+  int32_t train_begin, train_end;
 } rtgs_map_step_args;
 /* The normal term on its own: value added to loss4[0], gradient added to d_normal[owner] with the row marked live in
  * row_state (nullable: dense gradients) - a row that carried no gradient is all-zero by the arena's invariant, so marking
@@ -417,6 +438,11 @@ typedef struct rtgs_map_step_args {
 int rtgs_slam_normal_loss(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
                           const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight, float* scratch2,
                           float* loss_out4, float* d_normal, uint8_t* row_state, const uint32_t* skip_flag, void* stream);
+/* ... with a trainable range: owners outside [train_begin, train_end) count in the value, receive no gradient. */
+int rtgs_slam_normal_loss_range(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
+                                const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight, float* scratch2,
+                                float* loss_out4, float* d_normal, uint8_t* row_state, const uint32_t* skip_flag,
+                                int32_t train_begin, int32_t train_end, void* stream);
 int rtgs_slam_map_step(const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
 /* The same call without its last stage (rtgs_map_tail_rows): the gradient rows of this rank's view are in the arena,
  * nothing has been stepped.  Multi-GPU callers exchange the rows (below) before they run the tail. */

@@ -78,7 +78,7 @@ class MapStepArgsC(C.Structure):
         + [("attach", C.POINTER(AttachC)), ("confidence", C.c_void_p), ("activated_valid", C.c_int32)]
         + [("geom_resize", RESIZE_FN), ("geom_user", C.c_void_p), ("binning_resize", RESIZE_FN),
            ("binning_user", C.c_void_p), ("image_resize", RESIZE_FN), ("image_user", C.c_void_p)]
-        + [("normal_weight", C.c_float), ("gt_normal", C.c_void_p)])
+        + [("normal_weight", C.c_float), ("gt_normal", C.c_void_p), ("train_begin", C.c_int32), ("train_end", C.c_int32)])
 
 
 _SIGNATURES = {
@@ -130,6 +130,10 @@ _SIGNATURES = {
                                  + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P]),
     "rtgs_raster_backward_rows_ctx": (C.c_int, [_P, C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6
                                       + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P, _P]),
+    "rtgs_raster_backward_range_ctx": (C.c_int, [_P, C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6
+                                       + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P, C.c_int32, C.c_int32, _P]),
+    "rtgs_slam_normal_loss_range": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P, _P,
+                                              C.c_int32, C.c_int32, _P]),
     "rtgs_raster_geom_bytes_ctx": (C.c_size_t, [_P, C.c_int32, C.c_int32, C.c_int32]),
     "rtgs_raster_last_stats_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "rtgs_raster_set_counters_ctx": (None, [_P, _P]),

@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(256) normal_loss_grads_kernel(const float* __r
                                                                 int64_t hw, float weight, const float* __restrict__ sums2,
                                                                 float* __restrict__ loss4, float* __restrict__ d_normal,
                                                                 uint8_t* __restrict__ row_state,
-                                                                const uint32_t* __restrict__ skip) {
+                                                                const uint32_t* __restrict__ skip, uint32_t t0, uint32_t tn) {
   if (skip && skip[0] != 0u) return;
   const float cnt = fmaxf(sums2[1], 1.f);                         // an empty set gives 0 (nan in the reference)
   if (blockIdx.x == 0 && threadIdx.x == 0) loss4[0] += weight * (sums2[0] / cnt);
@@ -908,6 +908,7 @@ __global__ void __launch_bounds__(256) normal_loss_grads_kernel(const float* __r
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
     int owner; float n[3], g[3];
     if (!normal_pixel(normal_w, didx, gtn, mask, i, owner, n, g)) continue;
+    if ((uint32_t)owner - t0 >= tn) continue;                     // frozen owner: in the value, no gradient
     const float nr = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), gr = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
     const float nn = fmaxf(nr, 1e-8f), gg = fmaxf(gr, 1e-8f);
     const float dot = n[0] * g[0] + n[1] * g[1] + n[2] * g[2];
@@ -921,11 +922,12 @@ __global__ void __launch_bounds__(256) normal_loss_grads_kernel(const float* __r
 
 }  // namespace rtgs
 
-extern "C" int rtgs_slam_normal_loss(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
-                                     const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight, float* scratch2,
-                                     float* loss_out4, float* d_normal, uint8_t* row_state, const uint32_t* skip_flag,
-                                     void* stream) {
+extern "C" int rtgs_slam_normal_loss_range(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
+                                           const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight,
+                                           float* scratch2, float* loss_out4, float* d_normal, uint8_t* row_state,
+                                           const uint32_t* skip_flag, int32_t train_begin, int32_t train_end, void* stream) {
   if (!normal_w || !depth_index || !gt_normal || !scratch2 || !loss_out4 || !d_normal || H <= 0 || W <= 0) return -1;
+  if (train_begin < 0 || train_end < train_begin) return -1;
   hipStream_t st = (hipStream_t)stream;
   const int64_t hw = (int64_t)H * W;
   int blocks = (int)((hw + 255) / 256);
@@ -934,6 +936,15 @@ extern "C" int rtgs_slam_normal_loss(const float* normal_w, const int32_t* depth
   hipLaunchKernelGGL(rtgs::normal_loss_sums_kernel, dim3(blocks), dim3(256), 0, st, normal_w, depth_index, gt_normal, render_mask,
                      hw, scratch2, skip_flag);
   hipLaunchKernelGGL(rtgs::normal_loss_grads_kernel, dim3(blocks), dim3(256), 0, st, normal_w, depth_index, gt_normal,
-                     render_mask, hw, normal_weight, (const float*)scratch2, loss_out4, d_normal, row_state, skip_flag);
+                     render_mask, hw, normal_weight, (const float*)scratch2, loss_out4, d_normal, row_state, skip_flag,
+                     (uint32_t)train_begin, (uint32_t)(train_end - train_begin));
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int rtgs_slam_normal_loss(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
+                                     const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight, float* scratch2,
+                                     float* loss_out4, float* d_normal, uint8_t* row_state, const uint32_t* skip_flag,
+                                     void* stream) {
+  return rtgs_slam_normal_loss_range(normal_w, depth_index, gt_normal, render_mask, H, W, normal_weight, scratch2, loss_out4,
+                                     d_normal, row_state, skip_flag, 0, 0x7fffffff, stream);
 }

@@ -32,17 +32,20 @@ static int map_step_front(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* n
   rc = rtgs_slam_loss(a->out_color, a->out_depth, a->out_depth_index, a->gt_color, a->gt_depth, H, W, &a->loss,
                       a->loss_scratch, a->loss4, a->dL_dcolor, a->dL_ddepth, stream);
   if (rc != 0) return RTGS_E_HIP;
-  rc = rtgs_raster_backward_rows_ctx(ctx, a->settings, P, M, *num_rendered_host, a->xyz, a->opacity, a->shs, a->scales,
-                                 a->rotations, a->normal, geom, bin, img, a->out_color, a->out_T, a->out_depth_index,
-                                 a->dL_dcolor, a->dL_ddepth, a->d_xyz, a->d_opacity, a->d_shs, a->d_scales,
-                                 a->d_rotations, a->d_normal, a->grad_scratch, a->row_state, stream);
+  int32_t t0 = 0, t1 = P;                                 // the trainable rows (rtgs_map_step_args: 0, 0 = all)
+  if (a->train_end > a->train_begin) { t0 = a->train_begin; t1 = a->train_end; }
+  if (t0 < 0 || t1 > P) return RTGS_E_INVALID;
+  rc = rtgs_raster_backward_range_ctx(ctx, a->settings, P, M, *num_rendered_host, a->xyz, a->opacity, a->shs, a->scales,
+                                  a->rotations, a->normal, geom, bin, img, a->out_color, a->out_T, a->out_depth_index,
+                                  a->dL_dcolor, a->dL_ddepth, a->d_xyz, a->d_opacity, a->d_shs, a->d_scales,
+                                  a->d_rotations, a->d_normal, a->grad_scratch, a->row_state, t0, t1, stream);
   if (rc != RTGS_OK) return rc;
   if (a->normal_weight > 0.f && a->gt_normal) {
     // the normal term (mapper.py:433-442): value into loss4[0], gradient into the depth owners' d_normal rows; the two
     // floats it needs are words 5-6 of the loss scratch's 8-float header (the image loss uses 0-4 and is done by now)
-    rc = rtgs_slam_normal_loss(a->normal, a->out_depth_index, a->gt_normal, a->loss.render_mask, H, W, a->normal_weight,
-                               reinterpret_cast<float*>(a->loss_scratch) + 5, a->loss4, a->d_normal, a->row_state,
-                               rtgs_raster_spec_fail_ptr_ctx(ctx), stream);
+    rc = rtgs_slam_normal_loss_range(a->normal, a->out_depth_index, a->gt_normal, a->loss.render_mask, H, W, a->normal_weight,
+                                     reinterpret_cast<float*>(a->loss_scratch) + 5, a->loss4, a->d_normal, a->row_state,
+                                     rtgs_raster_spec_fail_ptr_ctx(ctx), t0, t1, stream);
     if (rc != 0) return RTGS_E_HIP;
   }
   return RTGS_OK;
@@ -66,11 +69,17 @@ static int map_step_once(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* nu
   const int32_t P = a->P;
   // activation backward (+ attach gradient) + Adam on the three block tensors (+ confidence increment), one launch;
   // the rows it steps are re-activated, so the next call may skip the full activation pass (activated_valid)
-  const rtgs_activated act{a->opacity, a->scales, a->rotations, a->normal};
-  rc = rtgs_map_tail_rows(a->xyz, a->shs, a->raw8, a->d_opacity, a->d_scales, a->d_rotations, a->d_normal, a->d_xyz,
-                          a->d_shs, a->d_raw8, a->row_state, a->m_xyz, a->v_xyz, a->m_shs, a->v_shs, a->m_raw8, a->v_raw8,
-                          a->lr_xyz, a->lr_shs, a->lr_raw8, a->ever_xyz, a->ever_shs, a->ever_raw8, P, a->step, a->beta1,
-                          a->beta2, a->eps, a->attach, a->confidence, rtgs_raster_spec_fail_ptr_ctx(ctx), &act, stream);
+  // ... over the trainable rows only: every per-row pointer moves to row t0 (the Adam state, the attach snapshot and the
+  // confidence array already start there, see rtgs_map_step_args)
+  int32_t t0 = 0, t1 = P;
+  if (a->train_end > a->train_begin) { t0 = a->train_begin; t1 = a->train_end; }
+  const size_t o = (size_t)t0;
+  const rtgs_activated act{a->opacity + o, a->scales + 3 * o, a->rotations + 4 * o, a->normal + 3 * o};
+  rc = rtgs_map_tail_rows(a->xyz + 3 * o, a->shs + 48 * o, a->raw8 + 8 * o, a->d_opacity + o, a->d_scales + 3 * o,
+                          a->d_rotations + 4 * o, a->d_normal + 3 * o, a->d_xyz + 3 * o, a->d_shs + 48 * o, a->d_raw8 + 8 * o,
+                          a->row_state + o, a->m_xyz, a->v_xyz, a->m_shs, a->v_shs, a->m_raw8, a->v_raw8,
+                          a->lr_xyz, a->lr_shs, a->lr_raw8, a->ever_xyz, a->ever_shs, a->ever_raw8, (int64_t)(t1 - t0), a->step,
+                          a->beta1, a->beta2, a->eps, a->attach, a->confidence, rtgs_raster_spec_fail_ptr_ctx(ctx), &act, stream);
   return rc != 0 ? RTGS_E_HIP : RTGS_OK;
 }
 

@@ -22,10 +22,10 @@ void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const 
                       int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, uint32_t*, uint32_t*, int, hipStream_t);
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
                       const uint32_t*, const int32_t*, const float*, const float*, const uint32_t*, uint32_t*,
-                      const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, uint32_t, hipStream_t);
+                      const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, uint32_t, uint32_t, hipStream_t);
 void launch_blend_bwd_mfma(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const uint32_t*,
                            const int32_t*, const uint32_t*, const uint32_t*, const float*, const float*, const uint32_t*, uint32_t*,
-                           const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, hipStream_t);
+                           const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, uint32_t, hipStream_t);
 void launch_grad_reduce(int, const uint8_t*, const uint32_t*, uint32_t*, const BwdInfo*, SplatGrad*, const uint32_t*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
@@ -780,7 +780,7 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
                          const int32_t* out_didx,
                          const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
                          float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
-                         void* grad_scratch, uint8_t* row_state, void* stream) {
+                         void* grad_scratch, uint8_t* row_state, int32_t train_begin, int32_t train_end, void* stream) {
   rtgs_ctx* c = use(ctx);   // NOTE: the geometry buffer is written here (slot counters): it is scratch of the pair
   RasterParams p;
   int rc = make_params(s, P, M, p);
@@ -821,7 +821,8 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
     // context's setting at backward time; a backward this context does not remember launches all three - each kernel
     // takes only the tiles that carry its walk
     const int which = !hinted ? 7 : (c->hint_walk == 2 ? 4 : (c->hint_walk == -1 ? 3 : (c->hint_walk == 0 ? 1 : 2)));
-    const uint32_t n_train = (uint32_t)P;
+    if (train_begin < 0 || train_end > P || train_end < train_begin) return RTGS_E_INVALID;
+    const uint32_t t0 = (uint32_t)train_begin, tn = (uint32_t)(train_end - train_begin);   // trainable rows (the rest: rendered only)
     const uint32_t* depth_pos = (const uint32_t*)(img + I.depth_pos);
     for (int set = 0; set < 2; ++set) {
       if (hinted && !(set == 0 ? c->hint_slice_lists : c->hint_main_lists)) continue;
@@ -829,11 +830,11 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
       const uint32_t* pl = set == 0 ? (const uint32_t*)(geom + G.list1) : (const uint32_t*)(bin + B.vals_b);
       if (which & 3)
         launch_blend_bwd(p, rg, pl, (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib),
-                         out_didx, dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode, which & 3, n_train, st);
+                         out_didx, dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode, which & 3, t0, tn, st);
       if (which & 4)
         launch_blend_bwd_mfma(p, rg, pl, (const Splat*)(geom + G.splats), out_color, (const uint32_t*)(img + I.n_contrib),
                               out_didx, depth_pos, (const uint32_t*)(img + I.tile_last), dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads,
-                              touched, tile_mode, n_train, st);
+                              touched, tile_mode, t0, tn, st);
     }
     prof_mark(c, EV_BWALK, st);
     // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
@@ -859,7 +860,7 @@ int rtgs_raster_backward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32
                              float* dL_drotations, float* dL_dnormal_w, void* grad_scratch, void* stream) {
   return backward_impl(ctx, s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer, binning_buffer,
                        image_buffer, out_color, out_T, out_didx, dL_dcolor, dL_ddepth, dL_dmeans3D, dL_dopacities,
-                       dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, nullptr, stream);
+                       dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, nullptr, 0, P, stream);
 }
 
 int rtgs_raster_backward_rows_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R,
@@ -870,10 +871,24 @@ int rtgs_raster_backward_rows_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, 
                                   const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
                                   float* dL_dscales, float* dL_drotations, float* dL_dnormal_w, void* grad_scratch,
                                   uint8_t* row_state, void* stream) {
+  return rtgs_raster_backward_range_ctx(ctx, s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer,
+                                        binning_buffer, image_buffer, out_color, out_T, out_didx, dL_dcolor, dL_ddepth,
+                                        dL_dmeans3D, dL_dopacities, dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w,
+                                        grad_scratch, row_state, 0, P, stream);
+}
+
+int rtgs_raster_backward_range_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R,
+                                   const float* means3D, const float* opacities, const float* shs, const float* scales,
+                                   const float* rotations, const float* normal_w, void* geom_buffer,
+                                   void* binning_buffer, const void* image_buffer, const float* out_color,
+                                   const float* out_T, const int32_t* out_didx, const float* dL_dcolor,
+                                   const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
+                                   float* dL_dscales, float* dL_drotations, float* dL_dnormal_w, void* grad_scratch,
+                                   uint8_t* row_state, int32_t train_begin, int32_t train_end, void* stream) {
   if (P > 0 && !row_state) return RTGS_E_INVALID;
   return backward_impl(ctx, s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer, binning_buffer,
                        image_buffer, out_color, out_T, out_didx, dL_dcolor, dL_ddepth, dL_dmeans3D, dL_dopacities,
-                       dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, row_state, stream);
+                       dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, row_state, train_begin, train_end, stream);
 }
 
 void rtgs_raster_set_profiling_ctx(rtgs_ctx* c, int enable) { use(c)->prof = enable != 0; }
@@ -978,7 +993,7 @@ int rtgs_raster_backward(const rtgs_raster_settings* s, int32_t P, int32_t M, in
                          void* grad_scratch, void* stream) {
   return backward_impl(nullptr, s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer,
                        binning_buffer, image_buffer, out_color, out_T, out_didx, dL_dcolor, dL_ddepth, dL_dmeans3D,
-                       dL_dopacities, dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, nullptr, stream);
+                       dL_dopacities, dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, nullptr, 0, P, stream);
 }
 int rtgs_raster_backward_rows(const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R, const float* means3D,
                               const float* opacities, const float* shs, const float* scales, const float* rotations,

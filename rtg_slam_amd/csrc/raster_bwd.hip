@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_strip_kernel(
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
     SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode,
-    uint32_t n_train) {
+    uint32_t t0, uint32_t tn) {
   __shared__ float4 s_rec[BATCH * 3];           // u v ca cb | cc o r g | b hy id slot: three 16-B broadcast reads per entry
   __shared__ float s_grad[4 * BATCH * NGS];      // one private copy per wave: plain stores, no LDS atomics
   __shared__ float s_dep[BATCH * 4];            // depth-plane partials of the batch's entries (rare: LDS float adds)
@@ -298,8 +298,8 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_strip_kernel(
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) { t[NGS + k] = s_dep[tid * 4 + k]; any |= (t[NGS + k] != 0.f); }
-      // a frozen row (id >= n_train: rendered, never differentiated - the stable part of the map) takes no slot
-      if (any && __float_as_uint(s_rec[tid * 3 + 2].z) < n_train) {
+      // a frozen row (id outside [t0, t0 + tn): rendered, never differentiated - the stable part of the map) takes no slot
+      if (any && __float_as_uint(s_rec[tid * 3 + 2].z) - t0 < tn) {
         // t[0..4] hold the moments sum(gdl dx), sum(gdl dy), sum(gdl dx^2), sum(gdl dx dy), sum(gdl dy^2) with
         // d = centre - pixel; d alpha / d(u, v, conic) of G = exp(-1/2 (ca dx^2 + cc dy^2) - cb dx dy):
         {
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_rows_kernel(
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
     SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode,
-    uint32_t n_train) {
+    uint32_t t0, uint32_t tn) {
   __shared__ float4 s_rec[BATCH * 4];           // u v ca cb | cc o r g | b id slot - | - : one 64-B line per entry
   __shared__ float s_acc[BATCH * ACC_STRIDE];   // per-entry partial sums of the tile (LDS float adds)
   __shared__ uint32_t s_live[16][BWD_CHUNKS];   // per 4x4 block: the staged entries that reach it
@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_rows_kernel(
       bool any = false;
 #pragma unroll
       for (int k = 0; k < NACC; ++k) { t[k] = s_acc[tid * ACC_STRIDE + k]; any |= (t[k] != 0.f); }
-      if (any && __float_as_uint(s_rec[tid * 4 + 2].y) < n_train) {     // frozen rows take no slot
+      if (any && __float_as_uint(s_rec[tid * 4 + 2].y) - t0 < tn) {     // frozen rows take no slot
         // t[0..4] hold the moments sum(gdl dx), sum(gdl dy), sum(gdl dx^2), sum(gdl dx dy), sum(gdl dy^2) with
         // d = centre - pixel; d alpha / d(u, v, conic) of G = exp(-1/2 (ca dx^2 + cc dy^2) - cb dx dy):
         {
@@ -1000,16 +1000,16 @@ void launch_blend_bwd(const RasterParams& p, const uint2* ranges, const uint32_t
                       const float* out_color, const float* final_T, const uint32_t* n_contrib,
                       const int32_t* depth_index, const float* dL_dcolor, const float* dL_ddepth, const uint32_t* gbase,
                       uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
-                      const uint32_t* tile_mode, int which, uint32_t n_train, hipStream_t st) {
+                      const uint32_t* tile_mode, int which, uint32_t t0, uint32_t tn, hipStream_t st) {
   // which: bit 0 = tiles on the strip walk exist (or unknown), bit 1 = tiles on the row-granular walk exist (or unknown)
   if (which & 1)
     hipLaunchKernelGGL(blend_bwd_strip_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
                        final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched, tile_mode,
-                       n_train);
+                       t0, tn);
   if (which & 2)
     hipLaunchKernelGGL(blend_bwd_rows_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
                        final_T, n_contrib, depth_index, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched, tile_mode,
-                       n_train);
+                       t0, tn);
 }
 void launch_grad_reduce(int P, const uint8_t* touched, const uint32_t* gbase, uint32_t* count, const BwdInfo* info,
                         SplatGrad* grads, const uint32_t* spec_fail, hipStream_t st) {

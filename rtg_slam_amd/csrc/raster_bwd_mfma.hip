@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
     SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode,
-    uint32_t n_train, uint32_t dbg) {
+    uint32_t t0, uint32_t tn, uint32_t dbg) {
   __shared__ float4 s_rec[MB * 3];              // u v ca cb | cc o r g | b id slot0 -
   __shared__ float s_acc[MB * MACC];            // per-entry sums of the tile (LDS float adds: one flush per wave and group)
   __shared__ float s_g[4][4][16][3];            // [wave][k][quad][channel]: colour gradients on their way into X
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
 #pragma unroll
       for (int q = 0; q < 13; ++q) { t[q] = s_acc[tid * MACC + q]; any |= (t[q] != 0.f); }
       const uint32_t gid = __float_as_uint(s_rec[tid * 3 + 2].y);
-      if (any && gid < n_train && !(dbg & 4u)) {          // a frozen row (id >= n_train) takes no slot
+      if (any && gid - t0 < tn && !(dbg & 4u)) {          // a frozen row (outside [t0, t0 + tn)) takes no slot
         const float4 q0 = s_rec[tid * 3 + 0];            // u v ca cb
         const float4 q1 = s_rec[tid * 3 + 1];            // cc o r g
         // sums over the pixels of gdl = o gda times powers of d = centre - pixel, from the moments about the tile centre
@@ -444,11 +444,11 @@ void launch_blend_bwd_mfma(const RasterParams& p, const uint2* ranges, const uin
                            const float* out_color, const uint32_t* n_contrib, const int32_t* depth_index,
                            const uint32_t* depth_pos, const uint32_t* tile_last, const float* dL_dcolor, const float* dL_ddepth,
                            const uint32_t* gbase, uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
-                           const uint32_t* tile_mode, uint32_t n_train, hipStream_t st) {
+                           const uint32_t* tile_mode, uint32_t t0, uint32_t tn, hipStream_t st) {
   static const uint32_t dbg = getenv("RTGS_MFMA_DEBUG") ? (uint32_t)atoi(getenv("RTGS_MFMA_DEBUG")) : 0u;   // experiments only
   hipLaunchKernelGGL(blend_bwd_mfma_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
                      n_contrib, depth_index, depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched,
-                     tile_mode, n_train, dbg);
+                     tile_mode, t0, tn, dbg);
 }
 
 }  // namespace rtgs

@@ -189,8 +189,19 @@ class _GrowArena:
 
 
 class ShardedMapOptimizer:
+    """The map (block-SoA, see the module docstring) with its optimiser.
+
+    Row order: rows [0, n_frozen) are FROZEN - rendered, never differentiated, never stepped: the "stable" Gaussians
+    of RTG-SLAM (mapper.py:1026-1108 renders cat(unstable, stable) but only the unstable cloud is parametrized, :143-156) -
+    and rows [n_frozen, N) are the TRAINABLE ("unstable") ones.  Frozen rows come first so that `append_rows` - the
+    reference's per-frame gaussians_add (gaussian_pointcloud.py:286-303) - is an O(new rows) write behind the last row;
+    `freeze_rows` (gaussians_fix, mapper.py:253-271) and `remove_rows` (:298-335, gaussian_pointcloud.py:195-235) permute.
+    Adam state, the attach snapshot, the row shards of the multi-GPU forms and the sparse gradient exchange cover the
+    trainable rows only.  Storage has a capacity (geometric growth); `gaussian_data()` hands out zero-copy views."""
+
     def __init__(self, packed: torch.Tensor, lr_col: Optional[torch.Tensor] = None, eps: float = 1e-15,
-                 group=None, adam_fn: Optional[Callable] = None, activate_fn: Optional[Callable] = None):
+                 group=None, adam_fn: Optional[Callable] = None, activate_fn: Optional[Callable] = None,
+                 n_frozen: int = 0, capacity: Optional[int] = None):
         """`packed` [N,59] raw parameters.  `adam_fn(p, g, m, v, lr_col, step, eps)` defaults to the HIP
         fused Adam and `activate_fn(raw8) -> dict` to the HIP activation kernels (device tensors only -
         there is no CPU path in the product); the gloo tests inject torch restatements."""
@@ -202,40 +213,98 @@ class ShardedMapOptimizer:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self.N = int(packed.shape[0])
-        self.per, self.Npad = shard_rows(self.N, self.world)
-        dev = packed.device
-        lr = (default_lr_columns() if lr_col is None else lr_col).to(dev).float()
+        self.n_frozen = int(n_frozen)
+        if not 0 <= self.n_frozen <= self.N:
+            raise ValueError("n_frozen must be in [0, N]")
+        self.device = packed.device
+        self.lr_full = (default_lr_columns() if lr_col is None else lr_col).to(self.device).float()
         self.eps = eps
+        self._use_arena = self.row_skip and activate_fn is None
         self.state = {}
-        for name, c0, c1 in BLOCKS:
-            full = torch.zeros(self.Npad, c1 - c0, dtype=torch.float32, device=dev)
-            full[:self.N] = packed[:, c0:c1]
-            self.state[name] = dict(
-                p=full, lr=lr[c0:c1].contiguous(),
-                m=torch.zeros(self.per, c1 - c0, dtype=torch.float32, device=dev),      # sharded Adam state
-                v=torch.zeros(self.per, c1 - c0, dtype=torch.float32, device=dev),
-                ever=torch.zeros(self.per, dtype=torch.uint8, device=dev),
-                gpad=(torch.zeros(self.Npad, c1 - c0, dtype=torch.float32, device=dev) if self.world > 1 else None),
-                gshard=(torch.zeros(self.per, c1 - c0, dtype=torch.float32, device=dev) if self.world > 1 else None))
-        self.step_count = 0
-        # Single-GPU HIP path: persistent gradient rows + row states (rasterizer.RowGradArena).  step() hands the
-        # arena to loss_fn as gd["grad_rows"]; a loss_fn that forwards it to the rasterizer (grad_rows=...) gets the
-        # row-state backward, one that ignores it gets the dense path - the results are identical.
         self.grad_rows = None
+        self.act = None                # activated copies of raw8 (opacity, scales, rotations, normal), kept current by step_slam
         self._slam_ws = None
+        self._slam_state = None        # world > 1: full-size Adam state of the replicated sparse step (step_slam)
+        self.capacity = 0
+        self._allocate(max(int(capacity) if capacity is not None else self.N, self.N, 1), packed)
+        self.step_count = 0
         self.last_render = None
         self.last_num_rendered = 0
-        self._slam_state = None        # world > 1: full-size Adam state of the replicated sparse step (step_slam)
         self.attach_init = None        # begin_local_optimization(): snapshot for the attach regulariser
         self._row_capacity = 16384     # world > 1: rows per rank in the sparse gradient exchange (grows on overflow)
         self._pending = None           # world > 1: the last exchange, until its overflow flag has been looked at
         self.overflow_redos = 0
         self._cap_peak, self._cap_steps, self._shrink_every = 0, 0, 32   # ... and shrinks when it stays mostly empty
-        self._act_valid = False        # step_slam's activated copies of raw8 are current (its tail re-activates moved rows)
+        self._act_valid = False        # self.act holds the activation of the current raw8 (step_slam's tail re-activates moved rows)
         self._mode = None              # world > 1: "sharded" (step) or "replicated" (step_slam); they keep different state
-        if self.row_skip and activate_fn is None:
+
+    # ------------------------------------------------------------------ storage
+    @property
+    def n_train(self) -> int:
+        return self.N - self.n_frozen
+
+    @property
+    def per(self) -> int:
+        """Trainable rows per rank in the row-sharded form."""
+        return shard_rows(self.n_train, self.world)[0]
+
+    @property
+    def Npad(self) -> int:
+        """Rows the parameter tensors must hold for the sharded form's all-gather: frozen + world * per."""
+        return self.n_frozen + shard_rows(self.n_train, self.world)[1]
+
+    def _allocate(self, cap: int, packed: Optional[torch.Tensor] = None):
+        """(Re)allocate every per-row array for `cap` rows (+ `world` rows of all-gather padding) and carry the live rows
+        over.  Adam state and gradient rows start from zero: callers re-begin the optimisation after a change of shape."""
+        dev, N = self.device, self.N
+        rows = cap + self.world
+        old = self.state
+        f = dict(dtype=torch.float32, device=dev)
+        per_cap = (cap + self.world - 1) // self.world + 1
+        adam_rows = cap if self.world == 1 else per_cap
+        self.state = {}
+        for name, c0, c1 in BLOCKS:
+            full = torch.zeros(rows, c1 - c0, **f)
+            if packed is not None:
+                full[:N] = packed[:, c0:c1]
+            elif old:
+                full[:N] = old[name]["p"][:N]
+            self.state[name] = dict(
+                p=full, lr=self.lr_full[c0:c1].contiguous(),
+                m=torch.zeros(adam_rows, c1 - c0, **f), v=torch.zeros(adam_rows, c1 - c0, **f),   # row 0 = first trainable row (of the shard)
+                ever=torch.zeros(adam_rows, dtype=torch.uint8, device=dev),
+                gpad=(torch.zeros(rows, c1 - c0, **f) if self.world > 1 else None),
+                gshard=(torch.zeros(per_cap, c1 - c0, **f) if self.world > 1 else None))
+        self.capacity = cap
+        if self._use_arena:
+            # Single-GPU HIP path: persistent gradient rows + row states (rasterizer.RowGradArena).  step() hands the
+            # arena to loss_fn as gd["grad_rows"]; a loss_fn that forwards it to the rasterizer (grad_rows=...) gets the
+            # row-state backward, one that ignores it gets the dense path - the results are identical.
             from .rasterizer import RowGradArena
-            self.grad_rows = RowGradArena(self.N, 16, dev)
+            self.grad_rows = RowGradArena(N, 16, dev, capacity=rows)
+            self.grad_rows.train = (self.n_frozen, N)
+            self.act = dict(opacity=torch.empty(rows, 1, **f), scales=torch.empty(rows, 3, **f),
+                            rotations=torch.empty(rows, 4, **f), normal=torch.empty(rows, 3, **f))
+        self._act_valid = False
+        if self._slam_state is not None:
+            self._slam_state = None    # re-created (zero) by the next step_slam
+        if self._slam_ws is not None:
+            self._slam_ws["radii"] = torch.empty(rows, dtype=torch.int32, device=dev)
+
+    def _shape_changed(self):
+        """After rows were added / removed / permuted: gradient rows and states refer to other Gaussians, the Adam moments
+        belong to other rows.  Everything derived is dropped; `begin_local_optimization()` starts the next optimisation
+        (the reference creates a new Adam for every local optimisation anyway, mapper.py:156)."""
+        if self.grad_rows is not None:
+            self.grad_rows.resize(self.N)
+            self.grad_rows.train = (self.n_frozen, self.N)
+        for holder in (self.state, self._slam_state or {}):
+            for n in holder:
+                for k in ("m", "v", "ever"):
+                    holder[n][k].zero_()
+        self.attach_init = None
+        self.step_count = 0
+        self._pending = None
 
     @property
     def params(self) -> torch.Tensor:
@@ -243,21 +312,113 @@ class ShardedMapOptimizer:
         self.flush()
         return torch.cat([self.state[n]["p"][:self.N] for n, _, _ in BLOCKS], dim=1)
 
-    def _adam(self, st, shard, gs, row_state=None):
-        if self.row_skip:
-            _adam_rows_hip(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps, st["ever"], row_state)
+    def gaussian_data(self) -> Dict[str, torch.Tensor]:
+        """The `gaussian_data` dict of SLAM/render.py:93-98 as ZERO-COPY views of the optimiser's own arrays: xyz / shs are
+        the parameter tensors, opacity / scales / rotations / normal the activated copies the one-call step keeps current
+        (its tail re-activates exactly the rows it moved) - refreshed here by one activation pass only if something else
+        changed raw8.  Valid until the next step / change of shape; do not write through them."""
+        self.flush()
+        N = self.N
+        if self.act is None:
+            gd = self.activate_fn(self.state["raw8"]["p"][:N])
+            gd = {k: gd[k] for k in ("opacity", "scales", "rotations", "normal")}
         else:
-            self.adam_fn(shard, gs, st["m"], st["v"], st["lr"], self.step_count, self.eps)
+            self._activate_rows(0, N)
+            gd = {k: v[:N] for k, v in self.act.items()}
+        gd["xyz"] = self.state["xyz"]["p"][:N]
+        gd["shs"] = self.state["shs"]["p"][:N].view(N, 16, 3)
+        return gd
+
+    def _activate_rows(self, r0: int, r1: int, force: bool = False):
+        """Bring self.act up to date: everything when it is stale, else (force) just rows [r0, r1)."""
+        if self.act is None or (self._act_valid and not force):
+            return
+        from . import _lib
+        lib = _lib.load()
+        if not self._act_valid:
+            r0, r1 = 0, self.N
+        if r1 > r0:
+            dev = self.device
+            P = lambda t, c: C.c_void_p(t.data_ptr() + 4 * c * r0)
+            with torch.cuda.device(dev):
+                rc = lib.rtgs_map_activate8_forward(P(self.state["raw8"]["p"], 8), r1 - r0, P(self.act["opacity"], 1),
+                                                    P(self.act["scales"], 3), P(self.act["rotations"], 4), P(self.act["normal"], 3),
+                                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(rc, "rtgs_map_activate8_forward")
+        self._act_valid = True
+
+    def append_rows(self, packed_new: torch.Tensor):
+        """New TRAINABLE rows behind the last row (gaussians_add -> GaussianPointCloud.cat, gaussian_pointcloud.py:286-303:
+        the reference concatenates every parameter tensor - an O(N) copy per frame; here O(new) unless the capacity is
+        exhausted, which grows by half).  On several ranks every rank must append the same rows."""
+        self.flush()
+        n = int(packed_new.shape[0])
+        if n == 0:
+            return
+        if self.N + n > self.capacity:
+            self._allocate(max(self.N + n, self.capacity + self.capacity // 2))
+        r0 = self.N
+        for name, c0, c1 in BLOCKS:
+            self.state[name]["p"][r0:r0 + n] = packed_new[:, c0:c1]
+        self.N += n
+        was_valid = self._act_valid
+        self._shape_changed()
+        if self.act is not None and was_valid:
+            self._act_valid = True
+            self._activate_rows(r0, self.N, force=True)        # only the new rows
+
+    def _permute(self, keep_idx: torch.Tensor, n_frozen: int):
+        n = int(keep_idx.numel())
+        for name, _, _ in BLOCKS:
+            pfull = self.state[name]["p"]
+            pfull[:n] = pfull.index_select(0, keep_idx)
+            pfull[n:self.N].zero_()
+        self.N, self.n_frozen = n, int(n_frozen)
+        self._act_valid = False
+        self._shape_changed()
+
+    def remove_rows(self, mask: torch.Tensor):
+        """Delete the rows where `mask` [N] is set (GaussianPointCloud.delete / remove, gaussian_pointcloud.py:195-235;
+        mapper.py:298-335 drops unstable Gaussians that outlived their window or went transparent).  Order is kept."""
+        self.flush()
+        mask = mask.to(self.device).bool().reshape(-1)
+        keep = ~mask
+        nf = int(keep[:self.n_frozen].sum()) if self.n_frozen else 0
+        self._permute(torch.nonzero(keep).reshape(-1), nf)
+
+    def freeze_rows(self, mask: torch.Tensor):
+        """Make the trainable rows where `mask` [N] is set FROZEN (gaussians_fix: unstable Gaussians whose confidence passed
+        the threshold join the stable cloud, mapper.py:253-271): they move, in order, behind the frozen prefix."""
+        self.flush()
+        mask = mask.to(self.device).bool().reshape(-1).clone()
+        mask[:self.n_frozen] = True
+        order = torch.sort((~mask).to(torch.int8), stable=True).indices       # frozen first, order kept inside both parts
+        self._permute(order, int(mask.sum()))
+
+    def _adam(self, st, shard, gs, row_state=None):
+        n = shard.shape[0]                                  # the state arrays are allocated for the capacity
+        if self.row_skip:
+            _adam_rows_hip(shard, gs, st["m"][:n], st["v"][:n], st["lr"], self.step_count, self.eps, st["ever"][:n], row_state)
+        else:
+            self.adam_fn(shard, gs, st["m"][:n], st["v"][:n], st["lr"], self.step_count, self.eps)
 
     # ------------------------------------------------------------------ one-call SLAM step (single GPU)
     def begin_local_optimization(self):
         """Snapshot the raw parameters the attach regulariser ties low-opacity Gaussians to (`history_stat` /
-        `init_stat` of mapper.py:147-153, 660-666) and re-create the Adam state, as the reference does for every
-        local / global optimisation (mapper.py:156: a new torch.optim.Adam per call)."""
+        `init_stat` of mapper.py:147-153, 660-666) and reset the Adam state, as the reference does for every
+        local / global optimisation (mapper.py:156: a new torch.optim.Adam per call) - in place: nothing is allocated
+        once the buffers exist.  Covers the trainable rows."""
         self.flush()
-        N, st = self.N, self.state
-        self.attach_init = dict(xyz=st["xyz"]["p"][:N].clone(), raw8=st["raw8"]["p"][:N].clone(),
-                                info=torch.zeros(6, dtype=torch.float32, device=st["xyz"]["p"].device))
+        N, nf, st = self.N, self.n_frozen, self.state
+        rows = st["xyz"]["p"].shape[0]
+        buf = getattr(self, "_attach_buf", None)
+        if buf is None or buf["xyz"].shape[0] < rows:
+            buf = self._attach_buf = dict(xyz=torch.empty(rows, 3, dtype=torch.float32, device=self.device),
+                                          raw8=torch.empty(rows, 8, dtype=torch.float32, device=self.device),
+                                          info=torch.zeros(6, dtype=torch.float32, device=self.device))
+        buf["xyz"][:N - nf].copy_(st["xyz"]["p"][nf:N])
+        buf["raw8"][:N - nf].copy_(st["raw8"]["p"][nf:N])
+        self.attach_init = dict(xyz=buf["xyz"][:N - nf], raw8=buf["raw8"][:N - nf], info=buf["info"])
         for holder in (self.state, self._slam_state or {}):
             for n in holder:
                 for k in ("m", "v", "ever"):
@@ -271,12 +432,12 @@ class ShardedMapOptimizer:
         reference's report) - a device scalar.  The one-call step applies its gradient without evaluating it."""
         from . import _lib
         lib = _lib.load()
-        ai, st, N = self.attach_init, self.state, self.N
+        ai, st, N, nf = self.attach_init, self.state, self.N, self.n_frozen
         dev = st["xyz"]["p"].device
         attach = _lib.AttachC(ai["xyz"].data_ptr(), ai["raw8"].data_ptr(), ai["info"].data_ptr())
         with torch.cuda.device(dev):
-            rc = lib.rtgs_attach_prepare(C.c_void_p(st["xyz"]["p"].data_ptr()), C.c_void_p(st["raw8"]["p"].data_ptr()),
-                                         C.byref(attach), N, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            rc = lib.rtgs_attach_prepare(C.c_void_p(st["xyz"]["p"].data_ptr() + 12 * nf), C.c_void_p(st["raw8"]["p"].data_ptr() + 32 * nf),
+                                         C.byref(attach), N - nf, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         _lib.check(rc, "rtgs_attach_prepare")
         return ai["info"][1]
 
@@ -286,7 +447,8 @@ class ShardedMapOptimizer:
                   render_mask: Optional[torch.Tensor] = None, confidence: Optional[torch.Tensor] = None,
                   tile_band: bool = False, normal_weight: float = 0.0,
                   gt_normal: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """One iteration with the built-in SLAM loss (`slam_losses`): identical kernels and results as
+        """(`confidence`, if given, is float[n_train]: element 0 belongs to the first trainable row.)
+        One iteration with the built-in SLAM loss (`slam_losses`): identical kernels and results as
         `step(lambda gd: slam_losses_hip(render(gd), gt_color, gt_depth))`, but enqueued by a single C call
         (`rtgs_slam_map_step`) - no autograd graph, no per-launch Python.  With more than one rank the map and the
         Adam state stay REPLICATED and only the gradient rows that exist travel: every rank renders its view, packs
@@ -308,7 +470,7 @@ class ShardedMapOptimizer:
             return self.step(loss_fn)
         lib = _lib.load()
         rs = raster_settings
-        N, st, a = self.N, self.state, self.grad_rows
+        N, nf, st, a = self.N, self.n_frozen, self.state, self.grad_rows
         dev = st["xyz"]["p"].device
         if self.world > 1:
             if self._mode == "sharded":
@@ -316,11 +478,12 @@ class ShardedMapOptimizer:
                                    "different Adam state (replicated vs row-sharded); use one of them per optimizer")
             self._mode = "replicated"
             self._resolve_pending()            # before this step's backward overwrites the arena
-            if self._slam_state is None:
+            if self._slam_state is None:       # replicated Adam state of the trainable rows (row 0 = first trainable row)
+                cap = self.capacity
                 self._slam_state = {
-                    n: dict(m=torch.zeros(N, c1 - c0, dtype=torch.float32, device=dev),
-                            v=torch.zeros(N, c1 - c0, dtype=torch.float32, device=dev),
-                            ever=torch.zeros(N, dtype=torch.uint8, device=dev)) for n, c0, c1 in BLOCKS}
+                    n: dict(m=torch.zeros(cap, c1 - c0, dtype=torch.float32, device=dev),
+                            v=torch.zeros(cap, c1 - c0, dtype=torch.float32, device=dev),
+                            ever=torch.zeros(cap, dtype=torch.uint8, device=dev)) for n, c0, c1 in BLOCKS}
         ad = self._slam_state if self.world > 1 else st      # where m / v / ever live
         H, W = int(rs.image_height), int(rs.image_width)
         ws = self._slam_ws
@@ -328,25 +491,21 @@ class ShardedMapOptimizer:
             f = dict(dtype=torch.float32, device=dev)
             i = dict(dtype=torch.int32, device=dev)
             ws = self._slam_ws = dict(
-                hw=(H, W), opacity=torch.empty(N, 1, **f), scales=torch.empty(N, 3, **f), rotations=torch.empty(N, 4, **f),
-                normal=torch.empty(N, 3, **f), color=torch.empty(3, H, W, **f), depth=torch.empty(1, H, W, **f),
+                hw=(H, W), color=torch.empty(3, H, W, **f), depth=torch.empty(1, H, W, **f),
                 cidx=torch.empty(1, H, W, **i), didx=torch.empty(1, H, W, **i), cw=torch.empty(1, H, W, **f),
-                dw=torch.empty(1, H, W, **f), T=torch.empty(1, H, W, **f), radii=torch.empty(N, **i),
+                dw=torch.empty(1, H, W, **f), T=torch.empty(1, H, W, **f), radii=torch.empty(st["xyz"]["p"].shape[0], **i),
                 g_color=torch.empty(3, H, W, **f), g_depth=torch.empty(1, H, W, **f), loss=torch.empty(4, **f),
                 loss_scratch=None,
                 ones=torch.ones((H + 15) // 16, (W + 15) // 16, **i),
                 arenas=[_GrowArena(dev), _GrowArena(dev), _GrowArena(dev)])
-            self._act_valid = False
+        act = self.act
         if tile_mask is None:
             tile_mask = ws["ones"]
         tile_mask = tile_mask.to(device=dev, dtype=torch.int32).contiguous()
         gt_color, gt_depth = gt_color.contiguous(), gt_depth.contiguous()
         if normal_weight > 0 and gt_normal is not None:
-            # the normal term (mapper.py:433-442) runs inside the one-call step on one GPU; the multi-GPU forms exchange
-            # gradient rows before the tail and do not carry it yet
-            if self.world > 1:
-                raise RuntimeError("step_slam(normal_weight > 0) is single-GPU; use step(loss_fn) with slam_losses_hip(..., "
-                                   "normal_weight=...) on several ranks")
+            # the normal term (mapper.py:433-442) runs between the rasterizer backward and the row exchange / the tail: on
+            # several ranks its d_normal rows travel with the other gradient rows (tile bands: each rank owns its pixels)
             gt_normal = gt_normal.to(device=dev, dtype=torch.float32).contiguous()      # [H, W, 3]
         else:
             gt_normal = None
@@ -366,8 +525,8 @@ class ShardedMapOptimizer:
             C.pointer(keep.c), N, 16, P(st["xyz"]["p"]), P(st["shs"]["p"]), P(st["raw8"]["p"]), P(tile_mask), P(gt_color),
             P(gt_depth), _lib.LossCfgC(float(color_weight), float(depth_weight), float(ssim_weight), float(add_depth_thres),
                                        rm.data_ptr() if rm is not None else None),
-            P(ws["loss_scratch"]), P(ws["opacity"]), P(ws["scales"]), P(ws["rotations"]),
-            P(ws["normal"]), P(ws["color"]), P(ws["depth"]), P(ws["cidx"]), P(ws["didx"]), P(ws["cw"]), P(ws["dw"]),
+            P(ws["loss_scratch"]), P(act["opacity"]), P(act["scales"]), P(act["rotations"]),
+            P(act["normal"]), P(ws["color"]), P(ws["depth"]), P(ws["cidx"]), P(ws["didx"]), P(ws["cw"]), P(ws["dw"]),
             P(ws["T"]), P(ws["radii"]), P(ws["g_color"]), P(ws["g_depth"]), P(ws["loss"]), P(a.d_means), P(a.d_opac),
             P(a.d_shs), P(a.d_scales), P(a.d_rots), P(a.d_normal), P(a.d_raw8), P(a.scratch), P(a.row_state),
             P(ad["xyz"]["m"]), P(ad["xyz"]["v"]), P(ad["shs"]["m"]), P(ad["shs"]["v"]), P(ad["raw8"]["m"]),
@@ -375,7 +534,8 @@ class ShardedMapOptimizer:
             P(ad["shs"]["ever"]), P(ad["raw8"]["ever"]), int(self.step_count), 0.9, 0.999, float(self.eps),
             C.pointer(attach) if attach is not None else None, P(confidence) if confidence is not None else None,
             int(self._act_valid), geom.cb, None, binning.cb, None, img.cb, None,
-            float(normal_weight) if gt_normal is not None else 0.0, P(gt_normal) if gt_normal is not None else None)
+            float(normal_weight) if gt_normal is not None else 0.0, P(gt_normal) if gt_normal is not None else None,
+            int(nf), int(N))
         R = C.c_int64(0)
         stream = torch.cuda.current_stream(dev).cuda_stream
         if tile_band and self.world > 1:
@@ -439,13 +599,12 @@ class ShardedMapOptimizer:
         cfg = _lib.LossCfgC(args.loss.color_weight, args.loss.depth_weight, args.loss.ssim_weight, args.loss.add_depth_thres,
                             band_rm.data_ptr())
         ctx = current_context().ptr
+        act = self.act
+        self._activate_rows(0, N)
         with torch.cuda.device(dev):
-            if not self._act_valid:
-                _lib.check(lib.rtgs_map_activate8_forward(V(x["raw8"]["p"]), N, V(ws["opacity"]), V(ws["scales"]),
-                                                          V(ws["rotations"]), V(ws["normal"]), st()), "rtgs_map_activate8_forward")
             _lib.check(lib.rtgs_raster_forward_ctx(
-                ctx, C.byref(keep.c), N, 16, V(x["xyz"]["p"]), V(ws["opacity"]), V(x["shs"]["p"]), V(ws["scales"]),
-                V(ws["rotations"]), V(ws["normal"]), V(band), V(ws["color"]), V(ws["depth"]), V(ws["cidx"]), V(ws["didx"]),
+                ctx, C.byref(keep.c), N, 16, V(x["xyz"]["p"]), V(act["opacity"]), V(x["shs"]["p"]), V(act["scales"]),
+                V(act["rotations"]), V(act["normal"]), V(band), V(ws["color"]), V(ws["depth"]), V(ws["cidx"]), V(ws["didx"]),
                 V(ws["cw"]), V(ws["dw"]), V(ws["T"]), V(ws["radii"]), geom.cb, None, binning.cb, None, img.cb, None,
                 C.byref(R), 0, st()), "rtgs_raster_forward")
             _lib.check(lib.rtgs_slam_loss_sums(V(ws["color"]), V(ws["depth"]), V(ws["didx"]), C.c_void_p(args.gt_color),
@@ -457,11 +616,19 @@ class ShardedMapOptimizer:
             _lib.check(lib.rtgs_slam_loss_grads(V(ws["color"]), V(ws["depth"]), V(ws["didx"]), C.c_void_p(args.gt_color),
                                                 C.c_void_p(args.gt_depth), H, W, C.byref(cfg), V(ws["loss_scratch"]),
                                                 V(ws["loss"]), V(ws["g_color"]), V(ws["g_depth"]), st()), "rtgs_slam_loss_grads")
-            _lib.check(lib.rtgs_raster_backward_rows_ctx(
-                ctx, C.byref(keep.c), N, 16, R.value, V(x["xyz"]["p"]), V(ws["opacity"]), V(x["shs"]["p"]), V(ws["scales"]),
-                V(ws["rotations"]), V(ws["normal"]), V(geom.tensor), V(binning.tensor), V(img.tensor), V(ws["color"]), V(ws["T"]),
+            _lib.check(lib.rtgs_raster_backward_range_ctx(
+                ctx, C.byref(keep.c), N, 16, R.value, V(x["xyz"]["p"]), V(act["opacity"]), V(x["shs"]["p"]), V(act["scales"]),
+                V(act["rotations"]), V(act["normal"]), V(geom.tensor), V(binning.tensor), V(img.tensor), V(ws["color"]), V(ws["T"]),
                 V(ws["didx"]), V(ws["g_color"]), V(ws["g_depth"]), V(a.d_means), V(a.d_opac), V(a.d_shs), V(a.d_scales),
-                V(a.d_rots), V(a.d_normal), V(a.scratch), V(a.row_state), st()), "rtgs_raster_backward_rows")
+                V(a.d_rots), V(a.d_normal), V(a.scratch), V(a.row_state), int(self.n_frozen), int(N), st()), "rtgs_raster_backward_range")
+            if args.normal_weight > 0 and args.gt_normal:
+                # the band's pixels only (band_rm): every pixel of the view is counted by exactly one rank.  NOTE: the mean's
+                # normaliser is this rank's count - exact on one rank; with bands the reference's global mean would need the
+                # two sums all-reduced like the image terms (normal_weight is 0 in every shipped config)
+                _lib.check(lib.rtgs_slam_normal_loss_range(
+                    V(act["normal"]), V(ws["didx"]), C.c_void_p(args.gt_normal), V(band_rm), H, W, float(args.normal_weight),
+                    C.c_void_p(ws["loss_scratch"].data_ptr() + 20), V(ws["loss"]), V(a.d_normal), V(a.row_state), None,
+                    int(self.n_frozen), int(N), st()), "rtgs_slam_normal_loss")
 
     # ------------------------------------------------------------------ sparse exchange (world > 1), no host sync
     def _exchange_and_tail(self, job):
@@ -506,15 +673,18 @@ class ShardedMapOptimizer:
             for r in range(W):                                        # same order on every rank: bit-identical replicas
                 lst = C.c_void_p(ws["gathered"].data_ptr() + r * stride)
                 _lib.check(lib.rtgs_rows_apply(lst, cap, 1, *arena, V(a.row_state), V(flag), stream()), "rtgs_rows_apply")
+            nf = self.n_frozen
+            O = lambda t, c: C.c_void_p(t.data_ptr() + 4 * c * nf)          # row nf of a [rows, c] float32 array
+            act = self.act
             rc = lib.rtgs_map_tail_rows(
-                V(st["xyz"]["p"]), V(st["shs"]["p"]), V(st["raw8"]["p"]), V(a.d_opac), V(a.d_scales), V(a.d_rots),
-                V(a.d_normal), V(a.d_means), V(a.d_shs), V(a.d_raw8), V(a.row_state), V(ad["xyz"]["m"]),
-                V(ad["xyz"]["v"]), V(ad["shs"]["m"]), V(ad["shs"]["v"]), V(ad["raw8"]["m"]), V(ad["raw8"]["v"]),
+                O(st["xyz"]["p"], 3), O(st["shs"]["p"], 48), O(st["raw8"]["p"], 8), O(a.d_opac, 1), O(a.d_scales, 3), O(a.d_rots, 4),
+                O(a.d_normal, 3), O(a.d_means, 3), O(a.d_shs, 48), O(a.d_raw8, 8), C.c_void_p(a.row_state.data_ptr() + nf),
+                V(ad["xyz"]["m"]), V(ad["xyz"]["v"]), V(ad["shs"]["m"]), V(ad["shs"]["v"]), V(ad["raw8"]["m"]), V(ad["raw8"]["v"]),
                 V(st["xyz"]["lr"]), V(st["shs"]["lr"]), V(st["raw8"]["lr"]), V(ad["xyz"]["ever"]), V(ad["shs"]["ever"]),
-                V(ad["raw8"]["ever"]), N, job["step"], 0.9, 0.999, float(self.eps),
+                V(ad["raw8"]["ever"]), N - nf, job["step"], 0.9, 0.999, float(self.eps),
                 C.byref(att) if att is not None else None, V(conf) if conf is not None else None, V(flag),
-                C.byref(_lib.ActivatedC(ws["opacity"].data_ptr(), ws["scales"].data_ptr(), ws["rotations"].data_ptr(),
-                                        ws["normal"].data_ptr())), stream())
+                C.byref(_lib.ActivatedC(act["opacity"].data_ptr() + 4 * nf, act["scales"].data_ptr() + 12 * nf,
+                                        act["rotations"].data_ptr() + 16 * nf, act["normal"].data_ptr() + 12 * nf)), stream())
             _lib.check(rc, "rtgs_map_tail_rows")
         ws["flag_host"].copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
@@ -558,12 +728,15 @@ class ShardedMapOptimizer:
         return dict(xyz=a.d_means, shs=a.d_shs, raw8=a.d_raw8)[name]
 
     def my_rows(self) -> slice:
-        return slice(self.rank * self.per, (self.rank + 1) * self.per)
+        """This rank's shard of the trainable rows."""
+        return slice(self.n_frozen + self.rank * self.per, self.n_frozen + (self.rank + 1) * self.per)
 
     def step(self, loss_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor]) -> torch.Tensor:
         """loss_fn(gaussian_data) -> scalar loss of THIS rank's view.  Gradients are summed over
-        ranks (the sum of per-view losses is what a single GPU looping over the views optimises)."""
-        N = self.N
+        ranks (the sum of per-view losses is what a single GPU looping over the views optimises).  Only the trainable
+        rows [n_frozen, N) are reduced, stepped and gathered; the row shards partition that range."""
+        N, nf = self.N, self.n_frozen
+        per, span = self.per, self.per * self.world        # rows of one shard / of all shards (>= n_train: padded)
         self._act_valid = False            # raw8 moves without step_slam's tail: its activated copies go stale
         if self.world > 1:
             if self._mode == "replicated":
@@ -595,18 +768,22 @@ class ShardedMapOptimizer:
             rs, ag = {}, []
             for name in order:
                 st = self.state[name]
-                st["gpad"][:N] = gmap[name]
-                rs[name] = dist.reduce_scatter_tensor(st["gshard"], st["gpad"], op=dist.ReduceOp.SUM, group=self.group,
+                g = gmap[name]
+                if nf + span == N:
+                    src = g[nf:N]                       # the trainable gradient rows as they lie (no staging copy)
+                else:
+                    st["gpad"][nf:N] = g[nf:N]          # the shards' padding rows stay zero
+                    src = st["gpad"][nf:nf + span]
+                rs[name] = dist.reduce_scatter_tensor(st["gshard"][:per], src, op=dist.ReduceOp.SUM, group=self.group,
                                                       async_op=True)
             for name in order:
                 st = self.state[name]
                 rs[name].wait()                         # stream-side wait, the host does not block
                 shard = st["p"][rows]
-                self._adam(st, shard, st["gshard"])
-                if st.get("send") is None:
-                    st["send"] = torch.empty_like(shard)
-                st["send"].copy_(shard)                 # all-gather input must not alias its output
-                ag.append(dist.all_gather_into_tensor(st["p"], st["send"], group=self.group, async_op=True))
+                self._adam(st, shard, st["gshard"][:per])
+                # in place: the shard IS this rank's slice of the gathered range (sendbuff = recvbuff + rank * count, the
+                # in-place form of the collective) - no staging copy of the updated rows
+                ag.append(dist.all_gather_into_tensor(st["p"][nf:nf + span], shard, group=self.group, async_op=True))
             for w in ag:
                 w.wait()
             return loss.detach()
@@ -615,20 +792,21 @@ class ShardedMapOptimizer:
             st = self.state[name]
             g = gmap[name]
             if self.world > 1:                          # gloo (CPU tests): no reduce-scatter -> all-reduce, take the local rows
-                st["gpad"][:N] = g
-                dist.all_reduce(st["gpad"], op=dist.ReduceOp.SUM, group=self.group)
+                st["gpad"][nf:N] = g[nf:N]
+                red = st["gpad"][nf:nf + span]
+                dist.all_reduce(red, op=dist.ReduceOp.SUM, group=self.group)
                 gs = st["gpad"][rows].contiguous()
             else:
-                gs = g if self.Npad == N else torch.nn.functional.pad(g, (0, 0, 0, self.Npad - N))
+                gs = g[nf:N]
             shard = st["p"][rows]
             row_state = None
-            if arena is not None and arena.calls == 1 and gs.data_ptr() == self._arena_grad(name).data_ptr():
-                row_state = arena.row_state      # gs IS the rasterizer's persistent rows: their states are exact
+            if arena is not None and arena.calls == 1 and gs.data_ptr() == self._arena_grad(name)[nf:].data_ptr():
+                row_state = arena.row_state[nf:]   # gs IS the rasterizer's persistent rows: their states are exact
             self._adam(st, shard, gs, row_state)
             if self.world > 1:
                 parts = [torch.empty_like(shard) for _ in range(self.world)]
                 dist.all_gather(parts, shard.clone(), group=self.group)
-                st["p"].copy_(torch.cat(parts, dim=0))
+                st["p"][nf:nf + span].copy_(torch.cat(parts, dim=0))
         return loss.detach()
 
 

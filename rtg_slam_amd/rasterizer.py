@@ -183,22 +183,46 @@ class RowGradArena:
     tensors of the rasterizer, the raw8 gradient of the activation kernel, the SplatGrad scratch and one state
     byte per Gaussian, all allocated (zero) once.  Pass it as `grad_rows=` to `GaussianRasterizer.forward`; the
     first backward after `begin_step()` then touches only the rows that received gradient.  The tensors handed
-    to autograd ARE these buffers - they are overwritten by the next step."""
+    to autograd ARE these buffers - they are overwritten by the next step.
 
-    def __init__(self, P: int, M: int, device):
+    `capacity` rows are allocated, `P` of them are in use (a map that grows re-uses the arena: `resize`).  `train` =
+    (begin, end): only these rows are differentiated (rtgs_raster_backward_range_ctx) - the trainable, "unstable" part
+    of an RTG-SLAM map (mapper.py:143-156); None = every row."""
+
+    def __init__(self, P: int, M: int, device, capacity: Optional[int] = None):
         lib = _lib.load()
         f = dict(dtype=torch.float32, device=device)
-        self.P, self.M = int(P), int(M)
-        self.d_means = torch.zeros(P, 3, **f)
-        self.d_opac = torch.zeros(P, 1, **f)
-        self.d_shs = torch.zeros(P, M, 3, **f)
-        self.d_scales = torch.zeros(P, 3, **f)
-        self.d_rots = torch.zeros(P, 4, **f)
-        self.d_normal = torch.zeros(P, 3, **f)
-        self.d_raw8 = torch.zeros(P, 8, **f)
-        self.scratch = torch.zeros(lib.rtgs_raster_backward_scratch_bytes(P), dtype=torch.uint8, device=device)
-        self.row_state = torch.zeros(max(P, 1), dtype=torch.uint8, device=device)
+        cap = max(int(capacity) if capacity is not None else int(P), int(P), 1)
+        self.P, self.M, self.capacity = int(P), int(M), cap
+        self._full = dict(d_means=torch.zeros(cap, 3, **f), d_opac=torch.zeros(cap, 1, **f), d_shs=torch.zeros(cap, M, 3, **f),
+                          d_scales=torch.zeros(cap, 3, **f), d_rots=torch.zeros(cap, 4, **f), d_normal=torch.zeros(cap, 3, **f),
+                          d_raw8=torch.zeros(cap, 8, **f))
+        self.scratch = torch.zeros(lib.rtgs_raster_backward_scratch_bytes(cap), dtype=torch.uint8, device=device)
+        self._state_full = torch.zeros(cap, dtype=torch.uint8, device=device)
+        self.train = None
         self.calls = 0           # rasterizer backward passes since begin_step(); the row states describe exactly one
+        self._views()
+
+    def _views(self):
+        P = self.P
+        for k, t in self._full.items():
+            setattr(self, k, t[:P])                       # same storage, row 0 at the same address
+        self.row_state = self._state_full[:max(P, 1)]
+
+    def resize(self, P: int):
+        """Use `P` rows of the allocation from now on.  The rows are zeroed (states too): their ids mean other Gaussians."""
+        if P > self.capacity:
+            raise ValueError("RowGradArena.resize beyond the allocated capacity")
+        self.P = int(P)
+        self.clear()
+        self._views()
+
+    def clear(self):
+        for t in self._full.values():
+            t.zero_()
+        self.scratch.zero_()
+        self._state_full.zero_()
+        self.calls = 0
 
     def begin_step(self):
         self.calls = 0
@@ -280,14 +304,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             if first and P > 0 and arena.P == P and arena.M == ctx.M and arena.d_means.device == dev:
                 keep = _Keep(rs, dev)
                 stream = torch.cuda.current_stream(dev).cuda_stream
+                t0, t1 = arena.train if arena.train is not None else (0, P)
                 with torch.cuda.device(dev):
-                    rc = lib.rtgs_raster_backward_rows_ctx(
+                    rc = lib.rtgs_raster_backward_range_ctx(
                         ctx.rctx.ptr, C.byref(keep.c), P, ctx.M, ctx.num_rendered, _ptr(means3D), _ptr(opacities), _ptr(shs),
                         _ptr(scales), _ptr(rotations), _ptr(normal_w), _ptr(geom), _ptr(binning), _ptr(img),
                         _ptr(color), _ptr(Tm), _ptr(didx), _ptr(g_color), _ptr(g_depth), _ptr(arena.d_means),
                         _ptr(arena.d_opac), _ptr(arena.d_shs), _ptr(arena.d_scales), _ptr(arena.d_rots),
-                        _ptr(arena.d_normal), _ptr(arena.scratch), _ptr(arena.row_state), C.c_void_p(stream))
-                _lib.check(rc, "rtgs_raster_backward_rows")
+                        _ptr(arena.d_normal), _ptr(arena.scratch), _ptr(arena.row_state), int(t0), int(t1), C.c_void_p(stream))
+                _lib.check(rc, "rtgs_raster_backward_range")
                 return (arena.d_means, arena.d_opac, arena.d_shs.view_as(shs), arena.d_scales, arena.d_rots,
                         arena.d_normal, None, None, None, None)
         d_means = torch.empty_like(means3D)

@@ -330,7 +330,7 @@ def test_step_slam_attach_regulariser_and_confidence():
     # the persistent activated arrays must equal a fresh activation of the current raw8 bit for bit
     fresh = mo.activate8_hip(ob.state["raw8"]["p"][:N])
     for k in ("opacity", "scales", "rotations", "normal"):
-        assert torch.equal(ob._slam_ws[k], fresh[k].reshape(ob._slam_ws[k].shape)), k
+        assert torch.equal(ob.act[k][:N], fresh[k].reshape(ob.act[k][:N].shape)), k
     assert ob._act_valid
     pa, pb = oa.params.cpu(), ob.params.cpu()
     assert ru.frac_bad(pa, pb, 1e-5) < 2e-3
@@ -598,7 +598,7 @@ def test_one_call_slam_step_matches_autograd_step():
     # the persistent activated arrays must equal a fresh activation of the current raw8 bit for bit
     fresh = mo.activate8_hip(ob.state["raw8"]["p"][:N])
     for k in ("opacity", "scales", "rotations", "normal"):
-        assert torch.equal(ob._slam_ws[k], fresh[k].reshape(ob._slam_ws[k].shape)), k
+        assert torch.equal(ob.act[k][:N], fresh[k].reshape(ob.act[k][:N].shape)), k
     assert ob._act_valid
     pa, pb = oa.params.cpu(), ob.params.cpu()
     assert ru.frac_bad(pa, pb, 1e-5) < 2e-3

@@ -1,0 +1,154 @@
+"""The trainable range and the growing map of ShardedMapOptimizer (rtg_slam_amd/map_optim.py).
+
+RTG-SLAM renders cat(unstable, stable) but optimises only the unstable Gaussians (mapper.py:143-156 parametrizes
+self.pointcloud; :1026-1108 concatenates the stable rows without requires_grad) and the map changes every frame
+(gaussians_add -> GaussianPointCloud.cat, gaussian_pointcloud.py:286-303; delete / remove :195-235; gaussians_fix,
+mapper.py:253-271).  Here: frozen rows are rendered, never differentiated (exact zeros, no row state), never stepped
+(bitwise untouched); the trainable rows move exactly as if the frozen ones were constants of an autograd graph; appending,
+removing and freezing rows keeps parameters and renders consistent and costs no re-allocation inside the capacity."""
+import pytest
+import torch
+
+from rtg_slam_amd import synth
+from tests import raster_util as ru
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CAM = synth.CameraSpec(128, 192, 160.0, 160.0, 95.5, 63.5)
+
+
+def _setup(N=12000, seed=4):
+    from rtg_slam_amd import map_optim as mo
+    g, s = ru.make_scene(N, CAM, seed=seed, pose_seed=2)
+    packed = mo.pack_from_activated({k: v.to(DEV) for k, v in g.items()})
+    gen = torch.Generator().manual_seed(seed)
+    gt_c = torch.rand(3, CAM.H, CAM.W, generator=gen).to(DEV)
+    gt_d = (1.0 + torch.rand(1, CAM.H, CAM.W, generator=gen)).to(DEV)
+    return mo, packed, ru.hip_settings(s, DEV), gt_c, gt_d
+
+
+@pytest.mark.parametrize("nf", [0, 7000, 11990])
+def test_frozen_rows_untouched_and_trainable_rows_match_the_autograd_step(nf):
+    """step_slam (one C call: range backward + tail over the trainable rows) against step(loss_fn) (autograd through the
+    arena with the same range) on the same optimiser state, five iterations with the attach regulariser and a confidence
+    array; and against an optimiser that trains everything, after ONE step (same forward, so the trainable rows receive
+    the same gradients whether or not the others are differentiated)."""
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    mo, packed, rs, gt_c, gt_d = _setup()
+    N = packed.shape[0]
+    oa = mo.ShardedMapOptimizer(packed.clone(), n_frozen=nf)
+    ob = mo.ShardedMapOptimizer(packed.clone(), n_frozen=nf)
+    full = mo.ShardedMapOptimizer(packed.clone())
+    rast = GaussianRasterizer(raster_settings=rs)
+    rm = torch.ones(CAM.H, CAM.W, dtype=torch.uint8, device=DEV)
+
+    def loss_fn(gd):
+        out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
+                   rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=None,
+                   grad_rows=gd.get("grad_rows"))
+        return mo.slam_losses_hip(out, gt_c, gt_d, render_mask=rm)
+    conf = torch.zeros(N - nf, device=DEV)
+    full.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
+    for it in range(5):
+        la = float(oa.step(loss_fn))
+        lb = float(ob.step_slam(rs, gt_c, gt_d, None, render_mask=rm, confidence=conf))
+        assert abs(la - lb) <= 1e-4 * max(1.0, abs(la)), it
+        if it == 0:
+            pf, pb = full.params, ob.params
+            assert float((pf[nf:] - pb[nf:]).abs().max()) <= 1e-6          # same gradients for the trainable rows
+            if nf:
+                assert not torch.equal(pf[:nf], packed[:nf])               # ... while `full` did move the others
+    pa, pb = oa.params, ob.params
+    assert torch.equal(pb[:nf], packed[:nf]) and torch.equal(pa[:nf], packed[:nf])      # frozen rows: bitwise untouched
+    assert ru.frac_bad(pa.cpu(), pb.cpu(), 1e-5) < 2e-3
+    moved = (pb[nf:] - packed[nf:]).abs().max(dim=1).values > 0
+    assert int(moved.sum()) > 0
+    a = ob.grad_rows
+    assert int(a.row_state[:nf].sum()) == 0                                # never differentiated: no state, exact zeros
+    for t in (a.d_means, a.d_shs, a.d_opac, a.d_scales, a.d_rots, a.d_normal, a.d_raw8):
+        assert float(t[:nf].abs().sum()) == 0.0
+    # confidence (mapper.py:454-456) counts the trainable rows whose f_dc gradient was non-zero, element 0 = row nf
+    assert float(conf.sum()) > 0 and float(conf.max()) <= 5.0
+    # _features_dc.grad == 0 semantics (mapper.py:455): a trainable row that reached no pixel has exactly zero gradient
+    assert float(a.d_shs[nf:][a.row_state[nf:] != 1].abs().sum()) == 0.0
+
+
+def test_frozen_rows_with_the_attach_regulariser_count_only_trainable_rows():
+    mo, packed, rs, gt_c, gt_d = _setup()
+    nf = 5000
+    N = packed.shape[0]
+    part = mo.ShardedMapOptimizer(packed.clone(), n_frozen=nf)
+    only = mo.ShardedMapOptimizer(packed[nf:].clone())                     # the trainable rows as a map of their own
+    part.begin_local_optimization(); only.begin_local_optimization()
+    assert float(part.attach_init["info"][0]) == float(only.attach_init["info"][0]) > 0
+    rm = torch.ones(CAM.H, CAM.W, dtype=torch.uint8, device=DEV)
+    for _ in range(3):
+        part.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
+    assert torch.equal(part.params[:nf], packed[:nf])
+    assert float(part.attach_loss()) > 0.0
+
+
+def test_append_remove_freeze_keep_the_map_consistent():
+    """Rows are appended behind the map (inside the capacity: no re-allocation, the parameter tensors keep their
+    addresses), removed and frozen; after every change the zero-copy gaussian_data() renders exactly what a fresh
+    optimiser built from `.params` renders, and optimisation continues."""
+    from rtg_slam_amd.render import Renderer          # noqa: F401  (import check only)
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    mo, packed, rs, gt_c, gt_d = _setup(N=9000)
+    rast = GaussianRasterizer(raster_settings=rs)
+
+    def render(gd):
+        with torch.no_grad():
+            return rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
+                        rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=None)
+
+    def check(opt):
+        ref = mo.ShardedMapOptimizer(opt.params.clone(), n_frozen=opt.n_frozen)
+        a, b = render(opt.gaussian_data()), render(ref.gaussian_data())
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        return a
+
+    opt = mo.ShardedMapOptimizer(packed[:6000].clone(), capacity=12000)
+    addr = opt.state["shs"]["p"].data_ptr()
+    rm = torch.ones(CAM.H, CAM.W, dtype=torch.uint8, device=DEV)
+    opt.begin_local_optimization()
+    for _ in range(3):
+        opt.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
+    gd = opt.gaussian_data()
+    assert gd["xyz"].data_ptr() == opt.state["xyz"]["p"].data_ptr() and gd["opacity"].data_ptr() == opt.act["opacity"].data_ptr()
+    check(opt)
+    before = opt.params.clone()
+    opt.append_rows(packed[6000:9000])
+    assert opt.N == 9000 and opt.state["shs"]["p"].data_ptr() == addr      # inside the capacity: nothing moved
+    assert torch.equal(opt.params[:6000], before) and torch.equal(opt.params[6000:], packed[6000:9000])
+    check(opt)
+    opt.begin_local_optimization()
+    for _ in range(3):
+        opt.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
+    check(opt)
+    # freeze every third row, then remove a fifth of all rows
+    p0 = opt.params.clone()
+    fmask = torch.zeros(9000, dtype=torch.bool, device=DEV); fmask[::3] = True
+    opt.freeze_rows(fmask)
+    assert opt.n_frozen == 3000 and torch.equal(opt.params[:3000], p0[fmask]) and torch.equal(opt.params[3000:], p0[~fmask])
+    check(opt)
+    p1 = opt.params.clone()
+    rmask = torch.zeros(9000, dtype=torch.bool, device=DEV); rmask[::5] = True
+    opt.remove_rows(rmask)
+    assert opt.N == 9000 - int(rmask.sum()) and opt.n_frozen == 3000 - int(rmask[:3000].sum())
+    assert torch.equal(opt.params, p1[~rmask])
+    check(opt)
+    frozen = opt.params[:opt.n_frozen].clone()
+    opt.begin_local_optimization()
+    for _ in range(3):
+        opt.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
+    assert torch.equal(opt.params[:opt.n_frozen], frozen)
+    check(opt)
+    # beyond the capacity: re-allocation, contents preserved
+    opt.append_rows(packed[:8000])
+    assert opt.capacity >= opt.N == 9000 - int(rmask.sum()) + 8000
+    check(opt)
+    opt.begin_local_optimization()
+    opt.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
+    check(opt)
