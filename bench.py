@@ -318,6 +318,21 @@ def main():
             map_iter_ms = 1e3 * (time.perf_counter() - ts) / args.steps
             surface = profile_scene(lib, mo, rast, opt_s, N, cam, tile_mask, gt_color, gt_d_s, dev, 5)
             surface["map_iteration_ms"] = round(map_iter_ms, 4)
+            # ... and as RTG-SLAM optimises it: most of a mature map is STABLE (rendered, not differentiated, not stepped -
+            # mapper.py:1026-1108); here the first 80 % of the rows are frozen, the last 20 % trainable
+            opt_u = mo.ShardedMapOptimizer(opt_s.params, lr_col=mo.default_lr_columns() * 1e-4, n_frozen=int(0.8 * N))
+            opt_u.begin_local_optimization()
+            for _ in range(20):
+                opt_u.step_slam(rs, gt_color, gt_d_s, tile_mask, render_mask=rm_s)
+            torch.cuda.synchronize(dev)
+            tu = time.perf_counter()
+            for _ in range(args.steps):
+                opt_u.step_slam(rs, gt_color, gt_d_s, tile_mask, render_mask=rm_s)
+            torch.cuda.synchronize(dev)
+            surface["unstable_20pct"] = {"map_iteration_ms": round(1e3 * (time.perf_counter() - tu) / args.steps, 4),
+                                         "trainable_rows": int(opt_u.n_train), "frozen_rows": int(opt_u.n_frozen),
+                                         "rows_with_gradient": int((opt_u.grad_rows.row_state == 1).sum())}
+            del opt_u
             surface["workload"] = (f"{N} opaque discs on the walls of the 5 x 3 x 6 m box room (one layer, opacity 0.99, radius = "
                                    "sqrt(area / N) clipped to [0.001, 0.05] m), camera inside, all tiles")
             del opt_s
@@ -415,7 +430,7 @@ def main():
             "strong_scaling_one_view": strong,
             "near_slice": slice_stats, "kernels": kernels, "roofline": roofline, "cpu_baseline": cpu,
             "surface_scene": None if surface is None else {k: surface[k] for k in (
-                "workload", "map_iteration_ms", "raster_fwd_ms", "raster_bwd_ms", "raster_fwd_bwd_ms", "instances", "consumed",
+                "workload", "map_iteration_ms", "unstable_20pct", "raster_fwd_ms", "raster_bwd_ms", "raster_fwd_bwd_ms", "instances", "consumed",
                 "consumed_fraction", "rows_touched", "near_slice", "kernels")},
         }
         print(json.dumps(result), flush=True)
@@ -427,13 +442,14 @@ def main():
 def reference_schedule_leg(cam, N, dev, cycles=3, iters=50, every=6, window=5, n_new=40800):
     """The reference's Replica schedule as a measured workload (slam.py main loop; mapper.py:97-110, 157-205;
     configs/replica_base.yaml:9-18): EVERY frame is preprocessed (tracker.py:97-159), tracked frame-to-model
-    (IcpTracker.predict_pose + update_last_status with a render of the map at the new pose), and `uniform_sample_num`
-    = 40 800 new Gaussians are built for it (sample_pixels + distCUDA2 radii, gaussian_pointcloud.py:366-405); every 6th
+    (IcpTracker.predict_pose + update_last_status with a render of the map at the new pose), and new Gaussians are added
+    where the rendered model is transparent or wrong (temp_points_init's rule with `uniform_sample_num` = 40 800; sample_pixels +
+    distCUDA2 radii, gaussian_pointcloud.py:366-405 - the first frame of a run adds all 40 800, later ones what the rule gives); every 6th
     frame the map is optimised: a fresh Adam state (mapper.py:156), evaluate_render_range on each of the 5 window frames
     (one render + T_map -> render / tile masks), then 50 loss_update iterations on a random frame of the window (the last
     frame in the second half, mapper.py:176-183).  1200x680, the 1.2 M single-layer surface map, one GPU, one stream,
-    sequential like slam.py.  The new Gaussians are computed and discarded so that the map stays at N (appending would
-    only change N between cycles); dataset IO and the keyframe / stable-set policies are out of scope."""
+    sequential like slam.py, through the product's map object (ShardedMapOptimizer: rows appended every frame, zero-copy
+    gaussian_data(), in-place begin_local_optimization).  Dataset IO and the keyframe / stable-set policies are out of scope."""
     import numpy as np
     from types import SimpleNamespace
     from rtg_slam_amd import synth, slam_ops, map_optim as mo
@@ -455,17 +471,23 @@ def reference_schedule_leg(cam, N, dev, cycles=3, iters=50, every=6, window=5, n
     gen = torch.Generator(device=dev).manual_seed(3)
     rng = np.random.RandomState(5)
     lr = mo.default_lr_columns() * 1e-4          # as in the headline leg: random-ish targets must not inflate the map
-    state = dict(params=packed, win=[], c2w=poses[0].clone(), iters=0)
+    # ONE optimiser for the run (the product's map object): new Gaussians are appended to it every frame, it hands the
+    # renderer zero-copy views of its own arrays, and a local optimisation begins by resetting its Adam state in place
+    opt = mo.ShardedMapOptimizer(packed, lr_col=lr, capacity=N + 4 * n_new)
+    del packed
+    state = dict(win=[], c2w=poses[0].clone(), iters=0)
     prof = {} if os.environ.get("RTGS_SCHED_PROFILE") else None     # diagnosis only: per-stage wall time WITH syncs
 
     def mark(name, t):
         if prof is not None:
             torch.cuda.synchronize(dev)
-            prof[name] = prof.get(name, 0.0) + (time.perf_counter() - t)
+            if state.get("timed"):                          # the untimed first cycle carries the one-off costs
+                prof[name] = prof.get(name, 0.0) + (time.perf_counter() - t)
         return time.perf_counter()
 
     def one_frame(fid):
         depth, color = frames[fid]
+        state["timed"] = fid >= every
         tm_ = time.perf_counter()
         fm = slam_ops.frame_preprocess(depth, K, 0.3, 8.0, False, 0.2)
         tm_ = mark("frame_preprocess", tm_)
@@ -480,20 +502,38 @@ def reference_schedule_leg(cam, N, dev, cycles=3, iters=50, every=6, window=5, n
         vertex_w = fm["vertex_map_c"] @ Rw.t() + tw
         normal_w = fm["normal_map_c"] @ Rw.t()
         view = ms._camera(cam, c2w, dev)
-        # gaussians_add: uniform_sample_num new Gaussians from the frame's pixels, radius from the 3 nearest neighbours
-        pts, nrm, col = slam_ops.sample_pixels(vertex_w, normal_w, color.permute(1, 2, 0).contiguous(), n_new, None, gen)
-        new = mo.pack_from_activated(ms.gaussians_from_pixels(pts, nrm, col))
-        del new
+        # gaussians_add (mapper.py:128-132 -> temp_points_init :715-800, configs/base.yaml:47-52): render the model at the new
+        # pose; sample transmission_sample_ratio x (uncovered fraction) x uniform_sample_num pixels where the map is
+        # transparent (T > add_transmission_thres) and error_sample_ratio x (# pixels) where depth or colour are off; the new
+        # Gaussians (radius from the 3 nearest neighbours) are APPENDED to the map - it grows over the run
+        with torch.no_grad():
+            out = renderer.render(view, opt.gaussian_data())
+        T = out["T_map"][0]
+        dmap = fm["depth_map"][..., 0]
+        depth_ok = dmap > 0
+        tmask = (T > 0.5) & depth_ok
+        n_trans = int(float(tmask.float().mean()) * 1.0 * n_new)
+        cerr = (color - out["render"]).abs().mean(dim=0)
+        emask = (((dmap - out["depth"][0]).abs() > 0.1) & depth_ok & (out["depth_index_map"][0] > -1)) | \
+                ((cerr > 0.1) & depth_ok & (T < 0.5))
+        emask = emask & ~tmask
+        n_err = int(float(emask.sum()) * 0.05)
+        cmap = color.permute(1, 2, 0).contiguous()
+        parts = [slam_ops.sample_pixels(vertex_w, normal_w, cmap, n, m, gen) for n, m in ((n_trans, tmask), (n_err, emask)) if n > 0]
+        n_added = sum(int(q[0].shape[0]) for q in parts)
+        if n_added >= 4:
+            pts, nrm, col = (torch.cat([q[k] for q in parts], 0) for k in range(3))
+            opt.append_rows(mo.pack_from_activated(ms.gaussians_from_pixels(pts, nrm, col)))
+            state["added"] = state.get("added", 0) + n_added
         tm_ = mark("gaussians_add", tm_)
         rs = ms.renderer_settings(renderer, view, dev)
         state["win"] = (state["win"] + [(rs, color, fm["depth_map"].permute(2, 0, 1).contiguous(), view)])[-window:]
         if (fid + 1) % every == 0 or fid == 0:
-            opt = mo.ShardedMapOptimizer(state["params"], lr_col=lr)          # Adam re-created per local_optimize
-            opt.begin_local_optimization()
+            opt.begin_local_optimization()                                     # Adam re-created per local_optimize (in place)
             masks = []
             for (rs_w, _, _, view_w) in state["win"]:                          # evaluate_render_range (mapper.py:471-508)
                 with torch.no_grad():
-                    out = renderer.render(view_w, mo.activate_packed(opt.params))
+                    out = renderer.render(view_w, opt.gaussian_data())
                 rm, tm, _ = slam_ops.render_range(out["T_map"], 0.5)
                 masks.append((rm.to(torch.uint8), tm))
             tm_ = mark("optimizer_setup_and_render_range", tm_)
@@ -501,11 +541,10 @@ def reference_schedule_leg(cam, N, dev, cycles=3, iters=50, every=6, window=5, n
                 j = len(state["win"]) - 1 if it > iters / 2 else int(rng.randint(0, len(state["win"])))
                 rs_w, col_w, dep_w, _ = state["win"][j]
                 opt.step_slam(rs_w, col_w, dep_w, masks[j][1], render_mask=masks[j][0])
-            state["params"] = opt.params
             state["iters"] += iters
             tm_ = mark("map_iterations", tm_)
         with torch.no_grad():                                                  # model depth / normals for the next track
-            out = renderer.render(view, mo.activate_packed(state["params"]))
+            out = renderer.render(view, opt.gaussian_data())
         tracker.update_last_status(None, out["depth"].permute(1, 2, 0).contiguous(), fm["depth_map"],
                                    out["normal"].permute(1, 2, 0).contiguous(), normal_w)
         mark("model_render_for_tracker", tm_)
@@ -522,12 +561,13 @@ def reference_schedule_leg(cam, N, dev, cycles=3, iters=50, every=6, window=5, n
     nf = n_frames - every
     if prof is not None:
         print("schedule leg, ms per frame by stage (with syncs):",
-              {k: round(1e3 * v / n_frames, 3) for k, v in prof.items()}, file=sys.stderr)
+              {k: round(1e3 * v / nf, 3) for k, v in prof.items()}, file=sys.stderr)
     err = float((state["c2w"][:3, 3] - poses[-1][:3, 3]).norm())
     from rtg_slam_amd.rasterizer import current_context
     return {"frames_per_sec": round(nf / dt, 2), "speculation": current_context().speculation_stats(), "ms_per_frame": round(1e3 * dt / nf, 3), "frames": nf,
             "map_iterations": state["iters"] - it0, "iterations_per_frame": round((state["iters"] - it0) / nf, 2),
-            "gaussians": N, "image": [cam.H, cam.W], "new_gaussians_per_frame_built": n_new, "window": window,
+            "gaussians_start": N, "gaussians_end": int(opt.N), "image": [cam.H, cam.W], "gaussians_appended": int(state.get("added", 0)), "uniform_sample_num": n_new,
+            "window": window,
             "final_translation_error_m": round(err, 5),
             "what": "reference Replica schedule (replica_base.yaml: gaussian_update_frame 6, gaussian_update_iter 50, "
                     "memory_length 5, uniform_sample_num 40800), sequential single stream, 1.2 M surface map"}

@@ -291,20 +291,29 @@ class ShardedMapOptimizer:
         if self._slam_ws is not None:
             self._slam_ws["radii"] = torch.empty(rows, dtype=torch.int32, device=dev)
 
-    def _shape_changed(self):
-        """After rows were added / removed / permuted: gradient rows and states refer to other Gaussians, the Adam moments
-        belong to other rows.  Everything derived is dropped; `begin_local_optimization()` starts the next optimisation
-        (the reference creates a new Adam for every local optimisation anyway, mapper.py:156)."""
+    def _shape_changed(self, permuted: bool):
+        """After rows were added / removed / permuted.  Appending keeps every existing row where it was: gradient rows,
+        row states and Adam moments of the old rows stay valid and the new rows' are zero (never used since the last
+        clear) - nothing is touched, the append stays O(new rows).  After a permutation they belong to other Gaussians:
+        they are zeroed - lazily, by the next begin_local_optimization() / step (the reference creates a new Adam for
+        every local optimisation anyway, mapper.py:156)."""
         if self.grad_rows is not None:
-            self.grad_rows.resize(self.N)
+            self.grad_rows.resize(self.N, clear=False)
             self.grad_rows.train = (self.n_frozen, self.N)
-        for holder in (self.state, self._slam_state or {}):
-            for n in holder:
-                for k in ("m", "v", "ever"):
-                    holder[n][k].zero_()
-        self.attach_init = None
-        self.step_count = 0
+        self._stale = getattr(self, "_stale", False) or permuted
+        self.attach_init = None            # the snapshot no longer covers the trainable rows: begin_local_optimization()
         self._pending = None
+
+    def _clean(self):
+        if getattr(self, "_stale", False):
+            if self.grad_rows is not None:
+                self.grad_rows.clear()
+            for holder in (self.state, self._slam_state or {}):
+                for n in holder:
+                    for k in ("m", "v", "ever"):
+                        holder[n][k].zero_()
+            self.step_count = 0
+            self._stale = False
 
     @property
     def params(self) -> torch.Tensor:
@@ -361,10 +370,8 @@ class ShardedMapOptimizer:
         for name, c0, c1 in BLOCKS:
             self.state[name]["p"][r0:r0 + n] = packed_new[:, c0:c1]
         self.N += n
-        was_valid = self._act_valid
-        self._shape_changed()
-        if self.act is not None and was_valid:
-            self._act_valid = True
+        self._shape_changed(permuted=False)
+        if self.act is not None and self._act_valid:
             self._activate_rows(r0, self.N, force=True)        # only the new rows
 
     def _permute(self, keep_idx: torch.Tensor, n_frozen: int):
@@ -375,7 +382,7 @@ class ShardedMapOptimizer:
             pfull[n:self.N].zero_()
         self.N, self.n_frozen = n, int(n_frozen)
         self._act_valid = False
-        self._shape_changed()
+        self._shape_changed(permuted=True)
 
     def remove_rows(self, mask: torch.Tensor):
         """Delete the rows where `mask` [N] is set (GaussianPointCloud.delete / remove, gaussian_pointcloud.py:195-235;
@@ -409,6 +416,7 @@ class ShardedMapOptimizer:
         local / global optimisation (mapper.py:156: a new torch.optim.Adam per call) - in place: nothing is allocated
         once the buffers exist.  Covers the trainable rows."""
         self.flush()
+        self._clean()
         N, nf, st = self.N, self.n_frozen, self.state
         rows = st["xyz"]["p"].shape[0]
         buf = getattr(self, "_attach_buf", None)
@@ -459,6 +467,7 @@ class ShardedMapOptimizer:
         the next call); the rendered images of the step are in `self.last_render`."""
         from . import _lib
         from .rasterizer import GaussianRasterizer, _Keep, current_context
+        self._clean()
         if self.grad_rows is None:
             rast = GaussianRasterizer(raster_settings)
 
@@ -735,6 +744,7 @@ class ShardedMapOptimizer:
         """loss_fn(gaussian_data) -> scalar loss of THIS rank's view.  Gradients are summed over
         ranks (the sum of per-view losses is what a single GPU looping over the views optimises).  Only the trainable
         rows [n_frozen, N) are reduced, stepped and gathered; the row shards partition that range."""
+        self._clean()
         N, nf = self.N, self.n_frozen
         per, span = self.per, self.per * self.world        # rows of one shard / of all shards (>= n_train: padded)
         self._act_valid = False            # raw8 moves without step_slam's tail: its activated copies go stale

@@ -209,12 +209,15 @@ class RowGradArena:
             setattr(self, k, t[:P])                       # same storage, row 0 at the same address
         self.row_state = self._state_full[:max(P, 1)]
 
-    def resize(self, P: int):
-        """Use `P` rows of the allocation from now on.  The rows are zeroed (states too): their ids mean other Gaussians."""
+    def resize(self, P: int, clear: bool = True):
+        """Use `P` rows of the allocation from now on.  clear=True zeroes rows and states (after a permutation the ids
+        mean other Gaussians); clear=False keeps them - rows appended behind the old ones are zero already (the arena's
+        invariant: a row whose state is not 1 is all-zero, and rows beyond P were never handed out since the last clear)."""
         if P > self.capacity:
             raise ValueError("RowGradArena.resize beyond the allocated capacity")
         self.P = int(P)
-        self.clear()
+        if clear:
+            self.clear()
         self._views()
 
     def clear(self):

@@ -67,7 +67,7 @@ def _emulate_rccl_collectives():
     dist.all_gather_into_tensor = all_gather_into_tensor
 
 
-def _worker(rank, world, port, ret, rccl_branch=False):
+def _worker(rank, world, port, ret, rccl_branch=False, n_frozen=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -75,11 +75,11 @@ def _worker(rank, world, port, ret, rccl_branch=False):
     from rtg_slam_amd import map_optim as mo
     from tests.dist_util import adam_reference
     packed, views, gts = _scene()
-    opt = mo.ShardedMapOptimizer(packed, adam_fn=adam_reference, activate_fn=td.activate8)
+    opt = mo.ShardedMapOptimizer(packed, adam_fn=adam_reference, activate_fn=td.activate8, n_frozen=n_frozen)
     if rccl_branch:
         _emulate_rccl_collectives()
         opt.backend = "nccl"
-    assert opt.world == 2 and opt.per == 51 and opt.Npad == 102
+    assert opt.world == 2 and opt.per == (101 - n_frozen + 1) // 2 and opt.Npad == n_frozen + 2 * opt.per
     for _ in range(2):
         opt.step(_loss_fn(views[rank], gts[rank]))
     ret[rank] = opt.params.clone()
@@ -90,14 +90,16 @@ def _worker(rank, world, port, ret, rccl_branch=False):
 import pytest
 
 
-@pytest.mark.parametrize("rccl_branch", [False, True])
-def test_sharded_step_matches_single_process(rccl_branch):
+@pytest.mark.parametrize("rccl_branch,n_frozen", [(False, 0), (True, 0), (False, 30), (True, 31)])
+def test_sharded_step_matches_single_process(rccl_branch, n_frozen):
+    """n_frozen > 0: the first rows are rendered but are no parameters (the stable part of an RTG-SLAM map,
+    mapper.py:1026-1108) - the shards partition the trainable rows only, the frozen rows stay bitwise untouched."""
     from rtg_slam_amd import map_optim as mo
     from tests.dist_util import adam_reference
-    port = 29600 + (os.getpid() % 300) + (7 if rccl_branch else 0)
+    port = 29600 + (os.getpid() % 300) + (7 if rccl_branch else 0) + n_frozen
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, ret, rccl_branch), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, ret, rccl_branch, n_frozen), nprocs=2, join=True)
     p0, p1 = ret[0], ret[1]
     assert torch.equal(p0, p1), "all ranks hold the same gathered parameters"
     # single-process reference: sum of both views' gradients, Adam on all rows
@@ -109,7 +111,8 @@ def test_sharded_step_matches_single_process(rccl_branch):
         leaf = p.detach().clone().requires_grad_(True)
         loss = _loss_fn(views[0], gts[0])(td.activate(leaf)) + _loss_fn(views[1], gts[1])(td.activate(leaf))
         (g,) = torch.autograd.grad(loss, leaf)
-        adam_reference(p, g, m, v, lr, step, 1e-15)
+        adam_reference(p[n_frozen:], g[n_frozen:], m[n_frozen:], v[n_frozen:], lr, step, 1e-15)
+    assert torch.equal(p0[:n_frozen], packed[:n_frozen])
     assert float((p0 - p).abs().max()) < 1e-5
     assert float((p0 - packed).abs().max()) > 1e-4, "the step moved the parameters"
 

@@ -68,7 +68,7 @@ def run(cam, n_frames=8, iters_per_frame=10, first_frame_iters=30, samples_first
     K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32, device=dev)
     tracker, renderer = IcpTracker(ARGS), Renderer(ARGS)
     gen = torch.Generator(device=dev).manual_seed(seed)
-    packed, opt = None, None
+    opt = None                                              # ONE optimiser for the run: the map grows inside it
     pose_es, stats = [], []
     for fid in range(n_frames):
         depth = synth.box_room_depth(cam, poses_gt[fid])
@@ -90,27 +90,28 @@ def run(cam, n_frames=8, iters_per_frame=10, first_frame_iters=30, samples_first
         normal_w = fm["normal_map_c"] @ Rw.t()
         view = _camera(cam, c2w, dev)
         # ---- mapping: cover what the map does not explain yet, then optimise on this frame
-        if packed is None:
+        if opt is None:
             sel, n_new = None, samples_first
         else:
             with torch.no_grad():
-                out = renderer.render(view, mo.activate_packed(packed))
+                out = renderer.render(view, opt.gaussian_data())                 # zero-copy views of the optimiser's arrays
             seen, _, _ = slam_ops.render_range(out["T_map"], 0.5)                 # T_map != 1
             sel = (seen == 0) | ((out["depth"][0] - fm["depth_map"][..., 0]).abs() > 0.05)
             n_new = samples_new
         pts, nrm, col = slam_ops.sample_pixels(vertex_w, normal_w, color.permute(1, 2, 0).contiguous(), n_new, sel, gen)
         if pts.shape[0] >= 4:
             new = mo.pack_from_activated(gaussians_from_pixels(pts, nrm, col))
-            packed = new if packed is None else torch.cat([packed, new], 0)
-        opt = mo.ShardedMapOptimizer(packed)
-        opt.begin_local_optimization()
+            if opt is None:
+                opt = mo.ShardedMapOptimizer(new, capacity=int(1.5 * new.shape[0]) + n_frames * samples_new)
+            else:
+                opt.append_rows(new)                                              # gaussians_add: O(new rows), no re-allocation
+        opt.begin_local_optimization()                                            # fresh Adam state, in place (mapper.py:156)
         rs = renderer_settings(renderer, view, dev)
         gt_depth = fm["depth_map"].permute(2, 0, 1).contiguous()
         for _ in range(first_frame_iters if fid == 0 else iters_per_frame):
             opt.step_slam(rs, color, gt_depth, None)
-        packed = opt.params
         with torch.no_grad():
-            out = renderer.render(view, mo.activate_packed(packed))
+            out = renderer.render(view, opt.gaussian_data())
         render_depth = out["depth"].permute(1, 2, 0).contiguous()
         tracker.update_last_status(None, render_depth, fm["depth_map"], out["normal"].permute(1, 2, 0).contiguous(), normal_w)
         torch.cuda.synchronize(dev)
@@ -121,7 +122,7 @@ def run(cam, n_frames=8, iters_per_frame=10, first_frame_iters=30, samples_first
         d_l1 = float((out["depth"][0] - fm["depth_map"][..., 0]).abs()[valid & (out["depth"][0] > 0)].mean())
         err_t = float((c2w[:3, 3] - poses_gt[fid][:3, 3]).norm())
         err_r = math.degrees(math.acos(max(-1.0, min(1.0, (float(torch.trace(c2w[:3, :3].t() @ poses_gt[fid][:3, :3])) - 1) / 2))))
-        stats.append(dict(frame=fid, gaussians=int(packed.shape[0]), trans_err_m=err_t, rot_err_deg=err_r, psnr=psnr,
+        stats.append(dict(frame=fid, gaussians=int(opt.N), trans_err_m=err_t, rot_err_deg=err_r, psnr=psnr,
                           depth_l1_m=d_l1, covered=float((out["T_map"][0] != 1).float().mean()), track_ms=1e3 * t_track,
                           frame_ms=1e3 * t_all))
         if log:
