@@ -329,6 +329,19 @@ typedef struct rtgs_attach {
 } rtgs_attach;
 int rtgs_attach_prepare(const float* xyz, const float* raw8, const rtgs_attach* attach, int64_t rows, void* stream);
 
+/* Mapping.history_merge (mapper.py:212-251, called at the end of every local_optimize :205-210): the optimised rows are
+ * blended with the snapshot taken when the optimisation began, weighted by how much confidence a row had then,
+ *   w[r]      = max_weight * conf_then[r] / (conf_now[r] + 1e-6)                       (history_merge_max_weight 0.5)
+ *   xyz[r]    = xyz_then[r] w[r] + (1 - w[r]) xyz[r]
+ *   shs[r], raw scaling[r] = then w[0] + (1 - w[0]) now      - the reference indexes history_weight[0]: the weight of
+ *                                                               ROW 0 scales the features and the scaling of every row
+ *   rotation[r] = slerp(normalize(rot_then[r]), normalize(rot[r]), 1 - w[r])  (SLAM/utils.py:593-651: lerp where
+ *                 |dot| > 0.9995 or NaN), stored as the raw rotation;  opacity is left alone.
+ * rows = the rows the snapshot covers (the trainable range); every pointer starts at its first row.  max_weight <= 0: no-op. */
+int rtgs_history_merge(float* xyz, float* shs, float* raw8, const float* then_xyz, const float* then_shs,
+                       const float* then_raw8, const float* conf_then, const float* conf_now, int64_t rows,
+                       float max_weight, void* stream);
+
 /* rtgs_map_activate8_backward_rows followed by rtgs_fused_adam_rows on xyz[rows,3], shs[rows,48] and raw8[rows,8], as
  * ONE launch (the tail of rtgs_slam_map_step).  g_* are the persistent gradient rows of rtgs_raster_backward_rows,
  * row_state its state bytes; g_raw8 is written for state 1 (value) and state 2 (zero) rows.

@@ -220,3 +220,33 @@ def attach_loss(opacity_act, scaling, xyz, rotation, init_scaling, init_xyz, ini
         return xyz.new_zeros(())
     l2 = lambda a, b: ((a - b) ** 2).mean()
     return 1000 * (l2(scaling[m], init_scaling[m]) + l2(xyz[m], init_xyz[m]) + l2(rotation[m], init_rotation[m]))
+
+
+def slerp(v0: torch.Tensor, v1: torch.Tensor, t: torch.Tensor, dot_threshold: float = 0.9995) -> torch.Tensor:
+    """SLAM/utils.py:593-651 for v0, v1 [N,4] and t [N,1]: spherical interpolation, linear where the (re-normalised)
+    vectors are colinear (|dot| > 0.9995) or the dot product is NaN."""
+    a = v0 / torch.norm(v0, dim=-1, keepdim=True)
+    b = v1 / torch.norm(v1, dim=-1, keepdim=True)
+    dot = (a * b).sum(-1)
+    lerp = dot.abs().isnan() | (dot.abs() > dot_threshold)
+    th0 = dot.arccos().unsqueeze(-1)
+    tht = th0 * t
+    sl = (th0 - tht).sin() / th0.sin() * v0 + tht.sin() / th0.sin() * v1
+    return torch.where(lerp.unsqueeze(-1), torch.lerp(v0, v1, t), sl)
+
+
+def history_merge(xyz, shs, raw8, then_xyz, then_shs, then_raw8, conf_then, conf_now, max_weight: float = 0.5):
+    """Mapping.history_merge (mapper.py:212-251) on the block-SoA map: xyz [N,3], shs [N,48], raw8 [N,8] = opacity |
+    scaling | rotation (raw), confidences [N,1].  Returns the merged (xyz, shs, raw8).  Faithful to the reference's
+    `history_weight[0]`: features and scaling of EVERY row are blended with the weight of row 0; xyz and the rotation
+    use the row's own weight; the opacity is not merged; the rotation is slerp(get_rotation then, get_rotation now,
+    1 - w) with get_rotation = F.normalize (gaussian_pointcloud.py:19, 519-521)."""
+    if max_weight <= 0:
+        return xyz, shs, raw8
+    w = max_weight * conf_then / (conf_now + 1e-6)                     # [N,1]
+    out_xyz = then_xyz * w + (1 - w) * xyz
+    out_shs = then_shs * w[0] + (1 - w[0]) * shs
+    out_raw8 = raw8.clone()
+    out_raw8[:, 1:4] = then_raw8[:, 1:4] * w[0] + (1 - w[0]) * raw8[:, 1:4]
+    out_raw8[:, 4:8] = slerp(F.normalize(then_raw8[:, 4:8]), F.normalize(raw8[:, 4:8]), 1 - w)
+    return out_xyz, out_shs, out_raw8

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "rtgs_map_tail_rows": (C.c_int, [_P] * 23 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float,
                                      C.POINTER(AttachC), _P, _P, C.POINTER(ActivatedC), _P]),
     "rtgs_attach_prepare": (C.c_int, [_P, _P, C.POINTER(AttachC), C.c_int64, _P]),
+    "rtgs_history_merge": (C.c_int, [_P] * 8 + [C.c_int64, C.c_float, _P]),
     "rtgs_slam_loss_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rtgs_slam_map_step_front": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_rows_pack": (C.c_int, [_P, C.c_int32] + [_P] * 7 + [C.c_int32, _P, _P]),

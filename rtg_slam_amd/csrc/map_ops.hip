@@ -328,6 +328,81 @@ __global__ void attach_finish_kernel(const float* __restrict__ sums4, float* __r
 }
 }  // namespace rtgs
 
+// ---------------------------------------------------------------------------------------------
+// Mapping.history_merge (mapper.py:212-251).  One lane per row for xyz / scaling / rotation, then the wave's rows 12 lanes
+// x float4 each for the 48 SH columns (as the Adam tail moves them).
+// ---------------------------------------------------------------------------------------------
+namespace rtgs {
+__global__ void __launch_bounds__(256) history_merge_kernel(float* __restrict__ xyz, float4* __restrict__ shs, float4* __restrict__ raw8,
+                                                            const float* __restrict__ t_xyz, const float4* __restrict__ t_shs,
+                                                            const float4* __restrict__ t_raw8, const float* __restrict__ c_then,
+                                                            const float* __restrict__ c_now, long long rows, float max_weight) {
+  const float w0 = max_weight * c_then[0] / (c_now[0] + 1e-6f);          // history_weight[0]: the reference's indexing
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long base = wave0 * 64; base < rows; base += nwaves * 64) {
+    const long long r = base + lane;
+    if (r < rows) {
+      const float w = max_weight * c_then[r] / (c_now[r] + 1e-6f);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xyz[r * 3 + c] = t_xyz[r * 3 + c] * w + (1.f - w) * xyz[r * 3 + c];
+      float4 lo = raw8[2 * r], hi = raw8[2 * r + 1];
+      const float4 tlo = t_raw8[2 * r], thi = t_raw8[2 * r + 1];
+      lo.y = tlo.y * w0 + (1.f - w0) * lo.y; lo.z = tlo.z * w0 + (1.f - w0) * lo.z; lo.w = tlo.w * w0 + (1.f - w0) * lo.w;
+      // slerp(v0 = get_rotation then, v1 = get_rotation now, t = 1 - w), both normalised (F.normalize: / max(|q|, 1e-12))
+      const float n0 = fmaxf(sqrtf(thi.x * thi.x + thi.y * thi.y + thi.z * thi.z + thi.w * thi.w), 1e-12f);
+      const float n1 = fmaxf(sqrtf(hi.x * hi.x + hi.y * hi.y + hi.z * hi.z + hi.w * hi.w), 1e-12f);
+      const float v0[4] = {thi.x / n0, thi.y / n0, thi.z / n0, thi.w / n0}, v1[4] = {hi.x / n1, hi.y / n1, hi.z / n1, hi.w / n1};
+      // slerp normalises its inputs again (utils.py:608-612) before the dot product
+      const float m0 = sqrtf(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3]);
+      const float m1 = sqrtf(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2] + v1[3] * v1[3]);
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dot += (v0[c] / m0) * (v1[c] / m1);
+      const float t = 1.f - w;
+      float o[4];
+      if (!(fabsf(dot) <= 0.9995f)) {                                    // colinear (or NaN): torch.lerp(v0, v1, t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = v0[c] + t * (v1[c] - v0[c]);
+      } else {
+        const float th0 = acosf(dot), s0n = sinf(th0), tht = th0 * t;
+        const float s0 = sinf(th0 - tht) / s0n, s1 = sinf(tht) / s0n;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = s0 * v0[c] + s1 * v1[c];
+      }
+      raw8[2 * r] = lo;
+      raw8[2 * r + 1] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    // SH: 64 rows x 12 float4, five rows per sweep
+    const long long nrow = rows - base < 64 ? rows - base : 64;
+    const int slot = lane / 12, sub = lane - slot * 12;
+    for (long long k0 = 0; k0 < nrow; k0 += 5) {
+      const long long k = k0 + slot;
+      if (slot < 5 && k < nrow) {
+        const size_t o = (size_t)(base + k) * 12 + sub;
+        const float4 a = t_shs[o], b = shs[o];
+        shs[o] = make_float4(a.x * w0 + (1.f - w0) * b.x, a.y * w0 + (1.f - w0) * b.y, a.z * w0 + (1.f - w0) * b.z,
+                             a.w * w0 + (1.f - w0) * b.w);
+      }
+    }
+  }
+}
+}  // namespace rtgs
+
+extern "C" int rtgs_history_merge(float* xyz, float* shs, float* raw8, const float* then_xyz, const float* then_shs,
+                                  const float* then_raw8, const float* conf_then, const float* conf_now, int64_t rows,
+                                  float max_weight, void* stream) {
+  if (rows < 0) return -1;
+  if (rows == 0 || !(max_weight > 0.f)) return 0;
+  if (!xyz || !shs || !raw8 || !then_xyz || !then_shs || !then_raw8 || !conf_then || !conf_now) return -1;
+  long long blocks = (rows + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rtgs::history_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xyz, (float4*)shs,
+                     (float4*)raw8, then_xyz, (const float4*)then_shs, (const float4*)then_raw8, conf_then, conf_now,
+                     (long long)rows, max_weight);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // attach->attach_info must point at 6 floats: [0] n_selected, [1] loss, [2..5] scratch sums
 extern "C" int rtgs_attach_prepare(const float* xyz, const float* raw8, const rtgs_attach* attach, int64_t rows, void* stream) {
   if (!attach || !attach->init_xyz || !attach->init_raw8 || !attach->attach_info || rows < 0) return -1;

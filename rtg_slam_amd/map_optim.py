@@ -231,6 +231,7 @@ class ShardedMapOptimizer:
         self.last_render = None
         self.last_num_rendered = 0
         self.attach_init = None        # begin_local_optimization(): snapshot for the attach regulariser
+        self._history = None           # ... and, with a confidence array, for history_merge()
         self._row_capacity = 16384     # world > 1: rows per rank in the sparse gradient exchange (grows on overflow)
         self._pending = None           # world > 1: the last exchange, until its overflow flag has been looked at
         self.overflow_redos = 0
@@ -302,6 +303,7 @@ class ShardedMapOptimizer:
             self.grad_rows.train = (self.n_frozen, self.N)
         self._stale = getattr(self, "_stale", False) or permuted
         self.attach_init = None            # the snapshot no longer covers the trainable rows: begin_local_optimization()
+        self._history = None
         self._pending = None
 
     def _clean(self):
@@ -410,8 +412,9 @@ class ShardedMapOptimizer:
             self.adam_fn(shard, gs, st["m"][:n], st["v"][:n], st["lr"], self.step_count, self.eps)
 
     # ------------------------------------------------------------------ one-call SLAM step (single GPU)
-    def begin_local_optimization(self):
-        """Snapshot the raw parameters the attach regulariser ties low-opacity Gaussians to (`history_stat` /
+    def begin_local_optimization(self, confidence: Optional[torch.Tensor] = None):
+        """(`confidence` float[n_train], optional: also snapshot the SH block and the confidences, for `history_merge`.)
+        Snapshot the raw parameters the attach regulariser ties low-opacity Gaussians to (`history_stat` /
         `init_stat` of mapper.py:147-153, 660-666) and reset the Adam state, as the reference does for every
         local / global optimisation (mapper.py:156: a new torch.optim.Adam per call) - in place: nothing is allocated
         once the buffers exist.  Covers the trainable rows."""
@@ -427,6 +430,14 @@ class ShardedMapOptimizer:
         buf["xyz"][:N - nf].copy_(st["xyz"]["p"][nf:N])
         buf["raw8"][:N - nf].copy_(st["raw8"]["p"][nf:N])
         self.attach_init = dict(xyz=buf["xyz"][:N - nf], raw8=buf["raw8"][:N - nf], info=buf["info"])
+        self._history = None
+        if confidence is not None:
+            if buf.get("shs") is None or buf["shs"].shape[0] < rows:
+                buf["shs"] = torch.empty(rows, 48, dtype=torch.float32, device=self.device)
+                buf["conf"] = torch.empty(rows, dtype=torch.float32, device=self.device)
+            buf["shs"][:N - nf].copy_(st["shs"]["p"][nf:N])
+            buf["conf"][:N - nf].copy_(confidence.reshape(-1))
+            self._history = dict(shs=buf["shs"][:N - nf], conf=buf["conf"][:N - nf])
         for holder in (self.state, self._slam_state or {}):
             for n in holder:
                 for k in ("m", "v", "ever"):
@@ -434,6 +445,30 @@ class ShardedMapOptimizer:
         self.step_count = 0
         if st["xyz"]["p"].is_cuda:
             self.attach_loss()                 # counts the selected rows once: the selection is fixed by the snapshot
+
+    def history_merge(self, confidence: torch.Tensor, max_weight: float = 0.5):
+        """Mapping.history_merge (mapper.py:212-251; history_merge_max_weight 0.5, configs/base.yaml:54), called by the
+        reference when the iterations of a local optimisation are done: the trainable rows are blended with the snapshot
+        `begin_local_optimization(confidence=...)` took, weighted by max_weight * confidence_then / (confidence_now + 1e-6)
+        (rtgs_history_merge; the reference's `history_weight[0]` indexing is kept).  `confidence` float[n_train] = now."""
+        from . import _lib
+        if self._history is None or self.attach_init is None:
+            raise RuntimeError("history_merge() needs begin_local_optimization(confidence=...) on the current rows")
+        if max_weight <= 0:
+            return
+        self.flush()
+        lib = _lib.load()
+        N, nf, st, ai, h = self.N, self.n_frozen, self.state, self.attach_init, self._history
+        V = lambda t: C.c_void_p(t.data_ptr())
+        O = lambda t, c: C.c_void_p(t.data_ptr() + 4 * c * nf)
+        conf = confidence.reshape(-1).contiguous().float()
+        dev = self.device
+        with torch.cuda.device(dev):
+            rc = lib.rtgs_history_merge(O(st["xyz"]["p"], 3), O(st["shs"]["p"], 48), O(st["raw8"]["p"], 8), V(ai["xyz"]), V(h["shs"]),
+                                        V(ai["raw8"]), V(h["conf"]), V(conf), N - nf, float(max_weight),
+                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(rc, "rtgs_history_merge")
+        self._act_valid = False            # scaling and rotation moved outside the step's tail
 
     def attach_loss(self) -> torch.Tensor:
         """Value of the attach regulariser at the current parameters (mapper.py:384-401; `scale_loss` of the

@@ -127,3 +127,38 @@ def test_product_torch_loss_equals_the_oracle_restatement():
         a = td.slam_losses(render, gt_c, gt_d, render_mask=rm)
         b, _ = so.slam_loss(render, gt_c, gt_d, render_mask=rm)
         assert abs(float(a) - float(b)) < 1e-6
+
+
+def test_history_merge_oracle_equals_the_reference_method():
+    """oracle.slam_ops_oracle.history_merge against the REFERENCE's own Mapping.history_merge (mapper.py:212-251, run here
+    on a stand-in `self` carrying exactly the attributes the method reads) - including its `history_weight[0]` indexing
+    and its slerp (SLAM/utils.py:593-651) with rotations on both sides of the colinearity threshold."""
+    from types import SimpleNamespace
+    from oracle import ref_shim, slam_ops_oracle as so
+    if not ref_shim.available():
+        pytest.skip("needs /root/reference (build container)")
+    mp = ref_shim.load("SLAM.multiprocess.mapper")
+    gen = torch.Generator().manual_seed(4)
+    N = 500
+    F = torch.nn.functional
+    then = dict(xyz=torch.randn(N, 3, generator=gen), shs=torch.randn(N, 48, generator=gen), raw8=torch.randn(N, 8, generator=gen))
+    now = {k: v + 0.05 * torch.randn(v.shape, generator=gen) for k, v in then.items()}
+    now["raw8"][:50, 4:8] = then["raw8"][:50, 4:8] * 1.3          # colinear rotations: the lerp branch
+    now["raw8"][50:100, 4:8] = torch.randn(50, 4, generator=gen)  # far apart: the slerp branch
+    c_then = torch.randint(0, 40, (N, 1), generator=gen).float()
+    c_now = c_then + torch.randint(0, 51, (N, 1), generator=gen).float()
+    pc = SimpleNamespace(get_confidence=c_now, get_xyz=now["xyz"], _features_dc=now["shs"].view(N, 16, 3)[:, :1].clone(),
+                         _features_rest=now["shs"].view(N, 16, 3)[:, 1:].clone(), _scaling=now["raw8"][:, 1:4].clone(),
+                         get_rotation=F.normalize(now["raw8"][:, 4:8]))
+    me = SimpleNamespace(pointcloud=pc, verbose=False)
+    hist = dict(confidence=c_then, xyz=then["xyz"], features_dc=then["shs"].view(N, 16, 3)[:, :1],
+                features_rest=then["shs"].view(N, 16, 3)[:, 1:], scaling=then["raw8"][:, 1:4],
+                rotation=F.normalize(then["raw8"][:, 4:8]))
+    mp.Mapping.history_merge(me, hist, 0.5)
+    xyz, shs, raw8 = so.history_merge(now["xyz"], now["shs"], now["raw8"], then["xyz"], then["shs"], then["raw8"], c_then, c_now, 0.5)
+    assert torch.allclose(pc._xyz, xyz, atol=1e-6)
+    assert torch.allclose(torch.cat([pc._features_dc, pc._features_rest], 1).reshape(N, 48), shs, atol=1e-6)
+    assert torch.allclose(pc._scaling, raw8[:, 1:4], atol=1e-6)
+    assert torch.allclose(pc._rotation, raw8[:, 4:8], atol=1e-5)
+    assert torch.equal(raw8[:, 0], now["raw8"][:, 0])            # the opacity is not merged
+    assert float((raw8[:, 4:8] - now["raw8"][:, 4:8]).abs().max()) > 1e-3

@@ -154,3 +154,36 @@ def test_append_remove_freeze_keep_the_map_consistent():
     opt.begin_local_optimization()
     opt.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
     check(opt)
+
+
+def test_history_merge_equals_the_oracle_on_the_trainable_rows():
+    """rtgs_history_merge (mapper.py:212-251) through ShardedMapOptimizer.history_merge against the oracle that is pinned to
+    the reference's own method (tests/test_oracle_slam_ops.py): a few iterations move the trainable rows, the merge pulls
+    them back towards the snapshot by their confidence; frozen rows and opacities stay untouched."""
+    from oracle import slam_ops_oracle as so
+    mo, packed, rs, gt_c, gt_d = _setup()
+    nf, N = 4000, packed.shape[0]
+    opt = mo.ShardedMapOptimizer(packed.clone(), n_frozen=nf, lr_col=mo.default_lr_columns() * 5.0)
+    gen = torch.Generator().manual_seed(1)
+    conf = torch.randint(0, 30, (N - nf,), generator=gen).float().to(DEV)
+    conf_then = conf.clone()
+    opt.begin_local_optimization(confidence=conf)
+    rm = torch.ones(CAM.H, CAM.W, dtype=torch.uint8, device=DEV)
+    for _ in range(4):
+        opt.step_slam(rs, gt_c, gt_d, None, render_mask=rm, confidence=conf)
+    assert float((conf - conf_then).sum()) > 0
+    before = opt.params.clone()
+    b = before[nf:].cpu()
+    t = packed[nf:].cpu()
+    xyz, shs, raw8 = so.history_merge(b[:, 0:3], b[:, 3:51], b[:, 51:59], t[:, 0:3], t[:, 3:51], t[:, 51:59],
+                                      conf_then.cpu().reshape(-1, 1), conf.cpu().reshape(-1, 1), 0.5)
+    opt.history_merge(conf, 0.5)
+    after = opt.params
+    assert torch.equal(after[:nf], packed[:nf])
+    a = after[nf:].cpu()
+    assert torch.allclose(a[:, 0:3], xyz, atol=1e-6) and torch.allclose(a[:, 3:51], shs, atol=1e-6)
+    assert torch.allclose(a[:, 51:59], raw8, atol=2e-6)
+    assert float((after - before).abs().max()) > 1e-4
+    gd = opt.gaussian_data()                                   # the activated views follow the merged raw8
+    fresh = mo.activate8_hip(opt.state["raw8"]["p"][:N])
+    assert torch.equal(gd["rotations"], fresh["rotations"]) and torch.equal(gd["scales"], fresh["scales"])
