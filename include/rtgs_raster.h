@@ -205,6 +205,19 @@ int rtgs_raster_backward_range_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* se
                                   float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
                                   float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
                                   void* grad_scratch, uint8_t* row_state, int32_t train_begin, int32_t train_end, void* stream);
+/* ... only its tile WALK (blend_bwd): gradient slots and touched bytes are left for rtgs_map_fused_tail; the dL_d*
+ * tensors and row_state are not written (they may be NULL). */
+int rtgs_raster_backward_walk_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* settings, int32_t P, int32_t sh_coeffs,
+                                  int64_t num_rendered,
+                                  const float* means3D, const float* opacities, const float* shs,
+                                  const float* scales, const float* rotations, const float* normal_w,
+                                  void* geom_buffer, void* binning_buffer,
+                                  const void* image_buffer, const float* out_color, const float* out_T,
+                                  const int32_t* out_depth_index,
+                                  const float* dL_dcolor, const float* dL_ddepth,
+                                  float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
+                                  float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
+                                  void* grad_scratch, uint8_t* row_state, int32_t train_begin, int32_t train_end, void* stream);
 
 /* Sizes the forward will request through the callbacks (for pre-allocation / accounting).  The geometry buffer's size
  * depends on the context's near-slice budget; its layout is such that a backward never needs to know that budget. */
@@ -444,6 +457,14 @@ typedef struct rtgs_map_step_args {
    * state m_* / v_* / ever_*, attach->init_* and confidence cover ONLY those rows: element 0 belongs to row train_begin.
    * Everything else (parameters, activated arrays, gradient rows, row_state) is indexed by the row itself. */
   int32_t train_begin, train_end;
+  /* The per-Gaussian tail.  tail_mode 0 (default): ONE fused kernel over the live rows - slot sums, chain rule,
+   * activation backward, attach gradient, Adam and re-activation with the SplatGrad record and the gradient rows held in
+   * registers (rtgs_map_fused_tail; the arena's gradient rows are then NOT produced: they stay zero, row_state 0) - whenever
+   * the step can take it (rtgs_slam_map_step on its own, normal_weight == 0); 1: always the three-kernel form
+   * (grad_reduce, preprocess_bwd, rtgs_map_tail_rows - what rtgs_slam_map_step_front + the multi-GPU exchange use).
+   * live_counts (nullable, device uint32[2]): += {rows with gradient, rows stepped} of the fused tail. */
+  int32_t tail_mode;
+  uint32_t* live_counts;
 } rtgs_map_step_args;
 /* The normal term on its own: value added to loss4[0], gradient added to d_normal[owner] with the row marked live in
  * row_state (nullable: dense gradients) - a row that carried no gradient is all-zero by the arena's invariant, so marking
@@ -457,6 +478,14 @@ int rtgs_slam_normal_loss_range(const float* normal_w, const int32_t* depth_inde
                                 float* loss_out4, float* d_normal, uint8_t* row_state, const uint32_t* skip_flag,
                                 int32_t train_begin, int32_t train_end, void* stream);
 int rtgs_slam_map_step(const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
+/* The fused tail on its own (after the WALK of a backward, rtgs_raster_backward_walk_ctx): geom_buffer / image_buffer of
+ * that forward, spec_fail = rtgs_raster_spec_fail_ptr_ctx() or NULL. */
+int rtgs_map_fused_tail(const rtgs_raster_settings* settings, const rtgs_map_step_args* args, void* geom_buffer,
+                        const void* image_buffer, const uint32_t* spec_fail, uint32_t* live_counts2, void* stream);
+/* Byte offsets of what a backward's walk leaves for a fused consumer: [0] clamp flags (u8[P], geometry buffer), [1] first
+ * gradient slot per Gaussian (u32[P], geometry), [2] slots taken per Gaussian (u32[P], geometry), [3] BwdInfo (image
+ * buffer), [4] touched bytes (u8[P], inside grad_scratch, behind the P SplatGrad records). */
+int rtgs_raster_backward_buffers(int32_t P, int32_t image_height, int32_t image_width, size_t* out8_host);
 /* The same call without its last stage (rtgs_map_tail_rows): the gradient rows of this rank's view are in the arena,
  * nothing has been stepped.  Multi-GPU callers exchange the rows (below) before they run the tail. */
 int rtgs_slam_map_step_front(const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);

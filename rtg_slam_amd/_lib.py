@@ -78,7 +78,8 @@ class MapStepArgsC(C.Structure):
         + [("attach", C.POINTER(AttachC)), ("confidence", C.c_void_p), ("activated_valid", C.c_int32)]
         + [("geom_resize", RESIZE_FN), ("geom_user", C.c_void_p), ("binning_resize", RESIZE_FN),
            ("binning_user", C.c_void_p), ("image_resize", RESIZE_FN), ("image_user", C.c_void_p)]
-        + [("normal_weight", C.c_float), ("gt_normal", C.c_void_p), ("train_begin", C.c_int32), ("train_end", C.c_int32)])
+        + [("normal_weight", C.c_float), ("gt_normal", C.c_void_p), ("train_begin", C.c_int32), ("train_end", C.c_int32),
+           ("tail_mode", C.c_int32), ("live_counts", C.c_void_p)])
 
 
 _SIGNATURES = {
@@ -105,6 +106,10 @@ _SIGNATURES = {
                                      C.POINTER(AttachC), _P, _P, C.POINTER(ActivatedC), _P]),
     "rtgs_attach_prepare": (C.c_int, [_P, _P, C.POINTER(AttachC), C.c_int64, _P]),
     "rtgs_history_merge": (C.c_int, [_P] * 8 + [C.c_int64, C.c_float, _P]),
+    "rtgs_map_fused_tail": (C.c_int, [C.POINTER(RasterSettingsC), C.POINTER(MapStepArgsC), _P, _P, _P, _P, _P]),
+    "rtgs_raster_backward_buffers": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "rtgs_raster_backward_walk_ctx": (C.c_int, [_P, C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6
+                                      + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P, C.c_int32, C.c_int32, _P]),
     "rtgs_slam_loss_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rtgs_slam_map_step_front": (C.c_int, [C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_rows_pack": (C.c_int, [_P, C.c_int32] + [_P] * 7 + [C.c_int32, _P, _P]),

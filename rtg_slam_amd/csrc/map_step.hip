@@ -7,7 +7,7 @@
 
 // Everything up to and including the rasterizer backward: the gradient rows are in the arena, nothing is stepped yet.
 static int map_step_front(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* num_rendered_host, int32_t fwd_flags,
-                          void* stream) {
+                          void* stream, bool walk_only = false) {
   if (!a || !num_rendered_host || !a->settings) return RTGS_E_INVALID;
   const int32_t P = a->P, M = a->sh_coeffs;
   if (P <= 0 || M != 16 || a->step < 1) return RTGS_E_INVALID;
@@ -35,10 +35,10 @@ static int map_step_front(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* n
   int32_t t0 = 0, t1 = P;                                 // the trainable rows (rtgs_map_step_args: 0, 0 = all)
   if (a->train_end > a->train_begin) { t0 = a->train_begin; t1 = a->train_end; }
   if (t0 < 0 || t1 > P) return RTGS_E_INVALID;
-  rc = rtgs_raster_backward_range_ctx(ctx, a->settings, P, M, *num_rendered_host, a->xyz, a->opacity, a->shs, a->scales,
-                                  a->rotations, a->normal, geom, bin, img, a->out_color, a->out_T, a->out_depth_index,
-                                  a->dL_dcolor, a->dL_ddepth, a->d_xyz, a->d_opacity, a->d_shs, a->d_scales,
-                                  a->d_rotations, a->d_normal, a->grad_scratch, a->row_state, t0, t1, stream);
+  rc = (walk_only ? rtgs_raster_backward_walk_ctx : rtgs_raster_backward_range_ctx)(
+      ctx, a->settings, P, M, *num_rendered_host, a->xyz, a->opacity, a->shs, a->scales, a->rotations, a->normal, geom, bin, img,
+      a->out_color, a->out_T, a->out_depth_index, a->dL_dcolor, a->dL_ddepth, a->d_xyz, a->d_opacity, a->d_shs, a->d_scales,
+      a->d_rotations, a->d_normal, a->grad_scratch, a->row_state, t0, t1, stream);
   if (rc != RTGS_OK) return rc;
   if (a->normal_weight > 0.f && a->gt_normal) {
     // the normal term (mapper.py:433-442): value into loss4[0], gradient into the depth owners' d_normal rows; the two
@@ -64,8 +64,17 @@ extern "C" int rtgs_slam_map_step_front(const rtgs_map_step_args* a, int64_t* nu
 // the whole iteration is enqueued back to back, the tail is guarded by the forward's device word, and the totals are
 // verified at the end - while the GPU is still busy with the backward.
 static int map_step_once(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* num_rendered_host, bool speculate, void* stream) {
-  int rc = map_step_front(ctx, a, num_rendered_host, speculate ? RTGS_FWD_SPECULATE : 0, stream);
+  // one fused kernel for everything per-Gaussian behind the tile walk, unless the caller asks for the three-kernel form or
+  // the normal term (which adds to the arena's d_normal rows) is on
+  const bool fused = a->tail_mode == 0 && !(a->normal_weight > 0.f && a->gt_normal);
+  int rc = map_step_front(ctx, a, num_rendered_host, speculate ? RTGS_FWD_SPECULATE : 0, stream, fused);
   if (rc != RTGS_OK) return rc;
+  if (fused) {
+    void* geom = a->geom_resize(a->geom_user, 0);
+    void* img = a->image_resize(a->image_user, 0);
+    if (!geom || !img) return RTGS_E_ALLOC;
+    return rtgs_map_fused_tail(a->settings, a, geom, img, rtgs_raster_spec_fail_ptr_ctx(ctx), a->live_counts, stream);
+  }
   const int32_t P = a->P;
   // activation backward (+ attach gradient) + Adam on the three block tensors (+ confidence increment), one launch;
   // the rows it steps are re-activated, so the next call may skip the full activation pass (activated_valid)

@@ -780,7 +780,8 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
                          const int32_t* out_didx,
                          const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities,
                          float* dL_dshs, float* dL_dscales, float* dL_drotations, float* dL_dnormal_w,
-                         void* grad_scratch, uint8_t* row_state, int32_t train_begin, int32_t train_end, void* stream) {
+                         void* grad_scratch, uint8_t* row_state, int32_t train_begin, int32_t train_end, void* stream,
+                         bool walk_only = false) {
   rtgs_ctx* c = use(ctx);   // NOTE: the geometry buffer is written here (slot counters): it is scratch of the pair
   RasterParams p;
   int rc = make_params(s, P, M, p);
@@ -789,9 +790,9 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
   // the backward of a speculative forward guards itself with that forward's device word (see rtgs_raster_forward_verify)
   if (c->spec.geom == geom_buffer && c->spec.fail_dev) p.spec_fail = c->spec.fail_dev;
   if (!means3D || !opacities || !shs || !scales || !rotations || !normal_w || !geom_buffer || !binning_buffer ||
-      !image_buffer || !out_color || !out_T || !out_didx || !dL_dcolor || !dL_ddepth || !dL_dmeans3D || !dL_dopacities || !dL_dshs ||
-      !dL_dscales || !dL_drotations || !dL_dnormal_w || !grad_scratch || R < 0)
+      !image_buffer || !out_color || !out_T || !out_didx || !dL_dcolor || !dL_ddepth || !grad_scratch || R < 0)
     return RTGS_E_INVALID;
+  if (!walk_only && (!dL_dmeans3D || !dL_dopacities || !dL_dshs || !dL_dscales || !dL_drotations || !dL_dnormal_w)) return RTGS_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = p.gx * p.gy;
   const GeomLayout G = geom_layout(P, p.gx, p.gy, 1);   // only budget-independent offsets are read here
@@ -838,10 +839,11 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
     }
     prof_mark(c, EV_BWALK, st);
     // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
-    launch_grad_reduce(P, touched, gbase, slot_count, binfo, grads, p.spec_fail, st);
+    if (!walk_only) launch_grad_reduce(P, touched, gbase, slot_count, binfo, grads, p.spec_fail, st);
     DBG(s, st);
   }
   prof_mark(c, EV_BBLEND, st);
+  if (walk_only) { prof_mark(c, EV_BPRE, st); HIP_TRY(hipGetLastError()); return RTGS_OK; }   // a fused consumer takes over
   launch_preprocess_bwd(p, means3D, opacities, shs, scales, rotations, normal_w, radii,
                         (const uint8_t*)(geom + G.clamped), grads, touched, row_state, dL_dmeans3D, dL_dopacities,
                         dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, st);
@@ -889,6 +891,19 @@ int rtgs_raster_backward_range_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s,
   return backward_impl(ctx, s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer, binning_buffer,
                        image_buffer, out_color, out_T, out_didx, dL_dcolor, dL_ddepth, dL_dmeans3D, dL_dopacities,
                        dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, row_state, train_begin, train_end, stream);
+}
+
+int rtgs_raster_backward_walk_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P, int32_t M, int64_t R,
+                                   const float* means3D, const float* opacities, const float* shs, const float* scales,
+                                   const float* rotations, const float* normal_w, void* geom_buffer,
+                                   void* binning_buffer, const void* image_buffer, const float* out_color,
+                                   const float* out_T, const int32_t* out_didx, const float* dL_dcolor,
+                                   const float* dL_ddepth, float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs,
+                                   float* dL_dscales, float* dL_drotations, float* dL_dnormal_w, void* grad_scratch,
+                                   uint8_t* row_state, int32_t train_begin, int32_t train_end, void* stream) {
+  return backward_impl(ctx, s, P, M, R, means3D, opacities, shs, scales, rotations, normal_w, geom_buffer, binning_buffer,
+                       image_buffer, out_color, out_T, out_didx, dL_dcolor, dL_ddepth, dL_dmeans3D, dL_dopacities,
+                       dL_dshs, dL_dscales, dL_drotations, dL_dnormal_w, grad_scratch, row_state, train_begin, train_end, stream, true);
 }
 
 void rtgs_raster_set_profiling_ctx(rtgs_ctx* c, int enable) { use(c)->prof = enable != 0; }
@@ -942,6 +957,15 @@ int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
   return RTGS_OK;
 }
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode >= 1 && mode <= 4) ? mode : 0; }
+int rtgs_raster_backward_buffers(int32_t P, int32_t H, int32_t W, size_t* out) {
+  if (!out || P < 0 || H <= 0 || W <= 0) return RTGS_E_INVALID;
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const GeomLayout G = geom_layout(P, gx, gy, 1);        // budget-independent offsets only
+  const ImgLayout I = img_layout(H, W, gx * gy);
+  out[0] = G.clamped; out[1] = G.offsets; out[2] = G.slot_count; out[3] = I.bwd_info;
+  out[4] = align_up((size_t)(P > 0 ? P : 1) * sizeof(SplatGrad)); out[5] = G.radii; out[6] = 0; out[7] = 0;
+  return RTGS_OK;
+}
 int rtgs_raster_image_offsets(int32_t H, int32_t W, size_t* out) {
   if (!out || H <= 0 || W <= 0) return RTGS_E_INVALID;
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;

@@ -237,6 +237,9 @@ class ShardedMapOptimizer:
         self.overflow_redos = 0
         self._cap_peak, self._cap_steps, self._shrink_every = 0, 0, 32   # ... and shrinks when it stays mostly empty
         self._act_valid = False        # self.act holds the activation of the current raw8 (step_slam's tail re-activates moved rows)
+        # 0: the one-call step's fused per-Gaussian tail; 1: the three-kernel form (A-B, tests; RTGS_TAIL_MODE at construction)
+        self.tail_mode = 1 if __import__("os").environ.get("RTGS_TAIL_MODE", "0") == "1" else 0
+        self.live_counts = torch.zeros(2, dtype=torch.int32, device=self.device) if packed.is_cuda else None   # fused tail: += {rows with gradient, rows stepped}
         self._mode = None              # world > 1: "sharded" (step) or "replicated" (step_slam); they keep different state
 
     # ------------------------------------------------------------------ storage
@@ -579,7 +582,7 @@ class ShardedMapOptimizer:
             C.pointer(attach) if attach is not None else None, P(confidence) if confidence is not None else None,
             int(self._act_valid), geom.cb, None, binning.cb, None, img.cb, None,
             float(normal_weight) if gt_normal is not None else 0.0, P(gt_normal) if gt_normal is not None else None,
-            int(nf), int(N))
+            int(nf), int(N), int(self.tail_mode), P(self.live_counts) if self.live_counts is not None else None)
         R = C.c_int64(0)
         stream = torch.cuda.current_stream(dev).cuda_stream
         if tile_band and self.world > 1:

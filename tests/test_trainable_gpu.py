@@ -187,3 +187,46 @@ def test_history_merge_equals_the_oracle_on_the_trainable_rows():
     gd = opt.gaussian_data()                                   # the activated views follow the merged raw8
     fresh = mo.activate8_hip(opt.state["raw8"]["p"][:N])
     assert torch.equal(gd["rotations"], fresh["rotations"]) and torch.equal(gd["scales"], fresh["scales"])
+
+
+@pytest.mark.parametrize("kind,nf", [("volume", 0), ("surface", 0), ("surface", 9000)])
+def test_fused_tail_equals_the_three_kernel_tail(kind, nf):
+    """rtgs_slam_map_step with its fused per-Gaussian tail (map_fused.hip: slot sums, chain rule, activation backward,
+    attach gradient, Adam, re-activation in ONE kernel, gradient rows never written) against the same step through
+    grad_reduce + preprocess_bwd + rtgs_map_tail_rows (tail_mode 1): same device functions, so the parameters, the Adam
+    moments, the activated arrays and the confidence agree to the rounding of the slot-summation order; the fused form
+    leaves the arena's gradient rows zero."""
+    from rtg_slam_amd import map_optim as mo
+    N = 30000
+    g, s = ru.make_scene(N, CAM, seed=11, pose_seed=2)
+    if kind == "surface":
+        g = synth.surface_gaussians(N, CAM, seed=5)
+        _, s = ru.make_scene(1, CAM, seed=1)
+    packed = mo.pack_from_activated({k: v.to(DEV) for k, v in g.items()})
+    rs = ru.hip_settings(s, DEV)
+    gen = torch.Generator().manual_seed(3)
+    gt_c = torch.rand(3, CAM.H, CAM.W, generator=gen).to(DEV)
+    gt_d = (1.0 + torch.rand(1, CAM.H, CAM.W, generator=gen)).to(DEV)
+    rm = (torch.rand(CAM.H, CAM.W, generator=gen) < 0.9).to(torch.uint8).to(DEV)
+    opts = [mo.ShardedMapOptimizer(packed.clone(), n_frozen=nf), mo.ShardedMapOptimizer(packed.clone(), n_frozen=nf)]
+    opts[1].tail_mode = 1
+    confs = [torch.zeros(N - nf, device=DEV), torch.zeros(N - nf, device=DEV)]
+    for o, c in zip(opts, confs):
+        o.begin_local_optimization()
+        for _ in range(6):
+            o.step_slam(rs, gt_c, gt_d, None, render_mask=rm, confidence=c)
+    pa, pb = opts[0].params.cpu(), opts[1].params.cpu()
+    assert torch.equal(pa[:nf], packed[:nf].cpu())
+    assert float((pa - packed.cpu()).abs().max()) > 1e-4
+    assert ru.frac_bad(pa, pb, 1e-5) < 2e-3, float((pa - pb).abs().max())
+    assert torch.equal(confs[0] > 0, confs[1] > 0) and float((confs[0] - confs[1]).abs().max()) <= 1.0
+    for k in ("opacity", "scales", "rotations", "normal"):      # the fused tail re-activates what it steps
+        fresh = mo.activate8_hip(opts[0].state["raw8"]["p"][:N])
+        assert torch.equal(opts[0].act[k][:N], fresh[k].reshape(opts[0].act[k][:N].shape)), k
+    for name in ("xyz", "shs", "raw8"):
+        assert ru.frac_bad(opts[0].state[name]["m"][:N - nf].cpu(), opts[1].state[name]["m"][:N - nf].cpu(), 1e-5) < 2e-3, name
+    a = opts[0].grad_rows
+    assert float(a.d_shs.abs().sum()) == 0.0 and int(a.row_state.sum()) == 0            # gradient rows never materialised
+    assert int(opts[1].grad_rows.row_state.sum()) > 0
+    lc = opts[0].live_counts.cpu()
+    assert 0 < int(lc[0]) <= int(lc[1]) <= 6 * (N - nf)
