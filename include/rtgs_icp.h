@@ -78,6 +78,8 @@ int rtgs_icp_track(const rtgs_icp_level* levels_host, int32_t n_levels, const fl
                    float distance_threshold, float cos_normal_threshold, float damping,
                    float* pose_inout, float* stats_out, void* scratch, int32_t flags, void* stream);
 #define RTGS_ICP_FLAG_PERSISTENT 1
+#define RTGS_ICP_FLAG_CLUSTER 2     /* every level but the finest in one launch on a cluster of workgroups of ONE XCD (an
+                                       in-XCD barrier per Gauss-Newton iteration), the finest level one launch per iteration */
 
 /* In-place model-depth hole filling (icp.py:397-415): render_depth[H,W] takes frame_depth where
  * |render - frame| > dist_thr, or render == 0, or 1 - cos(render_normal, frame_normal) >

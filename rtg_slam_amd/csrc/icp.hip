@@ -642,6 +642,11 @@ struct TrackArgs {
   uint32_t* ticket;
   uint32_t* abort_flag;
   unsigned long long* dbg;     // nullptr = no timing stamps
+  // Cluster form: only the first `levels_here` levels run in this kernel, on `cluster` workgroups that all sit on ONE XCD
+  // (workgroups are dealt round-robin over the 8 XCDs: of a launch of 8 x cluster workgroups those with
+  // blockIdx % 8 == 0 stay, the rest leave at once) - the barrier's atomics and the coarse maps stay in that XCD's L2
+  // and the other 224 CUs are free for the mapper's stream.  0 = every workgroup of the launch, every level + the p2p loss.
+  int cluster, levels_here;
 };
 
 __device__ __forceinline__ bool grid_arrive_wait(uint32_t* ticket, uint32_t target, uint32_t* abort_flag, float* stats) {
@@ -677,26 +682,31 @@ __global__ void __launch_bounds__(256) icp_track_kernel(TrackArgs a) {
   __shared__ float s_pose[16];
   __shared__ float s_stat[4];
   __shared__ double s_tot[PSTRIDE];
-  const int G = (int)gridDim.x;
+  int G = (int)gridDim.x, bid = (int)blockIdx.x;
+  if (a.cluster > 0) {
+    if ((blockIdx.x & 7u) != 0u) return;       // the other XCDs' workgroups: not part of the cluster
+    G = a.cluster; bid = (int)(blockIdx.x >> 3);
+  }
+  const int n_levels = a.cluster > 0 ? a.levels_here : a.n_levels;
   if (threadIdx.x < 16) s_pose[threadIdx.x] = a.pose[threadIdx.x];
   if (threadIdx.x < 4) s_stat[threadIdx.x] = 0.f;
   __syncthreads();
   uint32_t epoch = 0;
   float acc[NACC];
-  for (int l = 0; l < a.n_levels; ++l) {
+  for (int l = 0; l < n_levels; ++l) {
     const TrackLevel L = a.lv[l];
     const int n = L.H * L.W;
     const float inv = 1.f / ((float)L.H * (float)L.W);
     for (int it = 0; it < L.iters; ++it) {
-      const bool stamp = a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && epoch < 19;
+      const bool stamp = a.dbg && bid == 0 && threadIdx.x == 0 && epoch < 19;
       if (stamp) a.dbg[5 * epoch] = wall_clock64();
       const LevelGeom g = make_geom(s_pose, a.K, L.ds, L.H, L.W, a.dist_thr, a.cos_thr);
 #pragma unroll
       for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
-      accumulate_range(g, L.vs, L.ns, L.vt, L.nt, n, (int)(blockIdx.x * 256 + threadIdx.x), G * 256, acc);
+      accumulate_range(g, L.vs, L.ns, L.vt, L.nt, n, bid * 256 + (int)threadIdx.x, G * 256, acc);
       double* totals = a.sums + (size_t)epoch * 8 * PSTRIDE;
       if (stamp) a.dbg[5 * epoch + 1] = wall_clock64();
-      block_add_totals(acc, totals + (blockIdx.x & 7u) * PSTRIDE);
+      block_add_totals(acc, totals + ((uint32_t)bid & 7u) * PSTRIDE);
       ++epoch;
       if (!grid_arrive_wait(a.ticket, epoch * (uint32_t)G, a.abort_flag, a.stats)) return;
       if (stamp) a.dbg[5 * epoch - 3] = wall_clock64();
@@ -714,6 +724,13 @@ __global__ void __launch_bounds__(256) icp_track_kernel(TrackArgs a) {
       __syncthreads();
     }
   }
+  if (a.cluster > 0) {          // the finest level and the p2p loss follow as launches of their own: hand the pose over
+    if (bid == 0) {
+      if (threadIdx.x < 12) a.pose[threadIdx.x] = s_pose[threadIdx.x];
+      if (threadIdx.x == 0) { a.stats[0] = s_stat[0]; a.stats[2] = s_stat[2]; }
+    }
+    return;
+  }
   // point2plane_loss (icp.py:7-13, :443-447) of the final pose at the finest level, no association
   {
     const TrackLevel F = a.lv[a.n_levels - 1];
@@ -723,7 +740,7 @@ __global__ void __launch_bounds__(256) icp_track_kernel(TrackArgs a) {
     const float R20 = s_pose[8], R21 = s_pose[9], R22 = s_pose[10], t2 = s_pose[11];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
-    for (int idx = (int)(blockIdx.x * 256 + threadIdx.x); idx < n; idx += G * 256) {
+    for (int idx = bid * 256 + (int)threadIdx.x; idx < n; idx += G * 256) {
       const size_t j = (size_t)idx * 3;
       const float v0 = F.vs[j], v1 = F.vs[j + 1], v2 = F.vs[j + 2];
       const float px = (v0 * R00 + v1 * R01 + v2 * R02) + t0;
@@ -733,10 +750,10 @@ __global__ void __launch_bounds__(256) icp_track_kernel(TrackArgs a) {
       acc[0] += lp * lp;
     }
     double* totals = a.sums + (size_t)epoch * 8 * PSTRIDE;
-    block_add_totals(acc, totals + (blockIdx.x & 7u) * PSTRIDE);
+    block_add_totals(acc, totals + ((uint32_t)bid & 7u) * PSTRIDE);
     ++epoch;
     if (!grid_arrive_wait(a.ticket, epoch * (uint32_t)G, a.abort_flag, a.stats)) return;
-    if (blockIdx.x != 0) return;
+    if (bid != 0) return;
     if (threadIdx.x < 12) a.pose[threadIdx.x] = s_pose[threadIdx.x];
     if (threadIdx.x == 0) {
       a.stats[0] = s_stat[0];
@@ -873,7 +890,32 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
     ICP_TRY(hipGetLastError());
     return 0;
   }
-  for (int l = 0; l < n_levels; ++l) {
+  // Cluster form (RTGS_ICP_FLAG_CLUSTER / RTGS_ICP_CLUSTER=1): every level but the finest - 10 of the 15 iterations, 51 k
+  // and 204 k pixels at 1200x680 - in ONE launch on a cluster of workgroups of one XCD, with a barrier inside the XCD per
+  // iteration instead of a kernel boundary, a 50-200-way ticket fan-in and a relaunch; the finest level keeps one launch
+  // per iteration (816 k pixels want the whole chip).
+  static const int env_cluster = [] { const char* e = getenv("RTGS_ICP_CLUSTER"); return e ? atoi(e) : -1; }();
+  const int cluster = env_cluster >= 0 ? env_cluster : ((flags & RTGS_ICP_FLAG_CLUSTER) ? 64 : 0);
+  int first_launched = 0;
+  if (cluster > 0 && n_levels >= 2) {
+    TrackArgs a{};
+    int n_barriers = 0;
+    for (int l = 0; l < n_levels - 1; ++l) {
+      a.lv[l] = TrackLevel{lv[l].vertex_src, lv[l].normal_src, lv[l].vertex_tgt, lv[l].normal_tgt, lv[l].H, lv[l].W,
+                           lv[l].iters, lv[l].downscale};
+      n_barriers += lv[l].iters;
+    }
+    if (n_barriers > 24) return -1;
+    a.n_levels = n_levels; a.K = K; a.dist_thr = dist_thr; a.cos_thr = cos_thr; a.damping = damping;
+    a.pose = pose; a.stats = stats; a.sums = sc->sums; a.ticket = &sc->ticket; a.abort_flag = &sc->pad[0];
+    a.dbg = nullptr;
+    a.cluster = cluster > 64 ? 64 : cluster; a.levels_here = n_levels - 1;
+    ICP_TRY(hipMemsetAsync(sc->sums, 0, (size_t)(n_barriers + 1) * 8 * PSTRIDE * sizeof(double), st));
+    hipLaunchKernelGGL(icp_track_kernel, dim3(8 * a.cluster), dim3(256), 0, st, a);
+    ICP_TRY(hipMemsetAsync(&sc->ticket, 0, sizeof(uint32_t), st));       // the launches below elect their last arriver from 0
+    first_launched = n_levels - 1;
+  }
+  for (int l = first_launched; l < n_levels; ++l) {
     const rtgs_icp_level& L = lv[l];
     // a lane takes FOUR pixels (accumulate_range): one workgroup per 1024 pixels - at the coarse levels that is 50 / 200
     // workgroups instead of 200 / 512 with three lanes in four idle, and as many fewer tickets and partial rows for the
