@@ -10,7 +10,11 @@
 // SplatGrad (long runs: the whole wave sums them first) -> chain rule in registers (raster_chain.h) -> activation
 // backward + attach gradient -> Adam on raw8 and xyz -> re-activation; then the wave sweeps the 48 SH columns of its rows
 // with 12 lanes x float4 per row, forming the SH gradient basis[k] * gc[c] on the fly.  Same device functions as the
-// three kernels it replaces: results are theirs bit for bit (tests/test_raster_gpu.py: step_slam vs step through autograd).
+// three kernels it replaces: results are theirs to the rounding of the slot-summation order (tests/test_trainable_gpu.py).
+// Measured and NOT kept (profiles/r04_fused_tail_variants.txt): one global live-row list built by a light first pass (every
+// wave of the heavy pass full, but the long slot runs of a depth-complex map then queue up inside a few waves: 105 us
+// instead of 55 on the headline scene); a third workgroup per CU at 168 registers with spills (+20 %); the SH block reduced
+// group by group to save registers (the serialised loads cost more than the registers saved).
 // The gradient rows of the arena are NOT produced here (they stay all-zero, row_state 0): multi-GPU steps, which exchange
 // them, and the autograd path keep the three-kernel form.
 #include "../../include/rtgs_raster.h"
@@ -104,15 +108,42 @@ __global__ void __launch_bounds__(256) map_fused_tail_kernel(FusedArgs a) {
           bigm &= bigm - 1ull;
           const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)cnt, src);
           const size_t base = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)b0, src);
-          const int grp = lane >> 4, c = lane & 15;             // 16 lanes per slot, four slots per step
-          float m0 = 0.f, m1 = 0.f;
-          uint32_t s = grp;
-          for (; s + 4 < n; s += 8) { m0 += slots[(base + s) * 16 + c]; m1 += slots[(base + s + 4) * 16 + c]; }
-          if (s < n) m0 += slots[(base + s) * 16 + c];
-          float acc = m0 + m1;
-          acc += __shfl_xor(acc, 16);
-          acc += __shfl_xor(acc, 32);
-          if (lane < 16) s_big[wv][src][c] = acc;
+          if (n <= 48u) {                                       // 16 lanes per slot, four slots per step
+            const int grp = lane >> 4, c = lane & 15;
+            float m0 = 0.f, m1 = 0.f;
+            uint32_t s = grp;
+            for (; s + 4 < n; s += 8) { m0 += slots[(base + s) * 16 + c]; m1 += slots[(base + s + 4) * 16 + c]; }
+            if (s < n) m0 += slots[(base + s) * 16 + c];
+            float acc = m0 + m1;
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            if (lane < 16) s_big[wv][src][c] = acc;
+          } else {
+            // a near, screen-filling Gaussian (hundreds of tiles): four lanes per slot (one 16-B load each), 16 slots per
+            // load instruction, four instructions in flight - the run is this wave's critical path (as in grad_reduce)
+            const float4* __restrict__ s4 = reinterpret_cast<const float4*>(slots);
+            const uint32_t sub = (uint32_t)lane & 3u, sg = (uint32_t)lane >> 2;
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            uint32_t s = sg;
+            for (; s + 48 < n; s += 64) {
+              const float4 t0 = s4[(base + s) * 4 + sub], t1 = s4[(base + s + 16) * 4 + sub];
+              const float4 t2 = s4[(base + s + 32) * 4 + sub], t3 = s4[(base + s + 48) * 4 + sub];
+              a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w; a1.x += t1.x; a1.y += t1.y; a1.z += t1.z; a1.w += t1.w;
+              a2.x += t2.x; a2.y += t2.y; a2.z += t2.z; a2.w += t2.w; a3.x += t3.x; a3.y += t3.y; a3.z += t3.z; a3.w += t3.w;
+            }
+            for (; s < n; s += 16) {
+              const float4 t0 = s4[(base + s) * 4 + sub];
+              a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w;
+            }
+            float4 acc = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                                     (a0.w + a1.w) + (a2.w + a3.w));
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) {
+              acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+              acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+            }
+            if (lane < 4) { s_big[wv][src][4 * sub] = acc.x; s_big[wv][src][4 * sub + 1] = acc.y; s_big[wv][src][4 * sub + 2] = acc.z; s_big[wv][src][4 * sub + 3] = acc.w; }
+          }
         }
         __builtin_amdgcn_wave_barrier();
         if (rgrad) {
