@@ -1,10 +1,10 @@
 # One gpurun call that produces everything profiles/ quotes for a round:
-#   bash tools/measure_round.sh r03            -> gpurun_out/r03/*
+#   bash tools/measure_round.sh r04            -> gpurun_out/r04/*
 # GPU tests, the default bench line, kernel traces (bench, map iteration of both scenes, ICP), gap traces, and the PMC
 # passes - FETCH_SIZE and WRITE_SIZE in separate runs (TCC slots), two SQ counter sets - each with --kernel-trace only.
 set -x
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_bench -o bench -- python $R/bench.py --no-cpu-baseline --no-schedule > $O/ks_bench.log 2>&1
 for w in headline surface; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$w -o k -- python $R/tools/prof_raster.py $w 50 > $O/ks_$w.log 2>&1
-  python $R/tools/gap_trace.py $(find $O/ks_$w -name "*kernel_trace.csv" | head -1) map_tail_rows 25 > $O/gaps_$w.txt
+  python $R/tools/gap_trace.py $(find $O/ks_$w -name "*kernel_trace.csv" | head -1) map_fused_tail 25 > $O/gaps_$w.txt
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f_$w -o f -- python $R/tools/prof_raster.py $w 5 > $O/pmc_f_$w.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w_$w -o w -- python $R/tools/prof_raster.py $w 5 > $O/pmc_w_$w.log 2>&1
   python $R/tools/traffic_from_pmc.py $(find $O/pmc_f_$w -name "*counter_collection.csv" | head -1) $(find $O/pmc_w_$w -name "*counter_collection.csv" | head -1) $O/traffic_$w.json > $O/traffic_$w.txt
