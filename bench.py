@@ -331,7 +331,7 @@ def main():
             torch.cuda.synchronize(dev)
             surface["unstable_20pct"] = {"map_iteration_ms": round(1e3 * (time.perf_counter() - tu) / args.steps, 4),
                                          "trainable_rows": int(opt_u.n_train), "frozen_rows": int(opt_u.n_frozen),
-                                         "rows_with_gradient": int((opt_u.grad_rows.row_state == 1).sum())}
+                                         "rows_with_gradient_per_step": int(opt_u.live_counts[0]) // (20 + args.steps)}
             del opt_u
             surface["workload"] = (f"{N} opaque discs on the walls of the 5 x 3 x 6 m box room (one layer, opacity 0.99, radius = "
                                    "sqrt(area / N) clipped to [0.001, 0.05] m), camera inside, all tiles")
@@ -581,9 +581,10 @@ def profile_scene(lib, mo, rast, opt, N, cam, tile_mask, gt_color, gt_depth, dev
     consumed = pairs = R = 0
     rows_touched = rows_cleared = 0
     slice_stats = None
-    for i in range(nprof + 1):                                     # first pass is a warm-up
-        counters.zero_()
-        lib.rtgs_raster_set_counters(C.c_void_p(counters.data_ptr()))
+    for i in range(nprof + 1):                                     # first pass: warm-up AND the work counters (their
+        if i == 0:                                                 # per-tile atomics cost blend_fwd ~25 us: not in the timed passes)
+            counters.zero_()
+            lib.rtgs_raster_set_counters(C.c_void_p(counters.data_ptr()))
         lv = {nm: opt.state[nm]["p"][:N].detach().clone().requires_grad_(True) for nm in ("xyz", "shs", "raw8")}
         opt.grad_rows.begin_step()                                 # same backward as opt.step(): persistent rows + row states
         gd = mo.activate8_hip(lv["raw8"], opt.grad_rows)
@@ -596,6 +597,8 @@ def profile_scene(lib, mo, rast, opt, N, cam, tile_mask, gt_color, gt_depth, dev
         loss.backward()
         torch.cuda.synchronize(dev)
         if i == 0:
+            cc = counters.view(-1, 2).sum(0).cpu()
+            consumed, pairs = int(cc[0]), int(cc[1])
             continue
         ms = (C.c_float * 12)()
         lib.rtgs_raster_last_timings(ms)
@@ -608,8 +611,6 @@ def profile_scene(lib, mo, rast, opt, N, cam, tile_mask, gt_color, gt_depth, dev
         st = (C.c_int64 * 8)()
         lib.rtgs_raster_last_stats(st)
         R = int(st[0])
-        cc = counters.view(-1, 2).sum(0).cpu()
-        consumed, pairs = int(cc[0]), int(cc[1])
         rows_touched = int((opt.grad_rows.row_state == 1).sum())
         rows_cleared = int((opt.grad_rows.row_state == 2).sum())
     stage = acc

@@ -388,6 +388,7 @@ int rtgs_map_tail_rows(float* xyz, float* shs, float* raw8, const float* g_opaci
 typedef struct rtgs_loss_cfg {
   float color_weight, depth_weight, ssim_weight, add_depth_thres;
   const uint8_t* render_mask;
+  int32_t sums_zeroed;       /* non-zero: the caller guarantees ((float*)scratch)[0..7] are zero on entry (no memset launch) */
 } rtgs_loss_cfg;
 size_t rtgs_slam_loss_scratch_bytes(int32_t H, int32_t W, int32_t with_ssim);
 int rtgs_slam_loss(const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
@@ -486,6 +487,13 @@ int rtgs_map_fused_tail(const rtgs_raster_settings* settings, const rtgs_map_ste
  * gradient slot per Gaussian (u32[P], geometry), [2] slots taken per Gaussian (u32[P], geometry), [3] BwdInfo (image
  * buffer), [4] touched bytes (u8[P], inside grad_scratch, behind the P SplatGrad records). */
 int rtgs_raster_backward_buffers(int32_t P, int32_t image_height, int32_t image_width, size_t* out8_host);
+/* The geometry / binning / image buffers the most recent forward on the context obtained from its resize callbacks
+ * (out3_host[0..2]) - for a native caller that enqueues forward and backward back to back and would otherwise have to
+ * call back into its allocator (a Python callback costs ~5 us of GPU idle time at each of the step's two hand-overs). */
+int rtgs_raster_last_buffers_ctx(rtgs_ctx* ctx, void** out3_host);
+/* One-shot: eight 32-bit words the NEXT forward on the context clears inside its blend kernel (stream-ordered before
+ * anything enqueued after the forward) - rtgs_slam_map_step clears its loss sums this way instead of with a memset. */
+void rtgs_raster_set_aux_zero_ctx(rtgs_ctx* ctx, void* eight_words);
 /* The same call without its last stage (rtgs_map_tail_rows): the gradient rows of this rank's view are in the arena,
  * nothing has been stepped.  Multi-GPU callers exchange the rows (below) before they run the tail. */
 int rtgs_slam_map_step_front(const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);

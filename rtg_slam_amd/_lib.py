@@ -49,7 +49,7 @@ _P = C.c_void_p
 class LossCfgC(C.Structure):
     """Mirror of `rtgs_loss_cfg` (include/rtgs_raster.h)."""
     _fields_ = [("color_weight", C.c_float), ("depth_weight", C.c_float), ("ssim_weight", C.c_float),
-                ("add_depth_thres", C.c_float), ("render_mask", C.c_void_p)]
+                ("add_depth_thres", C.c_float), ("render_mask", C.c_void_p), ("sums_zeroed", C.c_int32)]
 
 
 class AttachC(C.Structure):
@@ -108,6 +108,8 @@ _SIGNATURES = {
     "rtgs_history_merge": (C.c_int, [_P] * 8 + [C.c_int64, C.c_float, _P]),
     "rtgs_map_fused_tail": (C.c_int, [C.POINTER(RasterSettingsC), C.POINTER(MapStepArgsC), _P, _P, _P, _P, _P]),
     "rtgs_raster_backward_buffers": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "rtgs_raster_last_buffers_ctx": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "rtgs_raster_set_aux_zero_ctx": (None, [_P, _P]),
     "rtgs_raster_backward_walk_ctx": (C.c_int, [_P, C.POINTER(RasterSettingsC), C.c_int32, C.c_int32, C.c_int64] + [_P] * 6
                                       + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P, C.c_int32, C.c_int32, _P]),
     "rtgs_slam_loss_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

@@ -797,7 +797,7 @@ extern "C" int rtgs_slam_loss_sums(const float* color, const float* depth, const
   const int64_t hw = (int64_t)H * W;
   float* sums = (float*)scratch;
   const bool ssim = cfg->render_mask == nullptr && cfg->ssim_weight != 0.f;
-  if (hipMemsetAsync(sums, 0, 8 * sizeof(float), st) != hipSuccess) return -2;
+  if (!cfg->sums_zeroed && hipMemsetAsync(sums, 0, 8 * sizeof(float), st) != hipSuccess) return -2;
   int64_t blocks = (hw + 255) / 256;
   // the sums kernel ends with four same-address global atomics per workgroup (~20 ns each, serialised): keep it to
   // 192 workgroups (1 024 of them cost 20 us for a 23 MB read)

@@ -18,18 +18,20 @@ static int map_step_front(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* n
     rc = rtgs_map_activate8_forward(a->raw8, P, a->opacity, a->scales, a->rotations, a->normal, stream);
     if (rc != 0) return RTGS_E_HIP;
   }
+  if (!a->loss_scratch || !a->loss4) return RTGS_E_INVALID;
+  rtgs_raster_set_aux_zero_ctx(ctx, a->loss_scratch);     // the forward's blend clears the loss sums: no memset launch
   rc = rtgs_raster_forward_ctx(ctx, a->settings, P, M, a->xyz, a->opacity, a->shs, a->scales, a->rotations, a->normal,
                            a->tile_mask, a->out_color, a->out_depth, a->out_color_index, a->out_depth_index,
                            a->out_color_weight, a->out_depth_weight, a->out_T, a->out_radii, a->geom_resize,
                            a->geom_user, a->binning_resize, a->binning_user, a->image_resize, a->image_user,
                            num_rendered_host, fwd_flags, stream);
   if (rc != RTGS_OK) return rc;
-  void* geom = a->geom_resize(a->geom_user, 0);          // size 0 = "hand me the buffer of the last request"
-  void* bin = a->binning_resize(a->binning_user, 0);
-  void* img = a->image_resize(a->image_user, 0);
-  if (!geom || !bin || !img) return RTGS_E_ALLOC;
-  if (!a->loss_scratch || !a->loss4) return RTGS_E_INVALID;
-  rc = rtgs_slam_loss(a->out_color, a->out_depth, a->out_depth_index, a->gt_color, a->gt_depth, H, W, &a->loss,
+  void* bufs[3];                                          // what the forward got from the resize callbacks (no call back)
+  if (rtgs_raster_last_buffers_ctx(ctx, bufs) != RTGS_OK) return RTGS_E_ALLOC;
+  void *geom = bufs[0], *bin = bufs[1], *img = bufs[2];
+  rtgs_loss_cfg lcfg = a->loss;
+  lcfg.sums_zeroed = P > 0 ? 1 : 0;
+  rc = rtgs_slam_loss(a->out_color, a->out_depth, a->out_depth_index, a->gt_color, a->gt_depth, H, W, &lcfg,
                       a->loss_scratch, a->loss4, a->dL_dcolor, a->dL_ddepth, stream);
   if (rc != 0) return RTGS_E_HIP;
   int32_t t0 = 0, t1 = P;                                 // the trainable rows (rtgs_map_step_args: 0, 0 = all)
@@ -70,10 +72,9 @@ static int map_step_once(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* nu
   int rc = map_step_front(ctx, a, num_rendered_host, speculate ? RTGS_FWD_SPECULATE : 0, stream, fused);
   if (rc != RTGS_OK) return rc;
   if (fused) {
-    void* geom = a->geom_resize(a->geom_user, 0);
-    void* img = a->image_resize(a->image_user, 0);
-    if (!geom || !img) return RTGS_E_ALLOC;
-    return rtgs_map_fused_tail(a->settings, a, geom, img, rtgs_raster_spec_fail_ptr_ctx(ctx), a->live_counts, stream);
+    void* bufs[3];
+    if (rtgs_raster_last_buffers_ctx(ctx, bufs) != RTGS_OK) return RTGS_E_ALLOC;
+    return rtgs_map_fused_tail(a->settings, a, bufs[0], bufs[2], rtgs_raster_spec_fail_ptr_ctx(ctx), a->live_counts, stream);
   }
   const int32_t P = a->P;
   // activation backward (+ attach gradient) + Adam on the three block tensors (+ confidence increment), one launch;

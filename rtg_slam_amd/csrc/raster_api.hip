@@ -19,7 +19,7 @@ void launch_emit_keys(const RasterParams&, const Splat*, const int32_t*, const u
                       uint32_t*, hipStream_t);
 void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
-                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, uint32_t*, uint32_t*, int, hipStream_t);
+                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, hipStream_t);
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
                       const uint32_t*, const int32_t*, const float*, const float*, const uint32_t*, uint32_t*,
                       const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, uint32_t, uint32_t, hipStream_t);
@@ -79,6 +79,8 @@ struct rtgs_ctx {
   const void* hint_geom = nullptr;
   bool hint_slice_lists = true, hint_main_lists = true;
   int hint_walk = -2;               // what that forward wrote into tile_mode (-1 per-tile choice, 0 strip, 1 rows, 2 MFMA)
+  void *last_geom = nullptr, *last_bin = nullptr, *last_img = nullptr;   // buffers of the most recent forward (rtgs_raster_last_buffers_ctx)
+  uint32_t* aux_zero = nullptr;     // eight words the NEXT forward's blend clears (one-shot; rtgs_raster_set_aux_zero_ctx)
   // Automatic near-slice mode: whether a call takes the slice is decided on the device from that call's histograms and
   // never depends on history.  Only HOW the host learns it does: after a call that declined, the next one asks for the
   // decision (one extra pinned-flag sync, ~10 us) before it launches the slice's kernels instead of launching them
@@ -397,6 +399,9 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   // what blend_fwd writes there: the MFMA walk (2) by default, a forced pixel-per-lane walk (0 strip, 1 rows), or their
   // per-tile choice from the measured list share (-1: bwd_walk 4)
   const int fwd_walk = c->bwd_walk == 0 || c->bwd_walk == 3 ? 2 : (c->bwd_walk == 4 ? -1 : c->bwd_walk - 1);
+  uint32_t* const aux_zero = c->aux_zero;
+  c->aux_zero = nullptr;
+  c->last_geom = geom; c->last_img = img; c->last_bin = nullptr;
 
   int64_t R = 0, R1 = 0;
   for (int i = 0; i < EV_B0; ++i) c->ev_set[i] = false;
@@ -498,12 +503,13 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         const BinLayout B = bin_layout(0, ntiles, false, use_sl ? (size_t)sl : 0);
         char* bin = (char*)binning_resize(binning_user, B.total);
         if (!bin) return RTGS_E_ALLOC;
+        c->last_bin = bin;
         b_total = B.total;
         hipLaunchKernelGGL(bwd_info_kernel, dim3(1), dim3(1), 0, st, (BwdInfo*)(img + I.bwd_info),
                            (SplatGrad*)(bin + B.slot_grads), use_sl ? sl : 0u, use_sl ? 1u : 0u);
         const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
         launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                         n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, st);
+                         n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, st);
         launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, fail, st);
         prof_mark(c, EV_SL_BLEND, st);
         prof_mark(c, EV_BLEND0, st); prof_mark(c, EV_BLEND, st);
@@ -513,6 +519,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         const BinLayout B = bin_layout((int64_t)capR, ntiles, false, (size_t)capS);
         char* bin = (char*)binning_resize(binning_user, B.total);
         if (!bin) return RTGS_E_ALLOC;
+        c->last_bin = bin;
         b_total = B.total;
         RasterParams pg = p;                       // the guarded kernels' view of the parameters
         pg.spec_fail = fail;
@@ -553,7 +560,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         prof_mark(c, EV_SORT, st);
         prof_mark(c, EV_BLEND0, st);
         launch_blend_fwd(pg, ranges, (uint32_t*)(bin + B.vals_b), splats, out_color, out_depth, out_cidx, out_didx, out_cw,
-                         out_dw, out_T, n_contrib, c->counters, SlicePass{0, nullptr, nullptr, nullptr, nullptr}, tile_mode, depth_pos, tile_last, fwd_walk, st);
+                         out_dw, out_T, n_contrib, c->counters, SlicePass{0, nullptr, nullptr, nullptr, nullptr}, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, st);
         prof_mark(c, EV_BLEND, st);
         c->hint_slice_lists = false; c->hint_main_lists = true;
         c->slice_stats[0] = pl.kind == 2 ? 1 : 0; c->slice_stats[1] = 0; c->slice_stats[2] = 0;
@@ -632,7 +639,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       if (++c->seq == 0u) c->seq = 1u;
       const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
       launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                       n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, st);
+                       n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, st);
       launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, nullptr, st);
       DBG(s, st);
       prof_mark(c, EV_SL_BLEND, st);
@@ -707,6 +714,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   const BinLayout B = bin_layout(R, ntiles, sort_path, use_slots ? (size_t)slots : 0);
   char* bin = (char*)binning_resize(binning_user, B.total);
   if (!bin) return RTGS_E_ALLOC;
+  c->last_bin = bin;
   hipLaunchKernelGGL(bwd_info_kernel, dim3(1), dim3(1), 0, st, (BwdInfo*)(img + I.bwd_info),
                      (SplatGrad*)(bin + B.slot_grads), use_slots ? slots : 0u, use_slots ? 1u : 0u);
   uint64_t* keys_a = (uint64_t*)(bin + B.keys_a);
@@ -745,7 +753,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   prof_mark(c, EV_BLEND0, st);
   if (!sliced || n_left > 0)     // pass 2 (or the only pass); with every tile finished by the slice there is nothing to draw
     launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                     n_contrib, c->counters, pass, tile_mode, depth_pos, tile_last, fwd_walk, st);
+                     n_contrib, c->counters, pass, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, st);
   prof_mark(c, EV_BLEND, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
@@ -957,6 +965,13 @@ int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
   return RTGS_OK;
 }
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode >= 1 && mode <= 4) ? mode : 0; }
+void rtgs_raster_set_aux_zero_ctx(rtgs_ctx* ctx, void* eight_words) { use(ctx)->aux_zero = (uint32_t*)eight_words; }
+int rtgs_raster_last_buffers_ctx(rtgs_ctx* ctx, void** out3) {
+  rtgs_ctx* c = use(ctx);
+  if (!out3 || !c->last_geom || !c->last_bin || !c->last_img) return RTGS_E_INVALID;
+  out3[0] = c->last_geom; out3[1] = c->last_bin; out3[2] = c->last_img;
+  return RTGS_OK;
+}
 int rtgs_raster_backward_buffers(int32_t P, int32_t H, int32_t W, size_t* out) {
   if (!out || P < 0 || H <= 0 || W <= 0) return RTGS_E_INVALID;
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;

@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256, 6) blend_fwd_kernel(
     int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
     float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
     unsigned long long* __restrict__ counters, SlicePass sp, uint32_t* __restrict__ tile_mode,
-    uint32_t* __restrict__ depth_pos, uint32_t* __restrict__ tile_last, int walk) {
+    uint32_t* __restrict__ depth_pos, uint32_t* __restrict__ tile_last, int walk, uint32_t* __restrict__ aux_zero) {
   __shared__ float4 s_rec[FWD_BATCH * 4];     // u v ca cb | cc o r g | b - - id | nx ny nz pd: the walk reads the first three
   __shared__ float s_z[FWD_BATCH];            // centre depth (opaque-surface test only)
   __shared__ uint32_t s_live[16][FWD_CHUNKS]; // per 4x4 block: the staged entries that reach it
@@ -318,6 +318,9 @@ __global__ void __launch_bounds__(256, 6) blend_fwd_kernel(
   const int lane = tid & 63, wv = tid >> 6;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
   if (spec_failed(p.spec_fail)) return;                // lists were not built (speculative sizes did not hold): redone by the host
+  // eight words a later kernel of the caller's step accumulates into (the loss sums of rtgs_slam_map_step): cleared here,
+  // stream-ordered before that kernel, instead of by a memset launch of their own
+  if (aux_zero && blockIdx.x == 0 && blockIdx.y == 0 && tid < 8) aux_zero[tid] = 0u;
   if (sp.mode == 2 && sp.mask2[tile] == 0) return;     // finished by the near slice (or masked off): outputs stay
   // wave = 8x8 quadrant, DPP row = 4x4 block, lane = pixel of the block
   const int bx = ((wv & 1) << 1) | ((lane >> 4) & 1), by = (wv & 2) | (lane >> 5);
@@ -572,10 +575,10 @@ void launch_slice_publish(int ntiles, const int32_t* user_mask, const int32_t* m
 void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                       float* out_color, float* out_depth, int32_t* out_cidx, int32_t* out_didx, float* out_cw,
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
-                      SlicePass sp, uint32_t* tile_mode, uint32_t* depth_pos, uint32_t* tile_last, int walk, hipStream_t st) {
+                      SlicePass sp, uint32_t* tile_mode, uint32_t* depth_pos, uint32_t* tile_last, int walk, uint32_t* aux_zero, hipStream_t st) {
   hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats,
                      out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp, tile_mode,
-                     depth_pos, tile_last, walk);
+                     depth_pos, tile_last, walk, aux_zero);
 }
 
 }  // namespace rtgs

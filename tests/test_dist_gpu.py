@@ -64,7 +64,7 @@ def _worker(rank, world, port, ret):
     dev = _init(rank, world)
     from rtg_slam_amd import map_optim as mo
     packed, fns = _setup(dev)
-    opt = mo.ShardedMapOptimizer(packed)          # HIP activations + HIP Adam, gloo (or RCCL) collectives
+    opt = mo.ShardedMapOptimizer(packed, n_frozen=NF())          # HIP activations + HIP Adam, gloo (or RCCL) collectives
     for _ in range(2):
         opt.step(fns[rank])
     ret[rank] = opt.params.cpu()
@@ -72,10 +72,18 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_match_single_process():
+def NF():
+    """Frozen prefix of the map in the workers and the single-process reference (set by the parametrised tests)."""
+    return int(os.environ.get("RTGS_TEST_NFROZEN", "0"))
+
+
+@pytest.mark.parametrize("nf", [0, 701])
+def test_two_ranks_one_gpu_match_single_process(nf, monkeypatch):
+    """nf > 0: rows [0, nf) are frozen (rendered, not parameters): the row shards partition the trainable rows only."""
+    monkeypatch.setenv("RTGS_TEST_NFROZEN", str(nf))
     sys.path.insert(0, ROOT)
     from rtg_slam_amd import map_optim as mo
-    port = 29700 + (os.getpid() % 200)
+    port = 29700 + (os.getpid() % 200) + (nf % 7)
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     ret = mgr.dict()
@@ -83,11 +91,12 @@ def test_two_ranks_one_gpu_match_single_process():
     assert torch.equal(ret[0], ret[1])
     dev = torch.device("cuda", 0)
     packed, fns = _setup(dev)
-    ref = mo.ShardedMapOptimizer(packed)          # world 1: both views summed in one process
+    ref = mo.ShardedMapOptimizer(packed, n_frozen=nf)          # world 1: both views summed in one process
     for _ in range(2):
         ref.step(lambda gd: fns[0](gd) + fns[1](gd))
     d = float((ret[0] - ref.params.cpu()).abs().max())
     assert d < 2e-5, d
+    assert torch.equal(ret[0][:nf], packed[:nf].cpu())
     assert float((ret[0] - packed.cpu()).abs().max()) > 1e-4
 
 
@@ -98,7 +107,7 @@ def _worker_slam(rank, world, port, ret):
     dev = _init(rank, world)
     from rtg_slam_amd import map_optim as mo
     packed, fns = _setup(dev)
-    opt = mo.ShardedMapOptimizer(packed)
+    opt = mo.ShardedMapOptimizer(packed, n_frozen=NF())
     opt._row_capacity, opt._shrink_every = 1 << 16, 1              # far too large: must shrink (same steps on every rank)
     rs, gt_c, gt_d = fns[rank].spec
     losses = []
@@ -116,12 +125,15 @@ def _worker_slam(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_ranks_sparse_slam_step_matches_single_process():
+@pytest.mark.parametrize("nf", [0, 701])
+def test_two_ranks_sparse_slam_step_matches_single_process(nf, monkeypatch):
     """step_slam with two ranks: only the gradient rows that exist are exchanged, every rank takes the same Adam
-    step.  Replicas bit-identical; result equal to one process optimising the sum of both views."""
+    step.  Replicas bit-identical; result equal to one process optimising the sum of both views.  nf > 0: a frozen
+    prefix - its rows never enter the exchange and stay bitwise untouched."""
+    monkeypatch.setenv("RTGS_TEST_NFROZEN", str(nf))
     sys.path.insert(0, ROOT)
     from rtg_slam_amd import map_optim as mo
-    port = 29300 + (os.getpid() % 200)
+    port = 29300 + (os.getpid() % 200) + (nf % 7)
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     ret = mgr.dict()
@@ -132,10 +144,11 @@ def test_two_ranks_sparse_slam_step_matches_single_process():
     assert "different Adam state" in ret["mixed0"]            # step() after step_slam() on > 1 rank is refused
     dev = torch.device("cuda", 0)
     packed, fns = _setup(dev)
-    ref = mo.ShardedMapOptimizer(packed)
+    ref = mo.ShardedMapOptimizer(packed, n_frozen=nf)
     for _ in range(3):
         ref.step(lambda gd: fns[0](gd) + fns[1](gd))
     rp = ref.params.cpu()
+    assert torch.equal(p0[:nf], packed[:nf].cpu())
     bad = float(((p0 - rp).abs() > 2e-5).float().mean())
     assert bad < 2e-3, bad                                     # Adam's +-lr first steps: a gradient ~0 may flip
     moved = (p0 - packed.cpu()).abs().max(dim=1).values > 0
