@@ -285,6 +285,11 @@ int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms12_host);
  * (u32 per pixel), [2] BwdInfo, [3] tile walk (u32 per tile: bits 0..1 = 0 strip / 1 row-granular / 2 MFMA, bits 8.. the
  * measured share in 1/1000), [4] total size, [5] list position of every pixel's depth owner (u32 per pixel). */
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* ctx, int mode);
+/* One-pass binning (round 4; default on, RTGS_BIN_ONEPASS=0 at load time turns it off): where the geometry buffer gives
+ * every tile a segment (maps of >= 100 000 Gaussians on >= 256 tiles), instances are placed by ONE enumeration sweep
+ * (bin_place_kernel) instead of count + scan + scatter.  Outputs are bit-identical either way (the tile sort's order is
+ * total); the switch exists for A-B runs and tests. */
+void rtgs_raster_set_onepass_ctx(rtgs_ctx* ctx, int on);
 /* Speculative forward (RTGS_FWD_SPECULATE).  verify: 0 = the guessed sizes held (or nothing was pending), 1 = they did
  * not - nothing persistent was changed, redo without the flag; < 0 = error.  It waits (spinning on pinned memory) only
  * until the kernel that publishes the totals has run.  spec_fail_ptr: device word (non-zero = failed) while a

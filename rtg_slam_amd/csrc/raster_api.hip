@@ -40,7 +40,8 @@ size_t bin_slice_block_counts_bytes(int, size_t, int);
 size_t bin_list_block_counts_bytes(int, int);
 void launch_visible_compact(int, const uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, hipStream_t);
 void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, hipStream_t);
-void launch_slice_publish(int, const int32_t*, const int32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, hipStream_t);
+void launch_slice_publish(int, const int32_t*, const int32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, hipStream_t,
+                          const uint32_t* seg_count = nullptr);
 void launch_preprocess_cull(const RasterParams&, const float*, const float*, const float*, uint32_t*, int32_t*, int32_t*,
                             uint32_t*, int, uint8_t*, float2*, hipStream_t);
 void launch_preprocess_shade(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
@@ -49,8 +50,13 @@ void launch_bin_tilescan(int, const uint32_t*, uint2*, uint32_t*, uint32_t*, uin
                          const uint32_t*, const uint32_t*, uint32_t, SpecCaps, hipStream_t);
 void launch_bin_scatter(const RasterParams&, const Splat*, const int32_t*, const int32_t*, const uint16_t*, uint32_t*,
                         unsigned long long*, SliceSel, SliceList, size_t, hipStream_t);
-void launch_slice_hist(int, const uint8_t*, const uint32_t*, const int32_t*, uint32_t*, unsigned long long*, hipStream_t);
-void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*, uint32_t*, const uint32_t*, hipStream_t);
+void launch_slice_hist(int, const uint8_t*, const uint32_t*, const int32_t*, uint32_t*, unsigned long long*, hipStream_t,
+                       BwdInfoInit bi = BwdInfoInit{nullptr, nullptr, 0u, 0u});
+void launch_bin_tilesort(int, uint32_t, const uint2*, const unsigned long long*, uint32_t*, const uint32_t*, hipStream_t,
+                         const uint32_t* seg_count = nullptr, uint32_t seg = 0, uint2* ranges_out = nullptr,
+                         const BinFinish* finish = nullptr);
+void launch_bin_place(const RasterParams&, const Splat*, const int32_t*, const int32_t*, uint32_t*, unsigned long long*, uint32_t,
+                      uint32_t*, SliceSel, SliceList, size_t, hipStream_t);
 
 }  // namespace rtgs
 
@@ -67,6 +73,7 @@ struct rtgs_ctx {
   int slice_budget = 384;
   int64_t slice_stats[4] = {0};     // used, near-slice instances, tiles finished, tiles left to pass 2
   unsigned long long* counters = nullptr;
+  bool onepass = true;              // one-pass placement into per-tile segments where the layout provides them
   bool prof = false;                // optional per-stage HIP-event timing (bench.py's roofline leg)
   bool force_sort_path = false;     // testing aid: take the global radix-sort binning path
   int bwd_walk = 0;                 // 0 / 3 = MFMA walk (default); 1 = strip walk everywhere; 2 = row-granular walk everywhere; 4 = per-tile choice between those two
@@ -127,6 +134,7 @@ static rtgs_ctx* default_ctx() {
     if (const char* e = getenv("RTGS_NEAR_SLICE")) n->slice_mode = atoi(e);
     if (const char* e = getenv("RTGS_NEAR_SLICE_BUDGET")) { const int b = atoi(e); if (b > 0) n->slice_budget = b; }
     if (const char* e = getenv("RTGS_SPECULATE")) n->speculation = atoi(e) != 0;
+    if (const char* e = getenv("RTGS_BIN_ONEPASS")) n->onepass = atoi(e) != 0;
     if (const char* e = getenv("RTGS_BWD_WALK")) { const int m = atoi(e); n->bwd_walk = (m >= 1 && m <= 4) ? m : 0; }
     return n;
   }();
@@ -224,10 +232,14 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
     if (L.slice_max_list > Pn) L.slice_max_list = Pn;
     L.vis_ids = off; off = align_up(off + Pn * sizeof(uint32_t));             // work list of every visible Gaussian
     L.block_counts_vis = off; off = align_up(off + bin_list_block_counts_bytes((int)Pn, gx * gy));
-    L.list1 = off; off = align_up(off + L.slice_cap * sizeof(uint32_t));      // last budget-independent OFFSET
+    // one-pass placement (bin_place_kernel): on maps where the automatic mode considers the slice, every tile owns a
+    // SEGMENT of SLICE_MAX_LIST entries in list1 / bucket1 (sparse use; 37 KB per tile, 119 MB at 1200x680 of 288 GB)
+    L.slice_seg = (Pn >= 100000 && nt >= 256) ? (size_t)SLICE_MAX_LIST : 0;
+    const size_t cap1 = L.slice_seg ? (nt * L.slice_seg > L.slice_cap ? nt * L.slice_seg : L.slice_cap) : L.slice_cap;
+    L.list1 = off; off = align_up(off + cap1 * sizeof(uint32_t));             // last budget-independent OFFSET
     L.block_counts1 = off; off = align_up(off + bin_slice_block_counts_bytes((int)Pn, L.slice_max_list, gx * gy));
     L.slice_ids = off; off = align_up(off + L.slice_max_list * sizeof(uint32_t));
-    L.bucket1 = off; off = align_up(off + L.slice_cap * sizeof(uint64_t));
+    L.bucket1 = off; off = align_up(off + cap1 * sizeof(uint64_t));
   }
   size_t tb = 0, tb2 = 0;
   (void)rocprim::inclusive_scan(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, Pn, rocprim::plus<uint32_t>());
@@ -325,7 +337,7 @@ const char* rtgs_version(void) { return "rtgs-hip 0.2.0 (gfx950)"; }
 
 rtgs_ctx* rtgs_ctx_create(void) {
   rtgs_ctx* c = new (std::nothrow) rtgs_ctx();
-  if (c) { c->slice_mode = default_ctx()->slice_mode; c->slice_budget = default_ctx()->slice_budget; c->bwd_walk = default_ctx()->bwd_walk; c->speculation = default_ctx()->speculation; }
+  if (c) { c->slice_mode = default_ctx()->slice_mode; c->slice_budget = default_ctx()->slice_budget; c->bwd_walk = default_ctx()->bwd_walk; c->onepass = default_ctx()->onepass; c->speculation = default_ctx()->speculation; }
   return c;
 }
 void rtgs_ctx_destroy(rtgs_ctx* c) {
@@ -422,6 +434,8 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   int32_t* mask2 = (int32_t*)(geom + G.mask2);
   uint32_t* list1 = (uint32_t*)(geom + G.list1);
   uint32_t longest = 0;
+  // one-pass placement of the near slice's instances into per-tile segments (RTGS_BIN_ONEPASS=0: count / scan / scatter)
+  const uint32_t seg1 = c->onepass ? (uint32_t)G.slice_seg : 0u;
   // gradient slots of the backward (BwdInfo): gbase = exclusive scan of the rect areas, into `offsets`
   const bool want_bwd = !(flags & RTGS_FWD_NO_BACKWARD);
   uint32_t slots = 0;
@@ -476,17 +490,32 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       const SpecCaps nocaps{nullptr, 0u, 0u, 0u, nullptr};
       if (++c->seq == 0u) c->seq = 1u;
       size_t b_total = 0;
+      bool seg_main = false;                     // main pass placed into per-tile segments: no bound on the total
       if (pl.kind == 1) {
         // the near slice finished every tile last time: pass 1 only, the slot space is the slice's instance budget
         launch_preprocess_cull(p, means3D, scales, rotations, tiles_touched, radii, out_radii, zero_words, zero_n, zbin,
                                (float2*)(geom + G.uv), st);
         prof_mark(c, EV_PRE, st);
-        launch_slice_hist(P, zbin, tiles_touched, radii, slice_hist, slice_cover, st);
+        const uint32_t sl = (uint32_t)G.slice_cap;
+        const bool use_sl = sl > 0 && sl <= SLOTS_MAX;
+        const BinLayout B = bin_layout(0, ntiles, false, use_sl ? (size_t)sl : 0);
+        char* bin = (char*)binning_resize(binning_user, B.total);
+        if (!bin) return RTGS_E_ALLOC;
+        c->last_bin = bin;
+        b_total = B.total;
+        launch_slice_hist(P, zbin, tiles_touched, radii, slice_hist, slice_cover, st,
+                          BwdInfoInit{(BwdInfo*)(img + I.bwd_info), (SplatGrad*)(bin + B.slot_grads), use_sl ? sl : 0u, use_sl ? 1u : 0u});
         launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, tiles_touched, offsets, slice_ctr + 4,
                              nullptr, 0u, nullptr, st);
         const SliceList work{(const uint32_t*)(geom + G.slice_ids), slice_ctr + 2};
         launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
                                 (float2*)(geom + G.uv), work, sel1, G.slice_max_list, st);
+        if (seg1) {       // one pass: no count, no scan (tile_count1 was cleared by the cull pass; the sort writes ranges1)
+          launch_bin_place(p, splats, radii, tile_mask, tile_count1, (unsigned long long*)(geom + G.bucket1), seg1, nullptr,
+                           sel1, work, G.slice_max_list, st);
+          launch_bin_tilesort(ntiles, (uint32_t)SLICE_MAX_LIST, ranges1, (const unsigned long long*)(geom + G.bucket1), list1,
+                              nullptr, st, tile_count1, seg1, ranges1);
+        } else {
         if (launch_bin_count(p, splats, radii, tile_mask, tile_count1, (uint16_t*)(geom + G.block_counts1), sel1, work,
                              G.slice_max_list, st) != 0)
           return RTGS_E_HIP;
@@ -497,26 +526,22 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                            G.slice_max_list, st);
         launch_bin_tilesort(ntiles, (uint32_t)SLICE_MAX_LIST, ranges1, (const unsigned long long*)(geom + G.bucket1), list1,
                             nullptr, st);
+        }
         prof_mark(c, EV_SL_BIN, st);
-        const uint32_t sl = (uint32_t)G.slice_cap;
-        const bool use_sl = sl > 0 && sl <= SLOTS_MAX;
-        const BinLayout B = bin_layout(0, ntiles, false, use_sl ? (size_t)sl : 0);
-        char* bin = (char*)binning_resize(binning_user, B.total);
-        if (!bin) return RTGS_E_ALLOC;
-        c->last_bin = bin;
-        b_total = B.total;
-        hipLaunchKernelGGL(bwd_info_kernel, dim3(1), dim3(1), 0, st, (BwdInfo*)(img + I.bwd_info),
-                           (SplatGrad*)(bin + B.slot_grads), use_sl ? sl : 0u, use_sl ? 1u : 0u);
         const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
         launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
                          n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, st);
-        launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, fail, st);
-        prof_mark(c, EV_SL_BLEND, st);
+        prof_mark(c, EV_SL_BLEND, st);      // the bracket holds the blend alone (bench.py's roofline divides by it)
+        launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, fail, st, seg1 ? tile_count1 : nullptr);
         prof_mark(c, EV_BLEND0, st); prof_mark(c, EV_BLEND, st);
         c->hint_slice_lists = true; c->hint_main_lists = false;
         c->slice_stats[0] = 1; c->slice_stats[1] = pl.R1; c->slice_stats[2] = pl.n_fin; c->slice_stats[3] = 0;
       } else {
-        const BinLayout B = bin_layout((int64_t)capR, ntiles, false, (size_t)capS);
+        // one pass (kind 2, through the visible list): every tile owns a segment of the sort class that covered the last
+        // verified longest list; a list that outgrows it raises `fail` like any other wrong guess
+        const uint32_t seg2 = (c->onepass && pl.kind == 2 && G.slice_seg) ? capL : 0u;
+        const BinLayout B = bin_layout(seg2 ? (int64_t)ntiles * (int64_t)seg2 : (int64_t)capR, ntiles, false, (size_t)capS);
+        seg_main = seg2 != 0u;
         char* bin = (char*)binning_resize(binning_user, B.total);
         if (!bin) return RTGS_E_ALLOC;
         c->last_bin = bin;
@@ -529,7 +554,8 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
           launch_preprocess_cull(p, means3D, scales, rotations, tiles_touched, radii, out_radii, zero_words, zero_n, zbin,
                                  (float2*)(geom + G.uv), st);
           prof_mark(c, EV_PRE, st);
-          launch_slice_hist(P, zbin, tiles_touched, radii, slice_hist, slice_cover, st);
+          launch_slice_hist(P, zbin, tiles_touched, radii, slice_hist, slice_cover, st,
+                            BwdInfoInit{(BwdInfo*)(img + I.bwd_info), (SplatGrad*)(bin + B.slot_grads), capS, 1u});
           launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, tiles_touched, offsets, slice_ctr + 4,
                                nullptr, 0u, fail, st);
           vl = SliceList{(const uint32_t*)(geom + G.vis_ids), slice_ctr + 4};
@@ -543,6 +569,15 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
           prof_mark(c, EV_PRE, st);
         }
         const SliceSel sel2{0, nullptr, nullptr, 0u, 0u, slice_ctr, nullptr, (const float2*)(geom + G.uv), nullptr, 0u, 0};
+        if (seg2) {
+          launch_bin_place(pg, splats, radii, tile_mask, tile_count, (unsigned long long*)(bin + B.keys_a), seg2, fail, sel2, vl,
+                           (size_t)P, st);
+          prof_mark(c, EV_SCAN, st); prof_mark(c, EV_BIN0, st); prof_mark(c, EV_EMIT, st);
+          const BinFinish fin{tile_count, ntiles, info, info_host, slice_ctr + 5, nullptr, c->seq,
+                              SpecCaps{fail, 0xffffffffu, capL, capS, (const int32_t*)(slice_ctr + 3)}};
+          launch_bin_tilesort(ntiles, capL, ranges, (const unsigned long long*)(bin + B.keys_a), (uint32_t*)(bin + B.vals_b), fail, st,
+                              tile_count, seg2, ranges, &fin);
+        } else {
         if (launch_bin_count(pg, splats, radii, tile_mask, tile_count, vl.ids ? (uint16_t*)(geom + G.block_counts_vis) : block_counts,
                              sel2, vl, (size_t)P, st) != 0)
           return RTGS_E_HIP;
@@ -550,13 +585,15 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, info_host, nullptr, nullptr,
                             vl.ids ? slice_ctr + 5 : offsets + (P - 1), vl.ids ? nullptr : tiles_touched + (P - 1), c->seq, caps, st);
         prof_mark(c, EV_SCAN, st);
-        hipLaunchKernelGGL(bwd_info_kernel, dim3(1), dim3(1), 0, st, (BwdInfo*)(img + I.bwd_info),
-                           (SplatGrad*)(bin + B.slot_grads), capS, 1u);
+        if (pl.kind != 2)
+          hipLaunchKernelGGL(bwd_info_kernel, dim3(1), dim3(1), 0, st, (BwdInfo*)(img + I.bwd_info),
+                             (SplatGrad*)(bin + B.slot_grads), capS, 1u);
         prof_mark(c, EV_BIN0, st);
         launch_bin_scatter(pg, splats, radii, tile_mask, vl.ids ? (const uint16_t*)(geom + G.block_counts_vis) : block_counts,
                            cursor, (unsigned long long*)(bin + B.keys_a), sel2, vl, (size_t)P, st);
         prof_mark(c, EV_EMIT, st);
         launch_bin_tilesort(ntiles, capL, ranges, (const unsigned long long*)(bin + B.keys_a), (uint32_t*)(bin + B.vals_b), fail, st);
+        }
         prof_mark(c, EV_SORT, st);
         prof_mark(c, EV_BLEND0, st);
         launch_blend_fwd(pg, ranges, (uint32_t*)(bin + B.vals_b), splats, out_color, out_depth, out_cidx, out_didx, out_cw,
@@ -568,7 +605,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       }
       HIP_TRY(hipGetLastError());
       c->hint_geom = geom; c->hint_walk = fwd_walk;
-      c->spec.pending = true; c->spec.kind = pl.kind; c->spec.seq = c->seq; c->spec.capR = capR; c->spec.capL = capL;
+      c->spec.pending = true; c->spec.kind = pl.kind; c->spec.seq = c->seq; c->spec.capR = seg_main ? 0xffffffffu : capR; c->spec.capL = capL;
       c->spec.capS = capS; c->spec.geom = geom; c->spec.fail_dev = fail; c->spec.stream = stream; c->spec.ntiles = ntiles;
       c->spec.G_total = (int64_t)G.total; c->spec.B_total = (int64_t)b_total; c->spec.I_total = (int64_t)I.total;
       ++c->spec_stats[0];
@@ -624,6 +661,12 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       const SliceList work{(const uint32_t*)(geom + G.slice_ids), slice_ctr + 2};
       launch_preprocess_shade(p, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
                               (float2*)(geom + G.uv), work, sel1, G.slice_max_list, st);
+      if (seg1) {
+        launch_bin_place(p, splats, radii, tile_mask, tile_count1, (unsigned long long*)(geom + G.bucket1), seg1, nullptr,
+                         sel1, work, G.slice_max_list, st);
+        launch_bin_tilesort(ntiles, (uint32_t)SLICE_MAX_LIST, ranges1, (const unsigned long long*)(geom + G.bucket1), list1,
+                            nullptr, st, tile_count1, seg1, ranges1);
+      } else {
       if (launch_bin_count(p, splats, radii, tile_mask, tile_count1, (uint16_t*)(geom + G.block_counts1), sel1, work,
                            G.slice_max_list, st) != 0)
         return RTGS_E_HIP;
@@ -634,15 +677,16 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                          G.slice_max_list, st);
       launch_bin_tilesort(ntiles, (uint32_t)SLICE_MAX_LIST, ranges1, (const unsigned long long*)(geom + G.bucket1), list1,
                           nullptr, st);
+      }
       DBG(s, st);
       prof_mark(c, EV_SL_BIN, st);
       if (++c->seq == 0u) c->seq = 1u;
       const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
       launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
                        n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, st);
-      launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, nullptr, st);
-      DBG(s, st);
       prof_mark(c, EV_SL_BLEND, st);
+      launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, nullptr, st, seg1 ? tile_count1 : nullptr);
+      DBG(s, st);
       // the forward's host sync: the last tile of the slice publishes how many tiles are left
       if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
       n_left = pub[2]; n_fin = pub[3];
@@ -964,6 +1008,7 @@ int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
   memcpy(out3, use(ctx)->spec_stats, sizeof(use(ctx)->spec_stats));
   return RTGS_OK;
 }
+void rtgs_raster_set_onepass_ctx(rtgs_ctx* c, int on) { use(c)->onepass = on != 0; use(c)->plan.valid = false; }
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode >= 1 && mode <= 4) ? mode : 0; }
 void rtgs_raster_set_aux_zero_ctx(rtgs_ctx* ctx, void* eight_words) { use(ctx)->aux_zero = (uint32_t*)eight_words; }
 int rtgs_raster_last_buffers_ctx(rtgs_ctx* ctx, void** out3) {

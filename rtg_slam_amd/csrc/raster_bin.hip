@@ -178,8 +178,10 @@ __device__ __forceinline__ void enumerate_balanced(const RasterParams& p, const 
         __hip_atomic_fetch_or(&wb->head, 1ull << (excl - it0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const unsigned long long hm = __hip_atomic_load(&wb->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const uint32_t item = it0 + (uint32_t)lane;
+      bool hit = false;
+      int t = 0, owner = 0;
       if (item < total) {
-        const int owner = (int)started + __popcll(hm & le_mask) - 1;
+        owner = (int)started + __popcll(hm & le_mask) - 1;
         const uint32_t* r = wb->rec + owner * GREC;
         BinG b;
         b.u = __uint_as_float(r[0]); b.v = __uint_as_float(r[1]); b.ca = __uint_as_float(r[2]); b.cb = __uint_as_float(r[3]);
@@ -189,9 +191,10 @@ __device__ __forceinline__ void enumerate_balanced(const RasterParams& p, const 
         const int ry = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)bw));   // exact: margin 0.5/bw >> rcp error
         const int rx = (int)local - ry * (int)bw;
         const int tx = (int)(xy & 0xffffu) + rx, ty = (int)(xy >> 16) + ry;
-        const int t = ty * p.gx + tx;
-        if (mask[t] != 0 && tile_visible(b, tx, ty)) f(t, r[10], r[11]);
+        t = ty * p.gx + tx;
+        hit = mask[t] != 0 && tile_visible(b, tx, ty);
       }
+      f(hit, t, owner);                              // every lane of the wave calls: f may ballot
       started += (uint32_t)__popcll(hm);
     }
   }
@@ -212,7 +215,7 @@ __global__ void __launch_bounds__(256) bin_count_kernel(RasterParams p, const Sp
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
   __syncthreads();
   enumerate_balanced(p, splats, radii, mask, nullptr, 0, list, gpb, sel.mode == 2 ? sel.sat : nullptr, sel.uv,
-                     &s_wb[threadIdx.x >> 6], [&](int t, uint32_t, uint32_t) { atomicAdd(&s_cnt[t], 1u); });
+                     &s_wb[threadIdx.x >> 6], [&](bool hit, int t, int) { if (hit) atomicAdd(&s_cnt[t], 1u); });
   __syncthreads();
   // the workgroup's row of per-tile counts is kept for bin_scatter (same Gaussian -> workgroup mapping),
   // which therefore needs only ONE enumeration sweep; a workgroup holds GPB <= 65535 Gaussians, so u16 fits
@@ -300,13 +303,122 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(RasterParams p, const 
   }
   __syncthreads();
   enumerate_balanced(p, splats, radii, mask, nullptr, 0, list, gpb, sel.mode == 2 ? sel.sat : nullptr, sel.uv,
-                     &s_wb[threadIdx.x >> 6], [&](int t, uint32_t id, uint32_t zbits) {
-    const uint32_t base = s_base[t];
+                     &s_wb[threadIdx.x >> 6], [&](bool hit, int t, int owner) {
+    const uint32_t base = hit ? s_base[t] : 0xffffffffu;
     if (base != 0xffffffffu) {
+      const uint32_t* r = s_wb[threadIdx.x >> 6].rec + owner * GREC;
       const uint32_t slot = base + atomicAdd(&s_cnt[t], 1u);
-      bucket[slot] = ((unsigned long long)zbits << 32) | id;
+      bucket[slot] = ((unsigned long long)r[11] << 32) | r[10];
     }
   });
+}
+
+// ---------------------------------------------------------------------------------------------
+// ONE-PASS placement into per-tile SEGMENTS (round 4): tile t owns bucket[t * seg, (t + 1) * seg) - the near slice's
+// lists are capped at SLICE_MAX_LIST anyway (a longer one leaves its tile to pass 2), the main pass of a speculative
+// forward takes the sort-class capacity of the last verified longest list - so nothing has to be counted and scanned
+// before a key can be placed: bin_count, bin_tilescan and the per-workgroup count rows are not launched.
+// A workgroup enumerates its Gaussians ONCE: every hit takes its rank inside the workgroup from an LDS counter of its
+// tile and is parked in the wave's staging area as (owner, tile, rank) - 4 bytes; then one global atomic per touched
+// tile reserves the workgroup's run of the segment, and the parked hits are written out.  A wave whose staging area
+// is full places the rest with one global atomic per hit (both forms reserve on the same counter).
+// count[t] ends as the tile's TRUE number of hits; keys beyond the segment are dropped (near slice: the tile is left
+// to pass 2, as before; main pass: `fail` is raised and the host redoes the call with exact sizes).
+// ---------------------------------------------------------------------------------------------
+struct SegBins { uint32_t* count; unsigned long long* bucket; uint32_t seg; uint32_t* fail; };
+constexpr int STAGE_W = 1024;                     // parked hits per wave
+
+__global__ void __launch_bounds__(256) bin_place_kernel(RasterParams p, const Splat* __restrict__ splats,
+                                                        const int32_t* __restrict__ radii,
+                                                        const int32_t* __restrict__ mask, SegBins sb, SliceSel sel,
+                                                        SliceList list, int gpb, int stage_cap) {
+  extern __shared__ uint32_t s_mem[];
+  __shared__ WaveBin s_wb[BLOCK / 64];
+  __shared__ uint32_t s_stage[BLOCK / 64][STAGE_W];
+  const int ntiles = p.gx * p.gy;
+  if (spec_failed(p.spec_fail)) return;
+  if (sel.mode == 2 && sel.ctr[0] == 0u) return;
+  if (blockIdx.x * gpb >= (int)*list.count) return;
+  uint32_t* s_cnt = s_mem;
+  for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  uint32_t* stage = s_stage[w];
+  const uint32_t* rec = s_wb[w].rec;
+  uint32_t parked = 0;                            // wave-uniform
+  enumerate_balanced(p, splats, radii, mask, nullptr, 0, list, gpb, sel.mode == 2 ? sel.sat : nullptr, sel.uv,
+                     &s_wb[w], [&](bool hit, int t, int owner) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+    if (m == 0ull) return;
+    const uint32_t pos = parked + (uint32_t)__popcll(m & lt_mask);
+    if (hit) {
+      if (pos < (uint32_t)stage_cap) {
+        const uint32_t rank = atomicAdd(&s_cnt[t], 1u);              // < gpb <= 256: a Gaussian meets a tile once
+        stage[pos] = (uint32_t)owner | ((uint32_t)t << 6) | (rank << 20);
+      } else {
+        const uint32_t slot = atomicAdd(&sb.count[t], 1u);
+        const uint32_t* r = rec + owner * GREC;
+        if (slot < sb.seg) sb.bucket[(size_t)t * sb.seg + slot] = ((unsigned long long)r[11] << 32) | r[10];
+        else if (sb.fail) *sb.fail = 1u;
+      }
+    }
+    parked += (uint32_t)__popcll(m);
+  });
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntiles; t += BLOCK) {
+    const uint32_t c = s_cnt[t];
+    if (c) {
+      const uint32_t base = atomicAdd(&sb.count[t], c);
+      s_cnt[t] = base;
+      if (base + c > sb.seg && sb.fail) *sb.fail = 1u;
+    }
+  }
+  __syncthreads();
+  const uint32_t n = min(parked, (uint32_t)stage_cap);
+  for (uint32_t k = lane; k < n; k += 64) {
+    const uint32_t e = stage[k];
+    const uint32_t t = (e >> 6) & 0x3fffu;
+    const uint32_t slot = s_cnt[t] + (e >> 20);
+    const uint32_t* r = rec + (e & 63u) * GREC;
+    if (slot < sb.seg) sb.bucket[(size_t)t * sb.seg + slot] = ((unsigned long long)r[11] << 32) | r[10];
+  }
+}
+
+// Segment mode (one-pass placement): the tile's range is [tile * seg, + count[tile]); the first sort launch - it
+// visits every tile - also writes it where the blends and the backward read it.  count may exceed seg (keys beyond were
+// dropped): no size class takes such a tile, and the consumers treat it as they did before (slice: left to pass 2).
+struct TileSeg { const uint32_t* count; uint32_t seg; uint2* ranges_out; };
+__device__ __forceinline__ uint2 tile_range(const uint2* __restrict__ ranges, const TileSeg& ts, bool writer) {
+  if (!ts.count) return ranges[blockIdx.x];
+  const uint32_t x = blockIdx.x * ts.seg;
+  const uint2 r = make_uint2(x, x + ts.count[blockIdx.x]);
+  if (writer && ts.ranges_out) ts.ranges_out[blockIdx.x] = r;
+  return r;
+}
+
+// What bin_tilescan's last thread did, for a forward that placed its instances in one pass and never scanned: totals of
+// the per-tile counts, the speculative forward's capacity check, the words the host's verify waits for.  Run by ONE EXTRA
+// workgroup of the first sort launch (128 threads, ~25 counts each) beside the tiles' sorts - no launch of its own.
+__device__ __forceinline__ void bin_finish(const BinFinish& f) {
+  __shared__ uint32_t s_sum[2], s_max[2];
+  uint32_t sum = 0, mx = 0;
+  for (int t = threadIdx.x; t < f.ntiles; t += 128) { const uint32_t c = f.count[t]; sum += c; mx = max(mx, c); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sum += (uint32_t)__shfl_xor((int)sum, off); mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); }
+  if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_max[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const uint32_t R = s_sum[0] + s_sum[1], longest = max(s_max[0], s_max[1]);
+  f.info[0] = R; f.info[1] = longest;
+  const uint32_t slots_total = (f.slot_a ? f.slot_a[0] : 0u) + (f.slot_b ? f.slot_b[0] : 0u);
+  const int32_t cut = f.caps.cut ? *f.caps.cut : 0;
+  if (f.caps.fail && (R > f.caps.R || longest > f.caps.longest || slots_total > f.caps.slots || (f.caps.cut && cut >= 0)))
+    *f.caps.fail = 1u;                           // only ever raised here: bin_place may have raised it already
+  if (f.info_host) {
+    const uint32_t w[7] = {R, longest, 0u, 0u, 0u, slots_total, (uint32_t)cut};
+    publish_to_host(f.info_host, w, f.seq);
+  }
 }
 
 // one workgroup per tile; keys (depth bits << 32 | id) are unique, so the order is total
@@ -316,10 +428,12 @@ template <int THREADS>
 __global__ void __launch_bounds__(THREADS) bin_tilesort_kernel(const uint2* __restrict__ ranges,
                                                                const unsigned long long* __restrict__ bucket,
                                                                uint32_t* __restrict__ point_list, int lo, int hi,
-                                                               const uint32_t* __restrict__ spec_fail) {
+                                                               const uint32_t* __restrict__ spec_fail, TileSeg ts,
+                                                               BinFinish fin) {
   extern __shared__ unsigned long long s_key[];
+  if (fin.count && (int)blockIdx.x == fin.ntiles) { bin_finish(fin); return; }     // also after a failed guess: the host waits for it
   if (spec_failed(spec_fail)) return;
-  const uint2 r = ranges[blockIdx.x];
+  const uint2 r = tile_range(ranges, ts, threadIdx.x == 0);
   const int n = (int)(r.y - r.x);
   if (n < lo || n >= hi) return;
   const int tid = threadIdx.x;
@@ -353,7 +467,8 @@ template <int THREADS>
 __global__ void __launch_bounds__(THREADS) bin_tilesort_radix_kernel(const uint2* __restrict__ ranges,
                                                                      const unsigned long long* __restrict__ bucket,
                                                                      uint32_t* __restrict__ point_list, int lo, int hi,
-                                                                     int cap, const uint32_t* __restrict__ spec_fail) {
+                                                                     int cap, const uint32_t* __restrict__ spec_fail,
+                                                                     TileSeg ts) {
   constexpr int NW = THREADS / 64;
   extern __shared__ unsigned long long s_dyn[];
   unsigned long long* kA = s_dyn;
@@ -362,7 +477,7 @@ __global__ void __launch_bounds__(THREADS) bin_tilesort_radix_kernel(const uint2
   uint32_t* s_tot = s_cnt + NW * 256;                                   // [256]
   __shared__ uint32_t s_or;
   if (spec_failed(spec_fail)) return;
-  const uint2 r = ranges[blockIdx.x];
+  const uint2 r = tile_range(ranges, ts, false);
   const int n = (int)(r.y - r.x);
   if (n < lo || n >= hi) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -487,8 +602,11 @@ __global__ void __launch_bounds__(256) slice_hist_kernel(int P, const uint8_t* _
                                                          const uint32_t* __restrict__ rect_area,
                                                          const int32_t* __restrict__ radii,
                                                          uint32_t* __restrict__ hist,
-                                                         unsigned long long* __restrict__ cover) {
+                                                         unsigned long long* __restrict__ cover, BwdInfoInit bi) {
   __shared__ uint32_t s_h[SLICE_BINS], s_c[SLICE_BINS], s_r[SLICE_BINS];
+  if (bi.dst && blockIdx.x == 0 && threadIdx.x == 0) {     // host-known words of the backward (was a kernel of its own)
+    bi.dst->slot_grads = bi.slot_grads; bi.dst->slots = bi.slots; bi.dst->use_slots = bi.use_slots;
+  }
   s_h[threadIdx.x] = 0; s_c[threadIdx.x] = 0; s_r[threadIdx.x] = 0;
   __syncthreads();
   // 8 consecutive Gaussians per thread, all loads in flight at once (the grid-stride form was a chain of
@@ -528,11 +646,11 @@ __global__ void __launch_bounds__(256) slice_hist_kernel(int P, const uint8_t* _
   }
 }
 void launch_slice_hist(int P, const uint8_t* zbin, const uint32_t* rect_area, const int32_t* radii, uint32_t* hist,
-                       unsigned long long* cover, hipStream_t st) {
+                       unsigned long long* cover, hipStream_t st, BwdInfoInit bi) {
   if (P == 0) return;
   int blocks = (P + 2047) / 2048;       // few workgroups: each ends with up to 256 same-address global atomics
   if (blocks > 128) blocks = 128;
-  hipLaunchKernelGGL(slice_hist_kernel, dim3(blocks), dim3(256), 0, st, P, zbin, rect_area, radii, hist, cover);
+  hipLaunchKernelGGL(slice_hist_kernel, dim3(blocks), dim3(256), 0, st, P, zbin, rect_area, radii, hist, cover, bi);
 }
 
 // ids of the Gaussians in the near slice (depth bin <= cut), in arbitrary order (the tile sort orders by (depth, id));
@@ -733,30 +851,51 @@ void launch_bin_scatter(const RasterParams& p, const Splat* splats, const int32_
   hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)((n + gpb - 1) / gpb)), dim3(BLOCK), lds, st, p, splats, radii,
                      mask, block_counts, cursor, bucket, sel, list, gpb);
 }
+void launch_bin_place(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,
+                      uint32_t* seg_count, unsigned long long* bucket, uint32_t seg, uint32_t* fail, SliceSel sel,
+                      SliceList list, size_t max_items, hipStream_t st) {
+  if (p.P == 0) return;
+  const int ntiles = p.gx * p.gy;
+  const size_t lds = (size_t)ntiles * sizeof(uint32_t);
+  static LdsGrant grant(24 * 1024);
+  grant.ensure((const void*)bin_place_kernel, lds);
+  static const int stage_cap = [] { const char* e = getenv("RTGS_BIN_STAGE"); const int v = e ? atoi(e) : STAGE_W;
+                                    return v < 0 ? 0 : (v > STAGE_W ? STAGE_W : v); }();
+  const int gpb = list_gpb(list, max_items);
+  const size_t n = max_items < (size_t)p.P ? max_items : (size_t)p.P;
+  hipLaunchKernelGGL(bin_place_kernel, dim3((unsigned)((n + gpb - 1) / gpb)), dim3(BLOCK), lds, st, p, splats, radii, mask,
+                     SegBins{seg_count, bucket, seg, fail}, sel, list, gpb, stage_cap);
+}
+
 template <int THREADS>
 static void launch_radix(int ntiles, const uint2* ranges, const unsigned long long* bucket, uint32_t* point_list, int lo,
-                         int hi, int cap, const uint32_t* spec_fail, hipStream_t st) {
+                         int hi, int cap, const uint32_t* spec_fail, TileSeg ts, hipStream_t st) {
   const size_t lds = (size_t)cap * 16 + (size_t)(THREADS / 64 + 1) * 256 * sizeof(uint32_t);
   static LdsGrant grant(48 * 1024);            // one static per THREADS instantiation
   grant.ensure((const void*)bin_tilesort_radix_kernel<THREADS>, lds);
   hipLaunchKernelGGL(bin_tilesort_radix_kernel<THREADS>, dim3(ntiles), dim3(THREADS), lds, st, ranges, bucket, point_list,
-                     lo, hi, cap, spec_fail);
+                     lo, hi, cap, spec_fail, ts);
 }
 
 void launch_bin_tilesort(int ntiles, uint32_t longest, const uint2* ranges, const unsigned long long* bucket,
-                         uint32_t* point_list, const uint32_t* spec_fail, hipStream_t st) {
+                         uint32_t* point_list, const uint32_t* spec_fail, hipStream_t st, const uint32_t* seg_count,
+                         uint32_t seg, uint2* ranges_out, const BinFinish* finish) {
+  const TileSeg ts{seg_count, seg, nullptr}, ts0{seg_count, seg, ranges_out};
+  const BinFinish nofin{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0u, SpecCaps{nullptr, 0u, 0u, 0u, nullptr}};
+  const BinFinish fin = finish ? *finish : nofin;
   // size classes by list length; every class runs with the LDS footprint its lists need:
   //   (0,256]  bitonic, 128 threads      (256,1024] radix, 256 threads   (1024,3072] radix, 512 threads
   //   (3072,8192] radix, 1024 threads    (8192,16384] bitonic in place, 1024 threads
-  hipLaunchKernelGGL(bin_tilesort_kernel<128>, dim3(ntiles), dim3(128), 256 * 8, st, ranges, bucket, point_list, 1, 257, spec_fail);
-  if (longest > 256) launch_radix<256>(ntiles, ranges, bucket, point_list, 257, 1025, 1024, spec_fail, st);
-  if (longest > 1024) launch_radix<512>(ntiles, ranges, bucket, point_list, 1025, 3073, 3072, spec_fail, st);
-  if (longest > 3072) launch_radix<1024>(ntiles, ranges, bucket, point_list, 3073, 8193, 8192, spec_fail, st);
+  hipLaunchKernelGGL(bin_tilesort_kernel<128>, dim3(ntiles + (fin.count ? 1 : 0)), dim3(128), 256 * 8, st, ranges, bucket, point_list,
+                     1, 257, spec_fail, ts0, fin);
+  if (longest > 256) launch_radix<256>(ntiles, ranges, bucket, point_list, 257, 1025, 1024, spec_fail, ts, st);
+  if (longest > 1024) launch_radix<512>(ntiles, ranges, bucket, point_list, 1025, 3073, 3072, spec_fail, ts, st);
+  if (longest > 3072) launch_radix<1024>(ntiles, ranges, bucket, point_list, 3073, 8193, 8192, spec_fail, ts, st);
   if (longest > 8192) {
     static LdsGrant grant(48 * 1024);
     grant.ensure((const void*)bin_tilesort_kernel<1024>, 16384 * 8);
     hipLaunchKernelGGL(bin_tilesort_kernel<1024>, dim3(ntiles), dim3(1024), 16384 * 8, st, ranges, bucket, point_list,
-                       8193, 16385, spec_fail);
+                       8193, 16385, spec_fail, ts, nofin);
   }
 }
 

@@ -63,6 +63,12 @@ struct SpecCaps {
   const int32_t* cut;
 };
 
+// the totals step of a one-pass binning (raster_bin.hip: bin_finish)
+struct BinFinish {
+  const uint32_t* count; int ntiles;
+  uint32_t* info; uint32_t* info_host; const uint32_t* slot_a; const uint32_t* slot_b; uint32_t seq; SpecCaps caps;
+};
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
@@ -74,6 +80,7 @@ struct GeomLayout {
   size_t zbin, cursor1, ranges1, mask2, block_counts1, bucket1, list1, uv, slice_ids;
   size_t vis_ids, block_counts_vis;   // list of every visible Gaussian + its per-workgroup tile counts (declined single pass)
   size_t slot_count;                 // [P] u32: slots taken per Gaussian (backward; zeroed by it)
+  size_t slice_seg;                                                   // entries per tile segment of list1 / bucket1 (0: none)
   size_t slice_cap, slice_max_list;                                  // capacity of bucket1 / list1; of the work list
 };
 
@@ -156,6 +163,7 @@ struct BwdInfo {
   uint32_t slots;              // capacity
   uint32_t use_slots;          // 0 = accumulate into SplatGrad records with global atomics
 };
+struct BwdInfoInit { BwdInfo* dst; SplatGrad* slot_grads; uint32_t slots, use_slots; };   // written by a kernel that runs anyway
 constexpr uint32_t SLOTS_MAX = 12u << 20;   // 12 Mi slots = 768 MiB of partials; above that: atomics
 
 // Tile rectangle of a Gaussian: C (int) truncation then clamp - identical to

@@ -547,29 +547,33 @@ __global__ void __launch_bounds__(256) slice_publish_kernel(int ntiles, const in
                                                             const int32_t* __restrict__ mask2,
                                                             const uint32_t* __restrict__ r1, uint32_t* __restrict__ ctr,
                                                             uint32_t* __restrict__ host, uint32_t seq,
-                                                            uint32_t* __restrict__ spec_fail) {
-  int left = 0, fin = 0;
+                                                            uint32_t* __restrict__ spec_fail,
+                                                            const uint32_t* __restrict__ seg_count) {
+  int left = 0, fin = 0, inst = 0;
   for (int t = threadIdx.x; t < ntiles; t += 256) {
     const bool on = user_mask[t] != 0, l = mask2[t] != 0;
     left += l ? 1 : 0;
     fin += (on && !l) ? 1 : 0;
+    if (seg_count) inst += (int)seg_count[t];      // one-pass placement: nobody scanned the counts, the total is summed here
   }
-  __shared__ int s_l[4], s_f[4];
+  __shared__ int s_l[4], s_f[4], s_i[4];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { left += __shfl_xor(left, off); fin += __shfl_xor(fin, off); }
-  if ((threadIdx.x & 63) == 0) { s_l[threadIdx.x >> 6] = left; s_f[threadIdx.x >> 6] = fin; }
+  for (int off = 32; off > 0; off >>= 1) { left += __shfl_xor(left, off); fin += __shfl_xor(fin, off); inst += __shfl_xor(inst, off); }
+  if ((threadIdx.x & 63) == 0) { s_l[threadIdx.x >> 6] = left; s_f[threadIdx.x >> 6] = fin; s_i[threadIdx.x >> 6] = inst; }
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t L = (uint32_t)(s_l[0] + s_l[1] + s_l[2] + s_l[3]), F = (uint32_t)(s_f[0] + s_f[1] + s_f[2] + s_f[3]);
     ctr[0] = L; ctr[1] = F;                      // device copy: pass 2's kernels exit at once when nothing is left
     if (spec_fail) *spec_fail = L != 0u ? 1u : 0u;   // speculative forward: the host assumed the slice finishes every tile
-    const uint32_t w[7] = {0u, 0u, L, F, r1[0], 0u, 0u};
+    const uint32_t R1 = seg_count ? (uint32_t)(s_i[0] + s_i[1] + s_i[2] + s_i[3]) : r1[0];
+    const uint32_t w[7] = {0u, 0u, L, F, R1, 0u, 0u};
     publish_to_host(host, w, seq);
   }
 }
 void launch_slice_publish(int ntiles, const int32_t* user_mask, const int32_t* mask2, const uint32_t* r1, uint32_t* ctr,
-                          uint32_t* host, uint32_t seq, uint32_t* spec_fail, hipStream_t st) {
-  hipLaunchKernelGGL(slice_publish_kernel, dim3(1), dim3(256), 0, st, ntiles, user_mask, mask2, r1, ctr, host, seq, spec_fail);
+                          uint32_t* host, uint32_t seq, uint32_t* spec_fail, hipStream_t st, const uint32_t* seg_count) {
+  hipLaunchKernelGGL(slice_publish_kernel, dim3(1), dim3(256), 0, st, ntiles, user_mask, mask2, r1, ctr, host, seq, spec_fail,
+                     seg_count);
 }
 
 void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,

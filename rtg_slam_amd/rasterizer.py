@@ -73,8 +73,12 @@ class RasterContext:
         _lib.load().rtgs_raster_force_sort_path_ctx(self.ptr, int(bool(enable)))
 
     def set_bwd_walk(self, mode: int):
-        """0 = blend_fwd chooses the backward's walk per tile (default), 1 = strip walk, 2 = row-granular walk."""
+        """0 / 3 = MFMA walk (default), 1 = strip walk, 2 = row-granular walk, 4 = per-tile choice of 1 / 2 (round 3)."""
         _lib.load().rtgs_raster_set_bwd_walk_ctx(self.ptr, int(mode))
+
+    def set_onepass(self, enable: bool):
+        """One-pass binning into per-tile segments (default on); off = count + scan + scatter.  Bit-identical outputs."""
+        _lib.load().rtgs_raster_set_onepass_ctx(self.ptr, int(bool(enable)))
 
     def set_speculation(self, enable: bool):
         """Speculative sizing of the forward inside the one-call map step (RTGS_FWD_SPECULATE); default on."""

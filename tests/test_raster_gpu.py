@@ -545,6 +545,51 @@ def test_near_slice_forward_is_bit_identical(cam, N, budget, masked):
     print("near slice:", dict(budget=budget, r1=r1, finished=fin, left=left))
 
 
+@pytest.mark.parametrize("budget,r_range,masked", [(384, (0.02, 0.12), True), (6000, (0.02, 0.12), False), (0, (0.01, 0.05), False)])
+def test_onepass_binning_is_bit_identical(budget, r_range, masked):
+    """One-pass placement into per-tile segments (bin_place_kernel; maps >= 100 k Gaussians) vs count + scan + scatter:
+    every forward output bit-identical (the tile sort's order is total), same slice statistics - with a slice that fits,
+    with one whose tile lists outgrow their segments (those tiles are left to pass 2 either way) and in automatic mode."""
+    from rtg_slam_amd import _lib
+    lib = _lib.load()
+    cam, N, dev = synth.CONFIG2, 120_000, "cuda:0"
+    g, s = ru.make_scene(N, cam, seed=7, pose_seed=None if budget == 6000 else 2, r_range=r_range)
+    if budget == 6000:
+        # 5 000 faint specks right in front of the camera (identity view), all on the four tiles round the principal
+        # point: their near-slice lists outgrow the 3 072-entry segment
+        n = 5000
+        gen0 = torch.Generator().manual_seed(11)
+        g["xyz"][:n] = torch.cat([(torch.rand(n, 2, generator=gen0) - 0.5) * 0.003, 0.3 + 0.01 * torch.rand(n, 1, generator=gen0)], 1)
+        g["scales"][:n] = 0.002
+        g["opacity"][:n] = 0.02
+    mask = None
+    if masked:
+        gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+        mask = (torch.rand(gy, gx, generator=torch.Generator().manual_seed(4)) < 0.7).int()
+    gen = torch.Generator().manual_seed(5)
+    grads = (torch.randn(3, cam.H, cam.W, generator=gen), torch.randn(1, cam.H, cam.W, generator=gen))
+    try:
+        lib.rtgs_raster_set_near_slice(1 if budget else 2, budget if budget else 384)
+        lib.rtgs_raster_set_onepass_ctx(None, 0)
+        out_a, gd_a = ru.hip_run(s, g, tile_mask=mask, grads=grads, dev=dev)
+        st_a = _slice_stats(lib)
+        lib.rtgs_raster_set_onepass_ctx(None, 1)
+        out_b, gd_b = ru.hip_run(s, g, tile_mask=mask, grads=grads, dev=dev)
+        st_b = _slice_stats(lib)
+    finally:
+        lib.rtgs_raster_set_near_slice(2, 384)
+        lib.rtgs_raster_set_onepass_ctx(None, 1)
+    assert st_a == st_b, (st_a, st_b)
+    for k, (a, b) in enumerate(zip(out_a, out_b)):
+        assert torch.equal(a, b), (k, st_a)
+    for k in ru.FIELDS:
+        scale = float(gd_a[k].abs().max()) + 1e-12
+        assert ru.frac_bad(gd_b[k], gd_a[k], 1e-4 * scale) < 1e-3, (k, st_a)
+    if budget == 6000:
+        assert st_a[3] >= 4, st_a          # overgrown lists: tiles left to pass 2
+    print("one-pass binning:", dict(budget=budget, slice=st_a))
+
+
 def test_near_slice_automatic_on_large_map():
     """Automatic mode: a 200 k map takes the two-pass forward; result identical to the single pass."""
     from rtg_slam_amd import _lib

@@ -82,16 +82,47 @@ def test_speculative_steps_equal_plain_steps(kind):
     assert on[2]["speculative"] >= 5, on[2]        # the first call(s) build the history, the rest speculate
 
 
-def test_a_failed_guess_changes_nothing_and_is_redone():
+@pytest.mark.parametrize("onepass", [False, True])
+def test_a_failed_guess_changes_nothing_and_is_redone(onepass):
     cam = MID
     g = synth.surface_gaussians(150_000, cam, seed=5)
     # three steps on a few tiles build the history (the first two cannot speculate: the slice's decision has to be
     # learnt first), then the instance total jumps by far more than the 12 % margin; the view changes too
     masks, poses = _masks(cam, [0.15, 0.15, 0.15, 1.0, 0.15, 1.0]), [1, 3, 5]
+    ctx = rz.current_context()
+    ctx.set_onepass(onepass)
+    try:
+        on = _run(g, cam, masks, poses, True, 12)
+        off = _run(g, cam, masks, poses, False, 12)
+    finally:
+        ctx.set_onepass(True)
+    _same(on, off)
+    if not onepass:     # count + scan + scatter sizes ONE buffer by the guessed total: the jump to the full mask overruns it
+        assert on[2]["failed"] >= 1, on[2]  # (afterwards the decaying maximum covers the loop)
+    # one-pass placement has no bound on the total - every tile owns a segment - so the jump is not a wrong guess there;
+    # what is one, is a tile list that outgrows its segment: next test
+
+
+def test_a_list_that_outgrows_its_segment_fails_the_guess_and_is_redone():
+    """One-pass placement (bin_place_kernel): the segment of a tile is the sort class of the last verified longest list.
+    2 500 faint specks sit on ONE tile that the first steps mask out; when the mask opens, that tile's list no longer
+    fits, the device word is raised by the placement itself, nothing persistent changes and the step is redone plainly."""
+    cam = MID
+    g = synth.surface_gaussians(150_000, cam, seed=5)
+    n = 2500
+    gen = torch.Generator().manual_seed(11)
+    g["xyz"][:n] = torch.cat([(torch.rand(n, 2, generator=gen) - 0.5) * 0.002, 0.5 + 0.01 * torch.rand(n, 1, generator=gen)], 1)
+    g["scales"][:n] = 0.002
+    g["opacity"][:n] = 0.02
+    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+    closed = torch.ones(gy, gx, dtype=torch.int32)
+    closed[int(cam.cy) // 16, int(cam.cx) // 16] = 0           # the tile under the principal point (identity view)
+    masks, poses = [closed, closed, closed, None, closed, None], [None]
     on = _run(g, cam, masks, poses, True, 12)
     off = _run(g, cam, masks, poses, False, 12)
     _same(on, off)
-    assert on[2]["failed"] >= 1, on[2]      # the jump to the full mask; afterwards the decaying maximum covers the loop
+    assert on[2]["failed"] >= 1, on[2]
+    assert on[2]["speculative"] >= 4, on[2]
 
 
 def test_pass_structure_change_is_caught():

@@ -48,3 +48,15 @@ sl = (C.c_int64 * 4)()
 lib.rtgs_raster_last_slice_stats(sl)
 print("near slice: used %d instances %d tiles finished %d left %d" % tuple(sl))
 print(which, f"iter {dt:.3f} ms (with per-iteration sync) |", " ".join(f"{n}={v * 1e3:.0f}us" for n, v in zip(names, acc)))
+lib.rtgs_raster_set_profiling(0)
+torch.cuda.synchronize()
+blocks = []
+for _ in range(5):
+    t0 = time.perf_counter()
+    for _ in range(100):
+        opt.step_slam(rs, gt_color, gt_depth, None, render_mask=rm)
+    torch.cuda.synchronize()
+    blocks.append((time.perf_counter() - t0) * 10)
+sp = (C.c_int64 * 3)()
+lib.rtgs_raster_speculation_stats_ctx(None, sp)
+print(which, "un-profiled iteration ms, 5 x 100:", " ".join(f"{b:.4f}" for b in blocks), "| speculation (ok, failed, not eligible):", list(sp))
