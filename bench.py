@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--gaussians", type=int, default=1_200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-surface", action="store_true", help="skip the surface-shaped 1.2 M scene leg")
+    ap.add_argument("--reserve-cus", type=int, default=32,
+                    help="compute units the mapper's stream leaves to the tracker (rtgs_stream_create_reserving; 0 = none): "
+                         "measured 0 / 16 / 24 / 32 / 40 / 64 -> 0.452 / 0.449 / 0.438 / 0.432 / 0.442 / 0.456 ms per unit")
     ap.add_argument("--mode", choices=["sparse", "sharded", "tileband"], default="sparse",
                     help="multi-GPU form of the map step (ignored on one GPU): sparse = every rank renders its own view, "
                          "gradient rows that exist are all-gathered (in-band counts, no host sync), identical Adam step on "
@@ -163,7 +166,10 @@ def main():
     # processes, SLAM/multiprocess/system.py): the tracker's kernels go to a second HIP stream, enqueued by a helper
     # thread - rtg_slam_amd/pipeline.py
     from rtg_slam_amd.pipeline import TrackMapPipeline
-    pipe = TrackMapPipeline(dev)
+    pipe = TrackMapPipeline(dev, reserve_cus=args.reserve_cus)
+    if pipe.mapper_stream is not None:       # everything this thread enqueues from here on: the mapper's masked stream
+        pipe.mapper_stream.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(pipe.mapper_stream)
 
     def track_stage():
         vp1, np1 = hicp.build_pyramids(d1, K, 3)
@@ -222,10 +228,13 @@ def main():
             torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         frame()
+    host_ms = []                                              # host time of every frame() call of the timed blocks (diagnostic)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        th = time.perf_counter()
         frame()
+        host_ms.append(1e3 * (time.perf_counter() - th))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -239,7 +248,9 @@ def main():
         barrier()
         tb = time.perf_counter()
         for _ in range(args.steps):
+            th = time.perf_counter()
             frame()
+            host_ms.append(1e3 * (time.perf_counter() - th))
         barrier()
         db = time.perf_counter() - tb
         if world > 1:
@@ -248,7 +259,44 @@ def main():
             db = float(t.item())
         block_ms.append(1e3 * db / args.steps)
 
+    # the unit taken apart (same K, world 1 only): what each stage costs on its own THROUGH the same plumbing
+    unit_parts = None
+    if world == 1:
+        def timed(fn):
+            for _ in range(5):
+                fn()
+            barrier()
+            tq = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            barrier()
+            return round(1e3 * (time.perf_counter() - tq) / args.steps, 4)
+
+        def track_via_pipe():
+            pipe.track(track_stage)
+            return pipe.result()
+
+        def track_direct():
+            with torch.cuda.stream(pipe.tracker_stream):
+                return track_stage()
+
+        def frame_inline():
+            cur = torch.cuda.current_stream(dev)
+            pipe.tracker_stream.wait_stream(cur)
+            with torch.cuda.stream(pipe.tracker_stream):
+                r = track_stage()
+            map_step()
+            cur.wait_stream(pipe.tracker_stream)
+            return r
+
+        unit_parts = {"both_tracker_enqueued_first_by_this_thread_ms": timed(frame_inline),
+                      "tracker_only_through_the_pipeline_ms": timed(track_via_pipe),
+                      "tracker_only_enqueued_by_this_thread_ms": timed(track_direct),
+                      "map_step_only_ms": timed(map_step), "both_ms": timed(frame)}
     opt.flush()
+    if pipe.mapper_stream is not None:       # the legs below time the mapper ALONE: back on an unmasked stream
+        torch.cuda.synchronize(dev)
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
     # Strong scaling of ONE view (a single SLAM stream has one frame per step): every rank takes a band of the tiles of
     # rank 0's view.  Map iterations only (no tracker), barrier-bracketed, max over ranks.  On one GPU this is the plain
     # map iteration - the number the N > 1 runs are to be compared with.
@@ -419,11 +467,13 @@ def main():
             "raster_fwd_ms": round(sum(stage[:6]) + sum(stage[8:10]), 4), "raster_bwd_ms": round(sum(stage[6:8]) + stage[10], 4),
             "raster_fwd_bwd_ms": round(sum(stage), 4), "icp_track_ms": round(icp_ms, 4),
             "raster_fwd_bwd_ms_30pct_tiles": round(sum(prof30["stage"]), 4),
-            "cold_first_frame_ms": round(cold_ms, 2), "prewarm_frames": args.prewarm,
+            "cold_first_frame_ms": round(cold_ms, 2), "prewarm_frames": args.prewarm, "mapper_reserved_cus": args.reserve_cus, "unit_parts": unit_parts,
             "unstable": bool(spread > 0.05),
             "repeats": {"blocks": len(block_ms), "spread_over_median": round(spread, 4), "ms_per_step": [round(x, 4) for x in block_ms],
                         "median_ms_per_step": round(bs[len(bs) // 2], 4), "min": round(bs[0], 4), "max": round(bs[-1], 4),
-                        "median_frames_per_sec": round(frames_per_step * 1e3 / bs[len(bs) // 2], 2)},
+                        "median_frames_per_sec": round(frames_per_step * 1e3 / bs[len(bs) // 2], 2),
+                        "slowest_host_frame_ms_per_block": [round(max(host_ms[i:i + args.steps]), 3)
+                                                            for i in range(0, len(host_ms), args.steps)]},
             "rccl_ranks": rccl_ranks,
             "frames_per_sec_replica_schedule": None if sched is None else sched["frames_per_sec"],
             "replica_schedule": sched,

@@ -44,6 +44,21 @@ int rtgs_icp_build_pyramids(const float* depth, int32_t H, int32_t W, const floa
                             float* const* vertex_out_host, float* const* normal_out_host,
                             void* scratch, void* stream);
 
+/* The tracker is a chain of ~20 short DEPENDENT launches; beside a mapper on another stream every launch costs
+ * dispatch latency, so the small memsets of the plain calls are avoidable launches on the frame's critical path:
+ * rtgs_icp_scratch_init arms a scratch ONCE (zero; both min / max sets to their neutral value); after that
+ *   rtgs_icp_build_pyramids_ex(flags = RTGS_ICP_PYR_SCRATCH_READY [| RTGS_ICP_PYR_SECOND_SET]) issues no memset - the
+ *     build uses one min / max set and re-arms the other for the NEXT build: the caller alternates SECOND_SET from call
+ *     to call on the same scratch;
+ *   rtgs_icp_track(flags | RTGS_ICP_FLAG_SCRATCH_READY) issues no memset either (launch-per-iteration form).
+ * Results are bit-identical to the plain calls. */
+int rtgs_icp_scratch_init(void* scratch, void* stream);
+#define RTGS_ICP_PYR_SCRATCH_READY 1
+#define RTGS_ICP_PYR_SECOND_SET 2
+int rtgs_icp_build_pyramids_ex(const float* depth, int32_t H, int32_t W, const float* K, int32_t levels,
+                               float* const* vertex_out_host, float* const* normal_out_host,
+                               void* scratch, int32_t flags, void* stream);
+
 /* One evaluation of the normal equations at `pose` (device float[16], row-major 4x4, maps
  * source-frame points into the target frame):
  *   JtJ_out[36], Jtr_out[6], nvalid_out[1] (float, number of valid correspondences) on device.
@@ -78,6 +93,9 @@ int rtgs_icp_track(const rtgs_icp_level* levels_host, int32_t n_levels, const fl
                    float distance_threshold, float cos_normal_threshold, float damping,
                    float* pose_inout, float* stats_out, void* scratch, int32_t flags, void* stream);
 #define RTGS_ICP_FLAG_PERSISTENT 1
+#define RTGS_ICP_FLAG_SCRATCH_READY 4   /* scratch armed by rtgs_icp_scratch_init and only ever used by these entry points */
+#define RTGS_ICP_FLAG_FROM_IDENTITY 8   /* the initial guess is the identity: pose_inout need not be initialised (saves the
+                                           caller two fill / copy launches) */
 #define RTGS_ICP_FLAG_CLUSTER 2     /* every level but the finest in one launch on a cluster of workgroups of ONE XCD (an
                                        in-XCD barrier per Gauss-Newton iteration), the finest level one launch per iteration */
 

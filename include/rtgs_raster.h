@@ -484,10 +484,23 @@ int rtgs_slam_normal_loss_range(const float* normal_w, const int32_t* depth_inde
                                 float* loss_out4, float* d_normal, uint8_t* row_state, const uint32_t* skip_flag,
                                 int32_t train_begin, int32_t train_end, void* stream);
 int rtgs_slam_map_step(const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
+/* A HIP stream whose CU mask leaves the last `reserve_cus` compute units of the current device unused - for the MAPPER of
+ * a tracker || mapper pipeline: the tracker's short dependent kernels then always find free wave slots.
+ * NULL on failure or when reserve_cus is not in (0, #CUs).  Destroy with rtgs_stream_destroy. */
+void* rtgs_stream_create_reserving(int32_t reserve_cus);
+void rtgs_stream_destroy(void* stream);
 /* The fused tail on its own (after the WALK of a backward, rtgs_raster_backward_walk_ctx): geom_buffer / image_buffer of
  * that forward, spec_fail = rtgs_raster_spec_fail_ptr_ctx() or NULL. */
 int rtgs_map_fused_tail(const rtgs_raster_settings* settings, const rtgs_map_step_args* args, void* geom_buffer,
                         const void* image_buffer, const uint32_t* spec_fail, uint32_t* live_counts2, void* stream);
+/* ... with the number of Gaussians the forward listed for binning (rtgs_raster_last_listed_ctx; 0 = unknown): sizes the
+ * kernel's row chunks - few live rows: few large chunks; many: many small ones.  RTGS_FUSED_CHUNK=512|1024|2048 forces. */
+int rtgs_map_fused_tail_hint(const rtgs_raster_settings* settings, const rtgs_map_step_args* args, void* geom_buffer,
+                             const void* image_buffer, const uint32_t* spec_fail, uint32_t* live_counts2,
+                             uint32_t listed_hint, void* stream);
+/* Gaussians the last VERIFIED speculative forward on the context listed for binning (near-slice work list, or the list of
+ * the visible ones when the slice was declined); 0 when unknown. */
+uint32_t rtgs_raster_last_listed_ctx(rtgs_ctx* ctx);
 /* Byte offsets of what a backward's walk leaves for a fused consumer: [0] clamp flags (u8[P], geometry buffer), [1] first
  * gradient slot per Gaussian (u32[P], geometry), [2] slots taken per Gaussian (u32[P], geometry), [3] BwdInfo (image
  * buffer), [4] touched bytes (u8[P], inside grad_scratch, behind the P SplatGrad records). */

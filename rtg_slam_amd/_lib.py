@@ -107,6 +107,10 @@ _SIGNATURES = {
     "rtgs_attach_prepare": (C.c_int, [_P, _P, C.POINTER(AttachC), C.c_int64, _P]),
     "rtgs_history_merge": (C.c_int, [_P] * 8 + [C.c_int64, C.c_float, _P]),
     "rtgs_map_fused_tail": (C.c_int, [C.POINTER(RasterSettingsC), C.POINTER(MapStepArgsC), _P, _P, _P, _P, _P]),
+    "rtgs_map_fused_tail_hint": (C.c_int, [C.POINTER(RasterSettingsC), C.POINTER(MapStepArgsC), _P, _P, _P, _P, C.c_uint32, _P]),
+    "rtgs_raster_last_listed_ctx": (C.c_uint32, [_P]),
+    "rtgs_stream_create_reserving": (C.c_void_p, [C.c_int]),
+    "rtgs_stream_destroy": (None, [_P]),
     "rtgs_raster_backward_buffers": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "rtgs_raster_last_buffers_ctx": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "rtgs_raster_set_aux_zero_ctx": (None, [_P, _P]),
@@ -160,6 +164,8 @@ _SIGNATURES = {
     "rtgs_slam_map_step_ctx": (C.c_int, [_P, C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_slam_map_step_front_ctx": (C.c_int, [_P, C.POINTER(MapStepArgsC), C.POINTER(C.c_int64), _P]),
     "rtgs_icp_build_pyramids": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P), _P, _P]),
+    "rtgs_icp_build_pyramids_ex": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P), _P, C.c_int32, _P]),
+    "rtgs_icp_scratch_init": (C.c_int, [_P, _P]),
     "rtgs_icp_step": (C.c_int, [_P] * 4 + [C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "rtgs_icp_track": (C.c_int, [C.POINTER(IcpLevelC), C.c_int32, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P,
                                  C.c_int32, _P]),

@@ -22,7 +22,20 @@ struct Scratch {
   uint32_t pad[15];                           // pad[0]: abort flag of the persistent track kernel
   double sums[24 * 8 * PSTRIDE];              // persistent track: 8 rows of float64 totals per grid barrier
   unsigned long long dbg[96];                 // RTGS_ICP_DEBUG_TIMING=1: wall-clock stamps of workgroup 0 (5 per barrier)
+  uint32_t minmax_b[2 * RTGS_ICP_MAX_LEVELS]; // second set: a build re-arms the set the NEXT build uses (no memset launch)
 };
+
+// The tracker's kernels are a chain the frame waits for; beside the mapper (VALU-issue-bound tile walks on every SIMD)
+// their waves would take turns with five or six others.  Raising the wave's issue priority (s_setprio, an SQ arbitration
+// hint) lets the chain through; the mapper has the slack.  RTGS_ICP_WAVE_PRIO=0 at build time turns it off.
+#ifndef RTGS_ICP_WAVE_PRIO
+#define RTGS_ICP_WAVE_PRIO 3
+#endif
+__device__ __forceinline__ void wave_priority_high() {
+#if RTGS_ICP_WAVE_PRIO > 0
+  __builtin_amdgcn_s_setprio(RTGS_ICP_WAVE_PRIO);
+#endif
+}
 
 __device__ __forceinline__ uint32_t enc_f(float f) {
   const uint32_t u = __float_as_uint(f);
@@ -39,6 +52,8 @@ struct PyrDesc {
   int block_start[RTGS_ICP_MAX_LEVELS + 1];
   float* vertex[RTGS_ICP_MAX_LEVELS];
   float* normal[RTGS_ICP_MAX_LEVELS];
+  uint32_t* mm;                               // this build's min / max words
+  uint32_t* mm_rearm;                         // nullable: the other set, re-armed (0xffffffff) for the next build
 };
 
 // ---- K10: max-pool depth pyramid + back-projection (SLAM/utils.py:511-521, :65-75) ------------
@@ -84,7 +99,8 @@ __global__ void __launch_bounds__(256) icp_vertex_kernel(PyrDesc d, const float*
     }
   }
   __syncthreads();
-  if (threadIdx.x < 2 * d.levels && s_mm[threadIdx.x] != 0xffffffffu) atomicMin(&sc->minmax[threadIdx.x], s_mm[threadIdx.x]);
+  if (threadIdx.x < 2 * d.levels && s_mm[threadIdx.x] != 0xffffffffu) atomicMin(&d.mm[threadIdx.x], s_mm[threadIdx.x]);
+  if (d.mm_rearm && blockIdx.x == 0 && threadIdx.x < 2 * d.levels) d.mm_rearm[threadIdx.x] = 0xffffffffu;
 }
 
 // ---- K10, three levels in ONE pass: a lane owns a 4x4 block of the full-resolution depth (four 16-B row loads when the
@@ -98,6 +114,7 @@ __device__ __forceinline__ void vertex_of(float* __restrict__ out, int x, int y,
 }
 __global__ void __launch_bounds__(256) icp_vertex3_kernel(PyrDesc d, const float* __restrict__ depth,
                                                           const float* __restrict__ K, Scratch* sc) {
+  wave_priority_high();
   __shared__ uint32_t s_mm[6];
   if (threadIdx.x < 6) s_mm[threadIdx.x] = 0xffffffffu;
   __syncthreads();
@@ -187,12 +204,14 @@ __global__ void __launch_bounds__(256) icp_vertex3_kernel(PyrDesc d, const float
     if ((threadIdx.x & 63) == 0 && a != 0xffffffffu) { atomicMin(&s_mm[2 * l], a); atomicMin(&s_mm[2 * l + 1], bq); }
   }
   __syncthreads();
-  if (threadIdx.x < 6 && s_mm[threadIdx.x] != 0xffffffffu) atomicMin(&sc->minmax[threadIdx.x], s_mm[threadIdx.x]);
+  if (threadIdx.x < 6 && s_mm[threadIdx.x] != 0xffffffffu) atomicMin(&d.mm[threadIdx.x], s_mm[threadIdx.x]);
+  if (d.mm_rearm && blockIdx.x == 0 && threadIdx.x < 6) d.mm_rearm[threadIdx.x] = 0xffffffffu;
 }
 
 // ---- K11: Sobel normals (SLAM/utils.py:77-122): replicate pad, cross(dy, dx), / (|n| + 1e-8),
 //      zero where depth <= min or depth >= max --------------------------------------------------
 __global__ void __launch_bounds__(256) icp_normal_kernel(PyrDesc d, const Scratch* sc) {
+  wave_priority_high();
   int l = 0;
   while (l + 1 < d.levels && (int)blockIdx.x >= d.block_start[l + 1]) ++l;
   const int Hl = d.Hl[l], Wl = d.Wl[l];
@@ -220,7 +239,7 @@ __global__ void __launch_bounds__(256) icp_normal_kernel(PyrDesc d, const Scratc
   const float mag = sqrtf(__fmaf_rn(nz, nz, __fmaf_rn(ny, ny, nx * nx))) + 1e-8f;
   nx /= mag; ny /= mag; nz /= mag;
   const float dep = V[(size_t)idx * 3 + 2];
-  const float dmin = dec_f(sc->minmax[2 * l]), dmax = dec_f(~sc->minmax[2 * l + 1]);
+  const float dmin = dec_f(d.mm[2 * l]), dmax = dec_f(~d.mm[2 * l + 1]);
   if (dep <= dmin || dep >= dmax) { nx = 0.f; ny = 0.f; nz = 0.f; }
   float* N = d.normal[l] + (size_t)idx * 3;
   N[0] = nx; N[1] = ny; N[2] = nz;
@@ -295,6 +314,8 @@ struct FinalArgs {
   float* JtJ_out;
   float* Jtr_out;
   float* nvalid_out;
+  int first;       // bit 0: first iteration of a track (the last arriver clears the failure counters - no memset launch);
+                   // bit 1: the track starts from the identity (`pose` is not read before the last arriver writes it)
 };
 
 // Sum of the per-workgroup partial rows in float64, by ONE whole workgroup (256 threads); the 28 totals land in
@@ -465,6 +486,11 @@ __device__ __forceinline__ void final_stage(const float* __restrict__ partials, 
     fa.nvalid_out[0] = (float)S[27];
     return;
   }
+  if (fa.first & 1) { fa.stats[1] = 0.f; fa.stats[2] = 0.f; fa.stats[3] = 0.f; }
+  if (fa.first & 2) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) fa.pose[k] = (k % 5 == 0) ? 1.f : 0.f;
+  }
   fa.stats[0] = (float)(S[27] * (double)fa.inv_pixels);            // valid_ratio (icp.py:46-47)
   if (!gn_update(S, fa.damping, fa.pose)) fa.stats[2] += 1.f;
 }
@@ -540,6 +566,8 @@ __device__ __forceinline__ void accumulate_pixel(const LevelGeom& g, float v0, f
   acc[27] += 1.f;
 }
 
+__device__ const float c_identity[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
+
 __device__ __forceinline__ LevelGeom make_geom(const float* pose, const float* __restrict__ K, float ds, int H, int W,
                                                float dist_thr, float cos_thr) {
   LevelGeom g;
@@ -582,7 +610,8 @@ __global__ void __launch_bounds__(256) icp_reduce_kernel(
     const float* __restrict__ nt, int H, int W, const float* __restrict__ K, float ds,
     const float* __restrict__ pose, float dist_thr, float cos_thr, float* __restrict__ partials,
     uint32_t* __restrict__ ticket, FinalArgs fa) {
-  const LevelGeom g = make_geom(pose, K, ds, H, W, dist_thr, cos_thr);
+  wave_priority_high();
+  const LevelGeom g = make_geom((fa.first & 2) ? c_identity : pose, K, ds, H, W, dist_thr, cos_thr);
   float acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
@@ -596,6 +625,7 @@ __global__ void __launch_bounds__(256) icp_p2p_kernel(const float* __restrict__ 
                                                       const float* __restrict__ nt, int n,
                                                       const float* __restrict__ pose, float* __restrict__ partials,
                                                       uint32_t* __restrict__ ticket, FinalArgs fa) {
+  wave_priority_high();
   const float R00 = pose[0], R01 = pose[1], R02 = pose[2], t0 = pose[3];
   const float R10 = pose[4], R11 = pose[5], R12 = pose[6], t1 = pose[7];
   const float R20 = pose[8], R21 = pose[9], R22 = pose[10], t2 = pose[11];
@@ -800,6 +830,22 @@ size_t rtgs_icp_scratch_bytes(void) { return sizeof(Scratch); }
 
 int rtgs_icp_build_pyramids(const float* depth, int32_t H, int32_t W, const float* K, int32_t levels,
                             float* const* vertex_out, float* const* normal_out, void* scratch, void* stream) {
+  return rtgs_icp_build_pyramids_ex(depth, H, W, K, levels, vertex_out, normal_out, scratch, 0, stream);
+}
+
+int rtgs_icp_scratch_init(void* scratch, void* stream) {
+  if (!scratch) return -1;
+  Scratch* sc = (Scratch*)scratch;
+  hipStream_t st = (hipStream_t)stream;
+  ICP_TRY(hipMemsetAsync(sc, 0, sizeof(Scratch), st));
+  ICP_TRY(hipMemsetAsync(sc->minmax, 0xff, sizeof(sc->minmax), st));
+  ICP_TRY(hipMemsetAsync(sc->minmax_b, 0xff, sizeof(sc->minmax_b), st));
+  return 0;
+}
+
+int rtgs_icp_build_pyramids_ex(const float* depth, int32_t H, int32_t W, const float* K, int32_t levels,
+                               float* const* vertex_out, float* const* normal_out, void* scratch, int32_t flags,
+                               void* stream) {
   if (!depth || !K || !vertex_out || !normal_out || !scratch || H <= 0 || W <= 0 || levels < 1 ||
       levels > RTGS_ICP_MAX_LEVELS)
     return -1;
@@ -817,7 +863,14 @@ int rtgs_icp_build_pyramids(const float* depth, int32_t H, int32_t W, const floa
     blocks += (d.Hl[l] * d.Wl[l] + 255) / 256;
   }
   d.block_start[levels] = blocks;
-  ICP_TRY(hipMemsetAsync(sc->minmax, 0xff, sizeof(sc->minmax), st));
+  if (flags & RTGS_ICP_PYR_SCRATCH_READY) {       // both sets were armed once (rtgs_icp_scratch_init): use one, re-arm the other
+    const bool second = (flags & RTGS_ICP_PYR_SECOND_SET) != 0;
+    d.mm = second ? sc->minmax_b : sc->minmax;
+    d.mm_rearm = second ? sc->minmax : sc->minmax_b;
+  } else {
+    d.mm = sc->minmax; d.mm_rearm = nullptr;
+    ICP_TRY(hipMemsetAsync(sc->minmax, 0xff, sizeof(sc->minmax), st));
+  }
   // the one-pass kernel moves 16-byte rows: it needs the depth image and the vertex maps 16-byte aligned (torch
   // allocations are; a view with a storage offset may not be) - anything else takes the scalar kernel
   uintptr_t align_bits = (uintptr_t)depth;
@@ -859,8 +912,10 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
     if (!L.vertex_src || !L.normal_src || !L.vertex_tgt || !L.normal_tgt || L.H <= 0 || L.W <= 0 || L.iters < 0)
       return -1;
   }
-  ICP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
-  ICP_TRY(hipMemsetAsync(&sc->ticket, 0, 2 * sizeof(uint32_t), st));       // ticket + abort flag
+  // launch-per-iteration form on a scratch that was initialised once (RTGS_ICP_FLAG_SCRATCH_READY): no memset launches -
+  // the ticket is re-armed by every last arriver, the failure counters are cleared by the first iteration's
+  const bool ready = (flags & RTGS_ICP_FLAG_SCRATCH_READY) != 0;
+  const bool from_identity = (flags & RTGS_ICP_FLAG_FROM_IDENTITY) != 0;
   // Two forms, same arithmetic.  One launch per Gauss-Newton iteration (default): 16 short kernels that leave the GPU
   // to whatever else is queued between them - measured best when the tracker overlaps the map optimisation on another
   // stream (1 690 vs 1 511 frames/s in bench.py).  One persistent kernel (RTGS_ICP_FLAG_PERSISTENT, or the environment
@@ -868,6 +923,17 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
   // 1200x680 track), but its resident, mostly waiting workgroups slow co-running kernels down.
   static const int env_persistent = [] { const char* e = getenv("RTGS_ICP_PERSISTENT"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
   const bool persistent = env_persistent >= 0 ? env_persistent == 1 : (flags & RTGS_ICP_FLAG_PERSISTENT) != 0;
+  static const int env_cluster = [] { const char* e = getenv("RTGS_ICP_CLUSTER"); return e ? atoi(e) : -1; }();
+  const int cluster = env_cluster >= 0 ? env_cluster : ((flags & RTGS_ICP_FLAG_CLUSTER) ? 64 : 0);
+  const bool plain = !persistent && !(cluster > 0 && n_levels >= 2);
+  if (!(plain && ready)) {
+    ICP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
+    ICP_TRY(hipMemsetAsync(&sc->ticket, 0, 2 * sizeof(uint32_t), st));       // ticket + abort flag
+  }
+  if (from_identity && !plain) {                   // the one-kernel forms read the pose: give them the identity
+    static const float eye[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
+    ICP_TRY(hipMemcpyAsync(pose, eye, sizeof(eye), hipMemcpyHostToDevice, st));
+  }
   if (persistent) {
     int dev = 0, cus = 0;
     ICP_TRY(hipGetDevice(&dev));
@@ -887,6 +953,8 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
     static const bool dbg_timing = [] { const char* e = getenv("RTGS_ICP_DEBUG_TIMING"); return e && atoi(e) != 0; }();
     a.dbg = dbg_timing ? sc->dbg : nullptr;
     hipLaunchKernelGGL(icp_track_kernel, dim3(G), dim3(256), 0, st, a);
+    // leave the scratch ARMED (ticket = 0, no abort) for a later launch-per-iteration track that skips its memsets
+    ICP_TRY(hipMemsetAsync(&sc->ticket, 0, 2 * sizeof(uint32_t), st));
     ICP_TRY(hipGetLastError());
     return 0;
   }
@@ -894,8 +962,6 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
   // and 204 k pixels at 1200x680 - in ONE launch on a cluster of workgroups of one XCD, with a barrier inside the XCD per
   // iteration instead of a kernel boundary, a 50-200-way ticket fan-in and a relaunch; the finest level keeps one launch
   // per iteration (816 k pixels want the whole chip).
-  static const int env_cluster = [] { const char* e = getenv("RTGS_ICP_CLUSTER"); return e ? atoi(e) : -1; }();
-  const int cluster = env_cluster >= 0 ? env_cluster : ((flags & RTGS_ICP_FLAG_CLUSTER) ? 64 : 0);
   int first_launched = 0;
   if (cluster > 0 && n_levels >= 2) {
     TrackArgs a{};
@@ -915,6 +981,7 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
     ICP_TRY(hipMemsetAsync(&sc->ticket, 0, sizeof(uint32_t), st));       // the launches below elect their last arriver from 0
     first_launched = n_levels - 1;
   }
+  bool launched_any = false;
   for (int l = first_launched; l < n_levels; ++l) {
     const rtgs_icp_level& L = lv[l];
     // a lane takes FOUR pixels (accumulate_range): one workgroup per 1024 pixels - at the coarse levels that is 50 / 200
@@ -922,11 +989,21 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
     // last arriver to collect
     const int g = grid_for((L.H * L.W + 3) / 4);
     const float inv = 1.f / ((float)L.H * (float)L.W);
-    FinalArgs fa{(int)MODE_SOLVE, damping, inv, pose, stats, nullptr, nullptr, nullptr};
-    for (int it = 0; it < L.iters; ++it)   // ONE launch per Gauss-Newton iteration: residuals + solve + pose update
+    FinalArgs fa{(int)MODE_SOLVE, damping, inv, pose, stats, nullptr, nullptr, nullptr, 0};
+    for (int it = 0; it < L.iters; ++it) {   // ONE launch per Gauss-Newton iteration: residuals + solve + pose update
+      fa.first = (plain && !launched_any) ? (1 | (from_identity ? 2 : 0)) : 0;
+      launched_any = true;
       hipLaunchKernelGGL(icp_reduce_kernel, dim3(g), dim3(256), 0, st, L.vertex_src, L.normal_src, L.vertex_tgt,
                          L.normal_tgt, L.H, L.W, K, L.downscale, (const float*)pose, dist_thr, cos_thr, sc->partials,
                          &sc->ticket, fa);
+    }
+  }
+  if (plain && !launched_any) {                    // no iteration anywhere: nobody cleared / initialised anything
+    ICP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
+    if (from_identity) {
+      static const float eye0[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
+      ICP_TRY(hipMemcpyAsync(pose, eye0, sizeof(eye0), hipMemcpyHostToDevice, st));
+    }
   }
   const rtgs_icp_level& F = lv[n_levels - 1];
   const int n = F.H * F.W;

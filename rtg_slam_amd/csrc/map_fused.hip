@@ -54,13 +54,18 @@ struct FusedArgs {
   int t0, rows;                  // the trainable rows [t0, t0 + rows)
 };
 
-constexpr int FCHUNK = 1024;     // rows a workgroup compacts per pass
+// Rows a workgroup compacts per pass - chosen per launch (fused_chunk below).  The kernel holds 2 waves per SIMD (512
+// workgroups resident), and a pass is a chain of dependent memory round trips whatever it holds: few live rows (the
+// headline map: 4.5 k of 1.2 M) want FEW, LARGE chunks - 586 of 2 048 rows are about one resident round, 341 us per
+// iteration against 357 at 1 024 and 375 at 512; many live rows (the surface map: 209 k) want MANY SMALL ones for the
+// balance of the last round - 0.643 ms at 512 against 0.657 at 1 024 / 2 048 and 0.72 at 4 096 (profiles/r04_fused_tail_variants.txt).
 constexpr int BIG_RUN = 8;       // slot runs longer than this are summed by the whole wave
 
 __device__ __forceinline__ bool attach_sel(const float4 init_lo) {
   return 1.f / (1.f + __expf(-init_lo.x)) < 0.9f;                // opacity_activation(init_stat["opacity"]) < 0.9 (map_ops.hip)
 }
 
+template <int FCHUNK>
 __global__ void __launch_bounds__(256) map_fused_tail_kernel(FusedArgs a) {
   __shared__ uint32_t s_list[FCHUNK];
   __shared__ uint32_t s_n;
@@ -77,11 +82,19 @@ __global__ void __launch_bounds__(256) map_fused_tail_kernel(FusedArgs a) {
     if (tid == 0) s_n = 0;
     __syncthreads();
     // ---- the live rows of this chunk, compacted (four byte reads per row)
+    // all flag bytes of the chunk in flight at once (inside the loop below each row's four loads waited for the
+    // previous row's ballot: a round trip to memory per 256 rows)
+    uint32_t flags = 0;
+#pragma unroll
+    for (int k = 0; k < FCHUNK / 256; ++k) {
+      const int rl = min(c0 + k * 256 + tid, a.rows - 1);
+      const uint32_t f = (uint32_t)a.touched[a.t0 + rl] | (uint32_t)a.ever_raw8[rl] | (uint32_t)a.ever_xyz[rl] | (uint32_t)a.ever_shs[rl];
+      flags |= (f != 0u ? 1u : 0u) << k;
+    }
 #pragma unroll
     for (int k = 0; k < FCHUNK / 256; ++k) {
       const int rl = c0 + k * 256 + tid;                       // row relative to t0
-      bool work = false;
-      if (rl < a.rows) work = (a.touched[a.t0 + rl] != 0) | (a.ever_raw8[rl] != 0) | (a.ever_xyz[rl] != 0) | (a.ever_shs[rl] != 0);
+      const bool work = rl < a.rows && ((flags >> k) & 1u) != 0u;
       const unsigned long long m = __builtin_amdgcn_ballot_w64(work);
       if (m == 0ull) continue;
       uint32_t base = 0;
@@ -293,6 +306,12 @@ __global__ void __launch_bounds__(256) map_fused_tail_kernel(FusedArgs a) {
 
 extern "C" int rtgs_map_fused_tail(const rtgs_raster_settings* settings, const rtgs_map_step_args* s, void* geom_buffer,
                                    const void* image_buffer, const uint32_t* spec_fail, uint32_t* live_counts2, void* stream) {
+  return rtgs_map_fused_tail_hint(settings, s, geom_buffer, image_buffer, spec_fail, live_counts2, 0, stream);
+}
+
+extern "C" int rtgs_map_fused_tail_hint(const rtgs_raster_settings* settings, const rtgs_map_step_args* s, void* geom_buffer,
+                                        const void* image_buffer, const uint32_t* spec_fail, uint32_t* live_counts2,
+                                        uint32_t listed_hint, void* stream) {
   using namespace rtgs;
   if (!settings || !s || !geom_buffer || !image_buffer) return RTGS_E_INVALID;
   const int32_t P = s->P;
@@ -341,8 +360,19 @@ extern "C" int rtgs_map_fused_tail(const rtgs_raster_settings* settings, const r
   a.act_opacity = s->opacity; a.act_scales = s->scales; a.act_normal = s->normal; a.act_rots = (float4*)s->rotations;
   a.live_counts = live_counts2;
   a.t0 = t0; a.rows = t1 - t0;
-  int blocks = (a.rows + FCHUNK - 1) / FCHUNK;
+  // chunk size from the number of Gaussians the last verified forward LISTED for binning (the rows with gradient are among
+  // them; 0 = unknown): the largest chunk that still expects at most one wave pass (64 live rows) per workgroup
+  static const int forced = [] { const char* e = getenv("RTGS_FUSED_CHUNK"); return e ? atoi(e) : 0; }();
+  int chunk = 1024;
+  if (forced == 512 || forced == 1024 || forced == 2048) chunk = forced;
+  else if (listed_hint > 0u) {
+    const double per_row = (double)listed_hint / (double)(P > 0 ? P : 1);
+    chunk = per_row * 2048.0 <= 64.0 ? 2048 : (per_row * 1024.0 <= 64.0 ? 1024 : 512);
+  }
+  int blocks = (a.rows + chunk - 1) / chunk;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(map_fused_tail_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (chunk == 2048) hipLaunchKernelGGL(map_fused_tail_kernel<2048>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else if (chunk == 512) hipLaunchKernelGGL(map_fused_tail_kernel<512>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(map_fused_tail_kernel<1024>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? RTGS_OK : RTGS_E_HIP;
 }

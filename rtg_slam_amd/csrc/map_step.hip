@@ -3,6 +3,8 @@
 // row-state rasterizer backward -> activation backward + row-skipping Adam on the three block tensors (one kernel).
 // Nothing new is computed here - it is the sequence map_optim.ShardedMapOptimizer.step() issues through autograd,
 // without the per-launch Python / autograd cost (which exceeds the GPU time of the step on a 1.2 M map).
+#include <hip/hip_runtime.h>
+
 #include "../../include/rtgs_raster.h"
 
 // Everything up to and including the rasterizer backward: the gradient rows are in the arena, nothing is stepped yet.
@@ -74,7 +76,8 @@ static int map_step_once(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* nu
   if (fused) {
     void* bufs[3];
     if (rtgs_raster_last_buffers_ctx(ctx, bufs) != RTGS_OK) return RTGS_E_ALLOC;
-    return rtgs_map_fused_tail(a->settings, a, bufs[0], bufs[2], rtgs_raster_spec_fail_ptr_ctx(ctx), a->live_counts, stream);
+    return rtgs_map_fused_tail_hint(a->settings, a, bufs[0], bufs[2], rtgs_raster_spec_fail_ptr_ctx(ctx), a->live_counts,
+                                    rtgs_raster_last_listed_ctx(ctx), stream);
   }
   const int32_t P = a->P;
   // activation backward (+ attach gradient) + Adam on the three block tensors (+ confidence increment), one launch;
@@ -110,3 +113,25 @@ extern "C" int rtgs_slam_map_step(const rtgs_map_step_args* a, int64_t* num_rend
 // binding's side at load time.
 extern "C" size_t rtgs_map_step_args_size(void) { return sizeof(rtgs_map_step_args); }
 extern "C" size_t rtgs_raster_settings_size(void) { return sizeof(rtgs_raster_settings); }
+
+// ---- a stream for the mapper that leaves some compute units to the tracker ---------------------------------------------
+// Tracker || mapper on two streams (rtg_slam_amd/pipeline.py): the tracker is a chain of ~20 short dependent kernels, the
+// mapper a chain of long ones with thousands of workgroups.  Priority only orders DISPATCH: a tracker kernel that becomes
+// ready still waits for the mapper's resident workgroups to retire before it finds wave slots (icp_reduce: 16 us alone,
+// 24 us beside the mapper - and the frame waits for the tracker).  A mapper stream whose CU mask excludes `reserve_cus`
+// compute units keeps those free: the tracker's workgroups start at once there (and anywhere else a slot opens).
+extern "C" void* rtgs_stream_create_reserving(int32_t reserve_cus) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return nullptr;
+  if (reserve_cus <= 0 || reserve_cus >= cus || cus > 1024) return nullptr;
+  uint32_t mask[32] = {0};
+  const int words = (cus + 31) / 32;
+  for (int i = 0; i < cus - reserve_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+  hipStream_t s = nullptr;
+  if (hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask) != hipSuccess) return nullptr;
+  return (void*)s;
+}
+extern "C" void rtgs_stream_destroy(void* stream) {
+  if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+}

@@ -73,6 +73,7 @@ struct rtgs_ctx {
   int slice_budget = 384;
   int64_t slice_stats[4] = {0};     // used, near-slice instances, tiles finished, tiles left to pass 2
   unsigned long long* counters = nullptr;
+  uint32_t last_listed = 0;         // Gaussians the last verified speculative forward listed for binning
   bool onepass = true;              // one-pass placement into per-tile segments where the layout provides them
   bool prof = false;                // optional per-stage HIP-event timing (bench.py's roofline leg)
   bool force_sort_path = false;     // testing aid: take the global radix-sort binning path
@@ -573,7 +574,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
           launch_bin_place(pg, splats, radii, tile_mask, tile_count, (unsigned long long*)(bin + B.keys_a), seg2, fail, sel2, vl,
                            (size_t)P, st);
           prof_mark(c, EV_SCAN, st); prof_mark(c, EV_BIN0, st); prof_mark(c, EV_EMIT, st);
-          const BinFinish fin{tile_count, ntiles, info, info_host, slice_ctr + 5, nullptr, c->seq,
+          const BinFinish fin{tile_count, ntiles, info, info_host, slice_ctr + 5, nullptr, slice_ctr + 4, c->seq,
                               SpecCaps{fail, 0xffffffffu, capL, capS, (const int32_t*)(slice_ctr + 3)}};
           launch_bin_tilesort(ntiles, capL, ranges, (const unsigned long long*)(bin + B.keys_a), (uint32_t*)(bin + B.vals_b), fail, st,
                               tile_count, seg2, ranges, &fin);
@@ -982,10 +983,12 @@ int rtgs_raster_forward_verify_ctx(rtgs_ctx* ctx, int64_t* num_rendered_host) {
     const uint32_t n_left = pub[2];
     ok = n_left == 0u;
     pl.R1 = pub[4]; pl.n_fin = pub[3]; pl.R = 0; pl.longest = 0;
+    c->last_listed = pub[0];
     c->slice_stats[1] = pub[4]; c->slice_stats[2] = pub[3]; c->slice_stats[3] = n_left;
   } else {
     ok = pub[0] <= c->spec.capR && pub[1] <= c->spec.capL && pub[5] <= c->spec.capS && (c->spec.kind != 2 || (int32_t)pub[6] < 0);
     pl.note(pub[0], pub[1], pub[5]); pl.R1 = 0;
+    c->last_listed = pub[2];
   }
   c->stats[0] = (int64_t)pl.R + (int64_t)pl.R1; c->stats[1] = 32 + bits_for((uint32_t)c->spec.ntiles); c->stats[2] = c->spec.ntiles;
   c->stats[3] = c->spec.G_total; c->stats[4] = c->spec.B_total; c->stats[5] = c->spec.I_total; c->stats[6] = 1;
@@ -1008,6 +1011,7 @@ int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
   memcpy(out3, use(ctx)->spec_stats, sizeof(use(ctx)->spec_stats));
   return RTGS_OK;
 }
+uint32_t rtgs_raster_last_listed_ctx(rtgs_ctx* c) { return use(c)->last_listed; }
 void rtgs_raster_set_onepass_ctx(rtgs_ctx* c, int on) { use(c)->onepass = on != 0; use(c)->plan.valid = false; }
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode >= 1 && mode <= 4) ? mode : 0; }
 void rtgs_raster_set_aux_zero_ctx(rtgs_ctx* ctx, void* eight_words) { use(ctx)->aux_zero = (uint32_t*)eight_words; }

@@ -366,13 +366,20 @@ __global__ void __launch_bounds__(256) bin_place_kernel(RasterParams p, const Sp
     parked += (uint32_t)__popcll(m);
   });
   __syncthreads();
-  for (int t = threadIdx.x; t < ntiles; t += BLOCK) {
-    const uint32_t c = s_cnt[t];
-    if (c) {
-      const uint32_t base = atomicAdd(&sb.count[t], c);
-      s_cnt[t] = base;
-      if (base + c > sb.seg && sb.fail) *sb.fail = 1u;
-    }
+  // reservations: eight returning atomics in flight per thread (issued one at a time each costs a round trip to the
+  // memory side: 13 of them per thread were most of this kernel)
+  for (int t0 = threadIdx.x; t0 < ntiles; t0 += BLOCK * 8) {
+    uint32_t c[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int t = t0 + k * BLOCK; c[k] = t < ntiles ? s_cnt[t] : 0u; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b[k] = c[k] ? atomicAdd(&sb.count[t0 + k * BLOCK], c[k]) : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (c[k]) {
+        s_cnt[t0 + k * BLOCK] = b[k];
+        if (b[k] + c[k] > sb.seg && sb.fail) *sb.fail = 1u;
+      }
   }
   __syncthreads();
   const uint32_t n = min(parked, (uint32_t)stage_cap);
@@ -416,7 +423,7 @@ __device__ __forceinline__ void bin_finish(const BinFinish& f) {
   if (f.caps.fail && (R > f.caps.R || longest > f.caps.longest || slots_total > f.caps.slots || (f.caps.cut && cut >= 0)))
     *f.caps.fail = 1u;                           // only ever raised here: bin_place may have raised it already
   if (f.info_host) {
-    const uint32_t w[7] = {R, longest, 0u, 0u, 0u, slots_total, (uint32_t)cut};
+    const uint32_t w[7] = {R, longest, f.listed ? f.listed[0] : 0u, 0u, 0u, slots_total, (uint32_t)cut};
     publish_to_host(f.info_host, w, f.seq);
   }
 }
@@ -579,7 +586,10 @@ int bin_sort_capacity() { return 16384; }            // 16384 x 8 B = 128 KiB
 
 // Gaussians per workgroup: the whole map by index -> GPB; the near slice's short list (<= 65 536 ids, each covering tens
 // of tiles) -> small work items, many workgroups; the list of every visible Gaussian -> one wave's worth per wave
-constexpr int LIST_GPB = 256;
+#ifndef RTGS_LIST_GPB
+#define RTGS_LIST_GPB 256
+#endif
+constexpr int LIST_GPB = RTGS_LIST_GPB;
 static inline int list_gpb(const SliceList& list, size_t max_items) {
   return !list.ids ? GPB : (max_items > 65536 ? LIST_GPB : SLICE_GPB);
 }
@@ -680,11 +690,19 @@ __global__ void __launch_bounds__(256) slice_compact_kernel(int P, SliceSel sel,
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int begin = blockIdx.x * COMPACT_CHUNK;
-  for (int i0 = begin; i0 < begin + COMPACT_CHUNK && i0 < P; i0 += 256 * 4) {
-    const int i = i0 + (int)threadIdx.x * 4;
+  uint32_t zall[COMPACT_CHUNK / 1024];             // the chunk's depth bins, all loads in flight before the first ballot
+#pragma unroll
+  for (int j = 0; j < COMPACT_CHUNK / 1024; ++j) {
+    const int i = begin + j * 1024 + (int)threadIdx.x * 4;
     uint32_t zb4 = 0xffffffffu;
     if (i + 4 <= P) zb4 = *reinterpret_cast<const uint32_t*>(sel.zbin + i);
     else for (int k = 0; k < 4; ++k) if (i + k < P) zb4 = (zb4 & ~(0xffu << (8 * k))) | ((uint32_t)sel.zbin[i + k] << (8 * k));
+    zall[j] = zb4;
+  }
+#pragma unroll
+  for (int j = 0; j < COMPACT_CHUNK / 1024; ++j) {
+    const int i = begin + j * 1024 + (int)threadIdx.x * 4;
+    const uint32_t zb4 = zall[j];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int zb = (int)((zb4 >> (8 * k)) & 0xffu);
@@ -881,7 +899,7 @@ void launch_bin_tilesort(int ntiles, uint32_t longest, const uint2* ranges, cons
                          uint32_t* point_list, const uint32_t* spec_fail, hipStream_t st, const uint32_t* seg_count,
                          uint32_t seg, uint2* ranges_out, const BinFinish* finish) {
   const TileSeg ts{seg_count, seg, nullptr}, ts0{seg_count, seg, ranges_out};
-  const BinFinish nofin{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0u, SpecCaps{nullptr, 0u, 0u, 0u, nullptr}};
+  const BinFinish nofin{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, SpecCaps{nullptr, 0u, 0u, 0u, nullptr}};
   const BinFinish fin = finish ? *finish : nofin;
   // size classes by list length; every class runs with the LDS footprint its lists need:
   //   (0,256]  bitonic, 128 threads      (256,1024] radix, 256 threads   (1024,3072] radix, 512 threads

@@ -66,7 +66,9 @@ struct SpecCaps {
 // the totals step of a one-pass binning (raster_bin.hip: bin_finish)
 struct BinFinish {
   const uint32_t* count; int ntiles;
-  uint32_t* info; uint32_t* info_host; const uint32_t* slot_a; const uint32_t* slot_b; uint32_t seq; SpecCaps caps;
+  uint32_t* info; uint32_t* info_host; const uint32_t* slot_a; const uint32_t* slot_b;
+  const uint32_t* listed;            // length of the work list (published for the host's next launch geometry)
+  uint32_t seq; SpecCaps caps;
 };
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

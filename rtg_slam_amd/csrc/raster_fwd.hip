@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(256) slice_publish_kernel(int ntiles, const in
     ctr[0] = L; ctr[1] = F;                      // device copy: pass 2's kernels exit at once when nothing is left
     if (spec_fail) *spec_fail = L != 0u ? 1u : 0u;   // speculative forward: the host assumed the slice finishes every tile
     const uint32_t R1 = seg_count ? (uint32_t)(s_i[0] + s_i[1] + s_i[2] + s_i[3]) : r1[0];
-    const uint32_t w[7] = {0u, 0u, L, F, R1, 0u, 0u};
+    const uint32_t w[7] = {ctr[2], 0u, L, F, R1, 0u, 0u};     // [0]: length of the slice's work list
     publish_to_host(host, w, seq);
   }
 }

@@ -33,14 +33,26 @@ def _vp(t: torch.Tensor):
 
 
 _scratch = {}
+_builds = {}            # pyramid builds per scratch: the min / max set alternates (include/rtgs_icp.h)
+FLAG_PERSISTENT, FLAG_CLUSTER, FLAG_SCRATCH_READY, FLAG_FROM_IDENTITY = 1, 2, 4, 8
+PYR_SCRATCH_READY, PYR_SECOND_SET = 1, 2
+
+
+def _scratch_key(dev):
+    return (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _get_scratch(dev) -> torch.Tensor:
-    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    """One scratch per (device, stream), armed once (rtgs_icp_scratch_init): the calls below then issue no memsets."""
+    key = _scratch_key(dev)
     s = _scratch.get(key)
     if s is None:
-        s = torch.empty(_lib.load().rtgs_icp_scratch_bytes(), dtype=torch.uint8, device=dev)
+        lib = _lib.load()
+        s = torch.empty(lib.rtgs_icp_scratch_bytes(), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rtgs_icp_scratch_init(_vp(s), C.c_void_p(key[2])), "rtgs_icp_scratch_init")
         _scratch[key] = s
+        _builds[key] = 0
     return s
 
 
@@ -62,10 +74,14 @@ def build_pyramids(depth: torch.Tensor, K: torch.Tensor, levels: int = 3) -> Tup
     vp = (C.c_void_p * levels)(*[v.data_ptr() for v in verts])
     npp = (C.c_void_p * levels)(*[n.data_ptr() for n in norms])
     stream = torch.cuda.current_stream(dev).cuda_stream
+    scratch = _get_scratch(dev)
+    key = _scratch_key(dev)
+    flags = PYR_SCRATCH_READY | (PYR_SECOND_SET if _builds[key] & 1 else 0)
+    _builds[key] += 1
     with torch.cuda.device(dev):
-        rc = lib.rtgs_icp_build_pyramids(_vp(depth), H, W, _vp(K), levels, vp, npp, _vp(_get_scratch(dev)),
-                                         C.c_void_p(stream))
-    _lib.check(rc, "rtgs_icp_build_pyramids")
+        rc = lib.rtgs_icp_build_pyramids_ex(_vp(depth), H, W, _vp(K), levels, vp, npp, _vp(scratch), flags,
+                                            C.c_void_p(stream))
+    _lib.check(rc, "rtgs_icp_build_pyramids_ex")
     return verts, norms
 
 
@@ -109,15 +125,16 @@ def icp_track(vertex_src: Sequence[torch.Tensor], normal_src, vertex_tgt, normal
                                ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr())
     K = _f32c(K.to(dev))
     out = torch.empty(20, dtype=torch.float32, device=dev)
+    flags = (FLAG_PERSISTENT if persistent else 0) | FLAG_SCRATCH_READY
     if pose0 is None:
-        out[:16] = torch.eye(4, dtype=torch.float32, device=dev).reshape(-1)
+        flags |= FLAG_FROM_IDENTITY            # the first iteration's last workgroup writes the pose: no fill / copy launches
     else:
         out[:16] = _f32c(pose0.to(dev)).reshape(-1)
     stream = torch.cuda.current_stream(dev).cuda_stream
     with torch.cuda.device(dev):
         rc = lib.rtgs_icp_track(lv, n, _vp(K), float(dist_thr), float(cos_thr), float(damping),
                                 C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr() + 64),
-                                _vp(_get_scratch(dev)), 1 if persistent else 0, C.c_void_p(stream))
+                                _vp(_get_scratch(dev)), flags, C.c_void_p(stream))
     _lib.check(rc, "rtgs_icp_track")
     return out
 

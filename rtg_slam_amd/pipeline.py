@@ -22,8 +22,21 @@ import torch
 
 
 class TrackMapPipeline:
-    def __init__(self, device: torch.device, tracker_stream: Optional[torch.cuda.Stream] = None, tracker_priority: int = -1):
+    def __init__(self, device: torch.device, tracker_stream: Optional[torch.cuda.Stream] = None, tracker_priority: int = -1,
+                 reserve_cus: int = 0):
         self.device = torch.device(device)
+        # reserve_cus > 0: `mapper_stream` is a stream whose CU mask leaves that many compute units free - run the mapper
+        # on it (with torch.cuda.stream(pipe.mapper_stream): ...) and the tracker's short dependent kernels always find
+        # wave slots instead of waiting for the mapper's workgroups to retire (include/rtgs_raster.h)
+        self.mapper_stream: Optional[torch.cuda.Stream] = None
+        self._masked = None
+        if reserve_cus > 0:
+            from . import _lib
+            with torch.cuda.device(self.device):
+                self._masked = _lib.load().rtgs_stream_create_reserving(int(reserve_cus))
+            if not self._masked:
+                raise RuntimeError(f"rtgs_stream_create_reserving({reserve_cus}) failed")
+            self.mapper_stream = torch.cuda.ExternalStream(self._masked, device=self.device)
         # The tracker's kernels are short and sit on the frame's critical path (16 dependent launches); on a high-priority
         # stream they are dispatched ahead of the mapper's queued workgroups instead of waiting behind them.
         self.tracker_stream = (tracker_stream if tracker_stream is not None
@@ -69,6 +82,13 @@ class TrackMapPipeline:
         if self._thread.is_alive():
             self._req.put(None)
             self._thread.join(timeout=5.0)
+        if self._masked:
+            from . import _lib
+            torch.cuda.synchronize(self.device)
+            if torch.cuda.current_stream(self.device) == self.mapper_stream:
+                torch.cuda.set_stream(torch.cuda.default_stream(self.device))
+            _lib.load().rtgs_stream_destroy(self._masked)
+            self._masked, self.mapper_stream = None, None
 
     def __del__(self):
         try:

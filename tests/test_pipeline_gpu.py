@@ -55,7 +55,10 @@ def _map_step(g, s, grads):
     return outs[0].detach(), {k: leaves[k].grad.detach() for k in ru.FIELDS}
 
 
-def test_pipelined_frames_equal_sequential_execution():
+@pytest.mark.parametrize("reserve_cus", [0, 32])
+def test_pipelined_frames_equal_sequential_execution(reserve_cus):
+    """reserve_cus = 32: the mapper runs on `pipe.mapper_stream`, whose CU mask leaves 32 compute units to the tracker
+    (rtgs_stream_create_reserving) - same results, it only changes where workgroups may run."""
     from rtg_slam_amd.icp import IcpTracker
     from rtg_slam_amd.pipeline import TrackMapPipeline
     depths, K = _frames(5)
@@ -77,12 +80,20 @@ def test_pipelined_frames_equal_sequential_execution():
         return out
 
     def pipelined():
+        import contextlib
         tr = IcpTracker(Args())
-        pipe = TrackMapPipeline(DEV)
+        pipe = TrackMapPipeline(DEV, reserve_cus=reserve_cus)
+        assert (pipe.mapper_stream is not None) == (reserve_cus > 0)
         tr.update_curr_status(depths[0], K)
         tr.move_last_status()
         out = []
+        main = torch.cuda.current_stream()
+        ctx = contextlib.nullcontext()
+        if pipe.mapper_stream is not None:
+            pipe.mapper_stream.wait_stream(main)
+            ctx = torch.cuda.stream(pipe.mapper_stream)
         try:
+          with ctx:
             for i in range(1, len(depths)):
                 # the frame's depth is scaled IN PLACE on the main stream right before track(): the tracker stage must be
                 # ordered after it (it sees the restored values or the poses differ)
@@ -97,6 +108,9 @@ def test_pipelined_frames_equal_sequential_execution():
                 pose, ok = pipe.result()
                 out.append((pose.copy(), ok, img.clone(), {k: v.clone() for k, v in gd.items()}))
         finally:
+            if pipe.mapper_stream is not None:
+                main.wait_stream(pipe.mapper_stream)
+            torch.cuda.synchronize()
             pipe.close()
         return out
 
