@@ -13,9 +13,11 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
 fi
 python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_bench -o bench -- python $R/bench.py --no-cpu-baseline --no-schedule > $O/ks_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_bench -o bench -- python $R/bench.py --no-cpu-baseline --no-schedule --no-surface --prewarm 400 > $O/ks_bench.log 2>&1
+python $R/tools/unit_trace.py $(find $O/ks_bench -name "*kernel_trace.csv" | head -1) 150 200 > $O/unit_trace.txt 2>&1
 for w in headline surface; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$w -o k -- python $R/tools/prof_raster.py $w 50 > $O/ks_$w.log 2>&1
+  python $R/tools/kernel_table.py $O/ks_$w 30 > $O/table_$w.txt
   python $R/tools/gap_trace.py $(find $O/ks_$w -name "*kernel_trace.csv" | head -1) map_fused_tail 25 > $O/gaps_$w.txt
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f_$w -o f -- python $R/tools/prof_raster.py $w 5 > $O/pmc_f_$w.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w_$w -o w -- python $R/tools/prof_raster.py $w 5 > $O/pmc_w_$w.log 2>&1
