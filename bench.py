@@ -166,7 +166,12 @@ def main():
     # processes, SLAM/multiprocess/system.py): the tracker's kernels go to a second HIP stream, enqueued by a helper
     # thread - rtg_slam_amd/pipeline.py
     from rtg_slam_amd.pipeline import TrackMapPipeline
-    pipe = TrackMapPipeline(dev, reserve_cus=args.reserve_cus)
+    try:
+        pipe = TrackMapPipeline(dev, reserve_cus=args.reserve_cus)
+    except RuntimeError as e:                # no CU-masked stream on this device / partition mode: run without the reservation
+        print(f"bench.py: {e}; running with --reserve-cus 0", file=sys.stderr)
+        args.reserve_cus = 0
+        pipe = TrackMapPipeline(dev)
     if pipe.mapper_stream is not None:       # everything this thread enqueues from here on: the mapper's masked stream
         pipe.mapper_stream.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.set_stream(pipe.mapper_stream)
