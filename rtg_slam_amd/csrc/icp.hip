@@ -11,7 +11,13 @@
 
 namespace rtgs_icp {
 
-constexpr int MAX_BLOCKS = 512;     // residual workgroups (2 per CU)
+// Residual workgroups per launch, at most.  One per CU measured best at 1200x680, alone and beside the mapper (track alone /
+// unit, us: 64: 457 / 556, 128: 317 / 445, 192: 281 / 437, 256: 263 / 420, 384: 270 / 427, 512: 283 / 431): fewer tickets and
+// partial rows for the last arriver, and - the kernel needs 151 VGPRs - fewer wave slots to find beside the mapper's.
+#ifndef RTGS_ICP_MAX_BLOCKS
+#define RTGS_ICP_MAX_BLOCKS 256
+#endif
+constexpr int MAX_BLOCKS = RTGS_ICP_MAX_BLOCKS;
 constexpr int NACC = 28;            // 21 upper-triangular JtJ + 6 Jtr + 1 valid count
 constexpr int PSTRIDE = 32;         // floats per block partial
 
