@@ -1,0 +1,144 @@
+"""The map object's host logic on CPU tensors (rtg_slam_amd/map_optim.py::ShardedMapOptimizer with the torch
+restatements of the Adam / activation kernels injected - the product itself has no CPU path): what the reference does
+to its point clouds between optimisations, and what must hold for the rows afterwards.
+
+* gaussians_add -> GaussianPointCloud.cat (gaussian_pointcloud.py:286-303): `append_rows` writes behind the last row,
+  keeps every old row bit for bit, grows the capacity geometrically;
+* GaussianPointCloud.delete / remove (:195-235; mapper.py:298-335): `remove_rows` keeps the order of the survivors and
+  the frozen / trainable boundary;
+* gaussians_fix (mapper.py:253-271): `freeze_rows` moves rows, in order, behind the frozen prefix;
+* only the trainable rows are parametrized (mapper.py:143-156): a step leaves the frozen rows bit-unchanged and equals
+  a step of a map that holds the trainable rows' gradients only; Adam state starts from zero after a permutation."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from rtg_slam_amd import map_optim as mo  # noqa: E402
+from rtg_slam_amd import synth  # noqa: E402
+from tests import torch_doubles as td  # noqa: E402
+from tests.dist_util import adam_reference  # noqa: E402
+
+CAM = synth.CameraSpec(32, 48, 40.0, 40.0, 23.5, 15.5)
+
+
+def _packed(n, seed):
+    return mo.pack_from_activated(synth.random_gaussians(n, CAM, seed=seed))
+
+
+def _opt(packed, **kw):
+    return mo.ShardedMapOptimizer(packed.clone(), adam_fn=adam_reference, activate_fn=td.activate8, **kw)
+
+
+def _loss(weights):
+    """A loss every parameter column takes part in, with per-row weights (0 = the row gets no gradient)."""
+    def fn(gd):
+        n = gd["xyz"].shape[0]
+        w = weights[:n].reshape(n, 1)
+        return ((gd["xyz"] * w).pow(2).sum() + (gd["shs"].reshape(n, -1) * w).sum() + (gd["opacity"] * w).sum()
+                + (gd["scales"] * w).pow(2).sum() + (gd["rotations"] * w * torch.arange(1, 5.0)).sum())
+    return fn
+
+
+def test_append_keeps_old_rows_and_grows_the_capacity_geometrically():
+    a, b, c = _packed(10, 1), _packed(3, 2), _packed(9, 3)
+    opt = _opt(a, n_frozen=4, capacity=14)
+    assert (opt.N, opt.n_frozen, opt.n_train, opt.capacity) == (10, 4, 6, 14)
+    p_before = {n: opt.state[n]["p"] for n, _, _ in mo.BLOCKS}
+    opt.append_rows(b)                                                  # fits: same storage, O(new rows)
+    assert (opt.N, opt.n_frozen, opt.capacity) == (13, 4, 14)
+    for n, _, _ in mo.BLOCKS:
+        assert opt.state[n]["p"].data_ptr() == p_before[n].data_ptr()
+    assert torch.equal(opt.params, torch.cat([a, b]))
+    opt.append_rows(c)                                                  # does not fit: capacity + capacity // 2 = 21 < 22 -> 22
+    assert (opt.N, opt.n_frozen, opt.capacity) == (22, 4, 22)
+    assert torch.equal(opt.params, torch.cat([a, b, c]))
+    opt.append_rows(_packed(0, 4))                                      # nothing to add: nothing changes
+    assert opt.N == 22
+    opt.append_rows(_packed(1, 5))                                      # 22 + 11 = 33 rows of capacity now
+    assert (opt.N, opt.capacity) == (23, 33)
+
+
+def test_remove_keeps_order_and_the_boundary():
+    a = _packed(12, 6)
+    opt = _opt(a, n_frozen=5)
+    mask = torch.zeros(12, dtype=torch.bool)
+    mask[[1, 4, 5, 11]] = True                                          # two frozen rows, two trainable ones
+    opt.remove_rows(mask)
+    assert (opt.N, opt.n_frozen, opt.n_train) == (8, 3, 5)
+    assert torch.equal(opt.params, a[~mask])
+    # the storage behind the live rows is zero again (the next append / all-gather padding starts clean)
+    for n, _, _ in mo.BLOCKS:
+        assert float(opt.state[n]["p"][opt.N:].abs().max()) == 0.0
+
+
+def test_freeze_moves_rows_behind_the_frozen_prefix_in_order():
+    a = _packed(10, 7)
+    opt = _opt(a, n_frozen=3)
+    mask = torch.zeros(10, dtype=torch.bool)
+    mask[[4, 8]] = True
+    mask[1] = True                                                      # already frozen: stays where it is
+    opt.freeze_rows(mask)
+    assert (opt.N, opt.n_frozen) == (10, 5)
+    assert torch.equal(opt.params, a[[0, 1, 2, 4, 8, 3, 5, 6, 7, 9]])
+
+
+def test_gaussian_data_hands_out_views_of_the_live_rows():
+    a = _packed(7, 8)
+    opt = _opt(a, capacity=20)
+    gd = opt.gaussian_data()
+    assert gd["xyz"].shape == (7, 3) and gd["shs"].shape == (7, 16, 3) and gd["opacity"].shape == (7, 1)
+    assert gd["xyz"].data_ptr() == opt.state["xyz"]["p"].data_ptr()      # zero-copy: the parameter tensors themselves
+    assert gd["shs"].data_ptr() == opt.state["shs"]["p"].data_ptr()
+    ref = td.activate8(a[:, 51:59])
+    for k in ("opacity", "scales", "rotations", "normal"):
+        assert torch.equal(gd[k], ref[k])
+
+
+@pytest.mark.parametrize("nf", [0, 4])
+def test_a_step_moves_only_trainable_rows_and_equals_the_step_of_the_trainable_part(nf):
+    a = _packed(11, 9)
+    w = torch.linspace(0.5, 1.5, 11)
+    opt = _opt(a, n_frozen=nf)
+    for _ in range(3):
+        opt.step(_loss(w))
+    after = opt.params
+    assert torch.equal(after[:nf], a[:nf])                              # frozen rows: bit for bit
+    assert float((after[nf:] - a[nf:]).abs().max()) > 0
+    # the same three steps on a map that IS the trainable part (the loss is a sum over rows)
+    ref = _opt(a[nf:])
+    for _ in range(3):
+        ref.step(_loss(w[nf:]))
+    assert torch.equal(after[nf:], ref.params)
+
+
+def test_adam_state_starts_over_after_a_permutation_but_not_after_an_append():
+    a, b = _packed(8, 10), _packed(2, 11)
+    w = torch.ones(16)
+    opt = _opt(a, capacity=16)
+    opt.step(_loss(w))
+    m_old = opt.state["xyz"]["m"][:8].clone()
+    assert float(m_old.abs().max()) > 0 and opt.step_count == 1
+    opt.append_rows(b)                                                  # old rows keep their moments, new rows start from zero
+    assert torch.equal(opt.state["xyz"]["m"][:8], m_old) and float(opt.state["xyz"]["m"][8:10].abs().max()) == 0.0
+    opt.step(_loss(w))
+    assert opt.step_count == 2
+    opt.remove_rows(torch.tensor([True] + [False] * 9))                 # rows moved: the moments belong to other Gaussians now
+    p0 = opt.params
+    opt.step(_loss(w))                                                  # ... zeroed lazily, by the next step
+    assert opt.step_count == 1
+    ref = _opt(p0)
+    ref.step(_loss(w))
+    assert torch.equal(opt.params, ref.params)
+
+
+def test_invalid_boundaries_are_refused():
+    a = _packed(5, 12)
+    with pytest.raises(ValueError):
+        _opt(a, n_frozen=6)
+    with pytest.raises(ValueError):
+        _opt(a, n_frozen=-1)
