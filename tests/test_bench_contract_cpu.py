@@ -1,0 +1,60 @@
+"""What of bench.py's contract can be held without a GPU: the default flags the driver relies on (N = 1, K / W that finish
+within minutes), the fields of the committed line, and that the PMC-derived numbers it quotes come from tables stamped
+with the kernel sources it ran on (bench.source_hash)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def test_default_flags_are_the_contracts(monkeypatch):
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.steps, a.warmup) == (1, 20, 3)
+    assert a.gaussians == 1_200_000 and a.mode == "sparse"
+    assert not a.no_cpu_baseline and not a.no_schedule and not a.no_surface and not a.surface_map
+    assert a.prewarm >= 3000 and a.repeats == 5
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "50", "--warmup", "5"])
+    a = bench.parse()
+    assert (a.gpus, a.steps, a.warmup) == (8, 50, 5)
+
+
+def test_committed_pmc_numbers_and_bench_line_belong_to_the_same_kernel_sources():
+    """The committed bench line quotes PMC traffic / VALU counts only from tables stamped with the hash of the kernel
+    sources it ran on (bench.source_hash; a tree edited since then makes bench.py report null instead)."""
+    import bench
+    assert len(bench.source_hash()) == 16
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("r") and f.endswith("_bench.json"))
+    r = json.load(open(os.path.join(ROOT, "profiles", files[-1])))["roofline"]
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    v = json.load(open(os.path.join(ROOT, "profiles", "valu_latest.json")))
+    assert t["_source_sha16"] == v["_source_sha16"]
+    if r["traffic"] is not None:
+        assert r["source_sha16"] == t["_source_sha16"]
+        assert r["traffic"] == t["blend_bwd_mfma"]["hbm_bytes_per_launch"]
+    if r.get("valu") is not None:
+        assert r["valu"]["wave_insts_per_launch"] == int(v["blend_bwd_mfma"]["SQ_INSTS_VALU"])
+
+
+def test_the_committed_bench_line_has_the_contracts_fields():
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("r") and f.endswith("_bench.json"))
+    d = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "slam_frames_per_sec" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port")
+    # value is the whole-job rate of the timed block
+    assert abs(d["value"] - 1e3 * d["n_gpus"] / d["ms_per_step"]) / d["value"] < 0.01
