@@ -279,6 +279,12 @@ class ShardedMapOptimizer:
                 ever=torch.zeros(adam_rows, dtype=torch.uint8, device=dev),
                 gpad=(torch.zeros(rows, c1 - c0, **f) if self.world > 1 else None),
                 gshard=(torch.zeros(per_cap, c1 - c0, **f) if self.world > 1 else None))
+            if old and self.world == 1:
+                # a larger allocation of the SAME rows: their Adam state moves with them (an append that happens to
+                # exhaust the capacity behaves like one that does not); on several ranks append_rows re-shards instead
+                k = min(old[name]["m"].shape[0], adam_rows)
+                for key in ("m", "v", "ever"):
+                    self.state[name][key][:k] = old[name][key][:k]
         self.capacity = cap
         if self._use_arena:
             # Single-GPU HIP path: persistent gradient rows + row states (rasterizer.RowGradArena).  step() hands the
@@ -369,15 +375,48 @@ class ShardedMapOptimizer:
         n = int(packed_new.shape[0])
         if n == 0:
             return
+        carried = self._gather_sharded_adam()
         if self.N + n > self.capacity:
             self._allocate(max(self.N + n, self.capacity + self.capacity // 2))
         r0 = self.N
         for name, c0, c1 in BLOCKS:
             self.state[name]["p"][r0:r0 + n] = packed_new[:, c0:c1]
         self.N += n
+        self._scatter_sharded_adam(carried)
         self._shape_changed(permuted=False)
         if self.act is not None and self._act_valid:
             self._activate_rows(r0, self.N, force=True)        # only the new rows
+
+    def _gather_sharded_adam(self):
+        """Row-sharded form on several ranks: the shard a trainable row belongs to depends on N (shard_rows), so an append
+        moves rows between ranks - and their Adam moments must move with them, or the next step pairs moments and rows of
+        different Gaussians.  Gathers m / v / ever of every shard into global trainable-row order (None when there is
+        nothing to carry: one rank, the replicated form, no step taken yet, or a pending reset)."""
+        if self.world == 1 or self._mode != "sharded" or self.step_count == 0 or getattr(self, "_stale", False):
+            return None
+        per, out = self.per, {}
+        for name, _, _ in BLOCKS:
+            st = self.state[name]
+            out[name] = {}
+            for key in ("m", "v", "ever"):
+                mine = st[key][:per].contiguous()
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                out[name][key] = torch.cat(parts, dim=0)[:self.n_train]
+        return out
+
+    def _scatter_sharded_adam(self, carried):
+        if carried is None:
+            return
+        per, lo = self.per, self.rank * self.per
+        for name, _, _ in BLOCKS:
+            st = self.state[name]
+            for key in ("m", "v", "ever"):
+                full = carried[name][key]
+                st[key].zero_()
+                k = max(0, min(per, full.shape[0] - lo))
+                if k:
+                    st[key][:k] = full[lo:lo + k]
 
     def _permute(self, keep_idx: torch.Tensor, n_frozen: int):
         n = int(keep_idx.numel())

@@ -117,6 +117,56 @@ def test_sharded_step_matches_single_process(rccl_branch, n_frozen):
     assert float((p0 - packed).abs().max()) > 1e-4, "the step moved the parameters"
 
 
+def _grow_worker(rank, world, port, ret, capacity=120):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from rtg_slam_amd import map_optim as mo
+    from tests.dist_util import adam_reference
+    packed, views, gts = _scene()
+    opt = mo.ShardedMapOptimizer(packed[:90].clone(), adam_fn=adam_reference, activate_fn=td.activate8, n_frozen=20, capacity=capacity)
+    opt.step(_loss_fn(views[rank], gts[rank]))
+    opt.append_rows(packed[90:].clone())             # 11 new trainable rows on every rank: the shards re-partition
+    assert opt.N == 101 and opt.per == (101 - 20 + 1) // 2
+    opt.step(_loss_fn(views[rank], gts[rank]))
+    mask = torch.zeros(101, dtype=torch.bool)
+    mask[25:40] = True
+    opt.freeze_rows(mask)                            # 15 trainable rows join the frozen prefix
+    assert opt.n_frozen == 35
+    opt.step(_loss_fn(views[rank], gts[rank]))
+    ret[rank] = opt.params.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("capacity", [120, 92])
+def test_a_map_that_grows_and_freezes_between_sharded_steps_matches_one_process(capacity):
+    """append_rows / freeze_rows on two ranks (every rank applies the same change): the row shards, and with them the rows
+    a rank's Adam state belongs to, change - the result must be what ONE process gets from the same sequence with the
+    sum of both views' losses - whether the append fits the capacity or forces a re-allocation."""
+    from rtg_slam_amd import map_optim as mo
+    from tests.dist_util import adam_reference
+    port = 29950 + (os.getpid() % 40) + (capacity % 7)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_grow_worker, args=(2, port, ret, capacity), nprocs=2, join=True)
+    assert torch.equal(ret[0], ret[1])
+    packed, views, gts = _scene()
+
+    def both(gd):
+        return _loss_fn(views[0], gts[0])(gd) + _loss_fn(views[1], gts[1])(gd)
+    one = mo.ShardedMapOptimizer(packed[:90].clone(), adam_fn=adam_reference, activate_fn=td.activate8, n_frozen=20, capacity=120)
+    one.step(both)
+    one.append_rows(packed[90:].clone())
+    one.step(both)
+    mask = torch.zeros(101, dtype=torch.bool)
+    mask[25:40] = True
+    one.freeze_rows(mask)
+    one.step(both)
+    assert float((ret[0] - one.params).abs().max()) < 1e-5
+
+
 def test_shard_rows_partition():
     from rtg_slam_amd import map_optim as mo
     for N in (1, 7, 8, 1_200_000, 5_000_001):

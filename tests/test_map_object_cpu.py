@@ -136,6 +136,20 @@ def test_adam_state_starts_over_after_a_permutation_but_not_after_an_append():
     assert torch.equal(opt.params, ref.params)
 
 
+def test_an_append_that_exhausts_the_capacity_behaves_like_one_that_does_not():
+    a, b = _packed(8, 13), _packed(5, 14)
+    w = torch.ones(16)
+    res = []
+    for cap in (16, 9):                                                  # fits / forces a re-allocation
+        opt = _opt(a, capacity=cap)
+        opt.step(_loss(w))
+        opt.append_rows(b)
+        assert opt.step_count == 1 and float(opt.state["shs"]["m"][:8].abs().max()) > 0
+        opt.step(_loss(w))
+        res.append(opt.params)
+    assert torch.equal(res[0], res[1])
+
+
 def test_invalid_boundaries_are_refused():
     a = _packed(5, 12)
     with pytest.raises(ValueError):
