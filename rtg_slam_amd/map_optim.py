@@ -296,8 +296,16 @@ class ShardedMapOptimizer:
             self.act = dict(opacity=torch.empty(rows, 1, **f), scales=torch.empty(rows, 3, **f),
                             rotations=torch.empty(rows, 4, **f), normal=torch.empty(rows, 3, **f))
         self._act_valid = False
-        if self._slam_state is not None:
-            self._slam_state = None    # re-created (zero) by the next step_slam
+        if self._slam_state is not None:   # the replicated form's full-size Adam state: same rows, larger arrays
+            olds = self._slam_state
+            self._slam_state = {}
+            for n, c0, c1 in BLOCKS:
+                k = olds[n]["m"].shape[0]
+                new = dict(m=torch.zeros(cap, c1 - c0, **f), v=torch.zeros(cap, c1 - c0, **f),
+                           ever=torch.zeros(cap, dtype=torch.uint8, device=dev))
+                for key in ("m", "v", "ever"):
+                    new[key][:min(k, cap)] = olds[n][key][:min(k, cap)]
+                self._slam_state[n] = new
         if self._slam_ws is not None:
             self._slam_ws["radii"] = torch.empty(rows, dtype=torch.int32, device=dev)
 

@@ -156,6 +156,54 @@ def test_two_ranks_sparse_slam_step_matches_single_process(nf, monkeypatch):
     assert torch.equal(moved, (rp - packed.cpu()).abs().max(dim=1).values > 0)
 
 
+def _worker_slam_grow(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = _init(rank, world)
+    from rtg_slam_amd import map_optim as mo
+    packed, fns = _setup(dev)
+    opt = mo.ShardedMapOptimizer(packed[:1500].clone(), n_frozen=300, capacity=1600)
+    rs, gt_c, gt_d = fns[rank].spec
+    for _ in range(2):
+        opt.step_slam(rs, gt_c, gt_d)
+    opt.append_rows(packed[1500:].clone())             # 501 rows: beyond the capacity - every per-row array is re-allocated
+    assert opt.N == 2001 and opt.capacity >= 2001
+    for _ in range(2):
+        opt.step_slam(rs, gt_c, gt_d)
+    opt.flush()
+    ret[rank] = opt.params.cpu()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sparse_slam_step_with_a_map_that_outgrows_its_capacity():
+    """The replicated form's full-size Adam state follows the map through a re-allocation (rows keep their moments, as
+    on one rank): two ranks stepping, appending beyond the capacity and stepping again equal one process doing the same
+    with the sum of both views."""
+    sys.path.insert(0, ROOT)
+    from rtg_slam_amd import map_optim as mo
+    port = 29520 + (os.getpid() % 100)
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_slam_grow, args=(2, port, ret), nprocs=2, join=True)
+    assert torch.equal(ret[0], ret[1])
+    dev = torch.device("cuda", 0)
+    packed, fns = _setup(dev)
+    ref = mo.ShardedMapOptimizer(packed[:1500].clone(), n_frozen=300, capacity=1600)
+    both = lambda gd: fns[0](gd) + fns[1](gd)
+    for _ in range(2):
+        ref.step(both)
+    ref.append_rows(packed[1500:].clone())
+    for _ in range(2):
+        ref.step(both)
+    rp = ref.params.cpu()
+    assert torch.equal(ret[0][:300], packed[:300].cpu())
+    bad = float(((ret[0] - rp).abs() > 2e-5).float().mean())
+    assert bad < 2e-3, bad
+
+
 def _worker_band(rank, world, port, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
