@@ -150,6 +150,31 @@ def test_an_append_that_exhausts_the_capacity_behaves_like_one_that_does_not():
     assert torch.equal(res[0], res[1])
 
 
+def test_fully_frozen_and_empty_maps_are_legal_states():
+    """mapper.py:1000-1009 hands the renderer empty sub-clouds; a map may hold no trainable row (everything became stable)
+    or no row at all between two frames."""
+    a, w = _packed(6, 15), torch.ones(32)
+    opt = _opt(a, n_frozen=2)
+    opt.step(_loss(w))
+    opt.freeze_rows(torch.ones(6, dtype=torch.bool))
+    assert (opt.N, opt.n_frozen, opt.n_train, opt.per) == (6, 6, 0, 0)
+    p = opt.params.clone()
+    opt.step(_loss(w))                                                   # nothing to step
+    assert torch.equal(opt.params, p)
+    b = _packed(3, 16)
+    opt.append_rows(b)
+    opt.step(_loss(w))
+    assert torch.equal(opt.params[:6], p) and float((opt.params[6:] - b).abs().max()) > 0
+    opt.remove_rows(torch.ones(9, dtype=torch.bool))
+    assert (opt.N, opt.n_frozen, opt.n_train) == (0, 0, 0)
+    gd = opt.gaussian_data()
+    assert gd["xyz"].shape == (0, 3) and gd["shs"].shape == (0, 16, 3) and gd["opacity"].shape == (0, 1)
+    c = _packed(4, 17)
+    opt.append_rows(c)
+    opt.step(_loss(w))
+    assert opt.N == 4 and float((opt.params - c).abs().max()) > 0
+
+
 def test_invalid_boundaries_are_refused():
     a = _packed(5, 12)
     with pytest.raises(ValueError):
