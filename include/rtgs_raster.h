@@ -232,64 +232,10 @@ size_t rtgs_raster_image_bytes(int32_t image_height, int32_t image_width);
 int rtgs_raster_last_stats(int64_t* stats8_host);
 int rtgs_raster_last_stats_ctx(rtgs_ctx* ctx, int64_t* stats8_host);
 
-/* Device-side counters of work actually done by blend_fwd: per tile, [2 t] = list entries the tile's walk consumed
- * before every pixel had terminated, [2 t + 1] = (entry, pixel) pairs evaluated.  `counters` = device uint64[2 x tiles]
- * (written, not accumulated, by each forward), or NULL to disable.  Per context, sticky until reset with NULL
- * (measurement aid). */
-void rtgs_raster_set_counters(void* counters);
-void rtgs_raster_set_counters_ctx(rtgs_ctx* ctx, void* counters);
-
-/* Optional per-stage HIP-event timing of the calls made through the context (off by default;
- * measurement aid - the backward of a forward must use the same context for its stages to show up).
- * rtgs_raster_last_timings fills ms12_host[0..11] with the last forward/backward's stage
- * durations in milliseconds (-1 = stage did not run):
- *   [0] preprocess_fwd (+ mask SAT)  [1] bin_count + tilescan (fallback: scan)  [2] bin_scatter
- *   (fallback: emit_keys)  [3] bin_tilesort (fallback: radix sort)  [4] tile_ranges (fallback only)
- *   [5] blend_fwd  [6] blend_bwd (the launches that have lists to walk)  [7] preprocess_bwd
- *   [8] near-slice binning (histogram, count, scan, scatter, sort)  [9] near-slice blend_fwd
- *   [10] grad_reduce (sum of the gradient slots per Gaussian)  [11] unused
- * With the near-slice pass on, [1]..[5] describe the second pass (tiles the slice left unfinished). */
-void rtgs_raster_set_profiling(int enable);
-void rtgs_raster_set_profiling_ctx(rtgs_ctx* ctx, int enable);
-/* Near-slice (occlusion) pass of the forward.  The nearest Gaussians - as many depth bins as fit a budget of
- * `budget_per_tile` x tiles instances - are binned, sorted and blended first; a tile whose every pixel reaches
- * T < T_threshold inside that slice is final (the slice list is a prefix of the tile's full depth-ordered list, so
- * the walk would have stopped there anyway); only the other tiles are binned against the whole map.  Outputs are
- * bit-identical to the single-pass forward; the backward walks each tile's list of the pass that finished it.
- * mode 0 = off, 1 = always, 2 = automatic (default): considered for maps of >= 100 000 Gaussians on >= 256 tiles, and
- * there the kernels decide from the depth histograms of THIS call (no history): the slice runs only if its Gaussians
- * carry enough optical depth to saturate the image (sum of radius^2 >= 24 per pixel) and the map holds at least twice
- * the slice's instances; otherwise the slice is empty and every tile goes to the second pass.  budget_per_tile <= 0
- * keeps the current budget (default 384).  Environment overrides at load time: RTGS_NEAR_SLICE, RTGS_NEAR_SLICE_BUDGET.
- * rtgs_raster_last_slice_stats: [0] slice used by the last forward, [1] instances binned for the slice,
+/* Near-slice pass of the last forward (the pass itself: rtgs_debug.h): [0] slice used, [1] instances binned for the slice,
  * [2] tiles it finished, [3] tiles left to the second pass. */
-void rtgs_raster_set_near_slice(int mode, int budget_per_tile);
-void rtgs_raster_set_near_slice_ctx(rtgs_ctx* ctx, int mode, int budget_per_tile);
 int rtgs_raster_last_slice_stats(int64_t* out4_host);
 int rtgs_raster_last_slice_stats_ctx(rtgs_ctx* ctx, int64_t* out4_host);
-/* Testing aid: force the fallback binning path (global 64-bit radix sort, rocPRIM) that is
- * otherwise taken only when the tile grid or one tile list exceeds the LDS-resident path. */
-void rtgs_raster_force_sort_path(int enable);
-void rtgs_raster_force_sort_path_ctx(rtgs_ctx* ctx, int enable);
-int rtgs_raster_last_timings(float* ms12_host);
-int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms12_host);
-/* The backward's tile walk.  Three kernels exist (raster_bwd.hip, raster_bwd_mfma.hip):
- *  - MFMA walk (default): a lane holds one (pixel, ENTRY) pair - 16 entries x 4 pixels per wave step - T and the colour
- *    behind are in-row DPP scans, and the sums over the pixels run on the matrix cores (v_mfma_f32_16x16x4_f32);
- *  - strip walk: pixel per lane, one entry per wave pass, tile-uniform (large footprints);
- *  - row-granular walk: pixel per lane, every 4x4 block walks its own sub-list (small footprints).
- * mode 0 (default) and 3 = MFMA walk on every tile; 1 = strip walk; 2 = row-granular walk; 4 = per-tile choice between
- * strip and row-granular from the share of the tile's list its 4x4 blocks need (ROWS_MAX_SHARE, raster_common.h) - the
- * round-3 behaviour, kept for A-B runs.  RTGS_BWD_WALK at load time.  Gradients of the walks agree to float rounding.
- * rtgs_raster_image_offsets: byte offsets inside the image buffer - [0] tile ranges (uint2 per tile), [1] n_contrib
- * (u32 per pixel), [2] BwdInfo, [3] tile walk (u32 per tile: bits 0..1 = 0 strip / 1 row-granular / 2 MFMA, bits 8.. the
- * measured share in 1/1000), [4] total size, [5] list position of every pixel's depth owner (u32 per pixel). */
-void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* ctx, int mode);
-/* One-pass binning (round 4; default on, RTGS_BIN_ONEPASS=0 at load time turns it off): where the geometry buffer gives
- * every tile a segment (maps of >= 100 000 Gaussians on >= 256 tiles), instances are placed by ONE enumeration sweep
- * (bin_place_kernel) instead of count + scan + scatter.  Outputs are bit-identical either way (the tile sort's order is
- * total); the switch exists for A-B runs and tests. */
-void rtgs_raster_set_onepass_ctx(rtgs_ctx* ctx, int on);
 /* Speculative forward (RTGS_FWD_SPECULATE).  verify: 0 = the guessed sizes held (or nothing was pending), 1 = they did
  * not - nothing persistent was changed, redo without the flag; < 0 = error.  It waits (spinning on pinned memory) only
  * until the kernel that publishes the totals has run.  spec_fail_ptr: device word (non-zero = failed) while a
@@ -300,6 +246,9 @@ int rtgs_raster_forward_verify_ctx(rtgs_ctx* ctx, int64_t* num_rendered_host);
 const uint32_t* rtgs_raster_spec_fail_ptr_ctx(rtgs_ctx* ctx);
 void rtgs_raster_set_speculation_ctx(rtgs_ctx* ctx, int enable);
 int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3_host);
+/* Byte offsets inside the image buffer - [0] tile ranges (uint2 per tile), [1] n_contrib (u32 per pixel), [2] BwdInfo,
+ * [3] tile walk (u32 per tile: bits 0..1 = 0 strip / 1 row-granular / 2 MFMA, bits 8.. the measured share in 1/1000),
+ * [4] total size, [5] list position of every pixel's depth owner (u32 per pixel). */
 int rtgs_raster_image_offsets(int32_t image_height, int32_t image_width, size_t* out6_host);
 
 /* Fused Adam over a packed [rows, cols] float32 parameter shard with one learning rate per
@@ -456,7 +405,8 @@ typedef struct rtgs_map_step_args {
    * is added to the owners' d_normal rows (rtgs_slam_normal_loss below) between the rasterizer backward and the tail. */
   float normal_weight;
   const float* gt_normal;                                 /* [H,W,3] world normals of the frame (image_input["normal_map"]) */
-  /* The TRAINABLE rows [train_begin, train_end) (0, 0 = every row).  RTG-SLAM renders cat(unstable, stable) but only the
+  /* The TRAINABLE rows [train_begin, train_end).  ONLY (0, 0) means every row; train_begin == train_end != 0 is an EMPTY
+   * range (a fully frozen map: rendered, loss evaluated, nothing differentiated or stepped).  RTG-SLAM renders cat(unstable, stable) but only the
    * unstable Gaussians are parameters of the optimisation (mapper.py:143-156 parametrizes self.pointcloud only,
    * :1026-1108 concatenates the stable rows without requires_grad): rows outside the range are rendered, never
    * differentiated (no gradient slot, no SplatGrad record, row_state stays 0), never stepped.  With a range the Adam

@@ -317,8 +317,9 @@ extern "C" int rtgs_map_fused_tail_hint(const rtgs_raster_settings* settings, co
   const int32_t P = s->P;
   if (P <= 0 || s->sh_coeffs != 16 || s->step < 1) return RTGS_E_INVALID;
   int32_t t0 = 0, t1 = P;
-  if (s->train_end > s->train_begin) { t0 = s->train_begin; t1 = s->train_end; }
-  if (t0 < 0 || t1 > P) return RTGS_E_INVALID;
+  if (s->train_begin != 0 || s->train_end != 0) { t0 = s->train_begin; t1 = s->train_end; }   // only (0, 0) means every row
+  if (t0 < 0 || t1 > P || t1 < t0) return RTGS_E_INVALID;
+  if (t1 == t0) return RTGS_OK;                            // empty range: nothing to step
   FusedArgs a{};
   RasterParams& p = a.p;
   p.H = settings->image_height; p.W = settings->image_width;

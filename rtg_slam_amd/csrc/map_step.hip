@@ -36,9 +36,10 @@ static int map_step_front(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* n
   rc = rtgs_slam_loss(a->out_color, a->out_depth, a->out_depth_index, a->gt_color, a->gt_depth, H, W, &lcfg,
                       a->loss_scratch, a->loss4, a->dL_dcolor, a->dL_ddepth, stream);
   if (rc != 0) return RTGS_E_HIP;
-  int32_t t0 = 0, t1 = P;                                 // the trainable rows (rtgs_map_step_args: 0, 0 = all)
-  if (a->train_end > a->train_begin) { t0 = a->train_begin; t1 = a->train_end; }
-  if (t0 < 0 || t1 > P) return RTGS_E_INVALID;
+  int32_t t0 = 0, t1 = P;                                 // the trainable rows (rtgs_map_step_args: ONLY 0, 0 = all)
+  if (a->train_begin != 0 || a->train_end != 0) { t0 = a->train_begin; t1 = a->train_end; }
+  if (t0 < 0 || t1 > P || t1 < t0) return RTGS_E_INVALID;
+  if (t1 == t0) return RTGS_OK;                           // an empty range (a fully frozen map): rendered, loss evaluated, nothing differentiated
   rc = (walk_only ? rtgs_raster_backward_walk_ctx : rtgs_raster_backward_range_ctx)(
       ctx, a->settings, P, M, *num_rendered_host, a->xyz, a->opacity, a->shs, a->scales, a->rotations, a->normal, geom, bin, img,
       a->out_color, a->out_T, a->out_depth_index, a->dL_dcolor, a->dL_ddepth, a->d_xyz, a->d_opacity, a->d_shs, a->d_scales,
@@ -73,6 +74,7 @@ static int map_step_once(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* nu
   const bool fused = a->tail_mode == 0 && !(a->normal_weight > 0.f && a->gt_normal);
   int rc = map_step_front(ctx, a, num_rendered_host, speculate ? RTGS_FWD_SPECULATE : 0, stream, fused);
   if (rc != RTGS_OK) return rc;
+  if ((a->train_begin != 0 || a->train_end != 0) && a->train_end == a->train_begin) return RTGS_OK;   // empty range: no tail
   if (fused) {
     void* bufs[3];
     if (rtgs_raster_last_buffers_ctx(ctx, bufs) != RTGS_OK) return RTGS_E_ALLOC;
@@ -85,7 +87,7 @@ static int map_step_once(rtgs_ctx* ctx, const rtgs_map_step_args* a, int64_t* nu
   // ... over the trainable rows only: every per-row pointer moves to row t0 (the Adam state, the attach snapshot and the
   // confidence array already start there, see rtgs_map_step_args)
   int32_t t0 = 0, t1 = P;
-  if (a->train_end > a->train_begin) { t0 = a->train_begin; t1 = a->train_end; }
+  if (a->train_begin != 0 || a->train_end != 0) { t0 = a->train_begin; t1 = a->train_end; }
   const size_t o = (size_t)t0;
   const rtgs_activated act{a->opacity + o, a->scales + 3 * o, a->rotations + 4 * o, a->normal + 3 * o};
   rc = rtgs_map_tail_rows(a->xyz + 3 * o, a->shs + 48 * o, a->raw8 + 8 * o, a->d_opacity + o, a->d_scales + 3 * o,

@@ -1,6 +1,7 @@
 // C-ABI entry points of the rasterizer (include/rtgs_raster.h): argument checks, scratch-buffer
 // carving, the rocPRIM scan / radix sort between the hand-written kernels, and launch order.
 #include "../../include/rtgs_raster.h"
+#include "../../include/rtgs_debug.h"
 #include "raster_common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -381,6 +382,10 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                             rtgs_resize_fn binning_resize, void* binning_user, rtgs_resize_fn image_resize,
                             void* image_user, int64_t* num_rendered_host, int32_t flags, void* stream) {
   rtgs_ctx* c = use(ctx);
+  // one-shot: consumed HERE, before any early return - a refused forward must not leave the pointer armed for the next,
+  // unrelated forward on this context
+  uint32_t* const aux_zero = c->aux_zero;
+  c->aux_zero = nullptr;
   RasterParams p;
   int rc = make_params(s, P, M, p);
   if (rc != RTGS_OK) return rc;
@@ -412,8 +417,6 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   // what blend_fwd writes there: the MFMA walk (2) by default, a forced pixel-per-lane walk (0 strip, 1 rows), or their
   // per-tile choice from the measured list share (-1: bwd_walk 4)
   const int fwd_walk = c->bwd_walk == 0 || c->bwd_walk == 3 ? 2 : (c->bwd_walk == 4 ? -1 : c->bwd_walk - 1);
-  uint32_t* const aux_zero = c->aux_zero;
-  c->aux_zero = nullptr;
   c->last_geom = geom; c->last_img = img; c->last_bin = nullptr;
 
   int64_t R = 0, R1 = 0;

@@ -881,8 +881,12 @@ void launch_bin_place(const RasterParams& p, const Splat* splats, const int32_t*
                                     return v < 0 ? 0 : (v > STAGE_W ? STAGE_W : v); }();
   const int gpb = list_gpb(list, max_items);
   const size_t n = max_items < (size_t)p.P ? max_items : (size_t)p.P;
+  // parked hits name their owner's record in the wave's area (6 bits), the tile (14 bits) and the rank: valid only while
+  // a wave handles ONE 64-Gaussian batch (a work list with gpb <= BLOCK) and tiles fit 14 bits - otherwise place every
+  // hit with its own atomic (always correct)
+  const int stage = (list.ids != nullptr && gpb <= BLOCK && ntiles < 16384) ? stage_cap : 0;
   hipLaunchKernelGGL(bin_place_kernel, dim3((unsigned)((n + gpb - 1) / gpb)), dim3(BLOCK), lds, st, p, splats, radii, mask,
-                     SegBins{seg_count, bucket, seg, fail}, sel, list, gpb, stage_cap);
+                     SegBins{seg_count, bucket, seg, fail}, sel, list, gpb, stage);
 }
 
 template <int THREADS>

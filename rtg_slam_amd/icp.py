@@ -77,11 +77,11 @@ def build_pyramids(depth: torch.Tensor, K: torch.Tensor, levels: int = 3) -> Tup
     scratch = _get_scratch(dev)
     key = _scratch_key(dev)
     flags = PYR_SCRATCH_READY | (PYR_SECOND_SET if _builds[key] & 1 else 0)
-    _builds[key] += 1
     with torch.cuda.device(dev):
         rc = lib.rtgs_icp_build_pyramids_ex(_vp(depth), H, W, _vp(K), levels, vp, npp, _vp(scratch), flags,
                                             C.c_void_p(stream))
     _lib.check(rc, "rtgs_icp_build_pyramids_ex")
+    _builds[key] += 1          # only a build that was launched flips the min / max set (a refused call re-armed nothing)
     return verts, norms
 
 

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for h in ("rtgs_raster.h", "rtgs_icp.h", "rtgs_slam.h"):
+    for h in ("rtgs_raster.h", "rtgs_debug.h", "rtgs_icp.h", "rtgs_slam.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(rtgs_[a-z0-9_]+)\s*\(", src))
