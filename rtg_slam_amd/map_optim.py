@@ -52,6 +52,23 @@ def default_lr_columns(position_lr=1e-3, feature_lr=5e-4, opacity_lr=0.0, scalin
     return lr
 
 
+def global_lr_scale(final: bool = False, feature_lr_coef: float = 1.0, scaling_lr_coef: float = 1.0,
+                    rotation_lr_coef: float = 1.0) -> torch.Tensor:
+    """The learning-rate rescaling of Mapping.global_optimization as a [59] column factor (mapper.py:605-616; group order
+    xyz, f_dc, f_rest, opacity, scaling, rotation - gaussian_pointcloud.py:252-283).  Keyframe-triggered form
+    (`select_keyframe_num != -1`): position 0, every other group x 0.1.  Final form: position 0, f_dc and f_rest x
+    feature_lr_coef, scaling x scaling_lr_coef, rotation x rotation_lr_coef, opacity unchanged."""
+    s = torch.ones(COLS)
+    s[0:3] = 0.0
+    if not final:
+        s[3:] = 0.1
+    else:
+        s[3:51] = feature_lr_coef
+        s[52:55] = scaling_lr_coef
+        s[55:59] = rotation_lr_coef
+    return s
+
+
 def pack_from_activated(g: Dict[str, torch.Tensor]) -> torch.Tensor:
     """Inverse activations of a `gaussian_data` dict (SLAM/render.py:93-98 keys) -> packed raw [N,59]."""
     N = g["xyz"].shape[0]
@@ -226,6 +243,11 @@ class ShardedMapOptimizer:
         self._slam_ws = None
         self._slam_state = None        # world > 1: full-size Adam state of the replicated sparse step (step_slam)
         self.capacity = 0
+        self.aux = {}                  # per-row side arrays that follow every append / remove / freeze (add_aux)
+        self._aux_spec = {}
+        self._scope = "local"          # "global": begin_global_optimization() - the stable prefix is what is rendered and trained
+        self._lr_scope = None          # learning-rate columns of the running global optimisation
+        self.version = 0               # bumped by everything that changes what a render of the map shows
         self._allocate(max(int(capacity) if capacity is not None else self.N, self.N, 1), packed)
         self.step_count = 0
         self.last_render = None
@@ -247,15 +269,30 @@ class ShardedMapOptimizer:
     def n_train(self) -> int:
         return self.N - self.n_frozen
 
+    def _active(self):
+        """(rows rendered, first trainable row) of the running optimisation.  Local optimisation (mapper.py:134-210): the
+        whole map is rendered, the unstable suffix [n_frozen, N) is trained.  Global optimisation (mapper.py:594-707): only
+        the stable prefix [0, n_frozen) is rendered, and all of it is trained - the unstable suffix is neither rendered nor
+        stepped (`self.renderer.render(frame_input, self.stable_params, ...)`, :679-683)."""
+        return (self.n_frozen, 0) if self._scope == "global" else (self.N, self.n_frozen)
+
+    @property
+    def n_active_train(self) -> int:
+        n, t0 = self._active()
+        return n - t0
+
     @property
     def per(self) -> int:
         """Trainable rows per rank in the row-sharded form."""
-        return shard_rows(self.n_train, self.world)[0]
+        return shard_rows(self.n_active_train, self.world)[0]
 
     @property
     def Npad(self) -> int:
-        """Rows the parameter tensors must hold for the sharded form's all-gather: frozen + world * per."""
-        return self.n_frozen + shard_rows(self.n_train, self.world)[1]
+        """Rows the parameter tensors must hold for the sharded form's all-gather: first trainable row + world * per."""
+        return self._active()[1] + shard_rows(self.n_active_train, self.world)[1]
+
+    def _lr(self, name):
+        return self._lr_scope[name] if self._lr_scope is not None else self.state[name]["lr"]
 
     def _allocate(self, cap: int, packed: Optional[torch.Tensor] = None):
         """(Re)allocate every per-row array for `cap` rows (+ `world` rows of all-gather padding) and carry the live rows
@@ -285,6 +322,10 @@ class ShardedMapOptimizer:
                 k = min(old[name]["m"].shape[0], adam_rows)
                 for key in ("m", "v", "ever"):
                     self.state[name][key][:k] = old[name][key][:k]
+        for name, (width, dtype, fill) in self._aux_spec.items():
+            new = torch.full((rows, width), fill, dtype=dtype, device=dev)
+            new[:N] = self.aux[name][:N]
+            self.aux[name] = new
         self.capacity = cap
         if self._use_arena:
             # Single-GPU HIP path: persistent gradient rows + row states (rasterizer.RowGradArena).  step() hands the
@@ -340,21 +381,34 @@ class ShardedMapOptimizer:
         self.flush()
         return torch.cat([self.state[n]["p"][:self.N] for n, _, _ in BLOCKS], dim=1)
 
-    def gaussian_data(self) -> Dict[str, torch.Tensor]:
+    def add_aux(self, name: str, width: int = 1, dtype=torch.float32, fill=0):
+        """A per-row side array [capacity, width] that lives with the rows: appended rows get `fill` (or what append_rows
+        is handed), removed rows take theirs away, frozen rows move with them.  The reference keeps these as members of
+        GaussianPointCloud (_confidence, _add_tick, _depth_error_counter, _color_error_counter,
+        gaussian_pointcloud.py:286-303, 195-235).  Returns the full array; rows [0, N) are live."""
+        rows = self.state["xyz"]["p"].shape[0]
+        self._aux_spec[name] = (int(width), dtype, fill)
+        self.aux[name] = torch.full((rows, int(width)), fill, dtype=dtype, device=self.device)
+        return self.aux[name]
+
+    def gaussian_data(self, rows: str = "all") -> Dict[str, torch.Tensor]:
         """The `gaussian_data` dict of SLAM/render.py:93-98 as ZERO-COPY views of the optimiser's own arrays: xyz / shs are
         the parameter tensors, opacity / scales / rotations / normal the activated copies the one-call step keeps current
         (its tail re-activates exactly the rows it moved) - refreshed here by one activation pass only if something else
-        changed raw8.  Valid until the next step / change of shape; do not write through them."""
+        changed raw8.  Valid until the next step / change of shape; do not write through them.
+        `rows`: "all" = Mapping.global_params (mapper.py:1069-1108), "stable" = stable_params (:984-1011: the frozen prefix),
+        "unstable" = unstable_params (:1013-1037: the trainable suffix) - contiguous row ranges, so still views."""
         self.flush()
         N = self.N
+        r0, r1 = {"all": (0, N), "stable": (0, self.n_frozen), "unstable": (self.n_frozen, N)}[rows]
         if self.act is None:
-            gd = self.activate_fn(self.state["raw8"]["p"][:N])
+            gd = self.activate_fn(self.state["raw8"]["p"][r0:r1])
             gd = {k: gd[k] for k in ("opacity", "scales", "rotations", "normal")}
         else:
             self._activate_rows(0, N)
-            gd = {k: v[:N] for k, v in self.act.items()}
-        gd["xyz"] = self.state["xyz"]["p"][:N]
-        gd["shs"] = self.state["shs"]["p"][:N].view(N, 16, 3)
+            gd = {k: v[r0:r1] for k, v in self.act.items()}
+        gd["xyz"] = self.state["xyz"]["p"][r0:r1]
+        gd["shs"] = self.state["shs"]["p"][r0:r1].view(r1 - r0, 16, 3)
         return gd
 
     def _activate_rows(self, r0: int, r1: int, force: bool = False):
@@ -375,10 +429,13 @@ class ShardedMapOptimizer:
             _lib.check(rc, "rtgs_map_activate8_forward")
         self._act_valid = True
 
-    def append_rows(self, packed_new: torch.Tensor):
+    def append_rows(self, packed_new: torch.Tensor, aux: Optional[Dict[str, torch.Tensor]] = None):
         """New TRAINABLE rows behind the last row (gaussians_add -> GaussianPointCloud.cat, gaussian_pointcloud.py:286-303:
         the reference concatenates every parameter tensor - an O(N) copy per frame; here O(new) unless the capacity is
-        exhausted, which grows by half).  On several ranks every rank must append the same rows."""
+        exhausted, which grows by half).  On several ranks every rank must append the same rows.  `aux`: values of the
+        side arrays (add_aux) for the new rows, [n, width] or a scalar each; arrays not named get their fill value."""
+        if self._scope != "local":
+            raise RuntimeError("append_rows() inside a global optimisation: end_global_optimization() first")
         self.flush()
         n = int(packed_new.shape[0])
         if n == 0:
@@ -389,6 +446,12 @@ class ShardedMapOptimizer:
         r0 = self.N
         for name, c0, c1 in BLOCKS:
             self.state[name]["p"][r0:r0 + n] = packed_new[:, c0:c1]
+        for name, (width, dtype, fill) in self._aux_spec.items():
+            val = fill if aux is None or name not in aux else aux[name]
+            if torch.is_tensor(val):
+                val = val.reshape(n, width).to(dtype)
+            self.aux[name][r0:r0 + n] = val
+        self.version += 1
         self.N += n
         self._scatter_sharded_adam(carried)
         self._shape_changed(permuted=False)
@@ -427,11 +490,18 @@ class ShardedMapOptimizer:
                     st[key][:k] = full[lo:lo + k]
 
     def _permute(self, keep_idx: torch.Tensor, n_frozen: int):
+        if self._scope != "local":
+            raise RuntimeError("rows cannot be removed or frozen inside a global optimisation: end_global_optimization() first")
         n = int(keep_idx.numel())
         for name, _, _ in BLOCKS:
             pfull = self.state[name]["p"]
             pfull[:n] = pfull.index_select(0, keep_idx)
             pfull[n:self.N].zero_()
+        for name, (width, dtype, fill) in self._aux_spec.items():
+            a = self.aux[name]
+            a[:n] = a.index_select(0, keep_idx)
+            a[n:self.N] = fill
+        self.version += 1
         self.N, self.n_frozen = n, int(n_frozen)
         self._act_valid = False
         self._shape_changed(permuted=True)
@@ -454,12 +524,13 @@ class ShardedMapOptimizer:
         order = torch.sort((~mask).to(torch.int8), stable=True).indices       # frozen first, order kept inside both parts
         self._permute(order, int(mask.sum()))
 
-    def _adam(self, st, shard, gs, row_state=None):
+    def _adam(self, name, shard, gs, row_state=None):
+        st, lr = self.state[name], self._lr(name)
         n = shard.shape[0]                                  # the state arrays are allocated for the capacity
         if self.row_skip:
-            _adam_rows_hip(shard, gs, st["m"][:n], st["v"][:n], st["lr"], self.step_count, self.eps, st["ever"][:n], row_state)
+            _adam_rows_hip(shard, gs, st["m"][:n], st["v"][:n], lr, self.step_count, self.eps, st["ever"][:n], row_state)
         else:
-            self.adam_fn(shard, gs, st["m"][:n], st["v"][:n], st["lr"], self.step_count, self.eps)
+            self.adam_fn(shard, gs, st["m"][:n], st["v"][:n], lr, self.step_count, self.eps)
 
     # ------------------------------------------------------------------ one-call SLAM step (single GPU)
     def begin_local_optimization(self, confidence: Optional[torch.Tensor] = None):
@@ -467,10 +538,56 @@ class ShardedMapOptimizer:
         Snapshot the raw parameters the attach regulariser ties low-opacity Gaussians to (`history_stat` /
         `init_stat` of mapper.py:147-153, 660-666) and reset the Adam state, as the reference does for every
         local / global optimisation (mapper.py:156: a new torch.optim.Adam per call) - in place: nothing is allocated
-        once the buffers exist.  Covers the trainable rows."""
+        once the buffers exist.  Covers the trainable rows.  Ends a global optimisation that was still open."""
+        if self._scope != "local":
+            self.end_global_optimization()
+        self._begin(confidence)
+
+    def begin_global_optimization(self, lr_scale: Optional[torch.Tensor] = None):
+        """Mapping.global_optimization (mapper.py:594-707) as a mode of the map object: until `end_global_optimization()`
+        (or the next `begin_local_optimization()`) the STABLE prefix [0, n_frozen) is what `step_slam` / `step` render AND
+        train - `self.renderer.render(frame_input, self.stable_params, ...)` (:679-683) with `l = self.stable_pointcloud.
+        parametrize(update_args)` (:605) - while the unstable suffix is neither rendered nor stepped.  `lr_scale` [59]
+        multiplies the learning-rate columns for the duration (:606-616: position 0 and everything else x 0.1 for the
+        keyframe-triggered form, position 0 and feature / scaling / rotation x their `*_lr_coef` for the final one; see
+        `global_lr_scale`).  Adam state restarts from zero (:627: a new Adam) and the attach snapshot (`init_stat`,
+        :621-626) covers the stable rows.  Adam state, snapshot and a `confidence` array handed to `step_slam` index the
+        stable rows: element 0 = row 0."""
+        self.flush()
+        if self.n_frozen == 0:
+            raise RuntimeError("begin_global_optimization() on a map without stable rows (mapper.py:603-604 returns early)")
+        self._scope = "global"
+        if lr_scale is not None:
+            full = self.lr_full * lr_scale.to(self.device).float()
+            self._lr_scope = {name: full[c0:c1].contiguous() for name, c0, c1 in BLOCKS}
+        else:
+            self._lr_scope = None
+        if self.grad_rows is not None:
+            self.grad_rows.resize(self.n_frozen, clear=False)       # the rasterizer sees a map of n_frozen rows
+            self.grad_rows.train = (0, self.n_frozen)
+        self._stale = True                  # gradient rows / row states of the local optimisation before it: cleared by _begin
+        self._begin(None)
+
+    def end_global_optimization(self):
+        """Back to the local form: the whole map is rendered, the unstable suffix is trained (`stable_pointcloud.detach()`,
+        mapper.py:707).  Adam state and gradient rows restart from zero at the next begin_local_optimization() / step."""
+        if self._scope == "local":
+            return
+        self.flush()
+        self._scope = "local"
+        self._lr_scope = None
+        if self.grad_rows is not None:
+            self.grad_rows.resize(self.N, clear=False)
+            self.grad_rows.train = (self.n_frozen, self.N)
+        self._stale = True
+        self.attach_init = None
+        self._history = None
+
+    def _begin(self, confidence):
         self.flush()
         self._clean()
-        N, nf, st = self.N, self.n_frozen, self.state
+        st = self.state
+        N, nf = self._active()
         rows = st["xyz"]["p"].shape[0]
         buf = getattr(self, "_attach_buf", None)
         if buf is None or buf["xyz"].shape[0] < rows:
@@ -493,7 +610,7 @@ class ShardedMapOptimizer:
                 for k in ("m", "v", "ever"):
                     holder[n][k].zero_()
         self.step_count = 0
-        if st["xyz"]["p"].is_cuda:
+        if st["xyz"]["p"].is_cuda and N > nf:
             self.attach_loss()                 # counts the selected rows once: the selection is fixed by the snapshot
 
     def history_merge(self, confidence: torch.Tensor, max_weight: float = 0.5):
@@ -508,7 +625,10 @@ class ShardedMapOptimizer:
             return
         self.flush()
         lib = _lib.load()
-        N, nf, st, ai, h = self.N, self.n_frozen, self.state, self.attach_init, self._history
+        (N, nf), st, ai, h = self._active(), self.state, self.attach_init, self._history
+        if N == nf:
+            return
+        self.version += 1
         V = lambda t: C.c_void_p(t.data_ptr())
         O = lambda t, c: C.c_void_p(t.data_ptr() + 4 * c * nf)
         conf = confidence.reshape(-1).contiguous().float()
@@ -525,7 +645,7 @@ class ShardedMapOptimizer:
         reference's report) - a device scalar.  The one-call step applies its gradient without evaluating it."""
         from . import _lib
         lib = _lib.load()
-        ai, st, N, nf = self.attach_init, self.state, self.N, self.n_frozen
+        ai, st, (N, nf) = self.attach_init, self.state, self._active()
         dev = st["xyz"]["p"].device
         attach = _lib.AttachC(ai["xyz"].data_ptr(), ai["raw8"].data_ptr(), ai["info"].data_ptr())
         with torch.cuda.device(dev):
@@ -564,8 +684,11 @@ class ShardedMapOptimizer:
             return self.step(loss_fn)
         lib = _lib.load()
         rs = raster_settings
-        N, nf, st, a = self.N, self.n_frozen, self.state, self.grad_rows
+        (N, nf), st, a = self._active(), self.state, self.grad_rows
         dev = st["xyz"]["p"].device
+        if N == 0:
+            raise RuntimeError("step_slam() on an empty map")
+        self.version += 1
         if self.world > 1:
             if self._mode == "sharded":
                 raise RuntimeError("ShardedMapOptimizer: step_slam() after step() on more than one rank - the two keep "
@@ -624,7 +747,7 @@ class ShardedMapOptimizer:
             P(ws["T"]), P(ws["radii"]), P(ws["g_color"]), P(ws["g_depth"]), P(ws["loss"]), P(a.d_means), P(a.d_opac),
             P(a.d_shs), P(a.d_scales), P(a.d_rots), P(a.d_normal), P(a.d_raw8), P(a.scratch), P(a.row_state),
             P(ad["xyz"]["m"]), P(ad["xyz"]["v"]), P(ad["shs"]["m"]), P(ad["shs"]["v"]), P(ad["raw8"]["m"]),
-            P(ad["raw8"]["v"]), P(st["xyz"]["lr"]), P(st["shs"]["lr"]), P(st["raw8"]["lr"]), P(ad["xyz"]["ever"]),
+            P(ad["raw8"]["v"]), P(self._lr("xyz")), P(self._lr("shs")), P(self._lr("raw8")), P(ad["xyz"]["ever"]),
             P(ad["shs"]["ever"]), P(ad["raw8"]["ever"]), int(self.step_count), 0.9, 0.999, float(self.eps),
             C.pointer(attach) if attach is not None else None, P(confidence) if confidence is not None else None,
             int(self._act_valid), geom.cb, None, binning.cb, None, img.cb, None,
@@ -671,7 +794,7 @@ class ShardedMapOptimizer:
     def _front_tileband(self, lib, args, ws, keep, tile_mask, rm, R, dev):
         from . import _lib
         from .rasterizer import current_context
-        N = self.N
+        N, t0 = self._active()
         H, W = ws["hw"]
         # The band of a mask pair is cached, keyed on the tensor OBJECTS (held here, so their ids cannot be recycled) and
         # their in-place version counters - never on data pointers: the reference picks a random frame of the window per
@@ -714,7 +837,7 @@ class ShardedMapOptimizer:
                 ctx, C.byref(keep.c), N, 16, R.value, V(x["xyz"]["p"]), V(act["opacity"]), V(x["shs"]["p"]), V(act["scales"]),
                 V(act["rotations"]), V(act["normal"]), V(geom.tensor), V(binning.tensor), V(img.tensor), V(ws["color"]), V(ws["T"]),
                 V(ws["didx"]), V(ws["g_color"]), V(ws["g_depth"]), V(a.d_means), V(a.d_opac), V(a.d_shs), V(a.d_scales),
-                V(a.d_rots), V(a.d_normal), V(a.scratch), V(a.row_state), int(self.n_frozen), int(N), st()), "rtgs_raster_backward_range")
+                V(a.d_rots), V(a.d_normal), V(a.scratch), V(a.row_state), int(t0), int(N), st()), "rtgs_raster_backward_range")
             if args.normal_weight > 0 and args.gt_normal:
                 # the band's pixels only (band_rm): every pixel of the view is counted by exactly one rank.  NOTE: the mean's
                 # normaliser is this rank's count - exact on one rank; with bands the reference's global mean would need the
@@ -722,7 +845,7 @@ class ShardedMapOptimizer:
                 _lib.check(lib.rtgs_slam_normal_loss_range(
                     V(act["normal"]), V(ws["didx"]), C.c_void_p(args.gt_normal), V(band_rm), H, W, float(args.normal_weight),
                     C.c_void_p(ws["loss_scratch"].data_ptr() + 20), V(ws["loss"]), V(a.d_normal), V(a.row_state), None,
-                    int(self.n_frozen), int(N), st()), "rtgs_slam_normal_loss")
+                    int(t0), int(N), st()), "rtgs_slam_normal_loss")
 
     # ------------------------------------------------------------------ sparse exchange (world > 1), no host sync
     def _exchange_and_tail(self, job):
@@ -734,7 +857,7 @@ class ShardedMapOptimizer:
         larger capacity.  Steady state: zero host synchronisations per step."""
         from . import _lib
         lib = _lib.load()
-        N, st, a, ws = self.N, self.state, self.grad_rows, self._slam_ws
+        (N, nf), st, a, ws = self._active(), self.state, self.grad_rows, self._slam_ws
         ad = self._slam_state
         dev = st["xyz"]["p"].device
         W, cap = self.world, int(self._row_capacity)
@@ -767,14 +890,13 @@ class ShardedMapOptimizer:
             for r in range(W):                                        # same order on every rank: bit-identical replicas
                 lst = C.c_void_p(ws["gathered"].data_ptr() + r * stride)
                 _lib.check(lib.rtgs_rows_apply(lst, cap, 1, *arena, V(a.row_state), V(flag), stream()), "rtgs_rows_apply")
-            nf = self.n_frozen
             O = lambda t, c: C.c_void_p(t.data_ptr() + 4 * c * nf)          # row nf of a [rows, c] float32 array
             act = self.act
             rc = lib.rtgs_map_tail_rows(
                 O(st["xyz"]["p"], 3), O(st["shs"]["p"], 48), O(st["raw8"]["p"], 8), O(a.d_opac, 1), O(a.d_scales, 3), O(a.d_rots, 4),
                 O(a.d_normal, 3), O(a.d_means, 3), O(a.d_shs, 48), O(a.d_raw8, 8), C.c_void_p(a.row_state.data_ptr() + nf),
                 V(ad["xyz"]["m"]), V(ad["xyz"]["v"]), V(ad["shs"]["m"]), V(ad["shs"]["v"]), V(ad["raw8"]["m"]), V(ad["raw8"]["v"]),
-                V(st["xyz"]["lr"]), V(st["shs"]["lr"]), V(st["raw8"]["lr"]), V(ad["xyz"]["ever"]), V(ad["shs"]["ever"]),
+                V(self._lr("xyz")), V(self._lr("shs")), V(self._lr("raw8")), V(ad["xyz"]["ever"]), V(ad["shs"]["ever"]),
                 V(ad["raw8"]["ever"]), N - nf, job["step"], 0.9, 0.999, float(self.eps),
                 C.byref(att) if att is not None else None, V(conf) if conf is not None else None, V(flag),
                 C.byref(_lib.ActivatedC(act["opacity"].data_ptr() + 4 * nf, act["scales"].data_ptr() + 12 * nf,
@@ -823,16 +945,18 @@ class ShardedMapOptimizer:
 
     def my_rows(self) -> slice:
         """This rank's shard of the trainable rows."""
-        return slice(self.n_frozen + self.rank * self.per, self.n_frozen + (self.rank + 1) * self.per)
+        t0 = self._active()[1]
+        return slice(t0 + self.rank * self.per, t0 + (self.rank + 1) * self.per)
 
     def step(self, loss_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor]) -> torch.Tensor:
         """loss_fn(gaussian_data) -> scalar loss of THIS rank's view.  Gradients are summed over
         ranks (the sum of per-view losses is what a single GPU looping over the views optimises).  Only the trainable
         rows [n_frozen, N) are reduced, stepped and gathered; the row shards partition that range."""
         self._clean()
-        N, nf = self.N, self.n_frozen
+        N, nf = self._active()
         per, span = self.per, self.per * self.world        # rows of one shard / of all shards (>= n_train: padded)
         self._act_valid = False            # raw8 moves without step_slam's tail: its activated copies go stale
+        self.version += 1
         if self.world > 1:
             if self._mode == "replicated":
                 raise RuntimeError("ShardedMapOptimizer: step() after step_slam() on more than one rank - the two keep "
@@ -867,15 +991,16 @@ class ShardedMapOptimizer:
                 if nf + span == N:
                     src = g[nf:N]                       # the trainable gradient rows as they lie (no staging copy)
                 else:
-                    st["gpad"][nf:N] = g[nf:N]          # the shards' padding rows stay zero
-                    src = st["gpad"][nf:nf + span]
+                    st["gpad"][nf:N] = g[nf:N]
+                    st["gpad"][N:nf + span].zero_()     # the shards' padding rows: zero gradient (in a global optimisation they
+                    src = st["gpad"][nf:nf + span]      # are real, unstable rows: zero gradient + zero moments leave them as they are)
                 rs[name] = dist.reduce_scatter_tensor(st["gshard"][:per], src, op=dist.ReduceOp.SUM, group=self.group,
                                                       async_op=True)
             for name in order:
                 st = self.state[name]
                 rs[name].wait()                         # stream-side wait, the host does not block
                 shard = st["p"][rows]
-                self._adam(st, shard, st["gshard"][:per])
+                self._adam(name, shard, st["gshard"][:per])
                 # in place: the shard IS this rank's slice of the gathered range (sendbuff = recvbuff + rank * count, the
                 # in-place form of the collective) - no staging copy of the updated rows
                 ag.append(dist.all_gather_into_tensor(st["p"][nf:nf + span], shard, group=self.group, async_op=True))
@@ -888,6 +1013,7 @@ class ShardedMapOptimizer:
             g = gmap[name]
             if self.world > 1:                          # gloo (CPU tests): no reduce-scatter -> all-reduce, take the local rows
                 st["gpad"][nf:N] = g[nf:N]
+                st["gpad"][N:nf + span].zero_()
                 red = st["gpad"][nf:nf + span]
                 dist.all_reduce(red, op=dist.ReduceOp.SUM, group=self.group)
                 gs = st["gpad"][rows].contiguous()
@@ -897,7 +1023,7 @@ class ShardedMapOptimizer:
             row_state = None
             if arena is not None and arena.calls == 1 and gs.data_ptr() == self._arena_grad(name)[nf:].data_ptr():
                 row_state = arena.row_state[nf:]   # gs IS the rasterizer's persistent rows: their states are exact
-            self._adam(st, shard, gs, row_state)
+            self._adam(name, shard, gs, row_state)
             if self.world > 1:
                 parts = [torch.empty_like(shard) for _ in range(self.world)]
                 dist.all_gather(parts, shard.clone(), group=self.group)

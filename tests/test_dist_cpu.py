@@ -216,3 +216,54 @@ def test_tile_band_partition_of_the_switched_on_tiles():
             assert torch.equal(torch.stack(regions).int().sum(0), torch.ones_like(tm))
             counts = [int(b.sum()) for b in bands]
             assert max(counts) - min(counts) <= 1, (world, frac, counts)
+
+
+def _global_worker(rank, world, port, ret, rccl_branch, nf):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from rtg_slam_amd import map_optim as mo
+    from tests.dist_util import adam_reference
+    packed, views, gts = _scene()
+    opt = mo.ShardedMapOptimizer(packed, adam_fn=adam_reference, activate_fn=td.activate8, n_frozen=nf)
+    if rccl_branch:
+        _emulate_rccl_collectives()
+        opt.backend = "nccl"
+    opt.step(_loss_fn(views[rank], gts[rank]))                       # a local step: the unstable suffix moves
+    mid = opt.params.clone()
+    opt.begin_global_optimization(mo.global_lr_scale(final=False))
+    assert opt.per == (nf + 1) // 2 and opt.my_rows().start == rank * opt.per
+    for _ in range(2):
+        opt.step(_loss_fn(views[rank], gts[rank]))                   # the loss renders the stable rows only
+    opt.end_global_optimization()
+    ret[rank] = (mid, opt.params.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rccl_branch,nf", [(False, 60), (True, 61)])
+def test_global_optimization_on_two_ranks_matches_one_process(rccl_branch, nf):
+    """Mapping.global_optimization (mapper.py:594-707) with the stable rows sharded over two ranks: equals one process that
+    renders the stable prefix from both views, sums the gradients and steps every stable row with the rescaled learning
+    rates; the unstable suffix - which includes the rows the shard padding reaches into - is bit-unchanged."""
+    from rtg_slam_amd import map_optim as mo
+    from tests.dist_util import adam_reference
+    port = 29950 + (os.getpid() % 300) + (11 if rccl_branch else 0)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_global_worker, args=(2, port, ret, rccl_branch, nf), nprocs=2, join=True)
+    (mid0, p0), (mid1, p1) = ret[0], ret[1]
+    assert torch.equal(mid0, mid1) and torch.equal(p0, p1)
+    assert torch.equal(p0[nf:], mid0[nf:]), "unstable rows are neither rendered nor stepped"
+    packed, views, gts = _scene()
+    p = mid0[:nf].clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    lr = mo.default_lr_columns() * mo.global_lr_scale(final=False)
+    for step in (1, 2):
+        leaf = p.detach().clone().requires_grad_(True)
+        loss = _loss_fn(views[0], gts[0])(td.activate(leaf)) + _loss_fn(views[1], gts[1])(td.activate(leaf))
+        (g,) = torch.autograd.grad(loss, leaf)
+        adam_reference(p, g, m, v, lr, step, 1e-15)
+    assert float((p0[:nf] - p).abs().max()) < 1e-5
+    assert torch.equal(p0[:nf, :3], mid0[:nf, :3]) and float((p0[:nf] - mid0[:nf]).abs().max()) > 1e-5

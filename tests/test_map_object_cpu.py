@@ -181,3 +181,79 @@ def test_invalid_boundaries_are_refused():
         _opt(a, n_frozen=6)
     with pytest.raises(ValueError):
         _opt(a, n_frozen=-1)
+
+
+def test_side_arrays_follow_their_rows():
+    """_confidence / _add_tick and the error counters are members of the reference's point clouds and travel with the rows
+    through cat / remove / delete (gaussian_pointcloud.py:286-303, 195-235)."""
+    a, b = _packed(6, 20), _packed(3, 21)
+    opt = _opt(a, n_frozen=2, capacity=7)
+    conf = opt.add_aux("confidence", 1, torch.float32, 0.0)
+    tick = opt.add_aux("add_tick", 1, torch.int32, -1)
+    conf[:6, 0] = torch.arange(6.0)
+    tick[:6, 0] = torch.arange(6, dtype=torch.int32) * 10
+    opt.append_rows(b, aux={"add_tick": 77})                              # re-allocates (capacity 7): old values survive
+    assert opt.aux["confidence"][:9, 0].tolist() == [0, 1, 2, 3, 4, 5, 0, 0, 0]
+    assert opt.aux["add_tick"][:9, 0].tolist() == [0, 10, 20, 30, 40, 50, 77, 77, 77]
+    mask = torch.zeros(9, dtype=torch.bool)
+    mask[[3, 7]] = True
+    opt.freeze_rows(mask)                                                  # rows 3 and 7 move behind the frozen prefix
+    assert opt.aux["confidence"][:9, 0].tolist() == [0, 1, 3, 0, 2, 4, 5, 0, 0]
+    assert opt.aux["add_tick"][:9, 0].tolist() == [0, 10, 30, 77, 20, 40, 50, 77, 77]
+    rm = torch.zeros(9, dtype=torch.bool)
+    rm[[0, 4]] = True
+    opt.remove_rows(rm)
+    assert (opt.N, opt.n_frozen) == (7, 3)
+    assert opt.aux["add_tick"][:7, 0].tolist() == [10, 30, 77, 40, 50, 77, 77]
+    assert opt.aux["add_tick"][7:9, 0].tolist() == [-1, -1]                # vacated storage is back at the fill value
+    gd = opt.gaussian_data("stable")
+    assert gd["xyz"].shape == (3, 3) and gd["xyz"].data_ptr() == opt.state["xyz"]["p"].data_ptr()
+    gu = opt.gaussian_data("unstable")
+    assert gu["xyz"].shape == (4, 3) and torch.equal(gu["xyz"], opt.params[3:, 0:3])
+
+
+def test_global_optimization_trains_the_stable_prefix_and_nothing_else():
+    """Mapping.global_optimization (mapper.py:594-707): `stable_pointcloud.parametrize` with rescaled learning rates, the
+    renderer is handed `self.stable_params` only.  In the map object: between begin_ and end_global_optimization the loss
+    sees the stable prefix alone, its rows step with the scaled rates, the unstable suffix is bit-unchanged; afterwards the
+    local form works as before."""
+    a = _packed(12, 22)
+    nf = 7
+    w = torch.linspace(0.5, 1.5, 12)
+    opt = _opt(a, n_frozen=nf)
+    opt.step(_loss(w))                                                     # a local step first: unstable rows move
+    mid = opt.params
+    assert torch.equal(mid[:nf], a[:nf])
+    scale = mo.global_lr_scale(final=False)
+    assert scale[:3].tolist() == [0, 0, 0] and float(scale[3:].min()) == float(scale[3:].max()) == pytest.approx(0.1)
+    opt.begin_global_optimization(scale)
+    seen = []
+
+    def loss(gd):
+        seen.append(int(gd["xyz"].shape[0]))
+        return _loss(w)(gd)
+    for _ in range(3):
+        opt.step(loss)
+    assert seen == [nf] * 3                                                # the loss (the renderer) sees the stable rows only
+    after = opt.params
+    assert torch.equal(after[nf:], mid[nf:])                               # unstable suffix: bit for bit
+    assert torch.equal(after[:nf, 0:3], mid[:nf, 0:3])                     # position lr 0 (mapper.py:607)
+    assert float((after[:nf, 3:] - mid[:nf, 3:]).abs().max()) > 0
+    ref = mo.ShardedMapOptimizer(mid[:nf].clone(), lr_col=mo.default_lr_columns() * scale, adam_fn=adam_reference,
+                                 activate_fn=td.activate8)
+    for _ in range(3):
+        ref.step(_loss(w))
+    assert torch.equal(after[:nf], ref.params)
+    with pytest.raises(RuntimeError):
+        opt.append_rows(_packed(1, 23))                                    # the shape is fixed while the mode is on
+    opt.end_global_optimization()
+    opt.step(_loss(w))                                                     # local again: fresh Adam state, unstable rows only
+    last = opt.params
+    assert torch.equal(last[:nf], after[:nf]) and opt.step_count == 1
+    ref2 = _opt(after[nf:])
+    ref2.step(_loss(w[nf:]))
+    assert torch.equal(last[nf:], ref2.params)
+    final = mo.global_lr_scale(final=True, feature_lr_coef=4.0, scaling_lr_coef=4.0, rotation_lr_coef=4.0)
+    assert final[3:51].unique().tolist() == [4.0] and final[51].item() == 1.0 and final[52:].unique().tolist() == [4.0]
+    with pytest.raises(RuntimeError):
+        _opt(a, n_frozen=0).begin_global_optimization()
