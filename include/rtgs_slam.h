@@ -7,6 +7,8 @@
  *   tile-mask producers      SLAM/utils.py:681-734 (pixelmask2tilemask, transmission2tilemask, colorerror2tilemask)
  *                            and the render-range step of mapper.py:471-508
  *   rtgs_knn3                simple_knn._C.distCUDA2 (un-vendored CUDA submodule; call site gaussian_pointcloud.py:376)
+ *   rtgs_knn3_query          pytorch3d.ops.knn_points as Mapping.temp_points_filter uses it (mapper.py:803-827), and the
+ *                            new-point rows of update_geometry's distCUDA2 (gaussian_pointcloud.py:366-381)
  *   rtgs_accumulate_error    cuda_utils._C.accumulate_gaussian_error (un-vendored; call site mapper.py:541-565)
  *   frame preprocessing      tracker.py:97-159 -> SLAM/utils.py:65-139 (vertex / normal / confidence maps),
  *                            SLAM/utils.py:550-589 (bilateral filter), SLAM/utils.py:141-183 (sample_pixels' mask)
@@ -55,6 +57,17 @@ int rtgs_render_range(const float* T_map, int32_t H, int32_t W, float ratio, uin
  * scratch: rtgs_knn3_scratch_bytes(N) bytes. */
 size_t rtgs_knn3_scratch_bytes(int32_t N);
 int rtgs_knn3(const float* points, int32_t N, float* mean_dist2, int32_t* idx, float* dist2, void* scratch, void* stream);
+/* Cross-set form: for each of the Nq QUERY points its three nearest REFERENCE points (idx[Nq,3] into ref_points, ascending
+ * by distance; dist2[Nq,3], may be NULL; fewer than three references: -1 / FLT_MAX).  Exact, same search structure (built
+ * over the references; queries are seeded by a binary search of their Morton code).  What it replaces in the reference:
+ * pytorch3d.ops.knn_points(temp_xyz, exist_xyz, K=3) in Mapping.temp_points_filter (mapper.py:803-827), and - with
+ * self_offset >= 0: query i IS reference self_offset + i and does not find itself - the `knn_indices[:points_num]` rows
+ * of distCUDA2(total_xyz) in GaussianPointCloud.update_geometry (gaussian_pointcloud.py:366-381), which needs the
+ * neighbours of the NEW points only.  self_offset < 0: the sets are unrelated.  ref_box6 (device float[6] = lo xyz, hi xyz;
+ * NULL = none): references outside the OPEN box are ignored - bbox_filter (SLAM/utils.py:737-744), which both call sites
+ * apply to the existing points before the search, without a compaction.  scratch: rtgs_knn3_scratch_bytes(Nr). */
+int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_points, int32_t Nq, int32_t self_offset,
+                    const float* ref_box6, int32_t* idx, float* dist2, void* scratch, void* stream);
 
 /* ---- cuda_utils.accumulate_gaussian_error --------------------------------------------------------------------- */
 /* FROZEN semantics (the CUDA source is absent; mapper.py:541-571 is the evidence): colour error goes to the Gaussian in

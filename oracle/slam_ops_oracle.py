@@ -73,6 +73,33 @@ def dist2_knn(points: torch.Tensor, chunk: int = 2048):
     return best_d.sum(1) / 3.0, best_i.int(), best_d
 
 
+def knn_query(ref: torch.Tensor, query: torch.Tensor, self_offset: int = -1, ref_box=None, chunk: int = 2048):
+    """Three nearest REFERENCE points of every query point, brute force: (dist2 [Nq,3] ascending, idx [Nq,3]) - what
+    pytorch3d.ops.knn_points(query[None], ref[None], K=3) returns (squared distances; mapper.py:811-818 takes their sqrt),
+    with the float32 distance formula of dist2_knn.  self_offset >= 0: query i is ref[self_offset + i] and is skipped
+    (the new-point rows of update_geometry's distCUDA2, gaussian_pointcloud.py:366-381)."""
+    Nq, Nr = query.shape[0], ref.shape[0]
+    q, r = query.float(), ref.float()
+    best_d = torch.full((Nq, 3), torch.finfo(torch.float32).max)
+    best_i = torch.full((Nq, 3), -1, dtype=torch.int64)
+    for s in range(0, Nq, chunk):
+        e = min(Nq, s + chunk)
+        dx, dy, dz = q[s:e, 0, None] - r[None, :, 0], q[s:e, 1, None] - r[None, :, 1], q[s:e, 2, None] - r[None, :, 2]
+        d = dx * dx + dy * dy + dz * dz
+        if self_offset >= 0:
+            d[torch.arange(e - s), self_offset + torch.arange(s, e)] = float("inf")
+        if ref_box is not None:                                   # bbox_filter (SLAM/utils.py:737-744): strict inequalities
+            inb = (r > ref_box[:3]).all(-1) & (r < ref_box[3:]).all(-1)
+            d[:, ~inb] = float("inf")
+        k = min(3, Nr)
+        if k > 0:
+            v, i = torch.topk(d, k=k, dim=1, largest=False)
+            ok = torch.isfinite(v)
+            best_d[s:e, :k] = torch.where(ok, v, best_d[s:e, :k])
+            best_i[s:e, :k] = torch.where(ok, i, best_i[s:e, :k])
+    return best_d, best_i.int()
+
+
 # ------------------------------------------------------------------ (f-1) cuda_utils.accumulate_gaussian_error  [FROZEN]
 def accumulate_gaussian_error(H, W, P, color_err, depth_err, normal_err, color_index, depth_index, thr_c, thr_d, thr_n,
                               mean=True):

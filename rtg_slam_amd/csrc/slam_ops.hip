@@ -138,6 +138,11 @@ __global__ void __launch_bounds__(1024) tile_topk_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------ 3-NN search
 constexpr int KNN_BOX = 1024;
 
+__global__ void __launch_bounds__(256) fill_f32_kernel(float* __restrict__ out, int n, float v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = v;
+}
+
 __global__ void __launch_bounds__(256) knn_bbox_kernel(const float* __restrict__ pts, int N, uint32_t* __restrict__ bbox) {
   uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256)
@@ -187,7 +192,7 @@ __global__ void __launch_bounds__(256) knn_gather_kernel(const float* __restrict
     if (i < N) {
       const uint32_t o = order[i];
       const float x = pts[(size_t)o * 3], y = pts[(size_t)o * 3 + 1], z = pts[(size_t)o * 3 + 2];
-      sorted[i] = make_float4(x, y, z, 0.f);
+      sorted[i] = make_float4(x, y, z, __int_as_float((int)o));     // .w: the point's index (rtgs_knn3_query's self test)
       mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
       mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
     }
@@ -262,6 +267,78 @@ __global__ void __launch_bounds__(256) knn_search_kernel(const float4* __restric
   for (int k = 0; k < 3; ++k) {
     idx[(size_t)o * 3 + k] = bj[k] >= 0 ? (int32_t)order[bj[k]] : -1;
     if (dist_out) dist_out[(size_t)o * 3 + k] = bd[k];
+  }
+}
+
+// Cross-set query (rtgs_knn3_query): the three nearest REFERENCE points of every query point.  Queries come in caller order
+// (no sort): a lane finds where its point would sit in the references' Morton order by a binary search of its code among
+// the sorted codes and seeds its bound with the eight references around that position - close in space as a rule - so that
+// the box sweep opens only boxes near the query.  `self_offset` >= 0: query i IS reference self_offset + i (the new points
+// of GaussianPointCloud.update_geometry, gaussian_pointcloud.py:366-405, sit at the front of `total_xyz`) and is skipped.
+__global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict__ sorted, int N, const uint32_t* __restrict__ codes_sorted,
+                                                        const uint32_t* __restrict__ bbox, const float* __restrict__ boxes, int nboxes,
+                                                        const float* __restrict__ query, int Nq, int self_offset,
+                                                        const float* __restrict__ ref_box, int32_t* __restrict__ idx,
+                                                        float* __restrict__ dist_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < Nq;
+  // optional open box (lo, hi): references outside it do not exist for the search (bbox_filter, SLAM/utils.py:737-744)
+  float blo[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}, bhi[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  if (ref_box) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { blo[c] = ref_box[c]; bhi[c] = ref_box[3 + c]; }
+  }
+  auto inbox = [&](const float4 s) {
+    return s.x > blo[0] && s.y > blo[1] && s.z > blo[2] && s.x < bhi[0] && s.y < bhi[1] && s.z < bhi[2];
+  };
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bd[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  int bj[3] = {-1, -1, -1};
+  const int self = (live && self_offset >= 0) ? self_offset + i : -1;
+  if (live) {
+    p = make_float4(query[(size_t)i * 3], query[(size_t)i * 3 + 1], query[(size_t)i * 3 + 2], 0.f);
+    uint32_t q[3];
+    const float pc[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float lo = dec_f(bbox[c]), hi = dec_f(bbox[3 + c]);
+      const float ext = hi - lo;
+      const float t = ext > 0.f ? (pc[c] - lo) / ext : 0.f;
+      q[c] = (uint32_t)fminf(1023.f, fmaxf(0.f, t * 1023.f));
+    }
+    const uint32_t code = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    int lo = 0, hi = N;                                         // lower bound of `code`
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (codes_sorted[mid] < code) lo = mid + 1; else hi = mid; }
+    for (int j = max(0, lo - 4); j <= min(N - 1, lo + 3); ++j) {
+      const float4 s = sorted[j];
+      if (__float_as_int(s.w) != self && inbox(s)) knn_insert(dist2(p, s), j, bd, bj);
+    }
+  }
+  for (int b = 0; b < nboxes; ++b) {
+    const float* bx = boxes + b * 6;
+    const float ex = fmaxf(0.f, fmaxf(bx[0] - p.x, p.x - bx[3]));
+    const float ey = fmaxf(0.f, fmaxf(bx[1] - p.y, p.y - bx[4]));
+    const float ez = fmaxf(0.f, fmaxf(bx[2] - p.z, p.z - bx[5]));
+    const float lower = ((ex * ex + ey * ey) + ez * ez) * 0.9999f;
+    // a run of references entirely outside the filter box holds nothing to find
+    const bool outside = bx[3] <= blo[0] || bx[4] <= blo[1] || bx[5] <= blo[2] || bx[0] >= bhi[0] || bx[1] >= bhi[1] || bx[2] >= bhi[2];
+    const bool open = live && !outside && lower < bd[2];
+    if (__builtin_amdgcn_ballot_w64(open) == 0ull) continue;
+    if (open) {
+      const int j0 = b * KNN_BOX, j1 = min(N, j0 + KNN_BOX);
+      for (int j = j0; j < j1; ++j) {
+        const int already = (j == bj[0]) | (j == bj[1]) | (j == bj[2]);    // the seeds
+        if (already) continue;
+        const float4 s = sorted[j];
+        if (__float_as_int(s.w) != self && inbox(s)) knn_insert(dist2(p, s), j, bd, bj);
+      }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    idx[(size_t)i * 3 + k] = bj[k] >= 0 ? __float_as_int(sorted[bj[k]].w) : -1;
+    if (dist_out) dist_out[(size_t)i * 3 + k] = bd[k];
   }
 }
 
@@ -559,10 +636,8 @@ int rtgs_render_range(const float* T_map, int32_t H, int32_t W, float ratio, uin
 
 size_t rtgs_knn3_scratch_bytes(int32_t N) { return knn_layout(N).total; }
 
-int rtgs_knn3(const float* points, int32_t N, float* mean_dist2, int32_t* idx, float* dist2_out, void* scratch, void* stream) {
-  if (N < 0 || (N > 0 && (!points || !mean_dist2 || !idx || !scratch))) return -1;
-  if (N == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
+// bounding box -> Morton codes -> sorted order -> points gathered in that order + one AABB per run of KNN_BOX points
+static int knn_build(const float* points, int32_t N, void* scratch, hipStream_t st) {
   const KnnLayout L = knn_layout(N);
   char* s = (char*)scratch;
   uint32_t* bbox = (uint32_t*)(s + L.bbox);
@@ -581,8 +656,45 @@ int rtgs_knn3(const float* points, int32_t N, float* mean_dist2, int32_t* idx, f
   SLAM_TRY(rocprim::radix_sort_pairs(s + L.cub, tb, codes, codes_sorted, order_in, order, (size_t)N, 0u, 30u, st));
   const int nboxes = (N + KNN_BOX - 1) / KNN_BOX;
   hipLaunchKernelGGL(knn_gather_kernel, dim3(nboxes), dim3(256), 0, st, points, N, (const uint32_t*)order, sorted, boxes);
-  hipLaunchKernelGGL(knn_search_kernel, dim3(g), dim3(256), 0, st, (const float4*)sorted, N, (const uint32_t*)order,
-                     (const float*)boxes, nboxes, mean_dist2, idx, dist2_out);
+  return 0;
+}
+
+int rtgs_knn3(const float* points, int32_t N, float* mean_dist2, int32_t* idx, float* dist2_out, void* scratch, void* stream) {
+  if (N < 0 || (N > 0 && (!points || !mean_dist2 || !idx || !scratch))) return -1;
+  if (N == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const KnnLayout L = knn_layout(N);
+  char* s = (char*)scratch;
+  const int rc = knn_build(points, N, scratch, st);
+  if (rc != 0) return rc;
+  const int nboxes = (N + KNN_BOX - 1) / KNN_BOX;
+  hipLaunchKernelGGL(knn_search_kernel, dim3(grid1(N)), dim3(256), 0, st, (const float4*)(s + L.sorted), N,
+                     (const uint32_t*)(s + L.order), (const float*)(s + L.boxes), nboxes, mean_dist2, idx, dist2_out);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_points, int32_t Nq, int32_t self_offset,
+                    const float* ref_box6, int32_t* idx, float* dist2_out, void* scratch, void* stream) {
+  if (Nr < 0 || Nq < 0 || (Nq > 0 && (!query_points || !idx))) return -1;
+  if (Nr > 0 && (!ref_points || !scratch)) return -1;
+  if (self_offset >= 0 && (int64_t)self_offset + Nq > Nr) return -1;
+  if (Nq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (Nr == 0) {                                              // nobody to find: -1 / FLT_MAX, as rtgs_knn3 with < 4 points
+    SLAM_TRY(hipMemsetAsync(idx, 0xff, (size_t)Nq * 3 * sizeof(int32_t), st));
+    if (dist2_out) hipLaunchKernelGGL(fill_f32_kernel, dim3(grid1(Nq * 3)), dim3(256), 0, st, dist2_out, Nq * 3, FLT_MAX);
+    SLAM_TRY(hipGetLastError());
+    return 0;
+  }
+  const KnnLayout L = knn_layout(Nr);
+  char* s = (char*)scratch;
+  const int rc = knn_build(ref_points, Nr, scratch, st);
+  if (rc != 0) return rc;
+  const int nboxes = (Nr + KNN_BOX - 1) / KNN_BOX;
+  hipLaunchKernelGGL(knn_query_kernel, dim3(grid1(Nq)), dim3(256), 0, st, (const float4*)(s + L.sorted), Nr,
+                     (const uint32_t*)(s + L.codes_sorted), (const uint32_t*)(s + L.bbox), (const float*)(s + L.boxes), nboxes,
+                     query_points, Nq, self_offset, ref_box6, idx, dist2_out);
   SLAM_TRY(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,622 @@
+"""`Mapping`: the lifecycle of RTG-SLAM's map around the hot path - the callers of the rasterizer and of the one-call map
+step - under the reference's own method names (/root/reference/SLAM/multiprocess/mapper.py), on the product's map object
+(`ShardedMapOptimizer`: rows [stable | unstable], side arrays, local / global optimisation modes) and the HIP ops.
+
+    mapping                  mapper.py:97-126     per frame: add, optimise every `gaussian_update_frame`-th frame, fix, prune
+    gaussians_add            :128-132, 709-883    temp_points_init / _filter / _attach / temp_to_optimize
+    local_optimize           :134-210             evaluate_render_range on the UNSTABLE rows of each window frame, a fresh
+                                                  Adam, `gaussian_update_iter` loss_update iterations, history_merge
+    global_optimization      :594-707             the stable rows alone, rescaled learning rates, colour-error tile masks
+    gaussians_fix            :253-271             confidence > stable_confidence_thres -> stable (freeze_rows)
+    gaussians_delete         :298-335             too big / unstable for too long -> removed (remove_rows)
+    error_gaussians_remove   :510-592             per-Gaussian error accumulation, counters, delete / release
+    check_keyframe           :337-369
+    evaluate_render_range    :471-508
+    get_render_output        :943-958
+
+What is NOT here: dataset IO, the ORB backend, tensorboard / model snapshots (io_formats.py writes the PLYs), the
+multi-process plumbing.  What differs, deliberately:
+  * row order is [stable | unstable] (the reference concatenates [unstable, stable], :1069-1108); indices of a render of
+    the whole map therefore address stable rows first.  Only tie-breaks between equal depths can see the order.
+  * shape changes cost O(moved rows) in place (append / freeze / remove of the map object) instead of re-concatenating
+    every tensor; boolean-mask compactions - each a device-to-host synchronisation in the reference - are kept to the
+    ones whose result changes a shape: two per added frame, one per fix / delete that finds something.
+  * bbox_filter (SLAM/utils.py:737-744) runs inside the neighbour query (rtgs_knn3_query's box), not as a compaction.
+  * keyframe images stay on the device (the reference parks them on the CPU, :349-367; 288 GB of HBM make that moot).
+  * a render of (frame, map version) is remembered: error_gaussians_remove and get_render_output ask for the same frame
+    of the same map when nothing was deleted in between.
+There is no CPU path: `ops` defaults to the HIP modules; tests inject torch doubles to exercise the host logic."""
+from __future__ import annotations
+
+import math
+import random
+from collections import deque
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import map_optim as mo
+
+SH_C0 = 0.28209479177387814
+
+
+def replica_args(**over) -> SimpleNamespace:
+    """configs/base.yaml overlaid with configs/replica_base.yaml (the values Mapping / Tracker / Renderer / IcpTracker read)."""
+    a = dict(
+        # gaussian params (base.yaml:30-36)
+        active_sh_degree=3, max_sh_degree=3, xyz_factor=[1.0, 1.0, 0.1], init_opacity=0.99, scale_factor=1.0,
+        max_radius=0.05, min_radius=0.001,
+        # map preprocess (:38-43)
+        min_depth=0.3, max_depth=5.0, depth_filter=False, invalid_confidence_thresh=0.2, global_keyframe_num=3,
+        # map params (:45-54; replica_base.yaml:9,14)
+        memory_length=5, uniform_sample_num=40800, add_transmission_thres=0.5, transmission_sample_ratio=1.0,
+        error_sample_ratio=0.05, add_depth_thres=0.1, add_color_thres=0.1, add_normal_thres=1000.0,
+        history_merge_max_weight=0.5,
+        # state manage (:56-62; replica_base.yaml:12-13)
+        keyframe_trans_thes=0.3, keyframe_theta_thes=30.0, stable_confidence_thres=100.0, unstable_time_window=120,
+        KNN_num=15, KNN_threshold=-1,
+        # render params (:64-70)
+        renderer_opaque_threshold=0.6, renderer_normal_threshold=60.0, renderer_depth_threshold=1.0, color_sigma=3.0,
+        global_opt_top_ratio=0.4,
+        # optimize params (:73-91; replica_base.yaml:16-24, 38-40)
+        gaussian_update_iter=50, gaussian_update_frame=6, final_global_iter=20, color_weight=0.8, depth_weight=1.0,
+        ssim_weight=0.2, normal_weight=0.0, position_lr=0.001, feature_lr=0.0005, opacity_lr=0.0, scaling_lr=0.004,
+        rotation_lr=0.001, feature_lr_coef=4.0, scaling_lr_coef=4.0, rotation_lr_coef=4.0,
+        # ICP (:93-103; replica_base.yaml:26-35)
+        use_gt_pose=False, icp_use_model_depth=True, icp_downscales=[0.25, 0.5, 1.0], icp_damping=0.0001,
+        icp_downscale_iters=[5, 5, 5], icp_distance_threshold=0.1, icp_normal_threshold=20.0,
+        icp_sample_distance_threshold=0.01, icp_sample_normal_threshold=0.01, icp_warmup_frames=0, icp_fail_threshold=0.02,
+        verbose=False, type="Replica")
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+def tum_args(**over) -> SimpleNamespace:
+    """configs/tum_base.yaml over base.yaml (the keys that differ from Replica's)."""
+    a = dict(uniform_sample_num=30720, memory_length=5, stable_confidence_thres=200.0, unstable_time_window=150,
+             gaussian_update_iter=50, gaussian_update_frame=4, invalid_confidence_thresh=0.5, type="TUM")
+    a.update(over)
+    return replica_args(**a)
+
+
+class Frame:
+    """What the reference's Camera (scene/cameras.py) offers the mapper, tracker and renderer: the attributes
+    Renderer.render reads (render.py:66-86), the pose (R = W2C[:3,:3]^T, T = W2C[:3,3]; cameras.py:96-137), intrinsics
+    (:147-154) and get_uv (:161-168).  `camera_center` is NOT refreshed by updatePose - cameras.py:125-137 does not either
+    (SURVEY.md Appendix A): SH view directions use the pose the frame was constructed with."""
+
+    _serial = 0
+
+    def __init__(self, cam, c2w, device, uid: int = 0):
+        Frame._serial += 1
+        self.serial, self.pose_version = Frame._serial, 0                 # identity of (frame, pose) for render caches
+        self.image_height, self.image_width = int(cam.H), int(cam.W)
+        self.fx, self.fy, self.cx, self.cy = float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy)
+        self.FoVx = 2 * math.atan(cam.W / (2 * cam.fx))
+        self.FoVy = 2 * math.atan(cam.H / (2 * cam.fy))
+        self.device, self.uid = device, uid
+        self.K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32, device=device)
+        c2w = torch.as_tensor(np.asarray(c2w, dtype=np.float64))
+        self.camera_center = c2w[:3, 3].float().to(device)
+        self._rs = None
+        self.updatePose(c2w)
+
+    def updatePose(self, pose_c2w):
+        c2w = torch.as_tensor(np.asarray(pose_c2w, dtype=np.float64))
+        self.c2w = c2w
+        self.pose_version += 1
+        w2c = torch.linalg.inv(c2w)
+        self.R = w2c[:3, :3].t().numpy().copy()
+        self.T = w2c[:3, 3].numpy().copy()
+        self.world_view_transform = w2c.float().t().contiguous().to(self.device)
+        self.full_proj_transform = self.world_view_transform
+        self._w2c = w2c.float().to(self.device)
+        self._rs = None
+
+    @property
+    def get_intrinsic(self):
+        return self.K
+
+    @property
+    def get_c2w(self):
+        return self.c2w.float().to(self.device)
+
+    def get_w2c(self):
+        return self._w2c
+
+    def get_uv(self, xyz_w):
+        xyz_c = xyz_w @ self._w2c[:3, :3].T + self._w2c[:3, 3]
+        uv = xyz_c @ self.K.T
+        return (uv[:, :2] / uv[:, 2:]).long()
+
+    def raster_settings(self, args):
+        if self._rs is None:
+            from .rasterizer import GaussianRasterizationSettings
+            deg = args.max_sh_degree if args.active_sh_degree < 0 else args.active_sh_degree
+            self._rs = GaussianRasterizationSettings(
+                image_height=self.image_height, image_width=self.image_width, tanfovx=math.tan(self.FoVx * 0.5),
+                tanfovy=math.tan(self.FoVy * 0.5), bg=torch.zeros(3, device=self.device), scale_modifier=1.0,
+                viewmatrix=self.world_view_transform, projmatrix=self.full_proj_transform, sh_degree=deg,
+                campos=self.camera_center, opaque_threshold=args.renderer_opaque_threshold,
+                depth_threshold=args.renderer_depth_threshold,
+                normal_threshold=math.cos(math.radians(args.renderer_normal_threshold)), color_sigma=args.color_sigma,
+                prefiltered=False, debug=False, cx=self.cx, cy=self.cy, T_threshold=0.0001)
+        return self._rs
+
+
+class HipOps:
+    """The HIP kernels behind Mapping (the only implementation the product ships)."""
+
+    def __init__(self, args, device):
+        from . import slam_ops
+        from .render import Renderer
+        self.so = slam_ops
+        self.renderer = Renderer(args)
+        self.args = args
+        self.gen = torch.Generator(device=device).manual_seed(int(getattr(args, "seed", 0)))
+
+    def make_optimizer(self, packed, lr_col, capacity):
+        return mo.ShardedMapOptimizer(packed, lr_col=lr_col, capacity=capacity)
+
+    def render(self, frame, gd, tile_mask=None):
+        with torch.no_grad():
+            return self.renderer.render(frame, gd, tile_mask=tile_mask)
+
+    def render_range(self, T_map, ratio):
+        return self.so.render_range(T_map, ratio)
+
+    def colorerror2tilemask(self, err, stride, ratio):
+        return self.so.colorerror2tilemask(err, stride, ratio)
+
+    def sample_pixels(self, vertex, normal, color, n, mask):
+        return self.so.sample_pixels(vertex, normal, color, n, mask, self.gen)
+
+    def knn_query(self, ref, query, self_offset=-1, ref_box=None):
+        return self.so.knn_query(ref, query, self_offset, ref_box)
+
+    def accumulate_gaussian_error(self, *a):
+        return self.so.accumulate_gaussian_error(*a)
+
+    def history_merge(self, opt, confidence, max_weight):
+        opt.history_merge(confidence, max_weight)
+
+    def step(self, opt, frame, gt_color, gt_depth, tile_mask, render_mask, confidence, w):
+        return opt.step_slam(frame.raster_settings(self.args), gt_color, gt_depth, tile_mask, color_weight=w.color_weight,
+                             depth_weight=w.depth_weight, ssim_weight=w.ssim_weight, add_depth_thres=w.add_depth_thres,
+                             render_mask=render_mask, confidence=confidence)
+
+
+def RGB2SH(rgb):
+    return (rgb - 0.5) / SH_C0
+
+
+def inverse_sigmoid(x):
+    return math.log(x / (1 - x))
+
+
+def compute_rot(target_vec: torch.Tensor) -> torch.Tensor:
+    """compute_rot((0,0,1), normal) of SLAM/utils.py:216-221 + quaternion_from_axis_angle (general_utils.py:185-191):
+    the quaternion (w, x, y, z) that turns the z axis onto `target_vec`."""
+    z = torch.zeros_like(target_vec)
+    z[:, 2] = 1.0
+    axis = torch.linalg.cross(z, target_vec)
+    axis = axis / (torch.norm(axis, p=2, dim=-1, keepdim=True) + 1e-8)
+    angle = torch.acos(target_vec[:, 2:3])
+    axis = axis / (torch.norm(axis, p=2, dim=-1, keepdim=True) + 1e-8)
+    return torch.cat([torch.cos(angle / 2), axis * torch.sin(angle / 2)], dim=1)
+
+
+class Mapping:
+    def __init__(self, args, device, ops=None, capacity: Optional[int] = None, lr_scale: float = 1.0):
+        self.args, self.device = args, device
+        self.ops = ops if ops is not None else HipOps(args, device)
+        self.time = 0
+        self.iter = 0
+        self.processed_frames = deque(maxlen=args.memory_length)
+        self.processed_map = deque(maxlen=args.memory_length)
+        self.keyframe_list, self.keymap_list, self.keyframe_ids, self.optimize_frames_ids = [], [], [], []
+        self.lr_col = mo.default_lr_columns(args.position_lr, args.feature_lr, args.opacity_lr, args.scaling_lr,
+                                            args.rotation_lr) * float(lr_scale)
+        cap = int(capacity) if capacity is not None else 8 * int(args.uniform_sample_num)
+        self.opt = self.ops.make_optimizer(torch.zeros(0, mo.COLS, dtype=torch.float32, device=device), self.lr_col, cap)
+        for name, dtype, fill in (("confidence", torch.float32, 0.0), ("add_tick", torch.int32, 0),
+                                  ("depth_error_counter", torch.int32, 0), ("color_error_counter", torch.int32, 0)):
+            self.opt.add_aux(name, 1, dtype, fill)
+        self.frame_map: Dict[str, torch.Tensor] = {}
+        self.model_map: Dict[str, torch.Tensor] = {}
+        self._render_cache = None
+        self.xyz_factor = torch.tensor(args.xyz_factor, dtype=torch.float32, device=device)
+        self.rng = random.Random(int(getattr(args, "seed", 0)))
+        self.stats = dict(added=0, fixed=0, deleted_unstable=0, deleted_stable=0, released=0, local_opts=0, global_opts=0,
+                          iterations=0, renders=0, renders_reused=0)
+        self.weights = SimpleNamespace(color_weight=args.color_weight, depth_weight=args.depth_weight,
+                                       ssim_weight=args.ssim_weight, add_depth_thres=args.add_depth_thres)
+
+    # ------------------------------------------------------------------ sizes and views
+    @property
+    def get_stable_num(self) -> int:
+        return self.opt.n_frozen
+
+    @property
+    def get_unstable_num(self) -> int:
+        return self.opt.n_train
+
+    @property
+    def get_pixel_num(self) -> int:
+        return int(self.frame_map["depth_map"].shape[0] * self.frame_map["depth_map"].shape[1])
+
+    @property
+    def get_keyframe_num(self) -> int:
+        return len(self.keyframe_list)
+
+    def aux(self, name, rows="all"):
+        o = self.opt
+        r0, r1 = {"all": (0, o.N), "stable": (0, o.n_frozen), "unstable": (o.n_frozen, o.N)}[rows]
+        return o.aux[name][r0:r1]
+
+    def params(self, rows="all"):
+        """global_params / stable_params / unstable_params (mapper.py:984-1108) incl. `radius` and `confidence`."""
+        gd = self.opt.gaussian_data(rows)
+        s = gd["scales"]
+        gd["radius"] = (s.sum(dim=1) - s.min(dim=1).values) / 2 if s.shape[0] else s.new_zeros(0)   # get_radius, gaussian_pointcloud.py:515-519
+        gd["confidence"] = self.aux("confidence", rows)
+        return gd
+
+    @property
+    def global_params(self):
+        return self.params("all")
+
+    @property
+    def stable_params(self):
+        return self.params("stable")
+
+    @property
+    def unstable_params(self):
+        return self.params("unstable")
+
+    def _render(self, frame, rows="all", tile_mask=None):
+        key = (frame.serial, frame.pose_version, rows, self.opt.version)
+        if tile_mask is None and self._render_cache is not None and self._render_cache[0] == key:
+            self.stats["renders_reused"] += 1
+            return self._render_cache[1]
+        out = self.ops.render(frame, self.opt.gaussian_data(rows), tile_mask=tile_mask)
+        self.stats["renders"] += 1
+        if tile_mask is None:
+            self._render_cache = (key, out)
+        return out
+
+    # ------------------------------------------------------------------ per frame (mapper.py:97-126)
+    def mapping(self, frame, frame_map, frame_id, optimization_params=None):
+        self.frame_map = frame_map
+        if "color_chw" not in frame_map:                                 # the [C,H,W] form the loss kernels read, once per frame
+            frame_map["color_chw"] = frame_map["color_map"].permute(2, 0, 1).contiguous()
+            frame_map["depth_chw"] = frame_map["depth_map"].permute(2, 0, 1).contiguous()
+        self.gaussians_add(frame)
+        self.processed_frames.append(frame)
+        self.processed_map.append(frame_map)
+        if (self.time + 1) % self.args.gaussian_update_frame == 0 or self.time == 0:
+            self.optimize_frames_ids.append(frame_id)
+            is_keyframe = self.check_keyframe(frame, frame_id)
+            if self.args.type == "Scannetpp":
+                self.local_optimize(frame)
+                if is_keyframe:
+                    self.global_optimization(select_keyframe_num=self.args.global_keyframe_num)
+            else:
+                if not is_keyframe or self.get_stable_num <= 0:
+                    self.local_optimize(frame)
+                else:
+                    self.global_optimization(select_keyframe_num=self.args.global_keyframe_num)
+                self.gaussians_delete(unstable=False)
+        self.gaussians_fix()
+        self.error_gaussians_remove()
+        self.gaussians_delete()
+
+    def gaussians_add(self, frame):
+        temp = self.temp_points_init(frame)
+        if temp is None:
+            return
+        keep = self.temp_points_filter(temp)
+        self.temp_points_attach(frame, temp)
+        self.temp_to_optimize(temp, keep)
+
+    # ------------------------------------------------------------------ new Gaussians (mapper.py:709-883)
+    def _new_points(self, parts):
+        """GaussianPointCloud.add_empty_points (gaussian_pointcloud.py:305-364) for the sampled pixels of this frame: unit
+        normals, SH dc from the colour, raw scale log(1e-6) until update_geometry, rotation z -> normal, init opacity.
+        (sample_pixels never returns a pixel whose normal sums to zero, which is the only thing :319-322 filters.)"""
+        parts = [p for p in parts if p[0].shape[0] > 0]
+        if not parts:
+            return None
+        xyz, normal, color = (torch.cat([p[k] for p in parts], 0) for k in range(3))
+        normal = normal / (torch.norm(normal, p=2, dim=-1, keepdim=True) + 1e-8)
+        n = xyz.shape[0]
+        a = self.args
+        same = a.xyz_factor[0] == 1 and a.xyz_factor[1] == 1 and a.xyz_factor[2] == 1
+        rots = torch.zeros(n, 4, device=xyz.device) if same else compute_rot(normal)
+        if same:
+            rots[:, 0] = 1
+        return dict(xyz=xyz.contiguous(), normal=normal, color=color, rots=rots,
+                    opacity_raw=torch.full((n, 1), inverse_sigmoid(a.init_opacity), device=xyz.device))
+
+    def temp_points_init(self, frame):
+        a, fm = self.args, self.frame_map
+        if self.time == 0:
+            mask = fm["depth_map"] > 0
+            return self._new_points([self.ops.sample_pixels(fm["vertex_map_w"], fm["normal_map_w"], fm["color_map"],
+                                                            a.uniform_sample_num, mask)])
+        self.get_render_output(frame)
+        mm = self.model_map
+        depth_ok = fm["depth_map"] > 0
+        tmask = (mm["render_transmission"] > a.add_transmission_thres) & depth_ok
+        depth_error = torch.abs(fm["depth_map"] - mm["render_depth"])
+        color_error = torch.abs(fm["color_map"] - mm["render_color"]).mean(dim=-1, keepdim=True)
+        dmask = (depth_error > a.add_depth_thres) & depth_ok & (mm["render_depth_index"] > -1)
+        cmask = (color_error > a.add_color_thres) & depth_ok & (mm["render_transmission"] < a.add_transmission_thres)
+        emask = (cmask | dmask) & (~tmask)
+        n_t, n_e = torch.stack([tmask.sum(), emask.sum()]).tolist()          # ONE synchronisation for both counts
+        # float32 arithmetic and truncation as devI(...) of mapper.py:737-741, 772
+        ratio = np.float32(n_t) / np.float32(self.get_pixel_num)
+        n_trans = int(np.float32(a.transmission_sample_ratio) * ratio * np.float32(a.uniform_sample_num))
+        n_err = int(np.float32(n_e) * np.float32(a.error_sample_ratio))
+        parts = []
+        for n, m in ((n_trans, tmask), (n_err, emask)):
+            if n > 0:
+                parts.append(self.ops.sample_pixels(fm["vertex_map_w"], fm["normal_map_w"], fm["color_map"], n, m))
+        return self._new_points(parts)
+
+    def temp_points_filter(self, temp, topk=3):
+        """Drop temp points that fall within 0.6 radius of one of their 3 nearest existing unstable Gaussians
+        (mapper.py:803-827).  Returns the keep mask (the compaction happens once, in temp_to_optimize)."""
+        n = temp["xyz"].shape[0]
+        keep = torch.ones(n, dtype=torch.bool, device=temp["xyz"].device)
+        if self.get_unstable_num > 0:
+            up = self.params("unstable")
+            lo, hi = temp["xyz"].min(dim=0)[0] - 0.05, temp["xyz"].max(dim=0)[0] + 0.05          # bbox_filter
+            d2, idx = self.ops.knn_query(up["xyz"], temp["xyz"], -1, torch.cat([lo, hi]))
+            found = idx >= 0
+            rad = up["radius"][idx.clamp_min(0).long()] * 0.6
+            keep = ~((torch.sqrt(d2) < rad) & found).any(dim=-1)
+        return keep
+
+    def temp_points_attach(self, frame, temp, unstable_opacity_low=0.1):
+        """Temp points that project onto a stable Gaussian and lie on its plane start at opacity 0.1 and are tied to their
+        initial state by the attach regulariser (mapper.py:830-883).  Mask arithmetic instead of index compactions."""
+        if self.get_stable_num == 0:
+            return
+        xyz = temp["xyz"]
+        uv = frame.get_uv(xyz)
+        inside = (uv[:, 0] >= 0) & (uv[:, 0] < frame.image_width) & (uv[:, 1] >= 0) & (uv[:, 1] < frame.image_height)
+        out = self._render(frame, "stable")
+        sidx = out["color_index_map"][0]
+        u, v = uv[:, 0].clamp(0, frame.image_width - 1), uv[:, 1].clamp(0, frame.image_height - 1)
+        hit = sidx[v, u].long()
+        valid = inside & (hit >= 0)
+        sp = self.opt.gaussian_data("stable")
+        h = hit.clamp_min(0)
+        p2p = ((sp["xyz"][h] - xyz) * sp["normal"][h]).sum(dim=-1)
+        attach = valid & (p2p.abs() < 0.5 * self.args.add_depth_thres)
+        low = torch.full_like(temp["opacity_raw"], inverse_sigmoid(unstable_opacity_low))
+        temp["opacity_raw"] = torch.where(attach[:, None], low, temp["opacity_raw"])
+
+    def temp_to_optimize(self, temp, keep):
+        """update_geometry (gaussian_pointcloud.py:366-405) + cat into the unstable cloud (mapper.py:886-899): the in-plane
+        scale of a new Gaussian = rms of (distance - 3 radius) to its three nearest neighbours among the new points and the
+        existing ones inside the new points' box; a new point INSIDE 3 radii of a neighbour is dropped."""
+        a = self.args
+        n_all = int(keep.shape[0])
+        sel = torch.nonzero(keep).reshape(-1)                        # synchronisation 1 of the add: what the filter left
+        if int(sel.shape[0]) < n_all:
+            temp = {k: v[sel] for k, v in temp.items()}
+        xyz = temp["xyz"].contiguous()
+        n = xyz.shape[0]
+        if n == 0:
+            return
+        gp = self.params("all")
+        tiny = torch.full((n,), 1e-6, device=xyz.device)             # get_radius of the still unscaled temp points
+        total_xyz = torch.cat([xyz, gp["xyz"]])
+        total_radius = torch.cat([tiny, gp["radius"]])
+        lo, hi = xyz.min(dim=0)[0] - 0.05, xyz.max(dim=0)[0] + 0.05
+        d2, idx = self.ops.knn_query(total_xyz, xyz, 0, torch.cat([lo, hi]))
+        j = idx.clamp_min(0).long()
+        dist = torch.sqrt(d2) - 3 * total_radius[j]                  # [n,3]; a missing neighbour (idx -1) is infinitely far
+        dist = torch.where(idx >= 0, dist, torch.full_like(dist, 1e30))
+        invalid = (dist < 0).any(dim=-1)
+        scales = torch.sqrt((dist ** 2).sum(dim=-1) / 3).clamp(a.min_radius, a.max_radius)
+        log_scales = torch.log(a.scale_factor * scales[:, None] * self.xyz_factor[None, :])
+        good = torch.nonzero(~invalid).reshape(-1)                   # synchronisation 2 of the add
+        m = int(good.shape[0])
+        if m == 0:
+            return
+        packed = torch.zeros(m, mo.COLS, dtype=torch.float32, device=xyz.device)
+        packed[:, 0:3] = xyz[good]
+        packed[:, 3:6] = RGB2SH(temp["color"][good])
+        packed[:, 51:52] = temp["opacity_raw"][good]
+        packed[:, 52:55] = log_scales[good]
+        packed[:, 55:59] = temp["rots"][good]
+        self.opt.append_rows(packed, aux={"add_tick": int(self.time)})
+        self.stats["added"] += m
+        self.stats["last_add"] = (n_all, n, m)
+
+    # ------------------------------------------------------------------ optimisation
+    def evaluate_render_range(self, frame, global_opt=False, sample_ratio=-1, unstable=True, gt_color=None):
+        """mapper.py:471-508.  Local: render the UNSTABLE rows, render_mask = T != 1, tile_mask = tiles more than half
+        covered.  Global: render the STABLE rows; with a sample ratio the tiles with the largest colour error."""
+        out = self._render(frame, "unstable" if unstable else "stable")
+        T = out["T_map"]
+        if global_opt and sample_ratio > 0:
+            render_image = out["render"].permute(1, 2, 0)
+            color_error = (render_image - gt_color).abs().sum(dim=-1)
+            color_error = torch.where(render_image.sum(dim=-1) == 0, torch.zeros_like(color_error), color_error)
+            tile_mask = self.ops.colorerror2tilemask(color_error, 16, sample_ratio)
+            H, W = color_error.shape
+            render_mask = tile_mask.bool().repeat_interleave(16, 0).repeat_interleave(16, 1)[:H, :W]
+            return render_mask.contiguous(), tile_mask, None
+        render_mask, tile_mask, count = self.ops.render_range(T, 0.5)
+        if global_opt:
+            tile_mask = None
+        return render_mask, tile_mask, count
+
+    def local_optimize(self, frame, update_args=None):
+        a, o = self.args, self.opt
+        conf = self.aux("confidence", "unstable").reshape(-1)
+        o.begin_local_optimization(confidence=conf)                      # history_stat + a fresh Adam (mapper.py:136-156)
+        masks = [self.evaluate_render_range(f) for f in self.processed_frames]
+        self.stats["local_opts"] += 1
+        if o.n_train == 0:
+            return
+        n_win = len(self.processed_frames)
+        for it in range(a.gaussian_update_iter):
+            self.iter = it
+            j = self.rng.randint(0, n_win - 1)
+            if it > a.gaussian_update_iter / 2:
+                j = -1
+            fm = self.processed_map[j]
+            self.ops.step(o, self.processed_frames[j], fm["color_chw"], fm["depth_chw"], masks[j][1],
+                          masks[j][0], conf, self.weights)
+        self.stats["iterations"] += a.gaussian_update_iter
+        self.iter = 0
+        self.ops.history_merge(o, conf, a.history_merge_max_weight)
+
+    def global_optimization(self, update_args=None, select_keyframe_num=-1, is_end=False):
+        """mapper.py:594-707.  Keyframe-triggered form (select_keyframe_num = global_keyframe_num): the last keyframes,
+        position lr 0 and everything else x 0.1, tiles with the largest 40 % colour error.  Final form (-1): everything
+        becomes stable first, all keyframes x final_global_iter iterations, no depth term, feature / scaling / rotation
+        rates x their coefficients, masks from the stable rows' transmission."""
+        a, o = self.args, self.opt
+        final = select_keyframe_num == -1
+        if final:
+            self.gaussians_fix(mask=self.aux("confidence", "unstable").reshape(-1) > -1)
+        if self.get_stable_num == 0:
+            return
+        scale = mo.global_lr_scale(final, a.feature_lr_coef, a.scaling_lr_coef, a.rotation_lr_coef)
+        o.begin_global_optimization(scale)
+        total_iter = int(a.gaussian_update_iter)
+        sample_ratio = 0.4
+        w = SimpleNamespace(**vars(self.weights))
+        if final:
+            total_iter = self.get_keyframe_num * a.final_global_iter
+            select_keyframe_num = self.get_keyframe_num
+            w.depth_weight = 0.0
+            self.weights.depth_weight = 0.0                              # the reference overwrites update_args (:633)
+            sample_ratio = -1
+        select_keyframe_num = min(select_keyframe_num, self.get_keyframe_num)
+        sel = [-i - 1 for i in range(select_keyframe_num)]
+        frames = [self.keyframe_list[i] for i in sel]
+        maps = [self.keymap_list[i] for i in sel]
+        masks = [self.evaluate_render_range(f, global_opt=True, unstable=False, sample_ratio=sample_ratio,
+                                            gt_color=m["color_map"]) for f, m in zip(frames, maps)]
+        conf = self.aux("confidence", "stable").reshape(-1)
+        for it in range(total_iter):
+            self.iter = it
+            j = self.rng.randint(0, select_keyframe_num - 1)
+            fr, im = frames[j], maps[j]
+            if it > total_iter / 2 and not final:
+                j = -1           # as the reference (:675-678): the FRAME stays the random one, the MASKS become the last entry's
+            self.ops.step(o, fr, im["color_chw"], im["depth_chw"], masks[j][1], masks[j][0], conf, w)
+        self.stats["iterations"] += total_iter
+        self.stats["global_opts"] += 1
+        self.iter = 0
+        o.end_global_optimization()
+
+    # ------------------------------------------------------------------ state management
+    def gaussians_fix(self, mask=None):
+        """mapper.py:253-271: unstable Gaussians whose confidence passed the threshold join the stable cloud."""
+        o = self.opt
+        if o.n_train == 0:
+            return
+        conf_u = self.aux("confidence", "unstable").reshape(-1)
+        stable_mask = (conf_u > self.args.stable_confidence_thres) if mask is None else mask.reshape(-1)
+        k = int(stable_mask.sum())                                       # the reference synchronises here too (:267)
+        if k > 0:
+            full = torch.zeros(o.N, dtype=torch.bool, device=self.device)
+            full[o.n_frozen:] = stable_mask
+            nf0 = o.n_frozen
+            o.freeze_rows(full)
+            c = o.aux["confidence"]
+            c[nf0:nf0 + k] = torch.clip(c[nf0:nf0 + k], max=self.args.stable_confidence_thres)
+            self.stats["fixed"] += k
+
+    def gaussians_delete(self, unstable=True):
+        """mapper.py:298-335: too big (radius > 10 x mean), or - unstable only - older than the time window."""
+        o = self.opt
+        rows = "unstable" if unstable else "stable"
+        r0, r1 = (o.n_frozen, o.N) if unstable else (0, o.n_frozen)
+        if r1 == r0:
+            return
+        radius = self.params(rows)["radius"]
+        delete_mask = radius > radius.mean() * 10
+        if unstable:
+            delete_mask = delete_mask | ((self.time - self.aux("add_tick", rows).reshape(-1)) > self.args.unstable_time_window)
+        k = int(delete_mask.sum())
+        if k > 0:
+            full = torch.zeros(o.N, dtype=torch.bool, device=self.device)
+            full[r0:r1] = delete_mask
+            o.remove_rows(full)
+            self.stats["deleted_unstable" if unstable else "deleted_stable"] += k
+
+    def check_keyframe(self, frame, frame_id):
+        def keep():
+            self.keyframe_list.append(frame)
+            self.keymap_list.append(self.frame_map)
+            self.keyframe_ids.append(frame_id)
+        if self.time == 0:
+            keep()
+            return False
+        prev = self.keyframe_list[-1]
+        rot_diff = prev.R @ frame.R.T                                    # rot_compare(prev.R.T, curr.R.T) = prev_rot.T @ curr_rot, SLAM/utils.py:42-47
+        theta = np.rad2deg(np.arccos(np.clip((np.trace(rot_diff) - 1) / 2, -1.0, 1.0)))
+        l2 = np.linalg.norm(prev.T - frame.T, ord=2)
+        if theta > self.args.keyframe_theta_thes or l2 > self.args.keyframe_trans_thes:
+            keep()
+            return True
+        return False
+
+    def error_gaussians_remove(self):
+        """mapper.py:510-592: back-project the errors of the newest frame onto the Gaussians that own its pixels; stable
+        Gaussians that were wrong in depth 10 times are deleted, wrong in colour 10 times "released" (confidence 0, new tick;
+        the reference re-appends them to the STABLE cloud - :286-295 - so they stay stable)."""
+        if self.get_stable_num <= 0:
+            return
+        o, a = self.opt, self.args
+        frame, cm = self.processed_frames[-1], self.processed_map[-1]
+        out = self._render(frame, "all")
+        color, depth = out["render"].permute(1, 2, 0), out["depth"].permute(1, 2, 0)
+        depth_index, color_index = out["depth_index_map"].permute(1, 2, 0), out["color_index_map"].permute(1, 2, 0)
+        diff = cm["depth_map"] - depth
+        depth_error = torch.where(diff < 0, torch.zeros_like(diff), diff.abs())
+        color_error = torch.abs(cm["color_map"] - color).sum(dim=-1, keepdim=True)
+        invalid = (cm["depth_map"] == 0) | (depth_index == -1)
+        depth_error = torch.where(invalid, torch.zeros_like(depth_error), depth_error)
+        color_error = torch.where(cm["depth_map"] == 0, torch.zeros_like(color_error), color_error)
+        normal_error = torch.zeros_like(depth_error)
+        H, W = cm["color_map"].shape[:2]
+        g_color, g_depth, _, _ = self.ops.accumulate_gaussian_error(
+            H, W, o.N, color_error, depth_error, normal_error, color_index, depth_index, a.add_color_thres,
+            a.add_depth_thres, a.add_normal_thres, True)
+        nf = o.n_frozen                                                  # stable rows come FIRST here ([unstable, stable] there)
+        dcnt, ccnt = o.aux["depth_error_counter"], o.aux["color_error_counter"]
+        dcnt[:nf, 0] += (g_depth[:nf] > 2 * a.add_depth_thres).to(dcnt.dtype)
+        ccnt[:nf, 0] += (g_color[:nf] > 2 * a.add_color_thres).to(ccnt.dtype)
+        delete_thresh = 10
+        ddel = dcnt[:nf, 0] >= delete_thresh
+        crel = (ccnt[:nf, 0] >= delete_thresh) & ~ddel
+        n_del, n_rel = torch.stack([ddel.sum(), crel.sum()]).tolist()
+        if n_rel > 0:
+            o.aux["confidence"][:nf, 0] = torch.where(crel, torch.zeros_like(o.aux["confidence"][:nf, 0]), o.aux["confidence"][:nf, 0])
+            o.aux["add_tick"][:nf, 0] = torch.where(crel, torch.full_like(o.aux["add_tick"][:nf, 0], int(self.time)), o.aux["add_tick"][:nf, 0])
+            self.stats["released"] += n_rel
+        if n_del > 0:
+            full = torch.zeros(o.N, dtype=torch.bool, device=self.device)
+            full[:nf] = ddel
+            o.remove_rows(full)
+            self.stats["deleted_stable"] += n_del
+
+    def get_render_output(self, frame):
+        out = self._render(frame, "all")
+        self.model_map = {
+            "render_color": out["render"].permute(1, 2, 0), "render_depth": out["depth"].permute(1, 2, 0),
+            "render_normal": out["normal"].permute(1, 2, 0), "render_color_index": out["color_index_map"].permute(1, 2, 0),
+            "render_depth_index": out["depth_index_map"].permute(1, 2, 0), "render_transmission": out["T_map"].permute(1, 2, 0)}
+        return self.model_map

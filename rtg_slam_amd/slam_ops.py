@@ -114,6 +114,28 @@ def distCUDA2(points: torch.Tensor, return_dist2: bool = False):
     return (mean, idx, d3) if return_dist2 else (mean, idx)
 
 
+def knn_query(ref_points: torch.Tensor, query_points: torch.Tensor, self_offset: int = -1,
+              ref_box: Optional[torch.Tensor] = None):
+    """The three nearest REFERENCE points of every query point -> (dist2 [Nq,3] ascending, idx [Nq,3] int32 into
+    ref_points; -1 / FLT_MAX where fewer than three exist).  Exact.  Stands where the reference calls
+    pytorch3d.ops.knn_points(temp_xyz, exist_xyz, K=3) (mapper.py:803-827; note knn_points returns SQUARED distances
+    too).  self_offset >= 0: query i is reference self_offset + i and is not its own neighbour.  ref_box float[6]
+    (lo xyz, hi xyz, device): references outside the open box are ignored - bbox_filter (SLAM/utils.py:737-744) without
+    the compaction."""
+    lib, dev = _lib.load(), _dev(query_points)
+    ref = ref_points.float().contiguous()
+    q = query_points.float().contiguous()
+    Nr, Nq = int(ref.shape[0]), int(q.shape[0])
+    idx = torch.empty(Nq, 3, dtype=torch.int32, device=dev)
+    d3 = torch.empty(Nq, 3, dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.rtgs_knn3_scratch_bytes(Nr), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        box = None if ref_box is None else ref_box.to(device=dev, dtype=torch.float32).reshape(6).contiguous()
+        rc = lib.rtgs_knn3_query(_p(ref), Nr, _p(q), Nq, int(self_offset), _p(box), _p(idx), _p(d3), _p(scratch), _stream(dev))
+    _lib.check(rc, "rtgs_knn3_query")
+    return d3, idx
+
+
 def accumulate_gaussian_error(H, W, P, color_error, depth_error, normal_error, color_index, depth_index, color_thres,
                               depth_thres, normal_thres, mean=True):
     """`cuda_utils._C.accumulate_gaussian_error` (frozen semantics, include/rtgs_slam.h) ->

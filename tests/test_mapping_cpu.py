@@ -1,0 +1,147 @@
+"""Host logic of rtg_slam_amd.mapping.Mapping on the CPU (torch doubles for every kernel, tests/mapping_doubles.py): the
+map's lifecycle through a short synthetic stream - add on an EMPTY map, local optimisation with masks from the UNSTABLE
+rows, fix by confidence, delete by age, attach, error counters, keyframes, the keyframe-triggered and the final global
+optimisation - against what mapper.py:97-126, 134-210, 253-335, 471-592, 594-707 prescribe."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from oracle import slam_ops_oracle as so  # noqa: E402
+from rtg_slam_amd import synth, mapping as mp  # noqa: E402
+from tests.mapping_doubles import TorchOps  # noqa: E402
+
+CAM = synth.CameraSpec(48, 64, 40.0, 40.0, 31.5, 23.5)
+
+
+def _stream(n, seed=4):
+    base = torch.eye(4, dtype=torch.float64)
+    poses = [base @ p for p in synth.trajectory(n, seed=seed)]
+    out = []
+    for c2w in poses:
+        d = synth.box_room_depth(CAM, c2w)
+        out.append((d, synth.box_room_color(CAM, c2w, d), c2w))
+    return out
+
+
+def _frame_map(depth, color, frame, args):
+    K = frame.K
+    fm = so.frame_preprocess(depth.reshape(CAM.H, CAM.W, 1), K, args.min_depth, 8.0, False, args.invalid_confidence_thresh)
+    c2w = frame.get_c2w
+    fm["color_map"] = color.permute(1, 2, 0).contiguous()
+    fm["vertex_map_w"] = fm["vertex_map_c"] @ c2w[:3, :3].T + c2w[:3, 3]
+    fm["normal_map_w"] = fm["normal_map_c"] @ c2w[:3, :3].T
+    return fm
+
+
+def _args(**kw):
+    base = dict(uniform_sample_num=260, gaussian_update_iter=4, gaussian_update_frame=2, memory_length=3,
+                stable_confidence_thres=2.0, unstable_time_window=3, max_depth=8.0, keyframe_trans_thes=0.015,
+                final_global_iter=2, seed=3)
+    base.update(kw)
+    return mp.replica_args(**base)
+
+
+def _run(n_frames, args, final=False):
+    ops = TorchOps(args)
+    m = mp.Mapping(args, torch.device("cpu"), ops=ops, capacity=400)
+    log = []
+    for fid, (d, c, c2w) in enumerate(_stream(n_frames)):
+        fr = mp.Frame(CAM, c2w, torch.device("cpu"), uid=fid)
+        fm = _frame_map(d, c, fr, args)
+        before = (m.opt.N, m.opt.n_frozen)
+        p_stable = m.opt.params[:m.opt.n_frozen].clone()
+        n_steps = len(ops.steps)
+        m.mapping(fr, fm, fid)
+        m.get_render_output(fr)
+        log.append(dict(fid=fid, before=before, after=(m.opt.N, m.opt.n_frozen), stable_before=p_stable,
+                        steps=ops.steps[n_steps:], stats=dict(m.stats)))
+        m.time += 1
+    if final:
+        m.global_optimization(select_keyframe_num=-1, is_end=True)
+    return m, ops, log
+
+
+def test_lifecycle_from_an_empty_map():
+    args = _args()
+    m, ops, log = _run(7, args)
+    o = m.opt
+    tiles = ((CAM.H + 15) // 16) * ((CAM.W + 15) // 16)
+    # frame 0: an empty map takes uniform_sample_num pixels (minus those update_geometry drops), all unstable, and is optimised
+    assert log[0]["before"] == (0, 0) and 150 < log[0]["stats"]["added"] <= args.uniform_sample_num
+    assert len(log[0]["steps"]) == args.gaussian_update_iter
+    assert all(s[0] == log[0]["stats"]["added"] and s[1] == 0 for s in log[0]["steps"])
+    # optimised frames: time 0 and every gaussian_update_frame-th (mapper.py:103)
+    assert m.optimize_frames_ids == [0, 1, 3, 5]
+    assert [bool(l["steps"]) for l in log] == [True, True, False, True, False, True, False]
+    # confidence counts optimisation hits; above the threshold a Gaussian turns stable
+    assert m.stats["fixed"] > 0 and o.n_frozen > 0 and log[0]["after"][1] > 0
+    # frame 1 is no keyframe: LOCAL optimisation - the whole map rendered, training starts behind the stable prefix, and the
+    # tile masks come from a render of the UNSTABLE rows alone (a few tiles, not all 12)
+    nf1 = log[1]["before"][1]
+    assert nf1 > 0 and all(s[1] == nf1 and s[0] > nf1 and 0 < s[2] < tiles for s in log[1]["steps"])
+    # frames 3 and 5 moved far enough to be keyframes with stable rows present: GLOBAL optimisation - only the stable rows
+    # are rendered, trained from row 0, on the 40 % of the tiles with the largest colour error (mapper.py:477-496)
+    assert m.keyframe_ids == [0, 3, 5] and m.stats["global_opts"] == 2 and m.stats["local_opts"] == 2
+    for l in (log[3], log[5]):
+        nf = l["before"][1]
+        assert all(s == (nf, 0, int(tiles * 0.4), int(tiles * 0.4) * 256) for s in l["steps"])
+        assert l["after"][0] > nf                                            # the unstable rows exist, and were left out
+    assert m.opt._scope == "local"
+    # unstable Gaussians older than the window are gone (mapper.py:309-311)
+    age = m.time - 1 - o.aux["add_tick"][o.n_frozen:o.N, 0]
+    assert o.n_train > 0 and int(age.max()) <= args.unstable_time_window and m.stats["deleted_unstable"] > 0
+    # error_gaussians_remove and get_render_output share one render when nothing was deleted in between
+    assert m.stats["renders_reused"] > 0
+    # new points that project onto a stable Gaussian and lie on its plane start at opacity 0.1 (mapper.py:830-883)
+    op = torch.sigmoid(o.state["raw8"]["p"][:o.N, 0])
+    assert int(((op - 0.1).abs() < 1e-4).sum()) > 0 and bool((op[:log[0]["after"][1]] > 0.9).all())
+
+
+def test_stable_rows_do_not_move_in_a_local_optimisation_and_masks_come_from_the_unstable_rows():
+    args = _args(keyframe_trans_thes=10.0, keyframe_theta_thes=400.0)       # never a keyframe: every optimisation is local
+    m, ops, log = _run(4, args)
+    assert m.stats["global_opts"] == 0 and m.stats["local_opts"] == 3
+    # fixed Gaussians carry a confidence clipped to the threshold (mapper.py:268-270; only a global optimisation raises it again)
+    assert m.opt.n_frozen > 0 and float(m.opt.aux["confidence"][:m.opt.n_frozen].max()) <= args.stable_confidence_thres
+    l = log[3]                                                               # optimised at time 3 with stable rows present
+    nf = l["before"][1]
+    assert nf > 0 and l["steps"]
+    assert all(s[1] >= nf for s in l["steps"])                               # trainable range behind the stable prefix
+    # the stable rows the frame started with are still the first rows, bit for bit (fix only appends behind them)
+    assert torch.equal(m.opt.params[:nf], l["stable_before"])
+    # a fresh render of the unstable rows alone gives exactly the masks evaluate_render_range handed the steps
+    fr = m.processed_frames[-1]
+    rm, tm, _ = m.evaluate_render_range(fr)
+    full = ops.render(fr, m.opt.gaussian_data("all"))
+    assert int(tm.sum()) <= int(ops.render_range(full["T_map"], 0.5)[1].sum())
+
+
+def test_keyframe_triggers_a_global_optimisation_of_the_stable_rows_only():
+    args = _args(keyframe_trans_thes=0.0)                                    # every optimised frame after the first is a keyframe
+    m, ops, log = _run(6, args)
+    assert m.keyframe_ids == [0, 1, 3, 5] and m.stats["global_opts"] == 3 and m.stats["local_opts"] == 1
+    k = int(((CAM.H + 15) // 16) * ((CAM.W + 15) // 16) * 0.4)
+    for l in (log[1], log[3], log[5]):
+        nf = l["before"][1]
+        assert nf > 0 and len(l["steps"]) == args.gaussian_update_iter
+        assert all(s == (nf, 0, k, k * 256) for s in l["steps"])             # stable rows only, top-40 % colour-error tiles
+        # the unstable rows of that frame were neither rendered nor stepped: bit-unchanged through the optimisation is
+        # covered by tests/test_map_object_cpu.py; here: they are still there afterwards
+        assert l["after"][0] > nf
+    assert m.opt._scope == "local"
+
+
+def test_final_global_optimisation_fixes_everything_first():
+    args = _args()
+    m, ops, log = _run(3, args, final=True)
+    assert m.opt.n_train == 0 and m.opt.n_frozen == m.opt.N > 0
+    n_final = m.get_keyframe_num * args.final_global_iter
+    last = ops.steps[-n_final:]
+    assert all(s[0] == m.opt.N and s[1] == 0 and s[2] is None for s in last)  # all rows, no tile mask (mapper.py:497-499)
+    assert m.weights.depth_weight == 0.0                                     # update_args.depth_weight = 0 (mapper.py:633)

@@ -107,6 +107,48 @@ def test_knn3_large_map_subset_check():
     assert torch.equal(mean.cpu()[rows], want.sum(1) / 3.0)
 
 
+@pytest.mark.parametrize("kind", ["disjoint", "self", "few", "none", "boxed"])
+def test_knn_query_is_exact(kind):
+    """rtgs_knn3_query (what Mapping.temp_points_filter asks pytorch3d.knn_points for, and the new-point rows of
+    update_geometry's distCUDA2) against brute force: same float32 distances bit for bit, indices realise them."""
+    from rtg_slam_amd import slam_ops as ops
+    g = torch.Generator().manual_seed(11)
+    ref = synth.surface_gaussians(30000, synth.CONFIG2, seed=6)["xyz"]
+    off, box = -1, None
+    if kind == "disjoint":
+        q = ref[torch.randperm(30000, generator=g)[:4000]] + 0.02 * torch.randn(4000, 3, generator=g)
+        q[:40] += 50.0                                                # far outside the references' bounding box
+    elif kind == "self":
+        off = 1234
+        q = ref[off:off + 5000].clone()                               # the queries ARE references: must not find themselves
+    elif kind == "few":
+        ref, q = ref[:2], torch.rand(300, 3, generator=g)
+    elif kind == "boxed":                                             # bbox_filter: only references inside the queries' padded box
+        q = ref[:3000] + 0.01 * torch.randn(3000, 3, generator=g)
+        q = q[(q[:, 0] > -0.5) & (q[:, 0] < 0.7)]
+        box = torch.cat([q.min(0).values - 0.05, q.max(0).values + 0.05])
+    else:
+        ref, q = ref[:0], torch.rand(10, 3, generator=g)
+    d3, idx = ops.knn_query(ref.to(DEV), q.to(DEV), off, None if box is None else box.to(DEV))
+    d3_o, idx_o = so.knn_query(ref, q, off, box)
+    assert torch.equal(d3.cpu(), d3_o), kind
+    idx = idx.cpu().long()
+    if kind in ("disjoint", "self", "boxed"):
+        assert torch.all((idx >= 0) & (idx < ref.shape[0]))
+        if box is not None:
+            assert torch.all((ref[idx] > box[:3]).all(-1) & (ref[idx] < box[3:]).all(-1))
+        if off >= 0:
+            assert torch.all(idx != (off + torch.arange(q.shape[0]))[:, None])
+        for k in range(3):
+            r = ref[idx[:, k]]
+            dx, dy, dz = q[:, 0] - r[:, 0], q[:, 1] - r[:, 1], q[:, 2] - r[:, 2]
+            assert torch.equal(dx * dx + dy * dy + dz * dz, d3_o[:, k]), (kind, k)
+    elif kind == "few":
+        assert torch.all(idx[:, 2] == -1) and torch.all(idx[:, :2] >= 0)
+    else:
+        assert torch.all(idx == -1)
+
+
 def test_accumulate_gaussian_error_vs_oracle():
     from cuda_utils._C import accumulate_gaussian_error
     g = torch.Generator().manual_seed(4)
