@@ -41,12 +41,22 @@ def parse():
     ap.add_argument("--reserve-cus", type=int, default=32,
                     help="compute units the mapper's stream leaves to the tracker (rtgs_stream_create_reserving; 0 = none): "
                          "measured 0 / 16 / 24 / 32 / 40 / 64 -> 0.452 / 0.449 / 0.438 / 0.432 / 0.442 / 0.456 ms per unit")
-    ap.add_argument("--mode", choices=["sparse", "sharded", "tileband"], default="sparse",
+    ap.add_argument("--mode", choices=["auto", "sparse", "sharded", "tileband"], default="auto",
                     help="multi-GPU form of the map step (ignored on one GPU): sparse = every rank renders its own view, "
                          "gradient rows that exist are all-gathered (in-band counts, no host sync), identical Adam step on "
                          "every replica [weak scaling]; sharded = dense reduce-scatter of the gradients, Adam on the rank's "
                          "row shard, all-gather of the updated rows [weak]; tileband = ONE view split into tile bands, "
-                         "loss normalisers all-reduced, gradient rows summed by the sparse exchange [strong]")
+                         "loss normalisers all-reduced, gradient rows summed by the sparse exchange [strong]; auto (default) = "
+                         "tileband: a SLAM stream has ONE frame per step, so N GPUs can only split that frame - the weak-scaling "
+                         "sparse form is reported beside it as `weak_scaling_one_view_per_rank`")
+    ap.add_argument("--sequence-frames", type=int, default=400,
+                    help="frames of the `sequence` leg (BASELINE configs[2]: empty map, reference schedule and lifecycle, 1200x680)")
+    ap.add_argument("--no-sequence", action="store_true")
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (5 M Gaussians, sharded, 10 iterations)")
+    ap.add_argument("--config5-gaussians", type=int, default=5_000_000)
+    ap.add_argument("--no-dropin", action="store_true", help="skip the unchanged-reference-iteration leg")
+    ap.add_argument("--only", choices=["sequence", "config5", "icp_tum"], default=None,
+                    help="run ONE extra leg and print its JSON (profiling aid; not the contract line)")
     ap.add_argument("--prewarm", type=int, default=3000,
                     help="untimed frames of the real workload before the warm-up: a FIXED count (every rank issues the same "
                          "collectives), >= 1.5 s of GPU work - a fresh box needs that long to reach its steady clocks (the "
@@ -125,6 +135,11 @@ def main():
 
     cam = synth.REPLICA
     N = args.gaussians
+    if args.mode == "auto":
+        args.mode = "tileband"
+    if args.only is not None:
+        return only_leg(args, rank, world, dev)
+    one_stream = args.mode == "tileband" and world > 1        # every rank works on rank 0's frame
     # same map on every rank
     g = synth.surface_gaussians(N, cam, seed=7) if args.surface_map else synth.random_gaussians(N, cam, seed=2024)
     packed = mo.pack_from_activated({k: v.to(dev) for k, v in g.items()})
@@ -133,7 +148,8 @@ def main():
     opt = mo.ShardedMapOptimizer(packed, lr_col=mo.default_lr_columns() * 1e-4)
 
     # this rank's view: a small pose offset per rank (sliding-window views of one map)
-    c2w = synth.look_at_pose(seed=100 + rank, max_angle_deg=2.0, max_trans=0.05) if world > 1 else torch.eye(4, dtype=torch.float64)
+    c2w = (synth.look_at_pose(seed=100 + rank, max_angle_deg=2.0, max_trans=0.05) if (world > 1 and not one_stream)
+           else torch.eye(4, dtype=torch.float64))
     view = torch.linalg.inv(c2w).float().t().contiguous().to(dev)
     campos = c2w[:3, 3].float().to(dev)
     tanfovx, tanfovy = cam.W / (2 * cam.fx), cam.H / (2 * cam.fy)
@@ -146,9 +162,9 @@ def main():
     rast = GaussianRasterizer(raster_settings=rs)
     tile_mask = torch.ones((cam.H + 15) // 16, (cam.W + 15) // 16, dtype=torch.int32, device=dev)
 
-    gen = torch.Generator().manual_seed(7 + rank)
+    gen = torch.Generator().manual_seed(7 + (0 if one_stream else rank))
     gt_color = torch.rand(3, cam.H, cam.W, generator=gen).to(dev)
-    poses = synth.trajectory(2, seed=9 + rank)
+    poses = synth.trajectory(2, seed=9 + (0 if one_stream else rank))
     base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
     d0 = synth.box_room_depth(cam, base @ poses[0]).to(dev)
     d1 = synth.box_room_depth(cam, base @ poses[1]).to(dev)
@@ -337,6 +353,35 @@ def main():
                   "n_gpus": world, "ms_per_iteration": round(1e3 * dts / args.steps, 4),
                   "overflow_redos": opt.overflow_redos, "row_capacity": opt._row_capacity}
 
+    # Weak scaling, labelled as such (one view of the sliding window PER RANK; a single SLAM stream cannot produce that many
+    # frames at once - tracking is sequential - so this is never `value`): sparse gradient-row exchange, replicated Adam.
+    weak = None
+    if world > 1 and mode == "tileband":
+        c2w_r = synth.look_at_pose(seed=100 + rank, max_angle_deg=2.0, max_trans=0.05)
+        view_r = torch.linalg.inv(c2w_r).float().t().contiguous().to(dev)
+        rs_r = rs._replace(viewmatrix=view_r, projmatrix=view_r, campos=c2w_r[:3, 3].float().to(dev))
+        gt_r = torch.rand(3, cam.H, cam.W, generator=torch.Generator().manual_seed(7 + rank)).to(dev)
+        rm1 = torch.ones(cam.H, cam.W, dtype=torch.uint8, device=dev)
+        for _ in range(10):
+            opt.step_slam(rs_r, gt_r, gt_depth, tile_mask, render_mask=rm1)
+        barrier()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            opt.step_slam(rs_r, gt_r, gt_depth, tile_mask, render_mask=rm1)
+        opt.flush()
+        barrier()
+        dtw = time.perf_counter() - tw
+        t = torch.tensor([dtw], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        weak = {"what": "map iterations with ONE VIEW PER RANK (sparse gradient-row all-gather, identical Adam step on every "
+                        "replica); views per second over all ranks - not a SLAM frame rate",
+                "n_gpus": world, "ms_per_step": round(1e3 * float(t.item()) / args.steps, 4),
+                "views_per_sec": round(world * args.steps / float(t.item()), 2)}
+
+    config5 = None
+    if not args.no_config5:
+        config5 = config5_block(dev, rank, world, barrier, N=args.config5_gaussians)
+
     result = None
     if rank == 0:
         lib.rtgs_raster_set_profiling(1)
@@ -456,14 +501,22 @@ def main():
         sched = None
         if world == 1 and not args.no_schedule and not args.no_surface:
             sched = reference_schedule_leg(cam, N, dev)
+        seq = None
+        if world == 1 and not args.no_sequence:
+            seq = sequence_leg(cam, dev, args.sequence_frames)
+        tum = icp_tum_leg(dev)
+        dropin = None
+        if world == 1 and not args.no_dropin:
+            dropin = dropin_leg(g, cam, rs, tile_mask, gt_color, gt_depth, render_mask, dev, min(args.steps, 10))
         bs = sorted(block_ms)
         spread = (bs[-1] - bs[0]) / bs[len(bs) // 2]
         result = {
-            "metric": "slam_frames_per_sec", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
+            "metric": "hot_path_units_per_sec", "value": round(fps, 3), "unit": "units/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "strong" if mode == "tileband" else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "one UNIT per step = 1 ICP track (3 levels x 5 GN iters, 1200x680, on a second HIP stream) "
+            "config": {"workload": "`value` counts UNITS, not SLAM frames (the SLAM frame rate by the reference's definition is "
+                                   "`slam_frames_per_sec`, from the `slam_sequence` leg).  One UNIT per step = 1 ICP track (3 levels x 5 GN iters, 1200x680, on a second HIP stream) "
                                    "+ 1 map-optimisation iteration (raster fwd + masked L1 colour / gated depth loss + attach "
                                    f"regulariser + raster bwd + fused Adam) over {N} "
                                    + ("opaque wall discs (single-layer surface map)" if args.surface_map else
@@ -485,6 +538,13 @@ def main():
                         "slowest_host_frame_ms_per_block": [round(max(host_ms[i:i + args.steps]), 3)
                                                             for i in range(0, len(host_ms), args.steps)]},
             "rccl_ranks": rccl_ranks,
+            "slam_frames_per_sec": None if seq is None else seq["fps"],
+            "slam_sequence": seq,
+            "icp_track_ms_tum_480x640_noisy": tum,
+            "dropin_iteration_ms": None if dropin is None else dropin["dropin_iteration_ms"],
+            "dropin": dropin,
+            "config5": config5,
+            "weak_scaling_one_view_per_rank": weak,
             "frames_per_sec_replica_schedule": None if sched is None else sched["frames_per_sec"],
             "replica_schedule": sched,
             "strong_scaling_one_view": strong,
@@ -638,6 +698,273 @@ def reference_schedule_leg(cam, N, dev, cycles=3, iters=50, every=6, window=5, n
             "final_translation_error_m": round(err, 5),
             "what": "reference Replica schedule (replica_base.yaml: gaussian_update_frame 6, gaussian_update_iter 50, "
                     "memory_length 5, uniform_sample_num 40800), sequential single stream, 1.2 M surface map"}
+
+
+
+def sequence_leg(cam, dev, n_frames, seed=21):
+    """BASELINE.json configs[2] in the reference's real form, through the product's map object and `Mapping` lifecycle
+    (rtg_slam_amd/mapping.py, slam.py): a synthetic Replica-shaped stream (box room, bounded tour: <= 2 cm and <= 1 degree
+    per frame), 1200x680, starting from an EMPTY map; per frame preprocess + ICP frame-to-model tracking + gaussians_add;
+    every 6th frame evaluate_render_range on the UNSTABLE rows of the 5 window frames and 50 iterations with the stable
+    prefix frozen (or, on a keyframe with stable rows, the global optimisation of the stable rows); gaussians_fix at
+    confidence > 100, deletion after 120 frames, error counters; reference learning rates (configs/replica_base.yaml).
+    `fps` is the reference's number: 1 / mean(mapping seconds per frame) (utils/monitor.py:22-24)."""
+    from rtg_slam_amd import mapping as mp, slam, synth
+    import gc
+    args = mp.replica_args(seed=1)
+    poses = synth.room_tour(n_frames, seed=seed)
+
+    def stream():
+        for c2w in poses:
+            d = synth.box_room_depth(cam, c2w, device=dev)
+            c = synth.box_room_color(cam, c2w, d)
+            torch.cuda.synchronize(dev)                 # the "dataset read" is over before the frame's clock starts
+            yield d.reshape(cam.H, cam.W), c, c2w.numpy()
+    torch.cuda.reset_peak_memory_stats(dev)
+    gc.collect()
+    mapper, tracker, rep = slam.run_sequence(cam, stream(), args, dev, capacity=600_000)
+    pf = rep.pop("per_frame")
+    opt_frames = [p for i, p in enumerate(pf) if (i + 1) % args.gaussian_update_frame == 0 or i == 0]
+    oth_frames = [p for i, p in enumerate(pf) if not ((i + 1) % args.gaussian_update_frame == 0 or i == 0)]
+    from rtg_slam_amd.rasterizer import current_context
+    out = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in rep.items()}
+    out.update({
+        "image": [cam.H, cam.W], "start": "empty map", "lr": "reference rates (replica_base.yaml:19-23)",
+        "mapping_ms_mean_optimised_frames": round(1e3 * sum(p[1] for p in opt_frames) / max(len(opt_frames), 1), 3),
+        "mapping_ms_mean_other_frames": round(1e3 * sum(p[1] for p in oth_frames) / max(len(oth_frames), 1), 3),
+        "tracking_ms_mean": round(1e3 * rep["tracking_s_mean"], 3),
+        "peak_device_memory_MB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 20, 1),
+        "speculation": current_context().speculation_stats(),
+        "what": "slam.py:56-95 + mapper.py:97-126 on a synthetic Replica-shaped stream (configs[2]); fps = 1 / mean mapping "
+                "seconds per frame (utils/monitor.py:22-24); `fps_tracking_plus_mapping` counts the tracker too (single process, "
+                "sequential)"})
+    return out
+
+
+def icp_tum_leg(dev, reps=20):
+    """BASELINE.json configs[3]: the ICP front-end alone on a TUM fr1-shaped frame pair (640x480, sigma_z noise, 5 % holes,
+    1/5000 m quantisation - synth.tum_noise): pyramids of the current frame + 15 Gauss-Newton iterations, HIP events."""
+    from rtg_slam_amd import synth, icp as hicp
+    cam = synth.TUM_FR1
+    poses = synth.trajectory(2, seed=4)
+    base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
+    d0 = synth.tum_noise(synth.box_room_depth(cam, base @ poses[0]), seed=1).to(dev).reshape(cam.H, cam.W)
+    d1 = synth.tum_noise(synth.box_room_depth(cam, base @ poses[1]), seed=2).to(dev).reshape(cam.H, cam.W)
+    K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32, device=dev)
+    vp0, np0 = hicp.build_pyramids(d0, K, 3)
+    cos_thr = math.cos(math.radians(20.0))
+    ms = []
+    for i in range(reps + 3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        vp1, np1 = hicp.build_pyramids(d1, K, 3)
+        out = hicp.icp_track(vp1, np1, vp0, np0, K, [0.25, 0.5, 1.0], [5, 5, 5], 0.1, cos_thr, 1e-4)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        if i >= 3:
+            ms.append(e0.elapsed_time(e1))
+    ms.sort()
+    host = out.cpu().numpy()
+    rel = host[:16].reshape(4, 4)
+    gt = (torch.linalg.inv(base @ poses[0]) @ (base @ poses[1])).numpy()
+    return {"ms_median": round(ms[len(ms) // 2], 4), "ms_min": round(ms[0], 4), "image": [cam.H, cam.W],
+            "translation_error_m": round(float(((rel[:3, 3] - gt[:3, 3]) ** 2).sum() ** 0.5), 5),
+            "what": "pyramids of the new frame + 3 levels x 5 Gauss-Newton iterations + point-to-plane check, TUM fr1 intrinsics, "
+                    "noisy depth with holes (configs[3]); frame-to-frame"}
+
+
+def dropin_leg(g, cam, rs, tile_mask, gt_color, gt_depth, render_mask, dev, steps):
+    """What north_star promises the EXISTING Python loop: one iteration of Mapping.loss_update as the reference writes it
+    (mapper.py:371-469) - six leaf tensors with torch activations (gaussian_pointcloud.py:16-25, 502-550), the Renderer
+    wrapper (SLAM/render.py:60-145; here rtg_slam_amd.render.Renderer, which has the same interface - the reference file
+    itself binds unchanged, tests/test_reference_wrapper.py, but /root/reference is not on the GPU box), boolean-mask L1
+    colour / depth losses, the attach regulariser, `.backward()`, torch.optim.Adam(lr=0, eps=1e-15) over six groups, the
+    confidence update from `_features_dc.grad`, six `.item()` reports, zero_grad - on this package's rasterizer, 1.2 M
+    Gaussians, 1200x680.  Beside it the same iteration through the one-call step."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from types import SimpleNamespace
+    from rtg_slam_amd.render import Renderer
+    from rtg_slam_amd import map_optim as mo
+    N = g["xyz"].shape[0]
+    lrs = [x * 1e-4 for x in (1e-3, 5e-4, 5e-4 / 20.0, 0.0, 4e-3, 1e-3)]        # the headline leg's scaled rates
+    P = lambda t: nn.Parameter(t.to(dev).contiguous().requires_grad_(True))
+    op = g["opacity"].clamp(1e-6, 1 - 1e-6)
+    _xyz, _fdc, _frest = P(g["xyz"]), P(g["shs"][:, :1]), P(g["shs"][:, 1:])
+    _opacity, _scaling, _rotation = P(torch.log(op / (1 - op))), P(torch.log(g["scales"])), P(g["rotations"])
+    l = [{"params": [p], "lr": lr, "name": n} for p, lr, n in zip((_xyz, _fdc, _frest, _opacity, _scaling, _rotation), lrs,
+                                                                   ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"))]
+    init = {"opacity": _opacity.detach().clone(), "scaling": _scaling.detach().clone(), "xyz": _xyz.detach().clone(),
+            "rotation_raw": _rotation.detach().clone()}
+    optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15)
+    confidence = torch.zeros(N, 1, device=dev)
+    args = SimpleNamespace(renderer_opaque_threshold=0.6, renderer_normal_threshold=60.0, renderer_depth_threshold=1.0,
+                           max_sh_degree=3, color_sigma=3.0, active_sh_degree=3)
+    renderer = Renderer(args)
+    view = SimpleNamespace(FoVx=2 * math.atan(cam.W / (2 * cam.fx)), FoVy=2 * math.atan(cam.H / (2 * cam.fy)),
+                           image_height=cam.H, image_width=cam.W, world_view_transform=rs.viewmatrix,
+                           full_proj_transform=rs.projmatrix, camera_center=rs.campos, cx=cam.cx, cy=cam.cy)
+    image_input = {"color_map": gt_color.permute(1, 2, 0).contiguous(), "depth_map": gt_depth.permute(1, 2, 0).contiguous()}
+    rmask = render_mask.bool()
+
+    def build_rotation(r):                                                     # utils/general_utils.py:108-131
+        q = r / torch.sqrt((r * r).sum(dim=1, keepdim=True))
+        w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                            2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                            2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(-1, 3, 3)
+
+    def gaussian_data():
+        scales = torch.exp(_scaling)
+        rot = F.normalize(_rotation)
+        R = build_rotation(rot)
+        idx = torch.argmin(scales, dim=1)
+        normal = torch.gather(R.transpose(1, 2), 1, idx.unsqueeze(1).unsqueeze(2).expand(-1, -1, 3))[:, 0, :]
+        normal = normal / (torch.norm(normal, p=2, dim=-1, keepdim=True) + 1e-8)
+        return {"xyz": _xyz, "opacity": torch.sigmoid(_opacity), "scales": scales, "rotations": rot,
+                "shs": torch.cat((_fdc, _frest), dim=1), "normal": normal}
+
+    def loss_update():
+        out = renderer.render(view, gaussian_data(), tile_mask=tile_mask)
+        attach_mask = (torch.sigmoid(init["opacity"]) < 0.9).squeeze()
+        attach_loss = torch.tensor(0)
+        if attach_mask.sum() > 0:
+            l2 = lambda a, b: ((a - b) ** 2).mean()
+            attach_loss = 1000 * (l2(_scaling[attach_mask], init["scaling"][attach_mask]) + l2(_xyz[attach_mask], init["xyz"][attach_mask])
+                                  + l2(_rotation[attach_mask], init["rotation_raw"][attach_mask]))
+        image, depth, depth_index = out["render"].permute(1, 2, 0), out["depth"].permute(1, 2, 0), out["depth_index_map"].permute(1, 2, 0)
+        color_loss = torch.abs(image[rmask] - image_input["color_map"][rmask]).mean()
+        depth_error = depth - image_input["depth_map"]
+        valid = (depth_index != -1).squeeze() & (image_input["depth_map"] > 0).squeeze() & (depth_error < 0.1).squeeze() & rmask
+        depth_loss = torch.abs(depth_error[valid]).mean()
+        total = 1.0 * depth_loss + 0.8 * color_loss
+        (total + attach_loss).backward()
+        optimizer.step()
+        grad_mask = (_fdc.grad.abs() != 0).any(dim=-1)
+        confidence[grad_mask] += 1
+        rep = {"total_loss": total.item(), "depth_loss": depth_loss.item(), "ssim_loss": 0.0, "normal_loss": 0.0,
+               "color_loss": color_loss.item(), "scale_loss": attach_loss.item()}
+        optimizer.zero_grad(set_to_none=True)
+        return rep
+    for _ in range(3):
+        loss_update()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rep = loss_update()
+    torch.cuda.synchronize(dev)
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    touched = int((confidence > 0).sum())
+    del optimizer, l
+    # the same iteration through the product's one-call step (same map, same rates, same masks)
+    opt = mo.ShardedMapOptimizer(mo.pack_from_activated({k: v.to(dev) for k, v in g.items()}), lr_col=mo.default_lr_columns() * 1e-4)
+    opt.begin_local_optimization()
+    for _ in range(5):
+        opt.step_slam(rs, gt_color, gt_depth, tile_mask, render_mask=render_mask)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        opt.step_slam(rs, gt_color, gt_depth, tile_mask, render_mask=render_mask)
+    torch.cuda.synchronize(dev)
+    one = 1e3 * (time.perf_counter() - t1) / steps
+    return {"dropin_iteration_ms": round(ms, 3), "one_call_step_ms": round(one, 4), "ratio": round(ms / one, 1),
+            "gaussians": N, "gaussians_that_ever_received_gradient": touched, "last_losses": {k: round(v, 6) for k, v in rep.items()},
+            "what": "mapper.py:371-469 literally (torch activations, Renderer wrapper, boolean-mask losses, attach term, autograd "
+                    "backward with DENSE [N,*] gradients, torch.optim.Adam over six groups, confidence from f_dc.grad, six .item() "
+                    "calls) vs ShardedMapOptimizer.step_slam on the same map"}
+
+
+def config5_block(dev, rank, world, barrier, N=5_000_000, iters=10):
+    """BASELINE.json configs[4] as SURVEY.md 8d concretises it: 5 M Gaussians (all unstable), 1200x680, the unstable set
+    sharded `world`-way (dense gradient reduce-scatter over RCCL, Adam on the rank's row shard, all-gather of the updated
+    rows - ShardedMapOptimizer.step), 10 optimisation iterations, ms per iteration split into render forward (+ loss) /
+    render backward / collectives / Adam from HIP events at the phase borders.  One view per rank (the sliding-window form).
+    Emitted at every N, including 1 (the anchor of the curve)."""
+    from rtg_slam_amd import synth, map_optim as mo
+    from rtg_slam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    cam = synth.REPLICA
+    g = synth.random_gaussians(N, cam, seed=2025, z_range=(0.5, 8.0))
+    opt = mo.ShardedMapOptimizer(mo.pack_from_activated({k: v.to(dev) for k, v in g.items()}), lr_col=mo.default_lr_columns() * 1e-4)
+    del g
+    c2w = synth.look_at_pose(seed=100 + rank, max_angle_deg=2.0, max_trans=0.05) if world > 1 else torch.eye(4, dtype=torch.float64)
+    view = torch.linalg.inv(c2w).float().t().contiguous().to(dev)
+    rs = GaussianRasterizationSettings(
+        image_height=cam.H, image_width=cam.W, tanfovx=cam.W / (2 * cam.fx), tanfovy=cam.H / (2 * cam.fy),
+        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=view, projmatrix=view, sh_degree=3,
+        campos=c2w[:3, 3].float().to(dev), opaque_threshold=0.6, depth_threshold=1.0,
+        normal_threshold=math.cos(math.radians(60.0)), color_sigma=3.0, prefiltered=False, debug=False, cx=cam.cx, cy=cam.cy,
+        T_threshold=1e-4)
+    rast = GaussianRasterizer(raster_settings=rs)
+    gen = torch.Generator().manual_seed(70 + rank)
+    gt_c = torch.rand(3, cam.H, cam.W, generator=gen).to(dev)
+    gt_d = (0.5 + 4.0 * torch.rand(1, cam.H, cam.W, generator=gen)).to(dev)
+    rm = torch.ones(cam.H, cam.W, dtype=torch.uint8, device=dev)
+
+    def loss_fn(gd):
+        out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
+                   rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=None, grad_rows=gd.get("grad_rows"))
+        return mo.slam_losses_hip(out, gt_c, gt_d, render_mask=rm)
+    for _ in range(3):
+        opt.step(loss_fn)
+    barrier()
+    opt.phase_marks = []
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        opt.step(loss_fn)
+    barrier()
+    dt = time.perf_counter() - t0
+    marks, opt.phase_marks = opt.phase_marks, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    acc = {"render_fwd_and_loss": 0.0, "render_bwd": 0.0, "adam": 0.0, "tail_total": 0.0}
+    prev, adam0 = None, None
+    for name, ev in marks:
+        if name == "forward_and_loss":
+            acc["render_fwd_and_loss"] += prev[1].elapsed_time(ev)
+        elif name == "backward":
+            acc["render_bwd"] += prev[1].elapsed_time(ev)
+            bwd_end = ev
+        elif name == "adam_begin":
+            adam0 = ev
+        elif name == "adam_end":
+            acc["adam"] += adam0.elapsed_time(ev)
+        elif name == "end":
+            acc["tail_total"] += bwd_end.elapsed_time(ev)
+        if name in ("begin", "forward_and_loss", "backward"):
+            prev = (name, ev)
+    out = {"gaussians": N, "n_gpus": world, "mode": "sharded", "iterations": iters, "ms_per_iteration": round(1e3 * dt / iters, 3),
+           "split_ms": {"render_fwd_and_loss": round(acc["render_fwd_and_loss"] / iters, 3), "render_bwd": round(acc["render_bwd"] / iters, 3),
+                        "collective": round(max(0.0, acc["tail_total"] - acc["adam"]) / iters, 3), "adam": round(acc["adam"] / iters, 3)},
+           "dense_gradient_MB_per_rank": round(opt.n_train * 59 * 4 / 1e6, 1),
+           "what": "BASELINE configs[4] (SURVEY.md 8d): 5 M Gaussians, 1200x680, unstable set sharded world-way, dense gradient "
+                   "reduce-scatter + sharded Adam + all-gather; rank 0's HIP-event split (collective = tail minus Adam, 0 on one GPU)"}
+    del opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def only_leg(args, rank, world, dev):
+    """--only <leg>: one extra leg alone (for rocprofv3 runs); prints its JSON on rank 0."""
+    from rtg_slam_amd import synth
+    cam = synth.REPLICA
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    if args.only == "sequence":
+        res = sequence_leg(cam, dev, args.sequence_frames)
+    elif args.only == "icp_tum":
+        res = icp_tum_leg(dev)
+    else:
+        res = config5_block(dev, rank, world, barrier, N=args.config5_gaussians)
+    if rank == 0:
+        print(json.dumps({args.only: res}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def profile_scene(lib, mo, rast, opt, N, cam, tile_mask, gt_color, gt_depth, dev, nprof):

@@ -433,6 +433,16 @@ int rtgs_slam_normal_loss_range(const float* normal_w, const int32_t* depth_inde
                                 const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight, float* scratch2,
                                 float* loss_out4, float* d_normal, uint8_t* row_state, const uint32_t* skip_flag,
                                 int32_t train_begin, int32_t train_end, void* stream);
+/* The two halves of rtgs_slam_normal_loss_range, for callers whose pixels are spread over several ranks (tile bands): the
+ * sums {sum of 1 - cos, count} land in scratch2, the caller all-reduces the two floats (the reference's mean is over the
+ * pixels of the WHOLE image, mapper.py:433-442), and the second half divides by the global count. */
+int rtgs_slam_normal_loss_sums(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
+                               const uint8_t* render_mask, int32_t H, int32_t W, float* scratch2, const uint32_t* skip_flag,
+                               void* stream);
+int rtgs_slam_normal_loss_grads(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
+                                const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight, const float* sums2,
+                                float* loss_out4, float* d_normal, uint8_t* row_state, const uint32_t* skip_flag,
+                                int32_t train_begin, int32_t train_end, void* stream);
 int rtgs_slam_map_step(const rtgs_map_step_args* args, int64_t* num_rendered_host, void* stream);
 /* A HIP stream whose CU mask leaves the last `reserve_cus` compute units of the current device unused - for the MAPPER of
  * a tracker || mapper pipeline: the tracker's short dependent kernels then always find free wave slots.

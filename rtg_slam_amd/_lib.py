@@ -146,6 +146,9 @@ _SIGNATURES = {
                                        + [_P] * 3 + [_P, _P, _P] + [_P, _P] + [_P] * 6 + [_P, _P, C.c_int32, C.c_int32, _P]),
     "rtgs_slam_normal_loss_range": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P, _P,
                                               C.c_int32, C.c_int32, _P]),
+    "rtgs_slam_normal_loss_sums": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "rtgs_slam_normal_loss_grads": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P, _P,
+                                              C.c_int32, C.c_int32, _P]),
     "rtgs_raster_geom_bytes_ctx": (C.c_size_t, [_P, C.c_int32, C.c_int32, C.c_int32]),
     "rtgs_raster_last_stats_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "rtgs_raster_set_counters_ctx": (None, [_P, _P]),

@@ -931,12 +931,10 @@ __global__ void __launch_bounds__(256) normal_loss_grads_kernel(const float* __r
 
 }  // namespace rtgs
 
-extern "C" int rtgs_slam_normal_loss_range(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
-                                           const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight,
-                                           float* scratch2, float* loss_out4, float* d_normal, uint8_t* row_state,
-                                           const uint32_t* skip_flag, int32_t train_begin, int32_t train_end, void* stream) {
-  if (!normal_w || !depth_index || !gt_normal || !scratch2 || !loss_out4 || !d_normal || H <= 0 || W <= 0) return -1;
-  if (train_begin < 0 || train_end < train_begin) return -1;
+extern "C" int rtgs_slam_normal_loss_sums(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
+                                          const uint8_t* render_mask, int32_t H, int32_t W, float* scratch2,
+                                          const uint32_t* skip_flag, void* stream) {
+  if (!normal_w || !depth_index || !gt_normal || !scratch2 || H <= 0 || W <= 0) return -1;
   hipStream_t st = (hipStream_t)stream;
   const int64_t hw = (int64_t)H * W;
   int blocks = (int)((hw + 255) / 256);
@@ -944,10 +942,33 @@ extern "C" int rtgs_slam_normal_loss_range(const float* normal_w, const int32_t*
   if (hipMemsetAsync(scratch2, 0, 2 * sizeof(float), st) != hipSuccess) return -2;
   hipLaunchKernelGGL(rtgs::normal_loss_sums_kernel, dim3(blocks), dim3(256), 0, st, normal_w, depth_index, gt_normal, render_mask,
                      hw, scratch2, skip_flag);
-  hipLaunchKernelGGL(rtgs::normal_loss_grads_kernel, dim3(blocks), dim3(256), 0, st, normal_w, depth_index, gt_normal,
-                     render_mask, hw, normal_weight, (const float*)scratch2, loss_out4, d_normal, row_state, skip_flag,
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int rtgs_slam_normal_loss_grads(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
+                                           const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight,
+                                           const float* sums2, float* loss_out4, float* d_normal, uint8_t* row_state,
+                                           const uint32_t* skip_flag, int32_t train_begin, int32_t train_end, void* stream) {
+  if (!normal_w || !depth_index || !gt_normal || !sums2 || !loss_out4 || !d_normal || H <= 0 || W <= 0) return -1;
+  if (train_begin < 0 || train_end < train_begin) return -1;
+  const int64_t hw = (int64_t)H * W;
+  int blocks = (int)((hw + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rtgs::normal_loss_grads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, normal_w, depth_index,
+                     gt_normal, render_mask, hw, normal_weight, sums2, loss_out4, d_normal, row_state, skip_flag,
                      (uint32_t)train_begin, (uint32_t)(train_end - train_begin));
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int rtgs_slam_normal_loss_range(const float* normal_w, const int32_t* depth_index, const float* gt_normal,
+                                           const uint8_t* render_mask, int32_t H, int32_t W, float normal_weight,
+                                           float* scratch2, float* loss_out4, float* d_normal, uint8_t* row_state,
+                                           const uint32_t* skip_flag, int32_t train_begin, int32_t train_end, void* stream) {
+  if (!loss_out4 || !d_normal) return -1;
+  const int rc = rtgs_slam_normal_loss_sums(normal_w, depth_index, gt_normal, render_mask, H, W, scratch2, skip_flag, stream);
+  if (rc != 0) return rc;
+  return rtgs_slam_normal_loss_grads(normal_w, depth_index, gt_normal, render_mask, H, W, normal_weight, scratch2, loss_out4,
+                                     d_normal, row_state, skip_flag, train_begin, train_end, stream);
 }
 
 extern "C" int rtgs_slam_normal_loss(const float* normal_w, const int32_t* depth_index, const float* gt_normal,

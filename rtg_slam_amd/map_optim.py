@@ -839,13 +839,20 @@ class ShardedMapOptimizer:
                 V(ws["didx"]), V(ws["g_color"]), V(ws["g_depth"]), V(a.d_means), V(a.d_opac), V(a.d_shs), V(a.d_scales),
                 V(a.d_rots), V(a.d_normal), V(a.scratch), V(a.row_state), int(t0), int(N), st()), "rtgs_raster_backward_range")
             if args.normal_weight > 0 and args.gt_normal:
-                # the band's pixels only (band_rm): every pixel of the view is counted by exactly one rank.  NOTE: the mean's
-                # normaliser is this rank's count - exact on one rank; with bands the reference's global mean would need the
-                # two sums all-reduced like the image terms (normal_weight is 0 in every shipped config)
-                _lib.check(lib.rtgs_slam_normal_loss_range(
+                # the band's pixels only (band_rm: every pixel of the view is counted by exactly one rank); the mean's two
+                # sums are all-reduced like the image terms, so that the normaliser is the reference's - the count over the
+                # WHOLE image (mapper.py:433-442) - and the partial gradients of the bands add up to the one-rank gradient
+                nsum = C.c_void_p(ws["loss_scratch"].data_ptr() + 20)
+                _lib.check(lib.rtgs_slam_normal_loss_sums(V(act["normal"]), V(ws["didx"]), C.c_void_p(args.gt_normal), V(band_rm),
+                                                          H, W, nsum, None, st()), "rtgs_slam_normal_loss_sums")
+        if args.normal_weight > 0 and args.gt_normal:
+            nsums = ws["loss_scratch"][20:28].view(torch.float32)
+            dist.all_reduce(nsums, op=dist.ReduceOp.SUM, group=self.group)
+            with torch.cuda.device(dev):
+                _lib.check(lib.rtgs_slam_normal_loss_grads(
                     V(act["normal"]), V(ws["didx"]), C.c_void_p(args.gt_normal), V(band_rm), H, W, float(args.normal_weight),
                     C.c_void_p(ws["loss_scratch"].data_ptr() + 20), V(ws["loss"]), V(a.d_normal), V(a.row_state), None,
-                    int(t0), int(N), st()), "rtgs_slam_normal_loss")
+                    int(t0), int(N), st()), "rtgs_slam_normal_loss_grads")
 
     # ------------------------------------------------------------------ sparse exchange (world > 1), no host sync
     def _exchange_and_tail(self, job):
@@ -957,6 +964,14 @@ class ShardedMapOptimizer:
         per, span = self.per, self.per * self.world        # rows of one shard / of all shards (>= n_train: padded)
         self._act_valid = False            # raw8 moves without step_slam's tail: its activated copies go stale
         self.version += 1
+        marks = getattr(self, "phase_marks", None)          # measurement aid (bench.py config5): events at the phase borders
+
+        def mark(name):
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(self.device))
+                marks.append((name, ev))
+        mark("begin")
         if self.world > 1:
             if self._mode == "replicated":
                 raise RuntimeError("ShardedMapOptimizer: step() after step_slam() on more than one rank - the two keep "
@@ -973,7 +988,9 @@ class ShardedMapOptimizer:
         gd["xyz"] = leaves["xyz"]
         gd["shs"] = leaves["shs"].view(N, 16, 3)
         loss = loss_fn(gd)
+        mark("forward_and_loss")
         grads = torch.autograd.grad(loss, [leaves[n] for n, _, _ in BLOCKS], allow_unused=True)
+        mark("backward")
         self.step_count += 1
         rows = self.my_rows()
         gmap = {}
@@ -1000,12 +1017,15 @@ class ShardedMapOptimizer:
                 st = self.state[name]
                 rs[name].wait()                         # stream-side wait, the host does not block
                 shard = st["p"][rows]
+                mark("adam_begin")
                 self._adam(name, shard, st["gshard"][:per])
+                mark("adam_end")
                 # in place: the shard IS this rank's slice of the gathered range (sendbuff = recvbuff + rank * count, the
                 # in-place form of the collective) - no staging copy of the updated rows
                 ag.append(dist.all_gather_into_tensor(st["p"][nf:nf + span], shard, group=self.group, async_op=True))
             for w in ag:
                 w.wait()
+            mark("end")
             return loss.detach()
 
         for name, _, _ in BLOCKS:
@@ -1023,11 +1043,14 @@ class ShardedMapOptimizer:
             row_state = None
             if arena is not None and arena.calls == 1 and gs.data_ptr() == self._arena_grad(name)[nf:].data_ptr():
                 row_state = arena.row_state[nf:]   # gs IS the rasterizer's persistent rows: their states are exact
+            mark("adam_begin")
             self._adam(name, shard, gs, row_state)
+            mark("adam_end")
             if self.world > 1:
                 parts = [torch.empty_like(shard) for _ in range(self.world)]
                 dist.all_gather(parts, shard.clone(), group=self.group)
                 st["p"][nf:nf + span].copy_(torch.cat(parts, dim=0))
+        mark("end")
         return loss.detach()
 
 

@@ -99,7 +99,8 @@ def run_sequence(cam, stream: Iterable, args, device, mapper: Optional[Mapping] 
         t1 = time.perf_counter()                                # predict_pose returned a host pose: the tracker is done
         mapper.mapping(frame, frame_map, frame_id)
         mm = mapper.get_render_output(frame)
-        tracker.update_last_status(frame, mm["render_depth"].contiguous(), frame_map["depth_map"],
+        # update_last_status fills holes of the model depth IN PLACE (icp.py:397-415): hand it a copy, the render is cached
+        tracker.update_last_status(frame, mm["render_depth"].clone(), frame_map["depth_map"],
                                    mm["render_normal"].contiguous(), frame_map["normal_map_w"])
         torch.cuda.synchronize(device)                          # the mapper's frame is over when its kernels are
         t2 = time.perf_counter()

@@ -212,18 +212,19 @@ def se3_exp(xi: torch.Tensor) -> torch.Tensor:
 
 
 def box_room_depth(cam: CameraSpec, c2w: torch.Tensor, half=(2.5, 1.5, 3.0),
-                   bump: float = 0.05) -> torch.Tensor:
+                   bump: float = 0.05, device=None) -> torch.Tensor:
     """Depth map [H,W,1] (camera z, metres, float32) of a camera inside an axis-aligned box
     |x|<hx, |y|<hy, |z|<hz whose walls carry a smooth sinusoidal relief (so ICP is
-    well-conditioned in all 6 DoF)."""
+    well-conditioned in all 6 DoF).  `device`: where to evaluate it (default CPU: bit-reproducible across hosts; a long
+    synthetic sequence renders its frames on the GPU)."""
     H, W = cam.H, cam.W
-    c2w = c2w.double()
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    c2w = c2w.double().to(device) if device is not None else c2w.double()
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64, device=device), torch.arange(W, dtype=torch.float64, device=device), indexing="ij")
     rays_c = torch.stack([(xs - cam.cx) / cam.fx, (ys - cam.cy) / cam.fy, torch.ones_like(xs)], -1)
     rays_w = rays_c @ c2w[:3, :3].t()
     o = c2w[:3, 3]
-    hv = torch.tensor(half, dtype=torch.float64)
-    tbest = torch.full((H, W), float("inf"), dtype=torch.float64)
+    hv = torch.tensor(half, dtype=torch.float64, device=device)
+    tbest = torch.full((H, W), float("inf"), dtype=torch.float64, device=device)
     for ax in range(3):
         for sgn in (-1.0, 1.0):
             d = rays_w[..., ax]
@@ -242,10 +243,12 @@ def box_room_depth(cam: CameraSpec, c2w: torch.Tensor, half=(2.5, 1.5, 3.0),
 
 def box_room_color(cam: CameraSpec, c2w: torch.Tensor, depth: torch.Tensor) -> torch.Tensor:
     """Colour image [3,H,W] of the box room: a smooth function of the WORLD point every pixel sees (the same one
-    `surface_gaussians` paints its discs with), so colour is consistent across views.  `depth` = box_room_depth."""
+    `surface_gaussians` paints its discs with), so colour is consistent across views.  `depth` = box_room_depth (evaluated
+    on the depth's device)."""
     H, W = cam.H, cam.W
-    c2w = c2w.double()
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    device = depth.device
+    c2w = c2w.double().to(device)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64, device=device), torch.arange(W, dtype=torch.float64, device=device), indexing="ij")
     z = depth.reshape(H, W).double()
     pc = torch.stack([(xs - cam.cx) / cam.fx * z, (ys - cam.cy) / cam.fy * z, z], -1)
     pw = pc @ c2w[:3, :3].t() + c2w[:3, 3]
@@ -264,6 +267,33 @@ def tum_noise(depth: torch.Tensor, seed: int = 0, hole_frac: float = 0.05, scale
     holes = torch.rand(z.shape, generator=g, dtype=torch.float64) < hole_frac
     z = torch.where(holes | (depth <= 0), torch.zeros_like(z), z)
     return z.to(torch.float32)
+
+
+def room_tour(n_frames: int, seed: int = 0, half=(2.5, 1.5, 3.0), max_trans: float = 0.02, max_rot_deg: float = 1.0):
+    """A bounded camera-to-world trajectory for LONG sequences in the box room (BASELINE configs[2] is a 2000-frame
+    sequence; `trajectory` drifts out of the room after ~150 frames): the position follows a Lissajous curve well inside
+    the walls, the camera pans steadily and nods, and every frame moves <= max_trans and turns <= max_rot_deg."""
+    g = torch.Generator().manual_seed(seed)
+    ph = (torch.rand(3, generator=g, dtype=torch.float64) * 2 * math.pi).tolist()
+    amp = [0.45 * half[0], 0.3 * half[1], 0.45 * half[2]]
+    w = [1.0, 0.7, 1.3]
+    # angular speed of the curve so that |dp/di| <= 0.8 max_trans: |dp/di| <= k * sqrt(sum (amp w)^2)
+    k = 0.8 * max_trans / math.sqrt(sum((a * ww) ** 2 for a, ww in zip(amp, w)))
+    yaw_rate = math.radians(max_rot_deg) * 0.6
+    poses = []
+    yaw = 0.0
+    for i in range(n_frames):
+        p = [amp[c] * math.sin(w[c] * k * i + ph[c]) for c in range(3)]
+        yaw += yaw_rate * (0.75 + 0.25 * math.sin(0.01 * i))
+        pitch = math.radians(12.0) * math.sin(0.013 * i + ph[0])
+        cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
+        Ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=torch.float64)      # pan about the world's vertical (y down)
+        Rx = torch.tensor([[1, 0, 0], [0, cp, -sp], [0, sp, cp]], dtype=torch.float64)
+        T = torch.eye(4, dtype=torch.float64)
+        T[:3, :3] = Ry @ Rx
+        T[:3, 3] = torch.tensor(p, dtype=torch.float64)
+        poses.append(T)
+    return poses
 
 
 def trajectory(n_frames: int, seed: int = 0, max_trans: float = 0.02, max_rot_deg: float = 1.0):

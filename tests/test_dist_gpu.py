@@ -204,7 +204,14 @@ def test_two_ranks_sparse_slam_step_with_a_map_that_outgrows_its_capacity():
     assert bad < 2e-3, bad
 
 
-def _worker_band(rank, world, port, ret):
+def _gt_normal(H, W, dev):
+    n = torch.randn(H, W, 3, generator=torch.Generator().manual_seed(12))
+    n = n / n.norm(dim=-1, keepdim=True)
+    n[:7] = 0                                                           # rows without a frame normal: not in the mean
+    return n.to(dev)
+
+
+def _worker_band(rank, world, port, ret, nw=0.0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -225,14 +232,16 @@ def _worker_band(rank, world, port, ret):
     opt.begin_local_optimization()
     losses = []
     for i in range(4):
-        losses.append(float(opt.step_slam(rs, gt_c, gt_d, tm, render_mask=(rm2 if i % 2 else rm), tile_band=True)))
+        losses.append(float(opt.step_slam(rs, gt_c, gt_d, tm, render_mask=(rm2 if i % 2 else rm), tile_band=True,
+                                          normal_weight=nw, gt_normal=_gt_normal(H, W, dev) if nw > 0 else None)))
     band = opt.band_tile_mask(tm).cpu()
     ret[rank] = (opt.params.cpu(), losses, band, opt.overflow_redos, opt._row_capacity)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_tile_band_split_of_one_view_and_overflow_redo():
+@pytest.mark.parametrize("nw", [0.0, 0.3])
+def test_tile_band_split_of_one_view_and_overflow_redo(nw=0.0):
     """ONE view, each rank renders and differentiates its band of tiles, loss normalisers all-reduced,
     gradient rows summed by the sparse exchange - equal to a single process stepping on the whole view.  The exchange
     starts with a capacity that is too small: the overflow is detected on the device, nothing is applied, and the host
@@ -243,7 +252,7 @@ def test_tile_band_split_of_one_view_and_overflow_redo():
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker_band, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_worker_band, args=(2, port + (37 if nw > 0 else 0), ret, nw), nprocs=2, join=True)
     (p0, l0, b0, redo0, cap0), (p1, l1, b1, redo1, cap1) = ret[0], ret[1]
     assert torch.equal(p0, p1) and l0 == l1                          # replicas bit-identical, same (global) loss
     assert redo0 >= 1 and redo0 == redo1 and cap0 == cap1 > 32
@@ -259,7 +268,10 @@ def test_tile_band_split_of_one_view_and_overflow_redo():
     rm2 = (torch.rand(H, W, generator=torch.Generator().manual_seed(10)) < 0.5).to(dev)
     ref = mo.ShardedMapOptimizer(packed)
     ref.begin_local_optimization()
-    lr = [float(ref.step_slam(rs, gt_c, gt_d, tm, render_mask=(rm2 if i % 2 else rm))) for i in range(4)]
+    # nw > 0: the normal term's mean is over the pixels of the WHOLE view (mapper.py:433-442) - its two sums are all-reduced
+    # across the bands like the image terms' normalisers (it used the rank-local count)
+    lr = [float(ref.step_slam(rs, gt_c, gt_d, tm, render_mask=(rm2 if i % 2 else rm), normal_weight=nw,
+                              gt_normal=_gt_normal(H, W, dev) if nw > 0 else None)) for i in range(4)]
     for a, b in zip(l0, lr):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b))
     rp = ref.params.cpu()

@@ -1,0 +1,120 @@
+"""BASELINE.json configs[2] at reduced size: a synthetic Replica-shaped stream through the reference's loop
+(slam.py:56-95 -> rtg_slam_amd.slam.run_sequence) from an EMPTY map, with the map's whole lifecycle in the loop
+(mapper.py:97-126): per-frame add, every 6th frame render-range masks from the UNSTABLE rows and a local optimisation
+with the stable prefix frozen, gaussians_fix by confidence, deletion by age, error counters, keyframe-triggered global
+optimisations, and the final global optimisation.  Full size: bench.py's `sequence` leg."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from rtg_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _half_replica():
+    c = synth.REPLICA
+    return synth.CameraSpec(c.H // 2, c.W // 2, c.fx / 2, c.fy / 2, (c.cx + 0.5) / 2 - 0.5, (c.cy + 0.5) / 2 - 0.5)
+
+
+def _stream(cam, n, seed=21):
+    base = torch.eye(4, dtype=torch.float64)
+    for p in synth.trajectory(n, seed=seed):
+        c2w = base @ p
+        d = synth.box_room_depth(cam, c2w)
+        yield d.to(DEV), synth.box_room_color(cam, c2w, d).to(DEV), c2w.numpy()
+
+
+def test_sequence_from_an_empty_map_with_the_whole_lifecycle():
+    from rtg_slam_amd import mapping as mp, slam
+    cam = _half_replica()
+    n_frames = 72
+    args = mp.replica_args(uniform_sample_num=10200, gaussian_update_iter=30, stable_confidence_thres=40.0,
+                           unstable_time_window=24, max_depth=8.0, keyframe_trans_thes=0.25, seed=1)
+    mapper = mp.Mapping(args, DEV, capacity=200_000)
+    checks = dict(local=0, frozen_moved=0, masked_tiles=[], global_=0)
+    tiles = ((cam.H + 15) // 16) * ((cam.W + 15) // 16)
+    orig_local, orig_global, orig_range = mapper.local_optimize, mapper.global_optimization, mapper.evaluate_render_range
+
+    def local_optimize(frame, update_args=None):
+        nf = mapper.opt.n_frozen
+        before = mapper.opt.params[:nf].clone()
+        orig_local(frame, update_args)
+        checks["local"] += 1
+        checks["frozen_moved"] += int(not torch.equal(mapper.opt.params[:nf], before))
+
+    def global_optimization(update_args=None, select_keyframe_num=-1, is_end=False):
+        nf, N = mapper.opt.n_frozen, mapper.opt.N
+        before = mapper.opt.params[nf:N].clone()
+        orig_global(update_args, select_keyframe_num, is_end)
+        if not is_end and select_keyframe_num != -1:
+            checks["global_"] += 1
+            assert torch.equal(mapper.opt.params[nf:N], before)              # the unstable rows: neither rendered nor stepped
+
+    def evaluate_render_range(frame, **kw):
+        out = orig_range(frame, **kw)
+        if not kw.get("global_opt") and out[1] is not None:
+            checks["masked_tiles"].append(int(out[1].sum()))
+        return out
+    mapper.local_optimize, mapper.global_optimization, mapper.evaluate_render_range = local_optimize, global_optimization, evaluate_render_range
+
+    mapper, tracker, rep = slam.run_sequence(cam, _stream(cam, n_frames), args, DEV, mapper=mapper)
+    print({k: v for k, v in rep.items() if k != "per_frame"})
+    assert rep["frames"] == n_frames
+    # tracking: frame-to-model ICP holds the trajectory (the stream moves <= 2 cm / 1 degree per frame)
+    assert rep["ate_rmse_m"] < 0.01 and rep["final_translation_error_m"] < 0.02, rep["ate_rmse_m"]
+    # lifecycle: started empty, grew, most of the map turned stable, unstable Gaussians older than the window were deleted
+    st = rep["stats"]
+    assert st["added"] > 10000 and st["fixed"] > 5000 and st["deleted_unstable"] > 0
+    assert rep["stable"] > 0.5 * rep["gaussians"] and rep["stable_fraction_over_time"][0] < rep["stable_fraction_over_time"][-1]
+    assert st["local_opts"] == checks["local"] >= 8
+    # frozen (stable) rows are bit-unchanged across every local optimisation
+    assert checks["frozen_moved"] == 0
+    # render-range masks come from the unstable rows: once the map is mostly stable they switch most tiles OFF
+    assert min(checks["masked_tiles"][len(checks["masked_tiles"]) // 2:]) < 0.7 * tiles, checks["masked_tiles"]
+    assert max(checks["masked_tiles"]) <= tiles
+    # the map explains the last frame
+    fr = mapper.processed_frames[-1]
+    fm = mapper.processed_map[-1]
+    out = mapper._render(fr, "all")
+    mse = float(((out["render"] - fm["color_chw"]) ** 2).mean())
+    valid = (fm["depth_chw"][0] > 0) & (out["depth"][0] > 0)
+    d_l1 = float((out["depth"][0] - fm["depth_chw"][0]).abs()[valid].mean())
+    assert 10 * math.log10(1.0 / max(mse, 1e-12)) > 22.0 and d_l1 < 0.02
+    assert float((out["T_map"][0] != 1).float().mean()) > 0.97
+    # the final global optimisation (slam.py:104-106): everything becomes stable, then all keyframes are revisited
+    n_before = mapper.opt.N
+    mapper.global_optimization(select_keyframe_num=-1, is_end=True)
+    assert mapper.opt.n_train == 0 and mapper.opt.n_frozen == n_before and mapper.opt._scope == "local"
+    out2 = mapper._render(fr, "all")
+    mse2 = float(((out2["render"] - fm["color_chw"]) ** 2).mean())
+    assert mse2 < 1.5 * mse + 1e-4
+
+
+def test_global_optimisation_runs_inside_the_sequence_when_the_camera_moves_far():
+    """A keyframe (translation > keyframe_trans_thes) with stable rows present switches that frame's optimisation to the
+    global form (mapper.py:113-119): the stable rows move, the unstable rows do not."""
+    from rtg_slam_amd import mapping as mp, slam
+    cam = _half_replica()
+    args = mp.replica_args(uniform_sample_num=10200, gaussian_update_iter=20, stable_confidence_thres=15.0,
+                           unstable_time_window=24, max_depth=8.0, keyframe_trans_thes=0.03, seed=2)
+    mapper = mp.Mapping(args, DEV, capacity=200_000)
+    seen = dict(n=0, moved=0)
+    orig = mapper.global_optimization
+
+    def global_optimization(update_args=None, select_keyframe_num=-1, is_end=False):
+        nf, N = mapper.opt.n_frozen, mapper.opt.N
+        s0, u0 = mapper.opt.params[:nf].clone(), mapper.opt.params[nf:N].clone()
+        orig(update_args, select_keyframe_num, is_end)
+        seen["n"] += 1
+        seen["moved"] += int(not torch.equal(mapper.opt.params[:nf], s0))
+        assert torch.equal(mapper.opt.params[nf:N], u0)
+        assert torch.equal(mapper.opt.params[:nf, 0:3], s0[:, 0:3])          # position lr 0
+    mapper.global_optimization = global_optimization
+    mapper, tracker, rep = slam.run_sequence(cam, _stream(cam, 30, seed=8), args, DEV, mapper=mapper)
+    print({k: v for k, v in rep.items() if k != "per_frame"})
+    assert seen["n"] >= 2 and seen["moved"] == seen["n"] and rep["stats"]["global_opts"] == seen["n"]
+    assert rep["ate_rmse_m"] < 0.01

@@ -230,3 +230,86 @@ def test_fused_tail_equals_the_three_kernel_tail(kind, nf):
     assert int(opts[1].grad_rows.row_state.sum()) > 0
     lc = opts[0].live_counts.cpu()
     assert 0 < int(lc[0]) <= int(lc[1]) <= 6 * (N - nf)
+
+
+def test_step_slam_on_a_fully_frozen_map_changes_nothing():
+    """an EMPTY trainable range (n_frozen == N) is a legal state and must not read as "every row": the one-call
+    step renders, evaluates the loss and steps nothing - parameters, Adam state and gradient rows stay as they were."""
+    mo, packed, rs, gt_c, gt_d = _setup(N=6000)
+    N = packed.shape[0]
+    opt = mo.ShardedMapOptimizer(packed.clone(), n_frozen=N)
+    rm = torch.ones(CAM.H, CAM.W, dtype=torch.uint8, device=DEV)
+    opt.begin_local_optimization()
+    conf = torch.zeros(0, device=DEV)
+    for _ in range(2):
+        loss = opt.step_slam(rs, gt_c, gt_d, None, render_mask=rm, confidence=conf)
+    assert float(loss) > 0 and torch.isfinite(loss)
+    assert torch.equal(opt.params, packed)
+    a = opt.grad_rows
+    assert int(a.row_state.sum()) == 0 and float(a.d_means.abs().sum()) == 0.0 and float(a.d_shs.abs().sum()) == 0.0
+    for n in ("xyz", "shs", "raw8"):
+        assert float(opt.state[n]["m"].abs().sum()) == 0.0 and int(opt.state[n]["ever"].sum()) == 0
+    ref = mo.ShardedMapOptimizer(packed.clone())                             # ... and it rendered what a normal forward renders
+    ref.begin_local_optimization()
+    l2 = ref.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
+    assert abs(float(l2) - float(loss)) <= 1e-6 * max(1.0, abs(float(l2)))
+
+
+@pytest.mark.parametrize("tail_mode", [0, 1])
+def test_global_optimization_equals_the_autograd_step_on_the_stable_rows(tail_mode):
+    """Mapping.global_optimization (mapper.py:594-707) as a mode of the map object: between begin_ and
+    end_global_optimization the one-call step renders the STABLE prefix only and trains all of it with the rescaled
+    learning-rate columns (:605-616).  Against (a) `step(loss_fn)` - autograd through the rasterizer - in the same mode, and
+    (b) a map that IS the stable prefix with the scaled rates; the unstable suffix stays bit for bit, and the local mode
+    works again afterwards."""
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    mo, packed, rs, gt_c, gt_d = _setup()
+    N, nf = packed.shape[0], 8000
+    scale = mo.global_lr_scale(final=False)
+    oa = mo.ShardedMapOptimizer(packed.clone(), n_frozen=nf)
+    ob = mo.ShardedMapOptimizer(packed.clone(), n_frozen=nf)
+    ob.tail_mode = tail_mode
+    only = mo.ShardedMapOptimizer(packed[:nf].clone(), lr_col=mo.default_lr_columns() * scale)
+    only.tail_mode = tail_mode
+    rast = GaussianRasterizer(raster_settings=rs)
+    rm = torch.ones(CAM.H, CAM.W, dtype=torch.uint8, device=DEV)
+    seen = []
+
+    def loss_fn(gd):
+        seen.append(int(gd["xyz"].shape[0]))
+        out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
+                   rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=None,
+                   grad_rows=gd.get("grad_rows"))
+        return mo.slam_losses_hip(out, gt_c, gt_d, render_mask=rm)
+    for o in (oa, ob):                                                       # a local optimisation first: the suffix moves
+        o.begin_local_optimization()
+        for _ in range(2):
+            o.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
+    mid = ob.params.clone()
+    assert torch.equal(mid[:nf], packed[:nf]) and torch.equal(oa.params, mid)
+    conf = torch.zeros(nf, device=DEV)
+    oa.begin_global_optimization(scale)
+    ob.begin_global_optimization(scale)
+    only.begin_local_optimization()
+    assert float(ob.attach_init["info"][0]) == float(only.attach_init["info"][0])      # attach snapshot covers the stable rows
+    for it in range(4):
+        la = float(oa.step(loss_fn))
+        lb = float(ob.step_slam(rs, gt_c, gt_d, None, render_mask=rm, confidence=conf))
+        lc = float(only.step_slam(rs, gt_c, gt_d, None, render_mask=rm))
+        assert abs(lb - lc) <= 1e-6 * max(1.0, abs(lc)), it                  # the same map is rendered: the prefix alone
+        assert abs(la - lb) <= 1e-4 * max(1.0, abs(la)), it
+    assert seen == [nf] * 4
+    pa, pb, pc = oa.params, ob.params, only.params
+    assert torch.equal(pb[nf:], mid[nf:]) and torch.equal(pa[nf:], mid[nf:])           # unstable suffix: bit for bit
+    assert torch.equal(pb[:nf], pc)                                          # = the stable rows as a map of their own
+    assert torch.equal(pb[:nf, 0:3], mid[:nf, 0:3])                          # position lr 0 (mapper.py:607)
+    assert float((pb[:nf, 3:] - mid[:nf, 3:]).abs().max()) > 0
+    assert ru.frac_bad(pa[:nf].cpu(), pb[:nf].cpu(), 1e-5) < 2e-3
+    assert float(conf.sum()) > 0 and float(conf.max()) <= 4.0                # confidence of the STABLE rows (loss_update, unstable=False)
+    assert int(ob.grad_rows.row_state[nf:].sum()) == 0 if tail_mode == 1 else True
+    ob.end_global_optimization()
+    ob.begin_local_optimization()
+    for _ in range(2):
+        ob.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
+    pl = ob.params
+    assert torch.equal(pl[:nf], pb[:nf]) and float((pl[nf:] - pb[nf:]).abs().max()) > 0
