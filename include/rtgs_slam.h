@@ -65,7 +65,9 @@ int rtgs_knn3(const float* points, int32_t N, float* mean_dist2, int32_t* idx, f
  * of distCUDA2(total_xyz) in GaussianPointCloud.update_geometry (gaussian_pointcloud.py:366-381), which needs the
  * neighbours of the NEW points only.  self_offset < 0: the sets are unrelated.  ref_box6 (device float[6] = lo xyz, hi xyz;
  * NULL = none): references outside the OPEN box are ignored - bbox_filter (SLAM/utils.py:737-744), which both call sites
- * apply to the existing points before the search, without a compaction.  scratch: rtgs_knn3_scratch_bytes(Nr). */
+ * apply to the existing points before the search, without a compaction.  The queries are visited in Morton order (sorted
+ * inside the call) so that the lanes of a wave open the same boxes.  scratch: rtgs_knn3_query_scratch_bytes(Nr, Nq). */
+size_t rtgs_knn3_query_scratch_bytes(int32_t Nr, int32_t Nq);
 int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_points, int32_t Nq, int32_t self_offset,
                     const float* ref_box6, int32_t* idx, float* dist2, void* scratch, void* stream);
 

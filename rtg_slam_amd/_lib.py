@@ -183,6 +183,7 @@ _SIGNATURES = {
     "rtgs_render_range": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P, _P]),
     "rtgs_knn3_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "rtgs_knn3": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    "rtgs_knn3_query_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "rtgs_knn3_query": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "rtgs_accumulate_error": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_float, C.c_float,
                                         C.c_float, C.c_int32, _P, _P, _P, _P, _P, _P]),

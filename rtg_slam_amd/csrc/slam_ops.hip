@@ -275,13 +275,34 @@ __global__ void __launch_bounds__(256) knn_search_kernel(const float4* __restric
 // the sorted codes and seeds its bound with the eight references around that position - close in space as a rule - so that
 // the box sweep opens only boxes near the query.  `self_offset` >= 0: query i IS reference self_offset + i (the new points
 // of GaussianPointCloud.update_geometry, gaussian_pointcloud.py:366-405, sit at the front of `total_xyz`) and is skipped.
+__global__ void __launch_bounds__(256) knn_query_codes_kernel(const float* __restrict__ query, int Nq, const uint32_t* __restrict__ bbox,
+                                                              uint32_t* __restrict__ codes, uint32_t* __restrict__ order) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Nq) return;
+  uint32_t q[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {                                   // the REFERENCES' box: a query outside clamps to its faces
+    const float lo = dec_f(bbox[c]), hi = dec_f(bbox[3 + c]);
+    const float ext = hi - lo;
+    const float t = ext > 0.f ? (query[(size_t)i * 3 + c] - lo) / ext : 0.f;
+    q[c] = (uint32_t)fminf(1023.f, fmaxf(0.f, t * 1023.f));
+  }
+  codes[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+  order[i] = (uint32_t)i;
+}
+
+// One lane per query, queries taken in MORTON order (q_order): the lanes of a wave are neighbours in space and open the
+// same few boxes - in caller order (random pixels of a frame) a wave's 64 queries are spread over the whole scene, every
+// wave opens nearly every box, and 4 000 queries against 100 000 references took 2.8 ms on 63 waves.
 __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict__ sorted, int N, const uint32_t* __restrict__ codes_sorted,
-                                                        const uint32_t* __restrict__ bbox, const float* __restrict__ boxes, int nboxes,
-                                                        const float* __restrict__ query, int Nq, int self_offset,
+                                                        const float* __restrict__ boxes, int nboxes,
+                                                        const float* __restrict__ query, int Nq, const uint32_t* __restrict__ q_order,
+                                                        const uint32_t* __restrict__ q_codes_sorted, int self_offset,
                                                         const float* __restrict__ ref_box, int32_t* __restrict__ idx,
                                                         float* __restrict__ dist_out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool live = i < Nq;
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  const bool live = slot < Nq;
+  const int i = live ? (int)q_order[slot] : 0;
   // optional open box (lo, hi): references outside it do not exist for the search (bbox_filter, SLAM/utils.py:737-744)
   float blo[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}, bhi[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
   if (ref_box) {
@@ -297,16 +318,7 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
   const int self = (live && self_offset >= 0) ? self_offset + i : -1;
   if (live) {
     p = make_float4(query[(size_t)i * 3], query[(size_t)i * 3 + 1], query[(size_t)i * 3 + 2], 0.f);
-    uint32_t q[3];
-    const float pc[3] = {p.x, p.y, p.z};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float lo = dec_f(bbox[c]), hi = dec_f(bbox[3 + c]);
-      const float ext = hi - lo;
-      const float t = ext > 0.f ? (pc[c] - lo) / ext : 0.f;
-      q[c] = (uint32_t)fminf(1023.f, fmaxf(0.f, t * 1023.f));
-    }
-    const uint32_t code = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    const uint32_t code = q_codes_sorted[slot];
     int lo = 0, hi = N;                                         // lower bound of `code`
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (codes_sorted[mid] < code) lo = mid + 1; else hi = mid; }
     for (int j = max(0, lo - 4); j <= min(N - 1, lo + 3); ++j) {
@@ -674,6 +686,26 @@ int rtgs_knn3(const float* points, int32_t N, float* mean_dist2, int32_t* idx, f
   return 0;
 }
 
+struct KnnQueryLayout { size_t codes, codes_sorted, order_in, order, cub, total, cub_bytes; };
+static KnnQueryLayout knn_query_layout(int Nr, int Nq) {
+  KnnQueryLayout Q{};
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t n = (size_t)(Nq > 0 ? Nq : 1);
+  size_t off = knn_layout(Nr).total;
+  Q.codes = off; off = al(off + n * 4);
+  Q.codes_sorted = off; off = al(off + n * 4);
+  Q.order_in = off; off = al(off + n * 4);
+  Q.order = off; off = al(off + n * 4);
+  size_t tb = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, n, 0u, 30u);
+  Q.cub_bytes = tb;
+  Q.cub = off; off = al(off + tb);
+  Q.total = off;
+  return Q;
+}
+size_t rtgs_knn3_query_scratch_bytes(int32_t Nr, int32_t Nq) { return knn_query_layout(Nr, Nq).total; }
+
 int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_points, int32_t Nq, int32_t self_offset,
                     const float* ref_box6, int32_t* idx, float* dist2_out, void* scratch, void* stream) {
   if (Nr < 0 || Nq < 0 || (Nq > 0 && (!query_points || !idx))) return -1;
@@ -688,13 +720,22 @@ int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_poin
     return 0;
   }
   const KnnLayout L = knn_layout(Nr);
+  const KnnQueryLayout Q = knn_query_layout(Nr, Nq);
   char* s = (char*)scratch;
   const int rc = knn_build(ref_points, Nr, scratch, st);
   if (rc != 0) return rc;
+  uint32_t* q_codes = (uint32_t*)(s + Q.codes);
+  uint32_t* q_codes_sorted = (uint32_t*)(s + Q.codes_sorted);
+  uint32_t* q_order_in = (uint32_t*)(s + Q.order_in);
+  uint32_t* q_order = (uint32_t*)(s + Q.order);
+  hipLaunchKernelGGL(knn_query_codes_kernel, dim3(grid1(Nq)), dim3(256), 0, st, query_points, Nq, (const uint32_t*)(s + L.bbox),
+                     q_codes, q_order_in);
+  size_t tb = Q.cub_bytes;
+  SLAM_TRY(rocprim::radix_sort_pairs(s + Q.cub, tb, q_codes, q_codes_sorted, q_order_in, q_order, (size_t)Nq, 0u, 30u, st));
   const int nboxes = (Nr + KNN_BOX - 1) / KNN_BOX;
   hipLaunchKernelGGL(knn_query_kernel, dim3(grid1(Nq)), dim3(256), 0, st, (const float4*)(s + L.sorted), Nr,
-                     (const uint32_t*)(s + L.codes_sorted), (const uint32_t*)(s + L.bbox), (const float*)(s + L.boxes), nboxes,
-                     query_points, Nq, self_offset, ref_box6, idx, dist2_out);
+                     (const uint32_t*)(s + L.codes_sorted), (const float*)(s + L.boxes), nboxes, query_points, Nq,
+                     (const uint32_t*)q_order, (const uint32_t*)q_codes_sorted, self_offset, ref_box6, idx, dist2_out);
   SLAM_TRY(hipGetLastError());
   return 0;
 }

@@ -231,6 +231,7 @@ class Mapping:
         self.rng = random.Random(int(getattr(args, "seed", 0)))
         self.stats = dict(added=0, fixed=0, deleted_unstable=0, deleted_stable=0, released=0, local_opts=0, global_opts=0,
                           iterations=0, renders=0, renders_reused=0)
+        self.prof = {} if __import__("os").environ.get("RTGS_MAP_PROFILE") else None
         self.weights = SimpleNamespace(color_weight=args.color_weight, depth_weight=args.depth_weight,
                                        ssim_weight=args.ssim_weight, add_depth_thres=args.add_depth_thres)
 
@@ -288,38 +289,51 @@ class Mapping:
         return out
 
     # ------------------------------------------------------------------ per frame (mapper.py:97-126)
+    def _stage(self, name, fn, *a, **kw):
+        """Diagnosis aid (RTGS_MAP_PROFILE=1): wall time per stage WITH a device synchronisation after each - the sum is
+        larger than the unprofiled frame, the shares say where a frame goes."""
+        if self.prof is None:
+            return fn(*a, **kw)
+        import time
+        torch.cuda.synchronize(self.device)
+        t = time.perf_counter()
+        r = fn(*a, **kw)
+        torch.cuda.synchronize(self.device)
+        self.prof[name] = self.prof.get(name, 0.0) + time.perf_counter() - t
+        return r
+
     def mapping(self, frame, frame_map, frame_id, optimization_params=None):
         self.frame_map = frame_map
         if "color_chw" not in frame_map:                                 # the [C,H,W] form the loss kernels read, once per frame
             frame_map["color_chw"] = frame_map["color_map"].permute(2, 0, 1).contiguous()
             frame_map["depth_chw"] = frame_map["depth_map"].permute(2, 0, 1).contiguous()
-        self.gaussians_add(frame)
+        self._stage("gaussians_add", self.gaussians_add, frame)
         self.processed_frames.append(frame)
         self.processed_map.append(frame_map)
         if (self.time + 1) % self.args.gaussian_update_frame == 0 or self.time == 0:
             self.optimize_frames_ids.append(frame_id)
             is_keyframe = self.check_keyframe(frame, frame_id)
             if self.args.type == "Scannetpp":
-                self.local_optimize(frame)
+                self._stage("local_optimize", self.local_optimize, frame)
                 if is_keyframe:
-                    self.global_optimization(select_keyframe_num=self.args.global_keyframe_num)
+                    self._stage("global_optimization", self.global_optimization, select_keyframe_num=self.args.global_keyframe_num)
             else:
                 if not is_keyframe or self.get_stable_num <= 0:
-                    self.local_optimize(frame)
+                    self._stage("local_optimize", self.local_optimize, frame)
                 else:
-                    self.global_optimization(select_keyframe_num=self.args.global_keyframe_num)
-                self.gaussians_delete(unstable=False)
-        self.gaussians_fix()
-        self.error_gaussians_remove()
-        self.gaussians_delete()
+                    self._stage("global_optimization", self.global_optimization, select_keyframe_num=self.args.global_keyframe_num)
+                self._stage("gaussians_delete_stable", self.gaussians_delete, unstable=False)
+        self._stage("gaussians_fix", self.gaussians_fix)
+        self._stage("error_gaussians_remove", self.error_gaussians_remove)
+        self._stage("gaussians_delete", self.gaussians_delete)
 
     def gaussians_add(self, frame):
-        temp = self.temp_points_init(frame)
+        temp = self._stage("add.temp_points_init", self.temp_points_init, frame)
         if temp is None:
             return
-        keep = self.temp_points_filter(temp)
-        self.temp_points_attach(frame, temp)
-        self.temp_to_optimize(temp, keep)
+        keep = self._stage("add.temp_points_filter", self.temp_points_filter, temp)
+        self._stage("add.temp_points_attach", self.temp_points_attach, frame, temp)
+        self._stage("add.temp_to_optimize", self.temp_to_optimize, temp, keep)
 
     # ------------------------------------------------------------------ new Gaussians (mapper.py:709-883)
     def _new_points(self, parts):
@@ -462,7 +476,8 @@ class Mapping:
         a, o = self.args, self.opt
         conf = self.aux("confidence", "unstable").reshape(-1)
         o.begin_local_optimization(confidence=conf)                      # history_stat + a fresh Adam (mapper.py:136-156)
-        masks = [self.evaluate_render_range(f) for f in self.processed_frames]
+        masks = [self._stage("opt.evaluate_render_range", self.evaluate_render_range, f) for f in self.processed_frames]
+        masks = [(m[0].to(torch.uint8), m[1], m[2]) for m in masks]     # the loss kernels read bytes: converted once, not per step
         self.stats["local_opts"] += 1
         if o.n_train == 0:
             return
@@ -507,6 +522,7 @@ class Mapping:
         maps = [self.keymap_list[i] for i in sel]
         masks = [self.evaluate_render_range(f, global_opt=True, unstable=False, sample_ratio=sample_ratio,
                                             gt_color=m["color_map"]) for f, m in zip(frames, maps)]
+        masks = [(m[0].to(torch.uint8), m[1], m[2]) for m in masks]
         conf = self.aux("confidence", "stable").reshape(-1)
         for it in range(total_iter):
             self.iter = it

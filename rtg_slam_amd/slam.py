@@ -128,5 +128,6 @@ def run_sequence(cam, stream: Iterable, args, device, mapper: Optional[Mapping] 
         "stable_fraction_over_time": [round(p[3] / max(p[2], 1), 4) for p in per_frame[::max(1, n // 20)]],
         "gaussians_over_time": [p[2] for p in per_frame[::max(1, n // 20)]],
         "per_frame": per_frame,
+        "stage_profile_ms_per_frame": None if mapper.prof is None else {k: round(1e3 * v / max(n, 1), 3) for k, v in mapper.prof.items()},
     }
     return mapper, tracker, report

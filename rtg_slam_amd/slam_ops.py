@@ -128,7 +128,7 @@ def knn_query(ref_points: torch.Tensor, query_points: torch.Tensor, self_offset:
     Nr, Nq = int(ref.shape[0]), int(q.shape[0])
     idx = torch.empty(Nq, 3, dtype=torch.int32, device=dev)
     d3 = torch.empty(Nq, 3, dtype=torch.float32, device=dev)
-    scratch = torch.empty(lib.rtgs_knn3_scratch_bytes(Nr), dtype=torch.uint8, device=dev)
+    scratch = torch.empty(lib.rtgs_knn3_query_scratch_bytes(Nr, Nq), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         box = None if ref_box is None else ref_box.to(device=dev, dtype=torch.float32).reshape(6).contiguous()
         rc = lib.rtgs_knn3_query(_p(ref), Nr, _p(q), Nq, int(self_offset), _p(box), _p(idx), _p(d3), _p(scratch), _stream(dev))

@@ -241,7 +241,7 @@ def _worker_band(rank, world, port, ret, nw=0.0):
 
 
 @pytest.mark.parametrize("nw", [0.0, 0.3])
-def test_tile_band_split_of_one_view_and_overflow_redo(nw=0.0):
+def test_tile_band_split_of_one_view_and_overflow_redo(nw):
     """ONE view, each rank renders and differentiates its band of tiles, loss normalisers all-reduced,
     gradient rows summed by the sparse exchange - equal to a single process stepping on the whole view.  The exchange
     starts with a capacity that is too small: the overflow is detected on the device, nothing is applied, and the host
@@ -288,4 +288,5 @@ def test_the_three_multi_gpu_forms_on_real_rccl(monkeypatch):
     monkeypatch.setenv("RTGS_TEST_BACKEND", "nccl")
     test_two_ranks_one_gpu_match_single_process()
     test_two_ranks_sparse_slam_step_matches_single_process()
-    test_tile_band_split_of_one_view_and_overflow_redo()
+    test_tile_band_split_of_one_view_and_overflow_redo(0.0)
+    test_tile_band_split_of_one_view_and_overflow_redo(0.3)

@@ -285,28 +285,34 @@ def test_global_optimization_equals_the_autograd_step_on_the_stable_rows(tail_mo
         o.begin_local_optimization()
         for _ in range(2):
             o.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
-    mid = ob.params.clone()
-    assert torch.equal(mid[:nf], packed[:nf]) and torch.equal(oa.params, mid)
+    mid, mid_a = ob.params.clone(), oa.params.clone()          # (two runs of the same steps agree to summation-order rounding)
+    assert torch.equal(mid[:nf], packed[:nf]) and torch.equal(mid_a[:nf], packed[:nf])
+    assert ru.frac_bad(mid_a.cpu(), mid.cpu(), 1e-5) < 2e-3
     conf = torch.zeros(nf, device=DEV)
+    oc = mo.ShardedMapOptimizer(mid_a.clone(), n_frozen=nf)                  # step_slam WITHOUT the attach term: the partner of
+    oc.tail_mode = tail_mode                                                 # oa's autograd step, whose loss_fn has none either
     oa.begin_global_optimization(scale)
     ob.begin_global_optimization(scale)
+    oc.begin_global_optimization(scale)
+    oa.attach_init = oc.attach_init = None
     only.begin_local_optimization()
-    assert float(ob.attach_init["info"][0]) == float(only.attach_init["info"][0])      # attach snapshot covers the stable rows
+    assert float(ob.attach_init["info"][0]) == float(only.attach_init["info"][0]) > 0  # attach snapshot covers the stable rows
     for it in range(4):
         la = float(oa.step(loss_fn))
         lb = float(ob.step_slam(rs, gt_c, gt_d, None, render_mask=rm, confidence=conf))
         lc = float(only.step_slam(rs, gt_c, gt_d, None, render_mask=rm))
+        ld = float(oc.step_slam(rs, gt_c, gt_d, None, render_mask=rm))
         assert abs(lb - lc) <= 1e-6 * max(1.0, abs(lc)), it                  # the same map is rendered: the prefix alone
-        assert abs(la - lb) <= 1e-4 * max(1.0, abs(la)), it
+        assert abs(la - ld) <= 1e-4 * max(1.0, abs(la)), it
     assert seen == [nf] * 4
-    pa, pb, pc = oa.params, ob.params, only.params
-    assert torch.equal(pb[nf:], mid[nf:]) and torch.equal(pa[nf:], mid[nf:])           # unstable suffix: bit for bit
-    assert torch.equal(pb[:nf], pc)                                          # = the stable rows as a map of their own
+    pa, pb, pc, pd = oa.params, ob.params, only.params, oc.params
+    assert torch.equal(pb[nf:], mid[nf:]) and torch.equal(pa[nf:], mid_a[nf:])         # unstable suffix: bit for bit
+    assert ru.frac_bad(pb[:nf].cpu(), pc.cpu(), 1e-6) < 1e-3                 # = the stable rows as a map of their own
     assert torch.equal(pb[:nf, 0:3], mid[:nf, 0:3])                          # position lr 0 (mapper.py:607)
     assert float((pb[:nf, 3:] - mid[:nf, 3:]).abs().max()) > 0
-    assert ru.frac_bad(pa[:nf].cpu(), pb[:nf].cpu(), 1e-5) < 2e-3
+    assert ru.frac_bad(pa[:nf].cpu(), pd[:nf].cpu(), 1e-5) < 2e-3            # autograd through the rasterizer = the one-call step
+    assert torch.equal(pd[nf:], mid_a[nf:])
     assert float(conf.sum()) > 0 and float(conf.max()) <= 4.0                # confidence of the STABLE rows (loss_update, unstable=False)
-    assert int(ob.grad_rows.row_state[nf:].sum()) == 0 if tail_mode == 1 else True
     ob.end_global_optimization()
     ob.begin_local_optimization()
     for _ in range(2):

@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(256) probe(float* out, unsigned long long* cyc
         a7 = a0 + 7.f;
   const float m = 0.999f, c = 1e-3f;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  unsigned sc0 = 1u, sc1 = 2u;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < ITERS; ++it) {
     if (KIND == 0) {                    // 8 chains x 8 = 64 independent-enough FMAs
@@ -69,16 +70,16 @@ __global__ void __launch_bounds__(256) probe(float* out, unsigned long long* cyc
                         "v_mul_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
                         : "+v"(a0), "+v"(a1), "+v"(a2));)
     } else if (KIND == 6) {             // scalar + vector mix as in blend_fwd's mask walk: 1 SALU per 2 VALU
-      REP8(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n s_add_u32 s20, s20, 1\n"
-                        "v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n s_add_u32 s21, s21, 1\n"
-                        "v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n s_add_u32 s20, s20, 1\n"
-                        "v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n s_add_u32 s21, s21, 1\n"
-                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m), "v"(c) : "s20", "s21");)
+      REP8(asm volatile("v_fma_f32 %0, %0, %6, %7\n v_fma_f32 %1, %1, %6, %7\n s_add_u32 %4, %4, 1\n"
+                        "v_fma_f32 %2, %2, %6, %7\n v_fma_f32 %3, %3, %6, %7\n s_add_u32 %5, %5, 1\n"
+                        "v_fma_f32 %0, %0, %6, %7\n v_fma_f32 %1, %1, %6, %7\n s_add_u32 %4, %4, 1\n"
+                        "v_fma_f32 %2, %2, %6, %7\n v_fma_f32 %3, %3, %6, %7\n s_add_u32 %5, %5, 1\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(sc0), "+s"(sc1) : "v"(m), "v"(c) : "scc");)
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   const float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + acc0[0] + acc1[0] + acc0[1] + acc1[3];
-  if (r == 12345.678f) out[0] = r;                       // keeps the chains alive
+  if (r == 12345.678f || sc0 + sc1 == 7u) out[0] = r;                       // keeps the chains alive
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
@@ -110,12 +111,13 @@ static void run(const char* name, int per_trip_counted, float* out, unsigned lon
 }
 
 int main() {
+  setvbuf(stdout, nullptr, _IOLBF, 0);
   int dev = 0, cus = 0, clk = 0;
   hipGetDevice(&dev);
   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, dev);
-  printf("device: %d CUs, peak clock %.0f MHz; s_memtime ticks are a FIXED-frequency counter (100 MHz on gfx9): the tick columns "
-         "compare kinds, the wall-time rate is the number\n", cus, clk / 1e3);
+  printf("device: %d CUs, peak clock %.0f MHz; s_memtime ticks = shader cycles (ticks / wall time gives the clock the chip "
+         "actually ran at under that load)\n", cus, clk / 1e3);
   float* out; unsigned long long *cyc, *hcyc;
   hipMalloc(&out, 64);
   hipMalloc(&cyc, sizeof(unsigned long long) * cus * 8 * 4);
