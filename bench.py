@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (5 M Gaussians, sharded, 10 iterations)")
     ap.add_argument("--config5-gaussians", type=int, default=5_000_000)
     ap.add_argument("--no-dropin", action="store_true", help="skip the unchanged-reference-iteration leg")
-    ap.add_argument("--only", choices=["sequence", "config5", "icp_tum"], default=None,
+    ap.add_argument("--only", choices=["sequence", "config5", "icp_tum", "dropin"], default=None,
                     help="run ONE extra leg and print its JSON (profiling aid; not the contract line)")
     ap.add_argument("--prewarm", type=int, default=3000,
                     help="untimed frames of the real workload before the warm-up: a FIXED count (every rank issues the same "
@@ -958,6 +958,21 @@ def only_leg(args, rank, world, dev):
         res = sequence_leg(cam, dev, args.sequence_frames)
     elif args.only == "icp_tum":
         res = icp_tum_leg(dev)
+    elif args.only == "dropin":
+        from rtg_slam_amd.rasterizer import GaussianRasterizationSettings
+        g = synth.random_gaussians(args.gaussians, cam, seed=2024)
+        eye = torch.eye(4, device=dev)
+        rs = GaussianRasterizationSettings(
+            image_height=cam.H, image_width=cam.W, tanfovx=cam.W / (2 * cam.fx), tanfovy=cam.H / (2 * cam.fy),
+            bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=eye, projmatrix=eye, sh_degree=3,
+            campos=torch.zeros(3, device=dev), opaque_threshold=0.6, depth_threshold=1.0,
+            normal_threshold=math.cos(math.radians(60.0)), color_sigma=3.0, prefiltered=False, debug=False, cx=cam.cx, cy=cam.cy,
+            T_threshold=1e-4)
+        tm = torch.ones((cam.H + 15) // 16, (cam.W + 15) // 16, dtype=torch.int32, device=dev)
+        gt_c = torch.rand(3, cam.H, cam.W, generator=torch.Generator().manual_seed(7)).to(dev)
+        gt_d = synth.box_room_depth(cam, torch.eye(4, dtype=torch.float64), device=dev).reshape(1, cam.H, cam.W)
+        rm = torch.ones(cam.H, cam.W, dtype=torch.uint8, device=dev)
+        res = dropin_leg(g, cam, rs, tm, gt_c, gt_d, rm, dev, args.steps)
     else:
         res = config5_block(dev, rank, world, barrier, N=args.config5_gaussians)
     if rank == 0:

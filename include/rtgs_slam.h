@@ -99,6 +99,9 @@ int rtgs_sample_candidates(const float* normal_map, const uint8_t* select_mask, 
                            int32_t* count_out, uint8_t* flags_scratch, void* scratch, void* stream);
 
 /* ---- Renderer.render's normal map (SLAM/render.py:130-133) ----------------------------------------------------- */
+/* transform_map (SLAM/utils.py:56-63; tracker.py:283-288 builds vertex_map_w / normal_map_w with it): out[i] = T[:3,:3] in[i] +
+ * T[:3,3] for n 3-vectors; transform16 = device float[16], row-major 4x4 (pass get_rot(c2w) - zero translation - for normals). */
+int rtgs_transform_map(const float* map3, int64_t n, const float* transform16, float* out3, void* stream);
 /* out[3,n]: out[:, p] = rows[index[p]] (rows float32 [N,3]) where index[p] >= 0, zeros elsewhere - the reference's two
  * boolean-mask indexings (two device-to-host syncs per render) as one kernel.  scatter = its backward: grad_rows[index[p]] +=
  * g[:, p] (accumulates; caller zeroes). */

@@ -193,6 +193,7 @@ _SIGNATURES = {
                                         _P, _P]),
     "rtgs_compact_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "rtgs_sample_candidates": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "rtgs_transform_map": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "rtgs_gather_rows3": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "rtgs_scatter_rows3": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
 }

@@ -65,7 +65,11 @@ __device__ __forceinline__ bool attach_sel(const float4 init_lo) {
   return 1.f / (1.f + __expf(-init_lo.x)) < 0.9f;                // opacity_activation(init_stat["opacity"]) < 0.9 (map_ops.hip)
 }
 
-template <int FCHUNK>
+// RPW: list entries a wave takes per pass.  64 = every lane a row (large maps: the chunk choice above).  16 = a quarter of the
+// lanes (FCHUNK 64): for SMALL trainable sets - the unstable rows of a SLAM map, a few thousand - where 1 024-row chunks
+// left 5-10 workgroups on a 256-CU device and the kernel took 112 us for 8 000 rows (r05 sequence trace): spread thin,
+// the same rows occupy sixteen times the waves and a wave's SH sweep is 4 sub-passes instead of 13.
+template <int FCHUNK, int RPW = 64>
 __global__ void __launch_bounds__(256) map_fused_tail_kernel(FusedArgs a) {
   __shared__ uint32_t s_list[FCHUNK];
   __shared__ uint32_t s_n;
@@ -84,17 +88,18 @@ __global__ void __launch_bounds__(256) map_fused_tail_kernel(FusedArgs a) {
     // ---- the live rows of this chunk, compacted (four byte reads per row)
     // all flag bytes of the chunk in flight at once (inside the loop below each row's four loads waited for the
     // previous row's ballot: a round trip to memory per 256 rows)
+    constexpr int PASSES = FCHUNK >= 256 ? FCHUNK / 256 : 1;
     uint32_t flags = 0;
 #pragma unroll
-    for (int k = 0; k < FCHUNK / 256; ++k) {
+    for (int k = 0; k < PASSES; ++k) {
       const int rl = min(c0 + k * 256 + tid, a.rows - 1);
       const uint32_t f = (uint32_t)a.touched[a.t0 + rl] | (uint32_t)a.ever_raw8[rl] | (uint32_t)a.ever_xyz[rl] | (uint32_t)a.ever_shs[rl];
       flags |= (f != 0u ? 1u : 0u) << k;
     }
 #pragma unroll
-    for (int k = 0; k < FCHUNK / 256; ++k) {
+    for (int k = 0; k < PASSES; ++k) {
       const int rl = c0 + k * 256 + tid;                       // row relative to t0
-      const bool work = rl < a.rows && ((flags >> k) & 1u) != 0u;
+      const bool work = rl < a.rows && k * 256 + tid < FCHUNK && ((flags >> k) & 1u) != 0u;
       const unsigned long long m = __builtin_amdgcn_ballot_w64(work);
       if (m == 0ull) continue;
       uint32_t base = 0;
@@ -104,9 +109,9 @@ __global__ void __launch_bounds__(256) map_fused_tail_kernel(FusedArgs a) {
     }
     __syncthreads();
     const int nlive = (int)s_n;
-    for (int q0 = wv * 64; q0 < nlive; q0 += 256) {             // a wave takes 64 list entries per pass
+    for (int q0 = wv * RPW; q0 < nlive; q0 += 4 * RPW) {        // a wave takes RPW list entries per pass
       const int q = q0 + lane;
-      const bool have = q < nlive;
+      const bool have = lane < RPW && q < nlive;
       const int rl = have ? (int)s_list[q] : 0;                 // relative to t0 (Adam state, snapshot, confidence)
       const int r = a.t0 + rl;                                  // absolute (parameters, activated arrays, slots)
       bool rgrad = have && a.touched[r] != 0;
@@ -370,9 +375,11 @@ extern "C" int rtgs_map_fused_tail_hint(const rtgs_raster_settings* settings, co
     const double per_row = (double)listed_hint / (double)(P > 0 ? P : 1);
     chunk = per_row * 2048.0 <= 64.0 ? 2048 : (per_row * 1024.0 <= 64.0 ? 1024 : 512);
   }
+  if (forced == 64 || (forced == 0 && a.rows <= 65536)) chunk = 64;     // a small trainable set: spread thin (RPW 16)
   int blocks = (a.rows + chunk - 1) / chunk;
   if (blocks > 4096) blocks = 4096;
-  if (chunk == 2048) hipLaunchKernelGGL(map_fused_tail_kernel<2048>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (chunk == 64) hipLaunchKernelGGL((map_fused_tail_kernel<64, 16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else if (chunk == 2048) hipLaunchKernelGGL(map_fused_tail_kernel<2048>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   else if (chunk == 512) hipLaunchKernelGGL(map_fused_tail_kernel<512>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(map_fused_tail_kernel<1024>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? RTGS_OK : RTGS_E_HIP;

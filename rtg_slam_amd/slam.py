@@ -55,9 +55,11 @@ class Tracker:
         self.icp_tracker.move_last_status()
         self.pose_es.append(pose)
         frame.updatePose(pose)
-        c2w = frame.get_c2w
-        frame_map["vertex_map_w"] = frame_map["vertex_map_c"] @ c2w[:3, :3].T + c2w[:3, 3]      # transform_map, SLAM/utils.py:56-63
-        frame_map["normal_map_w"] = frame_map["normal_map_c"] @ c2w[:3, :3].T
+        c2w = frame.get_c2w                                                   # transform_map, SLAM/utils.py:56-63; tracker.py:283-288
+        rot = c2w.clone()
+        rot[:3, 3] = 0                                                        # get_rot(c2w)
+        frame_map["vertex_map_w"] = self.so.transform_map(frame_map["vertex_map_c"], c2w)
+        frame_map["normal_map_w"] = self.so.transform_map(frame_map["normal_map_c"], rot)
         # transform_map moves the zero vertices of invalid pixels too; they are never sampled (depth 0 / zero normal masks)
         return ok
 

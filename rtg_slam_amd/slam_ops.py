@@ -191,6 +191,19 @@ def frame_preprocess(depth_map: torch.Tensor, K: torch.Tensor, min_depth: float 
     return dict(depth_map=dout, vertex_map_c=vout, normal_map_c=nout, confidence_map=cout, invalid_confidence_mask=bad.bool())
 
 
+def transform_map(map3: torch.Tensor, transform: torch.Tensor) -> torch.Tensor:
+    """SLAM/utils.py:56-63: every 3-vector of `map3` [..., 3] through the 4x4 `transform` (its rotation only when the
+    caller passes get_rot(c2w), as for normal maps).  One streaming kernel (a `@` would be a K = 3 GEMM)."""
+    lib, dev = _lib.load(), _dev(map3)
+    m = map3.float().contiguous()
+    T = transform.to(device=dev, dtype=torch.float32).contiguous()
+    out = torch.empty_like(m)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_transform_map(_p(m), m.numel() // 3, _p(T), _p(out), _stream(dev))
+    _lib.check(rc, "rtgs_transform_map")
+    return out
+
+
 def sample_candidates(normal_map: torch.Tensor, select_mask: Optional[torch.Tensor] = None):
     """Flat indices (ascending) of the pixels sample_pixels may draw from, and their number (device int32[1])."""
     lib, dev = _lib.load(), _dev(normal_map)

@@ -259,3 +259,19 @@ def test_renderer_wrapper_matches_the_reference_wrapper_logic():
         (g_hip,) = torch.autograd.grad((out["normal"] * w).sum(), gd["normal"], retain_graph=True)
         (g_ref,) = torch.autograd.grad((want * w).sum(), nrm)
         assert float((g_hip - g_ref).abs().max()) <= 1e-5 * float(g_ref.abs().max() + 1e-12)
+
+
+def test_transform_map_is_the_references_transform_map():
+    """SLAM/utils.py:56-63 (restated: homogeneous coordinate, 4x4 product, first three components)."""
+    from rtg_slam_amd import slam_ops as ops
+    g = torch.Generator().manual_seed(3)
+    m = torch.randn(37, 53, 3, generator=g)
+    m[5:9] = 0
+    T = torch.eye(4)
+    T[:3, :3] = synth.look_at_pose(seed=2, max_angle_deg=40, max_trans=0.5)[:3, :3].float()
+    T[:3, 3] = torch.tensor([0.3, -1.2, 2.0])
+    out = ops.transform_map(m.to(DEV), T.to(DEV)).cpu()
+    hom = torch.cat([m, torch.ones(37, 53, 1)], -1)
+    want = torch.matmul(T[None, None].expand(37, 53, -1, -1), hom.unsqueeze(-1)).squeeze(-1)[..., :3]
+    assert out.shape == m.shape and float((out - want).abs().max()) < 1e-6
+    assert torch.equal(out[5:9], T[:3, 3].expand(4, 53, 3))               # zero vertices land on the translation, as there
