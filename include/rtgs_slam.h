@@ -99,6 +99,26 @@ int rtgs_sample_candidates(const float* normal_map, const uint8_t* select_mask, 
                            int32_t* count_out, uint8_t* flags_scratch, void* scratch, void* stream);
 
 /* ---- Renderer.render's normal map (SLAM/render.py:130-133) ----------------------------------------------------- */
+/* ---- per-frame mask / error producers of the mapper ------------------------------------------------------------- */
+/* Mapping.temp_points_init (mapper.py:728-775) in one pass: transmission_mask = T > thr_T & depth > 0; error_mask =
+ * ((|depth - render_depth| > thr_depth & depth > 0 & depth_index > -1) | (mean_c |frame - render colour| > thr_color &
+ * depth > 0 & T < thr_T)) & ~transmission_mask; counts2[0..1] = set pixels of the two (device uint32, zeroed here).  Maps
+ * are [H,W] (colours [3,H,W]) float32 / int32; masks uint8. */
+int rtgs_add_masks(const float* T_map, const float* depth, const float* render_depth, const float* render_color_chw,
+                   const float* frame_color_chw, const int32_t* depth_index, int32_t H, int32_t W, float thr_transmission,
+                   float thr_depth, float thr_color, uint8_t* transmission_mask, uint8_t* error_mask, uint32_t* counts2,
+                   void* stream);
+/* Mapping.error_gaussians_remove (mapper.py:527-540): depth_error = |depth - render_depth|, 0 where the render lies behind the
+ * frame, the frame has no depth or the pixel has no depth owner; color_error = sum_c |frame - render colour|, 0 where the
+ * frame has no depth.  The inputs of rtgs_accumulate_error. */
+int rtgs_frame_errors(const float* depth, const float* render_depth, const float* render_color_chw, const float* frame_color_chw,
+                      const int32_t* depth_index, int32_t H, int32_t W, float* color_error, float* depth_error, void* stream);
+/* Mapping.temp_points_attach (mapper.py:830-883): attach_out[i] = 1 iff point i projects (w2c16 row-major 4x4, pinhole fx fy
+ * cx cy, truncation like Camera.get_uv, scene/cameras.py:161-168) inside the image onto a pixel whose stable colour index
+ * is >= 0 and lies within max_plane_dist of that Gaussian's plane (stable_xyz / stable_normal rows). */
+int rtgs_attach_test(const float* points, int32_t n, const float* w2c16, float fx, float fy, float cx, float cy, int32_t H,
+                     int32_t W, const int32_t* stable_color_index, const float* stable_xyz, const float* stable_normal,
+                     float max_plane_dist, uint8_t* attach_out, void* stream);
 /* transform_map (SLAM/utils.py:56-63; tracker.py:283-288 builds vertex_map_w / normal_map_w with it): out[i] = T[:3,:3] in[i] +
  * T[:3,3] for n 3-vectors; transform16 = device float[16], row-major 4x4 (pass get_rot(c2w) - zero translation - for normals). */
 int rtgs_transform_map(const float* map3, int64_t n, const float* transform16, float* out3, void* stream);

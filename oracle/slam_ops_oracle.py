@@ -100,6 +100,58 @@ def knn_query(ref: torch.Tensor, query: torch.Tensor, self_offset: int = -1, ref
     return best_d, best_i.int()
 
 
+# ------------------------------------------------------------------ per-frame masks / errors of the mapper (mapper.py)
+def add_masks(T_map, depth, render_depth, render_color, frame_color, depth_index, thr_T, thr_d, thr_c):
+    """Mapping.temp_points_init, mapper.py:728-768, line by line on [H,W,C] maps.  Inputs: T_map / render_depth /
+    depth_index [1,H,W], depth [H,W,1], colours [3,H,W].  Returns (transmission mask, error mask) bool [H,W], counts."""
+    T = T_map.permute(1, 2, 0)
+    rd, di = render_depth.permute(1, 2, 0), depth_index.permute(1, 2, 0)
+    rc, fc = render_color.permute(1, 2, 0), frame_color.permute(1, 2, 0)
+    d = depth.reshape(rd.shape)
+    transmission_sample_mask = (T > thr_T) & (d > 0)
+    depth_error = torch.abs(d - rd)
+    color_error = torch.abs(fc - rc).mean(dim=-1, keepdim=True)
+    depth_sample_mask = (depth_error > thr_d) & (d > 0) & (di > -1)
+    color_sample_mask = (color_error > thr_c) & (d > 0) & (T < thr_T)
+    sample_mask = (color_sample_mask | depth_sample_mask) & (~transmission_sample_mask)
+    tm, em = transmission_sample_mask[..., 0], sample_mask[..., 0]
+    return tm, em, torch.stack([tm.sum(), em.sum()]).int()
+
+
+def frame_errors(depth, render_depth, render_color, frame_color, depth_index):
+    """Mapping.error_gaussians_remove, mapper.py:527-540 -> (color_error [H,W], depth_error [H,W])."""
+    rd, di = render_depth.permute(1, 2, 0), depth_index.permute(1, 2, 0)
+    color, cm_color = render_color.permute(1, 2, 0), frame_color.permute(1, 2, 0)
+    d = depth.reshape(rd.shape)
+    depth_error = torch.abs(d - rd)
+    depth_error[(d - rd) < 0] = 0
+    image_error = torch.abs(cm_color - color)
+    color_error = torch.sum(image_error, dim=-1, keepdim=True)
+    invalid_mask = ((d == 0) | (di == -1)).squeeze()
+    depth_error[invalid_mask] = 0
+    color_error[d == 0] = 0
+    return color_error[..., 0], depth_error[..., 0]
+
+
+def attach_test(points, w2c, fx, fy, cx, cy, H, W, stable_color_index, stable_xyz, stable_normal, max_plane_dist):
+    """Mapping.temp_points_attach, mapper.py:838-872 (all new points have opacity > 0.1), as a flag per point."""
+    K = torch.tensor([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=torch.float32)
+    xyz_c = points @ w2c[:3, :3].T + w2c[:3, 3]
+    uv = xyz_c @ K.T
+    uv = (uv[:, :2] / uv[:, 2:]).long()
+    inside = (uv[:, 0] >= 0) & (uv[:, 0] < W) & (uv[:, 1] >= 0) & (uv[:, 1] < H)
+    out = torch.zeros(points.shape[0], dtype=torch.uint8)
+    idx = torch.nonzero(inside).reshape(-1)
+    if idx.numel() == 0 or stable_xyz.shape[0] == 0:
+        return out
+    sidx = stable_color_index.reshape(H, W)[uv[idx, 1], uv[idx, 0]].long()
+    hit = sidx >= 0
+    idx, sidx = idx[hit], sidx[hit]
+    p2p = ((stable_xyz[sidx] - points[idx]) * stable_normal[sidx]).sum(dim=-1)
+    out[idx[p2p.abs() < max_plane_dist]] = 1
+    return out
+
+
 # ------------------------------------------------------------------ (f-1) cuda_utils.accumulate_gaussian_error  [FROZEN]
 def accumulate_gaussian_error(H, W, P, color_err, depth_err, normal_err, color_index, depth_index, thr_c, thr_d, thr_n,
                               mean=True):

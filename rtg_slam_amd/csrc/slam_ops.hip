@@ -325,19 +325,30 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
   float bd[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
   int bj[3] = {-1, -1, -1};
   const int self = (live && self_offset >= 0) ? self_offset + i : -1;
+  int home = 0;
   if (live) {
     p = make_float4(query[(size_t)i * 3], query[(size_t)i * 3 + 1], query[(size_t)i * 3 + 2], 0.f);
     const uint32_t code = q_codes_sorted[slot];
     int lo = 0, hi = N;                                         // lower bound of `code`
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (codes_sorted[mid] < code) lo = mid + 1; else hi = mid; }
-    // seeds: the eight references around that position - each part takes the two it owns
-    for (int j = max(0, lo - 4); j <= min(N - 1, lo + 3); ++j) {
+    // seeds: the sixteen references around that position - each part takes the four it owns, so that every part starts
+    // with a finite third-best distance (with two seeds per part the bound stayed FLT_MAX until a whole box was scanned,
+    // and the first boxes in Morton order - usually far from the query - were opened by everyone)
+    for (int j = max(0, lo - 8); j <= min(N - 1, lo + 7); ++j) {
       if ((j & 3) != part) continue;
       const float4 s = sorted[j];
       if (__float_as_int(s.w) != self && inbox(s)) knn_insert(dist2(p, s), j, bd, bj);
     }
+    home = lo / KNN_BOX;
   }
-  for (int b = 0; b < nboxes; ++b) {
+  // boxes are visited outward from the box the wave's first query falls into: Morton neighbours are near in space, so the
+  // bound tightens before the far boxes are tested
+  const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
+  const int b0 = lv ? min(nboxes - 1, __builtin_amdgcn_readlane(home, __builtin_ctzll(lv))) : 0;
+  for (int step = 0; step < 2 * nboxes; ++step) {
+    const int d = (step + 1) >> 1;
+    const int b = (step & 1) ? b0 - d : b0 + d;                 // b0, b0 - 1, b0 + 1, b0 - 2, ...
+    if (b < 0 || b >= nboxes) continue;
     const float* bx = boxes + b * 6;
     const float ex = fmaxf(0.f, fmaxf(bx[0] - p.x, p.x - bx[3]));
     const float ey = fmaxf(0.f, fmaxf(bx[1] - p.y, p.y - bx[4]));
@@ -851,6 +862,123 @@ int rtgs_sample_candidates(const float* normal_map, const uint8_t* select_mask, 
   return 0;
 }
 
+
+// ---- per-frame mask / error producers of the mapper (one streaming pass each instead of ~25 torch launches) --------------
+// Mapping.temp_points_init, mapper.py:728-775: where does the map not explain the frame?
+//   transmission mask = T > thr_T & depth > 0                                  (:729-731)
+//   error mask        = ((|depth - render depth| > thr_d & depth > 0 & depth index > -1)        (:757-761)
+//                        | (mean_c |colour - render colour| > thr_c & depth > 0 & T < thr_T))   (:762-766)
+//                       & ~transmission mask                                                     (:767-768)
+// counts[0..1] += set pixels of the two masks (the caller sizes its two sample_pixels draws from them).
+__global__ void __launch_bounds__(256) add_masks_kernel(const float* __restrict__ T, const float* __restrict__ depth,
+                                                        const float* __restrict__ rdepth, const float* __restrict__ rcolor,
+                                                        const float* __restrict__ fcolor, const int32_t* __restrict__ didx, int hw,
+                                                        float thr_T, float thr_d, float thr_c, uint8_t* __restrict__ tmask,
+                                                        uint8_t* __restrict__ emask, uint32_t* __restrict__ counts) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool tm = false, em = false;
+  if (i < hw) {
+    const float d = depth[i], t = T[i];
+    const bool ok = d > 0.f;
+    tm = t > thr_T && ok;
+    const float de = fabsf(d - rdepth[i]);
+    // torch: abs(frame - render).mean(dim=-1) over the three channels = ((a + b) + c) / 3
+    const float ce = ((fabsf(fcolor[i] - rcolor[i]) + fabsf(fcolor[hw + i] - rcolor[hw + i])) + fabsf(fcolor[2 * hw + i] - rcolor[2 * hw + i])) / 3.f;
+    const bool dm = de > thr_d && ok && didx[i] > -1;
+    const bool cm = ce > thr_c && ok && t < thr_T;
+    em = (cm || dm) && !tm;
+    tmask[i] = tm ? 1 : 0;
+    emask[i] = em ? 1 : 0;
+  }
+  const unsigned long long bt = __builtin_amdgcn_ballot_w64(tm), be = __builtin_amdgcn_ballot_w64(em);
+  if ((threadIdx.x & 63) == 0) {
+    if (bt) atomicAdd(&counts[0], (uint32_t)__popcll(bt));
+    if (be) atomicAdd(&counts[1], (uint32_t)__popcll(be));
+  }
+}
+int rtgs_add_masks(const float* T_map, const float* depth, const float* render_depth, const float* render_color_chw,
+                   const float* frame_color_chw, const int32_t* depth_index, int32_t H, int32_t W, float thr_transmission,
+                   float thr_depth, float thr_color, uint8_t* transmission_mask, uint8_t* error_mask, uint32_t* counts2,
+                   void* stream) {
+  if (H <= 0 || W <= 0 || !T_map || !depth || !render_depth || !render_color_chw || !frame_color_chw || !depth_index ||
+      !transmission_mask || !error_mask || !counts2)
+    return -1;
+  hipStream_t st = (hipStream_t)stream;
+  SLAM_TRY(hipMemsetAsync(counts2, 0, 2 * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(add_masks_kernel, dim3(grid1(H * W)), dim3(256), 0, st, T_map, depth, render_depth, render_color_chw,
+                     frame_color_chw, depth_index, H * W, thr_transmission, thr_depth, thr_color, transmission_mask, error_mask, counts2);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+// Mapping.error_gaussians_remove, mapper.py:527-540: the error maps that are back-projected onto the Gaussians.
+//   depth error  = |depth - render depth|, 0 where the render is BEHIND the frame (depth - render < 0), where the frame has
+//                  no depth or the pixel has no depth owner
+//   colour error = sum_c |colour - render colour|, 0 where the frame has no depth
+__global__ void __launch_bounds__(256) frame_errors_kernel(const float* __restrict__ depth, const float* __restrict__ rdepth,
+                                                           const float* __restrict__ rcolor, const float* __restrict__ fcolor,
+                                                           const int32_t* __restrict__ didx, int hw, float* __restrict__ color_err,
+                                                           float* __restrict__ depth_err) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const float d = depth[i], diff = d - rdepth[i];
+  const bool invalid = d == 0.f || didx[i] == -1;
+  depth_err[i] = (diff < 0.f || invalid) ? 0.f : fabsf(diff);
+  const float ce = (fabsf(fcolor[i] - rcolor[i]) + fabsf(fcolor[hw + i] - rcolor[hw + i])) + fabsf(fcolor[2 * hw + i] - rcolor[2 * hw + i]);
+  color_err[i] = d == 0.f ? 0.f : ce;
+}
+int rtgs_frame_errors(const float* depth, const float* render_depth, const float* render_color_chw, const float* frame_color_chw,
+                      const int32_t* depth_index, int32_t H, int32_t W, float* color_error, float* depth_error, void* stream) {
+  if (H <= 0 || W <= 0 || !depth || !render_depth || !render_color_chw || !frame_color_chw || !depth_index || !color_error || !depth_error)
+    return -1;
+  hipLaunchKernelGGL(frame_errors_kernel, dim3(grid1(H * W)), dim3(256), 0, (hipStream_t)stream, depth, render_depth,
+                     render_color_chw, frame_color_chw, depth_index, H * W, color_error, depth_error);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+// Mapping.temp_points_attach, mapper.py:830-883: a new point whose projection lands on a pixel owned (colour index) by a stable
+// Gaussian, and which lies within `max_plane_dist` of that Gaussian's plane, is attached: attach[i] = 1.
+//   uv = (K (R p + t))[:2] / z, truncated toward zero like `.long()` (scene/cameras.py:161-168); inside the image;
+//   owner = stable colour index at (v, u) >= 0;  |(x_owner - p) . n_owner| < max_plane_dist.
+__global__ void __launch_bounds__(256) attach_test_kernel(const float* __restrict__ pts, int n, const float* __restrict__ w2c,
+                                                          float fx, float fy, float cx, float cy, int H, int W,
+                                                          const int32_t* __restrict__ cidx, const float* __restrict__ sxyz,
+                                                          const float* __restrict__ snrm, float max_dist, uint8_t* __restrict__ attach) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  float c[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) c[r] = ((x * w2c[4 * r] + y * w2c[4 * r + 1]) + z * w2c[4 * r + 2]) + w2c[4 * r + 3];
+  // uv = xyz_c @ K.T: u = fx x + 0 y + cx z (torch sums the three products in order), then / z, then truncation
+  const float un = (c[0] * fx + c[1] * 0.f) + c[2] * cx, vn = (c[0] * 0.f + c[1] * fy) + c[2] * cy;
+  const float uf = un / c[2], vf = vn / c[2];
+  uint8_t a = 0;
+  if (uf == uf && vf == vf && fabsf(uf) < 1e9f && fabsf(vf) < 1e9f) {
+    const long long u = (long long)uf, v = (long long)vf;
+    if (u >= 0 && u < W && v >= 0 && v < H) {
+      const int o = cidx[(size_t)v * W + u];
+      if (o >= 0) {
+        const float d = ((sxyz[3 * (size_t)o] - x) * snrm[3 * (size_t)o] + (sxyz[3 * (size_t)o + 1] - y) * snrm[3 * (size_t)o + 1]) +
+                        (sxyz[3 * (size_t)o + 2] - z) * snrm[3 * (size_t)o + 2];
+        a = fabsf(d) < max_dist ? 1 : 0;
+      }
+    }
+  }
+  attach[i] = a;
+}
+int rtgs_attach_test(const float* points, int32_t n, const float* w2c16, float fx, float fy, float cx, float cy, int32_t H,
+                     int32_t W, const int32_t* stable_color_index, const float* stable_xyz, const float* stable_normal,
+                     float max_plane_dist, uint8_t* attach_out, void* stream) {
+  if (n < 0 || H <= 0 || W <= 0) return -1;
+  if (n == 0) return 0;
+  if (!points || !w2c16 || !stable_color_index || !stable_xyz || !stable_normal || !attach_out) return -1;
+  hipLaunchKernelGGL(attach_test_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, points, n, w2c16, fx, fy, cx, cy, H,
+                     W, stable_color_index, stable_xyz, stable_normal, max_plane_dist, attach_out);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
 
 // transform_map (SLAM/utils.py:56-63): every 3-vector of a map through a 4x4 transform (homogeneous 1 appended; for normals
 // the caller passes get_rot(c2w), whose translation column is zero).  The reference does it as a batched 4x4 matmul per

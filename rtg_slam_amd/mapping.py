@@ -179,6 +179,15 @@ class HipOps:
     def accumulate_gaussian_error(self, *a):
         return self.so.accumulate_gaussian_error(*a)
 
+    def add_masks(self, *a):
+        return self.so.add_masks(*a)
+
+    def frame_errors(self, *a):
+        return self.so.frame_errors(*a)
+
+    def attach_test(self, *a):
+        return self.so.attach_test(*a)
+
     def history_merge(self, opt, confidence, max_weight):
         opt.history_merge(confidence, max_weight)
 
@@ -227,6 +236,7 @@ class Mapping:
         self.frame_map: Dict[str, torch.Tensor] = {}
         self.model_map: Dict[str, torch.Tensor] = {}
         self._render_cache = None
+        self._zero_map = None
         self.xyz_factor = torch.tensor(args.xyz_factor, dtype=torch.float32, device=device)
         self.rng = random.Random(int(getattr(args, "seed", 0)))
         self.stats = dict(added=0, fixed=0, deleted_unstable=0, deleted_stable=0, released=0, local_opts=0, global_opts=0,
@@ -360,16 +370,12 @@ class Mapping:
             mask = fm["depth_map"] > 0
             return self._new_points([self.ops.sample_pixels(fm["vertex_map_w"], fm["normal_map_w"], fm["color_map"],
                                                             a.uniform_sample_num, mask)])
-        self.get_render_output(frame)
-        mm = self.model_map
-        depth_ok = fm["depth_map"] > 0
-        tmask = (mm["render_transmission"] > a.add_transmission_thres) & depth_ok
-        depth_error = torch.abs(fm["depth_map"] - mm["render_depth"])
-        color_error = torch.abs(fm["color_map"] - mm["render_color"]).mean(dim=-1, keepdim=True)
-        dmask = (depth_error > a.add_depth_thres) & depth_ok & (mm["render_depth_index"] > -1)
-        cmask = (color_error > a.add_color_thres) & depth_ok & (mm["render_transmission"] < a.add_transmission_thres)
-        emask = (cmask | dmask) & (~tmask)
-        n_t, n_e = torch.stack([tmask.sum(), emask.sum()]).tolist()          # ONE synchronisation for both counts
+        out = self._render(frame, "all")                                    # get_render_output (:727): the model at the new pose
+        # transmission mask / error mask of :728-768 and their sizes in ONE pass over the frame (rtgs_add_masks)
+        tmask, emask, counts = self.ops.add_masks(out["T_map"], fm["depth_map"], out["depth"], out["render"], fm["color_chw"],
+                                                  out["depth_index_map"], a.add_transmission_thres, a.add_depth_thres,
+                                                  a.add_color_thres)
+        n_t, n_e = counts.tolist()                                          # ONE synchronisation for both counts
         # float32 arithmetic and truncation as devI(...) of mapper.py:737-741, 772
         ratio = np.float32(n_t) / np.float32(self.get_pixel_num)
         n_trans = int(np.float32(a.transmission_sample_ratio) * ratio * np.float32(a.uniform_sample_num))
@@ -400,17 +406,11 @@ class Mapping:
         if self.get_stable_num == 0:
             return
         xyz = temp["xyz"]
-        uv = frame.get_uv(xyz)
-        inside = (uv[:, 0] >= 0) & (uv[:, 0] < frame.image_width) & (uv[:, 1] >= 0) & (uv[:, 1] < frame.image_height)
         out = self._render(frame, "stable")
-        sidx = out["color_index_map"][0]
-        u, v = uv[:, 0].clamp(0, frame.image_width - 1), uv[:, 1].clamp(0, frame.image_height - 1)
-        hit = sidx[v, u].long()
-        valid = inside & (hit >= 0)
         sp = self.opt.gaussian_data("stable")
-        h = hit.clamp_min(0)
-        p2p = ((sp["xyz"][h] - xyz) * sp["normal"][h]).sum(dim=-1)
-        attach = valid & (p2p.abs() < 0.5 * self.args.add_depth_thres)
+        attach = self.ops.attach_test(xyz, frame.get_w2c(), frame.fx, frame.fy, frame.cx, frame.cy, frame.image_height,
+                                      frame.image_width, out["color_index_map"], sp["xyz"], sp["normal"],
+                                      0.5 * self.args.add_depth_thres).bool()
         low = torch.full_like(temp["opacity_raw"], inverse_sigmoid(unstable_opacity_low))
         temp["opacity_raw"] = torch.where(attach[:, None], low, temp["opacity_raw"])
 
@@ -598,19 +598,14 @@ class Mapping:
         o, a = self.opt, self.args
         frame, cm = self.processed_frames[-1], self.processed_map[-1]
         out = self._render(frame, "all")
-        color, depth = out["render"].permute(1, 2, 0), out["depth"].permute(1, 2, 0)
-        depth_index, color_index = out["depth_index_map"].permute(1, 2, 0), out["color_index_map"].permute(1, 2, 0)
-        diff = cm["depth_map"] - depth
-        depth_error = torch.where(diff < 0, torch.zeros_like(diff), diff.abs())
-        color_error = torch.abs(cm["color_map"] - color).sum(dim=-1, keepdim=True)
-        invalid = (cm["depth_map"] == 0) | (depth_index == -1)
-        depth_error = torch.where(invalid, torch.zeros_like(depth_error), depth_error)
-        color_error = torch.where(cm["depth_map"] == 0, torch.zeros_like(color_error), color_error)
-        normal_error = torch.zeros_like(depth_error)
+        color_error, depth_error = self.ops.frame_errors(cm["depth_map"], out["depth"], out["render"], cm["color_chw"],
+                                                         out["depth_index_map"])
         H, W = cm["color_map"].shape[:2]
+        if self._zero_map is None or self._zero_map.shape != depth_error.shape:
+            self._zero_map = torch.zeros_like(depth_error)              # normal_error: zeros (:531), allocated once
         g_color, g_depth, _, _ = self.ops.accumulate_gaussian_error(
-            H, W, o.N, color_error, depth_error, normal_error, color_index, depth_index, a.add_color_thres,
-            a.add_depth_thres, a.add_normal_thres, True)
+            H, W, o.N, color_error, depth_error, self._zero_map, out["color_index_map"], out["depth_index_map"],
+            a.add_color_thres, a.add_depth_thres, a.add_normal_thres, True)
         nf = o.n_frozen                                                  # stable rows come FIRST here ([unstable, stable] there)
         dcnt, ccnt = o.aux["depth_error_counter"], o.aux["color_error_counter"]
         dcnt[:nf, 0] += (g_depth[:nf] > 2 * a.add_depth_thres).to(dcnt.dtype)

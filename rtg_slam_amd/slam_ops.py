@@ -191,6 +191,55 @@ def frame_preprocess(depth_map: torch.Tensor, K: torch.Tensor, min_depth: float 
     return dict(depth_map=dout, vertex_map_c=vout, normal_map_c=nout, confidence_map=cout, invalid_confidence_mask=bad.bool())
 
 
+def add_masks(T_map, depth, render_depth, render_color, frame_color, depth_index, thr_transmission, thr_depth, thr_color):
+    """Mapping.temp_points_init's two sampling masks (mapper.py:728-775) in one pass ->
+    (transmission_mask uint8 [H,W], error_mask uint8 [H,W], counts int32[2] on the device).  Maps: any layout with H*W
+    elements per plane; colours [3,H,W]."""
+    lib, dev = _lib.load(), _dev(T_map)
+    H, W = int(render_color.shape[-2]), int(render_color.shape[-1])
+    f = lambda t: t.float().contiguous()
+    tm = torch.empty(H, W, dtype=torch.uint8, device=dev)
+    em = torch.empty(H, W, dtype=torch.uint8, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    T, d, rd, rc, fc, di = f(T_map), f(depth), f(render_depth), f(render_color), f(frame_color), depth_index.to(torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        rc_ = lib.rtgs_add_masks(_p(T), _p(d), _p(rd), _p(rc), _p(fc), _p(di), H, W, float(thr_transmission), float(thr_depth),
+                                 float(thr_color), _p(tm), _p(em), _p(counts), _stream(dev))
+    _lib.check(rc_, "rtgs_add_masks")
+    return tm, em, counts
+
+
+def frame_errors(depth, render_depth, render_color, frame_color, depth_index):
+    """The error maps of Mapping.error_gaussians_remove (mapper.py:527-540) -> (color_error [H,W], depth_error [H,W])."""
+    lib, dev = _lib.load(), _dev(depth)
+    H, W = int(render_color.shape[-2]), int(render_color.shape[-1])
+    f = lambda t: t.float().contiguous()
+    ce = torch.empty(H, W, dtype=torch.float32, device=dev)
+    de = torch.empty(H, W, dtype=torch.float32, device=dev)
+    d, rd, rc, fc, di = f(depth), f(render_depth), f(render_color), f(frame_color), depth_index.to(torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        rc_ = lib.rtgs_frame_errors(_p(d), _p(rd), _p(rc), _p(fc), _p(di), H, W, _p(ce), _p(de), _stream(dev))
+    _lib.check(rc_, "rtgs_frame_errors")
+    return ce, de
+
+
+def attach_test(points, w2c, fx, fy, cx, cy, H, W, stable_color_index, stable_xyz, stable_normal, max_plane_dist):
+    """Mapping.temp_points_attach's test (mapper.py:830-883) -> uint8 [n]: 1 where the point projects onto a pixel owned by a
+    stable Gaussian and lies within `max_plane_dist` of its plane."""
+    lib, dev = _lib.load(), _dev(points)
+    pts = points.float().contiguous()
+    n = int(pts.shape[0])
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    T = w2c.to(device=dev, dtype=torch.float32).contiguous()
+    ci = stable_color_index.to(torch.int32).contiguous()
+    sx, sn = stable_xyz.float().contiguous(), stable_normal.float().contiguous()
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_attach_test(_p(pts), n, _p(T), float(fx), float(fy), float(cx), float(cy), int(H), int(W), _p(ci), _p(sx), _p(sn),
+                                  float(max_plane_dist), _p(out), _stream(dev))
+    _lib.check(rc, "rtgs_attach_test")
+    return out
+
+
 def transform_map(map3: torch.Tensor, transform: torch.Tensor) -> torch.Tensor:
     """SLAM/utils.py:56-63: every 3-vector of `map3` [..., 3] through the 4x4 `transform` (its rotation only when the
     caller passes get_rot(c2w), as for normal maps).  One streaming kernel (a `@` would be a K = 3 GEMM)."""

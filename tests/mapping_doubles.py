@@ -63,6 +63,16 @@ class TorchOps:
     def accumulate_gaussian_error(self, *a):
         return so.accumulate_gaussian_error(*a)
 
+    def add_masks(self, *a):
+        tm, em, c = so.add_masks(*a)
+        return tm.to(torch.uint8), em.to(torch.uint8), c
+
+    def frame_errors(self, *a):
+        return so.frame_errors(*a)
+
+    def attach_test(self, *a):
+        return so.attach_test(*a)
+
     def history_merge(self, opt, confidence, max_weight):
         N, t0 = opt._active()
         ai, h, st = opt.attach_init, opt._history, opt.state

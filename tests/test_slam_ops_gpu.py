@@ -275,3 +275,51 @@ def test_transform_map_is_the_references_transform_map():
     want = torch.matmul(T[None, None].expand(37, 53, -1, -1), hom.unsqueeze(-1)).squeeze(-1)[..., :3]
     assert out.shape == m.shape and float((out - want).abs().max()) < 1e-6
     assert torch.equal(out[5:9], T[:3, 3].expand(4, 53, 3))               # zero vertices land on the translation, as there
+
+
+def _frame_and_render(seed=5, H=96, W=144):
+    g = torch.Generator().manual_seed(seed)
+    T = torch.rand(1, H, W, generator=g)
+    T[0, :10] = 1.0
+    depth = 1.0 + 3.0 * torch.rand(H, W, 1, generator=g)
+    depth[20:30] = 0.0
+    rdepth = depth.permute(2, 0, 1) + 0.15 * torch.randn(1, H, W, generator=g)
+    rdepth[0, 40:50] = 0.0
+    didx = torch.randint(-1, 50, (1, H, W), generator=g, dtype=torch.int32)
+    fcol, rcol = torch.rand(3, H, W, generator=g), torch.rand(3, H, W, generator=g)
+    rcol[:, 60:] = fcol[:, 60:] + 0.01
+    return T, depth, rdepth, rcol, fcol, didx
+
+
+def test_add_masks_and_frame_errors_vs_the_mapper_lines():
+    """rtgs_add_masks / rtgs_frame_errors against mapper.py:728-768 / :527-540 restated line by line in torch."""
+    from rtg_slam_amd import slam_ops as ops
+    T, depth, rdepth, rcol, fcol, didx = _frame_and_render()
+    D = lambda t: t.to(DEV)
+    tm, em, cnt = ops.add_masks(D(T), D(depth), D(rdepth), D(rcol), D(fcol), D(didx), 0.5, 0.1, 0.1)
+    tm_o, em_o, cnt_o = so.add_masks(T, depth, rdepth, rcol, fcol, didx, 0.5, 0.1, 0.1)
+    assert torch.equal(tm.cpu().bool(), tm_o) and torch.equal(em.cpu().bool(), em_o)
+    assert cnt.cpu().tolist() == cnt_o.tolist() and 0 < cnt_o[0] and 0 < cnt_o[1]
+    ce, de = ops.frame_errors(D(depth), D(rdepth), D(rcol), D(fcol), D(didx))
+    ce_o, de_o = so.frame_errors(depth, rdepth, rcol, fcol, didx)
+    assert torch.equal(de.cpu(), de_o) and float((ce.cpu() - ce_o).abs().max()) < 1e-6
+    assert float(de_o[20:30].abs().max()) == 0 and float(ce_o[20:30].abs().max()) == 0
+
+
+def test_attach_test_vs_the_mapper_lines():
+    from rtg_slam_amd import slam_ops as ops
+    g = torch.Generator().manual_seed(8)
+    H, W, fx, fy, cx, cy = 60, 80, 70.0, 70.0, 39.5, 29.5
+    c2w = synth.look_at_pose(seed=4, max_angle_deg=10, max_trans=0.2)
+    w2c = torch.linalg.inv(c2w).float()
+    pts_c = torch.stack([(torch.rand(3000, generator=g) - 0.5) * 3, (torch.rand(3000, generator=g) - 0.5) * 2.4,
+                         0.5 + 3 * torch.rand(3000, generator=g)], -1)
+    pts = pts_c @ c2w[:3, :3].float().T + c2w[:3, 3].float()            # many inside the view, some outside
+    S = 200
+    sxyz = pts[:S] + 0.02 * torch.randn(S, 3, generator=g)
+    snrm = torch.nn.functional.normalize(torch.randn(S, 3, generator=g), dim=-1)
+    cidx = torch.randint(-1, S, (1, H, W), generator=g, dtype=torch.int32)
+    out = ops.attach_test(pts.to(DEV), w2c.to(DEV), fx, fy, cx, cy, H, W, cidx.to(DEV), sxyz.to(DEV), snrm.to(DEV), 0.05).cpu()
+    want = so.attach_test(pts, w2c, fx, fy, cx, cy, H, W, cidx, sxyz, snrm, 0.05)
+    diff = int((out != want).sum())
+    assert 0 < int(want.sum()) < 3000 and diff <= 3, diff                # the projection is float32 either way: a pixel-border tie may flip

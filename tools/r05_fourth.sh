@@ -1,0 +1,20 @@
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r05d
+mkdir -p $O
+cd $R
+timeout 600 python -m pytest tests/test_slam_ops_gpu.py tests/test_trainable_gpu.py tests/test_sequence_gpu.py -m gpu -q 2>&1 | tail -30 > $O/t1.txt
+timeout 600 python -m pytest tests/test_raster_gpu.py -m gpu -q -k "slam or tail or step" 2>&1 | tail -15 > $O/t2.txt
+timeout 300 python bench.py --only sequence --sequence-frames 400 > $O/seq400.json 2> $O/seq400.err
+RTGS_MAP_PROFILE=1 timeout 300 python bench.py --only sequence --sequence-frames 150 > $O/seq150_prof.json 2> $O/seq150_prof.err
+cd /tmp && export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_seq -o k -- python $R/bench.py --only sequence --sequence-frames 150 > $O/ks_seq.log 2>&1
+cd $R
+python tools/kernel_table.py $O/ks_seq 60 > $O/table_seq.txt 2>&1
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
+tail -6 $O/t1.txt; tail -4 $O/t2.txt; python -c "
+import json
+d=json.load(open('$O/seq150_prof.json'))['sequence']; print(d['fps'], d['stage_profile_ms_per_frame'])
+d=json.load(open('$O/seq400.json'))['sequence']; print({k:d[k] for k in ('fps','fps_tracking_plus_mapping','ate_rmse_m','gaussians','mapping_ms_mean_optimised_frames','mapping_ms_mean_other_frames','tracking_ms_mean')})
+"
+head -50 $O/table_seq.txt
