@@ -908,9 +908,12 @@ def config5_block(dev, rank, world, barrier, N=5_000_000, iters=10):
         opt.step(loss_fn)
     barrier()
     opt.phase_marks = []
+    host = []
     t0 = time.perf_counter()
     for _ in range(iters):
+        th = time.perf_counter()
         opt.step(loss_fn)
+        host.append(1e3 * (time.perf_counter() - th))
     barrier()
     dt = time.perf_counter() - t0
     marks, opt.phase_marks = opt.phase_marks, None
@@ -937,10 +940,36 @@ def config5_block(dev, rank, world, barrier, N=5_000_000, iters=10):
     out = {"gaussians": N, "n_gpus": world, "mode": "sharded", "iterations": iters, "ms_per_iteration": round(1e3 * dt / iters, 3),
            "split_ms": {"render_fwd_and_loss": round(acc["render_fwd_and_loss"] / iters, 3), "render_bwd": round(acc["render_bwd"] / iters, 3),
                         "collective": round(max(0.0, acc["tail_total"] - acc["adam"]) / iters, 3), "adam": round(acc["adam"] / iters, 3)},
+           "host_enqueue_ms_per_iteration": [round(x, 3) for x in host],
+           "device_memory_reserved_MB": round(torch.cuda.memory_reserved(dev) / 2 ** 20, 1),
            "dense_gradient_MB_per_rank": round(opt.n_train * 59 * 4 / 1e6, 1),
            "what": "BASELINE configs[4] (SURVEY.md 8d): 5 M Gaussians, 1200x680, unstable set sharded world-way, dense gradient "
                    "reduce-scatter + sharded Adam + all-gather; rank 0's HIP-event split (collective = tail minus Adam, 0 on one GPU)"}
+    # The same 5 M map through the SPARSE form (what a SLAM run uses: only the gradient rows that exist travel - a few MB instead
+    # of the 1.18 GB dense reduce-scatter + all-gather; replicated Adam state; one C call per iteration)
+    packed = opt.params
     del opt
+    torch.cuda.empty_cache()
+    opt2 = mo.ShardedMapOptimizer(packed, lr_col=mo.default_lr_columns() * 1e-4)
+    del packed
+    opt2.begin_local_optimization()
+    for _ in range(5):
+        opt2.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
+    opt2.flush()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(iters):
+        opt2.step_slam(rs, gt_c, gt_d, None, render_mask=rm)
+    opt2.flush()
+    barrier()
+    ds = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([ds], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ds = float(t.item())
+    out["sparse_form_ms_per_iteration"] = round(1e3 * ds / iters, 3)
+    out["sparse_form_rows_exchanged_capacity"] = int(opt2._row_capacity) if world > 1 else 0
+    del opt2
     torch.cuda.empty_cache()
     return out
 

@@ -59,3 +59,44 @@ def hip_run(s, g, tile_mask=None, grads=None, dev="cuda:0"):
 
 def frac_bad(a, b, atol):
     return float(((a - b).abs() > atol).float().mean())
+
+
+def explain_outliers(out_h, out_o, T_thr=1e-4, tol=1e-4, limit=24):
+    """For every pixel whose colour / depth / weights / T differ by more than `tol` between the HIP maps and the oracle's:
+    WHICH discontinuous decision of the blend flipped (SURVEY.md Appendix B "per-pixel forward").  Read off the seven
+    output maps alone:
+      depth gate         depth_index differs (the first opaque contributor passed |cos|, z_hit > 0 or |z_hit - z| < thr on one
+                         side only, or a different contributor crossed opaque_threshold first)
+      T-threshold stop   final T differs and the smaller one sits within a factor 4 of T_threshold: one side blended a last
+                         contributor the other stopped before (T' < T_threshold)
+      1/255 skip         final T differs elsewhere: an entry with alpha ~ 1/255 (or power ~ 0) was blended by one side only
+      arg-max tie        only color_index / color_weight differ: two contributors with (almost) equal alpha T
+      rounding           none of the above: accumulated float error over a long list
+    Returns {kind: count}; prints one line per pixel (at most `limit`)."""
+    H, W = out_o[0].shape[-2:]
+    over = torch.zeros(H, W, dtype=torch.bool)
+    for k in (0, 1, 4, 5, 6):
+        over |= ((out_h[k].float().cpu() - out_o[k].float().cpu()).abs() > tol).reshape(-1, H, W).any(0)
+    kinds = {}
+    ys, xs = torch.nonzero(over, as_tuple=True)
+    for n, (y, x) in enumerate(zip(ys.tolist(), xs.tolist())):
+        Th, To = float(out_h[6][0, y, x]), float(out_o[6][0, y, x])
+        dih, dio = int(out_h[3][0, y, x]), int(out_o[3][0, y, x])
+        cih, cio = int(out_h[2][0, y, x]), int(out_o[2][0, y, x])
+        dc = float((out_h[0][:, y, x].cpu() - out_o[0][:, y, x].cpu()).abs().max())
+        dd = abs(float(out_h[1][0, y, x]) - float(out_o[1][0, y, x]))
+        if dih != dio:
+            kind = "depth gate"
+        elif abs(Th - To) > 1e-6 * max(1.0, To) and min(Th, To) < 4 * T_thr:
+            kind = "T-threshold stop"
+        elif abs(Th - To) > 1e-6 * max(1.0, To):
+            kind = "1/255 skip"
+        elif cih != cio:
+            kind = "arg-max tie"
+        else:
+            kind = "rounding"
+        kinds[kind] = kinds.get(kind, 0) + 1
+        if n < limit:
+            print(f"  outlier pixel ({y},{x}): {kind}; T hip {Th:.3e} oracle {To:.3e}; |d colour| {dc:.2e} |d depth| {dd:.2e}; "
+                  f"depth owner {dih} / {dio}; colour arg-max {cih} / {cio}")
+    return kinds

@@ -57,8 +57,15 @@ def _big_case(name):
     return _cache[name]
 
 
-def _check_maps(out_h, out_o, max_bad=2e-3, tag="maps"):
+def _check_maps(out_h, out_o, max_bad=None, tag="maps"):
+    """Bounds derived from what round 4 recorded (profiles/r04_parity_margins.json: at most 2.0e-6 of the pixels of any map
+    over 1e-4, on one scene; 0 elsewhere): a map may hold max(4 pixels, 1e-5 of its pixels) over 1e-4 - north_star's 1e-4 is a
+    max-norm bound that discontinuous decisions (T-threshold stop, 1/255 skip, depth gates) break on isolated pixels; every
+    such pixel is printed with the decision that flipped (ru.explain_outliers) and counted in the margins file."""
     names = ["color", "depth", "color_index", "depth_index", "color_weight", "depth_weight", "T"]
+    npix = out_o[0].shape[-1] * out_o[0].shape[-2]
+    if max_bad is None:
+        max_bad = max(4.0 / npix, 1e-5)
     seen = {}
     for k in (0, 1, 4, 5, 6):
         bad = ru.frac_bad(out_h[k], out_o[k], 1e-4)
@@ -70,6 +77,8 @@ def _check_maps(out_h, out_o, max_bad=2e-3, tag="maps"):
                           "max_abs_err_of_pixels_inside_tol": float(err[inside].max()) if inside.any() else 0.0}
     for k in (2, 3):
         seen[names[k]] = {"frac_different": float((out_h[k] != out_o[k]).float().mean())}
+    if any(seen[names[k]]["frac_over_1e-4"] > 0 for k in (0, 1, 4, 5, 6)):
+        seen["flipped_decisions"] = ru.explain_outliers([t.cpu() for t in out_h], [t.cpu() for t in out_o])
     margins.record(tag, **seen)
     for k in (0, 1, 4, 5, 6):
         assert seen[names[k]]["frac_over_1e-4"] <= max_bad, (names[k], seen[names[k]])
@@ -90,7 +99,7 @@ def _check_grads(gd_h, gd_o, tag="grads"):
         untouched = ~touched
         leak = float(gd_h[k].reshape(ref.shape[0], -1)[untouched].abs().max() if untouched.any() else 0.0) / scale
         n_over = float((row_err > 1e-3).float().sum())
-        allowed = max(2.0, 2e-3 * float(touched.sum()))
+        allowed = 2.0          # observed in every recorded run: 0 rows (r04 margins); a flipped pixel may move a row or two
         srt = torch.sort(row_err, descending=True).values
         seen[k] = {"max_rel_err": float(row_err.max()), "rows_over_1e-3": n_over, "rows_allowed": allowed,
                    "touched_rows": float(touched.sum()),
