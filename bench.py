@@ -904,7 +904,7 @@ def config5_block(dev, rank, world, barrier, N=5_000_000, iters=10):
         out = rast(means3D=gd["xyz"], opacities=gd["opacity"], shs=gd["shs"], colors_precomp=None, scales=gd["scales"],
                    rotations=gd["rotations"], cov3D_precomp=None, normal_w=gd["normal"], tile_mask=None, grad_rows=gd.get("grad_rows"))
         return mo.slam_losses_hip(out, gt_c, gt_d, render_mask=rm)
-    for _ in range(3):
+    for _ in range(15):             # the map took seconds of HOST time to generate: the device idled its clocks down meanwhile
         opt.step(loss_fn)
     barrier()
     opt.phase_marks = []

@@ -67,9 +67,11 @@ def explain_outliers(out_h, out_o, T_thr=1e-4, tol=1e-4, limit=24):
     output maps alone:
       depth gate         depth_index differs (the first opaque contributor passed |cos|, z_hit > 0 or |z_hit - z| < thr on one
                          side only, or a different contributor crossed opaque_threshold first)
-      T-threshold stop   final T differs and the smaller one sits within a factor 4 of T_threshold: one side blended a last
+      1/255 skip         the two final T differ by the factor (1 - alpha) of ONE entry with alpha ~ 1/255 (ratio in
+                         [0.990, 0.9985]): that entry was blended by one side only; the colour moves by alpha T c at its depth
+      T-threshold stop   final T differ otherwise and the smaller one is below 4 T_threshold: one side blended a last
                          contributor the other stopped before (T' < T_threshold)
-      1/255 skip         final T differs elsewhere: an entry with alpha ~ 1/255 (or power ~ 0) was blended by one side only
+      other flip         final T differ otherwise (power ~ 0 skip, clamp)
       arg-max tie        only color_index / color_weight differ: two contributors with (almost) equal alpha T
       rounding           none of the above: accumulated float error over a long list
     Returns {kind: count}; prints one line per pixel (at most `limit`)."""
@@ -85,12 +87,15 @@ def explain_outliers(out_h, out_o, T_thr=1e-4, tol=1e-4, limit=24):
         cih, cio = int(out_h[2][0, y, x]), int(out_o[2][0, y, x])
         dc = float((out_h[0][:, y, x].cpu() - out_o[0][:, y, x].cpu()).abs().max())
         dd = abs(float(out_h[1][0, y, x]) - float(out_o[1][0, y, x]))
+        ratio = min(Th, To) / max(Th, To, 1e-30)
         if dih != dio:
             kind = "depth gate"
-        elif abs(Th - To) > 1e-6 * max(1.0, To) and min(Th, To) < 4 * T_thr:
-            kind = "T-threshold stop"
-        elif abs(Th - To) > 1e-6 * max(1.0, To):
+        elif 0.990 <= ratio <= 0.9985:
             kind = "1/255 skip"
+        elif ratio < 0.999 and min(Th, To) < 4 * T_thr:
+            kind = "T-threshold stop"
+        elif ratio < 0.999:
+            kind = "other flip"
         elif cih != cio:
             kind = "arg-max tie"
         else:
