@@ -465,23 +465,27 @@ def main():
                 vj = json.load(open(vpath))
                 if vj.get("_source_sha16") == src and dom_pmc in vj:
                     insts = float(vj[dom_pmc]["SQ_INSTS_VALU"])
-                    # a wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.08
-                    # quad-cycle-normalised on every kernel profiled): peak = 1024 SIMDs x 2.4 GHz / 4
-                    peak = 1024 * 2.4e9 / 4
+                    # MEASURED issue peak (tools/probe/valu_rate.hip, profiles/r05_valu_rate.txt): 0.99 G wave64 VALU
+                    # instructions / s / SIMD for an FMA stream at 8 waves per SIMD (0.92 at this kernel's 5), by wall clock -
+                    # one per ~1.4 shader cycles, not the 4 round 4 assumed nor the 2 the guide implies; DPP instructions
+                    # issue at 0.58, v_exp_f32 at 0.29 of that unit
+                    peak = 1024 * 0.99e9
                     valu = {"wave_insts_per_launch": int(insts), "achieved_Ginst_s": round(insts / (dom_ms * 1e-3) / 1e9, 1),
                             "peak_Ginst_s": round(peak / 1e9, 1), "frac": round(insts / (dom_ms * 1e-3) / peak, 4),
-                            "valu_active_frac_of_busy_pmc": vj[dom_pmc].get("valu_active_frac"),
+                            "peak_source": "measured: tools/probe/valu_rate.hip (FMA stream, 8 waves/SIMD, wall clock)",
+                            "valu_per_busy_simd_cycle_pmc": vj[dom_pmc].get("valu_per_busy_simd_cycle"),
                             "source": "profiles/valu_latest.json (rocprofv3 --pmc SQ_INSTS_VALU ..., own pass), duration live"}
             except Exception:
                 valu = None
         hbm_frac = achieved / HBM_PEAK_GBS
-        roofline = {"kernel": dom, "bound": "valu" if (valu and valu["frac"] > hbm_frac) else "hbm",
+        roofline = {"kernel": dom, "bound": "latency" if valu else "hbm",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic,
                     "avg_launch_ms": round(dom_ms, 4), "alg_bytes_per_launch": int(alg[dom]), "valu": valu,
                     "note": "achieved / peak / frac are the HBM roofline north_star asks for (algorithmic bytes over the live "
-                            "launch time); `bound` names what the SQ counters say limits the kernel - VALU issue when the "
-                            "`valu` block is present and its fraction exceeds the HBM one.  traffic / valu are null when "
+                            "launch time).  `bound`: the tile walks reach neither roofline - ~5 % of HBM and (`valu` block) ~40 % of "
+                            "the MEASURED VALU issue peak: they wait on dependent DPP scans and LDS (DESIGN.md 6), so "
+                            "'latency'.  traffic / valu are null when "
                             "profiles/*_latest.json were not measured on the current kernel sources or the workload is not "
                             "the default one", "source_sha16": src}
 

@@ -19,9 +19,11 @@ def main():
             if "SQ_INSTS_VALU" not in c:
                 continue
             e = {"SQ_INSTS_VALU": int(c["SQ_INSTS_VALU"]), "table": os.path.basename(path)}
-            if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
-                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, SQ_BUSY_CYCLES cycles summed over 32 SEs
-                e["valu_active_frac"] = round((c["SQ_ACTIVE_INST_VALU"] * 4 / 1024) / (c["SQ_BUSY_CYCLES"] / 32), 3)
+            if "SQ_BUSY_CYCLES" in c:
+                # instructions per busy SIMD-cycle (SQ_BUSY_CYCLES is summed over the 32 SEs); the issue-rate probe's floor is
+                # ~0.72 (one per 1.4 cycles).  Round 4's "valu_active_frac" multiplied the instruction count by a nominal 4
+                # cycles - a definition, dropped.
+                e["valu_per_busy_simd_cycle"] = round((c["SQ_INSTS_VALU"] / 1024) / (c["SQ_BUSY_CYCLES"] / 32), 4)
             out[k] = e
     out["_source_sha16"] = source_hash()
     json.dump(out, open(sys.argv[-1], "w"), indent=1)
