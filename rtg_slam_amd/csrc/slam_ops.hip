@@ -148,6 +148,9 @@ __global__ void __launch_bounds__(256) knn_bbox_kernel(const float* __restrict__
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256)
 #pragma unroll
     for (int c = 0; c < 3; ++c) { const uint32_t e = enc_f(pts[(size_t)i * 3 + c]); mn[c] = min(mn[c], e); mx[c] = max(mx[c], e); }
+  // one set of six global atomics per WORKGROUP (per wave, on a grid of 1024 workgroups, the 24 576 atomics on six words
+  // took 48 us - the longest step of the structure's build)
+  __shared__ uint32_t s_mn[4][3], s_mx[4][3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
 #pragma unroll
@@ -155,7 +158,13 @@ __global__ void __launch_bounds__(256) knn_bbox_kernel(const float* __restrict__
       mn[c] = min(mn[c], (uint32_t)__shfl_xor((int)mn[c], off));
       mx[c] = max(mx[c], (uint32_t)__shfl_xor((int)mx[c], off));
     }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&bbox[c], mn[c]); atomicMax(&bbox[3 + c], mx[c]); }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6][c] = mn[c]; s_mx[threadIdx.x >> 6][c] = mx[c]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    atomicMin(&bbox[c], min(min(s_mn[0][c], s_mn[1][c]), min(s_mn[2][c], s_mn[3][c])));
+    atomicMax(&bbox[3 + c], max(max(s_mx[0][c], s_mx[1][c]), max(s_mx[2][c], s_mx[3][c])));
   }
 }
 
@@ -706,7 +715,7 @@ static int knn_build(const float* points, int32_t N, void* scratch, hipStream_t 
   SLAM_TRY(hipMemsetAsync(bbox, 0xff, 3 * sizeof(uint32_t), st));
   SLAM_TRY(hipMemsetAsync(bbox + 3, 0, 3 * sizeof(uint32_t), st));
   int g = grid1(N);
-  hipLaunchKernelGGL(knn_bbox_kernel, dim3(g > 1024 ? 1024 : g), dim3(256), 0, st, points, N, bbox);
+  hipLaunchKernelGGL(knn_bbox_kernel, dim3(g > 256 ? 256 : g), dim3(256), 0, st, points, N, bbox);
   hipLaunchKernelGGL(knn_morton_kernel, dim3(g), dim3(256), 0, st, points, N, (const uint32_t*)bbox, codes, order_in);
   size_t tb = L.cub_bytes;
   SLAM_TRY(rocprim::radix_sort_pairs(s + L.cub, tb, codes, codes_sorted, order_in, order, (size_t)N, 0u, 30u, st));
