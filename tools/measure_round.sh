@@ -4,7 +4,7 @@
 # passes - FETCH_SIZE and WRITE_SIZE in separate runs (TCC slots), two SQ counter sets - each with --kernel-trace only.
 set -x
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -24,6 +24,15 @@ for w in headline surface; do
   python $R/tools/traffic_from_pmc.py $(find $O/pmc_f_$w -name "*counter_collection.csv" | head -1) $(find $O/pmc_w_$w -name "*counter_collection.csv" | head -1) $O/traffic_$w.json > $O/traffic_$w.txt
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_icp -o k -- python $R/tools/prof_icp.py replica 40 > $O/ks_icp.log 2>&1
+# round 5: the SLAM sequence (BASELINE configs[2]), the unchanged-reference iteration and BASELINE configs[4] under the kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_seq -o k -- python $R/bench.py --only sequence --sequence-frames 300 > $O/ks_seq.log 2>&1
+python $R/tools/kernel_table.py $O/ks_seq 45 > $O/table_sequence.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_dropin -o k -- python $R/bench.py --only dropin --steps 10 > $O/ks_dropin.log 2>&1
+python $R/tools/kernel_table.py $O/ks_dropin 45 > $O/table_dropin.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_c5 -o k -- python $R/bench.py --only config5 > $O/ks_c5.log 2>&1
+python $R/tools/kernel_table.py $O/ks_c5 30 > $O/table_config5.txt
+RTGS_MAP_PROFILE=1 python $R/bench.py --only sequence --sequence-frames 300 > $O/sequence_stage_profile.json 2> /dev/null
+$R/tools/probe/valu_rate > $O/valu_rate.txt 2>&1
 bash $R/tools/pmc_sq_passes.sh $TAG/sq > $O/pmc_sq.log 2>&1
 python $R/tools/valu_from_pmc.py $O/sq/pmc_sq_surface.csv $O/sq/pmc_sq_headline.csv $O/valu.json
 for w in headline surface; do python $R/tools/pmc_summary.py $O/sq/pmc_sq_$w.csv > $O/sq_summary_$w.txt; done
