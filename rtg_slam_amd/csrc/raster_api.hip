@@ -196,6 +196,13 @@ __global__ void bwd_info_kernel(BwdInfo* dst, SplatGrad* slot_grads, uint32_t sl
 
 // Offsets the BACKWARD reads (splats, radii, clamped, ranges1_bwd, list1) do not depend on `budget`: everything sized
 // by the near-slice budget sits behind them, so a backward never needs to know the budget of its forward.
+// Maps of at least this many Gaussians (on >= 256 tiles) take the "large map" forward: the near slice is CONSIDERED (its
+// kernels decide per call whether it runs) and tiles own segments for one-pass placement.  RTGS_LARGE_MAP_MIN at load time.
+static int large_map_min() {
+  static const int v = [] { const char* e = getenv("RTGS_LARGE_MAP_MIN"); const int x = e ? atoi(e) : 100000; return x > 0 ? x : 100000; }();
+  return v;
+}
+
 static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
   GeomLayout L{};
   size_t off = 0;
@@ -236,7 +243,7 @@ static GeomLayout geom_layout(int32_t P, int gx, int gy, int budget) {
     L.block_counts_vis = off; off = align_up(off + bin_list_block_counts_bytes((int)Pn, gx * gy));
     // one-pass placement (bin_place_kernel): on maps where the automatic mode considers the slice, every tile owns a
     // SEGMENT of SLICE_MAX_LIST entries in list1 / bucket1 (sparse use; 37 KB per tile, 119 MB at 1200x680 of 288 GB)
-    L.slice_seg = (Pn >= 100000 && nt >= 256) ? (size_t)SLICE_MAX_LIST : 0;
+    L.slice_seg = (Pn >= (size_t)large_map_min() && nt >= 256) ? (size_t)SLICE_MAX_LIST : 0;
     const size_t cap1 = L.slice_seg ? (nt * L.slice_seg > L.slice_cap ? nt * L.slice_seg : L.slice_cap) : L.slice_cap;
     L.list1 = off; off = align_up(off + cap1 * sizeof(uint32_t));             // last budget-independent OFFSET
     L.block_counts1 = off; off = align_up(off + bin_slice_block_counts_bytes((int)Pn, L.slice_max_list, gx * gy));
@@ -452,7 +459,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   // near-slice pass: mode 1 forces it (tests); automatic mode considers it on large maps only, and there the kernels
   // decide from the depth histograms whether it runs (an empty slice sends every tile to the second pass)
   const bool slice_auto = c->slice_mode == 2;
-  bool sliced = !sort_path && P > 0 && (c->slice_mode == 1 || (slice_auto && P >= 100000 && ntiles >= 256));
+  bool sliced = !sort_path && P > 0 && (c->slice_mode == 1 || (slice_auto && P >= large_map_min() && ntiles >= 256));
   SlicePass pass{0, nullptr, nullptr, nullptr, nullptr};
   bool declined = false, considered = false;
   SliceList vis{nullptr, nullptr};             // every visible Gaussian, when the declined single pass built the list
