@@ -15,7 +15,8 @@ def test_default_flags_are_the_contracts(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
     assert (a.gpus, a.steps, a.warmup) == (1, 20, 3)
-    assert a.gaussians == 1_200_000 and a.mode == "sparse"
+    assert a.gaussians == 1_200_000 and a.mode == "auto"        # auto = tile bands of ONE stream at N > 1 (a SLAM stream has one frame per step)
+    assert a.sequence_frames >= 300 and not a.no_sequence and not a.no_config5 and not a.no_dropin and a.only is None
     assert not a.no_cpu_baseline and not a.no_schedule and not a.no_surface and not a.surface_map
     assert a.prewarm >= 3000 and a.repeats == 5
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "50", "--warmup", "5"])
@@ -46,7 +47,18 @@ def test_the_committed_bench_line_has_the_contracts_fields():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["metric"] == "slam_frames_per_sec" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    # `value` counts hot-path UNITS (1 ICP track || 1 map iteration), and is named so since round 5; the SLAM frame rate by
+    # the reference's definition is its own field, from the sequence leg (BASELINE configs[2])
+    assert d["metric"] == "hot_path_units_per_sec" and d["unit"] == "units/s"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None
+    seq = d["slam_sequence"]
+    assert d["slam_frames_per_sec"] == seq["fps"] > 0 and seq["frames"] >= 300 and seq["start"] == "empty map"
+    assert seq["image"] == [680, 1200] and seq["ate_rmse_m"] < 0.05 and seq["stable"] > 0 and seq["stats"]["global_opts"] > 0
+    assert d["icp_track_ms_tum_480x640_noisy"]["image"] == [480, 640] and d["icp_track_ms_tum_480x640_noisy"]["ms_median"] > 0
+    assert d["dropin_iteration_ms"] > d["dropin"]["one_call_step_ms"] > 0
+    c5 = d["config5"]
+    assert c5["gaussians"] == 5_000_000 and c5["mode"] == "sharded" and c5["iterations"] == 10
+    assert set(c5["split_ms"]) == {"render_fwd_and_loss", "render_bwd", "collective", "adam"}
     assert d["n_gpus"] == 1 and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
