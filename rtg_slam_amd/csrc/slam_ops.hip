@@ -513,16 +513,18 @@ __global__ void __launch_bounds__(256) bilateral_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) frame_vertex_kernel(const float* __restrict__ depth, int H, int W, const float* __restrict__ K,
                                                            float dmin, float dmax, float* __restrict__ vertex,
                                                            uint32_t* __restrict__ mm) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  // grid-stride over at most 512 workgroups: one pair of same-address atomics per WORKGROUP below - with a workgroup per 256
+  // pixels (3 188 of them at 1200x680) those atomics were most of the kernel's 76 us
   uint32_t emin = 0xffffffffu, emax = 0u;
-  if (i < H * W) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
     float d = depth[i];
     if (!((d > dmin) && (d < dmax))) d = 0.f;
     const int x = i % W, y = i / W;
     vertex[(size_t)i * 3] = (((float)x - K[2]) / K[0]) * d;
     vertex[(size_t)i * 3 + 1] = (((float)y - K[5]) / K[4]) * d;
     vertex[(size_t)i * 3 + 2] = d;
-    emin = emax = enc_f(d);
+    const uint32_t e = enc_f(d);
+    emin = min(emin, e); emax = max(emax, e);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -844,7 +846,7 @@ int rtgs_frame_preprocess(const float* depth_in, int32_t H, int32_t W, const flo
   SLAM_TRY(hipMemsetAsync(mm, 0xff, sizeof(uint32_t), st));
   SLAM_TRY(hipMemsetAsync(mm + 1, 0, sizeof(uint32_t), st));
   const int n = H * W;
-  hipLaunchKernelGGL(frame_vertex_kernel, dim3(grid1(n)), dim3(256), 0, st, depth_in, H, W, K, min_depth, max_depth, V, mm);
+  hipLaunchKernelGGL(frame_vertex_kernel, dim3(grid1(n) > 512 ? 512 : grid1(n)), dim3(256), 0, st, depth_in, H, W, K, min_depth, max_depth, V, mm);
   hipLaunchKernelGGL(frame_normal_kernel, dim3(grid1(n)), dim3(256), 0, st, (const float*)V, H, W, K, (const uint32_t*)mm,
                      invalid_confidence_thresh, depth_out, vertex_out, normal_out, conf_out, bad_out);
   SLAM_TRY(hipGetLastError());

@@ -624,6 +624,26 @@ class Mapping:
             o.remove_rows(full)
             self.stats["deleted_stable"] += n_del
 
+    def save_model(self, path: str, save_data: bool = True, save_sibr: bool = True, save_merge: bool = True):
+        """Mapping.save_model (mapper.py:916-941): `<path>.ply` = the unstable cloud, `<path>_stable.ply` = the stable one (raw
+        values + confidence), `_sibr` variants without the confidence column, `_merge` = both.  Bytes as the reference's
+        writer lays them out (io_formats.py)."""
+        from . import io_formats as iof
+        o = self.opt
+        P = o.params
+        conf = o.aux["confidence"][:o.N]
+        parts = {"": (o.n_frozen, o.N), "_stable": (0, o.n_frozen)}
+        for with_conf, tag in ((True, ""), (False, "_sibr")):
+            if not (save_data if with_conf else save_sibr):
+                continue
+            for name, (r0, r1) in parts.items():
+                m = iof.packed_to_model(P[r0:r1].detach().cpu().numpy())
+                iof.save_model_ply(path + name + tag + ".ply", m["xyz"], m["features_dc"], m["features_rest"], m["opacity"],
+                                   m["scaling"], m["rotation"], conf[r0:r1] if with_conf else None, include_confidence=with_conf)
+            if save_merge and o.n_train > 0 and o.n_frozen > 0:
+                iof.merge_ply(path + tag + ".ply", path + "_stable" + tag + ".ply", path + "_merge" + tag + ".ply",
+                              include_confidence=with_conf)
+
     def get_render_output(self, frame):
         out = self._render(frame, "all")
         self.model_map = {

@@ -145,3 +145,24 @@ def test_final_global_optimisation_fixes_everything_first():
     last = ops.steps[-n_final:]
     assert all(s[0] == m.opt.N and s[1] == 0 and s[2] is None for s in last)  # all rows, no tile mask (mapper.py:497-499)
     assert m.weights.depth_weight == 0.0                                     # update_args.depth_weight = 0 (mapper.py:633)
+
+
+def test_save_model_writes_the_reference_snapshot_files(tmp_path):
+    """Mapping.save_model (mapper.py:916-941): unstable / stable / merged clouds with and without the confidence column,
+    readable back (io_formats.load_model_ply) to the map's own rows."""
+    from rtg_slam_amd import io_formats as iof
+    args = _args()
+    m, ops, log = _run(3, args)
+    o = m.opt
+    assert o.n_frozen > 0 and o.n_train > 0
+    base = str(tmp_path / "iter_0000")
+    m.save_model(base)
+    for suffix in ("", "_stable", "_merge", "_sibr", "_stable_sibr", "_merge_sibr"):
+        assert os.path.exists(base + suffix + ".ply"), suffix
+    st, un, me = iof.load_model_ply(base + "_stable.ply"), iof.load_model_ply(base + ".ply"), iof.load_model_ply(base + "_merge.ply")
+    P = o.params.numpy()
+    assert st["xyz"].shape[0] == o.n_frozen and un["xyz"].shape[0] == o.n_train and me["xyz"].shape[0] == o.N
+    assert np.array_equal(iof.model_to_packed(st), P[:o.n_frozen]) and np.array_equal(iof.model_to_packed(un), P[o.n_frozen:])
+    assert np.array_equal(st["confidence"].reshape(-1), o.aux["confidence"][:o.n_frozen, 0].numpy())
+    names, _ = iof._read_ply_table(base + "_sibr.ply")                      # the viewer's files carry no confidence column
+    assert "confidence" not in names and "confidence" in iof._read_ply_table(base + ".ply")[0]

@@ -118,3 +118,24 @@ def test_global_optimisation_runs_inside_the_sequence_when_the_camera_moves_far(
     print({k: v for k, v in rep.items() if k != "per_frame"})
     assert seen["n"] >= 2 and seen["moved"] == seen["n"] and rep["stats"]["global_opts"] == seen["n"]
     assert rep["ate_rmse_m"] < 0.01
+
+
+def test_a_tum_shaped_noisy_sequence_tracks_and_maps():
+    """BASELINE configs[3]'s sensor (TUM fr1 intrinsics, 640x480, sigma_z noise, 5 % holes, 1/5000 m quantisation -
+    synth.tum_noise) through the same loop with the TUM schedule (configs/tum_base.yaml via mapping.tum_args): the ICP
+    front-end holds the trajectory on noisy depth and the lifecycle runs (add, local optimisation every 4th frame, fix)."""
+    from rtg_slam_amd import mapping as mp, slam
+    cam = synth.TUM_FR1
+    n = 32
+    args = mp.tum_args(max_depth=8.0, stable_confidence_thres=60.0, seed=3)
+
+    def stream():
+        for i, p in enumerate(synth.trajectory(n, seed=13, max_trans=0.01, max_rot_deg=0.5)):
+            d = synth.tum_noise(synth.box_room_depth(cam, p), seed=100 + i).reshape(cam.H, cam.W)
+            clean = synth.box_room_depth(cam, p)
+            yield d.to(DEV), synth.box_room_color(cam, p, clean).to(DEV), p.numpy()
+    mapper, tracker, rep = slam.run_sequence(cam, stream(), args, DEV, capacity=200_000)
+    print({k: v for k, v in rep.items() if k != "per_frame"})
+    assert rep["frames"] == n and rep["stats"]["local_opts"] == 1 + n // args.gaussian_update_frame
+    assert rep["ate_rmse_m"] < 0.03, rep["ate_rmse_m"]           # frame-to-model ICP on noisy depth with holes
+    assert rep["stats"]["added"] > 20000 and rep["gaussians"] > 20000 and rep["stable"] > 0
