@@ -74,9 +74,13 @@ def replica_args(**over) -> SimpleNamespace:
 
 
 def tum_args(**over) -> SimpleNamespace:
-    """configs/tum_base.yaml over base.yaml (the keys that differ from Replica's)."""
-    a = dict(uniform_sample_num=30720, memory_length=5, stable_confidence_thres=200.0, unstable_time_window=150,
-             gaussian_update_iter=50, gaussian_update_frame=4, invalid_confidence_thresh=0.5, type="TUM")
+    """configs/base.yaml overlaid with configs/tum_base.yaml: stable_confidence_thres 200, unstable_time_window 150,
+    memory_length 5, gaussian_update_iter 50, gaussian_update_frame 4, feature_lr 0.001, scaling_lr 0.02 (tum_base.yaml:10-22);
+    everything replica_base.yaml overrides falls back to base.yaml (uniform_sample_num 50000, final_global_iter 10, the three
+    *_lr_coef 1.0).  (tum_base.yaml also switches the ORB backend on - out of scope here: ICP only, as BASELINE configs[3].)"""
+    a = dict(uniform_sample_num=50000, memory_length=5, stable_confidence_thres=200.0, unstable_time_window=150,
+             gaussian_update_iter=50, gaussian_update_frame=4, feature_lr=0.001, scaling_lr=0.02, final_global_iter=10,
+             feature_lr_coef=1.0, scaling_lr_coef=1.0, rotation_lr_coef=1.0, type="TUM")
     a.update(over)
     return replica_args(**a)
 
