@@ -49,8 +49,9 @@ def parse():
                          "loss normalisers all-reduced, gradient rows summed by the sparse exchange [strong]; auto (default) = "
                          "tileband: a SLAM stream has ONE frame per step, so N GPUs can only split that frame - the weak-scaling "
                          "sparse form is reported beside it as `weak_scaling_one_view_per_rank`")
-    ap.add_argument("--sequence-frames", type=int, default=400,
-                    help="frames of the `sequence` leg (BASELINE configs[2]: empty map, reference schedule and lifecycle, 1200x680)")
+    ap.add_argument("--sequence-frames", type=int, default=2000,
+                    help="frames of the `sequence` leg (BASELINE configs[2]: empty map, reference schedule and lifecycle, 1200x680; 2 000 = the "
+                         "length of a Replica sequence, ~17 s on one MI355X)")
     ap.add_argument("--no-sequence", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (5 M Gaussians, sharded, 10 iterations)")
     ap.add_argument("--config5-gaussians", type=int, default=5_000_000)
@@ -726,7 +727,7 @@ def sequence_leg(cam, dev, n_frames, seed=21):
             yield d.reshape(cam.H, cam.W), c, c2w.numpy()
     torch.cuda.reset_peak_memory_stats(dev)
     gc.collect()
-    mapper, tracker, rep = slam.run_sequence(cam, stream(), args, dev, capacity=600_000)
+    mapper, tracker, rep = slam.run_sequence(cam, stream(), args, dev, capacity=800_000)
     pf = rep.pop("per_frame")
     opt_frames = [p for i, p in enumerate(pf) if (i + 1) % args.gaussian_update_frame == 0 or i == 0]
     oth_frames = [p for i, p in enumerate(pf) if not ((i + 1) % args.gaussian_update_frame == 0 or i == 0)]

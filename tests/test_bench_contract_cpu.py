@@ -53,7 +53,7 @@ def test_the_committed_bench_line_has_the_contracts_fields():
     assert d["higher_is_better"] is True and d["vs_baseline"] is None
     seq = d["slam_sequence"]
     assert d["slam_frames_per_sec"] == seq["fps"] > 0 and seq["frames"] >= 300 and seq["start"] == "empty map"
-    assert seq["image"] == [680, 1200] and seq["ate_rmse_m"] < 0.05 and seq["stable"] > 0 and seq["stats"]["global_opts"] > 0
+    assert seq["image"] == [680, 1200] and seq["ate_rmse_m"] < 0.10 and seq["stable"] > 0 and seq["stats"]["global_opts"] > 0
     assert d["icp_track_ms_tum_480x640_noisy"]["image"] == [480, 640] and d["icp_track_ms_tum_480x640_noisy"]["ms_median"] > 0
     assert d["dropin_iteration_ms"] > d["dropin"]["one_call_step_ms"] > 0
     c5 = d["config5"]
