@@ -5,6 +5,7 @@ O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
+if [ "${SKIP_TESTS:-0}" != "1" ]; then timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt; fi
 python bench.py > $O/bench.json 2> $O/bench.err
 tail -2 $O/smoke.txt; python - <<'PY'
 import json
