@@ -71,6 +71,9 @@ void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* ctx, int mode);
  * (bin_place_kernel) instead of count + scan + scatter.  Outputs are bit-identical either way (the tile sort's order is
  * total); the switch exists for A-B runs and tests. */
 void rtgs_raster_set_onepass_ctx(rtgs_ctx* ctx, int on);
+/* The forward's tile walk: 1 (default) = one pixel per lane, 2 = two pixels per lane (128 threads per tile; round 5: built,
+ * bit-identical, measured slower on small footprints - kept for A-B runs).  PROCESS-WIDE; RTGS_FWD_KERNEL at load time. */
+void rtgs_raster_set_fwd_kernel(int which);
 
 #ifdef __cplusplus
 }
