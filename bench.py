@@ -450,7 +450,7 @@ def main():
         # measured on THESE kernel sources: the files carry the hash of rtg_slam_amd/csrc they were collected at.
         traffic, valu = None, None
         src = source_hash()
-        dom_pmc = {"blend_bwd": "blend_bwd_mfma", "near_slice_blend_fwd": "blend_fwd"}.get(dom, dom)
+        dom_pmc = {"blend_bwd": "blend_bwd_entry", "near_slice_blend_fwd": "blend_fwd"}.get(dom, dom)
         same_workload = N == 1_200_000 and not args.surface_map       # the PMC passes ran the default headline workload
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if same_workload and os.path.exists(tpath):     # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes

@@ -74,6 +74,13 @@ void rtgs_raster_set_onepass_ctx(rtgs_ctx* ctx, int on);
 /* The forward's tile walk: 1 (default) = one pixel per lane, 2 = two pixels per lane (128 threads per tile; round 5: built,
  * bit-identical, measured slower on small footprints - kept for A-B runs).  PROCESS-WIDE; RTGS_FWD_KERNEL at load time. */
 void rtgs_raster_set_fwd_kernel(int which);
+/* Timing decompositions of the MFMA backward walk: bits 0..2 switch parts of the kernel OFF (1 walk, 2 depth partials,
+ * 4 stores) - results are then wrong by construction.  PROCESS-WIDE; RTGS_MFMA_DEBUG at load time. */
+void rtgs_raster_set_mfma_walk(int bits);
+/* Per-wave time stamps of the MFMA backward walk (tools/mfma_stamps.py): `dev` = device uint64[tiles x 4 waves x 14] or NULL
+ * (default: the product kernel carries no stamping code).  Per wave: wall clock (100 MHz) at entry and exit, shader cycles
+ * in the group loop and in the kernel, groups walked, quad steps entered, cycles of the six other phases.  PROCESS-WIDE. */
+void rtgs_raster_set_mfma_stamps(void* dev);
 
 #ifdef __cplusplus
 }

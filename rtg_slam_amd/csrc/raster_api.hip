@@ -20,6 +20,8 @@ void launch_emit_keys(const RasterParams&, const Splat*, const int32_t*, const u
                       uint32_t*, hipStream_t);
 void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
 void set_fwd_kernel(int which);
+void set_mfma_debug(int bits);
+void set_mfma_stamps(void* dev);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
                       int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, hipStream_t);
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
@@ -1024,6 +1026,8 @@ int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
 }
 uint32_t rtgs_raster_last_listed_ctx(rtgs_ctx* c) { return use(c)->last_listed; }
 void rtgs_raster_set_fwd_kernel(int which) { rtgs::set_fwd_kernel(which); }
+void rtgs_raster_set_mfma_walk(int bits) { rtgs::set_mfma_debug(bits); }
+void rtgs_raster_set_mfma_stamps(void* dev) { rtgs::set_mfma_stamps(dev); }
 void rtgs_raster_set_onepass_ctx(rtgs_ctx* c, int on) { use(c)->onepass = on != 0; use(c)->plan.valid = false; }
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode >= 1 && mode <= 4) ? mode : 0; }
 void rtgs_raster_set_aux_zero_ctx(rtgs_ctx* ctx, void* eight_words) { use(ctx)->aux_zero = (uint32_t*)eight_words; }

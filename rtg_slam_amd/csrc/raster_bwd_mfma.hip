@@ -1,4 +1,4 @@
-// K7 blend_bwd, third walk: ENTRY-PER-LANE with the pixel reduction on the matrix cores.
+// K7 blend_bwd, third walk: ENTRY-PER-LANE.
 //
 // The strip and row-granular walks (raster_bwd.hip) give a lane one PIXEL and an instruction one ENTRY: every entry
 // then costs a cross-lane reduction of nine partials (a third of the instructions of kernels that are VALU-issue
@@ -6,26 +6,37 @@
 //
 //     lane l = (k = l >> 4, n = l & 15)  <->  pixel k of a 2x2 quad, n-th entry of a group of 16 list entries
 //
-// which is exactly the B-operand lane map of v_mfma_f32_16x16x4_f32 (B[k][n]).  The sums over pixels
-//     sum_p gda[p][e] * {1, x_p, y_p, x_p^2, x_p y_p, y_p^2}      (dL/dopacity and the five moments behind du dv dconic)
-//     sum_p  w [p][e] * {g_r, g_g, g_b}[p]                         (dL/dcolour)
-// are contractions over the pixel index: two MFMAs per step with the per-pixel factors as A operands
-// (A[m][k] = feature m of pixel k), accumulated IN THE ACCUMULATOR REGISTERS over the 16 quads of the wave's 8x8
-// quadrant - no butterfly, no per-entry LDS traffic; one flush of 9 x 16 sums per (wave, 16 entries).  What is
-// sequential along a ray - T_k = prod (1 - a_m), the colour behind - becomes two in-row prefix scans over the 16
+// What is sequential along a ray - T_k = prod (1 - a_m), the colour behind - becomes two in-row prefix scans over the 16
 // entries (DPP row_shr:1/2/4/8, four instructions each) with a per-pixel carry between groups:
 //     T_k  = Tc * exclusive_prod(1 - a)           Q_k = Qc - inclusive_sum((c . g) a T),   Qc(0) = C_pixel . g
 //     dL/da_k = T_k (c_k . g) - Q_k / (1 - a_k)                                   (front to back)
 // Per-pixel values (g, last contributor, carries) live in the lane whose n equals the quad's index and reach the 16
 // entry lanes of their row through DPP row_newbcast as an OPERAND of the instruction that uses them.
 //
+// The sums over pixels
+//     sum_p gda[p][e] * {1, x_p, y_p, x_p^2, x_p y_p, y_p^2}      (dL/dopacity and the five moments behind du dv dconic)
+//     sum_p  w [p][e] * {g_r, g_g, g_b}[p]                         (dL/dcolour)
+// exist in two forms:
+//   * round 5 (the product kernel, blend_bwd_entry_kernel): every lane keeps the nine sums of ITS pixel k over the 16 quads
+//     of the wave's 8x8 quadrant (8 plain VALU + 3 FMAs with a DPP operand per step); at the end of a group the four k rows
+//     meet in registers (v_permlane32_swap / v_permlane16_swap) and row 0 adds 9 x 16 sums to the entries' LDS accumulators;
+//   * round 4 (blend_bwd_entry_mfma_kernel, rtgs_raster_set_mfma_walk(8)): the lane map above is exactly the B-operand map of
+//     v_mfma_f32_16x16x4_f32 (B[k][n]), so the sums are two MFMAs per step with the per-pixel factors as A operands,
+//     accumulated in the accumulator registers.  Elegant, and slower: the MFMA holds the SIMD for most of its 32 cycles, two
+//     of them cost more issue time than the eleven instructions that replace them.  Measured A-B in one session: 98.6 -> 89.0
+//     us (headline), 158.3 -> 145.2 us (surface) - profiles/r05_bwd_walk_ab.txt.
+//
 // A wave walks only the entries that reach its quadrant (compacted at staging time from the forward's exact
 // block test), 16 at a time, and skips the quads whose four pixels are past their last contributor.  The opaque-depth
 // partials do not ride the walk at all: blend_fwd leaves the list position of every pixel's depth owner and the
-// owners' four partials go straight to the entry accumulators once per batch.
+// owners' four partials go straight to the entry accumulators once per batch (depth_adds).
 //
 // alpha, the skip tests and the contributor set are evaluated exactly as the forward does (same dx, splat_power,
 // splat_exp, list positions against n_contrib); T differs from the forward's in rounding only (product order).
+//
+// Where a launch spends its time is measured, not guessed: tools/mfma_stamps.py (per-wave cycle stamps of every phase,
+// profiles/r05_bwd_stamps_*.txt).  Half of a wave's life is the group loop; a quarter is the prologue's three dependent
+// memory round trips (per-tile words -> per-pixel values / list -> records), a tenth the barriers of the compaction.
 #include "raster_common.h"
 #include <stdlib.h>
 
@@ -78,6 +89,9 @@ struct MfmaWalk {
   float X[4];                      // colour gradients of 5 quads per register, 3 lanes each (A operand by rotation)
   f32x4 C1, C2;
   int n;                           // lane & 15
+  // lane-accumulate form (round 5): the lane's own sums over the quads of its pixel k, reduced over k at the flush
+  float xq[4], yq[4];              // pixel coordinates about the tile centre, per quad column / row
+  float s0, sx, sy, sxx, sxy, syy, sr, sg, sb;
 
   template <int S>
   __device__ __forceinline__ void step(uint32_t stepmask) {
@@ -175,45 +189,195 @@ struct MfmaWalk {
         : [tn] "=&v"(tn), [qn] "=&v"(qn), [Tc] "+v"(Tc), [Qc] "+v"(Qc)
         : [incl] "v"(incl), [sinc] "v"(sinc), [mine] "s"(MINE));
   }
+  // The same step WITHOUT the matrix cores (round 5).  Measured (tools/probe/valu_rate.hip, tools/mfma_stamps.py): a
+  // v_mfma_f32_16x16x4_f32 holds the SIMD for its 32 cycles - VALU instructions of the other waves do not issue under it -
+  // so the two MFMAs of a step cost 64 of its ~156 SIMD cycles, for 9 x 16 x 4 useful multiply-adds.  The lane keeps the
+  // nine sums of ITS pixel k over the quads (8 plain VALU for the moments, 3 FMAs with the colour gradient as a DPP
+  // operand: ~20 cycles) and the four k rows meet in the LDS accumulator at the flush.
+  template <int S>
+  __device__ __forceinline__ void step_lane(uint32_t stepmask) {
+    if (!((stepmask >> S) & 1u)) return;
+    float power, G, alpha;
+    {
+      float dx, dy, t1, t2;
+      asm volatile(
+          "v_sub_f32 %[dx], %[u], %[px]\n\t"
+          "v_sub_f32 %[dy], %[v], %[py]\n\t"
+          "v_mul_f32 %[t1], %[ca], %[dx]\n\t"
+          "v_mul_f32 %[t2], %[cc], %[dy]\n\t"
+          "v_mul_f32 %[t2], %[t2], %[dy]\n\t"
+          "v_fma_f32 %[t1], %[t1], %[dx], %[t2]\n\t"
+          "v_mul_f32 %[t2], %[cb], %[dx]\n\t"
+          "v_mul_f32 %[t2], %[t2], %[dy]\n\t"
+          "v_fma_f32 %[pw], -0.5, %[t1], -%[t2]\n\t"
+          "v_min_f32 %[t1], 0, %[pw]\n\t"
+          "v_mul_f32 %[t1], 0x3fb8aa3b, %[t1]\n\t"
+          "v_exp_f32 %[G], %[t1]\n\t"
+          "s_nop 0\n\t"
+          "v_mul_f32 %[al], %[o], %[G]\n\t"
+          "v_min_f32 %[al], 0x3f7d70a4, %[al]\n\t"
+          : [dx] "=&v"(dx), [dy] "=&v"(dy), [t1] "=&v"(t1), [t2] "=&v"(t2), [pw] "=&v"(power), [G] "=&v"(G), [al] "=&v"(alpha)
+          : [u] "v"(u), [v] "v"(v), [ca] "v"(ca), [cb] "v"(cb), [cc] "v"(cc), [o] "v"(o), [px] "v"(pxc[S & 3]), [py] "v"(pyc[S >> 2]));
+    }
+    const uint32_t lastp = bcast_u<S>(last);
+    const bool valid = (pos < lastp) & !(power > 0.f) & !(alpha < 1.f / 255.f);
+    if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
+    const float a = valid ? alpha : 0.f;
+    const float Gv = valid ? G : 0.f;
+    constexpr unsigned long long MINE = 0x0001000100010001ull << S;
+    float incl, sinc, gda, w, cg, ia, t0, gx, gy;
+    asm volatile(
+        "v_sub_f32 %[incl], 1.0, %[a]\n\t"
+        "v_mul_f32_dpp %[cg], %[G0], %[cr] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
+        "v_rcp_f32 %[ia], %[incl]\n\t"
+        "v_fmac_f32_dpp %[cg], %[G1], %[cgn] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[cg], %[G2], %[cb] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %[t0], %[Tc], %[ia] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"      // Tc[quad] / (1 - a)
+        "v_mul_f32 %[t0], %[t0], %[incl]\n\t"                                                       // Tk = Tc incl / (1 - a): the exclusive product without a shift
+        "v_mul_f32 %[w], %[a], %[t0]\n\t"
+        "v_mul_f32 %[sinc], %[cg], %[w]\n\t"
+        "v_mul_f32 %[gda], %[t0], %[cg]\n\t"                                                        // Tk cg
+        "v_fmac_f32_dpp %[sr], %[G0], %[w] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"      // colour sums of pixel k
+        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[sg], %[G1], %[w] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[sb], %[G2], %[w] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_sub_f32_dpp %[t0], %[Qc], %[sinc] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"    // Qk
+        "v_fma_f32 %[gda], -%[t0], %[ia], %[gda]\n\t"                                               // Tk cg - Qk / (1 - a)
+        "v_mul_f32 %[gda], %[Gv], %[gda]\n\t"
+        : [incl] "=&v"(incl), [sinc] "=&v"(sinc), [gda] "=&v"(gda), [w] "=&v"(w), [cg] "=&v"(cg), [ia] "=&v"(ia), [t0] "=&v"(t0),
+          [sr] "+v"(sr), [sg] "+v"(sg), [sb] "+v"(sb)
+        : [a] "v"(a), [Gv] "v"(Gv), [cr] "v"(cr), [cgn] "v"(cg_), [cb] "v"(cbl), [G0] "v"(G0), [G1] "v"(G1), [G2] "v"(G2),
+          [Tc] "v"(Tc), [Qc] "v"(Qc), [S] "n"(S));
+    float tn, qn;
+    asm volatile(
+        // moments of pixel k about the tile centre (three plain instructions ahead of the DPP reads of incl / sinc)
+        "v_add_f32 %[s0], %[s0], %[gda]\n\t"
+        "v_mul_f32 %[gx], %[gda], %[x]\n\t"
+        "v_mul_f32 %[gy], %[gda], %[y]\n\t"
+        // the quad's carries move past this group: lane n == S of every row owns them
+        "v_mul_f32_dpp %[tn], %[incl], %[Tc] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_subrev_f32_dpp %[qn], %[sinc], %[Qc] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32 %[sx], %[sx], %[gx]\n\t"
+        "v_add_f32 %[sy], %[sy], %[gy]\n\t"
+        "v_cndmask_b32 %[Tc], %[Tc], %[tn], %[mine]\n\t"
+        "v_cndmask_b32 %[Qc], %[Qc], %[qn], %[mine]\n\t"
+        "v_fmac_f32 %[sxx], %[gx], %[x]\n\t"
+        "v_fmac_f32 %[sxy], %[gx], %[y]\n\t"
+        "v_fmac_f32 %[syy], %[gy], %[y]\n\t"
+        : [tn] "=&v"(tn), [qn] "=&v"(qn), [gx] "=&v"(gx), [gy] "=&v"(gy), [Tc] "+v"(Tc), [Qc] "+v"(Qc), [s0] "+v"(s0), [sx] "+v"(sx),
+          [sy] "+v"(sy), [sxx] "+v"(sxx), [sxy] "+v"(sxy), [syy] "+v"(syy)
+        : [incl] "v"(incl), [sinc] "v"(sinc), [gda] "v"(gda), [x] "v"(xq[S & 3]), [y] "v"(yq[S >> 2]), [mine] "s"(MINE));
+  }
+  __device__ __forceinline__ void run16_lane(uint32_t sm) {
+    step_lane<0>(sm); step_lane<1>(sm); step_lane<2>(sm); step_lane<3>(sm); step_lane<4>(sm); step_lane<5>(sm); step_lane<6>(sm);
+    step_lane<7>(sm); step_lane<8>(sm); step_lane<9>(sm); step_lane<10>(sm); step_lane<11>(sm); step_lane<12>(sm); step_lane<13>(sm);
+    step_lane<14>(sm); step_lane<15>(sm);
+  }
   __device__ __forceinline__ void run16(uint32_t sm) {
     step<0>(sm); step<1>(sm); step<2>(sm); step<3>(sm); step<4>(sm); step<5>(sm); step<6>(sm); step<7>(sm);
     step<8>(sm); step<9>(sm); step<10>(sm); step<11>(sm); step<12>(sm); step<13>(sm); step<14>(sm); step<15>(sm);
   }
 };
 
-// Sum of v over the wave's 64 lanes, in every lane (DPP inside the rows, four readlanes across them).
-__device__ __forceinline__ float wave_total(float v) {
-  v += dppf<0xB1>(0.f, v);                 // quad_perm [1,0,3,2]
-  v += dppf<0x4E>(0.f, v);                 // quad_perm [2,3,0,1]
-  v += dppf<0x141>(0.f, v);                // row_half_mirror
-  v += dppf<0x140>(0.f, v);                // row_mirror: every lane of a row holds the row sum
-  return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
-         (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
+// x[n] + x[n + 16] + x[n + 32] + x[n + 48] in every lane (gfx950's row swaps: upper half <-> lower half, odd rows <-> even rows)
+__device__ __forceinline__ float sum_rows(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float y = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
-// The opaque-depth partials of the wave's pixels whose owner entry is staged (rel = its index in the batch), summed per
-// owner BEFORE they reach LDS: neighbouring pixels share their owner (a near Gaussian owns a whole quadrant), and 64
-// same-address LDS float adds serialise - measured 21 us of the headline launch when every lane added for itself.
+// The opaque-depth partials of the wave's pixels whose owner entry is staged (rel = its index in the batch) on their way to
+// the owners' LDS accumulators.  Neighbouring pixels share their owner (a near Gaussian owns a whole quadrant) and same-address
+// LDS float adds serialise (21 us of the headline launch when every lane added for itself, round 4), so equal keys are merged
+// in registers first.  Round 4 did that with a loop over the wave's DISTINCT owners, one full wave reduction per owner - fine
+// for one owner, 12-17 % of a wave's lifetime where a quadrant has dozens (tools/mfma_stamps.py).  Round 5: a fixed binary
+// tree over the lane index - rows 0|1 and 2|3 (v_permlane16_swap), rows 0|2 (v_permlane32_swap), then lanes n | n+1, n+2,
+// n+4, n+8 of row 0 (DPP row_shl / row_shr: the quads of the quadrant, neighbours first) - where the representative of the lower half absorbs the representative of the
+// upper half IF their owners are equal; whoever was not absorbed adds for itself.  One owner per wave: one lane adds.  All
+// different: 64 lanes add to 64 addresses.  ~100 instructions either way, no loop.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dppu(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, 0xf, false);
+}
 __device__ __forceinline__ void depth_adds(bool pend, uint32_t rel, float d0, float d1, float d2, float d3, float* s_acc, int lane) {
-  unsigned long long todo = __builtin_amdgcn_ballot_w64(pend);
-  while (todo != 0ull) {
-    const int leader = __builtin_ctzll(todo);
-    const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)rel, leader);
-    const bool mine = pend && rel == key;
-    todo &= ~__builtin_amdgcn_ballot_w64(mine);
-    const float t0 = wave_total(mine ? d0 : 0.f), t1 = wave_total(mine ? d1 : 0.f);
-    const float t2 = wave_total(mine ? d2 : 0.f), t3 = wave_total(mine ? d3 : 0.f);
-    if (lane < 4) atomicAdd(&s_acc[key * MACC + 9 + lane], lane == 0 ? t0 : lane == 1 ? t1 : lane == 2 ? t2 : t3);
+  if (__builtin_amdgcn_ballot_w64(pend) == 0ull) return;
+  constexpr uint32_t NONE = 0xffffffffu;
+  uint32_t key = pend ? rel : NONE;
+  const int k = lane >> 4, n = lane & 15;
+  {   // rows 0|1, 2|3
+    const auto q = __builtin_amdgcn_permlane16_swap(key, key, false, false);
+    const uint32_t other = (k & 1) ? q[0] : q[1];
+    const bool same = key != NONE && other == key;
+    const auto e0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d0), __float_as_uint(d0), false, false);
+    const auto e1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d1), __float_as_uint(d1), false, false);
+    const auto e2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d2), __float_as_uint(d2), false, false);
+    const auto e3 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d3), __float_as_uint(d3), false, false);
+    const bool take = same && !(k & 1);
+    d0 += take ? __uint_as_float(e0[1]) : 0.f; d1 += take ? __uint_as_float(e1[1]) : 0.f;
+    d2 += take ? __uint_as_float(e2[1]) : 0.f; d3 += take ? __uint_as_float(e3[1]) : 0.f;
+    if (same && (k & 1)) key = NONE;
+  }
+  {   // rows 0|2
+    const auto q = __builtin_amdgcn_permlane32_swap(key, key, false, false);
+    const uint32_t other = (k & 2) ? q[0] : q[1];
+    const bool same = key != NONE && other == key && !(k & 1);
+    const auto e0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0), __float_as_uint(d0), false, false);
+    const auto e1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d1), __float_as_uint(d1), false, false);
+    const auto e2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d2), __float_as_uint(d2), false, false);
+    const auto e3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d3), __float_as_uint(d3), false, false);
+    const bool take = same && k == 0;
+    d0 += take ? __uint_as_float(e0[1]) : 0.f; d1 += take ? __uint_as_float(e1[1]) : 0.f;
+    d2 += take ? __uint_as_float(e2[1]) : 0.f; d3 += take ? __uint_as_float(e3[1]) : 0.f;
+    if (same && k == 2) key = NONE;
+  }
+#define RTGS_DEPTH_LEVEL(SH)                                                                                          \
+  {                                                                                                                    \
+    const uint32_t up = dppu<0x100 + SH>(NONE, key), down = dppu<0x110 + SH>(NONE, key); /* lane n + SH, lane n - SH */ \
+    const float u0 = dppf<0x100 + SH>(0.f, d0), u1 = dppf<0x100 + SH>(0.f, d1), u2 = dppf<0x100 + SH>(0.f, d2),        \
+                u3 = dppf<0x100 + SH>(0.f, d3);                                                                        \
+    const bool lower = k == 0 && (n & (2 * SH - 1)) == 0, upper = k == 0 && (n & (2 * SH - 1)) == SH;                 \
+    const bool take = lower && key != NONE && up == key;                                                               \
+    d0 += take ? u0 : 0.f; d1 += take ? u1 : 0.f; d2 += take ? u2 : 0.f; d3 += take ? u3 : 0.f;                        \
+    if (upper && key != NONE && down == key) key = NONE;                                                               \
+  }
+  RTGS_DEPTH_LEVEL(1) RTGS_DEPTH_LEVEL(2) RTGS_DEPTH_LEVEL(4) RTGS_DEPTH_LEVEL(8)
+#undef RTGS_DEPTH_LEVEL
+  if (key != NONE) {
+    float* const acc = &s_acc[key * MACC + 9];
+    atomicAdd(acc + 0, d0); atomicAdd(acc + 1, d1); atomicAdd(acc + 2, d2); atomicAdd(acc + 3, d3);
   }
 }
 
-__global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
-    RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+// STAMP (measurement only, rtgs_raster_set_mfma_stamps): every wave leaves fourteen 64-bit words - wall clock (100 MHz) at entry
+// and exit, shader cycles spent in the group loop and in the whole kernel, groups walked, quad steps entered, the cycles of
+// the other phases (prologue | accumulator zeroing + depth partials | staging: gather -> LDS, block test | compaction |
+// barrier behind the loop: the tile's slowest quadrant | per-entry tail: moments -> slot store) and two marks inside the
+// prologue (per-tile words there | per-pixel loads used and first barrier passed).
+// MF: the pixel sums on the matrix cores (round 4) instead of in lane accumulators (round 5, the product kernel).
+template <bool STAMP, bool MF>
+__device__ __forceinline__ void blend_bwd_entry_body(
+    const RasterParams& p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, const float* __restrict__ out_color, const uint32_t* __restrict__ n_contrib,
     const int32_t* __restrict__ depth_index, const uint32_t* __restrict__ depth_pos, const uint32_t* __restrict__ tile_last,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
     SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode,
-    uint32_t t0, uint32_t tn, uint32_t dbg) {
+    uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long* __restrict__ stamps) {
+  unsigned long long st_wall = 0, st_cyc = 0, st_walk = 0, st_groups = 0, st_steps = 0;
+  unsigned long long st_seg[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;   // prologue | zero + depth | stage | compact | after-loop barrier | entry tail
+  if constexpr (STAMP) { st_wall = wall_clock64(); st_cyc = __builtin_readcyclecounter(); }
   __shared__ float4 s_rec[MB * 3];              // u v ca cb | cc o r g | b id slot0 -
   __shared__ float s_acc[MB * MACC];            // per-entry sums of the tile (LDS float adds: one flush per wave and group)
   __shared__ float s_g[4][4][16][3];            // [wave][k][quad][channel]: colour gradients on their way into X
@@ -256,6 +420,8 @@ __global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
   asm volatile("" ::"v"(last_ld), "v"(g0), "v"(g1), "v"(g2), "v"(oc0), "v"(oc1), "v"(oc2), "v"(owner_ld), "v"(gD_ld), "v"(dpos_ld), "v"(id0),
                "s"(use_slots_w), "s"(slot_grads));
   if (!act) return;
+  unsigned long long st_p1 = 0, st_p2 = 0;
+  if constexpr (STAMP) st_p1 = __builtin_readcyclecounter() - st_cyc;   // the per-tile words are here
   const bool use_slots = use_slots_w != 0;
 
   const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
@@ -272,16 +438,20 @@ __global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
   const bool has_owner = inside && owner_ld >= 0 && gD_ld != 0.f;
   const uint32_t dpos = has_owner ? dpos_ld : 0xffffffffu;
   for (int q = tid; q < m0n * MACC; q += BLOCK) s_acc[q] = 0.f;
-  s_g[wv][k][n][0] = W.G0; s_g[wv][k][n][1] = W.G1; s_g[wv][k][n][2] = W.G2;
+  if constexpr (MF) { s_g[wv][k][n][0] = W.G0; s_g[wv][k][n][1] = W.G1; s_g[wv][k][n][2] = W.G2; }
   // a wave walks no further than its own last contributor
   uint32_t wave_last = W.last;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, off));
   const unsigned long long lt = (1ull << lane) - 1ull;
   __syncthreads();                                     // the first batch's accumulators are zero
+  if constexpr (STAMP) st_p2 = __builtin_readcyclecounter() - st_cyc;   // per-pixel loads used, accumulators zeroed, barrier passed
   // Opaque-surface depth: D = pd / (n_c . r); only the pixel's owner receives it.  A pixel owns
   // at most one entry of the whole list: its four partials go to that entry's accumulator in the batch that stages it -
   // for the first batch here, with the owner's record fetched beside the gather (later batches: inside the loop).
+  // (Round 5 also tried the owner's plane from the staged records - 4 float4 per entry in LDS, partials behind the
+  // compaction: the prologue shrinks by a tenth of a wave's lifetime and the compaction barrier grows by as much - the
+  // record gather is the critical path either way.  89.7 / 146.6 us against 88.0 / 142.6: not kept.)
   {
     const bool pend = dpos < (uint32_t)m0n && !(dbg & 2u);
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
@@ -296,6 +466,7 @@ __global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
     depth_adds(pend, dpos, d0, d1, d2, d3, s_acc, lane);
   }
 
+  if constexpr (STAMP) { st_t = __builtin_readcyclecounter(); st_seg[0] = st_t - st_cyc; }
   for (int base = 0; base < nuse; base += MB) {
     const int m = min(MB, nuse - base);
     if (base > 0) {
@@ -316,6 +487,7 @@ __global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
       }
       depth_adds(pend, dpos - (uint32_t)base, d0, d1, d2, d3, s_acc, lane);
     }
+    if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[1] += t - st_t; st_t = t; }
     // ---- stage one record per thread, test it against the four quadrants, count per quadrant
     uint32_t reach = 0;
     float txl = tx0, tyl = ty0;                        // laundered: the block test's per-tile constants must not be hoisted
@@ -333,6 +505,7 @@ __global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
       s_rec[tid * 3 + 2] = make_float4(b, __uint_as_float(id), __uint_as_float(slot0), 0.f);
       reach = quads_reached(q0.x, q0.y, hxy.x, hxy.y, q0.z, q0.w, q1.x, q1.y, txl, tyl);
     }
+    if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); st_seg[2] += t - st_t; st_t = t; }
     unsigned long long bal[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -359,18 +532,26 @@ __global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
       for (int j = 0; j < 4; ++j) {
         W.pxc[j] = (float)(blockIdx.x * TILE + qx0 + 2 * j + (kq & 1));
         W.pyc[j] = (float)(blockIdx.y * TILE + qy0 + 2 * j + (kq >> 1));
-        // features 1 x y x^2 xy y^2 of the pixel, factored into a column and a row term per lane (lane & 15 = feature)
         const float x = W.pxc[j] - cxT, y = W.pyc[j] - cyT;
-        W.fP[j] = (nq == 1 || nq == 4) ? x : nq == 3 ? x * x : nq <= 5 ? 1.f : 0.f;
-        W.fQ[j] = (nq == 2 || nq == 4) ? y : nq == 5 ? y * y : 1.f;
+        if constexpr (MF) {
+          // features 1 x y x^2 xy y^2 of the pixel, factored into a column and a row term per lane (lane & 15 = feature)
+          W.fP[j] = (nq == 1 || nq == 4) ? x : nq == 3 ? x * x : nq <= 5 ? 1.f : 0.f;
+          W.fQ[j] = (nq == 2 || nq == 4) ? y : nq == 5 ? y * y : 1.f;
+        } else {
+          W.xq[j] = x; W.yq[j] = y;
+        }
       }
       // colour gradients as A operands: X[r] lane (k, 3 t + c) = g_c of pixel (quad 5 r + t, k)
+      if constexpr (MF) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int q = 5 * r + nq / 3;
-        W.X[r] = (nq < 15 && q < 16) ? s_g[wv][kq][q][nq % 3] : 0.f;
+        for (int r = 0; r < 4; ++r) {
+          const int q = 5 * r + nq / 3;
+          W.X[r] = (nq < 15 && q < 16) ? s_g[wv][kq][q][nq % 3] : 0.f;
+        }
       }
     }
+    unsigned long long w_in = 0;
+    if constexpr (STAMP) { w_in = __builtin_readcyclecounter(); st_seg[3] += w_in - st_t; }
     for (int g0 = 0; g0 < cnt && !(dbg & 1u); g0 += 16) {
       const bool have = g0 + n < cnt;
       const int e = have ? (int)s_sub[wv][g0 + n] : 0;
@@ -381,24 +562,42 @@ __global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
       const unsigned long long lb = __builtin_amdgcn_ballot_w64(W.last > first_pos);
       const uint32_t stepmask = (uint32_t)((lb | (lb >> 16) | (lb >> 32) | (lb >> 48)) & 0xffffull);
       if (stepmask == 0u) continue;
+      if constexpr (STAMP) { st_groups += 1; st_steps += (unsigned long long)__popc(stepmask); }
       const float4 r0 = s_rec[e * 3 + 0], r1 = s_rec[e * 3 + 1];
       const float rb = s_rec[e * 3 + 2].x;
       W.u = r0.x; W.v = r0.y; W.ca = r0.z; W.cb = r0.w; W.cc = r1.x; W.o = r1.y; W.cr = r1.z; W.cg_ = r1.w; W.cbl = rb;
-      W.C1 = f32x4{0.f, 0.f, 0.f, 0.f};
-      W.C2 = f32x4{0.f, 0.f, 0.f, 0.f};
-      W.run16(stepmask);
-      // flush: lane (k, n) holds rows 4 k + i of column n.  C1 rows 0..5 = m0 mx my mxx | mxy myy; C2 rows 0..2 = colour
-      if (have) {
-        float* const acc = &s_acc[e * MACC];
-        if (k == 0) {
-          atomicAdd(acc + 0, W.C1[0]); atomicAdd(acc + 1, W.C1[1]); atomicAdd(acc + 2, W.C1[2]); atomicAdd(acc + 3, W.C1[3]);
-          atomicAdd(acc + 6, W.C2[0]); atomicAdd(acc + 7, W.C2[1]); atomicAdd(acc + 8, W.C2[2]);
-        } else if (k == 1) {
-          atomicAdd(acc + 4, W.C1[0]); atomicAdd(acc + 5, W.C1[1]);
+      if constexpr (MF) {
+        W.C1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        W.C2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        W.run16(stepmask);
+        // flush: lane (k, n) holds rows 4 k + i of column n.  C1 rows 0..5 = m0 mx my mxx | mxy myy; C2 rows 0..2 = colour
+        if (have) {
+          float* const acc = &s_acc[e * MACC];
+          if (k == 0) {
+            atomicAdd(acc + 0, W.C1[0]); atomicAdd(acc + 1, W.C1[1]); atomicAdd(acc + 2, W.C1[2]); atomicAdd(acc + 3, W.C1[3]);
+            atomicAdd(acc + 6, W.C2[0]); atomicAdd(acc + 7, W.C2[1]); atomicAdd(acc + 8, W.C2[2]);
+          } else if (k == 1) {
+            atomicAdd(acc + 4, W.C1[0]); atomicAdd(acc + 5, W.C1[1]);
+          }
+        }
+      } else {
+        W.s0 = W.sx = W.sy = W.sxx = W.sxy = W.syy = W.sr = W.sg = W.sb = 0.f;
+        W.run16_lane(stepmask);
+        // the four pixel rows k of an entry meet in registers (v_permlane32_swap / v_permlane16_swap: two instructions per
+        // sum) and row 0 adds them to the entry's accumulator.  64 lanes adding for themselves cost 4x the LDS float adds of
+        // the MFMA form, and those run at about a lane per cycle per CU: measured 153 / 277 us instead of 99 / 165.
+        const float f0 = sum_rows(W.s0), f1 = sum_rows(W.sx), f2 = sum_rows(W.sy), f3 = sum_rows(W.sxx), f4 = sum_rows(W.sxy);
+        const float f5 = sum_rows(W.syy), f6 = sum_rows(W.sr), f7 = sum_rows(W.sg), f8 = sum_rows(W.sb);
+        if (have && k == 0) {
+          float* const acc = &s_acc[e * MACC];
+          atomicAdd(acc + 0, f0); atomicAdd(acc + 1, f1); atomicAdd(acc + 2, f2); atomicAdd(acc + 3, f3); atomicAdd(acc + 4, f4);
+          atomicAdd(acc + 5, f5); atomicAdd(acc + 6, f6); atomicAdd(acc + 7, f7); atomicAdd(acc + 8, f8);
         }
       }
     }
+    if constexpr (STAMP) { st_t = __builtin_readcyclecounter(); st_walk += st_t - w_in; }
     __syncthreads();
+    if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[4] += t - st_t; st_t = t; }
 
     // ---- one thread per staged entry: moments -> d(u, v, conic), slot store
     if (tid < m) {
@@ -437,18 +636,60 @@ __global__ void __launch_bounds__(256, 5) blend_bwd_mfma_kernel(
         }
       }
     }
+    if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); st_seg[5] += t - st_t; st_t = t; }
+  }
+  if constexpr (STAMP) {
+    if (lane == 0) {
+      unsigned long long* o = stamps + (size_t)(tile * 4 + wv) * 14;
+      o[0] = st_wall; o[1] = wall_clock64(); o[2] = st_walk; o[3] = __builtin_readcyclecounter() - st_cyc; o[4] = st_groups; o[5] = st_steps;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) o[6 + q] = st_seg[q];
+      o[12] = st_p1; o[13] = st_p2;
+    }
   }
 }
+
+#define RTGS_BWD_ARGS                                                                                                             \
+  RasterParams p, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, const Splat *__restrict__ splats,       \
+      const float *__restrict__ out_color, const uint32_t *__restrict__ n_contrib, const int32_t *__restrict__ depth_index,          \
+      const uint32_t *__restrict__ depth_pos, const uint32_t *__restrict__ tile_last, const float *__restrict__ dL_dcolor,           \
+      const float *__restrict__ dL_ddepth, const uint32_t *__restrict__ gbase, uint32_t *__restrict__ slot_count,                    \
+      const BwdInfo *__restrict__ info, SplatGrad *__restrict__ grads, uint8_t *__restrict__ touched,                               \
+      const uint32_t *__restrict__ tile_mode, uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long *__restrict__ stamps
+#define RTGS_BWD_PASS                                                                                                             \
+  p, ranges, point_list, splats, out_color, n_contrib, depth_index, depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, \
+      info, grads, touched, tile_mode, t0, tn, dbg, stamps
+// the product kernel: entry-per-lane walk, pixel sums in lane accumulators
+__global__ void __launch_bounds__(256, 5) blend_bwd_entry_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false, false>(RTGS_BWD_PASS); }
+// round 4's form of it (pixel sums by v_mfma_f32_16x16x4_f32), kept for A-B runs: rtgs_raster_set_mfma_walk(8)
+__global__ void __launch_bounds__(256, 5) blend_bwd_entry_mfma_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false, true>(RTGS_BWD_PASS); }
+// either, leaving per-wave time stamps (tools/mfma_stamps.py)
+template <bool MF>
+__global__ void __launch_bounds__(256, 5) blend_bwd_entry_stamped_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<true, MF>(RTGS_BWD_PASS); }
+#undef RTGS_BWD_ARGS
+#undef RTGS_BWD_PASS
+
+// bits 0..2: timing decompositions (walk off / depth partials off / stores off - results are then wrong by construction);
+// bit 3: the MFMA form
+static int g_mfma_dbg = getenv("RTGS_MFMA_DEBUG") ? atoi(getenv("RTGS_MFMA_DEBUG")) : 0;
+static unsigned long long* g_mfma_stamps = nullptr;
+void set_mfma_debug(int bits) { g_mfma_dbg = bits; }
+void set_mfma_stamps(void* dev) { g_mfma_stamps = (unsigned long long*)dev; }
 
 void launch_blend_bwd_mfma(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                            const float* out_color, const uint32_t* n_contrib, const int32_t* depth_index,
                            const uint32_t* depth_pos, const uint32_t* tile_last, const float* dL_dcolor, const float* dL_ddepth,
                            const uint32_t* gbase, uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
                            const uint32_t* tile_mode, uint32_t t0, uint32_t tn, hipStream_t st) {
-  static const uint32_t dbg = getenv("RTGS_MFMA_DEBUG") ? (uint32_t)atoi(getenv("RTGS_MFMA_DEBUG")) : 0u;   // experiments only
-  hipLaunchKernelGGL(blend_bwd_mfma_kernel, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color,
-                     n_contrib, depth_index, depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched,
-                     tile_mode, t0, tn, dbg);
+  const uint32_t dbg = (uint32_t)g_mfma_dbg;
+#define RTGS_BWD_LAUNCH(KERNEL)                                                                                                      \
+  hipLaunchKernelGGL(KERNEL, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color, n_contrib, depth_index, \
+                     depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched, tile_mode, t0, tn, dbg,    \
+                     g_mfma_stamps)
+  const bool mf = (dbg & 8u) != 0;
+  if (g_mfma_stamps) { if (mf) RTGS_BWD_LAUNCH(blend_bwd_entry_stamped_kernel<true>); else RTGS_BWD_LAUNCH(blend_bwd_entry_stamped_kernel<false>); }
+  else { if (mf) RTGS_BWD_LAUNCH(blend_bwd_entry_mfma_kernel); else RTGS_BWD_LAUNCH(blend_bwd_entry_kernel); }
+#undef RTGS_BWD_LAUNCH
 }
 
 }  // namespace rtgs

@@ -798,3 +798,4 @@ def test_two_pixel_forward_is_bit_identical(kind, N, cam_i, mode, masked):
         scale = float(gd_a[k].abs().max()) + 1e-12
         assert ru.frac_bad(gd_b[k], gd_a[k], 1e-4 * scale) < 1e-3, k
         assert torch.equal(gd_a[k].reshape(N, -1).ne(0).any(1), gd_b[k].reshape(N, -1).ne(0).any(1)), k
+
