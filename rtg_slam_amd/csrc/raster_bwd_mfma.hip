@@ -386,11 +386,15 @@ __device__ __forceinline__ void blend_bwd_entry_body(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
-  const int tile = blockIdx.y * p.gx + blockIdx.x;
+  // Workgroup -> tile in launch order.  XCD-aware orders were measured in round 5 and change nothing here (contiguous bands of
+  // tiles per XCD: 92.3 / 139.2 us - the heavy rows of the image land on two XCDs; 4 x 4 tile blocks going round the XCDs:
+  // 88.6 / 143.3 us; launch order: 88.0 / 142.6 us): the records neighbouring tiles share are a tenth of this kernel's traffic.
+  const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  const int tile = by * p.gx + bx;
   // wave = 8x8 quadrant, step = 2x2 quad s of it, DPP row k = pixel of the quad; THIS lane's own pixel is (quad n, k)
   const int n = lane & 15, k = lane >> 4;
   const int qx0 = (wv & 1) * 8, qy0 = (wv >> 1) * 8;
-  const int px = blockIdx.x * TILE + qx0 + 2 * (n & 3) + (k & 1), py = blockIdx.y * TILE + qy0 + 2 * (n >> 2) + (k >> 1);
+  const int px = bx * TILE + qx0 + 2 * (n & 3) + (k & 1), py = by * TILE + qy0 + 2 * (n >> 2) + (k >> 1);
   const bool inside = px < p.W && py < p.H;
   const uint32_t HW = (uint32_t)(p.H * p.W);
   const uint32_t pix = inside ? (uint32_t)(py * p.W + px) : 0u;       // clamped: the loads below carry no branch
@@ -424,7 +428,7 @@ __device__ __forceinline__ void blend_bwd_entry_body(
   if constexpr (STAMP) st_p1 = __builtin_readcyclecounter() - st_cyc;   // the per-tile words are here
   const bool use_slots = use_slots_w != 0;
 
-  const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
+  const float tx0 = (float)(bx * TILE), ty0 = (float)(by * TILE);
   const float cxT = tx0 + 7.5f, cyT = ty0 + 7.5f;     // moments are taken about the tile centre
 
   MfmaWalk W;
@@ -530,8 +534,8 @@ __device__ __forceinline__ void blend_bwd_entry_body(
       asm volatile("" : "+v"(kq), "+v"(nq));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        W.pxc[j] = (float)(blockIdx.x * TILE + qx0 + 2 * j + (kq & 1));
-        W.pyc[j] = (float)(blockIdx.y * TILE + qy0 + 2 * j + (kq >> 1));
+        W.pxc[j] = (float)(bx * TILE + qx0 + 2 * j + (kq & 1));
+        W.pyc[j] = (float)(by * TILE + qy0 + 2 * j + (kq >> 1));
         const float x = W.pxc[j] - cxT, y = W.pyc[j] - cyT;
         if constexpr (MF) {
           // features 1 x y x^2 xy y^2 of the pixel, factored into a column and a row term per lane (lane & 15 = feature)
