@@ -484,9 +484,12 @@ def main():
                     "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic,
                     "avg_launch_ms": round(dom_ms, 4), "alg_bytes_per_launch": int(alg[dom]), "valu": valu,
                     "note": "achieved / peak / frac are the HBM roofline north_star asks for (algorithmic bytes over the live "
-                            "launch time).  `bound`: the tile walks reach neither roofline - ~5 % of HBM and (`valu` block) ~40 % of "
-                            "the MEASURED VALU issue peak: they wait on dependent DPP scans and LDS (DESIGN.md 6), so "
-                            "'latency'.  traffic / valu are null when "
+                            "launch time).  `bound`: the tile walks reach neither roofline - ~5 % of HBM and (`valu` block) under half "
+                            "of the MEASURED VALU issue peak.  Per-wave cycle stamps (tools/mfma_stamps.py, profiles/r05_bwd_stamps_*) "
+                            "say where a wave's life goes: half in the group loop (dependent DPP scans, one instruction per ~5 "
+                            "cycles per wave), a quarter in the three dependent memory round trips before it (per-tile words -> "
+                            "list -> records, ~2 us each under load), a tenth at the compaction barriers - so 'latency'.  "
+                            "traffic / valu are null when "
                             "profiles/*_latest.json were not measured on the current kernel sources or the workload is not "
                             "the default one", "source_sha16": src}
 
@@ -1167,7 +1170,7 @@ def cpu_baseline(g, cam, d0, d1, dev):
         ms.append(1e3 * (time.perf_counter() - th))
     c2_gpu_ms = sorted(ms[2:])[len(ms[2:]) // 2]
     c2_err = float((oh[0].detach().cpu() - o2[0].detach()).abs().max())
-    return {"value": round(1.0 / (raster_full + icp_s), 5), "unit": "frames/s", "cores": threads, "kind": "port",
+    return {"value": round(1.0 / (raster_full + icp_s), 5), "unit": "units/s", "cores": threads, "kind": "port",
             "extrapolated": False,
             "threads_by_stage": {"per_gaussian_stage_and_autograd": threads, "tile_blend_loop": min(threads, 4), "icp": threads},
             "note": "measured, nothing scaled; the tile loop of the oracle caps torch's intra-op threads at 4 (its tensors are "

@@ -55,15 +55,16 @@ int rtgs_raster_last_timings(float* ms12_host);
 int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms12_host);
 
 /* The backward's tile walk.  Three kernels exist (raster_bwd.hip, raster_bwd_mfma.hip):
- *  - MFMA walk (default): a lane holds one (pixel, ENTRY) pair - 16 entries x 4 pixels per wave step - T and the colour
- *    behind are in-row DPP scans, and the sums over the pixels run on the matrix cores (v_mfma_f32_16x16x4_f32);
+ *  - entry-per-lane walk (default): a lane holds one (pixel, ENTRY) pair - 16 entries x 4 pixels per wave step - T and the
+ *    colour behind are in-row DPP scans, and the sums over the pixels are kept per lane (round 5) or run on the matrix cores
+ *    (v_mfma_f32_16x16x4_f32: round 4's form, rtgs_raster_set_mfma_walk(8));
  *  - strip walk: pixel per lane, one entry per wave pass, tile-uniform (large footprints);
  *  - row-granular walk: pixel per lane, every 4x4 block walks its own sub-list (small footprints).
- * mode 0 (default) and 3 = MFMA walk on every tile; 1 = strip walk; 2 = row-granular walk; 4 = per-tile choice between
+ * mode 0 (default) and 3 = entry-per-lane walk on every tile; 1 = strip walk; 2 = row-granular walk; 4 = per-tile choice between
  * strip and row-granular from the share of the tile's list its 4x4 blocks need (ROWS_MAX_SHARE, raster_common.h) - the
  * round-3 behaviour, kept for A-B runs.  RTGS_BWD_WALK at load time.  Gradients of the walks agree to float rounding.
  * rtgs_raster_image_offsets: byte offsets inside the image buffer - [0] tile ranges (uint2 per tile), [1] n_contrib
- * (u32 per pixel), [2] BwdInfo, [3] tile walk (u32 per tile: bits 0..1 = 0 strip / 1 row-granular / 2 MFMA, bits 8.. the
+ * (u32 per pixel), [2] BwdInfo, [3] tile walk (u32 per tile: bits 0..1 = 0 strip / 1 row-granular / 2 entry-per-lane, bits 8.. the
  * measured share in 1/1000), [4] total size, [5] list position of every pixel's depth owner (u32 per pixel). */
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* ctx, int mode);
 /* One-pass binning (round 4; default on, RTGS_BIN_ONEPASS=0 at load time turns it off): where the geometry buffer gives
@@ -74,10 +75,11 @@ void rtgs_raster_set_onepass_ctx(rtgs_ctx* ctx, int on);
 /* The forward's tile walk: 1 (default) = one pixel per lane, 2 = two pixels per lane (128 threads per tile; round 5: built,
  * bit-identical, measured slower on small footprints - kept for A-B runs).  PROCESS-WIDE; RTGS_FWD_KERNEL at load time. */
 void rtgs_raster_set_fwd_kernel(int which);
-/* Timing decompositions of the MFMA backward walk: bits 0..2 switch parts of the kernel OFF (1 walk, 2 depth partials,
- * 4 stores) - results are then wrong by construction.  PROCESS-WIDE; RTGS_MFMA_DEBUG at load time. */
+/* The entry-per-lane backward walk: bit 3 (8) = round 4's form, the pixel sums by two MFMAs per step instead of lane
+ * accumulators (gradients agree to rounding); bits 0..2 switch parts of the kernel OFF for timing decompositions (1 walk,
+ * 2 depth partials, 4 stores) - results are then wrong by construction.  PROCESS-WIDE; RTGS_MFMA_DEBUG at load time. */
 void rtgs_raster_set_mfma_walk(int bits);
-/* Per-wave time stamps of the MFMA backward walk (tools/mfma_stamps.py): `dev` = device uint64[tiles x 4 waves x 14] or NULL
+/* Per-wave time stamps of the entry-per-lane backward walk (tools/mfma_stamps.py): `dev` = device uint64[tiles x 4 waves x 14] or NULL
  * (default: the product kernel carries no stamping code).  Per wave: wall clock (100 MHz) at entry and exit, shader cycles
  * in the group loop and in the kernel, groups walked, quad steps entered, cycles of the six other phases.  PROCESS-WIDE. */
 void rtgs_raster_set_mfma_stamps(void* dev);

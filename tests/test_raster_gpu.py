@@ -799,3 +799,36 @@ def test_two_pixel_forward_is_bit_identical(kind, N, cam_i, mode, masked):
         assert ru.frac_bad(gd_b[k], gd_a[k], 1e-4 * scale) < 1e-3, k
         assert torch.equal(gd_a[k].reshape(N, -1).ne(0).any(1), gd_b[k].reshape(N, -1).ne(0).any(1)), k
 
+
+@pytest.mark.parametrize("kind,N,cam_i,masked", [("volume", 3000, 0, False), ("volume", 20000, 1, True), ("surface", 60000, 2, False),
+                                                 ("volume", 150000, 3, True), ("surface", 150000, 3, False)])
+def test_lane_sums_equal_the_matrix_core_sums(kind, N, cam_i, masked):
+    """The entry-per-lane backward keeps the pixel sums in lane accumulators (round 5, blend_bwd_entry_kernel); round 4 formed
+    them with two v_mfma_f32_16x16x4_f32 per step (blend_bwd_entry_mfma_kernel, rtgs_raster_set_mfma_walk(8)).  Same alpha,
+    same scans, same carries - the gradients differ by the order of the sums over a quad's four pixels and of the LDS adds:
+    as much as two runs of either form differ from each other, within a factor."""
+    from rtg_slam_amd import _lib
+    lib = _lib.load()
+    cam = [synth.CameraSpec(70, 90, 80.0, 80.0, 44.5, 34.5), synth.CameraSpec(128, 192, 160.0, 160.0, 95.5, 63.5),
+           synth.CameraSpec(240, 320, 200.0, 200.0, 159.5, 119.5), synth.CameraSpec(339, 601, 300.0, 300.0, 300.0, 169.0)][cam_i]
+    g, s = ru.make_scene(N, cam, seed=33, pose_seed=4, r_range=(0.01, 0.08))
+    if kind == "surface":
+        g = synth.surface_gaussians(N, cam, seed=11)
+    mask = None
+    if masked:
+        gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+        mask = (torch.rand(gy, gx, generator=torch.Generator().manual_seed(8)) < 0.6).int()
+    gen = torch.Generator().manual_seed(9)
+    grads = (torch.randn(3, cam.H, cam.W, generator=gen), torch.randn(1, cam.H, cam.W, generator=gen))
+    try:
+        lib.rtgs_raster_set_mfma_walk(8)
+        out_a, gd_a = ru.hip_run(s, g, tile_mask=mask, grads=grads)
+        lib.rtgs_raster_set_mfma_walk(0)
+        out_b, gd_b = ru.hip_run(s, g, tile_mask=mask, grads=grads)
+    finally:
+        lib.rtgs_raster_set_mfma_walk(0)
+    assert float((out_a[6] != 1).float().mean()) > 0.2
+    for k in ru.FIELDS:
+        scale = float(gd_a[k].abs().max()) + 1e-12
+        assert ru.frac_bad(gd_b[k], gd_a[k], 2e-5 * scale) < 1e-4, (k, float((gd_b[k] - gd_a[k]).abs().max()) / scale)
+        assert torch.equal(gd_a[k].reshape(N, -1).ne(0).any(1), gd_b[k].reshape(N, -1).ne(0).any(1)), k
