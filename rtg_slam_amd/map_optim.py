@@ -987,6 +987,7 @@ class ShardedMapOptimizer:
             gd = self.activate_fn(leaves["raw8"])
         gd["xyz"] = leaves["xyz"]
         gd["shs"] = leaves["shs"].view(N, 16, 3)
+        gd["raw8"] = leaves["raw8"]          # the raw leaf itself, for loss terms on raw values (the attach regulariser)
         loss = loss_fn(gd)
         mark("forward_and_loss")
         grads = torch.autograd.grad(loss, [leaves[n] for n, _, _ in BLOCKS], allow_unused=True)

@@ -97,10 +97,11 @@ class TorchOps:
                                   None if render_mask is None else render_mask.bool())
             if ai is not None and N > t0:                                  # attach regulariser, mapper.py:384-401
                 sel = torch.sigmoid(ai["raw8"][:, 0]) < 0.9
-                if bool(sel.any()):
-                    raw8 = opt.state["raw8"]["p"]          # the leaf is a detached copy: re-derive from gd for the gradient
-                    sc = torch.log(gd["scales"][t0:N][sel])
-                    loss = loss + 1000 * (((sc - ai["raw8"][sel, 1:4]) ** 2).mean() + ((gd["xyz"][t0:N][sel] - ai["xyz"][sel]) ** 2).mean())
+                if bool(sel.any()):                       # raw scaling, position AND raw rotation (mapper.py:389-400)
+                    raw8 = gd["raw8"][t0:N]
+                    l2 = lambda x, y: ((x - y) ** 2).mean()
+                    loss = loss + 1000 * (l2(raw8[sel, 1:4], ai["raw8"][sel, 1:4]) + l2(gd["xyz"][t0:N][sel], ai["xyz"][sel]) +
+                                          l2(raw8[sel, 4:8], ai["raw8"][sel, 4:8]))
             return loss
         loss = opt.step(loss_fn)
         g = grads.get("shs")

@@ -29,6 +29,22 @@ def _stream(n, seed=4):
     return out
 
 
+def _changing_stream(n, seed=4):
+    """The stream above with a scene CHANGE from frame 2 on: a patch of the view comes 0.25 m closer and one moves 0.3 m away (the stable
+    Gaussians there collect depth-error strikes until error_gaussians_remove deletes them, mapper.py:560-575) and another patch
+    changes colour (colour-error strikes until they are released, :576-592)."""
+    out = []
+    for fid, (d, c, c2w) in enumerate(_stream(n, seed)):
+        if fid >= 2:
+            d = d.clone()
+            d[8:26, 6:26] -= 0.25                                    # [H, W, 1]
+            d[30:44, 6:26] += 0.3                                    # ... and one moves away
+            c = synth.box_room_color(CAM, c2w, d)
+            c[:, 28:44, 36:60] = (c[:, 28:44, 36:60] + 0.5) % 1.0
+        out.append((d, c, c2w))
+    return out
+
+
 def _frame_map(depth, color, frame, args):
     K = frame.K
     fm = so.frame_preprocess(depth.reshape(CAM.H, CAM.W, 1), K, args.min_depth, 8.0, False, args.invalid_confidence_thresh)
@@ -166,3 +182,85 @@ def test_save_model_writes_the_reference_snapshot_files(tmp_path):
     assert np.array_equal(st["confidence"].reshape(-1), o.aux["confidence"][:o.n_frozen, 0].numpy())
     names, _ = iof._read_ply_table(base + "_sibr.ply")                      # the viewer's files carry no confidence column
     assert "confidence" not in names and "confidence" in iof._read_ply_table(base + ".ply")[0]
+
+
+def _against_the_references_own_mapping(golden, stream_fn, every_frame):
+    """tests/golden/mapping_ref.npz holds the states of the reference's OWN Mapping (SLAM/multiprocess/mapper.py with its
+    gaussian_pointcloud.py / render.py / utils.py, run on the CPU from /root/reference by oracle/gen_mapping_golden.py) after
+    every frame of this file's stream: gaussians_add on an empty map, local optimisations, two keyframe-triggered global
+    optimisations, fixes, deletions, error counters, and after the final global optimisation of slam.py:129.  Both sides use the same oracle rasterizer / k-NN / error accumulation
+    and the same random streams, so what is compared is the lifecycle itself: the sizes of both clouds EXACTLY, every raw
+    tensor of every Gaussian to float tolerance (the reference steps torch.optim.Adam over six tensors, this package its
+    block-SoA Adam: same arithmetic, different summation order in the loss), the optimised frames and the keyframes."""
+    import random
+    ref = np.load(os.path.join(ROOT, "tests", "golden", golden))
+    n_frames, seed = int(ref["n_frames"][0]), int(ref["seed"][0])
+    args = _args()
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    ops = TorchOps(args)
+    ops.gen = None                               # torch's default generator, as SLAM/utils.py:173 uses it
+    m = mp.Mapping(args, torch.device("cpu"), ops=ops, capacity=600)
+    m.rng = random                               # python's global stream, as mapper.py:178, 682
+    worst = 0.0
+
+    def compare(tag_prefix):
+        nonlocal worst
+        o = m.opt
+        nu, ns = (int(v) for v in ref[f"{tag_prefix}_sizes"])
+        assert (o.N - o.n_frozen, o.n_frozen) == (nu, ns), (tag_prefix, (o.N - o.n_frozen, o.n_frozen), (nu, ns))
+        P = o.params[:o.N]
+        for tag, r0, r1 in (("s", 0, o.n_frozen), ("u", o.n_frozen, o.N)):
+            if r1 == r0:
+                continue
+            mine = {"xyz": P[r0:r1, 0:3], "f_dc": P[r0:r1, 3:6].reshape(-1, 1, 3), "f_rest": P[r0:r1, 6:51].reshape(-1, 15, 3),
+                    "opacity": P[r0:r1, 51:52], "scaling": P[r0:r1, 52:55], "rotation": P[r0:r1, 55:59],
+                    "confidence": o.aux["confidence"][r0:r1], "add_tick": o.aux["add_tick"][r0:r1],
+                    "depth_error_counter": o.aux["depth_error_counter"][r0:r1], "color_error_counter": o.aux["color_error_counter"][r0:r1]}
+            order_m = order_w = None
+            if not every_frame:
+                # the reference RE-APPENDS a released Gaussian to the end of the stable cloud (mapper.py:286-295), this package
+                # leaves the row where it is: same rows, another order - compared in the order of their positions
+                key = lambda x: np.lexsort(np.round(x.numpy().astype(np.float64), 3).T[::-1])
+                order_m = torch.from_numpy(key(mine["xyz"]))
+                order_w = torch.from_numpy(key(torch.from_numpy(ref[f"{tag_prefix}_{tag}_xyz"])))
+            for k, v in mine.items():
+                want = torch.from_numpy(ref[f"{tag_prefix}_{tag}_{k}"]).to(v.dtype)
+                assert want.shape == v.shape, (tag_prefix, tag, k, want.shape, v.shape)
+                if order_m is not None:
+                    v, want = v[order_m], want[order_w]
+                if k in ("confidence", "add_tick", "depth_error_counter", "color_error_counter"):
+                    assert torch.equal(v, want), (tag_prefix, tag, k)
+                else:
+                    err = float((v - want).abs().max())
+                    worst = max(worst, err)
+                    assert err < 2e-4, (tag_prefix, tag, k, err)
+
+    for fid, (d, c, c2w) in enumerate(stream_fn(n_frames)):
+        fr = mp.Frame(CAM, c2w, torch.device("cpu"), uid=fid)
+        m.mapping(fr, _frame_map(d, c, fr, args), fid)
+        m.get_render_output(fr)
+        o = m.opt
+        assert (o.N - o.n_frozen, o.n_frozen) == tuple(int(v) for v in ref[f"f{fid}_sizes"]), fid
+        if every_frame or fid == n_frames - 1:
+            compare(f"f{fid}")
+        m.time += 1
+    assert m.optimize_frames_ids == ref["optimize_frames_ids"].tolist()
+    assert m.keyframe_ids == ref["keyframe_ids"].tolist()
+    m.global_optimization(select_keyframe_num=-1, is_end=True)           # slam.py:129
+    compare("final")
+    print(golden, "- largest difference to the reference's own Mapping over the stream:", worst)
+    return m
+
+
+def test_lifecycle_matches_the_references_own_mapping():
+    _against_the_references_own_mapping("mapping_ref.npz", _stream, True)
+
+
+def test_lifecycle_matches_the_references_own_mapping_on_a_changing_scene():
+    """Fifteen frames with a scene change from frame 2 on (_changing_stream): colour-error strikes release stable Gaussians
+    (confidence 0, new tick - mapper.py:576-592), a large fix at frame 11, six keyframes; sizes after every frame, all
+    tensors and counters after the last one and after the final global optimisation."""
+    m = _against_the_references_own_mapping("mapping_ref_changing.npz", _changing_stream, False)
+    assert m.stats["released"] > 0
