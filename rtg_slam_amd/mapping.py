@@ -266,6 +266,27 @@ class Mapping:
     def get_keyframe_num(self) -> int:
         return len(self.keyframe_list)
 
+    @property
+    def get_total_num(self) -> int:                                       # mapper.py:1128-1130
+        return self.get_stable_num + self.get_unstable_num
+
+    @property
+    def get_total_iter(self) -> int:                                      # mapper.py:1116-1118
+        return self.iter + self.time * self.args.gaussian_update_iter
+
+    @property
+    def get_curr_frame(self):                                             # mapper.py:1132-1134
+        return self.optimize_frames_ids[-1]
+
+    def update_poses(self, new_poses):
+        """mapper.py:134-141: poses corrected by the tracker's back end (tracker.py:69-74; None without one) replace those of
+        the frames the map still optimises against - the window and the keyframes.  Frame.updatePose bumps the frame's pose
+        version, so renders cached for the old pose are not reused."""
+        if new_poses is None:
+            return
+        for frame in list(self.processed_frames) + list(self.keyframe_list):
+            frame.updatePose(new_poses[frame.uid])
+
     def aux(self, name, rows="all"):
         o = self.opt
         r0, r1 = {"all": (0, o.N), "stable": (0, o.n_frozen), "unstable": (o.n_frozen, o.N)}[rows]
@@ -558,6 +579,20 @@ class Mapping:
             c[nf0:nf0 + k] = torch.clip(c[nf0:nf0 + k], max=self.args.stable_confidence_thres)
             self.stats["fixed"] += k
 
+    def gaussians_release(self, mask, count=None):
+        """mapper.py:286-295: the stable Gaussians under `mask` (one entry per stable row) start over - confidence 0, tick =
+        now.  The reference removes them from the stable cloud and re-appends them to its end; here the rows stay where they
+        are (row order carries no meaning; tests compare the two in a canonical order)."""
+        o = self.opt
+        nf = o.n_frozen
+        mask = mask.reshape(-1).bool()
+        n = int(mask.sum()) if count is None else int(count)
+        if n > 0:
+            conf, tick = o.aux["confidence"][:nf, 0], o.aux["add_tick"][:nf, 0]
+            o.aux["confidence"][:nf, 0] = torch.where(mask, torch.zeros_like(conf), conf)
+            o.aux["add_tick"][:nf, 0] = torch.where(mask, torch.full_like(tick, int(self.time)), tick)
+            self.stats["released"] += n
+
     def gaussians_delete(self, unstable=True):
         """mapper.py:298-335: too big (radius > 10 x mean), or - unstable only - older than the time window."""
         o = self.opt
@@ -619,9 +654,7 @@ class Mapping:
         crel = (ccnt[:nf, 0] >= delete_thresh) & ~ddel
         n_del, n_rel = torch.stack([ddel.sum(), crel.sum()]).tolist()
         if n_rel > 0:
-            o.aux["confidence"][:nf, 0] = torch.where(crel, torch.zeros_like(o.aux["confidence"][:nf, 0]), o.aux["confidence"][:nf, 0])
-            o.aux["add_tick"][:nf, 0] = torch.where(crel, torch.full_like(o.aux["add_tick"][:nf, 0], int(self.time)), o.aux["add_tick"][:nf, 0])
-            self.stats["released"] += n_rel
+            self.gaussians_release(crel, count=n_rel)
         if n_del > 0:
             full = torch.zeros(o.N, dtype=torch.bool, device=self.device)
             full[:nf] = ddel

@@ -264,3 +264,34 @@ def test_lifecycle_matches_the_references_own_mapping_on_a_changing_scene():
     tensors and counters after the last one and after the final global optimisation."""
     m = _against_the_references_own_mapping("mapping_ref_changing.npz", _changing_stream, False)
     assert m.stats["released"] > 0
+
+
+def test_update_poses_and_the_small_accessors():
+    """mapper.py:134-141 (poses corrected by a back end reach the window's frames and the keyframes, and invalidate their
+    cached renders), :286-295 (release), :1116-1134 (counters)."""
+    args = _args()
+    m, ops, log = _run(4, args)
+    assert m.get_total_num == m.get_stable_num + m.get_unstable_num == m.opt.N
+    assert m.get_curr_frame == m.optimize_frames_ids[-1] and m.get_total_iter == m.iter + m.time * args.gaussian_update_iter
+    m.update_poses(None)                                                  # no back end: nothing moves (tracker.py:69-74)
+    frames = {f.uid: f for f in list(m.processed_frames) + list(m.keyframe_list)}
+    before = {u: (f.pose_version, f.c2w.clone()) for u, f in frames.items()}
+    new = {u: f.c2w.numpy().copy() for u, f in frames.items()}
+    moved = sorted(frames)[-1]
+    new[moved][:3, 3] += 0.01
+    m.update_poses(new)
+    for u, f in frames.items():
+        assert f.pose_version > before[u][0]               # a keyframe still in the window is visited twice, as in the reference
+        assert torch.allclose(f.c2w, torch.as_tensor(new[u]))
+    assert abs(float(frames[moved].c2w[0, 3] - before[moved][1][0, 3]) - 0.01) < 1e-12
+    # release: confidence 0 and a new tick for the masked stable rows, nothing moves
+    nf = m.opt.n_frozen
+    assert nf > 4
+    mask = torch.zeros(nf, dtype=torch.bool)
+    mask[1] = mask[3] = True
+    P = m.opt.params[:m.opt.N].clone()
+    m.time = 9
+    m.gaussians_release(mask)
+    assert torch.equal(m.opt.params[:m.opt.N], P)
+    assert float(m.opt.aux["confidence"][1, 0]) == 0 and float(m.opt.aux["confidence"][3, 0]) == 0
+    assert int(m.opt.aux["add_tick"][1, 0]) == 9 and int(m.opt.aux["add_tick"][0, 0]) != 9
