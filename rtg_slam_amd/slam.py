@@ -66,6 +66,11 @@ class Tracker:
     def update_last_status(self, frame, render_depth, frame_depth, render_normal, frame_normal):
         self.icp_tracker.update_last_status(frame, render_depth, frame_depth, render_normal, frame_normal)
 
+    def get_new_poses(self):
+        """tracker.py:69-74: the trajectory as a back end (ORB-SLAM2 in the reference, out of scope here) has corrected it,
+        or None without one - Mapping.update_poses(None) then leaves every frame where it is."""
+        return None
+
 
 def ate_rmse(pose_es, pose_gt, align: bool = False) -> float:
     """RMSE of the translation error; align=True first fits the rigid transform (Horn) the reference's eval applies."""
@@ -99,6 +104,7 @@ def run_sequence(cam, stream: Iterable, args, device, mapper: Optional[Mapping] 
         frame_map = tracker.map_preprocess(frame, depth, color, frame_id)
         tracker.tracking(frame, frame_map, pose_gt=gt_c2w, init_pose=gt_c2w if frame_id == 0 else None)
         t1 = time.perf_counter()                                # predict_pose returned a host pose: the tracker is done
+        mapper.update_poses(tracker.get_new_poses())            # slam.py:76-77
         mapper.mapping(frame, frame_map, frame_id)
         mm = mapper.get_render_output(frame)
         # update_last_status fills holes of the model depth IN PLACE (icp.py:397-415): hand it a copy, the render is cached
