@@ -73,7 +73,7 @@ class RasterContext:
         _lib.load().rtgs_raster_force_sort_path_ctx(self.ptr, int(bool(enable)))
 
     def set_bwd_walk(self, mode: int):
-        """0 / 3 = MFMA walk (default), 1 = strip walk, 2 = row-granular walk, 4 = per-tile choice of 1 / 2 (round 3)."""
+        """0 / 3 = entry-per-lane walk (default), 1 = strip walk, 2 = row-granular walk, 4 = per-tile choice of 1 / 2 (round 3)."""
         _lib.load().rtgs_raster_set_bwd_walk_ctx(self.ptr, int(mode))
 
     def set_onepass(self, enable: bool):
@@ -113,7 +113,7 @@ class RasterContext:
 
 def image_buffer_views(img: torch.Tensor, H: int, W: int):
     """Views into a forward's image buffer (tests / diagnostics; layout: rtgs_raster_image_offsets): tile ranges
-    int32[tiles, 2], n_contrib int32[H*W], the backward's walk per tile int32[tiles] (0 strip, 1 row-granular, 2 MFMA), the list position
+    int32[tiles, 2], n_contrib int32[H*W], the backward's walk per tile int32[tiles] (0 strip, 1 row-granular, 2 entry-per-lane), the list position
     of every pixel's depth owner int32[H*W] and the share of
     the tile's list its 4x4 blocks need on average (what the choice is made from)."""
     off = (C.c_size_t * 6)()
