@@ -1,4 +1,4 @@
-"""The backward's three tile walks: the entry-per-lane MFMA walk (raster_bwd_mfma.hip, the default), the tile-uniform
+"""The backward's three tile walks: the entry-per-lane walk (raster_bwd_mfma.hip, the default; lane sums since round 5), the tile-uniform
 strip walk and the row-granular walk (raster_bwd.hip; mode 4 chooses between those two per tile from the measured share of
 the list the 4x4 blocks need).  Here each is forced on every tile of the same scenes and compared
 
@@ -79,8 +79,8 @@ def test_the_two_walks_agree_and_match_the_oracle(kind, N, cam, depth, masked):
     out_s, gd_s, m_s = _run(s, g, grads, 1, mask)
     out_r, gd_r, m_r = _run(s, g, grads, 2, mask)
     out_a, gd_a, m_a = _run(s, g, grads, 4, mask)              # per-tile choice between strip and rows (round 3's default)
-    out_d, gd_d, m_d = _run(s, g, grads, 0, mask)              # the default: MFMA walk
-    out_m, gd_m, m_m = _run(s, g, grads, 3, mask)              # entry-per-lane MFMA walk on every tile
+    out_d, gd_d, m_d = _run(s, g, grads, 0, mask)              # the default: entry-per-lane walk
+    out_m, gd_m, m_m = _run(s, g, grads, 3, mask)              # entry-per-lane walk on every tile
     assert int(m_s.sum()) == 0 and int(m_r.sum()) == m_r.numel() and bool((m_m == 2).all()) and bool((m_d == 2).all())
     for a, b in zip(out_s, out_r):
         assert torch.equal(a, b)                       # the forward does not depend on the backward's walk
