@@ -72,7 +72,14 @@ class _Rasterizer(torch.nn.Module):
             z = torch.zeros
             return (z(3, H, W), z(1, H, W), -torch.ones(1, H, W, dtype=torch.int32), -torch.ones(1, H, W, dtype=torch.int32),
                     z(1, H, W), z(1, H, W), torch.ones(1, H, W))
-        return ro.rasterize(st, means3D, opacities, shs, scales, rotations, normal_w, tile_mask)
+        out = ro.rasterize(st, means3D, opacities, shs, scales, rotations, normal_w, tile_mask)
+        # A custom autograd Function hands EVERY input a gradient tensor (zeros where nothing was rendered, e.g. under an empty
+        # tile mask); plain autograd leaves `.grad` None there and mapper.py:455 dereferences it.  Tie the inputs in with an
+        # exact zero so that the stand-in behaves like the Function it stands for (values unchanged: x + 0.0).
+        tie = sum((t * 0.0).sum() for t in (means3D, opacities, shs, scales, rotations) if t is not None and t.requires_grad)
+        if torch.is_tensor(tie):
+            out = tuple(o + tie if o.is_floating_point() else o for o in out)
+        return out
 
 
 def _dist_cuda2(points):

@@ -63,6 +63,15 @@ def _args(**kw):
     return mp.replica_args(**base)
 
 
+def _args_tum(**kw):
+    """The same reduced schedule on configs/tum_base.yaml's values (feature_lr 0.001, scaling_lr 0.02, the *_lr_coef 1.0)."""
+    base = dict(uniform_sample_num=260, gaussian_update_iter=4, gaussian_update_frame=2, memory_length=3,
+                stable_confidence_thres=2.0, unstable_time_window=3, max_depth=8.0, keyframe_trans_thes=0.015,
+                final_global_iter=2, seed=3)
+    base.update(kw)
+    return mp.tum_args(**base)
+
+
 def _run(n_frames, args, final=False):
     ops = TorchOps(args)
     m = mp.Mapping(args, torch.device("cpu"), ops=ops, capacity=400)
@@ -184,7 +193,7 @@ def test_save_model_writes_the_reference_snapshot_files(tmp_path):
     assert "confidence" not in names and "confidence" in iof._read_ply_table(base + ".ply")[0]
 
 
-def _against_the_references_own_mapping(golden, stream_fn, every_frame):
+def _against_the_references_own_mapping(golden, stream_fn, every_frame, args_fn=None):
     """tests/golden/mapping_ref.npz holds the states of the reference's OWN Mapping (SLAM/multiprocess/mapper.py with its
     gaussian_pointcloud.py / render.py / utils.py, run on the CPU from /root/reference by oracle/gen_mapping_golden.py) after
     every frame of this file's stream: gaussians_add on an empty map, local optimisations, two keyframe-triggered global
@@ -195,7 +204,7 @@ def _against_the_references_own_mapping(golden, stream_fn, every_frame):
     import random
     ref = np.load(os.path.join(ROOT, "tests", "golden", golden))
     n_frames, seed = int(ref["n_frames"][0]), int(ref["seed"][0])
-    args = _args()
+    args = (args_fn or _args)()
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
@@ -258,6 +267,12 @@ def test_lifecycle_matches_the_references_own_mapping():
     _against_the_references_own_mapping("mapping_ref.npz", _stream, True)
 
 
+def test_lifecycle_matches_the_references_own_mapping_with_the_tum_rates():
+    """The 7-frame stream with configs/tum_base.yaml's learning rates and coefficients: pins the learning-rate columns of the
+    local, the keyframe-triggered and the final global optimisation for the second argument set."""
+    _against_the_references_own_mapping("mapping_ref_tum.npz", _stream, True, _args_tum)
+
+
 def test_lifecycle_matches_the_references_own_mapping_on_a_changing_scene():
     """Fifteen frames with a scene change from frame 2 on (_changing_stream): colour-error strikes release stable Gaussians
     (confidence 0, new tick - mapper.py:576-592), a large fix at frame 11, six keyframes; sizes after every frame, all
@@ -295,3 +310,44 @@ def test_update_poses_and_the_small_accessors():
     assert torch.equal(m.opt.params[:m.opt.N], P)
     assert float(m.opt.aux["confidence"][1, 0]) == 0 and float(m.opt.aux["confidence"][3, 0]) == 0
     assert int(m.opt.aux["add_tick"][1, 0]) == 9 and int(m.opt.aux["add_tick"][0, 0]) != 9
+
+
+@pytest.mark.parametrize("leaf,build", [("replica_base.yaml", "replica_args"), ("tum_base.yaml", "tum_args")])
+def test_argument_sets_are_the_references_config_files(leaf, build):
+    """replica_args() / tum_args() against configs/base.yaml overlaid with the dataset's base file (the `parent:` chain the
+    reference's loader follows), read from /root/reference where it lies: every value the two have in common is equal, and
+    every name Mapping / Tracker / Renderer / IcpTracker read from `args` is in the argument set.  (Build container only.)"""
+    import yaml
+    cfg_dir = "/root/reference/configs"
+    if not os.path.isdir(cfg_dir):
+        pytest.skip("reference tree not present")
+
+    def load(path):
+        d = yaml.safe_load(open(path))
+        parent = d.pop("parent", None)
+        base = load(os.path.join("/root/reference", parent)) if parent not in (None, "None", "") else {}
+        base.update(d)
+        return base
+    ref = load(os.path.join(cfg_dir, leaf))
+    mine = vars(getattr(mp, build)())
+    common = sorted(set(ref) & set(mine))
+    assert len(common) >= 45, common
+    for k in common:
+        a, b = ref[k], mine[k]
+        if isinstance(a, (list, tuple)):
+            assert [float(x) for x in a] == [float(x) for x in b], k
+        elif isinstance(a, (bool, str)):
+            assert a == b, (k, a, b)
+        else:
+            assert float(a) == float(b), (k, a, b)
+    # what the ported classes read and the files define must all be there
+    needed = {"uniform_sample_num", "stable_confidence_thres", "unstable_time_window", "memory_length", "gaussian_update_iter",
+              "gaussian_update_frame", "position_lr", "feature_lr", "opacity_lr", "scaling_lr", "rotation_lr", "final_global_iter",
+              "feature_lr_coef", "scaling_lr_coef", "rotation_lr_coef", "keyframe_trans_thes", "keyframe_theta_thes",
+              "add_depth_thres", "add_color_thres", "add_transmission_thres", "transmission_sample_ratio", "error_sample_ratio",
+              "history_merge_max_weight", "renderer_opaque_threshold", "renderer_normal_threshold", "renderer_depth_threshold",
+              "color_sigma", "icp_downscales", "icp_downscale_iters", "icp_damping", "icp_distance_threshold",
+              "icp_normal_threshold", "icp_sample_distance_threshold", "icp_sample_normal_threshold", "icp_fail_threshold",
+              "min_depth", "max_depth", "invalid_confidence_thresh", "global_keyframe_num", "color_weight", "depth_weight",
+              "ssim_weight", "normal_weight", "init_opacity", "xyz_factor", "max_radius", "min_radius", "scale_factor"}
+    assert needed <= set(common), sorted(needed - set(common))
