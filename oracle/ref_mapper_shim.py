@@ -95,10 +95,12 @@ def _knn_points(p1, p2, K=3, **kw):
 
 
 def install():
-    """Stub / oracle-back everything the reference's mapper imports; returns the reference's mapper module."""
+    """Stub / oracle-back everything the reference's mapper imports; returns the reference's mapper module.
+    PROCESS-WIDE and not undone (sys.modules entries for the four native modules, torch.Tensor.cuda): call it from a process
+    of its own (oracle/gen_mapping_golden.py), never from inside the test suite."""
     ref_shim.install_stubs()
     sys.modules["pytorch3d.ops"].knn_points = _knn_points
-    for name in ("simple_knn", "simple_knn._C", "cuda_utils", "cuda_utils._C", "diff_gaussian_rasterization_depth", "tqdm_stub"):
+    for name in ("simple_knn", "simple_knn._C", "cuda_utils", "cuda_utils._C", "diff_gaussian_rasterization_depth"):
         sys.modules[name] = types.ModuleType(name)
     sys.modules["simple_knn"].__path__ = []
     sys.modules["cuda_utils"].__path__ = []
