@@ -211,10 +211,14 @@ def inverse_sigmoid(x):
 
 def compute_rot(target_vec: torch.Tensor) -> torch.Tensor:
     """compute_rot((0,0,1), normal) of SLAM/utils.py:216-221 + quaternion_from_axis_angle (general_utils.py:185-191):
-    the quaternion (w, x, y, z) that turns the z axis onto `target_vec`."""
+    the quaternion (w, x, y, z) that turns the z axis onto `target_vec`.
+    One quirk is kept because the maps would differ otherwise: the reference calls `torch.cross(init_vec, target_vec)`
+    WITHOUT a dim, and torch's legacy rule takes the FIRST dimension of size 3 - for a batch of exactly three points that is
+    the batch dimension, not the vector one (found by oracle/fuzz_mapping_vs_reference.py; the three Gaussians then start
+    turned about the z axis).  add_empty_points is called per sampling pass, so `target_vec` here is ONE pass's points."""
     z = torch.zeros_like(target_vec)
     z[:, 2] = 1.0
-    axis = torch.linalg.cross(z, target_vec)
+    axis = torch.linalg.cross(z, target_vec, dim=0 if target_vec.shape[0] == 3 else 1)
     axis = axis / (torch.norm(axis, p=2, dim=-1, keepdim=True) + 1e-8)
     angle = torch.acos(target_vec[:, 2:3])
     axis = axis / (torch.norm(axis, p=2, dim=-1, keepdim=True) + 1e-8)
@@ -378,14 +382,22 @@ class Mapping:
         parts = [p for p in parts if p[0].shape[0] > 0]
         if not parts:
             return None
-        xyz, normal, color = (torch.cat([p[k] for p in parts], 0) for k in range(3))
-        normal = normal / (torch.norm(normal, p=2, dim=-1, keepdim=True) + 1e-8)
-        n = xyz.shape[0]
         a = self.args
         same = a.xyz_factor[0] == 1 and a.xyz_factor[1] == 1 and a.xyz_factor[2] == 1
-        rots = torch.zeros(n, 4, device=xyz.device) if same else compute_rot(normal)
-        if same:
-            rots[:, 0] = 1
+        xyz, color = (torch.cat([p[k] for p in parts], 0) for k in (0, 2))
+        # normals and rotations PER sampling pass, as add_empty_points is called (mapper.py:754, 794)
+        normals, rot_parts = [], []
+        for p in parts:
+            nrm = p[1] / (torch.norm(p[1], p=2, dim=-1, keepdim=True) + 1e-8)
+            normals.append(nrm)
+            if same:
+                r = torch.zeros(nrm.shape[0], 4, device=nrm.device)
+                r[:, 0] = 1
+            else:
+                r = compute_rot(nrm)
+            rot_parts.append(r)
+        normal, rots = torch.cat(normals, 0), torch.cat(rot_parts, 0)
+        n = xyz.shape[0]
         return dict(xyz=xyz.contiguous(), normal=normal, color=color, rots=rots,
                     opacity_raw=torch.full((n, 1), inverse_sigmoid(a.init_opacity), device=xyz.device))
 

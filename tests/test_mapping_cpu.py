@@ -351,3 +351,26 @@ def test_argument_sets_are_the_references_config_files(leaf, build):
               "min_depth", "max_depth", "invalid_confidence_thresh", "global_keyframe_num", "color_weight", "depth_weight",
               "ssim_weight", "normal_weight", "init_opacity", "xyz_factor", "max_radius", "min_radius", "scale_factor"}
     assert needed <= set(common), sorted(needed - set(common))
+
+
+def test_initial_rotation_follows_the_references_cross_product_rule():
+    """SLAM/utils.py:216-221 calls torch.cross WITHOUT a dim; the legacy rule takes the first dimension of size 3, which for a
+    sampling pass of exactly THREE points is the batch dimension.  compute_rot keeps that (the maps of the two lifecycles
+    differ otherwise: found by oracle/fuzz_mapping_vs_reference.py) - checked here against the legacy call itself."""
+    import warnings
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 2, 3, 4, 7):
+        nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+        z = torch.zeros_like(nrm)
+        z[:, 2] = 1.0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            axis = torch.cross(z, nrm)                                    # the reference's call, legacy default dim
+        axis = axis / (torch.norm(axis, p=2, dim=-1, keepdim=True) + 1e-8)
+        angle = torch.acos(torch.sum(z * nrm, dim=1)).unsqueeze(-1)
+        want = torch.cat([torch.cos(angle / 2), axis * torch.sin(angle / 2)], dim=1)   # quaternion_from_axis_angle
+        got = mp.compute_rot(nrm)
+        assert torch.allclose(got, want, atol=1e-6), n
+    three = torch.nn.functional.normalize(torch.tensor([[0.1, 0.2, -1.0], [0.3, -0.1, -1.0], [-0.2, 0.1, -1.0]]), dim=1)
+    q = mp.compute_rot(three)
+    assert float(q[:, 1:3].abs().max()) < 1e-6 and float(q[:, 3].abs().max()) > 0.9      # turned about z (if at all): the quirk
