@@ -3,6 +3,7 @@ place, oracle/ref_mapper_shim.py): random argument sets and streams, both lifecy
 sizes compared after every frame, every raw tensor (in a canonical row order) at the end.
 
     python -m oracle.fuzz_mapping_vs_reference [n_cases] [first_seed]        (build container only; ~1 minute per case)
+    python -m oracle.fuzz_mapping_vs_reference long                           (the 20-frame case with stable deletions)
 
 TEST INFRASTRUCTURE: a search for lifecycle branches the fixed golden streams do not reach.  What it finds becomes a golden
 stream in oracle/gen_mapping_golden.py."""
@@ -30,9 +31,19 @@ def case(seed):
                 add_depth_thres=r.choice([0.05, 0.1]), add_color_thres=r.choice([0.05, 0.1, 0.2]),
                 add_transmission_thres=r.choice([0.3, 0.5]), error_sample_ratio=r.choice([0.05, 0.2]),
                 transmission_sample_ratio=r.choice([0.5, 1.0]), global_keyframe_num=r.choice([1, 3]),
-                final_global_iter=r.choice([1, 2]), history_merge_max_weight=r.choice([0.3, 0.5]), max_depth=8.0, seed=3)
+                final_global_iter=r.choice([1, 2]), history_merge_max_weight=r.choice([0.3, 0.5]), max_depth=8.0, seed=3,
+                xyz_factor=r.choice([[1.0, 1.0, 0.1], [1.0, 1.0, 0.1], [1.0, 1.0, 1.0]]), init_opacity=r.choice([0.99, 0.8]))
     return dict(over=over, tum=r.random() < 0.4, changing=r.random() < 0.5, n_frames=r.choice([6, 8, 10]),
                 stream_seed=r.choice([4, 5, 9, 12]), rng_seed=100 + seed)
+
+
+def long_case():
+    """Twenty frames of the changing scene with a sparse optimisation schedule: the one fixed case that reaches the DELETION of
+    stable Gaussians by depth-error strikes (mapper.py:560-575; 19 rows in two batches) besides thousands of releases."""
+    return dict(over=dict(uniform_sample_num=260, gaussian_update_iter=2, gaussian_update_frame=3, memory_length=2,
+                          stable_confidence_thres=1.0, unstable_time_window=3, keyframe_trans_thes=0.05, keyframe_theta_thes=30.0,
+                          max_depth=8.0, seed=3, final_global_iter=1),
+                tum=False, changing=True, n_frames=20, stream_seed=4, rng_seed=321)
 
 
 def snapshot_ref(m):
@@ -153,7 +164,8 @@ def run_case(c, ref_mod):
         got = (M.opt.N - M.opt.n_frozen, M.opt.n_frozen)
         if got != want:
             return f"frame {fid}: sizes (unstable, stable) {got} vs the reference's {want}", ref_sizes
-        msg, w = compare(snapshot_mine(M), state)
+        # float-level gradient differences become learning-rate-sized steps under Adam (eps 1e-15): up to one rate per iteration
+        msg, w = compare(snapshot_mine(M), state, tol=max(3e-3, 2e-3 * args.gaussian_update_iter))
         if msg:
             return f"frame {fid}: {msg}", ref_sizes
         worst_frame = max(worst_frame, w)
@@ -163,20 +175,23 @@ def run_case(c, ref_mod):
     if M.keyframe_ids != R.keyframe_ids or M.optimize_frames_ids != R.optimize_frames_ids:
         return f"keyframes {M.keyframe_ids} vs {R.keyframe_ids}; optimised {M.optimize_frames_ids} vs {R.optimize_frames_ids}", ref_sizes
     M.global_optimization(select_keyframe_num=-1, is_end=True)
-    msg, worst = compare(snapshot_mine(M), ref_final)
+    msg, worst = compare(snapshot_mine(M), ref_final, tol=max(3e-3, 2e-3 * len(M.keyframe_list) * args.final_global_iter))
     return (f"final: {msg}", ref_sizes) if msg else (None, (ref_sizes, max(worst, worst_frame), dict(M.stats)))
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if len(sys.argv) > 1 and sys.argv[1] == "long":
+        cases = [("long", long_case())]
+    else:
+        n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+        first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+        cases = [(seed, case(seed)) for seed in range(first, first + n)]
     import io
     import contextlib
     from oracle import ref_mapper_shim as rm
     ref_mod = rm.install()
     bad = 0
-    for seed in range(first, first + n):
-        c = case(seed)
+    for seed, c in cases:
         sink = io.StringIO()
         try:
             with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
@@ -191,7 +206,7 @@ def main():
             print(f"seed {seed}: ok  frames {c['n_frames']} tum {c['tum']} changing {c['changing']}  final sizes {sizes[-1]}  "
                   f"largest difference {worst:.2e}  fixed {stats['fixed']} deleted {stats['deleted_unstable']}+{stats['deleted_stable']} "
                   f"released {stats['released']} global {stats['global_opts']}", flush=True)
-    print(f"{bad} mismatching case(s) of {n}")
+    print(f"{bad} mismatching case(s) of {len(cases)}")
 
 
 if __name__ == "__main__":
