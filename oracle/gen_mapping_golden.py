@@ -72,6 +72,8 @@ def run_reference(changing=False, tum=False):
         fr.original_depth = d
         fr.move_to_cpu_clone = (lambda f=fr: f)
         fmap = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in fm.items()}
+        out[f"f{fid}_rng_py"] = np.array(random.getstate()[1], dtype=np.int64)      # the random streams at the frame's start
+        out[f"f{fid}_rng_torch"] = torch.get_rng_state().numpy().copy()
         m.mapping(fr, fmap, fid, upd)
         m.get_render_output(fr)
         for tag, pc in (("u", m.pointcloud), ("s", m.stable_pointcloud)):
