@@ -105,3 +105,15 @@ def test_model_ply_bytes_equal_the_reference_writers_recipe(tmp_path):
         p = str(tmp_path / f"m{int(include_confidence)}.ply")
         io.save_model_ply(p, **m, include_confidence=include_confidence)
         assert open(p, "rb").read() == want
+
+
+def test_model_ply_bytes_equal_what_the_references_own_writer_produces(tmp_path):
+    """tests/golden/model_ply_ref.npz: the file the reference's OWN GaussianPointCloud.save_model_ply writes for the seeded
+    model below (gaussian_pointcloud.py:424-466 run on the CPU in place by oracle/gen_ply_golden.py; only plyfile's
+    serialisation of the finished structured array is a stand-in) - byte for byte, with and without the confidence column."""
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_ply_ref.npz"))
+    m = _model(int(ref["n"][0]), seed=int(ref["seed"][0]))
+    for inc in (True, False):
+        p = str(tmp_path / f"m{int(inc)}.ply")
+        io.save_model_ply(p, **m, include_confidence=inc)
+        assert open(p, "rb").read() == ref[f"bytes_conf{int(inc)}"].tobytes()
