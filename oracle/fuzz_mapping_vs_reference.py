@@ -33,6 +33,8 @@ def case(seed):
                 transmission_sample_ratio=r.choice([0.5, 1.0]), global_keyframe_num=r.choice([1, 3]),
                 final_global_iter=r.choice([1, 2]), history_merge_max_weight=r.choice([0.3, 0.5]), max_depth=8.0, seed=3,
                 xyz_factor=r.choice([[1.0, 1.0, 0.1], [1.0, 1.0, 0.1], [1.0, 1.0, 1.0]]), init_opacity=r.choice([0.99, 0.8]))
+    if r.random() < 0.25:
+        over["type"] = "Scannetpp"          # local AND (on a keyframe) global optimisation per optimised frame; loss without depth-less pixels
     return dict(over=over, tum=r.random() < 0.4, changing=r.random() < 0.5, n_frames=r.choice([6, 8, 10]),
                 stream_seed=r.choice([4, 5, 9, 12]), rng_seed=100 + seed)
 
@@ -109,9 +111,16 @@ def compare(a, b, tol=3e-3):
         if len(set(match.tolist())) != n:
             return f"{tag}: rows cannot be matched one to one by position (nearest distances up to {float(d.min(1).values.max()):.3g})", None
         for k in x:
-            e = float((x[k].reshape(n, -1) - y[k][match].reshape(n, -1)).abs().max())
+            rows = (x[k].reshape(n, -1) - y[k][match].reshape(n, -1)).abs().max(dim=1).values
+            e = float(rows.max())
+            if k in ("depth_error_counter", "color_error_counter"):
+                # a strike is `mean error of the Gaussian's pixels > 2 x threshold` on renders of the map the frame has just
+                # optimised: with parameters a learning rate apart, a Gaussian sitting on the threshold may count on one side only
+                if e > 1 or float((rows > 0).float().mean()) > 0.02:
+                    return f"{tag}.{k}: max difference {e} on {int((rows > 0).sum())} of {n} rows", worst
+                continue
             worst = max(worst, e)
-            if e > (0 if k in ("confidence", "add_tick", "depth_error_counter", "color_error_counter") else tol):
+            if e > (0 if k in ("confidence", "add_tick") else tol):
                 return f"{tag}.{k}: max difference {e}", worst
     return None, worst
 

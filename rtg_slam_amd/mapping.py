@@ -85,6 +85,20 @@ def tum_args(**over) -> SimpleNamespace:
     return replica_args(**a)
 
 
+def scannetpp_args(**over) -> SimpleNamespace:
+    """configs/base.yaml overlaid with configs/scannetpp_base.yaml: uniform_sample_num 68620, max_depth 10, stable_confidence_thres
+    400, unstable_time_window 200, gaussian_update_iter 75, gaussian_update_frame 3, ground-truth poses (scannetpp_base.yaml:3-23);
+    what replica_base.yaml overrides falls back to base.yaml (memory_length 1, final_global_iter 10, the three *_lr_coef 1.0,
+    icp_use_model_depth False).  On this dataset
+    type every optimised frame runs the local optimisation AND - on a keyframe - the global one (mapper.py:107-113), and the loss
+    leaves out the pixels without depth (:419-420)."""
+    a = dict(uniform_sample_num=68620, max_depth=10.0, stable_confidence_thres=400.0, unstable_time_window=200,
+             gaussian_update_iter=75, gaussian_update_frame=3, use_gt_pose=True, final_global_iter=10, feature_lr_coef=1.0,
+             scaling_lr_coef=1.0, rotation_lr_coef=1.0, memory_length=1, icp_use_model_depth=False, type="Scannetpp")
+    a.update(over)
+    return replica_args(**a)
+
+
 class Frame:
     """What the reference's Camera (scene/cameras.py) offers the mapper, tracker and renderer: the attributes
     Renderer.render reads (render.py:66-86), the pose (R = W2C[:3,:3]^T, T = W2C[:3,3]; cameras.py:96-137), intrinsics
@@ -509,6 +523,14 @@ class Mapping:
             tile_mask = None
         return render_mask, tile_mask, count
 
+    def _loss_mask(self, render_mask, frame_map):
+        """mapper.py:419-420: on Scannetpp the loss also leaves out the pixels without depth - of the image the step is GIVEN
+        (in a keyframe-triggered global optimisation that is the randomly drawn keyframe even where the masks are the last
+        one's, :672-678)."""
+        if self.args.type != "Scannetpp" or render_mask is None:
+            return render_mask
+        return (render_mask.bool() & (frame_map["depth_chw"][0] > 0)).to(torch.uint8)
+
     def local_optimize(self, frame, update_args=None):
         a, o = self.args, self.opt
         conf = self.aux("confidence", "unstable").reshape(-1)
@@ -526,7 +548,7 @@ class Mapping:
                 j = -1
             fm = self.processed_map[j]
             self.ops.step(o, self.processed_frames[j], fm["color_chw"], fm["depth_chw"], masks[j][1],
-                          masks[j][0], conf, self.weights)
+                          self._loss_mask(masks[j][0], fm), conf, self.weights)
         self.stats["iterations"] += a.gaussian_update_iter
         self.iter = 0
         self.ops.history_merge(o, conf, a.history_merge_max_weight)
@@ -567,7 +589,7 @@ class Mapping:
             fr, im = frames[j], maps[j]
             if it > total_iter / 2 and not final:
                 j = -1           # as the reference (:675-678): the FRAME stays the random one, the MASKS become the last entry's
-            self.ops.step(o, fr, im["color_chw"], im["depth_chw"], masks[j][1], masks[j][0], conf, w)
+            self.ops.step(o, fr, im["color_chw"], im["depth_chw"], masks[j][1], self._loss_mask(masks[j][0], im), conf, w)
         self.stats["iterations"] += total_iter
         self.stats["global_opts"] += 1
         self.iter = 0

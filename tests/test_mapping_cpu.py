@@ -72,6 +72,12 @@ def _args_tum(**kw):
     return mp.tum_args(**base)
 
 
+def _args_scannetpp(**kw):
+    """The reduced schedule on the Scannetpp dataset type: every optimised frame runs the local optimisation and - on a
+    keyframe - the global one too (mapper.py:107-113), and the loss leaves out the pixels without depth (:419-420)."""
+    return _args(type="Scannetpp", **kw)
+
+
 def _run(n_frames, args, final=False):
     ops = TorchOps(args)
     m = mp.Mapping(args, torch.device("cpu"), ops=ops, capacity=400)
@@ -273,6 +279,12 @@ def test_lifecycle_matches_the_references_own_mapping_with_the_tum_rates():
     _against_the_references_own_mapping("mapping_ref_tum.npz", _stream, True, _args_tum)
 
 
+def test_lifecycle_matches_the_references_own_mapping_on_the_scannetpp_branch():
+    """The 7-frame stream with args.type = "Scannetpp": local + keyframe-triggered global optimisation in ONE frame, loss mask
+    without the depth-less pixels of the image the step is given."""
+    _against_the_references_own_mapping("mapping_ref_scannetpp.npz", _stream, True, _args_scannetpp)
+
+
 def test_lifecycle_matches_the_references_own_mapping_on_a_changing_scene():
     """Fifteen frames with a scene change from frame 2 on (_changing_stream): colour-error strikes release stable Gaussians
     (confidence 0, new tick - mapper.py:576-592), a large fix at frame 11, six keyframes; sizes after every frame, all
@@ -312,7 +324,8 @@ def test_update_poses_and_the_small_accessors():
     assert int(m.opt.aux["add_tick"][1, 0]) == 9 and int(m.opt.aux["add_tick"][0, 0]) != 9
 
 
-@pytest.mark.parametrize("leaf,build", [("replica_base.yaml", "replica_args"), ("tum_base.yaml", "tum_args")])
+@pytest.mark.parametrize("leaf,build", [("replica_base.yaml", "replica_args"), ("tum_base.yaml", "tum_args"),
+                                        ("scannetpp_base.yaml", "scannetpp_args")])
 def test_argument_sets_are_the_references_config_files(leaf, build):
     """replica_args() / tum_args() against configs/base.yaml overlaid with the dataset's base file (the `parent:` chain the
     reference's loader follows), read from /root/reference where it lies: every value the two have in common is equal, and
