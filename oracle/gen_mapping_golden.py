@@ -36,10 +36,10 @@ def reference_args(a):
 N_FRAMES_CHANGING = 15
 
 
-def stream_inputs(changing=False, tum=False, scannetpp=False):
+def stream_inputs(changing=False, tum=False, scannetpp=False, normal=False):
     from tests import test_mapping_cpu as t
     from rtg_slam_amd import mapping as mp
-    args = t._args_tum() if tum else (t._args_scannetpp() if scannetpp else t._args())
+    args = t._args_tum() if tum else (t._args_scannetpp() if scannetpp else t._args(**({"normal_weight": 0.2} if normal else {})))
     frames = []
     for fid, (d, c, c2w) in enumerate(t._changing_stream(N_FRAMES_CHANGING) if changing else t._stream(N_FRAMES)):
         fr = mp.Frame(t.CAM, c2w, torch.device("cpu"), uid=fid)
@@ -55,10 +55,10 @@ def snapshot(pc):
                 depth_error_counter=g(pc._depth_error_counter), color_error_counter=g(pc._color_error_counter))
 
 
-def run_reference(changing=False, tum=False, scannetpp=False):
+def run_reference(changing=False, tum=False, scannetpp=False, normal=False):
     from oracle import ref_mapper_shim as rm
     ref = rm.install()
-    args, frames = stream_inputs(changing, tum, scannetpp)
+    args, frames = stream_inputs(changing, tum, scannetpp, normal)
     rargs = reference_args(args)
     os.makedirs(rargs.save_path, exist_ok=True)
     random.seed(SEED)
@@ -95,11 +95,15 @@ def run_reference(changing=False, tum=False, scannetpp=False):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "both"
-    for changing, tum, sc, name in ((False, False, False, "mapping_ref.npz"), (True, False, False, "mapping_ref_changing.npz"),
-                                    (False, True, False, "mapping_ref_tum.npz"), (False, False, True, "mapping_ref_scannetpp.npz")):
-        if which not in ("both", "scannetpp" if sc else ("tum" if tum else ("changing" if changing else "static"))):
+    for changing, tum, sc, nrm, name in ((False, False, False, False, "mapping_ref.npz"),
+                                         (True, False, False, False, "mapping_ref_changing.npz"),
+                                         (False, True, False, False, "mapping_ref_tum.npz"),
+                                         (False, False, True, False, "mapping_ref_scannetpp.npz"),
+                                         (False, False, False, True, "mapping_ref_normal.npz")):
+        kind = "normal" if nrm else ("scannetpp" if sc else ("tum" if tum else ("changing" if changing else "static")))
+        if which not in ("both", kind):
             continue
-        out = run_reference(changing, tum, sc)
+        out = run_reference(changing, tum, sc, nrm)
         if changing:                                               # sizes, counters and the last states are enough here
             n = int(out["n_frames"][0])
             out = {k: v for k, v in out.items() if not k.startswith("f") or k.endswith("_sizes") or k.startswith(f"f{n - 1}_")

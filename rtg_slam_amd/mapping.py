@@ -209,10 +209,14 @@ class HipOps:
     def history_merge(self, opt, confidence, max_weight):
         opt.history_merge(confidence, max_weight)
 
-    def step(self, opt, frame, gt_color, gt_depth, tile_mask, render_mask, confidence, w):
+    def step(self, opt, frame, gt_color, gt_depth, tile_mask, render_mask, confidence, w, gt_normal=None):
+        """gt_normal: the step's image's world normals [H, W, 3] - read only when the normal term is weighted (mapper.py:433-443;
+        0.0 in every configuration file of the reference)."""
+        nw = float(getattr(w, "normal_weight", 0.0))
         return opt.step_slam(frame.raster_settings(self.args), gt_color, gt_depth, tile_mask, color_weight=w.color_weight,
                              depth_weight=w.depth_weight, ssim_weight=w.ssim_weight, add_depth_thres=w.add_depth_thres,
-                             render_mask=render_mask, confidence=confidence)
+                             render_mask=render_mask, confidence=confidence, normal_weight=nw,
+                             gt_normal=gt_normal if nw > 0 else None)
 
 
 def RGB2SH(rgb):
@@ -265,7 +269,8 @@ class Mapping:
                           iterations=0, renders=0, renders_reused=0)
         self.prof = {} if __import__("os").environ.get("RTGS_MAP_PROFILE") else None
         self.weights = SimpleNamespace(color_weight=args.color_weight, depth_weight=args.depth_weight,
-                                       ssim_weight=args.ssim_weight, add_depth_thres=args.add_depth_thres)
+                                       ssim_weight=args.ssim_weight, add_depth_thres=args.add_depth_thres,
+                                       normal_weight=float(getattr(args, "normal_weight", 0.0)))
 
     # ------------------------------------------------------------------ sizes and views
     @property
@@ -548,7 +553,7 @@ class Mapping:
                 j = -1
             fm = self.processed_map[j]
             self.ops.step(o, self.processed_frames[j], fm["color_chw"], fm["depth_chw"], masks[j][1],
-                          self._loss_mask(masks[j][0], fm), conf, self.weights)
+                          self._loss_mask(masks[j][0], fm), conf, self.weights, gt_normal=fm.get("normal_map_w"))
         self.stats["iterations"] += a.gaussian_update_iter
         self.iter = 0
         self.ops.history_merge(o, conf, a.history_merge_max_weight)
@@ -589,7 +594,8 @@ class Mapping:
             fr, im = frames[j], maps[j]
             if it > total_iter / 2 and not final:
                 j = -1           # as the reference (:675-678): the FRAME stays the random one, the MASKS become the last entry's
-            self.ops.step(o, fr, im["color_chw"], im["depth_chw"], masks[j][1], self._loss_mask(masks[j][0], im), conf, w)
+            self.ops.step(o, fr, im["color_chw"], im["depth_chw"], masks[j][1], self._loss_mask(masks[j][0], im), conf, w,
+                          gt_normal=im.get("normal_map_w"))
         self.stats["iterations"] += total_iter
         self.stats["global_opts"] += 1
         self.iter = 0

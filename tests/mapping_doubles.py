@@ -83,7 +83,7 @@ class TorchOps:
         st["xyz"]["p"][t0:N], st["shs"]["p"][t0:N], st["raw8"]["p"][t0:N] = x, sh, r8
         opt.version += 1
 
-    def step(self, opt, frame, gt_color, gt_depth, tile_mask, render_mask, confidence, w):
+    def step(self, opt, frame, gt_color, gt_depth, tile_mask, render_mask, confidence, w, gt_normal=None):
         N, t0 = opt._active()
         ai = opt.attach_init
         grads = {}
@@ -95,6 +95,14 @@ class TorchOps:
             out = self._raster(frame, gd, tile_mask)
             loss = td.slam_losses(out, gt_color, gt_depth, w.color_weight, w.depth_weight, w.ssim_weight, w.add_depth_thres,
                                   None if render_mask is None else render_mask.bool())
+            nw = float(getattr(w, "normal_weight", 0.0))
+            if nw > 0 and gt_normal is not None:                          # mapper.py:433-443, on the normals the wrapper gathers
+                didx = out[3][0].long()
+                rn = torch.where((didx >= 0)[None], gd["normal"][didx.clamp_min(0)].permute(2, 0, 1), torch.zeros(3, *didx.shape))
+                gn = gt_normal.permute(2, 0, 1)
+                m = torch.ones_like(didx, dtype=torch.bool) if render_mask is None else render_mask.bool()
+                vn = m & (didx != -1) & ~((gn == 0).all(dim=0))
+                loss = loss + nw * (1 - torch.nn.functional.cosine_similarity(rn, gn, dim=0))[vn].mean()
             if ai is not None and N > t0:                                  # attach regulariser, mapper.py:384-401
                 sel = torch.sigmoid(ai["raw8"][:, 0]) < 0.9
                 if bool(sel.any()):                       # raw scaling, position AND raw rotation (mapper.py:389-400)

@@ -285,6 +285,12 @@ def test_lifecycle_matches_the_references_own_mapping_on_the_scannetpp_branch():
     _against_the_references_own_mapping("mapping_ref_scannetpp.npz", _stream, True, _args_scannetpp)
 
 
+def test_lifecycle_matches_the_references_own_mapping_with_the_normal_term():
+    """normal_weight 0.2 (0.0 in every configuration file of the reference, so this is the only place the term is held to
+    mapper.py:433-443): the 7-frame stream again, every parameter within 2e-4."""
+    _against_the_references_own_mapping("mapping_ref_normal.npz", _stream, True, lambda: _args(normal_weight=0.2))
+
+
 def test_lifecycle_matches_the_references_own_mapping_on_a_changing_scene():
     """Fifteen frames with a scene change from frame 2 on (_changing_stream): colour-error strikes release stable Gaussians
     (confidence 0, new tick - mapper.py:576-592), a large fix at frame 11, six keyframes; sizes after every frame, all
