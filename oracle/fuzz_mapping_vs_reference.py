@@ -33,6 +33,10 @@ def case(seed):
                 transmission_sample_ratio=r.choice([0.5, 1.0]), global_keyframe_num=r.choice([1, 3]),
                 final_global_iter=r.choice([1, 2]), history_merge_max_weight=r.choice([0.3, 0.5]), max_depth=8.0, seed=3,
                 xyz_factor=r.choice([[1.0, 1.0, 0.1], [1.0, 1.0, 0.1], [1.0, 1.0, 1.0]]), init_opacity=r.choice([0.99, 0.8]))
+    if r.random() < 0.3:                                         # other rates and loss weights than the configuration files'
+        over.update(opacity_lr=r.choice([0.0, 0.01]), position_lr=r.choice([0.0005, 0.001, 0.002]),
+                    rotation_lr=r.choice([0.0005, 0.001]), color_weight=r.choice([0.5, 0.8, 1.0]),
+                    depth_weight=r.choice([0.0, 0.5, 1.0]), ssim_weight=r.choice([0.0, 0.2]))
     if r.random() < 0.25:
         over["normal_weight"] = r.choice([0.05, 0.2])     # the normal term of the loss (0.0 in every configuration file)
     if r.random() < 0.25:
