@@ -41,8 +41,9 @@ def case(seed):
         over["normal_weight"] = r.choice([0.05, 0.2])     # the normal term of the loss (0.0 in every configuration file)
     if r.random() < 0.25:
         over["type"] = "Scannetpp"          # local AND (on a keyframe) global optimisation per optimised frame; loss without depth-less pixels
+    cam = r.choice([(48, 64, 40.0, 31.5, 23.5)] * 2 + [(50, 70, 44.0, 34.5, 24.5), (41, 57, 36.0, 28.0, 20.0)])   # H W f cx cy
     return dict(over=over, tum=r.random() < 0.4, changing=r.random() < 0.5, n_frames=r.choice([6, 8, 10]),
-                stream_seed=r.choice([4, 5, 9, 12]), rng_seed=100 + seed)
+                stream_seed=r.choice([4, 5, 9, 12]), rng_seed=100 + seed, cam=cam)
 
 
 def long_case():
@@ -136,6 +137,10 @@ def run_case(c, ref_mod):
     from tests.mapping_doubles import TorchOps
     from rtg_slam_amd import mapping as mp
     from oracle.gen_mapping_golden import reference_args
+    if "cam" in c:                                              # image sizes that are no multiples of the 16-pixel tile too
+        from rtg_slam_amd import synth
+        H, W, f, cx, cy = c["cam"]
+        t.CAM = synth.CameraSpec(H, W, f, f, cx, cy)
     args = (mp.tum_args if c["tum"] else mp.replica_args)(**c["over"])
     stream = (t._changing_stream if c["changing"] else t._stream)(c["n_frames"], c["stream_seed"])
     inputs = []
