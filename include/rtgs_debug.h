@@ -54,10 +54,9 @@ void rtgs_raster_force_sort_path_ctx(rtgs_ctx* ctx, int enable);
 int rtgs_raster_last_timings(float* ms12_host);
 int rtgs_raster_last_timings_ctx(rtgs_ctx* ctx, float* ms12_host);
 
-/* The backward's tile walk.  Three kernels exist (raster_bwd.hip, raster_bwd_mfma.hip):
+/* The backward's tile walk.  Three kernels exist (raster_bwd.hip, raster_bwd_entry.hip):
  *  - entry-per-lane walk (default): a lane holds one (pixel, ENTRY) pair - 16 entries x 4 pixels per wave step - T and the
- *    colour behind are in-row DPP scans, and the sums over the pixels are kept per lane (round 5) or run on the matrix cores
- *    (v_mfma_f32_16x16x4_f32: round 4's form, rtgs_raster_set_mfma_walk(8));
+ *    colour behind are in-row DPP scans, and the sums over the pixels are kept per lane;
  *  - strip walk: pixel per lane, one entry per wave pass, tile-uniform (large footprints);
  *  - row-granular walk: pixel per lane, every 4x4 block walks its own sub-list (small footprints).
  * mode 0 (default) and 3 = entry-per-lane walk on every tile; 1 = strip walk; 2 = row-granular walk; 4 = per-tile choice between
@@ -72,17 +71,18 @@ void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* ctx, int mode);
  * (bin_place_kernel) instead of count + scan + scatter.  Outputs are bit-identical either way (the tile sort's order is
  * total); the switch exists for A-B runs and tests. */
 void rtgs_raster_set_onepass_ctx(rtgs_ctx* ctx, int on);
-/* The forward's tile walk: 1 (default) = one pixel per lane, 2 = two pixels per lane (128 threads per tile; round 5: built,
- * bit-identical, measured slower on small footprints - kept for A-B runs).  PROCESS-WIDE; RTGS_FWD_KERNEL at load time. */
-void rtgs_raster_set_fwd_kernel(int which);
-/* The entry-per-lane backward walk: bit 3 (8) = round 4's form, the pixel sums by two MFMAs per step instead of lane
- * accumulators (gradients agree to rounding); bits 0..2 switch parts of the kernel OFF for timing decompositions (1 walk,
- * 2 depth partials, 4 stores) - results are then wrong by construction.  PROCESS-WIDE; RTGS_MFMA_DEBUG at load time. */
-void rtgs_raster_set_mfma_walk(int bits);
-/* Per-wave time stamps of the entry-per-lane backward walk (tools/mfma_stamps.py): `dev` = device uint64[tiles x 4 waves x 14] or NULL
+/* Timing decompositions of the entry-per-lane backward walk (tools only): bits 0..2 switch parts of the kernel OFF (1 walk,
+ * 2 depth partials, 4 stores) - results are then wrong by construction, so the bits are never read from the environment and a
+ * tool that sets them clears them again.  PROCESS-WIDE. */
+void rtgs_raster_set_bwd_debug(int bits);
+/* Per-wave time stamps of the entry-per-lane backward walk (tools/bwd_stamps.py): `dev` = device uint64[tiles x 4 waves x 14] or NULL
  * (default: the product kernel carries no stamping code).  Per wave: wall clock (100 MHz) at entry and exit, shader cycles
- * in the group loop and in the kernel, groups walked, quad steps entered, cycles of the six other phases.  PROCESS-WIDE. */
-void rtgs_raster_set_mfma_stamps(void* dev);
+ * in the group loop and in the kernel, groups walked, quad steps entered, cycles of the six other phases.  PROCESS-WIDE; the
+ * caller keeps the buffer alive until it has passed NULL again. */
+void rtgs_raster_set_bwd_stamps(void* dev);
+/* The same for blend_fwd (tools/fwd_stamps.py): `dev` = device uint64[tiles x 4 waves x 8]: wall clock at entry / exit, cycles until
+ * the tile range is there | until the first batch is staged | inside the walk loops | in the kernel, walk steps, batches. */
+void rtgs_raster_set_fwd_stamps(void* dev);
 
 #ifdef __cplusplus
 }

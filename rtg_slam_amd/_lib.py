@@ -155,9 +155,9 @@ _SIGNATURES = {
     "rtgs_raster_set_profiling_ctx": (None, [_P, C.c_int]),
     "rtgs_raster_force_sort_path_ctx": (None, [_P, C.c_int]),
     "rtgs_raster_set_bwd_walk_ctx": (None, [_P, C.c_int]),
-    "rtgs_raster_set_fwd_kernel": (None, [C.c_int]),
-    "rtgs_raster_set_mfma_walk": (None, [C.c_int]),
-    "rtgs_raster_set_mfma_stamps": (None, [C.c_void_p]),
+    "rtgs_raster_set_bwd_debug": (None, [C.c_int]),
+    "rtgs_raster_set_bwd_stamps": (None, [C.c_void_p]),
+    "rtgs_raster_set_fwd_stamps": (None, [C.c_void_p]),
     "rtgs_raster_set_onepass_ctx": (None, [_P, C.c_int]),
     "rtgs_raster_forward_verify_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "rtgs_raster_spec_fail_ptr_ctx": (C.c_void_p, [_P]),

@@ -19,17 +19,18 @@ void launch_preprocess_fwd(const RasterParams&, const float*, const float*, cons
 void launch_emit_keys(const RasterParams&, const Splat*, const int32_t*, const uint32_t*, const int32_t*, uint64_t*,
                       uint32_t*, hipStream_t);
 void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
-void set_fwd_kernel(int which);
-void set_mfma_debug(int bits);
-void set_mfma_stamps(void* dev);
+void set_fwd_stamps(void* dev);
+void set_bwd_debug(int bits);
+void set_bwd_stamps(void* dev);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
-                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, hipStream_t);
+                      int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*,
+                      TileCache, hipStream_t);
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
                       const uint32_t*, const int32_t*, const float*, const float*, const uint32_t*, uint32_t*,
                       const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, uint32_t, uint32_t, hipStream_t);
-void launch_blend_bwd_mfma(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const uint32_t*,
-                           const int32_t*, const uint32_t*, const uint32_t*, const float*, const float*, const uint32_t*, uint32_t*,
-                           const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, uint32_t, hipStream_t);
+void launch_blend_bwd_entry(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const uint32_t*,
+                            const int32_t*, const uint32_t*, const uint32_t*, const float*, const float*, const uint32_t*, uint32_t*,
+                            const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, uint32_t, TileCache, const uint32_t*, hipStream_t);
 void launch_grad_reduce(int, const uint8_t*, const uint32_t*, uint32_t*, const BwdInfo*, SplatGrad*, const uint32_t*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
@@ -295,6 +296,12 @@ static ImgLayout img_layout(int H, int W, int ntiles) {
   L.tile_mode = off; off = align_up(off + (size_t)ntiles * sizeof(uint32_t));
   L.depth_pos = off; off = align_up(off + (size_t)H * W * sizeof(uint32_t));
   L.tile_last = off; off = align_up(off + (size_t)ntiles * sizeof(uint32_t));
+  // the TileCache (raster_common.h): 48 B of record + 2 B of block mask for the first TILE_RECS list positions of every tile
+  // (39.6 + 1.7 MB at 1200x680), two plane words per pixel, the backward's tile order
+  L.tile_recs = off; off = align_up(off + (size_t)ntiles * TILE_RECS * 3 * sizeof(float4));
+  L.tile_masks = off; off = align_up(off + (size_t)ntiles * TILE_RECS * sizeof(uint16_t));
+  L.depth_aux = off; off = align_up(off + (size_t)H * W * sizeof(float2));
+  L.tile_order = off; off = align_up(off + (size_t)ntiles * sizeof(uint32_t));
   L.total = off;
   return L;
 }
@@ -428,6 +435,9 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   // per-tile choice from the measured list share (-1: bwd_walk 4)
   const int fwd_walk = c->bwd_walk == 0 || c->bwd_walk == 3 ? 2 : (c->bwd_walk == 4 ? -1 : c->bwd_walk - 1);
   c->last_geom = geom; c->last_img = img; c->last_bin = nullptr;
+  // what blend_fwd leaves for the entry-per-lane backward (nothing when the caller promises there is no backward)
+  const TileCache tcache = (flags & RTGS_FWD_NO_BACKWARD) ? TileCache{nullptr, nullptr, nullptr}
+                                                          : TileCache{(float4*)(img + I.tile_recs), (uint16_t*)(img + I.tile_masks), (float2*)(img + I.depth_aux)};
 
   int64_t R = 0, R1 = 0;
   for (int i = 0; i < EV_B0; ++i) c->ev_set[i] = false;
@@ -544,7 +554,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         prof_mark(c, EV_SL_BIN, st);
         const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
         launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                         n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, st);
+                         n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, st);
         prof_mark(c, EV_SL_BLEND, st);      // the bracket holds the blend alone (bench.py's roofline divides by it)
         launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, fail, st, seg1 ? tile_count1 : nullptr);
         prof_mark(c, EV_BLEND0, st); prof_mark(c, EV_BLEND, st);
@@ -611,7 +621,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         prof_mark(c, EV_SORT, st);
         prof_mark(c, EV_BLEND0, st);
         launch_blend_fwd(pg, ranges, (uint32_t*)(bin + B.vals_b), splats, out_color, out_depth, out_cidx, out_didx, out_cw,
-                         out_dw, out_T, n_contrib, c->counters, SlicePass{0, nullptr, nullptr, nullptr, nullptr}, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, st);
+                         out_dw, out_T, n_contrib, c->counters, SlicePass{0, nullptr, nullptr, nullptr, nullptr}, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, st);
         prof_mark(c, EV_BLEND, st);
         c->hint_slice_lists = false; c->hint_main_lists = true;
         c->slice_stats[0] = pl.kind == 2 ? 1 : 0; c->slice_stats[1] = 0; c->slice_stats[2] = 0;
@@ -697,7 +707,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       if (++c->seq == 0u) c->seq = 1u;
       const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
       launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                       n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, st);
+                       n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, st);
       prof_mark(c, EV_SL_BLEND, st);
       launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, nullptr, st, seg1 ? tile_count1 : nullptr);
       DBG(s, st);
@@ -811,7 +821,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   prof_mark(c, EV_BLEND0, st);
   if (!sliced || n_left > 0)     // pass 2 (or the only pass); with every tile finished by the slice there is nothing to draw
     launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                     n_contrib, c->counters, pass, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, st);
+                     n_contrib, c->counters, pass, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, st);
   prof_mark(c, EV_BLEND, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
@@ -899,9 +909,11 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
         launch_blend_bwd(p, rg, pl, (const Splat*)(geom + G.splats), out_color, out_T, (const uint32_t*)(img + I.n_contrib),
                          out_didx, dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads, touched, tile_mode, which & 3, t0, tn, st);
       if (which & 4)
-        launch_blend_bwd_mfma(p, rg, pl, (const Splat*)(geom + G.splats), out_color, (const uint32_t*)(img + I.n_contrib),
-                              out_didx, depth_pos, (const uint32_t*)(img + I.tile_last), dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads,
-                              touched, tile_mode, t0, tn, st);
+        launch_blend_bwd_entry(p, rg, pl, (const Splat*)(geom + G.splats), out_color, (const uint32_t*)(img + I.n_contrib),
+                               out_didx, depth_pos, (const uint32_t*)(img + I.tile_last), dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads,
+                               touched, tile_mode, t0, tn,
+                               TileCache{(float4*)(img + I.tile_recs), (uint16_t*)(img + I.tile_masks), (float2*)(img + I.depth_aux)},
+                               nullptr, st);
     }
     prof_mark(c, EV_BWALK, st);
     // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
@@ -1025,9 +1037,9 @@ int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
   return RTGS_OK;
 }
 uint32_t rtgs_raster_last_listed_ctx(rtgs_ctx* c) { return use(c)->last_listed; }
-void rtgs_raster_set_fwd_kernel(int which) { rtgs::set_fwd_kernel(which); }
-void rtgs_raster_set_mfma_walk(int bits) { rtgs::set_mfma_debug(bits); }
-void rtgs_raster_set_mfma_stamps(void* dev) { rtgs::set_mfma_stamps(dev); }
+void rtgs_raster_set_bwd_debug(int bits) { rtgs::set_bwd_debug(bits); }
+void rtgs_raster_set_bwd_stamps(void* dev) { rtgs::set_bwd_stamps(dev); }
+void rtgs_raster_set_fwd_stamps(void* dev) { rtgs::set_fwd_stamps(dev); }
 void rtgs_raster_set_onepass_ctx(rtgs_ctx* c, int on) { use(c)->onepass = on != 0; use(c)->plan.valid = false; }
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode >= 1 && mode <= 4) ? mode : 0; }
 void rtgs_raster_set_aux_zero_ctx(rtgs_ctx* ctx, void* eight_words) { use(ctx)->aux_zero = (uint32_t*)eight_words; }

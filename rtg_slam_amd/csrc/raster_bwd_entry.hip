@@ -16,33 +16,33 @@
 // The sums over pixels
 //     sum_p gda[p][e] * {1, x_p, y_p, x_p^2, x_p y_p, y_p^2}      (dL/dopacity and the five moments behind du dv dconic)
 //     sum_p  w [p][e] * {g_r, g_g, g_b}[p]                         (dL/dcolour)
-// exist in two forms:
-//   * round 5 (the product kernel, blend_bwd_entry_kernel): every lane keeps the nine sums of ITS pixel k over the 16 quads
-//     of the wave's 8x8 quadrant (8 plain VALU + 3 FMAs with a DPP operand per step); at the end of a group the four k rows
-//     meet in registers (v_permlane32_swap / v_permlane16_swap) and row 0 adds 9 x 16 sums to the entries' LDS accumulators;
-//   * round 4 (blend_bwd_entry_mfma_kernel, rtgs_raster_set_mfma_walk(8)): the lane map above is exactly the B-operand map of
-//     v_mfma_f32_16x16x4_f32 (B[k][n]), so the sums are two MFMAs per step with the per-pixel factors as A operands,
-//     accumulated in the accumulator registers.  Elegant, and slower: the MFMA holds the SIMD for most of its 32 cycles, two
-//     of them cost more issue time than the eleven instructions that replace them.  Measured A-B in one session: 98.6 -> 89.0
-//     us (headline), 158.3 -> 145.2 us (surface) - profiles/r05_bwd_walk_ab.txt.
+// stay in the lane: every lane keeps the nine sums of ITS pixel k over the 16 quads of the wave's 8x8 quadrant (8 plain VALU +
+// 3 FMAs with a DPP operand per step); at the end of a group the four k rows meet in registers (v_permlane32_swap /
+// v_permlane16_swap) and row 0 adds 9 x 16 sums to the entries' LDS accumulators.  (Round 4 ran these sums as two
+// v_mfma_f32_16x16x4_f32 per step - the lane map above is that instruction's B-operand map.  Elegant, and slower: the MFMA
+// holds the SIMD for most of its 32 cycles.  Measured A-B in round 5, 98.6 -> 89.0 us / 158.3 -> 145.2 us,
+// profiles/r05_bwd_walk_ab.txt; the MFMA form left the tree in round 6.)
 //
-// A wave walks only the entries that reach its quadrant (compacted at staging time from the forward's exact
-// block test), 16 at a time, and skips the quads whose four pixels are past their last contributor.  The opaque-depth
-// partials do not ride the walk at all: blend_fwd leaves the list position of every pixel's depth owner and the
-// owners' four partials go straight to the entry accumulators once per batch (depth_adds).
+// A wave walks only the entries that reach its quadrant, 16 at a time, and skips the quads whose four pixels are past their
+// last contributor.  The opaque-depth partials do not ride the walk at all: blend_fwd leaves the list position of every
+// pixel's depth owner and the owners' four partials go straight to the entry accumulators once per batch (depth_adds).
 //
 // alpha, the skip tests and the contributor set are evaluated exactly as the forward does (same dx, splat_power,
 // splat_exp, list positions against n_contrib); T differs from the forward's in rounding only (product order).
 //
-// Where a launch spends its time is measured, not guessed: tools/mfma_stamps.py (per-wave cycle stamps of every phase,
-// profiles/r05_bwd_stamps_*.txt).  Half of a wave's life is the group loop; a quarter is the prologue's three dependent
-// memory round trips (per-tile words -> per-pixel values / list -> records), a tenth the barriers of the compaction.
+// ROUND 6 - the prologue is ONE memory round trip.  Round 5's per-wave stamps (profiles/r05_bwd_stamps_*.txt) put a quarter
+// of a wave's life into three DEPENDENT round trips before the first step (tile range -> list ids -> record gather), a tenth
+// into the barriers of a cross-wave compaction that waited for the tile's slowest gather, and another tenth into a second
+// dependent chain for the depth owners' planes (depth_index -> Splat record).  All of these values pass through blend_fwd's
+// registers, so blend_fwd now leaves them where the backward finds them from the TILE INDEX alone (TileCache,
+// raster_common.h): records and block masks of the first TILE_RECS list positions at tile * TILE_RECS, the owner's plane
+// words per pixel.  Every load of the prologue is issued before the first wait; the sub-list of a quadrant is compacted by
+// its own wave from the block masks (no cross-wave step); one barrier, then the walk.  List positions >= TILE_RECS (a tile
+// walked deeper than 256 entries) and forwards that left no cache (RTGS_FWD_NO_BACKWARD) take the gather path.
 #include "raster_common.h"
 #include <stdlib.h>
 
 namespace rtgs {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MB = 256;            // list entries staged per batch: one per thread
 constexpr int MACC = 13;           // floats of an entry's LDS accumulator (odd stride: conflict-free; 16 would cost the fifth workgroup per CU)
@@ -76,7 +76,7 @@ __device__ __forceinline__ float row_scan_add(float v) {         // inclusive pr
 }
 
 // Everything a lane holds during the walk of one group of 16 entries.
-struct MfmaWalk {
+struct EntryWalk {
   // entry n of the group (constant over the 16 steps)
   float u, v, ca, cb, cc, o, cr, cg_, cbl;
   uint32_t pos;                    // list position (0x7fffffff: no entry in this lane)
@@ -85,111 +85,12 @@ struct MfmaWalk {
   uint32_t last;
   // pixel coordinates of the lane's k for the four quad columns / rows
   float pxc[4], pyc[4];
-  float fP[4], fQ[4];              // MFMA A operand of the moments = fP[quad column] * fQ[quad row]: feature (lane & 15) of pixel (quad s, k)
-  float X[4];                      // colour gradients of 5 quads per register, 3 lanes each (A operand by rotation)
-  f32x4 C1, C2;
   int n;                           // lane & 15
   // lane-accumulate form (round 5): the lane's own sums over the quads of its pixel k, reduced over k at the flush
   float xq[4], yq[4];              // pixel coordinates about the tile centre, per quad column / row
   float s0, sx, sy, sxx, sxy, syy, sr, sg, sb;
 
-  template <int S>
-  __device__ __forceinline__ void step(uint32_t stepmask) {
-    if (!((stepmask >> S) & 1u)) return;                     // wave-uniform: the quad's four pixels are through
-    // alpha exactly as blend_fwd evaluates it (splat_power / splat_exp, raster_common.h: same operations, same order,
-    // same roundings - the skip decisions below must be the forward's).  In a volatile block: left to itself the
-    // compiler hoists the shared subexpressions of the 16 unrolled steps (4 dx, 4 dy and their products) out of the
-    // group loop and pays for it with 40 more registers - one wave per SIMD less.
-    float power, G, alpha;
-    {
-      float dx, dy, t1, t2;
-      asm volatile(
-          "v_sub_f32 %[dx], %[u], %[px]\n\t"
-          "v_sub_f32 %[dy], %[v], %[py]\n\t"
-          "v_mul_f32 %[t1], %[ca], %[dx]\n\t"
-          "v_mul_f32 %[t2], %[cc], %[dy]\n\t"
-          "v_mul_f32 %[t2], %[t2], %[dy]\n\t"
-          "v_fma_f32 %[t1], %[t1], %[dx], %[t2]\n\t"          // q = fma(ca dx, dx, (cc dy) dy)
-          "v_mul_f32 %[t2], %[cb], %[dx]\n\t"
-          "v_mul_f32 %[t2], %[t2], %[dy]\n\t"
-          "v_fma_f32 %[pw], -0.5, %[t1], -%[t2]\n\t"          // power = fma(-0.5, q, -(cb dx) dy)
-          "v_min_f32 %[t1], 0, %[pw]\n\t"
-          "v_mul_f32 %[t1], 0x3fb8aa3b, %[t1]\n\t"            // * log2(e), as splat_exp
-          "v_exp_f32 %[G], %[t1]\n\t"
-          "s_nop 0\n\t"                                       // transcendental result -> next VALU
-          "v_mul_f32 %[al], %[o], %[G]\n\t"
-          "v_min_f32 %[al], 0x3f7d70a4, %[al]\n\t"            // min(0.99, o G)
-          : [dx] "=&v"(dx), [dy] "=&v"(dy), [t1] "=&v"(t1), [t2] "=&v"(t2), [pw] "=&v"(power), [G] "=&v"(G), [al] "=&v"(alpha)
-          : [u] "v"(u), [v] "v"(v), [ca] "v"(ca), [cb] "v"(cb), [cc] "v"(cc), [o] "v"(o), [px] "v"(pxc[S & 3]), [py] "v"(pyc[S >> 2]));
-    }
-    const uint32_t lastp = bcast_u<S>(last);
-    const bool valid = (pos < lastp) & !(power > 0.f) & !(alpha < 1.f / 255.f);
-    if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;  // nothing blended here: carries stay
-    const float a = valid ? alpha : 0.f;
-    const float Gv = valid ? G : 0.f;
-    // Hand-scheduled (the compiler neither folds the row broadcasts / shifts into the arithmetic that uses them nor keeps
-    // the scans to one instruction per step): every DPP source below is written at least two issue slots before it is
-    // read (s_nop where nothing useful fits).  row_shr without bound_ctrl: a lane without a source keeps its value, which
-    // makes `x op= x[lane - d]` an in-place Kogge-Stone step.
-    //   incl  = prod_{m <= n} (1 - a_m)          Tk = Tc[quad] * incl[n - 1]        w = a Tk
-    //   cg    = c . g[quad]                      sinc = sum_{m <= n} cg_m w_m        Qk = Qc[quad] - sinc
-    //   gda   = Gv (Tk cg - Qk / (1 - a))        (the alpha clamp is transparent in the backward)
-    float incl, sinc, gda, w, cg, ia, t0, a1;
-    asm volatile(
-        "v_sub_f32 %[incl], 1.0, %[a]\n\t"
-        "v_mul_f32 %[a1], %[fp], %[fq]\n\t"                                                         // A operand of the moments
-        "v_mul_f32_dpp %[cg], %[G0], %[cr] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
-        "v_rcp_f32 %[ia], %[incl]\n\t"
-        "v_fmac_f32_dpp %[cg], %[G1], %[cgn] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[cg], %[G2], %[cb] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32 %[t0], 1.0\n\t"
-        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_mul_f32_dpp %[incl], %[incl], %[incl] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_mov_b32_dpp %[t0], %[incl] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %[t0], %[Tc], %[t0] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"      // Tk (DPP source: Tc)
-        "v_mul_f32 %[w], %[a], %[t0]\n\t"
-        "v_mul_f32 %[sinc], %[cg], %[w]\n\t"
-        "v_mul_f32 %[gda], %[t0], %[cg]\n\t"                                                        // Tk cg
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[sinc], %[sinc], %[sinc] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_sub_f32_dpp %[t0], %[Qc], %[sinc] row_newbcast:%[S] row_mask:0xf bank_mask:0xf\n\t"    // Qk (reads sinc as a plain operand)
-        "v_fma_f32 %[gda], -%[t0], %[ia], %[gda]\n\t"                                               // Tk cg - Qk / (1 - a)
-        "v_mul_f32 %[gda], %[Gv], %[gda]\n\t"
-        "s_nop 1\n\t"       // VALU write -> MFMA read of gda: two wait states (the compiler cannot see into this block)
-        : [incl] "=&v"(incl), [sinc] "=&v"(sinc), [gda] "=&v"(gda), [w] "=&v"(w), [cg] "=&v"(cg), [ia] "=&v"(ia), [t0] "=&v"(t0),
-          [a1] "=&v"(a1)
-        : [a] "v"(a), [Gv] "v"(Gv), [cr] "v"(cr), [cgn] "v"(cg_), [cb] "v"(cbl), [G0] "v"(G0), [G1] "v"(G1), [G2] "v"(G2),
-          [Tc] "v"(Tc), [Qc] "v"(Qc), [fp] "v"(fP[S & 3]), [fq] "v"(fQ[S >> 2]), [S] "n"(S));
-    C1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, gda, C1, 0, 0, 0);
-    constexpr int R = S / 5, Tq = S % 5;
-    float a2 = X[R];
-    if constexpr (Tq != 0)                                                // row_ror:(16 - 3 Tq): lane m reads lane m + 3 Tq
-      a2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(X[R]), 0x120 + 16 - 3 * Tq, 0xf, 0xf, false));
-    C2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, w, C2, 0, 0, 0);
-    // the quad's carries move past this group: lane n == S of every row owns them
-    constexpr unsigned long long MINE = 0x0001000100010001ull << S;
-    float tn, qn;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mul_f32_dpp %[tn], %[incl], %[Tc] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_subrev_f32_dpp %[qn], %[sinc], %[Qc] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32 %[Tc], %[Tc], %[tn], %[mine]\n\t"
-        "v_cndmask_b32 %[Qc], %[Qc], %[qn], %[mine]\n\t"
-        : [tn] "=&v"(tn), [qn] "=&v"(qn), [Tc] "+v"(Tc), [Qc] "+v"(Qc)
-        : [incl] "v"(incl), [sinc] "v"(sinc), [mine] "s"(MINE));
-  }
-  // The same step WITHOUT the matrix cores (round 5).  Measured (tools/probe/valu_rate.hip, tools/mfma_stamps.py): a
+  // The same step WITHOUT the matrix cores (round 5).  Measured (tools/probe/valu_rate.hip, tools/bwd_stamps.py): a
   // v_mfma_f32_16x16x4_f32 holds the SIMD for its 32 cycles - VALU instructions of the other waves do not issue under it -
   // so the two MFMAs of a step cost 64 of its ~156 SIMD cycles, for 9 x 16 x 4 useful multiply-adds.  The lane keeps the
   // nine sums of ITS pixel k over the quads (8 plain VALU for the moments, 3 FMAs with the colour gradient as a DPP
@@ -285,10 +186,6 @@ struct MfmaWalk {
     step_lane<7>(sm); step_lane<8>(sm); step_lane<9>(sm); step_lane<10>(sm); step_lane<11>(sm); step_lane<12>(sm); step_lane<13>(sm);
     step_lane<14>(sm); step_lane<15>(sm);
   }
-  __device__ __forceinline__ void run16(uint32_t sm) {
-    step<0>(sm); step<1>(sm); step<2>(sm); step<3>(sm); step<4>(sm); step<5>(sm); step<6>(sm); step<7>(sm);
-    step<8>(sm); step<9>(sm); step<10>(sm); step<11>(sm); step<12>(sm); step<13>(sm); step<14>(sm); step<15>(sm);
-  }
 };
 
 // x[n] + x[n + 16] + x[n + 32] + x[n + 48] in every lane (gfx950's row swaps: upper half <-> lower half, odd rows <-> even rows)
@@ -302,7 +199,7 @@ __device__ __forceinline__ float sum_rows(float x) {
 // the owners' LDS accumulators.  Neighbouring pixels share their owner (a near Gaussian owns a whole quadrant) and same-address
 // LDS float adds serialise (21 us of the headline launch when every lane added for itself, round 4), so equal keys are merged
 // in registers first.  Round 4 did that with a loop over the wave's DISTINCT owners, one full wave reduction per owner - fine
-// for one owner, 12-17 % of a wave's lifetime where a quadrant has dozens (tools/mfma_stamps.py).  Round 5: a fixed binary
+// for one owner, 12-17 % of a wave's lifetime where a quadrant has dozens (tools/bwd_stamps.py).  Round 5: a fixed binary
 // tree over the lane index - rows 0|1 and 2|3 (v_permlane16_swap), rows 0|2 (v_permlane32_swap), then lanes n | n+1, n+2,
 // n+4, n+8 of row 0 (DPP row_shl / row_shr: the quads of the quadrant, neighbours first) - where the representative of the lower half absorbs the representative of the
 // upper half IF their owners are equal; whoever was not absorbed adds for itself.  One owner per wave: one lane adds.  All
@@ -360,13 +257,37 @@ __device__ __forceinline__ void depth_adds(bool pend, uint32_t rel, float d0, fl
   }
 }
 
-// STAMP (measurement only, rtgs_raster_set_mfma_stamps): every wave leaves fourteen 64-bit words - wall clock (100 MHz) at entry
+// The sub-list of a wave's quadrant, compacted by the wave itself: lane l looks at the block masks of list entries 4 l .. 4 l + 3
+// of the batch (`mk`: four 16-bit masks), keeps those that reach quadrant `qm` and lie below `m`, and writes their indices to
+// `sub` in list order (four ballots, no cross-wave step).  Returns the length of the sub-list.
+__device__ __forceinline__ int compact_quadrant(uint2 mk, uint32_t qm, int m, int lane, uint8_t* __restrict__ sub) {
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t mask = ((j < 2 ? mk.x : mk.y) >> (16 * (j & 1))) & 0xffffu;
+    bits |= (((mask & qm) != 0u) & (4 * lane + j < m)) ? (1u << j) : 0u;
+  }
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t pre = 0, total = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(((bits >> j) & 1u) != 0u);
+    pre += (uint32_t)__popcll(bal & lt);
+    total += (uint32_t)__popcll(bal);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if ((bits >> j) & 1u) sub[pre + (uint32_t)__popc(bits & ((1u << j) - 1u))] = (uint8_t)(4 * lane + j);
+  return (int)total;
+}
+
+// STAMP (measurement only, rtgs_raster_set_bwd_stamps): every wave leaves fourteen 64-bit words - wall clock (100 MHz) at entry
 // and exit, shader cycles spent in the group loop and in the whole kernel, groups walked, quad steps entered, the cycles of
-// the other phases (prologue | accumulator zeroing + depth partials | staging: gather -> LDS, block test | compaction |
-// barrier behind the loop: the tile's slowest quadrant | per-entry tail: moments -> slot store) and two marks inside the
-// prologue (per-tile words there | per-pixel loads used and first barrier passed).
-// MF: the pixel sums on the matrix cores (round 4) instead of in lane accumulators (round 5, the product kernel).
-template <bool STAMP, bool MF>
+// the other phases (prologue: until every first load has landed | accumulator zeroing + depth partials | staging: records ->
+// LDS (gather path: the gather and the quadrant test) | compaction + the barrier before the walk | barrier behind the loop:
+// the tile's slowest quadrant | per-entry tail: moments -> slot store) and two marks inside the prologue (per-tile words
+// there | every load of the prologue there).
+template <bool STAMP>
 __device__ __forceinline__ void blend_bwd_entry_body(
     const RasterParams& p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, const float* __restrict__ out_color, const uint32_t* __restrict__ n_contrib,
@@ -374,23 +295,22 @@ __device__ __forceinline__ void blend_bwd_entry_body(
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
     SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode,
-    uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long* __restrict__ stamps) {
+    uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long* __restrict__ stamps, const TileCache& tc,
+    const uint32_t* __restrict__ order) {
   unsigned long long st_wall = 0, st_cyc = 0, st_walk = 0, st_groups = 0, st_steps = 0;
   unsigned long long st_seg[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;   // prologue | zero + depth | stage | compact | after-loop barrier | entry tail
   if constexpr (STAMP) { st_wall = wall_clock64(); st_cyc = __builtin_readcyclecounter(); }
-  __shared__ float4 s_rec[MB * 3];              // u v ca cb | cc o r g | b id slot0 -
+  __shared__ float4 s_rec[MB * 3];              // u v ca cb | cc o r g | b id blockmask -
   __shared__ float s_acc[MB * MACC];            // per-entry sums of the tile (LDS float adds: one flush per wave and group)
-  __shared__ float s_g[4][4][16][3];            // [wave][k][quad][channel]: colour gradients on their way into X
   __shared__ uint8_t s_sub[4][MB];              // per quadrant: the staged entries that reach it, in list order
-  __shared__ uint32_t s_cnt[4][4];              // [quadrant][staging wave]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
-  // Workgroup -> tile in launch order.  XCD-aware orders were measured in round 5 and change nothing here (contiguous bands of
-  // tiles per XCD: 92.3 / 139.2 us - the heavy rows of the image land on two XCDs; 4 x 4 tile blocks going round the XCDs:
-  // 88.6 / 143.3 us; launch order: 88.0 / 142.6 us): the records neighbouring tiles share are a tenth of this kernel's traffic.
-  const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
-  const int tile = by * p.gx + bx;
+  // Workgroup -> tile: launch order, or (order != nullptr) the longest walks first - the last third of a launch in tile order
+  // is a tail of the heavy tiles that started late (stamps).  XCD-aware orders were measured in round 5 and change nothing
+  // here: the records neighbouring tiles share are a tenth of this kernel's traffic.
+  const int tile = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
+  const int bx = tile % p.gx, by = tile / p.gx;
   // wave = 8x8 quadrant, step = 2x2 quad s of it, DPP row k = pixel of the quad; THIS lane's own pixel is (quad n, k)
   const int n = lane & 15, k = lane >> 4;
   const int qx0 = (wv & 1) * 8, qy0 = (wv >> 1) * 8;
@@ -399,8 +319,9 @@ __device__ __forceinline__ void blend_bwd_entry_body(
   const uint32_t HW = (uint32_t)(p.H * p.W);
   const uint32_t pix = inside ? (uint32_t)(py * p.W + px) : 0u;       // clamped: the loads below carry no branch
 
-  // This phase is latency: every load whose address is known is issued before the first one is waited for - the
-  // per-tile words (one scalar round trip, not four dependent ones) and the per-pixel values.
+  // This phase is latency: EVERY load of it is issued before the first one is waited for - the per-tile words, the
+  // per-pixel values, and (round 6) the tile's records and block masks from the TileCache, whose addresses need the tile
+  // index only.  The cache is allocated for every tile, so the loads are in bounds whether or not the forward filled it.
   const uint32_t tmode = tile_mode[tile];
   const uint2 range = ranges[tile];
   const uint32_t tlast = tile_last[tile];               // the tile's last contributor (left by blend_fwd)
@@ -413,17 +334,25 @@ __device__ __forceinline__ void blend_bwd_entry_body(
   const int owner_ld = depth_index[pix];
   const float gD_ld = dL_ddepth[pix];
   const uint32_t dpos_ld = depth_pos[pix];
-  // the tile stages no further than its last contributor: no reduction of n_contrib, no barrier before the first gather
-  const int nuse = min((int)(range.y - range.x), (int)tlast);
-  const bool act = !failed & ((tmode & 3u) == 2u) & (nuse > 0);      // else: another walk has this tile, or nothing to do
-  // first batch: the gather's two dependent hops start now, under the per-pixel loads still in flight
-  const int m0n = min(MB, nuse);
-  const uint32_t id0 = (act && tid < m0n) ? point_list[range.x + tid] : 0u;
+  const bool have_cache = tc.recs != nullptr;
+  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0;
+  uint2 mk = make_uint2(0u, 0u);
+  float2 aux = make_float2(0.f, 0.f);
+  if (have_cache) {
+    const float4* const rsrc = tc.recs + ((size_t)tile * TILE_RECS + (size_t)tid) * 3;
+    c0 = rsrc[0]; c1 = rsrc[1]; c2 = rsrc[2];
+    mk = reinterpret_cast<const uint2*>(tc.masks + (size_t)tile * TILE_RECS)[lane];      // entries 4 lane .. 4 lane + 3
+    aux = tc.depth_aux[pix];
+  }
   // (keeps the loads above the exit: sunk below it - where their first use is - they would start one scalar round trip
   // per test later, and this phase is nothing but round trips)
-  asm volatile("" ::"v"(last_ld), "v"(g0), "v"(g1), "v"(g2), "v"(oc0), "v"(oc1), "v"(oc2), "v"(owner_ld), "v"(gD_ld), "v"(dpos_ld), "v"(id0),
-               "s"(use_slots_w), "s"(slot_grads));
+  asm volatile("" ::"v"(last_ld), "v"(g0), "v"(g1), "v"(g2), "v"(oc0), "v"(oc1), "v"(oc2), "v"(owner_ld), "v"(gD_ld), "v"(dpos_ld),
+               "v"(c0.x), "v"(c1.x), "v"(c2.x), "v"(mk.x), "v"(aux.x), "s"(use_slots_w), "s"(slot_grads));
+  // the tile stages no further than its last contributor: no reduction of n_contrib, no barrier before the first load
+  const int nuse = min((int)(range.y - range.x), (int)tlast);
+  const bool act = !failed & ((tmode & 3u) == 2u) & (nuse > 0);      // else: another walk has this tile, or nothing to do
   if (!act) return;
+  const bool cached = have_cache && (tmode & 4u) != 0u && !(dbg & 8u);   // this forward filled the cache for this tile (bit 3: ignore it, A-B / tests)
   unsigned long long st_p1 = 0, st_p2 = 0;
   if constexpr (STAMP) st_p1 = __builtin_readcyclecounter() - st_cyc;   // the per-tile words are here
   const bool use_slots = use_slots_w != 0;
@@ -431,134 +360,119 @@ __device__ __forceinline__ void blend_bwd_entry_body(
   const float tx0 = (float)(bx * TILE), ty0 = (float)(by * TILE);
   const float cxT = tx0 + 7.5f, cyT = ty0 + 7.5f;     // moments are taken about the tile centre
 
-  MfmaWalk W;
+  EntryWalk W;
   W.n = n;
   W.last = inside ? last_ld : 0u;
   W.G0 = inside ? g0 : 0.f; W.G1 = inside ? g1 : 0.f; W.G2 = inside ? g2 : 0.f;
   W.Tc = 1.f;
   // (colour behind the walk) . g + T_final (bg . g) before the first entry = the pixel's output colour . g
   W.Qc = oc0 * W.G0 + oc1 * W.G1 + oc2 * W.G2;
-  // list position of this pixel's depth owner, if it has one with gradient
-  const bool has_owner = inside && owner_ld >= 0 && gD_ld != 0.f;
+  // Opaque-surface depth: D = pd / (n_c . r); only the pixel's owner receives it.  A pixel owns at
+  // most one entry of the whole list: its four partials go to that entry's accumulator in the batch that stages it.  The
+  // two words they need beyond the pixel's own ray - 1 / (n_c . r) and pd - come from the forward (TileCache::depth_aux);
+  // without a cache, from the owner's Splat record (a dependent gather).
+  const bool has_owner = inside && owner_ld >= 0 && gD_ld != 0.f && !(dbg & 2u);
   const uint32_t dpos = has_owner ? dpos_ld : 0xffffffffu;
-  for (int q = tid; q < m0n * MACC; q += BLOCK) s_acc[q] = 0.f;
-  if constexpr (MF) { s_g[wv][k][n][0] = W.G0; s_g[wv][k][n][1] = W.G1; s_g[wv][k][n][2] = W.G2; }
   // a wave walks no further than its own last contributor
   uint32_t wave_last = W.last;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, off));
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  __syncthreads();                                     // the first batch's accumulators are zero
-  if constexpr (STAMP) st_p2 = __builtin_readcyclecounter() - st_cyc;   // per-pixel loads used, accumulators zeroed, barrier passed
-  // Opaque-surface depth: D = pd / (n_c . r); only the pixel's owner receives it.  A pixel owns
-  // at most one entry of the whole list: its four partials go to that entry's accumulator in the batch that stages it -
-  // for the first batch here, with the owner's record fetched beside the gather (later batches: inside the loop).
-  // (Round 5 also tried the owner's plane from the staged records - 4 float4 per entry in LDS, partials behind the
-  // compaction: the prologue shrinks by a tenth of a wave's lifetime and the compaction barrier grows by as much - the
-  // record gather is the critical path either way.  89.7 / 146.6 us against 88.0 / 142.6: not kept.)
-  {
-    const bool pend = dpos < (uint32_t)m0n && !(dbg & 2u);
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-    if (pend) {
-      const float4 r2 = reinterpret_cast<const float4*>(splats + owner_ld)[2];   // b nx ny nz
-      const float pd = reinterpret_cast<const float*>(splats + owner_ld)[12];
-      const float rx = ((float)px - p.cx) / p.fx, ry = ((float)py - p.cy) / p.fy;
-      const float iden = 1.f / (r2.y * rx + r2.z * ry + r2.w);
-      const float kk = -gD_ld * (pd * iden) * iden;
-      d0 = kk * rx; d1 = kk * ry; d2 = kk; d3 = gD_ld * iden;
-    }
-    depth_adds(pend, dpos, d0, d1, d2, d3, s_acc, lane);
+  const uint32_t qmask = 0x0033u << (2 * (wv & 1) + 8 * (wv >> 1));    // the 4x4 blocks of this wave's quadrant (blocks_reached numbering)
+  if constexpr (STAMP) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    st_t = __builtin_readcyclecounter(); st_p2 = st_t - st_cyc; st_seg[0] = st_t - st_cyc;
   }
 
-  if constexpr (STAMP) { st_t = __builtin_readcyclecounter(); st_seg[0] = st_t - st_cyc; }
   for (int base = 0; base < nuse; base += MB) {
     const int m = min(MB, nuse - base);
-    if (base > 0) {
-      __syncthreads();                                 // previous batch flushed before its LDS is reused
-      for (int q = tid; q < m * MACC; q += BLOCK) s_acc[q] = 0.f;
+    if (base > 0) __syncthreads();                     // the previous batch's tail has read its LDS
+    for (int q = tid; q < m * MACC; q += BLOCK) s_acc[q] = 0.f;
+    if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[1] += t - st_t; st_t = t; }
+    int cnt;
+    if (base == 0 && cached) {
+      // ---- the forward's records: already in registers, one LDS write; the sub-list from the block masks, by this wave alone
+      if (tid < m) { s_rec[tid * 3 + 0] = c0; s_rec[tid * 3 + 1] = c1; s_rec[tid * 3 + 2] = c2; }
+      if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[2] += t - st_t; st_t = t; }
+      cnt = compact_quadrant(mk, qmask, m, lane, s_sub[wv]);
       __syncthreads();
+    } else {
+      // ---- gather path: one record per thread through the list, tested against the four quadrants here
+      float txl = tx0, tyl = ty0;                        // laundered: the test's per-tile constants must not be hoisted
+      asm volatile("" : "+v"(txl), "+v"(tyl));           // out of the batch loop (they would be live through the walk)
+      uint32_t bm = 0;
+      int tl = tid, ll = lane;
+      asm volatile("" : "+v"(tl), "+v"(ll));            // this path's addresses are formed here (held from the prologue on they spill)
+      if (tid < m) {
+        const uint32_t id = point_list[range.x + base + tl];
+        const float4* src = reinterpret_cast<const float4*>(splats + id);
+        const float4 q0 = src[0];
+        s_rec[tid * 3 + 0] = q0;
+        const float4 q1 = src[1];
+        s_rec[tid * 3 + 1] = q1;
+        const float b = reinterpret_cast<const float*>(splats + id)[8];
+        const float2 hxy = reinterpret_cast<const float2*>(splats + id)[7];
+        const uint32_t reach = quads_reached(q0.x, q0.y, hxy.x, hxy.y, q0.z, q0.w, q1.x, q1.y, txl, tyl);
+        bm = ((reach & 1u) ? 0x0033u : 0u) | ((reach & 2u) ? 0x00ccu : 0u) | ((reach & 4u) ? 0x3300u : 0u) | ((reach & 8u) ? 0xcc00u : 0u);
+        s_rec[tid * 3 + 2] = make_float4(b, __uint_as_float(id), __uint_as_float(bm), 0.f);
+      }
+      if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); st_seg[2] += t - st_t; st_t = t; }
+      __syncthreads();
+      uint2 ml;
+      {
+        const int e0 = 4 * ll;
+        const uint32_t m0 = e0 + 0 < m ? __float_as_uint(s_rec[(e0 + 0) * 3 + 2].z) : 0u, m1 = e0 + 1 < m ? __float_as_uint(s_rec[(e0 + 1) * 3 + 2].z) : 0u;
+        const uint32_t m2 = e0 + 2 < m ? __float_as_uint(s_rec[(e0 + 2) * 3 + 2].z) : 0u, m3 = e0 + 3 < m ? __float_as_uint(s_rec[(e0 + 3) * 3 + 2].z) : 0u;
+        ml = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
+      }
+      cnt = compact_quadrant(ml, qmask, m, lane, s_sub[wv]);
+      // (s_sub[wv] is read by this wave only: no barrier between its compaction and its walk)
+    }
+    if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[3] += t - st_t; st_t = t; }
+    // ---- the depth owners of this batch (accumulators are zero and visible: behind the barrier).  kk = -gD D / (n_c . r).
+    {
       const bool pend = dpos >= (uint32_t)base && dpos < (uint32_t)(base + m);
       float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-      if (pend) {
-        const int owner = depth_index[pix];
-        const float gD = dL_ddepth[pix];
-        const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
-        const float pd = reinterpret_cast<const float*>(splats + owner)[12];
-        const float rx = ((float)px - p.cx) / p.fx, ry = ((float)py - p.cy) / p.fy;
-        const float iden = 1.f / (r2.y * rx + r2.z * ry + r2.w);
-        const float kk = -gD * (pd * iden) * iden;
-        d0 = kk * rx; d1 = kk * ry; d2 = kk; d3 = gD * iden;
+      if (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
+        if (pend) {
+          float iden, Dd, gD;
+          const float rx = ((float)px - p.cx) / p.fx, ry = ((float)py - p.cy) / p.fy;
+          uint32_t pl = pix;
+          asm volatile("" : "+v"(pl));              // the addresses of these rare loads are formed here, not held from the prologue on
+          if (base == 0) { iden = aux.x; Dd = aux.y; gD = gD_ld; }
+          else { gD = dL_ddepth[pl]; const float2 a2 = cached ? tc.depth_aux[pl] : make_float2(0.f, 0.f); iden = a2.x; Dd = a2.y; }
+          if (!cached) {
+            const int owner = depth_index[pl];
+            const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
+            const float pd = reinterpret_cast<const float*>(splats + owner)[12];
+            iden = 1.f / (r2.y * rx + r2.z * ry + r2.w);
+            Dd = pd * iden;
+          }
+          const float kk = -gD * Dd * iden;
+          d0 = kk * rx; d1 = kk * ry; d2 = kk; d3 = gD * iden;
+        }
+        depth_adds(pend, dpos - (uint32_t)base, d0, d1, d2, d3, s_acc, lane);
       }
-      depth_adds(pend, dpos - (uint32_t)base, d0, d1, d2, d3, s_acc, lane);
     }
     if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[1] += t - st_t; st_t = t; }
-    // ---- stage one record per thread, test it against the four quadrants, count per quadrant
-    uint32_t reach = 0;
-    float txl = tx0, tyl = ty0;                        // laundered: the block test's per-tile constants must not be hoisted
-    asm volatile("" : "+v"(txl), "+v"(tyl));           // out of the batch loop (they would be live through the walk)
-    if (tid < m) {
-      const uint32_t id = base == 0 ? id0 : point_list[range.x + base + tid];
-      const float4* src = reinterpret_cast<const float4*>(splats + id);
-      const float4 q0 = src[0];
-      s_rec[tid * 3 + 0] = q0;
-      const float4 q1 = src[1];
-      s_rec[tid * 3 + 1] = q1;
-      const float b = reinterpret_cast<const float*>(splats + id)[8];
-      const float2 hxy = reinterpret_cast<const float2*>(splats + id)[7];
-      const uint32_t slot0 = use_slots ? gbase[id] : 0u;
-      s_rec[tid * 3 + 2] = make_float4(b, __uint_as_float(id), __uint_as_float(slot0), 0.f);
-      reach = quads_reached(q0.x, q0.y, hxy.x, hxy.y, q0.z, q0.w, q1.x, q1.y, txl, tyl);
-    }
-    if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); st_seg[2] += t - st_t; st_t = t; }
-    unsigned long long bal[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      bal[q] = __builtin_amdgcn_ballot_w64(((reach >> q) & 1u) != 0u);
-      if (lane == 0) s_cnt[q][wv] = (uint32_t)__popcll(bal[q]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uint32_t off = 0;
-      for (int w2 = 0; w2 < wv; ++w2) off += s_cnt[q][w2];
-      if ((bal[q] >> lane) & 1ull) s_sub[q][off + (uint32_t)__popcll(bal[q] & lt)] = (uint8_t)tid;
-    }
-    __syncthreads();
 
     // ---- the wave walks its quadrant's sub-list, 16 entries at a time
-    const int cnt = (int)(s_cnt[wv][0] + s_cnt[wv][1] + s_cnt[wv][2] + s_cnt[wv][3]);
     {
       // Per-lane constants of the walk, (re)built per batch from the laundered lane coordinates: held across the batch
-      // loop they would be live through the staging above (whose block test is register-hungry) and cost a wave per SIMD.
-      int kq = k, nq = n;
-      asm volatile("" : "+v"(kq), "+v"(nq));
+      // loop they would be live through the staging above and cost a wave per SIMD.
+      int kq = k;
+      asm volatile("" : "+v"(kq));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         W.pxc[j] = (float)(bx * TILE + qx0 + 2 * j + (kq & 1));
         W.pyc[j] = (float)(by * TILE + qy0 + 2 * j + (kq >> 1));
-        const float x = W.pxc[j] - cxT, y = W.pyc[j] - cyT;
-        if constexpr (MF) {
-          // features 1 x y x^2 xy y^2 of the pixel, factored into a column and a row term per lane (lane & 15 = feature)
-          W.fP[j] = (nq == 1 || nq == 4) ? x : nq == 3 ? x * x : nq <= 5 ? 1.f : 0.f;
-          W.fQ[j] = (nq == 2 || nq == 4) ? y : nq == 5 ? y * y : 1.f;
-        } else {
-          W.xq[j] = x; W.yq[j] = y;
-        }
-      }
-      // colour gradients as A operands: X[r] lane (k, 3 t + c) = g_c of pixel (quad 5 r + t, k)
-      if constexpr (MF) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = 5 * r + nq / 3;
-          W.X[r] = (nq < 15 && q < 16) ? s_g[wv][kq][q][nq % 3] : 0.f;
-        }
+        W.xq[j] = W.pxc[j] - cxT; W.yq[j] = W.pyc[j] - cyT;
       }
     }
     unsigned long long w_in = 0;
-    if constexpr (STAMP) { w_in = __builtin_readcyclecounter(); st_seg[3] += w_in - st_t; }
-    for (int g0 = 0; g0 < cnt && !(dbg & 1u); g0 += 16) {
-      const bool have = g0 + n < cnt;
-      const int e = have ? (int)s_sub[wv][g0 + n] : 0;
+    if constexpr (STAMP) w_in = __builtin_readcyclecounter();
+    for (int g0i = 0; g0i < cnt && !(dbg & 1u); g0i += 16) {
+      const bool have = g0i + n < cnt;
+      const int e = have ? (int)s_sub[wv][g0i + n] : 0;
       W.pos = have ? (uint32_t)(base + e) : 0x7fffffffu;
       const uint32_t first_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.pos);
       if (first_pos >= wave_last) break;                 // positions increase: the wave is through
@@ -570,33 +484,17 @@ __device__ __forceinline__ void blend_bwd_entry_body(
       const float4 r0 = s_rec[e * 3 + 0], r1 = s_rec[e * 3 + 1];
       const float rb = s_rec[e * 3 + 2].x;
       W.u = r0.x; W.v = r0.y; W.ca = r0.z; W.cb = r0.w; W.cc = r1.x; W.o = r1.y; W.cr = r1.z; W.cg_ = r1.w; W.cbl = rb;
-      if constexpr (MF) {
-        W.C1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        W.C2 = f32x4{0.f, 0.f, 0.f, 0.f};
-        W.run16(stepmask);
-        // flush: lane (k, n) holds rows 4 k + i of column n.  C1 rows 0..5 = m0 mx my mxx | mxy myy; C2 rows 0..2 = colour
-        if (have) {
-          float* const acc = &s_acc[e * MACC];
-          if (k == 0) {
-            atomicAdd(acc + 0, W.C1[0]); atomicAdd(acc + 1, W.C1[1]); atomicAdd(acc + 2, W.C1[2]); atomicAdd(acc + 3, W.C1[3]);
-            atomicAdd(acc + 6, W.C2[0]); atomicAdd(acc + 7, W.C2[1]); atomicAdd(acc + 8, W.C2[2]);
-          } else if (k == 1) {
-            atomicAdd(acc + 4, W.C1[0]); atomicAdd(acc + 5, W.C1[1]);
-          }
-        }
-      } else {
-        W.s0 = W.sx = W.sy = W.sxx = W.sxy = W.syy = W.sr = W.sg = W.sb = 0.f;
-        W.run16_lane(stepmask);
-        // the four pixel rows k of an entry meet in registers (v_permlane32_swap / v_permlane16_swap: two instructions per
-        // sum) and row 0 adds them to the entry's accumulator.  64 lanes adding for themselves cost 4x the LDS float adds of
-        // the MFMA form, and those run at about a lane per cycle per CU: measured 153 / 277 us instead of 99 / 165.
-        const float f0 = sum_rows(W.s0), f1 = sum_rows(W.sx), f2 = sum_rows(W.sy), f3 = sum_rows(W.sxx), f4 = sum_rows(W.sxy);
-        const float f5 = sum_rows(W.syy), f6 = sum_rows(W.sr), f7 = sum_rows(W.sg), f8 = sum_rows(W.sb);
-        if (have && k == 0) {
-          float* const acc = &s_acc[e * MACC];
-          atomicAdd(acc + 0, f0); atomicAdd(acc + 1, f1); atomicAdd(acc + 2, f2); atomicAdd(acc + 3, f3); atomicAdd(acc + 4, f4);
-          atomicAdd(acc + 5, f5); atomicAdd(acc + 6, f6); atomicAdd(acc + 7, f7); atomicAdd(acc + 8, f8);
-        }
+      W.s0 = W.sx = W.sy = W.sxx = W.sxy = W.syy = W.sr = W.sg = W.sb = 0.f;
+      W.run16_lane(stepmask);
+      // the four pixel rows k of an entry meet in registers (v_permlane32_swap / v_permlane16_swap: two instructions per
+      // sum) and row 0 adds them to the entry's accumulator.  64 lanes adding for themselves cost 4x the LDS float adds,
+      // and those run at about a lane per cycle per CU: measured 153 / 277 us instead of 99 / 165.
+      const float f0 = sum_rows(W.s0), f1 = sum_rows(W.sx), f2 = sum_rows(W.sy), f3 = sum_rows(W.sxx), f4 = sum_rows(W.sxy);
+      const float f5 = sum_rows(W.syy), f6 = sum_rows(W.sr), f7 = sum_rows(W.sg), f8 = sum_rows(W.sb);
+      if (have && k == 0) {
+        float* const acc = &s_acc[e * MACC];
+        atomicAdd(acc + 0, f0); atomicAdd(acc + 1, f1); atomicAdd(acc + 2, f2); atomicAdd(acc + 3, f3); atomicAdd(acc + 4, f4);
+        atomicAdd(acc + 5, f5); atomicAdd(acc + 6, f6); atomicAdd(acc + 7, f7); atomicAdd(acc + 8, f8);
       }
     }
     if constexpr (STAMP) { st_t = __builtin_readcyclecounter(); st_walk += st_t - w_in; }
@@ -611,6 +509,9 @@ __device__ __forceinline__ void blend_bwd_entry_body(
       for (int q = 0; q < 13; ++q) { t[q] = s_acc[tid * MACC + q]; any |= (t[q] != 0.f); }
       const uint32_t gid = __float_as_uint(s_rec[tid * 3 + 2].y);
       if (any && gid - t0 < tn && !(dbg & 4u)) {          // a frozen row (outside [t0, t0 + tn)) takes no slot
+        // the slot run of the Gaussian and its next free slot: two independent round trips, issued together
+        uint32_t slot = 0u;
+        if (use_slots) slot = gbase[gid] + atomicAdd(&slot_count[gid], 1u);
         const float4 q0 = s_rec[tid * 3 + 0];            // u v ca cb
         const float4 q1 = s_rec[tid * 3 + 1];            // cc o r g
         // sums over the pixels of gdl = o gda times powers of d = centre - pixel, from the moments about the tile centre
@@ -625,7 +526,6 @@ __device__ __forceinline__ void blend_bwd_entry_body(
         touched[gid] = 1;
         if (use_slots) {
           // SplatGrad order: du dv dca dcb | dcc dop dr dg | db dnx dny dnz | dpd - - -
-          const uint32_t slot = __float_as_uint(s_rec[tid * 3 + 2].z) + atomicAdd(&slot_count[gid], 1u);
           float4* dst = reinterpret_cast<float4*>(slot_grads + slot);
           dst[0] = make_float4(du, dv, dca, dcb);
           dst[1] = make_float4(dcc, dop, t[6], t[7]);
@@ -659,40 +559,37 @@ __device__ __forceinline__ void blend_bwd_entry_body(
       const uint32_t *__restrict__ depth_pos, const uint32_t *__restrict__ tile_last, const float *__restrict__ dL_dcolor,           \
       const float *__restrict__ dL_ddepth, const uint32_t *__restrict__ gbase, uint32_t *__restrict__ slot_count,                    \
       const BwdInfo *__restrict__ info, SplatGrad *__restrict__ grads, uint8_t *__restrict__ touched,                               \
-      const uint32_t *__restrict__ tile_mode, uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long *__restrict__ stamps
+      const uint32_t *__restrict__ tile_mode, uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long *__restrict__ stamps,       \
+      TileCache tc, const uint32_t *__restrict__ order
 #define RTGS_BWD_PASS                                                                                                             \
   p, ranges, point_list, splats, out_color, n_contrib, depth_index, depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, \
-      info, grads, touched, tile_mode, t0, tn, dbg, stamps
-// the product kernel: entry-per-lane walk, pixel sums in lane accumulators
-__global__ void __launch_bounds__(256, 5) blend_bwd_entry_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false, false>(RTGS_BWD_PASS); }
-// round 4's form of it (pixel sums by v_mfma_f32_16x16x4_f32), kept for A-B runs: rtgs_raster_set_mfma_walk(8)
-__global__ void __launch_bounds__(256, 5) blend_bwd_entry_mfma_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false, true>(RTGS_BWD_PASS); }
-// either, leaving per-wave time stamps (tools/mfma_stamps.py)
-template <bool MF>
-__global__ void __launch_bounds__(256, 5) blend_bwd_entry_stamped_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<true, MF>(RTGS_BWD_PASS); }
+      info, grads, touched, tile_mode, t0, tn, dbg, stamps, tc, order
+// the product kernel
+__global__ void __launch_bounds__(256, 5) blend_bwd_entry_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false>(RTGS_BWD_PASS); }
+// the same, leaving per-wave time stamps (tools/bwd_stamps.py)
+__global__ void __launch_bounds__(256, 5) blend_bwd_entry_stamped_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<true>(RTGS_BWD_PASS); }
 #undef RTGS_BWD_ARGS
 #undef RTGS_BWD_PASS
 
-// bits 0..2: timing decompositions (walk off / depth partials off / stores off - results are then wrong by construction);
-// bit 3: the MFMA form
-static int g_mfma_dbg = getenv("RTGS_MFMA_DEBUG") ? atoi(getenv("RTGS_MFMA_DEBUG")) : 0;
-static unsigned long long* g_mfma_stamps = nullptr;
-void set_mfma_debug(int bits) { g_mfma_dbg = bits; }
-void set_mfma_stamps(void* dev) { g_mfma_stamps = (unsigned long long*)dev; }
+// timing decompositions (tools only; rtgs_raster_set_bwd_debug): bit 0 walk off, bit 1 depth partials off, bit 2 stores off -
+// results are then wrong by construction, so the bits are NOT read from the environment and the tools that set
+// them clear them again.  Bit 3 (results unchanged): ignore the TileCache, take the gather path (tests, A-B)
+static int g_bwd_dbg = 0;
+static unsigned long long* g_bwd_stamps = nullptr;
+void set_bwd_debug(int bits) { g_bwd_dbg = bits & 15; }
+void set_bwd_stamps(void* dev) { g_bwd_stamps = (unsigned long long*)dev; }
 
-void launch_blend_bwd_mfma(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
-                           const float* out_color, const uint32_t* n_contrib, const int32_t* depth_index,
-                           const uint32_t* depth_pos, const uint32_t* tile_last, const float* dL_dcolor, const float* dL_ddepth,
-                           const uint32_t* gbase, uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
-                           const uint32_t* tile_mode, uint32_t t0, uint32_t tn, hipStream_t st) {
-  const uint32_t dbg = (uint32_t)g_mfma_dbg;
+void launch_blend_bwd_entry(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
+                            const float* out_color, const uint32_t* n_contrib, const int32_t* depth_index,
+                            const uint32_t* depth_pos, const uint32_t* tile_last, const float* dL_dcolor, const float* dL_ddepth,
+                            const uint32_t* gbase, uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
+                            const uint32_t* tile_mode, uint32_t t0, uint32_t tn, TileCache tc, const uint32_t* order, hipStream_t st) {
+  const uint32_t dbg = (uint32_t)g_bwd_dbg;
 #define RTGS_BWD_LAUNCH(KERNEL)                                                                                                      \
-  hipLaunchKernelGGL(KERNEL, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color, n_contrib, depth_index, \
+  hipLaunchKernelGGL(KERNEL, dim3(p.gx * p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color, n_contrib, depth_index, \
                      depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched, tile_mode, t0, tn, dbg,    \
-                     g_mfma_stamps)
-  const bool mf = (dbg & 8u) != 0;
-  if (g_mfma_stamps) { if (mf) RTGS_BWD_LAUNCH(blend_bwd_entry_stamped_kernel<true>); else RTGS_BWD_LAUNCH(blend_bwd_entry_stamped_kernel<false>); }
-  else { if (mf) RTGS_BWD_LAUNCH(blend_bwd_entry_mfma_kernel); else RTGS_BWD_LAUNCH(blend_bwd_entry_kernel); }
+                     g_bwd_stamps, tc, order)
+  if (g_bwd_stamps) RTGS_BWD_LAUNCH(blend_bwd_entry_stamped_kernel); else RTGS_BWD_LAUNCH(blend_bwd_entry_kernel);
 #undef RTGS_BWD_LAUNCH
 }
 

@@ -141,7 +141,20 @@ struct BinLayout {
   size_t slot_grads;                 // backward partial slots (see BwdInfo); 0 slots = not laid out
 };
 struct ImgLayout {
-  size_t ranges, n_contrib, bwd_info, tile_mode, depth_pos, tile_last, total;
+  size_t ranges, n_contrib, bwd_info, tile_mode, depth_pos, tile_last, tile_recs, tile_masks, depth_aux, tile_order, total;
+};
+// What blend_fwd leaves for the entry-per-lane backward at a place that depends on the TILE alone (round 6).  The backward's
+// chain "tile range -> list ids -> record gather -> block test" was three dependent memory round trips and ~150 VALU
+// instructions per entry before the first walk step (a quarter of a wave's life: profiles/r05_bwd_stamps_*); the forward
+// has every one of these values in registers when it stages a batch, so it stores them: the record of list position
+// `pos < TILE_RECS` of tile t at recs[(t * TILE_RECS + pos) * 3], the 16 block bits beside it, and per PIXEL the two words
+// of its depth owner the plane partials need.  The backward then issues every load of its prologue at once - one round trip.
+// Positions >= TILE_RECS (lists walked deeper than 256 entries) take the gather path as before.
+constexpr int TILE_RECS = 256;
+struct TileCache {
+  float4* recs;        // [tiles][TILE_RECS][3]: u v ca cb | cc o r g | b id - -
+  uint16_t* masks;     // [tiles][TILE_RECS]: blocks_reached() of the entry on this tile
+  float2* depth_aux;   // [H * W]: 1 / (n_c . r) of the pixel's depth owner, and the depth D = pd / (n_c . r) itself (0, 0: none)
 };
 // blend_fwd leaves one word per tile for its backward: bits 0..1 = the walk - 0 tile-uniform strip walk (the tile's 4x4
 // blocks share its list), 1 row-granular walk (each block needs only a fraction of it), 2 entry-per-lane MFMA walk

@@ -303,18 +303,24 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint6
 constexpr int FWD_BATCH = BLOCK;                // list entries staged through LDS per refill (one per thread)
 constexpr int FWD_CHUNKS = FWD_BATCH / 32;      // 32-entry words of a block's sub-list
 
-template <int OCC>
+// STAMP (measurement only, tools/fwd_stamps.py): every wave leaves eight 64-bit words - wall clock (100 MHz) at entry and exit,
+// shader cycles until the tile's range is there | until the first batch is staged and its barrier passed | inside the walk
+// loops | in the whole kernel, walk steps taken, batches staged.
+template <int OCC, bool STAMP>
 __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
     int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
     float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
     unsigned long long* __restrict__ counters, SlicePass sp, uint32_t* __restrict__ tile_mode,
-    uint32_t* __restrict__ depth_pos, uint32_t* __restrict__ tile_last, int walk, uint32_t* __restrict__ aux_zero) {
+    uint32_t* __restrict__ depth_pos, uint32_t* __restrict__ tile_last, int walk, uint32_t* __restrict__ aux_zero,
+    TileCache tc, unsigned long long* __restrict__ stamps) {
   __shared__ float4 s_rec[FWD_BATCH * 4];     // u v ca cb | cc o r g | b - - id | nx ny nz pd: the walk reads the first three
   __shared__ float s_z[FWD_BATCH];            // centre depth (opaque-surface test only)
   __shared__ uint32_t s_live[16][FWD_CHUNKS]; // per 4x4 block: the staged entries that reach it
 
+  unsigned long long st_wall = 0, st_cyc = 0, st_range = 0, st_first = 0, st_walk = 0, st_steps = 0, st_batches = 0;
+  if constexpr (STAMP) { st_wall = wall_clock64(); st_cyc = __builtin_readcyclecounter(); }
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
@@ -335,12 +341,14 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
   const uint2 range = ranges[tile];
   int n = (int)(range.y - range.x);
   if (sp.mode == 1 && n > SLICE_MAX_LIST) n = 0;       // near-slice list too long to have been sorted: leave the tile to pass 2
+  if constexpr (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_range = __builtin_readcyclecounter() - st_cyc; }
 
   bool done = !inside;
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   float best_w = 0.f; int best_id = -1;
   float D = 0.f, d_w = 0.f; int d_id = -1;
-  uint32_t d_pos = 0u;                       // list position of the depth owner (the backward's MFMA walk hands the owner its partials by position)
+  float d_iden = 0.f;                        // 1 / (n_c . r) of the depth owner: with D, all the backward's plane partials need beyond the pixel's ray
+  uint32_t d_pos = 0u;                       // list position of the depth owner (the backward's entry walk hands the owner its partials by position)
   uint32_t last_contributor = 0;
   uint32_t evals = 0;
   uint32_t reach_sum = 0, staged = 0;        // wave-uniform: (block, entry) pairs of the sub-lists / entries this wave staged
@@ -366,8 +374,19 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
         s_rec[tid * 4 + 2] = make_float4(q2.x, 0.f, 0.f, __uint_as_float(id));
         s_rec[tid * 4 + 3] = make_float4(q2.y, q2.z, q2.w, q3.x);
         s_z[tid] = q3.y;
+        // For the backward (TileCache, raster_common.h): the record and the block mask of list position base + tid at a place
+        // that depends on the TILE only - its first loads need no tile range, no list id, no gather and no block test.
+        // (The record goes out before the block test, the mask after it: nothing but the position stays live across the test.)
+        const bool keep = tc.recs != nullptr && base + tid < TILE_RECS;
+        if (keep) {
+          float4* const dst = tc.recs + ((size_t)tile * TILE_RECS + (size_t)(base + tid)) * 3;
+          dst[0] = q0; dst[1] = q1;
+          dst[2] = make_float4(q2.x, __uint_as_float(id), 0.f, 0.f);
+        }
         reach = blocks_reached(q0.x, q0.y, q3.z, q3.w, q0.z, q0.w, q1.x, q1.y, tx0, ty0);
+        if (keep) tc.masks[(size_t)tile * TILE_RECS + (size_t)(base + tid)] = (uint16_t)reach;
       }
+      if constexpr (STAMP) st_batches += 1;
 #pragma unroll
       for (int b = 0; b < 16; ++b) {
         const unsigned long long bal = __builtin_amdgcn_ballot_w64((reach >> b) & 1u);
@@ -377,6 +396,8 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
       staged += (uint32_t)max(0, min(64, m - wv * 64));
     }
     __syncthreads();
+    unsigned long long w_in = 0;
+    if constexpr (STAMP) { w_in = __builtin_readcyclecounter(); if (base == 0) st_first = w_in - st_cyc; }
     const int nch = (m + 31) >> 5;
     int c = -1;
     uint32_t cur = 0u;                               // row-uniform: the unread part of the current word of the sub-list
@@ -388,6 +409,7 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
       if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;     // every row of the wave is through its sub-list (or finished)
       const int e = has ? (c << 5) + __builtin_ctz(cur) : 0;
       cur &= cur - 1u;
+      if constexpr (STAMP) st_steps += 1;
       const float4 r0 = s_rec[e * 4 + 0];        // u v ca cb
       const float4 r1 = s_rec[e * 4 + 1];        // cc o r g
       const float4 r2 = s_rec[e * 4 + 2];        // b - - id
@@ -419,11 +441,14 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
           const float den = r3.x * rx + r3.y * ry + r3.z;
           if (fabsf(den) / rnorm > p.normal_thr) {
             const float zhit = r3.w / den;
-            if (zhit > 0.f && fabsf(zhit - s_z[e]) < p.depth_thr) { D = zhit; d_w = al; d_id = gid; d_pos = (uint32_t)(base + e); }
+            if (zhit > 0.f && fabsf(zhit - s_z[e]) < p.depth_thr) {
+              D = zhit; d_w = al; d_id = gid; d_pos = (uint32_t)(base + e); d_iden = 1.f / den;
+            }
           }
         }
       }
     }
+    if constexpr (STAMP) st_walk += __builtin_readcyclecounter() - w_in;
   }
 
   bool write_out = true;
@@ -455,6 +480,7 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     out_T[pix] = T;
     n_contrib[pix] = last_contributor;
     depth_pos[pix] = d_pos;
+    if (tc.depth_aux != nullptr) tc.depth_aux[pix] = make_float2(d_iden, D);
   }
   {
     // For the backward: which walk the tile takes (raster_bwd.hip) - row-granular when its 4x4 blocks need, on average,
@@ -474,7 +500,9 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
       // bits 0..1 = the walk; bits 8.. = the measured share in 1/1000 (diagnostics)
       const float share = s_share[1] ? (float)s_share[0] / (16.f * (float)s_share[1]) : 1.f;
       // walk < 0: the choice between the two pixel-per-lane walks from the share; else the walk the context asks for
-      tile_mode[tile] = (walk >= 0 ? (uint32_t)walk : (share < ROWS_MAX_SHARE ? 1u : 0u)) | ((uint32_t)(share * 1000.f) << 8);
+      // bit 2: this forward left the tile's records / masks / plane words in the TileCache
+      tile_mode[tile] = (walk >= 0 ? (uint32_t)walk : (share < ROWS_MAX_SHARE ? 1u : 0u)) | (tc.recs != nullptr ? 4u : 0u) |
+                        ((uint32_t)(share * 1000.f) << 8);
       tile_last[tile] = s_tl;
     }
   }
@@ -496,222 +524,19 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
       counters[2 * tile + 1] = (add ? counters[2 * tile + 1] : 0ull) + s_ev;
     }
   }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// K6 blend_fwd, TWO PIXELS PER LANE (round 5) - built, bit-identical, measured, NOT the default.
-// Same walk, same per-pixel arithmetic in the same order - outputs are bit-identical to blend_fwd_kernel
-// (tests/test_raster_gpu.py::test_two_pixel_forward_is_bit_identical) - but a tile is 128 threads: eight lanes own a 4x4 block
-// (lane j: pixels (j & 3, j >> 2) and (j & 3, (j >> 2) + 2) of it), so everything a step does that is NOT per pixel - the
-// sub-list mask walk, the three LDS record reads, dx and the column terms of the power (the compiler packs them: v_pk_mul /
-// v_pk_fma), the loop's ballots - is paid once for two (entry, pixel) pairs.  Batches are 128 entries: 9 KB of LDS per tile.
-// MEASURED (profiles/r05_experiments_not_kept.txt): headline 79.9 -> 78.6 us, surface 127.4 -> 165.5 us (5 waves / SIMD; 83.4 /
-// 173.9 at 4).  Fewer instructions per pair do not buy time here - and neither do more waves: the one-pixel kernel at 5 / 6 /
-// 7 / 8 waves per SIMD runs 85.9 / 80.3 / 79.6 / 79.0 us (headline) and 130.1 / 128.0 / 125.4 / 123.4 us (surface).  The walk
-// is bound by the dependent chain of a STEP (LDS record read -> power -> exp -> T update -> ballot -> next mask bit), of which
-// a tile's four waves each run one at a time; halving the waves per tile lengthens the tile's critical path by what the
-// second pixel adds to a step.  Kept behind RTGS_FWD_KERNEL=2 / rtgs_raster_set_fwd_kernel(2) with its test.
-constexpr int F2_THREADS = 128;
-constexpr int F2_BATCH = F2_THREADS;
-constexpr int F2_CHUNKS = F2_BATCH / 32;
-
-template <int OCC>
-__global__ void __launch_bounds__(128, OCC) blend_fwd2_kernel(
-    RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
-    int32_t* __restrict__ out_cidx, int32_t* __restrict__ out_didx, float* __restrict__ out_cw,
-    float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
-    unsigned long long* __restrict__ counters, SlicePass sp, uint32_t* __restrict__ tile_mode,
-    uint32_t* __restrict__ depth_pos, uint32_t* __restrict__ tile_last, int walk, uint32_t* __restrict__ aux_zero) {
-  __shared__ float4 s_rec[F2_BATCH * 4];      // u v ca cb | cc o r g | b - - id | nx ny nz pd
-  __shared__ float s_z[F2_BATCH];
-  __shared__ uint32_t s_live[16][F2_CHUNKS];  // per 4x4 block: the staged entries that reach it
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
-  const int tile = blockIdx.y * p.gx + blockIdx.x;
-  if (spec_failed(p.spec_fail)) return;
-  if (aux_zero && blockIdx.x == 0 && blockIdx.y == 0 && tid < 8) aux_zero[tid] = 0u;
-  if (sp.mode == 2 && sp.mask2[tile] == 0) return;
-  // eight lanes = a 4x4 block (block numbering of blocks_reached: bit i + 4 j = block column i, row j)
-  const int blk = tid >> 3;
-  const int bx = blk & 3, by = blk >> 2;
-  const int px = blockIdx.x * TILE + bx * 4 + (tid & 3);
-  const int py0 = blockIdx.y * TILE + by * 4 + ((tid >> 2) & 1);
-  const int gsh = lane & 56;                           // first lane of this lane's group of eight
-  const bool inside[2] = {px < p.W && py0 < p.H, px < p.W && py0 + 2 < p.H};
-  const float pxf = (float)px;
-  const float pyf[2] = {(float)py0, (float)(py0 + 2)};
-  const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
-  const uint2 range = ranges[tile];
-  int n = (int)(range.y - range.x);
-  if (sp.mode == 1 && n > SLICE_MAX_LIST) n = 0;
-
-  bool done[2] = {!inside[0], !inside[1]};
-  float T[2] = {1.f, 1.f}, C0[2] = {0.f, 0.f}, C1[2] = {0.f, 0.f}, C2[2] = {0.f, 0.f};
-  float best_w[2] = {0.f, 0.f}; int best_id[2] = {-1, -1};
-  float D[2] = {0.f, 0.f}, d_w[2] = {0.f, 0.f}; int d_id[2] = {-1, -1};
-  uint32_t d_pos[2] = {0u, 0u};
-  uint32_t last_contributor[2] = {0u, 0u};
-  uint32_t evals = 0;
-  uint32_t reach_sum = 0, staged = 0;
-
-  int bs = sp.mode == 1 ? F2_BATCH / 2 : F2_BATCH;     // near slice: a short first batch (its walks stop early)
-  for (int base = 0; base < n; base += bs, bs = F2_BATCH) {
-    if (__syncthreads_and(done[0] && done[1])) break;
-    const int m = min(bs, n - base);
-    {
-      uint32_t reach = 0;
-      if (tid < m) {
-        const uint32_t id = point_list[range.x + base + tid];
-        const float4* src = reinterpret_cast<const float4*>(splats + id);
-        const float4 q0 = src[0];
-        s_rec[tid * 4 + 0] = q0;
-        const float4 q1 = src[1];
-        s_rec[tid * 4 + 1] = q1;
-        const float4 q2 = src[2];
-        const float4 q3 = src[3];
-        s_rec[tid * 4 + 2] = make_float4(q2.x, 0.f, 0.f, __uint_as_float(id));
-        s_rec[tid * 4 + 3] = make_float4(q2.y, q2.z, q2.w, q3.x);
-        s_z[tid] = q3.y;
-        reach = blocks_reached(q0.x, q0.y, q3.z, q3.w, q0.z, q0.w, q1.x, q1.y, tx0, ty0);
-      }
-#pragma unroll
-      for (int b = 0; b < 16; ++b) {
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64((reach >> b) & 1u);
-        if (lane == 0) { s_live[b][2 * wv] = (uint32_t)bal; s_live[b][2 * wv + 1] = (uint32_t)(bal >> 32); }
-        reach_sum += (uint32_t)__popcll(bal);
-      }
-      staged += (uint32_t)max(0, min(64, m - wv * 64));
-    }
-    __syncthreads();
-    const int nch = (m + 31) >> 5;
-    int c = -1;
-    uint32_t cur = 0u;                               // group-uniform: the unread part of the current word of the sub-list
-    for (;;) {
-      while (cur == 0u && c + 1 < nch) { ++c; cur = s_live[blk][c]; }
-      const unsigned long long am = __builtin_amdgcn_ballot_w64(!(done[0] && done[1]));
-      const bool group_alive = (uint32_t)((am >> gsh) & 0xffull) != 0u;
-      const bool has = cur != 0u && group_alive;
-      if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;
-      const int e = has ? (c << 5) + __builtin_ctz(cur) : 0;
-      cur &= cur - 1u;
-      const float4 r0 = s_rec[e * 4 + 0];        // u v ca cb
-      const float4 r1 = s_rec[e * 4 + 1];        // cc o r g
-      const float4 r2 = s_rec[e * 4 + 2];        // b - - id
-      const float dx = r0.x - pxf;
-      bool contrib[2];
-      float w[2], al[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float dy = r0.y - pyf[q];
-        const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
-        al[q] = fminf(0.99f, r1.y * splat_exp(fminf(power, 0.f)));
-        const bool ok = has && !done[q] && !(power > 0.f) && !(al[q] < 1.f / 255.f);
-        const float test_T = T[q] * (1.f - al[q]);
-        const bool stop = ok && (test_T < p.T_thr);
-        contrib[q] = ok && !stop;
-        evals += (has && !done[q]) ? 1u : 0u;
-        done[q] = done[q] || stop;
-        w[q] = contrib[q] ? al[q] * T[q] : 0.f;
-        T[q] = contrib[q] ? test_T : T[q];
-        last_contributor[q] = contrib[q] ? (uint32_t)(base + e + 1) : last_contributor[q];
-      }
-      if (__builtin_amdgcn_ballot_w64(contrib[0] || contrib[1]) == 0ull) continue;
-      const int gid = (int)__float_as_uint(r2.w);
-      bool want_depth[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        C0[q] += r1.z * w[q]; C1[q] += r1.w * w[q]; C2[q] += r2.x * w[q];
-        const bool better = w[q] > best_w[q];
-        best_w[q] = better ? w[q] : best_w[q];
-        best_id[q] = better ? gid : best_id[q];
-        want_depth[q] = contrib[q] && d_id[q] < 0 && al[q] > p.opaque_thr;
-      }
-      if (__builtin_amdgcn_ballot_w64(want_depth[0] || want_depth[1]) != 0ull) {   // rare: opaque-surface depth candidates
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          if (want_depth[q]) {
-            const float rx = (pxf - p.cx) / p.fx, ry = (pyf[q] - p.cy) / p.fy;
-            const float rnorm = sqrtf(rx * rx + ry * ry + 1.f);
-            const float4 r3 = s_rec[e * 4 + 3];    // nx ny nz pd
-            const float den = r3.x * rx + r3.y * ry + r3.z;
-            if (fabsf(den) / rnorm > p.normal_thr) {
-              const float zhit = r3.w / den;
-              if (zhit > 0.f && fabsf(zhit - s_z[e]) < p.depth_thr) { D[q] = zhit; d_w[q] = al[q]; d_id[q] = gid; d_pos[q] = (uint32_t)(base + e); }
-            }
-          }
-        }
-      }
-    }
-  }
-
-  bool write_out = true;
-  if (sp.mode == 1) {
-    const bool finished = __syncthreads_and(done[0] && done[1]) != 0;
-    const bool on = sp.user_mask[tile] != 0;
-    if (tid == 0) {
-      sp.mask2[tile] = (on && !finished) ? 1 : 0;
-      sp.ranges_bwd[tile] = finished ? range : make_uint2(0u, 0u);
-      sp.ranges_main[tile] = make_uint2(0u, 0u);
-    }
-    write_out = finished || !on;
-  }
-
-  const size_t HW = (size_t)p.H * p.W;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    if (inside[q] && write_out) {
-      const size_t pix = (size_t)(py0 + 2 * q) * p.W + px;
-      out_color[pix] = C0[q] + T[q] * p.bg[0];
-      out_color[HW + pix] = C1[q] + T[q] * p.bg[1];
-      out_color[2 * HW + pix] = C2[q] + T[q] * p.bg[2];
-      out_depth[pix] = D[q];
-      out_cidx[pix] = best_id[q];
-      out_didx[pix] = d_id[q];
-      out_cw[pix] = best_w[q];
-      out_dw[pix] = d_w[q];
-      out_T[pix] = T[q];
-      n_contrib[pix] = last_contributor[q];
-      depth_pos[pix] = d_pos[q];
-    }
-  }
-  {
-    __shared__ uint32_t s_share[2];
-    __shared__ unsigned int s_tl;
-    if (tid == 0) { s_share[0] = 0u; s_share[1] = 0u; s_tl = 0u; }
-    __syncthreads();
-    uint32_t wl = max(last_contributor[0], last_contributor[1]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, off));
-    if (lane == 0) { atomicAdd(&s_share[0], reach_sum); atomicAdd(&s_share[1], staged); atomicMax(&s_tl, wl); }
-    __syncthreads();
-    if (tid == 0 && write_out) {
-      const float share = s_share[1] ? (float)s_share[0] / (16.f * (float)s_share[1]) : 1.f;
-      tile_mode[tile] = (walk >= 0 ? (uint32_t)walk : (share < ROWS_MAX_SHARE ? 1u : 0u)) | ((uint32_t)(share * 1000.f) << 8);
-      tile_last[tile] = s_tl;
-    }
-  }
-  if (counters) {
-    __shared__ unsigned int s_max;
-    __shared__ unsigned long long s_ev;
-    if (tid == 0) { s_max = 0; s_ev = 0; }
-    __syncthreads();
-    atomicMax(&s_max, max(last_contributor[0], last_contributor[1]));
-    atomicAdd(&s_ev, (unsigned long long)evals);
-    __syncthreads();
-    if (tid == 0) {
-      const bool add = sp.mode == 2;
-      counters[2 * tile] = (add ? counters[2 * tile] : 0ull) + (unsigned long long)s_max;
-      counters[2 * tile + 1] = (add ? counters[2 * tile + 1] : 0ull) + s_ev;
+  if constexpr (STAMP) {
+    if (lane == 0 && stamps != nullptr) {
+      unsigned long long* o = stamps + (size_t)(tile * 4 + wv) * 8;
+      o[0] = st_wall; o[1] = wall_clock64(); o[2] = st_range; o[3] = st_first; o[4] = st_walk;
+      o[5] = __builtin_readcyclecounter() - st_cyc; o[6] = st_steps; o[7] = st_batches;
     }
   }
 }
 
-static int g_fwd_kernel = [] { const char* e = getenv("RTGS_FWD_KERNEL"); return (e && atoi(e) == 2) ? 2 : 1; }();
+
 static int g_f1_occ = [] { const char* e = getenv("RTGS_F1_OCC"); const int v = e ? atoi(e) : 6; return (v == 5 || v == 7 || v == 8) ? v : 6; }();
-static int g_f2_occ = [] { const char* e = getenv("RTGS_F2_OCC"); return (e && atoi(e) == 4) ? 4 : 5; }();   // waves / SIMD the two-pixel kernel is compiled for
+static unsigned long long* g_fwd_stamps = nullptr;   // measurement only (rtgs_raster_set_fwd_stamps)
+void set_fwd_stamps(void* dev) { g_fwd_stamps = (unsigned long long*)dev; }
 
 // ------------------------------------------------------------------ host-side launch helpers
 void launch_mask_sat(const int32_t* mask, int gx, int gy, int32_t* sat, hipStream_t st) {
@@ -795,23 +620,14 @@ void launch_slice_publish(int ntiles, const int32_t* user_mask, const int32_t* m
 void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                       float* out_color, float* out_depth, int32_t* out_cidx, int32_t* out_didx, float* out_cw,
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
-                      SlicePass sp, uint32_t* tile_mode, uint32_t* depth_pos, uint32_t* tile_last, int walk, uint32_t* aux_zero, hipStream_t st) {
-  // two pixels per lane (default) or the one-pixel kernel (g_fwd_kernel 1: A-B runs and the bit-identity test)
-#define RTGS_FWD1(OCC) hipLaunchKernelGGL(blend_fwd_kernel<OCC>, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, \
+                      SlicePass sp, uint32_t* tile_mode, uint32_t* depth_pos, uint32_t* tile_last, int walk, uint32_t* aux_zero,
+                      TileCache tc, hipStream_t st) {
+#define RTGS_FWD1(OCC, STAMP) hipLaunchKernelGGL((blend_fwd_kernel<OCC, STAMP>), dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, \
                        out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp, tile_mode, \
-                       depth_pos, tile_last, walk, aux_zero)
-  if (g_fwd_kernel == 1) {
-    if (g_f1_occ == 8) RTGS_FWD1(8); else if (g_f1_occ == 7) RTGS_FWD1(7); else if (g_f1_occ == 5) RTGS_FWD1(5); else RTGS_FWD1(6);
-  }
-  else if (g_f2_occ == 4)
-    hipLaunchKernelGGL(blend_fwd2_kernel<4>, dim3(p.gx, p.gy), dim3(F2_THREADS), 0, st, p, ranges, point_list, splats,
-                       out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp, tile_mode,
-                       depth_pos, tile_last, walk, aux_zero);
-  else
-    hipLaunchKernelGGL(blend_fwd2_kernel<5>, dim3(p.gx, p.gy), dim3(F2_THREADS), 0, st, p, ranges, point_list, splats,
-                       out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp, tile_mode,
-                       depth_pos, tile_last, walk, aux_zero);
+                       depth_pos, tile_last, walk, aux_zero, tc, g_fwd_stamps)
+  if (g_fwd_stamps) RTGS_FWD1(6, true);
+  else if (g_f1_occ == 8) RTGS_FWD1(8, false); else if (g_f1_occ == 7) RTGS_FWD1(7, false); else if (g_f1_occ == 5) RTGS_FWD1(5, false); else RTGS_FWD1(6, false);
+#undef RTGS_FWD1
 }
-void set_fwd_kernel(int which) { g_fwd_kernel = which == 1 ? 1 : 2; }
 
 }  // namespace rtgs

@@ -763,50 +763,14 @@ def test_one_call_step_with_the_normal_term_matches_the_autograd_step():
 
 
 @pytest.mark.parametrize("kind,N,cam_i,mode,masked", [("volume", 3000, 0, 0, False), ("volume", 20000, 1, 1, True), ("surface", 60000, 2, 2, False),
-                                                     ("volume", 150000, 3, 2, True), ("surface", 150000, 3, 0, False)])
-def test_two_pixel_forward_is_bit_identical(kind, N, cam_i, mode, masked):
-    """blend_fwd2_kernel (two pixels per lane, 128 threads per tile - VERDICT r4 item 4; measured, not the default: DESIGN.md
-    6) against blend_fwd_kernel (one pixel per lane): EVERY output of the forward bit for bit - colour, depth, both index maps, both weights, T - and what
-    it leaves for the backward (n_contrib, depth_pos, tile_last through the gradients), on small and large maps, odd image
-    sizes (partial tiles), with the near slice off / forced / automatic and with a tile mask."""
-    from rtg_slam_amd import _lib
-    lib = _lib.load()
-    cam = [synth.CameraSpec(70, 90, 80.0, 80.0, 44.5, 34.5), synth.CameraSpec(128, 192, 160.0, 160.0, 95.5, 63.5),
-           synth.CameraSpec(240, 320, 200.0, 200.0, 159.5, 119.5), synth.CameraSpec(339, 601, 300.0, 300.0, 300.0, 169.0)][cam_i]
-    g, s = ru.make_scene(N, cam, seed=31, pose_seed=2, r_range=(0.01, 0.08))
-    if kind == "surface":
-        g = synth.surface_gaussians(N, cam, seed=9)
-    mask = None
-    if masked:
-        gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
-        mask = (torch.rand(gy, gx, generator=torch.Generator().manual_seed(6)) < 0.6).int()
-    gen = torch.Generator().manual_seed(7)
-    grads = (torch.randn(3, cam.H, cam.W, generator=gen), torch.randn(1, cam.H, cam.W, generator=gen))
-    try:
-        lib.rtgs_raster_set_near_slice(mode, 0)
-        lib.rtgs_raster_set_fwd_kernel(1)
-        out_a, gd_a = ru.hip_run(s, g, tile_mask=mask, grads=grads)
-        lib.rtgs_raster_set_fwd_kernel(2)
-        out_b, gd_b = ru.hip_run(s, g, tile_mask=mask, grads=grads)
-    finally:
-        lib.rtgs_raster_set_near_slice(2, 384)
-        lib.rtgs_raster_set_fwd_kernel(1)
-    assert float((out_a[6] != 1).float().mean()) > 0.2                      # something was rendered
-    for k, (a, b) in enumerate(zip(out_a, out_b)):
-        assert torch.equal(a, b), (k, float((a != b).float().mean()))
-    for k in ru.FIELDS:                                                      # same forward, same backward inputs
-        scale = float(gd_a[k].abs().max()) + 1e-12
-        assert ru.frac_bad(gd_b[k], gd_a[k], 1e-4 * scale) < 1e-3, k
-        assert torch.equal(gd_a[k].reshape(N, -1).ne(0).any(1), gd_b[k].reshape(N, -1).ne(0).any(1)), k
-
-
-@pytest.mark.parametrize("kind,N,cam_i,masked", [("volume", 3000, 0, False), ("volume", 20000, 1, True), ("surface", 60000, 2, False),
-                                                 ("volume", 150000, 3, True), ("surface", 150000, 3, False)])
-def test_lane_sums_equal_the_matrix_core_sums(kind, N, cam_i, masked):
-    """The entry-per-lane backward keeps the pixel sums in lane accumulators (round 5, blend_bwd_entry_kernel); round 4 formed
-    them with two v_mfma_f32_16x16x4_f32 per step (blend_bwd_entry_mfma_kernel, rtgs_raster_set_mfma_walk(8)).  Same alpha,
-    same scans, same carries - the gradients differ by the order of the sums over a quad's four pixels and of the LDS adds:
-    as much as two runs of either form differ from each other, within a factor."""
+                                                      ("volume", 150000, 3, 1, True), ("surface", 150000, 3, 0, False), ("surface", 400000, 1, 0, False)])
+def test_tile_cache_backward_equals_the_gather_backward(kind, N, cam_i, mode, masked):
+    """Round 6: blend_fwd leaves the records, block masks and plane words of every tile's first 256 list positions where the
+    backward finds them from the tile index alone (TileCache, raster_common.h); the entry-per-lane backward then needs ONE memory
+    round trip before its walk.  rtgs_raster_set_bwd_debug(8) makes the same kernel ignore the cache and take the gather path
+    (tile range -> list ids -> Splat records -> quadrant test; what positions >= 256 and cache-less forwards take).  Same
+    entries, same arithmetic: the gradients differ by the order of the LDS float adds only.  The last case has lists longer
+    than 256 entries (60 Gaussians per pixel column on 192 x 128): both paths inside one tile."""
     from rtg_slam_amd import _lib
     lib = _lib.load()
     cam = [synth.CameraSpec(70, 90, 80.0, 80.0, 44.5, 34.5), synth.CameraSpec(128, 192, 160.0, 160.0, 95.5, 63.5),
@@ -821,13 +785,17 @@ def test_lane_sums_equal_the_matrix_core_sums(kind, N, cam_i, masked):
     gen = torch.Generator().manual_seed(9)
     grads = (torch.randn(3, cam.H, cam.W, generator=gen), torch.randn(1, cam.H, cam.W, generator=gen))
     try:
-        lib.rtgs_raster_set_mfma_walk(8)
+        lib.rtgs_raster_set_near_slice(mode, 0)
+        lib.rtgs_raster_set_bwd_debug(8)
         out_a, gd_a = ru.hip_run(s, g, tile_mask=mask, grads=grads)
-        lib.rtgs_raster_set_mfma_walk(0)
+        lib.rtgs_raster_set_bwd_debug(0)
         out_b, gd_b = ru.hip_run(s, g, tile_mask=mask, grads=grads)
     finally:
-        lib.rtgs_raster_set_mfma_walk(0)
+        lib.rtgs_raster_set_bwd_debug(0)
+        lib.rtgs_raster_set_near_slice(2, 384)
     assert float((out_a[6] != 1).float().mean()) > 0.2
+    for k, (a, b) in enumerate(zip(out_a, out_b)):
+        assert torch.equal(a, b), k
     for k in ru.FIELDS:
         scale = float(gd_a[k].abs().max()) + 1e-12
         assert ru.frac_bad(gd_b[k], gd_a[k], 2e-5 * scale) < 1e-4, (k, float((gd_b[k] - gd_a[k]).abs().max()) / scale)

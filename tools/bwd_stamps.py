@@ -1,6 +1,6 @@
-"""Where a launch of blend_bwd_mfma spends its time: per-wave stamps (rtgs_raster_set_mfma_stamps, include/rtgs_debug.h) of ONE
+"""Where a launch of blend_bwd_entry spends its time: per-wave stamps (rtgs_raster_set_bwd_stamps, include/rtgs_debug.h) of ONE
 map-optimisation iteration on the 1.2 M / 1200x680 scenes.
-    python tools/mfma_stamps.py [headline|surface]
+    python tools/bwd_stamps.py [headline|surface]
 Prints: the launch's span, the distribution of tile (workgroup) lifetimes against it, how many waves are resident over time,
 the share of a wave's cycles inside the group loop, cycles per quad step, and the critical tiles."""
 import math
@@ -37,11 +37,11 @@ tiles = gx * gy
 runs = []
 for rep in range(3):
     st = torch.zeros(tiles * 4 * 14, dtype=torch.int64, device=dev)
-    lib.rtgs_raster_set_mfma_stamps(st.data_ptr())
+    lib.rtgs_raster_set_bwd_stamps(st.data_ptr())
     for _ in range(3):                                   # the stamped kernel's third launch: clocks and caches as in a run
         opt.step_slam(rs, gt_color, gt_depth, None, render_mask=rm)
     torch.cuda.synchronize()
-    lib.rtgs_raster_set_mfma_stamps(None)
+    lib.rtgs_raster_set_bwd_stamps(None)
     runs.append(st.cpu().numpy().reshape(tiles, 4, 14).astype(np.int64))
 s = runs[-1]
 live = s[:, :, 0] > 0
@@ -71,14 +71,14 @@ print(f"per wave: groups mean {groups.mean():.1f} (max {groups.max():.0f}), quad
 print(f"whole launch: {int(steps.sum())} quad steps = {steps.sum() / 1024:.0f} per SIMD;  at the loop's cycles per step, one SIMD running its share "
       f"back to back needs {steps.sum() / 1024 * cyc_walk.sum() / max(1.0, steps.sum()) / mhz:.1f} us")
 seg = s[:, :, 6:12][live].astype(np.float64).sum(0)
-names = ["prologue (per-pixel loads, first gather issued)", "accumulator zeroing + depth partials", "staging (gather -> LDS, block test)",
-         "compaction (2 barriers)", "group loop", "barrier behind the loop", "per-entry tail (moments, slot store)"]
+names = ["prologue (every first load landed)", "accumulator zeroing + depth partials", "staging (records -> LDS)",
+         "compaction + barrier before the walk", "group loop", "barrier behind the loop", "per-entry tail (moments, slot store)"]
 vals = [seg[0], seg[1], seg[2], seg[3], cyc_walk.sum(), seg[4], seg[5]]
 print("share of the waves' cycles: " + "; ".join(f"{n} {v / cyc_total.sum():.3f}" for n, v in zip(names, vals)) +
       f"; unaccounted {1.0 - sum(vals) / cyc_total.sum():.3f}")
 p1 = s[:, :, 12][live].astype(np.float64).sum(); p2 = s[:, :, 13][live].astype(np.float64).sum()
-print(f"inside the prologue: per-tile words arrive {p1 / cyc_total.sum():.3f}; per-pixel loads + zeroing + first barrier {(p2 - p1) / cyc_total.sum():.3f}; "
-      f"depth partials of the first batch {(seg[0] - p2) / cyc_total.sum():.3f}  (mean prologue {seg[0] / live.sum() / mhz:.2f} us)")
+print(f"inside the prologue: per-tile words arrive {p1 / cyc_total.sum():.3f}; the rest of the first loads {(p2 - p1) / cyc_total.sum():.3f} "
+      f"(mean prologue {seg[0] / live.sum() / mhz:.2f} us)")
 # waves of a tile: how unequal (the tile waits for its slowest quadrant at every batch barrier)
 wsteps = np.where(live, s[:, :, 5], 0).astype(np.float64)
 imb = wsteps.max(1)[act].sum() * 4 / max(1.0, wsteps[act].sum())
