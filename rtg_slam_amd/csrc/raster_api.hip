@@ -22,6 +22,7 @@ void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
 void set_fwd_stamps(void* dev);
 void set_bwd_debug(int bits);
 void set_bwd_stamps(void* dev);
+void set_bwd_form(int form);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
                       int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*,
                       TileCache, hipStream_t);
@@ -30,7 +31,7 @@ void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const 
                       const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, uint32_t, uint32_t, hipStream_t);
 void launch_blend_bwd_entry(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const uint32_t*,
                             const int32_t*, const uint32_t*, const uint32_t*, const float*, const float*, const uint32_t*, uint32_t*,
-                            const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, uint32_t, TileCache, const uint32_t*, hipStream_t);
+                            const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, uint32_t, TileCache, void*, hipStream_t);
 void launch_grad_reduce(int, const uint8_t*, const uint32_t*, uint32_t*, const BwdInfo*, SplatGrad*, const uint32_t*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
@@ -301,7 +302,7 @@ static ImgLayout img_layout(int H, int W, int ntiles) {
   L.tile_recs = off; off = align_up(off + (size_t)ntiles * TILE_RECS * 3 * sizeof(float4));
   L.tile_masks = off; off = align_up(off + (size_t)ntiles * TILE_RECS * sizeof(uint16_t));
   L.depth_aux = off; off = align_up(off + (size_t)H * W * sizeof(float2));
-  L.tile_order = off; off = align_up(off + (size_t)ntiles * sizeof(uint32_t));
+  L.tile_order = off; off = align_up(off + ((size_t)ntiles + 4) * sizeof(uint32_t));      // BwdQueue: 4 words + the order
   L.total = off;
   return L;
 }
@@ -913,7 +914,7 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
                                out_didx, depth_pos, (const uint32_t*)(img + I.tile_last), dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads,
                                touched, tile_mode, t0, tn,
                                TileCache{(float4*)(img + I.tile_recs), (uint16_t*)(img + I.tile_masks), (float2*)(img + I.depth_aux)},
-                               nullptr, st);
+                               (void*)(img + I.tile_order), st);
     }
     prof_mark(c, EV_BWALK, st);
     // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
@@ -1039,6 +1040,7 @@ int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
 uint32_t rtgs_raster_last_listed_ctx(rtgs_ctx* c) { return use(c)->last_listed; }
 void rtgs_raster_set_bwd_debug(int bits) { rtgs::set_bwd_debug(bits); }
 void rtgs_raster_set_bwd_stamps(void* dev) { rtgs::set_bwd_stamps(dev); }
+void rtgs_raster_set_bwd_form(int form) { rtgs::set_bwd_form(form); }
 void rtgs_raster_set_fwd_stamps(void* dev) { rtgs::set_fwd_stamps(dev); }
 void rtgs_raster_set_onepass_ctx(rtgs_ctx* c, int on) { use(c)->onepass = on != 0; use(c)->plan.valid = false; }
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode >= 1 && mode <= 4) ? mode : 0; }

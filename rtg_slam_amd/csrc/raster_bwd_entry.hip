@@ -125,7 +125,9 @@ struct EntryWalk {
     if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
     const float a = valid ? alpha : 0.f;
     const float Gv = valid ? G : 0.f;
-    constexpr unsigned long long MINE = 0x0001000100010001ull << S;
+    // lane n == S of every row owns quad S's carries.  The lane mask is a compare INSIDE the statement that uses it (one
+    // VALU per step, vcc): as sixteen 64-bit "s" operands the masks are loop invariants the compiler holds in 32 SGPRs for
+    // the whole kernel - which a persistent kernel with twenty pointers does not have (they went to VGPR lanes and scratch).
     float incl, sinc, gda, w, cg, ia, t0, gx, gy;
     asm volatile(
         "v_sub_f32 %[incl], 1.0, %[a]\n\t"
@@ -163,6 +165,7 @@ struct EntryWalk {
           [Tc] "v"(Tc), [Qc] "v"(Qc), [S] "n"(S));
     float tn, qn;
     asm volatile(
+        "v_cmp_eq_u32 vcc, %[S], %[n]\n\t"
         // moments of pixel k about the tile centre (three plain instructions ahead of the DPP reads of incl / sinc)
         "v_add_f32 %[s0], %[s0], %[gda]\n\t"
         "v_mul_f32 %[gx], %[gda], %[x]\n\t"
@@ -172,14 +175,15 @@ struct EntryWalk {
         "v_subrev_f32_dpp %[qn], %[sinc], %[Qc] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32 %[sx], %[sx], %[gx]\n\t"
         "v_add_f32 %[sy], %[sy], %[gy]\n\t"
-        "v_cndmask_b32 %[Tc], %[Tc], %[tn], %[mine]\n\t"
-        "v_cndmask_b32 %[Qc], %[Qc], %[qn], %[mine]\n\t"
+        "v_cndmask_b32 %[Tc], %[Tc], %[tn], vcc\n\t"
+        "v_cndmask_b32 %[Qc], %[Qc], %[qn], vcc\n\t"
         "v_fmac_f32 %[sxx], %[gx], %[x]\n\t"
         "v_fmac_f32 %[sxy], %[gx], %[y]\n\t"
         "v_fmac_f32 %[syy], %[gy], %[y]\n\t"
         : [tn] "=&v"(tn), [qn] "=&v"(qn), [gx] "=&v"(gx), [gy] "=&v"(gy), [Tc] "+v"(Tc), [Qc] "+v"(Qc), [s0] "+v"(s0), [sx] "+v"(sx),
           [sy] "+v"(sy), [sxx] "+v"(sxx), [sxy] "+v"(sxy), [syy] "+v"(syy)
-        : [incl] "v"(incl), [sinc] "v"(sinc), [gda] "v"(gda), [x] "v"(xq[S & 3]), [y] "v"(yq[S >> 2]), [mine] "s"(MINE));
+        : [incl] "v"(incl), [sinc] "v"(sinc), [gda] "v"(gda), [x] "v"(xq[S & 3]), [y] "v"(yq[S >> 2]), [n] "v"(n), [S] "n"(S)
+        : "vcc");
   }
   __device__ __forceinline__ void run16_lane(uint32_t sm) {
     step_lane<0>(sm); step_lane<1>(sm); step_lane<2>(sm); step_lane<3>(sm); step_lane<4>(sm); step_lane<5>(sm); step_lane<6>(sm);
@@ -188,6 +192,19 @@ struct EntryWalk {
   }
 };
 
+// max over the wave's 64 lanes, in every lane - row swaps and row rotations only: no ds_bpermute, hence none of its six
+// per-lane address registers (which, loop-invariant, are hoisted out of the tile loop and then spilled)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  x = max(r[0], r[1]);
+  const auto q = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  x = max(q[0], q[1]);
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false));    // row_ror:8
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false));    // row_ror:4
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false));    // row_ror:2
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false));    // row_ror:1
+  return x;
+}
 // x[n] + x[n + 16] + x[n + 32] + x[n + 48] in every lane (gfx950's row swaps: upper half <-> lower half, odd rows <-> even rows)
 __device__ __forceinline__ float sum_rows(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -281,13 +298,42 @@ __device__ __forceinline__ int compact_quadrant(uint2 mk, uint32_t qm, int m, in
   return (int)total;
 }
 
-// STAMP (measurement only, rtgs_raster_set_bwd_stamps): every wave leaves fourteen 64-bit words - wall clock (100 MHz) at entry
-// and exit, shader cycles spent in the group loop and in the whole kernel, groups walked, quad steps entered, the cycles of
-// the other phases (prologue: until every first load has landed | accumulator zeroing + depth partials | staging: records ->
-// LDS (gather path: the gather and the quadrant test) | compaction + the barrier before the walk | barrier behind the loop:
-// the tile's slowest quadrant | per-entry tail: moments -> slot store) and two marks inside the prologue (per-tile words
-// there | every load of the prologue there).
-template <bool STAMP>
+// ---------------------------------------------------------------------------------------------------------------------
+// The kernel is PERSISTENT and QUEUE-FED (round 6).  A launch holds one workgroup per resident slot (5 per CU); tiles come
+// from a device queue in the order bwd_order_kernel left them - longest walk first (in tile order the last third of a launch
+// was a tail of heavy tiles that started late: profiles/r05_bwd_stamps_*) and only tiles that have something to walk.  What
+// that buys, by round 6's stamps (profiles/r06_a_bwd_stamps_*): a fresh workgroup spent 17 % of its life on FIVE serialised
+// scalar waits (kernel arguments -> speculation word -> BwdInfo -> its words -> the tile's words) before its first vector
+// load left; here the launch constants are read once per workgroup, the tile's words travel as vector loads beside the
+// per-pixel values, and the next tile's loads are issued BEFORE the current tile's per-entry tail waits for its slot
+// atomics - the two round trips overlap.  Per tile: one exposed round trip, three barriers.
+// ---------------------------------------------------------------------------------------------------------------------
+struct BwdQueue {
+  uint32_t head;     // next ticket (bwd_order_kernel sets it to the launch's workgroup count: ticket b < grid is workgroup b's first tile)
+  uint32_t count;    // tiles in `order`
+  uint32_t pad0, pad1;
+  // uint32_t order[]: (tile row << 16) | tile column, longest walk first
+};
+
+// Everything the prologue of one tile loads: issued in one go, consumed after one wait.
+struct TileLoads {
+  uint32_t tmode, r0, r1, tlast;        // the tile's words (same address in every lane)
+  uint32_t last;                        // per pixel
+  float g0, g1, g2, oc0, oc1, oc2, gD;
+  int owner;
+  uint32_t dpos;
+  float2 aux;
+  float4 c0, c1, c2;                    // the record of list position tid (TileCache)
+  uint2 mk;                             // block masks of list positions 4 lane .. 4 lane + 3
+};
+
+// STAMP (measurement only, rtgs_raster_set_bwd_stamps): every wave leaves, per TILE, fourteen 64-bit words - wall clock (100 MHz)
+// at the start and end of the tile's turn, shader cycles spent in the group loop and in the whole turn, groups walked, quad
+// steps entered, the cycles of the other phases (prologue: until every first load has landed | accumulator zeroing + depth
+// partials | staging: records -> LDS (gather path: the gather and the quadrant test) | compaction + the barrier before the
+// walk | barrier behind the loop: the tile's slowest quadrant | per-entry tail: moments -> slot store, incl. the barrier
+// behind it) and two marks inside the prologue (unused | every load of the prologue there).
+template <bool STAMP, bool DEFER>
 __device__ __forceinline__ void blend_bwd_entry_body(
     const RasterParams& p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, const float* __restrict__ out_color, const uint32_t* __restrict__ n_contrib,
@@ -296,114 +342,213 @@ __device__ __forceinline__ void blend_bwd_entry_body(
     const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
     SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode,
     uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long* __restrict__ stamps, const TileCache& tc,
-    const uint32_t* __restrict__ order) {
-  unsigned long long st_wall = 0, st_cyc = 0, st_walk = 0, st_groups = 0, st_steps = 0;
-  unsigned long long st_seg[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;   // prologue | zero + depth | stage | compact | after-loop barrier | entry tail
-  if constexpr (STAMP) { st_wall = wall_clock64(); st_cyc = __builtin_readcyclecounter(); }
+    BwdQueue* __restrict__ queue) {
   __shared__ float4 s_rec[MB * 3];              // u v ca cb | cc o r g | b id blockmask -
   __shared__ float s_acc[MB * MACC];            // per-entry sums of the tile (LDS float adds: one flush per wave and group)
   __shared__ uint8_t s_sub[4][MB];              // per quadrant: the staged entries that reach it, in list order
+  __shared__ int s_next;                        // the workgroup's next tile (packed), -1: the queue is empty
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
-  // Workgroup -> tile: launch order, or (order != nullptr) the longest walks first - the last third of a launch in tile order
-  // is a tail of the heavy tiles that started late (stamps).  XCD-aware orders were measured in round 5 and change nothing
-  // here: the records neighbouring tiles share are a tenth of this kernel's traffic.
-  const int tile = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
-  const int bx = tile % p.gx, by = tile / p.gx;
-  // wave = 8x8 quadrant, step = 2x2 quad s of it, DPP row k = pixel of the quad; THIS lane's own pixel is (quad n, k)
-  const int n = lane & 15, k = lane >> 4;
-  const int qx0 = (wv & 1) * 8, qy0 = (wv >> 1) * 8;
-  const int px = bx * TILE + qx0 + 2 * (n & 3) + (k & 1), py = by * TILE + qy0 + 2 * (n >> 2) + (k >> 1);
-  const bool inside = px < p.W && py < p.H;
-  const uint32_t HW = (uint32_t)(p.H * p.W);
-  const uint32_t pix = inside ? (uint32_t)(py * p.W + px) : 0u;       // clamped: the loads below carry no branch
-
-  // This phase is latency: EVERY load of it is issued before the first one is waited for - the per-tile words, the
-  // per-pixel values, and (round 6) the tile's records and block masks from the TileCache, whose addresses need the tile
-  // index only.  The cache is allocated for every tile, so the loads are in bounds whether or not the forward filled it.
-  const uint32_t tmode = tile_mode[tile];
-  const uint2 range = ranges[tile];
-  const uint32_t tlast = tile_last[tile];               // the tile's last contributor (left by blend_fwd)
-  const bool failed = spec_failed(p.spec_fail);
-  const uint32_t use_slots_w = info->use_slots;
+  const uint32_t* const order = reinterpret_cast<const uint32_t*>(queue + 1);
+  // ---- once per workgroup: the launch's constants, the first tile
+  if (spec_failed(p.spec_fail)) return;
+  const uint32_t n_queued = queue->count;
+  if (blockIdx.x >= n_queued) return;
+  const bool use_slots = info->use_slots != 0;
   SplatGrad* const slot_grads = info->slot_grads;
-  const uint32_t last_ld = n_contrib[pix];
-  const float g0 = dL_dcolor[pix], g1 = dL_dcolor[HW + pix], g2 = dL_dcolor[2 * HW + pix];
-  const float oc0 = out_color[pix], oc1 = out_color[HW + pix], oc2 = out_color[2 * HW + pix];
-  const int owner_ld = depth_index[pix];
-  const float gD_ld = dL_ddepth[pix];
-  const uint32_t dpos_ld = depth_pos[pix];
-  const bool have_cache = tc.recs != nullptr;
-  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0;
-  uint2 mk = make_uint2(0u, 0u);
-  float2 aux = make_float2(0.f, 0.f);
-  if (have_cache) {
-    const float4* const rsrc = tc.recs + ((size_t)tile * TILE_RECS + (size_t)tid) * 3;
-    c0 = rsrc[0]; c1 = rsrc[1]; c2 = rsrc[2];
-    mk = reinterpret_cast<const uint2*>(tc.masks + (size_t)tile * TILE_RECS)[lane];      // entries 4 lane .. 4 lane + 3
-    aux = tc.depth_aux[pix];
-  }
-  // (keeps the loads above the exit: sunk below it - where their first use is - they would start one scalar round trip
-  // per test later, and this phase is nothing but round trips)
-  asm volatile("" ::"v"(last_ld), "v"(g0), "v"(g1), "v"(g2), "v"(oc0), "v"(oc1), "v"(oc2), "v"(owner_ld), "v"(gD_ld), "v"(dpos_ld),
-               "v"(c0.x), "v"(c1.x), "v"(c2.x), "v"(mk.x), "v"(aux.x), "s"(use_slots_w), "s"(slot_grads));
-  // the tile stages no further than its last contributor: no reduction of n_contrib, no barrier before the first load
-  const int nuse = min((int)(range.y - range.x), (int)tlast);
-  const bool act = !failed & ((tmode & 3u) == 2u) & (nuse > 0);      // else: another walk has this tile, or nothing to do
-  if (!act) return;
-  const bool cached = have_cache && (tmode & 4u) != 0u && !(dbg & 8u);   // this forward filled the cache for this tile (bit 3: ignore it, A-B / tests)
-  unsigned long long st_p1 = 0, st_p2 = 0;
-  if constexpr (STAMP) st_p1 = __builtin_readcyclecounter() - st_cyc;   // the per-tile words are here
-  const bool use_slots = use_slots_w != 0;
+  const uint32_t HW = (uint32_t)(p.H * p.W);
 
-  const float tx0 = (float)(bx * TILE), ty0 = (float)(by * TILE);
-  const float cxT = tx0 + 7.5f, cyT = ty0 + 7.5f;     // moments are taken about the tile centre
+  // every load of a tile's prologue; the addresses need the tile index only (the TileCache is allocated for every tile, so
+  // its loads are in bounds whether or not the forward filled it)
+  auto issue = [&](int packed, TileLoads& L) {
+    // per-lane address parts are formed HERE, per tile: hoisted out of the tile loop they live in scratch, and a reload from
+    // scratch at the top of a turn is a wait for every store of the previous tile's tail
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const int ln = tl & 15, lk = (tl >> 4) & 3, lw = tl >> 6;
+    const int lx = (lw & 1) * 8 + 2 * (ln & 3) + (lk & 1), ly = (lw >> 1) * 8 + 2 * (ln >> 2) + (lk >> 1);      // the lane's pixel inside the tile
+    const int bx = packed & 0xffff, by = packed >> 16;
+    const int tile = by * p.gx + bx;
+    const int px = bx * TILE + lx, py = by * TILE + ly;
+    const uint32_t pix = (px < p.W && py < p.H) ? (uint32_t)(py * p.W + px) : 0u;       // clamped: the loads carry no branch
+    // the tile's words as VECTOR loads (every lane the same address; `tz` is a zero the compiler cannot see): as scalar loads
+    // they must be waited for with lgkmcnt(0) - in front of the loads that follow
+    int tz = 0;
+    asm volatile("" : "+v"(tz));
+    tz += tile;
+    L.tmode = tile_mode[tz];
+    const uint2 rg = ranges[tz];
+    L.r0 = rg.x; L.r1 = rg.y;
+    L.tlast = tile_last[tz];
+    L.last = n_contrib[pix];
+    L.g0 = dL_dcolor[pix]; L.g1 = dL_dcolor[HW + pix]; L.g2 = dL_dcolor[2 * HW + pix];
+    L.oc0 = out_color[pix]; L.oc1 = out_color[HW + pix]; L.oc2 = out_color[2 * HW + pix];
+    L.owner = depth_index[pix];
+    L.gD = dL_ddepth[pix];
+    L.dpos = depth_pos[pix];
+    {
+      const float4* const rsrc = tc.recs + ((size_t)tile * TILE_RECS + (size_t)tl) * 3;
+      L.c0 = rsrc[0]; L.c1 = rsrc[1]; L.c2 = rsrc[2];
+      L.mk = reinterpret_cast<const uint2*>(tc.masks + (size_t)tile * TILE_RECS)[tl & 63];      // entries 4 lane .. 4 lane + 3
+      L.aux = tc.depth_aux[pix];
+    }
+  };
 
-  EntryWalk W;
-  W.n = n;
-  W.last = inside ? last_ld : 0u;
-  W.G0 = inside ? g0 : 0.f; W.G1 = inside ? g1 : 0.f; W.G2 = inside ? g2 : 0.f;
-  W.Tc = 1.f;
-  // (colour behind the walk) . g + T_final (bg . g) before the first entry = the pixel's output colour . g
-  W.Qc = oc0 * W.G0 + oc1 * W.G1 + oc2 * W.G2;
-  // Opaque-surface depth: D = pd / (n_c . r); only the pixel's owner receives it.  A pixel owns at
-  // most one entry of the whole list: its four partials go to that entry's accumulator in the batch that stages it.  The
-  // two words they need beyond the pixel's own ray - 1 / (n_c . r) and pd - come from the forward (TileCache::depth_aux);
-  // without a cache, from the owner's Splat record (a dependent gather).
-  const bool has_owner = inside && owner_ld >= 0 && gD_ld != 0.f && !(dbg & 2u);
-  const uint32_t dpos = has_owner ? dpos_ld : 0xffffffffu;
-  // a wave walks no further than its own last contributor
-  uint32_t wave_last = W.last;
+  // the accumulators are zero between tiles: the per-entry tail clears what it has read
+  for (int q = tid; q < MB * MACC; q += BLOCK) s_acc[q] = 0.f;
+  int cur = (int)order[blockIdx.x];
+  // The per-entry tail of a tile's LAST batch is DEFERRED: it runs at the top of the next turn, behind the issue of the next
+  // tile's loads - its slot atomics and stores and that tile's load round trip overlap, and no load queues behind the
+  // acknowledgement of a store.  (Issuing the next tile's loads from inside the tail instead keeps thirty values live round
+  // the loop's back edge; the register allocator answers with scratch.)  pend_m entries of s_acc / s_rec wait for it.
+  int pend_m = 0;
+  float pend_cx = 0.f, pend_cy = 0.f;
+
+  // one thread per staged entry: moments -> d(u, v, conic), slot store; the thread clears the sums it has read
+  auto entry_tail = [&](int m, float cxT, float cyT) {
+    int tt = tid;
+    asm volatile("" : "+v"(tt));
+    float t[13];
+    bool any = false;
+    uint32_t gid = 0u;
+    if (tt < m) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, off));
-  const uint32_t qmask = 0x0033u << (2 * (wv & 1) + 8 * (wv >> 1));    // the 4x4 blocks of this wave's quadrant (blocks_reached numbering)
-  if constexpr (STAMP) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    st_t = __builtin_readcyclecounter(); st_p2 = st_t - st_cyc; st_seg[0] = st_t - st_cyc;
-  }
-
-  for (int base = 0; base < nuse; base += MB) {
-    const int m = min(MB, nuse - base);
-    if (base > 0) __syncthreads();                     // the previous batch's tail has read its LDS
-    for (int q = tid; q < m * MACC; q += BLOCK) s_acc[q] = 0.f;
-    if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[1] += t - st_t; st_t = t; }
-    int cnt;
-    if (base == 0 && cached) {
-      // ---- the forward's records: already in registers, one LDS write; the sub-list from the block masks, by this wave alone
-      if (tid < m) { s_rec[tid * 3 + 0] = c0; s_rec[tid * 3 + 1] = c1; s_rec[tid * 3 + 2] = c2; }
-      if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[2] += t - st_t; st_t = t; }
-      cnt = compact_quadrant(mk, qmask, m, lane, s_sub[wv]);
-      __syncthreads();
+      for (int q = 0; q < 13; ++q) { t[q] = s_acc[tt * MACC + q]; any |= (t[q] != 0.f); }
+#pragma unroll
+      for (int q = 0; q < 13; ++q) s_acc[tt * MACC + q] = 0.f;
+      gid = __float_as_uint(s_rec[tt * 3 + 2].y);
+    }
+    const bool store = any && gid - t0 < tn && !(dbg & 4u);         // a frozen row (outside [t0, t0 + tn)) takes no slot
+    if (!store) return;
+    // the slot run of the Gaussian and its next free slot: two independent round trips, issued together
+    uint32_t slot = 0u;
+    if (use_slots) slot = gbase[gid] + atomicAdd(&slot_count[gid], 1u);
+    const float4 q0 = s_rec[tt * 3 + 0], q1 = s_rec[tt * 3 + 1];       // u v ca cb | cc o r g
+    // sums over the pixels of gdl = o gda times powers of d = centre - pixel, from the moments about the tile centre
+    const float ut = q0.x - cxT, vt = q0.y - cyT, o = q1.y;
+    const float m0 = t[0], mx = t[1], my = t[2], mxx = t[3], mxy = t[4], myy = t[5];
+    const float sx = o * (ut * m0 - mx), sy = o * (vt * m0 - my);
+    const float sxx = o * (ut * (ut * m0 - 2.f * mx) + mxx);
+    const float sxy = o * (ut * (vt * m0 - my) - vt * mx + mxy);
+    const float syy = o * (vt * (vt * m0 - 2.f * my) + myy);
+    const float du = -(q0.z * sx + q0.w * sy), dv = -(q1.x * sy + q0.w * sx);
+    const float dca = -0.5f * sxx, dcb = -sxy, dcc = -0.5f * syy, dop = m0;
+    touched[gid] = 1;
+    if (use_slots) {
+      // SplatGrad order: du dv dca dcb | dcc dop dr dg | db dnx dny dnz | dpd - - -
+      // (slot_grads comes out of BwdInfo, i.e. out of memory: without the address space the stores are FLAT ones, which
+      // count on lgkmcnt as well - every LDS wait and barrier behind them would wait for their acknowledgement)
+      typedef float vf4 __attribute__((ext_vector_type(4)));
+      typedef __attribute__((address_space(1))) vf4 global_vf4;
+      global_vf4* dst = (global_vf4*)(slot_grads + slot);
+      dst[0] = vf4{du, dv, dca, dcb};
+      dst[1] = vf4{dcc, dop, t[6], t[7]};
+      dst[2] = vf4{t[8], t[9], t[10], t[11]};
+      dst[3] = vf4{t[12], 0.f, 0.f, 0.f};
     } else {
-      // ---- gather path: one record per thread through the list, tested against the four quadrants here
+      float* dst = reinterpret_cast<float*>(grads + gid);
+      const float vals[13] = {du, dv, dca, dcb, dcc, dop, t[6], t[7], t[8], t[9], t[10], t[11], t[12]};
+#pragma unroll
+      for (int q = 0; q < 13; ++q)
+        if (vals[q] != 0.f) unsafeAtomicAdd(dst + q, vals[q]);
+    }
+  };
+  __syncthreads();
+
+  for (;;) {
+    unsigned long long st_wall = 0, st_cyc = 0, st_walk = 0, st_groups = 0, st_steps = 0;
+    unsigned long long st_seg[6] = {0, 0, 0, 0, 0, 0}, st_t = 0, st_p2 = 0;
+    if constexpr (STAMP) { st_wall = wall_clock64(); st_cyc = __builtin_readcyclecounter(); }
+    TileLoads L;
+    if constexpr (!DEFER) { if (cur < 0) break; issue(cur, L); }
+    else if (cur >= 0) issue(cur, L);
+    unsigned long long st_p1 = 0;
+    if constexpr (STAMP) st_p1 = __builtin_readcyclecounter() - st_cyc;      // every load of the turn is issued
+    if constexpr (DEFER) {
+      if (pend_m > 0) entry_tail(pend_m, pend_cx, pend_cy);
+      __syncthreads();                                   // the tail has read (and cleared) its LDS: this tile may write it
+    }
+    if (cur < 0) break;
+    if constexpr (STAMP) { st_t = __builtin_readcyclecounter(); st_seg[5] = st_t - st_cyc; }
+    // the workgroup's next ticket: one returning atomic per tile, needed only when this tile's walk is over
+    uint32_t ticket = 0u;
+    if (tid == 0) ticket = atomicAdd(&queue->head, 1u);
+
+    // wave = 8x8 quadrant, step = 2x2 quad s of it, DPP row k = pixel of the quad; THIS lane's own pixel is (quad n, k).
+    // (From a laundered thread index, per tile: see issue().)
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+    const int lane = tq & 63, wv = tq >> 6;
+    const int n = lane & 15, k = lane >> 4;
+    const int qx0 = (wv & 1) * 8, qy0 = (wv >> 1) * 8;
+    const int lx = qx0 + 2 * (n & 3) + (k & 1), ly = qy0 + 2 * (n >> 2) + (k >> 1);      // the lane's pixel inside the tile
+    const uint32_t qmask = 0x0033u << (2 * (wv & 1) + 8 * (wv >> 1));    // the 4x4 blocks of this wave's quadrant (blocks_reached numbering)
+    const int bx = cur & 0xffff, by = cur >> 16;
+    const int tile = by * p.gx + bx;
+    const int px = bx * TILE + lx, py = by * TILE + ly;
+    const bool inside = px < p.W && py < p.H;
+    const uint32_t pix = inside ? (uint32_t)(py * p.W + px) : 0u;
+    // ---- the first wait of the turn: every load of the prologue lands
+    const uint32_t tmode = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tmode);
+    if constexpr (STAMP) { asm volatile("" ::"s"(tmode)); st_p1 |= (__builtin_readcyclecounter() - st_cyc) << 32; }   // the FIRST load is back
+    const uint32_t range_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.r0), range_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.r1);
+    const uint32_t tlast = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tlast);
+    // the tile stages no further than its last contributor (0: another walk has this tile - the order kernel queues no such tile)
+    const int nuse = ((tmode & 3u) == 2u) ? min((int)(range_y - range_x), (int)tlast) : 0;
+    const bool cached = (tmode & 4u) != 0u && !(dbg & 8u);   // this forward filled the cache for this tile (bit 3: ignore it, A-B / tests)
+    if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); st_p2 = t - st_cyc; st_seg[0] = t - st_t; st_t = t; }
+
+    const float tx0 = (float)(bx * TILE), ty0 = (float)(by * TILE);
+    const float cxT = tx0 + 7.5f, cyT = ty0 + 7.5f;     // moments are taken about the tile centre
+
+    EntryWalk W;
+    W.n = n;
+    W.last = inside ? L.last : 0u;
+    W.G0 = inside ? L.g0 : 0.f; W.G1 = inside ? L.g1 : 0.f; W.G2 = inside ? L.g2 : 0.f;
+    W.Tc = 1.f;
+    // (colour behind the walk) . g + T_final (bg . g) before the first entry = the pixel's output colour . g
+    W.Qc = L.oc0 * W.G0 + L.oc1 * W.G1 + L.oc2 * W.G2;
+    // Opaque-surface depth: D = pd / (n_c . r); only the pixel's owner receives it.  A pixel owns at
+    // most one entry of the whole list: its four partials go to that entry's accumulator in the batch that stages it.  The
+    // two words they need beyond the pixel's own ray - 1 / (n_c . r) and D - come from the forward (TileCache::depth_aux);
+    // without a cache, from the owner's Splat record (a dependent gather).
+    const bool has_owner = inside && L.owner >= 0 && L.gD != 0.f && !(dbg & 2u);
+    const uint32_t dpos = has_owner ? L.dpos : 0xffffffffu;
+    // a wave walks no further than its own last contributor
+    const uint32_t wave_last = wave_max_u32(W.last);
+
+    // the depth owners of the batch [base, base + m): kk = -gD D / (n_c . r).  The accumulators are zero and visible (the
+    // barrier behind the previous tail), so this runs BEFORE the barrier that precedes the walk.
+    auto depth_batch = [&](int base, int m, float iden, float Dd, float gD, bool reload) {
+      const bool pend = dpos >= (uint32_t)base && dpos < (uint32_t)(base + m);
+      if (__builtin_amdgcn_ballot_w64(pend) == 0ull) return;
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+      if (pend) {
+        const float rx = ((float)px - p.cx) / p.fx, ry = ((float)py - p.cy) / p.fy;
+        uint32_t pl = pix;
+        asm volatile("" : "+v"(pl));              // the addresses of these rare loads are formed here, not held from the prologue on
+        if (reload) { gD = dL_ddepth[pl]; const float2 a2 = cached ? tc.depth_aux[pl] : make_float2(0.f, 0.f); iden = a2.x; Dd = a2.y; }
+        if (!cached) {
+          const int owner = depth_index[pl];
+          const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
+          const float pd = reinterpret_cast<const float*>(splats + owner)[12];
+          iden = 1.f / (r2.y * rx + r2.z * ry + r2.w);
+          Dd = pd * iden;
+        }
+        const float kk = -gD * Dd * iden;
+        d0 = kk * rx; d1 = kk * ry; d2 = kk; d3 = gD * iden;
+      }
+      depth_adds(pend, dpos - (uint32_t)base, d0, d1, d2, d3, s_acc, lane);
+    };
+    // gather path of one batch: a record per thread through the list, tested against the four quadrants here; returns the
+    // length of this wave's sub-list.  One barrier inside (the masks of all staged entries must be in LDS).
+    auto stage_gather = [&](int base, int m) -> int {
       float txl = tx0, tyl = ty0;                        // laundered: the test's per-tile constants must not be hoisted
       asm volatile("" : "+v"(txl), "+v"(tyl));           // out of the batch loop (they would be live through the walk)
-      uint32_t bm = 0;
       int tl = tid, ll = lane;
       asm volatile("" : "+v"(tl), "+v"(ll));            // this path's addresses are formed here (held from the prologue on they spill)
       if (tid < m) {
-        const uint32_t id = point_list[range.x + base + tl];
+        const uint32_t id = point_list[range_x + base + tl];
         const float4* src = reinterpret_cast<const float4*>(splats + id);
         const float4 q0 = src[0];
         s_rec[tid * 3 + 0] = q0;
@@ -412,144 +557,116 @@ __device__ __forceinline__ void blend_bwd_entry_body(
         const float b = reinterpret_cast<const float*>(splats + id)[8];
         const float2 hxy = reinterpret_cast<const float2*>(splats + id)[7];
         const uint32_t reach = quads_reached(q0.x, q0.y, hxy.x, hxy.y, q0.z, q0.w, q1.x, q1.y, txl, tyl);
-        bm = ((reach & 1u) ? 0x0033u : 0u) | ((reach & 2u) ? 0x00ccu : 0u) | ((reach & 4u) ? 0x3300u : 0u) | ((reach & 8u) ? 0xcc00u : 0u);
+        const uint32_t bm = ((reach & 1u) ? 0x0033u : 0u) | ((reach & 2u) ? 0x00ccu : 0u) | ((reach & 4u) ? 0x3300u : 0u) | ((reach & 8u) ? 0xcc00u : 0u);
         s_rec[tid * 3 + 2] = make_float4(b, __uint_as_float(id), __uint_as_float(bm), 0.f);
       }
-      if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); st_seg[2] += t - st_t; st_t = t; }
       __syncthreads();
-      uint2 ml;
+      const int e0 = 4 * ll;
+      const uint32_t m0 = e0 + 0 < m ? __float_as_uint(s_rec[(e0 + 0) * 3 + 2].z) : 0u, m1 = e0 + 1 < m ? __float_as_uint(s_rec[(e0 + 1) * 3 + 2].z) : 0u;
+      const uint32_t m2 = e0 + 2 < m ? __float_as_uint(s_rec[(e0 + 2) * 3 + 2].z) : 0u, m3 = e0 + 3 < m ? __float_as_uint(s_rec[(e0 + 3) * 3 + 2].z) : 0u;
+      return compact_quadrant(make_uint2(m0 | (m1 << 16), m2 | (m3 << 16)), qmask, m, lane, s_sub[wv]);
+    };
+
+    // ---- the first batch: it alone consumes the prologue's loads
+    int base = 0, m = min(MB, nuse), cnt = 0;
+    if (nuse > 0) {
+      if (cached) {
+        // the forward's records: already in registers, one LDS write; the sub-list from the block masks, by this wave alone
+        if (tid < m) { s_rec[tid * 3 + 0] = L.c0; s_rec[tid * 3 + 1] = L.c1; s_rec[tid * 3 + 2] = L.c2; }
+        cnt = compact_quadrant(L.mk, qmask, m, lane, s_sub[wv]);
+      } else {
+        cnt = stage_gather(0, m);
+      }
+      depth_batch(0, m, L.aux.x, L.aux.y, L.gD, false);
+    }
+    if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[2] += t - st_t; st_t = t; }
+    int nx_all = -1;
+    for (;;) {
+      const bool lastb = base + MB >= nuse;
+      __syncthreads();                                   // records, sub-lists and depth partials of the batch are in LDS
+      if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[3] += t - st_t; st_t = t; }
+      // the next tile of this workgroup: the ticket came back long ago; the load of its queue entry rides under the walk
+      int nxt = -1;
+      if (lastb && tid == 0) nxt = ticket < n_queued ? (int)order[ticket] : -1;
+
+      // ---- the wave walks its quadrant's sub-list, 16 entries at a time
       {
-        const int e0 = 4 * ll;
-        const uint32_t m0 = e0 + 0 < m ? __float_as_uint(s_rec[(e0 + 0) * 3 + 2].z) : 0u, m1 = e0 + 1 < m ? __float_as_uint(s_rec[(e0 + 1) * 3 + 2].z) : 0u;
-        const uint32_t m2 = e0 + 2 < m ? __float_as_uint(s_rec[(e0 + 2) * 3 + 2].z) : 0u, m3 = e0 + 3 < m ? __float_as_uint(s_rec[(e0 + 3) * 3 + 2].z) : 0u;
-        ml = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
-      }
-      cnt = compact_quadrant(ml, qmask, m, lane, s_sub[wv]);
-      // (s_sub[wv] is read by this wave only: no barrier between its compaction and its walk)
-    }
-    if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[3] += t - st_t; st_t = t; }
-    // ---- the depth owners of this batch (accumulators are zero and visible: behind the barrier).  kk = -gD D / (n_c . r).
-    {
-      const bool pend = dpos >= (uint32_t)base && dpos < (uint32_t)(base + m);
-      float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-      if (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
-        if (pend) {
-          float iden, Dd, gD;
-          const float rx = ((float)px - p.cx) / p.fx, ry = ((float)py - p.cy) / p.fy;
-          uint32_t pl = pix;
-          asm volatile("" : "+v"(pl));              // the addresses of these rare loads are formed here, not held from the prologue on
-          if (base == 0) { iden = aux.x; Dd = aux.y; gD = gD_ld; }
-          else { gD = dL_ddepth[pl]; const float2 a2 = cached ? tc.depth_aux[pl] : make_float2(0.f, 0.f); iden = a2.x; Dd = a2.y; }
-          if (!cached) {
-            const int owner = depth_index[pl];
-            const float4 r2 = reinterpret_cast<const float4*>(splats + owner)[2];   // b nx ny nz
-            const float pd = reinterpret_cast<const float*>(splats + owner)[12];
-            iden = 1.f / (r2.y * rx + r2.z * ry + r2.w);
-            Dd = pd * iden;
-          }
-          const float kk = -gD * Dd * iden;
-          d0 = kk * rx; d1 = kk * ry; d2 = kk; d3 = gD * iden;
+        // Per-lane constants of the walk, (re)built per batch from the laundered lane coordinates: held across the batch
+        // loop they would be live through the staging and cost a wave per SIMD.
+        int kq = k;
+        asm volatile("" : "+v"(kq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          W.pxc[j] = (float)(bx * TILE + qx0 + 2 * j + (kq & 1));
+          W.pyc[j] = (float)(by * TILE + qy0 + 2 * j + (kq >> 1));
+          W.xq[j] = W.pxc[j] - cxT; W.yq[j] = W.pyc[j] - cyT;
         }
-        depth_adds(pend, dpos - (uint32_t)base, d0, d1, d2, d3, s_acc, lane);
       }
-    }
-    if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[1] += t - st_t; st_t = t; }
+      unsigned long long w_in = 0;
+      if constexpr (STAMP) w_in = __builtin_readcyclecounter();
+      for (int g0i = 0; g0i < cnt && !(dbg & 1u); g0i += 16) {
+        const bool have = g0i + n < cnt;
+        const int e = have ? (int)s_sub[wv][g0i + n] : 0;
+        W.pos = have ? (uint32_t)(base + e) : 0x7fffffffu;
+        const uint32_t first_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.pos);
+        if (first_pos >= wave_last) break;                 // positions increase: the wave is through
+        // quads with a pixel that still blends at or behind the group's first entry
+        const unsigned long long lb = __builtin_amdgcn_ballot_w64(W.last > first_pos);
+        const uint32_t stepmask = (uint32_t)((lb | (lb >> 16) | (lb >> 32) | (lb >> 48)) & 0xffffull);
+        if (stepmask == 0u) continue;
+        if constexpr (STAMP) { st_groups += 1; st_steps += (unsigned long long)__popc(stepmask); }
+        const float4 r0 = s_rec[e * 3 + 0], r1 = s_rec[e * 3 + 1];
+        const float rb = s_rec[e * 3 + 2].x;
+        W.u = r0.x; W.v = r0.y; W.ca = r0.z; W.cb = r0.w; W.cc = r1.x; W.o = r1.y; W.cr = r1.z; W.cg_ = r1.w; W.cbl = rb;
+        W.s0 = W.sx = W.sy = W.sxx = W.sxy = W.syy = W.sr = W.sg = W.sb = 0.f;
+        W.run16_lane(stepmask);
+        // the four pixel rows k of an entry meet in registers (v_permlane32_swap / v_permlane16_swap: two instructions per
+        // sum) and row 0 adds them to the entry's accumulator.  64 lanes adding for themselves cost 4x the LDS float adds,
+        // and those run at about a lane per cycle per CU: measured 153 / 277 us instead of 99 / 165.
+        const float f0 = sum_rows(W.s0), f1 = sum_rows(W.sx), f2 = sum_rows(W.sy), f3 = sum_rows(W.sxx), f4 = sum_rows(W.sxy);
+        const float f5 = sum_rows(W.syy), f6 = sum_rows(W.sr), f7 = sum_rows(W.sg), f8 = sum_rows(W.sb);
+        if (have && k == 0) {
+          float* const acc = &s_acc[e * MACC];
+          atomicAdd(acc + 0, f0); atomicAdd(acc + 1, f1); atomicAdd(acc + 2, f2); atomicAdd(acc + 3, f3); atomicAdd(acc + 4, f4);
+          atomicAdd(acc + 5, f5); atomicAdd(acc + 6, f6); atomicAdd(acc + 7, f7); atomicAdd(acc + 8, f8);
+        }
+      }
+      if constexpr (STAMP) { st_t = __builtin_readcyclecounter(); st_walk += st_t - w_in; }
+      if (lastb && tid == 0) s_next = nxt;
+      __syncthreads();
+      if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[4] += t - st_t; st_t = t; }
 
-    // ---- the wave walks its quadrant's sub-list, 16 entries at a time
-    {
-      // Per-lane constants of the walk, (re)built per batch from the laundered lane coordinates: held across the batch
-      // loop they would be live through the staging above and cost a wave per SIMD.
-      int kq = k;
-      asm volatile("" : "+v"(kq));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        W.pxc[j] = (float)(bx * TILE + qx0 + 2 * j + (kq & 1));
-        W.pyc[j] = (float)(by * TILE + qy0 + 2 * j + (kq >> 1));
-        W.xq[j] = W.pxc[j] - cxT; W.yq[j] = W.pyc[j] - cyT;
-      }
-    }
-    unsigned long long w_in = 0;
-    if constexpr (STAMP) w_in = __builtin_readcyclecounter();
-    for (int g0i = 0; g0i < cnt && !(dbg & 1u); g0i += 16) {
-      const bool have = g0i + n < cnt;
-      const int e = have ? (int)s_sub[wv][g0i + n] : 0;
-      W.pos = have ? (uint32_t)(base + e) : 0x7fffffffu;
-      const uint32_t first_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.pos);
-      if (first_pos >= wave_last) break;                 // positions increase: the wave is through
-      // quads with a pixel that still blends at or behind the group's first entry
-      const unsigned long long lb = __builtin_amdgcn_ballot_w64(W.last > first_pos);
-      const uint32_t stepmask = (uint32_t)((lb | (lb >> 16) | (lb >> 32) | (lb >> 48)) & 0xffffull);
-      if (stepmask == 0u) continue;
-      if constexpr (STAMP) { st_groups += 1; st_steps += (unsigned long long)__popc(stepmask); }
-      const float4 r0 = s_rec[e * 3 + 0], r1 = s_rec[e * 3 + 1];
-      const float rb = s_rec[e * 3 + 2].x;
-      W.u = r0.x; W.v = r0.y; W.ca = r0.z; W.cb = r0.w; W.cc = r1.x; W.o = r1.y; W.cr = r1.z; W.cg_ = r1.w; W.cbl = rb;
-      W.s0 = W.sx = W.sy = W.sxx = W.sxy = W.syy = W.sr = W.sg = W.sb = 0.f;
-      W.run16_lane(stepmask);
-      // the four pixel rows k of an entry meet in registers (v_permlane32_swap / v_permlane16_swap: two instructions per
-      // sum) and row 0 adds them to the entry's accumulator.  64 lanes adding for themselves cost 4x the LDS float adds,
-      // and those run at about a lane per cycle per CU: measured 153 / 277 us instead of 99 / 165.
-      const float f0 = sum_rows(W.s0), f1 = sum_rows(W.sx), f2 = sum_rows(W.sy), f3 = sum_rows(W.sxx), f4 = sum_rows(W.sxy);
-      const float f5 = sum_rows(W.syy), f6 = sum_rows(W.sr), f7 = sum_rows(W.sg), f8 = sum_rows(W.sb);
-      if (have && k == 0) {
-        float* const acc = &s_acc[e * MACC];
-        atomicAdd(acc + 0, f0); atomicAdd(acc + 1, f1); atomicAdd(acc + 2, f2); atomicAdd(acc + 3, f3); atomicAdd(acc + 4, f4);
-        atomicAdd(acc + 5, f5); atomicAdd(acc + 6, f6); atomicAdd(acc + 7, f7); atomicAdd(acc + 8, f8);
-      }
-    }
-    if constexpr (STAMP) { st_t = __builtin_readcyclecounter(); st_walk += st_t - w_in; }
-    __syncthreads();
-    if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[4] += t - st_t; st_t = t; }
-
-    // ---- one thread per staged entry: moments -> d(u, v, conic), slot store
-    if (tid < m) {
-      float t[13];
-      bool any = false;
-#pragma unroll
-      for (int q = 0; q < 13; ++q) { t[q] = s_acc[tid * MACC + q]; any |= (t[q] != 0.f); }
-      const uint32_t gid = __float_as_uint(s_rec[tid * 3 + 2].y);
-      if (any && gid - t0 < tn && !(dbg & 4u)) {          // a frozen row (outside [t0, t0 + tn)) takes no slot
-        // the slot run of the Gaussian and its next free slot: two independent round trips, issued together
-        uint32_t slot = 0u;
-        if (use_slots) slot = gbase[gid] + atomicAdd(&slot_count[gid], 1u);
-        const float4 q0 = s_rec[tid * 3 + 0];            // u v ca cb
-        const float4 q1 = s_rec[tid * 3 + 1];            // cc o r g
-        // sums over the pixels of gdl = o gda times powers of d = centre - pixel, from the moments about the tile centre
-        const float ut = q0.x - cxT, vt = q0.y - cyT, o = q1.y;
-        const float m0 = t[0], mx = t[1], my = t[2], mxx = t[3], mxy = t[4], myy = t[5];
-        const float sx = o * (ut * m0 - mx), sy = o * (vt * m0 - my);
-        const float sxx = o * (ut * (ut * m0 - 2.f * mx) + mxx);
-        const float sxy = o * (ut * (vt * m0 - my) - vt * mx + mxy);
-        const float syy = o * (vt * (vt * m0 - 2.f * my) + myy);
-        const float du = -(q0.z * sx + q0.w * sy), dv = -(q1.x * sy + q0.w * sx);
-        const float dca = -0.5f * sxx, dcb = -sxy, dcc = -0.5f * syy, dop = m0;
-        touched[gid] = 1;
-        if (use_slots) {
-          // SplatGrad order: du dv dca dcb | dcc dop dr dg | db dnx dny dnz | dpd - - -
-          float4* dst = reinterpret_cast<float4*>(slot_grads + slot);
-          dst[0] = make_float4(du, dv, dca, dcb);
-          dst[1] = make_float4(dcc, dop, t[6], t[7]);
-          dst[2] = make_float4(t[8], t[9], t[10], t[11]);
-          dst[3] = make_float4(t[12], 0.f, 0.f, 0.f);
+      if (lastb) {
+        nx_all = s_next;
+        if constexpr (DEFER) {
+          // the tail of the tile's last batch waits for the next turn (see the top of the loop)
+          pend_m = m; pend_cx = cxT; pend_cy = cyT;
         } else {
-          float* dst = reinterpret_cast<float*>(grads + gid);
-          const float vals[13] = {du, dv, dca, dcb, dcc, dop, t[6], t[7], t[8], t[9], t[10], t[11], t[12]};
-#pragma unroll
-          for (int q = 0; q < 13; ++q)
-            if (vals[q] != 0.f) unsafeAtomicAdd(dst + q, vals[q]);
+          entry_tail(m, cxT, cyT);
+          __syncthreads();
+          if constexpr (STAMP) { const unsigned long long t2 = __builtin_readcyclecounter(); st_seg[5] += t2 - st_t; st_t = t2; }
         }
+        break;
+      }
+      entry_tail(m, cxT, cyT);
+      __syncthreads();                                   // the tail has read (and cleared) its LDS: the next batch may write it
+      if constexpr (STAMP) { const unsigned long long t2 = __builtin_readcyclecounter(); st_seg[5] += t2 - st_t; st_t = t2; }
+      base += MB;
+      m = min(MB, nuse - base);
+      cnt = stage_gather(base, m);
+      depth_batch(base, m, 0.f, 0.f, 0.f, true);
+      if constexpr (STAMP) { const unsigned long long t2 = __builtin_readcyclecounter(); st_seg[2] += t2 - st_t; st_t = t2; }
+    }
+    if constexpr (STAMP) {
+      if (lane == 0) {
+        unsigned long long* o = stamps + (size_t)(tile * 4 + wv) * 14;
+        o[0] = st_wall; o[1] = wall_clock64(); o[2] = st_walk; o[3] = __builtin_readcyclecounter() - st_cyc; o[4] = st_groups; o[5] = st_steps;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) o[6 + q] = st_seg[q];
+        o[12] = st_p1; o[13] = st_p2;
       }
     }
-    if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); st_seg[5] += t - st_t; st_t = t; }
-  }
-  if constexpr (STAMP) {
-    if (lane == 0) {
-      unsigned long long* o = stamps + (size_t)(tile * 4 + wv) * 14;
-      o[0] = st_wall; o[1] = wall_clock64(); o[2] = st_walk; o[3] = __builtin_readcyclecounter() - st_cyc; o[4] = st_groups; o[5] = st_steps;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) o[6 + q] = st_seg[q];
-      o[12] = st_p1; o[13] = st_p2;
-    }
+    cur = nx_all;
   }
 }
 
@@ -560,16 +677,100 @@ __device__ __forceinline__ void blend_bwd_entry_body(
       const float *__restrict__ dL_ddepth, const uint32_t *__restrict__ gbase, uint32_t *__restrict__ slot_count,                    \
       const BwdInfo *__restrict__ info, SplatGrad *__restrict__ grads, uint8_t *__restrict__ touched,                               \
       const uint32_t *__restrict__ tile_mode, uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long *__restrict__ stamps,       \
-      TileCache tc, const uint32_t *__restrict__ order
+      TileCache tc, BwdQueue *__restrict__ queue
 #define RTGS_BWD_PASS                                                                                                             \
   p, ranges, point_list, splats, out_color, n_contrib, depth_index, depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, \
-      info, grads, touched, tile_mode, t0, tn, dbg, stamps, tc, order
-// the product kernel
-__global__ void __launch_bounds__(256, 5) blend_bwd_entry_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false>(RTGS_BWD_PASS); }
+      info, grads, touched, tile_mode, t0, tn, dbg, stamps, tc, queue
+// The product kernel, in two forms (rtgs_raster_set_bwd_form / RTGS_BWD_FORM at load time; A-B in profiles/r06_*):
+//   5: five workgroups per CU (96 VGPRs); a tile's loads leave at the top of its turn, its per-entry tail runs in place;
+//   4: four workgroups per CU (128 VGPRs) - room to hold a tile's thirty loaded values across the PREVIOUS tile's deferred tail.
+__global__ void __launch_bounds__(256, 5) blend_bwd_entry_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false, false>(RTGS_BWD_PASS); }
+__global__ void __launch_bounds__(256, 4) blend_bwd_entry_defer_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false, true>(RTGS_BWD_PASS); }
 // the same, leaving per-wave time stamps (tools/bwd_stamps.py)
-__global__ void __launch_bounds__(256, 5) blend_bwd_entry_stamped_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<true>(RTGS_BWD_PASS); }
+__global__ void __launch_bounds__(256, 5) blend_bwd_entry_stamped_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<true, false>(RTGS_BWD_PASS); }
+__global__ void __launch_bounds__(256, 4) blend_bwd_entry_defer_stamped_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<true, true>(RTGS_BWD_PASS); }
 #undef RTGS_BWD_ARGS
 #undef RTGS_BWD_PASS
+
+// The queue of one backward launch: every tile of this list set that the entry-per-lane walk has something to walk in
+// (tile_mode says 2, min(list length, last contributor) > 0), LONGEST WALK FIRST - a counting sort over the walk length in one
+// workgroup (3 225 tiles at 1200x680: ~3 us) - and the ticket counter, armed for a grid of `grid` workgroups.
+constexpr int ORDER_BINS = 1024;          // walk lengths 0 .. 4 095 in steps of 4 (longer: first bin)
+// mode 0: no order (one bin: whatever order the threads arrive in); 1: longest walk first; 2: longest first, INTERLEAVED - the
+// heaviest fifth spread one in five over the whole queue (co-resident heavy tiles share a SIMD's issue slots and all take
+// long; co-resident light tiles leave it idle: profiles/r06_d_*); one_shot: every workgroup takes one tile (head stays
+// beyond the count)
+__global__ void __launch_bounds__(1024) bwd_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_last,
+                                                         const uint32_t* __restrict__ tile_mode, int ntiles, int gx, uint32_t grid,
+                                                         const uint32_t* __restrict__ spec_fail, BwdQueue* __restrict__ queue,
+                                                         int mode, int one_shot) {
+  __shared__ uint32_t s_hist[ORDER_BINS];
+  __shared__ uint32_t s_wsum[16];
+  __shared__ uint32_t s_ord[4096];
+  uint32_t* const order = reinterpret_cast<uint32_t*>(queue + 1);
+  const int tid = threadIdx.x;
+  if (spec_failed(spec_fail)) { if (tid == 0) { queue->head = grid; queue->count = 0u; } return; }
+  s_hist[tid] = 0u;
+  // one pass of loads (a tile per thread and pass, PER passes: 4 096 tiles = 1024 x 1024 pixels; beyond that the image is
+  // taken in further sweeps over the same bins), everything independent issued before the first use
+  constexpr int PER = 4;
+  uint32_t bin[PER];
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 1024 * PER) {
+    uint32_t tm[PER], tl[PER];
+    uint2 rg[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int t = min(base + j * 1024 + tid, ntiles - 1);
+      tm[j] = tile_mode[t]; rg[j] = ranges[t]; tl[j] = tile_last[t];
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int t = base + j * 1024 + tid;
+      const uint32_t nuse = (t < ntiles && (tm[j] & 3u) == 2u) ? min(rg[j].y - rg[j].x, tl[j]) : 0u;
+      bin[j] = nuse > 0u ? (mode == 0 ? 0u : (uint32_t)ORDER_BINS - 1u - min(nuse >> 2, (uint32_t)ORDER_BINS - 1u)) : 0xffffffffu;
+      if (nuse > 0u) atomicAdd(&s_hist[bin[j]], 1u);
+    }
+    if (ntiles > 1024 * PER) {
+      // (large images only) the bins of this sweep are not kept: the scatter below recomputes them per sweep
+    }
+  }
+  __syncthreads();
+  // exclusive prefix over the bins (bin 0 = the longest walks)
+  const uint32_t mine = s_hist[tid];
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if ((tid & 63) >= off) incl += o; }
+  if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int w = 0; w < (tid >> 6); ++w) before += s_wsum[w];
+  __syncthreads();
+  s_hist[tid] = before + incl - mine;        // the bin's cursor
+  if (tid == 1023) { queue->count = before + incl; queue->head = one_shot ? 0x80000000u : grid; s_wsum[0] = before + incl; }
+  __syncthreads();
+  if (ntiles <= 1024 * PER) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int t = j * 1024 + tid;
+      if (bin[j] != 0xffffffffu) s_ord[atomicAdd(&s_hist[bin[j]], 1u)] = ((uint32_t)(t / gx) << 16) | (uint32_t)(t % gx);
+    }
+    __syncthreads();
+    const uint32_t nq = s_wsum[0], nh = mode == 2 ? nq / 5u : 0u;
+    for (uint32_t q = (uint32_t)tid; q < nq; q += 1024u) {
+      uint32_t src = q;
+      if (q < 5u * nh) { const uint32_t j = q / 5u, r = q % 5u; src = r == 0u ? j : nh + 4u * j + r - 1u; }
+      order[q] = s_ord[src];
+    }
+  } else {
+    for (int t = tid; t < ntiles; t += 1024) {
+      if ((tile_mode[t] & 3u) != 2u) continue;
+      const uint2 r = ranges[t];
+      const uint32_t nuse = min(r.y - r.x, tile_last[t]);
+      if (nuse > 0u) order[atomicAdd(&s_hist[mode == 0 ? 0 : ORDER_BINS - 1 - min(nuse >> 2, (uint32_t)ORDER_BINS - 1u)], 1u)] = ((uint32_t)(t / gx) << 16) | (uint32_t)(t % gx);
+    }
+  }
+}
 
 // timing decompositions (tools only; rtgs_raster_set_bwd_debug): bit 0 walk off, bit 1 depth partials off, bit 2 stores off -
 // results are then wrong by construction, so the bits are NOT read from the environment and the tools that set
@@ -579,17 +780,42 @@ static unsigned long long* g_bwd_stamps = nullptr;
 void set_bwd_debug(int bits) { g_bwd_dbg = bits & 15; }
 void set_bwd_stamps(void* dev) { g_bwd_stamps = (unsigned long long*)dev; }
 
+static int g_bwd_form = [] { const char* e = getenv("RTGS_BWD_FORM"); const int v = e ? atoi(e) : 5; return (v == 4 || v == 1) ? v : 5; }();
+static int g_bwd_order = [] { const char* e = getenv("RTGS_BWD_ORDER"); const int v = e ? atoi(e) : 1; return (v >= 0 && v <= 2) ? v : 1; }();
+void set_bwd_form(int form) { g_bwd_form = (form == 4 || form == 1) ? form : 5; }
+// workgroups of a persistent launch: `per` per CU (what the form's __launch_bounds__ and 26.6 KB of LDS give), per device
+static uint32_t persistent_grid(int per) {
+  static int cus_of[16] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16) dev = 0;
+  if (cus_of[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cus_of[dev] = cus;
+  }
+  return (uint32_t)(cus_of[dev] * per);
+}
+
 void launch_blend_bwd_entry(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                             const float* out_color, const uint32_t* n_contrib, const int32_t* depth_index,
                             const uint32_t* depth_pos, const uint32_t* tile_last, const float* dL_dcolor, const float* dL_ddepth,
                             const uint32_t* gbase, uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
-                            const uint32_t* tile_mode, uint32_t t0, uint32_t tn, TileCache tc, const uint32_t* order, hipStream_t st) {
+                            const uint32_t* tile_mode, uint32_t t0, uint32_t tn, TileCache tc, void* queue_words, hipStream_t st) {
   const uint32_t dbg = (uint32_t)g_bwd_dbg;
+  const int ntiles = p.gx * p.gy;
+  const bool defer = g_bwd_form == 4;
+  const bool one_shot = g_bwd_form == 1;             // one tile per workgroup (the hardware's dispatcher is the queue)
+  const uint32_t grid = one_shot ? (uint32_t)ntiles : min(persistent_grid(defer ? 4 : 5), (uint32_t)ntiles);
+  BwdQueue* const queue = (BwdQueue*)queue_words;
+  hipLaunchKernelGGL(bwd_order_kernel, dim3(1), dim3(1024), 0, st, ranges, tile_last, tile_mode, ntiles, p.gx, grid, p.spec_fail, queue,
+                     g_bwd_order, one_shot ? 1 : 0);
 #define RTGS_BWD_LAUNCH(KERNEL)                                                                                                      \
-  hipLaunchKernelGGL(KERNEL, dim3(p.gx * p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color, n_contrib, depth_index, \
+  hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color, n_contrib, depth_index,       \
                      depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched, tile_mode, t0, tn, dbg,    \
-                     g_bwd_stamps, tc, order)
-  if (g_bwd_stamps) RTGS_BWD_LAUNCH(blend_bwd_entry_stamped_kernel); else RTGS_BWD_LAUNCH(blend_bwd_entry_kernel);
+                     g_bwd_stamps, tc, queue)
+  if (g_bwd_stamps) { if (defer) RTGS_BWD_LAUNCH(blend_bwd_entry_defer_stamped_kernel); else RTGS_BWD_LAUNCH(blend_bwd_entry_stamped_kernel); }
+  else { if (defer) RTGS_BWD_LAUNCH(blend_bwd_entry_defer_kernel); else RTGS_BWD_LAUNCH(blend_bwd_entry_kernel); }
 #undef RTGS_BWD_LAUNCH
 }
 

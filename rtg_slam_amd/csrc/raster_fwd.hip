@@ -306,7 +306,7 @@ constexpr int FWD_CHUNKS = FWD_BATCH / 32;      // 32-entry words of a block's s
 // STAMP (measurement only, tools/fwd_stamps.py): every wave leaves eight 64-bit words - wall clock (100 MHz) at entry and exit,
 // shader cycles until the tile's range is there | until the first batch is staged and its barrier passed | inside the walk
 // loops | in the whole kernel, walk steps taken, batches staged.
-template <int OCC, bool STAMP>
+template <int OCC, bool STAMP, int LAYOUT>
 __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -316,6 +316,9 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     uint32_t* __restrict__ depth_pos, uint32_t* __restrict__ tile_last, int walk, uint32_t* __restrict__ aux_zero,
     TileCache tc, unsigned long long* __restrict__ stamps) {
   __shared__ float4 s_rec[FWD_BATCH * 4];     // u v ca cb | cc o r g | b - - id | nx ny nz pd: the walk reads the first three
+  // LAYOUT 0: entry-major (64 B per entry); 1: four planes of FWD_BATCH float4 (the four rows of a wave read four DIFFERENT
+  // entries per step: entry-major, two entries collide on their banks whenever their indices agree mod 4; plane-major, mod 16)
+#define RI(e, j) (LAYOUT ? (j) * FWD_BATCH + (e) : (e) * 4 + (j))
   __shared__ float s_z[FWD_BATCH];            // centre depth (opaque-surface test only)
   __shared__ uint32_t s_live[16][FWD_CHUNKS]; // per 4x4 block: the staged entries that reach it
 
@@ -366,13 +369,13 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
         const uint32_t id = point_list[range.x + base + tid];
         const float4* src = reinterpret_cast<const float4*>(splats + id);
         const float4 q0 = src[0];
-        s_rec[tid * 4 + 0] = q0;
+        s_rec[RI(tid, 0)] = q0;
         const float4 q1 = src[1];
-        s_rec[tid * 4 + 1] = q1;
+        s_rec[RI(tid, 1)] = q1;
         const float4 q2 = src[2];               // b nx ny nz
         const float4 q3 = src[3];               // pd z hx hy
-        s_rec[tid * 4 + 2] = make_float4(q2.x, 0.f, 0.f, __uint_as_float(id));
-        s_rec[tid * 4 + 3] = make_float4(q2.y, q2.z, q2.w, q3.x);
+        s_rec[RI(tid, 2)] = make_float4(q2.x, 0.f, 0.f, __uint_as_float(id));
+        s_rec[RI(tid, 3)] = make_float4(q2.y, q2.z, q2.w, q3.x);
         s_z[tid] = q3.y;
         // For the backward (TileCache, raster_common.h): the record and the block mask of list position base + tid at a place
         // that depends on the TILE only - its first loads need no tile range, no list id, no gather and no block test.
@@ -410,9 +413,9 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
       const int e = has ? (c << 5) + __builtin_ctz(cur) : 0;
       cur &= cur - 1u;
       if constexpr (STAMP) st_steps += 1;
-      const float4 r0 = s_rec[e * 4 + 0];        // u v ca cb
-      const float4 r1 = s_rec[e * 4 + 1];        // cc o r g
-      const float4 r2 = s_rec[e * 4 + 2];        // b - - id
+      const float4 r0 = s_rec[RI(e, 0)];        // u v ca cb
+      const float4 r1 = s_rec[RI(e, 1)];        // cc o r g
+      const float4 r2 = s_rec[RI(e, 2)];        // b - - id
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
       const float al = fminf(0.99f, r1.y * splat_exp(fminf(power, 0.f)));
@@ -437,7 +440,7 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
           // the pixel's ray, recomputed here (a handful of times per pixel) rather than held in registers across the walk
           const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
           const float rnorm = sqrtf(rx * rx + ry * ry + 1.f);
-          const float4 r3 = s_rec[e * 4 + 3];    // nx ny nz pd
+          const float4 r3 = s_rec[RI(e, 3)];    // nx ny nz pd
           const float den = r3.x * rx + r3.y * ry + r3.z;
           if (fabsf(den) / rnorm > p.normal_thr) {
             const float zhit = r3.w / den;
@@ -532,9 +535,11 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     }
   }
 }
+#undef RI
 
 
 static int g_f1_occ = [] { const char* e = getenv("RTGS_F1_OCC"); const int v = e ? atoi(e) : 6; return (v == 5 || v == 7 || v == 8) ? v : 6; }();
+static int g_f1_layout = [] { const char* e = getenv("RTGS_F1_LAYOUT"); return e ? atoi(e) : 0; }();
 static unsigned long long* g_fwd_stamps = nullptr;   // measurement only (rtgs_raster_set_fwd_stamps)
 void set_fwd_stamps(void* dev) { g_fwd_stamps = (unsigned long long*)dev; }
 
@@ -622,11 +627,12 @@ void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
                       SlicePass sp, uint32_t* tile_mode, uint32_t* depth_pos, uint32_t* tile_last, int walk, uint32_t* aux_zero,
                       TileCache tc, hipStream_t st) {
-#define RTGS_FWD1(OCC, STAMP) hipLaunchKernelGGL((blend_fwd_kernel<OCC, STAMP>), dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, \
+#define RTGS_FWD1(OCC, STAMP, LAYOUT) hipLaunchKernelGGL((blend_fwd_kernel<OCC, STAMP, LAYOUT>), dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, \
                        out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp, tile_mode, \
                        depth_pos, tile_last, walk, aux_zero, tc, g_fwd_stamps)
-  if (g_fwd_stamps) RTGS_FWD1(6, true);
-  else if (g_f1_occ == 8) RTGS_FWD1(8, false); else if (g_f1_occ == 7) RTGS_FWD1(7, false); else if (g_f1_occ == 5) RTGS_FWD1(5, false); else RTGS_FWD1(6, false);
+  if (g_fwd_stamps) { if (g_f1_layout) RTGS_FWD1(6, true, 1); else RTGS_FWD1(6, true, 0); }
+  else if (g_f1_layout) { if (g_f1_occ == 8) RTGS_FWD1(8, false, 1); else if (g_f1_occ == 5) RTGS_FWD1(5, false, 1); else RTGS_FWD1(6, false, 1); }
+  else if (g_f1_occ == 8) RTGS_FWD1(8, false, 0); else if (g_f1_occ == 7) RTGS_FWD1(7, false, 0); else if (g_f1_occ == 5) RTGS_FWD1(5, false, 0); else RTGS_FWD1(6, false, 0);
 #undef RTGS_FWD1
 }
 

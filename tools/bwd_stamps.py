@@ -76,7 +76,9 @@ names = ["prologue (every first load landed)", "accumulator zeroing + depth part
 vals = [seg[0], seg[1], seg[2], seg[3], cyc_walk.sum(), seg[4], seg[5]]
 print("share of the waves' cycles: " + "; ".join(f"{n} {v / cyc_total.sum():.3f}" for n, v in zip(names, vals)) +
       f"; unaccounted {1.0 - sum(vals) / cyc_total.sum():.3f}")
-p1 = s[:, :, 12][live].astype(np.float64).sum(); p2 = s[:, :, 13][live].astype(np.float64).sum()
+p1w = s[:, :, 12][live]
+p_issue = (p1w & 0xffffffff).astype(np.float64).sum(); p1 = (p1w >> 32).astype(np.float64).sum(); p2 = s[:, :, 13][live].astype(np.float64).sum()
+print(f"prologue, mean us per wave: all loads issued {p_issue / live.sum() / mhz:.2f}; first load back {p1 / live.sum() / mhz:.2f}; all back {p2 / live.sum() / mhz:.2f}")
 print(f"inside the prologue: per-tile words arrive {p1 / cyc_total.sum():.3f}; the rest of the first loads {(p2 - p1) / cyc_total.sum():.3f} "
       f"(mean prologue {seg[0] / live.sum() / mhz:.2f} us)")
 # waves of a tile: how unequal (the tile waits for its slowest quadrant at every batch barrier)

@@ -14,6 +14,8 @@ which = sys.argv[1] if len(sys.argv) > 1 else "headline"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 N = int(os.environ.get("RTGS_N", 1_200_000))
 lib = _lib.load()
+if os.environ.get("RTGS_BWD_DEBUG_TOOL"):       # timing decompositions (tools/r06_decomp.sh): parts of the backward walk off, results wrong
+    lib.rtgs_raster_set_bwd_debug(int(os.environ["RTGS_BWD_DEBUG_TOOL"]))
 cam = synth.REPLICA
 dev = torch.device("cuda", 0)
 g = synth.random_gaussians(N, cam, seed=2024) if which == "headline" else synth.surface_gaussians(N, cam, seed=7)
