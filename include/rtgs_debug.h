@@ -80,10 +80,6 @@ void rtgs_raster_set_bwd_debug(int bits);
  * in the group loop and in the kernel, groups walked, quad steps entered, cycles of the six other phases.  PROCESS-WIDE; the
  * caller keeps the buffer alive until it has passed NULL again. */
 void rtgs_raster_set_bwd_stamps(void* dev);
-/* The entry-per-lane backward's persistent kernel exists in two forms (raster_bwd_entry.hip): 5 = five workgroups per CU, the
- * per-entry tail in place; 4 = four per CU (128 VGPRs), the tail of a tile deferred behind the issue of the next tile's loads.
- * Same results.  PROCESS-WIDE; RTGS_BWD_FORM at load time. */
-void rtgs_raster_set_bwd_form(int form);
 /* The same for blend_fwd (tools/fwd_stamps.py): `dev` = device uint64[tiles x 4 waves x 8]: wall clock at entry / exit, cycles until
  * the tile range is there | until the first batch is staged | inside the walk loops | in the kernel, walk steps, batches. */
 void rtgs_raster_set_fwd_stamps(void* dev);

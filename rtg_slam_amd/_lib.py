@@ -158,7 +158,6 @@ _SIGNATURES = {
     "rtgs_raster_set_bwd_debug": (None, [C.c_int]),
     "rtgs_raster_set_bwd_stamps": (None, [C.c_void_p]),
     "rtgs_raster_set_fwd_stamps": (None, [C.c_void_p]),
-    "rtgs_raster_set_bwd_form": (None, [C.c_int]),
     "rtgs_raster_set_onepass_ctx": (None, [_P, C.c_int]),
     "rtgs_raster_forward_verify_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "rtgs_raster_spec_fail_ptr_ctx": (C.c_void_p, [_P]),

@@ -22,16 +22,15 @@ void launch_tile_ranges(int64_t, const uint64_t*, uint2*, hipStream_t);
 void set_fwd_stamps(void* dev);
 void set_bwd_debug(int bits);
 void set_bwd_stamps(void* dev);
-void set_bwd_form(int form);
 void launch_blend_fwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, float*, float*, int32_t*,
                       int32_t*, float*, float*, float*, uint32_t*, unsigned long long*, SlicePass, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*,
-                      TileCache, hipStream_t);
+                      TileCache, uint32_t, hipStream_t);
 void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const float*,
                       const uint32_t*, const int32_t*, const float*, const float*, const uint32_t*, uint32_t*,
                       const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, uint32_t, uint32_t, hipStream_t);
 void launch_blend_bwd_entry(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const uint32_t*,
                             const int32_t*, const uint32_t*, const uint32_t*, const float*, const float*, const uint32_t*, uint32_t*,
-                            const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, uint32_t, TileCache, void*, hipStream_t);
+                            const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, uint32_t, TileCache, hipStream_t);
 void launch_grad_reduce(int, const uint8_t*, const uint32_t*, uint32_t*, const BwdInfo*, SplatGrad*, const uint32_t*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
@@ -298,11 +297,10 @@ static ImgLayout img_layout(int H, int W, int ntiles) {
   L.depth_pos = off; off = align_up(off + (size_t)H * W * sizeof(uint32_t));
   L.tile_last = off; off = align_up(off + (size_t)ntiles * sizeof(uint32_t));
   // the TileCache (raster_common.h): 48 B of record + 2 B of block mask for the first TILE_RECS list positions of every tile
-  // (39.6 + 1.7 MB at 1200x680), two plane words per pixel, the backward's tile order
+  // (39.6 + 1.7 MB at 1200x680), two plane words per pixel
   L.tile_recs = off; off = align_up(off + (size_t)ntiles * TILE_RECS * 3 * sizeof(float4));
   L.tile_masks = off; off = align_up(off + (size_t)ntiles * TILE_RECS * sizeof(uint16_t));
   L.depth_aux = off; off = align_up(off + (size_t)H * W * sizeof(float2));
-  L.tile_order = off; off = align_up(off + ((size_t)ntiles + 4) * sizeof(uint32_t));      // BwdQueue: 4 words + the order
   L.total = off;
   return L;
 }
@@ -555,7 +553,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         prof_mark(c, EV_SL_BIN, st);
         const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
         launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                         n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, st);
+                         n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, seg1, st);
         prof_mark(c, EV_SL_BLEND, st);      // the bracket holds the blend alone (bench.py's roofline divides by it)
         launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, fail, st, seg1 ? tile_count1 : nullptr);
         prof_mark(c, EV_BLEND0, st); prof_mark(c, EV_BLEND, st);
@@ -622,7 +620,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         prof_mark(c, EV_SORT, st);
         prof_mark(c, EV_BLEND0, st);
         launch_blend_fwd(pg, ranges, (uint32_t*)(bin + B.vals_b), splats, out_color, out_depth, out_cidx, out_didx, out_cw,
-                         out_dw, out_T, n_contrib, c->counters, SlicePass{0, nullptr, nullptr, nullptr, nullptr}, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, st);
+                         out_dw, out_T, n_contrib, c->counters, SlicePass{0, nullptr, nullptr, nullptr, nullptr}, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, seg2, st);
         prof_mark(c, EV_BLEND, st);
         c->hint_slice_lists = false; c->hint_main_lists = true;
         c->slice_stats[0] = pl.kind == 2 ? 1 : 0; c->slice_stats[1] = 0; c->slice_stats[2] = 0;
@@ -708,7 +706,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       if (++c->seq == 0u) c->seq = 1u;
       const SlicePass pass1{1, tile_mask, mask2, ranges1_bwd, ranges};
       launch_blend_fwd(p, ranges1, list1, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                       n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, st);
+                       n_contrib, c->counters, pass1, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, seg1, st);
       prof_mark(c, EV_SL_BLEND, st);
       launch_slice_publish(ntiles, tile_mask, mask2, info + 2, slice_ctr, info_host, c->seq, nullptr, st, seg1 ? tile_count1 : nullptr);
       DBG(s, st);
@@ -822,7 +820,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   prof_mark(c, EV_BLEND0, st);
   if (!sliced || n_left > 0)     // pass 2 (or the only pass); with every tile finished by the slice there is nothing to draw
     launch_blend_fwd(p, ranges, vals_b, splats, out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T,
-                     n_contrib, c->counters, pass, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, st);
+                     n_contrib, c->counters, pass, tile_mode, depth_pos, tile_last, fwd_walk, aux_zero, tcache, 0u, st);
   prof_mark(c, EV_BLEND, st);
   DBG(s, st);
   HIP_TRY(hipGetLastError());
@@ -914,7 +912,7 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
                                out_didx, depth_pos, (const uint32_t*)(img + I.tile_last), dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads,
                                touched, tile_mode, t0, tn,
                                TileCache{(float4*)(img + I.tile_recs), (uint16_t*)(img + I.tile_masks), (float2*)(img + I.depth_aux)},
-                               (void*)(img + I.tile_order), st);
+                               st);
     }
     prof_mark(c, EV_BWALK, st);
     // sum each touched Gaussian's slots into its SplatGrad record (no-op on the atomic fallback)
@@ -1040,7 +1038,6 @@ int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
 uint32_t rtgs_raster_last_listed_ctx(rtgs_ctx* c) { return use(c)->last_listed; }
 void rtgs_raster_set_bwd_debug(int bits) { rtgs::set_bwd_debug(bits); }
 void rtgs_raster_set_bwd_stamps(void* dev) { rtgs::set_bwd_stamps(dev); }
-void rtgs_raster_set_bwd_form(int form) { rtgs::set_bwd_form(form); }
 void rtgs_raster_set_fwd_stamps(void* dev) { rtgs::set_fwd_stamps(dev); }
 void rtgs_raster_set_onepass_ctx(rtgs_ctx* c, int on) { use(c)->onepass = on != 0; use(c)->plan.valid = false; }
 void rtgs_raster_set_bwd_walk_ctx(rtgs_ctx* c, int mode) { use(c)->bwd_walk = (mode >= 1 && mode <= 4) ? mode : 0; }

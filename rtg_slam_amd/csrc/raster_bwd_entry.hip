@@ -192,19 +192,6 @@ struct EntryWalk {
   }
 };
 
-// max over the wave's 64 lanes, in every lane - row swaps and row rotations only: no ds_bpermute, hence none of its six
-// per-lane address registers (which, loop-invariant, are hoisted out of the tile loop and then spilled)
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-  x = max(r[0], r[1]);
-  const auto q = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-  x = max(q[0], q[1]);
-  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false));    // row_ror:8
-  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false));    // row_ror:4
-  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false));    // row_ror:2
-  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false));    // row_ror:1
-  return x;
-}
 // x[n] + x[n + 16] + x[n + 32] + x[n + 48] in every lane (gfx950's row swaps: upper half <-> lower half, odd rows <-> even rows)
 __device__ __forceinline__ float sum_rows(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -299,25 +286,26 @@ __device__ __forceinline__ int compact_quadrant(uint2 mk, uint32_t qm, int m, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The kernel is PERSISTENT and QUEUE-FED (round 6).  A launch holds one workgroup per resident slot (5 per CU); tiles come
-// from a device queue in the order bwd_order_kernel left them - longest walk first (in tile order the last third of a launch
-// was a tail of heavy tiles that started late: profiles/r05_bwd_stamps_*) and only tiles that have something to walk.  What
-// that buys, by round 6's stamps (profiles/r06_a_bwd_stamps_*): a fresh workgroup spent 17 % of its life on FIVE serialised
-// scalar waits (kernel arguments -> speculation word -> BwdInfo -> its words -> the tile's words) before its first vector
-// load left; here the launch constants are read once per workgroup, the tile's words travel as vector loads beside the
-// per-pixel values, and the next tile's loads are issued BEFORE the current tile's per-entry tail waits for its slot
-// atomics - the two round trips overlap.  Per tile: one exposed round trip, three barriers.
+// One workgroup per tile, in tile order (the hardware's dispatcher is the queue).  Round 6 also built the kernel PERSISTENT
+// and queue-fed - one workgroup per resident slot taking tiles from a device queue, longest walk first, launch constants read
+// once, the next tile's loads issued behind the previous tile's deferred tail - in three forms; all three are parity-green and
+// all three are SLOWER than this (profiles/r06_persistent_bwd_ab.txt: 94-107 us against 85 on the headline scene; git
+// e6aa13c has the code).  Why, by the stamps: (1) longest-first co-schedules the heavy tiles, which then share their SIMDs'
+// issue slots and ALL take 60-80 us, while the light tiles that follow leave the SIMDs idle - the mix of a launch in tile
+// order is the better schedule; (2) neighbouring tiles share records and gradient slots in L2: a scrambled order costs 8 us;
+// (3) a workgroup that ends hands its slot to a fresh one while its stores are still in flight, a persistent one waits for
+// them at its next barrier; (4) thirty loaded values cannot stay live across any other code at 96 VGPRs - the allocator
+// answers with scratch - and at 128 VGPRs (four workgroups per CU) the hidden round trip does not pay for the lost wave.
+// What the experiment left in the product kernel: the tile's words as vector loads beside the per-pixel values (as scalar
+// loads they were five serialised waits), the carry masks from a compare instead of sixteen SGPR pairs, the wave maximum
+// without ds_bpermute, the slot stores as GLOBAL stores (they were FLAT ones, counted on lgkmcnt: every LDS wait behind them
+// waited for their acknowledgement), the accumulators cleared by the tail that reads them.
 // ---------------------------------------------------------------------------------------------------------------------
-struct BwdQueue {
-  uint32_t head;     // next ticket (bwd_order_kernel sets it to the launch's workgroup count: ticket b < grid is workgroup b's first tile)
-  uint32_t count;    // tiles in `order`
-  uint32_t pad0, pad1;
-  // uint32_t order[]: (tile row << 16) | tile column, longest walk first
-};
-
 // Everything the prologue of one tile loads: issued in one go, consumed after one wait.
 struct TileLoads {
   uint32_t tmode, r0, r1, tlast;        // the tile's words (same address in every lane)
+  uint32_t fail;                        // the speculation word of the forward (0: lists are what the host assumed)
+  uint4 info;                           // BwdInfo: slot_grads (two words), slots, use_slots
   uint32_t last;                        // per pixel
   float g0, g1, g2, oc0, oc1, oc2, gD;
   int owner;
@@ -333,7 +321,7 @@ struct TileLoads {
 // partials | staging: records -> LDS (gather path: the gather and the quadrant test) | compaction + the barrier before the
 // walk | barrier behind the loop: the tile's slowest quadrant | per-entry tail: moments -> slot store, incl. the barrier
 // behind it) and two marks inside the prologue (unused | every load of the prologue there).
-template <bool STAMP, bool DEFER>
+template <bool STAMP>
 __device__ __forceinline__ void blend_bwd_entry_body(
     const RasterParams& p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, const float* __restrict__ out_color, const uint32_t* __restrict__ n_contrib,
@@ -341,21 +329,12 @@ __device__ __forceinline__ void blend_bwd_entry_body(
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
     SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode,
-    uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long* __restrict__ stamps, const TileCache& tc,
-    BwdQueue* __restrict__ queue) {
+    uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long* __restrict__ stamps, const TileCache& tc) {
   __shared__ float4 s_rec[MB * 3];              // u v ca cb | cc o r g | b id blockmask -
   __shared__ float s_acc[MB * MACC];            // per-entry sums of the tile (LDS float adds: one flush per wave and group)
   __shared__ uint8_t s_sub[4][MB];              // per quadrant: the staged entries that reach it, in list order
-  __shared__ int s_next;                        // the workgroup's next tile (packed), -1: the queue is empty
 
   const int tid = threadIdx.x;
-  const uint32_t* const order = reinterpret_cast<const uint32_t*>(queue + 1);
-  // ---- once per workgroup: the launch's constants, the first tile
-  if (spec_failed(p.spec_fail)) return;
-  const uint32_t n_queued = queue->count;
-  if (blockIdx.x >= n_queued) return;
-  const bool use_slots = info->use_slots != 0;
-  SplatGrad* const slot_grads = info->slot_grads;
   const uint32_t HW = (uint32_t)(p.H * p.W);
 
   // every load of a tile's prologue; the addresses need the tile index only (the TileCache is allocated for every tile, so
@@ -380,6 +359,11 @@ __device__ __forceinline__ void blend_bwd_entry_body(
     const uint2 rg = ranges[tz];
     L.r0 = rg.x; L.r1 = rg.y;
     L.tlast = tile_last[tz];
+    // the launch's words that live in memory travel the same way: as scalar loads each is a dependent round trip in front
+    // of the first vector load.  (Everything this prologue reads exists whether or not the speculation held; the word is
+    // tested before anything is read THROUGH a list.)
+    L.fail = p.spec_fail ? p.spec_fail[tz - tile] : 0u;
+    L.info = reinterpret_cast<const uint4*>(info)[tz - tile];
     L.last = n_contrib[pix];
     L.g0 = dL_dcolor[pix]; L.g1 = dL_dcolor[HW + pix]; L.g2 = dL_dcolor[2 * HW + pix];
     L.oc0 = out_color[pix]; L.oc1 = out_color[HW + pix]; L.oc2 = out_color[2 * HW + pix];
@@ -394,16 +378,19 @@ __device__ __forceinline__ void blend_bwd_entry_body(
     }
   };
 
-  // the accumulators are zero between tiles: the per-entry tail clears what it has read
+  const int cur = (int)((blockIdx.y << 16) | blockIdx.x);
+  unsigned long long st_wall = 0, st_cyc = 0, st_walk = 0, st_groups = 0, st_steps = 0;
+  unsigned long long st_seg[6] = {0, 0, 0, 0, 0, 0}, st_t = 0, st_p2 = 0, st_p1 = 0;
+  if constexpr (STAMP) { st_wall = wall_clock64(); st_cyc = __builtin_readcyclecounter(); }
+  TileLoads L;
+  issue(cur, L);
+  if constexpr (STAMP) st_p1 = __builtin_readcyclecounter() - st_cyc;      // every load of the tile is issued
+  // under the loads' flight: the accumulators start at zero (later batches: the per-entry tail clears what it has read)
   for (int q = tid; q < MB * MACC; q += BLOCK) s_acc[q] = 0.f;
-  int cur = (int)order[blockIdx.x];
-  // The per-entry tail of a tile's LAST batch is DEFERRED: it runs at the top of the next turn, behind the issue of the next
-  // tile's loads - its slot atomics and stores and that tile's load round trip overlap, and no load queues behind the
-  // acknowledgement of a store.  (Issuing the next tile's loads from inside the tail instead keeps thirty values live round
-  // the loop's back edge; the register allocator answers with scratch.)  pend_m entries of s_acc / s_rec wait for it.
-  int pend_m = 0;
-  float pend_cx = 0.f, pend_cy = 0.f;
+  __syncthreads();
 
+  bool use_slots = false;                       // BwdInfo, once its words are here
+  SplatGrad* slot_grads = nullptr;
   // one thread per staged entry: moments -> d(u, v, conic), slot store; the thread clears the sums it has read
   auto entry_tail = [&](int m, float cxT, float cyT) {
     int tt = tid;
@@ -453,27 +440,7 @@ __device__ __forceinline__ void blend_bwd_entry_body(
         if (vals[q] != 0.f) unsafeAtomicAdd(dst + q, vals[q]);
     }
   };
-  __syncthreads();
-
-  for (;;) {
-    unsigned long long st_wall = 0, st_cyc = 0, st_walk = 0, st_groups = 0, st_steps = 0;
-    unsigned long long st_seg[6] = {0, 0, 0, 0, 0, 0}, st_t = 0, st_p2 = 0;
-    if constexpr (STAMP) { st_wall = wall_clock64(); st_cyc = __builtin_readcyclecounter(); }
-    TileLoads L;
-    if constexpr (!DEFER) { if (cur < 0) break; issue(cur, L); }
-    else if (cur >= 0) issue(cur, L);
-    unsigned long long st_p1 = 0;
-    if constexpr (STAMP) st_p1 = __builtin_readcyclecounter() - st_cyc;      // every load of the turn is issued
-    if constexpr (DEFER) {
-      if (pend_m > 0) entry_tail(pend_m, pend_cx, pend_cy);
-      __syncthreads();                                   // the tail has read (and cleared) its LDS: this tile may write it
-    }
-    if (cur < 0) break;
-    if constexpr (STAMP) { st_t = __builtin_readcyclecounter(); st_seg[5] = st_t - st_cyc; }
-    // the workgroup's next ticket: one returning atomic per tile, needed only when this tile's walk is over
-    uint32_t ticket = 0u;
-    if (tid == 0) ticket = atomicAdd(&queue->head, 1u);
-
+  {
     // wave = 8x8 quadrant, step = 2x2 quad s of it, DPP row k = pixel of the quad; THIS lane's own pixel is (quad n, k).
     // (From a laundered thread index, per tile: see issue().)
     int tq = tid;
@@ -493,10 +460,14 @@ __device__ __forceinline__ void blend_bwd_entry_body(
     if constexpr (STAMP) { asm volatile("" ::"s"(tmode)); st_p1 |= (__builtin_readcyclecounter() - st_cyc) << 32; }   // the FIRST load is back
     const uint32_t range_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.r0), range_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.r1);
     const uint32_t tlast = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tlast);
-    // the tile stages no further than its last contributor (0: another walk has this tile - the order kernel queues no such tile)
+    if (__builtin_amdgcn_readfirstlane((int)L.fail) != 0) return;        // the speculative forward's lists were not built: the host redoes the step
+    use_slots = __builtin_amdgcn_readfirstlane((int)L.info.w) != 0;
+    slot_grads = reinterpret_cast<SplatGrad*>(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.info.y) << 32) |
+                                                               (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.info.x));
+    // the tile stages no further than its last contributor (0: another walk has this tile)
     const int nuse = ((tmode & 3u) == 2u) ? min((int)(range_y - range_x), (int)tlast) : 0;
     const bool cached = (tmode & 4u) != 0u && !(dbg & 8u);   // this forward filled the cache for this tile (bit 3: ignore it, A-B / tests)
-    if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); st_p2 = t - st_cyc; st_seg[0] = t - st_t; st_t = t; }
+    if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); st_p2 = t - st_cyc; st_seg[0] = st_p2; st_t = t; }
 
     const float tx0 = (float)(bx * TILE), ty0 = (float)(by * TILE);
     const float cxT = tx0 + 7.5f, cyT = ty0 + 7.5f;     // moments are taken about the tile centre
@@ -580,14 +551,10 @@ __device__ __forceinline__ void blend_bwd_entry_body(
       depth_batch(0, m, L.aux.x, L.aux.y, L.gD, false);
     }
     if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[2] += t - st_t; st_t = t; }
-    int nx_all = -1;
     for (;;) {
       const bool lastb = base + MB >= nuse;
       __syncthreads();                                   // records, sub-lists and depth partials of the batch are in LDS
       if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[3] += t - st_t; st_t = t; }
-      // the next tile of this workgroup: the ticket came back long ago; the load of its queue entry rides under the walk
-      int nxt = -1;
-      if (lastb && tid == 0) nxt = ticket < n_queued ? (int)order[ticket] : -1;
 
       // ---- the wave walks its quadrant's sub-list, 16 entries at a time
       {
@@ -632,20 +599,12 @@ __device__ __forceinline__ void blend_bwd_entry_body(
         }
       }
       if constexpr (STAMP) { st_t = __builtin_readcyclecounter(); st_walk += st_t - w_in; }
-      if (lastb && tid == 0) s_next = nxt;
       __syncthreads();
       if constexpr (STAMP) { const unsigned long long t = __builtin_readcyclecounter(); st_seg[4] += t - st_t; st_t = t; }
 
       if (lastb) {
-        nx_all = s_next;
-        if constexpr (DEFER) {
-          // the tail of the tile's last batch waits for the next turn (see the top of the loop)
-          pend_m = m; pend_cx = cxT; pend_cy = cyT;
-        } else {
-          entry_tail(m, cxT, cyT);
-          __syncthreads();
-          if constexpr (STAMP) { const unsigned long long t2 = __builtin_readcyclecounter(); st_seg[5] += t2 - st_t; st_t = t2; }
-        }
+        entry_tail(m, cxT, cyT);
+        if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t2 = __builtin_readcyclecounter(); st_seg[5] += t2 - st_t; st_t = t2; }
         break;
       }
       entry_tail(m, cxT, cyT);
@@ -666,7 +625,6 @@ __device__ __forceinline__ void blend_bwd_entry_body(
         o[12] = st_p1; o[13] = st_p2;
       }
     }
-    cur = nx_all;
   }
 }
 
@@ -677,100 +635,16 @@ __device__ __forceinline__ void blend_bwd_entry_body(
       const float *__restrict__ dL_ddepth, const uint32_t *__restrict__ gbase, uint32_t *__restrict__ slot_count,                    \
       const BwdInfo *__restrict__ info, SplatGrad *__restrict__ grads, uint8_t *__restrict__ touched,                               \
       const uint32_t *__restrict__ tile_mode, uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long *__restrict__ stamps,       \
-      TileCache tc, BwdQueue *__restrict__ queue
+      TileCache tc
 #define RTGS_BWD_PASS                                                                                                             \
   p, ranges, point_list, splats, out_color, n_contrib, depth_index, depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, \
-      info, grads, touched, tile_mode, t0, tn, dbg, stamps, tc, queue
-// The product kernel, in two forms (rtgs_raster_set_bwd_form / RTGS_BWD_FORM at load time; A-B in profiles/r06_*):
-//   5: five workgroups per CU (96 VGPRs); a tile's loads leave at the top of its turn, its per-entry tail runs in place;
-//   4: four workgroups per CU (128 VGPRs) - room to hold a tile's thirty loaded values across the PREVIOUS tile's deferred tail.
-__global__ void __launch_bounds__(256, 5) blend_bwd_entry_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false, false>(RTGS_BWD_PASS); }
-__global__ void __launch_bounds__(256, 4) blend_bwd_entry_defer_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false, true>(RTGS_BWD_PASS); }
+      info, grads, touched, tile_mode, t0, tn, dbg, stamps, tc
+// the product kernel
+__global__ void __launch_bounds__(256, 5) blend_bwd_entry_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false>(RTGS_BWD_PASS); }
 // the same, leaving per-wave time stamps (tools/bwd_stamps.py)
-__global__ void __launch_bounds__(256, 5) blend_bwd_entry_stamped_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<true, false>(RTGS_BWD_PASS); }
-__global__ void __launch_bounds__(256, 4) blend_bwd_entry_defer_stamped_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<true, true>(RTGS_BWD_PASS); }
+__global__ void __launch_bounds__(256, 5) blend_bwd_entry_stamped_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<true>(RTGS_BWD_PASS); }
 #undef RTGS_BWD_ARGS
 #undef RTGS_BWD_PASS
-
-// The queue of one backward launch: every tile of this list set that the entry-per-lane walk has something to walk in
-// (tile_mode says 2, min(list length, last contributor) > 0), LONGEST WALK FIRST - a counting sort over the walk length in one
-// workgroup (3 225 tiles at 1200x680: ~3 us) - and the ticket counter, armed for a grid of `grid` workgroups.
-constexpr int ORDER_BINS = 1024;          // walk lengths 0 .. 4 095 in steps of 4 (longer: first bin)
-// mode 0: no order (one bin: whatever order the threads arrive in); 1: longest walk first; 2: longest first, INTERLEAVED - the
-// heaviest fifth spread one in five over the whole queue (co-resident heavy tiles share a SIMD's issue slots and all take
-// long; co-resident light tiles leave it idle: profiles/r06_d_*); one_shot: every workgroup takes one tile (head stays
-// beyond the count)
-__global__ void __launch_bounds__(1024) bwd_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_last,
-                                                         const uint32_t* __restrict__ tile_mode, int ntiles, int gx, uint32_t grid,
-                                                         const uint32_t* __restrict__ spec_fail, BwdQueue* __restrict__ queue,
-                                                         int mode, int one_shot) {
-  __shared__ uint32_t s_hist[ORDER_BINS];
-  __shared__ uint32_t s_wsum[16];
-  __shared__ uint32_t s_ord[4096];
-  uint32_t* const order = reinterpret_cast<uint32_t*>(queue + 1);
-  const int tid = threadIdx.x;
-  if (spec_failed(spec_fail)) { if (tid == 0) { queue->head = grid; queue->count = 0u; } return; }
-  s_hist[tid] = 0u;
-  // one pass of loads (a tile per thread and pass, PER passes: 4 096 tiles = 1024 x 1024 pixels; beyond that the image is
-  // taken in further sweeps over the same bins), everything independent issued before the first use
-  constexpr int PER = 4;
-  uint32_t bin[PER];
-  __syncthreads();
-  for (int base = 0; base < ntiles; base += 1024 * PER) {
-    uint32_t tm[PER], tl[PER];
-    uint2 rg[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int t = min(base + j * 1024 + tid, ntiles - 1);
-      tm[j] = tile_mode[t]; rg[j] = ranges[t]; tl[j] = tile_last[t];
-    }
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int t = base + j * 1024 + tid;
-      const uint32_t nuse = (t < ntiles && (tm[j] & 3u) == 2u) ? min(rg[j].y - rg[j].x, tl[j]) : 0u;
-      bin[j] = nuse > 0u ? (mode == 0 ? 0u : (uint32_t)ORDER_BINS - 1u - min(nuse >> 2, (uint32_t)ORDER_BINS - 1u)) : 0xffffffffu;
-      if (nuse > 0u) atomicAdd(&s_hist[bin[j]], 1u);
-    }
-    if (ntiles > 1024 * PER) {
-      // (large images only) the bins of this sweep are not kept: the scatter below recomputes them per sweep
-    }
-  }
-  __syncthreads();
-  // exclusive prefix over the bins (bin 0 = the longest walks)
-  const uint32_t mine = s_hist[tid];
-  uint32_t incl = mine;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if ((tid & 63) >= off) incl += o; }
-  if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
-  __syncthreads();
-  uint32_t before = 0;
-  for (int w = 0; w < (tid >> 6); ++w) before += s_wsum[w];
-  __syncthreads();
-  s_hist[tid] = before + incl - mine;        // the bin's cursor
-  if (tid == 1023) { queue->count = before + incl; queue->head = one_shot ? 0x80000000u : grid; s_wsum[0] = before + incl; }
-  __syncthreads();
-  if (ntiles <= 1024 * PER) {
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int t = j * 1024 + tid;
-      if (bin[j] != 0xffffffffu) s_ord[atomicAdd(&s_hist[bin[j]], 1u)] = ((uint32_t)(t / gx) << 16) | (uint32_t)(t % gx);
-    }
-    __syncthreads();
-    const uint32_t nq = s_wsum[0], nh = mode == 2 ? nq / 5u : 0u;
-    for (uint32_t q = (uint32_t)tid; q < nq; q += 1024u) {
-      uint32_t src = q;
-      if (q < 5u * nh) { const uint32_t j = q / 5u, r = q % 5u; src = r == 0u ? j : nh + 4u * j + r - 1u; }
-      order[q] = s_ord[src];
-    }
-  } else {
-    for (int t = tid; t < ntiles; t += 1024) {
-      if ((tile_mode[t] & 3u) != 2u) continue;
-      const uint2 r = ranges[t];
-      const uint32_t nuse = min(r.y - r.x, tile_last[t]);
-      if (nuse > 0u) order[atomicAdd(&s_hist[mode == 0 ? 0 : ORDER_BINS - 1 - min(nuse >> 2, (uint32_t)ORDER_BINS - 1u)], 1u)] = ((uint32_t)(t / gx) << 16) | (uint32_t)(t % gx);
-    }
-  }
-}
 
 // timing decompositions (tools only; rtgs_raster_set_bwd_debug): bit 0 walk off, bit 1 depth partials off, bit 2 stores off -
 // results are then wrong by construction, so the bits are NOT read from the environment and the tools that set
@@ -780,42 +654,17 @@ static unsigned long long* g_bwd_stamps = nullptr;
 void set_bwd_debug(int bits) { g_bwd_dbg = bits & 15; }
 void set_bwd_stamps(void* dev) { g_bwd_stamps = (unsigned long long*)dev; }
 
-static int g_bwd_form = [] { const char* e = getenv("RTGS_BWD_FORM"); const int v = e ? atoi(e) : 5; return (v == 4 || v == 1) ? v : 5; }();
-static int g_bwd_order = [] { const char* e = getenv("RTGS_BWD_ORDER"); const int v = e ? atoi(e) : 1; return (v >= 0 && v <= 2) ? v : 1; }();
-void set_bwd_form(int form) { g_bwd_form = (form == 4 || form == 1) ? form : 5; }
-// workgroups of a persistent launch: `per` per CU (what the form's __launch_bounds__ and 26.6 KB of LDS give), per device
-static uint32_t persistent_grid(int per) {
-  static int cus_of[16] = {0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16) dev = 0;
-  if (cus_of[dev] == 0) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    cus_of[dev] = cus;
-  }
-  return (uint32_t)(cus_of[dev] * per);
-}
-
 void launch_blend_bwd_entry(const RasterParams& p, const uint2* ranges, const uint32_t* point_list, const Splat* splats,
                             const float* out_color, const uint32_t* n_contrib, const int32_t* depth_index,
                             const uint32_t* depth_pos, const uint32_t* tile_last, const float* dL_dcolor, const float* dL_ddepth,
                             const uint32_t* gbase, uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
-                            const uint32_t* tile_mode, uint32_t t0, uint32_t tn, TileCache tc, void* queue_words, hipStream_t st) {
+                            const uint32_t* tile_mode, uint32_t t0, uint32_t tn, TileCache tc, hipStream_t st) {
   const uint32_t dbg = (uint32_t)g_bwd_dbg;
-  const int ntiles = p.gx * p.gy;
-  const bool defer = g_bwd_form == 4;
-  const bool one_shot = g_bwd_form == 1;             // one tile per workgroup (the hardware's dispatcher is the queue)
-  const uint32_t grid = one_shot ? (uint32_t)ntiles : min(persistent_grid(defer ? 4 : 5), (uint32_t)ntiles);
-  BwdQueue* const queue = (BwdQueue*)queue_words;
-  hipLaunchKernelGGL(bwd_order_kernel, dim3(1), dim3(1024), 0, st, ranges, tile_last, tile_mode, ntiles, p.gx, grid, p.spec_fail, queue,
-                     g_bwd_order, one_shot ? 1 : 0);
 #define RTGS_BWD_LAUNCH(KERNEL)                                                                                                      \
-  hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color, n_contrib, depth_index,       \
+  hipLaunchKernelGGL(KERNEL, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color, n_contrib, depth_index, \
                      depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched, tile_mode, t0, tn, dbg,    \
-                     g_bwd_stamps, tc, queue)
-  if (g_bwd_stamps) { if (defer) RTGS_BWD_LAUNCH(blend_bwd_entry_defer_stamped_kernel); else RTGS_BWD_LAUNCH(blend_bwd_entry_stamped_kernel); }
-  else { if (defer) RTGS_BWD_LAUNCH(blend_bwd_entry_defer_kernel); else RTGS_BWD_LAUNCH(blend_bwd_entry_kernel); }
+                     g_bwd_stamps, tc)
+  if (g_bwd_stamps) RTGS_BWD_LAUNCH(blend_bwd_entry_stamped_kernel); else RTGS_BWD_LAUNCH(blend_bwd_entry_kernel);
 #undef RTGS_BWD_LAUNCH
 }
 

@@ -141,7 +141,7 @@ struct BinLayout {
   size_t slot_grads;                 // backward partial slots (see BwdInfo); 0 slots = not laid out
 };
 struct ImgLayout {
-  size_t ranges, n_contrib, bwd_info, tile_mode, depth_pos, tile_last, tile_recs, tile_masks, depth_aux, tile_order, total;
+  size_t ranges, n_contrib, bwd_info, tile_mode, depth_pos, tile_last, tile_recs, tile_masks, depth_aux, total;
 };
 // What blend_fwd leaves for the entry-per-lane backward at a place that depends on the TILE alone (round 6).  The backward's
 // chain "tile range -> list ids -> record gather -> block test" was three dependent memory round trips and ~150 VALU
@@ -277,6 +277,20 @@ __device__ __forceinline__ uint32_t quads_reached(float u, float v, float hx, fl
 #define RTGS_SH_C3_4 -0.4570457994644658f
 #define RTGS_SH_C3_5 1.445305721320277f
 #define RTGS_SH_C3_6 -0.5900435899266435f
+
+// max over the wave's 64 lanes, in every lane - row swaps and row rotations only: no ds_bpermute, hence none of its six
+// per-lane address registers (which, loop-invariant, are hoisted out of the tile loop and then spilled)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  x = max(r[0], r[1]);
+  const auto q = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  x = max(q[0], q[1]);
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false));    // row_ror:8
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false));    // row_ror:4
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false));    // row_ror:2
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false));    // row_ror:1
+  return x;
+}
 
 // The alpha of one (Gaussian, pixel) pair.  Written with explicit _rn intrinsics so the forward
 // and the backward kernel evaluate bit-identical skip / stop decisions regardless of how the

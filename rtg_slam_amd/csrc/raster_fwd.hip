@@ -306,7 +306,7 @@ constexpr int FWD_CHUNKS = FWD_BATCH / 32;      // 32-entry words of a block's s
 // STAMP (measurement only, tools/fwd_stamps.py): every wave leaves eight 64-bit words - wall clock (100 MHz) at entry and exit,
 // shader cycles until the tile's range is there | until the first batch is staged and its barrier passed | inside the walk
 // loops | in the whole kernel, walk steps taken, batches staged.
-template <int OCC, bool STAMP, int LAYOUT>
+template <int OCC, bool STAMP>
 __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -314,11 +314,12 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     float* __restrict__ out_dw, float* __restrict__ out_T, uint32_t* __restrict__ n_contrib,
     unsigned long long* __restrict__ counters, SlicePass sp, uint32_t* __restrict__ tile_mode,
     uint32_t* __restrict__ depth_pos, uint32_t* __restrict__ tile_last, int walk, uint32_t* __restrict__ aux_zero,
-    TileCache tc, unsigned long long* __restrict__ stamps) {
+    TileCache tc, unsigned long long* __restrict__ stamps, uint32_t seg) {
   __shared__ float4 s_rec[FWD_BATCH * 4];     // u v ca cb | cc o r g | b - - id | nx ny nz pd: the walk reads the first three
-  // LAYOUT 0: entry-major (64 B per entry); 1: four planes of FWD_BATCH float4 (the four rows of a wave read four DIFFERENT
-  // entries per step: entry-major, two entries collide on their banks whenever their indices agree mod 4; plane-major, mod 16)
-#define RI(e, j) (LAYOUT ? (j) * FWD_BATCH + (e) : (e) * 4 + (j))
+  // (entry-major, 64 B per entry.  Four planes of FWD_BATCH float4 - the four rows of a wave read four DIFFERENT entries per
+  // step, and entry-major two of them collide on their banks whenever their indices agree mod 4 - were measured in round 6:
+  // 82.1 / 131.3 us against 80.9 / 131.0.  The walk is not bound by LDS bank conflicts.)
+#define RI(e, j) ((e) * 4 + (j))
   __shared__ float s_z[FWD_BATCH];            // centre depth (opaque-surface test only)
   __shared__ uint32_t s_live[16][FWD_CHUNKS]; // per 4x4 block: the staged entries that reach it
 
@@ -327,11 +328,21 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int tile = blockIdx.y * p.gx + blockIdx.x;
-  if (spec_failed(p.spec_fail)) return;                // lists were not built (speculative sizes did not hold): redone by the host
+  // The words this tile waits for first - its range, the speculation word, its pass-2 mask, and (lists in per-tile segments:
+  // `seg` entries per tile, raster_bin.hip) the ids of its first batch, whose addresses need no range - leave as VECTOR loads
+  // in one go.  As scalar loads each is a wait of its own in front of the next (round 6's stamps: six serialised scalar waits
+  // and the id hop were 5.4 us of a 27-us tile).  `z` is a zero the compiler cannot see.
+  int z = 0;
+  asm volatile("" : "+v"(z));
+  const uint2 range_v = ranges[tile + z];
+  const uint32_t fail_v = p.spec_fail ? p.spec_fail[z] : 0u;
+  const int32_t m2_v = sp.mode == 2 ? sp.mask2[tile + z] : 1;
+  const int32_t on_v = sp.mode == 1 ? sp.user_mask[tile + z] : 1;
+  uint32_t id_first = 0u;
+  if (seg != 0u) id_first = point_list[(size_t)tile * seg + (size_t)tid];     // (inside the tile's segment whatever its count)
   // eight words a later kernel of the caller's step accumulates into (the loss sums of rtgs_slam_map_step): cleared here,
   // stream-ordered before that kernel, instead of by a memset launch of their own
   if (aux_zero && blockIdx.x == 0 && blockIdx.y == 0 && tid < 8) aux_zero[tid] = 0u;
-  if (sp.mode == 2 && sp.mask2[tile] == 0) return;     // finished by the near slice (or masked off): outputs stay
   // wave = 8x8 quadrant, DPP row = 4x4 block, lane = pixel of the block
   const int bx = ((wv & 1) << 1) | ((lane >> 4) & 1), by = (wv & 2) | (lane >> 5);
   const int blk = by * 4 + bx;
@@ -341,10 +352,12 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
   const bool inside = px < p.W && py < p.H;
   const float pxf = (float)px, pyf = (float)py;
   const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
-  const uint2 range = ranges[tile];
+  if (__builtin_amdgcn_readfirstlane((int)fail_v) != 0) return;   // lists were not built (speculative sizes did not hold): redone by the host
+  if (__builtin_amdgcn_readfirstlane(m2_v) == 0) return;          // finished by the near slice (or masked off): outputs stay
+  const uint2 range = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.y));
   int n = (int)(range.y - range.x);
   if (sp.mode == 1 && n > SLICE_MAX_LIST) n = 0;       // near-slice list too long to have been sorted: leave the tile to pass 2
-  if constexpr (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_range = __builtin_readcyclecounter() - st_cyc; }
+  if constexpr (STAMP) { st_range = __builtin_readcyclecounter() - st_cyc; }
 
   bool done = !inside;
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
@@ -361,12 +374,12 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
   // per entry) is not paid for entries no pixel will reach.  Batching does not change a result.
   int bs = sp.mode == 1 ? FWD_BATCH / 4 : FWD_BATCH;
   for (int base = 0; base < n; base += bs, bs = FWD_BATCH) {
-    if (__syncthreads_and(done)) break;
+    if (base > 0 && __syncthreads_and(done)) break;      // (nothing is done before the first batch; wave-uniform condition)
     const int m = min(bs, n - base);
     {
       uint32_t reach = 0;
       if (tid < m) {
-        const uint32_t id = point_list[range.x + base + tid];
+        const uint32_t id = (seg != 0u && base == 0) ? id_first : point_list[range.x + base + tid];
         const float4* src = reinterpret_cast<const float4*>(splats + id);
         const float4 q0 = src[0];
         s_rec[RI(tid, 0)] = q0;
@@ -454,13 +467,24 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     if constexpr (STAMP) st_walk += __builtin_readcyclecounter() - w_in;
   }
 
+  // ---- epilogue: ONE barrier.  Every wave leaves four words - (block, entry) pairs of its sub-lists, entries it staged, its last
+  // contributor, whether all its pixels have stopped - and every thread reads the sixteen.
+  __shared__ uint32_t s_ep[4][4];
+  {
+    const uint32_t wl = wave_max_u32(last_contributor);
+    const bool wave_done = __builtin_amdgcn_ballot_w64(done) == ~0ull;
+    if (lane == 0) { s_ep[wv][0] = reach_sum; s_ep[wv][1] = staged; s_ep[wv][2] = wl; s_ep[wv][3] = wave_done ? 1u : 0u; }
+  }
+  __syncthreads();
+  const uint32_t reach_all = s_ep[0][0] + s_ep[1][0] + s_ep[2][0] + s_ep[3][0], staged_all = s_ep[0][1] + s_ep[1][1] + s_ep[2][1] + s_ep[3][1];
+  const uint32_t tl_all = max(max(s_ep[0][2], s_ep[1][2]), max(s_ep[2][2], s_ep[3][2]));
   bool write_out = true;
   if (sp.mode == 1) {
     // A tile whose every pixel stopped inside the near slice is final: the slice's list is a prefix of the tile's full
     // list (depth bins are monotone in depth), so nothing behind it would have been read.  Anything else is redone
     // from scratch by pass 2 (which overwrites every output of the tile: nothing is written for it here).
-    const bool finished = __syncthreads_and(done) != 0;
-    const bool on = sp.user_mask[tile] != 0;
+    const bool finished = (s_ep[0][3] & s_ep[1][3] & s_ep[2][3] & s_ep[3][3]) != 0u;
+    const bool on = __builtin_amdgcn_readfirstlane(on_v) != 0;
     if (tid == 0) {
       sp.mask2[tile] = (on && !finished) ? 1 : 0;
       sp.ranges_bwd[tile] = finished ? range : make_uint2(0u, 0u);
@@ -485,29 +509,18 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     depth_pos[pix] = d_pos;
     if (tc.depth_aux != nullptr) tc.depth_aux[pix] = make_float2(d_iden, D);
   }
-  {
+  if (tid == 0 && write_out) {
     // For the backward: which walk the tile takes (raster_bwd.hip) - row-granular when its 4x4 blocks need, on average,
     // less than ROWS_MAX_SHARE of the entries staged, measured here on the sub-lists themselves, no heuristic about the
     // scene - and the tile's last contributor (the backward stages no further; it would otherwise have to reduce
-    // n_contrib over the tile before it can issue its first gather).
-    __shared__ uint32_t s_share[2];
-    __shared__ unsigned int s_tl;
-    if (tid == 0) { s_share[0] = 0u; s_share[1] = 0u; s_tl = 0u; }
-    __syncthreads();
-    uint32_t wl = last_contributor;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, off));
-    if (lane == 0) { atomicAdd(&s_share[0], reach_sum); atomicAdd(&s_share[1], staged); atomicMax(&s_tl, wl); }
-    __syncthreads();
-    if (tid == 0 && write_out) {
-      // bits 0..1 = the walk; bits 8.. = the measured share in 1/1000 (diagnostics)
-      const float share = s_share[1] ? (float)s_share[0] / (16.f * (float)s_share[1]) : 1.f;
-      // walk < 0: the choice between the two pixel-per-lane walks from the share; else the walk the context asks for
-      // bit 2: this forward left the tile's records / masks / plane words in the TileCache
-      tile_mode[tile] = (walk >= 0 ? (uint32_t)walk : (share < ROWS_MAX_SHARE ? 1u : 0u)) | (tc.recs != nullptr ? 4u : 0u) |
-                        ((uint32_t)(share * 1000.f) << 8);
-      tile_last[tile] = s_tl;
-    }
+    // n_contrib over the tile before it can issue its first load).
+    // bits 0..1 = the walk; bit 2: this forward left the tile's records / masks / plane words in the TileCache; bits 8.. =
+    // the measured share in 1/1000 (diagnostics).  walk < 0: the choice between the two pixel-per-lane walks from the
+    // share; else the walk the context asks for
+    const float share = staged_all ? (float)reach_all / (16.f * (float)staged_all) : 1.f;
+    tile_mode[tile] = (walk >= 0 ? (uint32_t)walk : (share < ROWS_MAX_SHARE ? 1u : 0u)) | (tc.recs != nullptr ? 4u : 0u) |
+                      ((uint32_t)(share * 1000.f) << 8);
+    tile_last[tile] = tl_all;
   }
   if (counters) {
     // work accounting for the roofline: entries any pixel of this tile consumed, and
@@ -539,7 +552,6 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
 
 
 static int g_f1_occ = [] { const char* e = getenv("RTGS_F1_OCC"); const int v = e ? atoi(e) : 6; return (v == 5 || v == 7 || v == 8) ? v : 6; }();
-static int g_f1_layout = [] { const char* e = getenv("RTGS_F1_LAYOUT"); return e ? atoi(e) : 0; }();
 static unsigned long long* g_fwd_stamps = nullptr;   // measurement only (rtgs_raster_set_fwd_stamps)
 void set_fwd_stamps(void* dev) { g_fwd_stamps = (unsigned long long*)dev; }
 
@@ -626,13 +638,12 @@ void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t
                       float* out_color, float* out_depth, int32_t* out_cidx, int32_t* out_didx, float* out_cw,
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
                       SlicePass sp, uint32_t* tile_mode, uint32_t* depth_pos, uint32_t* tile_last, int walk, uint32_t* aux_zero,
-                      TileCache tc, hipStream_t st) {
-#define RTGS_FWD1(OCC, STAMP, LAYOUT) hipLaunchKernelGGL((blend_fwd_kernel<OCC, STAMP, LAYOUT>), dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, \
+                      TileCache tc, uint32_t seg, hipStream_t st) {
+#define RTGS_FWD1(OCC, STAMP) hipLaunchKernelGGL((blend_fwd_kernel<OCC, STAMP>), dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, \
                        out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp, tile_mode, \
-                       depth_pos, tile_last, walk, aux_zero, tc, g_fwd_stamps)
-  if (g_fwd_stamps) { if (g_f1_layout) RTGS_FWD1(6, true, 1); else RTGS_FWD1(6, true, 0); }
-  else if (g_f1_layout) { if (g_f1_occ == 8) RTGS_FWD1(8, false, 1); else if (g_f1_occ == 5) RTGS_FWD1(5, false, 1); else RTGS_FWD1(6, false, 1); }
-  else if (g_f1_occ == 8) RTGS_FWD1(8, false, 0); else if (g_f1_occ == 7) RTGS_FWD1(7, false, 0); else if (g_f1_occ == 5) RTGS_FWD1(5, false, 0); else RTGS_FWD1(6, false, 0);
+                       depth_pos, tile_last, walk, aux_zero, tc, g_fwd_stamps, seg)
+  if (g_fwd_stamps) RTGS_FWD1(6, true);
+  else if (g_f1_occ == 8) RTGS_FWD1(8, false); else if (g_f1_occ == 7) RTGS_FWD1(7, false); else if (g_f1_occ == 5) RTGS_FWD1(5, false); else RTGS_FWD1(6, false);
 #undef RTGS_FWD1
 }
 
