@@ -760,8 +760,11 @@ void launch_slice_compact(int P, SliceSel sel, uint32_t* ids, uint32_t* n_list, 
 // Every visible Gaussian (zbin != 255), compacted into a work list: when the near slice is declined and the host knows
 // it, the single pass that follows shades / counts / scatters through this list with dense lanes instead of sweeping
 // all P Gaussians with one lane in six active (a surface map shows ~18 % of its Gaussians to a view).
-constexpr int VIS_CHUNK = 8192;      // ids per workgroup: few workgroups - each ends in ONE same-address atomic (~25 ns, serialised)
-__global__ void __launch_bounds__(256) visible_compact_kernel(int P, const uint8_t* __restrict__ zbin, uint32_t* __restrict__ ids,
+constexpr int VIS_CHUNK = 8192;      // ids per workgroup at most: few workgroups - each ends in ONE same-address atomic (~25 ns, serialised)
+// `chunk` (a multiple of 1024, <= VIS_CHUNK) is chosen per launch: at SLAM sizes (100-300 k Gaussians) 8192 ids per workgroup
+// left 12-36 workgroups on 256 CUs, each a serial chain of 8 ballot rounds and 32 scan rounds - 29.5 us per call, 22 000 calls in
+// the 2 000-frame sequence (profiles/r06_sequence_*): the third-largest kernel of a SLAM frame
+__global__ void __launch_bounds__(256) visible_compact_kernel(int P, int chunk, const uint8_t* __restrict__ zbin, uint32_t* __restrict__ ids,
                                                               uint32_t* __restrict__ n_list,
                                                               const uint32_t* __restrict__ rect_area,
                                                               uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_cursor,
@@ -772,8 +775,8 @@ __global__ void __launch_bounds__(256) visible_compact_kernel(int P, const uint8
   if (threadIdx.x == 0) { s_n = 0; s_tot = 0; s_run = 0; }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int begin = blockIdx.x * VIS_CHUNK;
-  for (int i0 = begin; i0 < begin + VIS_CHUNK && i0 < P; i0 += 256 * 4) {
+  const int begin = blockIdx.x * chunk;
+  for (int i0 = begin; i0 < begin + chunk && i0 < P; i0 += 256 * 4) {
     const int i = i0 + (int)threadIdx.x * 4;
     uint32_t zb4 = 0xffffffffu;
     if (i + 4 <= P) zb4 = *reinterpret_cast<const uint32_t*>(zbin + i);
@@ -832,7 +835,10 @@ __global__ void __launch_bounds__(256) visible_compact_kernel(int P, const uint8
 void launch_visible_compact(int P, const uint8_t* zbin, uint32_t* ids, uint32_t* n_list, const uint32_t* rect_area,
                             uint32_t* gbase, uint32_t* slot_cursor, const uint32_t* spec_fail, hipStream_t st) {
   if (P == 0) return;
-  hipLaunchKernelGGL(visible_compact_kernel, dim3((P + VIS_CHUNK - 1) / VIS_CHUNK), dim3(256), 0, st, P, zbin, ids, n_list,
+  // ~192+ workgroups below a million Gaussians, VIS_CHUNK ids each above
+  int chunk = VIS_CHUNK;
+  if (P < 1000000) { chunk = ((P / 192 + 1023) / 1024) * 1024; chunk = chunk < 1024 ? 1024 : (chunk > VIS_CHUNK ? VIS_CHUNK : chunk); }
+  hipLaunchKernelGGL(visible_compact_kernel, dim3((P + chunk - 1) / chunk), dim3(256), 0, st, P, chunk, zbin, ids, n_list,
                      rect_area, gbase, slot_cursor, spec_fail);
 }
 

@@ -306,7 +306,10 @@ constexpr int FWD_CHUNKS = FWD_BATCH / 32;      // 32-entry words of a block's s
 // STAMP (measurement only, tools/fwd_stamps.py): every wave leaves eight 64-bit words - wall clock (100 MHz) at entry and exit,
 // shader cycles until the tile's range is there | until the first batch is staged and its barrier passed | inside the walk
 // loops | in the whole kernel, walk steps taken, batches staged.
-template <int OCC, bool STAMP>
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+template <int OCC, bool STAMP, bool COUNT, bool ASMW>
 __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     RasterParams p, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const Splat* __restrict__ splats, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -348,7 +351,6 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
   const int blk = by * 4 + bx;
   const int px = blockIdx.x * TILE + bx * 4 + (lane & 3);
   const int py = blockIdx.y * TILE + by * 4 + ((lane >> 2) & 3);
-  const int rsh = lane & 48;                            // first lane of this lane's row
   const bool inside = px < p.W && py < p.H;
   const float pxf = (float)px, pyf = (float)py;
   const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
@@ -360,6 +362,8 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
   if constexpr (STAMP) { st_range = __builtin_readcyclecounter() - st_cyc; }
 
   bool done = !inside;
+  unsigned long long Dm = __builtin_amdgcn_ballot_w64(!inside);     // ASMW: the wave's stopped pixels as a mask in SGPRs
+  unsigned long long evals_w = 0;                                     // ASMW + COUNT: wave-uniform
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   float best_w = 0.f; int best_id = -1;
   float D = 0.f, d_w = 0.f; int d_id = -1;
@@ -374,7 +378,7 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
   // per entry) is not paid for entries no pixel will reach.  Batching does not change a result.
   int bs = sp.mode == 1 ? FWD_BATCH / 4 : FWD_BATCH;
   for (int base = 0; base < n; base += bs, bs = FWD_BATCH) {
-    if (base > 0 && __syncthreads_and(done)) break;      // (nothing is done before the first batch; wave-uniform condition)
+    if (base > 0 && __syncthreads_and(ASMW ? (Dm == ~0ull) : done)) break;      // (nothing is done before the first batch; wave-uniform condition)
     const int m = min(bs, n - base);
     {
       uint32_t reach = 0;
@@ -417,13 +421,120 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     const int nch = (m + 31) >> 5;
     int c = -1;
     uint32_t cur = 0u;                               // row-uniform: the unread part of the current word of the sub-list
+    if constexpr (ASMW) {
+      // The step, hand-scheduled (round 6).  The compiler's form of the loop below is 86 instructions per step on the common
+      // path - every ballot as v_cndmask + v_cmp, every "contrib ? x : y" as a select, masks shuffled between SGPR pairs - and
+      // the walk is bound by instruction issue (profiles/r05_valu_rate.txt).  Here the lanes that have an entry ARE the exec
+      // mask: the two tests narrow it (v_cmpx), the stop test splits it, and what is left updates T / C / best with plain
+      // instructions.  ~45 instructions per step.  Same arithmetic in the same order: outputs are bit-identical.
+      uint32_t rec_base = (uint32_t)(uintptr_t)&s_rec[0];
+      uint32_t base1 = (uint32_t)base + 1u;
+      float thr = p.T_thr, opq = p.opaque_thr;
+      // (opaque to the compiler: as kernel arguments it RELOADS them inside the loop - an s_load and a wait for everything in
+      // flight, the step's LDS reads included - rather than hold four more SGPRs)
+      asm volatile("" : "+s"(rec_base), "+s"(base1), "+s"(thr), "+s"(opq));
+      for (;;) {
+        while (cur == 0u && c + 1 < nch) { ++c; cur = s_live[blk][c]; }
+        const unsigned long long H = __builtin_amdgcn_ballot_w64(cur != 0u) & ~Dm;     // a lane walks on while ITS pixel is open and its row has entries
+        if (H == 0ull) break;
+        if constexpr (STAMP) st_steps += 1;
+        if constexpr (COUNT) evals_w += (unsigned long long)__popcll(H);
+        unsigned long long sv, WD;
+        uint32_t e, addr;
+        f4v q0, q1;
+        f2v q2;
+        float al, dx, dy, t1, t2, pw, tT, w;
+        // the entry's record: every lane reads (a stopped pixel reads what its row reads - one broadcast; a row without an
+        // entry reads slot 255 and ignores it).  Outputs of one statement, inputs of the next: the compiler hands the
+        // sub-registers of the tuples over as they are.
+        asm volatile(
+            "v_ffbl_b32 %[e], %[cur]\n\t"
+            "v_lshl_or_b32 %[e], %[c], 5, %[e]\n\t"
+            "v_and_b32 %[e], 0xff, %[e]\n\t"
+            "v_lshl_add_u32 %[addr], %[e], 6, %[rb]\n\t"
+            "ds_read_b128 %[q0], %[addr]\n\t"
+            "ds_read_b128 %[q1], %[addr] offset:16\n\t"
+            "ds_read2_b32 %[q2], %[addr] offset0:8 offset1:11\n\t"
+            : [e] "=&v"(e), [addr] "=&v"(addr), [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2)
+            : [cur] "v"(cur), [c] "v"(c), [rb] "s"(rec_base));
+        cur &= cur - 1u;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_mov_b64 exec, %[H]\n\t"
+            "s_mov_b64 %[WD], 0\n\t"
+            "s_waitcnt lgkmcnt(2)\n\t"
+            "v_sub_f32 %[dx], %[u], %[px]\n\t"
+            "v_sub_f32 %[dy], %[v], %[py]\n\t"
+            "v_mul_f32 %[t1], %[ca], %[dx]\n\t"
+            "v_mul_f32 %[t2], %[cb], %[dx]\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_mul_f32 %[pw], %[cc], %[dy]\n\t"
+            "v_mul_f32 %[pw], %[pw], %[dy]\n\t"
+            "v_fma_f32 %[t1], %[t1], %[dx], %[pw]\n\t"
+            "v_mul_f32 %[t2], %[t2], %[dy]\n\t"
+            "v_fma_f32 %[pw], -0.5, %[t1], -%[t2]\n\t"
+            "v_min_f32 %[t1], 0, %[pw]\n\t"
+            "v_mul_f32 %[t1], 0x3fb8aa3b, %[t1]\n\t"
+            "v_exp_f32 %[t1], %[t1]\n\t"
+            "v_cmpx_nlt_f32 vcc, 0, %[pw]\n\t"                   // exec: !(power > 0)
+            "s_nop 0\n\t"
+            "v_mul_f32 %[al], %[o], %[t1]\n\t"
+            "v_min_f32 %[al], 0x3f7d70a4, %[al]\n\t"
+            "v_cmpx_ngt_f32 vcc, 0x3b808081, %[al]\n\t"          // exec: !(alpha < 1/255)
+            "v_sub_f32 %[t2], 1.0, %[al]\n\t"
+            "v_mul_f32 %[tT], %[T], %[t2]\n\t"
+            "v_cmp_gt_f32 vcc, %[thr], %[tT]\n\t"                // the pixel stops in front of this entry
+            "s_or_b64 %[D], %[D], vcc\n\t"
+            "s_andn2_b64 exec, exec, vcc\n\t"                   // exec: the contributing lanes
+            "s_cbranch_scc0 1f\n\t"
+            "v_mul_f32 %[w], %[al], %[T]\n\t"
+            "v_mov_b32 %[T], %[tT]\n\t"
+            "v_add_u32 %[last], %[base1], %[e]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_fmac_f32 %[C0], %[r], %[w]\n\t"
+            "v_fmac_f32 %[C1], %[g], %[w]\n\t"
+            "v_fmac_f32 %[C2], %[b], %[w]\n\t"
+            "v_cmp_gt_f32 vcc, %[w], %[bw]\n\t"
+            "v_cndmask_b32 %[bw], %[bw], %[w], vcc\n\t"
+            "v_cndmask_b32 %[bid], %[bid], %[id], vcc\n\t"
+            "v_cmp_gt_i32 vcc, 0, %[did]\n\t"                    // no depth owner yet ...
+            "v_cmp_lt_f32 %[WD], %[opq], %[al]\n\t"              // ... and this entry is opaque enough to be one
+            "s_and_b64 %[WD], %[WD], vcc\n\t"
+            "1:\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            : [sv] "=&s"(sv), [WD] "=&s"(WD), [D] "+s"(Dm), [al] "=&v"(al), [dx] "=&v"(dx), [dy] "=&v"(dy), [t1] "=&v"(t1),
+              [t2] "=&v"(t2), [pw] "=&v"(pw), [tT] "=&v"(tT), [w] "=&v"(w), [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2),
+              [bw] "+v"(best_w), [bid] "+v"(best_id), [last] "+v"(last_contributor)
+            : [H] "s"(H), [px] "v"(pxf), [py] "v"(pyf), [thr] "s"(thr), [opq] "s"(opq), [base1] "s"(base1), [did] "v"(d_id), [e] "v"(e),
+              [u] "v"(q0.x), [v] "v"(q0.y), [ca] "v"(q0.z), [cb] "v"(q0.w), [cc] "v"(q1.x), [o] "v"(q1.y), [r] "v"(q1.z),
+              [g] "v"(q1.w), [b] "v"(q2.x), [id] "v"(q2.y)
+            : "vcc", "scc");
+        if (WD != 0ull) {                                          // rare: opaque-surface depth candidates
+          unsigned long long mine;                                 // (inside the branch and opaque: the test stays a SCALAR branch)
+          asm volatile("v_lshrrev_b64 %[t], %[l], %[m]" : [t] "=v"(mine) : [l] "v"(lane), [m] "s"(WD));
+          if ((uint32_t)mine & 1u) {
+            const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
+            const float rnorm = sqrtf(rx * rx + ry * ry + 1.f);
+            const float4 r3 = s_rec[RI(e, 3)];    // nx ny nz pd
+            const float den = r3.x * rx + r3.y * ry + r3.z;
+            if (fabsf(den) / rnorm > p.normal_thr) {
+              const float zhit = r3.w / den;
+              if (zhit > 0.f && fabsf(zhit - s_z[e]) < p.depth_thr) {
+                D = zhit; d_w = al; d_id = (int)__float_as_uint(q2.y); d_pos = (uint32_t)base + e; d_iden = 1.f / den;
+              }
+            }
+          }
+        }
+      }
+    } else
     for (;;) {
       while (cur == 0u && c + 1 < nch) { ++c; cur = s_live[blk][c]; }
-      const unsigned long long am = __builtin_amdgcn_ballot_w64(!done);
-      const bool row_alive = (uint32_t)((am >> rsh) & 0xffffull) != 0u;
-      const bool has = cur != 0u && row_alive;
-      if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;     // every row of the wave is through its sub-list (or finished)
-      const int e = has ? (c << 5) + __builtin_ctz(cur) : 0;
+      // a lane walks on while ITS pixel is open and its row's sub-list has entries (a row whose pixels have all stopped drops
+      // out of the loop condition by itself: no per-row "anyone alive" test)
+      const bool has = cur != 0u && !done;
+      if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;     // every pixel of the wave is through its row's sub-list (or finished)
+      const int e = has ? (c << 5) + __builtin_ctz(cur) : 0;   // (a lane without an entry reads slot 0 - a STAGED record: its finite values times w = 0 leave the sums alone)
       cur &= cur - 1u;
       if constexpr (STAMP) st_steps += 1;
       const float4 r0 = s_rec[RI(e, 0)];        // u v ca cb
@@ -432,11 +543,11 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = splat_power(r0.z, r0.w, r1.x, dx, dy);
       const float al = fminf(0.99f, r1.y * splat_exp(fminf(power, 0.f)));
-      const bool ok = has && !done && !(power > 0.f) && !(al < 1.f / 255.f);
+      const bool ok = has && !(power > 0.f) && !(al < 1.f / 255.f);
       const float test_T = T * (1.f - al);
       const bool stop = ok && (test_T < p.T_thr);
       const bool contrib = ok && !stop;
-      evals += (has && !done) ? 1u : 0u;
+      if constexpr (COUNT) evals += has ? 1u : 0u;
       done = done || stop;
       const float w = contrib ? al * T : 0.f;
       T = contrib ? test_T : T;
@@ -472,7 +583,7 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
   __shared__ uint32_t s_ep[4][4];
   {
     const uint32_t wl = wave_max_u32(last_contributor);
-    const bool wave_done = __builtin_amdgcn_ballot_w64(done) == ~0ull;
+    const bool wave_done = ASMW ? (Dm == ~0ull) : (__builtin_amdgcn_ballot_w64(done) == ~0ull);
     if (lane == 0) { s_ep[wv][0] = reach_sum; s_ep[wv][1] = staged; s_ep[wv][2] = wl; s_ep[wv][3] = wave_done ? 1u : 0u; }
   }
   __syncthreads();
@@ -522,7 +633,7 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
                       ((uint32_t)(share * 1000.f) << 8);
     tile_last[tile] = tl_all;
   }
-  if (counters) {
+  if (COUNT && counters) {
     // work accounting for the roofline: entries any pixel of this tile consumed, and
     // (entry, pixel) pairs evaluated
     __shared__ unsigned int s_max;
@@ -530,7 +641,8 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
     if (tid == 0) { s_max = 0; s_ev = 0; }
     __syncthreads();
     atomicMax(&s_max, last_contributor);
-    atomicAdd(&s_ev, (unsigned long long)evals);
+    if constexpr (ASMW) { if (lane == 0) atomicAdd(&s_ev, evals_w); }
+    else atomicAdd(&s_ev, (unsigned long long)evals);
     __syncthreads();
     // one slot pair per tile, plain stores (3 225 same-address atomics cost ~80 us - more than the kernel itself);
     // the second pass of a two-pass forward adds to what the first wrote for the tile
@@ -552,6 +664,7 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
 
 
 static int g_f1_occ = [] { const char* e = getenv("RTGS_F1_OCC"); const int v = e ? atoi(e) : 6; return (v == 5 || v == 7 || v == 8) ? v : 6; }();
+static int g_f1_asm = [] { const char* e = getenv("RTGS_F1_ASM"); return e ? atoi(e) : 1; }();
 static unsigned long long* g_fwd_stamps = nullptr;   // measurement only (rtgs_raster_set_fwd_stamps)
 void set_fwd_stamps(void* dev) { g_fwd_stamps = (unsigned long long*)dev; }
 
@@ -639,11 +752,13 @@ void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t
                       float* out_dw, float* out_T, uint32_t* n_contrib, unsigned long long* counters,
                       SlicePass sp, uint32_t* tile_mode, uint32_t* depth_pos, uint32_t* tile_last, int walk, uint32_t* aux_zero,
                       TileCache tc, uint32_t seg, hipStream_t st) {
-#define RTGS_FWD1(OCC, STAMP) hipLaunchKernelGGL((blend_fwd_kernel<OCC, STAMP>), dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, \
+#define RTGS_FWD1(OCC, STAMP, COUNT, ASMW) hipLaunchKernelGGL((blend_fwd_kernel<OCC, STAMP, COUNT, ASMW>), dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, \
                        out_color, out_depth, out_cidx, out_didx, out_cw, out_dw, out_T, n_contrib, counters, sp, tile_mode, \
                        depth_pos, tile_last, walk, aux_zero, tc, g_fwd_stamps, seg)
-  if (g_fwd_stamps) RTGS_FWD1(6, true);
-  else if (g_f1_occ == 8) RTGS_FWD1(8, false); else if (g_f1_occ == 7) RTGS_FWD1(7, false); else if (g_f1_occ == 5) RTGS_FWD1(5, false); else RTGS_FWD1(6, false);
+  if (g_f1_asm == 0) RTGS_FWD1(6, false, true, false);      // the compiler's walk loop (A-B, tests): RTGS_F1_ASM=0
+  else if (counters) RTGS_FWD1(6, false, true, true);        // work counters asked for (bench.py's roofline, tests): the accounting variant
+  else if (g_fwd_stamps) RTGS_FWD1(6, true, false, true);
+  else if (g_f1_occ == 8) RTGS_FWD1(8, false, false, true); else if (g_f1_occ == 7) RTGS_FWD1(7, false, false, true); else if (g_f1_occ == 5) RTGS_FWD1(5, false, false, true); else RTGS_FWD1(6, false, false, true);
 #undef RTGS_FWD1
 }
 

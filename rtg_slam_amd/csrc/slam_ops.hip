@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(1024) tile_topk_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ 3-NN search
-constexpr int KNN_BOX = 1024;
+constexpr int KNN_BOX = 1024;      // sorted points per AABB: the all-against-all search (rtgs_knn3)
+constexpr int KNN_QBOX = 256;      // ... the cross-set query (rtgs_knn3_query): boxes are pre-tested 64 at a time, so small ones cost little to skip
 
 __global__ void __launch_bounds__(256) fill_f32_kernel(float* __restrict__ out, int n, float v) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -193,11 +194,11 @@ __global__ void __launch_bounds__(256) knn_morton_kernel(const float* __restrict
 
 // points gathered into Morton order as float4 (w unused) + the AABB of every run of KNN_BOX sorted points
 __global__ void __launch_bounds__(256) knn_gather_kernel(const float* __restrict__ pts, int N, const uint32_t* __restrict__ order,
-                                                         float4* __restrict__ sorted, float* __restrict__ boxes) {
+                                                         float4* __restrict__ sorted, float* __restrict__ boxes, int box) {
   const int b = blockIdx.x;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int q = threadIdx.x; q < KNN_BOX; q += 256) {
-    const int i = b * KNN_BOX + q;
+  for (int q = threadIdx.x; q < box; q += 256) {
+    const int i = b * box + q;
     if (i < N) {
       const uint32_t o = order[i];
       const float x = pts[(size_t)o * 3], y = pts[(size_t)o * 3 + 1], z = pts[(size_t)o * 3 + 2];
@@ -348,40 +349,79 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
       const float4 s = sorted[j];
       if (__float_as_int(s.w) != self && inbox(s)) knn_insert(dist2(p, s), j, bd, bj);
     }
-    home = lo / KNN_BOX;
+    home = lo / KNN_QBOX;
   }
-  // boxes are visited outward from the box the wave's first query falls into: Morton neighbours are near in space, so the
-  // bound tightens before the far boxes are tested
+  // Boxes are visited outward from the box the wave's first query falls into (Morton neighbours are near in space, so the
+  // bound tightens before the far boxes are tested) - SIXTY-FOUR AT A TIME (round 6): lane l tests box c * 64 + l against the
+  // bounding box of the wave's queries and the loosest bound any of its lanes holds - a conservative form of every lane's own
+  // test - and only the boxes that pass are looked at by the lanes themselves.  Before, a wave walked all boxes one by one with
+  // a scalar load and its wait per box: 286 dependent round trips per wave on the 290 k references of a grown SLAM map were
+  // most of the kernel's 384 us (profiles/r06_sequence_*; the kernel is a handful of waves there, i.e. pure latency).
   const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
   const int b0 = lv ? min(nboxes - 1, __builtin_amdgcn_readlane(home, __builtin_ctzll(lv))) : 0;
-  for (int step = 0; step < 2 * nboxes; ++step) {
+  float wlo[3], whi[3];
+  {
+    const float q3[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float a = live ? q3[c] : FLT_MAX, b = live ? q3[c] : -FLT_MAX;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { a = fminf(a, __shfl_xor(a, off)); b = fmaxf(b, __shfl_xor(b, off)); }
+      wlo[c] = a; whi[c] = b;
+    }
+  }
+  const int nchunks = (nboxes + 63) >> 6, c0 = b0 >> 6;
+  for (int step = 0; step < 2 * nchunks; ++step) {
     const int d = (step + 1) >> 1;
-    const int b = (step & 1) ? b0 - d : b0 + d;                 // b0, b0 - 1, b0 + 1, b0 - 2, ...
-    if (b < 0 || b >= nboxes) continue;
-    const float* bx = boxes + b * 6;
-    const float ex = fmaxf(0.f, fmaxf(bx[0] - p.x, p.x - bx[3]));
-    const float ey = fmaxf(0.f, fmaxf(bx[1] - p.y, p.y - bx[4]));
-    const float ez = fmaxf(0.f, fmaxf(bx[2] - p.z, p.z - bx[5]));
-    const float lower = ((ex * ex + ey * ey) + ez * ez) * 0.9999f;
-    // a run of references entirely outside the filter box holds nothing to find
-    const bool outside = bx[3] <= blo[0] || bx[4] <= blo[1] || bx[5] <= blo[2] || bx[0] >= bhi[0] || bx[1] >= bhi[1] || bx[2] >= bhi[2];
-    const bool open = live && !outside && lower < bd[2];
-    if (__builtin_amdgcn_ballot_w64(open) == 0ull) continue;
-    const int j0 = b * KNN_BOX, j1 = min(N, j0 + KNN_BOX);
-    float4 nxt = (j0 + lane < j1) ? sorted[j0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t0 = j0; t0 < j1; t0 += 64) {
-      __builtin_amdgcn_wave_barrier();                          // the previous tile is read
-      s_tile[wv][lane] = nxt;
-      __builtin_amdgcn_wave_barrier();
-      if (t0 + 64 + lane < j1) nxt = sorted[t0 + 64 + lane];    // in flight during the compares below
-      if (open) {
-        const int n = min(64, j1 - t0);
+    const int ck = (step & 1) ? c0 - d : c0 + d;                // c0, c0 - 1, c0 + 1, c0 - 2, ...
+    if (ck < 0 || ck >= nchunks) continue;
+    float wb = live ? bd[2] : 0.f;                              // the loosest bound of the wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wb = fmaxf(wb, __shfl_xor(wb, off));
+    const int bl = ck * 64 + lane;
+    float b6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool cand = false;
+    if (bl < nboxes) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) b6[c] = boxes[bl * 6 + c];
+      const float ex = fmaxf(0.f, fmaxf(b6[0] - whi[0], wlo[0] - b6[3]));
+      const float ey = fmaxf(0.f, fmaxf(b6[1] - whi[1], wlo[1] - b6[4]));
+      const float ez = fmaxf(0.f, fmaxf(b6[2] - whi[2], wlo[2] - b6[5]));
+      const float lower = ((ex * ex + ey * ey) + ez * ez) * 0.9999f;
+      const bool outside = b6[3] <= blo[0] || b6[4] <= blo[1] || b6[5] <= blo[2] || b6[0] >= bhi[0] || b6[1] >= bhi[1] || b6[2] >= bhi[2];
+      cand = !outside && lower < wb;
+    }
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(cand);
+    while (todo) {
+      const int l = __builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const int b = ck * 64 + l;
+      float bx[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) bx[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b6[c]), l));
+      const float ex = fmaxf(0.f, fmaxf(bx[0] - p.x, p.x - bx[3]));
+      const float ey = fmaxf(0.f, fmaxf(bx[1] - p.y, p.y - bx[4]));
+      const float ez = fmaxf(0.f, fmaxf(bx[2] - p.z, p.z - bx[5]));
+      // a lower bound of the distance to anything in the box, with slack for its rounding: never prunes a true neighbour
+      const float lower = ((ex * ex + ey * ey) + ez * ez) * 0.9999f;
+      const bool open = live && lower < bd[2];                  // (a run of references outside the filter box was dropped above)
+      if (__builtin_amdgcn_ballot_w64(open) == 0ull) continue;
+      const int j0 = b * KNN_QBOX, j1 = min(N, j0 + KNN_QBOX);
+      float4 nxt = (j0 + lane < j1) ? sorted[j0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t0 = j0; t0 < j1; t0 += 64) {
+        __builtin_amdgcn_wave_barrier();                        // the previous tile is read
+        s_tile[wv][lane] = nxt;
+        __builtin_amdgcn_wave_barrier();
+        if (t0 + 64 + lane < j1) nxt = sorted[t0 + 64 + lane];  // in flight during the compares below
+        if (open) {
+          const int n = min(64, j1 - t0);
 #pragma unroll 4
-        for (int t = part; t < n; t += 4) {                     // positions t0 + t with ((t0 + t) & 3) == part (t0 is a multiple of 64)
-          const int jj = t0 + t;
-          const float4 s = s_tile[wv][t];
-          const int already = (jj == bj[0]) | (jj == bj[1]) | (jj == bj[2]);    // the seeds
-          if (!already && __float_as_int(s.w) != self && inbox(s)) knn_insert(dist2(p, s), jj, bd, bj);
+          for (int t = part; t < n; t += 4) {                   // positions t0 + t with ((t0 + t) & 3) == part (t0 is a multiple of 64)
+            const int jj = t0 + t;
+            const float4 s = s_tile[wv][t];
+            const int already = (jj == bj[0]) | (jj == bj[1]) | (jj == bj[2]);    // the seeds
+            if (!already && __float_as_int(s.w) != self && inbox(s)) knn_insert(dist2(p, s), jj, bd, bj);
+          }
         }
       }
     }
@@ -421,7 +461,7 @@ static KnnLayout knn_layout(int N) {
   L.order_in = off; off = al(off + n * 4);
   L.order = off; off = al(off + n * 4);
   L.sorted = off; off = al(off + n * sizeof(float4));
-  L.boxes = off; off = al(off + ((n + KNN_BOX - 1) / KNN_BOX) * 6 * sizeof(float));
+  L.boxes = off; off = al(off + ((n + KNN_QBOX - 1) / KNN_QBOX) * 6 * sizeof(float));      // sized for the smaller of the two box sizes
   size_t tb = 0;
   (void)rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                   (uint32_t*)nullptr, n, 0u, 30u);
@@ -704,7 +744,7 @@ int rtgs_render_range(const float* T_map, int32_t H, int32_t W, float ratio, uin
 size_t rtgs_knn3_scratch_bytes(int32_t N) { return knn_layout(N).total; }
 
 // bounding box -> Morton codes -> sorted order -> points gathered in that order + one AABB per run of KNN_BOX points
-static int knn_build(const float* points, int32_t N, void* scratch, hipStream_t st) {
+static int knn_build(const float* points, int32_t N, void* scratch, hipStream_t st, int box = KNN_BOX) {
   const KnnLayout L = knn_layout(N);
   char* s = (char*)scratch;
   uint32_t* bbox = (uint32_t*)(s + L.bbox);
@@ -721,8 +761,8 @@ static int knn_build(const float* points, int32_t N, void* scratch, hipStream_t 
   hipLaunchKernelGGL(knn_morton_kernel, dim3(g), dim3(256), 0, st, points, N, (const uint32_t*)bbox, codes, order_in);
   size_t tb = L.cub_bytes;
   SLAM_TRY(rocprim::radix_sort_pairs(s + L.cub, tb, codes, codes_sorted, order_in, order, (size_t)N, 0u, 30u, st));
-  const int nboxes = (N + KNN_BOX - 1) / KNN_BOX;
-  hipLaunchKernelGGL(knn_gather_kernel, dim3(nboxes), dim3(256), 0, st, points, N, (const uint32_t*)order, sorted, boxes);
+  const int nboxes = (N + box - 1) / box;
+  hipLaunchKernelGGL(knn_gather_kernel, dim3(nboxes), dim3(256), 0, st, points, N, (const uint32_t*)order, sorted, boxes, box);
   return 0;
 }
 
@@ -777,7 +817,7 @@ int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_poin
   const KnnLayout L = knn_layout(Nr);
   const KnnQueryLayout Q = knn_query_layout(Nr, Nq);
   char* s = (char*)scratch;
-  const int rc = knn_build(ref_points, Nr, scratch, st);
+  const int rc = knn_build(ref_points, Nr, scratch, st, KNN_QBOX);
   if (rc != 0) return rc;
   uint32_t* q_codes = (uint32_t*)(s + Q.codes);
   uint32_t* q_codes_sorted = (uint32_t*)(s + Q.codes_sorted);
@@ -787,7 +827,7 @@ int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_poin
                      q_codes, q_order_in);
   size_t tb = Q.cub_bytes;
   SLAM_TRY(rocprim::radix_sort_pairs(s + Q.cub, tb, q_codes, q_codes_sorted, q_order_in, q_order, (size_t)Nq, 0u, 30u, st));
-  const int nboxes = (Nr + KNN_BOX - 1) / KNN_BOX;
+  const int nboxes = (Nr + KNN_QBOX - 1) / KNN_QBOX;
   hipLaunchKernelGGL(knn_query_kernel, dim3((Nq + 63) / 64), dim3(256), 0, st, (const float4*)(s + L.sorted), Nr,
                      (const uint32_t*)(s + L.codes_sorted), (const float*)(s + L.boxes), nboxes, query_points, Nq,
                      (const uint32_t*)q_order, (const uint32_t*)q_codes_sorted, self_offset, ref_box6, idx, dist2_out);
