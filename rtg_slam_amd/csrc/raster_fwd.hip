@@ -428,90 +428,113 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
       // mask: the two tests narrow it (v_cmpx), the stop test splits it, and what is left updates T / C / best with plain
       // instructions.  ~45 instructions per step.  Same arithmetic in the same order: outputs are bit-identical.
       uint32_t rec_base = (uint32_t)(uintptr_t)&s_rec[0];
+      const uint32_t live_base = (uint32_t)(uintptr_t)&s_live[blk][0];     // per lane: its row's sub-list words
       uint32_t base1 = (uint32_t)base + 1u;
       float thr = p.T_thr, opq = p.opaque_thr;
+      uint32_t steps_w = 0u, evals_lo = 0u;                                  // wave-uniform counters (STAMP / COUNT variants)
       // (opaque to the compiler: as kernel arguments it RELOADS them inside the loop - an s_load and a wait for everything in
       // flight, the step's LDS reads included - rather than hold four more SGPRs)
       asm volatile("" : "+s"(rec_base), "+s"(base1), "+s"(thr), "+s"(opq));
+      // The WHOLE walk loop is one statement: refill of a row's sub-list word, the loop condition, the step.  It leaves for
+      // two reasons: nobody has an entry left (WD == 0), or the step met opaque-surface depth candidates (WD = their lanes; a
+      // handful of times per wave: handled below in C++, then the loop is entered again).  The three record loads land in
+      // v[70:79] (named: an operand's sub-registers cannot be; they are listed as clobbers, so nothing else lives there -
+      // which is why this kernel exists at 5 and 6 waves per SIMD only, 80+ VGPRs).
+#define RTGS_FWD_WALK(EXTRA)                                                                                                     \
+      asm volatile(                                                                                                              \
+          "s_mov_b64 %[WD], 0\n\t"                                                                                               \
+          "1:\n\t"                                                                                                               \
+          "v_cmp_eq_u32 vcc, 0, %[cur]\n\t"                     /* rows whose word is used up */                                 \
+          "s_cbranch_vccz 3f\n\t"                                                                                                \
+          "v_add_u32 %[t1], 1, %[c]\n\t"                                                                                         \
+          "v_cmp_gt_i32 %[tm], %[nch], %[t1]\n\t"               /* ... and have another word */                                  \
+          "s_and_b64 vcc, vcc, %[tm]\n\t"                                                                                        \
+          "s_cbranch_vccz 3f\n\t"                                                                                                \
+          "s_mov_b64 exec, vcc\n\t"                                                                                              \
+          "v_mov_b32 %[c], %[t1]\n\t"                                                                                            \
+          "v_lshl_add_u32 %[addr], %[t1], 2, %[lb]\n\t"                                                                          \
+          "ds_read_b32 %[cur], %[addr]\n\t"                                                                                      \
+          "s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
+          "s_mov_b64 exec, -1\n\t"                                                                                               \
+          "s_branch 1b\n\t"                                     /* (the new word may be empty too) */                            \
+          "3:\n\t"                                                                                                               \
+          "v_cmp_ne_u32 vcc, 0, %[cur]\n\t"                                                                                      \
+          "s_andn2_b64 %[tm], vcc, %[D]\n\t"                    /* a lane walks on while ITS pixel is open and its row has entries */ \
+          "s_cbranch_scc0 9f\n\t"                                                                                                \
+          "s_mov_b64 exec, %[tm]\n\t"                                                                                            \
+          EXTRA                                                                                                                  \
+          "v_ffbl_b32 %[e], %[cur]\n\t"                                                                                          \
+          "v_lshl_or_b32 %[e], %[c], 5, %[e]\n\t"                                                                                \
+          "v_lshl_add_u32 %[addr], %[e], 6, %[rb]\n\t"                                                                           \
+          "ds_read_b128 v[70:73], %[addr]\n\t"                  /* u v ca cb */                                                  \
+          "ds_read_b128 v[74:77], %[addr] offset:16\n\t"        /* cc o r g */                                                   \
+          "ds_read2_b32 v[78:79], %[addr] offset0:8 offset1:11\n\t"   /* b id */                                                 \
+          "v_add_u32 %[t1], -1, %[cur]\n\t"                                                                                      \
+          "v_and_b32 %[cur], %[t1], %[cur]\n\t"                 /* the entry is taken (lanes outside: no entry, or stopped for good) */ \
+          "s_waitcnt lgkmcnt(2)\n\t"                                                                                             \
+          "v_sub_f32 %[dx], v70, %[px]\n\t"                                                                                      \
+          "v_sub_f32 %[dy], v71, %[py]\n\t"                                                                                      \
+          "v_mul_f32 %[t1], v72, %[dx]\n\t"                                                                                      \
+          "v_mul_f32 %[t2], v73, %[dx]\n\t"                                                                                      \
+          "s_waitcnt lgkmcnt(1)\n\t"                                                                                             \
+          "v_mul_f32 %[pw], v74, %[dy]\n\t"                                                                                      \
+          "v_mul_f32 %[pw], %[pw], %[dy]\n\t"                                                                                    \
+          "v_fma_f32 %[t1], %[t1], %[dx], %[pw]\n\t"                                                                             \
+          "v_mul_f32 %[t2], %[t2], %[dy]\n\t"                                                                                    \
+          "v_fma_f32 %[pw], -0.5, %[t1], -%[t2]\n\t"                                                                             \
+          "v_min_f32 %[t1], 0, %[pw]\n\t"                                                                                        \
+          "v_mul_f32 %[t1], 0x3fb8aa3b, %[t1]\n\t"                                                                               \
+          "v_exp_f32 %[t1], %[t1]\n\t"                                                                                           \
+          "v_cmpx_nlt_f32 vcc, 0, %[pw]\n\t"                    /* exec: !(power > 0) */                                         \
+          "s_nop 0\n\t"                                                                                                          \
+          "v_mul_f32 %[al], v75, %[t1]\n\t"                                                                                      \
+          "v_min_f32 %[al], 0x3f7d70a4, %[al]\n\t"                                                                               \
+          "v_cmpx_ngt_f32 vcc, 0x3b808081, %[al]\n\t"           /* exec: !(alpha < 1/255) */                                     \
+          "v_sub_f32 %[t2], 1.0, %[al]\n\t"                                                                                      \
+          "v_mul_f32 %[tT], %[T], %[t2]\n\t"                                                                                     \
+          "v_cmp_gt_f32 vcc, %[thr], %[tT]\n\t"                 /* the pixel stops in front of this entry */                     \
+          "s_or_b64 %[D], %[D], vcc\n\t"                                                                                         \
+          "s_andn2_b64 exec, exec, vcc\n\t"                     /* exec: the contributing lanes */                               \
+          "s_cbranch_scc0 5f\n\t"                                                                                                \
+          "v_mul_f32 %[w], %[al], %[T]\n\t"                                                                                      \
+          "v_mov_b32 %[T], %[tT]\n\t"                                                                                            \
+          "v_add_u32 %[last], %[base1], %[e]\n\t"                                                                                \
+          "s_waitcnt lgkmcnt(0)\n\t"                                                                                             \
+          "v_fmac_f32 %[C0], v76, %[w]\n\t"                                                                                      \
+          "v_fmac_f32 %[C1], v77, %[w]\n\t"                                                                                      \
+          "v_fmac_f32 %[C2], v78, %[w]\n\t"                                                                                      \
+          "v_cmp_gt_f32 vcc, %[w], %[bw]\n\t"                                                                                    \
+          "v_cndmask_b32 %[bw], %[bw], %[w], vcc\n\t"                                                                            \
+          "v_cndmask_b32 %[bid], %[bid], v79, vcc\n\t"                                                                           \
+          "v_cmp_gt_i32 vcc, 0, %[did]\n\t"                     /* no depth owner yet ... */                                     \
+          "v_cmp_lt_f32 %[WD], %[opq], %[al]\n\t"               /* ... and this entry is opaque enough to be one */              \
+          "s_and_b64 %[WD], %[WD], vcc\n\t"                                                                                      \
+          "s_mov_b64 exec, -1\n\t"                                                                                               \
+          "s_cmp_eq_u64 %[WD], 0\n\t"                                                                                            \
+          "s_cbranch_scc1 1b\n\t"                                                                                                \
+          "v_mov_b32 %[gid], v79\n\t"                           /* depth candidates: leave with (e, alpha, id) */                \
+          "s_branch 9f\n\t"                                                                                                      \
+          "5:\n\t"                                                                                                               \
+          "s_mov_b64 exec, -1\n\t"                                                                                               \
+          "s_branch 1b\n\t"                                                                                                      \
+          "9:\n\t"                                                                                                               \
+          : [WD] "=&s"(WD), [tm] "=&s"(tm), [D] "+s"(Dm), [e] "=&v"(e), [addr] "=&v"(addr), [al] "=&v"(al), [gid] "=&v"(gid),    \
+            [dx] "=&v"(dx), [dy] "=&v"(dy), [t1] "=&v"(t1), [t2] "=&v"(t2), [pw] "=&v"(pw), [tT] "=&v"(tT), [w] "=&v"(w),         \
+            [cur] "+v"(cur), [c] "+v"(c), [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [bw] "+v"(best_w),            \
+            [bid] "+v"(best_id), [last] "+v"(last_contributor), [steps] "+s"(steps_w), [ev] "+s"(evals_lo)                       \
+          : [px] "v"(pxf), [py] "v"(pyf), [thr] "s"(thr), [opq] "s"(opq), [base1] "s"(base1), [did] "v"(d_id), [rb] "s"(rec_base), \
+            [lb] "v"(live_base), [nch] "s"(nch)                                                                                  \
+          : "vcc", "scc", "memory", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79")
       for (;;) {
-        while (cur == 0u && c + 1 < nch) { ++c; cur = s_live[blk][c]; }
-        const unsigned long long H = __builtin_amdgcn_ballot_w64(cur != 0u) & ~Dm;     // a lane walks on while ITS pixel is open and its row has entries
-        if (H == 0ull) break;
-        if constexpr (STAMP) st_steps += 1;
-        if constexpr (COUNT) evals_w += (unsigned long long)__popcll(H);
-        unsigned long long sv, WD;
-        uint32_t e, addr;
-        f4v q0, q1;
-        f2v q2;
+        unsigned long long WD, tm;
+        uint32_t e, addr, gid;
         float al, dx, dy, t1, t2, pw, tT, w;
-        // the entry's record: every lane reads (a stopped pixel reads what its row reads - one broadcast; a row without an
-        // entry reads slot 255 and ignores it).  Outputs of one statement, inputs of the next: the compiler hands the
-        // sub-registers of the tuples over as they are.
-        asm volatile(
-            "v_ffbl_b32 %[e], %[cur]\n\t"
-            "v_lshl_or_b32 %[e], %[c], 5, %[e]\n\t"
-            "v_and_b32 %[e], 0xff, %[e]\n\t"
-            "v_lshl_add_u32 %[addr], %[e], 6, %[rb]\n\t"
-            "ds_read_b128 %[q0], %[addr]\n\t"
-            "ds_read_b128 %[q1], %[addr] offset:16\n\t"
-            "ds_read2_b32 %[q2], %[addr] offset0:8 offset1:11\n\t"
-            : [e] "=&v"(e), [addr] "=&v"(addr), [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2)
-            : [cur] "v"(cur), [c] "v"(c), [rb] "s"(rec_base));
-        cur &= cur - 1u;
-        asm volatile(
-            "s_mov_b64 %[sv], exec\n\t"
-            "s_mov_b64 exec, %[H]\n\t"
-            "s_mov_b64 %[WD], 0\n\t"
-            "s_waitcnt lgkmcnt(2)\n\t"
-            "v_sub_f32 %[dx], %[u], %[px]\n\t"
-            "v_sub_f32 %[dy], %[v], %[py]\n\t"
-            "v_mul_f32 %[t1], %[ca], %[dx]\n\t"
-            "v_mul_f32 %[t2], %[cb], %[dx]\n\t"
-            "s_waitcnt lgkmcnt(1)\n\t"
-            "v_mul_f32 %[pw], %[cc], %[dy]\n\t"
-            "v_mul_f32 %[pw], %[pw], %[dy]\n\t"
-            "v_fma_f32 %[t1], %[t1], %[dx], %[pw]\n\t"
-            "v_mul_f32 %[t2], %[t2], %[dy]\n\t"
-            "v_fma_f32 %[pw], -0.5, %[t1], -%[t2]\n\t"
-            "v_min_f32 %[t1], 0, %[pw]\n\t"
-            "v_mul_f32 %[t1], 0x3fb8aa3b, %[t1]\n\t"
-            "v_exp_f32 %[t1], %[t1]\n\t"
-            "v_cmpx_nlt_f32 vcc, 0, %[pw]\n\t"                   // exec: !(power > 0)
-            "s_nop 0\n\t"
-            "v_mul_f32 %[al], %[o], %[t1]\n\t"
-            "v_min_f32 %[al], 0x3f7d70a4, %[al]\n\t"
-            "v_cmpx_ngt_f32 vcc, 0x3b808081, %[al]\n\t"          // exec: !(alpha < 1/255)
-            "v_sub_f32 %[t2], 1.0, %[al]\n\t"
-            "v_mul_f32 %[tT], %[T], %[t2]\n\t"
-            "v_cmp_gt_f32 vcc, %[thr], %[tT]\n\t"                // the pixel stops in front of this entry
-            "s_or_b64 %[D], %[D], vcc\n\t"
-            "s_andn2_b64 exec, exec, vcc\n\t"                   // exec: the contributing lanes
-            "s_cbranch_scc0 1f\n\t"
-            "v_mul_f32 %[w], %[al], %[T]\n\t"
-            "v_mov_b32 %[T], %[tT]\n\t"
-            "v_add_u32 %[last], %[base1], %[e]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_fmac_f32 %[C0], %[r], %[w]\n\t"
-            "v_fmac_f32 %[C1], %[g], %[w]\n\t"
-            "v_fmac_f32 %[C2], %[b], %[w]\n\t"
-            "v_cmp_gt_f32 vcc, %[w], %[bw]\n\t"
-            "v_cndmask_b32 %[bw], %[bw], %[w], vcc\n\t"
-            "v_cndmask_b32 %[bid], %[bid], %[id], vcc\n\t"
-            "v_cmp_gt_i32 vcc, 0, %[did]\n\t"                    // no depth owner yet ...
-            "v_cmp_lt_f32 %[WD], %[opq], %[al]\n\t"              // ... and this entry is opaque enough to be one
-            "s_and_b64 %[WD], %[WD], vcc\n\t"
-            "1:\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            : [sv] "=&s"(sv), [WD] "=&s"(WD), [D] "+s"(Dm), [al] "=&v"(al), [dx] "=&v"(dx), [dy] "=&v"(dy), [t1] "=&v"(t1),
-              [t2] "=&v"(t2), [pw] "=&v"(pw), [tT] "=&v"(tT), [w] "=&v"(w), [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2),
-              [bw] "+v"(best_w), [bid] "+v"(best_id), [last] "+v"(last_contributor)
-            : [H] "s"(H), [px] "v"(pxf), [py] "v"(pyf), [thr] "s"(thr), [opq] "s"(opq), [base1] "s"(base1), [did] "v"(d_id), [e] "v"(e),
-              [u] "v"(q0.x), [v] "v"(q0.y), [ca] "v"(q0.z), [cb] "v"(q0.w), [cc] "v"(q1.x), [o] "v"(q1.y), [r] "v"(q1.z),
-              [g] "v"(q1.w), [b] "v"(q2.x), [id] "v"(q2.y)
-            : "vcc", "scc");
-        if (WD != 0ull) {                                          // rare: opaque-surface depth candidates
-          unsigned long long mine;                                 // (inside the branch and opaque: the test stays a SCALAR branch)
+        if constexpr (STAMP) RTGS_FWD_WALK("s_add_u32 %[steps], %[steps], 1\n\t");
+        else if constexpr (COUNT) RTGS_FWD_WALK("s_bcnt1_i32_b64 %[steps], %[tm]\n\ts_add_u32 %[ev], %[ev], %[steps]\n\t");
+        else RTGS_FWD_WALK("");
+        if (WD == 0ull) break;
+        {                                                          // rare: opaque-surface depth candidates
+          unsigned long long mine;                                 // (opaque: the test above stays a SCALAR branch)
           asm volatile("v_lshrrev_b64 %[t], %[l], %[m]" : [t] "=v"(mine) : [l] "v"(lane), [m] "s"(WD));
           if ((uint32_t)mine & 1u) {
             const float rx = (pxf - p.cx) / p.fx, ry = (pyf - p.cy) / p.fy;
@@ -521,12 +544,15 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
             if (fabsf(den) / rnorm > p.normal_thr) {
               const float zhit = r3.w / den;
               if (zhit > 0.f && fabsf(zhit - s_z[e]) < p.depth_thr) {
-                D = zhit; d_w = al; d_id = (int)__float_as_uint(q2.y); d_pos = (uint32_t)base + e; d_iden = 1.f / den;
+                D = zhit; d_w = al; d_id = (int)gid; d_pos = (uint32_t)base + e; d_iden = 1.f / den;
               }
             }
           }
         }
       }
+#undef RTGS_FWD_WALK
+      if constexpr (STAMP) st_steps += steps_w;
+      if constexpr (COUNT) evals_w += evals_lo;
     } else
     for (;;) {
       while (cur == 0u && c + 1 < nch) { ++c; cur = s_live[blk][c]; }
@@ -663,7 +689,7 @@ __global__ void __launch_bounds__(256, OCC) blend_fwd_kernel(
 #undef RI
 
 
-static int g_f1_occ = [] { const char* e = getenv("RTGS_F1_OCC"); const int v = e ? atoi(e) : 6; return (v == 5 || v == 7 || v == 8) ? v : 6; }();
+static int g_f1_occ = [] { const char* e = getenv("RTGS_F1_OCC"); const int v = e ? atoi(e) : 6; return v == 5 ? 5 : 6; }();
 static int g_f1_asm = [] { const char* e = getenv("RTGS_F1_ASM"); return e ? atoi(e) : 1; }();
 static unsigned long long* g_fwd_stamps = nullptr;   // measurement only (rtgs_raster_set_fwd_stamps)
 void set_fwd_stamps(void* dev) { g_fwd_stamps = (unsigned long long*)dev; }
@@ -758,7 +784,7 @@ void launch_blend_fwd(const RasterParams& p, const uint2* ranges, const uint32_t
   if (g_f1_asm == 0) RTGS_FWD1(6, false, true, false);      // the compiler's walk loop (A-B, tests): RTGS_F1_ASM=0
   else if (counters) RTGS_FWD1(6, false, true, true);        // work counters asked for (bench.py's roofline, tests): the accounting variant
   else if (g_fwd_stamps) RTGS_FWD1(6, true, false, true);
-  else if (g_f1_occ == 8) RTGS_FWD1(8, false, false, true); else if (g_f1_occ == 7) RTGS_FWD1(7, false, false, true); else if (g_f1_occ == 5) RTGS_FWD1(5, false, false, true); else RTGS_FWD1(6, false, false, true);
+  else if (g_f1_occ == 5) RTGS_FWD1(5, false, false, true); else RTGS_FWD1(6, false, false, true);   // (7 / 8 waves: 79.6 / 79.0 us against 80.3 in round 5; the walk's named registers need 80 VGPRs)
 #undef RTGS_FWD1
 }
 

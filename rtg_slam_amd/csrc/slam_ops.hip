@@ -302,24 +302,28 @@ __global__ void __launch_bounds__(256) knn_query_codes_kernel(const float* __res
 }
 
 // Queries are taken in MORTON order (q_order: the lanes of a wave are neighbours in space and open the same few boxes) and a
-// query is FOUR lanes (lane = part << 4 | query-of-the-wave): part p owns the references at sorted positions j with
-// (j & 3) == p, keeps its own three best, and the four lists are merged at the end.  An opened box streams through LDS in
-// tiles of 64 references (one coalesced load per tile, the next tile in flight while this one is compared).  Why: the
-// first form - one lane per query, caller order, a global load per reference inside the compare loop - had 63 waves for
-// 4 000 queries, each paying an L2 round trip per reference: 2.8 ms per call on 100 000 references (1.9 ms in Morton
-// order), 40 % of the SLAM sequence's mapping time.
+// query is PARTS lanes (lane = part * QW + query-of-the-wave, QW = 64 / PARTS): part p owns the references at sorted
+// positions j with j % PARTS == p, keeps its own three best, and the lists are merged at the end.  An opened box (256
+// references) comes in one round trip - four coalesced loads per lane - and is compared from LDS.  History: one lane per query,
+// caller order, a global load per reference inside the compare loop: 2.8 ms per call on 100 000 references (1.9 ms in Morton
+// order), 40 % of the SLAM sequence's mapping time in round 5; four lanes per query, boxes of 1 024 walked one by one with a
+// scalar load each and streamed in tiles of 64: 0.31-0.42 ms; round 6 (this form): boxes pre-tested 64 at a time, the home box
+// first, a box per round trip, and SIXTEEN lanes per query when the call is small (a SLAM frame asks for a few hundred new
+// points: with sixteen queries per wave the launch was a handful of waves, each opening the union of its queries' boxes).
+template <int PARTS>
 __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict__ sorted, int N, const uint32_t* __restrict__ codes_sorted,
                                                         const float* __restrict__ boxes, int nboxes,
                                                         const float* __restrict__ query, int Nq, const uint32_t* __restrict__ q_order,
                                                         const uint32_t* __restrict__ q_codes_sorted, int self_offset,
                                                         const float* __restrict__ ref_box, int32_t* __restrict__ idx,
                                                         float* __restrict__ dist_out) {
-  __shared__ float4 s_tile[4][64];
-  __shared__ float s_md[4][16][4][3];
-  __shared__ int s_mi[4][16][4][3];
+  constexpr int QW = 64 / PARTS;
+  __shared__ float4 s_tile[4][KNN_QBOX];
+  __shared__ float s_md[4][QW][PARTS][3];
+  __shared__ int s_mi[4][QW][PARTS][3];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int qw = lane & 15, part = lane >> 4;
-  const int slot = (blockIdx.x * 4 + wv) * 16 + qw;
+  const int qw = lane % QW, part = lane / QW;
+  const int slot = (blockIdx.x * 4 + wv) * QW + qw;
   const bool live = slot < Nq;
   const int i = live ? (int)q_order[slot] : 0;
   // optional open box (lo, hi): references outside it do not exist for the search (bbox_filter, SLAM/utils.py:737-744)
@@ -341,24 +345,37 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
     const uint32_t code = q_codes_sorted[slot];
     int lo = 0, hi = N;                                         // lower bound of `code`
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (codes_sorted[mid] < code) lo = mid + 1; else hi = mid; }
-    // seeds: the sixteen references around that position - each part takes the four it owns, so that every part starts
-    // with a finite third-best distance (with two seeds per part the bound stayed FLT_MAX until a whole box was scanned,
-    // and the first boxes in Morton order - usually far from the query - were opened by everyone)
-    for (int j = max(0, lo - 8); j <= min(N - 1, lo + 7); ++j) {
-      if ((j & 3) != part) continue;
-      const float4 s = sorted[j];
-      if (__float_as_int(s.w) != self && inbox(s)) knn_insert(dist2(p, s), j, bd, bj);
-    }
-    home = lo / KNN_QBOX;
+    home = min(lo, N - 1) / KNN_QBOX;
   }
-  // Boxes are visited outward from the box the wave's first query falls into (Morton neighbours are near in space, so the
-  // bound tightens before the far boxes are tested) - SIXTY-FOUR AT A TIME (round 6): lane l tests box c * 64 + l against the
-  // bounding box of the wave's queries and the loosest bound any of its lanes holds - a conservative form of every lane's own
-  // test - and only the boxes that pass are looked at by the lanes themselves.  Before, a wave walked all boxes one by one with
-  // a scalar load and its wait per box: 286 dependent round trips per wave on the 290 k references of a grown SLAM map were
-  // most of the kernel's 384 us (profiles/r06_sequence_*; the kernel is a handful of waves there, i.e. pure latency).
+  // one box, for the lanes that ask for it (`open`; wave-uniform call): ONE round trip - four coalesced loads per lane, issued
+  // together - then compared from LDS (tile by tile with the next tile's load behind the compares it was four dependent
+  // round trips per box, and a launch of a few waves IS its chain of round trips)
+  auto scan_box = [&](int b, bool open) {
+    const int j0 = b * KNN_QBOX, j1 = min(N, j0 + KNN_QBOX);
+    float4 in4[KNN_QBOX / 64];
+#pragma unroll
+    for (int q = 0; q < KNN_QBOX / 64; ++q) in4[q] = (j0 + q * 64 + lane < j1) ? sorted[j0 + q * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_wave_barrier();                            // the previous box is read
+#pragma unroll
+    for (int q = 0; q < KNN_QBOX / 64; ++q) s_tile[wv][q * 64 + lane] = in4[q];
+    __builtin_amdgcn_wave_barrier();
+    if (open) {
+      const int n = j1 - j0;
+#pragma unroll 4
+      for (int t = part; t < n; t += PARTS) {                   // positions j0 + t with (j0 + t) % PARTS == part (j0 is a multiple of 256)
+        const float4 s = s_tile[wv][t];
+        if (__float_as_int(s.w) != self && inbox(s)) knn_insert(dist2(p, s), j0 + t, bd, bj);
+      }
+    }
+  };
+  // Boxes: the HOME box of the wave's first query first (it holds the query's Morton neighbours: the bound is tight from
+  // the start), then all others outward from it, SIXTY-FOUR AT A TIME: lane l tests box c * 64 + l against the bounding box
+  // of the wave's queries and the loosest bound any of its lanes holds - a conservative form of every lane's own test - and
+  // only the boxes that pass are looked at by the lanes themselves.  (Round 5 walked all boxes one by one with a scalar load
+  // and its wait per box: 286 dependent round trips per wave on the 290 k references of a grown SLAM map.)
   const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
   const int b0 = lv ? min(nboxes - 1, __builtin_amdgcn_readlane(home, __builtin_ctzll(lv))) : 0;
+  scan_box(b0, live);
   float wlo[3], whi[3];
   {
     const float q3[3] = {p.x, p.y, p.z};
@@ -381,13 +398,14 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
     const int bl = ck * 64 + lane;
     float b6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bool cand = false;
-    if (bl < nboxes) {
+    if (bl < nboxes && bl != b0) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) b6[c] = boxes[bl * 6 + c];
       const float ex = fmaxf(0.f, fmaxf(b6[0] - whi[0], wlo[0] - b6[3]));
       const float ey = fmaxf(0.f, fmaxf(b6[1] - whi[1], wlo[1] - b6[4]));
       const float ez = fmaxf(0.f, fmaxf(b6[2] - whi[2], wlo[2] - b6[5]));
       const float lower = ((ex * ex + ey * ey) + ez * ez) * 0.9999f;
+      // a run of references entirely outside the filter box holds nothing to find
       const bool outside = b6[3] <= blo[0] || b6[4] <= blo[1] || b6[5] <= blo[2] || b6[0] >= bhi[0] || b6[1] >= bhi[1] || b6[2] >= bhi[2];
       cand = !outside && lower < wb;
     }
@@ -395,7 +413,6 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
     while (todo) {
       const int l = __builtin_ctzll(todo);
       todo &= todo - 1ull;
-      const int b = ck * 64 + l;
       float bx[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) bx[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b6[c]), l));
@@ -404,29 +421,12 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
       const float ez = fmaxf(0.f, fmaxf(bx[2] - p.z, p.z - bx[5]));
       // a lower bound of the distance to anything in the box, with slack for its rounding: never prunes a true neighbour
       const float lower = ((ex * ex + ey * ey) + ez * ez) * 0.9999f;
-      const bool open = live && lower < bd[2];                  // (a run of references outside the filter box was dropped above)
+      const bool open = live && lower < bd[2];
       if (__builtin_amdgcn_ballot_w64(open) == 0ull) continue;
-      const int j0 = b * KNN_QBOX, j1 = min(N, j0 + KNN_QBOX);
-      float4 nxt = (j0 + lane < j1) ? sorted[j0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int t0 = j0; t0 < j1; t0 += 64) {
-        __builtin_amdgcn_wave_barrier();                        // the previous tile is read
-        s_tile[wv][lane] = nxt;
-        __builtin_amdgcn_wave_barrier();
-        if (t0 + 64 + lane < j1) nxt = sorted[t0 + 64 + lane];  // in flight during the compares below
-        if (open) {
-          const int n = min(64, j1 - t0);
-#pragma unroll 4
-          for (int t = part; t < n; t += 4) {                   // positions t0 + t with ((t0 + t) & 3) == part (t0 is a multiple of 64)
-            const int jj = t0 + t;
-            const float4 s = s_tile[wv][t];
-            const int already = (jj == bj[0]) | (jj == bj[1]) | (jj == bj[2]);    // the seeds
-            if (!already && __float_as_int(s.w) != self && inbox(s)) knn_insert(dist2(p, s), jj, bd, bj);
-          }
-        }
-      }
+      scan_box(ck * 64 + l, open);
     }
   }
-  // ---- merge the four parts of every query (disjoint reference sets: no duplicates)
+  // ---- merge the parts of every query (disjoint reference sets: no duplicates)
   int bid[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) bid[k] = bj[k] >= 0 ? __float_as_int(sorted[bj[k]].w) : -1;
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
   for (int k = 0; k < 3; ++k) { s_md[wv][qw][part][k] = bd[k]; s_mi[wv][qw][part][k] = bid[k]; }
   __builtin_amdgcn_wave_barrier();
   if (!live || part != 0) return;
-  for (int q = 1; q < 4; ++q)
+  for (int q = 1; q < PARTS; ++q)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int id = s_mi[wv][qw][q][k];
@@ -828,9 +828,15 @@ int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_poin
   size_t tb = Q.cub_bytes;
   SLAM_TRY(rocprim::radix_sort_pairs(s + Q.cub, tb, q_codes, q_codes_sorted, q_order_in, q_order, (size_t)Nq, 0u, 30u, st));
   const int nboxes = (Nr + KNN_QBOX - 1) / KNN_QBOX;
-  hipLaunchKernelGGL(knn_query_kernel, dim3((Nq + 63) / 64), dim3(256), 0, st, (const float4*)(s + L.sorted), Nr,
-                     (const uint32_t*)(s + L.codes_sorted), (const float*)(s + L.boxes), nboxes, query_points, Nq,
-                     (const uint32_t*)q_order, (const uint32_t*)q_codes_sorted, self_offset, ref_box6, idx, dist2_out);
+  // a query is 16 lanes in a small call (<= 4 096 queries: 4 queries per wave, >= 4x the waves), 4 lanes in a large one
+  if (Nq <= 4096)
+    hipLaunchKernelGGL(knn_query_kernel<16>, dim3((Nq + 15) / 16), dim3(256), 0, st, (const float4*)(s + L.sorted), Nr,
+                       (const uint32_t*)(s + L.codes_sorted), (const float*)(s + L.boxes), nboxes, query_points, Nq,
+                       (const uint32_t*)q_order, (const uint32_t*)q_codes_sorted, self_offset, ref_box6, idx, dist2_out);
+  else
+    hipLaunchKernelGGL(knn_query_kernel<4>, dim3((Nq + 63) / 64), dim3(256), 0, st, (const float4*)(s + L.sorted), Nr,
+                       (const uint32_t*)(s + L.codes_sorted), (const float*)(s + L.boxes), nboxes, query_points, Nq,
+                       (const uint32_t*)q_order, (const uint32_t*)q_codes_sorted, self_offset, ref_box6, idx, dist2_out);
   SLAM_TRY(hipGetLastError());
   return 0;
 }
