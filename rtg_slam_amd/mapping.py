@@ -22,7 +22,8 @@ multi-process plumbing.  What differs, deliberately:
     every tensor; boolean-mask compactions - each a device-to-host synchronisation in the reference - are kept to the
     ones whose result changes a shape: two per added frame, one per fix / delete that finds something.
   * bbox_filter (SLAM/utils.py:737-744) runs inside the neighbour query (rtgs_knn3_query's box), not as a compaction.
-  * keyframe images stay on the device (the reference parks them on the CPU, :349-367; 288 GB of HBM make that moot).
+  * keyframe images stay on the device (the reference parks them on the CPU, :349-367) - the four maps the global
+    optimisation reads, 33 MB per 1200x680 keyframe.
   * a render of (frame, map version) is remembered: error_gaussians_remove and get_render_output ask for the same frame
     of the same map when nothing was deleted in between.
 There is no CPU path: `ops` defaults to the HIP modules; tests inject torch doubles to exercise the host logic."""
@@ -653,8 +654,12 @@ class Mapping:
 
     def check_keyframe(self, frame, frame_id):
         def keep():
+            # what the global optimisation reads of a keyframe (the reference keeps colour / depth / normal too, on the CPU:
+            # mapper.py:340-367) - not the whole frame map (vertex maps, camera-space normals, confidence: 68 MB per 1200x680
+            # keyframe for the life of the map)
             self.keyframe_list.append(frame)
-            self.keymap_list.append(self.frame_map)
+            self.keymap_list.append({k: self.frame_map[k] for k in ("color_map", "color_chw", "depth_chw", "normal_map_w", "time")
+                                     if k in self.frame_map})
             self.keyframe_ids.append(frame_id)
         if self.time == 0:
             keep()

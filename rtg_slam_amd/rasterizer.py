@@ -281,6 +281,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _ptr(normal_w), _ptr(tile_mask), _ptr(color), _ptr(depth), _ptr(cidx), _ptr(didx), _ptr(cw),
                 _ptr(dw), _ptr(Tm), _ptr(radii), geom.cb, None, binning.cb, None, img.cb, None, C.byref(R),
                 0 if any(ctx.needs_input_grad[:6]) else _lib.FWD_NO_BACKWARD, C.c_void_p(stream))
+        # the callbacks are bound methods of the arenas they sit in - a reference cycle per arena, i.e. the three buffers of
+        # EVERY forward (146 MB of tile segments among them) stayed allocated until Python's cyclic collector came by: 8-9 GB of
+        # "live" garbage in the SLAM sequence against 2.5-3.3 GB after a collection (tools/seq_memory.py, round 6)
+        geom.cb = binning.cb = img.cb = None
         _lib.check(rc, "rtgs_raster_forward")
         ctx.raster_settings = rs
         ctx.num_rendered = int(R.value)
