@@ -113,6 +113,22 @@ int rtgs_add_masks(const float* T_map, const float* depth, const float* render_d
  * frame has no depth.  The inputs of rtgs_accumulate_error. */
 int rtgs_frame_errors(const float* depth, const float* render_depth, const float* render_color_chw, const float* frame_color_chw,
                       const int32_t* depth_index, int32_t H, int32_t W, float* color_error, float* depth_error, void* stream);
+/* The new Gaussians of a frame (round 6): what Mapping._new_points and the tail of Mapping.temp_to_optimize (this package's
+ * mapping.py; the reference: GaussianPointCloud.add_empty_points / update_geometry, gaussian_pointcloud.py:305-405, compute_rot
+ * SLAM/utils.py:216-221, mapper.py:886-899) spell as ~80 tensor operations, as two kernels with the same float32 operations.
+ * gather_new_points: pick int64[n] (pixel indices into the [H*W,3] maps) -> xyz, UNIT normal (v / (|v| + 1e-8)), colour, rotation
+ * quaternion (w,x,y,z) turning z onto the normal (identity_rot != 0: (1,0,0,0), the reference's branch for xyz_factor = 1,1,1).
+ * (A pass of exactly THREE points must not come here: the reference's torch.cross without a dim then crosses along the batch.)
+ * new_rows: candidate i with its three nearest neighbours (dist2 / idx [n,3] of rtgs_knn3_query over cat(candidates, existing);
+ * idx < n names a candidate - radius 1e-6 -, idx >= n the existing Gaussian idx - n with activated scales exist_scales[., 3],
+ * -1 no neighbour) -> packed59[n,59] raw rows (xyz | SH dc from the colour | zeros | raw opacity | log(scale_factor * s * factor)
+ * | rotation) of EVERY candidate and valid[n] = 0 where the candidate lies inside three radii of a neighbour. */
+int rtgs_gather_new_points(const int64_t* pick, int32_t n, const float* vertex_map, const float* normal_map, const float* color_map,
+                           int32_t identity_rot, float* xyz, float* normal, float* color, float* rots, void* stream);
+int rtgs_new_rows(int32_t n, const float* xyz, const float* color, const float* opacity_raw, const float* rots, const float* dist2,
+                  const int32_t* idx, const float* exist_scales, float min_radius, float max_radius, float scale_factor,
+                  float factor_x, float factor_y, float factor_z, float* packed59, uint8_t* valid, void* stream);
+
 /* Mapping.temp_points_attach (mapper.py:830-883): attach_out[i] = 1 iff point i projects (w2c16 row-major 4x4, pinhole fx fy
  * cx cy, truncation like Camera.get_uv, scene/cameras.py:161-168) inside the image onto a pixel whose stable colour index
  * is >= 0 and lies within max_plane_dist of that Gaussian's plane (stable_xyz / stable_normal rows). */

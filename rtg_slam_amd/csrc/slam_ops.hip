@@ -633,6 +633,83 @@ __global__ void __launch_bounds__(256) sample_flags_kernel(const float* __restri
 
 static inline int grid1(long long n) { return (int)((n + 255) / 256); }
 
+// ---- the new Gaussians of a frame: what Mapping._new_points and the tail of Mapping.temp_to_optimize spell as ~80 torch
+// operations (gaussian_pointcloud.py:305-405, SLAM/utils.py:216-221, general_utils.py:185-191), as two kernels.  Same float32
+// operations in the same order (this file is built without FMA contraction), so results equal the torch form bit for bit
+// wherever torch's own kernels evaluate the same expression tree (tests/test_slam_ops_gpu.py).
+// gather_new_points: the sampled pixels `pick` -> position, UNIT normal, colour, rotation z -> normal.
+__global__ void __launch_bounds__(256) gather_new_points_kernel(const int64_t* __restrict__ pick, int n, const float* __restrict__ vertex,
+                                                                const float* __restrict__ normal, const float* __restrict__ color,
+                                                                int identity_rot, float* __restrict__ xyz, float* __restrict__ nrm,
+                                                                float* __restrict__ col, float* __restrict__ rot) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t q = pick[i];
+  const float vx = vertex[q * 3], vy = vertex[q * 3 + 1], vz = vertex[q * 3 + 2];
+  const float nx = normal[q * 3], ny = normal[q * 3 + 1], nz = normal[q * 3 + 2];
+  xyz[i * 3] = vx; xyz[i * 3 + 1] = vy; xyz[i * 3 + 2] = vz;
+  col[i * 3] = color[q * 3]; col[i * 3 + 1] = color[q * 3 + 1]; col[i * 3 + 2] = color[q * 3 + 2];
+  const float len = sqrtf((nx * nx + ny * ny) + nz * nz) + 1e-8f;         // normals / (norm + 1e-8), gaussian_pointcloud.py:315-318
+  const float tx = nx / len, ty = ny / len, tz = nz / len;
+  nrm[i * 3] = tx; nrm[i * 3 + 1] = ty; nrm[i * 3 + 2] = tz;
+  if (identity_rot) { rot[i * 4] = 1.f; rot[i * 4 + 1] = 0.f; rot[i * 4 + 2] = 0.f; rot[i * 4 + 3] = 0.f; return; }
+  // compute_rot((0, 0, 1), t): axis = z x t = (-t_y, t_x, 0), normalised TWICE as the reference does, angle = acos(t_z)
+  float ax = 0.f * tz - 1.f * ty, ay = 1.f * tx - 0.f * tz, az = 0.f * ty - 0.f * tx;
+  float al = sqrtf((ax * ax + ay * ay) + az * az) + 1e-8f;
+  ax = ax / al; ay = ay / al; az = az / al;
+  const float angle = acosf(tz);
+  al = sqrtf((ax * ax + ay * ay) + az * az) + 1e-8f;
+  ax = ax / al; ay = ay / al; az = az / al;
+  const float h = angle / 2.f, sh = sinf(h);
+  rot[i * 4] = cosf(h); rot[i * 4 + 1] = ax * sh; rot[i * 4 + 2] = ay * sh; rot[i * 4 + 3] = az * sh;
+}
+
+// new_rows: update_geometry (gaussian_pointcloud.py:366-405) + the packing of the new rows (mapper.py:886-899).  Candidate i
+// has its three nearest neighbours among (the n candidates, then the existing Gaussians): in-plane scale = rms of
+// (distance - 3 radius) over the three, clamped; a candidate INSIDE three radii of a neighbour is invalid.  Writes the packed
+// 59-column row of EVERY candidate (the caller keeps the valid ones) and the validity byte.
+__global__ void __launch_bounds__(256) new_rows_kernel(int n, const float* __restrict__ xyz, const float* __restrict__ color,
+                                                       const float* __restrict__ opacity_raw, const float* __restrict__ rots,
+                                                       const float* __restrict__ d2, const int32_t* __restrict__ idx,
+                                                       const float* __restrict__ exist_scales, float min_radius, float max_radius,
+                                                       float scale_factor, float fx, float fy, float fz,
+                                                       float* __restrict__ packed, uint8_t* __restrict__ valid) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int32_t j = idx[i * 3 + k];
+    float dist = 1e30f;
+    if (j >= 0) {
+      float radius = 1e-6f;                                          // get_radius of a still unscaled candidate
+      if (j >= n) {
+        const float* sc = exist_scales + (size_t)(j - n) * 3;
+        const float s0 = sc[0], s1 = sc[1], s2 = sc[2];
+        radius = (((s0 + s1) + s2) - fminf(fminf(s0, s1), s2)) / 2.f; // (sum - min) / 2, gaussian_pointcloud.py:515-519
+      }
+      dist = sqrtf(d2[i * 3 + k]) - 3.f * radius;
+    }
+    bad = bad || (dist < 0.f);
+    acc = k == 0 ? dist * dist : acc + dist * dist;
+  }
+  float sc = sqrtf(acc / 3.f);
+  sc = fminf(fmaxf(sc, min_radius), max_radius);
+  float* row = packed + (size_t)i * 59;
+#pragma unroll 1
+  for (int c = 0; c < 59; ++c) row[c] = 0.f;
+  row[0] = xyz[i * 3]; row[1] = xyz[i * 3 + 1]; row[2] = xyz[i * 3 + 2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) row[3 + c] = (color[i * 3 + c] - 0.5f) / 0.28209479177387814f;      // RGB2SH
+  row[51] = opacity_raw[i];
+  const float base = scale_factor * sc;
+  row[52] = logf(base * fx); row[53] = logf(base * fy); row[54] = logf(base * fz);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) row[55 + c] = rots[i * 4 + c];
+  valid[i] = bad ? 0 : 1;
+}
+
 }  // namespace rtgs_slam
 
 using namespace rtgs_slam;
@@ -1025,6 +1102,29 @@ __global__ void __launch_bounds__(256) attach_test_kernel(const float* __restric
   }
   attach[i] = a;
 }
+int rtgs_gather_new_points(const int64_t* pick, int32_t n, const float* vertex_map, const float* normal_map, const float* color_map,
+                           int32_t identity_rot, float* xyz, float* normal, float* color, float* rots, void* stream) {
+  if (n < 0) return -1;
+  if (n == 0) return 0;
+  if (!pick || !vertex_map || !normal_map || !color_map || !xyz || !normal || !color || !rots) return -1;
+  hipLaunchKernelGGL(gather_new_points_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, pick, (int)n, vertex_map, normal_map,
+                     color_map, (int)identity_rot, xyz, normal, color, rots);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_new_rows(int32_t n, const float* xyz, const float* color, const float* opacity_raw, const float* rots, const float* dist2,
+                  const int32_t* idx, const float* exist_scales, float min_radius, float max_radius, float scale_factor,
+                  float factor_x, float factor_y, float factor_z, float* packed59, uint8_t* valid, void* stream) {
+  if (n < 0) return -1;
+  if (n == 0) return 0;
+  if (!xyz || !color || !opacity_raw || !rots || !dist2 || !idx || !packed59 || !valid) return -1;
+  hipLaunchKernelGGL(new_rows_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, (int)n, xyz, color, opacity_raw, rots, dist2,
+                     idx, exist_scales, min_radius, max_radius, scale_factor, factor_x, factor_y, factor_z, packed59, valid);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
 int rtgs_attach_test(const float* points, int32_t n, const float* w2c16, float fx, float fy, float cx, float cy, int32_t H,
                      int32_t W, const int32_t* stable_color_index, const float* stable_xyz, const float* stable_normal,
                      float max_plane_dist, uint8_t* attach_out, void* stream) {

@@ -195,6 +195,31 @@ class HipOps:
     def knn_query(self, ref, query, self_offset=-1, ref_box=None):
         return self.so.knn_query(ref, query, self_offset, ref_box)
 
+    def sample_new_points(self, vertex, normal, color, n, mask, identity_rot):
+        """sample_pixels + the per-point part of add_empty_points (unit normal, rotation z -> normal) as ONE gather kernel
+        behind the draw (rtgs_gather_new_points) instead of three gathers and ~20 elementwise launches.  -> (xyz, unit
+        normal, colour, rotation), or None when nothing can be drawn."""
+        so = self.so
+        idx, count = so.sample_candidates(normal, mask)
+        n_cand = int(count.item())                       # the reference synchronises here too (boolean-mask indexing)
+        k = min(int(n), n_cand)
+        if k <= 0:
+            return None
+        pick = idx[:n_cand][torch.randperm(n_cand, device=idx.device, generator=self.gen)[:k]].long()
+        if k == 3:                                       # the reference's torch.cross quirk (compute_rot): keep the torch form
+            nrm = normal.reshape(-1, 3)[pick]
+            nrm = nrm / (torch.norm(nrm, p=2, dim=-1, keepdim=True) + 1e-8)
+            if identity_rot:
+                rot = torch.zeros(3, 4, device=nrm.device)
+                rot[:, 0] = 1
+            else:
+                rot = compute_rot(nrm)
+            return vertex.reshape(-1, 3)[pick], nrm, color.reshape(-1, 3)[pick], rot
+        return so.gather_new_points(pick, vertex, normal, color, identity_rot)
+
+    def new_rows(self, *a):
+        return self.so.new_rows(*a)
+
     def accumulate_gaussian_error(self, *a):
         return self.so.accumulate_gaussian_error(*a)
 
@@ -399,10 +424,15 @@ class Mapping:
         """GaussianPointCloud.add_empty_points (gaussian_pointcloud.py:305-364) for the sampled pixels of this frame: unit
         normals, SH dc from the colour, raw scale log(1e-6) until update_geometry, rotation z -> normal, init opacity.
         (sample_pixels never returns a pixel whose normal sums to zero, which is the only thing :319-322 filters.)"""
-        parts = [p for p in parts if p[0].shape[0] > 0]
+        parts = [p for p in parts if p is not None and p[0].shape[0] > 0]
         if not parts:
             return None
         a = self.args
+        if len(parts[0]) == 4:                           # ops.sample_new_points: normals are unit, rotations are there
+            cat = lambda k: parts[0][k] if len(parts) == 1 else torch.cat([p[k] for p in parts], 0)
+            xyz = cat(0)
+            return dict(xyz=xyz.contiguous(), normal=cat(1), color=cat(2), rots=cat(3),
+                        opacity_raw=torch.full((xyz.shape[0], 1), inverse_sigmoid(a.init_opacity), device=xyz.device))
         same = a.xyz_factor[0] == 1 and a.xyz_factor[1] == 1 and a.xyz_factor[2] == 1
         xyz, color = (torch.cat([p[k] for p in parts], 0) for k in (0, 2))
         # normals and rotations PER sampling pass, as add_empty_points is called (mapper.py:754, 794)
@@ -423,10 +453,16 @@ class Mapping:
 
     def temp_points_init(self, frame):
         a, fm = self.args, self.frame_map
+        fused = hasattr(self.ops, "sample_new_points")
+        same = a.xyz_factor[0] == 1 and a.xyz_factor[1] == 1 and a.xyz_factor[2] == 1
+
+        def draw(n, m):
+            if fused:
+                return self.ops.sample_new_points(fm["vertex_map_w"], fm["normal_map_w"], fm["color_map"], n, m, same)
+            return self.ops.sample_pixels(fm["vertex_map_w"], fm["normal_map_w"], fm["color_map"], n, m)
         if self.time == 0:
             mask = fm["depth_map"] > 0
-            return self._new_points([self.ops.sample_pixels(fm["vertex_map_w"], fm["normal_map_w"], fm["color_map"],
-                                                            a.uniform_sample_num, mask)])
+            return self._new_points([draw(a.uniform_sample_num, mask)])
         out = self._render(frame, "all")                                    # get_render_output (:727): the model at the new pose
         # transmission mask / error mask of :728-768 and their sizes in ONE pass over the frame (rtgs_add_masks)
         tmask, emask, counts = self.ops.add_masks(out["T_map"], fm["depth_map"], out["depth"], out["render"], fm["color_chw"],
@@ -440,7 +476,7 @@ class Mapping:
         parts = []
         for n, m in ((n_trans, tmask), (n_err, emask)):
             if n > 0:
-                parts.append(self.ops.sample_pixels(fm["vertex_map_w"], fm["normal_map_w"], fm["color_map"], n, m))
+                parts.append(draw(n, m))
         return self._new_points(parts)
 
     def temp_points_filter(self, temp, topk=3):
@@ -483,6 +519,20 @@ class Mapping:
         xyz = temp["xyz"].contiguous()
         n = xyz.shape[0]
         if n == 0:
+            return
+        if hasattr(self.ops, "new_rows"):
+            # the same arithmetic as below in ONE kernel behind the neighbour query (rtgs_new_rows): ~45 launches fewer per frame
+            gd = self.opt.gaussian_data("all")
+            d2, idx = self.ops.knn_query(torch.cat([xyz, gd["xyz"]]), xyz, 0, torch.cat([xyz.min(dim=0)[0] - 0.05, xyz.max(dim=0)[0] + 0.05]))
+            rows, valid = self.ops.new_rows(xyz, temp["color"], temp["opacity_raw"], temp["rots"], d2, idx, gd["scales"],
+                                            a.min_radius, a.max_radius, a.scale_factor, a.xyz_factor)
+            good = torch.nonzero(valid).reshape(-1)                  # synchronisation 2 of the add
+            m = int(good.shape[0])
+            if m == 0:
+                return
+            self.opt.append_rows(rows if m == n else rows[good], aux={"add_tick": int(self.time)})
+            self.stats["added"] += m
+            self.stats["last_add"] = (n_all, n, m)
             return
         gp = self.params("all")
         tiny = torch.full((n,), 1e-6, device=xyz.device)             # get_radius of the still unscaled temp points

@@ -240,6 +240,41 @@ def attach_test(points, w2c, fx, fy, cx, cy, H, W, stable_color_index, stable_xy
     return out
 
 
+def gather_new_points(pick, vertex_map, normal_map, color_map, identity_rot: bool):
+    """The sampled pixels of one pass -> (xyz [n,3], unit normal [n,3], colour [n,3], rotation [n,4]) in one kernel
+    (include/rtgs_slam.h: rtgs_gather_new_points).  Not for a pass of exactly three points (Mapping keeps the torch form there)."""
+    lib, dev = _lib.load(), _dev(vertex_map)
+    pick = pick.to(torch.int64).contiguous()
+    n = int(pick.shape[0])
+    v, nm, c = (t.float().contiguous() for t in (vertex_map, normal_map, color_map))
+    xyz, nrm, col = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
+    rot = torch.empty(n, 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_gather_new_points(_p(pick), n, _p(v), _p(nm), _p(c), int(bool(identity_rot)), _p(xyz), _p(nrm), _p(col), _p(rot),
+                                        _stream(dev))
+    _lib.check(rc, "rtgs_gather_new_points")
+    return xyz, nrm, col, rot
+
+
+def new_rows(xyz, color, opacity_raw, rots, d2, idx, exist_scales, min_radius, max_radius, scale_factor, xyz_factor):
+    """update_geometry + row packing for the new Gaussians of a frame in one kernel (include/rtgs_slam.h: rtgs_new_rows) ->
+    (packed [n,59] raw rows of every candidate, valid uint8 [n])."""
+    lib, dev = _lib.load(), _dev(xyz)
+    n = int(xyz.shape[0])
+    f = lambda t: t.float().contiguous()
+    xyz, color, opacity_raw, rots, d2 = f(xyz), f(color), f(opacity_raw), f(rots), f(d2)
+    idx = idx.to(torch.int32).contiguous()
+    es = f(exist_scales) if exist_scales is not None and exist_scales.numel() else None
+    packed = torch.empty(n, 59, dtype=torch.float32, device=dev)
+    valid = torch.empty(n, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_new_rows(n, _p(xyz), _p(color), _p(opacity_raw), _p(rots), _p(d2), _p(idx), _p(es), float(min_radius),
+                               float(max_radius), float(scale_factor), float(xyz_factor[0]), float(xyz_factor[1]),
+                               float(xyz_factor[2]), _p(packed), _p(valid), _stream(dev))
+    _lib.check(rc, "rtgs_new_rows")
+    return packed, valid
+
+
 def transform_map(map3: torch.Tensor, transform: torch.Tensor) -> torch.Tensor:
     """SLAM/utils.py:56-63: every 3-vector of `map3` [..., 3] through the 4x4 `transform` (its rotation only when the
     caller passes get_rot(c2w), as for normal maps).  One streaming kernel (a `@` would be a K = 3 GEMM)."""

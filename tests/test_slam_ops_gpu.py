@@ -323,3 +323,47 @@ def test_attach_test_vs_the_mapper_lines():
     want = so.attach_test(pts, w2c, fx, fy, cx, cy, H, W, cidx, sxyz, snrm, 0.05)
     diff = int((out != want).sum())
     assert 0 < int(want.sum()) < 3000 and diff <= 3, diff                # the projection is float32 either way: a pixel-border tie may flip
+
+
+def test_new_gaussian_kernels_equal_the_torch_form():
+    """rtgs_gather_new_points / rtgs_new_rows (round 6) against the tensor expressions they replace in Mapping._new_points and
+    Mapping.temp_to_optimize (this package's restatement of gaussian_pointcloud.py:305-405, SLAM/utils.py:216-221)."""
+    from rtg_slam_amd import mapping as mp, map_optim as mo, slam_ops as ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(5)
+    H, W = 60, 80
+    vertex = torch.randn(H, W, 3, generator=gen).to(dev)
+    normal = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=gen), dim=-1).to(dev) * 0.97      # not exactly unit: the kernel normalises
+    color = torch.rand(H, W, 3, generator=gen).to(dev)
+    pick = torch.randperm(H * W, generator=gen)[:777].to(dev)
+    for ident in (False, True):
+        xyz, nrm, col, rot = ops.gather_new_points(pick, vertex, normal, color, ident)
+        n_t = normal.reshape(-1, 3)[pick]
+        n_t = n_t / (torch.norm(n_t, p=2, dim=-1, keepdim=True) + 1e-8)
+        assert torch.equal(xyz, vertex.reshape(-1, 3)[pick]) and torch.equal(col, color.reshape(-1, 3)[pick])
+        assert (nrm - n_t).abs().max() < 1e-6
+        r_t = torch.tensor([1.0, 0, 0, 0], device=dev).repeat(777, 1) if ident else mp.compute_rot(n_t)
+        assert (rot - r_t).abs().max() < 2e-6
+    # new_rows: candidates + existing Gaussians, neighbours from the exact query
+    n, ne = 500, 3000
+    xyz = (torch.rand(n, 3, generator=gen) * 2).to(dev)
+    exist = (torch.rand(ne, 3, generator=gen) * 2).to(dev)
+    exist_scales = (0.002 + 0.03 * torch.rand(ne, 3, generator=gen)).to(dev)
+    colr = torch.rand(n, 3, generator=gen).to(dev)
+    opac = torch.full((n, 1), 4.5951, device=dev)
+    rots = torch.nn.functional.normalize(torch.randn(n, 4, generator=gen), dim=-1).to(dev)
+    lo, hi = xyz.min(dim=0)[0] - 0.05, xyz.max(dim=0)[0] + 0.05
+    d2, idx = ops.knn_query(torch.cat([xyz, exist]), xyz, 0, torch.cat([lo, hi]))
+    factor = [1.0, 1.0, 0.1]
+    rows, valid = ops.new_rows(xyz, colr, opac, rots, d2, idx, exist_scales, 0.001, 0.05, 1.0, factor)
+    radius = (exist_scales.sum(dim=1) - exist_scales.min(dim=1).values) / 2
+    total_radius = torch.cat([torch.full((n,), 1e-6, device=dev), radius])
+    dist = torch.sqrt(d2) - 3 * total_radius[idx.clamp_min(0).long()]
+    dist = torch.where(idx >= 0, dist, torch.full_like(dist, 1e30))
+    invalid = (dist < 0).any(dim=-1)
+    scales = torch.sqrt((dist ** 2).sum(dim=-1) / 3).clamp(0.001, 0.05)
+    log_scales = torch.log(1.0 * scales[:, None] * torch.tensor(factor, device=dev)[None, :])
+    assert torch.equal(valid.bool(), ~invalid) and 0 < int(invalid.sum()) < n
+    ref = torch.zeros(n, mo.COLS, device=dev)
+    ref[:, 0:3] = xyz; ref[:, 3:6] = mp.RGB2SH(colr); ref[:, 51:52] = opac; ref[:, 52:55] = log_scales; ref[:, 55:59] = rots
+    assert (rows - ref).abs().max() < 2e-6
