@@ -96,6 +96,11 @@ int rtgs_icp_track(const rtgs_icp_level* levels_host, int32_t n_levels, const fl
 #define RTGS_ICP_FLAG_SCRATCH_READY 4   /* scratch armed by rtgs_icp_scratch_init and only ever used by these entry points */
 #define RTGS_ICP_FLAG_FROM_IDENTITY 8   /* the initial guess is the identity: pose_inout need not be initialised (saves the
                                            caller two fill / copy launches) */
+#define RTGS_ICP_FLAG_F32_SOLVE 16      /* the Gauss-Newton update in FLOAT32 in the reference's order of operations (icp.py:248-334:
+                                           lev_mar_H, LU inverse as torch.inverse / LAPACK does it, -invH @ Rhs, exp_se3, exp @ pose)
+                                           instead of the float64 Cholesky; launch-per-iteration chain only.  A measurement aid: it
+                                           separates "the solve" from "gate-flip amplification" in the distance to the reference's
+                                           float32 answer on noisy depth */
 #define RTGS_ICP_FLAG_CLUSTER 2     /* every level but the finest in one launch on a cluster of workgroups of ONE XCD (an
                                        in-XCD barrier per Gauss-Newton iteration), the finest level one launch per iteration */
 

@@ -261,6 +261,58 @@ def full_size_cases():
               "valid", float(save["valid_ratio"]), "loss", float(save["p2p_loss"]), os.path.getsize(path), "B")
 
 
+def add_iteration_poses():
+    """Adds `iter_poses` [15, 4, 4] to tests/golden/icp_full_*.npz: the reference's pose after EACH Gauss-Newton iteration (the
+    loop of ICP.icp, /root/reference/SLAM/icp.py:33-48, written out with the class's own static methods so that the pose can
+    be read between iterations), 8 torch threads like `pose_final` - which the last entry must reproduce bit for bit, or the
+    file is left alone.  Round 6: tests/test_icp_gpu.py compares the kernel's float32-solve mode (RTGS_ICP_FLAG_F32_SOLVE)
+    and its float64 mode with these, iteration by iteration (where does the distance on the noisy frame come from?).
+        python -m oracle.gen_icp_golden iter"""
+    ref_icp, ref_utils = import_reference_icp()
+    sys.path.insert(0, ROOT)
+    from rtg_slam_amd import synth
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    torch.set_num_threads(8)
+    for name, cam, noise in (("full_replica_clean", synth.REPLICA, False), ("full_tum_noisy", synth.TUM_FR1, True)):
+        path = os.path.join(out_dir, f"icp_{name}.npz")
+        z = dict(np.load(path))
+        poses = synth.trajectory(2, seed=9)
+        base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
+        d0 = synth.box_room_depth(cam, base @ poses[0])
+        d1 = synth.box_room_depth(cam, base @ poses[1])
+        if noise:
+            d0, d1 = synth.tum_noise(d0, 1), synth.tum_noise(d1, 2)
+        K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32)
+        builder = ref_icp.ImagePyramids([2, 1, 0], "max")
+        vp0 = ref_utils.build_vertex_pyramid(d0, builder, K.clone())
+        np0 = ref_utils.build_normal_pyramid(vp0)
+        vp1 = ref_utils.build_vertex_pyramid(d1, builder, K.clone())
+        np1 = ref_utils.build_normal_pyramid(vp1)
+        pose = torch.eye(4)
+        its = []
+        for l, ds in enumerate([0.25, 0.5, 1.0]):
+            Kl = K * ds
+            Kl[2, 2] = 1.0
+            tracker = ref_icp.ICP(5, damping=1e-4, distance_threshold=0.1, normal_threshold=20)
+            mask0 = vp1[l][..., -1] > 0.0
+            for _ in range(tracker.max_iterations):
+                res, J, valid = tracker.compute_residuals_jacobian(vp1[l], vp0[l], np1[l], np0[l], mask0, pose, Kl,
+                                                                   tracker.distance_threshold, tracker.normal_threshold)
+                pose = tracker.GN_solver(tracker.compute_jtj(J), tracker.compute_jtr(J, res), pose, damping=tracker.damping)
+                its.append(pose.numpy().copy())
+        its = np.stack(its)
+        same = np.array_equal(its[-1], z["pose_final"])
+        print(name, "per-iteration loop reproduces pose_final bit for bit:", same, "| max |diff|", float(np.abs(its[-1] - z["pose_final"]).max()))
+        if not same:
+            continue
+        z["iter_poses"] = its
+        np.savez(path, **z)
+        print("wrote", path, "iter_poses", its.shape)
+
+
 if __name__ == "__main__":
-    main()
-    full_size_cases()
+    if len(sys.argv) > 1 and sys.argv[1] == "iter":
+        add_iteration_poses()
+    else:
+        main()
+        full_size_cases()

@@ -322,6 +322,7 @@ struct FinalArgs {
   float* nvalid_out;
   int first;       // bit 0: first iteration of a track (the last arriver clears the failure counters - no memset launch);
                    // bit 1: the track starts from the identity (`pose` is not read before the last arriver writes it)
+  int f32_solve;   // RTGS_ICP_FLAG_F32_SOLVE: damping, inverse, exp and pose product in float32 in the reference's order
 };
 
 // Sum of the per-workgroup partial rows in float64, by ONE whole workgroup (256 threads); the 28 totals land in
@@ -469,6 +470,117 @@ __device__ __forceinline__ bool gn_update(const double (&S)[NACC], float damping
   return true;
 }
 
+// The same update in FLOAT32 and in the reference's own order of operations (RTGS_ICP_FLAG_F32_SOLVE):
+// lev_mar_H (icp.py:248-256) -> invH = torch.inverse(H) on the CPU (:313-325: LAPACK sgetrf + sgetri, i.e. an LU with row
+// pivoting, U inverted, then inv(A) L = inv(U) solved column by column from the right) -> xi = -invH @ Rhs (:328-334) ->
+// exp_se3 with float32 sin / cos and its eps test (:271-310) -> exp(xi) @ pose.  The 27 sums still arrive in float64 (with
+// float64 sums and the float32 solve the reference's own code reproduces its float32 answer to 2e-9).  What this
+// cannot reproduce is the blocked / vectorised order INSIDE the library calls (sgetri's triangular solves, the 8-lane
+// horizontal sum behind torch.sum): differences of one float32 rounding remain.  Measured: tests/test_icp_gpu.py.
+__device__ __forceinline__ bool gn_update_f32(const double (&S)[NACC], float damping, float* pose) {
+  float A[6][6], b[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) {
+      const int idx = r * 6 - (r * (r - 1)) / 2 + (c - r);
+      A[r][c] = (float)S[idx]; A[c][r] = (float)S[idx];
+    }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) b[r] = (float)S[21 + r];
+  float tr = 0.f;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) tr = __fadd_rn(tr, A[r][r]);
+  const float eps = __fmul_rn(tr, damping);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) A[r][r] = __fadd_rn(A[r][r], eps);
+  // sgetf2: right-looking LU with partial pivoting (column scaled by the reciprocal pivot, rank-1 update)
+  int piv[6];
+  for (int k = 0; k < 6; ++k) {
+    int pk = k;
+    float mx = fabsf(A[k][k]);
+    for (int r = k + 1; r < 6; ++r) if (fabsf(A[r][k]) > mx) { mx = fabsf(A[r][k]); pk = r; }
+    piv[k] = pk;
+    if (mx == 0.f) return false;
+    if (pk != k) for (int c = 0; c < 6; ++c) { const float t = A[k][c]; A[k][c] = A[pk][c]; A[pk][c] = t; }
+    const float rp = __fdiv_rn(1.f, A[k][k]);
+    for (int r = k + 1; r < 6; ++r) A[r][k] = __fmul_rn(A[r][k], rp);
+    for (int r = k + 1; r < 6; ++r)
+      for (int c = k + 1; c < 6; ++c) A[r][c] = __fsub_rn(A[r][c], __fmul_rn(A[r][k], A[k][c]));
+  }
+  // strtri: inv(U) in place, column by column (upper, non-unit)
+  for (int j = 0; j < 6; ++j) {
+    A[j][j] = __fdiv_rn(1.f, A[j][j]);
+    const float ajj = -A[j][j];
+    // x = U(0:j, 0:j) * U(0:j, j)  (strmv, upper, no transpose: rows from the top, each using the already inverted block)
+    for (int r = 0; r < j; ++r) {
+      float t = 0.f;
+      bool first = true;
+      for (int c = r; c < j; ++c) {
+        const float pr = __fmul_rn(A[r][c], A[c][j]);
+        t = first ? pr : __fadd_rn(t, pr);
+        first = false;
+      }
+      // (strmv works in place top-down: row r of the product needs only entries r..j-1 of the vector, still untouched)
+      A[r][j] = t;
+    }
+    for (int r = 0; r < j; ++r) A[r][j] = __fmul_rn(A[r][j], ajj);
+  }
+  // sgetri: for j = n-1 .. 0: save L's column j, zero it, A(:, j) -= A(:, j+1:) * l(j+1:)
+  for (int j = 4; j >= 0; --j) {
+    float l[6];
+    for (int r = j + 1; r < 6; ++r) { l[r] = A[r][j]; A[r][j] = 0.f; }
+    for (int r = 0; r < 6; ++r) {
+      float t = A[r][j];
+      for (int c = j + 1; c < 6; ++c) t = __fsub_rn(t, __fmul_rn(A[r][c], l[c]));
+      A[r][j] = t;
+    }
+  }
+  // the column interchanges that undo the row pivoting
+  for (int j = 4; j >= 0; --j)
+    if (piv[j] != j) for (int r = 0; r < 6; ++r) { const float t = A[r][j]; A[r][j] = A[r][piv[j]]; A[r][piv[j]] = t; }
+  float xi[6];
+  for (int r = 0; r < 6; ++r) {
+    float t = __fmul_rn(-A[r][0], b[0]);
+    for (int c = 1; c < 6; ++c) t = __fadd_rn(t, __fmul_rn(-A[r][c], b[c]));
+    xi[r] = t;
+  }
+  // exp_se3, icp.py:271-310, float32
+  const float w0 = xi[0], w1 = xi[1], w2 = xi[2];
+  const float Wm[3][3] = {{0.f, -w2, w1}, {w2, 0.f, -w0}, {-w1, w0, 0.f}};
+  float W2[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) W2[r][c] = __fadd_rn(__fadd_rn(__fmul_rn(Wm[r][0], Wm[0][c]), __fmul_rn(Wm[r][1], Wm[1][c])), __fmul_rn(Wm[r][2], Wm[2][c]));
+  const float theta = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(w0, w0), __fmul_rn(w1, w1)), __fmul_rn(w2, w2)));
+  float E[3][3], Jl[3][3];
+  if (theta <= 1e-8f) {
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { E[r][c] = r == c ? 1.f : 0.f; Jl[r][c] = E[r][c]; }
+  } else {
+    const float t2 = __fmul_rn(theta, theta), t3 = __fmul_rn(t2, theta), st = sinf(theta), ct = cosf(theta);
+    const float k1 = __fdiv_rn(__fsub_rn(1.f, ct), t2), k2 = __fdiv_rn(__fsub_rn(theta, st), t3);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        const float I = r == c ? 1.f : 0.f;
+        // eye + w_hat * sin / theta + w_hat_second * (1 - cos) / theta^2   (left to right, as the expression is written)
+        E[r][c] = __fadd_rn(__fadd_rn(I, __fdiv_rn(__fmul_rn(Wm[r][c], st), theta)), __fdiv_rn(__fmul_rn(W2[r][c], __fsub_rn(1.f, ct)), t2));
+        Jl[r][c] = __fadd_rn(__fadd_rn(I, __fmul_rn(k1, Wm[r][c])), __fmul_rn(k2, W2[r][c]));
+      }
+  }
+  float tv[3];
+  for (int r = 0; r < 3; ++r) tv[r] = __fadd_rn(__fadd_rn(__fmul_rn(Jl[r][0], xi[3]), __fmul_rn(Jl[r][1], xi[4])), __fmul_rn(Jl[r][2], xi[5]));
+  float Pm[4][4];
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Pm[r][c] = pose[r * 4 + c];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) {
+      float o = __fmul_rn(E[r][0], Pm[0][c]);
+      o = __fadd_rn(o, __fmul_rn(E[r][1], Pm[1][c]));
+      o = __fadd_rn(o, __fmul_rn(E[r][2], Pm[2][c]));
+      o = __fadd_rn(o, __fmul_rn(tv[r], Pm[3][c]));
+      pose[r * 4 + c] = o;
+    }
+  return true;
+}
+
 // Executed by ONE whole workgroup (256 threads): the last one to arrive in the residual kernel.
 __device__ __forceinline__ void final_stage(const float* __restrict__ partials, int nblocks, const FinalArgs& fa) {
   __shared__ double s_sum[32 * PSTRIDE];
@@ -498,7 +610,7 @@ __device__ __forceinline__ void final_stage(const float* __restrict__ partials, 
     for (int k = 0; k < 16; ++k) fa.pose[k] = (k % 5 == 0) ? 1.f : 0.f;
   }
   fa.stats[0] = (float)(S[27] * (double)fa.inv_pixels);            // valid_ratio (icp.py:46-47)
-  if (!gn_update(S, fa.damping, fa.pose)) fa.stats[2] += 1.f;
+  if (!(fa.f32_solve ? gn_update_f32(S, fa.damping, fa.pose) : gn_update(S, fa.damping, fa.pose))) fa.stats[2] += 1.f;
 }
 
 // Publish this workgroup's partial row and elect the last arriver.  Hand-off form (cdna_hip_programming.md
@@ -931,6 +1043,7 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
   const bool persistent = env_persistent >= 0 ? env_persistent == 1 : (flags & RTGS_ICP_FLAG_PERSISTENT) != 0;
   static const int env_cluster = [] { const char* e = getenv("RTGS_ICP_CLUSTER"); return e ? atoi(e) : -1; }();
   const int cluster = env_cluster >= 0 ? env_cluster : ((flags & RTGS_ICP_FLAG_CLUSTER) ? 64 : 0);
+  if ((flags & RTGS_ICP_FLAG_F32_SOLVE) && (persistent || (cluster > 0 && n_levels >= 2))) return -1;   // the launch-per-iteration chain only
   const bool plain = !persistent && !(cluster > 0 && n_levels >= 2);
   if (!(plain && ready)) {
     ICP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(float), st));
@@ -995,7 +1108,7 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
     // last arriver to collect
     const int g = grid_for((L.H * L.W + 3) / 4);
     const float inv = 1.f / ((float)L.H * (float)L.W);
-    FinalArgs fa{(int)MODE_SOLVE, damping, inv, pose, stats, nullptr, nullptr, nullptr, 0};
+    FinalArgs fa{(int)MODE_SOLVE, damping, inv, pose, stats, nullptr, nullptr, nullptr, 0, (flags & RTGS_ICP_FLAG_F32_SOLVE) ? 1 : 0};
     for (int it = 0; it < L.iters; ++it) {   // ONE launch per Gauss-Newton iteration: residuals + solve + pose update
       fa.first = (plain && !launched_any) ? (1 | (from_identity ? 2 : 0)) : 0;
       launched_any = true;
@@ -1014,7 +1127,7 @@ int rtgs_icp_track(const rtgs_icp_level* lv, int32_t n_levels, const float* K, f
   const rtgs_icp_level& F = lv[n_levels - 1];
   const int n = F.H * F.W;
   const int g = grid_for(n);
-  FinalArgs fp{(int)MODE_P2P, 0.f, 1.f / (float)n, pose, stats, nullptr, nullptr, nullptr};
+  FinalArgs fp{(int)MODE_P2P, 0.f, 1.f / (float)n, pose, stats, nullptr, nullptr, nullptr, 0, 0};
   hipLaunchKernelGGL(icp_p2p_kernel, dim3(g), dim3(256), 0, st, F.vertex_src, F.vertex_tgt, F.normal_tgt, n,
                      (const float*)pose, sc->partials, &sc->ticket, fp);
   ICP_TRY(hipGetLastError());

@@ -34,7 +34,7 @@ def _vp(t: torch.Tensor):
 
 _scratch = {}
 _builds = {}            # pyramid builds per scratch: the min / max set alternates (include/rtgs_icp.h)
-FLAG_PERSISTENT, FLAG_CLUSTER, FLAG_SCRATCH_READY, FLAG_FROM_IDENTITY = 1, 2, 4, 8
+FLAG_PERSISTENT, FLAG_CLUSTER, FLAG_SCRATCH_READY, FLAG_FROM_IDENTITY, FLAG_F32_SOLVE = 1, 2, 4, 8, 16
 PYR_SCRATCH_READY, PYR_SECOND_SET = 1, 2
 
 
@@ -109,9 +109,12 @@ def icp_step(v_src, n_src, v_tgt, n_tgt, K, pose, dist_thr: float, cos_thr: floa
 
 def icp_track(vertex_src: Sequence[torch.Tensor], normal_src, vertex_tgt, normal_tgt, K: torch.Tensor,
               downscales: Sequence[float], iters: Sequence[int], dist_thr: float, cos_thr: float,
-              damping: float, pose0: torch.Tensor | None = None, persistent: bool = False) -> torch.Tensor:
+              damping: float, pose0: torch.Tensor | None = None, persistent: bool = False,
+              f32_solve: bool = False) -> torch.Tensor:
     """The level loop of IcpTracker.predict_pose (icp.py:428-447) on the device.
-    Returns a device float32[20]: pose (16, row-major) + [valid_ratio, p2p_loss, n_singular, aborted]."""
+    Returns a device float32[20]: pose (16, row-major) + [valid_ratio, p2p_loss, n_singular, aborted].
+    f32_solve: the Gauss-Newton update in float32 in the reference's order of operations (RTGS_ICP_FLAG_F32_SOLVE,
+    include/rtgs_icp.h) - a measurement aid, launch-per-iteration chain only."""
     lib = _lib.load()
     dev = vertex_src[0].device
     _require_device(vertex_src[0])
@@ -125,7 +128,7 @@ def icp_track(vertex_src: Sequence[torch.Tensor], normal_src, vertex_tgt, normal
                                ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr())
     K = _f32c(K.to(dev))
     out = torch.empty(20, dtype=torch.float32, device=dev)
-    flags = (FLAG_PERSISTENT if persistent else 0) | FLAG_SCRATCH_READY
+    flags = (FLAG_PERSISTENT if persistent else 0) | FLAG_SCRATCH_READY | (FLAG_F32_SOLVE if f32_solve else 0)
     if pose0 is None:
         flags |= FLAG_FROM_IDENTITY            # the first iteration's last workgroup writes the pose: no fill / copy launches
     else:

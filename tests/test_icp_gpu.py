@@ -283,3 +283,65 @@ def test_pyramids_on_sizes_that_are_not_multiples_of_four(H, W):
         assert hv[l].shape == vp[l].shape
         assert torch.equal(hv[l].cpu(), vp[l]), l
         assert torch.equal(hn[l].cpu(), npyr[l]), l
+
+
+@pytest.mark.parametrize("name,cam,noise", [("full_replica_clean", synth.REPLICA, False), ("full_tum_noisy", synth.TUM_FR1, True)])
+def test_where_the_distance_to_the_reference_comes_from_iteration_by_iteration(golden_dir, name, cam, noise):
+    """VERDICT r5 item 7.  The reference's pose after EACH of its 15 Gauss-Newton iterations (tests/golden/icp_full_*.npz::iter_poses,
+    written by oracle/gen_icp_golden.py::add_iteration_poses from the reference's own static methods; its last entry is
+    `pose_final` bit for bit) against the kernel stepped one iteration at a time, in both solve modes: float64 Cholesky (the
+    product) and float32 in the reference's order of operations (RTGS_ICP_FLAG_F32_SOLVE).  What it settles: on the clean
+    frame both modes stay at float32 rounding of the reference through all 15 iterations; on the noisy TUM-shaped frame the
+    distance is born in single iterations where association gates flip (it jumps by an order of magnitude between two
+    consecutive iterations, in BOTH modes) - it is not the solve's precision, and a float32 solve does not bring it under
+    north_star's 1e-5.  The numbers are printed and recorded (profiles/r06_parity_margins.json)."""
+    from rtg_slam_amd import icp
+    g = load(golden_dir, name)
+    assert "iter_poses" in g and tuple(g["iter_poses"].shape) == (15, 4, 4)
+    assert torch.equal(g["iter_poses"][-1], g["pose_final"])
+    poses = synth.trajectory(2, seed=9)
+    base = synth.look_at_pose(seed=3, max_angle_deg=5, max_trans=0.3)
+    d0 = synth.box_room_depth(cam, base @ poses[0])
+    d1 = synth.box_room_depth(cam, base @ poses[1])
+    if noise:
+        d0, d1 = synth.tum_noise(d0, 1), synth.tum_noise(d1, 2)
+    K = g["K"]
+    hv0, hn0 = icp.build_pyramids(d0.to(DEV), K.to(DEV), 3)
+    hv1, hn1 = icp.build_pyramids(d1.to(DEV), K.to(DEV), 3)
+    cos_thr = float(np.cos(np.deg2rad(20.0)))
+    ref = g["iter_poses"]
+    curves = {}
+    for mode in ("f64", "f32"):
+        pose = torch.eye(4, device=DEV)
+        errs = []
+        for l, ds in enumerate([0.25, 0.5, 1.0]):
+            for _ in range(5):
+                out = icp.icp_track([hv1[l]], [hn1[l]], [hv0[l]], [hn0[l]], K, [ds], [1], 0.1, cos_thr, 1e-4, pose0=pose,
+                                    f32_solve=(mode == "f32"))
+                pose = out[:16].reshape(4, 4).clone()
+                errs.append(float((pose.cpu() - ref[len(errs)]).abs().max()))
+        curves[mode] = errs
+        # stepping one iteration per call IS the 15-iteration chain (same launches, same arithmetic)
+        whole = icp.icp_track(hv1, hn1, hv0, hn0, K, [0.25, 0.5, 1.0], [5, 5, 5], 0.1, cos_thr, 1e-4, f32_solve=(mode == "f32")).cpu()
+        assert torch.equal(whole[:16].reshape(4, 4), pose.cpu())
+    # teacher-forced: ONE iteration from the reference's own pose of the iteration before - the solve alone, no history
+    forced = {"f64": [], "f32": []}
+    for mode in ("f64", "f32"):
+        for it in range(15):
+            l = it // 5
+            start = torch.eye(4) if it == 0 else ref[it - 1]
+            out = icp.icp_track([hv1[l]], [hn1[l]], [hv0[l]], [hn0[l]], K, [[0.25, 0.5, 1.0][l]], [1], 0.1, cos_thr, 1e-4,
+                                pose0=start.to(DEV), f32_solve=(mode == "f32")).cpu()
+            forced[mode].append(float((out[:16].reshape(4, 4) - ref[it]).abs().max()))
+    fmt = lambda v: " ".join(f"{x:.1e}" for x in v)
+    print(f"{name}: |hip - reference| after each iteration, float64 solve: {fmt(curves['f64'])}")
+    print(f"{name}: |hip - reference| after each iteration, float32 solve: {fmt(curves['f32'])}")
+    print(f"{name}: ONE iteration from the reference's previous pose, float64 solve: {fmt(forced['f64'])}")
+    print(f"{name}: ONE iteration from the reference's previous pose, float32 solve: {fmt(forced['f32'])}")
+    margins.record("per_iteration", free_running_f64=curves["f64"], free_running_f32=curves["f32"],
+                   one_step_from_reference_pose_f64=forced["f64"], one_step_from_reference_pose_f32=forced["f32"])
+    tol = full_tol(g)
+    assert curves["f64"][-1] < tol and curves["f32"][-1] < 4 * tol
+    if not noise:
+        assert max(curves["f64"]) < 1e-6 and max(curves["f32"]) < 1e-6
+        assert max(forced["f64"]) < 1e-6 and max(forced["f32"]) < 1e-6
