@@ -453,7 +453,7 @@ class Mapping:
 
     def temp_points_init(self, frame):
         a, fm = self.args, self.frame_map
-        fused = hasattr(self.ops, "sample_new_points")
+        fused = getattr(self.ops, "sample_new_points", None) is not None
         same = a.xyz_factor[0] == 1 and a.xyz_factor[1] == 1 and a.xyz_factor[2] == 1
 
         def draw(n, m):
@@ -520,7 +520,7 @@ class Mapping:
         n = xyz.shape[0]
         if n == 0:
             return
-        if hasattr(self.ops, "new_rows"):
+        if getattr(self.ops, "new_rows", None) is not None:
             # the same arithmetic as below in ONE kernel behind the neighbour query (rtgs_new_rows): ~45 launches fewer per frame
             gd = self.opt.gaussian_data("all")
             d2, idx = self.ops.knn_query(torch.cat([xyz, gd["xyz"]]), xyz, 0, torch.cat([xyz.min(dim=0)[0] - 0.05, xyz.max(dim=0)[0] + 0.05]))

@@ -159,10 +159,15 @@ def test_the_product_lifecycle_against_the_references_own_mapping(golden, changi
     0 of 3 072 pixels differ, T within 3e-7); what flips is the attach test of a few new points (observed 4 of 78): they were
     sampled AT pixel centres, so their re-projection lands on an integer +- rounding and `.long()` (mapper.py:842-846) picks
     either neighbour pixel - HIP's explicit sums and torch's matmul round differently there, as two BLAS builds would.  Such a
-    point starts at opacity 0.1 on one side and at init_opacity on the other.  Observed: both sizes EQUAL the reference's after
-    all seven frames, confidence / ticks equal on every row, parameters within 5e-3 on 94.9-100 % of the rows.  Bounds per frame: both sizes within 4 % of the
-    reference's, most frames exactly equal; where equal, rows matched by position agree - confidence / ticks on >= 95 % of the
-    rows, parameters within 5e-3 on >= 90 %.
+    point starts at opacity 0.1 on one side and at init_opacity on the other.  Round 6: the test EXPLAINS
+    instead of tolerating.  The flipped rows are identified by what the decision leaves behind - the raw opacity, which never
+    moves again (opacity_lr 0) - their difference must be exactly inverse_sigmoid(init_opacity) - inverse_sigmoid(0.1), they are
+    counted (printed; <= max(5, 4 %) of a cloud) and only they are excluded; on EVERY other row: confidence and ticks equal,
+    error counters equal up to one strike on <= 2 % of the rows, parameters within 1e-4 on 100 % of the rows of every frame
+    WITHOUT optimisation (observed 4e-6) - on the frames with 50 Adam iterations the bound stays a share (>= 90 % within 5e-3):
+    Adam at eps 1e-15 turns the sign of a ~0 gradient into a learning-rate-sized step, and two rasterizers agree to 1e-3 of a
+    gradient tensor's maximum, not on those signs (the CPU double of this test, one rasterizer on both sides, holds 8.5e-6).  Sizes: within 4 % of the reference's
+    per frame (a flipped point can change a later filter decision), exactly equal on most frames.
     Second stream (`changing`): fifteen frames with a scene change from frame 2 on - colour-error strikes, releases, a 200-row
     fix - so the HIP error accumulation and the counters run against the reference's decisions too (a strike is a threshold
     on a per-Gaussian mean error: the counters may differ by one on a few rows)."""
@@ -184,10 +189,12 @@ def test_the_product_lifecycle_against_the_references_own_mapping(golden, changi
         pick = idx[torch.randperm(idx.numel())[:n]].to(dev)
         return vertex.reshape(-1, 3)[pick], normal.reshape(-1, 3)[pick], color.reshape(-1, 3)[pick]
     ops.sample_pixels = sample_pixels
+    ops.sample_new_points = None          # the draw follows the reference's rule (above), not the product's fused device-side form
     m = mp.Mapping(args, dev, ops=ops, capacity=600)
     m.rng = random
     verbose = bool(os.environ.get("RTGS_TEST_VERBOSE"))
-    equal_frames, sizes, worst = 0, [], dict(exact=1.0, params=1.0)
+    equal_frames, sizes, worst = 0, [], dict(counters_equal=1.0, params_max=0.0, optimised_share=1.0)
+    n_flipped = n_rows = 0
     for fid, (d, c, c2w) in enumerate((tm._changing_stream if changing else tm._stream)(n_frames)):
         random.setstate((3, tuple(int(v) for v in ref[f"f{fid}_rng_py"]), None))
         torch.set_rng_state(torch.from_numpy(ref[f"f{fid}_rng_torch"]))
@@ -217,16 +224,42 @@ def test_the_product_lifecycle_against_the_references_own_mapping(golden, changi
                         "color_error_counter": o.aux["color_error_counter"][r0:r1].cpu().float()}
                 match = torch.cdist(mine["xyz"].double(), want["xyz"].double()).argmin(dim=1)
                 n = r1 - r0
+                # The rows whose ATTACH decision fell the other way are found by what that decision leaves behind - the raw
+                # opacity (opacity_lr is 0: it never moves again): inverse_sigmoid(0.1) on one side, inverse_sigmoid(init_opacity)
+                # on the other.  They are excluded from the parameter comparison (and only they), counted, and their difference
+                # must be exactly that alternative - anything else in the opacity column is a finding.
+                dop = (mine["opacity"].reshape(n) - want["opacity"][match].reshape(n)).abs()
+                flipped = dop > 1e-3
+                alt = abs(mp.inverse_sigmoid(args.init_opacity) - mp.inverse_sigmoid(0.1))
+                assert bool(((dop[flipped] - alt).abs() < 1e-3).all()), (fid, tag, dop[flipped])
+                n_flipped += int(flipped.sum())
+                n_rows += n
+                assert int(flipped.sum()) <= max(5, int(0.04 * n)), (fid, tag, int(flipped.sum()), n)
+                keepr = ~flipped
                 for k in mine:
                     e = (mine[k].reshape(n, -1) - want[k][match].reshape(n, -1)).abs().max(1).values
                     exact = k in ("confidence", "add_tick", "depth_error_counter", "color_error_counter")
-                    share = float((e <= (0.0 if exact else 5e-3)).float().mean())
-                    if k.endswith("_counter"):
-                        assert float(e.max()) <= 1.0, (fid, tag, k, float(e.max()))
-                    worst["exact" if exact else "params"] = min(worst["exact" if exact else "params"], share)
                     if verbose:
-                        print(fid, tag, k, "rows", n, "share within bound", round(share, 4), "max", float(e.max()), "median", float(e.median()))
-                    assert share >= (0.95 if exact else 0.90), (fid, tag, k, share)
+                        print(fid, tag, k, "rows", n, "flipped", int(flipped.sum()), "max over the others", float(e[keepr].max()) if bool(keepr.any()) else 0.0)
+                    if k.endswith("_counter"):
+                        # a strike is a threshold on a per-Gaussian MEAN error: a counter may be one strike apart on a few rows
+                        assert float(e.max()) <= 1.0 and float((e > 0).float().mean()) <= 0.02, (fid, tag, k, float(e.max()), float((e > 0).float().mean()))
+                        worst["counters_equal"] = min(worst["counters_equal"], float((e == 0).float().mean()))
+                    elif exact:
+                        assert float(e.max()) == 0.0, (fid, tag, k, float(e.max()))                     # every row, flipped or not
+                    elif k != "opacity" and bool(keepr.any()):
+                        if fid in m.optimize_frames_ids:
+                            # a frame with 50 Adam iterations (eps 1e-15): where a gradient is ~0 its SIGN decides a learning-
+                            # rate-sized step, and the HIP rasterizer's gradients equal the oracle's to 1e-3 of the tensor
+                            # maximum, not to the sign of every ~0 entry (on the CPU, with one rasterizer on both sides, the
+                            # same lifecycle holds 8.5e-6: tests/test_mapping_cpu.py).  Share bound there, as before.
+                            share = float((e[keepr] <= 5e-3).float().mean())
+                            worst["optimised_share"] = min(worst["optimised_share"], share)
+                            assert share >= 0.90, (fid, tag, k, share)
+                        else:
+                            # every other frame: every row but the flipped ones, 100 % of them
+                            worst["params_max"] = max(worst["params_max"], float(e[keepr].max()))
+                            assert float(e[keepr].max()) <= 1e-4, (fid, tag, k, float(e[keepr].max()))
                 # teacher forcing: the reference's state, in the reference's row order
                 g = lambda k: torch.from_numpy(ref[f"f{fid}_{tag}_{k}"]).to(dev)
                 o.state["xyz"]["p"][r0:r1] = g("xyz")
@@ -241,4 +274,11 @@ def test_the_product_lifecycle_against_the_references_own_mapping(golden, changi
     assert m.optimize_frames_ids == ref["optimize_frames_ids"].tolist() and m.keyframe_ids == ref["keyframe_ids"].tolist()
     assert equal_frames >= n_frames - (5 if changing else 3) and sizes[0][0] == sizes[0][1], sizes
     print("(product, reference) sizes per frame:", sizes, "- frames with equal sizes:", equal_frames, "of", n_frames,
-          "- smallest share of rows within the bounds:", worst)
+          f"- rows excluded because their attach decision flipped: {n_flipped} of {n_rows} compared; on ALL other rows: confidence / "
+          f"ticks equal, largest parameter difference on frames without optimisation {worst['params_max']:.2e} (bound 1e-4), smallest "
+          f"share within 5e-3 on frames with 50 Adam iterations {worst['optimised_share']:.4f} (bound 0.90), smallest share of equal "
+          f"error counters {worst['counters_equal']:.4f}")
+    from tests import margins
+    margins.record("lifecycle", rows_compared=n_rows, rows_excluded_attach_flipped=n_flipped, params_max_other_rows_unoptimised_frames=worst["params_max"],
+                   share_within_5e3_optimised_frames=worst["optimised_share"],
+                   counters_equal_share=worst["counters_equal"], frames_with_equal_sizes=equal_frames, frames=n_frames)
