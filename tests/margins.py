@@ -19,15 +19,18 @@ def record(section, **values):
     """Merge `values` (numbers / short lists) under the current test's node id and `section`."""
     node = os.environ.get("PYTEST_CURRENT_TEST", "unknown").split(" (")[0]
     try:
+        import fcntl
         os.makedirs(os.path.dirname(PATH), exist_ok=True)
-        data = {}
-        if os.path.exists(PATH):
-            with open(PATH) as f:
-                data = json.load(f)
-        data.setdefault(node, {}).setdefault(section, {}).update(values)
-        tmp = PATH + ".tmp%d" % os.getpid()
-        with open(tmp, "w") as f:
-            json.dump(data, f, indent=1, sort_keys=True)
-        os.replace(tmp, PATH)
-    except OSError:
+        with open(PATH + ".lock", "w") as lock:              # the suite runs in several worker processes (pytest.ini)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            data = {}
+            if os.path.exists(PATH):
+                with open(PATH) as f:
+                    data = json.load(f)
+            data.setdefault(node, {}).setdefault(section, {}).update(values)
+            tmp = PATH + ".tmp%d" % os.getpid()
+            with open(tmp, "w") as f:
+                json.dump(data, f, indent=1, sort_keys=True)
+            os.replace(tmp, PATH)
+    except (OSError, ValueError):
         pass
