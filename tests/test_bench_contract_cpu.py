@@ -69,5 +69,24 @@ def test_the_committed_bench_line_has_the_contracts_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port")
-    # value is the whole-job rate of the timed block
+    # value is the whole-job rate of the timed block (since round 6: the MEDIAN of the five blocks; the first is beside it)
     assert abs(d["value"] - 1e3 * d["n_gpus"] / d["ms_per_step"]) / d["value"] < 0.01
+    if files[-1] >= "r06":
+        assert "first_block_ms_per_step" in d and d["repeats"]["blocks"] == 5
+        assert abs(d["ms_per_step"] - d["repeats"]["median_ms_per_step"]) < 2e-3
+        # BASELINE.json's three quantities where the driver's parser keeps VALUES: inside `config` / `roofline`
+        cfg = d["config"]
+        for k in ("slam_frames_per_sec", "raster_fwd_bwd_ms", "raster_fwd_bwd_ms_surface", "map_iteration_ms", "map_iteration_ms_surface",
+                  "icp_track_ms", "icp_track_ms_tum_480x640_noisy", "hbm_frac_blend_fwd_plus_bwd", "config0_cpu_frames_per_sec",
+                  "config5_ms_per_iteration"):
+            assert isinstance(cfg[k], (int, float)) and cfg[k] > 0, k
+        assert cfg["slam_frames_per_sec"] == d["slam_frames_per_sec"] and cfg["raster_fwd_bwd_ms"] == d["raster_fwd_bwd_ms"]
+        assert 0 < r["frac_blend_fwd_plus_bwd"] < 1 and 0 < r["frac_blend_fwd_plus_bwd_surface"] < 1
+        # configs[0]: 50 frames at GT poses through the CPU render path (in the cpu_baseline leg)
+        c0 = c["config0"]
+        assert c0["frames"] == 50 and c0["poses"] == "ground truth" and c0["cpu_frames_per_sec"] > 0 and c0["psnr_mean_db"] > 24
+        assert c0["max_abs_colour_diff_hip_vs_cpu"] < 2e-3
+        # configs[4]: the median of ten iterations, measured after iterations WITH the phase marks (the driver's r5 line held a cold one)
+        assert len(c5["ms_each_iteration"]) == 10 and c5["untimed_iterations_before"] >= 3
+        assert abs(c5["ms_per_iteration"] - sorted(c5["ms_each_iteration"])[5]) < 1e-3
+        assert max(c5["host_enqueue_ms_per_iteration"]) < 5.0
