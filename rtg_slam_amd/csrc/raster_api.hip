@@ -30,7 +30,7 @@ void launch_blend_bwd(const RasterParams&, const uint2*, const uint32_t*, const 
                       const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, int, uint32_t, uint32_t, hipStream_t);
 void launch_blend_bwd_entry(const RasterParams&, const uint2*, const uint32_t*, const Splat*, const float*, const uint32_t*,
                             const int32_t*, const uint32_t*, const uint32_t*, const float*, const float*, const uint32_t*, uint32_t*,
-                            const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, uint32_t, TileCache, hipStream_t);
+                            const BwdInfo*, SplatGrad*, uint8_t*, const uint32_t*, uint32_t, uint32_t, TileCache, uint32_t, hipStream_t);
 void launch_grad_reduce(int, const uint8_t*, const uint32_t*, uint32_t*, const BwdInfo*, SplatGrad*, const uint32_t*, hipStream_t);
 void launch_preprocess_bwd(const RasterParams&, const float*, const float*, const float*, const float*, const float*,
                            const float*, const int32_t*, const uint8_t*, SplatGrad*, uint8_t*, uint8_t*, float*, float*,
@@ -912,6 +912,7 @@ static int backward_impl(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_t P
                                out_didx, depth_pos, (const uint32_t*)(img + I.tile_last), dL_dcolor, dL_ddepth, gbase, slot_count, binfo, grads,
                                touched, tile_mode, t0, tn,
                                TileCache{(float4*)(img + I.tile_recs), (uint16_t*)(img + I.tile_masks), (float2*)(img + I.depth_aux)},
+                               set == 0 ? (uint32_t)(BLOCK / 4) : (uint32_t)BLOCK,      // the near slice's first batch is a quarter batch
                                st);
     }
     prof_mark(c, EV_BWALK, st);

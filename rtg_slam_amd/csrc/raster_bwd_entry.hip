@@ -329,7 +329,7 @@ __device__ __forceinline__ void blend_bwd_entry_body(
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
     const uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_count, const BwdInfo* __restrict__ info,
     SplatGrad* __restrict__ grads, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_mode,
-    uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long* __restrict__ stamps, const TileCache& tc) {
+    uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long* __restrict__ stamps, const TileCache& tc, uint32_t pre) {
   __shared__ float4 s_rec[MB * 3];              // u v ca cb | cc o r g | b id blockmask -
   __shared__ float s_acc[MB * MACC];            // per-entry sums of the tile (LDS float adds: one flush per wave and group)
   __shared__ uint8_t s_sub[4][MB];              // per quadrant: the staged entries that reach it, in list order
@@ -371,8 +371,12 @@ __device__ __forceinline__ void blend_bwd_entry_body(
     L.gD = dL_ddepth[pix];
     L.dpos = depth_pos[pix];
     {
+      // the records of the first `pre` list positions travel with the prologue (64 behind a near-slice pass - its first batch,
+      // where most tiles end: a mean of 53 entries on the headline scene - else the whole cache line-up of 256: all 256 for
+      // every tile were 40 MB of reads per launch that 78 % of the headline's tiles never used, PMC traffic 3.3x algorithmic);
+      // a tile that walks deeper fetches the rest once its length is known - one more round trip, still no dependent chain
       const float4* const rsrc = tc.recs + ((size_t)tile * TILE_RECS + (size_t)tl) * 3;
-      L.c0 = rsrc[0]; L.c1 = rsrc[1]; L.c2 = rsrc[2];
+      if ((uint32_t)tl < pre) { L.c0 = rsrc[0]; L.c1 = rsrc[1]; L.c2 = rsrc[2]; }
       L.mk = reinterpret_cast<const uint2*>(tc.masks + (size_t)tile * TILE_RECS)[tl & 63];      // entries 4 lane .. 4 lane + 3
       L.aux = tc.depth_aux[pix];
     }
@@ -543,7 +547,15 @@ __device__ __forceinline__ void blend_bwd_entry_body(
     if (nuse > 0) {
       if (cached) {
         // the forward's records: already in registers, one LDS write; the sub-list from the block masks, by this wave alone
-        if (tid < m) { s_rec[tid * 3 + 0] = L.c0; s_rec[tid * 3 + 1] = L.c1; s_rec[tid * 3 + 2] = L.c2; }
+        if (tid < m) {
+          if ((uint32_t)tid >= pre) {
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            const float4* const rsrc = tc.recs + ((size_t)tile * TILE_RECS + (size_t)tl) * 3;
+            L.c0 = rsrc[0]; L.c1 = rsrc[1]; L.c2 = rsrc[2];
+          }
+          s_rec[tid * 3 + 0] = L.c0; s_rec[tid * 3 + 1] = L.c1; s_rec[tid * 3 + 2] = L.c2;
+        }
         cnt = compact_quadrant(L.mk, qmask, m, lane, s_sub[wv]);
       } else {
         cnt = stage_gather(0, m);
@@ -635,10 +647,10 @@ __device__ __forceinline__ void blend_bwd_entry_body(
       const float *__restrict__ dL_ddepth, const uint32_t *__restrict__ gbase, uint32_t *__restrict__ slot_count,                    \
       const BwdInfo *__restrict__ info, SplatGrad *__restrict__ grads, uint8_t *__restrict__ touched,                               \
       const uint32_t *__restrict__ tile_mode, uint32_t t0, uint32_t tn, uint32_t dbg, unsigned long long *__restrict__ stamps,       \
-      TileCache tc
+      TileCache tc, uint32_t pre
 #define RTGS_BWD_PASS                                                                                                             \
   p, ranges, point_list, splats, out_color, n_contrib, depth_index, depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, \
-      info, grads, touched, tile_mode, t0, tn, dbg, stamps, tc
+      info, grads, touched, tile_mode, t0, tn, dbg, stamps, tc, pre
 // the product kernel
 __global__ void __launch_bounds__(256, 5) blend_bwd_entry_kernel(RTGS_BWD_ARGS) { blend_bwd_entry_body<false>(RTGS_BWD_PASS); }
 // the same, leaving per-wave time stamps (tools/bwd_stamps.py)
@@ -658,12 +670,12 @@ void launch_blend_bwd_entry(const RasterParams& p, const uint2* ranges, const ui
                             const float* out_color, const uint32_t* n_contrib, const int32_t* depth_index,
                             const uint32_t* depth_pos, const uint32_t* tile_last, const float* dL_dcolor, const float* dL_ddepth,
                             const uint32_t* gbase, uint32_t* slot_count, const BwdInfo* info, SplatGrad* grads, uint8_t* touched,
-                            const uint32_t* tile_mode, uint32_t t0, uint32_t tn, TileCache tc, hipStream_t st) {
+                            const uint32_t* tile_mode, uint32_t t0, uint32_t tn, TileCache tc, uint32_t pre, hipStream_t st) {
   const uint32_t dbg = (uint32_t)g_bwd_dbg;
 #define RTGS_BWD_LAUNCH(KERNEL)                                                                                                      \
   hipLaunchKernelGGL(KERNEL, dim3(p.gx, p.gy), dim3(BLOCK), 0, st, p, ranges, point_list, splats, out_color, n_contrib, depth_index, \
                      depth_pos, tile_last, dL_dcolor, dL_ddepth, gbase, slot_count, info, grads, touched, tile_mode, t0, tn, dbg,    \
-                     g_bwd_stamps, tc)
+                     g_bwd_stamps, tc, pre)
   if (g_bwd_stamps) RTGS_BWD_LAUNCH(blend_bwd_entry_stamped_kernel); else RTGS_BWD_LAUNCH(blend_bwd_entry_kernel);
 #undef RTGS_BWD_LAUNCH
 }
