@@ -43,7 +43,8 @@ int launch_bin_count(const RasterParams&, const Splat*, const int32_t*, const in
                      SliceList, size_t, hipStream_t);
 size_t bin_slice_block_counts_bytes(int, size_t, int);
 size_t bin_list_block_counts_bytes(int, int);
-void launch_visible_compact(int, const uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, hipStream_t);
+void launch_visible_compact(int, const uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, hipStream_t,
+                            const SliceSel* = nullptr, int32_t* = nullptr, uint32_t* = nullptr);
 void launch_slice_compact(int, SliceSel, uint32_t*, uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, hipStream_t);
 void launch_slice_publish(int, const int32_t*, const int32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, hipStream_t,
                           const uint32_t* seg_count = nullptr);
@@ -579,10 +580,10 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
           prof_mark(c, EV_PRE, st);
           launch_slice_hist(P, zbin, tiles_touched, radii, slice_hist, slice_cover, st,
                             BwdInfoInit{(BwdInfo*)(img + I.bwd_info), (SplatGrad*)(bin + B.slot_grads), capS, 1u});
-          launch_slice_compact(P, sel1, (uint32_t*)(geom + G.slice_ids), slice_ctr + 2, tiles_touched, offsets, slice_ctr + 4,
-                               nullptr, 0u, fail, st);
+          // (the decision - is the slice still declined? - is re-derived inside visible_compact: no slice_compact launch)
           vl = SliceList{(const uint32_t*)(geom + G.vis_ids), slice_ctr + 4};
-          launch_visible_compact(P, zbin, (uint32_t*)(geom + G.vis_ids), slice_ctr + 4, tiles_touched, offsets, slice_ctr + 5, fail, st);
+          launch_visible_compact(P, zbin, (uint32_t*)(geom + G.vis_ids), slice_ctr + 4, tiles_touched, offsets, slice_ctr + 5, fail, st,
+                                 &sel1, (int32_t*)(slice_ctr + 3), fail);
           launch_preprocess_shade(pg, means3D, opacities, shs, scales, rotations, normal_w, splats, radii, clamped,
                                   (float2*)(geom + G.uv), vl, sel1, (size_t)P, st);
         } else {

@@ -768,9 +768,22 @@ __global__ void __launch_bounds__(256) visible_compact_kernel(int P, int chunk, 
                                                               uint32_t* __restrict__ n_list,
                                                               const uint32_t* __restrict__ rect_area,
                                                               uint32_t* __restrict__ gbase, uint32_t* __restrict__ slot_cursor,
-                                                              const uint32_t* __restrict__ spec_fail) {
+                                                              const uint32_t* __restrict__ spec_fail, SliceSel sel,
+                                                              int32_t* __restrict__ cut_out, uint32_t* __restrict__ fail_if_taken) {
   __shared__ uint32_t s_ids[VIS_CHUNK];
   if (spec_failed(spec_fail)) return;
+  if (cut_out) {
+    // Speculative forward that assumed "the kernels decline the near slice" (raster_api.hip, plan kind 2): the decision is
+    // re-derived HERE from this call's histograms (every workgroup, as slice_compact does) instead of by a slice_compact
+    // launch in front of this kernel - 6 us + a kernel boundary per map iteration on a SLAM-sized map, where the slice is
+    // declined every time.  If the slice WOULD run, the guess was wrong: raise the word and touch nothing.
+    const int cut = slice_cut(sel);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *cut_out = cut;
+      if (cut >= 0) *fail_if_taken = 1u;
+    }
+    if (cut >= 0) return;
+  }
   __shared__ uint32_t s_n, s_base, s_tot, s_gb, s_run, s_w[4];
   if (threadIdx.x == 0) { s_n = 0; s_tot = 0; s_run = 0; }
   __syncthreads();
@@ -833,13 +846,17 @@ __global__ void __launch_bounds__(256) visible_compact_kernel(int P, int chunk, 
   }
 }
 void launch_visible_compact(int P, const uint8_t* zbin, uint32_t* ids, uint32_t* n_list, const uint32_t* rect_area,
-                            uint32_t* gbase, uint32_t* slot_cursor, const uint32_t* spec_fail, hipStream_t st) {
+                            uint32_t* gbase, uint32_t* slot_cursor, const uint32_t* spec_fail, hipStream_t st,
+                            const SliceSel* decide, int32_t* cut_out, uint32_t* fail_if_taken) {
   if (P == 0) return;
+  const SliceSel nosel{};
+  const SliceSel sel = decide ? *decide : nosel;
+  if (!decide) { cut_out = nullptr; fail_if_taken = nullptr; }
   // ~192+ workgroups below a million Gaussians, VIS_CHUNK ids each above
   int chunk = VIS_CHUNK;
   if (P < 1000000) { chunk = ((P / 192 + 1023) / 1024) * 1024; chunk = chunk < 1024 ? 1024 : (chunk > VIS_CHUNK ? VIS_CHUNK : chunk); }
   hipLaunchKernelGGL(visible_compact_kernel, dim3((P + chunk - 1) / chunk), dim3(256), 0, st, P, chunk, zbin, ids, n_list,
-                     rect_area, gbase, slot_cursor, spec_fail);
+                     rect_area, gbase, slot_cursor, spec_fail, sel, cut_out, fail_if_taken);
 }
 
 int launch_bin_count(const RasterParams& p, const Splat* splats, const int32_t* radii, const int32_t* mask,

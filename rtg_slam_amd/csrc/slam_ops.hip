@@ -488,25 +488,42 @@ __global__ void __launch_bounds__(256) accumulate_error_kernel(int n, const floa
   if ((unsigned)ic >= (unsigned)P) ic = -1;
   if ((unsigned)id >= (unsigned)P) id = -1;
   const float ec = live ? ce[i] : 0.f, ed = live ? de[i] : 0.f, en = live ? ne[i] : 0.f;
-  unsigned long long todo = __builtin_amdgcn_ballot_w64(ic >= 0);
-  while (todo) {
-    const int g = __builtin_amdgcn_readlane(ic, __ffsll((long long)todo) - 1);
-    const bool mine = ic == g;
-    const float s = wave_sum(mine ? ec : 0.f), c = wave_sum(mine ? 1.f : 0.f), o = wave_sum((mine && ec > thr_c) ? 1.f : 0.f);
-    if (lane == 0) { unsafeAtomicAdd(&g_c[g], s); unsafeAtomicAdd(&cnt_c[g], c); if (o > 0.f) atomicAdd(&outl[g], (int)o); }
-    todo &= ~__builtin_amdgcn_ballot_w64(mine);
-  }
-  todo = __builtin_amdgcn_ballot_w64(id >= 0);
-  while (todo) {
-    const int g = __builtin_amdgcn_readlane(id, __ffsll((long long)todo) - 1);
-    const bool mine = id == g;
-    const float s = wave_sum(mine ? ed : 0.f), sn = wave_sum(mine ? en : 0.f), c = wave_sum(mine ? 1.f : 0.f);
-    const float o = wave_sum(mine ? ((ed > thr_d ? 1.f : 0.f) + (en > thr_n ? 1.f : 0.f)) : 0.f);
-    if (lane == 0) {
-      unsafeAtomicAdd(&g_d[g], s); unsafeAtomicAdd(&g_n[g], sn); unsafeAtomicAdd(&cnt_d[g], c);
-      if (o > 0.f) atomicAdd(&outl[g], (int)o);
+  // Runs of equal owners along the wave (an opaque disc owns runs of neighbouring pixels) are summed by a SEGMENTED scan - six
+  // shuffle rounds whatever the number of runs - and the last lane of a run adds its totals.  (Round 5 looped over the wave's
+  // distinct owners with three to four full wave reductions each: 5-10 owners per wave on a SLAM map, 109 us per frame.)
+  auto seg_scan = [&](int key, float (&v)[4], int nv) -> bool {
+    const int prev = __shfl_up(key, 1);
+    int head = (lane == 0 || prev != key) ? 1 : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = q < nv ? __shfl_up(v[q], off) : 0.f;
+      const int oh = __shfl_up(head, off);
+      if (lane >= off && !head) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += o[q];
+        head |= oh;
+      }
     }
-    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+    const int next = __shfl_down(key, 1);
+    return lane == 63 || next != key;            // the run's last lane holds its totals
+  };
+  {
+    float v[4] = {ec, 1.f, ec > thr_c ? 1.f : 0.f, 0.f};
+    const bool tail = seg_scan(ic, v, 3);
+    if (tail && ic >= 0) {
+      unsafeAtomicAdd(&g_c[ic], v[0]); unsafeAtomicAdd(&cnt_c[ic], v[1]);
+      if (v[2] > 0.f) atomicAdd(&outl[ic], (int)v[2]);
+    }
+  }
+  {
+    float v[4] = {ed, en, 1.f, (ed > thr_d ? 1.f : 0.f) + (en > thr_n ? 1.f : 0.f)};
+    const bool tail = seg_scan(id, v, 4);
+    if (tail && id >= 0) {
+      unsafeAtomicAdd(&g_d[id], v[0]); unsafeAtomicAdd(&g_n[id], v[1]); unsafeAtomicAdd(&cnt_d[id], v[2]);
+      if (v[3] > 0.f) atomicAdd(&outl[id], (int)v[3]);
+    }
   }
 }
 __global__ void __launch_bounds__(256) error_mean_kernel(int P, float* __restrict__ g_c, float* __restrict__ g_d,
