@@ -113,6 +113,19 @@ int rtgs_add_masks(const float* T_map, const float* depth, const float* render_d
  * frame has no depth.  The inputs of rtgs_accumulate_error. */
 int rtgs_frame_errors(const float* depth, const float* render_depth, const float* render_color_chw, const float* frame_color_chw,
                       const int32_t* depth_index, int32_t H, int32_t W, float* color_error, float* depth_error, void* stream);
+/* Two bookkeeping passes of the mapper as single kernels (round 6).
+ * error_counters - Mapping.error_gaussians_remove's strikes (mapper.py:541-565): for the first nf (stable) rows,
+ * depth_counter += (g_depth > depth_strike_thr), color_counter += (g_color > color_strike_thr) (the caller passes twice the add
+ * thresholds); delete_mask = depth_counter >= limit, release_mask = color_counter >= limit and not deleted; counts2 = their sums.
+ * delete_mask - Mapping.gaussians_delete (mapper.py:298-335) for a cloud of n rows with activated scales [n,3]: radius
+ * (sum - min) / 2 > 10 x the cloud's mean radius, or (add_tick != NULL) time_now - add_tick > window; count1 = set entries.  One
+ * workgroup: meant for the unstable cloud (a few thousand rows). */
+int rtgs_error_counters(int32_t nf, const float* g_color, const float* g_depth, float color_strike_thr, float depth_strike_thr,
+                        int32_t* depth_counter, int32_t* color_counter, int32_t limit, uint8_t* delete_mask, uint8_t* release_mask,
+                        uint32_t* counts2, void* stream);
+int rtgs_delete_mask(int32_t n, const float* scales, const int32_t* add_tick, int32_t time_now, int32_t window, uint8_t* mask,
+                     uint32_t* count1, void* stream);
+
 /* The new Gaussians of a frame (round 6): what Mapping._new_points and the tail of Mapping.temp_to_optimize (this package's
  * mapping.py; the reference: GaussianPointCloud.add_empty_points / update_geometry, gaussian_pointcloud.py:305-405, compute_rot
  * SLAM/utils.py:216-221, mapper.py:886-899) spell as ~80 tensor operations, as two kernels with the same float32 operations.

@@ -198,6 +198,8 @@ _SIGNATURES = {
     "rtgs_sample_candidates": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "rtgs_add_masks": (C.c_int, [_P] * 6 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P]),
     "rtgs_frame_errors": (C.c_int, [_P] * 5 + [C.c_int32, C.c_int32, _P, _P, _P]),
+    "rtgs_error_counters": (C.c_int, [C.c_int32, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    "rtgs_delete_mask": (C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "rtgs_gather_new_points": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "rtgs_new_rows": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, _P, _P, _P]),

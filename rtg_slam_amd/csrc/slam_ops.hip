@@ -727,6 +727,66 @@ __global__ void __launch_bounds__(256) new_rows_kernel(int n, const float* __res
   valid[i] = bad ? 0 : 1;
 }
 
+// ---- two per-frame bookkeeping passes of the mapper as single kernels (round 6; each was 12-14 tensor operations and a
+// host synchronisation of its own).
+// error_counters (mapper.py:541-565): strikes of the stable Gaussians - depth / colour error above twice the add threshold -
+// the delete and release decisions at `limit` strikes, and their counts.
+__global__ void __launch_bounds__(256) error_counters_kernel(int nf, const float* __restrict__ g_color, const float* __restrict__ g_depth,
+                                                             float thr_c, float thr_d, int32_t* __restrict__ dcnt,
+                                                             int32_t* __restrict__ ccnt, int limit, uint8_t* __restrict__ ddel,
+                                                             uint8_t* __restrict__ crel, uint32_t* __restrict__ counts) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool del = false, rel = false;
+  if (i < nf) {
+    const int d = dcnt[i] + (g_depth[i] > thr_d ? 1 : 0), c = ccnt[i] + (g_color[i] > thr_c ? 1 : 0);
+    dcnt[i] = d; ccnt[i] = c;
+    del = d >= limit;
+    rel = c >= limit && !del;
+    ddel[i] = del ? 1 : 0; crel[i] = rel ? 1 : 0;
+  }
+  const unsigned long long md = __builtin_amdgcn_ballot_w64(del), mr = __builtin_amdgcn_ballot_w64(rel);
+  if ((threadIdx.x & 63) == 0) {
+    if (md) atomicAdd(&counts[0], (uint32_t)__popcll(md));
+    if (mr) atomicAdd(&counts[1], (uint32_t)__popcll(mr));
+  }
+}
+
+// delete_mask (mapper.py:298-335): radius = (sum of scales - smallest) / 2 > 10 x the cloud's mean radius, or - unstable cloud -
+// older than the time window.  ONE workgroup (the unstable cloud of a SLAM map is a few thousand rows): mean first, then the
+// mask and its count.
+__global__ void __launch_bounds__(1024) delete_mask_kernel(int n, const float* __restrict__ scales, const int32_t* __restrict__ add_tick,
+                                                           int time_now, int window, uint8_t* __restrict__ mask,
+                                                           uint32_t* __restrict__ count) {
+  __shared__ double s_sum[16];
+  __shared__ uint32_t s_cnt[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  double acc = 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    const float s0 = scales[i * 3], s1 = scales[i * 3 + 1], s2 = scales[i * 3 + 2];
+    acc += (double)((((s0 + s1) + s2) - fminf(fminf(s0, s1), s2)) / 2.f);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) s_sum[w] = acc;
+  __syncthreads();
+  double tot = 0.0;
+  for (int q = 0; q < 16; ++q) tot += s_sum[q];
+  const float thr = (float)(tot / (double)n) * 10.f;
+  uint32_t c = 0;
+  for (int i = tid; i < n; i += 1024) {
+    const float s0 = scales[i * 3], s1 = scales[i * 3 + 1], s2 = scales[i * 3 + 2];
+    const float r = (((s0 + s1) + s2) - fminf(fminf(s0, s1), s2)) / 2.f;
+    const bool d = r > thr || (add_tick != nullptr && (time_now - add_tick[i]) > window);
+    mask[i] = d ? 1 : 0;
+    c += d ? 1u : 0u;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off);
+  if (lane == 0) s_cnt[w] = c;
+  __syncthreads();
+  if (tid == 0) { uint32_t t = 0; for (int q = 0; q < 16; ++q) t += s_cnt[q]; count[0] = t; }
+}
+
 }  // namespace rtgs_slam
 
 using namespace rtgs_slam;
@@ -1119,6 +1179,29 @@ __global__ void __launch_bounds__(256) attach_test_kernel(const float* __restric
   }
   attach[i] = a;
 }
+int rtgs_error_counters(int32_t nf, const float* g_color, const float* g_depth, float color_strike_thr, float depth_strike_thr,
+                        int32_t* depth_counter, int32_t* color_counter, int32_t limit, uint8_t* delete_mask, uint8_t* release_mask,
+                        uint32_t* counts2, void* stream) {
+  if (nf < 0 || !counts2) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  SLAM_TRY(hipMemsetAsync(counts2, 0, 2 * sizeof(uint32_t), st));
+  if (nf == 0) return 0;
+  if (!g_color || !g_depth || !depth_counter || !color_counter || !delete_mask || !release_mask) return -1;
+  hipLaunchKernelGGL(error_counters_kernel, dim3(grid1(nf)), dim3(256), 0, st, (int)nf, g_color, g_depth, color_strike_thr,
+                     depth_strike_thr, depth_counter, color_counter, (int)limit, delete_mask, release_mask, counts2);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_delete_mask(int32_t n, const float* scales, const int32_t* add_tick, int32_t time_now, int32_t window, uint8_t* mask,
+                     uint32_t* count1, void* stream) {
+  if (n <= 0 || !scales || !mask || !count1) return -1;
+  hipLaunchKernelGGL(delete_mask_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)n, scales, add_tick, (int)time_now,
+                     (int)window, mask, count1);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
 int rtgs_gather_new_points(const int64_t* pick, int32_t n, const float* vertex_map, const float* normal_map, const float* color_map,
                            int32_t identity_rot, float* xyz, float* normal, float* color, float* rots, void* stream) {
   if (n < 0) return -1;

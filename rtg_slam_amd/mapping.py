@@ -225,6 +225,12 @@ class HipOps:
     def new_rows(self, *a):
         return self.so.new_rows(*a)
 
+    def error_counters(self, *a):
+        return self.so.error_counters(*a)
+
+    def delete_mask(self, *a):
+        return self.so.delete_mask(*a)
+
     def accumulate_gaussian_error(self, *a):
         return self.so.accumulate_gaussian_error(*a)
 
@@ -700,6 +706,17 @@ class Mapping:
         r0, r1 = (o.n_frozen, o.N) if unstable else (0, o.n_frozen)
         if r1 == r0:
             return
+        if unstable and r1 - r0 <= 65536 and getattr(self.ops, "delete_mask", None) is not None:
+            # the unstable cloud (a few thousand rows): mean radius, mask and count in one single-workgroup kernel
+            # (rtgs_delete_mask) instead of eleven tensor operations
+            sc = o.gaussian_data("unstable")["scales"]
+            dm, k = self.ops.delete_mask(sc, self.aux("add_tick", rows).reshape(-1), int(self.time), int(self.args.unstable_time_window))
+            if k > 0:
+                full = torch.zeros(o.N, dtype=torch.bool, device=self.device)
+                full[r0:r1] = dm.bool()
+                o.remove_rows(full)
+                self.stats["deleted_unstable"] += k
+            return
         radius = self.params(rows)["radius"]
         delete_mask = radius > radius.mean() * 10
         if unstable:
@@ -751,6 +768,18 @@ class Mapping:
             a.add_color_thres, a.add_depth_thres, a.add_normal_thres, True)
         nf = o.n_frozen                                                  # stable rows come FIRST here ([unstable, stable] there)
         dcnt, ccnt = o.aux["depth_error_counter"], o.aux["color_error_counter"]
+        if getattr(self.ops, "error_counters", None) is not None:
+            # strikes, decisions and both counts in one kernel and one synchronisation (rtgs_error_counters)
+            ddel, crel, (n_del, n_rel) = self.ops.error_counters(g_color, g_depth, nf, 2 * a.add_color_thres, 2 * a.add_depth_thres,
+                                                                 dcnt, ccnt, 10)
+            if n_rel > 0:
+                self.gaussians_release(crel, count=n_rel)
+            if n_del > 0:
+                full = torch.zeros(o.N, dtype=torch.bool, device=self.device)
+                full[:nf] = ddel.bool()
+                o.remove_rows(full)
+                self.stats["deleted_stable"] += n_del
+            return
         dcnt[:nf, 0] += (g_depth[:nf] > 2 * a.add_depth_thres).to(dcnt.dtype)
         ccnt[:nf, 0] += (g_color[:nf] > 2 * a.add_color_thres).to(ccnt.dtype)
         delete_thresh = 10

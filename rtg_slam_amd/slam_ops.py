@@ -240,6 +240,39 @@ def attach_test(points, w2c, fx, fy, cx, cy, H, W, stable_color_index, stable_xy
     return out
 
 
+def error_counters(g_color, g_depth, nf, color_strike_thr, depth_strike_thr, depth_counter, color_counter, limit=10):
+    """Strikes, delete / release decisions and their counts for the first `nf` rows in one kernel (include/rtgs_slam.h:
+    rtgs_error_counters; mapper.py:541-565).  The int32 counters [>= nf, 1] are updated IN PLACE.
+    -> (delete_mask uint8 [nf], release_mask uint8 [nf], (n_delete, n_release))  - one host synchronisation."""
+    lib, dev = _lib.load(), _dev(g_color)
+    nf = int(nf)
+    ddel = torch.empty(nf, dtype=torch.uint8, device=dev)
+    crel = torch.empty(nf, dtype=torch.uint8, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    assert depth_counter.dtype == torch.int32 and color_counter.dtype == torch.int32 and depth_counter.is_contiguous() and color_counter.is_contiguous()
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_error_counters(nf, _p(g_color.float().contiguous()), _p(g_depth.float().contiguous()), float(color_strike_thr),
+                                     float(depth_strike_thr), _p(depth_counter), _p(color_counter), int(limit), _p(ddel), _p(crel),
+                                     _p(counts), _stream(dev))
+    _lib.check(rc, "rtgs_error_counters")
+    n_del, n_rel = counts.tolist()
+    return ddel, crel, (n_del, n_rel)
+
+
+def delete_mask(scales, add_tick, time_now, window):
+    """Mapping.gaussians_delete's mask for one cloud (rtgs_delete_mask) -> (mask uint8 [n], count)."""
+    lib, dev = _lib.load(), _dev(scales)
+    sc = scales.float().contiguous()
+    n = int(sc.shape[0])
+    mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    tick = None if add_tick is None else add_tick.to(torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_delete_mask(n, _p(sc), _p(tick), int(time_now), int(window), _p(mask), _p(count), _stream(dev))
+    _lib.check(rc, "rtgs_delete_mask")
+    return mask, int(count.item())
+
+
 def gather_new_points(pick, vertex_map, normal_map, color_map, identity_rot: bool):
     """The sampled pixels of one pass -> (xyz [n,3], unit normal [n,3], colour [n,3], rotation [n,4]) in one kernel
     (include/rtgs_slam.h: rtgs_gather_new_points).  Not for a pass of exactly three points (Mapping keeps the torch form there)."""
