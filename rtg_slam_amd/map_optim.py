@@ -250,6 +250,7 @@ class ShardedMapOptimizer:
         self.version = 0               # bumped by everything that changes what a render of the map shows
         self._allocate(max(int(capacity) if capacity is not None else self.N, self.N, 1), packed)
         self.step_count = 0
+        self.total_steps = getattr(self, "total_steps", 0)      # steps ever taken (never reset: Mapping.gaussians_fix keys on it)
         self.last_render = None
         self.last_num_rendered = 0
         self.attach_init = None        # begin_local_optimization(): snapshot for the attach regulariser
@@ -736,6 +737,7 @@ class ShardedMapOptimizer:
             attach = _lib.AttachC(ai["xyz"].data_ptr(), ai["raw8"].data_ptr(), ai["info"].data_ptr())
         keep = _Keep(rs, dev)
         self.step_count += 1
+        self.total_steps = getattr(self, "total_steps", 0) + 1
         P = lambda t: t.data_ptr()
         geom, binning, img = ws["arenas"]
         args = _lib.MapStepArgsC(
@@ -993,6 +995,7 @@ class ShardedMapOptimizer:
         grads = torch.autograd.grad(loss, [leaves[n] for n, _, _ in BLOCKS], allow_unused=True)
         mark("backward")
         self.step_count += 1
+        self.total_steps = getattr(self, "total_steps", 0) + 1
         rows = self.my_rows()
         gmap = {}
         for (name, _, _), g in zip(BLOCKS, grads):

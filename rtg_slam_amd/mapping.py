@@ -673,6 +673,14 @@ class Mapping:
         o = self.opt
         if o.n_train == 0:
             return
+        if mask is None:
+            # Confidence only ever RISES inside an optimisation step (appended rows start at 0, a release resets to 0): if no
+            # step has run since this method last looked, nothing can have crossed the threshold - five frames in six.  Saves the
+            # compare, the sum and their host synchronisation; the outcome is the same by construction.
+            steps = getattr(o, "total_steps", None)
+            if steps is not None and steps == getattr(self, "_fix_seen_steps", None):
+                return
+            self._fix_seen_steps = steps
         conf_u = self.aux("confidence", "unstable").reshape(-1)
         stable_mask = (conf_u > self.args.stable_confidence_thres) if mask is None else mask.reshape(-1)
         k = int(stable_mask.sum())                                       # the reference synchronises here too (:267)
