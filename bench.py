@@ -505,14 +505,13 @@ def main():
                     "frac_surface": None if surface is None else round(
                         surface["alg"]["blend_bwd"] / (surface["stage"][6] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "note": "achieved / peak / frac are the HBM roofline north_star asks for (algorithmic bytes over the live "
-                            "launch time).  `bound`: the tile walks reach neither roofline - ~5 % of HBM and (`valu` block) under half "
-                            "of the MEASURED VALU issue peak.  Per-wave cycle stamps (tools/mfma_stamps.py, profiles/r05_bwd_stamps_*) "
-                            "say where a wave's life goes: half in the group loop (dependent DPP scans, one instruction per ~5 "
-                            "cycles per wave), a quarter in the three dependent memory round trips before it (per-tile words -> "
-                            "list -> records, ~2 us each under load), a tenth at the compaction barriers - so 'latency'.  "
-                            "traffic / valu are null when "
-                            "profiles/*_latest.json were not measured on the current kernel sources or the workload is not "
-                            "the default one", "source_sha16": src}
+                            "launch time).  `bound`: the tile walks reach neither the HBM roofline (~5-8 %) nor, by the probe's FMA "
+                            "peak, the VALU one - but SQ counters (profiles/r06_sq_summary_*) show both walks issuing one wave64 VALU "
+                            "instruction per ~4.2 cycles per SIMD, the rate of a 16-lane SIMD: they are bound by instruction COUNT "
+                            "(round 6: the forward went 79 -> 54 us when its walk loop went from 86 to 50 instructions per step), "
+                            "and by the dependent chains per wave that the stamps show (tools/bwd_stamps.py, fwd_stamps.py, "
+                            "profiles/r06_*_stamps_*).  traffic / valu are null when profiles/*_latest.json were not measured on "
+                            "the current kernel sources or the workload is not the default one", "source_sha16": src}
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only

@@ -1,4 +1,4 @@
-"""The backward's three tile walks: the entry-per-lane walk (raster_bwd_mfma.hip, the default; lane sums since round 5), the tile-uniform
+"""The backward's three tile walks: the entry-per-lane walk (raster_bwd_entry.hip, the default; lane sums since round 5), the tile-uniform
 strip walk and the row-granular walk (raster_bwd.hip; mode 4 chooses between those two per tile from the measured share of
 the list the 4x4 blocks need).  Here each is forced on every tile of the same scenes and compared
 
