@@ -367,3 +367,38 @@ def test_new_gaussian_kernels_equal_the_torch_form():
     ref = torch.zeros(n, mo.COLS, device=dev)
     ref[:, 0:3] = xyz; ref[:, 3:6] = mp.RGB2SH(colr); ref[:, 51:52] = opac; ref[:, 52:55] = log_scales; ref[:, 55:59] = rots
     assert (rows - ref).abs().max() < 2e-6
+
+
+def test_bookkeeping_kernels_equal_the_torch_form():
+    """rtgs_error_counters / rtgs_delete_mask (round 6) against the tensor expressions they replace in
+    Mapping.error_gaussians_remove and Mapping.gaussians_delete (mapper.py:541-565, 298-335)."""
+    from rtg_slam_amd import slam_ops as ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(9)
+    nf, n_all = 5000, 6000
+    g_color = (torch.rand(n_all, generator=gen) * 0.5).to(dev)
+    g_depth = (torch.rand(n_all, generator=gen) * 0.5).to(dev)
+    dcnt = torch.randint(0, 11, (n_all, 1), generator=gen, dtype=torch.int32).to(dev)
+    ccnt = torch.randint(0, 11, (n_all, 1), generator=gen, dtype=torch.int32).to(dev)
+    d0, c0 = dcnt.clone(), ccnt.clone()
+    ddel, crel, (n_del, n_rel) = ops.error_counters(g_color, g_depth, nf, 0.2, 0.2, dcnt, ccnt, 10)
+    d_ref, c_ref = d0.clone(), c0.clone()
+    d_ref[:nf, 0] += (g_depth[:nf] > 0.2).to(torch.int32)
+    c_ref[:nf, 0] += (g_color[:nf] > 0.2).to(torch.int32)
+    del_ref = d_ref[:nf, 0] >= 10
+    rel_ref = (c_ref[:nf, 0] >= 10) & ~del_ref
+    assert torch.equal(dcnt, d_ref) and torch.equal(ccnt, c_ref)                  # rows >= nf untouched
+    assert torch.equal(ddel.bool(), del_ref) and torch.equal(crel.bool(), rel_ref)
+    assert (n_del, n_rel) == (int(del_ref.sum()), int(rel_ref.sum())) and n_del > 0 and n_rel > 0
+    # delete mask: radius > 10 x mean, or older than the window
+    n = 3333
+    scales = (0.002 + 0.01 * torch.rand(n, 3, generator=gen)).to(dev)
+    scales[7] = torch.tensor([0.5, 0.4, 0.001], device=dev)                        # a giant
+    tick = torch.randint(0, 300, (n,), generator=gen, dtype=torch.int32).to(dev)
+    radius = (scales.sum(dim=1) - scales.min(dim=1).values) / 2
+    for with_tick in (True, False):
+        mask, k = ops.delete_mask(scales, tick if with_tick else None, 250, 120)
+        ref = radius > radius.mean() * 10
+        if with_tick:
+            ref = ref | ((250 - tick) > 120)
+        assert torch.equal(mask.bool(), ref) and k == int(ref.sum()) and bool(mask[7])
