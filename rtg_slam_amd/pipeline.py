@@ -41,14 +41,13 @@ class TrackMapPipeline:
         # stream they are dispatched ahead of the mapper's queued workgroups instead of waiting behind them.
         self.tracker_stream = (tracker_stream if tracker_stream is not None
                                else torch.cuda.Stream(device=self.device, priority=tracker_priority))
-        # Two threads of one interpreter take turns on the GIL; a thread that WAITS for it asks the holder to let go only
-        # after sys.getswitchinterval() - 5 ms by default, i.e. a dozen 0.42-ms units.  One frame in a few hundred met that
-        # wait (a single 5-9 ms host frame inside a 20-step block: bench.py's `slowest_host_frame_ms_per_block`, rounds 4-6).
-        # Both threads here run short pieces of Python between C calls that release the GIL, so a short interval costs nothing.
+        # (Round 6 measured whether the rare 8.5-ms host frame of bench.py's unit loop is the GIL hand-over between this thread
+        # pair: RTGS_GIL_SWITCH_US = 50 against the interpreter's 5 000 made no difference - tools/hiccup_ab.sh - so the
+        # interpreter's switch interval is left alone unless the variable is set.)
         import os
         import sys
-        us = float(os.environ.get("RTGS_GIL_SWITCH_US", "50"))
-        if us > 0 and sys.getswitchinterval() > us * 1e-6:
+        us = float(os.environ.get("RTGS_GIL_SWITCH_US", "0"))
+        if us > 0:
             sys.setswitchinterval(us * 1e-6)
         self._req: "queue.SimpleQueue[Optional[Callable[[], Any]]]" = queue.SimpleQueue()
         self._done: "queue.SimpleQueue[Any]" = queue.SimpleQueue()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # How often does a unit's host frame hiccup?  tools/hiccup_ab.sh  (through gpurun): 150 blocks of 20 units per GIL switch interval
 R=$(pwd); O=$R/gpurun_out/r06_hiccup; mkdir -p $O
-for us in 5000 50; do
+for us in 5000 50; do   # (0 would leave the interpreter default)
   RTGS_GIL_SWITCH_US=$us python bench.py --repeats 150 --no-cpu-baseline --no-surface --no-sequence --no-config5 --no-dropin --no-schedule > $O/b_$us.json 2> $O/b_$us.err
   python - <<PY
 import json
