@@ -222,14 +222,46 @@ class HipOps:
             return vertex.reshape(-1, 3)[pick], nrm, color.reshape(-1, 3)[pick], rot
         return so.gather_new_points(pick, vertex, normal, color, identity_rot)
 
+    def draw_two(self, vertex, normal, color, tmask, emask, counts, n_pixels, uniform_sample_num, transmission_ratio, error_ratio,
+                 identity_rot):
+        """Both sampling passes of temp_points_init behind ONE host synchronisation: the candidate lists of the two masks are
+        compacted before their sizes are known to the host, and the two mask counts and the two candidate counts come back in
+        one copy (separately: one synchronisation for the masks' counts and one per pass for its candidates).  The draw sizes
+        follow mapper.py:737-741, 772 in float32 as before; the random stream is consumed in the same order."""
+        so = self.so
+        idx_t, c_t = so.sample_candidates(normal, tmask)
+        idx_e, c_e = so.sample_candidates(normal, emask)
+        n_t, n_e, cand_t, cand_e = torch.cat([counts.reshape(-1), c_t.reshape(-1), c_e.reshape(-1)]).tolist()
+        ratio = np.float32(n_t) / np.float32(n_pixels)
+        n_trans = int(np.float32(transmission_ratio) * ratio * np.float32(uniform_sample_num))
+        n_err = int(np.float32(n_e) * np.float32(error_ratio))
+        parts = []
+        for n, idx, n_cand in ((n_trans, idx_t, cand_t), (n_err, idx_e, cand_e)):
+            k = min(int(n), int(n_cand))
+            if k <= 0:
+                continue
+            pick = idx[:n_cand][torch.randperm(n_cand, device=idx.device, generator=self.gen)[:k]].long()
+            if k == 3:                                   # the reference's torch.cross quirk (compute_rot): keep the torch form
+                nrm = normal.reshape(-1, 3)[pick]
+                nrm = nrm / (torch.norm(nrm, p=2, dim=-1, keepdim=True) + 1e-8)
+                if identity_rot:
+                    rot = torch.zeros(3, 4, device=nrm.device)
+                    rot[:, 0] = 1
+                else:
+                    rot = compute_rot(nrm)
+                parts.append((vertex.reshape(-1, 3)[pick], nrm, color.reshape(-1, 3)[pick], rot))
+            else:
+                parts.append(so.gather_new_points(pick, vertex, normal, color, identity_rot))
+        return parts
+
     def new_rows(self, *a):
         return self.so.new_rows(*a)
 
-    def error_counters(self, *a):
-        return self.so.error_counters(*a)
+    def error_counters(self, *a, **kw):
+        return self.so.error_counters(*a, **kw)
 
-    def delete_mask(self, *a):
-        return self.so.delete_mask(*a)
+    def delete_mask(self, *a, **kw):
+        return self.so.delete_mask(*a, **kw)
 
     def accumulate_gaussian_error(self, *a):
         return self.so.accumulate_gaussian_error(*a)
@@ -419,8 +451,12 @@ class Mapping:
                     self._stage("global_optimization", self.global_optimization, select_keyframe_num=self.args.global_keyframe_num)
                 self._stage("gaussians_delete_stable", self.gaussians_delete, unstable=False)
         self._stage("gaussians_fix", self.gaussians_fix)
-        self._stage("error_gaussians_remove", self.error_gaussians_remove)
-        self._stage("gaussians_delete", self.gaussians_delete)
+        if self.prof is None and __import__("os").environ.get("RTGS_MAP_ONE_SYNC", "1") != "0" and getattr(self.ops, "delete_mask", None) is not None and getattr(self.ops, "error_counters", None) is not None \
+                and 0 < self.opt.n_train <= 65536:
+            self._error_remove_and_delete()
+        else:
+            self._stage("error_gaussians_remove", self.error_gaussians_remove)
+            self._stage("gaussians_delete", self.gaussians_delete)
 
     def gaussians_add(self, frame):
         temp = self._stage("add.temp_points_init", self.temp_points_init, frame)
@@ -479,6 +515,10 @@ class Mapping:
         tmask, emask, counts = self.ops.add_masks(out["T_map"], fm["depth_map"], out["depth"], out["render"], fm["color_chw"],
                                                   out["depth_index_map"], a.add_transmission_thres, a.add_depth_thres,
                                                   a.add_color_thres)
+        if fused and getattr(self.ops, "draw_two", None) is not None:
+            return self._new_points(self.ops.draw_two(fm["vertex_map_w"], fm["normal_map_w"], fm["color_map"], tmask, emask, counts,
+                                                      self.get_pixel_num, a.uniform_sample_num, a.transmission_sample_ratio,
+                                                      a.error_sample_ratio, same))
         n_t, n_e = counts.tolist()                                          # ONE synchronisation for both counts
         # float32 arithmetic and truncation as devI(...) of mapper.py:737-741, 772
         ratio = np.float32(n_t) / np.float32(self.get_pixel_num)
@@ -801,6 +841,44 @@ class Mapping:
             full[:nf] = ddel
             o.remove_rows(full)
             self.stats["deleted_stable"] += n_del
+
+    def _error_remove_and_delete(self):
+        """error_gaussians_remove followed by gaussians_delete (mapper.py:123-125) behind ONE host synchronisation: which unstable
+        Gaussians the delete removes (too big, too old) does not depend on what the error pass does to the STABLE cloud (strikes,
+        releases, deletions of stable rows), so its mask is computed first and the three counts come back together."""
+        o, a = self.opt, self.args
+        dm, kd = self.ops.delete_mask(o.gaussian_data("unstable")["scales"], self.aux("add_tick", "unstable").reshape(-1),
+                                      int(self.time), int(a.unstable_time_window), sync=False)
+        n_del = n_rel = 0
+        ddel = crel = None
+        if self.get_stable_num > 0:
+            frame, cm = self.processed_frames[-1], self.processed_map[-1]
+            out = self._render(frame, "all")
+            color_error, depth_error = self.ops.frame_errors(cm["depth_map"], out["depth"], out["render"], cm["color_chw"],
+                                                             out["depth_index_map"])
+            H, W = cm["color_map"].shape[:2]
+            if self._zero_map is None or self._zero_map.shape != depth_error.shape:
+                self._zero_map = torch.zeros_like(depth_error)
+            g_color, g_depth, _, _ = self.ops.accumulate_gaussian_error(
+                H, W, o.N, color_error, depth_error, self._zero_map, out["color_index_map"], out["depth_index_map"],
+                a.add_color_thres, a.add_depth_thres, a.add_normal_thres, True)
+            ddel, crel, counts = self.ops.error_counters(g_color, g_depth, o.n_frozen, 2 * a.add_color_thres, 2 * a.add_depth_thres,
+                                                         o.aux["depth_error_counter"], o.aux["color_error_counter"], 10, sync=False)
+            n_del, n_rel, k = torch.cat([counts.reshape(-1), kd.reshape(-1)]).tolist()
+        else:
+            k = int(kd.item())
+        if n_rel > 0:
+            self.gaussians_release(crel, count=n_rel)
+        if n_del > 0:
+            full = torch.zeros(o.N, dtype=torch.bool, device=self.device)
+            full[:o.n_frozen] = ddel.bool()
+            o.remove_rows(full)
+            self.stats["deleted_stable"] += n_del
+        if k > 0:
+            full = torch.zeros(o.N, dtype=torch.bool, device=self.device)
+            full[o.n_frozen:] = dm.bool()
+            o.remove_rows(full)
+            self.stats["deleted_unstable"] += k
 
     def save_model(self, path: str, save_data: bool = True, save_sibr: bool = True, save_merge: bool = True):
         """Mapping.save_model (mapper.py:916-941): `<path>.ply` = the unstable cloud, `<path>_stable.ply` = the stable one (raw

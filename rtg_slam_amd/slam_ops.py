@@ -240,7 +240,7 @@ def attach_test(points, w2c, fx, fy, cx, cy, H, W, stable_color_index, stable_xy
     return out
 
 
-def error_counters(g_color, g_depth, nf, color_strike_thr, depth_strike_thr, depth_counter, color_counter, limit=10):
+def error_counters(g_color, g_depth, nf, color_strike_thr, depth_strike_thr, depth_counter, color_counter, limit=10, sync=True):
     """Strikes, delete / release decisions and their counts for the first `nf` rows in one kernel (include/rtgs_slam.h:
     rtgs_error_counters; mapper.py:541-565).  The int32 counters [>= nf, 1] are updated IN PLACE.
     -> (delete_mask uint8 [nf], release_mask uint8 [nf], (n_delete, n_release))  - one host synchronisation."""
@@ -255,11 +255,13 @@ def error_counters(g_color, g_depth, nf, color_strike_thr, depth_strike_thr, dep
                                      float(depth_strike_thr), _p(depth_counter), _p(color_counter), int(limit), _p(ddel), _p(crel),
                                      _p(counts), _stream(dev))
     _lib.check(rc, "rtgs_error_counters")
+    if not sync:
+        return ddel, crel, counts                    # int32[2] on the device: the caller reads it with its other counts
     n_del, n_rel = counts.tolist()
     return ddel, crel, (n_del, n_rel)
 
 
-def delete_mask(scales, add_tick, time_now, window):
+def delete_mask(scales, add_tick, time_now, window, sync=True):
     """Mapping.gaussians_delete's mask for one cloud (rtgs_delete_mask) -> (mask uint8 [n], count)."""
     lib, dev = _lib.load(), _dev(scales)
     sc = scales.float().contiguous()
@@ -270,7 +272,7 @@ def delete_mask(scales, add_tick, time_now, window):
     with torch.cuda.device(dev):
         rc = lib.rtgs_delete_mask(n, _p(sc), _p(tick), int(time_now), int(window), _p(mask), _p(count), _stream(dev))
     _lib.check(rc, "rtgs_delete_mask")
-    return mask, int(count.item())
+    return mask, (int(count.item()) if sync else count)
 
 
 def gather_new_points(pick, vertex_map, normal_map, color_map, identity_rot: bool):

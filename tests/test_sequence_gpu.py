@@ -190,6 +190,7 @@ def test_the_product_lifecycle_against_the_references_own_mapping(golden, changi
         return vertex.reshape(-1, 3)[pick], normal.reshape(-1, 3)[pick], color.reshape(-1, 3)[pick]
     ops.sample_pixels = sample_pixels
     ops.sample_new_points = None          # the draw follows the reference's rule (above), not the product's fused device-side form
+    ops.draw_two = None
     m = mp.Mapping(args, dev, ops=ops, capacity=600)
     m.rng = random
     verbose = bool(os.environ.get("RTGS_TEST_VERBOSE"))
