@@ -21,7 +21,7 @@ def record(section, **values):
     try:
         import fcntl
         os.makedirs(os.path.dirname(PATH), exist_ok=True)
-        with open(PATH + ".lock", "w") as lock:              # the suite runs in several worker processes (pytest.ini)
+        with open(PATH + ".lock", "w") as lock:              # safe if the suite is run in several worker processes (-n)
             fcntl.flock(lock, fcntl.LOCK_EX)
             data = {}
             if os.path.exists(PATH):
