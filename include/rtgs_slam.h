@@ -138,6 +138,19 @@ int rtgs_delete_mask(int32_t n, const float* scales, const int32_t* add_tick, in
  * | rotation) of EVERY candidate and valid[n] = 0 where the candidate lies inside three radii of a neighbour. */
 int rtgs_gather_new_points(const int64_t* pick, int32_t n, const float* vertex_map, const float* normal_map, const float* color_map,
                            int32_t identity_rot, float* xyz, float* normal, float* color, float* rots, void* stream);
+/* draw_new_points: SLAM/utils.py:171's `randperm(n_cand)[:k]` and gather_new_points in one launch.  cand int32[n_cand] = the
+ * pixels sample_pixels may draw from (rtgs_sample_candidates); output i takes cand[perm(i)], perm a keyed bijection of
+ * [0, n_cand) (balanced Feistel network + cycle walking; `key` = a fresh 64-bit word per pass from the caller's seeded
+ * generator), so the k outputs are distinct.  pick_out int32[k] (optional) receives the drawn pixel indices.  k <= n_cand.
+ * Not for k == 3 either.  filter_keep: Mapping.temp_points_filter's decision (mapper.py:812-826) behind the neighbour query:
+ * keep[i] = 0 iff for one of the three neighbours idx[i,.] >= 0: sqrt(dist2) < ratio * radius(scales[idx]) (radius = (sum -
+ * min) / 2 of the activated scales, gaussian_pointcloud.py:515-519; ratio 0.6).  bbox_pad: out6 = [min - pad | max + pad] of
+ * n >= 1 points, the neighbour query's box (SLAM/utils.py:737-744), one single-workgroup launch. */
+int rtgs_draw_new_points(const int32_t* cand, int32_t n_cand, int32_t k, uint64_t key, const float* vertex_map, const float* normal_map,
+                         const float* color_map, int32_t identity_rot, float* xyz, float* normal, float* color, float* rots,
+                         int32_t* pick_out, void* stream);
+int rtgs_filter_keep(int32_t n, const float* dist2, const int32_t* idx, const float* scales, float ratio, uint8_t* keep, void* stream);
+int rtgs_bbox_pad(int32_t n, const float* xyz, float pad, float* out6, void* stream);
 int rtgs_new_rows(int32_t n, const float* xyz, const float* color, const float* opacity_raw, const float* rots, const float* dist2,
                   const int32_t* idx, const float* exist_scales, float min_radius, float max_radius, float scale_factor,
                   float factor_x, float factor_y, float factor_z, float* packed59, uint8_t* valid, void* stream);

@@ -201,6 +201,9 @@ _SIGNATURES = {
     "rtgs_error_counters": (C.c_int, [C.c_int32, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int32, _P, _P, _P, _P]),
     "rtgs_delete_mask": (C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "rtgs_gather_new_points": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
+    "rtgs_draw_new_points": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "rtgs_filter_keep": (C.c_int, [C.c_int32, _P, _P, _P, C.c_float, _P, _P]),
+    "rtgs_bbox_pad": (C.c_int, [C.c_int32, _P, C.c_float, _P, _P]),
     "rtgs_new_rows": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, _P, _P, _P]),
     "rtgs_attach_test": (C.c_int, [_P, C.c_int32, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P, _P, _P,

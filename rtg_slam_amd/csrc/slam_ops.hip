@@ -681,6 +681,106 @@ __global__ void __launch_bounds__(256) gather_new_points_kernel(const int64_t* _
   rot[i * 4] = cosf(h); rot[i * 4 + 1] = ax * sh; rot[i * 4 + 2] = ay * sh; rot[i * 4 + 3] = az * sh;
 }
 
+// draw_new_points: the uniform draw without replacement of SLAM/utils.py:171 (randperm(n_cand)[:k]) and the gather above in
+// one kernel.  Output i takes candidate perm(i), perm = a keyed bijection of [0, n_cand): a balanced Feistel network over the
+// next even number of bits, walked until it lands inside the range (cycle walking keeps it a bijection; the domain is < 4 n_cand,
+// so a walk takes under four steps on average).  A prefix of a permutation never repeats an element, which is all "without
+// replacement" asks; the key is a fresh 64-bit word per pass from the host's seeded generator.
+__device__ __forceinline__ uint32_t draw_mix(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t draw_perm(uint32_t i, uint32_t n, uint32_t half_bits, uint64_t key) {
+  const uint32_t mask = (1u << half_bits) - 1u;
+  const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  uint32_t x = i;
+  do {
+    uint32_t l = x >> half_bits, r = x & mask;
+#pragma unroll
+    for (int round = 0; round < 6; ++round) {
+      const uint32_t f = draw_mix(r ^ ((round & 1) ? k1 : k0) ^ (0x9e3779b9u * (uint32_t)(round + 1))) & mask;
+      const uint32_t t = l ^ f;
+      l = r; r = t;
+    }
+    x = (l << half_bits) | r;
+  } while (x >= n);
+  return x;
+}
+__global__ void __launch_bounds__(256) draw_new_points_kernel(const int32_t* __restrict__ cand, uint32_t n_cand, int k, uint32_t half_bits,
+                                                              uint64_t key, const float* __restrict__ vertex,
+                                                              const float* __restrict__ normal, const float* __restrict__ color,
+                                                              int identity_rot, float* __restrict__ xyz, float* __restrict__ nrm,
+                                                              float* __restrict__ col, float* __restrict__ rot, int32_t* __restrict__ pick_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= k) return;
+  const int64_t q = cand[draw_perm((uint32_t)i, n_cand, half_bits, key)];
+  if (pick_out) pick_out[i] = (int32_t)q;
+  const float vx = vertex[q * 3], vy = vertex[q * 3 + 1], vz = vertex[q * 3 + 2];
+  const float nx = normal[q * 3], ny = normal[q * 3 + 1], nz = normal[q * 3 + 2];
+  xyz[i * 3] = vx; xyz[i * 3 + 1] = vy; xyz[i * 3 + 2] = vz;
+  col[i * 3] = color[q * 3]; col[i * 3 + 1] = color[q * 3 + 1]; col[i * 3 + 2] = color[q * 3 + 2];
+  const float len = sqrtf((nx * nx + ny * ny) + nz * nz) + 1e-8f;
+  const float tx = nx / len, ty = ny / len, tz = nz / len;
+  nrm[i * 3] = tx; nrm[i * 3 + 1] = ty; nrm[i * 3 + 2] = tz;
+  if (identity_rot) { rot[i * 4] = 1.f; rot[i * 4 + 1] = 0.f; rot[i * 4 + 2] = 0.f; rot[i * 4 + 3] = 0.f; return; }
+  float ax = 0.f * tz - 1.f * ty, ay = 1.f * tx - 0.f * tz, az = 0.f * ty - 0.f * tx;      // as gather_new_points_kernel
+  float al = sqrtf((ax * ax + ay * ay) + az * az) + 1e-8f;
+  ax = ax / al; ay = ay / al; az = az / al;
+  const float angle = acosf(tz);
+  al = sqrtf((ax * ax + ay * ay) + az * az) + 1e-8f;
+  ax = ax / al; ay = ay / al; az = az / al;
+  const float h = angle / 2.f, sh = sinf(h);
+  rot[i * 4] = cosf(h); rot[i * 4 + 1] = ax * sh; rot[i * 4 + 2] = ay * sh; rot[i * 4 + 3] = az * sh;
+}
+
+// filter_keep: the decision of Mapping.temp_points_filter (mapper.py:803-827) behind the neighbour query: a new point is dropped
+// when one of its (up to three) nearest unstable Gaussians is closer than 0.6 of that Gaussian's radius ((sum - min) / 2 of its
+// activated scales, gaussian_pointcloud.py:515-519).  The same float32 operations as the tensor form (sqrt, *, <).
+__global__ void __launch_bounds__(256) filter_keep_kernel(int n, const float* __restrict__ d2, const int32_t* __restrict__ idx,
+                                                          const float* __restrict__ scales, float ratio, uint8_t* __restrict__ keep) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  bool inside = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int32_t j = idx[i * 3 + k];
+    if (j < 0) continue;
+    const float* sc = scales + (size_t)j * 3;
+    const float s0 = sc[0], s1 = sc[1], s2 = sc[2];
+    const float radius = (((s0 + s1) + s2) - fminf(fminf(s0, s1), s2)) / 2.f;
+    inside = inside || (sqrtf(d2[i * 3 + k]) < radius * ratio);
+  }
+  keep[i] = inside ? 0 : 1;
+}
+
+// bbox_pad: [min - pad | max + pad] of n points (the box Mapping hands the neighbour query, SLAM/utils.py:737-744's bounds) as
+// ONE single-workgroup launch instead of min, max, two offsets and a concatenation.  n is a frame's new points (<= ~41 000).
+__global__ void __launch_bounds__(1024) bbox_pad_kernel(int n, const float* __restrict__ xyz, float pad, float* __restrict__ out6) {
+  __shared__ float s_lo[16][3], s_hi[16][3];
+  float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (int i = threadIdx.x; i < n; i += 1024) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float v = xyz[i * 3 + c]; lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s_lo[w][c] = lo[c]; s_hi[w][c] = hi[c]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float a = s_lo[0][threadIdx.x], b = s_hi[0][threadIdx.x];
+    for (int k = 1; k < 16; ++k) { a = fminf(a, s_lo[k][threadIdx.x]); b = fmaxf(b, s_hi[k][threadIdx.x]); }
+    out6[threadIdx.x] = a - pad;
+    out6[3 + threadIdx.x] = b + pad;
+  }
+}
+
 // new_rows: update_geometry (gaussian_pointcloud.py:366-405) + the packing of the new rows (mapper.py:886-899).  Candidate i
 // has its three nearest neighbours among (the n candidates, then the existing Gaussians): in-plane scale = rms of
 // (distance - 3 radius) over the three, clamped; a candidate INSIDE three radii of a neighbour is invalid.  Writes the packed
@@ -1209,6 +1309,37 @@ int rtgs_gather_new_points(const int64_t* pick, int32_t n, const float* vertex_m
   if (!pick || !vertex_map || !normal_map || !color_map || !xyz || !normal || !color || !rots) return -1;
   hipLaunchKernelGGL(gather_new_points_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, pick, (int)n, vertex_map, normal_map,
                      color_map, (int)identity_rot, xyz, normal, color, rots);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_draw_new_points(const int32_t* cand, int32_t n_cand, int32_t k, uint64_t key, const float* vertex_map, const float* normal_map,
+                         const float* color_map, int32_t identity_rot, float* xyz, float* normal, float* color, float* rots,
+                         int32_t* pick_out, void* stream) {
+  if (n_cand < 0 || k < 0 || k > n_cand) return -1;
+  if (k == 0) return 0;
+  if (!cand || !vertex_map || !normal_map || !color_map || !xyz || !normal || !color || !rots) return -1;
+  uint32_t bits = 2;
+  while (bits < 32 && (1ull << bits) < (uint64_t)n_cand) ++bits;
+  const uint32_t half_bits = (bits + 1) / 2;
+  hipLaunchKernelGGL(draw_new_points_kernel, dim3(grid1(k)), dim3(256), 0, (hipStream_t)stream, cand, (uint32_t)n_cand, (int)k, half_bits,
+                     key, vertex_map, normal_map, color_map, (int)identity_rot, xyz, normal, color, rots, pick_out);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_filter_keep(int32_t n, const float* dist2, const int32_t* idx, const float* scales, float ratio, uint8_t* keep, void* stream) {
+  if (n < 0) return -1;
+  if (n == 0) return 0;
+  if (!dist2 || !idx || !scales || !keep) return -1;
+  hipLaunchKernelGGL(filter_keep_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)stream, (int)n, dist2, idx, scales, ratio, keep);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_bbox_pad(int32_t n, const float* xyz, float pad, float* out6, void* stream) {
+  if (n <= 0 || !xyz || !out6) return -1;
+  hipLaunchKernelGGL(bbox_pad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)n, xyz, pad, out6);
   SLAM_TRY(hipGetLastError());
   return 0;
 }

@@ -180,6 +180,10 @@ class HipOps:
         self.renderer = Renderer(args)
         self.args = args
         self.gen = torch.Generator(device=device).manual_seed(int(getattr(args, "seed", 0)))
+        self.keys = random.Random(int(getattr(args, "seed", 0)))           # one 64-bit key per sampling pass (rtgs_draw_new_points)
+        self.kernel_draw = True
+        if __import__("os").environ.get("RTGS_ADD_KERNELS", "1") == "0":     # A/B aid: the tensor forms of the draw, the filter and the box
+            self.kernel_draw, self.filter_keep, self.bbox_pad = False, None, None
 
     def make_optimizer(self, packed, lr_col, capacity):
         return mo.ShardedMapOptimizer(packed, lr_col=lr_col, capacity=capacity)
@@ -235,6 +239,12 @@ class HipOps:
         ratio = np.float32(n_t) / np.float32(n_pixels)
         n_trans = int(np.float32(transmission_ratio) * ratio * np.float32(uniform_sample_num))
         n_err = int(np.float32(n_e) * np.float32(error_ratio))
+        ks = [min(int(n_trans), int(cand_t)), min(int(n_err), int(cand_e))]
+        if self.kernel_draw and 3 not in ks:
+            # the draw itself inside the gather kernel (rtgs_draw_new_points): no randperm, no index gathers, no concatenation
+            passes = [(idx, n_cand, k, self.keys.getrandbits(64)) for idx, n_cand, k in ((idx_t, cand_t, ks[0]), (idx_e, cand_e, ks[1]))
+                      if k > 0]
+            return [so.draw_new_points(passes, vertex, normal, color, identity_rot)] if passes else []
         parts = []
         for n, idx, n_cand in ((n_trans, idx_t, cand_t), (n_err, idx_e, cand_e)):
             k = min(int(n), int(n_cand))
@@ -256,6 +266,12 @@ class HipOps:
 
     def new_rows(self, *a):
         return self.so.new_rows(*a)
+
+    def filter_keep(self, *a):
+        return self.so.filter_keep(*a)
+
+    def bbox_pad(self, *a):
+        return self.so.bbox_pad(*a)
 
     def error_counters(self, *a, **kw):
         return self.so.error_counters(*a, **kw)
@@ -535,6 +551,11 @@ class Mapping:
         (mapper.py:803-827).  Returns the keep mask (the compaction happens once, in temp_to_optimize)."""
         n = temp["xyz"].shape[0]
         keep = torch.ones(n, dtype=torch.bool, device=temp["xyz"].device)
+        if self.get_unstable_num > 0 and getattr(self.ops, "filter_keep", None) is not None:
+            # box, query and decision as three launches (rtgs_bbox_pad, rtgs_knn3_query, rtgs_filter_keep)
+            ud = self.opt.gaussian_data("unstable")
+            d2, idx = self.ops.knn_query(ud["xyz"], temp["xyz"], -1, self.ops.bbox_pad(temp["xyz"], 0.05))
+            return self.ops.filter_keep(d2, idx, ud["scales"], 0.6)
         if self.get_unstable_num > 0:
             up = self.params("unstable")
             lo, hi = temp["xyz"].min(dim=0)[0] - 0.05, temp["xyz"].max(dim=0)[0] + 0.05          # bbox_filter
@@ -574,7 +595,9 @@ class Mapping:
         if getattr(self.ops, "new_rows", None) is not None:
             # the same arithmetic as below in ONE kernel behind the neighbour query (rtgs_new_rows): ~45 launches fewer per frame
             gd = self.opt.gaussian_data("all")
-            d2, idx = self.ops.knn_query(torch.cat([xyz, gd["xyz"]]), xyz, 0, torch.cat([xyz.min(dim=0)[0] - 0.05, xyz.max(dim=0)[0] + 0.05]))
+            box = self.ops.bbox_pad(xyz, 0.05) if getattr(self.ops, "bbox_pad", None) is not None else \
+                torch.cat([xyz.min(dim=0)[0] - 0.05, xyz.max(dim=0)[0] + 0.05])
+            d2, idx = self.ops.knn_query(torch.cat([xyz, gd["xyz"]]), xyz, 0, box)
             rows, valid = self.ops.new_rows(xyz, temp["color"], temp["opacity_raw"], temp["rots"], d2, idx, gd["scales"],
                                             a.min_radius, a.max_radius, a.scale_factor, a.xyz_factor)
             good = torch.nonzero(valid).reshape(-1)                  # synchronisation 2 of the add

@@ -291,6 +291,58 @@ def gather_new_points(pick, vertex_map, normal_map, color_map, identity_rot: boo
     return xyz, nrm, col, rot
 
 
+def draw_new_points(passes, vertex_map, normal_map, color_map, identity_rot: bool, want_pick: bool = False):
+    """Every sampling pass of a frame - `passes` = [(cand int32[>= n_cand], n_cand, k, key)] - into ONE set of arrays (xyz, unit
+    normal, colour, rotation; pass after pass), one launch per pass (include/rtgs_slam.h: rtgs_draw_new_points): the draw without
+    replacement happens inside the kernel (a keyed bijection of [0, n_cand)), so there is no randperm, no index gather and no
+    concatenation.  No pass may have k == 3 (Mapping keeps the torch form there)."""
+    lib, dev = _lib.load(), _dev(vertex_map)
+    total = sum(int(p[2]) for p in passes)
+    v, nm, c = (t.float().contiguous() for t in (vertex_map, normal_map, color_map))
+    xyz, nrm, col = (torch.empty(total, 3, dtype=torch.float32, device=dev) for _ in range(3))
+    rot = torch.empty(total, 4, dtype=torch.float32, device=dev)
+    pick = torch.empty(total, dtype=torch.int32, device=dev) if want_pick else None
+    off = 0
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        for cand, n_cand, k, key in passes:
+            k = int(k)
+            if k <= 0:
+                continue
+            assert cand.dtype == torch.int32 and cand.is_contiguous()
+            rc = lib.rtgs_draw_new_points(_p(cand), int(n_cand), k, int(key) & 0xFFFFFFFFFFFFFFFF, _p(v), _p(nm), _p(c),
+                                          int(bool(identity_rot)), xyz.data_ptr() + 12 * off, nrm.data_ptr() + 12 * off,
+                                          col.data_ptr() + 12 * off, rot.data_ptr() + 16 * off,
+                                          None if pick is None else pick.data_ptr() + 4 * off, st)
+            _lib.check(rc, "rtgs_draw_new_points")
+            off += k
+    return (xyz, nrm, col, rot, pick) if want_pick else (xyz, nrm, col, rot)
+
+
+def filter_keep(d2, idx, scales, ratio: float = 0.6):
+    """temp_points_filter's decision (mapper.py:812-826) from the neighbour query's output and the unstable Gaussians' activated
+    scales -> keep bool[n] (include/rtgs_slam.h: rtgs_filter_keep)."""
+    lib, dev = _lib.load(), _dev(d2)
+    n = int(d2.shape[0])
+    d2, idx, scales = d2.float().contiguous(), idx.to(torch.int32).contiguous(), scales.float().contiguous()
+    keep = torch.empty(n, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_filter_keep(n, _p(d2), _p(idx), _p(scales), float(ratio), _p(keep), _stream(dev))
+    _lib.check(rc, "rtgs_filter_keep")
+    return keep.view(torch.bool)
+
+
+def bbox_pad(xyz, pad: float):
+    """[min - pad | max + pad] float32[6] of the points (include/rtgs_slam.h: rtgs_bbox_pad)."""
+    lib, dev = _lib.load(), _dev(xyz)
+    xyz = xyz.float().contiguous()
+    out = torch.empty(6, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_bbox_pad(int(xyz.shape[0]), _p(xyz), float(pad), _p(out), _stream(dev))
+    _lib.check(rc, "rtgs_bbox_pad")
+    return out
+
+
 def new_rows(xyz, color, opacity_raw, rots, d2, idx, exist_scales, min_radius, max_radius, scale_factor, xyz_factor):
     """update_geometry + row packing for the new Gaussians of a frame in one kernel (include/rtgs_slam.h: rtgs_new_rows) ->
     (packed [n,59] raw rows of every candidate, valid uint8 [n])."""

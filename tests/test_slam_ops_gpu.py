@@ -369,6 +369,77 @@ def test_new_gaussian_kernels_equal_the_torch_form():
     assert (rows - ref).abs().max() < 2e-6
 
 
+def test_the_draw_inside_the_gather_is_a_draw_without_replacement():
+    """rtgs_draw_new_points (round 6; SLAM/utils.py:171 `randperm(n_cand)[:k]` + the gather in one launch): the k pixels are
+    DISTINCT members of the candidate list for every key and every size (incl. 1, powers of two and their neighbours, k =
+    n_cand = a full permutation), the rows equal rtgs_gather_new_points of the same pixels, two passes land behind one
+    another in one set of arrays, and over many keys every candidate is drawn equally often (chi-square against k / n_cand)."""
+    from rtg_slam_amd import slam_ops as ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(11)
+    H, W = 60, 80
+    vertex = torch.randn(H, W, 3, generator=gen).to(dev)
+    normal = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=gen), dim=-1).to(dev) * 0.97
+    color = torch.rand(H, W, 3, generator=gen).to(dev)
+    for n_cand, k in ((1, 1), (2, 1), (4, 4), (5, 4), (63, 10), (64, 64), (65, 20), (1000, 1000), (1025, 7), (4096, 2000), (4800, 4800)):
+        cand = torch.randperm(H * W, generator=gen)[:n_cand].sort().values.to(torch.int32).to(dev)
+        for key in (0, 1, 0xDEADBEEFCAFEF00D, 2 ** 64 - 1):
+            xyz, nrm, col, rot, pick = ops.draw_new_points([(cand, n_cand, k, key)], vertex, normal, color, False, want_pick=True)
+            p = pick.long()
+            assert p.unique().numel() == k and torch.isin(p, cand.long()).all(), (n_cand, k, key)
+            gx, gn, gc, gr = ops.gather_new_points(p, vertex, normal, color, False)
+            if k != 3:
+                assert torch.equal(xyz, gx) and torch.equal(nrm, gn) and torch.equal(col, gc) and torch.equal(rot, gr)
+    # two passes, one set of arrays; different keys draw different pixels
+    c1 = torch.arange(0, 2000, dtype=torch.int32, device=dev)
+    c2 = torch.arange(2000, 4800, dtype=torch.int32, device=dev)
+    xyz, nrm, col, rot, pick = ops.draw_new_points([(c1, 2000, 300, 7), (c2, 2800, 50, 8)], vertex, normal, color, True, want_pick=True)
+    assert xyz.shape == (350, 3) and rot.shape == (350, 4) and (pick[:300] < 2000).all() and (pick[300:] >= 2000).all()
+    assert torch.equal(rot, torch.tensor([1.0, 0, 0, 0], device=dev).repeat(350, 1))
+    other = ops.draw_new_points([(c1, 2000, 300, 9)], vertex, normal, color, True, want_pick=True)[4]
+    assert not torch.equal(other, pick[:300])
+    # uniformity: 400 keys x 100 of 1000 -> every candidate expects 40 draws; chi-square with 999 degrees of freedom has mean
+    # 999 and standard deviation 44.7: a flat draw stays inside +- 5 sigma, a biased one does not
+    n_cand, k, keys = 1000, 100, 400
+    cand = torch.arange(n_cand, dtype=torch.int32, device=dev)
+    hits = torch.zeros(n_cand, dtype=torch.int64, device=dev)
+    first = torch.zeros(n_cand, dtype=torch.int64, device=dev)
+    rng = __import__("random").Random(3)
+    for _ in range(keys):
+        pick = ops.draw_new_points([(cand, n_cand, k, rng.getrandbits(64))], vertex, normal, color, True, want_pick=True)[4].long()
+        hits += torch.bincount(pick, minlength=n_cand)
+        first[pick[0]] += 1
+    expect = keys * k / n_cand
+    chi2 = float(((hits.double() - expect) ** 2 / expect).sum())
+    assert abs(chi2 - (n_cand - 1) * (1 - k / n_cand)) < 5 * 44.7, chi2       # without replacement: variance shrinks by (1 - k/n)
+    assert int(first.max()) <= 6                                               # output 0 does not favour a pixel (expects 0.4 each)
+
+
+def test_filter_and_box_kernels_equal_the_torch_form():
+    """rtgs_filter_keep / rtgs_bbox_pad (round 6) against the tensor expressions they replace in Mapping.temp_points_filter
+    (mapper.py:803-827; bbox bounds SLAM/utils.py:737-744): the same float32 operations, so equal bit for bit."""
+    from rtg_slam_amd import slam_ops as ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(13)
+    for n, nu in ((1, 5), (700, 2), (5000, 3000), (40800, 900)):
+        xyz = (torch.rand(n, 3, generator=gen) * 2).to(dev)
+        exist = (torch.rand(nu, 3, generator=gen) * 2).to(dev)
+        scales = (0.002 + 0.08 * torch.rand(nu, 3, generator=gen)).to(dev)
+        box = ops.bbox_pad(xyz, 0.05)
+        lo, hi = xyz.min(dim=0)[0] - 0.05, xyz.max(dim=0)[0] + 0.05
+        assert torch.equal(box, torch.cat([lo, hi]))
+        d2, idx = ops.knn_query(exist, xyz, -1, box)
+        keep = ops.filter_keep(d2, idx, scales, 0.6)
+        radius = (scales.sum(dim=1) - scales.min(dim=1).values) / 2
+        rad = radius[idx.clamp_min(0).long()] * 0.6
+        want = ~((torch.sqrt(d2) < rad) & (idx >= 0)).any(dim=-1)
+        assert keep.dtype == torch.bool and torch.equal(keep, want)
+        if n >= 700 and nu >= 900:
+            assert 0 < int(want.sum()) < n
+        if nu == 2:
+            assert (idx[:, 2] < 0).all()                                       # fewer than three neighbours: -1 is "not inside"
+
+
 def test_bookkeeping_kernels_equal_the_torch_form():
     """rtgs_error_counters / rtgs_delete_mask (round 6) against the tensor expressions they replace in
     Mapping.error_gaussians_remove and Mapping.gaussians_delete (mapper.py:541-565, 298-335)."""
