@@ -248,6 +248,7 @@ class ShardedMapOptimizer:
         self._scope = "local"          # "global": begin_global_optimization() - the stable prefix is what is rendered and trained
         self._lr_scope = None          # learning-rate columns of the running global optimisation
         self.version = 0               # bumped by everything that changes what a render of the map shows
+        self._gd_views = {}            # gaussian_data's views per row range (see there)
         self._allocate(max(int(capacity) if capacity is not None else self.N, self.N, 1), packed)
         self.step_count = 0
         self.total_steps = getattr(self, "total_steps", 0)      # steps ever taken (never reset: Mapping.gaussians_fix keys on it)
@@ -301,6 +302,7 @@ class ShardedMapOptimizer:
         dev, N = self.device, self.N
         rows = cap + self.world
         old = self.state
+        self._gd_views = {}            # views of the arrays about to be replaced
         f = dict(dtype=torch.float32, device=dev)
         per_cap = (cap + self.world - 1) // self.world + 1
         adam_rows = cap if self.world == 1 else per_cap
@@ -407,9 +409,17 @@ class ShardedMapOptimizer:
             gd = {k: gd[k] for k in ("opacity", "scales", "rotations", "normal")}
         else:
             self._activate_rows(0, N)
+            # the views themselves are remembered per (row range, arrays): a SLAM frame asks seven times, and seven slices a
+            # time are ~100 us of interpreter per frame; the CONTENT is kept current in place by _activate_rows
+            key = (r0, r1, self.state["xyz"]["p"].data_ptr(), self.state["shs"]["p"].data_ptr(), self.act["scales"].data_ptr())
+            hit = self._gd_views.get(rows)
+            if hit is not None and hit[0] == key:
+                return dict(hit[1])
             gd = {k: v[r0:r1] for k, v in self.act.items()}
         gd["xyz"] = self.state["xyz"]["p"][r0:r1]
         gd["shs"] = self.state["shs"]["p"][r0:r1].view(r1 - r0, 16, 3)
+        if self.act is not None:
+            self._gd_views[rows] = (key, dict(gd))
         return gd
 
     def _activate_rows(self, r0: int, r1: int, force: bool = False):

@@ -550,12 +550,12 @@ class Mapping:
         """Drop temp points that fall within 0.6 radius of one of their 3 nearest existing unstable Gaussians
         (mapper.py:803-827).  Returns the keep mask (the compaction happens once, in temp_to_optimize)."""
         n = temp["xyz"].shape[0]
-        keep = torch.ones(n, dtype=torch.bool, device=temp["xyz"].device)
         if self.get_unstable_num > 0 and getattr(self.ops, "filter_keep", None) is not None:
             # box, query and decision as three launches (rtgs_bbox_pad, rtgs_knn3_query, rtgs_filter_keep)
             ud = self.opt.gaussian_data("unstable")
             d2, idx = self.ops.knn_query(ud["xyz"], temp["xyz"], -1, self.ops.bbox_pad(temp["xyz"], 0.05))
             return self.ops.filter_keep(d2, idx, ud["scales"], 0.6)
+        keep = torch.ones(n, dtype=torch.bool, device=temp["xyz"].device)
         if self.get_unstable_num > 0:
             up = self.params("unstable")
             lo, hi = temp["xyz"].min(dim=0)[0] - 0.05, temp["xyz"].max(dim=0)[0] + 0.05          # bbox_filter
@@ -575,9 +575,9 @@ class Mapping:
         sp = self.opt.gaussian_data("stable")
         attach = self.ops.attach_test(xyz, frame.get_w2c(), frame.fx, frame.fy, frame.cx, frame.cy, frame.image_height,
                                       frame.image_width, out["color_index_map"], sp["xyz"], sp["normal"],
-                                      0.5 * self.args.add_depth_thres).bool()
-        low = torch.full_like(temp["opacity_raw"], inverse_sigmoid(unstable_opacity_low))
-        temp["opacity_raw"] = torch.where(attach[:, None], low, temp["opacity_raw"])
+                                      0.5 * self.args.add_depth_thres)
+        attach = attach.view(torch.bool) if attach.dtype == torch.uint8 else attach.bool()      # 0 / 1 bytes: no conversion pass
+        temp["opacity_raw"] = temp["opacity_raw"].masked_fill(attach[:, None], inverse_sigmoid(unstable_opacity_low))
 
     def temp_to_optimize(self, temp, keep):
         """update_geometry (gaussian_pointcloud.py:366-405) + cat into the unstable cloud (mapper.py:886-899): the in-plane
@@ -587,7 +587,8 @@ class Mapping:
         n_all = int(keep.shape[0])
         sel = torch.nonzero(keep).reshape(-1)                        # synchronisation 1 of the add: what the filter left
         if int(sel.shape[0]) < n_all:
-            temp = {k: v[sel] for k, v in temp.items()}
+            fused = getattr(self.ops, "new_rows", None) is not None       # rtgs_new_rows reads no normals
+            temp = {k: v[sel] for k, v in temp.items() if not (fused and k == "normal")}
         xyz = temp["xyz"].contiguous()
         n = xyz.shape[0]
         if n == 0:
@@ -765,9 +766,8 @@ class Mapping:
         mask = mask.reshape(-1).bool()
         n = int(mask.sum()) if count is None else int(count)
         if n > 0:
-            conf, tick = o.aux["confidence"][:nf, 0], o.aux["add_tick"][:nf, 0]
-            o.aux["confidence"][:nf, 0] = torch.where(mask, torch.zeros_like(conf), conf)
-            o.aux["add_tick"][:nf, 0] = torch.where(mask, torch.full_like(tick, int(self.time)), tick)
+            o.aux["confidence"][:nf, 0].masked_fill_(mask, 0)
+            o.aux["add_tick"][:nf, 0].masked_fill_(mask, int(self.time))
             self.stats["released"] += n
 
     def gaussians_delete(self, unstable=True):
