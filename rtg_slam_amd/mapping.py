@@ -121,22 +121,39 @@ class Frame:
         self.FoVx = 2 * math.atan(cam.W / (2 * cam.fx))
         self.FoVy = 2 * math.atan(cam.H / (2 * cam.fy))
         self.device, self.uid = device, uid
-        self.K = torch.tensor([[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], dtype=torch.float32, device=device)
-        c2w = torch.as_tensor(np.asarray(c2w, dtype=np.float64))
-        self.camera_center = c2w[:3, 3].float().to(device)
         self._rs = None
+        self._first = True
         self.updatePose(c2w)
 
     def updatePose(self, pose_c2w):
-        c2w = torch.as_tensor(np.asarray(pose_c2w, dtype=np.float64))
-        self.c2w = c2w
+        """Everything the device reads of a pose - W2C^T (the view matrix), W2C, C2W, and at construction the intrinsics and
+        the camera centre - travels as ONE host-to-device copy (separately: five small copies, ~20 us of host time each)."""
+        c2w = np.ascontiguousarray(np.asarray(pose_c2w.numpy() if torch.is_tensor(pose_c2w) else pose_c2w, dtype=np.float64))
+        self.c2w = torch.from_numpy(c2w.copy())
         self.pose_version += 1
-        w2c = torch.linalg.inv(c2w)
-        self.R = w2c[:3, :3].t().numpy().copy()
-        self.T = w2c[:3, 3].numpy().copy()
-        self.world_view_transform = w2c.float().t().contiguous().to(self.device)
+        w2c = np.linalg.inv(c2w)
+        self.R = w2c[:3, :3].T.copy()
+        self.T = w2c[:3, 3].copy()
+        pack = np.zeros((5, 16), dtype=np.float32)
+        pack[0] = w2c.T.astype(np.float32).reshape(-1)
+        pack[1] = w2c.astype(np.float32).reshape(-1)
+        pack[2] = c2w.astype(np.float32).reshape(-1)
+        pack[4] = pack[2]
+        pack[4, 3::4] = 0                          # get_rot(c2w): the translation column cleared (SLAM/utils.py: get_rot)
+        pack[4, 15] = pack[2, 15]
+        if self._first:
+            pack[3, :9] = np.array([[self.fx, 0, self.cx], [0, self.fy, self.cy], [0, 0, 1]], dtype=np.float32).reshape(-1)
+            pack[3, 9:12] = c2w[:3, 3].astype(np.float32)
+        dev = torch.from_numpy(pack).to(self.device)
+        self.world_view_transform = dev[0].view(4, 4)
         self.full_proj_transform = self.world_view_transform
-        self._w2c = w2c.float().to(self.device)
+        self._w2c = dev[1].view(4, 4)
+        self._c2w_dev = dev[2].view(4, 4)
+        self._rot_dev = dev[4].view(4, 4)
+        if self._first:
+            self.K = dev[3, :9].view(3, 3)
+            self.camera_center = dev[3, 9:12]          # NOT refreshed by later poses (see the class docstring)
+            self._first = False
         self._rs = None
 
     @property
@@ -145,7 +162,11 @@ class Frame:
 
     @property
     def get_c2w(self):
-        return self.c2w.float().to(self.device)
+        return self._c2w_dev
+
+    @property
+    def get_rot(self):
+        return self._rot_dev
 
     def get_w2c(self):
         return self._w2c

@@ -56,8 +56,7 @@ class Tracker:
         self.pose_es.append(pose)
         frame.updatePose(pose)
         c2w = frame.get_c2w                                                   # transform_map, SLAM/utils.py:56-63; tracker.py:283-288
-        rot = c2w.clone()
-        rot[:3, 3] = 0                                                        # get_rot(c2w)
+        rot = frame.get_rot                                                   # get_rot(c2w): translation cleared
         frame_map["vertex_map_w"] = self.so.transform_map(frame_map["vertex_map_c"], c2w)
         frame_map["normal_map_w"] = self.so.transform_map(frame_map["normal_map_c"], rot)
         # transform_map moves the zero vertices of invalid pixels too; they are never sampled (depth 0 / zero normal masks)
