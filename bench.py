@@ -785,6 +785,7 @@ def sequence_leg(cam, dev, n_frames, seed=21):
         "tracking_ms_mean": round(1e3 * rep["tracking_s_mean"], 3),
         "peak_device_memory_MB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 20, 1),
         "speculation": current_context().speculation_stats(),
+        "plain_renders": current_context().plain_stats(),
         "what": "slam.py:56-95 + mapper.py:97-126 on a synthetic Replica-shaped stream (configs[2]); fps = 1 / mean mapping "
                 "seconds per frame (utils/monitor.py:22-24); `fps_tracking_plus_mapping` counts the tracker too (single process, "
                 "sequential)"})

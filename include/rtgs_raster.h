@@ -246,6 +246,14 @@ int rtgs_raster_forward_verify_ctx(rtgs_ctx* ctx, int64_t* num_rendered_host);
 const uint32_t* rtgs_raster_spec_fail_ptr_ctx(rtgs_ctx* ctx);
 void rtgs_raster_set_speculation_ctx(rtgs_ctx* ctx, int enable);
 int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3_host);
+/* Forwards WITHOUT a backward (RTGS_FWD_NO_BACKWARD; the plain renders of a SLAM frame, SLAM/render.py under torch.no_grad)
+ * on a context whose last such forward on the same image declined the near slice place their instances in one pass and check
+ * the assumed sort class themselves before returning (round 6): no count / scan / scatter and no host wait before the blend; a
+ * wrong guess is redone on the classic path inside the same call, so results never differ.  set_plain_onepass 0 = always the
+ * classic path (RTGS_PLAIN_ONEPASS=0 at load time); either value forgets the history.  plain_stats: [0] such forwards, [1] of
+ * which were redone. */
+void rtgs_raster_set_plain_onepass_ctx(rtgs_ctx* ctx, int enable);
+int rtgs_raster_plain_stats_ctx(rtgs_ctx* ctx, int64_t* out2_host);
 /* Byte offsets inside the image buffer - [0] tile ranges (uint2 per tile), [1] n_contrib (u32 per pixel), [2] BwdInfo,
  * [3] tile walk (u32 per tile: bits 0..1 = 0 strip / 1 row-granular / 2 MFMA, bits 8.. the measured share in 1/1000),
  * [4] total size, [5] list position of every pixel's depth owner (u32 per pixel). */

@@ -151,6 +151,18 @@ int rtgs_draw_new_points(const int32_t* cand, int32_t n_cand, int32_t k, uint64_
                          int32_t* pick_out, void* stream);
 int rtgs_filter_keep(int32_t n, const float* dist2, const int32_t* idx, const float* scales, float ratio, uint8_t* keep, void* stream);
 int rtgs_bbox_pad(int32_t n, const float* xyz, float pad, float* out6, void* stream);
+/* The two ordered compactions of Mapping.temp_to_optimize as one single-workgroup launch each (the tensor form: nonzero - five
+ * launches - and a gather per array).  compact_points: the candidates with keep[i] != 0 (the filter's survivors, mapper.py:826),
+ * in order, into out_* (capacity n rows each); count_out int32[1] = how many.  append_valid_rows: the rows of packed59 [n,59]
+ * (rtgs_new_rows) with valid[i] != 0, in order, split into the map's parameter blocks at xyz_dst [.,3] / shs_dst [.,48] /
+ * raw8_dst [.,8] (pointers to the first free row; the caller guarantees n free rows), and for each of the n_aux <= 8 side arrays
+ * (4-byte elements, one per row; host array of device pointers to the first free row) the 32-bit pattern aux_fill_bits[k];
+ * count_out = how many rows were appended. */
+int rtgs_compact_points(int32_t n, const uint8_t* keep, const float* xyz, const float* color, const float* opacity_raw,
+                        const float* rots, float* out_xyz, float* out_color, float* out_opacity_raw, float* out_rots,
+                        int32_t* count_out, void* stream);
+int rtgs_append_valid_rows(int32_t n, const uint8_t* valid, const float* rows59, float* xyz_dst, float* shs_dst, float* raw8_dst,
+                           int32_t n_aux, void* const* aux_dst, const uint32_t* aux_fill_bits, int32_t* count_out, void* stream);
 int rtgs_new_rows(int32_t n, const float* xyz, const float* color, const float* opacity_raw, const float* rots, const float* dist2,
                   const int32_t* idx, const float* exist_scales, float min_radius, float max_radius, float scale_factor,
                   float factor_x, float factor_y, float factor_z, float* packed59, uint8_t* valid, void* stream);

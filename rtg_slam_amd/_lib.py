@@ -163,6 +163,8 @@ _SIGNATURES = {
     "rtgs_raster_spec_fail_ptr_ctx": (C.c_void_p, [_P]),
     "rtgs_raster_set_speculation_ctx": (None, [_P, C.c_int]),
     "rtgs_raster_speculation_stats_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "rtgs_raster_plain_stats_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "rtgs_raster_set_plain_onepass_ctx": (None, [_P, C.c_int]),
     "rtgs_raster_image_offsets": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "rtgs_raster_set_near_slice_ctx": (None, [_P, C.c_int, C.c_int]),
     "rtgs_raster_last_slice_stats_ctx": (C.c_int, [_P, C.POINTER(C.c_int64)]),
@@ -204,6 +206,8 @@ _SIGNATURES = {
     "rtgs_draw_new_points": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "rtgs_filter_keep": (C.c_int, [C.c_int32, _P, _P, _P, C.c_float, _P, _P]),
     "rtgs_bbox_pad": (C.c_int, [C.c_int32, _P, C.c_float, _P, _P]),
+    "rtgs_compact_points": (C.c_int, [C.c_int32] + [_P] * 11),
+    "rtgs_append_valid_rows": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
     "rtgs_new_rows": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, _P, _P, _P]),
     "rtgs_attach_test": (C.c_int, [_P, C.c_int32, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _P, _P, _P,

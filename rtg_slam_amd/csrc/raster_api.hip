@@ -131,6 +131,12 @@ struct rtgs_ctx {
   } spec;
   bool speculation = true;
   int64_t spec_stats[3] = {0, 0, 0};   // speculative forwards, failed ones, forwards that could not speculate
+  // Forwards WITHOUT a backward (the plain renders of a SLAM frame: RTGS_FWD_NO_BACKWARD) keep a history of their own - the
+  // Gaussian count changes from one to the next, only the image and the sort class of the longest tile list are assumed -
+  // and check their guess before they return (forward_impl: `immediate`), so nothing is ever left pending.
+  Plan plan_plain;
+  bool plain_onepass = true;           // RTGS_PLAIN_ONEPASS=0: count / scan / scatter with the two host waits, as before round 6
+  int64_t plain_stats[2] = {0, 0};     // immediate one-pass forwards, those that had to be redone
 };
 
 namespace rtgs {
@@ -142,6 +148,7 @@ static rtgs_ctx* default_ctx() {
     if (const char* e = getenv("RTGS_NEAR_SLICE_BUDGET")) { const int b = atoi(e); if (b > 0) n->slice_budget = b; }
     if (const char* e = getenv("RTGS_SPECULATE")) n->speculation = atoi(e) != 0;
     if (const char* e = getenv("RTGS_BIN_ONEPASS")) n->onepass = atoi(e) != 0;
+    if (const char* e = getenv("RTGS_PLAIN_ONEPASS")) n->plain_onepass = atoi(e) != 0;
     if (const char* e = getenv("RTGS_BWD_WALK")) { const int m = atoi(e); n->bwd_walk = (m >= 1 && m <= 4) ? m : 0; }
     return n;
   }();
@@ -356,7 +363,7 @@ const char* rtgs_version(void) { return "rtgs-hip 0.2.0 (gfx950)"; }
 
 rtgs_ctx* rtgs_ctx_create(void) {
   rtgs_ctx* c = new (std::nothrow) rtgs_ctx();
-  if (c) { c->slice_mode = default_ctx()->slice_mode; c->slice_budget = default_ctx()->slice_budget; c->bwd_walk = default_ctx()->bwd_walk; c->onepass = default_ctx()->onepass; c->speculation = default_ctx()->speculation; }
+  if (c) { c->slice_mode = default_ctx()->slice_mode; c->slice_budget = default_ctx()->slice_budget; c->bwd_walk = default_ctx()->bwd_walk; c->onepass = default_ctx()->onepass; c->speculation = default_ctx()->speculation; c->plain_onepass = default_ctx()->plain_onepass; }
   return c;
 }
 void rtgs_ctx_destroy(rtgs_ctx* c) {
@@ -500,12 +507,21 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   if (c->spec.pending) return RTGS_E_INVALID;          // the previous speculative forward was never verified
   c->spec.geom = nullptr; c->spec.fail_dev = nullptr;
   {
-    const rtgs_ctx::Plan& pl = c->plan;
-    const bool eligible = (flags & RTGS_FWD_SPECULATE) && c->speculation && want_bwd && P > 0 && !sort_path && !s->debug &&
-                          pl.valid && pl.P == P && pl.H == p.H && pl.W == p.W && pl.slice_mode == c->slice_mode &&
-                          pl.slice_budget == c->slice_budget && (pl.kind == 0 ? !sliced : (pl.kind == 1 || pl.kind == 2) && sliced);
+    // `immediate`: a forward without a backward whose last such forward on this image declined the near slice runs the same
+    // one-pass flow (no count / scan / scatter, no host wait before the blend) and looks at the published totals itself,
+    // while the blend runs; a wrong guess (a list outgrew the assumed sort class, the slice was taken after all) falls
+    // through to the classic path below.  Nothing but the image size and that class is assumed: P may differ.
+    rtgs_ctx::Plan& pp = c->plan_plain;
+    const bool immediate = !(flags & RTGS_FWD_SPECULATE) && !want_bwd && c->speculation && c->plain_onepass && c->onepass &&
+                           P > 0 && !sort_path && !s->debug && sliced && G.slice_seg && pp.valid && pp.kind == 2 &&
+                           pp.H == p.H && pp.W == p.W && pp.slice_mode == c->slice_mode && pp.slice_budget == c->slice_budget;
+    const rtgs_ctx::Plan& pl = immediate ? pp : c->plan;
+    const bool eligible = immediate ||
+                          ((flags & RTGS_FWD_SPECULATE) && c->speculation && want_bwd && P > 0 && !sort_path && !s->debug &&
+                           pl.valid && pl.P == P && pl.H == p.H && pl.W == p.W && pl.slice_mode == c->slice_mode &&
+                           pl.slice_budget == c->slice_budget && (pl.kind == 0 ? !sliced : (pl.kind == 1 || pl.kind == 2) && sliced));
     const uint32_t capR = pl.R_hi + pl.R_hi / 8u + 8192u, capL = sort_class_cap(pl.longest_hi),
-                   capS = pl.slots_hi + pl.slots_hi / 8u + 8192u;
+                   capS = immediate ? 0u : pl.slots_hi + pl.slots_hi / 8u + 8192u;
     if ((flags & RTGS_FWD_SPECULATE) && !(eligible && (pl.kind == 1 || capS <= SLOTS_MAX))) ++c->spec_stats[2];
     if (eligible && (pl.kind == 1 || capS <= SLOTS_MAX)) {
       uint32_t* const fail = slice_ctr + 6;            // inside the span every forward clears
@@ -579,7 +595,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                                  (float2*)(geom + G.uv), st);
           prof_mark(c, EV_PRE, st);
           launch_slice_hist(P, zbin, tiles_touched, radii, slice_hist, slice_cover, st,
-                            BwdInfoInit{(BwdInfo*)(img + I.bwd_info), (SplatGrad*)(bin + B.slot_grads), capS, 1u});
+                            BwdInfoInit{(BwdInfo*)(img + I.bwd_info), (SplatGrad*)(bin + B.slot_grads), capS, immediate ? 0u : 1u});
           // (the decision - is the slice still declined? - is re-derived inside visible_compact: no slice_compact launch)
           vl = SliceList{(const uint32_t*)(geom + G.vis_ids), slice_ctr + 4};
           launch_visible_compact(P, zbin, (uint32_t*)(geom + G.vis_ids), slice_ctr + 4, tiles_touched, offsets, slice_ctr + 5, fail, st,
@@ -598,14 +614,14 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
                            (size_t)P, st);
           prof_mark(c, EV_SCAN, st); prof_mark(c, EV_BIN0, st); prof_mark(c, EV_EMIT, st);
           const BinFinish fin{tile_count, ntiles, info, info_host, slice_ctr + 5, nullptr, slice_ctr + 4, c->seq,
-                              SpecCaps{fail, 0xffffffffu, capL, capS, (const int32_t*)(slice_ctr + 3)}};
+                              SpecCaps{fail, 0xffffffffu, capL, immediate ? 0xffffffffu : capS, (const int32_t*)(slice_ctr + 3)}};
           launch_bin_tilesort(ntiles, capL, ranges, (const unsigned long long*)(bin + B.keys_a), (uint32_t*)(bin + B.vals_b), fail, st,
                               tile_count, seg2, ranges, &fin);
         } else {
         if (launch_bin_count(pg, splats, radii, tile_mask, tile_count, vl.ids ? (uint16_t*)(geom + G.block_counts_vis) : block_counts,
                              sel2, vl, (size_t)P, st) != 0)
           return RTGS_E_HIP;
-        const SpecCaps caps{fail, capR, capL, capS, pl.kind == 2 ? (const int32_t*)(slice_ctr + 3) : nullptr};
+        const SpecCaps caps{fail, capR, capL, immediate ? 0xffffffffu : capS, pl.kind == 2 ? (const int32_t*)(slice_ctr + 3) : nullptr};
         launch_bin_tilescan(ntiles, tile_count, ranges, cursor, info, info_host, nullptr, nullptr,
                             vl.ids ? slice_ctr + 5 : offsets + (P - 1), vl.ids ? nullptr : tiles_touched + (P - 1), c->seq, caps, st);
         prof_mark(c, EV_SCAN, st);
@@ -629,6 +645,25 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       }
       HIP_TRY(hipGetLastError());
       c->hint_geom = geom; c->hint_walk = fwd_walk;
+      if (immediate) {
+        // the blend is on its way; the totals were published before it started
+        if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
+        const bool ok = (seg_main || pub[0] <= capR) && pub[1] <= capL && (int32_t)pub[6] < 0;
+        ++c->plain_stats[0];
+        if (ok) {
+          pp.note(pub[0], pub[1], 0u);
+          c->last_listed = pub[2];
+          c->plan.valid = false;             // as after every forward without a backward (see the end of this function)
+          c->stats[0] = (int64_t)pub[0]; c->stats[1] = 32 + bits_for((uint32_t)ntiles); c->stats[2] = ntiles;
+          c->stats[3] = (int64_t)G.total; c->stats[4] = (int64_t)b_total; c->stats[5] = (int64_t)I.total; c->stats[6] = 1;
+          c->stats[7] = (int64_t)pub[1];
+          *num_rendered_host = (int64_t)pub[0];
+          return RTGS_OK;
+        }
+        // wrong guess: every guarded kernel after the one that noticed returned at once; start over on the classic path
+        pp.valid = false;
+        ++c->plain_stats[1];
+      } else {
       c->spec.pending = true; c->spec.kind = pl.kind; c->spec.seq = c->seq; c->spec.capR = seg_main ? 0xffffffffu : capR; c->spec.capL = capL;
       c->spec.capS = capS; c->spec.geom = geom; c->spec.fail_dev = fail; c->spec.stream = stream; c->spec.ntiles = ntiles;
       c->spec.G_total = (int64_t)G.total; c->spec.B_total = (int64_t)b_total; c->spec.I_total = (int64_t)I.total;
@@ -636,6 +671,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       *num_rendered_host = (int64_t)pl.R + (int64_t)pl.R1;      // the last verified call's; the exact number comes with verify
       if (*num_rendered_host < 1) *num_rendered_host = 1;
       return RTGS_OK;
+      }
     }
   }
   if (P == 0) HIP_TRY(hipMemsetAsync(zero_words, 0, (size_t)zero_n * sizeof(uint32_t), st));   // ranges1_bwd for the backward
@@ -845,6 +881,16 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
     if (!same_shape || !pl.valid) { pl.R_hi = pl.longest_hi = pl.slots_hi = 0; }     // another map / image: start the maxima over
     pl.note((uint32_t)R, longest, slots);
     pl.R1 = (uint32_t)R1; pl.n_fin = n_fin;
+    if (!want_bwd) {
+      // ... and what the next forward WITHOUT a backward on this image may assume (any Gaussian count)
+      rtgs_ctx::Plan& pp = c->plan_plain;
+      const bool same_image = pp.valid && pp.H == p.H && pp.W == p.W;
+      pp.kind = (!sort_path && considered) ? 2 : -1;
+      pp.valid = pp.kind == 2 && R <= 0xffffffffll;
+      pp.P = P; pp.H = p.H; pp.W = p.W; pp.slice_mode = c->slice_mode; pp.slice_budget = c->slice_budget;
+      if (!same_image || !pp.valid) { pp.R_hi = pp.longest_hi = pp.slots_hi = 0; }
+      pp.note((uint32_t)R, longest, 0u);
+    }
   }
   return RTGS_OK;
 }
@@ -1036,6 +1082,16 @@ int rtgs_raster_speculation_stats_ctx(rtgs_ctx* ctx, int64_t* out3) {
   if (!out3) return RTGS_E_INVALID;
   memcpy(out3, use(ctx)->spec_stats, sizeof(use(ctx)->spec_stats));
   return RTGS_OK;
+}
+int rtgs_raster_plain_stats_ctx(rtgs_ctx* ctx, int64_t* out2) {
+  if (!out2) return RTGS_E_INVALID;
+  memcpy(out2, use(ctx)->plain_stats, sizeof(use(ctx)->plain_stats));
+  return RTGS_OK;
+}
+void rtgs_raster_set_plain_onepass_ctx(rtgs_ctx* ctx, int enable) {
+  rtgs_ctx* c = use(ctx);
+  c->plain_onepass = enable != 0;
+  c->plan_plain = rtgs_ctx::Plan();
 }
 uint32_t rtgs_raster_last_listed_ctx(rtgs_ctx* c) { return use(c)->last_listed; }
 void rtgs_raster_set_bwd_debug(int bits) { rtgs::set_bwd_debug(bits); }

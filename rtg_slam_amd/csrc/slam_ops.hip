@@ -781,6 +781,73 @@ __global__ void __launch_bounds__(1024) bbox_pad_kernel(int n, const float* __re
   }
 }
 
+// Ordered compactions of a frame's new points, one single-workgroup launch each (n <= ~41 000 candidates; the tensor form is
+// nonzero - five launches and the host wait - plus one gather per array).  block_slot: this thread's output slot within a
+// chunk of 1024 flags and the chunk's total, by ballot + sixteen wave counts.
+__device__ __forceinline__ int block_slot(bool flag, int* s_cnt, int& total) {
+  const unsigned long long b = __ballot(flag);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) s_cnt[w] = __popcll(b);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { const int c = s_cnt[k]; off += k < w ? c : 0; tot += c; }
+  __syncthreads();
+  total = tot;
+  return off + __popcll(b & ((1ull << lane) - 1ull));
+}
+// compact_points: the candidates the filter kept (Mapping.temp_to_optimize's first compaction, mapper.py:826), in order.
+__global__ void __launch_bounds__(1024) compact_points_kernel(int n, const uint8_t* __restrict__ keep, const float* __restrict__ xyz,
+                                                              const float* __restrict__ color, const float* __restrict__ opac,
+                                                              const float* __restrict__ rots, float* __restrict__ o_xyz,
+                                                              float* __restrict__ o_color, float* __restrict__ o_opac,
+                                                              float* __restrict__ o_rots, int32_t* __restrict__ count_out) {
+  __shared__ int s_cnt[16];
+  int base = 0;
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + (int)threadIdx.x;
+    const bool flag = i < n && keep[i] != 0;
+    int tot;
+    const int o = base + block_slot(flag, s_cnt, tot);
+    if (flag) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { o_xyz[o * 3 + c] = xyz[i * 3 + c]; o_color[o * 3 + c] = color[i * 3 + c]; }
+      o_opac[o] = opac[i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o_rots[o * 4 + c] = rots[i * 4 + c];
+    }
+    base += tot;
+  }
+  if (threadIdx.x == 0) *count_out = base;
+}
+// append_valid_rows: the second compaction (the candidates update_geometry accepts) straight into the map's own arrays behind
+// its last row - packed rows split into the three parameter blocks, every side array set to its value for a new row.
+struct AuxFill { uint32_t* dst[8]; uint32_t bits[8]; int n; };
+__global__ void __launch_bounds__(1024) append_valid_rows_kernel(int n, const uint8_t* __restrict__ valid, const float* __restrict__ rows59,
+                                                                 float* __restrict__ d_xyz, float* __restrict__ d_shs,
+                                                                 float* __restrict__ d_raw8, AuxFill aux, int32_t* __restrict__ count_out) {
+  __shared__ int s_cnt[16];
+  int base = 0;
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + (int)threadIdx.x;
+    const bool flag = i < n && valid[i] != 0;
+    int tot;
+    const int o = base + block_slot(flag, s_cnt, tot);
+    if (flag) {
+      const float* r = rows59 + (size_t)i * 59;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) d_xyz[(size_t)o * 3 + c] = r[c];
+#pragma unroll 4
+      for (int c = 0; c < 48; ++c) d_shs[(size_t)o * 48 + c] = r[3 + c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d_raw8[(size_t)o * 8 + c] = r[51 + c];
+      for (int k = 0; k < aux.n; ++k) aux.dst[k][o] = aux.bits[k];
+    }
+    base += tot;
+  }
+  if (threadIdx.x == 0) *count_out = base;
+}
+
 // new_rows: update_geometry (gaussian_pointcloud.py:366-405) + the packing of the new rows (mapper.py:886-899).  Candidate i
 // has its three nearest neighbours among (the n candidates, then the existing Gaussians): in-plane scale = rms of
 // (distance - 3 radius) over the three, clamped; a candidate INSIDE three radii of a neighbour is invalid.  Writes the packed
@@ -1105,11 +1172,15 @@ int rtgs_accumulate_error(int32_t H, int32_t W, int32_t P, const float* color_er
       !outlier_count || !scratch)
     return -1;
   hipStream_t st = (hipStream_t)stream;
-  SLAM_TRY(hipMemsetAsync(g_color, 0, (size_t)P * 4, st));
-  SLAM_TRY(hipMemsetAsync(g_depth, 0, (size_t)P * 4, st));
-  SLAM_TRY(hipMemsetAsync(g_normal, 0, (size_t)P * 4, st));
-  SLAM_TRY(hipMemsetAsync(outlier_count, 0, (size_t)P * 4, st));
-  SLAM_TRY(hipMemsetAsync(scratch, 0, (size_t)P * 8, st));
+  if (g_depth == g_color + P && g_normal == g_depth + P && (float*)outlier_count == g_normal + P && scratch == g_normal + 2 * (size_t)P) {
+    SLAM_TRY(hipMemsetAsync(g_color, 0, (size_t)P * 24, st));        // one allocation behind the five arrays: one clear
+  } else {
+    SLAM_TRY(hipMemsetAsync(g_color, 0, (size_t)P * 4, st));
+    SLAM_TRY(hipMemsetAsync(g_depth, 0, (size_t)P * 4, st));
+    SLAM_TRY(hipMemsetAsync(g_normal, 0, (size_t)P * 4, st));
+    SLAM_TRY(hipMemsetAsync(outlier_count, 0, (size_t)P * 4, st));
+    SLAM_TRY(hipMemsetAsync(scratch, 0, (size_t)P * 8, st));
+  }
   const int n = H * W;
   hipLaunchKernelGGL(accumulate_error_kernel, dim3(grid1(n)), dim3(256), 0, st, n, color_err, depth_err, normal_err,
                      color_index, depth_index, thr_c, thr_d, thr_n, g_color, g_depth, g_normal, outlier_count, scratch,
@@ -1340,6 +1411,35 @@ int rtgs_filter_keep(int32_t n, const float* dist2, const int32_t* idx, const fl
 int rtgs_bbox_pad(int32_t n, const float* xyz, float pad, float* out6, void* stream) {
   if (n <= 0 || !xyz || !out6) return -1;
   hipLaunchKernelGGL(bbox_pad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)n, xyz, pad, out6);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_compact_points(int32_t n, const uint8_t* keep, const float* xyz, const float* color, const float* opacity_raw,
+                        const float* rots, float* out_xyz, float* out_color, float* out_opacity_raw, float* out_rots,
+                        int32_t* count_out, void* stream) {
+  if (n < 0 || !count_out) return -1;
+  if (n > 0 && (!keep || !xyz || !color || !opacity_raw || !rots || !out_xyz || !out_color || !out_opacity_raw || !out_rots)) return -1;
+  hipLaunchKernelGGL(compact_points_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)n, keep, xyz, color, opacity_raw, rots,
+                     out_xyz, out_color, out_opacity_raw, out_rots, count_out);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_append_valid_rows(int32_t n, const uint8_t* valid, const float* rows59, float* xyz_dst, float* shs_dst, float* raw8_dst,
+                           int32_t n_aux, void* const* aux_dst, const uint32_t* aux_fill_bits, int32_t* count_out, void* stream) {
+  if (n < 0 || n_aux < 0 || n_aux > 8 || !count_out) return -1;
+  if (n > 0 && (!valid || !rows59 || !xyz_dst || !shs_dst || !raw8_dst)) return -1;
+  if (n_aux > 0 && (!aux_dst || !aux_fill_bits)) return -1;
+  AuxFill aux;
+  aux.n = n_aux;
+  for (int k = 0; k < 8; ++k) {
+    aux.dst[k] = k < n_aux ? (uint32_t*)aux_dst[k] : nullptr;
+    aux.bits[k] = k < n_aux ? aux_fill_bits[k] : 0u;
+    if (k < n_aux && !aux.dst[k]) return -1;
+  }
+  hipLaunchKernelGGL(append_valid_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)n, valid, rows59, xyz_dst, shs_dst,
+                     raw8_dst, aux, count_out);
   SLAM_TRY(hipGetLastError());
   return 0;
 }

@@ -469,6 +469,51 @@ class ShardedMapOptimizer:
         if self.act is not None and self._act_valid:
             self._activate_rows(r0, self.N, force=True)        # only the new rows
 
+    def append_rows_masked(self, packed_new: torch.Tensor, valid: torch.Tensor, aux: Optional[Dict[str, object]] = None) -> int:
+        """append_rows(packed_new[valid != 0]) without the compaction on the host's side: one kernel (rtgs_append_valid_rows)
+        writes the accepted rows, in order, straight behind the map's last row and counts them; the one host synchronisation
+        reads the count (the tensor form: nonzero, a gather, three block copies, one fill per side array).  `aux`: SCALAR values
+        of side arrays for the new rows.  One rank, local scope, HIP arrays only; returns how many rows were appended."""
+        if self._scope != "local" or self.world != 1 or not packed_new.is_cuda:
+            raise RuntimeError("append_rows_masked(): one rank, local scope, device arrays")
+        from . import _lib
+        self.flush()
+        n = int(packed_new.shape[0])
+        if n == 0:
+            return 0
+        if self.N + n > self.capacity:
+            self._allocate(max(self.N + n, self.capacity + self.capacity // 2))
+        lib, dev, r0 = _lib.load(), self.device, self.N
+        rows = packed_new.float().contiguous()
+        v8 = valid.view(torch.uint8) if valid.dtype == torch.bool else valid.to(torch.uint8)
+        names = list(self._aux_spec)
+        ptrs = (C.c_void_p * max(len(names), 1))()
+        bits = (C.c_uint32 * max(len(names), 1))()
+        import struct
+        for k, name in enumerate(names):
+            width, dtype, fill = self._aux_spec[name]
+            if width != 1 or self.aux[name].element_size() != 4:
+                raise RuntimeError("append_rows_masked(): side arrays of one 4-byte element per row")
+            val = fill if aux is None or name not in aux else aux[name]
+            bits[k] = struct.unpack("<I", struct.pack("<f", float(val)) if dtype.is_floating_point else struct.pack("<i", int(val)))[0]
+            ptrs[k] = self.aux[name].data_ptr() + 4 * r0
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        P = lambda name, c: C.c_void_p(self.state[name]["p"].data_ptr() + 4 * c * r0)
+        with torch.cuda.device(dev):
+            rc = lib.rtgs_append_valid_rows(n, C.c_void_p(v8.contiguous().data_ptr()), C.c_void_p(rows.data_ptr()), P("xyz", 3), P("shs", 48),
+                                            P("raw8", 8), len(names), ptrs, bits, C.c_void_p(count.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(rc, "rtgs_append_valid_rows")
+        m = int(count.item())
+        if m == 0:
+            return 0
+        self.version += 1
+        self.N += m
+        self._shape_changed(permuted=False)
+        if self.act is not None and self._act_valid:
+            self._activate_rows(r0, self.N, force=True)        # only the new rows
+        return m
+
     def _gather_sharded_adam(self):
         """Row-sharded form on several ranks: the shard a trainable row belongs to depends on N (shard_rows), so an append
         moves rows between ranks - and their Adam moments must move with them, or the next step pairs moments and rows of

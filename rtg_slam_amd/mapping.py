@@ -204,7 +204,7 @@ class HipOps:
         self.keys = random.Random(int(getattr(args, "seed", 0)))           # one 64-bit key per sampling pass (rtgs_draw_new_points)
         self.kernel_draw = True
         if __import__("os").environ.get("RTGS_ADD_KERNELS", "1") == "0":     # A/B aid: the tensor forms of the draw, the filter and the box
-            self.kernel_draw, self.filter_keep, self.bbox_pad = False, None, None
+            self.kernel_draw, self.filter_keep, self.bbox_pad, self.compact_points = False, None, None, None
 
     def make_optimizer(self, packed, lr_col, capacity):
         return mo.ShardedMapOptimizer(packed, lr_col=lr_col, capacity=capacity)
@@ -291,6 +291,9 @@ class HipOps:
     def filter_keep(self, *a):
         return self.so.filter_keep(*a)
 
+    def compact_points(self, *a):
+        return self.so.compact_points(*a)
+
     def bbox_pad(self, *a):
         return self.so.bbox_pad(*a)
 
@@ -353,6 +356,7 @@ class Mapping:
     def __init__(self, args, device, ops=None, capacity: Optional[int] = None, lr_scale: float = 1.0):
         self.args, self.device = args, device
         self.ops = ops if ops is not None else HipOps(args, device)
+        self.masked_append = isinstance(self.ops, HipOps) and __import__("os").environ.get("RTGS_ADD_KERNELS", "1") != "0"
         self.time = 0
         self.iter = 0
         self.processed_frames = deque(maxlen=args.memory_length)
@@ -606,10 +610,15 @@ class Mapping:
         existing ones inside the new points' box; a new point INSIDE 3 radii of a neighbour is dropped."""
         a = self.args
         n_all = int(keep.shape[0])
-        sel = torch.nonzero(keep).reshape(-1)                        # synchronisation 1 of the add: what the filter left
-        if int(sel.shape[0]) < n_all:
-            fused = getattr(self.ops, "new_rows", None) is not None       # rtgs_new_rows reads no normals
-            temp = {k: v[sel] for k, v in temp.items() if not (fused and k == "normal")}
+        if getattr(self.ops, "compact_points", None) is not None and getattr(self.ops, "new_rows", None) is not None:
+            # synchronisation 1 of the add - what the filter left - as one launch + the count (rtgs_compact_points)
+            cx, cc, co, cr, n = self.ops.compact_points(keep, temp["xyz"], temp["color"], temp["opacity_raw"], temp["rots"])
+            temp = dict(xyz=cx, color=cc, opacity_raw=co, rots=cr)
+        else:
+            sel = torch.nonzero(keep).reshape(-1)                    # synchronisation 1 of the add: what the filter left
+            if int(sel.shape[0]) < n_all:
+                fused = getattr(self.ops, "new_rows", None) is not None       # rtgs_new_rows reads no normals
+                temp = {k: v[sel] for k, v in temp.items() if not (fused and k == "normal")}
         xyz = temp["xyz"].contiguous()
         n = xyz.shape[0]
         if n == 0:
@@ -622,11 +631,17 @@ class Mapping:
             d2, idx = self.ops.knn_query(torch.cat([xyz, gd["xyz"]]), xyz, 0, box)
             rows, valid = self.ops.new_rows(xyz, temp["color"], temp["opacity_raw"], temp["rots"], d2, idx, gd["scales"],
                                             a.min_radius, a.max_radius, a.scale_factor, a.xyz_factor)
-            good = torch.nonzero(valid).reshape(-1)                  # synchronisation 2 of the add
-            m = int(good.shape[0])
-            if m == 0:
-                return
-            self.opt.append_rows(rows if m == n else rows[good], aux={"add_tick": int(self.time)})
+            if self.masked_append and getattr(self.opt, "append_rows_masked", None) is not None and getattr(self.opt, "world", 1) == 1:
+                # synchronisation 2 of the add: the accepted rows go straight behind the map's last row, the count comes back
+                m = self.opt.append_rows_masked(rows, valid, aux={"add_tick": int(self.time)})
+                if m == 0:
+                    return
+            else:
+                good = torch.nonzero(valid).reshape(-1)              # synchronisation 2 of the add
+                m = int(good.shape[0])
+                if m == 0:
+                    return
+                self.opt.append_rows(rows if m == n else rows[good], aux={"add_tick": int(self.time)})
             self.stats["added"] += m
             self.stats["last_add"] = (n_all, n, m)
             return

@@ -89,6 +89,15 @@ class RasterContext:
         _lib.check(_lib.load().rtgs_raster_speculation_stats_ctx(self.ptr, out), "rtgs_raster_speculation_stats")
         return dict(speculative=int(out[0]), failed=int(out[1]), not_eligible=int(out[2]))
 
+    def set_plain_onepass(self, enable: bool):
+        """Forwards without a backward: one-pass placement with the check inside the call (include/rtgs_raster.h)."""
+        _lib.load().rtgs_raster_set_plain_onepass_ctx(self.ptr, int(bool(enable)))
+
+    def plain_stats(self):
+        out = (C.c_int64 * 2)()
+        _lib.check(_lib.load().rtgs_raster_plain_stats_ctx(self.ptr, out), "rtgs_raster_plain_stats")
+        return dict(onepass=int(out[0]), redone=int(out[1]))
+
     def set_profiling(self, enable: bool):
         _lib.load().rtgs_raster_set_profiling_ctx(self.ptr, int(bool(enable)))
 

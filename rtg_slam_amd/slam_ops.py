@@ -148,9 +148,10 @@ def accumulate_gaussian_error(H, W, P, color_error, depth_error, normal_error, c
     for t in (ce, de, ne, ci, di):
         if t.numel() != H * W:
             raise RuntimeError(f"accumulate_gaussian_error: expected {H}x{W} maps, got {tuple(t.shape)}")
-    gc, gd, gn = (torch.empty(P, dtype=torch.float32, device=dev) for _ in range(3))
-    oc = torch.empty(P, dtype=torch.int32, device=dev)
-    scratch = torch.empty(2 * max(P, 1), dtype=torch.float32, device=dev)
+    buf = torch.empty(6 * max(P, 1), dtype=torch.float32, device=dev)      # one allocation: the C side clears it in one go
+    gc, gd, gn = buf[0:P], buf[P:2 * P], buf[2 * P:3 * P]
+    oc = buf[3 * P:4 * P].view(torch.int32)
+    scratch = buf[4 * P:]
     with torch.cuda.device(dev):
         rc = lib.rtgs_accumulate_error(H, W, P, _p(ce), _p(de), _p(ne), _p(ci), _p(di), float(color_thres),
                                        float(depth_thres), float(normal_thres), int(bool(mean)), _p(gc), _p(gd), _p(gn),
@@ -341,6 +342,25 @@ def bbox_pad(xyz, pad: float):
         rc = lib.rtgs_bbox_pad(int(xyz.shape[0]), _p(xyz), float(pad), _p(out), _stream(dev))
     _lib.check(rc, "rtgs_bbox_pad")
     return out
+
+
+def compact_points(keep, xyz, color, opacity_raw, rots):
+    """The candidates with keep != 0, in order, and how many (ONE host synchronisation) - Mapping.temp_to_optimize's first
+    compaction in one launch (include/rtgs_slam.h: rtgs_compact_points).  -> (xyz, color, opacity_raw, rots, n)"""
+    lib, dev = _lib.load(), _dev(xyz)
+    n = int(xyz.shape[0])
+    k8 = keep.view(torch.uint8) if keep.dtype == torch.bool else _u8(keep)
+    f = lambda t: t.float().contiguous()
+    xyz, color, opacity_raw, rots = f(xyz), f(color), f(opacity_raw), f(rots)
+    o_xyz, o_col = torch.empty(n, 3, dtype=torch.float32, device=dev), torch.empty(n, 3, dtype=torch.float32, device=dev)
+    o_op, o_rot = torch.empty(n, 1, dtype=torch.float32, device=dev), torch.empty(n, 4, dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_compact_points(n, _p(k8.contiguous()), _p(xyz), _p(color), _p(opacity_raw), _p(rots), _p(o_xyz), _p(o_col), _p(o_op),
+                                     _p(o_rot), _p(count), _stream(dev))
+    _lib.check(rc, "rtgs_compact_points")
+    m = int(count.item())
+    return o_xyz[:m], o_col[:m], o_op[:m], o_rot[:m], m
 
 
 def new_rows(xyz, color, opacity_raw, rots, d2, idx, exist_scales, min_radius, max_radius, scale_factor, xyz_factor):

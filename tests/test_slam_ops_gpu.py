@@ -440,6 +440,48 @@ def test_filter_and_box_kernels_equal_the_torch_form():
             assert (idx[:, 2] < 0).all()                                       # fewer than three neighbours: -1 is "not inside"
 
 
+def test_the_adds_compactions_equal_the_torch_form():
+    """rtgs_compact_points / rtgs_append_valid_rows (round 6) against boolean-mask indexing and ShardedMapOptimizer.append_rows:
+    same rows in the same order, same side arrays, same count - for none, some and all rows, across chunk boundaries (1024)."""
+    from rtg_slam_amd import slam_ops as ops, map_optim as mo
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(17)
+    for n, p_keep in ((1, 1.0), (5, 0.0), (1023, 0.5), (1024, 0.5), (1025, 0.9), (7000, 0.3), (40800, 0.05), (3000, 1.0)):
+        keep = (torch.rand(n, generator=gen) < p_keep).to(dev)
+        xyz, col = torch.randn(n, 3, generator=gen).to(dev), torch.rand(n, 3, generator=gen).to(dev)
+        opa, rot = torch.randn(n, 1, generator=gen).to(dev), torch.randn(n, 4, generator=gen).to(dev)
+        cx, cc, co, cr, m = ops.compact_points(keep, xyz, col, opa, rot)
+        assert m == int(keep.sum())
+        assert torch.equal(cx, xyz[keep]) and torch.equal(cc, col[keep]) and torch.equal(co, opa[keep]) and torch.equal(cr, rot[keep])
+    for n, p_valid in ((4, 0.0), (1500, 0.6), (2048, 1.0), (5000, 0.2)):
+        base = torch.randn(300, mo.COLS, generator=gen).to(dev)
+        rows = torch.randn(n, mo.COLS, generator=gen).to(dev)
+        valid = (torch.rand(n, generator=gen) < p_valid).to(torch.uint8).to(dev)
+        maps = []
+        for masked in (False, True):
+            o = mo.ShardedMapOptimizer(base.clone(), lr_col=mo.default_lr_columns(), capacity=400)      # the append has to grow it
+            for name, dtype, fill in (("confidence", torch.float32, 0.25), ("add_tick", torch.int32, 0), ("strikes", torch.int32, 7)):
+                o.add_aux(name, 1, dtype, fill)
+            v0 = o.version
+            if masked:
+                m = o.append_rows_masked(rows, valid, aux={"add_tick": 41})
+            else:
+                good = torch.nonzero(valid).reshape(-1)
+                m = int(good.shape[0])
+                if m:
+                    o.append_rows(rows[good], aux={"add_tick": 41})
+            assert m == int(valid.sum()) and o.N == 300 + m and (o.version > v0) == (m > 0)
+            maps.append(o)
+        a, b = maps
+        assert torch.equal(a.params, b.params)
+        for name in ("confidence", "add_tick", "strikes"):
+            assert torch.equal(a.aux[name][:a.N], b.aux[name][:b.N]), name
+        if m:
+            assert int(b.aux["add_tick"][300, 0]) == 41 and int(b.aux["strikes"][b.N - 1, 0]) == 7 and float(b.aux["confidence"][300, 0]) == 0.25
+        ga, gb = a.gaussian_data("all"), b.gaussian_data("all")
+        assert all(torch.equal(ga[k], gb[k]) for k in ga)
+
+
 def test_bookkeeping_kernels_equal_the_torch_form():
     """rtgs_error_counters / rtgs_delete_mask (round 6) against the tensor expressions they replace in
     Mapping.error_gaussians_remove and Mapping.gaussians_delete (mapper.py:541-565, 298-335)."""

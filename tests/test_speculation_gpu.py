@@ -174,3 +174,52 @@ def test_alternating_views_do_not_keep_failing():
     off = _run(g, cam, masks, poses, False, 16)
     _same(on, off)
     assert on[2]["speculative"] >= 12 and on[2]["failed"] <= 2, on[2]
+
+
+def _plain_render(g, rows, cam, pose_seed, dev="cuda:0"):
+    """A forward without a backward (what SLAM/render.py does under torch.no_grad) of the first `rows` Gaussians."""
+    from rtg_slam_amd.rasterizer import GaussianRasterizer
+    _, s = ru.make_scene(8, cam, seed=1, pose_seed=pose_seed)
+    rs = ru.hip_settings(s, dev)
+    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+    with torch.no_grad():
+        out = GaussianRasterizer(rs)(means3D=g["xyz"][:rows], opacities=g["opacity"][:rows], shs=g["shs"][:rows], scales=g["scales"][:rows],
+                                     rotations=g["rotations"][:rows], normal_w=g["normal"][:rows],
+                                     tile_mask=torch.ones(gy, gx, dtype=torch.int32, device=dev))
+    return [t.clone() for t in out]
+
+
+def test_plain_renders_place_in_one_pass_and_equal_the_classic_path():
+    """Forwards WITHOUT a backward on a large surface map (round 6, include/rtgs_raster.h: set_plain_onepass): after the
+    forward that learns the near slice is declined, every further one - whatever its Gaussian count - places its instances
+    in one pass and checks the assumed sort class itself; images, index maps and weights equal the classic path's bit for
+    bit; a list that outgrows the assumed class (2 500 specks on one tile appear) is redone inside the call."""
+    dev = "cuda:0"
+    cam = MID
+    g = {k: v.to(dev) for k, v in synth.surface_gaussians(150_000, cam, seed=5).items()}
+    n = 2500
+    gen = torch.Generator().manual_seed(11)
+    specks = dict(xyz=torch.cat([(torch.rand(n, 2, generator=gen) - 0.5) * 0.002, 0.5 + 0.01 * torch.rand(n, 1, generator=gen)], 1).to(dev))
+    # the specks are the LAST rows: row counts below 147 500 leave them out
+    g["xyz"][-n:] = specks["xyz"]
+    g["scales"][-n:] = 0.002
+    g["opacity"][-n:] = 0.02
+    ctx = rz.current_context()
+    plan = [(147_000, None), (146_000, None), (147_400, 3), (120_000, None), (147_500, None), (150_000, None), (150_000, None), (147_000, 3)]
+    results = {}
+    try:
+        for onepass in (False, True):
+            ctx.set_plain_onepass(onepass)
+            before = ctx.plain_stats()
+            results[onepass] = [_plain_render(g, rows, cam, pose) for rows, pose in plan]
+            torch.cuda.synchronize()
+            after = ctx.plain_stats()
+            results[(onepass, "stats")] = {k: after[k] - before[k] for k in after}
+    finally:
+        ctx.set_plain_onepass(True)
+    for a, b in zip(results[False], results[True]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert results[(False, "stats")] == dict(onepass=0, redone=0)
+    st = results[(True, "stats")]
+    assert st["onepass"] >= 5 and st["redone"] >= 1, st          # the first two learn; the specks' first appearance is redone
