@@ -545,40 +545,48 @@ class ShardedMapOptimizer:
                 if k:
                     st[key][:k] = full[lo:lo + k]
 
-    def _permute(self, keep_idx: torch.Tensor, n_frozen: int):
+    def _permute(self, keep_idx: torch.Tensor, n_frozen: int, start: int = 0):
+        """Rows [start, N) become the rows `keep_idx` (indices >= start, in their new order); rows before `start` stay where
+        they are - a deletion or a freeze among the trainable suffix of a SLAM map moves a few thousand rows, not the map."""
         if self._scope != "local":
             raise RuntimeError("rows cannot be removed or frozen inside a global optimisation: end_global_optimization() first")
-        n = int(keep_idx.numel())
+        n = int(start) + int(keep_idx.numel())
         for name, _, _ in BLOCKS:
             pfull = self.state[name]["p"]
-            pfull[:n] = pfull.index_select(0, keep_idx)
-            pfull[n:self.N].zero_()
+            pfull[start:n] = pfull.index_select(0, keep_idx)
+            if n < self.N:
+                pfull[n:self.N].zero_()
         for name, (width, dtype, fill) in self._aux_spec.items():
             a = self.aux[name]
-            a[:n] = a.index_select(0, keep_idx)
-            a[n:self.N] = fill
+            a[start:n] = a.index_select(0, keep_idx)
+            if n < self.N:
+                a[n:self.N] = fill
         self.version += 1
         self.N, self.n_frozen = n, int(n_frozen)
         self._act_valid = False
         self._shape_changed(permuted=True)
 
-    def remove_rows(self, mask: torch.Tensor):
+    def remove_rows(self, mask: torch.Tensor, start: int = 0):
         """Delete the rows where `mask` [N] is set (GaussianPointCloud.delete / remove, gaussian_pointcloud.py:195-235;
-        mapper.py:298-335 drops unstable Gaussians that outlived their window or went transparent).  Order is kept."""
+        mapper.py:298-335 drops unstable Gaussians that outlived their window or went transparent).  Order is kept.
+        `start`: the caller's promise that no row before it is set in the mask (e.g. n_frozen when only trainable rows go) -
+        the rows before it are then neither read nor moved."""
         self.flush()
+        start = max(0, min(int(start), self.N))
         mask = mask.to(self.device).bool().reshape(-1)
-        keep = ~mask
-        nf = int(keep[:self.n_frozen].sum()) if self.n_frozen else 0
-        self._permute(torch.nonzero(keep).reshape(-1), nf)
+        keep = ~mask[start:] if start else ~mask
+        nf = self.n_frozen if start >= self.n_frozen else (start + int(keep[:self.n_frozen - start].sum()) if self.n_frozen else 0)
+        idx = torch.nonzero(keep).reshape(-1)
+        self._permute(idx + start if start else idx, nf, start)
 
     def freeze_rows(self, mask: torch.Tensor):
         """Make the trainable rows where `mask` [N] is set FROZEN (gaussians_fix: unstable Gaussians whose confidence passed
         the threshold join the stable cloud, mapper.py:253-271): they move, in order, behind the frozen prefix."""
         self.flush()
-        mask = mask.to(self.device).bool().reshape(-1).clone()
-        mask[:self.n_frozen] = True
-        order = torch.sort((~mask).to(torch.int8), stable=True).indices       # frozen first, order kept inside both parts
-        self._permute(order, int(mask.sum()))
+        nf0 = self.n_frozen
+        sub = mask.to(self.device).bool().reshape(-1)[nf0:]                  # the frozen prefix stays where it is
+        order = torch.sort((~sub).to(torch.int8), stable=True).indices      # newly frozen first, order kept inside both parts
+        self._permute(order + nf0 if nf0 else order, nf0 + int(sub.sum()), nf0)
 
     def _adam(self, name, shard, gs, row_state=None):
         st, lr = self.state[name], self._lr(name)

@@ -821,7 +821,7 @@ class Mapping:
             if k > 0:
                 full = torch.zeros(o.N, dtype=torch.bool, device=self.device)
                 full[r0:r1] = dm.bool()
-                o.remove_rows(full)
+                o.remove_rows(full, start=r0)
                 self.stats["deleted_unstable"] += k
             return
         radius = self.params(rows)["radius"]
@@ -936,7 +936,7 @@ class Mapping:
         if k > 0:
             full = torch.zeros(o.N, dtype=torch.bool, device=self.device)
             full[o.n_frozen:] = dm.bool()
-            o.remove_rows(full)
+            o.remove_rows(full, start=o.n_frozen)            # only trainable rows go: the stable prefix is not touched
             self.stats["deleted_unstable"] += k
 
     def save_model(self, path: str, save_data: bool = True, save_sibr: bool = True, save_merge: bool = True):

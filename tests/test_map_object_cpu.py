@@ -76,6 +76,28 @@ def test_remove_keeps_order_and_the_boundary():
         assert float(opt.state[n]["p"][opt.N:].abs().max()) == 0.0
 
 
+def test_remove_with_a_promised_untouched_prefix_equals_the_full_form():
+    """remove_rows(mask, start): rows before `start` are neither read nor moved (a deletion among the trainable suffix of a
+    SLAM map moves a few thousand rows, not the map) - same rows, same boundary, same side arrays as the full form."""
+    a = _packed(40, 8)
+    for n_frozen, removed, start in ((25, [26, 30, 39], 25), (25, [26, 30, 39], 26), (25, [3, 24, 25, 31], 3), (0, [0, 7], 0), (10, [39], 12),
+                                     (10, list(range(10, 40)), 10)):
+        outs = []
+        for st in (0, start):
+            opt = _opt(a, n_frozen=n_frozen)
+            opt.add_aux("tick", 1, torch.int32, 5)
+            opt.aux["tick"][:40, 0] = torch.arange(40, dtype=torch.int32)
+            mask = torch.zeros(40, dtype=torch.bool)
+            mask[removed] = True
+            opt.remove_rows(mask, start=st)
+            outs.append((opt.N, opt.n_frozen, opt.params.clone(), opt.aux["tick"][:opt.N].clone(), opt.aux["tick"][opt.N:40].clone()))
+            for n, _, _ in mo.BLOCKS:
+                assert opt.N == 40 or float(opt.state[n]["p"][opt.N:40].abs().max()) == 0.0
+        assert outs[0][:2] == outs[1][:2] == (40 - len(removed), n_frozen - sum(r < n_frozen for r in removed))
+        assert all(torch.equal(x, y) for x, y in zip(outs[0][2:], outs[1][2:]))
+        assert torch.equal(outs[1][2], a[~mask]) and bool((outs[1][4] == 5).all())
+
+
 def test_freeze_moves_rows_behind_the_frozen_prefix_in_order():
     a = _packed(10, 7)
     opt = _opt(a, n_frozen=3)
