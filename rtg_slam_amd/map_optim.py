@@ -249,6 +249,7 @@ class ShardedMapOptimizer:
         self._lr_scope = None          # learning-rate columns of the running global optimisation
         self.version = 0               # bumped by everything that changes what a render of the map shows
         self._gd_views = {}            # gaussian_data's views per row range (see there)
+        self._adam_dirty = None        # rows of state[.]["m" / "v" / "ever"] that may be non-zero: None, (lo, hi) or "all"
         self._allocate(max(int(capacity) if capacity is not None else self.N, self.N, 1), packed)
         self.step_count = 0
         self.total_steps = getattr(self, "total_steps", 0)      # steps ever taken (never reset: Mapping.gaussians_fix keys on it)
@@ -367,14 +368,33 @@ class ShardedMapOptimizer:
         self._history = None
         self._pending = None
 
+    def _mark_adam(self, lo: int, hi: int):
+        """Rows [lo, hi) of this rank's Adam moment arrays are about to be written."""
+        d = self._adam_dirty
+        if d != "all" and hi > lo:
+            self._adam_dirty = (int(lo), int(hi)) if d is None else (min(d[0], int(lo)), max(d[1], int(hi)))
+
+    def _zero_adam(self):
+        """A fresh Adam (mapper.py:156 creates one per optimisation) = zero moments.  Only the rows written since the last
+        time are cleared: the arrays are allocated for the CAPACITY (800 000 rows x 59 columns x two moments = 377 MB in the
+        SLAM sequence) while a local optimisation steps a few thousand trainable rows."""
+        d = self._adam_dirty
+        for holder in (self.state, self._slam_state or {}):
+            part = holder is self.state and d != "all" and self.world == 1
+            for n in holder:
+                for k in ("m", "v", "ever"):
+                    t = holder[n][k]
+                    if not part:
+                        t.zero_()
+                    elif d is not None:
+                        t[d[0]:min(d[1], t.shape[0])].zero_()
+        self._adam_dirty = None
+
     def _clean(self):
         if getattr(self, "_stale", False):
             if self.grad_rows is not None:
                 self.grad_rows.clear()
-            for holder in (self.state, self._slam_state or {}):
-                for n in holder:
-                    for k in ("m", "v", "ever"):
-                        holder[n][k].zero_()
+            self._zero_adam()
             self.step_count = 0
             self._stale = False
 
@@ -535,6 +555,7 @@ class ShardedMapOptimizer:
     def _scatter_sharded_adam(self, carried):
         if carried is None:
             return
+        self._adam_dirty = "all"
         per, lo = self.per, self.rank * self.per
         for name, _, _ in BLOCKS:
             st = self.state[name]
@@ -589,6 +610,7 @@ class ShardedMapOptimizer:
         self._permute(order + nf0 if nf0 else order, nf0 + int(sub.sum()), nf0)
 
     def _adam(self, name, shard, gs, row_state=None):
+        self._adam_dirty = "all"                            # shard-relative rows: no range kept for this path
         st, lr = self.state[name], self._lr(name)
         n = shard.shape[0]                                  # the state arrays are allocated for the capacity
         if self.row_skip:
@@ -669,10 +691,7 @@ class ShardedMapOptimizer:
             buf["shs"][:N - nf].copy_(st["shs"]["p"][nf:N])
             buf["conf"][:N - nf].copy_(confidence.reshape(-1))
             self._history = dict(shs=buf["shs"][:N - nf], conf=buf["conf"][:N - nf])
-        for holder in (self.state, self._slam_state or {}):
-            for n in holder:
-                for k in ("m", "v", "ever"):
-                    holder[n][k].zero_()
+        self._zero_adam()
         self.step_count = 0
         if st["xyz"]["p"].is_cuda and N > nf:
             self.attach_loss()                 # counts the selected rows once: the selection is fixed by the snapshot
@@ -829,6 +848,7 @@ class ShardedMapOptimizer:
             self._front_tileband(lib, args, ws, keep, tile_mask, rm, R, dev)
             self._exchange_and_tail(dict(step=int(self.step_count), attach=attach, confidence=confidence, keep=(keep, attach)))
         elif self.world == 1:
+            self._mark_adam(0, N - nf)                      # the moments of trainable row t0 + k sit in row k (rtgs_map_step_args)
             with torch.cuda.device(dev):
                 rc = lib.rtgs_slam_map_step_ctx(current_context().ptr, C.byref(args), C.byref(R), C.c_void_p(stream))
             _lib.check(rc, "rtgs_slam_map_step")

@@ -212,9 +212,23 @@ class RowGradArena:
                           d_raw8=torch.zeros(cap, 8, **f))
         self.scratch = torch.zeros(lib.rtgs_raster_backward_scratch_bytes(cap), dtype=torch.uint8, device=device)
         self._state_full = torch.zeros(cap, dtype=torch.uint8, device=device)
-        self.train = None
+        self._train = None
+        self._dirty = "all"      # rows of the seven gradient arrays a backward may have written since the last clear(): "all" or (lo, hi)
         self.calls = 0           # rasterizer backward passes since begin_step(); the row states describe exactly one
         self._views()
+
+    @property
+    def train(self):
+        return self._train
+
+    @train.setter
+    def train(self, rng):
+        self._train = rng
+        if rng is None:
+            self._dirty = "all"
+        elif self._dirty != "all":
+            lo, hi = int(rng[0]), int(rng[1])
+            self._dirty = (lo, hi) if self._dirty is None else (min(self._dirty[0], lo), max(self._dirty[1], hi))
 
     def _views(self):
         P = self.P
@@ -234,11 +248,19 @@ class RowGradArena:
         self._views()
 
     def clear(self):
+        """Zero rows and states.  Of the gradient arrays (70 floats per row, allocated for the capacity: 224 MB at 800 000 rows)
+        only the rows a backward could have written since the last clear - the union of the `train` ranges set meanwhile."""
+        d = self._dirty
         for t in self._full.values():
-            t.zero_()
+            if d == "all":
+                t.zero_()
+            elif d is not None and d[1] > d[0]:
+                t[d[0]:min(d[1], t.shape[0])].zero_()
         self.scratch.zero_()
         self._state_full.zero_()
         self.calls = 0
+        self._dirty = None
+        self.train = self._train          # the range in force stays in force: it is what the next backward writes
 
     def begin_step(self):
         self.calls = 0
