@@ -134,7 +134,8 @@ struct rtgs_ctx {
   // Forwards WITHOUT a backward (the plain renders of a SLAM frame: RTGS_FWD_NO_BACKWARD) keep a history of their own - the
   // Gaussian count changes from one to the next, only the image and the sort class of the longest tile list are assumed -
   // and check their guess before they return (forward_impl: `immediate`), so nothing is ever left pending.
-  Plan plan_plain;
+  Plan plan_plain;                     // ... on large maps (the near slice is considered; kind 2 once it was declined)
+  Plan plan_plain0;                    // ... on maps below the large-map size (kind 0: one pass over every Gaussian)
   bool plain_onepass = true;           // RTGS_PLAIN_ONEPASS=0: count / scan / scatter with the two host waits, as before round 6
   int64_t plain_stats[2] = {0, 0};     // immediate one-pass forwards, those that had to be redone
 };
@@ -480,6 +481,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
   // decide from the depth histograms whether it runs (an empty slice sends every tile to the second pass)
   const bool slice_auto = c->slice_mode == 2;
   bool sliced = !sort_path && P > 0 && (c->slice_mode == 1 || (slice_auto && P >= large_map_min() && ntiles >= 256));
+  const bool sliced0 = sliced;                 // what this call started as (the variable follows the passes below)
   SlicePass pass{0, nullptr, nullptr, nullptr, nullptr};
   bool declined = false, considered = false;
   SliceList vis{nullptr, nullptr};             // every visible Gaussian, when the declined single pass built the list
@@ -511,9 +513,9 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
     // one-pass flow (no count / scan / scatter, no host wait before the blend) and looks at the published totals itself,
     // while the blend runs; a wrong guess (a list outgrew the assumed sort class, the slice was taken after all) falls
     // through to the classic path below.  Nothing but the image size and that class is assumed: P may differ.
-    rtgs_ctx::Plan& pp = c->plan_plain;
+    rtgs_ctx::Plan& pp = sliced ? c->plan_plain : c->plan_plain0;
     const bool immediate = !(flags & RTGS_FWD_SPECULATE) && !want_bwd && c->speculation && c->plain_onepass && c->onepass &&
-                           P > 0 && !sort_path && !s->debug && sliced && G.slice_seg && pp.valid && pp.kind == 2 &&
+                           P > 0 && !sort_path && !s->debug && pp.valid && (sliced ? (pp.kind == 2 && G.slice_seg) : pp.kind == 0) &&
                            pp.H == p.H && pp.W == p.W && pp.slice_mode == c->slice_mode && pp.slice_budget == c->slice_budget;
     const rtgs_ctx::Plan& pl = immediate ? pp : c->plan;
     const bool eligible = immediate ||
@@ -579,7 +581,8 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       } else {
         // one pass (kind 2, through the visible list): every tile owns a segment of the sort class that covered the last
         // verified longest list; a list that outgrows it raises `fail` like any other wrong guess
-        const uint32_t seg2 = (c->onepass && pl.kind == 2 && G.slice_seg) ? capL : 0u;
+        // (a forward without a backward on a small map - `immediate`, kind 0 - takes segments too: no count, no scan)
+        const uint32_t seg2 = (c->onepass && ((pl.kind == 2 && G.slice_seg) || (immediate && pl.kind == 0))) ? capL : 0u;
         const BinLayout B = bin_layout(seg2 ? (int64_t)ntiles * (int64_t)seg2 : (int64_t)capR, ntiles, false, (size_t)capS);
         seg_main = seg2 != 0u;
         char* bin = (char*)binning_resize(binning_user, B.total);
@@ -605,16 +608,20 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
         } else {
           launch_preprocess_fwd(p, means3D, opacities, shs, scales, rotations, normal_w, nullptr, splats, tiles_touched, radii,
                                 clamped, out_radii, zero_words, zero_n, nullptr, st);
-          if ((rc = scan_all()) != RTGS_OK) return rc;
+          if (!immediate && (rc = scan_all()) != RTGS_OK) return rc;       // gradient-slot bases: only a backward reads them
           prof_mark(c, EV_PRE, st);
         }
         const SliceSel sel2{0, nullptr, nullptr, 0u, 0u, slice_ctr, nullptr, (const float2*)(geom + G.uv), nullptr, 0u, 0};
         if (seg2) {
+          if (pl.kind != 2)
+            hipLaunchKernelGGL(bwd_info_kernel, dim3(1), dim3(1), 0, st, (BwdInfo*)(img + I.bwd_info),
+                               (SplatGrad*)(bin + B.slot_grads), capS, immediate ? 0u : 1u);
           launch_bin_place(pg, splats, radii, tile_mask, tile_count, (unsigned long long*)(bin + B.keys_a), seg2, fail, sel2, vl,
                            (size_t)P, st);
           prof_mark(c, EV_SCAN, st); prof_mark(c, EV_BIN0, st); prof_mark(c, EV_EMIT, st);
           const BinFinish fin{tile_count, ntiles, info, info_host, slice_ctr + 5, nullptr, slice_ctr + 4, c->seq,
-                              SpecCaps{fail, 0xffffffffu, capL, immediate ? 0xffffffffu : capS, (const int32_t*)(slice_ctr + 3)}};
+                              SpecCaps{fail, 0xffffffffu, capL, immediate ? 0xffffffffu : capS,
+                                       pl.kind == 2 ? (const int32_t*)(slice_ctr + 3) : nullptr}};
           launch_bin_tilesort(ntiles, capL, ranges, (const unsigned long long*)(bin + B.keys_a), (uint32_t*)(bin + B.vals_b), fail, st,
                               tile_count, seg2, ranges, &fin);
         } else {
@@ -648,7 +655,7 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
       if (immediate) {
         // the blend is on its way; the totals were published before it started
         if ((rc = wait_published(c->seq)) != RTGS_OK) return rc;
-        const bool ok = (seg_main || pub[0] <= capR) && pub[1] <= capL && (int32_t)pub[6] < 0;
+        const bool ok = (seg_main || pub[0] <= capR) && pub[1] <= capL && (pl.kind != 2 || (int32_t)pub[6] < 0);
         ++c->plain_stats[0];
         if (ok) {
           pp.note(pub[0], pub[1], 0u);
@@ -883,10 +890,10 @@ int rtgs_raster_forward_ctx(rtgs_ctx* ctx, const rtgs_raster_settings* s, int32_
     pl.R1 = (uint32_t)R1; pl.n_fin = n_fin;
     if (!want_bwd) {
       // ... and what the next forward WITHOUT a backward on this image may assume (any Gaussian count)
-      rtgs_ctx::Plan& pp = c->plan_plain;
+      rtgs_ctx::Plan& pp = sliced0 ? c->plan_plain : c->plan_plain0;
       const bool same_image = pp.valid && pp.H == p.H && pp.W == p.W;
-      pp.kind = (!sort_path && considered) ? 2 : -1;
-      pp.valid = pp.kind == 2 && R <= 0xffffffffll;
+      pp.kind = sort_path ? -1 : (sliced0 ? (considered ? 2 : -1) : (P > 0 ? 0 : -1));
+      pp.valid = pp.kind >= 0 && R <= 0xffffffffll;
       pp.P = P; pp.H = p.H; pp.W = p.W; pp.slice_mode = c->slice_mode; pp.slice_budget = c->slice_budget;
       if (!same_image || !pp.valid) { pp.R_hi = pp.longest_hi = pp.slots_hi = 0; }
       pp.note((uint32_t)R, longest, 0u);
@@ -1092,6 +1099,7 @@ void rtgs_raster_set_plain_onepass_ctx(rtgs_ctx* ctx, int enable) {
   rtgs_ctx* c = use(ctx);
   c->plain_onepass = enable != 0;
   c->plan_plain = rtgs_ctx::Plan();
+  c->plan_plain0 = rtgs_ctx::Plan();
 }
 uint32_t rtgs_raster_last_listed_ctx(rtgs_ctx* c) { return use(c)->last_listed; }
 void rtgs_raster_set_bwd_debug(int bits) { rtgs::set_bwd_debug(bits); }

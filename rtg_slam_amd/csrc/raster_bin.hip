@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256) bin_place_kernel(RasterParams p, const Sp
   const int ntiles = p.gx * p.gy;
   if (spec_failed(p.spec_fail)) return;
   if (sel.mode == 2 && sel.ctr[0] == 0u) return;
-  if (blockIdx.x * gpb >= (int)*list.count) return;
+  if (list.count && blockIdx.x * gpb >= (int)*list.count) return;       // no list: every Gaussian (a forward without a backward on a small map)
   uint32_t* s_cnt = s_mem;
   for (int t = threadIdx.x; t < ntiles; t += BLOCK) s_cnt[t] = 0;
   __syncthreads();
