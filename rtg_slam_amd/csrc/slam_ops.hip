@@ -373,9 +373,32 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
   // of the wave's queries and the loosest bound any of its lanes holds - a conservative form of every lane's own test - and
   // only the boxes that pass are looked at by the lanes themselves.  (Round 5 walked all boxes one by one with a scalar load
   // and its wait per box: 286 dependent round trips per wave on the 290 k references of a grown SLAM map.)
+  // The bound a box is tested against is the QUERY's: each of its PARTS lanes keeps the three nearest of ITS share of the
+  // references, and the third-best of one share (what a lane alone knows) is a loose bound - after the home box a lane of
+  // sixteen has seen sixteen references.  The exact third-nearest of the union falls out of three steps of a PARTS-way merge
+  // of the lanes' sorted triples (min over the group, the first lane that holds it advances): log2(PARTS) shuffles and a
+  // ballot per step, after every box that was read.  (Round 6, last session: boxes opened per query fall several-fold.)
+  unsigned long long gmask = 0ull;
+#pragma unroll
+  for (int k = 0; k < PARTS; ++k) gmask |= 1ull << (k * QW);
+  gmask <<= qw;
+  auto query_bound = [&]() -> float {
+    float h0 = bd[0], h1 = bd[1], h2 = bd[2];                  // this lane's sorted triple; h0 is its head
+    float m = FLT_MAX;
+#pragma unroll
+    for (int step = 0; step < 3; ++step) {
+      m = h0;
+#pragma unroll
+      for (int off = QW; off < 64; off <<= 1) m = fminf(m, __shfl_xor(m, off));
+      const unsigned long long holders = __builtin_amdgcn_ballot_w64(h0 == m) & gmask;
+      if (holders && lane == (int)__builtin_ctzll(holders)) { h0 = h1; h1 = h2; h2 = FLT_MAX; }
+    }
+    return m;
+  };
   const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
   const int b0 = lv ? min(nboxes - 1, __builtin_amdgcn_readlane(home, __builtin_ctzll(lv))) : 0;
   scan_box(b0, live);
+  float qb = query_bound();
   float wlo[3], whi[3];
   {
     const float q3[3] = {p.x, p.y, p.z};
@@ -392,7 +415,7 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
     const int d = (step + 1) >> 1;
     const int ck = (step & 1) ? c0 - d : c0 + d;                // c0, c0 - 1, c0 + 1, c0 - 2, ...
     if (ck < 0 || ck >= nchunks) continue;
-    float wb = live ? bd[2] : 0.f;                              // the loosest bound of the wave
+    float wb = live ? qb : 0.f;                                 // the loosest bound of the wave
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wb = fmaxf(wb, __shfl_xor(wb, off));
     const int bl = ck * 64 + lane;
@@ -421,9 +444,10 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
       const float ez = fmaxf(0.f, fmaxf(bx[2] - p.z, p.z - bx[5]));
       // a lower bound of the distance to anything in the box, with slack for its rounding: never prunes a true neighbour
       const float lower = ((ex * ex + ey * ey) + ez * ez) * 0.9999f;
-      const bool open = live && lower < bd[2];
+      const bool open = live && lower < qb;
       if (__builtin_amdgcn_ballot_w64(open) == 0ull) continue;
       scan_box(ck * 64 + l, open);
+      qb = query_bound();
     }
   }
   // ---- merge the parts of every query (disjoint reference sets: no duplicates)
@@ -1150,7 +1174,11 @@ int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_poin
   SLAM_TRY(rocprim::radix_sort_pairs(s + Q.cub, tb, q_codes, q_codes_sorted, q_order_in, q_order, (size_t)Nq, 0u, 30u, st));
   const int nboxes = (Nr + KNN_QBOX - 1) / KNN_QBOX;
   // a query is 16 lanes in a small call (<= 4 096 queries: 4 queries per wave, >= 4x the waves), 4 lanes in a large one
-  if (Nq <= 4096)
+  if (Nq <= 1024)      // a few hundred queries spread over the scene (a frame's new points): ONE query per wave - the wave's bounding box is the query
+    hipLaunchKernelGGL(knn_query_kernel<64>, dim3((Nq + 3) / 4), dim3(256), 0, st, (const float4*)(s + L.sorted), Nr,
+                       (const uint32_t*)(s + L.codes_sorted), (const float*)(s + L.boxes), nboxes, query_points, Nq,
+                       (const uint32_t*)q_order, (const uint32_t*)q_codes_sorted, self_offset, ref_box6, idx, dist2_out);
+  else if (Nq <= 4096)
     hipLaunchKernelGGL(knn_query_kernel<16>, dim3((Nq + 15) / 16), dim3(256), 0, st, (const float4*)(s + L.sorted), Nr,
                        (const uint32_t*)(s + L.codes_sorted), (const float*)(s + L.boxes), nboxes, query_points, Nq,
                        (const uint32_t*)q_order, (const uint32_t*)q_codes_sorted, self_offset, ref_box6, idx, dist2_out);
