@@ -70,6 +70,23 @@ int rtgs_knn3(const float* points, int32_t N, float* mean_dist2, int32_t* idx, f
 size_t rtgs_knn3_query_scratch_bytes(int32_t Nr, int32_t Nq);
 int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_points, int32_t Nq, int32_t self_offset,
                     const float* ref_box6, int32_t* idx, float* dist2, void* scratch, void* stream);
+/* The same search split by what changes between frames (round 6; Mapping.temp_to_optimize, i.e. update_geometry's neighbour
+ * search over cat(new points, every existing Gaussian), gaussian_pointcloud.py:366-381).  build_ref leaves the search structure
+ * of Nr >= 1 reference points in `built` (rtgs_knn3_built_bytes(Nr) bytes; it holds a COPY of the points: rebuild when they
+ * change); query_built answers rtgs_knn3_query(self_offset = -1) against it (query_scratch: rtgs_knn3_query_built_scratch_bytes(Nq)).
+ * dynamic_merge: for every query i its three nearest among (a) the three stable neighbours handed in (dist2_stable / idx_stable
+ * [Nq,3], idx = stable row or -1), (b) the OTHER queries (query i is not its own neighbour) and (c) the Nu unstable points, the
+ * last two compared directly; references outside the open box ref_box6 are ignored as above.  Result indices address
+ * cat(queries, existing rows): query j -> j, stable row r -> Nq + r, unstable point u -> Nq + n_stable + u.  Same float32
+ * distance expression as rtgs_knn3_query: the result equals the one-structure search up to the order of equidistant points. */
+size_t rtgs_knn3_built_bytes(int32_t Nr);
+size_t rtgs_knn3_query_built_scratch_bytes(int32_t Nq);
+int rtgs_knn3_build_ref(const float* ref_points, int32_t Nr, void* built, void* stream);
+int rtgs_knn3_query_built(const void* built, int32_t Nr, const float* query_points, int32_t Nq, const float* ref_box6, int32_t* idx,
+                          float* dist2, void* query_scratch, void* stream);
+int rtgs_knn3_dynamic_merge(const float* query_points, int32_t Nq, const float* unstable_points, int32_t Nu, int32_t n_stable,
+                            const float* dist2_stable, const int32_t* idx_stable, const float* ref_box6, int32_t* idx, float* dist2,
+                            void* stream);
 
 /* ---- cuda_utils.accumulate_gaussian_error --------------------------------------------------------------------- */
 /* FROZEN semantics (the CUDA source is absent; mapper.py:541-571 is the evidence): colour error goes to the Gaussian in

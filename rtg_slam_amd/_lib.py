@@ -190,6 +190,11 @@ _SIGNATURES = {
     "rtgs_knn3": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "rtgs_knn3_query_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "rtgs_knn3_query": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "rtgs_knn3_built_bytes": (C.c_size_t, [C.c_int32]),
+    "rtgs_knn3_query_built_scratch_bytes": (C.c_size_t, [C.c_int32]),
+    "rtgs_knn3_build_ref": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "rtgs_knn3_query_built": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, _P]),
+    "rtgs_knn3_dynamic_merge": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "rtgs_accumulate_error": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_float, C.c_float,
                                         C.c_float, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "rtgs_bilateral_filter": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P]),

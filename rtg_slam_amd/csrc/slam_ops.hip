@@ -471,6 +471,58 @@ __global__ void __launch_bounds__(256) knn_query_kernel(const float4* __restrict
   }
 }
 
+// knn_dynamic_merge: the neighbour search of Mapping.temp_to_optimize split by what changes between frames.  The three nearest
+// STABLE Gaussians of every query come from a structure that is rebuilt only when the stable rows change (rtgs_knn3_build_ref /
+// rtgs_knn3_query_built: the Morton sort of ~300 000 references was two thirds of the frame's search); the few thousand references
+// that do change - the queries themselves (a new point is not its own neighbour) and the unstable Gaussians - are compared
+// directly, one wave per query, and merged in.  Index space of the result = cat(queries, all existing rows): a query i is i, the
+// stable row r is Nq + r, the unstable row u (u-th row behind the n_stable stable ones) is Nq + n_stable + u.  Same distance
+// expression and the same open box as knn_query_kernel, so the result equals the one-structure search (up to the order of
+// equidistant neighbours).
+__global__ void __launch_bounds__(256) knn_dynamic_merge_kernel(const float* __restrict__ query, int Nq, const float* __restrict__ unstable,
+                                                                int Nu, int n_stable, const float* __restrict__ d2_stable,
+                                                                const int32_t* __restrict__ idx_stable, const float* __restrict__ ref_box,
+                                                                int32_t* __restrict__ idx, float* __restrict__ dist_out) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= Nq) return;
+  float blo[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}, bhi[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  if (ref_box) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { blo[c] = ref_box[c]; bhi[c] = ref_box[3 + c]; }
+  }
+  const float4 p = make_float4(query[(size_t)i * 3], query[(size_t)i * 3 + 1], query[(size_t)i * 3 + 2], 0.f);
+  float bd[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  int bj[3] = {-1, -1, -1};
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int r = idx_stable[(size_t)i * 3 + k];
+      if (r >= 0) knn_insert(d2_stable[(size_t)i * 3 + k], Nq + r, bd, bj);
+    }
+  }
+  for (int j = lane; j < Nq + Nu; j += 64) {
+    if (j == i) continue;
+    const float* src = j < Nq ? query + (size_t)j * 3 : unstable + (size_t)(j - Nq) * 3;
+    const float4 s = make_float4(src[0], src[1], src[2], 0.f);
+    if (s.x > blo[0] && s.y > blo[1] && s.z > blo[2] && s.x < bhi[0] && s.y < bhi[1] && s.z < bhi[2])
+      knn_insert(dist2(p, s), j < Nq ? j : j + n_stable, bd, bj);
+  }
+  // 64 sorted triples -> the three smallest: butterfly of triple merges
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    float od[3]; int oj[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { od[k] = __shfl_xor(bd[k], off); oj[k] = __shfl_xor(bj[k], off); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (oj[k] >= 0) knn_insert(od[k], oj[k], bd, bj);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { idx[(size_t)i * 3 + k] = bj[k]; if (dist_out) dist_out[(size_t)i * 3 + k] = bd[k]; }
+  }
+}
+
 struct KnnLayout {
   size_t bbox, codes, codes_sorted, order_in, order, sorted, boxes, cub, total, cub_bytes;
 };
@@ -1146,32 +1198,24 @@ static KnnQueryLayout knn_query_layout(int Nr, int Nq) {
 }
 size_t rtgs_knn3_query_scratch_bytes(int32_t Nr, int32_t Nq) { return knn_query_layout(Nr, Nq).total; }
 
-int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_points, int32_t Nq, int32_t self_offset,
-                    const float* ref_box6, int32_t* idx, float* dist2_out, void* scratch, void* stream) {
-  if (Nr < 0 || Nq < 0 || (Nq > 0 && (!query_points || !idx))) return -1;
-  if (Nr > 0 && (!ref_points || !scratch)) return -1;
-  if (self_offset >= 0 && (int64_t)self_offset + Nq > Nr) return -1;
-  if (Nq == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
-  if (Nr == 0) {                                              // nobody to find: -1 / FLT_MAX, as rtgs_knn3 with < 4 points
-    SLAM_TRY(hipMemsetAsync(idx, 0xff, (size_t)Nq * 3 * sizeof(int32_t), st));
-    if (dist2_out) hipLaunchKernelGGL(fill_f32_kernel, dim3(grid1(Nq * 3)), dim3(256), 0, st, dist2_out, Nq * 3, FLT_MAX);
-    SLAM_TRY(hipGetLastError());
-    return 0;
-  }
+// the query half of rtgs_knn3_query against a structure knn_build left in `built` (query-side scratch at `qs`)
+static int knn_query_built(const void* built, int32_t Nr, const float* query_points, int32_t Nq, int32_t self_offset,
+                           const float* ref_box6, int32_t* idx, float* dist2_out, void* qs, hipStream_t st) {
   const KnnLayout L = knn_layout(Nr);
-  const KnnQueryLayout Q = knn_query_layout(Nr, Nq);
-  char* s = (char*)scratch;
-  const int rc = knn_build(ref_points, Nr, scratch, st, KNN_QBOX);
-  if (rc != 0) return rc;
-  uint32_t* q_codes = (uint32_t*)(s + Q.codes);
-  uint32_t* q_codes_sorted = (uint32_t*)(s + Q.codes_sorted);
-  uint32_t* q_order_in = (uint32_t*)(s + Q.order_in);
-  uint32_t* q_order = (uint32_t*)(s + Q.order);
+  const KnnQueryLayout Q0 = knn_query_layout(Nr, Nq);
+  const size_t base = knn_layout(Nr).total;
+  KnnQueryLayout Q = Q0;                                     // the same layout, relative to qs
+  Q.codes -= base; Q.codes_sorted -= base; Q.order_in -= base; Q.order -= base; Q.cub -= base;
+  const char* s = (const char*)built;
+  char* q = (char*)qs;
+  uint32_t* q_codes = (uint32_t*)(q + Q.codes);
+  uint32_t* q_codes_sorted = (uint32_t*)(q + Q.codes_sorted);
+  uint32_t* q_order_in = (uint32_t*)(q + Q.order_in);
+  uint32_t* q_order = (uint32_t*)(q + Q.order);
   hipLaunchKernelGGL(knn_query_codes_kernel, dim3(grid1(Nq)), dim3(256), 0, st, query_points, Nq, (const uint32_t*)(s + L.bbox),
                      q_codes, q_order_in);
   size_t tb = Q.cub_bytes;
-  SLAM_TRY(rocprim::radix_sort_pairs(s + Q.cub, tb, q_codes, q_codes_sorted, q_order_in, q_order, (size_t)Nq, 0u, 30u, st));
+  SLAM_TRY(rocprim::radix_sort_pairs(q + Q.cub, tb, q_codes, q_codes_sorted, q_order_in, q_order, (size_t)Nq, 0u, 30u, st));
   const int nboxes = (Nr + KNN_QBOX - 1) / KNN_QBOX;
   // a query is 16 lanes in a small call (<= 4 096 queries: 4 queries per wave, >= 4x the waves), 4 lanes in a large one
   if (Nq <= 1024)      // a few hundred queries spread over the scene (a frame's new points): ONE query per wave - the wave's bounding box is the query
@@ -1188,6 +1232,53 @@ int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_poin
                        (const uint32_t*)q_order, (const uint32_t*)q_codes_sorted, self_offset, ref_box6, idx, dist2_out);
   SLAM_TRY(hipGetLastError());
   return 0;
+}
+
+size_t rtgs_knn3_built_bytes(int32_t Nr) { return knn_layout(Nr).total; }
+size_t rtgs_knn3_query_built_scratch_bytes(int32_t Nq) { return knn_query_layout(1, Nq).total - knn_layout(1).total; }
+
+int rtgs_knn3_build_ref(const float* ref_points, int32_t Nr, void* built, void* stream) {
+  if (Nr <= 0 || !ref_points || !built) return -1;
+  return knn_build(ref_points, Nr, built, (hipStream_t)stream, KNN_QBOX);
+}
+
+int rtgs_knn3_query_built(const void* built, int32_t Nr, const float* query_points, int32_t Nq, const float* ref_box6, int32_t* idx,
+                          float* dist2_out, void* query_scratch, void* stream) {
+  if (Nr <= 0 || Nq < 0 || !built) return -1;
+  if (Nq == 0) return 0;
+  if (!query_points || !idx || !query_scratch) return -1;
+  return knn_query_built(built, Nr, query_points, Nq, -1, ref_box6, idx, dist2_out, query_scratch, (hipStream_t)stream);
+}
+
+int rtgs_knn3_dynamic_merge(const float* query_points, int32_t Nq, const float* unstable_points, int32_t Nu, int32_t n_stable,
+                            const float* dist2_stable, const int32_t* idx_stable, const float* ref_box6, int32_t* idx, float* dist2_out,
+                            void* stream) {
+  if (Nq < 0 || Nu < 0 || n_stable < 0) return -1;
+  if (Nq == 0) return 0;
+  if (!query_points || !dist2_stable || !idx_stable || !idx || (Nu > 0 && !unstable_points)) return -1;
+  hipLaunchKernelGGL(knn_dynamic_merge_kernel, dim3((Nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, query_points, (int)Nq,
+                     unstable_points, (int)Nu, (int)n_stable, dist2_stable, idx_stable, ref_box6, idx, dist2_out);
+  SLAM_TRY(hipGetLastError());
+  return 0;
+}
+
+int rtgs_knn3_query(const float* ref_points, int32_t Nr, const float* query_points, int32_t Nq, int32_t self_offset,
+                    const float* ref_box6, int32_t* idx, float* dist2_out, void* scratch, void* stream) {
+  if (Nr < 0 || Nq < 0 || (Nq > 0 && (!query_points || !idx))) return -1;
+  if (Nr > 0 && (!ref_points || !scratch)) return -1;
+  if (self_offset >= 0 && (int64_t)self_offset + Nq > Nr) return -1;
+  if (Nq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (Nr == 0) {                                              // nobody to find: -1 / FLT_MAX, as rtgs_knn3 with < 4 points
+    SLAM_TRY(hipMemsetAsync(idx, 0xff, (size_t)Nq * 3 * sizeof(int32_t), st));
+    if (dist2_out) hipLaunchKernelGGL(fill_f32_kernel, dim3(grid1(Nq * 3)), dim3(256), 0, st, dist2_out, Nq * 3, FLT_MAX);
+    SLAM_TRY(hipGetLastError());
+    return 0;
+  }
+  const int rc = knn_build(ref_points, Nr, scratch, st, KNN_QBOX);
+  if (rc != 0) return rc;
+  return knn_query_built(scratch, Nr, query_points, Nq, self_offset, ref_box6, idx, dist2_out,
+                         (char*)scratch + knn_layout(Nr).total, st);
 }
 
 int rtgs_accumulate_error(int32_t H, int32_t W, int32_t P, const float* color_err, const float* depth_err,

@@ -250,6 +250,7 @@ class ShardedMapOptimizer:
         self.version = 0               # bumped by everything that changes what a render of the map shows
         self._gd_views = {}            # gaussian_data's views per row range (see there)
         self._adam_dirty = None        # rows of state[.]["m" / "v" / "ever"] that may be non-zero: None, (lo, hi) or "all"
+        self._frozen_version = 0       # bumped by everything that may change a FROZEN row (see frozen_key)
         self._allocate(max(int(capacity) if capacity is not None else self.N, self.N, 1), packed)
         self.step_count = 0
         self.total_steps = getattr(self, "total_steps", 0)      # steps ever taken (never reset: Mapping.gaussians_fix keys on it)
@@ -280,6 +281,13 @@ class ShardedMapOptimizer:
         return (self.n_frozen, 0) if self._scope == "global" else (self.N, self.n_frozen)
 
     @property
+    def frozen_key(self):
+        """Identity of the frozen prefix's CONTENT: equal keys = the same rows with the same values (what a structure built over
+        the stable Gaussians - Mapping's neighbour search - may be kept for).  Changes with a reallocation, a freeze, a removal
+        or permutation that reaches into the prefix, and every step or merge of a global optimisation (which trains it)."""
+        return (self.state["xyz"]["p"].data_ptr(), int(self.n_frozen), int(self._frozen_version))
+
+    @property
     def n_active_train(self) -> int:
         n, t0 = self._active()
         return n - t0
@@ -304,6 +312,7 @@ class ShardedMapOptimizer:
         rows = cap + self.world
         old = self.state
         self._gd_views = {}            # views of the arrays about to be replaced
+        self._frozen_version = getattr(self, "_frozen_version", 0) + 1
         f = dict(dtype=torch.float32, device=dev)
         per_cap = (cap + self.world - 1) // self.world + 1
         adam_rows = cap if self.world == 1 else per_cap
@@ -572,6 +581,8 @@ class ShardedMapOptimizer:
         if self._scope != "local":
             raise RuntimeError("rows cannot be removed or frozen inside a global optimisation: end_global_optimization() first")
         n = int(start) + int(keep_idx.numel())
+        if start < self.n_frozen or int(n_frozen) != self.n_frozen:
+            self._frozen_version += 1
         for name, _, _ in BLOCKS:
             pfull = self.state[name]["p"]
             pfull[start:n] = pfull.index_select(0, keep_idx)
@@ -712,6 +723,8 @@ class ShardedMapOptimizer:
         if N == nf:
             return
         self.version += 1
+        if self._scope == "global":
+            self._frozen_version += 1
         V = lambda t: C.c_void_p(t.data_ptr())
         O = lambda t, c: C.c_void_p(t.data_ptr() + 4 * c * nf)
         conf = confidence.reshape(-1).contiguous().float()
@@ -772,6 +785,8 @@ class ShardedMapOptimizer:
         if N == 0:
             raise RuntimeError("step_slam() on an empty map")
         self.version += 1
+        if self._scope == "global":
+            self._frozen_version += 1
         if self.world > 1:
             if self._mode == "sharded":
                 raise RuntimeError("ShardedMapOptimizer: step_slam() after step() on more than one rank - the two keep "
@@ -1045,6 +1060,8 @@ class ShardedMapOptimizer:
         ranks (the sum of per-view losses is what a single GPU looping over the views optimises).  Only the trainable
         rows [n_frozen, N) are reduced, stepped and gathered; the row shards partition that range."""
         self._clean()
+        if self._scope == "global":
+            self._frozen_version += 1
         N, nf = self._active()
         per, span = self.per, self.per * self.world        # rows of one shard / of all shards (>= n_train: padded)
         self._act_valid = False            # raw8 moves without step_slam's tail: its activated copies go stale

@@ -203,6 +203,7 @@ class HipOps:
         self.gen = torch.Generator(device=device).manual_seed(int(getattr(args, "seed", 0)))
         self.keys = random.Random(int(getattr(args, "seed", 0)))           # one 64-bit key per sampling pass (rtgs_draw_new_points)
         self.kernel_draw = True
+        self._stable_built, self.stable_builds = None, 0
         if __import__("os").environ.get("RTGS_ADD_KERNELS", "1") == "0":     # A/B aid: the tensor forms of the draw, the filter and the box
             self.kernel_draw, self.filter_keep, self.bbox_pad, self.compact_points = False, None, None, None
 
@@ -294,6 +295,16 @@ class HipOps:
     def compact_points(self, *a):
         return self.so.compact_points(*a)
 
+    def knn_stable(self, opt, all_xyz, nf, query, box):
+        """knn_query(cat(query, all_xyz), query, 0, box) with the structure over the stable prefix all_xyz[:nf] remembered
+        while opt.frozen_key stands (rtgs_knn3_build_ref / _query_built / _dynamic_merge)."""
+        key = opt.frozen_key
+        if self._stable_built is None or self._stable_built[0] != key:
+            self._stable_built = (key, self.so.knn_build_ref(all_xyz[:nf]))
+            self.stable_builds += 1
+        d2s, ids = self.so.knn_query_built(self._stable_built[1], nf, query, box)
+        return self.so.knn_dynamic_merge(query, all_xyz[nf:], nf, d2s, ids, box)
+
     def bbox_pad(self, *a):
         return self.so.bbox_pad(*a)
 
@@ -357,6 +368,7 @@ class Mapping:
         self.args, self.device = args, device
         self.ops = ops if ops is not None else HipOps(args, device)
         self.masked_append = isinstance(self.ops, HipOps) and __import__("os").environ.get("RTGS_ADD_KERNELS", "1") != "0"
+        self.stable_search = __import__("os").environ.get("RTGS_STABLE_SEARCH", "1") != "0"      # A/B aid
         self.time = 0
         self.iter = 0
         self.processed_frames = deque(maxlen=args.memory_length)
@@ -628,7 +640,14 @@ class Mapping:
             gd = self.opt.gaussian_data("all")
             box = self.ops.bbox_pad(xyz, 0.05) if getattr(self.ops, "bbox_pad", None) is not None else \
                 torch.cat([xyz.min(dim=0)[0] - 0.05, xyz.max(dim=0)[0] + 0.05])
-            d2, idx = self.ops.knn_query(torch.cat([xyz, gd["xyz"]]), xyz, 0, box)
+            nf = self.get_stable_num
+            if self.stable_search and nf >= 20000 and n + (self.opt.N - nf) <= 32768 and getattr(self.opt, "world", 1) == 1 \
+                    and getattr(self.ops, "knn_stable", None) is not None:
+                # the structure over the STABLE Gaussians is kept while they do not change (opt.frozen_key): its Morton sort of
+                # ~300 000 points was two thirds of this search; the new points and the unstable Gaussians are compared directly
+                d2, idx = self.ops.knn_stable(self.opt, gd["xyz"], nf, xyz, box)
+            else:
+                d2, idx = self.ops.knn_query(torch.cat([xyz, gd["xyz"]]), xyz, 0, box)
             rows, valid = self.ops.new_rows(xyz, temp["color"], temp["opacity_raw"], temp["rots"], d2, idx, gd["scales"],
                                             a.min_radius, a.max_radius, a.scale_factor, a.xyz_factor)
             if self.masked_append and getattr(self.opt, "append_rows_masked", None) is not None and getattr(self.opt, "world", 1) == 1:

@@ -136,6 +136,53 @@ def knn_query(ref_points: torch.Tensor, query_points: torch.Tensor, self_offset:
     return d3, idx
 
 
+def knn_build_ref(ref_points: torch.Tensor) -> torch.Tensor:
+    """The search structure of `ref_points` [Nr >= 1, 3] as an opaque byte tensor (include/rtgs_slam.h: rtgs_knn3_build_ref); it
+    holds a copy of the points - build again when they change."""
+    lib, dev = _lib.load(), _dev(ref_points)
+    ref = ref_points.float().contiguous()
+    Nr = int(ref.shape[0])
+    built = torch.empty(lib.rtgs_knn3_built_bytes(Nr), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rtgs_knn3_build_ref(_p(ref), Nr, _p(built), _stream(dev))
+    _lib.check(rc, "rtgs_knn3_build_ref")
+    return built
+
+
+def knn_query_built(built: torch.Tensor, Nr: int, query_points: torch.Tensor, ref_box: Optional[torch.Tensor] = None):
+    """knn_query(ref, query, -1, ref_box) against a structure knn_build_ref left -> (dist2 [Nq,3], idx [Nq,3] into ref)."""
+    lib, dev = _lib.load(), _dev(query_points)
+    q = query_points.float().contiguous()
+    Nq = int(q.shape[0])
+    idx = torch.empty(Nq, 3, dtype=torch.int32, device=dev)
+    d3 = torch.empty(Nq, 3, dtype=torch.float32, device=dev)
+    qs = torch.empty(lib.rtgs_knn3_query_built_scratch_bytes(Nq), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        box = None if ref_box is None else ref_box.to(device=dev, dtype=torch.float32).reshape(6).contiguous()
+        rc = lib.rtgs_knn3_query_built(_p(built), int(Nr), _p(q), Nq, _p(box), _p(idx), _p(d3), _p(qs), _stream(dev))
+    _lib.check(rc, "rtgs_knn3_query_built")
+    return d3, idx
+
+
+def knn_dynamic_merge(query_points, unstable_points, n_stable: int, d2_stable, idx_stable, ref_box=None):
+    """The three nearest of every query among its stable neighbours (knn_query_built over the stable rows), the other queries
+    and the unstable points, the last two compared directly (include/rtgs_slam.h: rtgs_knn3_dynamic_merge) -> (dist2, idx) with
+    idx into cat(queries, stable rows, unstable points) - what knn_query(cat(query, existing), query, 0, box) returns."""
+    lib, dev = _lib.load(), _dev(query_points)
+    q = query_points.float().contiguous()
+    u = unstable_points.float().contiguous()
+    Nq, Nu = int(q.shape[0]), int(u.shape[0])
+    d2s, ids = d2_stable.float().contiguous(), idx_stable.to(torch.int32).contiguous()
+    idx = torch.empty(Nq, 3, dtype=torch.int32, device=dev)
+    d3 = torch.empty(Nq, 3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        box = None if ref_box is None else ref_box.to(device=dev, dtype=torch.float32).reshape(6).contiguous()
+        rc = lib.rtgs_knn3_dynamic_merge(_p(q), Nq, _p(u) if Nu else None, Nu, int(n_stable), _p(d2s), _p(ids), _p(box), _p(idx), _p(d3),
+                                         _stream(dev))
+    _lib.check(rc, "rtgs_knn3_dynamic_merge")
+    return d3, idx
+
+
 def accumulate_gaussian_error(H, W, P, color_error, depth_error, normal_error, color_index, depth_index, color_thres,
                               depth_thres, normal_thres, mean=True):
     """`cuda_utils._C.accumulate_gaussian_error` (frozen semantics, include/rtgs_slam.h) ->

@@ -98,6 +98,35 @@ def test_remove_with_a_promised_untouched_prefix_equals_the_full_form():
         assert torch.equal(outs[1][2], a[~mask]) and bool((outs[1][4] == 5).all())
 
 
+def test_frozen_key_follows_the_content_of_the_frozen_prefix():
+    """opt.frozen_key (what Mapping keeps its neighbour-search structure over the stable Gaussians for): unchanged by appends,
+    by removals among the trainable rows and by releases of side arrays; changed by a freeze, by a removal that reaches into the
+    prefix, and by a reallocation."""
+    a = _packed(30, 9)
+    opt = _opt(a, n_frozen=12, capacity=64)
+    k0 = opt.frozen_key
+    opt.append_rows(_packed(3, 10))
+    mask = torch.zeros(opt.N, dtype=torch.bool)
+    mask[[15, 31]] = True
+    opt.remove_rows(mask, start=12)
+    assert opt.frozen_key == k0 and opt.n_frozen == 12
+    opt.remove_rows(mask.new_zeros(opt.N).index_fill_(0, torch.tensor([20]), True))          # full form, but only a trainable row goes
+    assert opt.frozen_key[1:] == (12, k0[2] + 1) or opt.frozen_key == k0                     # conservative is allowed, stale is not
+    k1 = opt.frozen_key
+    fm = torch.zeros(opt.N, dtype=torch.bool)
+    fm[14] = True
+    opt.freeze_rows(fm)
+    assert opt.frozen_key != k1 and opt.n_frozen == 13
+    k2 = opt.frozen_key
+    rm = torch.zeros(opt.N, dtype=torch.bool)
+    rm[2] = True
+    opt.remove_rows(rm)
+    assert opt.frozen_key != k2 and opt.n_frozen == 12
+    k3 = opt.frozen_key
+    opt.append_rows(_packed(200, 11))                                    # exceeds the capacity: new arrays
+    assert opt.frozen_key != k3
+
+
 def test_freeze_moves_rows_behind_the_frozen_prefix_in_order():
     a = _packed(10, 7)
     opt = _opt(a, n_frozen=3)

@@ -482,6 +482,41 @@ def test_the_adds_compactions_equal_the_torch_form():
         assert all(torch.equal(ga[k], gb[k]) for k in ga)
 
 
+def test_the_split_neighbour_search_equals_the_one_structure_search():
+    """rtgs_knn3_build_ref + _query_built + _dynamic_merge (round 6: the structure over the stable Gaussians is kept between
+    frames) against rtgs_knn3_query over cat(new points, stable, unstable): the same three distances bit for bit, the same
+    indices wherever the three distances are distinct - with the open box cutting into all three groups, without unstable
+    points, with fewer than three references inside the box."""
+    from rtg_slam_amd import slam_ops as ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(23)
+    for nq, ns, nu, shrink in ((300, 60000, 2500, 0.0), (1, 30000, 0, 0.0), (700, 25000, 4000, 0.35), (40, 20000, 3, 0.0), (1500, 50000, 900, 0.1),
+                               (2, 20000, 1, -1.0)):
+        far = shrink < 0                                                                       # the stable wall lies outside the box
+        shrink = max(shrink, 0.0)
+        stable = (torch.rand(ns, 3, generator=gen) * torch.tensor([4.0, 3.0, 0.05]) + torch.tensor([0.0, 0.0, 12.0 if far else 2.0])).to(dev)   # a wall
+        unstable = (torch.rand(nu, 3, generator=gen) * torch.tensor([4.0, 3.0, 0.3]) + torch.tensor([0.0, 0.0, 1.9])).to(dev)
+        q = (torch.rand(nq, 3, generator=gen) * torch.tensor([4.0, 3.0, 0.1]) + torch.tensor([0.0, 0.0, 1.98])).to(dev)
+        lo, hi = q.min(0)[0] - 0.05, q.max(0)[0] + 0.05
+        mid = (lo + hi) / 2
+        box = torch.cat([mid + (lo - mid) * (1 - shrink), mid + (hi - mid) * (1 - shrink)])       # shrink > 0: some QUERIES lie outside too
+        want_d, want_i = ops.knn_query(torch.cat([q, stable, unstable]), q, 0, box)
+        built = ops.knn_build_ref(stable)
+        d2s, ids = ops.knn_query_built(built, ns, q, box)
+        got_d, got_i = ops.knn_dynamic_merge(q, unstable, ns, d2s, ids, box)
+        assert torch.equal(got_d, want_d), (nq, ns, nu, float((got_d - want_d).abs().max()))
+        distinct = (want_d[:, 0] != want_d[:, 1]) & (want_d[:, 1] != want_d[:, 2])
+        assert torch.equal(got_i[distinct], want_i[distinct])
+        assert torch.equal(got_i.sort(dim=1).values[~distinct] >= -1, torch.ones_like(got_i[~distinct], dtype=torch.bool))
+        if far:
+            assert bool((want_i[:, 2] < 0).all()) and bool((want_i[:, 0] >= 0).all())   # two references inside the box at most: -1 / FLT_MAX behind them
+        # the structure answers a second, different query set too (it holds its own copy of the points)
+        q2 = q + 0.01
+        d2b, idb = ops.knn_query_built(built, ns, q2, None)
+        wd, wi = ops.knn_query(stable, q2, -1, None)
+        assert torch.equal(d2b, wd)
+
+
 def test_bookkeeping_kernels_equal_the_torch_form():
     """rtgs_error_counters / rtgs_delete_mask (round 6) against the tensor expressions they replace in
     Mapping.error_gaussians_remove and Mapping.gaussians_delete (mapper.py:541-565, 298-335)."""
